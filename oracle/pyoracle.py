@@ -1,0 +1,261 @@
+"""ctypes binding of the CPU oracle (oracle/liboracle.so).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg -- never by the product package (tbv_slam_public_amd).  PARITY UNPINNED, see
+oracle/cfear_oracle.h.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+class OrcCell(C.Structure):
+    _fields_ = [("mean", C.c_double * 2), ("normal", C.c_double * 2), ("cov", C.c_double * 4),
+                ("scale", C.c_double), ("avg_intensity", C.c_double),
+                ("lambda_min", C.c_double), ("lambda_max", C.c_double),
+                ("nsamples", C.c_int32), ("pad", C.c_int32)]
+
+
+CELL_DTYPE = np.dtype([("mean", "<f8", (2,)), ("normal", "<f8", (2,)), ("cov", "<f8", (4,)),
+                       ("scale", "<f8"), ("avg_intensity", "<f8"), ("lambda_min", "<f8"),
+                       ("lambda_max", "<f8"), ("nsamples", "<i4"), ("pad", "<i4")])
+assert CELL_DTYPE.itemsize == C.sizeof(OrcCell) == 104
+
+COST = {"P2P": 0, "P2L": 1, "P2D": 2}
+LOSS = {"None": 0, "Huber": 1, "Cauchy": 2, "SoftLOne": 3, "Combined": 4, "Tukey": 5}
+
+
+class OrcRegParams(C.Structure):
+    _fields_ = [("cost", C.c_int32), ("loss", C.c_int32), ("loss_limit", C.c_double),
+                ("weight_opt", C.c_int32), ("max_outer", C.c_int32), ("max_inner", C.c_int32),
+                ("min_outer", C.c_int32), ("radius", C.c_double), ("cov_scale", C.c_double),
+                ("regularization", C.c_double), ("score_tolerance", C.c_double),
+                ("first_itr", C.c_int32), ("pad", C.c_int32)]
+
+
+class OrcRegResult(C.Structure):
+    _fields_ = [("pose", C.c_double * 3), ("score", C.c_double), ("final_cost", C.c_double),
+                ("num_residuals", C.c_int32), ("outer_iters", C.c_int32),
+                ("lm_iters", C.c_int32), ("status", C.c_int32)]
+
+
+class OrcFuserParams(C.Structure):
+    _fields_ = [("reg", OrcRegParams), ("res", C.c_float), ("submap_scan_size", C.c_int32),
+                ("weight_intensity", C.c_int32), ("use_guess", C.c_int32),
+                ("compensate", C.c_int32), ("radar_ccw", C.c_int32), ("use_keyframe", C.c_int32),
+                ("min_keyframe_dist", C.c_double), ("min_keyframe_rot_deg", C.c_double),
+                ("downsample_factor", C.c_double)]
+
+
+def reg_params(cost="P2L", loss="Huber", loss_limit=0.1, weight_opt=0, max_outer=8, max_inner=20,
+               min_outer=3, radius=2.0, cov_scale=1.0, regularization=0.01, first_itr=0):
+    """n_scan_normal_reg defaults (n_scan_normal.h:35,72-75; registration.h:117-122)."""
+    p = OrcRegParams()
+    p.cost = COST[cost] if isinstance(cost, str) else int(cost)
+    p.loss = LOSS[loss] if isinstance(loss, str) else int(loss)
+    p.loss_limit = loss_limit
+    p.weight_opt = weight_opt
+    p.max_outer, p.max_inner, p.min_outer = max_outer, max_inner, min_outer
+    p.radius, p.cov_scale, p.regularization = radius, cov_scale, regularization
+    p.score_tolerance = 1e-5
+    p.first_itr = first_itr
+    return p
+
+
+def build(force=False):
+    so = os.path.join(_HERE, "liboracle.so")
+    src = os.path.join(_HERE, "cfear_oracle.cpp")
+    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-s", "-B" if force else "-s"])
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        L = C.CDLL(build())
+        u8p, i32p, f32p, f64p = (C.POINTER(C.c_uint8), C.POINTER(C.c_int32), C.POINTER(C.c_float),
+                                 C.POINTER(C.c_double))
+        L.orc_kstrongest.argtypes = [u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, i32p, u8p, i32p]
+        L.orc_peaks.argtypes = [u8p, C.c_int, C.c_int, C.c_int, C.c_int, i32p, i32p, u8p]
+        L.orc_kstrongest_cloud.argtypes = [C.c_int, C.c_int, i32p, u8p, i32p, u8p, C.c_float, C.c_float, f32p]
+        L.orc_cacfar.argtypes = [u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float,
+                                 C.c_float, C.c_float, C.c_double, f32p, i32p, C.c_int]
+        L.orc_compensate.argtypes = [f32p, C.c_int, f64p, C.c_int]
+        L.orc_compensate.restype = None
+        L.orc_surface_points.argtypes = [f32p, C.c_int, C.c_float, C.c_double, f64p, C.c_int,
+                                         C.c_void_p, C.c_int, f32p, i32p]
+        pp = C.POINTER(C.c_void_p)
+        L.orc_register.argtypes = [pp, i32p, C.c_int, f64p, C.POINTER(OrcRegParams), C.POINTER(OrcRegResult)]
+        L.orc_get_cost.argtypes = [pp, i32p, C.c_int, f64p, C.POINTER(OrcRegParams), f64p, f64p, i32p, f64p]
+        L.orc_associate.argtypes = [pp, i32p, C.c_int, f64p, C.POINTER(OrcRegParams), C.c_int, i32p, f64p, C.c_int]
+        L.orc_normal_eq.argtypes = [pp, i32p, C.c_int, f64p, C.POINTER(OrcRegParams), C.c_int, f64p,
+                                    f64p, f64p, f64p, i32p]
+        L.orc_fuser_create.argtypes = [C.POINTER(OrcFuserParams)]
+        L.orc_fuser_create.restype = C.c_void_p
+        L.orc_fuser_destroy.argtypes = [C.c_void_p]
+        L.orc_fuser_destroy.restype = None
+        L.orc_fuser_process.argtypes = [C.c_void_p, f32p, C.c_int, f64p, i32p]
+        _LIB = L
+    return _LIB
+
+
+def _p(a, t):
+    return a.ctypes.data_as(C.POINTER(t))
+
+
+def kstrongest(img, k, z_min):
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    rows, cols = img.shape
+    sr = np.empty((rows, k), np.int32)
+    si = np.empty((rows, k), np.uint8)
+    sc = np.empty(rows, np.int32)
+    rc = lib().orc_kstrongest(_p(img, C.c_uint8), rows, cols, cols, k, int(z_min), _p(sr, C.c_int32),
+                              _p(si, C.c_uint8), _p(sc, C.c_int32))
+    assert rc == 0
+    return sr, si, sc
+
+
+def peaks(img, k, sel_range, sel_count):
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    rows, cols = img.shape
+    pk = np.empty((rows, k), np.uint8)
+    lib().orc_peaks(_p(img, C.c_uint8), rows, cols, cols, k, _p(sel_range, C.c_int32),
+                    _p(sel_count, C.c_int32), _p(pk, C.c_uint8))
+    return pk
+
+
+def kstrongest_cloud(sel_range, sel_intensity, sel_count, range_res, min_distance, mask=None):
+    rows, k = sel_range.shape
+    out = np.empty((rows * k, 4), np.float32)
+    m = _p(mask, C.c_uint8) if mask is not None else None
+    n = lib().orc_kstrongest_cloud(rows, k, _p(sel_range, C.c_int32), _p(sel_intensity, C.c_uint8),
+                                   _p(sel_count, C.c_int32), m, np.float32(range_res),
+                                   np.float32(min_distance), _p(out, C.c_float))
+    return out[:n].copy()
+
+
+def cacfar(img, window, guard, pfa, range_res, z_min, min_distance, max_distance=400.0):
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    rows, cols = img.shape
+    cap = rows * cols
+    out = np.empty((cap, 4), np.float32)
+    rc = np.empty((cap, 2), np.int32)
+    n = lib().orc_cacfar(_p(img, C.c_uint8), rows, cols, cols, window, guard, np.float32(pfa),
+                         np.float32(range_res), np.float32(z_min), np.float32(min_distance),
+                         float(max_distance), _p(out, C.c_float), _p(rc, C.c_int32), cap)
+    assert n >= 0
+    return out[:n].copy(), rc[:n].copy()
+
+
+def compensate(xyzi, mot, ccw):
+    out = np.ascontiguousarray(xyzi, dtype=np.float32).copy()
+    m = np.asarray(mot, np.float64).copy()
+    lib().orc_compensate(_p(out, C.c_float), out.shape[0], _p(m, C.c_double), int(ccw))
+    return out
+
+
+def surface_points(xyzi, radius, downsample_factor=1.0, origin=(0.0, 0.0), weight_intensity=False,
+                   return_centroids=False):
+    xyzi = np.ascontiguousarray(xyzi, dtype=np.float32)
+    n = xyzi.shape[0]
+    cells = np.zeros(max(n, 1), CELL_DTYPE)
+    cen = np.empty((max(n, 1), 2), np.float32)
+    nv = np.zeros(1, np.int32)
+    o = np.asarray(origin, np.float64).copy()
+    nc = lib().orc_surface_points(_p(xyzi, C.c_float), n, np.float32(radius), float(downsample_factor),
+                                  _p(o, C.c_double), int(weight_intensity), cells.ctypes.data, cells.shape[0],
+                                  _p(cen, C.c_float), _p(nv, C.c_int32))
+    assert nc >= 0
+    if return_centroids:
+        return cells[:nc].copy(), cen[:nv[0]].copy()
+    return cells[:nc].copy()
+
+
+def _scan_args(scans):
+    scans = [np.ascontiguousarray(s, dtype=CELL_DTYPE) for s in scans]
+    ptrs = (C.c_void_p * len(scans))(*[s.ctypes.data for s in scans])
+    n = np.array([s.shape[0] for s in scans], np.int32)
+    return scans, ptrs, n
+
+
+def register(scans, poses, par):
+    keep, ptrs, n = _scan_args(scans)
+    p = np.ascontiguousarray(poses, dtype=np.float64).copy()
+    res = OrcRegResult()
+    ok = lib().orc_register(ptrs, _p(n, C.c_int32), len(keep), _p(p, C.c_double), C.byref(par), C.byref(res))
+    return bool(ok), p, res
+
+
+def get_cost(scans, poses, par):
+    keep, ptrs, n = _scan_args(scans)
+    p = np.ascontiguousarray(poses, dtype=np.float64).copy()
+    cap = 2 * int(n.sum()) + 2
+    r = np.empty(cap, np.float64)
+    cost = C.c_double()
+    score = C.c_double()
+    nres = C.c_int32()
+    ok = lib().orc_get_cost(ptrs, _p(n, C.c_int32), len(keep), _p(p, C.c_double), C.byref(par),
+                            C.byref(cost), _p(r, C.c_double), C.byref(nres), C.byref(score))
+    return bool(ok), cost.value, r[:nres.value].copy(), score.value
+
+
+def associate(scans, poses, par, itr):
+    keep, ptrs, n = _scan_args(scans)
+    p = np.ascontiguousarray(poses, dtype=np.float64).copy()
+    cap = int(n[-1]) * max(len(keep) - 1, 1) + 1
+    pairs = np.empty((cap, 3), np.int32)
+    w = np.empty(cap, np.float64)
+    m = lib().orc_associate(ptrs, _p(n, C.c_int32), len(keep), _p(p, C.c_double), C.byref(par), int(itr),
+                            _p(pairs, C.c_int32), _p(w, C.c_double), cap)
+    assert m >= 0
+    return pairs[:m].copy(), w[:m].copy()
+
+
+def normal_eq(scans, poses, par, itr, x):
+    keep, ptrs, n = _scan_args(scans)
+    p = np.ascontiguousarray(poses, dtype=np.float64).copy()
+    xx = np.asarray(x, np.float64).copy()
+    H = np.empty(9, np.float64)
+    g = np.empty(3, np.float64)
+    cost = C.c_double()
+    nres = C.c_int32()
+    lib().orc_normal_eq(ptrs, _p(n, C.c_int32), len(keep), _p(p, C.c_double), C.byref(par), int(itr),
+                        _p(xx, C.c_double), _p(H, C.c_double), _p(g, C.c_double), C.byref(cost), C.byref(nres))
+    return H.reshape(3, 3), g, cost.value, nres.value
+
+
+class Fuser:
+    """OdometryKeyframeFuser restatement (odometrykeyframefuser.cpp:143-259)."""
+
+    def __init__(self, reg, res=3.0, submap_scan_size=4, weight_intensity=True, use_guess=True,
+                 compensate=True, radar_ccw=False, use_keyframe=True, min_keyframe_dist=1.5,
+                 min_keyframe_rot_deg=5.0, downsample_factor=1.0):
+        p = OrcFuserParams()
+        p.reg = reg
+        p.res = res
+        p.submap_scan_size = submap_scan_size
+        p.weight_intensity, p.use_guess, p.compensate = int(weight_intensity), int(use_guess), int(compensate)
+        p.radar_ccw, p.use_keyframe = int(radar_ccw), int(use_keyframe)
+        p.min_keyframe_dist, p.min_keyframe_rot_deg = min_keyframe_dist, min_keyframe_rot_deg
+        p.downsample_factor = downsample_factor
+        self._h = lib().orc_fuser_create(C.byref(p))
+
+    def process(self, xyzi):
+        x = np.ascontiguousarray(xyzi, dtype=np.float32).copy()
+        pose = np.empty(3, np.float64)
+        info = np.zeros(4, np.int32)
+        rc = lib().orc_fuser_process(self._h, _p(x, C.c_float), x.shape[0], _p(pose, C.c_double),
+                                     _p(info, C.c_int32))
+        assert rc == 0
+        return pose, info
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().orc_fuser_destroy(self._h)
+            self._h = None
