@@ -1,0 +1,297 @@
+/*
+ * cfear_hip.h -- C-ABI of libcfear_hip.so: the MI355X (gfx950) implementation of the CFEAR
+ * scan-registration hot path of TBV Radar SLAM (dan11003/tbv_slam_public).
+ *
+ * The reference has no FFI layer: its boundary is the C++ class API of the catkin library
+ * `cfear_radarodometry` (cfear_radarodometry/CMakeLists.txt:46-72).  Each entry point below names
+ * the reference function(s) it replaces (paths relative to
+ * cfear_radarodometry/{include,src}/cfear_radarodometry/).  INTEGRATION.md shows the shim a
+ * maintainer adds inside radarDriver / MapPointNormal / n_scan_normal_reg to call them.
+ *
+ * Conventions
+ *   - plain C: pointers + sizes, caller-owned buffers, opaque handles, no C++/torch types;
+ *   - every function returns an int status (CFEAR_OK = 0, < 0 = error); nothing exits or throws
+ *     (the reference calls exit(0) on several errors, e.g. pointnormal.cpp:72-75);
+ *   - data pointers may be HOST or DEVICE memory of the context's GPU (detected with
+ *     hipPointerGetAttributes); all buffers of one call must live in the same space;
+ *   - one cfear_ctx per host thread / HIP stream; calls on different contexts are independent
+ *     (the reference builds a fresh n_scan_normal_reg per loop-closure candidate on the
+ *     loop-closure thread, tbv_slam/src/tbv_slam/loopclosure.cpp:56);
+ *   - calls with host pointers are synchronous; calls with device pointers are enqueued on the
+ *     context's stream (use cfear_ctx_synchronize) unless they return values through host
+ *     scalars, in which case they synchronise themselves;
+ *   - float parameters that the reference holds as float (radarDriver::Parameters,
+ *     radar_driver.h:40-45) are float here and widened to double exactly where the reference
+ *     widens them.
+ */
+#ifndef CFEAR_HIP_H
+#define CFEAR_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CFEAR_ABI_VERSION 1
+
+/* ---- status codes ------------------------------------------------------------------------ */
+#define CFEAR_OK 0
+#define CFEAR_ERR_INVALID_ARGUMENT (-1)
+#define CFEAR_ERR_HIP (-2)              /* a HIP runtime call failed; see cfear_last_error     */
+#define CFEAR_ERR_CAPACITY (-3)         /* an output/workspace capacity was exceeded           */
+#define CFEAR_ERR_TOO_FEW_RESIDUALS (-4)/* n_scan_normal.cpp:368-369, 444-447                  */
+#define CFEAR_ERR_SOLVER (-5)           /* !summary_.IsSolutionUsable() (n_scan_normal.cpp:449)*/
+#define CFEAR_ERR_EMPTY_CLOUD (-6)      /* pointnormal.cpp:72-75 ("error, cloud empty")        */
+#define CFEAR_ERR_NO_DEVICE (-7)        /* no HIP device / kernels not loadable                */
+
+/* ---- enums (values follow the reference's enums) ------------------------------------------ */
+enum cfear_cost_metric { CFEAR_P2P = 0, CFEAR_P2L = 1, CFEAR_P2D = 2 };          /* registration.h:55 */
+enum cfear_loss_type { CFEAR_LOSS_NONE = 0, CFEAR_LOSS_HUBER = 1, CFEAR_LOSS_CAUCHY = 2,
+                       CFEAR_LOSS_SOFTLONE = 3, CFEAR_LOSS_COMBINED = 4,
+                       CFEAR_LOSS_TUKEY = 5 };                                    /* registration.h:60 */
+enum cfear_weight_option { CFEAR_W_UNIFORM = 0, CFEAR_W_SIM_N = 1, CFEAR_W_SIM_DIRECTION = 2,
+                           CFEAR_W_SIM_SCALE = 3, CFEAR_W_COMBINED = 4 };         /* registration.h:50 */
+enum cfear_filter_type { CFEAR_FILTER_KSTRONG = 0, CFEAR_FILTER_CACFAR = 1 };     /* radar_driver.h:25 */
+
+/* ---- context ------------------------------------------------------------------------------ */
+typedef struct cfear_ctx cfear_ctx;
+
+int cfear_abi_version(void);
+const char* cfear_status_string(int status);
+/* hip_stream: a hipStream_t to enqueue on (e.g. torch's current stream), or NULL to create one. */
+int cfear_ctx_create(int device, void* hip_stream, cfear_ctx** out);
+int cfear_ctx_destroy(cfear_ctx* ctx);
+int cfear_ctx_synchronize(cfear_ctx* ctx);
+const char* cfear_last_error(const cfear_ctx* ctx);
+/* Per-kernel-family device time measured with hipEvents on the context's stream.
+ * enable=1 brackets every launch with events (adds a sync per read-out, not per launch).
+ * cfear_ctx_profile_read: names[i] (static strings), total_ms[i], launches[i], up to cap rows;
+ * returns the number of rows; reset != 0 clears the accumulators.                             */
+int cfear_ctx_profile_enable(cfear_ctx* ctx, int enable);
+int cfear_ctx_profile_read(cfear_ctx* ctx, const char** names, double* total_ms, int64_t* launches,
+                           int cap, int reset);
+
+/* ---- F: polar filters ----------------------------------------------------------------------
+ * Replaces radarDriver::Process (radar_driver.cpp:48-73) =
+ *   StructuredKStrongest ctor + FilterKstrongest      radar_filters.cpp:198-237
+ *   getPeaksFilteredPointCloud(cloud,false)           radar_filters.cpp:300-337
+ *   getPeaksFilteredPointCloud(peaks,true) -> AxialNonMaxSupress   radar_filters.cpp:238-298
+ *   AzimuthCACFAR::getFilteredPointCloud               cfar.cpp:35-71
+ * Image: row-major uint8, rows = azimuths, cols = range bins, `stride` bytes between rows,
+ * `batch_stride` bytes between the `batch` images.                                            */
+typedef struct cfear_polar_desc {
+  int32_t rows, cols, stride, batch;
+  int64_t batch_stride;
+} cfear_polar_desc;
+
+typedef struct cfear_kstrong_params {   /* radarDriver::Parameters, radar_driver.h:40-45 */
+  int32_t k_strongest;                  /* >= 1, <= 1024 */
+  float z_min;                          /* converted float -> int -> uchar like radar_driver.cpp:58 */
+  float range_res;
+  float min_distance;
+  int32_t want_peaks;                   /* also run AxialNonMaxSupress */
+} cfear_kstrong_params;
+
+/* All output pointers are optional (NULL = not wanted) and per image b of the batch:
+ *   sel_range     int32 [batch][rows][k]  range bins kept per azimuth, ascending (intensity,range)
+ *                                          order (= dense_filtered_), padded with -1
+ *   sel_intensity uint8 [batch][rows][k]  their intensities, padded with 0
+ *   sel_count     int32 [batch][rows]
+ *   is_peak       uint8 [batch][rows][k]  1 where AxialNonMaxSupress keeps the bin (want_peaks)
+ *   xyzi          float [batch][rows*k][4] compacted PointXYZI cloud (x,y,z=0,intensity),
+ *                                          rows ascending, only bins > ceil(min_distance/range_res)
+ *   n_points      int32 [batch]
+ *   xyzi_peaks / n_peaks: the same for the peaks cloud (want_peaks)                           */
+typedef struct cfear_kstrong_out {
+  int32_t* sel_range;
+  uint8_t* sel_intensity;
+  int32_t* sel_count;
+  uint8_t* is_peak;
+  float* xyzi;
+  int32_t* n_points;
+  float* xyzi_peaks;
+  int32_t* n_peaks;
+} cfear_kstrong_out;
+
+int cfear_filter_kstrongest(cfear_ctx* ctx, const uint8_t* polar, const cfear_polar_desc* desc,
+                            const cfear_kstrong_params* par, const cfear_kstrong_out* out);
+
+typedef struct cfear_cacfar_params {    /* AzimuthCACFAR ctor, cfar.cpp:28-33; radar_driver.cpp:54 */
+  int32_t window_size;                  /* cells per side */
+  int32_t nb_guard_cells;
+  float false_alarm_rate;
+  float range_res;
+  float z_min;                          /* static_threshold */
+  float min_distance;
+  double max_distance;                  /* radar_driver.cpp:54 passes 400.0 */
+} cfear_cacfar_params;
+
+/* xyzi float [batch][cap_points][4], n_points int32 [batch]; det_mask (optional) uint8
+ * [batch][rows][cols] 0/1 per bin.  Detections are ordered (row, bin) like cfar.cpp:37-70.
+ * A batch element with more than cap_points detections yields CFEAR_ERR_CAPACITY.            */
+int cfear_filter_cacfar(cfear_ctx* ctx, const uint8_t* polar, const cfear_polar_desc* desc,
+                        const cfear_cacfar_params* par, float* xyzi, int32_t* n_points,
+                        int32_t cap_points, uint8_t* det_mask);
+
+/* ---- C: motion compensation ----------------------------------------------------------------
+ * Replaces Compensate(cloud, mot, ccw)  utils.cpp:96-107 (+ GetRelTimeStamp utils.h:28-32).
+ * xyzi float [n][4] modified in place; mot = (x, y, theta) of the previous motion.           */
+int cfear_compensate(cfear_ctx* ctx, float* xyzi, int32_t n, const double mot[3], int32_t ccw);
+
+/* ---- N: oriented surface points ------------------------------------------------------------
+ * cfear_scan is the device-resident MapPointNormal (pointnormal.h:110-243): the `cell`s plus the
+ * float copy of their means that the matcher searches (pointnormal.cpp:151-162).              */
+typedef struct cfear_scan cfear_scan;
+
+typedef struct cfear_cell {             /* class cell, pointnormal.h:45-105 */
+  double mean[2];                       /* u_ */
+  double normal[2];                     /* snormal_ */
+  double cov[4];                        /* cov_ row-major */
+  double scale;                         /* scale_ (GetPlanarity) */
+  double avg_intensity;                 /* avg_intensity_ */
+  double lambda_min, lambda_max;
+  int32_t nsamples;                     /* Nsamples_ */
+  int32_t pad;
+} cfear_cell;
+
+typedef struct cfear_feature_params {   /* MapPointNormal ctor arguments, pointnormal.cpp:65 */
+  float radius;                         /* par.res */
+  double downsample_factor;             /* MapPointNormal::downsample_factor (static, =1) */
+  double origin[2];
+  int32_t weight_intensity;
+  int32_t compensate;                   /* 1: run Compensate(mot, ccw) on the cloud first
+                                           (odometrykeyframefuser.cpp:146-150), in place */
+  double mot[3];
+  int32_t ccw;
+  int32_t pad;
+} cfear_feature_params;
+
+/* Replaces `new MapPointNormal(cloud, res, origin, weight_intensity, false)`
+ * (pointnormal.cpp:65-90 -> ComputeNormals :265-297 -> cell::cell :7-63 ->
+ * ComputeSearchTreeFromCells :151-162).  xyzi [n][4] host or device (modified in place only if
+ * compensate).  n == 0 -> CFEAR_ERR_EMPTY_CLOUD.                                              */
+int cfear_scan_create(cfear_ctx* ctx, float* xyzi, int32_t n, const cfear_feature_params* par,
+                      cfear_scan** out);
+/* Upload precomputed cells (loop closure consumes the MapPointNormal cached in each graph node,
+ * types.h:119-122; also `raw` mode, pointnormal.cpp:76-82).  cells: host array.               */
+int cfear_scan_from_cells(cfear_ctx* ctx, const cfear_cell* cells, int32_t n_cells, cfear_scan** out);
+int cfear_scan_size(const cfear_scan* scan);                            /* GetSize()  */
+int cfear_scan_get_cells(const cfear_scan* scan, cfear_cell* out_host, int32_t cap);  /* GetCells() */
+int cfear_scan_destroy(cfear_scan* scan);
+
+/* ---- M: registration -----------------------------------------------------------------------
+ * n_scan_normal_reg (n_scan_normal.h:27-85, n_scan_normal.cpp) in mode
+ * incremental_last_to_previous: scans[0..n-2] are fixed targets, scans[n-1] is the free source. */
+typedef struct cfear_reg_params {
+  int32_t cost;                         /* cfear_cost_metric; n_scan_normal_reg ctor */
+  int32_t loss;                         /* cfear_loss_type   */
+  double loss_limit;                    /* loss_limit_ (0.1) */
+  int32_t weight_opt;                   /* cfear_weight_option */
+  int32_t max_itr_association;          /* SetParameters(.,) / default 8 */
+  int32_t max_itr_solver;               /* options_.max_num_iterations, default 20 */
+  int32_t min_itr;                      /* min_itr_ = 3 */
+  double radius;                        /* radius_ = 2.0 (registration.h:122) */
+  double cov_scale;                     /* SetD2dPar */
+  double regularization;                /* SetD2dPar */
+  double score_tolerance;               /* 1e-5 (n_scan_normal.h:74) */
+  int32_t itr;                          /* GetCost only: the object's leftover itr_ (0 if fresh) */
+  int32_t pad;
+} cfear_reg_params;
+
+/* Fills the n_scan_normal_reg defaults (P2L, Huber 0.1, Uniform, 8 x 20, radius 2.0). */
+void cfear_reg_params_default(cfear_reg_params* p);
+
+typedef struct cfear_reg_result {
+  double pose[3];                       /* (x, y, theta) of the source after registration */
+  double score;                         /* score_ = final_cost / num_residuals (getScore) */
+  double final_cost;                    /* summary_.final_cost */
+  int32_t num_residuals;                /* summary_.num_residuals (elements) */
+  int32_t outer_iters;                  /* itr_ on exit (timing key "itrs") */
+  int32_t lm_iters;                     /* total LM iterations */
+  int32_t status;                       /* CFEAR_OK / CFEAR_ERR_TOO_FEW_RESIDUALS / CFEAR_ERR_SOLVER */
+  double last_relative_decrease;        /* summary_.iterations.back().relative_decrease */
+  double reserved;
+} cfear_reg_result;                     /* 72 bytes */
+
+/* Replaces n_scan_normal_reg::Register (n_scan_normal.cpp:82-185).  poses_xyt [n_scans][3]
+ * host, in/out: Affine3dToVectorXYeZ(Tsrc[i]) on entry; on return the last row holds the
+ * registered source pose (Tsrc.back() = vectorToAffine3d(parameters.back())).  Returns the
+ * result's status; reg_cov is the constant diag(0.01,0.01,0,0,0,1e-4) (n_scan_normal.cpp:171). */
+int cfear_register(cfear_ctx* ctx, const cfear_scan* const* scans, int32_t n_scans,
+                   double* poses_xyt, const cfear_reg_params* par, cfear_reg_result* result);
+
+/* One launch, many independent registrations (loop-closure candidate batches,
+ * loopclosure.cpp:35-97 called per candidate from :658-721).                                  */
+typedef struct cfear_reg_job {
+  const cfear_scan* const* scans;       /* n_scans handles */
+  int32_t n_scans;
+  int32_t pad;
+  const double* poses_xyt;              /* [n_scans][3] host */
+} cfear_reg_job;
+int cfear_register_batch(cfear_ctx* ctx, const cfear_reg_job* jobs, int32_t n_jobs,
+                         const cfear_reg_params* par, cfear_reg_result* results);
+
+/* Replaces n_scan_normal_reg::GetCost (n_scan_normal.cpp:186-211): one association pass at the
+ * given poses + robust cost.  residuals (optional, host, cap entries) receives the robustified
+ * residual vector; n_residuals its length; score = cost / max(n_residuals, 1).                */
+int cfear_get_cost(cfear_ctx* ctx, const cfear_scan* const* scans, int32_t n_scans,
+                   const double* poses_xyt, const cfear_reg_params* par, double* cost,
+                   double* residuals, int32_t cap, int32_t* n_residuals, double* score);
+
+/* Ceres-compatible evaluation of one association set (what AddScanPairCost would hand to
+ * ceres::Problem, n_scan_normal.cpp:264-318): prepare associates once at `poses_xyt`;
+ * evaluate returns the RAW residuals r [n_res] and Jacobian J [n_res][3] (row-major, like
+ * ceres::CostFunction::Evaluate), the per-block weights w [n_blocks] of ScaledLoss, and
+ * normal_eq the robustified H = J^T J [9], g = J^T r [3], cost = 1/2 sum rho at x.            */
+typedef struct cfear_cost cfear_cost;
+int cfear_cost_prepare(cfear_ctx* ctx, const cfear_scan* const* scans, int32_t n_scans,
+                       const double* poses_xyt, const cfear_reg_params* par, int32_t itr,
+                       cfear_cost** out);
+int cfear_cost_num_blocks(const cfear_cost* c);
+int cfear_cost_num_residuals(const cfear_cost* c);
+/* pairs int32 [n_blocks][3] = (target scan, target cell, source cell); weights [n_blocks]. */
+int cfear_cost_get_blocks(const cfear_cost* c, int32_t* pairs, double* weights);
+int cfear_cost_evaluate(cfear_cost* c, const double x[3], double* residuals, double* jacobian);
+int cfear_cost_normal_eq(cfear_cost* c, const double x[3], double H[9], double g[3], double* cost);
+int cfear_cost_destroy(cfear_cost* c);
+
+/* ---- caller: batched radarDriver + OdometryKeyframeFuser --------------------------------------
+ * n_streams independent sequences advance one frame per call: filter (F) -> compensate (C) ->
+ * surface points (N) -> Register against the keyframe window (M) -> keyframe policy.  Restates
+ * radarDriver::CallbackOffline (radar_driver.cpp:163-176) + OdometryKeyframeFuser::processFrame
+ * (odometrykeyframefuser.cpp:143-259) per stream; everything between the polar image and the
+ * pose stays on the GPU.                                                                      */
+typedef struct cfear_odometry_params {
+  int32_t filter_type;                  /* cfear_filter_type */
+  cfear_kstrong_params kstrong;
+  cfear_cacfar_params cacfar;
+  cfear_reg_params reg;
+  float res;                            /* par.res */
+  int32_t submap_scan_size;
+  int32_t weight_intensity, use_guess, compensate, radar_ccw, use_keyframe;
+  int32_t pad;
+  double min_keyframe_dist, min_keyframe_rot_deg, downsample_factor;
+} cfear_odometry_params;
+void cfear_odometry_params_default(cfear_odometry_params* p);   /* CFEAR-3 preset, Oxford */
+
+typedef struct cfear_odometry cfear_odometry;
+typedef struct cfear_frame_info {
+  double pose[3];                       /* Tcurrent (x,y,theta) */
+  int32_t n_points, n_cells;
+  int32_t keyframe_added;
+  int32_t reg_status;                   /* cfear_reg_result.status, or 1 for the first frame */
+  int32_t outer_iters, lm_iters;
+  double score;
+} cfear_frame_info;
+
+int cfear_odometry_create(cfear_ctx* ctx, int32_t n_streams, const cfear_polar_desc* desc,
+                          const cfear_odometry_params* par, cfear_odometry** out);
+/* polar: [n_streams] images laid out per desc (desc.batch must equal n_streams), host or device.
+ * info: host array [n_streams].                                                               */
+int cfear_odometry_process(cfear_odometry* od, const uint8_t* polar, cfear_frame_info* info);
+int cfear_odometry_destroy(cfear_odometry* od);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CFEAR_HIP_H */

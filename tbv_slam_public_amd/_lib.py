@@ -1,0 +1,185 @@
+"""ctypes binding of libcfear_hip.so (include/cfear_hip.h).
+
+The library is built in-tree by tbv_slam_public_amd/csrc/Makefile (hipcc, gfx950).  There is no
+CPU fallback: loading fails loudly if the .so is missing, and cfear_ctx_create fails with
+CFEAR_ERR_NO_DEVICE when no MI355X is visible.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_HERE, "libcfear_hip.so")
+
+OK = 0
+ERR_INVALID_ARGUMENT, ERR_HIP, ERR_CAPACITY = -1, -2, -3
+ERR_TOO_FEW_RESIDUALS, ERR_SOLVER, ERR_EMPTY_CLOUD, ERR_NO_DEVICE = -4, -5, -6, -7
+
+P2P, P2L, P2D = 0, 1, 2
+LOSS = {"None": 0, "Huber": 1, "Cauchy": 2, "SoftLOne": 3, "Combined": 4, "Tukey": 5}
+COST = {"P2P": 0, "P2L": 1, "P2D": 2}
+
+
+class CfearError(RuntimeError):
+    def __init__(self, status, msg=""):
+        super().__init__("cfear status %d: %s" % (status, msg))
+        self.status = status
+
+
+class PolarDesc(C.Structure):
+    _fields_ = [("rows", C.c_int32), ("cols", C.c_int32), ("stride", C.c_int32), ("batch", C.c_int32),
+                ("batch_stride", C.c_int64)]
+
+
+class KStrongParams(C.Structure):
+    _fields_ = [("k_strongest", C.c_int32), ("z_min", C.c_float), ("range_res", C.c_float),
+                ("min_distance", C.c_float), ("want_peaks", C.c_int32)]
+
+
+class KStrongOut(C.Structure):
+    _fields_ = [("sel_range", C.c_void_p), ("sel_intensity", C.c_void_p), ("sel_count", C.c_void_p),
+                ("is_peak", C.c_void_p), ("xyzi", C.c_void_p), ("n_points", C.c_void_p),
+                ("xyzi_peaks", C.c_void_p), ("n_peaks", C.c_void_p)]
+
+
+class CacfarParams(C.Structure):
+    _fields_ = [("window_size", C.c_int32), ("nb_guard_cells", C.c_int32), ("false_alarm_rate", C.c_float),
+                ("range_res", C.c_float), ("z_min", C.c_float), ("min_distance", C.c_float),
+                ("max_distance", C.c_double)]
+
+
+class Cell(C.Structure):
+    _fields_ = [("mean", C.c_double * 2), ("normal", C.c_double * 2), ("cov", C.c_double * 4),
+                ("scale", C.c_double), ("avg_intensity", C.c_double), ("lambda_min", C.c_double),
+                ("lambda_max", C.c_double), ("nsamples", C.c_int32), ("pad", C.c_int32)]
+
+
+CELL_DTYPE = np.dtype([("mean", "<f8", (2,)), ("normal", "<f8", (2,)), ("cov", "<f8", (4,)),
+                       ("scale", "<f8"), ("avg_intensity", "<f8"), ("lambda_min", "<f8"),
+                       ("lambda_max", "<f8"), ("nsamples", "<i4"), ("pad", "<i4")])
+assert CELL_DTYPE.itemsize == C.sizeof(Cell) == 104
+
+
+class FeatureParams(C.Structure):
+    _fields_ = [("radius", C.c_float), ("downsample_factor", C.c_double), ("origin", C.c_double * 2),
+                ("weight_intensity", C.c_int32), ("compensate", C.c_int32), ("mot", C.c_double * 3),
+                ("ccw", C.c_int32), ("pad", C.c_int32)]
+
+
+class RegParams(C.Structure):
+    _fields_ = [("cost", C.c_int32), ("loss", C.c_int32), ("loss_limit", C.c_double),
+                ("weight_opt", C.c_int32), ("max_itr_association", C.c_int32),
+                ("max_itr_solver", C.c_int32), ("min_itr", C.c_int32), ("radius", C.c_double),
+                ("cov_scale", C.c_double), ("regularization", C.c_double),
+                ("score_tolerance", C.c_double), ("itr", C.c_int32), ("pad", C.c_int32)]
+
+
+class RegResult(C.Structure):
+    _fields_ = [("pose", C.c_double * 3), ("score", C.c_double), ("final_cost", C.c_double),
+                ("num_residuals", C.c_int32), ("outer_iters", C.c_int32), ("lm_iters", C.c_int32),
+                ("status", C.c_int32), ("last_relative_decrease", C.c_double), ("reserved", C.c_double)]
+
+
+RESULT_DTYPE = np.dtype([("pose", "<f8", (3,)), ("score", "<f8"), ("final_cost", "<f8"),
+                         ("num_residuals", "<i4"), ("outer_iters", "<i4"), ("lm_iters", "<i4"),
+                         ("status", "<i4"), ("last_relative_decrease", "<f8"), ("reserved", "<f8")])
+assert RESULT_DTYPE.itemsize == C.sizeof(RegResult) == 72
+
+
+class RegJob(C.Structure):
+    _fields_ = [("scans", C.POINTER(C.c_void_p)), ("n_scans", C.c_int32), ("pad", C.c_int32),
+                ("poses_xyt", C.POINTER(C.c_double))]
+
+
+class OdometryParams(C.Structure):
+    _fields_ = [("filter_type", C.c_int32), ("kstrong", KStrongParams), ("cacfar", CacfarParams),
+                ("reg", RegParams), ("res", C.c_float), ("submap_scan_size", C.c_int32),
+                ("weight_intensity", C.c_int32), ("use_guess", C.c_int32), ("compensate", C.c_int32),
+                ("radar_ccw", C.c_int32), ("use_keyframe", C.c_int32), ("pad", C.c_int32),
+                ("min_keyframe_dist", C.c_double), ("min_keyframe_rot_deg", C.c_double),
+                ("downsample_factor", C.c_double)]
+
+
+class FrameInfo(C.Structure):
+    _fields_ = [("pose", C.c_double * 3), ("n_points", C.c_int32), ("n_cells", C.c_int32),
+                ("keyframe_added", C.c_int32), ("reg_status", C.c_int32), ("outer_iters", C.c_int32),
+                ("lm_iters", C.c_int32), ("score", C.c_double)]
+
+
+FRAMEINFO_DTYPE = np.dtype([("pose", "<f8", (3,)), ("n_points", "<i4"), ("n_cells", "<i4"),
+                            ("keyframe_added", "<i4"), ("reg_status", "<i4"), ("outer_iters", "<i4"),
+                            ("lm_iters", "<i4"), ("score", "<f8")])
+assert FRAMEINFO_DTYPE.itemsize == C.sizeof(FrameInfo) == 56
+
+# every symbol include/cfear_hip.h declares
+EXPORTS = [
+    "cfear_abi_version", "cfear_status_string", "cfear_ctx_create", "cfear_ctx_destroy",
+    "cfear_ctx_synchronize", "cfear_last_error", "cfear_ctx_profile_enable", "cfear_ctx_profile_read",
+    "cfear_filter_kstrongest", "cfear_filter_cacfar", "cfear_compensate", "cfear_scan_create",
+    "cfear_scan_from_cells", "cfear_scan_size", "cfear_scan_get_cells", "cfear_scan_destroy",
+    "cfear_reg_params_default", "cfear_register", "cfear_register_batch", "cfear_get_cost",
+    "cfear_cost_prepare", "cfear_cost_num_blocks", "cfear_cost_num_residuals", "cfear_cost_get_blocks",
+    "cfear_cost_evaluate", "cfear_cost_normal_eq", "cfear_cost_destroy",
+    "cfear_odometry_params_default", "cfear_odometry_create", "cfear_odometry_process",
+    "cfear_odometry_destroy",
+]
+
+_LIB = None
+
+
+def lib():
+    """Loads libcfear_hip.so; raises if it has not been built (no fallback)."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    if not os.path.exists(SO_PATH):
+        raise ImportError("libcfear_hip.so not built: run `make -C %s/csrc` (or __graft_entry__.build())" % _HERE)
+    L = C.CDLL(SO_PATH)
+    vp = C.c_void_p
+    L.cfear_abi_version.restype = C.c_int
+    L.cfear_status_string.restype = C.c_char_p
+    L.cfear_status_string.argtypes = [C.c_int]
+    L.cfear_ctx_create.argtypes = [C.c_int, vp, C.POINTER(vp)]
+    L.cfear_ctx_destroy.argtypes = [vp]
+    L.cfear_ctx_synchronize.argtypes = [vp]
+    L.cfear_last_error.argtypes = [vp]
+    L.cfear_last_error.restype = C.c_char_p
+    L.cfear_ctx_profile_enable.argtypes = [vp, C.c_int]
+    L.cfear_ctx_profile_read.argtypes = [vp, C.POINTER(C.c_char_p), C.POINTER(C.c_double),
+                                         C.POINTER(C.c_int64), C.c_int, C.c_int]
+    L.cfear_filter_kstrongest.argtypes = [vp, vp, C.POINTER(PolarDesc), C.POINTER(KStrongParams),
+                                          C.POINTER(KStrongOut)]
+    L.cfear_filter_cacfar.argtypes = [vp, vp, C.POINTER(PolarDesc), C.POINTER(CacfarParams), vp, vp,
+                                      C.c_int32, vp]
+    L.cfear_compensate.argtypes = [vp, vp, C.c_int32, C.POINTER(C.c_double), C.c_int32]
+    L.cfear_scan_create.argtypes = [vp, vp, C.c_int32, C.POINTER(FeatureParams), C.POINTER(vp)]
+    L.cfear_scan_from_cells.argtypes = [vp, vp, C.c_int32, C.POINTER(vp)]
+    L.cfear_scan_size.argtypes = [vp]
+    L.cfear_scan_get_cells.argtypes = [vp, vp, C.c_int32]
+    L.cfear_scan_destroy.argtypes = [vp]
+    L.cfear_reg_params_default.argtypes = [C.POINTER(RegParams)]
+    L.cfear_reg_params_default.restype = None
+    L.cfear_register.argtypes = [vp, C.POINTER(vp), C.c_int32, C.POINTER(C.c_double),
+                                 C.POINTER(RegParams), C.POINTER(RegResult)]
+    L.cfear_register_batch.argtypes = [vp, C.POINTER(RegJob), C.c_int32, C.POINTER(RegParams), vp]
+    L.cfear_get_cost.argtypes = [vp, C.POINTER(vp), C.c_int32, C.POINTER(C.c_double), C.POINTER(RegParams),
+                                 C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int32,
+                                 C.POINTER(C.c_int32), C.POINTER(C.c_double)]
+    L.cfear_cost_prepare.argtypes = [vp, C.POINTER(vp), C.c_int32, C.POINTER(C.c_double),
+                                     C.POINTER(RegParams), C.c_int32, C.POINTER(vp)]
+    L.cfear_cost_num_blocks.argtypes = [vp]
+    L.cfear_cost_num_residuals.argtypes = [vp]
+    L.cfear_cost_get_blocks.argtypes = [vp, vp, vp]
+    L.cfear_cost_evaluate.argtypes = [vp, C.POINTER(C.c_double), vp, vp]
+    L.cfear_cost_normal_eq.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                       C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    L.cfear_cost_destroy.argtypes = [vp]
+    L.cfear_odometry_params_default.argtypes = [C.POINTER(OdometryParams)]
+    L.cfear_odometry_params_default.restype = None
+    L.cfear_odometry_create.argtypes = [vp, C.c_int32, C.POINTER(PolarDesc), C.POINTER(OdometryParams),
+                                        C.POINTER(vp)]
+    L.cfear_odometry_process.argtypes = [vp, vp, vp]
+    L.cfear_odometry_destroy.argtypes = [vp]
+    _LIB = L
+    return L

@@ -1,0 +1,442 @@
+"""Host-side mirror of the reference's `cfear_radarodometry` class API over the C-ABI.
+
+Names, argument meaning and error behaviour follow namespace CFEAR_Radarodometry:
+  radarDriver            radar_driver.h:32-118        (filters: radar_filters.h / cfar.h)
+  MapPointNormal         pointnormal.h:110-243
+  n_scan_normal_reg      n_scan_normal.h:27-85 (+ Registration, registration.h:68-133)
+  OdometryKeyframeFuser  odometrykeyframefuser.h:72-249  (batched over independent streams here)
+with ROS / PCL / Eigen types replaced by NumPy arrays (host) or torch CUDA tensors (device):
+  pcl::PointCloud<PointXYZI>  ->  float32 [n,4] (x, y, z, intensity)
+  Eigen::Affine3d (planar)    ->  float64 (x, y, theta)  [Affine3dToVectorXYeZ, utils.cpp:115-122]
+Everything computes in libcfear_hip.so on the GPU; there is no CPU path in this package.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+
+
+def _is_torch(x):
+    return type(x).__module__.startswith("torch")
+
+
+def _ptr(x):
+    """(address, keepalive) of a NumPy array (host) or torch tensor (device)."""
+    if x is None:
+        return None, None
+    if _is_torch(x):
+        assert x.is_contiguous()
+        return x.data_ptr(), x
+    assert x.flags["C_CONTIGUOUS"]
+    return x.ctypes.data, x
+
+
+class Context:
+    """cfear_ctx: one per host thread / HIP stream."""
+
+    def __init__(self, device=0, stream=None):
+        self._lib = L.lib()
+        h = C.c_void_p()
+        rc = self._lib.cfear_ctx_create(int(device), C.c_void_p(stream) if stream else None, C.byref(h))
+        if rc != L.OK:
+            raise L.CfearError(rc, self._lib.cfear_status_string(rc).decode() +
+                               " (libcfear_hip needs an MI355X; there is no CPU fallback)")
+        self.h = h
+        self.device = device
+
+    def check(self, rc, allowed=()):
+        if rc != L.OK and rc not in allowed:
+            raise L.CfearError(rc, self._lib.cfear_last_error(self.h).decode())
+        return rc
+
+    def synchronize(self):
+        self.check(self._lib.cfear_ctx_synchronize(self.h))
+
+    def profile_enable(self, on=True):
+        self.check(self._lib.cfear_ctx_profile_enable(self.h, int(on)))
+
+    def profile_read(self, reset=True):
+        """{kernel family: (total_ms, launches)} measured with hipEvents on the context's stream."""
+        cap = 32
+        names = (C.c_char_p * cap)()
+        ms = (C.c_double * cap)()
+        cnt = (C.c_int64 * cap)()
+        n = self._lib.cfear_ctx_profile_read(self.h, names, ms, cnt, cap, int(reset))
+        return {names[i].decode(): (ms[i], cnt[i]) for i in range(min(n, cap))}
+
+    def close(self):
+        if getattr(self, "h", None):
+            self._lib.cfear_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+_DEFAULT_CTX = None
+
+
+def default_context():
+    global _DEFAULT_CTX
+    if _DEFAULT_CTX is None:
+        _DEFAULT_CTX = Context(0)
+    return _DEFAULT_CTX
+
+
+# ------------------------------------------------------------------------------------------------
+# radarDriver
+# ------------------------------------------------------------------------------------------------
+class radarDriverParameters:
+    """radarDriver::Parameters (radar_driver.h:35-84); float members are float32 like the reference."""
+
+    def __init__(self, z_min=60.0, range_res=0.0438, azimuths=400, k_strongest=12, nb_guard_cells=20,
+                 window_size=10, false_alarm_rate=0.01, min_distance=2.5, max_distance=200.0,
+                 dataset="oxford", filter_type="kstrong"):
+        self.z_min, self.range_res, self.azimuths, self.k_strongest = z_min, range_res, azimuths, k_strongest
+        self.nb_guard_cells, self.window_size, self.false_alarm_rate = nb_guard_cells, window_size, false_alarm_rate
+        self.min_distance, self.max_distance = min_distance, max_distance
+        self.dataset, self.filter_type = dataset, filter_type
+
+
+def _desc(img):
+    if img.ndim == 2:
+        rows, cols = img.shape
+        batch = 1
+    else:
+        batch, rows, cols = img.shape
+    d = L.PolarDesc()
+    d.rows, d.cols, d.stride, d.batch = rows, cols, cols, batch
+    d.batch_stride = rows * cols
+    return d, batch, rows, cols
+
+
+def filter_kstrongest(img, k, z_min, range_res, min_distance, want_peaks=False, ctx=None):
+    """StructuredKStrongest (radar_filters.cpp:198-337) for a uint8 image [rows, cols] or a batch
+    [b, rows, cols] (NumPy -> NumPy results, torch CUDA tensor -> torch CUDA results).
+    Returns dict(sel_range, sel_intensity, sel_count, is_peak, xyzi, n_points, xyzi_peaks, n_peaks)."""
+    ctx = ctx or default_context()
+    d, batch, rows, cols = _desc(img)
+    par = L.KStrongParams(int(k), float(z_min), float(range_res), float(min_distance), int(bool(want_peaks)))
+    if _is_torch(img):
+        import torch
+        dev = img.device
+        mk = lambda shape, dt: torch.empty(shape, dtype=dt, device=dev)
+        res = dict(sel_range=mk((batch, rows, k), torch.int32), sel_intensity=mk((batch, rows, k), torch.uint8),
+                   sel_count=mk((batch, rows), torch.int32), xyzi=mk((batch, rows * k, 4), torch.float32),
+                   n_points=mk((batch,), torch.int32))
+        if want_peaks:
+            res.update(is_peak=mk((batch, rows, k), torch.uint8), xyzi_peaks=mk((batch, rows * k, 4), torch.float32),
+                       n_peaks=mk((batch,), torch.int32))
+    else:
+        img = np.ascontiguousarray(img, dtype=np.uint8)
+        res = dict(sel_range=np.empty((batch, rows, k), np.int32), sel_intensity=np.empty((batch, rows, k), np.uint8),
+                   sel_count=np.empty((batch, rows), np.int32), xyzi=np.empty((batch, rows * k, 4), np.float32),
+                   n_points=np.empty((batch,), np.int32))
+        if want_peaks:
+            res.update(is_peak=np.empty((batch, rows, k), np.uint8),
+                       xyzi_peaks=np.empty((batch, rows * k, 4), np.float32), n_peaks=np.empty((batch,), np.int32))
+    out = L.KStrongOut()
+    for name in ("sel_range", "sel_intensity", "sel_count", "is_peak", "xyzi", "n_points", "xyzi_peaks", "n_peaks"):
+        setattr(out, name, _ptr(res.get(name))[0])
+    p, _keep = _ptr(img)
+    ctx.check(ctx._lib.cfear_filter_kstrongest(ctx.h, p, C.byref(d), C.byref(par), C.byref(out)))
+    return res
+
+
+def filter_cacfar(img, window_size, nb_guard_cells, false_alarm_rate, range_res, z_min, min_distance,
+                  max_distance=400.0, cap_points=None, want_mask=False, ctx=None):
+    """AzimuthCACFAR::getFilteredPointCloud (cfar.cpp:35-71).  Returns dict(xyzi, n_points[, det_mask])."""
+    ctx = ctx or default_context()
+    d, batch, rows, cols = _desc(img)
+    cap = int(cap_points or rows * cols)
+    par = L.CacfarParams(int(window_size), int(nb_guard_cells), float(false_alarm_rate), float(range_res),
+                         float(z_min), float(min_distance), float(max_distance))
+    if _is_torch(img):
+        import torch
+        xyzi = torch.empty((batch, cap, 4), dtype=torch.float32, device=img.device)
+        npts = torch.empty((batch,), dtype=torch.int32, device=img.device)
+        mask = torch.empty((batch, rows, cols), dtype=torch.uint8, device=img.device) if want_mask else None
+    else:
+        img = np.ascontiguousarray(img, dtype=np.uint8)
+        xyzi = np.empty((batch, cap, 4), np.float32)
+        npts = np.empty((batch,), np.int32)
+        mask = np.empty((batch, rows, cols), np.uint8) if want_mask else None
+    ctx.check(ctx._lib.cfear_filter_cacfar(ctx.h, _ptr(img)[0], C.byref(d), C.byref(par), _ptr(xyzi)[0],
+                                           _ptr(npts)[0], cap, _ptr(mask)[0]))
+    res = dict(xyzi=xyzi, n_points=npts)
+    if want_mask:
+        res["det_mask"] = mask
+    return res
+
+
+class radarDriver:
+    """radarDriver (radar_driver.cpp): CallbackOffline(image) -> (cloud, cloud_peaks)."""
+
+    def __init__(self, pars=None, ctx=None):
+        self.par = pars or radarDriverParameters()
+        self.ctx = ctx or default_context()
+        self.cv_polar_image = None
+
+    def CallbackOffline(self, radar_image_polar):
+        img = radar_image_polar
+        if self.par.dataset != "oxford":
+            # Callback (radar_driver.cpp:74-90): MONO8 + rotate 90 deg CCW so rows = azimuth
+            img = np.ascontiguousarray(np.rot90(np.asarray(img), 1))
+        self.cv_polar_image = img
+        p = self.par
+        if p.filter_type == "CA-CFAR":                                      # radar_driver.cpp:52-56
+            r = filter_cacfar(img, p.window_size, p.nb_guard_cells, p.false_alarm_rate, p.range_res, p.z_min,
+                              p.min_distance, 400.0, ctx=self.ctx)
+            n = int(r["n_points"][0])
+            return r["xyzi"][0, :n], r["xyzi"][0, :0]
+        r = filter_kstrongest(img, p.k_strongest, p.z_min, p.range_res, p.min_distance, True, ctx=self.ctx)
+        n, m = int(r["n_points"][0]), int(r["n_peaks"][0])
+        return r["xyzi"][0, :n], r["xyzi_peaks"][0, :m]
+
+
+# ------------------------------------------------------------------------------------------------
+# Compensate / MapPointNormal
+# ------------------------------------------------------------------------------------------------
+def Compensate(cloud, mot, ccw, ctx=None):
+    """Compensate(cloud, mot, ccw) (utils.cpp:96-107): in place on `cloud` (float32 [n,4])."""
+    ctx = ctx or default_context()
+    m = (C.c_double * 3)(*[float(v) for v in mot])
+    ctx.check(ctx._lib.cfear_compensate(ctx.h, _ptr(cloud)[0], int(cloud.shape[0]), m, int(bool(ccw))))
+    return cloud
+
+
+class MapPointNormal:
+    """MapPointNormal (pointnormal.h:110): device-resident oriented surface points of one scan."""
+
+    downsample_factor = 1.0      # static member, pointnormal.cpp:5
+
+    def __init__(self, cld=None, radius=3.0, origin=(0.0, 0.0), weight_intensity=False, raw=False, ctx=None,
+                 cells=None, compensate=None, ccw=False):
+        self.ctx = ctx or default_context()
+        self._h = C.c_void_p()
+        lib = self.ctx._lib
+        if cells is not None:
+            cells = np.ascontiguousarray(cells, dtype=L.CELL_DTYPE)
+            self.ctx.check(lib.cfear_scan_from_cells(self.ctx.h, cells.ctypes.data, int(cells.shape[0]), C.byref(self._h)))
+            return
+        if raw:
+            # GetIdentityCell per point (pointnormal.cpp:76-82, pointnormal.h:56,78-80)
+            pts = np.asarray(cld if not _is_torch(cld) else cld.cpu().numpy())
+            c = np.zeros(pts.shape[0], L.CELL_DTYPE)
+            c["mean"] = pts[:, :2]
+            c["normal"] = (1.0, 0.0)
+            c["cov"] = (0.1, 0.0, 0.0, 0.1)
+            c["scale"], c["avg_intensity"], c["lambda_min"], c["lambda_max"], c["nsamples"] = 1.0, 1.0, 1.0, 1.0, 1
+            self.ctx.check(lib.cfear_scan_from_cells(self.ctx.h, c.ctypes.data, int(c.shape[0]), C.byref(self._h)))
+            return
+        fp = L.FeatureParams()
+        fp.radius = float(radius)
+        fp.downsample_factor = float(MapPointNormal.downsample_factor)
+        fp.origin[0], fp.origin[1] = float(origin[0]), float(origin[1])
+        fp.weight_intensity = int(bool(weight_intensity))
+        fp.compensate = int(compensate is not None)
+        if compensate is not None:
+            fp.mot[0], fp.mot[1], fp.mot[2] = [float(v) for v in compensate]
+        fp.ccw = int(bool(ccw))
+        n = int(cld.shape[0])
+        self.ctx.check(lib.cfear_scan_create(self.ctx.h, _ptr(cld)[0], n, C.byref(fp), C.byref(self._h)))
+
+    def GetSize(self):
+        return self.ctx._lib.cfear_scan_size(self._h)
+
+    def GetCells(self):
+        n = self.GetSize()
+        out = np.zeros(max(n, 1), L.CELL_DTYPE)
+        rc = self.ctx._lib.cfear_scan_get_cells(self._h, out.ctypes.data, out.shape[0])
+        if rc < 0:
+            self.ctx.check(rc)
+        return out[:n]
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.ctx._lib.cfear_scan_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+# ------------------------------------------------------------------------------------------------
+# n_scan_normal_reg
+# ------------------------------------------------------------------------------------------------
+class n_scan_normal_reg:
+    """n_scan_normal_reg(cost, loss=Huber, loss_limit=0.1, opt=Uniform) (n_scan_normal.h:35)."""
+
+    def __init__(self, cost="P2L", loss="Huber", loss_limit=0.1, opt=0, ctx=None):
+        self.ctx = ctx or default_context()
+        self.par = L.RegParams()
+        self.ctx._lib.cfear_reg_params_default(C.byref(self.par))
+        self.par.cost = L.COST[cost] if isinstance(cost, str) else int(cost)
+        self.par.loss = L.LOSS[loss] if isinstance(loss, str) else int(loss)
+        self.par.loss_limit = float(loss_limit)
+        self.par.weight_opt = int(opt)
+        self.summary_ = None
+        self.score_ = 0.0
+
+    def SetParameters(self, max_itr_association, max_itr_solver):          # n_scan_normal.cpp:15-19
+        self.par.max_itr_association = int(max_itr_association)
+        self.par.max_itr_solver = int(max_itr_solver)
+
+    def SetD2dPar(self, cov_scale, regularization):                        # n_scan_normal.h:59
+        self.par.cov_scale, self.par.regularization = float(cov_scale), float(regularization)
+
+    def _handles(self, scans):
+        return (C.c_void_p * len(scans))(*[s._h for s in scans])
+
+    def Register(self, scans, Tsrc):
+        """Register(scans, Tsrc, reg_cov) (n_scan_normal.cpp:82-185): Tsrc float64 [n,3] (x,y,theta);
+        returns (success, Tsrc_out, reg_cov) with reg_cov the reference's constant diagonal."""
+        p = np.ascontiguousarray(Tsrc, dtype=np.float64).copy()
+        res = L.RegResult()
+        rc = self.ctx._lib.cfear_register(self.ctx.h, self._handles(scans), len(scans),
+                                          p.ctypes.data_as(C.POINTER(C.c_double)), C.byref(self.par), C.byref(res))
+        self.ctx.check(rc, allowed=(L.ERR_TOO_FEW_RESIDUALS, L.ERR_SOLVER))
+        self.summary_ = res
+        self.score_ = res.score
+        self.par.itr = res.outer_iters                                     # itr_ is left behind for GetCost
+        cov = np.diag([0.1 * 0.1, 0.1 * 0.1, 0, 0, 0, 0.01 * 0.01])        # n_scan_normal.cpp:171-175
+        return rc == L.OK, p, cov
+
+    def RegisterBatch(self, jobs):
+        """jobs: list of (scans, Tsrc).  One launch; returns a RESULT_DTYPE array."""
+        n = len(jobs)
+        arr = (L.RegJob * n)()
+        keep = []
+        for i, (scans, T) in enumerate(jobs):
+            hs = self._handles(scans)
+            p = np.ascontiguousarray(T, dtype=np.float64)
+            keep.append((hs, p))
+            arr[i].scans = C.cast(hs, C.POINTER(C.c_void_p))
+            arr[i].n_scans = len(scans)
+            arr[i].poses_xyt = p.ctypes.data_as(C.POINTER(C.c_double))
+        out = np.zeros(n, L.RESULT_DTYPE)
+        self.ctx.check(self.ctx._lib.cfear_register_batch(self.ctx.h, arr, n, C.byref(self.par), out.ctypes.data))
+        return out
+
+    def GetCost(self, scans, Tsrc):
+        """GetCost (n_scan_normal.cpp:186-211) -> (success, score(cost), residuals)."""
+        p = np.ascontiguousarray(Tsrc, dtype=np.float64)
+        cap = 2 * sum(s.GetSize() for s in scans) + 2
+        r = np.empty(cap, np.float64)
+        cost, score, nres = C.c_double(), C.c_double(), C.c_int32()
+        rc = self.ctx._lib.cfear_get_cost(self.ctx.h, self._handles(scans), len(scans),
+                                          p.ctypes.data_as(C.POINTER(C.c_double)), C.byref(self.par), C.byref(cost),
+                                          r.ctypes.data_as(C.POINTER(C.c_double)), cap, C.byref(nres), C.byref(score))
+        self.ctx.check(rc, allowed=(L.ERR_TOO_FEW_RESIDUALS,))
+        self.score_ = score.value
+        return rc == L.OK, cost.value, r[:nres.value].copy()
+
+    def getScore(self):
+        return self.score_
+
+
+class CeresCost:
+    """cfear_cost: Ceres-compatible evaluation of one association set (n_scan_normal.cpp:264-318)."""
+
+    def __init__(self, reg, scans, Tsrc, itr=1):
+        self.ctx = reg.ctx
+        p = np.ascontiguousarray(Tsrc, dtype=np.float64)
+        self._h = C.c_void_p()
+        self.rpb = 1 if reg.par.cost == L.P2L else 2
+        self.ctx.check(self.ctx._lib.cfear_cost_prepare(self.ctx.h, reg._handles(scans), len(scans),
+                                                        p.ctypes.data_as(C.POINTER(C.c_double)), C.byref(reg.par),
+                                                        int(itr), C.byref(self._h)))
+
+    def blocks(self):
+        n = self.ctx._lib.cfear_cost_num_blocks(self._h)
+        pairs = np.empty((max(n, 1), 3), np.int32)
+        w = np.empty(max(n, 1), np.float64)
+        self.ctx._lib.cfear_cost_get_blocks(self._h, pairs.ctypes.data, w.ctypes.data)
+        return pairs[:n], w[:n]
+
+    def evaluate(self, x):
+        n = self.ctx._lib.cfear_cost_num_residuals(self._h)
+        r = np.empty(max(n, 1), np.float64)
+        J = np.empty((max(n, 1), 3), np.float64)
+        xx = (C.c_double * 3)(*[float(v) for v in x])
+        self.ctx.check(self.ctx._lib.cfear_cost_evaluate(self._h, xx, r.ctypes.data, J.ctypes.data))
+        return r[:n], J[:n]
+
+    def normal_eq(self, x):
+        xx = (C.c_double * 3)(*[float(v) for v in x])
+        H = (C.c_double * 9)()
+        g = (C.c_double * 3)()
+        cost = C.c_double()
+        self.ctx.check(self.ctx._lib.cfear_cost_normal_eq(self._h, xx, H, g, C.byref(cost)))
+        return np.array(H).reshape(3, 3), np.array(g), cost.value
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.ctx._lib.cfear_cost_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+# ------------------------------------------------------------------------------------------------
+# batched radarDriver + OdometryKeyframeFuser
+# ------------------------------------------------------------------------------------------------
+def odometry_params(**kw):
+    """cfear_odometry_params with the CFEAR-3 / Oxford preset; keyword overrides use the C field names
+    (nested: kstrong_k_strongest, cacfar_window_size, reg_cost, ...)."""
+    p = L.OdometryParams()
+    L.lib().cfear_odometry_params_default(C.byref(p))
+    for k, v in kw.items():
+        for prefix, sub in (("kstrong_", p.kstrong), ("cacfar_", p.cacfar), ("reg_", p.reg)):
+            if k.startswith(prefix) and hasattr(sub, k[len(prefix):]):
+                setattr(sub, k[len(prefix):], v)
+                break
+        else:
+            if not hasattr(p, k):
+                raise KeyError(k)
+            setattr(p, k, v)
+    return p
+
+
+class OdometryKeyframeFuser:
+    """n_streams independent radarDriver + OdometryKeyframeFuser pairs advanced one frame per call
+    (radar_driver.cpp:163-176 + odometrykeyframefuser.cpp:143-259), everything on the GPU."""
+
+    def __init__(self, n_streams, rows, cols, par=None, ctx=None):
+        self.ctx = ctx or default_context()
+        self.par = par or odometry_params()
+        d = L.PolarDesc()
+        d.rows, d.cols, d.stride, d.batch = rows, cols, cols, n_streams
+        d.batch_stride = rows * cols
+        self.n_streams = n_streams
+        self._h = C.c_void_p()
+        self.ctx.check(self.ctx._lib.cfear_odometry_create(self.ctx.h, n_streams, C.byref(d), C.byref(self.par),
+                                                           C.byref(self._h)))
+        self._info = np.zeros(n_streams, L.FRAMEINFO_DTYPE)
+
+    def process(self, polar):
+        """polar: uint8 [n_streams, rows, cols] (NumPy or torch CUDA).  Returns a FRAMEINFO_DTYPE array."""
+        self.ctx.check(self.ctx._lib.cfear_odometry_process(self._h, _ptr(polar)[0], self._info.ctypes.data))
+        return self._info.copy()
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.ctx._lib.cfear_odometry_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

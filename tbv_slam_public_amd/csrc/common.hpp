@@ -1,0 +1,158 @@
+// common.hpp -- shared host/device infrastructure of libcfear_hip.so (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/cfear_hip.h"
+
+#define CFEAR_WAVE 64
+
+// ---------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------
+struct ProfRow {
+  const char* name;
+  double total_ms = 0.0;
+  int64_t launches = 0;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+};
+
+struct cfear_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  std::string last_error;
+  bool profile = false;
+  std::vector<ProfRow> prof;
+  std::vector<hipEvent_t> event_pool;
+  // grow-only device workspaces (indexed by purpose so stages of one pipeline do not alias)
+  struct Ws { void* p = nullptr; size_t bytes = 0; };
+  Ws ws[8];
+  // pinned host staging for small read-backs
+  void* pinned = nullptr;
+  size_t pinned_bytes = 0;
+  // free list of scan slabs (capacity -> device pointers) so streaming does not hipMalloc
+  struct Slab { void* p; int cap; };
+  std::vector<Slab> free_slabs;
+  int64_t live_scans = 0;
+  int trig_rows = 0;       // rows the cos/sin tables in ws[2] were built for
+};
+
+int cfear_set_error(cfear_ctx* ctx, int status, const char* fmt, ...);
+
+#define CFEAR_HIP_CHECK(ctx, expr)                                                              \
+  do {                                                                                          \
+    hipError_t _e = (expr);                                                                     \
+    if (_e != hipSuccess)                                                                       \
+      return cfear_set_error((ctx), CFEAR_ERR_HIP, "%s failed: %s (%s:%d)", #expr,              \
+                             hipGetErrorString(_e), __FILE__, __LINE__);                        \
+  } while (0)
+
+// true if p is device (or managed) memory visible to kernels without a copy
+bool cfear_is_device_ptr(const void* p);
+// grow-only workspace `slot` of at least `bytes`; returns nullptr on allocation failure
+void* cfear_workspace(cfear_ctx* ctx, int slot, size_t bytes);
+void* cfear_pinned(cfear_ctx* ctx, size_t bytes);
+
+// profiling: wrap a kernel launch
+int cfear_prof_row(cfear_ctx* ctx, const char* name);
+void cfear_prof_begin(cfear_ctx* ctx, int row);
+void cfear_prof_end(cfear_ctx* ctx, int row);
+
+struct ProfScope {
+  cfear_ctx* ctx;
+  int row;
+  ProfScope(cfear_ctx* c, const char* name) : ctx(c), row(-1) {
+    if (ctx->profile) { row = cfear_prof_row(ctx, name); cfear_prof_begin(ctx, row); }
+  }
+  ~ProfScope() { if (row >= 0) cfear_prof_end(ctx, row); }
+};
+
+// ---------------------------------------------------------------------------------------------
+// device-resident MapPointNormal ("scan"): SoA slab of `cap` cells
+// ---------------------------------------------------------------------------------------------
+struct ScanView {          // plain pointers into one slab; passed to kernels by value / in tables
+  float2* mean_f;          // float copy of the means (pointnormal.cpp:151-162), NN search space
+  double2* mean;           // u_
+  double2* normal;         // snormal_
+  double4* cov;            // cov_ row-major (c00,c01,c10,c11)
+  double* scale;           // scale_
+  double* avg_intensity;
+  double2* lambda;         // (lambda_min, lambda_max)
+  int32_t* nsamples;
+  int32_t* n_cells;        // device counter (written by the surface kernel)
+  int32_t cap;
+  int32_t pad;
+};
+
+struct cfear_scan {
+  cfear_ctx* ctx;
+  void* slab;
+  ScanView view;
+  int32_t n_cells_host;    // -1 until read back
+};
+
+size_t cfear_scan_slab_bytes(int cap);
+ScanView cfear_scan_view(void* slab, int cap);
+int cfear_scan_alloc(cfear_ctx* ctx, int cap, cfear_scan** out);
+
+// ---------------------------------------------------------------------------------------------
+// device helpers
+// ---------------------------------------------------------------------------------------------
+#if defined(__HIPCC__)
+
+// DPP move: lanes without a valid source (or masked off) receive 0.
+template <int CTRL, int ROW_MASK = 0xf, int BANK_MASK = 0xf, bool BOUND = true>
+__device__ __forceinline__ int dpp_mov(int v) {
+  return __builtin_amdgcn_update_dpp(0, v, CTRL, ROW_MASK, BANK_MASK, BOUND);
+}
+
+// Inclusive prefix sum across the 64 lanes of a wavefront (row_shr Hillis-Steele inside each
+// 16-lane DPP row, then row_bcast:15 / row_bcast:31 to carry row totals).  6 DPP adds, no LDS.
+__device__ __forceinline__ int wave_incl_scan_i32(int v) {
+  v += dpp_mov<0x111>(v);                      // row_shr:1
+  v += dpp_mov<0x112>(v);                      // row_shr:2
+  v += dpp_mov<0x114>(v);                      // row_shr:4
+  v += dpp_mov<0x118>(v);                      // row_shr:8
+  v += dpp_mov<0x142, 0xa, 0xf, false>(v);     // row_bcast:15 -> rows 1,3
+  v += dpp_mov<0x143, 0xc, 0xf, false>(v);     // row_bcast:31 -> rows 2,3
+  return v;
+}
+
+// Wave-uniform sum (result in an SGPR).
+__device__ __forceinline__ int wave_sum_i32(int v) {
+  return __builtin_amdgcn_readlane(wave_incl_scan_i32(v), 63);
+}
+
+// Sum of a double over each 16-lane DPP row; every lane of the row receives the row total.
+// Order: pairwise butterfly (quad xor 1, xor 2, half-mirror, mirror) -- deterministic.
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
+  hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double row16_sum_f64(double v) {
+  v += dpp_f64<0xB1>(v);    // quad_perm [1,0,3,2]
+  v += dpp_f64<0x4E>(v);    // quad_perm [2,3,0,1]
+  v += dpp_f64<0x141>(v);   // row_half_mirror
+  v += dpp_f64<0x140>(v);   // row_mirror
+  return v;
+}
+__device__ __forceinline__ double readlane_f64(double v, int lane) {
+  int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+  int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+  return __hiloint2double(hi, lo);
+}
+// Wave-uniform sum of a double: row sums, then rows 0..3 added in order.
+__device__ __forceinline__ double wave_sum_f64(double v) {
+  v = row16_sum_f64(v);
+  return ((readlane_f64(v, 0) + readlane_f64(v, 16)) + readlane_f64(v, 32)) + readlane_f64(v, 48);
+}
+#endif  // __HIPCC__

@@ -1,0 +1,764 @@
+// filter.hip -- stage F of the CFEAR hot path on gfx950: k-strongest / peaks / CA-CFAR filtering of
+// the polar radar image and polar->Cartesian conversion.
+//
+// Replaces (cfear_radarodometry/src/cfear_radarodometry/):
+//   StructuredKStrongest::FilterKstrongest          radar_filters.cpp:209-237
+//   StructuredKStrongest::AxialNonMaxSupress        radar_filters.cpp:238-298
+//   StructuredKStrongest::getPeaksFilteredPointCloud radar_filters.cpp:300-337
+//   AzimuthCACFAR::getFilteredPointCloud / getMean  cfar.cpp:35-83
+//
+// Kernel design (HBM-bound integer/byte work, no MFMA):
+//   kstrongest_rows_kernel  one 64-lane wavefront per azimuth row.  The row (cols bytes) is read
+//     ONCE from HBM with 16-byte-per-lane non-temporal loads into registers (cols <= 8192 ->
+//     <= 8 x dwordx4 per lane) and never re-read.  The k largest (intensity,range) pairs are found
+//     without sorting the row: a SWAR byte-compare + popcount counts "intensity >= t" for a wave-
+//     uniform threshold t (3 VALU per 4 bins), an 8-step bisection finds the cut intensity T, ties
+//     at T are resolved toward the larger range through a packed DPP prefix scan, and only the
+//     <= k survivors are ranked (LDS broadcast reads) to produce the reference's ascending
+//     (intensity,range) order.  Results are bit-exact integers.
+//   kstrong_cloud_kernel    one workgroup per image: per-row survivor counts -> scan -> compacted
+//     PointXYZI cloud, fp64 polar->Cartesian with host-computed cos/sin tables (bit-exact floats).
+//   cacfar_rows_kernel      one wavefront per row: exact uint32 prefix sums of squares in LDS,
+//     windowed means and thresholds in fp64 exactly as the reference evaluates them.
+#include <cmath>
+
+#include "common.hpp"
+
+namespace {
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4), aligned(4)));
+
+constexpr int kRowsPerBlock = 4;   // 4 wavefronts (rows) per 256-thread workgroup
+constexpr int kMaxCols = 8192;
+constexpr int kMaxK = 1024;
+
+struct KStrongArgs {
+  const uint8_t* polar;
+  int rows, cols, stride, batch;
+  long long batch_stride;
+  int k, u_zmin, want_peaks;
+  int32_t* sel_range;
+  uint8_t* sel_intensity;
+  int32_t* sel_count;
+  uint8_t* is_peak;
+};
+
+// bit 7 of every byte of the result is set iff that byte of x is >= t (0 <= t <= 255), given the
+// two precomputed halves xlo = (x & 0x7f7f7f7f) | 0x80808080 and xh = x & 0x80808080.
+// Per byte (0x80 + low7) - (t & 0x7f) stays in [1, 0xff]: no borrow crosses a byte boundary.
+__device__ __forceinline__ uint32_t swar_ge(uint32_t xlo, uint32_t xh, uint32_t tl4, bool thi) {
+  const uint32_t g = xlo - tl4;
+  return thi ? (xh & g) : ((g & 0x80808080u) | xh);
+}
+
+// Reads the row into registers: lane L of chunk c owns bytes [(c*64+L)*16, +16).
+template <int NCHUNK, bool VEC>
+__device__ __forceinline__ void load_row(const uint8_t* rowp, int cols, int lane, uint32_t (&w)[NCHUNK * 4]) {
+#pragma unroll
+  for (int c = 0; c < NCHUNK; c++) {
+    const int pos = (c * 64 + lane) * 16;
+    if (VEC && pos + 16 <= cols) {
+      const u32x4 v = __builtin_nontemporal_load((const u32x4*)(rowp + pos));
+      w[c * 4 + 0] = v.x; w[c * 4 + 1] = v.y; w[c * 4 + 2] = v.z; w[c * 4 + 3] = v.w;
+    } else {
+#pragma unroll
+      for (int d = 0; d < 4; d++) {
+        uint32_t word = 0;
+#pragma unroll
+        for (int by = 0; by < 4; by++) {
+          const int p = pos + d * 4 + by;
+          if (p < cols) word |= (uint32_t)rowp[p] << (8 * by);
+        }
+        w[c * 4 + d] = word;
+      }
+    }
+  }
+}
+
+// AxialNonMaxSupress for one kept bin m (radar_filters.cpp:238-298).
+__device__ bool peak_is_largest(int m, int cols, const uint8_t* rowbuf, const uint8_t* img, long long row_lin,
+                                long long total, const uint32_t* list, int n_sel) {
+  auto raw = [&](int q) -> int {
+    if (q >= 0 && q < cols) return rowbuf[q];
+    const long long lin = row_lin + q;            // unchecked cv::Mat::at on a continuous image
+    return (lin >= 0 && lin < total) ? (int)img[lin] : 0;
+  };
+  const bool valid_m = (m >= 3 && m < cols - 3);
+  int sc[7];
+  if (valid_m) {
+    int v[13];
+#pragma unroll
+    for (int i = 0; i < 13; i++) v[i] = raw(m - 6 + i);
+#pragma unroll
+    for (int i = 0; i < 7; i++) {
+      int s = 0;
+#pragma unroll
+      for (int j = 0; j < 7; j++) s += v[i + j];
+      sc[i] = s;
+    }
+  } else {
+    // m itself was never scored: a neighbour key exists only if another kept, valid bin created it
+    for (int i = 0; i < 7; i++) {
+      const int r = m - 3 + i;
+      bool covered = false;
+      for (int t = 0; t < n_sel; t++) {
+        const int mm = (int)(list[t] & 0xFFFFFFu);
+        if (mm >= 3 && mm < cols - 3 && r >= mm - 3 && r <= mm + 3) { covered = true; break; }
+      }
+      int s = 0;
+      if (covered)
+        for (int q = r - 3; q <= r + 3; q++) s += raw(q);
+      sc[i] = s & 0xFFFF;
+    }
+  }
+  const int pthis = sc[3];
+  bool largest = true;
+#pragma unroll
+  for (int i = 1; i <= 3; i++) {
+    const int pnext = sc[3 + i], pprev = sc[3 - i];
+    if (pprev > pthis || pthis < pnext) largest = false;
+  }
+  return largest;
+}
+
+template <int NCHUNK, bool VEC, bool MASK>
+__global__ __launch_bounds__(256) void kstrongest_rows_kernel(const KStrongArgs a) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const long long grow = (long long)blockIdx.x * kRowsPerBlock + wave;
+  if (grow >= (long long)a.batch * a.rows) return;          // no workgroup barrier below
+  const int b = (int)(grow / a.rows), r = (int)(grow - (long long)b * a.rows);
+  const uint8_t* img = a.polar + (long long)b * a.batch_stride;
+  const long long row_lin = (long long)r * a.stride;
+  const uint8_t* rowp = img + row_lin;
+  const int kpad = (a.k + 3) & ~3;
+  const int per_wave = kpad * 4 + (a.want_peaks ? NCHUNK * 1024 : 0);
+  uint32_t* list = (uint32_t*)(smem + wave * per_wave);
+  uint8_t* rowbuf = smem + wave * per_wave + kpad * 4;
+
+  uint32_t w[NCHUNK * 4];
+  load_row<NCHUNK, VEC>(rowp, a.cols, lane, w);
+
+  uint32_t xlo[NCHUNK * 4], xh[NCHUNK * 4], vm[NCHUNK * 4];
+#pragma unroll
+  for (int i = 0; i < NCHUNK * 4; i++) {
+    xlo[i] = (w[i] & 0x7f7f7f7fu) | 0x80808080u;
+    xh[i] = w[i] & 0x80808080u;
+    if (MASK) {                                    // validity of each byte position (tail / z_min==0)
+      const int pos = ((i >> 2) * 64 + lane) * 16 + (i & 3) * 4;
+      const int rem = a.cols - pos;
+      vm[i] = rem >= 4 ? 0x80808080u : (rem <= 0 ? 0u : (0x80808080u & ((1u << (8 * rem)) - 1u)));
+    } else {
+      vm[i] = 0x80808080u;
+    }
+  }
+  if (a.want_peaks) {                              // stage the raw row for the 7-tap box sums
+#pragma unroll
+    for (int c = 0; c < NCHUNK; c++)
+      *(uint4*)(rowbuf + (c * 64 + lane) * 16) = make_uint4(w[c * 4], w[c * 4 + 1], w[c * 4 + 2], w[c * 4 + 3]);
+  }
+
+  // number of bins with intensity >= t (wave-uniform t in [0,256])
+  auto count_ge = [&](int t) -> int {
+    if (t > 255) return 0;
+    const uint32_t tl4 = (uint32_t)(t & 0x7f) * 0x01010101u;
+    const bool thi = (t & 0x80) != 0;
+    int c0 = 0, c1 = 0;
+#pragma unroll
+    for (int i = 0; i < NCHUNK * 4; i += 2) {
+      uint32_t m0 = swar_ge(xlo[i], xh[i], tl4, thi), m1 = swar_ge(xlo[i + 1], xh[i + 1], tl4, thi);
+      if (MASK) { m0 &= vm[i]; m1 &= vm[i + 1]; }
+      c0 += __popc(m0);
+      c1 += __popc(m1);
+    }
+    return wave_sum_i32(c0 + c1);
+  };
+
+  // ---- threshold search: T = largest intensity with count(>= T) >= k ----------------------
+  const int k = a.k;
+  const int n_ge = count_ge(a.u_zmin);
+  int thr_gt, T, skip_eq;          // select all >= thr_gt, plus the (n_eq - skip_eq) largest ranges == T
+  bool ties;
+  if (n_ge <= k) {
+    thr_gt = a.u_zmin; T = -1; skip_eq = 0; ties = false;
+  } else {
+    int lo = a.u_zmin, hi = 255, n_lo = n_ge;
+    while (lo < hi) {              // invariant: count(>= lo) >= k, count(>= hi+1) < k
+      const int mid = (lo + hi + 1) >> 1;
+      const int c = count_ge(mid);
+      if (c >= k) { lo = mid; n_lo = c; } else { hi = mid - 1; }
+    }
+    T = lo;
+    const int n_gt = count_ge(T + 1);
+    const int n_eq = n_lo - n_gt;
+    skip_eq = n_eq - (k - n_gt);   // drop the lowest-range ties (lexicographic (intensity,range))
+    thr_gt = T + 1;
+    ties = true;
+  }
+
+  // ---- ordered compaction of the survivors into list[] (position order) --------------------
+  int g_base = 0, e_base = 0;      // survivors with intensity > T / == T before the current chunk
+  const uint32_t tg4 = (uint32_t)(thr_gt & 0x7f) * 0x01010101u;
+  const bool tghi = (thr_gt & 0x80) != 0;
+  const uint32_t te4 = (uint32_t)(T & 0x7f) * 0x01010101u;
+  const bool tehi = (T & 0x80) != 0;
+#pragma unroll
+  for (int c = 0; c < NCHUNK; c++) {
+    uint32_t mg[4], me[4];
+    int cg = 0, ce = 0;
+#pragma unroll
+    for (int d = 0; d < 4; d++) {
+      const int i = c * 4 + d;
+      mg[d] = thr_gt > 255 ? 0u : swar_ge(xlo[i], xh[i], tg4, tghi);
+      if (MASK) mg[d] &= vm[i];
+      me[d] = 0;
+      if (ties) {
+        uint32_t ge_t = swar_ge(xlo[i], xh[i], te4, tehi);
+        if (MASK) ge_t &= vm[i];
+        me[d] = ge_t & ~mg[d];
+      }
+      cg += __popc(mg[d]);
+      ce += __popc(me[d]);
+    }
+    const int packed = (ce << 16) | cg;            // one scan carries both prefixes (totals < 65536)
+    const int incl = wave_incl_scan_i32(packed);
+    const int tot = __builtin_amdgcn_readlane(incl, 63);
+    const int excl = incl - packed;
+    int g_run = g_base + (excl & 0xFFFF);
+    int e_run = e_base + (excl >> 16);
+    if (cg + ce) {
+#pragma unroll
+      for (int d = 0; d < 4; d++) {
+        uint32_t mm = mg[d] | me[d];
+        while (mm) {
+          const int bit = __ffs(mm) - 1;           // bit 7 of byte (bit >> 3)
+          mm &= mm - 1;
+          const int by = bit >> 3;
+          const bool is_eq = (me[d] >> bit) & 1u;
+          bool selected = true;
+          if (is_eq) { selected = e_run >= skip_eq; }
+          // slot = #(> T) before + #(selected == T) before
+          const int e_sel_before = e_run > skip_eq ? e_run - skip_eq : 0;
+          if (selected) {
+            const int slot = g_run + e_sel_before;
+            const int pos = (c * 64 + lane) * 16 + d * 4 + by;
+            const uint32_t inten = (w[c * 4 + d] >> (8 * by)) & 0xffu;
+            list[slot] = (inten << 24) | (uint32_t)pos;
+          }
+          if (is_eq) e_run++; else g_run++;
+        }
+      }
+    }
+    g_base += tot & 0xFFFF;
+    e_base += tot >> 16;
+  }
+  const int n_sel = ties ? k : n_ge;
+  for (int j = n_sel + lane; j < kpad; j += 64) list[j] = 0xFFFFFFFFu;    // pad for the b128 reads
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+  // ---- rank the <= k survivors: ascending (intensity, range) == ascending packed key --------
+  const long long obase = ((long long)b * a.rows + r) * k;
+  for (int j = lane; j < k; j += 64) {
+    if (j < n_sel) {
+      const uint32_t key = list[j];
+      int rank = 0;
+      for (int i = 0; i < kpad; i += 4) {
+        const uint4 q = *(const uint4*)(list + i);  // same address in every lane: LDS broadcast
+        rank += (q.x < key) + (q.y < key) + (q.z < key) + (q.w < key);
+      }
+      const int range = (int)(key & 0xFFFFFFu);
+      if (a.sel_range) a.sel_range[obase + rank] = range;
+      if (a.sel_intensity) a.sel_intensity[obase + rank] = (uint8_t)(key >> 24);
+      if (a.want_peaks && a.is_peak)
+        a.is_peak[obase + rank] = peak_is_largest(range, a.cols, rowbuf, img, row_lin,
+                                                  (long long)a.rows * a.stride, list, n_sel) ? 1 : 0;
+    } else {
+      if (a.sel_range) a.sel_range[obase + j] = -1;
+      if (a.sel_intensity) a.sel_intensity[obase + j] = 0;
+      if (a.want_peaks && a.is_peak) a.is_peak[obase + j] = 0;
+    }
+  }
+  if (lane == 0 && a.sel_count) a.sel_count[(long long)b * a.rows + r] = n_sel;
+}
+
+// ---------------------------------------------------------------------------------------------
+// cloud compaction: radar_filters.cpp:309-337
+// ---------------------------------------------------------------------------------------------
+struct CloudArgs {
+  const int32_t* sel_range;
+  const uint8_t* sel_intensity;
+  const int32_t* sel_count;
+  const uint8_t* is_peak;
+  const double* cos_t;      // [rows]
+  const double* sin_t;
+  int rows, k, min_range_bin;
+  double range_res;
+  float* xyzi;              // [batch][rows*k][4]
+  int32_t* n_points;        // [batch]
+  float* xyzi_peaks;
+  int32_t* n_peaks;
+};
+
+__global__ __launch_bounds__(256) void kstrong_cloud_kernel(const CloudArgs a) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  int32_t* row_off = (int32_t*)smem;                 // [rows + 1]
+  __shared__ int32_t wave_tot[4];
+  __shared__ int32_t run_base;
+  const int b = blockIdx.x;
+  const bool peaks = blockIdx.y == 1;
+  float* out = peaks ? a.xyzi_peaks : a.xyzi;
+  int32_t* nout = peaks ? a.n_peaks : a.n_points;
+  if (!out && !nout) return;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const long long ibase = (long long)b * a.rows * a.k;
+  // pass 1: survivors per row
+  for (int r = threadIdx.x; r < a.rows; r += blockDim.x) {
+    const int cnt = a.sel_count[(long long)b * a.rows + r];
+    int n = 0;
+    for (int j = 0; j < cnt; j++) {
+      const bool ok = a.sel_range[ibase + (long long)r * a.k + j] > a.min_range_bin &&
+                      (!peaks || a.is_peak[ibase + (long long)r * a.k + j]);
+      n += ok;
+    }
+    row_off[r] = n;
+  }
+  if (threadIdx.x == 0) run_base = 0;
+  __syncthreads();
+  // pass 2: exclusive scan of row_off (chunks of 256 rows)
+  for (int r0 = 0; r0 < a.rows; r0 += 256) {
+    const int r = r0 + threadIdx.x;
+    const int v = r < a.rows ? row_off[r] : 0;
+    const int incl = wave_incl_scan_i32(v);
+    if (lane == 63) wave_tot[wave] = incl;
+    __syncthreads();
+    int off = run_base;
+    for (int wv = 0; wv < wave; wv++) off += wave_tot[wv];
+    if (r < a.rows) row_off[r] = off + incl - v;
+    __syncthreads();
+    if (threadIdx.x == 0) run_base += wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0 && nout) nout[b] = run_base;
+  if (!out) return;
+  // pass 3: one wavefront per row writes its points in (intensity,range) order
+  const double range_res_half = a.range_res / 2.0;
+  for (int r = wave; r < a.rows; r += 4) {
+    const int cnt = a.sel_count[(long long)b * a.rows + r];
+    const double cos_t = a.cos_t[r], sin_t = a.sin_t[r];
+    int base = row_off[r];
+    for (int j0 = 0; j0 < cnt; j0 += 64) {
+      const int j = j0 + lane;
+      bool ok = false;
+      int range = 0;
+      if (j < cnt) {
+        range = a.sel_range[ibase + (long long)r * a.k + j];
+        ok = range > a.min_range_bin && (!peaks || a.is_peak[ibase + (long long)r * a.k + j]);
+      }
+      const unsigned long long bal = __ballot(ok);
+      if (ok) {
+        const int idx = base + __popcll(bal & ((1ull << lane) - 1ull));
+        const double rho = range_res_half + a.range_res * (double)range;
+        float4 p;
+        p.x = (float)(rho * cos_t);
+        p.y = (float)(rho * sin_t);
+        p.z = 0.f;
+        p.w = (float)a.sel_intensity[ibase + (long long)r * a.k + j];
+        ((float4*)out)[(long long)b * a.rows * a.k + idx] = p;
+      }
+      base += __popcll(bal);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// CA-CFAR: cfar.cpp:35-83
+// ---------------------------------------------------------------------------------------------
+struct CfarArgs {
+  const uint8_t* polar;
+  int rows, cols, stride, batch;
+  long long batch_stride;
+  int window, guard;
+  double scaling, range_res, static_threshold, min_distance, max_distance;
+  unsigned long long* det_bits;   // [batch][rows][words]  (words = ceil(cols/64))
+  int32_t* det_count;             // [batch][rows]
+  int words;
+};
+
+__global__ __launch_bounds__(256) void cacfar_rows_kernel(const CfarArgs a) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const long long grow = (long long)blockIdx.x * kRowsPerBlock + wave;
+  if (grow >= (long long)a.batch * a.rows) return;
+  const int b = (int)(grow / a.rows), r = (int)(grow - (long long)b * a.rows);
+  const uint8_t* rowp = a.polar + (long long)b * a.batch_stride + (long long)r * a.stride;
+  const int colsp = (a.cols + 64) & ~63;
+  uint32_t* P = (uint32_t*)(smem + (size_t)wave * ((size_t)colsp * 4 + 256));   // P[i] = sum_{q<i} I_q^2, exact in uint32
+  // prefix sums of squares, 64 bins per step (coalesced byte loads, conflict-free LDS writes)
+  uint32_t run = 0;
+  if (lane == 0) P[0] = 0;
+  for (int i0 = 0; i0 < a.cols; i0 += 64) {
+    const int i = i0 + lane;
+    const uint32_t v = i < a.cols ? (uint32_t)rowp[i] : 0u;
+    const int incl = wave_incl_scan_i32((int)(v * v));
+    if (i < a.cols) P[i + 1] = run + (uint32_t)incl;
+    run += (uint32_t)__builtin_amdgcn_readlane(incl, 63);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  int total = 0;
+  for (int i0 = 0; i0 < a.cols; i0 += 64) {
+    const int bin = i0 + lane;
+    bool det = false;
+    if (bin < a.cols) {
+      const double range = a.range_res * (double)bin;                         // cfar.cpp:43
+      const uint32_t sq = P[bin + 1] - P[bin];
+      const double intensity = (double)rowp[bin];
+      if (range > a.min_distance && range < a.max_distance && intensity > a.static_threshold) {   // :45
+        const int t0 = max(0, bin - a.guard - a.window), t1 = bin - a.guard;  // :48-49
+        const int f0 = bin + a.guard, f1 = min(a.cols, bin + a.guard + a.window);   // :52-53
+        // getMean: sequential sum of exact integer-valued doubles / count; an empty window is 0/0
+        if (t1 > t0 && f1 > f0) {
+          const double trailing_mean = (double)(P[t1] - P[t0]) / (double)(t1 - t0);
+          const double forwarding_mean = (double)(P[f1] - P[f0]) / (double)(f1 - f0);
+          const double mean = (trailing_mean + forwarding_mean) / 2.0;        // :56
+          const double threshold = a.scaling * mean;                          // :58
+          det = (double)sq > threshold;                                       // :59-60
+        }
+      }
+    }
+    const unsigned long long bal = __ballot(det);
+    if (lane == 0) a.det_bits[((long long)b * a.rows + r) * a.words + (i0 >> 6)] = bal;
+    total += __popcll(bal);
+  }
+  if (lane == 0) a.det_count[(long long)b * a.rows + r] = total;
+}
+
+struct CfarCloudArgs {
+  const uint8_t* polar;
+  int rows, cols, stride;
+  long long batch_stride;
+  const unsigned long long* det_bits;
+  const int32_t* det_count;
+  int words;
+  const double* cos_t;
+  const double* sin_t;
+  double range_res;
+  float* xyzi;
+  int32_t* n_points;
+  int cap_points;
+  uint8_t* det_mask;
+};
+
+__global__ __launch_bounds__(256) void cacfar_cloud_kernel(const CfarCloudArgs a) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  int32_t* row_off = (int32_t*)smem;
+  __shared__ int32_t wave_tot[4];
+  __shared__ int32_t run_base;
+  const int b = blockIdx.x;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (threadIdx.x == 0) run_base = 0;
+  __syncthreads();
+  for (int r0 = 0; r0 < a.rows; r0 += 256) {
+    const int r = r0 + threadIdx.x;
+    const int v = r < a.rows ? a.det_count[(long long)b * a.rows + r] : 0;
+    const int incl = wave_incl_scan_i32(v);
+    if (lane == 63) wave_tot[wave] = incl;
+    __syncthreads();
+    int off = run_base;
+    for (int wv = 0; wv < wave; wv++) off += wave_tot[wv];
+    if (r < a.rows) row_off[r] = off + incl - v;
+    __syncthreads();
+    if (threadIdx.x == 0) run_base += wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) a.n_points[b] = run_base;
+  const uint8_t* img = a.polar + (long long)b * a.batch_stride;
+  for (int r = wave; r < a.rows; r += 4) {
+    int base = row_off[r];
+    const double cos_t = a.cos_t[r], sin_t = a.sin_t[r];
+    for (int wd = 0; wd < a.words; wd++) {
+      const unsigned long long bits = a.det_bits[((long long)b * a.rows + r) * a.words + wd];
+      const int bin = wd * 64 + lane;
+      const bool det = (bits >> lane) & 1ull;
+      if (a.det_mask && bin < a.cols) a.det_mask[((long long)b * a.rows + r) * a.cols + bin] = det ? 1 : 0;
+      if (det) {
+        const int idx = base + __popcll(bits & ((1ull << lane) - 1ull));
+        if (idx < a.cap_points) {
+          const double range = a.range_res * (double)bin;
+          float4 p;
+          p.x = (float)(range * cos_t);                                       // cfar.cpp:63-65
+          p.y = (float)(range * sin_t);
+          p.z = 0.f;
+          p.w = (float)img[(long long)r * a.stride + bin];
+          ((float4*)a.xyzi)[(long long)b * a.cap_points + idx] = p;
+        }
+      }
+      base += __popcll(bits);
+    }
+  }
+}
+
+// ---- host helpers --------------------------------------------------------------------------------
+int upload_trig(cfear_ctx* ctx, int rows, double** d_cos, double** d_sin) {
+  if (ctx->trig_rows == rows && ctx->ws[2].p) {      // tables are cached per context
+    *d_cos = (double*)ctx->ws[2].p;
+    *d_sin = (double*)ctx->ws[2].p + rows;
+    return CFEAR_OK;
+  }
+  std::vector<double> h(2 * (size_t)rows);
+  for (int bearing = 0; bearing < rows; bearing++) {
+    const double theta = (double(bearing + 1) / rows) * 2. * M_PI;           // radar_filters.cpp:317
+    h[bearing] = std::cos(theta);
+    h[rows + bearing] = std::sin(theta);
+  }
+  double* d = (double*)cfear_workspace(ctx, 2, h.size() * sizeof(double));
+  if (!d) return cfear_set_error(ctx, CFEAR_ERR_HIP, "workspace allocation failed");
+  CFEAR_HIP_CHECK(ctx, hipMemcpyAsync(d, h.data(), h.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+  CFEAR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));   // h goes out of scope
+  ctx->trig_rows = rows;
+  *d_cos = d;
+  *d_sin = d + rows;
+  return CFEAR_OK;
+}
+
+int check_desc(cfear_ctx* ctx, const cfear_polar_desc* d) {
+  if (!d || d->rows <= 0 || d->cols <= 0 || d->stride < d->cols || d->batch <= 0 ||
+      (d->batch > 1 && d->batch_stride < (int64_t)d->rows * d->stride))
+    return cfear_set_error(ctx, CFEAR_ERR_INVALID_ARGUMENT, "bad polar descriptor");
+  if (d->cols > kMaxCols)
+    return cfear_set_error(ctx, CFEAR_ERR_INVALID_ARGUMENT, "cols > %d unsupported", kMaxCols);
+  return CFEAR_OK;
+}
+
+template <int NCHUNK>
+void launch_kstrong(cfear_ctx* ctx, const KStrongArgs& a, bool vec, bool mask, dim3 grid, size_t lds) {
+  if (vec) {
+    if (mask) hipLaunchKernelGGL((kstrongest_rows_kernel<NCHUNK, true, true>), grid, dim3(256), lds, ctx->stream, a);
+    else hipLaunchKernelGGL((kstrongest_rows_kernel<NCHUNK, true, false>), grid, dim3(256), lds, ctx->stream, a);
+  } else {
+    if (mask) hipLaunchKernelGGL((kstrongest_rows_kernel<NCHUNK, false, true>), grid, dim3(256), lds, ctx->stream, a);
+    else hipLaunchKernelGGL((kstrongest_rows_kernel<NCHUNK, false, false>), grid, dim3(256), lds, ctx->stream, a);
+  }
+}
+
+}  // namespace
+
+// Device-side entry used by cfear_filter_kstrongest and by the odometry pipeline: everything is
+// already in device memory; outputs that are nullptr are skipped.
+int cfear_kstrong_device(cfear_ctx* ctx, const uint8_t* d_polar, const cfear_polar_desc* desc,
+                         const cfear_kstrong_params* par, const cfear_kstrong_out* o) {
+  const int z_min_i = (int)par->z_min;                         // radar_driver.cpp:58 float -> int
+  KStrongArgs a;
+  a.polar = d_polar;
+  a.rows = desc->rows; a.cols = desc->cols; a.stride = desc->stride; a.batch = desc->batch;
+  a.batch_stride = desc->batch > 1 ? desc->batch_stride : (int64_t)desc->rows * desc->stride;
+  a.k = par->k_strongest;
+  a.u_zmin = (int)(uint8_t)z_min_i;                            // radar_filters.cpp:212 uchar(z_min_)
+  a.want_peaks = par->want_peaks && (o->is_peak != nullptr);
+  a.sel_range = o->sel_range; a.sel_intensity = o->sel_intensity; a.sel_count = o->sel_count;
+  a.is_peak = o->is_peak;
+  const bool vec = (((uintptr_t)d_polar) % 4 == 0) && (a.stride % 4 == 0) && (a.batch_stride % 4 == 0);
+  const bool mask = (a.cols % 16 != 0) || a.u_zmin == 0;
+  const int nchunk = (a.cols + 1023) / 1024;
+  const long long nrows = (long long)a.batch * a.rows;
+  dim3 grid((unsigned)((nrows + kRowsPerBlock - 1) / kRowsPerBlock));
+  const int kpad = (a.k + 3) & ~3;
+  {
+    ProfScope ps(ctx, "kstrongest_rows");
+    if (nchunk <= 1) launch_kstrong<1>(ctx, a, vec, mask, grid, (size_t)kRowsPerBlock * (kpad * 4 + (a.want_peaks ? 1 * 1024 : 0)));
+    else if (nchunk <= 2) launch_kstrong<2>(ctx, a, vec, mask, grid, (size_t)kRowsPerBlock * (kpad * 4 + (a.want_peaks ? 2 * 1024 : 0)));
+    else if (nchunk <= 4) launch_kstrong<4>(ctx, a, vec, mask, grid, (size_t)kRowsPerBlock * (kpad * 4 + (a.want_peaks ? 4 * 1024 : 0)));
+    else launch_kstrong<8>(ctx, a, vec, mask, grid, (size_t)kRowsPerBlock * (kpad * 4 + (a.want_peaks ? 8 * 1024 : 0)));
+  }
+  CFEAR_HIP_CHECK(ctx, hipGetLastError());
+  if (o->xyzi || o->n_points || o->xyzi_peaks || o->n_peaks) {
+    double *d_cos = nullptr, *d_sin = nullptr;
+    int rc = upload_trig(ctx, a.rows, &d_cos, &d_sin);
+    if (rc != CFEAR_OK) return rc;
+    CloudArgs c;
+    c.sel_range = o->sel_range; c.sel_intensity = o->sel_intensity; c.sel_count = o->sel_count;
+    c.is_peak = o->is_peak;
+    c.cos_t = d_cos; c.sin_t = d_sin;
+    c.rows = a.rows; c.k = a.k;
+    const double range_res_ = (double)par->range_res, min_distance_ = (double)par->min_distance;
+    c.min_range_bin = (int)std::ceil(min_distance_ / range_res_);            // radar_filters.cpp:315
+    c.range_res = range_res_;
+    c.xyzi = o->xyzi; c.n_points = o->n_points;
+    const bool pk = a.want_peaks && (o->xyzi_peaks || o->n_peaks);
+    c.xyzi_peaks = pk ? o->xyzi_peaks : nullptr;
+    c.n_peaks = pk ? o->n_peaks : nullptr;
+    ProfScope ps(ctx, "kstrong_cloud");
+    hipLaunchKernelGGL(kstrong_cloud_kernel, dim3(a.batch, pk ? 2 : 1), dim3(256),
+                       (size_t)(a.rows + 1) * 4, ctx->stream, c);
+    CFEAR_HIP_CHECK(ctx, hipGetLastError());
+  }
+  return CFEAR_OK;
+}
+
+extern "C" int cfear_filter_kstrongest(cfear_ctx* ctx, const uint8_t* polar, const cfear_polar_desc* desc,
+                                       const cfear_kstrong_params* par, const cfear_kstrong_out* out) {
+  if (!ctx) return CFEAR_ERR_INVALID_ARGUMENT;
+  if (!polar || !par || !out) return cfear_set_error(ctx, CFEAR_ERR_INVALID_ARGUMENT, "null argument");
+  int rc = check_desc(ctx, desc);
+  if (rc != CFEAR_OK) return rc;
+  if (par->k_strongest < 1 || par->k_strongest > kMaxK)
+    return cfear_set_error(ctx, CFEAR_ERR_INVALID_ARGUMENT, "k_strongest must be in [1,%d]", kMaxK);
+  if (!(par->range_res > 0.f))
+    return cfear_set_error(ctx, CFEAR_ERR_INVALID_ARGUMENT, "range_res must be > 0");
+  CFEAR_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  const int rows = desc->rows, k = par->k_strongest, batch = desc->batch;
+  const size_t nsel = (size_t)batch * rows * k;
+  const bool dev = cfear_is_device_ptr(polar);
+  const bool want_cloud = out->xyzi || out->n_points;
+  const bool want_pk = par->want_peaks && (out->is_peak || out->xyzi_peaks || out->n_peaks);
+  // device buffers: caller's (device mode) or workspace
+  size_t off = 0;
+  auto carve = [&](size_t bytes) { size_t o = off; off += (bytes + 255) / 256 * 256; return o; };
+  const bool need_ws_sel = !dev || !out->sel_range || !out->sel_intensity || !out->sel_count || (want_pk && !out->is_peak);
+  size_t o_sr = 0, o_si = 0, o_sc = 0, o_pk = 0, o_xyz = 0, o_np = 0, o_xyzp = 0, o_npp = 0;
+  if (need_ws_sel || !dev) {
+    o_sr = carve(nsel * 4); o_si = carve(nsel); o_sc = carve((size_t)batch * rows * 4); o_pk = carve(nsel);
+  }
+  if (!dev) {
+    o_xyz = carve(nsel * 16); o_np = carve((size_t)batch * 4);
+    o_xyzp = carve(nsel * 16); o_npp = carve((size_t)batch * 4);
+  }
+  char* ws = off ? (char*)cfear_workspace(ctx, 1, off) : nullptr;
+  if (off && !ws) return cfear_set_error(ctx, CFEAR_ERR_HIP, "workspace allocation failed (%zu bytes)", off);
+  cfear_kstrong_out d;
+  d.sel_range = (dev && out->sel_range) ? out->sel_range : (int32_t*)(ws + o_sr);
+  d.sel_intensity = (dev && out->sel_intensity) ? out->sel_intensity : (uint8_t*)(ws + o_si);
+  d.sel_count = (dev && out->sel_count) ? out->sel_count : (int32_t*)(ws + o_sc);
+  d.is_peak = want_pk ? ((dev && out->is_peak) ? out->is_peak : (uint8_t*)(ws + o_pk)) : nullptr;
+  if (dev) {
+    d.xyzi = out->xyzi; d.n_points = out->n_points;
+    d.xyzi_peaks = want_pk ? out->xyzi_peaks : nullptr; d.n_peaks = want_pk ? out->n_peaks : nullptr;
+  } else {
+    d.xyzi = want_cloud ? (float*)(ws + o_xyz) : nullptr;
+    d.n_points = want_cloud ? (int32_t*)(ws + o_np) : nullptr;
+    const bool pc = want_pk && (out->xyzi_peaks || out->n_peaks);
+    d.xyzi_peaks = pc ? (float*)(ws + o_xyzp) : nullptr;
+    d.n_peaks = pc ? (int32_t*)(ws + o_npp) : nullptr;
+  }
+  const uint8_t* d_polar = polar;
+  cfear_polar_desc dd = *desc;
+  if (!dev) {
+    // stage the images densely: [batch][rows][stride]
+    const size_t img_bytes = (size_t)rows * desc->stride;
+    uint8_t* st = (uint8_t*)cfear_workspace(ctx, 0, img_bytes * batch);
+    if (!st) return cfear_set_error(ctx, CFEAR_ERR_HIP, "workspace allocation failed");
+    const int64_t bs = batch > 1 ? desc->batch_stride : (int64_t)img_bytes;
+    for (int b = 0; b < batch; b++)
+      CFEAR_HIP_CHECK(ctx, hipMemcpyAsync(st + (size_t)b * img_bytes, polar + (size_t)b * bs, img_bytes,
+                                          hipMemcpyHostToDevice, ctx->stream));
+    d_polar = st;
+    dd.batch_stride = (int64_t)img_bytes;
+  }
+  rc = cfear_kstrong_device(ctx, d_polar, &dd, par, &d);
+  if (rc != CFEAR_OK) return rc;
+  if (!dev) {
+    auto back = [&](void* dst, const void* src, size_t bytes) -> hipError_t {
+      return dst ? hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream) : hipSuccess;
+    };
+    CFEAR_HIP_CHECK(ctx, back(out->sel_range, d.sel_range, nsel * 4));
+    CFEAR_HIP_CHECK(ctx, back(out->sel_intensity, d.sel_intensity, nsel));
+    CFEAR_HIP_CHECK(ctx, back(out->sel_count, d.sel_count, (size_t)batch * rows * 4));
+    if (want_pk) CFEAR_HIP_CHECK(ctx, back(out->is_peak, d.is_peak, nsel));
+    if (d.xyzi) CFEAR_HIP_CHECK(ctx, back(out->xyzi, d.xyzi, nsel * 16));
+    if (d.n_points) CFEAR_HIP_CHECK(ctx, back(out->n_points, d.n_points, (size_t)batch * 4));
+    if (d.xyzi_peaks) CFEAR_HIP_CHECK(ctx, back(out->xyzi_peaks, d.xyzi_peaks, nsel * 16));
+    if (d.n_peaks) CFEAR_HIP_CHECK(ctx, back(out->n_peaks, d.n_peaks, (size_t)batch * 4));
+    CFEAR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  }
+  return CFEAR_OK;
+}
+
+// Device-side CA-CFAR entry (also used by the odometry pipeline).
+int cfear_cacfar_device(cfear_ctx* ctx, const uint8_t* d_polar, const cfear_polar_desc* desc,
+                        const cfear_cacfar_params* par, float* d_xyzi, int32_t* d_n_points,
+                        int32_t cap_points, uint8_t* d_det_mask) {
+  const int rows = desc->rows, cols = desc->cols, batch = desc->batch;
+  const int words = (cols + 63) / 64;
+  size_t bits_bytes = (size_t)batch * rows * words * 8, cnt_bytes = (size_t)batch * rows * 4;
+  char* ws = (char*)cfear_workspace(ctx, 3, bits_bytes + cnt_bytes + 256);
+  if (!ws) return cfear_set_error(ctx, CFEAR_ERR_HIP, "workspace allocation failed");
+  CfarArgs a;
+  a.polar = d_polar; a.rows = rows; a.cols = cols; a.stride = desc->stride; a.batch = batch;
+  a.batch_stride = batch > 1 ? desc->batch_stride : (int64_t)rows * desc->stride;
+  a.window = par->window_size; a.guard = par->nb_guard_cells;
+  const double false_alarm_rate_ = (double)par->false_alarm_rate;
+  const double N = par->window_size * 2;                                     // cfar.cpp:32
+  a.scaling = N * (std::pow(false_alarm_rate_, -1. / N) - 1.);               // cfar.cpp:12-16
+  a.range_res = (double)par->range_res;
+  a.static_threshold = (double)par->z_min;
+  a.min_distance = (double)par->min_distance;
+  a.max_distance = par->max_distance;
+  a.det_bits = (unsigned long long*)ws;
+  a.det_count = (int32_t*)(ws + (bits_bytes + 255) / 256 * 256);
+  a.words = words;
+  const long long nrows = (long long)batch * rows;
+  const int colsp = (cols + 64) & ~63;
+  {
+    ProfScope ps(ctx, "cacfar_rows");
+    hipLaunchKernelGGL(cacfar_rows_kernel, dim3((unsigned)((nrows + kRowsPerBlock - 1) / kRowsPerBlock)), dim3(256),
+                       (size_t)kRowsPerBlock * ((size_t)colsp * 4 + 256), ctx->stream, a);
+  }
+  CFEAR_HIP_CHECK(ctx, hipGetLastError());
+  double *d_cos = nullptr, *d_sin = nullptr;
+  int rc = upload_trig(ctx, rows, &d_cos, &d_sin);
+  if (rc != CFEAR_OK) return rc;
+  CfarCloudArgs c;
+  c.polar = d_polar; c.rows = rows; c.cols = cols; c.stride = desc->stride; c.batch_stride = a.batch_stride;
+  c.det_bits = a.det_bits; c.det_count = a.det_count; c.words = words;
+  c.cos_t = d_cos; c.sin_t = d_sin; c.range_res = a.range_res;
+  c.xyzi = d_xyzi; c.n_points = d_n_points; c.cap_points = cap_points; c.det_mask = d_det_mask;
+  {
+    ProfScope ps(ctx, "cacfar_cloud");
+    hipLaunchKernelGGL(cacfar_cloud_kernel, dim3(batch), dim3(256), (size_t)(rows + 1) * 4, ctx->stream, c);
+  }
+  CFEAR_HIP_CHECK(ctx, hipGetLastError());
+  return CFEAR_OK;
+}
+
+extern "C" int cfear_filter_cacfar(cfear_ctx* ctx, const uint8_t* polar, const cfear_polar_desc* desc,
+                                   const cfear_cacfar_params* par, float* xyzi, int32_t* n_points,
+                                   int32_t cap_points, uint8_t* det_mask) {
+  if (!ctx) return CFEAR_ERR_INVALID_ARGUMENT;
+  if (!polar || !par || !xyzi || !n_points || cap_points <= 0)
+    return cfear_set_error(ctx, CFEAR_ERR_INVALID_ARGUMENT, "null argument");
+  int rc = check_desc(ctx, desc);
+  if (rc != CFEAR_OK) return rc;
+  if (par->window_size < 1 || par->nb_guard_cells < 0 || !(par->range_res > 0.f))
+    return cfear_set_error(ctx, CFEAR_ERR_INVALID_ARGUMENT, "bad CFAR parameters");
+  CFEAR_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  const int rows = desc->rows, cols = desc->cols, batch = desc->batch;
+  const bool dev = cfear_is_device_ptr(polar);
+  if (dev) return cfear_cacfar_device(ctx, polar, desc, par, xyzi, n_points, cap_points, det_mask);
+  const size_t img_bytes = (size_t)rows * desc->stride;
+  const size_t xyz_bytes = (size_t)batch * cap_points * 16, mask_bytes = det_mask ? (size_t)batch * rows * cols : 0;
+  char* st = (char*)cfear_workspace(ctx, 0, img_bytes * batch);
+  char* ws = (char*)cfear_workspace(ctx, 1, xyz_bytes + mask_bytes + 1024);
+  if (!st || !ws) return cfear_set_error(ctx, CFEAR_ERR_HIP, "workspace allocation failed");
+  const int64_t bs = batch > 1 ? desc->batch_stride : (int64_t)img_bytes;
+  for (int b = 0; b < batch; b++)
+    CFEAR_HIP_CHECK(ctx, hipMemcpyAsync(st + (size_t)b * img_bytes, polar + (size_t)b * bs, img_bytes,
+                                        hipMemcpyHostToDevice, ctx->stream));
+  cfear_polar_desc dd = *desc;
+  dd.batch_stride = (int64_t)img_bytes;
+  float* d_xyzi = (float*)ws;
+  int32_t* d_np = (int32_t*)(ws + (xyz_bytes + 255) / 256 * 256);
+  uint8_t* d_mask = det_mask ? (uint8_t*)(ws + (xyz_bytes + 255) / 256 * 256 + 256) : nullptr;
+  rc = cfear_cacfar_device(ctx, (const uint8_t*)st, &dd, par, d_xyzi, d_np, cap_points, d_mask);
+  if (rc != CFEAR_OK) return rc;
+  CFEAR_HIP_CHECK(ctx, hipMemcpyAsync(n_points, d_np, (size_t)batch * 4, hipMemcpyDeviceToHost, ctx->stream));
+  CFEAR_HIP_CHECK(ctx, hipMemcpyAsync(xyzi, d_xyzi, xyz_bytes, hipMemcpyDeviceToHost, ctx->stream));
+  if (det_mask) CFEAR_HIP_CHECK(ctx, hipMemcpyAsync(det_mask, d_mask, mask_bytes, hipMemcpyDeviceToHost, ctx->stream));
+  CFEAR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  for (int b = 0; b < batch; b++)
+    if (n_points[b] > cap_points)
+      return cfear_set_error(ctx, CFEAR_ERR_CAPACITY, "image %d: %d detections > cap_points %d", b, n_points[b], cap_points);
+  return CFEAR_OK;
+}

@@ -1,0 +1,916 @@
+// register.hip -- stage M of the CFEAR hot path on gfx950: many-to-one scan matcher.
+//
+// Replaces (cfear_radarodometry/src/cfear_radarodometry/ unless noted):
+//   n_scan_normal_reg::Register                        n_scan_normal.cpp:82-185
+//   n_scan_normal_reg::BuildOptimizationProblem        n_scan_normal.cpp:342-389
+//   n_scan_normal_reg::AddScanPairCost                 n_scan_normal.cpp:213-324
+//   MapPointNormal::GetClosestIdx (FLANN 1-NN)         pointnormal.cpp:238-254
+//   P2L/P2P/P2DEfficientCost (+ AutoDiff Jacobians)    include/.../n_scan_normal.h:180-361
+//   Registration::Weights::GetWeight, GetLoss          registration.cpp:67-96
+//   ceres::Solve (TRUST_REGION + LEVENBERG_MARQUARDT)  call site n_scan_normal.cpp:448
+//   n_scan_normal_reg::GetCost                         n_scan_normal.cpp:186-211
+//
+// Kernel design: ONE persistent 256-thread workgroup per registration, one launch for a whole
+// batch of registrations; nothing returns to the host between the first association and the
+// final pose.  Per outer iteration the float means of each fixed keyframe are staged in LDS and
+// every source cell finds its exact nearest neighbour by brute force (same float arithmetic as
+// FLANN's L2_Simple, lowest index on ties).  Each LM iteration evaluates all correspondences at
+// the candidate pose, reduces {cost, J^T r, J^T J} (10 doubles) with DPP row reductions + a
+// 4-entry LDS cross-wave sum in a fixed order, and every thread then runs the Ceres-2.1-equivalent
+// trust-region bookkeeping redundantly in registers (wave-uniform control flow, no broadcast).
+#include <cfloat>
+#include <cmath>
+
+#include "common.hpp"
+
+namespace {
+
+constexpr int kRegThreads = 256;
+constexpr int kMaxScans = 16;
+constexpr int kMaxTargetsLds = 8192;         // float2 targets staged in LDS (64 KiB)
+
+struct RegJob {
+  int32_t n_scans;
+  int32_t pad;
+  ScanView scans[kMaxScans];
+  double poses[kMaxScans][3];
+};
+
+struct RegCommon {
+  cfear_reg_params par;
+  double angle_outlier;                       // std::cos(M_PI/6.0), computed on the host
+  char* scratch;                              // per job: 6 doubles per slot
+  size_t scratch_stride;
+  int32_t slots_cap;
+  int32_t lds_targets;                        // capacity of the staged target array
+  cfear_reg_result* results;
+};
+
+struct Aff2 { double l0, l1, l2, l3, t0, t1; };
+
+// registration.cpp:128-135 vectorToAffine3d + n_scan_normal.cpp:350-351
+__device__ __forceinline__ Aff2 aff_from_xyt(const double* p) {
+  double s, c;
+  sincos(p[2], &s, &c);
+  return Aff2{c, -s, s, c, p[0], p[1]};
+}
+__device__ __forceinline__ Aff2 aff_mul(const Aff2& a, const Aff2& b) {
+  Aff2 r;
+  r.l0 = a.l0 * b.l0 + a.l1 * b.l2;
+  r.l1 = a.l0 * b.l1 + a.l1 * b.l3;
+  r.l2 = a.l2 * b.l0 + a.l3 * b.l2;
+  r.l3 = a.l2 * b.l1 + a.l3 * b.l3;
+  r.t0 = a.l0 * b.t0 + a.l1 * b.t1 + a.t0;
+  r.t1 = a.l2 * b.t0 + a.l3 * b.t1 + a.t1;
+  return r;
+}
+__device__ __forceinline__ Aff2 aff_inv(const Aff2& a) {   // Eigen Affine inverse: adjugate / det
+  const double det = a.l0 * a.l3 - a.l2 * a.l1;
+  const double invdet = 1.0 / det;
+  Aff2 r;
+  r.l0 = a.l3 * invdet; r.l1 = -a.l1 * invdet; r.l2 = -a.l2 * invdet; r.l3 = a.l0 * invdet;
+  r.t0 = -(r.l0 * a.t0 + r.l1 * a.t1);
+  r.t1 = -(r.l2 * a.t0 + r.l3 * a.t1);
+  return r;
+}
+
+__device__ __forceinline__ double similarity(double x, double y) { return 2 * fmin(x, y) / (x + y); }
+// registration.cpp:67-75
+__device__ __forceinline__ double get_weight(int opt, double N1, double N2, double sim_dir, double plan1, double plan2) {
+  switch (opt) {
+    case 0: return 1.0;
+    case 1: return similarity(N1, N2);
+    case 2: return sim_dir;
+    case 3: return similarity(plan1, plan2);
+    case 4: return similarity(N1, N2) + sim_dir + similarity(plan1, plan2);
+  }
+  return 1.0;
+}
+
+// ceres loss functions wrapped by ScaledLoss(loss, w) (registration.cpp:77-96, n_scan_normal.cpp:275)
+__device__ __forceinline__ void loss_eval(int loss, double a, double w, double s, double& rho0, double& rho1) {
+  const double dmin = DBL_MIN;
+  switch (loss) {
+    case 1: {  // Huber
+      const double b = a * a;
+      if (s > b) { const double r = sqrt(s); rho0 = 2.0 * a * r - b; rho1 = fmax(dmin, a / r); }
+      else { rho0 = s; rho1 = 1.0; }
+      break;
+    }
+    case 2: {  // Cauchy
+      const double b = a * a, c = 1.0 / b;
+      const double sum = 1.0 + s * c, inv = 1.0 / sum;
+      rho0 = b * log(sum); rho1 = fmax(dmin, inv);
+      break;
+    }
+    case 3: {  // SoftLOne
+      const double b = a * a, c = 1.0 / b;
+      const double sum = 1.0 + s * c, tmp = sqrt(sum);
+      rho0 = 2.0 * b * (tmp - 1.0); rho1 = fmax(dmin, 1.0 / tmp);
+      break;
+    }
+    case 4: {  // ComposedLoss(Huber(1), Cauchy(1)) = f(g(s))
+      const double sum = 1.0 + s, inv = 1.0 / sum;
+      const double g0 = log(sum), g1 = fmax(dmin, inv);
+      double f0, f1;
+      if (g0 > 1.0) { const double r = sqrt(g0); f0 = 2.0 * r - 1.0; f1 = fmax(dmin, 1.0 / r); }
+      else { f0 = g0; f1 = 1.0; }
+      rho0 = f0; rho1 = f1 * g1;
+      break;
+    }
+    case 5: {  // Tukey
+      const double a2 = a * a;
+      if (s <= a2) { const double value = 1.0 - s / a2, vs = value * value; rho0 = a2 / 3.0 * (1.0 - vs * value); rho1 = vs; }
+      else { rho0 = a2 / 3.0; rho1 = 0.0; }
+      break;
+    }
+    default: rho0 = s; rho1 = 1.0;
+  }
+  rho0 *= w; rho1 *= w;
+}
+
+struct Slots {          // per-job correspondence arrays (global scratch, SoA, index = slot)
+  double *tmx, *tmy, *a0, *a1, *a2, *w;
+  int32_t* tidx;        // matched target cell
+};
+__device__ __forceinline__ Slots slots_of(char* scratch, int cap) {
+  Slots s;
+  double* p = (double*)scratch;
+  s.tmx = p; s.tmy = p + cap; s.a0 = p + 2 * (size_t)cap; s.a1 = p + 3 * (size_t)cap;
+  s.a2 = p + 4 * (size_t)cap; s.w = p + 5 * (size_t)cap;
+  s.tidx = (int32_t*)(p + 6 * (size_t)cap);
+  return s;
+}
+
+// 10 accumulators: cost, g[3], H upper triangle (00,01,02,11,12,22)
+__device__ __forceinline__ void block_reduce10(double v[10], double* part /*[2][4][10]*/, int& phase) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  double* buf = part + phase * 40;
+#pragma unroll
+  for (int k = 0; k < 10; k++) {
+    const double t = wave_sum_f64(v[k]);
+    if (lane == 0) buf[wave * 10 + k] = t;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 10; k++) v[k] = ((buf[k] + buf[10 + k]) + buf[20 + k]) + buf[30 + k];
+  phase ^= 1;
+}
+__device__ __forceinline__ int block_sum_i32(int v, int* part /*[2][4]*/, int& phase) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  int* buf = part + phase * 4;
+  const int t = wave_sum_i32(v);
+  if (lane == 0) buf[wave] = t;
+  __syncthreads();
+  const int r = buf[0] + buf[1] + buf[2] + buf[3];
+  phase ^= 1;
+  return r;
+}
+
+// n_scan_normal.cpp:213-318 for every fixed keyframe i against the free source (last scan):
+// fills the slot arrays; returns this thread's number of accepted associations.
+__device__ int associate_all(const RegJob& job, const RegCommon& cm, const double* xsrc, int itr, const Slots& sl,
+                             float2* lds_tar) {
+  const int tid = threadIdx.x;
+  const int last = job.n_scans - 1;
+  const ScanView& src = job.scans[last];
+  const int n_src = *src.n_cells;
+  const double curr_radius = (itr == 1) ? 2 * cm.par.radius : cm.par.radius;    // :220
+  const double r2 = curr_radius * curr_radius;
+  const Aff2 Tsrc = aff_from_xyt(xsrc);
+  int accepted = 0;
+  for (int i = 0; i < last; i++) {
+    const ScanView& tar = job.scans[i];
+    const int n_tar = *tar.n_cells;
+    const Aff2 Ttar = aff_from_xyt(job.poses[i]);
+    const Aff2 Tst = aff_mul(aff_inv(Ttar), Tsrc);                              // :222
+    __syncthreads();                                     // previous keyframe's LDS readers are done
+    for (int j = tid; j < n_tar; j += kRegThreads) lds_tar[j] = tar.mean_f[j];
+    __syncthreads();
+    for (int s = tid; s < n_src; s += kRegThreads) {
+      const int slot = i * n_src + s;
+      const double2 u = src.mean[s];
+      const double px = Tst.l0 * u.x + Tst.l1 * u.y + Tst.t0;
+      const double py = Tst.l2 * u.x + Tst.l3 * u.y + Tst.t1;
+      const float qx = (float)px, qy = (float)py;                               // pointnormal.cpp:240-242
+      int best = -1;
+      float bestd = FLT_MAX;
+      for (int j = 0; j < n_tar; j++) {                   // exact 1-NN, FLANN L2_Simple float distance
+        const float2 t = lds_tar[j];
+        const float dx = __fsub_rn(qx, t.x), dy = __fsub_rn(qy, t.y);
+        const float d = __fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy));
+        if (d < bestd || best < 0) { best = j; bestd = d; }
+      }
+      double w = -1.0;
+      if (best >= 0 && (double)bestd < r2) {                                    // pointnormal.cpp:250
+        const double2 ns = src.normal[s];
+        const double2 nt = tar.normal[best];
+        const double nsx = Tst.l0 * ns.x + Tst.l1 * ns.y, nsy = Tst.l2 * ns.x + Tst.l3 * ns.y;
+        const double direction_similarity = fmax(nsx * nt.x + nsy * nt.y, 0.0);   // :244
+        if (direction_similarity > cm.angle_outlier) {                            // :245
+          w = get_weight(cm.par.weight_opt, (double)src.nsamples[s], (double)tar.nsamples[best],
+                         direction_similarity, src.scale[s], tar.scale[best]);   // :247-253, :273
+          const double2 tm = tar.mean[best];
+          sl.tmx[slot] = Ttar.l0 * tm.x + Ttar.l1 * tm.y + Ttar.t0;              // Ttar * tar_mean
+          sl.tmy[slot] = Ttar.l2 * tm.x + Ttar.l3 * tm.y + Ttar.t1;
+          if (cm.par.cost == CFEAR_P2D) {                                         // :288-297
+            const double4 S = tar.cov[best];
+            const double a00 = Ttar.l0 * S.x + Ttar.l1 * S.z, a01 = Ttar.l0 * S.y + Ttar.l1 * S.w;
+            const double a10 = Ttar.l2 * S.x + Ttar.l3 * S.z, a11 = Ttar.l2 * S.y + Ttar.l3 * S.w;
+            const double c00 = (cm.par.regularization + (a00 * Ttar.l0 + a01 * Ttar.l1)) * cm.par.cov_scale;
+            const double c01 = (0.0 + (a00 * Ttar.l2 + a01 * Ttar.l3)) * cm.par.cov_scale;
+            const double c10 = (0.0 + (a10 * Ttar.l0 + a11 * Ttar.l1)) * cm.par.cov_scale;
+            const double c11 = (cm.par.regularization + (a10 * Ttar.l2 + a11 * Ttar.l3)) * cm.par.cov_scale;
+            const double det = c00 * c11 - c10 * c01, invdet = 1.0 / det;
+            const double i00 = c11 * invdet, i10 = -c10 * invdet, i11 = c00 * invdet;
+            const double l00 = sqrt(i00), l10 = i10 / l00;
+            sl.a0[slot] = l00; sl.a1[slot] = l10; sl.a2[slot] = sqrt(i11 - l10 * l10);
+          } else {
+            sl.a0[slot] = Ttar.l0 * nt.x + Ttar.l1 * nt.y;                       // Ttar.linear() * tar_normal
+            sl.a1[slot] = Ttar.l2 * nt.x + Ttar.l3 * nt.y;
+          }
+          sl.tidx[slot] = best;
+          accepted++;
+        }
+      }
+      sl.w[slot] = w;
+    }
+  }
+  return accepted;
+}
+
+// Residual block of one slot at pose x (c = cos th, s = sin th): adds to acc[10].
+template <bool WITH_JAC>
+__device__ __forceinline__ void eval_slot(const cfear_reg_params& par, double smx, double smy, double tmx, double tmy,
+                                          double a0, double a1, double a2, double w, double tx, double ty, double c,
+                                          double s, double acc[10]) {
+  const double sx = (c * smx + (-s) * smy) + tx;        // n_scan_normal.h:194-197
+  const double sy = (s * smx + c * smy) + ty;
+  const double dx = -s * smx - c * smy, dy = c * smx - s * smy;   // d(R s)/dtheta
+  double r0, r1 = 0.0, j00, j01, j02, j10 = 0.0, j11 = 0.0, j12 = 0.0;
+  if (par.cost == CFEAR_P2L) {                          // n_scan_normal.h:180-213
+    const double v0 = sx - tmx, v1 = sy - tmy;
+    r0 = v0 * a0 + v1 * a1;
+    j00 = a0; j01 = a1; j02 = dx * a0 + dy * a1;
+  } else if (par.cost == CFEAR_P2P) {                   // n_scan_normal.h:330-361
+    r0 = tmx - sx; r1 = tmy - sy;
+    j00 = -1.0; j01 = 0.0; j02 = -dx; j10 = 0.0; j11 = -1.0; j12 = -dy;
+  } else {                                              // n_scan_normal.h:216-255, L = [a0 0; a1 a2]
+    const double v0 = sx - tmx, v1 = sy - tmy;
+    r0 = a0 * v0 + 0.0 * v1;
+    r1 = a1 * v0 + a2 * v1;
+    j00 = a0; j01 = 0.0; j02 = a0 * dx + 0.0 * dy;
+    j10 = a1; j11 = a2; j12 = a1 * dx + a2 * dy;
+  }
+  const double sq = (par.cost == CFEAR_P2L) ? r0 * r0 : (r0 * r0 + r1 * r1);
+  double rho0, rho1;
+  loss_eval(par.loss, par.loss_limit, w, sq, rho0, rho1);
+  acc[0] += 0.5 * rho0;
+  if (WITH_JAC) {
+    const double sr = sqrt(rho1);                       // Corrector, alpha = 0
+    r0 *= sr; j00 *= sr; j01 *= sr; j02 *= sr;
+    acc[1] += j00 * r0; acc[2] += j01 * r0; acc[3] += j02 * r0;
+    acc[4] += j00 * j00; acc[5] += j00 * j01; acc[6] += j00 * j02;
+    acc[7] += j01 * j01; acc[8] += j01 * j02; acc[9] += j02 * j02;
+    if (par.cost != CFEAR_P2L) {
+      r1 *= sr; j10 *= sr; j11 *= sr; j12 *= sr;
+      acc[1] += j10 * r1; acc[2] += j11 * r1; acc[3] += j12 * r1;
+      acc[4] += j10 * j10; acc[5] += j10 * j11; acc[6] += j10 * j12;
+      acc[7] += j11 * j11; acc[8] += j11 * j12; acc[9] += j12 * j12;
+    }
+  }
+}
+
+// cost, gradient and Gauss-Newton matrix of all correspondences at x (block-wide collective)
+__device__ void eval_all(const RegJob& job, const RegCommon& cm, const Slots& sl, int n_slots, int n_src,
+                         const double x[3], double out[10], double* part, int& phase) {
+  double s, c;
+  sincos(x[2], &s, &c);
+  const double2* smean = job.scans[job.n_scans - 1].mean;
+  double acc[10];
+#pragma unroll
+  for (int k = 0; k < 10; k++) acc[k] = 0.0;
+  for (int slot = threadIdx.x; slot < n_slots; slot += kRegThreads) {
+    const double w = sl.w[slot];
+    if (w < 0.0) continue;
+    const int si = slot % n_src;
+    const double2 sm = smean[si];
+    eval_slot<true>(cm.par, sm.x, sm.y, sl.tmx[slot], sl.tmy[slot], sl.a0[slot], sl.a1[slot],
+                    cm.par.cost == CFEAR_P2D ? sl.a2[slot] : 0.0, w, x[0], x[1], c, s, acc);
+  }
+  block_reduce10(acc, part, phase);
+#pragma unroll
+  for (int k = 0; k < 10; k++) out[k] = acc[k];
+}
+
+__device__ __forceinline__ bool chol3_solve(const double A[9], const double b[3], double y[3]) {
+  double L[9];
+#pragma unroll
+  for (int i = 0; i < 9; i++) L[i] = 0.0;
+#pragma unroll
+  for (int i = 0; i < 3; i++)
+#pragma unroll
+    for (int j = 0; j <= i; j++) {
+      double sum = A[i * 3 + j];
+#pragma unroll
+      for (int k = 0; k < j; k++) sum -= L[i * 3 + k] * L[j * 3 + k];
+      if (i == j) { if (!(sum > 0.0)) return false; L[i * 3 + i] = sqrt(sum); }
+      else L[i * 3 + j] = sum / L[j * 3 + j];
+    }
+  double z[3];
+#pragma unroll
+  for (int i = 0; i < 3; i++) { double sum = b[i];
+#pragma unroll
+    for (int k = 0; k < i; k++) sum -= L[i * 3 + k] * z[k]; z[i] = sum / L[i * 3 + i]; }
+#pragma unroll
+  for (int i = 2; i >= 0; i--) { double sum = z[i];
+#pragma unroll
+    for (int k = i + 1; k < 3; k++) sum -= L[k * 3 + i] * y[k]; y[i] = sum / L[i * 3 + i]; }
+  return isfinite(y[0]) && isfinite(y[1]) && isfinite(y[2]);
+}
+
+struct LmSummary {
+  double initial_cost, final_cost, last_relative_decrease;
+  int n_pushed;          // summary_.iterations.size()
+  bool usable;
+};
+
+// ceres::Solve as configured by the reference (Ceres 2.1 defaults, max_num_iterations = max_iter):
+// same bookkeeping as the oracle's lm_solve / SURVEY Appendix B.4.  Block-wide collective.
+__device__ void lm_solve(const RegJob& job, const RegCommon& cm, const Slots& sl, int n_slots, int n_src,
+                         double x[3], int max_iter, LmSummary& sum, double* part, int& phase) {
+  const double function_tolerance = 1e-6, gradient_tolerance = 1e-10, parameter_tolerance = 1e-8;
+  const double min_relative_decrease = 1e-3, min_lm_diagonal = 1e-6, max_lm_diagonal = 1e32;
+  const double max_radius = 1e16, min_radius = 1e-32;
+  double radius = 1e4, decrease_factor = 2.0;
+  bool reuse_diagonal = false;
+  double diagonal[3] = {0, 0, 0};
+  int num_consecutive_invalid_steps = 0;
+
+  double cur[10];                                        // cost, g, H at the accepted x
+  eval_all(job, cm, sl, n_slots, n_src, x, cur, part, phase);
+  double x_cost = cur[0];
+  double scale[3];
+  scale[0] = 1.0 / (1.0 + sqrt(cur[4]));                 // jacobi scaling from iteration 0
+  scale[1] = 1.0 / (1.0 + sqrt(cur[7]));
+  scale[2] = 1.0 / (1.0 + sqrt(cur[9]));
+  double gradient_max_norm = fmax(fabs(cur[1]), fmax(fabs(cur[2]), fabs(cur[3])));
+  double x_norm = sqrt(x[0] * x[0] + x[1] * x[1] + x[2] * x[2]);
+  sum.initial_cost = x_cost;
+  double min_iter_cost = x_cost;                         // SetSummaryFinalCost: min over pushed costs
+  double it_cost = x_cost, it_rel = 0.0;
+  bool it_success = true;
+  int iteration = 0;
+  sum.n_pushed = 0;
+  sum.usable = true;
+  for (;;) {
+    // FinalizeIterationAndCheckIfMinimizerCanContinue
+    sum.n_pushed++;
+    sum.last_relative_decrease = it_rel;
+    min_iter_cost = fmin(min_iter_cost, it_cost);
+    if (iteration >= max_iter) break;
+    if (it_success && gradient_max_norm <= gradient_tolerance) break;
+    if (radius <= min_radius) break;
+    iteration++;
+    it_cost = 0.0; it_rel = 0.0; it_success = false;
+    // scaled quantities: J_s = J diag(scale)
+    const double gs[3] = {cur[1] * scale[0], cur[2] * scale[1], cur[3] * scale[2]};
+    double Hs[9];
+    Hs[0] = cur[4] * scale[0] * scale[0]; Hs[1] = cur[5] * scale[0] * scale[1]; Hs[2] = cur[6] * scale[0] * scale[2];
+    Hs[3] = Hs[1]; Hs[4] = cur[7] * scale[1] * scale[1]; Hs[5] = cur[8] * scale[1] * scale[2];
+    Hs[6] = Hs[2]; Hs[7] = Hs[5]; Hs[8] = cur[9] * scale[2] * scale[2];
+    if (!reuse_diagonal) {
+      diagonal[0] = fmin(fmax(Hs[0], min_lm_diagonal), max_lm_diagonal);
+      diagonal[1] = fmin(fmax(Hs[4], min_lm_diagonal), max_lm_diagonal);
+      diagonal[2] = fmin(fmax(Hs[8], min_lm_diagonal), max_lm_diagonal);
+    }
+    double A[9];
+#pragma unroll
+    for (int k = 0; k < 9; k++) A[k] = Hs[k];
+#pragma unroll
+    for (int k = 0; k < 3; k++) { const double lm = sqrt(diagonal[k] / radius); A[k * 3 + k] += lm * lm; }
+    double y[3], step[3];
+    const bool solved = chol3_solve(A, gs, y);
+    reuse_diagonal = true;
+    bool step_is_valid = false;
+    double model_cost_change = 0.0;
+    if (solved) {
+      step[0] = -y[0]; step[1] = -y[1]; step[2] = -y[2];
+      // -(J step)^T (r + J step / 2) = -step^T g_s - 1/2 step^T H_s step
+      const double sg = step[0] * gs[0] + step[1] * gs[1] + step[2] * gs[2];
+      const double hs0 = Hs[0] * step[0] + Hs[1] * step[1] + Hs[2] * step[2];
+      const double hs1 = Hs[3] * step[0] + Hs[4] * step[1] + Hs[5] * step[2];
+      const double hs2 = Hs[6] * step[0] + Hs[7] * step[1] + Hs[8] * step[2];
+      model_cost_change = -sg - (step[0] * hs0 + step[1] * hs1 + step[2] * hs2) / 2.0;
+      step_is_valid = model_cost_change > 0.0;
+    }
+    if (!step_is_valid) {
+      if (++num_consecutive_invalid_steps >= 5) { sum.usable = false; break; }
+      radius = radius / decrease_factor; decrease_factor *= 2.0; reuse_diagonal = true;
+      it_cost = x_cost; it_success = false; it_rel = 0.0;
+      continue;
+    }
+    num_consecutive_invalid_steps = 0;
+    double cand[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) cand[k] = x[k] + step[k] * scale[k];
+    double cnd[10];                                      // cost (and, speculatively, g and H) at cand
+    eval_all(job, cm, sl, n_slots, n_src, cand, cnd, part, phase);
+    const double cand_cost = cnd[0];
+    const double step_norm = sqrt((x[0] - cand[0]) * (x[0] - cand[0]) + (x[1] - cand[1]) * (x[1] - cand[1]) +
+                                  (x[2] - cand[2]) * (x[2] - cand[2]));
+    if (step_norm <= parameter_tolerance * (x_norm + parameter_tolerance)) break;
+    const double cost_change = x_cost - cand_cost;
+    if (fabs(cost_change) <= function_tolerance * x_cost) break;
+    it_rel = cost_change / model_cost_change;
+    if (it_rel > min_relative_decrease) {
+      x[0] = cand[0]; x[1] = cand[1]; x[2] = cand[2];
+      x_norm = sqrt(x[0] * x[0] + x[1] * x[1] + x[2] * x[2]);
+#pragma unroll
+      for (int k = 0; k < 10; k++) cur[k] = cnd[k];
+      x_cost = cand_cost;
+      gradient_max_norm = fmax(fabs(cur[1]), fmax(fabs(cur[2]), fabs(cur[3])));
+      it_cost = x_cost; it_success = true;
+      const double q = 2.0 * it_rel - 1.0;
+      radius = radius / fmax(1.0 / 3.0, 1.0 - q * q * q);
+      radius = fmin(max_radius, radius);
+      decrease_factor = 2.0; reuse_diagonal = false;
+    } else {
+      it_cost = cand_cost; it_success = false;
+      radius = radius / decrease_factor; decrease_factor *= 2.0; reuse_diagonal = true;
+    }
+  }
+  sum.final_cost = fmin(sum.initial_cost, min_iter_cost);
+}
+
+__global__ __launch_bounds__(kRegThreads) void register_kernel(const RegJob* __restrict__ jobs, const RegCommon cm) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  double* part = (double*)smem;                          // [2][4][10]
+  int* ipart = (int*)(smem + 640);                       // [2][4]
+  float2* lds_tar = (float2*)(smem + 704);
+  const RegJob& job = jobs[blockIdx.x];
+  cfear_reg_result* res = cm.results + blockIdx.x;
+  const int last = job.n_scans - 1;
+  const int n_src = *job.scans[last].n_cells;
+  int max_tar = 0;
+  for (int i = 0; i < last; i++) max_tar = max(max_tar, *job.scans[i].n_cells);
+  const int n_slots = last * n_src;
+  double x[3] = {job.poses[last][0], job.poses[last][1], job.poses[last][2]};
+  if (n_slots > cm.slots_cap || max_tar > cm.lds_targets) {
+    if (threadIdx.x == 0) {
+      res->pose[0] = x[0]; res->pose[1] = x[1]; res->pose[2] = x[2];
+      res->score = 0; res->final_cost = 0; res->num_residuals = 0; res->outer_iters = 0; res->lm_iters = 0;
+      res->status = CFEAR_ERR_CAPACITY; res->last_relative_decrease = 0; res->reserved = 0;
+    }
+    return;
+  }
+  const Slots sl = slots_of(cm.scratch + (size_t)blockIdx.x * cm.scratch_stride, cm.slots_cap);
+  int phase = 0, iphase = 0;
+  const int rpb = cm.par.cost == CFEAR_P2L ? 1 : 2;
+  // n_scan_normal.cpp:82-185
+  double prev_par[3] = {x[0], x[1], x[2]};
+  double prev_score = DBL_MAX;
+  bool success = true;
+  int itr = 1, lm_iters = 0, num_residuals = 0, fail_status = CFEAR_OK;
+  LmSummary summary;
+  summary.final_cost = 0.0; summary.last_relative_decrease = 0.0; summary.n_pushed = 0; summary.usable = false;
+  for (itr = 1; itr <= cm.par.max_itr_association && success; itr++) {
+    const int mine = associate_all(job, cm, x, itr, sl, lds_tar);
+    __threadfence_block();
+    const int n_blocks = block_sum_i32(mine, ipart, iphase);     // barrier: slot arrays are complete
+    num_residuals = n_blocks * rpb;
+    success = num_residuals > 1;                                  // :368-369
+    if (!success) { fail_status = CFEAR_ERR_TOO_FEW_RESIDUALS; break; }
+    double xi[3] = {x[0], x[1], x[2]};
+    lm_solve(job, cm, sl, n_slots, n_src, xi, cm.par.max_itr_solver, summary, part, phase);
+    lm_iters += summary.n_pushed - 1;
+    success = summary.usable;
+    if (success) { x[0] = xi[0]; x[1] = xi[1]; x[2] = xi[2]; } else fail_status = CFEAR_ERR_SOLVER;
+    const double current_score = summary.final_cost;
+    const double rel_improvement = (prev_score - current_score) / prev_score;
+    if (itr > cm.par.min_itr) {                                   // :134-149
+      if (prev_score < current_score) {
+        x[0] = prev_par[0]; x[1] = prev_par[1]; x[2] = prev_par[2];
+        break;
+      } else if (rel_improvement < cm.par.score_tolerance) {
+        break;
+      } else if (summary.last_relative_decrease < cm.par.score_tolerance || summary.n_pushed == 1) {
+        break;
+      }
+    }
+    prev_score = current_score;
+    prev_par[0] = x[0]; prev_par[1] = x[1]; prev_par[2] = x[2];
+  }
+  if (threadIdx.x == 0) {
+    res->pose[0] = x[0]; res->pose[1] = x[1]; res->pose[2] = x[2];
+    res->final_cost = summary.final_cost;
+    res->num_residuals = num_residuals;
+    res->outer_iters = itr;
+    res->lm_iters = lm_iters;
+    res->last_relative_decrease = summary.last_relative_decrease;
+    res->reserved = 0;
+    if (success) { res->score = summary.final_cost / (double)num_residuals; res->status = CFEAR_OK; }   // :162
+    else { res->score = 0.0; res->status = fail_status; }
+  }
+}
+
+// association only (GetCost / cfear_cost_prepare): slot arrays stay in the caller's scratch
+__global__ __launch_bounds__(kRegThreads) void assoc_kernel(const RegJob* __restrict__ jobs, const RegCommon cm, int itr,
+                                                            int32_t* n_blocks_out) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  int* ipart = (int*)(smem + 640);
+  float2* lds_tar = (float2*)(smem + 704);
+  const RegJob& job = jobs[blockIdx.x];
+  const int last = job.n_scans - 1;
+  const int n_src = *job.scans[last].n_cells;
+  int max_tar = 0;
+  for (int i = 0; i < last; i++) max_tar = max(max_tar, *job.scans[i].n_cells);
+  if (last * n_src > cm.slots_cap || max_tar > cm.lds_targets) {
+    if (threadIdx.x == 0) n_blocks_out[blockIdx.x] = -1;
+    return;
+  }
+  const Slots sl = slots_of(cm.scratch + (size_t)blockIdx.x * cm.scratch_stride, cm.slots_cap);
+  int iphase = 0;
+  const int mine = associate_all(job, cm, job.poses[last], itr, sl, lds_tar);
+  const int n_blocks = block_sum_i32(mine, ipart, iphase);
+  if (threadIdx.x == 0) n_blocks_out[blockIdx.x] = n_blocks;
+}
+
+// per-slot evaluation at x for one job: raw residuals/Jacobians (Ceres CostFunction::Evaluate
+// semantics), robustified residuals, and the reduced normal equations.
+struct EvalOut {
+  double* raw_r;       // [slots][2]
+  double* raw_j;       // [slots][6]
+  double* rob_r;       // [slots][2]
+  double* neq;         // [10]: cost, g, H upper
+};
+__global__ __launch_bounds__(kRegThreads) void eval_kernel(const RegJob* __restrict__ jobs, const RegCommon cm, double x0,
+                                                           double x1, double x2, EvalOut o) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  double* part = (double*)smem;
+  const RegJob& job = jobs[0];
+  const int last = job.n_scans - 1;
+  const int n_src = *job.scans[last].n_cells;
+  const int n_slots = last * n_src;
+  const Slots sl = slots_of(cm.scratch, cm.slots_cap);
+  double s, c;
+  sincos(x2, &s, &c);
+  const double2* smean = job.scans[last].mean;
+  double acc[10];
+#pragma unroll
+  for (int k = 0; k < 10; k++) acc[k] = 0.0;
+  for (int slot = threadIdx.x; slot < n_slots; slot += kRegThreads) {
+    const double w = sl.w[slot];
+    if (w < 0.0) continue;
+    const double2 sm = smean[slot % n_src];
+    const double tmx = sl.tmx[slot], tmy = sl.tmy[slot], a0 = sl.a0[slot], a1 = sl.a1[slot];
+    const double a2 = cm.par.cost == CFEAR_P2D ? sl.a2[slot] : 0.0;
+    eval_slot<true>(cm.par, sm.x, sm.y, tmx, tmy, a0, a1, a2, w, x0, x1, c, s, acc);
+    // raw values, recomputed exactly as eval_slot does
+    const double sx = (c * sm.x + (-s) * sm.y) + x0, sy = (s * sm.x + c * sm.y) + x1;
+    const double dx = -s * sm.x - c * sm.y, dy = c * sm.x - s * sm.y;
+    double r0, r1 = 0.0, j[6] = {0, 0, 0, 0, 0, 0};
+    if (cm.par.cost == CFEAR_P2L) {
+      const double v0 = sx - tmx, v1 = sy - tmy;
+      r0 = v0 * a0 + v1 * a1; j[0] = a0; j[1] = a1; j[2] = dx * a0 + dy * a1;
+    } else if (cm.par.cost == CFEAR_P2P) {
+      r0 = tmx - sx; r1 = tmy - sy; j[0] = -1.0; j[2] = -dx; j[4] = -1.0; j[5] = -dy;
+    } else {
+      const double v0 = sx - tmx, v1 = sy - tmy;
+      r0 = a0 * v0 + 0.0 * v1; r1 = a1 * v0 + a2 * v1;
+      j[0] = a0; j[2] = a0 * dx + 0.0 * dy; j[3] = a1; j[4] = a2; j[5] = a1 * dx + a2 * dy;
+    }
+    const double sq = (cm.par.cost == CFEAR_P2L) ? r0 * r0 : (r0 * r0 + r1 * r1);
+    double rho0, rho1;
+    loss_eval(cm.par.loss, cm.par.loss_limit, w, sq, rho0, rho1);
+    const double sr = sqrt(rho1);
+    if (o.raw_r) { o.raw_r[slot * 2] = r0; o.raw_r[slot * 2 + 1] = r1; }
+    if (o.raw_j) for (int k = 0; k < 6; k++) o.raw_j[slot * 6 + k] = j[k];
+    if (o.rob_r) { o.rob_r[slot * 2] = r0 * sr; o.rob_r[slot * 2 + 1] = r1 * sr; }
+  }
+  int phase = 0;
+  block_reduce10(acc, part, phase);
+  if (threadIdx.x == 0 && o.neq) for (int k = 0; k < 10; k++) o.neq[k] = acc[k];
+}
+
+size_t reg_lds_bytes(int lds_targets) { return 704 + (size_t)lds_targets * 8; }
+size_t reg_scratch_bytes(int slots_cap) { return ((size_t)slots_cap * 52 + 255) / 256 * 256; }
+
+int check_params(cfear_ctx* ctx, const cfear_reg_params* p) {
+  if (!p) return cfear_set_error(ctx, CFEAR_ERR_INVALID_ARGUMENT, "null parameters");
+  if (p->cost < 0 || p->cost > 2 || p->loss < 0 || p->loss > 5 || p->weight_opt < 0 || p->weight_opt > 4)
+    return cfear_set_error(ctx, CFEAR_ERR_INVALID_ARGUMENT, "bad cost/loss/weight option");
+  if (p->max_itr_association < 1 || p->max_itr_solver < 0 || !(p->radius > 0))
+    return cfear_set_error(ctx, CFEAR_ERR_INVALID_ARGUMENT, "bad iteration limits / radius");
+  return CFEAR_OK;
+}
+
+}  // namespace
+
+size_t cfear_reg_job_bytes() { return sizeof(RegJob); }
+int cfear_reg_max_scans() { return kMaxScans; }
+
+void cfear_reg_fill_job(void* dst, const ScanView* views, int n_scans, const double* poses_xyt) {
+  RegJob j;
+  memset(&j, 0, sizeof(j));
+  j.n_scans = n_scans;
+  for (int i = 0; i < n_scans; i++) {
+    j.scans[i] = views[i];
+    j.poses[i][0] = poses_xyt[3 * i]; j.poses[i][1] = poses_xyt[3 * i + 1]; j.poses[i][2] = poses_xyt[3 * i + 2];
+  }
+  memcpy(dst, &j, sizeof(j));
+}
+
+// Enqueues the batched registration kernel: d_jobs [n_jobs] RegJob records (device), d_results
+// [n_jobs] (device).  slots_cap bounds (n_scans-1)*n_src per job, lds_targets the largest target.
+int cfear_register_launch(cfear_ctx* ctx, const void* d_jobs, int n_jobs, const cfear_reg_params* par, int slots_cap,
+                          int lds_targets, char* d_scratch, cfear_reg_result* d_results) {
+  if (lds_targets > kMaxTargetsLds)
+    return cfear_set_error(ctx, CFEAR_ERR_CAPACITY, "target scan with more than %d cells", kMaxTargetsLds);
+  if (lds_targets < 1) lds_targets = 1;
+  RegCommon cm;
+  cm.par = *par;
+  cm.angle_outlier = std::cos(M_PI / 6.0);                                     // n_scan_normal.cpp:217
+  cm.scratch = d_scratch;
+  cm.scratch_stride = reg_scratch_bytes(slots_cap);
+  cm.slots_cap = slots_cap;
+  cm.lds_targets = lds_targets;
+  cm.results = d_results;
+  static bool attr_set = false;
+  if (!attr_set) {
+    CFEAR_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)register_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                             (int)reg_lds_bytes(kMaxTargetsLds)));
+    CFEAR_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)assoc_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                             (int)reg_lds_bytes(kMaxTargetsLds)));
+    attr_set = true;
+  }
+  ProfScope ps(ctx, "register");
+  hipLaunchKernelGGL(register_kernel, dim3(n_jobs), dim3(kRegThreads), reg_lds_bytes(lds_targets), ctx->stream,
+                     (const RegJob*)d_jobs, cm);
+  CFEAR_HIP_CHECK(ctx, hipGetLastError());
+  return CFEAR_OK;
+}
+size_t cfear_register_scratch_bytes(int slots_cap) { return reg_scratch_bytes(slots_cap); }
+
+// ---- host-facing wrappers ----------------------------------------------------------------------
+namespace {
+
+struct JobSizes { int slots_cap = 1; int lds_targets = 1; };
+
+int gather_job(cfear_ctx* ctx, const cfear_scan* const* scans, int n_scans, const double* poses, unsigned char* dst,
+               JobSizes& sz) {
+  if (n_scans < 2 || n_scans > kMaxScans)
+    return cfear_set_error(ctx, CFEAR_ERR_INVALID_ARGUMENT, "n_scans must be in [2,%d]", kMaxScans);
+  ScanView views[kMaxScans];
+  for (int i = 0; i < n_scans; i++) {
+    if (!scans[i]) return cfear_set_error(ctx, CFEAR_ERR_INVALID_ARGUMENT, "null scan handle");
+    if (scans[i]->ctx != ctx) return cfear_set_error(ctx, CFEAR_ERR_INVALID_ARGUMENT, "scan belongs to another context");
+    views[i] = scans[i]->view;
+    const int nc = cfear_scan_size(scans[i]);
+    if (nc < 0) return nc;
+    if (i < n_scans - 1) sz.lds_targets = std::max(sz.lds_targets, nc);
+    else sz.slots_cap = std::max(sz.slots_cap, (n_scans - 1) * std::max(nc, 1));
+  }
+  cfear_reg_fill_job(dst, views, n_scans, poses);
+  return CFEAR_OK;
+}
+
+}  // namespace
+
+extern "C" int cfear_register_batch(cfear_ctx* ctx, const cfear_reg_job* jobs, int32_t n_jobs,
+                                    const cfear_reg_params* par, cfear_reg_result* results) {
+  if (!ctx) return CFEAR_ERR_INVALID_ARGUMENT;
+  if (!jobs || !results || n_jobs < 0) return cfear_set_error(ctx, CFEAR_ERR_INVALID_ARGUMENT, "null argument");
+  int rc = check_params(ctx, par);
+  if (rc != CFEAR_OK) return rc;
+  if (n_jobs == 0) return CFEAR_OK;
+  CFEAR_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  std::vector<unsigned char> hjobs((size_t)n_jobs * sizeof(RegJob));
+  JobSizes sz;
+  for (int j = 0; j < n_jobs; j++) {
+    rc = gather_job(ctx, jobs[j].scans, jobs[j].n_scans, jobs[j].poses_xyt, hjobs.data() + (size_t)j * sizeof(RegJob), sz);
+    if (rc != CFEAR_OK) return rc;
+  }
+  const size_t jb = hjobs.size(), rb = (size_t)n_jobs * sizeof(cfear_reg_result);
+  const size_t sb = reg_scratch_bytes(sz.slots_cap) * (size_t)n_jobs;
+  char* ws = (char*)cfear_workspace(ctx, 6, jb + rb + 512);
+  char* scr = (char*)cfear_workspace(ctx, 7, sb);
+  if (!ws || !scr) return cfear_set_error(ctx, CFEAR_ERR_HIP, "workspace allocation failed");
+  char* d_jobs = ws;
+  cfear_reg_result* d_res = (cfear_reg_result*)(ws + (jb + 255) / 256 * 256);
+  CFEAR_HIP_CHECK(ctx, hipMemcpyAsync(d_jobs, hjobs.data(), jb, hipMemcpyHostToDevice, ctx->stream));
+  rc = cfear_register_launch(ctx, d_jobs, n_jobs, par, sz.slots_cap, sz.lds_targets, scr, d_res);
+  if (rc != CFEAR_OK) { (void)hipStreamSynchronize(ctx->stream); return rc; }
+  CFEAR_HIP_CHECK(ctx, hipMemcpyAsync(results, d_res, rb, hipMemcpyDeviceToHost, ctx->stream));
+  CFEAR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  return CFEAR_OK;
+}
+
+extern "C" int cfear_register(cfear_ctx* ctx, const cfear_scan* const* scans, int32_t n_scans, double* poses_xyt,
+                              const cfear_reg_params* par, cfear_reg_result* result) {
+  if (!ctx) return CFEAR_ERR_INVALID_ARGUMENT;
+  if (!scans || !poses_xyt || !result) return cfear_set_error(ctx, CFEAR_ERR_INVALID_ARGUMENT, "null argument");
+  cfear_reg_job job;
+  job.scans = scans; job.n_scans = n_scans; job.pad = 0; job.poses_xyt = poses_xyt;
+  int rc = cfear_register_batch(ctx, &job, 1, par, result);
+  if (rc != CFEAR_OK) return rc;
+  // Tsrc.back() = vectorToAffine3d(parameters.back()) whenever a solve was usable (n_scan_normal.cpp:117-119)
+  poses_xyt[3 * (n_scans - 1)] = result->pose[0];
+  poses_xyt[3 * (n_scans - 1) + 1] = result->pose[1];
+  poses_xyt[3 * (n_scans - 1) + 2] = result->pose[2];
+  return result->status;
+}
+
+// ---- cfear_cost: one association set kept on the device -------------------------------------------
+struct cfear_cost {
+  cfear_ctx* ctx;
+  cfear_reg_params par;
+  void* d_job = nullptr;       // RegJob
+  char* d_scratch = nullptr;   // slots
+  double* d_out = nullptr;     // raw_r | raw_j | rob_r | neq
+  int slots_cap = 0, lds_targets = 0, n_src = 0, n_slots = 0, n_blocks = 0, n_scans = 0;
+  std::vector<double> h_w;     // slot weights (host copy), < 0 = no association
+  std::vector<int32_t> h_tidx; // matched target cell per slot
+};
+
+extern "C" int cfear_cost_prepare(cfear_ctx* ctx, const cfear_scan* const* scans, int32_t n_scans,
+                                  const double* poses_xyt, const cfear_reg_params* par, int32_t itr, cfear_cost** out) {
+  if (!ctx) return CFEAR_ERR_INVALID_ARGUMENT;
+  if (!scans || !poses_xyt || !out) return cfear_set_error(ctx, CFEAR_ERR_INVALID_ARGUMENT, "null argument");
+  *out = nullptr;
+  int rc = check_params(ctx, par);
+  if (rc != CFEAR_OK) return rc;
+  CFEAR_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  unsigned char hjob[sizeof(RegJob)];
+  JobSizes sz;
+  rc = gather_job(ctx, scans, n_scans, poses_xyt, hjob, sz);
+  if (rc != CFEAR_OK) return rc;
+  if (sz.lds_targets > kMaxTargetsLds) return cfear_set_error(ctx, CFEAR_ERR_CAPACITY, "target scan too large");
+  cfear_cost* c = new cfear_cost();
+  c->ctx = ctx; c->par = *par; c->slots_cap = sz.slots_cap; c->lds_targets = sz.lds_targets; c->n_scans = n_scans;
+  c->n_src = cfear_scan_size(scans[n_scans - 1]);
+  c->n_slots = (n_scans - 1) * c->n_src;
+  auto fail = [&](int status, const char* msg) { cfear_cost_destroy(c); return cfear_set_error(ctx, status, "%s", msg); };
+  if (hipMalloc(&c->d_job, sizeof(RegJob) + 256) != hipSuccess) return fail(CFEAR_ERR_HIP, "hipMalloc failed");
+  if (hipMalloc((void**)&c->d_scratch, reg_scratch_bytes(c->slots_cap)) != hipSuccess) return fail(CFEAR_ERR_HIP, "hipMalloc failed");
+  if (hipMalloc((void**)&c->d_out, ((size_t)c->slots_cap * 10 + 16) * sizeof(double)) != hipSuccess) return fail(CFEAR_ERR_HIP, "hipMalloc failed");
+  if (hipMemcpyAsync(c->d_job, hjob, sizeof(RegJob), hipMemcpyHostToDevice, ctx->stream) != hipSuccess) return fail(CFEAR_ERR_HIP, "memcpy failed");
+  RegCommon cm;
+  cm.par = *par; cm.angle_outlier = std::cos(M_PI / 6.0);
+  cm.scratch = c->d_scratch; cm.scratch_stride = reg_scratch_bytes(c->slots_cap);
+  cm.slots_cap = c->slots_cap; cm.lds_targets = c->lds_targets; cm.results = nullptr;
+  int32_t* d_nb = (int32_t*)((char*)c->d_job + sizeof(RegJob));
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)assoc_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)reg_lds_bytes(kMaxTargetsLds));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(assoc_kernel, dim3(1), dim3(kRegThreads), reg_lds_bytes(c->lds_targets), ctx->stream,
+                     (const RegJob*)c->d_job, cm, (int)itr, d_nb);
+  if (hipGetLastError() != hipSuccess) return fail(CFEAR_ERR_HIP, "assoc_kernel launch failed");
+  c->h_w.assign(std::max(c->n_slots, 1), -1.0);
+  c->h_tidx.assign(std::max(c->n_slots, 1), -1);
+  int32_t nb = 0;
+  bool ok = hipMemcpyAsync(&nb, d_nb, 4, hipMemcpyDeviceToHost, ctx->stream) == hipSuccess;
+  if (c->n_slots > 0) {
+    ok = ok && hipMemcpyAsync(c->h_w.data(), (double*)c->d_scratch + 5 * (size_t)c->slots_cap, (size_t)c->n_slots * 8,
+                              hipMemcpyDeviceToHost, ctx->stream) == hipSuccess;
+    ok = ok && hipMemcpyAsync(c->h_tidx.data(), (double*)c->d_scratch + 6 * (size_t)c->slots_cap, (size_t)c->n_slots * 4,
+                              hipMemcpyDeviceToHost, ctx->stream) == hipSuccess;
+  }
+  ok = ok && hipStreamSynchronize(ctx->stream) == hipSuccess;
+  if (!ok) return fail(CFEAR_ERR_HIP, "read-back failed");
+  if (nb < 0) return fail(CFEAR_ERR_CAPACITY, "association capacity exceeded");
+  c->n_blocks = nb;
+  *out = c;
+  return CFEAR_OK;
+}
+
+extern "C" int cfear_cost_num_blocks(const cfear_cost* c) { return c ? c->n_blocks : CFEAR_ERR_INVALID_ARGUMENT; }
+extern "C" int cfear_cost_num_residuals(const cfear_cost* c) {
+  return c ? c->n_blocks * (c->par.cost == CFEAR_P2L ? 1 : 2) : CFEAR_ERR_INVALID_ARGUMENT;
+}
+
+namespace {
+// blocks are ordered (target scan i, source cell s) exactly like AddScanPairCost builds them
+int run_eval(cfear_cost* c, const double x[3], bool want_raw) {
+  cfear_ctx* ctx = c->ctx;
+  RegCommon cm;
+  cm.par = c->par; cm.angle_outlier = 0; cm.scratch = c->d_scratch; cm.scratch_stride = 0;
+  cm.slots_cap = c->slots_cap; cm.lds_targets = c->lds_targets; cm.results = nullptr;
+  EvalOut o;
+  const size_t sc = (size_t)c->slots_cap;
+  o.raw_r = want_raw ? c->d_out : nullptr;
+  o.raw_j = want_raw ? c->d_out + 2 * sc : nullptr;
+  o.rob_r = c->d_out + 8 * sc;
+  o.neq = c->d_out + 10 * sc;
+  hipLaunchKernelGGL(eval_kernel, dim3(1), dim3(kRegThreads), 704, ctx->stream, (const RegJob*)c->d_job, cm, x[0], x[1],
+                     x[2], o);
+  CFEAR_HIP_CHECK(ctx, hipGetLastError());
+  return CFEAR_OK;
+}
+}  // namespace
+
+extern "C" int cfear_cost_get_blocks(const cfear_cost* c, int32_t* pairs, double* weights) {
+  if (!c) return CFEAR_ERR_INVALID_ARGUMENT;
+  int b = 0;
+  for (int slot = 0; slot < c->n_slots; slot++) {
+    if (c->h_w[slot] < 0.0) continue;
+    if (pairs) { pairs[3 * b] = slot / c->n_src; pairs[3 * b + 1] = c->h_tidx[slot]; pairs[3 * b + 2] = slot % c->n_src; }
+    if (weights) weights[b] = c->h_w[slot];
+    b++;
+  }
+  return b;
+}
+
+extern "C" int cfear_cost_evaluate(cfear_cost* c, const double x[3], double* residuals, double* jacobian) {
+  if (!c || !x) return CFEAR_ERR_INVALID_ARGUMENT;
+  cfear_ctx* ctx = c->ctx;
+  CFEAR_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  int rc = run_eval(c, x, true);
+  if (rc != CFEAR_OK) return rc;
+  const size_t sc = (size_t)c->slots_cap;
+  std::vector<double> r(2 * (size_t)std::max(c->n_slots, 1)), j(6 * (size_t)std::max(c->n_slots, 1));
+  if (c->n_slots > 0) {
+    CFEAR_HIP_CHECK(ctx, hipMemcpyAsync(r.data(), c->d_out, (size_t)c->n_slots * 16, hipMemcpyDeviceToHost, ctx->stream));
+    CFEAR_HIP_CHECK(ctx, hipMemcpyAsync(j.data(), c->d_out + 2 * sc, (size_t)c->n_slots * 48, hipMemcpyDeviceToHost, ctx->stream));
+  }
+  CFEAR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  const int rpb = c->par.cost == CFEAR_P2L ? 1 : 2;
+  int b = 0;
+  for (int slot = 0; slot < c->n_slots; slot++) {
+    if (c->h_w[slot] < 0.0) continue;
+    for (int i = 0; i < rpb; i++) {
+      if (residuals) residuals[b * rpb + i] = r[slot * 2 + i];
+      if (jacobian) for (int k = 0; k < 3; k++) jacobian[(b * rpb + i) * 3 + k] = j[slot * 6 + i * 3 + k];
+    }
+    b++;
+  }
+  return CFEAR_OK;
+}
+
+extern "C" int cfear_cost_normal_eq(cfear_cost* c, const double x[3], double H[9], double g[3], double* cost) {
+  if (!c || !x) return CFEAR_ERR_INVALID_ARGUMENT;
+  cfear_ctx* ctx = c->ctx;
+  CFEAR_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  int rc = run_eval(c, x, false);
+  if (rc != CFEAR_OK) return rc;
+  double neq[10];
+  CFEAR_HIP_CHECK(ctx, hipMemcpyAsync(neq, c->d_out + 10 * (size_t)c->slots_cap, sizeof(neq), hipMemcpyDeviceToHost, ctx->stream));
+  CFEAR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  if (cost) *cost = neq[0];
+  if (g) { g[0] = neq[1]; g[1] = neq[2]; g[2] = neq[3]; }
+  if (H) {
+    H[0] = neq[4]; H[1] = neq[5]; H[2] = neq[6];
+    H[3] = neq[5]; H[4] = neq[7]; H[5] = neq[8];
+    H[6] = neq[6]; H[7] = neq[8]; H[8] = neq[9];
+  }
+  return CFEAR_OK;
+}
+
+extern "C" int cfear_cost_destroy(cfear_cost* c) {
+  if (!c) return CFEAR_OK;
+  (void)hipSetDevice(c->ctx->device);
+  (void)hipStreamSynchronize(c->ctx->stream);
+  if (c->d_job) (void)hipFree(c->d_job);
+  if (c->d_scratch) (void)hipFree(c->d_scratch);
+  if (c->d_out) (void)hipFree(c->d_out);
+  delete c;
+  return CFEAR_OK;
+}
+
+extern "C" int cfear_get_cost(cfear_ctx* ctx, const cfear_scan* const* scans, int32_t n_scans, const double* poses_xyt,
+                              const cfear_reg_params* par, double* cost, double* residuals, int32_t cap,
+                              int32_t* n_residuals, double* score) {
+  if (!ctx) return CFEAR_ERR_INVALID_ARGUMENT;
+  if (!cost || !n_residuals || !score) return cfear_set_error(ctx, CFEAR_ERR_INVALID_ARGUMENT, "null argument");
+  *cost = 0.0; *n_residuals = 0; *score = 0.0;
+  cfear_cost* c = nullptr;
+  int rc = cfear_cost_prepare(ctx, scans, n_scans, poses_xyt, par, par ? par->itr : 0, &c);   // radius by itr_ (:220)
+  if (rc != CFEAR_OK) return rc;
+  const int nres = cfear_cost_num_residuals(c);
+  if (nres <= 1) { cfear_cost_destroy(c); return CFEAR_ERR_TOO_FEW_RESIDUALS; }           // :200-203
+  const double* x = poses_xyt + 3 * (n_scans - 1);
+  rc = run_eval(c, x, false);
+  if (rc != CFEAR_OK) { cfear_cost_destroy(c); return rc; }
+  const size_t sc = (size_t)c->slots_cap;
+  std::vector<double> r(2 * (size_t)c->n_slots);
+  double neq[10];
+  hipError_t e1 = hipMemcpyAsync(r.data(), c->d_out + 8 * sc, (size_t)c->n_slots * 16, hipMemcpyDeviceToHost, ctx->stream);
+  hipError_t e2 = hipMemcpyAsync(neq, c->d_out + 10 * sc, sizeof(neq), hipMemcpyDeviceToHost, ctx->stream);
+  hipError_t e3 = hipStreamSynchronize(ctx->stream);
+  if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) { cfear_cost_destroy(c); return cfear_set_error(ctx, CFEAR_ERR_HIP, "read-back failed"); }
+  const int rpb = par->cost == CFEAR_P2L ? 1 : 2;
+  int b = 0;
+  for (int slot = 0; slot < c->n_slots; slot++) {
+    if (c->h_w[slot] < 0.0) continue;
+    for (int i = 0; i < rpb; i++)
+      if (residuals && b * rpb + i < cap) residuals[b * rpb + i] = r[slot * 2 + i];
+    b++;
+  }
+  *cost = neq[0];
+  *n_residuals = nres;
+  *score = neq[0] / (double)std::max(nres, 1);                                            // :209
+  cfear_cost_destroy(c);
+  return CFEAR_OK;
+}

@@ -1,0 +1,607 @@
+// surface.hip -- stages C + N of the CFEAR hot path on gfx950: motion compensation and oriented
+// surface point ("cell") extraction.
+//
+// Replaces (cfear_radarodometry/src/cfear_radarodometry/):
+//   Compensate / GetRelTimeStamp                      utils.cpp:96-107, utils.h:28-32
+//   MapPointNormal ctor -> ComputeNormals             pointnormal.cpp:65-90, 265-297
+//     pcl::VoxelGrid<PointXYZI>::filter (PCL 1.10)    call site pointnormal.cpp:277-280
+//     pcl::search::KdTree::radiusSearchT (FLANN)      call site pointnormal.cpp:291
+//   cell::cell / cell::ComputeNormal                  pointnormal.cpp:7-63
+//   ComputeSearchTreeFromCells (float means)          pointnormal.cpp:151-162
+//
+// Kernel design: ONE 1024-thread workgroup per scan, one launch for a batch of scans.  The PCL
+// voxel grid + kd-tree radius search are replaced by a sort-based uniform grid that lives in LDS:
+//   1. (optional) per-point motion compensation in fp64, stored back as float;
+//   2. bounding box -> voxel index per point -> LDS bitonic sort of 64-bit (voxel, point) keys
+//      (128 KiB of the CU's 160 KiB LDS): voxels come out ascending (PCL's output order) and the
+//      points of a voxel in input order (the canonical in-voxel order of the oracle);
+//   3. per-voxel float centroid, summed sequentially in that order (bit-exact with the oracle);
+//   4. one 16-lane DPP row per voxel gathers the points of the (2*reach+1)^2 neighbouring voxels
+//      (contiguous runs of the sorted array), tests the float squared distance exactly as FLANN's
+//      L2_Simple does, and accumulates weighted mean / covariance in fp64 with DPP row reductions;
+//      closed-form 2x2 eigen decomposition, validity tests, normal orientation;
+//   5. block scan over the validity flags -> cells compacted in voxel order.
+// Working set per scan is a few hundred KB and stays in LDS / L2; nothing here is HBM-bound.
+#include <cfloat>
+#include <cmath>
+
+#include "common.hpp"
+
+namespace {
+
+constexpr int kSurfThreads = 1024;
+constexpr int kMaxPoints = 16384;            // LDS sort capacity (64-bit keys)
+constexpr int kMaxGridRows = 4096;           // rowbeg table
+constexpr int kPerThread = kMaxPoints / kSurfThreads;   // 16 sorted elements per thread
+// LDS map: [0, 128K) sort keys, later voxel key/start tables; then rowbeg; then small reductions
+constexpr size_t kLdsRowbegOff = (size_t)kMaxPoints * 8 + 16;
+constexpr size_t kLdsSmallOff = (kLdsRowbegOff + (size_t)(kMaxGridRows + 1) * 4 + 15) / 16 * 16;
+constexpr size_t kLdsTotal = kLdsSmallOff + 256 + 64 + 32;
+
+struct SurfJob {                              // one scan
+  float4* xyzi;                               // [n] points (compensated in place if requested)
+  const int32_t* n_ptr;                       // device-side point count, or nullptr -> n_host
+  int32_t n_host;
+  int32_t compensate;
+  double mot[3];
+  ScanView out;
+};
+
+struct SurfCommon {
+  float radius, leaf, inv_leaf, r2;
+  int reach;                                  // neighbouring voxels to visit per axis
+  int weight_intensity, ccw;
+  double origin[2];
+  // global scratch, per scan: sorted points + voxel tables + temporary cells
+  char* scratch;
+  size_t scratch_stride;
+  int32_t* status;                            // [n_jobs] CFEAR_OK / error
+};
+
+struct TmpCell {                              // one candidate cell per voxel (before compaction)
+  double mean[2], normal[2], cov[4], scale, avg_intensity, lmin, lmax;
+  int32_t nsamples, valid;
+};
+
+__host__ __device__ inline size_t scratch_bytes_per_scan() {
+  size_t b = 0;
+  b += (size_t)kMaxPoints * 4 * 3;            // sx, sy, si
+  b += (size_t)kMaxPoints * 8;                // centroids
+  b += (size_t)kMaxPoints * sizeof(TmpCell);
+  b += (size_t)kMaxPoints * 4;                // compaction offsets
+  return (b + 255) / 256 * 256;
+}
+
+__device__ __forceinline__ int row16_sum_i32(int v) {
+  v += __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xf, 0xf, false);
+  v += __builtin_amdgcn_update_dpp(v, v, 0x4E, 0xf, 0xf, false);
+  v += __builtin_amdgcn_update_dpp(v, v, 0x141, 0xf, 0xf, false);
+  v += __builtin_amdgcn_update_dpp(v, v, 0x140, 0xf, 0xf, false);
+  return v;
+}
+
+// utils.h:28-32
+__device__ __forceinline__ double get_rel_time_stamp(double x, double y, bool ccw) {
+  const double a = atan2(y, x);
+  const double d = ((a > 0.00001 ? a : (2 * M_PI + a)) / (2 * M_PI));
+  return ccw ? -(d - 0.5) : (d - 0.5);
+}
+
+// utils.cpp:96-107
+__device__ __forceinline__ float4 compensate_point(float4 p, const double mot[3], bool ccw) {
+  const double d = get_rel_time_stamp((double)p.x, (double)p.y, ccw);
+  const double s_1 = sin(d * mot[2]), c_1 = cos(d * mot[2]);
+  const double tx = d * mot[0], ty = d * mot[1];
+  const double x = (double)p.x, y = (double)p.y;
+  p.x = (float)((c_1 * x + (-s_1) * y) + tx);
+  p.y = (float)((s_1 * x + c_1 * y) + ty);
+  return p;
+}
+
+__global__ __launch_bounds__(256) void compensate_kernel(float4* xyzi, int n, double m0, double m1, double m2, int ccw) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const double mot[3] = {m0, m1, m2};
+  xyzi[i] = compensate_point(xyzi[i], mot, ccw != 0);
+}
+
+// symmetric 2x2 eigen decomposition (one Jacobi rotation), same formula as the oracle's sym2_eig
+__device__ __forceinline__ void sym2_eig(double a, double b, double d, double& l0, double& l1, double v0[2]) {
+  double c = 1.0, s = 0.0, e0 = a, e1 = d;
+  if (b != 0.0) {
+    const double theta = (d - a) / (2.0 * b);
+    const double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+    c = 1.0 / sqrt(t * t + 1.0);
+    s = t * c;
+    e0 = a - t * b;
+    e1 = d + t * b;
+  }
+  if (e0 <= e1) { l0 = e0; l1 = e1; v0[0] = c; v0[1] = -s; }
+  else { l0 = e1; l1 = e0; v0[0] = s; v0[1] = c; }
+}
+
+__device__ __forceinline__ int lower_bound_u32(const uint32_t* a, int lo, int hi, uint32_t key) {
+  while (lo < hi) { const int mid = (lo + hi) >> 1; if (a[mid] < key) lo = mid + 1; else hi = mid; }
+  return lo;
+}
+__device__ __forceinline__ int upper_bound_u32(const uint32_t* a, int lo, int hi, uint32_t key) {
+  while (lo < hi) { const int mid = (lo + hi) >> 1; if (a[mid] <= key) lo = mid + 1; else hi = mid; }
+  return lo;
+}
+
+__global__ __launch_bounds__(kSurfThreads) void surface_points_kernel(const SurfJob* __restrict__ jobs, const SurfCommon cm) {
+  // all LDS is carved from the dynamic region so its base stays 16-byte aligned (64-bit keys)
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  float (*red_f)[16] = (float (*)[16])(smem + kLdsSmallOff);          // [4][16]
+  int* red_i = (int*)(smem + kLdsSmallOff + 256);                     // [16]
+  int* sh_misc = (int*)(smem + kLdsSmallOff + 256 + 64);              // [8]
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const SurfJob job = jobs[blockIdx.x];
+  int n = job.n_ptr ? *job.n_ptr : job.n_host;
+  int32_t* status = cm.status + blockIdx.x;
+  if (n <= 0) {
+    if (tid == 0) { *job.out.n_cells = 0; *status = CFEAR_ERR_EMPTY_CLOUD; }
+    return;
+  }
+  if (n > kMaxPoints) {
+    if (tid == 0) { *job.out.n_cells = 0; *status = CFEAR_ERR_CAPACITY; }
+    return;
+  }
+  float4* pts = job.xyzi;
+  char* scr = cm.scratch + (size_t)blockIdx.x * cm.scratch_stride;
+  float* sx = (float*)scr;
+  float* sy = sx + kMaxPoints;
+  float* si = sy + kMaxPoints;
+  float2* cen = (float2*)(si + kMaxPoints);
+  TmpCell* tmp = (TmpCell*)(cen + kMaxPoints);
+  int32_t* coff = (int32_t*)(tmp + kMaxPoints);
+
+  // ---- 1. compensation + bounding box -------------------------------------------------------
+  float mnx = FLT_MAX, mny = FLT_MAX, mxx = -FLT_MAX, mxy = -FLT_MAX;
+  for (int i = tid; i < n; i += kSurfThreads) {
+    float4 p = pts[i];
+    if (job.compensate) {
+      p = compensate_point(p, job.mot, cm.ccw != 0);
+      pts[i] = p;
+    }
+    mnx = fminf(mnx, p.x); mxx = fmaxf(mxx, p.x);
+    mny = fminf(mny, p.y); mxy = fmaxf(mxy, p.y);
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    mnx = fminf(mnx, __shfl_xor(mnx, o)); mxx = fmaxf(mxx, __shfl_xor(mxx, o));
+    mny = fminf(mny, __shfl_xor(mny, o)); mxy = fmaxf(mxy, __shfl_xor(mxy, o));
+  }
+  if (lane == 0) { red_f[0][wave] = mnx; red_f[1][wave] = mxx; red_f[2][wave] = mny; red_f[3][wave] = mxy; }
+  __syncthreads();
+  mnx = red_f[0][0]; mxx = red_f[1][0]; mny = red_f[2][0]; mxy = red_f[3][0];
+  for (int wv = 1; wv < 16; wv++) {
+    mnx = fminf(mnx, red_f[0][wv]); mxx = fmaxf(mxx, red_f[1][wv]);
+    mny = fminf(mny, red_f[2][wv]); mxy = fmaxf(mxy, red_f[3][wv]);
+  }
+  // pcl::VoxelGrid::applyFilter: min_b = floor(min * inverse_leaf), div_b = max_b - min_b + 1
+  const int min_bx = (int)floorf(mnx * cm.inv_leaf), max_bx = (int)floorf(mxx * cm.inv_leaf);
+  const int min_by = (int)floorf(mny * cm.inv_leaf), max_by = (int)floorf(mxy * cm.inv_leaf);
+  const long long div_bx = (long long)max_bx - min_bx + 1, div_by = (long long)max_by - min_by + 1;
+  if (div_bx * div_by > 0x7fffffffLL || div_by > kMaxGridRows) {
+    if (tid == 0) { *job.out.n_cells = 0; *status = CFEAR_ERR_CAPACITY; }
+    return;
+  }
+  const int dbx = (int)div_bx, dby = (int)div_by;
+
+  // ---- 2. (voxel, point) keys -> LDS bitonic sort ---------------------------------------------
+  unsigned long long* keys = (unsigned long long*)smem;
+  int npad = 1024;
+  while (npad < n) npad <<= 1;
+  for (int i = tid; i < npad; i += kSurfThreads) {
+    unsigned long long key = ~0ull;
+    if (i < n) {
+      const float4 p = pts[i];
+      const int ijk0 = (int)(floorf(p.x * cm.inv_leaf) - (float)min_bx);
+      const int ijk1 = (int)(floorf(p.y * cm.inv_leaf) - (float)min_by);
+      const unsigned idx = (unsigned)(ijk0 + ijk1 * dbx);
+      key = ((unsigned long long)idx << 32) | (unsigned)i;
+    }
+    keys[i] = key;
+  }
+  __syncthreads();
+  for (int k = 2; k <= npad; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int t = tid; t < (npad >> 1); t += kSurfThreads) {
+        const int lo = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+        const int hi = lo | j;
+        const bool asc = (lo & k) == 0;
+        const unsigned long long a = keys[lo], b = keys[hi];
+        if ((a > b) == asc) { keys[lo] = b; keys[hi] = a; }
+      }
+      __syncthreads();
+    }
+  }
+
+  // ---- 3. sorted points -> global scratch; voxel table (key, start) -> LDS --------------------
+  // each thread owns kPerThread consecutive sorted elements, held in registers across the barrier
+  // because the voxel tables overwrite the key region.
+  const int per = npad / kSurfThreads;                 // 1..16
+  unsigned long long mine[kPerThread];
+  const unsigned prev_vox = (tid * per > 0) ? (unsigned)(keys[tid * per - 1] >> 32) : 0xFFFFFFFFu;
+  int heads = 0;
+#pragma unroll
+  for (int q = 0; q < kPerThread; q++) {
+    const int e = tid * per + q;
+    mine[q] = (q < per && e < n) ? keys[e] : ~0ull;
+  }
+  {
+    unsigned pv = prev_vox;
+#pragma unroll
+    for (int q = 0; q < kPerThread; q++) {
+      const int e = tid * per + q;
+      if (q < per && e < n) {
+        const unsigned vx = (unsigned)(mine[q] >> 32);
+        heads += (e == 0 || vx != pv);
+        pv = vx;
+      }
+    }
+  }
+  // block exclusive scan of `heads`
+  const int incl = wave_incl_scan_i32(heads);
+  if (lane == 63) red_i[wave] = incl;
+  __syncthreads();                                      // also: every thread has read its keys
+  int voff = incl - heads;
+  for (int wv = 0; wv < wave; wv++) voff += red_i[wv];
+  int V = 0;
+  for (int wv = 0; wv < 16; wv++) V += red_i[wv];
+  uint32_t* vox_key = (uint32_t*)smem;                  // [V]
+  int32_t* vox_start = (int32_t*)(smem + (size_t)npad * 4);   // [V + 1]
+  int32_t* rowbeg = (int32_t*)(smem + kLdsRowbegOff);          // [dby + 1]
+  {
+    unsigned pv = prev_vox;
+    int ord = voff;
+#pragma unroll
+    for (int q = 0; q < kPerThread; q++) {
+      const int e = tid * per + q;
+      if (q < per && e < n) {
+        const unsigned vx = (unsigned)(mine[q] >> 32);
+        const unsigned pi = (unsigned)(mine[q] & 0xFFFFFFFFu);
+        if (e == 0 || vx != pv) { vox_key[ord] = vx; vox_start[ord] = e; ord++; }
+        pv = vx;
+        const float4 p = pts[pi];
+        sx[e] = p.x; sy[e] = p.y; si[e] = p.w;
+      }
+    }
+  }
+  if (tid == 0) vox_start[V] = n;
+  __syncthreads();
+  // rowbeg[y] = first voxel ordinal whose grid row is >= y
+  for (int y = tid; y <= dby; y += kSurfThreads)
+    rowbeg[y] = lower_bound_u32(vox_key, 0, V, (uint32_t)((long long)y * dbx));
+  // ---- 4a. voxel centroids: sequential float sums in sorted (= input) order -------------------
+  __threadfence_block();
+  __syncthreads();
+  for (int v = tid; v < V; v += kSurfThreads) {
+    const int s = vox_start[v], e = vox_start[v + 1];
+    float ax = 0.f, ay = 0.f;
+    for (int p = s; p < e; p++) { ax = __fadd_rn(ax, sx[p]); ay = __fadd_rn(ay, sy[p]); }
+    const float cnt = (float)(e - s);
+    cen[v] = make_float2(__fdiv_rn(ax, cnt), __fdiv_rn(ay, cnt));
+  }
+  __threadfence_block();
+  __syncthreads();
+
+  // ---- 4b. one 16-lane group per voxel: radius gather + weighted mean / covariance ------------
+  const int grp = tid >> 4, gl = tid & 15, gbase = lane & 48;
+  const int nrows_n = 2 * cm.reach + 1;                 // <= 16 neighbour grid rows
+  for (int v = grp; v < V; v += kSurfThreads / 16) {
+    const float2 c = cen[v];
+    const uint32_t key = vox_key[v];
+    const int iy = (int)(key / (uint32_t)dbx), ix = (int)(key - (uint32_t)iy * (uint32_t)dbx);
+    // lane j < nrows_n finds the sorted-point run [p0, p1) of grid row iy + j - reach
+    int p0 = 0, p1 = 0;
+    if (gl < nrows_n) {
+      const int yy = iy + gl - cm.reach;
+      if (yy >= 0 && yy < dby) {
+        const int x0 = max(ix - cm.reach, 0), x1 = min(ix + cm.reach, dbx - 1);
+        const uint32_t klo = (uint32_t)(yy * dbx + x0), khi = (uint32_t)(yy * dbx + x1);
+        const int a = lower_bound_u32(vox_key, rowbeg[yy], rowbeg[yy + 1], klo);
+        const int b = upper_bound_u32(vox_key, rowbeg[yy], rowbeg[yy + 1], khi);
+        p0 = vox_start[a];
+        p1 = vox_start[b];
+      }
+    }
+    // pass 1: neighbour count and weight sum
+    int cnt = 0;
+    double wsum = 0.0;
+    for (int j = 0; j < nrows_n; j++) {
+      const int q0 = __shfl(p0, gbase + j), q1 = __shfl(p1, gbase + j);
+      for (int p = q0 + gl; p < q1; p += 16) {
+        const float dx = __fsub_rn(c.x, sx[p]), dy = __fsub_rn(c.y, sy[p]);
+        const float d2 = __fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy));     // FLANN L2_Simple
+        if (d2 < cm.r2) {                                                      // RadiusResultSet: strict <
+          cnt++;
+          wsum += cm.weight_intensity ? fmax((double)si[p] - 60.0, 0.0) : 1.0; // pointnormal.cpp:15
+        }
+      }
+    }
+    cnt = row16_sum_i32(cnt);
+    int valid = 0;
+    TmpCell tc;
+    if (cnt >= 6) {                                                            // pointnormal.cpp:291
+      const double sum_intensity = row16_sum_f64(wsum);
+      // pass 2: weighted mean (weights normalised first, pointnormal.cpp:21-24)
+      double u0 = 0.0, u1 = 0.0;
+      for (int j = 0; j < nrows_n; j++) {
+        const int q0 = __shfl(p0, gbase + j), q1 = __shfl(p1, gbase + j);
+        for (int p = q0 + gl; p < q1; p += 16) {
+          const float dx = __fsub_rn(c.x, sx[p]), dy = __fsub_rn(c.y, sy[p]);
+          const float d2 = __fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy));
+          if (d2 < cm.r2) {
+            const double w = (cm.weight_intensity ? fmax((double)si[p] - 60.0, 0.0) : 1.0) / sum_intensity;
+            u0 += w * (double)sx[p];
+            u1 += w * (double)sy[p];
+          }
+        }
+      }
+      u0 = row16_sum_f64(u0);
+      u1 = row16_sum_f64(u1);
+      // pass 3: covariance x^T (w .* x) about the mean (pointnormal.cpp:26-33)
+      double c00 = 0, c01 = 0, c10 = 0, c11 = 0;
+      for (int j = 0; j < nrows_n; j++) {
+        const int q0 = __shfl(p0, gbase + j), q1 = __shfl(p1, gbase + j);
+        for (int p = q0 + gl; p < q1; p += 16) {
+          const float dx = __fsub_rn(c.x, sx[p]), dy = __fsub_rn(c.y, sy[p]);
+          const float d2 = __fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy));
+          if (d2 < cm.r2) {
+            const double w = (cm.weight_intensity ? fmax((double)si[p] - 60.0, 0.0) : 1.0) / sum_intensity;
+            const double x0 = (double)sx[p] - u0, x1 = (double)sy[p] - u1;
+            const double xw0 = w * x0, xw1 = w * x1;
+            c00 += x0 * xw0; c01 += x0 * xw1; c10 += x1 * xw0; c11 += x1 * xw1;
+          }
+        }
+      }
+      c00 = row16_sum_f64(c00); c01 = row16_sum_f64(c01);
+      c10 = row16_sum_f64(c10); c11 = row16_sum_f64(c11);
+      double lmin, lmax, vmin[2];
+      sym2_eig(c00, c10, c11, lmin, lmax, vmin);                               // pointnormal.cpp:39-45
+      const double condition_number = fabs(lmax / lmin);                       // :53
+      const double determinant = lmax * lmin;
+      const bool cov_reasonable = (condition_number <= 10000) && (determinant > 0.00001) &&
+                                  lmin > 0 && lmax > 0;                        // :56
+      double n0 = vmin[0], n1 = vmin[1];
+      if (n0 * (cm.origin[0] - u0) + n1 * (cm.origin[1] - u1) < 0) { n0 = -n0; n1 = -n1; }   // :59-61
+      valid = cov_reasonable ? 1 : 0;
+      tc.mean[0] = u0; tc.mean[1] = u1;
+      tc.normal[0] = n0; tc.normal[1] = n1;
+      tc.cov[0] = c00; tc.cov[1] = c01; tc.cov[2] = c10; tc.cov[3] = c11;
+      tc.scale = log(1.0 + condition_number / 2);                              // :57
+      tc.avg_intensity = sum_intensity / (double)cnt;                          // :19
+      tc.lmin = lmin; tc.lmax = lmax;
+      tc.nsamples = cnt;
+      tc.valid = valid;
+      if (gl == 0 && valid) tmp[v] = tc;
+    }
+    if (gl == 0) coff[v] = valid;
+  }
+  __threadfence_block();
+  __syncthreads();
+
+  // ---- 5. compaction in voxel order -----------------------------------------------------------
+  if (tid == 0) sh_misc[0] = 0;
+  __syncthreads();
+  for (int v0 = 0; v0 < V; v0 += kSurfThreads) {
+    const int v = v0 + tid;
+    const int f = v < V ? coff[v] : 0;
+    const int inc = wave_incl_scan_i32(f);
+    if (lane == 63) red_i[wave] = inc;
+    __syncthreads();
+    int off = sh_misc[0] + inc - f;
+    for (int wv = 0; wv < wave; wv++) off += red_i[wv];
+    if (f) {
+      if (off < job.out.cap) {
+        const TmpCell t = tmp[v];
+        job.out.mean_f[off] = make_float2((float)t.mean[0], (float)t.mean[1]);  // pointnormal.cpp:154-157
+        job.out.mean[off] = make_double2(t.mean[0], t.mean[1]);
+        job.out.normal[off] = make_double2(t.normal[0], t.normal[1]);
+        job.out.cov[off] = make_double4(t.cov[0], t.cov[1], t.cov[2], t.cov[3]);
+        job.out.scale[off] = t.scale;
+        job.out.avg_intensity[off] = t.avg_intensity;
+        job.out.lambda[off] = make_double2(t.lmin, t.lmax);
+        job.out.nsamples[off] = t.nsamples;
+      }
+    }
+    __syncthreads();
+    if (tid == 0) { int tot = 0; for (int wv = 0; wv < 16; wv++) tot += red_i[wv]; sh_misc[0] += tot; }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    const int total = sh_misc[0];
+    *job.out.n_cells = total <= job.out.cap ? total : job.out.cap;
+    *status = total <= job.out.cap ? CFEAR_OK : CFEAR_ERR_CAPACITY;
+  }
+}
+
+// raw cells <-> SoA slab
+__global__ void cells_to_slab_kernel(const cfear_cell* cells, int n, ScanView v) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i == 0) *v.n_cells = n;
+  if (i >= n) return;
+  const cfear_cell c = cells[i];
+  v.mean_f[i] = make_float2((float)c.mean[0], (float)c.mean[1]);
+  v.mean[i] = make_double2(c.mean[0], c.mean[1]);
+  v.normal[i] = make_double2(c.normal[0], c.normal[1]);
+  v.cov[i] = make_double4(c.cov[0], c.cov[1], c.cov[2], c.cov[3]);
+  v.scale[i] = c.scale;
+  v.avg_intensity[i] = c.avg_intensity;
+  v.lambda[i] = make_double2(c.lambda_min, c.lambda_max);
+  v.nsamples[i] = c.nsamples;
+}
+__global__ void slab_to_cells_kernel(ScanView v, int n, cfear_cell* cells) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  cfear_cell c;
+  c.mean[0] = v.mean[i].x; c.mean[1] = v.mean[i].y;
+  c.normal[0] = v.normal[i].x; c.normal[1] = v.normal[i].y;
+  c.cov[0] = v.cov[i].x; c.cov[1] = v.cov[i].y; c.cov[2] = v.cov[i].z; c.cov[3] = v.cov[i].w;
+  c.scale = v.scale[i];
+  c.avg_intensity = v.avg_intensity[i];
+  c.lambda_min = v.lambda[i].x; c.lambda_max = v.lambda[i].y;
+  c.nsamples = v.nsamples[i];
+  c.pad = 0;
+  cells[i] = c;
+}
+
+}  // namespace
+
+size_t cfear_surface_lds_bytes() { return kLdsTotal; }
+size_t cfear_surface_scratch_bytes() { return scratch_bytes_per_scan(); }
+int cfear_surface_max_points() { return kMaxPoints; }
+
+// Launches the surface-point kernel for n_jobs scans.  d_jobs: device array of SurfJob-compatible
+// records built by cfear_surface_fill_job; d_status: device int32 [n_jobs].
+struct cfear_surf_job_pod { unsigned char bytes[sizeof(SurfJob)]; };
+size_t cfear_surface_job_bytes() { return sizeof(SurfJob); }
+
+void cfear_surface_fill_job(void* dst, float* d_xyzi, const int32_t* d_n, int32_t n_host, int compensate,
+                            const double mot[3], const ScanView& out) {
+  SurfJob j;
+  j.xyzi = (float4*)d_xyzi;
+  j.n_ptr = d_n;
+  j.n_host = n_host;
+  j.compensate = compensate;
+  j.mot[0] = mot ? mot[0] : 0.0; j.mot[1] = mot ? mot[1] : 0.0; j.mot[2] = mot ? mot[2] : 0.0;
+  j.out = out;
+  memcpy(dst, &j, sizeof(j));
+}
+
+int cfear_surface_launch(cfear_ctx* ctx, const void* d_jobs, int n_jobs, const cfear_feature_params* par,
+                         char* d_scratch, int32_t* d_status) {
+  if (par->radius <= 0.f || !(par->downsample_factor > 0.0))
+    return cfear_set_error(ctx, CFEAR_ERR_INVALID_ARGUMENT, "radius / downsample_factor must be > 0");
+  SurfCommon cm;
+  cm.radius = par->radius;
+  cm.leaf = (float)(par->radius / par->downsample_factor);                    // pointnormal.cpp:279
+  cm.inv_leaf = 1.0f / cm.leaf;                                               // Array4f::Ones() / leaf
+  cm.r2 = (float)((double)par->radius * (double)par->radius);                 // KdTreeFLANN::radiusSearch
+  cm.reach = (int)std::ceil((double)par->radius / (double)cm.leaf);
+  if (cm.reach < 1) cm.reach = 1;
+  if (2 * cm.reach + 1 > 16)
+    return cfear_set_error(ctx, CFEAR_ERR_INVALID_ARGUMENT, "downsample_factor too large (reach %d)", cm.reach);
+  cm.weight_intensity = par->weight_intensity;
+  cm.ccw = par->ccw;
+  cm.origin[0] = par->origin[0]; cm.origin[1] = par->origin[1];
+  cm.scratch = d_scratch;
+  cm.scratch_stride = scratch_bytes_per_scan();
+  cm.status = d_status;
+  static bool attr_set = false;
+  if (!attr_set) {
+    CFEAR_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)surface_points_kernel,
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)cfear_surface_lds_bytes()));
+    attr_set = true;
+  }
+  ProfScope ps(ctx, "surface_points");
+  hipLaunchKernelGGL(surface_points_kernel, dim3(n_jobs), dim3(kSurfThreads), cfear_surface_lds_bytes(), ctx->stream,
+                     (const SurfJob*)d_jobs, cm);
+  CFEAR_HIP_CHECK(ctx, hipGetLastError());
+  return CFEAR_OK;
+}
+
+extern "C" int cfear_compensate(cfear_ctx* ctx, float* xyzi, int32_t n, const double mot[3], int32_t ccw) {
+  if (!ctx) return CFEAR_ERR_INVALID_ARGUMENT;
+  if (!xyzi || !mot || n < 0) return cfear_set_error(ctx, CFEAR_ERR_INVALID_ARGUMENT, "null argument");
+  if (n == 0) return CFEAR_OK;
+  CFEAR_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  const bool dev = cfear_is_device_ptr(xyzi);
+  float* d = xyzi;
+  if (!dev) {
+    d = (float*)cfear_workspace(ctx, 4, (size_t)n * 16);
+    if (!d) return cfear_set_error(ctx, CFEAR_ERR_HIP, "workspace allocation failed");
+    CFEAR_HIP_CHECK(ctx, hipMemcpyAsync(d, xyzi, (size_t)n * 16, hipMemcpyHostToDevice, ctx->stream));
+  }
+  {
+    ProfScope ps(ctx, "compensate");
+    hipLaunchKernelGGL(compensate_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, (float4*)d, n, mot[0], mot[1], mot[2], ccw);
+  }
+  CFEAR_HIP_CHECK(ctx, hipGetLastError());
+  if (!dev) {
+    CFEAR_HIP_CHECK(ctx, hipMemcpyAsync(xyzi, d, (size_t)n * 16, hipMemcpyDeviceToHost, ctx->stream));
+    CFEAR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  }
+  return CFEAR_OK;
+}
+
+extern "C" int cfear_scan_create(cfear_ctx* ctx, float* xyzi, int32_t n, const cfear_feature_params* par, cfear_scan** out) {
+  if (!ctx) return CFEAR_ERR_INVALID_ARGUMENT;
+  if (!par || !out || (!xyzi && n > 0)) return cfear_set_error(ctx, CFEAR_ERR_INVALID_ARGUMENT, "null argument");
+  *out = nullptr;
+  if (n <= 0) return cfear_set_error(ctx, CFEAR_ERR_EMPTY_CLOUD, "error, cloud empty");   // pointnormal.cpp:72-75
+  if (n > kMaxPoints) return cfear_set_error(ctx, CFEAR_ERR_CAPACITY, "n = %d > %d points", n, kMaxPoints);
+  CFEAR_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  const bool dev = cfear_is_device_ptr(xyzi);
+  float* d = xyzi;
+  if (!dev) {
+    d = (float*)cfear_workspace(ctx, 4, (size_t)n * 16);
+    if (!d) return cfear_set_error(ctx, CFEAR_ERR_HIP, "workspace allocation failed");
+    CFEAR_HIP_CHECK(ctx, hipMemcpyAsync(d, xyzi, (size_t)n * 16, hipMemcpyHostToDevice, ctx->stream));
+  }
+  cfear_scan* s = nullptr;
+  int rc = cfear_scan_alloc(ctx, n, &s);          // at most one cell per point
+  if (rc != CFEAR_OK) return rc;
+  char* ws = (char*)cfear_workspace(ctx, 5, cfear_surface_scratch_bytes() + 1024);
+  if (!ws) { cfear_scan_destroy(s); return cfear_set_error(ctx, CFEAR_ERR_HIP, "workspace allocation failed"); }
+  char* d_job = ws;                                // job record + status in front of the scratch
+  int32_t* d_status = (int32_t*)(ws + 512);
+  char* d_scratch = ws + 1024;
+  unsigned char hjob[sizeof(SurfJob)];
+  cfear_surface_fill_job(hjob, d, nullptr, n, par->compensate, par->mot, s->view);
+  CFEAR_HIP_CHECK(ctx, hipMemcpyAsync(d_job, hjob, sizeof(SurfJob), hipMemcpyHostToDevice, ctx->stream));
+  CFEAR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));     // hjob is on the stack
+  rc = cfear_surface_launch(ctx, d_job, 1, par, d_scratch, d_status);
+  if (rc != CFEAR_OK) { cfear_scan_destroy(s); return rc; }
+  int32_t hst[2] = {0, 0};
+  CFEAR_HIP_CHECK(ctx, hipMemcpyAsync(&hst[0], d_status, 4, hipMemcpyDeviceToHost, ctx->stream));
+  CFEAR_HIP_CHECK(ctx, hipMemcpyAsync(&hst[1], s->view.n_cells, 4, hipMemcpyDeviceToHost, ctx->stream));
+  if (!dev && par->compensate)
+    CFEAR_HIP_CHECK(ctx, hipMemcpyAsync(xyzi, d, (size_t)n * 16, hipMemcpyDeviceToHost, ctx->stream));
+  CFEAR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  if (hst[0] != CFEAR_OK) {
+    cfear_scan_destroy(s);
+    return cfear_set_error(ctx, hst[0], "surface point extraction failed: %s", cfear_status_string(hst[0]));
+  }
+  s->n_cells_host = hst[1];
+  *out = s;
+  return CFEAR_OK;
+}
+
+extern "C" int cfear_scan_from_cells(cfear_ctx* ctx, const cfear_cell* cells, int32_t n_cells, cfear_scan** out) {
+  if (!ctx) return CFEAR_ERR_INVALID_ARGUMENT;
+  if (!out || n_cells < 0 || (!cells && n_cells > 0)) return cfear_set_error(ctx, CFEAR_ERR_INVALID_ARGUMENT, "null argument");
+  *out = nullptr;
+  CFEAR_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  cfear_scan* s = nullptr;
+  int rc = cfear_scan_alloc(ctx, n_cells > 0 ? n_cells : 1, &s);
+  if (rc != CFEAR_OK) return rc;
+  cfear_cell* d = (cfear_cell*)cfear_workspace(ctx, 4, (size_t)(n_cells > 0 ? n_cells : 1) * sizeof(cfear_cell));
+  if (!d) { cfear_scan_destroy(s); return cfear_set_error(ctx, CFEAR_ERR_HIP, "workspace allocation failed"); }
+  if (n_cells > 0)
+    CFEAR_HIP_CHECK(ctx, hipMemcpyAsync(d, cells, (size_t)n_cells * sizeof(cfear_cell), hipMemcpyHostToDevice, ctx->stream));
+  hipLaunchKernelGGL(cells_to_slab_kernel, dim3((n_cells + 255) / 256 + 1), dim3(256), 0, ctx->stream, d, n_cells, s->view);
+  CFEAR_HIP_CHECK(ctx, hipGetLastError());
+  CFEAR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));     // caller's host array may go away
+  s->n_cells_host = n_cells;
+  *out = s;
+  return CFEAR_OK;
+}
+
+extern "C" int cfear_scan_get_cells(const cfear_scan* scan, cfear_cell* out_host, int32_t cap) {
+  if (!scan || !out_host) return CFEAR_ERR_INVALID_ARGUMENT;
+  cfear_ctx* ctx = scan->ctx;
+  const int n = cfear_scan_size(scan);
+  if (n < 0) return n;
+  if (n > cap) return cfear_set_error(ctx, CFEAR_ERR_CAPACITY, "%d cells > cap %d", n, cap);
+  if (n == 0) return 0;
+  CFEAR_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  cfear_cell* d = (cfear_cell*)cfear_workspace(ctx, 4, (size_t)n * sizeof(cfear_cell));
+  if (!d) return cfear_set_error(ctx, CFEAR_ERR_HIP, "workspace allocation failed");
+  hipLaunchKernelGGL(slab_to_cells_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, scan->view, n, d);
+  CFEAR_HIP_CHECK(ctx, hipGetLastError());
+  CFEAR_HIP_CHECK(ctx, hipMemcpyAsync(out_host, d, (size_t)n * sizeof(cfear_cell), hipMemcpyDeviceToHost, ctx->stream));
+  CFEAR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  return n;
+}

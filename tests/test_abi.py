@@ -1,0 +1,57 @@
+"""CPU: the C-ABI library loads and exports every symbol include/cfear_hip.h declares; struct
+layouts of the ctypes binding match the header; without a GPU the product fails loudly."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+from tbv_slam_public_amd import _lib as L
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_so_exists_and_exports_header_symbols():
+    lib = L.lib()
+    hdr = open(os.path.join(ROOT, "include", "cfear_hip.h")).read()
+    declared = set(re.findall(r"\b(cfear_[a-z0-9_]+)\s*\(", hdr))
+    declared -= {"cfear_ctx", "cfear_scan", "cfear_cost", "cfear_odometry"}
+    assert declared == set(L.EXPORTS), declared ^ set(L.EXPORTS)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.cfear_abi_version() == 1
+
+
+def test_struct_sizes():
+    assert C.sizeof(L.Cell) == 104
+    assert C.sizeof(L.RegResult) == 72
+    assert C.sizeof(L.FrameInfo) == 56
+    assert C.sizeof(L.PolarDesc) == 24
+    assert C.sizeof(L.RegParams) == 72
+
+
+def test_defaults_follow_reference():
+    lib = L.lib()
+    p = L.RegParams()
+    lib.cfear_reg_params_default(C.byref(p))
+    # n_scan_normal.h:72-75, registration.h:117-122
+    assert (p.cost, p.loss, p.loss_limit, p.weight_opt) == (L.P2L, 1, 0.1, 0)
+    assert (p.max_itr_association, p.max_itr_solver, p.min_itr, p.radius) == (8, 20, 3, 2.0)
+    o = L.OdometryParams()
+    lib.cfear_odometry_params_default(C.byref(o))
+    # CFEAR-3 preset
+    assert (o.kstrong.k_strongest, o.kstrong.z_min, o.res, o.submap_scan_size) == (40, 60.0, 3.0, 4)
+    assert (o.reg.cost, o.reg.weight_opt, o.weight_intensity) == (L.P2P, 4, 1)
+    assert lib.cfear_status_string(-4) == b"too few residuals"
+
+
+def test_no_gpu_fails_loudly():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    h = C.c_void_p()
+    rc = L.lib().cfear_ctx_create(0, None, C.byref(h))
+    assert rc == L.ERR_NO_DEVICE and not h.value
+    from tbv_slam_public_amd import api
+    with pytest.raises(L.CfearError):
+        api.Context(0)

@@ -1,0 +1,136 @@
+"""GPU: stage F (k-strongest / peaks / CA-CFAR) through the C-ABI vs the CPU oracle -- bit-exact."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracle_kstrong(img, k, z_min, range_res, min_distance):
+    from oracle import pyoracle as O
+    sr, si, sc = O.kstrongest(img, k, z_min)
+    pk = O.peaks(img, k, sr, sc)
+    cloud = O.kstrongest_cloud(sr, si, sc, range_res, min_distance)
+    cloud_pk = O.kstrongest_cloud(sr, si, sc, range_res, min_distance, mask=pk)
+    return sr, si, sc, pk, cloud, cloud_pk
+
+
+def _check(img, k, z_min, range_res=0.0438, min_distance=2.5, device=False):
+    from tbv_slam_public_amd import api
+    if device:
+        import torch
+        r = api.filter_kstrongest(torch.from_numpy(img).cuda(), k, z_min, range_res, min_distance, want_peaks=True)
+        torch.cuda.synchronize()
+        api.default_context().synchronize()
+        r = {kk: v.cpu().numpy() for kk, v in r.items()}
+    else:
+        r = api.filter_kstrongest(img, k, z_min, range_res, min_distance, want_peaks=True)
+    imgs = img if img.ndim == 3 else img[None]
+    for b in range(imgs.shape[0]):
+        sr, si, sc, pk, cloud, cloud_pk = _oracle_kstrong(imgs[b], k, z_min, range_res, min_distance)
+        np.testing.assert_array_equal(r["sel_count"][b], sc)
+        np.testing.assert_array_equal(r["sel_range"][b], sr)
+        np.testing.assert_array_equal(r["sel_intensity"][b], si)
+        np.testing.assert_array_equal(r["is_peak"][b], pk)
+        assert r["n_points"][b] == cloud.shape[0]
+        np.testing.assert_array_equal(r["xyzi"][b, :cloud.shape[0]], cloud)
+        assert r["n_peaks"][b] == cloud_pk.shape[0]
+        np.testing.assert_array_equal(r["xyzi_peaks"][b, :cloud_pk.shape[0]], cloud_pk)
+
+
+@pytest.mark.parametrize("k,z_min", [(1, 60), (12, 60), (40, 60), (40, 0), (64, 200), (100, 250), (7, 255)])
+def test_kstrongest_uniform_small(k, z_min):
+    from tbv_slam_public_amd import synth
+    _check(synth.uniform_v1(11, rows=37, cols=512)[0], k, z_min)
+
+
+@pytest.mark.parametrize("cols", [16, 100, 1000, 1024, 1040, 2049, 3360, 3768, 5000, 8192])
+def test_kstrongest_ragged_widths(cols):
+    from tbv_slam_public_amd import synth
+    _check(synth.uniform_v1(cols, rows=9, cols=cols)[0], 12, 100)
+
+
+def test_kstrongest_ties_and_empty_rows():
+    img = np.zeros((8, 320), np.uint8)
+    img[1, :] = 255
+    img[2, 5:9] = 70
+    img[3, ::2] = 90
+    img[3, 1::2] = 91
+    img[4, 319] = 60
+    img[5, 0] = 59
+    img[6, 100:180] = 200       # plateau wider than k
+    img[7, :3] = 250            # kept bins below the peak window
+    img[7, 317:] = 250
+    _check(img, 12, 60)
+    _check(img, 40, 60)
+
+
+def test_kstrongest_full_size_scene_batch_host_and_device():
+    from tbv_slam_public_amd import synth
+    imgs, _, _ = synth.scene_v1(3, 3)
+    _check(imgs, 40, 60)
+    _check(imgs, 12, 60, device=True)
+    # MulRan / Kvarntorp presets (range_res widened from float)
+    _check(imgs[0], 12, 70, range_res=0.0595238, min_distance=2.5)
+    _check(imgs[0], 40, 60, range_res=0.175, min_distance=2.5)
+
+
+def test_kstrongest_full_size_uniform_properties():
+    """Size-independent properties at BASELINE size on the worst-tie input: per row the kept set is
+    the top-k multiset, ascending (intensity, range), ties resolved toward the larger range."""
+    from tbv_slam_public_amd import api, synth
+    img = synth.uniform_v1(99, batch=4)
+    k = 40
+    r = api.filter_kstrongest(img, k, 60, 0.0438, 2.5)
+    assert (r["sel_count"] == k).all()
+    key = r["sel_intensity"].astype(np.int64) * 65536 + r["sel_range"]
+    assert (np.diff(key, axis=2) > 0).all()
+    top = np.sort(img, axis=2)[:, :, -k:]
+    np.testing.assert_array_equal(np.sort(r["sel_intensity"], axis=2), top)
+    # tie rule: among bins equal to the cut intensity the kept ones are the largest ranges
+    cut = r["sel_intensity"][:, :, 0]
+    for b, row in [(0, 0), (1, 17), (3, 399)]:
+        eq = np.nonzero(img[b, row] == cut[b, row])[0]
+        kept = r["sel_range"][b, row][r["sel_intensity"][b, row] == cut[b, row]]
+        np.testing.assert_array_equal(np.sort(kept), eq[-kept.size:])
+
+
+def test_cacfar_vs_oracle():
+    from oracle import pyoracle as O
+    from tbv_slam_public_amd import api, synth
+    imgs, _, _ = synth.scene_v1(5, 2, range_res=0.175)
+    for args in [(40, 10, 0.01, 0.175, 20, 2.5), (10, 20, 0.01, 0.0438, 60, 2.5), (25, 3, 0.001, 0.0595238, 40, 2.5)]:
+        r = api.filter_cacfar(imgs, *args, want_mask=True)
+        for b in range(2):
+            cloud, rc = O.cacfar(imgs[b], *args)
+            assert r["n_points"][b] == cloud.shape[0]
+            np.testing.assert_array_equal(r["xyzi"][b, :cloud.shape[0]], cloud)
+            mask = np.zeros(imgs[b].shape, np.uint8)
+            mask[rc[:, 0], rc[:, 1]] = 1
+            np.testing.assert_array_equal(r["det_mask"][b], mask)
+    rng = np.random.default_rng(4)
+    img = (10 + rng.exponential(12, size=(16, 700))).clip(0, 255).astype(np.uint8)
+    img[3, 690:] = 255
+    r = api.filter_cacfar(img, 40, 10, 0.01, 0.175, 20, 2.5)
+    cloud, _ = O.cacfar(img, 40, 10, 0.01, 0.175, 20, 2.5)
+    np.testing.assert_array_equal(r["xyzi"][0, :r["n_points"][0]], cloud)
+
+
+def test_radar_driver_mirror():
+    from oracle import pyoracle as O
+    from tbv_slam_public_amd import api, synth
+    imgs, _, _ = synth.scene_v1(7, 1)
+    drv = api.radarDriver(api.radarDriverParameters(k_strongest=12, z_min=60, range_res=0.0438))
+    cloud, peaks = drv.CallbackOffline(imgs[0])
+    sr, si, sc, pk, oc, op = _oracle_kstrong(imgs[0], 12, 60, 0.0438, 2.5)
+    np.testing.assert_array_equal(cloud, oc)
+    np.testing.assert_array_equal(peaks, op)
+
+
+def test_invalid_arguments_return_status():
+    from tbv_slam_public_amd import api, _lib as L
+    img = np.zeros((4, 64), np.uint8)
+    with pytest.raises(L.CfearError) as e:
+        api.filter_kstrongest(img, 0, 60, 0.0438, 2.5)
+    assert e.value.status == L.ERR_INVALID_ARGUMENT
+    with pytest.raises(L.CfearError):
+        api.filter_kstrongest(np.zeros((4, 9000), np.uint8), 12, 60, 0.0438, 2.5)

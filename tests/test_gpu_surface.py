@@ -1,0 +1,111 @@
+"""GPU: stages C + N (compensation, oriented surface points) through the C-ABI vs the CPU oracle."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _cloud(seed, frame=0, k=40, range_res=0.0438):
+    from oracle import pyoracle as O
+    from tbv_slam_public_amd import synth
+    imgs, _, _ = synth.scene_v1(seed, frame + 1, range_res=range_res)
+    sr, si, sc = O.kstrongest(imgs[frame], k, 60)
+    return O.kstrongest_cloud(sr, si, sc, range_res, 2.5)
+
+
+def _cmp_cells(got, exp):
+    assert got.shape[0] == exp.shape[0]
+    np.testing.assert_array_equal(got["nsamples"], exp["nsamples"])
+    # fp64 sums are reduced in a different (tree) order on the GPU: rounding-level differences only
+    np.testing.assert_allclose(got["mean"], exp["mean"], rtol=0, atol=1e-9)
+    np.testing.assert_allclose(got["cov"], exp["cov"], rtol=1e-9, atol=1e-10)
+    np.testing.assert_allclose(got["normal"], exp["normal"], rtol=0, atol=1e-7)
+    np.testing.assert_allclose(got["scale"], exp["scale"], rtol=1e-8)
+    np.testing.assert_allclose(got["avg_intensity"], exp["avg_intensity"], rtol=1e-12)
+    np.testing.assert_allclose(got["lambda_min"], exp["lambda_min"], rtol=1e-8, atol=1e-12)
+
+
+def test_compensate_matches_oracle():
+    from oracle import pyoracle as O
+    from tbv_slam_public_amd import api
+    cloud = _cloud(1)
+    for mot, ccw in [((2.4, 0.1, 0.02), False), ((-1.0, 0.3, -0.05), True), ((0, 0, 0), False)]:
+        exp = O.compensate(cloud, mot, ccw)
+        got = api.Compensate(cloud.copy(), mot, ccw)
+        # device atan2/sin/cos differ from glibc in the last ulp of the fp64 intermediate; after
+        # rounding to float at most a 1-ulp flip on a handful of points is tolerated
+        d = np.abs(got[:, :2] - exp[:, :2])
+        assert d.max() <= 2e-5
+        assert (d > 0).mean() < 1e-3
+        np.testing.assert_array_equal(got[:, 2:], exp[:, 2:])
+
+
+@pytest.mark.parametrize("seed,radius,wi", [(1, 3.0, True), (2, 3.5, False), (3, 3.0, False), (4, 2.0, True)])
+def test_surface_points_match_oracle(seed, radius, wi):
+    from oracle import pyoracle as O
+    from tbv_slam_public_amd import api
+    cloud = _cloud(seed, k=40 if wi else 12)
+    exp = O.surface_points(cloud, radius, 1.0, (0, 0), wi)
+    m = api.MapPointNormal(cloud, radius, (0.0, 0.0), wi)
+    assert m.GetSize() == exp.shape[0]
+    _cmp_cells(m.GetCells(), exp)
+    assert 100 < exp.shape[0] < 700
+
+
+def test_surface_points_downsample_factor_and_origin():
+    from oracle import pyoracle as O
+    from tbv_slam_public_amd import api
+    cloud = _cloud(5, k=12)
+    api.MapPointNormal.downsample_factor = 2.0
+    try:
+        exp = O.surface_points(cloud, 3.0, 2.0, (10.0, -5.0), False)
+        m = api.MapPointNormal(cloud, 3.0, (10.0, -5.0), False)
+        _cmp_cells(m.GetCells(), exp)
+    finally:
+        api.MapPointNormal.downsample_factor = 1.0
+
+
+def test_surface_points_device_input_with_fused_compensation():
+    import torch
+    from oracle import pyoracle as O
+    from tbv_slam_public_amd import api
+    cloud = _cloud(6)
+    mot = (2.5, 0.05, 0.015)
+    # use the device-compensated cloud as the oracle's input so the comparison isolates stage N
+    comp = api.Compensate(cloud.copy(), mot, False)
+    exp = O.surface_points(comp, 3.0, 1.0, (0, 0), True)
+    t = torch.from_numpy(cloud).cuda()
+    m = api.MapPointNormal(t, 3.0, (0.0, 0.0), True, compensate=mot, ccw=False)
+    _cmp_cells(m.GetCells(), exp)
+    np.testing.assert_array_equal(t.cpu().numpy(), comp)      # compensated in place
+
+
+def test_surface_points_edge_cases():
+    from oracle import pyoracle as O
+    from tbv_slam_public_amd import api, _lib as L
+    with pytest.raises(L.CfearError) as e:
+        api.MapPointNormal(np.zeros((0, 4), np.float32), 3.0)
+    assert e.value.status == L.ERR_EMPTY_CLOUD
+    # fewer than 6 neighbours anywhere -> no cells
+    pts = np.zeros((5, 4), np.float32)
+    pts[:, 0] = np.arange(5) * 10
+    assert api.MapPointNormal(pts, 3.0).GetSize() == 0
+    # collinear points: condition number test rejects the cell
+    line = np.zeros((50, 4), np.float32)
+    line[:, 0] = np.linspace(0, 2, 50)
+    line[:, 3] = 100
+    exp = O.surface_points(line, 3.0, 1.0, (0, 0), False)
+    assert api.MapPointNormal(line, 3.0).GetSize() == exp.shape[0] == 0
+    # a dense blob: exactly the oracle's cells, negative coordinates
+    rng = np.random.default_rng(0)
+    blob = np.zeros((3000, 4), np.float32)
+    blob[:, :2] = rng.normal(0, 6, size=(3000, 2))
+    blob[:, 3] = rng.uniform(50, 200, size=3000)
+    exp = O.surface_points(blob, 3.0, 1.0, (0, 0), True)
+    _cmp_cells(api.MapPointNormal(blob, 3.0, (0, 0), True).GetCells(), exp)
+    # raw mode and cell upload round trip
+    raw = api.MapPointNormal(blob[:100], 3.0, raw=True)
+    c = raw.GetCells()
+    np.testing.assert_array_equal(c["mean"], blob[:100, :2].astype(np.float64))
+    back = api.MapPointNormal(cells=exp)
+    np.testing.assert_array_equal(back.GetCells(), exp)
