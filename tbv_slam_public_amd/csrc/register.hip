@@ -153,7 +153,13 @@ __device__ __forceinline__ void block_reduce10(double v[10], double* part /*[2][
   }
   __syncthreads();
 #pragma unroll
-  for (int k = 0; k < 10; k++) v[k] = ((buf[k] + buf[10 + k]) + buf[20 + k]) + buf[30 + k];
+  for (int k = 0; k < 10; k++) {
+    // readfirstlane: tell the compiler the totals are wave-uniform, so every decision derived from
+    // them compiles to scalar branches instead of exec-masked (structurized) control flow
+    const double t = ((buf[k] + buf[10 + k]) + buf[20 + k]) + buf[30 + k];
+    v[k] = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(t)),
+                            __builtin_amdgcn_readfirstlane(__double2loint(t)));
+  }
   phase ^= 1;
 }
 __device__ __forceinline__ int block_sum_i32(int v, int* part /*[2][4]*/, int& phase) {
@@ -162,7 +168,7 @@ __device__ __forceinline__ int block_sum_i32(int v, int* part /*[2][4]*/, int& p
   const int t = wave_sum_i32(v);
   if (lane == 0) buf[wave] = t;
   __syncthreads();
-  const int r = buf[0] + buf[1] + buf[2] + buf[3];
+  const int r = __builtin_amdgcn_readfirstlane(buf[0] + buf[1] + buf[2] + buf[3]);
   phase ^= 1;
   return r;
 }
@@ -488,18 +494,22 @@ __global__ __launch_bounds__(kRegThreads) void register_kernel(const RegJob* __r
     if (success) { x[0] = xi[0]; x[1] = xi[1]; x[2] = xi[2]; } else fail_status = CFEAR_ERR_SOLVER;
     const double current_score = summary.final_cost;
     const double rel_improvement = (prev_score - current_score) / prev_score;
-    if (itr > cm.par.min_itr) {                                   // :134-149
-      if (prev_score < current_score) {
-        x[0] = prev_par[0]; x[1] = prev_par[1]; x[2] = prev_par[2];
-        break;
-      } else if (rel_improvement < cm.par.score_tolerance) {
-        break;
-      } else if (summary.last_relative_decrease < cm.par.score_tolerance || summary.n_pushed == 1) {
-        break;
-      }
+    // n_scan_normal.cpp:134-149.  Written with selects instead of nested if/else-break: hipcc
+    // (ROCm 7.2, clang 22) mis-merged the phi of prev_par on the "continue" edge of the nested
+    // form and kept the stale prev_par (found by tests/test_gpu_register.py P2P-None-1).
+    const bool past_min = itr > cm.par.min_itr;
+    const bool worse = past_min && (prev_score < current_score);          // recover to prev iteration
+    const bool small_outer = past_min && !worse && (rel_improvement < cm.par.score_tolerance);
+    const bool small_inner = past_min && !worse && !small_outer &&
+                             (summary.last_relative_decrease < cm.par.score_tolerance || summary.n_pushed == 1);
+    const bool stop = worse || small_outer || small_inner;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      x[k] = worse ? prev_par[k] : x[k];
+      prev_par[k] = stop ? prev_par[k] : x[k];
     }
-    prev_score = current_score;
-    prev_par[0] = x[0]; prev_par[1] = x[1]; prev_par[2] = x[2];
+    prev_score = stop ? prev_score : current_score;
+    if (stop) break;
   }
   if (threadIdx.x == 0) {
     res->pose[0] = x[0]; res->pose[1] = x[1]; res->pose[2] = x[2];
