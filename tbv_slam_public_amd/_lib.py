@@ -135,6 +135,13 @@ def lib():
         return _LIB
     if not os.path.exists(SO_PATH):
         raise ImportError("libcfear_hip.so not built: run `make -C %s/csrc` (or __graft_entry__.build())" % _HERE)
+    # PyTorch-ROCm bundles its own libamdhip64; it must be the process's HIP runtime BEFORE this
+    # library is loaded, otherwise two runtimes coexist and torch device pointers / streams cannot be
+    # shared with the kernels (torch is plumbing here: device memory, streams, torch.distributed).
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(SO_PATH)
     vp = C.c_void_p
     L.cfear_abi_version.restype = C.c_int

@@ -102,6 +102,29 @@ ScanView cfear_scan_view(void* slab, int cap);
 int cfear_scan_alloc(cfear_ctx* ctx, int cap, cfear_scan** out);
 
 // ---------------------------------------------------------------------------------------------
+// cross-file entry points (device-pointer level; used by the batched odometry pipeline)
+// ---------------------------------------------------------------------------------------------
+int cfear_kstrong_device(cfear_ctx* ctx, const uint8_t* d_polar, const cfear_polar_desc* desc,
+                         const cfear_kstrong_params* par, const cfear_kstrong_out* o);
+int cfear_cacfar_device(cfear_ctx* ctx, const uint8_t* d_polar, const cfear_polar_desc* desc,
+                        const cfear_cacfar_params* par, float* d_xyzi, int32_t* d_n_points,
+                        int32_t cap_points, uint8_t* d_det_mask);
+size_t cfear_surface_lds_bytes();
+size_t cfear_surface_scratch_bytes();
+size_t cfear_surface_job_bytes();
+int cfear_surface_max_points();
+void cfear_surface_fill_job(void* dst, float* d_xyzi, const int32_t* d_n, int32_t n_host, int compensate,
+                            const double mot[3], const ScanView& out);
+int cfear_surface_launch(cfear_ctx* ctx, const void* d_jobs, int n_jobs, const cfear_feature_params* par,
+                         char* d_scratch, int32_t* d_status, int32_t* d_ncells_out);
+size_t cfear_reg_job_bytes();
+int cfear_reg_max_scans();
+void cfear_reg_fill_job(void* dst, const ScanView* views, int n_scans, const double* poses_xyt);
+size_t cfear_register_scratch_bytes(int slots_cap);
+int cfear_register_launch(cfear_ctx* ctx, const void* d_jobs, int n_jobs, const cfear_reg_params* par, int slots_cap,
+                          int lds_targets, char* d_scratch, cfear_reg_result* d_results);
+
+// ---------------------------------------------------------------------------------------------
 // device helpers
 // ---------------------------------------------------------------------------------------------
 #if defined(__HIPCC__)

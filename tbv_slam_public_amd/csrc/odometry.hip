@@ -1,8 +1,321 @@
-// odometry.hip -- placeholder, replaced below in this round.
+// odometry.hip -- batched radarDriver + OdometryKeyframeFuser: n_streams independent sequences advance
+// one frame per call, polar image in -> SE(2) pose out, everything in between on the GPU.
+//
+// Restates per stream (cfear_radarodometry/src/cfear_radarodometry/):
+//   radarDriver::CallbackOffline / Process            radar_driver.cpp:48-73, 163-176
+//   OdometryKeyframeFuser::processFrame               odometrykeyframefuser.cpp:143-259
+//     KeyFrameBasedFuse                               :62-73
+//     AccelerationVelocitySanityCheck                 :76-94
+//     FormatScans / AddToReference                    :470-494
+// The frame policy (constant-velocity guess, sanity check, keyframe test, sliding keyframe window)
+// is host code exactly as in the reference; the four stages F, C, N, M are three kernel launches
+// over the whole batch (kstrongest_rows + kstrong_cloud, surface_points, register) and one small
+// read-back (pose, counts) per call.
+#include <cmath>
+
 #include "common.hpp"
-extern "C" int cfear_odometry_create(cfear_ctx* ctx, int32_t, const cfear_polar_desc*, const cfear_odometry_params*, cfear_odometry** out) {
-  if (out) *out = nullptr;
-  return cfear_set_error(ctx, CFEAR_ERR_INVALID_ARGUMENT, "odometry pipeline not built yet");
+
+namespace {
+
+struct Aff2 { double l[4]; double t[2]; };
+Aff2 aff_identity() { return Aff2{{1, 0, 0, 1}, {0, 0}}; }
+Aff2 aff_from_xyt(double x, double y, double th) {      // registration.cpp:128-135 vectorToAffine3d
+  const double c = std::cos(th), s = std::sin(th);
+  return Aff2{{c, -s, s, c}, {x, y}};
 }
-extern "C" int cfear_odometry_process(cfear_odometry*, const uint8_t*, cfear_frame_info*) { return CFEAR_ERR_INVALID_ARGUMENT; }
-extern "C" int cfear_odometry_destroy(cfear_odometry*) { return CFEAR_OK; }
+Aff2 aff_mul(const Aff2& a, const Aff2& b) {
+  Aff2 r;
+  r.l[0] = a.l[0] * b.l[0] + a.l[1] * b.l[2];
+  r.l[1] = a.l[0] * b.l[1] + a.l[1] * b.l[3];
+  r.l[2] = a.l[2] * b.l[0] + a.l[3] * b.l[2];
+  r.l[3] = a.l[2] * b.l[1] + a.l[3] * b.l[3];
+  r.t[0] = a.l[0] * b.t[0] + a.l[1] * b.t[1] + a.t[0];
+  r.t[1] = a.l[2] * b.t[0] + a.l[3] * b.t[1] + a.t[1];
+  return r;
+}
+Aff2 aff_inv(const Aff2& a) {                            // Eigen Affine inverse
+  const double det = a.l[0] * a.l[3] - a.l[2] * a.l[1];
+  const double invdet = 1.0 / det;
+  Aff2 r;
+  r.l[0] = a.l[3] * invdet; r.l[1] = -a.l[1] * invdet; r.l[2] = -a.l[2] * invdet; r.l[3] = a.l[0] * invdet;
+  r.t[0] = -(r.l[0] * a.t[0] + r.l[1] * a.t[1]);
+  r.t[1] = -(r.l[2] * a.t[0] + r.l[3] * a.t[1]);
+  return r;
+}
+void aff_to_xyt(const Aff2& a, double p[3]) {            // utils.cpp:115-122 Affine3dToVectorXYeZ
+  p[0] = a.t[0]; p[1] = a.t[1]; p[2] = std::atan2(a.l[2], a.l[3]);
+}
+
+struct Keyframe { int slab; Aff2 pose; };
+struct Stream {
+  Aff2 T_prev = aff_identity(), Tmot = aff_identity(), Tcurrent = aff_identity();
+  std::vector<Keyframe> keyframes;
+  std::vector<int> free_slabs;
+  int cur_slab = -1;
+  Aff2 Tguess = aff_identity();
+  int job = -1;              // index into this call's registration batch, -1 = first frame
+};
+
+}  // namespace
+
+struct cfear_odometry {
+  cfear_ctx* ctx = nullptr;
+  int n_streams = 0;
+  cfear_polar_desc desc{};
+  cfear_odometry_params par{};
+  int cap_points = 0, cell_cap = 0, slabs_per_stream = 0;
+  size_t slab_bytes = 0;
+  // device memory (one allocation each)
+  uint8_t* d_polar = nullptr;          // staging when the caller passes host images
+  char* d_sel = nullptr;               // sel_range | sel_intensity | sel_count
+  float* d_xyzi = nullptr;
+  int32_t* d_npts = nullptr;
+  char* d_slabs = nullptr;
+  char* d_surf_jobs = nullptr;
+  char* d_reg_jobs = nullptr;
+  cfear_reg_result* d_results = nullptr;
+  int32_t* d_status = nullptr;
+  int32_t* d_ncells = nullptr;         // gathered n_cells of the current scans
+  char* d_surf_scratch = nullptr;
+  char* d_reg_scratch = nullptr;
+  // pinned host mirrors
+  char* h_surf_jobs = nullptr;
+  char* h_reg_jobs = nullptr;
+  cfear_reg_result* h_results = nullptr;
+  int32_t* h_status = nullptr;
+  int32_t* h_npts = nullptr;
+  int32_t* h_ncells = nullptr;
+  std::vector<Stream> streams;
+  std::vector<ScanView> views;         // [n_streams * slabs_per_stream]
+};
+
+namespace {
+
+template <typename T>
+bool dalloc(T** p, size_t bytes) {
+  if (hipMalloc((void**)p, bytes ? bytes : 256) != hipSuccess) { (void)hipGetLastError(); *p = nullptr; return false; }
+  return true;
+}
+template <typename T>
+bool halloc(T** p, size_t bytes) {
+  if (hipHostMalloc((void**)p, bytes ? bytes : 256, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); *p = nullptr; return false; }
+  return true;
+}
+
+}  // namespace
+
+extern "C" int cfear_odometry_destroy(cfear_odometry* od) {
+  if (!od) return CFEAR_OK;
+  (void)hipSetDevice(od->ctx->device);
+  (void)hipStreamSynchronize(od->ctx->stream);
+  void* dev[] = {od->d_polar, od->d_sel, od->d_xyzi, od->d_npts, od->d_slabs, od->d_surf_jobs, od->d_reg_jobs,
+                 od->d_results, od->d_status, od->d_ncells, od->d_surf_scratch, od->d_reg_scratch};
+  for (void* p : dev) if (p) (void)hipFree(p);
+  void* host[] = {od->h_surf_jobs, od->h_reg_jobs, od->h_results, od->h_status, od->h_npts, od->h_ncells};
+  for (void* p : host) if (p) (void)hipHostFree(p);
+  delete od;
+  return CFEAR_OK;
+}
+
+extern "C" int cfear_odometry_create(cfear_ctx* ctx, int32_t n_streams, const cfear_polar_desc* desc,
+                                     const cfear_odometry_params* par, cfear_odometry** out) {
+  if (!ctx) return CFEAR_ERR_INVALID_ARGUMENT;
+  if (!desc || !par || !out || n_streams < 1) return cfear_set_error(ctx, CFEAR_ERR_INVALID_ARGUMENT, "null argument");
+  *out = nullptr;
+  if (desc->batch != n_streams) return cfear_set_error(ctx, CFEAR_ERR_INVALID_ARGUMENT, "desc.batch must equal n_streams");
+  if (par->submap_scan_size < 1 || par->submap_scan_size + 1 > cfear_reg_max_scans())
+    return cfear_set_error(ctx, CFEAR_ERR_INVALID_ARGUMENT, "submap_scan_size must be in [1,%d]", cfear_reg_max_scans() - 1);
+  if (!(par->res > 0.05f)) return cfear_set_error(ctx, CFEAR_ERR_INVALID_ARGUMENT, "res must be > 0.05");   // odometrykeyframefuser.cpp:25
+  CFEAR_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  cfear_odometry* od = new cfear_odometry();
+  od->ctx = ctx; od->n_streams = n_streams; od->desc = *desc; od->par = *par;
+  const int B = n_streams, rows = desc->rows, k = par->kstrong.k_strongest;
+  od->cap_points = par->filter_type == CFEAR_FILTER_CACFAR ? cfear_surface_max_points()
+                                                           : std::min(rows * k, cfear_surface_max_points());
+  od->cell_cap = 2048;
+  od->slabs_per_stream = par->submap_scan_size + 2;
+  od->slab_bytes = cfear_scan_slab_bytes(od->cell_cap);
+  const size_t nsel = (size_t)B * rows * std::max(k, 1);
+  bool ok = true;
+  ok = ok && dalloc(&od->d_sel, nsel * 4 + nsel + (size_t)B * rows * 4 + 1024);
+  ok = ok && dalloc(&od->d_xyzi, (size_t)B * od->cap_points * 16);
+  ok = ok && dalloc(&od->d_npts, (size_t)B * 4);
+  ok = ok && dalloc(&od->d_slabs, (size_t)B * od->slabs_per_stream * od->slab_bytes);
+  ok = ok && dalloc(&od->d_surf_jobs, (size_t)B * cfear_surface_job_bytes());
+  ok = ok && dalloc(&od->d_reg_jobs, (size_t)B * cfear_reg_job_bytes());
+  ok = ok && dalloc(&od->d_results, (size_t)B * sizeof(cfear_reg_result));
+  ok = ok && dalloc(&od->d_status, (size_t)B * 4);
+  ok = ok && dalloc(&od->d_ncells, (size_t)B * 4);
+  ok = ok && dalloc(&od->d_surf_scratch, (size_t)B * cfear_surface_scratch_bytes());
+  ok = ok && dalloc(&od->d_reg_scratch, (size_t)B * cfear_register_scratch_bytes(par->submap_scan_size * od->cell_cap));
+  ok = ok && halloc(&od->h_surf_jobs, (size_t)B * cfear_surface_job_bytes());
+  ok = ok && halloc(&od->h_reg_jobs, (size_t)B * cfear_reg_job_bytes());
+  ok = ok && halloc(&od->h_results, (size_t)B * sizeof(cfear_reg_result));
+  ok = ok && halloc(&od->h_status, (size_t)B * 4);
+  ok = ok && halloc(&od->h_npts, (size_t)B * 4);
+  ok = ok && halloc(&od->h_ncells, (size_t)B * 4);
+  if (!ok) { cfear_odometry_destroy(od); return cfear_set_error(ctx, CFEAR_ERR_HIP, "odometry buffers: allocation failed"); }
+  od->streams.resize(B);
+  od->views.resize((size_t)B * od->slabs_per_stream);
+  for (int b = 0; b < B; b++) {
+    for (int s = 0; s < od->slabs_per_stream; s++) {
+      od->views[(size_t)b * od->slabs_per_stream + s] =
+          cfear_scan_view(od->d_slabs + ((size_t)b * od->slabs_per_stream + s) * od->slab_bytes, od->cell_cap);
+      od->streams[b].free_slabs.push_back(od->slabs_per_stream - 1 - s);
+    }
+  }
+  *out = od;
+  return CFEAR_OK;
+}
+
+extern "C" int cfear_odometry_process(cfear_odometry* od, const uint8_t* polar, cfear_frame_info* info) {
+  if (!od || !polar || !info) return CFEAR_ERR_INVALID_ARGUMENT;
+  cfear_ctx* ctx = od->ctx;
+  CFEAR_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  const int B = od->n_streams, rows = od->desc.rows, k = od->par.kstrong.k_strongest;
+  const cfear_odometry_params& par = od->par;
+  // ---- F: filter (radar_driver.cpp:48-73) -----------------------------------------------------
+  const uint8_t* d_polar = polar;
+  cfear_polar_desc dd = od->desc;
+  if (!cfear_is_device_ptr(polar)) {
+    const size_t img_bytes = (size_t)rows * od->desc.stride;
+    if (!od->d_polar && !dalloc(&od->d_polar, img_bytes * B)) return cfear_set_error(ctx, CFEAR_ERR_HIP, "staging allocation failed");
+    const int64_t bs = B > 1 ? od->desc.batch_stride : (int64_t)img_bytes;
+    for (int b = 0; b < B; b++)
+      CFEAR_HIP_CHECK(ctx, hipMemcpyAsync(od->d_polar + (size_t)b * img_bytes, polar + (size_t)b * bs, img_bytes,
+                                          hipMemcpyHostToDevice, ctx->stream));
+    d_polar = od->d_polar;
+    dd.batch_stride = (int64_t)img_bytes;
+  }
+  int rc;
+  if (par.filter_type == CFEAR_FILTER_CACFAR) {
+    cfear_cacfar_params cp = par.cacfar;
+    rc = cfear_cacfar_device(ctx, d_polar, &dd, &cp, od->d_xyzi, od->d_npts, od->cap_points, nullptr);
+  } else {
+    const size_t nsel = (size_t)B * rows * k;
+    cfear_kstrong_out o{};
+    o.sel_range = (int32_t*)od->d_sel;
+    o.sel_intensity = (uint8_t*)(od->d_sel + nsel * 4);
+    o.sel_count = (int32_t*)(od->d_sel + nsel * 4 + (nsel + 255) / 256 * 256);
+    o.xyzi = od->d_xyzi;
+    o.n_points = od->d_npts;
+    cfear_kstrong_params kp = par.kstrong;
+    kp.want_peaks = 0;     // the peaks cloud feeds CorAl / Scan Context, not the matcher
+    if (od->cap_points != rows * k)
+      return cfear_set_error(ctx, CFEAR_ERR_CAPACITY, "rows*k = %d exceeds %d points per scan", rows * k, od->cap_points);
+    rc = cfear_kstrong_device(ctx, d_polar, &dd, &kp, &o);
+  }
+  if (rc != CFEAR_OK) return rc;
+  // ---- C + N: compensate with the previous motion, surface points (odometrykeyframefuser.cpp:146-161)
+  const size_t sjb = cfear_surface_job_bytes();
+  for (int b = 0; b < B; b++) {
+    Stream& st = od->streams[b];
+    st.cur_slab = st.free_slabs.back();
+    st.free_slabs.pop_back();
+    double mot[3];
+    aff_to_xyt(st.Tmot, mot);                                     // Compensate(cloud, TprevMot, ccw)
+    cfear_surface_fill_job(od->h_surf_jobs + (size_t)b * sjb, od->d_xyzi + (size_t)b * od->cap_points * 4,
+                           od->d_npts + b, 0, par.compensate, mot, od->views[(size_t)b * od->slabs_per_stream + st.cur_slab]);
+  }
+  CFEAR_HIP_CHECK(ctx, hipMemcpyAsync(od->d_surf_jobs, od->h_surf_jobs, (size_t)B * sjb, hipMemcpyHostToDevice, ctx->stream));
+  cfear_feature_params fp{};
+  fp.radius = par.res;
+  fp.downsample_factor = par.downsample_factor;
+  fp.origin[0] = fp.origin[1] = 0.0;                              // Eigen::Vector2d(0,0), :161
+  fp.weight_intensity = par.weight_intensity;
+  fp.ccw = par.radar_ccw;
+  rc = cfear_surface_launch(ctx, od->d_surf_jobs, B, &fp, od->d_surf_scratch, od->d_status, od->d_ncells);
+  if (rc != CFEAR_OK) return rc;
+  // ---- M: Register against the keyframe window (:164-186) --------------------------------------
+  const size_t rjb = cfear_reg_job_bytes();
+  int n_jobs = 0;
+  std::vector<ScanView> views(cfear_reg_max_scans());
+  std::vector<double> poses(3 * (size_t)cfear_reg_max_scans());
+  for (int b = 0; b < B; b++) {
+    Stream& st = od->streams[b];
+    st.Tguess = par.use_guess ? aff_mul(st.T_prev, st.Tmot) : st.T_prev;      // :164-168
+    st.job = -1;
+    if (st.keyframes.empty()) continue;                                       // :171-177 first frame
+    const int ns = (int)st.keyframes.size() + 1;                              // FormatScans :478-494
+    for (int i = 0; i < ns - 1; i++) {
+      views[i] = od->views[(size_t)b * od->slabs_per_stream + st.keyframes[i].slab];
+      aff_to_xyt(st.keyframes[i].pose, &poses[3 * i]);
+    }
+    views[ns - 1] = od->views[(size_t)b * od->slabs_per_stream + st.cur_slab];
+    aff_to_xyt(st.Tguess, &poses[3 * (ns - 1)]);
+    cfear_reg_fill_job(od->h_reg_jobs + (size_t)n_jobs * rjb, views.data(), ns, poses.data());
+    st.job = n_jobs++;
+  }
+  if (n_jobs > 0) {
+    CFEAR_HIP_CHECK(ctx, hipMemcpyAsync(od->d_reg_jobs, od->h_reg_jobs, (size_t)n_jobs * rjb, hipMemcpyHostToDevice, ctx->stream));
+    rc = cfear_register_launch(ctx, od->d_reg_jobs, n_jobs, &par.reg, par.submap_scan_size * od->cell_cap, od->cell_cap,
+                               od->d_reg_scratch, od->d_results);
+    if (rc != CFEAR_OK) return rc;
+    CFEAR_HIP_CHECK(ctx, hipMemcpyAsync(od->h_results, od->d_results, (size_t)n_jobs * sizeof(cfear_reg_result),
+                                        hipMemcpyDeviceToHost, ctx->stream));
+  }
+  CFEAR_HIP_CHECK(ctx, hipMemcpyAsync(od->h_status, od->d_status, (size_t)B * 4, hipMemcpyDeviceToHost, ctx->stream));
+  CFEAR_HIP_CHECK(ctx, hipMemcpyAsync(od->h_npts, od->d_npts, (size_t)B * 4, hipMemcpyDeviceToHost, ctx->stream));
+  CFEAR_HIP_CHECK(ctx, hipMemcpyAsync(od->h_ncells, od->d_ncells, (size_t)B * 4, hipMemcpyDeviceToHost, ctx->stream));
+  CFEAR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  // ---- frame policy (:195-257) ------------------------------------------------------------------
+  int first_error = CFEAR_OK;
+  for (int b = 0; b < B; b++) {
+    Stream& st = od->streams[b];
+    cfear_frame_info& fi = info[b];
+    memset(&fi, 0, sizeof(fi));
+    fi.n_points = od->h_npts[b];
+    fi.n_cells = od->h_ncells[b];
+    if (od->h_status[b] != CFEAR_OK) {
+      // empty cloud / capacity: the reference would exit(0) (pointnormal.cpp:72-75); report and keep the state
+      if (first_error == CFEAR_OK)
+        first_error = cfear_set_error(ctx, od->h_status[b], "stream %d: surface points failed (%s)", b, cfear_status_string(od->h_status[b]));
+      fi.reg_status = od->h_status[b];
+      st.free_slabs.push_back(st.cur_slab);
+      aff_to_xyt(st.Tcurrent, fi.pose);
+      continue;
+    }
+    if (st.job < 0) {                                             // first frame becomes the first keyframe
+      st.keyframes.push_back(Keyframe{st.cur_slab, aff_identity()});
+      fi.keyframe_added = 1;
+      fi.reg_status = 1;
+      aff_to_xyt(st.Tcurrent, fi.pose);
+      continue;
+    }
+    const cfear_reg_result& rr = od->h_results[st.job];
+    fi.reg_status = rr.status; fi.outer_iters = rr.outer_iters; fi.lm_iters = rr.lm_iters; fi.score = rr.score;
+    // Tcurrent = T_vek.back(): Register rewrites Tsrc via vectorToAffine3d (registration failures are
+    // ignored by the reference: `bool success` is shadowed, odometrykeyframefuser.cpp:184-193)
+    Aff2 Tcurrent = aff_from_xyt(rr.pose[0], rr.pose[1], rr.pose[2]);
+    {                                                             // AccelerationVelocitySanityCheck :76-94
+      const Aff2 Tmot_current = aff_mul(aff_inv(st.T_prev), Tcurrent);
+      const double dt = 0.25, vel_limit = 200, acc_limit = 200;
+      const double vel = std::sqrt((Tmot_current.t[0] / dt) * (Tmot_current.t[0] / dt) + (Tmot_current.t[1] / dt) * (Tmot_current.t[1] / dt));
+      const double ax = (Tmot_current.t[0] - st.Tmot.t[0]) / (dt * dt), ay = (Tmot_current.t[1] - st.Tmot.t[1]) / (dt * dt);
+      const double acc = std::sqrt(ax * ax + ay * ay);
+      if (acc > acc_limit || vel > vel_limit) Tcurrent = st.Tguess;           // :198-199
+    }
+    st.Tmot = aff_mul(aff_inv(st.T_prev), Tcurrent);              // :200
+    const Aff2 Tkeydiff = aff_mul(aff_inv(st.keyframes.back().pose), Tcurrent);
+    bool fuse = true;                                             // KeyFrameBasedFuse :62-73
+    if (par.use_keyframe) {
+      const double tn = std::sqrt(Tkeydiff.t[0] * Tkeydiff.t[0] + Tkeydiff.t[1] * Tkeydiff.t[1]);
+      const double rot = std::fabs(std::atan2(Tkeydiff.l[2], Tkeydiff.l[3]));
+      fuse = tn > par.min_keyframe_dist || rot > (par.min_keyframe_rot_deg * M_PI / 180.0);
+    }
+    if (fuse) {                                                   // :236-250, AddToReference :470-476
+      st.keyframes.push_back(Keyframe{st.cur_slab, Tcurrent});
+      if ((int)st.keyframes.size() > par.submap_scan_size) {
+        st.free_slabs.push_back(st.keyframes.front().slab);
+        st.keyframes.erase(st.keyframes.begin());
+      }
+      fi.keyframe_added = 1;
+    } else {
+      st.free_slabs.push_back(st.cur_slab);
+    }
+    st.Tcurrent = Tcurrent;
+    st.T_prev = Tcurrent;                                         // :257
+    aff_to_xyt(Tcurrent, fi.pose);
+  }
+  return first_error;
+}

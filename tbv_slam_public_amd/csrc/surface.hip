@@ -56,6 +56,7 @@ struct SurfCommon {
   char* scratch;
   size_t scratch_stride;
   int32_t* status;                            // [n_jobs] CFEAR_OK / error
+  int32_t* ncells_out;                        // [n_jobs] dense copy of the cell counts (nullable)
 };
 
 struct TmpCell {                              // one candidate cell per voxel (before compaction)
@@ -140,11 +141,11 @@ __global__ __launch_bounds__(kSurfThreads) void surface_points_kernel(const Surf
   int n = job.n_ptr ? *job.n_ptr : job.n_host;
   int32_t* status = cm.status + blockIdx.x;
   if (n <= 0) {
-    if (tid == 0) { *job.out.n_cells = 0; *status = CFEAR_ERR_EMPTY_CLOUD; }
+    if (tid == 0) { *job.out.n_cells = 0; *status = CFEAR_ERR_EMPTY_CLOUD; if (cm.ncells_out) cm.ncells_out[blockIdx.x] = 0; }
     return;
   }
   if (n > kMaxPoints) {
-    if (tid == 0) { *job.out.n_cells = 0; *status = CFEAR_ERR_CAPACITY; }
+    if (tid == 0) { *job.out.n_cells = 0; *status = CFEAR_ERR_CAPACITY; if (cm.ncells_out) cm.ncells_out[blockIdx.x] = 0; }
     return;
   }
   float4* pts = job.xyzi;
@@ -183,7 +184,7 @@ __global__ __launch_bounds__(kSurfThreads) void surface_points_kernel(const Surf
   const int min_by = (int)floorf(mny * cm.inv_leaf), max_by = (int)floorf(mxy * cm.inv_leaf);
   const long long div_bx = (long long)max_bx - min_bx + 1, div_by = (long long)max_by - min_by + 1;
   if (div_bx * div_by > 0x7fffffffLL || div_by > kMaxGridRows) {
-    if (tid == 0) { *job.out.n_cells = 0; *status = CFEAR_ERR_CAPACITY; }
+    if (tid == 0) { *job.out.n_cells = 0; *status = CFEAR_ERR_CAPACITY; if (cm.ncells_out) cm.ncells_out[blockIdx.x] = 0; }
     return;
   }
   const int dbx = (int)div_bx, dby = (int)div_by;
@@ -414,6 +415,7 @@ __global__ __launch_bounds__(kSurfThreads) void surface_points_kernel(const Surf
     const int total = sh_misc[0];
     *job.out.n_cells = total <= job.out.cap ? total : job.out.cap;
     *status = total <= job.out.cap ? CFEAR_OK : CFEAR_ERR_CAPACITY;
+    if (cm.ncells_out) cm.ncells_out[blockIdx.x] = total <= job.out.cap ? total : job.out.cap;
   }
 }
 
@@ -471,7 +473,7 @@ void cfear_surface_fill_job(void* dst, float* d_xyzi, const int32_t* d_n, int32_
 }
 
 int cfear_surface_launch(cfear_ctx* ctx, const void* d_jobs, int n_jobs, const cfear_feature_params* par,
-                         char* d_scratch, int32_t* d_status) {
+                         char* d_scratch, int32_t* d_status, int32_t* d_ncells_out) {
   if (par->radius <= 0.f || !(par->downsample_factor > 0.0))
     return cfear_set_error(ctx, CFEAR_ERR_INVALID_ARGUMENT, "radius / downsample_factor must be > 0");
   SurfCommon cm;
@@ -489,6 +491,7 @@ int cfear_surface_launch(cfear_ctx* ctx, const void* d_jobs, int n_jobs, const c
   cm.scratch = d_scratch;
   cm.scratch_stride = scratch_bytes_per_scan();
   cm.status = d_status;
+  cm.ncells_out = d_ncells_out;
   static bool attr_set = false;
   if (!attr_set) {
     CFEAR_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)surface_points_kernel,
@@ -552,7 +555,7 @@ extern "C" int cfear_scan_create(cfear_ctx* ctx, float* xyzi, int32_t n, const c
   cfear_surface_fill_job(hjob, d, nullptr, n, par->compensate, par->mot, s->view);
   CFEAR_HIP_CHECK(ctx, hipMemcpyAsync(d_job, hjob, sizeof(SurfJob), hipMemcpyHostToDevice, ctx->stream));
   CFEAR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));     // hjob is on the stack
-  rc = cfear_surface_launch(ctx, d_job, 1, par, d_scratch, d_status);
+  rc = cfear_surface_launch(ctx, d_job, 1, par, d_scratch, d_status, nullptr);
   if (rc != CFEAR_OK) { cfear_scan_destroy(s); return rc; }
   int32_t hst[2] = {0, 0};
   CFEAR_HIP_CHECK(ctx, hipMemcpyAsync(&hst[0], d_status, 4, hipMemcpyDeviceToHost, ctx->stream));
