@@ -1,0 +1,195 @@
+#!/usr/bin/env python
+"""bench.py -- CFEAR scan registrations/s on MI355X (BASELINE.json metric).
+
+Workload (BASELINE.json configs[1], "Oxford 10k sequence, per-frame odometry registration streamed on
+1xMI355X"): `--streams` independent synthetic Oxford-like sequences (400 x 3360 uint8 polar sweeps,
+CFEAR-3 preset: k=40, z_min=60, r=3, P2P/Huber 0.1/weights 4, 4-keyframe window) each advance one
+frame per step.  One step = one pass of the whole hot path over the batch: k-strongest filter ->
+motion compensation -> oriented surface points -> many-to-one registration -> keyframe policy, polar
+image in, SE(2) pose out.  All polar images are resident in HBM before the timed region; every
+stream has its own physical copy of its frames.  value = streams * steps / time, aggregated over
+ranks (weak scaling: every rank runs its own `--streams` sequences, no collective on the data path).
+
+Also reports: roofline of the only kernel that moves compulsory HBM bytes (kstrongest_rows, the
+polar sweep) from hipEvent timings taken inside the timed region, the per-kernel time breakdown,
+the CPU oracle timed on the host (1 thread) on a bounded sample of the same frames, and the pose
+error of the GPU path against that CPU path.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+ROWS, COLS, K_STRONGEST = 400, 3360, 40
+N_SEEDS = 16                     # distinct synthetic sequences; streams replicate them round-robin
+HBM_PEAK_GBS = 8000.0            # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--streams", type=int, default=512, help="independent sequences per GPU")
+    ap.add_argument("--cpu-frames", type=int, default=0, help="frames of CPU baseline (0 = auto, ~10-30 s)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from tbv_slam_public_amd import api, synth
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    B, K, W = args.streams, args.steps, max(args.warmup, 1)   # frame 0 of a stream is not a registration
+    F = W + K
+    # ---- synthetic input, resident in HBM: [F][B][ROWS][COLS] uint8 -------------------------------
+    t0 = time.time()
+    base = []
+    for sd in range(min(N_SEEDS, B)):
+        sc = synth.Scene(1000 * rank + sd)
+        base.append(np.stack([sc.render(f, F) for f in range(F)]))
+    base = np.stack(base)                                            # [S][F][R][C]
+    dbase = torch.from_numpy(base).to(dev)
+    frames = torch.empty((F, B, ROWS, COLS), dtype=torch.uint8, device=dev)
+    for b in range(B):
+        frames[:, b] = dbase[b % dbase.shape[0]]                     # a physical copy per stream
+    del dbase
+    torch.cuda.synchronize()
+    t_gen = time.time() - t0
+
+    stream = torch.cuda.current_stream().cuda_stream
+    ctx = api.Context(local_rank, stream=stream)
+    od = api.OdometryKeyframeFuser(B, ROWS, COLS, api.odometry_params(), ctx=ctx)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+
+    for f in range(W):
+        info = od.process(frames[f])
+    barrier()
+    ctx.profile_enable(True)
+    ctx.profile_read(reset=True)
+    poses = np.zeros((K, B, 3))
+    n_points = np.zeros((K, B), np.int64)
+    n_cells = np.zeros((K, B), np.int64)
+    status_bad = 0
+    t1 = time.perf_counter()
+    for s in range(K):
+        info = od.process(frames[W + s])
+        poses[s] = info["pose"]
+        n_points[s] = info["n_points"]
+        n_cells[s] = info["n_cells"]
+        status_bad += int((info["reg_status"] != 0).sum())
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t2 = time.perf_counter()
+    elapsed = t2 - t1
+    prof = ctx.profile_read(reset=True)
+    ctx.profile_enable(False)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        bad = torch.tensor([status_bad], dtype=torch.int64, device=dev)
+        dist.all_reduce(bad)
+        status_bad = int(bad.item())
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    total_units = B * K * world
+    value = total_units / elapsed
+    # ---- roofline of the polar sweep (kstrongest_rows) ------------------------------------------------
+    ms, launches = prof.get("kstrongest_rows", (0.0, 0))
+    avg_ms = ms / max(launches, 1)
+    nf = float(n_points.mean())
+    # algorithmic bytes per scan filtered = R*C + 16*N_f + 4*R, N_f = points kept
+    bytes_per_scan = ROWS * COLS + 16.0 * nf + 4 * ROWS
+    achieved = (bytes_per_scan * B) / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+    breakdown = {k: {"ms_per_step": v[0] / max(K, 1), "launches": int(v[1])} for k, v in prof.items()}
+
+    # ---- CPU baseline: the oracle (port), 1 thread, bounded sample of the same frames -----------------
+    cpu = None
+    pose_err = None
+    if not args.no_cpu_baseline and world == 1:        # rank 0 at N=1 only
+        from oracle import pyoracle as O
+        n_seq = min(base.shape[0], 4)
+        budget_frames = args.cpu_frames or n_seq * F
+        reg = O.reg_params(cost="P2P", loss="Huber", loss_limit=0.1, weight_opt=4, regularization=0.0)
+        done, tc0 = 0, time.perf_counter()
+        err_xy, err_th = 0.0, 0.0
+        for sd in range(n_seq):
+            fz = O.Fuser(reg, res=3.0, submap_scan_size=4, weight_intensity=True)
+            for f in range(F):
+                if done >= budget_frames:
+                    break
+                sr, si, scn = O.kstrongest(base[sd, f], K_STRONGEST, 60)
+                cloud = O.kstrongest_cloud(sr, si, scn, 0.0438, 2.5)
+                pose, oi = fz.process(cloud)
+                done += 1
+                if f >= W:
+                    d = np.abs(poses[f - W, sd] - pose)
+                    err_xy, err_th = max(err_xy, d[:2].max()), max(err_th, d[2])
+        tc = time.perf_counter() - tc0
+        cpu = {"value": done / tc, "unit": "registrations/s", "cores": 1, "kind": "port",
+               "sample": "%d frames (%d sequences x %d frames of this run's input), full path filter->pose, "
+                         "oracle/liboracle.so g++ -O3, 1 thread; host has %d cores"
+                         % (done, n_seq, F, os.cpu_count())}
+        pose_err = {"max_abs_xy_m": err_xy, "max_abs_theta_rad": err_th, "frames_compared": int(min(done, n_seq * K))}
+
+    out = {
+        "metric": "radar scan registrations/sec (400x3360 polar)",
+        "value": value,
+        "unit": "registrations/s",
+        "n_gpus": world,
+        "steps": K,
+        "warmup": W,
+        "ms_per_step": elapsed / K * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "u8 filter / f32 search / f64 solve",
+        "data": "synthetic (scene_v1 walls+scatterers, %d distinct sequences replicated to %d streams per GPU, "
+                "each stream its own HBM copy)" % (base.shape[0], B),
+        "config": {"workload": "configs[1]: per-frame CFEAR-3 odometry registration (k=40, z_min=60, r=3, P2P, "
+                               "4-keyframe window), polar image -> pose, %d streams in flight per GPU" % B,
+                   "streams_per_gpu": B, "rows": ROWS, "cols": COLS, "parallelism": "replicas x%d" % world},
+        "roofline": {"bound": "hbm", "kernel": "kstrongest_rows", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "avg_launch_ms": avg_ms, "algorithmic_bytes_per_launch": bytes_per_scan * B,
+                     "mean_points_per_scan": nf},
+        "cpu_baseline": cpu,
+        "pose_error_vs_cpu": pose_err,
+        "kernel_breakdown": breakdown,
+        "mean_cells_per_scan": float(n_cells.mean()),
+        "failed_registrations": status_bad,
+        "input_generation_s": t_gen,
+    }
+    print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

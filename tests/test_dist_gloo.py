@@ -1,0 +1,108 @@
+"""CPU, world_size 2, gloo: the candidate-batch sharding + result all_gather of dist.py.  The per-rank
+compute is injected (here: the CPU oracle) because the product has no CPU path."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from tbv_slam_public_amd import _lib as L
+from tbv_slam_public_amd import dist as cdist
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _make_jobs(n):
+    from oracle import pyoracle as O
+    from tbv_slam_public_amd import synth
+    imgs, gt, _ = synth.scene_v1(9, 3)
+    cells = []
+    for f in range(3):
+        sr, si, sc = O.kstrongest(imgs[f], 12, 60)
+        cells.append(O.surface_points(O.kstrongest_cloud(sr, si, sc, 0.0438, 2.5), 3.5, 1.0, (0, 0), False))
+    rng = np.random.default_rng(5)
+    jobs = []
+    for i in range(n):
+        a, b = rng.choice(3, size=2, replace=False)
+        guess = np.array([2.5 * (b - a), 0.0, 0.0]) + rng.normal(0, 0.3, 3) * [1, 1, 0.05]
+        jobs.append(([cells[a], cells[b]], np.array([[0, 0, 0], guess])))
+    return jobs
+
+
+def _oracle_fn(jobs):
+    from oracle import pyoracle as O
+    par = O.reg_params(cost="P2L", max_outer=4, max_inner=10)
+    out = np.zeros(len(jobs), L.RESULT_DTYPE)
+    for i, (cells, T) in enumerate(jobs):
+        ok, p, r = O.register(cells, T, par)
+        out[i]["pose"] = p[-1]
+        out[i]["score"], out[i]["final_cost"] = r.score, r.final_cost
+        out[i]["num_residuals"], out[i]["outer_iters"], out[i]["lm_iters"] = r.num_residuals, r.outer_iters, r.lm_iters
+        out[i]["status"] = 0 if ok else L.ERR_SOLVER
+    return out
+
+
+def _worker(rank, world, port, n, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    jobs = _make_jobs(n)
+    calls = []
+
+    def fn(local):
+        calls.append(len(local))
+        return _oracle_fn(local)
+    out = cdist.register_candidates_sharded(jobs, fn)
+    q.put((rank, calls[0], out.tobytes()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n", [7, 8])
+def test_sharded_candidates_match_serial(n):
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    serial = _oracle_fn(_make_jobs(n))
+    per = (n + world - 1) // world
+    for rank, ncalls, raw in got:
+        out = np.frombuffer(raw, L.RESULT_DTYPE)
+        assert ncalls == min(per, n - rank * per)              # each rank computed only its block
+        assert out.shape[0] == n
+        np.testing.assert_array_equal(out["pose"], serial["pose"])          # candidate order preserved
+        np.testing.assert_array_equal(out["outer_iters"], serial["outer_iters"])
+        assert (out["status"] == 0).all()
+
+
+def test_shard_range_covers_everything():
+    for n in (0, 1, 5, 8, 4096, 4097):
+        for world in (1, 2, 3, 8):
+            got = []
+            for r in range(world):
+                lo, hi, per = cdist.shard_range(n, world, r)
+                assert hi - lo <= per
+                got += list(range(lo, hi))
+            assert got == list(range(n))
+
+
+def test_single_process_passthrough():
+    jobs = _make_jobs(3)
+    out = cdist.register_candidates_sharded(jobs, _oracle_fn)
+    assert out.shape[0] == 3 and (out["status"] == 0).all()

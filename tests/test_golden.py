@@ -1,0 +1,94 @@
+"""Golden fixtures (tests/golden/*.npz, made by tests/golden/make_golden.py from the oracle).
+CPU: the oracle still reproduces them.  GPU (-m gpu): the HIP path through the C-ABI reproduces them."""
+import os
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CASES = [("p2l_4x10", dict(cost="P2L"), 4, 10), ("p2p_w4", dict(cost="P2P", weight_opt=4), 8, 20),
+         ("p2d", dict(cost="P2D"), 8, 20), ("p2l_cauchy", dict(cost="P2L", loss="Cauchy", weight_opt=4), 8, 20)]
+
+
+@pytest.fixture(scope="module")
+def filt():
+    return np.load(os.path.join(HERE, "golden", "filters.npz"))
+
+
+@pytest.fixture(scope="module")
+def reg():
+    return np.load(os.path.join(HERE, "golden", "registration.npz"))
+
+
+def test_oracle_filters_golden(filt):
+    from oracle import pyoracle as O
+    sr, si, cnt = O.kstrongest(filt["img"], 12, 60)
+    np.testing.assert_array_equal(sr, filt["sel_range"])
+    np.testing.assert_array_equal(si, filt["sel_intensity"])
+    np.testing.assert_array_equal(cnt, filt["sel_count"])
+    np.testing.assert_array_equal(O.peaks(filt["img"], 12, sr, cnt), filt["is_peak"])
+    np.testing.assert_array_equal(O.kstrongest_cloud(sr, si, cnt, 0.0438, 2.5), filt["cloud"])
+    c, rc = O.cacfar(filt["img"], 20, 5, 0.01, 0.0438, 40, 2.5)
+    np.testing.assert_array_equal(c, filt["cfar_cloud"])
+    np.testing.assert_array_equal(rc, filt["cfar_rc"])
+    assert filt["sel_range"][5, 0] == 348 and filt["sel_count"][5] == 12       # plateau: the 12 largest ranges
+    assert filt["cfar_rc"].shape[0] > 50
+
+
+def test_oracle_registration_golden(reg):
+    from oracle import pyoracle as O
+    np.testing.assert_array_equal(O.compensate(reg["cloud1"], reg["mot"], False), reg["comp1"])
+    cells = [O.surface_points(reg["cloud0"], 3.0, 1.0, (0, 0), True), O.surface_points(reg["comp1"], 3.0, 1.0, (0, 0), True),
+             O.surface_points(reg["cloud2"], 3.0, 1.0, (0, 0), True)]
+    for i in range(3):
+        exp = reg["cells%d" % i]
+        assert cells[i].shape == exp.shape
+        for f in ("mean", "normal", "cov", "scale", "avg_intensity", "nsamples"):
+            np.testing.assert_array_equal(cells[i][f], exp[f])
+    for name, kw, mo, mi in CASES:
+        par = O.reg_params(max_outer=mo, max_inner=mi, **kw)
+        ok, p, r = O.register(cells, reg["poses"], par)
+        np.testing.assert_allclose(p[-1], reg[name + "_pose"], rtol=0, atol=1e-12)
+        np.testing.assert_array_equal([ok, r.outer_iters, r.lm_iters, r.num_residuals], reg[name + "_meta"])
+        pairs, w = O.associate(cells, reg["poses"], par, 1)
+        np.testing.assert_array_equal(pairs, reg[name + "_pairs"])
+
+
+@pytest.mark.gpu
+def test_hip_filters_golden(filt):
+    from tbv_slam_public_amd import api
+    r = api.filter_kstrongest(filt["img"], 12, 60, 0.0438, 2.5, want_peaks=True)
+    np.testing.assert_array_equal(r["sel_range"][0], filt["sel_range"])
+    np.testing.assert_array_equal(r["sel_intensity"][0], filt["sel_intensity"])
+    np.testing.assert_array_equal(r["sel_count"][0], filt["sel_count"])
+    np.testing.assert_array_equal(r["is_peak"][0], filt["is_peak"])
+    np.testing.assert_array_equal(r["xyzi"][0, :r["n_points"][0]], filt["cloud"])
+    np.testing.assert_array_equal(r["xyzi_peaks"][0, :r["n_peaks"][0]], filt["cloud_peaks"])
+    c = api.filter_cacfar(filt["img"], 20, 5, 0.01, 0.0438, 40, 2.5)
+    np.testing.assert_array_equal(c["xyzi"][0, :c["n_points"][0]], filt["cfar_cloud"])
+
+
+@pytest.mark.gpu
+def test_hip_registration_golden(reg):
+    from tbv_slam_public_amd import api
+    m = [api.MapPointNormal(reg["cloud0"], 3.0, (0, 0), True), api.MapPointNormal(reg["comp1"], 3.0, (0, 0), True),
+         api.MapPointNormal(reg["cloud2"], 3.0, (0, 0), True)]
+    for i in range(3):
+        got, exp = m[i].GetCells(), reg["cells%d" % i]
+        assert got.shape == exp.shape
+        np.testing.assert_array_equal(got["nsamples"], exp["nsamples"])
+        np.testing.assert_allclose(got["mean"], exp["mean"], atol=1e-9)
+    for name, kw, mo, mi in CASES:
+        r = api.n_scan_normal_reg(kw["cost"], kw.get("loss", "Huber"), 0.1, kw.get("weight_opt", 0))
+        r.SetParameters(mo, mi)
+        ok, p, _ = r.Register(m, reg["poses"])
+        meta = reg[name + "_meta"]
+        assert ok == bool(meta[0]) and r.summary_.outer_iters == meta[1] and r.summary_.lm_iters == meta[2]
+        assert r.summary_.num_residuals == meta[3]
+        d = np.abs(p[-1] - reg[name + "_pose"])
+        assert d[:2].max() <= 1e-4 and d[2] <= 1e-5
+        cc = api.CeresCost(r, m, reg["poses"], itr=1)
+        pairs, w = cc.blocks()
+        np.testing.assert_array_equal(pairs, reg[name + "_pairs"])
+        np.testing.assert_allclose(w, reg[name + "_weights"], rtol=1e-9)
+        okc, cost, res = r.GetCost(m, reg["poses"])
