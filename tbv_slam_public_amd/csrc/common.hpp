@@ -78,6 +78,9 @@ struct ProfScope {
 // ---------------------------------------------------------------------------------------------
 struct ScanView {          // plain pointers into one slab; passed to kernels by value / in tables
   float2* mean_f;          // float copy of the means (pointnormal.cpp:151-162), NN search space
+  float* sorted_x;         // the same float means sorted by (x, index): x, y and original cell index.
+  float* sorted_y;         //   The matcher's exact 1-NN only visits the window |x - qx| <= radius of
+  int32_t* sorted_idx;     //   this order instead of a kd-tree (register.hip).
   double2* mean;           // u_
   double2* normal;         // snormal_
   double4* cov;            // cov_ row-major (c00,c01,c10,c11)

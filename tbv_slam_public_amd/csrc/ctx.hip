@@ -112,6 +112,7 @@ size_t cfear_scan_slab_bytes(int cap) {
   size_t c = (size_t)cap;
   size_t b = 256;                                  // header: n_cells counter
   b += align_up(c * sizeof(float2), 256);
+  b += align_up(c * sizeof(float), 256) * 3;       // sorted_x, sorted_y, sorted_idx
   b += align_up(c * sizeof(double2), 256) * 3;     // mean, normal, lambda
   b += align_up(c * sizeof(double4), 256);
   b += align_up(c * sizeof(double), 256) * 2;      // scale, avg_intensity
@@ -125,6 +126,9 @@ ScanView cfear_scan_view(void* slab, int cap) {
   ScanView v;
   v.n_cells = (int32_t*)p; p += 256;
   v.mean_f = (float2*)p; p += align_up(c * sizeof(float2), 256);
+  v.sorted_x = (float*)p; p += align_up(c * sizeof(float), 256);
+  v.sorted_y = (float*)p; p += align_up(c * sizeof(float), 256);
+  v.sorted_idx = (int32_t*)p; p += align_up(c * sizeof(int32_t), 256);
   v.mean = (double2*)p; p += align_up(c * sizeof(double2), 256);
   v.normal = (double2*)p; p += align_up(c * sizeof(double2), 256);
   v.lambda = (double2*)p; p += align_up(c * sizeof(double2), 256);

@@ -42,9 +42,25 @@ struct RegCommon {
   char* scratch;                              // per job: 6 doubles per slot
   size_t scratch_stride;
   int32_t slots_cap;
-  int32_t lds_targets;                        // capacity of the staged target array
+  int32_t lds_targets;                        // capacity of the staged (x-sorted) target arrays
+  int32_t dense_cap_lds;                      // correspondences that fit the LDS dense arrays
+  int32_t dense_fields;                       // doubles per correspondence (5 P2P, 7 P2L, 8 P2D)
   cfear_reg_result* results;
 };
+
+__host__ __device__ inline size_t slots_bytes(int slots_cap) { return ((size_t)slots_cap * 52 + 255) / 256 * 256; }
+// LDS map: [0,640) reduction partials, [640,704) int partials, then x-sorted targets (x, y, idx:
+// 12 B each), then the dense correspondence arrays (dense_fields doubles each).
+__host__ __device__ inline size_t reg_lds_targets_bytes(int lds_targets) { return ((size_t)lds_targets * 12 + 15) / 16 * 16; }
+size_t reg_lds_bytes(int lds_targets, int dense_cap, int dense_fields) {
+  return 704 + reg_lds_targets_bytes(lds_targets) + (size_t)dense_cap * dense_fields * 8;
+}
+constexpr size_t kRegLdsBudget = 72 * 1024;          // keeps >= 2 workgroups per CU (160 KiB LDS)
+constexpr size_t kRegLdsBudgetWave = 16 * 1024;      // wave-per-job geometry: >= 8 wavefronts per CU
+// Measured on MI355X (round 1): with ~190 VGPRs only 2 wavefronts fit a SIMD, so the wave-per-job
+// geometry is latency-bound on its 4x longer per-lane loops (4096 jobs: 6.7 ms vs 6.0 ms); disabled.
+constexpr int kWavePerJobMinBatch = 1 << 30;
+int reg_dense_fields(int cost) { return cost == CFEAR_P2P ? 5 : (cost == CFEAR_P2L ? 7 : 8); }
 
 struct Aff2 { double l0, l1, l2, l3, t0, t1; };
 
@@ -143,7 +159,15 @@ __device__ __forceinline__ Slots slots_of(char* scratch, int cap) {
 }
 
 // 10 accumulators: cost, g[3], H upper triangle (00,01,02,11,12,22)
+// NW = wavefronts per registration: 4 (one 256-thread workgroup per job, lowest latency) or 1 (one
+// wavefront per job: no barriers or LDS exchange at all, 4x more jobs in flight -- large batches).
+template <int NW>
 __device__ __forceinline__ void block_reduce10(double v[10], double* part /*[2][4][10]*/, int& phase) {
+  if (NW == 1) {
+#pragma unroll
+    for (int k = 0; k < 10; k++) v[k] = wave_sum_f64(v[k]);     // already wave-uniform (readlane)
+    return;
+  }
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   double* buf = part + phase * 40;
 #pragma unroll
@@ -156,33 +180,44 @@ __device__ __forceinline__ void block_reduce10(double v[10], double* part /*[2][
   for (int k = 0; k < 10; k++) {
     // readfirstlane: tell the compiler the totals are wave-uniform, so every decision derived from
     // them compiles to scalar branches instead of exec-masked (structurized) control flow
-    const double t = ((buf[k] + buf[10 + k]) + buf[20 + k]) + buf[30 + k];
+    double t = buf[k];
+#pragma unroll
+    for (int wv = 1; wv < NW; wv++) t += buf[wv * 10 + k];
     v[k] = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(t)),
                             __builtin_amdgcn_readfirstlane(__double2loint(t)));
   }
   phase ^= 1;
 }
+template <int NW>
 __device__ __forceinline__ int block_sum_i32(int v, int* part /*[2][4]*/, int& phase) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  int* buf = part + phase * 4;
   const int t = wave_sum_i32(v);
+  if (NW == 1) { __syncthreads(); return t; }
+  int* buf = part + phase * 4;
   if (lane == 0) buf[wave] = t;
   __syncthreads();
-  const int r = __builtin_amdgcn_readfirstlane(buf[0] + buf[1] + buf[2] + buf[3]);
+  int r = buf[0];
+#pragma unroll
+  for (int wv = 1; wv < NW; wv++) r += buf[wv];
+  r = __builtin_amdgcn_readfirstlane(r);
   phase ^= 1;
   return r;
 }
 
 // n_scan_normal.cpp:213-318 for every fixed keyframe i against the free source (last scan):
 // fills the slot arrays; returns this thread's number of accepted associations.
+struct LdsTargets { float* x; float* y; int* idx; };
+
+template <int NW>
 __device__ int associate_all(const RegJob& job, const RegCommon& cm, const double* xsrc, int itr, const Slots& sl,
-                             float2* lds_tar) {
+                             const LdsTargets& lt) {
   const int tid = threadIdx.x;
   const int last = job.n_scans - 1;
   const ScanView& src = job.scans[last];
   const int n_src = *src.n_cells;
   const double curr_radius = (itr == 1) ? 2 * cm.par.radius : cm.par.radius;    // :220
   const double r2 = curr_radius * curr_radius;
+  const float rwin = (float)curr_radius + 1e-3f;        // window half-width (slightly generous)
   const Aff2 Tsrc = aff_from_xyt(xsrc);
   int accepted = 0;
   for (int i = 0; i < last; i++) {
@@ -191,21 +226,33 @@ __device__ int associate_all(const RegJob& job, const RegCommon& cm, const doubl
     const Aff2 Ttar = aff_from_xyt(job.poses[i]);
     const Aff2 Tst = aff_mul(aff_inv(Ttar), Tsrc);                              // :222
     __syncthreads();                                     // previous keyframe's LDS readers are done
-    for (int j = tid; j < n_tar; j += kRegThreads) lds_tar[j] = tar.mean_f[j];
+    for (int j = tid; j < n_tar; j += NW * 64) {          // x-sorted float means (+ original index)
+      lt.x[j] = tar.sorted_x[j];
+      lt.y[j] = tar.sorted_y[j];
+      lt.idx[j] = tar.sorted_idx[j];
+    }
     __syncthreads();
-    for (int s = tid; s < n_src; s += kRegThreads) {
+    for (int s = tid; s < n_src; s += NW * 64) {
       const int slot = i * n_src + s;
       const double2 u = src.mean[s];
       const double px = Tst.l0 * u.x + Tst.l1 * u.y + Tst.t0;
       const double py = Tst.l2 * u.x + Tst.l3 * u.y + Tst.t1;
       const float qx = (float)px, qy = (float)py;                               // pointnormal.cpp:240-242
+      // Exact 1-NN with FLANN's L2_Simple float distance, lowest index on ties.  Only targets with
+      // |x - qx| <= radius can pass the `dist < radius^2` gate (pointnormal.cpp:250), so the search is
+      // restricted to that window of the x-sorted order; the result equals the brute-force scan.
+      const float xlo = qx - rwin, xhi = qx + rwin;
+      int lo = 0, hi = n_tar;
+      while (lo < hi) { const int mid = (lo + hi) >> 1; if (lt.x[mid] < xlo) lo = mid + 1; else hi = mid; }
       int best = -1;
       float bestd = FLT_MAX;
-      for (int j = 0; j < n_tar; j++) {                   // exact 1-NN, FLANN L2_Simple float distance
-        const float2 t = lds_tar[j];
-        const float dx = __fsub_rn(qx, t.x), dy = __fsub_rn(qy, t.y);
+      for (int p = lo; p < n_tar; p++) {
+        const float tx = lt.x[p];
+        if (tx > xhi) break;
+        const float dx = __fsub_rn(qx, tx), dy = __fsub_rn(qy, lt.y[p]);
         const float d = __fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy));
-        if (d < bestd || best < 0) { best = j; bestd = d; }
+        const int idx = lt.idx[p];
+        if (d < bestd || (d == bestd && idx < best)) { best = idx; bestd = d; }
       }
       double w = -1.0;
       if (best >= 0 && (double)bestd < r2) {                                    // pointnormal.cpp:250
@@ -273,65 +320,119 @@ __device__ __forceinline__ void eval_slot(const cfear_reg_params& par, double sm
   loss_eval(par.loss, par.loss_limit, w, sq, rho0, rho1);
   acc[0] += 0.5 * rho0;
   if (WITH_JAC) {
-    const double sr = sqrt(rho1);                       // Corrector, alpha = 0
-    r0 *= sr; j00 *= sr; j01 *= sr; j02 *= sr;
-    acc[1] += j00 * r0; acc[2] += j01 * r0; acc[3] += j02 * r0;
-    acc[4] += j00 * j00; acc[5] += j00 * j01; acc[6] += j00 * j02;
-    acc[7] += j01 * j01; acc[8] += j01 * j02; acc[9] += j02 * j02;
+    // Corrector with alpha = 0 scales residual and Jacobian rows by sqrt(rho'); the normal equations
+    // only need the products, (sqrt(rho') J)^T (sqrt(rho') r) = rho' J^T r, so no square root here.
+    const double g0 = rho1 * r0;
+    acc[1] += j00 * g0; acc[2] += j01 * g0; acc[3] += j02 * g0;
+    const double h00 = rho1 * j00, h01 = rho1 * j01, h02 = rho1 * j02;
+    acc[4] += h00 * j00; acc[5] += h00 * j01; acc[6] += h00 * j02;
+    acc[7] += h01 * j01; acc[8] += h01 * j02; acc[9] += h02 * j02;
     if (par.cost != CFEAR_P2L) {
-      r1 *= sr; j10 *= sr; j11 *= sr; j12 *= sr;
-      acc[1] += j10 * r1; acc[2] += j11 * r1; acc[3] += j12 * r1;
-      acc[4] += j10 * j10; acc[5] += j10 * j11; acc[6] += j10 * j12;
-      acc[7] += j11 * j11; acc[8] += j11 * j12; acc[9] += j12 * j12;
+      const double g1 = rho1 * r1;
+      acc[1] += j10 * g1; acc[2] += j11 * g1; acc[3] += j12 * g1;
+      const double h10 = rho1 * j10, h11 = rho1 * j11, h12 = rho1 * j12;
+      acc[4] += h10 * j10; acc[5] += h10 * j11; acc[6] += h10 * j12;
+      acc[7] += h11 * j11; acc[8] += h11 * j12; acc[9] += h12 * j12;
     }
   }
 }
 
+// Dense correspondence arrays (SoA, stride dcap): 0 smx, 1 smy, 2 tmx, 3 tmy, 4 w, 5 a0, 6 a1, 7 a2.
+// They live in LDS when they fit (cm.dense_cap_lds), otherwise in the job's global scratch; the
+// pointer is generic, so one code path serves both.
+struct Dense { double* p; int cap; int n; };
+
 // cost, gradient and Gauss-Newton matrix of all correspondences at x (block-wide collective)
-__device__ void eval_all(const RegJob& job, const RegCommon& cm, const Slots& sl, int n_slots, int n_src,
-                         const double x[3], double out[10], double* part, int& phase) {
+template <int NW>
+__device__ void eval_all(const RegCommon& cm, const Dense& dn, const double x[3], double out[10], double* part, int& phase) {
   double s, c;
   sincos(x[2], &s, &c);
-  const double2* smean = job.scans[job.n_scans - 1].mean;
   double acc[10];
 #pragma unroll
   for (int k = 0; k < 10; k++) acc[k] = 0.0;
-  for (int slot = threadIdx.x; slot < n_slots; slot += kRegThreads) {
-    const double w = sl.w[slot];
-    if (w < 0.0) continue;
-    const int si = slot % n_src;
-    const double2 sm = smean[si];
-    eval_slot<true>(cm.par, sm.x, sm.y, sl.tmx[slot], sl.tmy[slot], sl.a0[slot], sl.a1[slot],
-                    cm.par.cost == CFEAR_P2D ? sl.a2[slot] : 0.0, w, x[0], x[1], c, s, acc);
+  const size_t cap = (size_t)dn.cap;
+  for (int i = threadIdx.x; i < dn.n; i += NW * 64) {
+    const double smx = dn.p[i], smy = dn.p[cap + i], tmx = dn.p[2 * cap + i], tmy = dn.p[3 * cap + i];
+    const double w = dn.p[4 * cap + i];
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+    if (cm.par.cost != CFEAR_P2P) { a0 = dn.p[5 * cap + i]; a1 = dn.p[6 * cap + i]; }
+    if (cm.par.cost == CFEAR_P2D) a2 = dn.p[7 * cap + i];
+    eval_slot<true>(cm.par, smx, smy, tmx, tmy, a0, a1, a2, w, x[0], x[1], c, s, acc);
   }
-  block_reduce10(acc, part, phase);
+  block_reduce10<NW>(acc, part, phase);
 #pragma unroll
   for (int k = 0; k < 10; k++) out[k] = acc[k];
 }
 
-__device__ __forceinline__ bool chol3_solve(const double A[9], const double b[3], double y[3]) {
-  double L[9];
+// Gathers the accepted slots (thread-major order, deterministic) into the dense arrays.
+template <int NW>
+__device__ int compact_slots(const RegJob& job, const RegCommon& cm, const Slots& sl, int n_slots, int n_src, int mine,
+                             double* lds_dense, double* gl_dense, Dense& dn, int* ipart, int& iphase) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int incl = wave_incl_scan_i32(mine);
+  int base = incl - mine, total;
+  if (NW == 1) {
+    __syncthreads();                                     // every slot array is complete
+    total = __builtin_amdgcn_readlane(incl, 63);
+  } else {
+    int* buf = ipart + iphase * 4;
+    if (lane == 63) buf[wave] = incl;
+    __syncthreads();                                     // also: every slot array is complete
+    for (int wv = 0; wv < wave; wv++) base += buf[wv];
+    int tt = buf[0];
 #pragma unroll
-  for (int i = 0; i < 9; i++) L[i] = 0.0;
-#pragma unroll
-  for (int i = 0; i < 3; i++)
-#pragma unroll
-    for (int j = 0; j <= i; j++) {
-      double sum = A[i * 3 + j];
-#pragma unroll
-      for (int k = 0; k < j; k++) sum -= L[i * 3 + k] * L[j * 3 + k];
-      if (i == j) { if (!(sum > 0.0)) return false; L[i * 3 + i] = sqrt(sum); }
-      else L[i * 3 + j] = sum / L[j * 3 + j];
+    for (int wv = 1; wv < NW; wv++) tt += buf[wv];
+    total = __builtin_amdgcn_readfirstlane(tt);
+    iphase ^= 1;
+  }
+  const bool in_lds = total <= cm.dense_cap_lds;
+  dn.p = in_lds ? lds_dense : gl_dense;
+  dn.cap = in_lds ? cm.dense_cap_lds : cm.slots_cap;
+  dn.n = total;
+  const size_t cap = (size_t)dn.cap;
+  const double2* smean = job.scans[job.n_scans - 1].mean;
+  int c = base;
+  // same visiting order as associate_all: keyframes outer, this thread's source cells inner
+  const int last = job.n_scans - 1;
+  for (int i = 0; i < last; i++)
+    for (int s = threadIdx.x; s < n_src; s += NW * 64) {
+      const int slot = i * n_src + s;
+      const double w = sl.w[slot];
+      if (w < 0.0) continue;
+      const double2 sm = smean[s];
+      dn.p[c] = sm.x; dn.p[cap + c] = sm.y;
+      dn.p[2 * cap + c] = sl.tmx[slot]; dn.p[3 * cap + c] = sl.tmy[slot];
+      dn.p[4 * cap + c] = w;
+      if (cm.par.cost != CFEAR_P2P) { dn.p[5 * cap + c] = sl.a0[slot]; dn.p[6 * cap + c] = sl.a1[slot]; }
+      if (cm.par.cost == CFEAR_P2D) dn.p[7 * cap + c] = sl.a2[slot];
+      c++;
     }
-  double z[3];
-#pragma unroll
-  for (int i = 0; i < 3; i++) { double sum = b[i];
-#pragma unroll
-    for (int k = 0; k < i; k++) sum -= L[i * 3 + k] * z[k]; z[i] = sum / L[i * 3 + i]; }
-#pragma unroll
-  for (int i = 2; i >= 0; i--) { double sum = z[i];
-#pragma unroll
-    for (int k = i + 1; k < 3; k++) sum -= L[k * 3 + i] * y[k]; y[i] = sum / L[i * 3 + i]; }
+  __syncthreads();
+  (void)n_slots;
+  return total;
+}
+
+// Solves the SPD system A y = b (3x3, A = J^T J + D^2) by LDL^T: three divisions, no square roots.
+// Ceres factorises the same matrix with a sparse Cholesky; the solutions agree to rounding.
+__device__ __forceinline__ bool chol3_solve(const double A[9], const double b[3], double y[3]) {
+  const double d0 = A[0];
+  if (!(d0 > 0.0)) return false;
+  const double i0 = 1.0 / d0;
+  const double l10 = A[3] * i0, l20 = A[6] * i0;
+  const double d1 = A[4] - l10 * A[3];
+  if (!(d1 > 0.0)) return false;
+  const double i1 = 1.0 / d1;
+  const double t21 = A[7] - l20 * A[3];
+  const double l21 = t21 * i1;
+  const double d2 = A[8] - l20 * A[6] - l21 * t21;
+  if (!(d2 > 0.0)) return false;
+  const double i2 = 1.0 / d2;
+  const double z0 = b[0];
+  const double z1 = b[1] - l10 * z0;
+  const double z2 = b[2] - l20 * z0 - l21 * z1;
+  y[2] = z2 * i2;
+  y[1] = z1 * i1 - l21 * y[2];
+  y[0] = z0 * i0 - l10 * y[1] - l20 * y[2];
   return isfinite(y[0]) && isfinite(y[1]) && isfinite(y[2]);
 }
 
@@ -343,8 +444,9 @@ struct LmSummary {
 
 // ceres::Solve as configured by the reference (Ceres 2.1 defaults, max_num_iterations = max_iter):
 // same bookkeeping as the oracle's lm_solve / SURVEY Appendix B.4.  Block-wide collective.
-__device__ void lm_solve(const RegJob& job, const RegCommon& cm, const Slots& sl, int n_slots, int n_src,
-                         double x[3], int max_iter, LmSummary& sum, double* part, int& phase) {
+template <int NW>
+__device__ void lm_solve(const RegCommon& cm, const Dense& dn, double x[3], int max_iter, LmSummary& sum, double* part,
+                         int& phase) {
   const double function_tolerance = 1e-6, gradient_tolerance = 1e-10, parameter_tolerance = 1e-8;
   const double min_relative_decrease = 1e-3, min_lm_diagonal = 1e-6, max_lm_diagonal = 1e32;
   const double max_radius = 1e16, min_radius = 1e-32;
@@ -354,7 +456,7 @@ __device__ void lm_solve(const RegJob& job, const RegCommon& cm, const Slots& sl
   int num_consecutive_invalid_steps = 0;
 
   double cur[10];                                        // cost, g, H at the accepted x
-  eval_all(job, cm, sl, n_slots, n_src, x, cur, part, phase);
+  eval_all<NW>(cm, dn, x, cur, part, phase);
   double x_cost = cur[0];
   double scale[3];
   scale[0] = 1.0 / (1.0 + sqrt(cur[4]));                 // jacobi scaling from iteration 0
@@ -421,7 +523,7 @@ __device__ void lm_solve(const RegJob& job, const RegCommon& cm, const Slots& sl
 #pragma unroll
     for (int k = 0; k < 3; k++) cand[k] = x[k] + step[k] * scale[k];
     double cnd[10];                                      // cost (and, speculatively, g and H) at cand
-    eval_all(job, cm, sl, n_slots, n_src, cand, cnd, part, phase);
+    eval_all<NW>(cm, dn, cand, cnd, part, phase);
     const double cand_cost = cnd[0];
     const double step_norm = sqrt((x[0] - cand[0]) * (x[0] - cand[0]) + (x[1] - cand[1]) * (x[1] - cand[1]) +
                                   (x[2] - cand[2]) * (x[2] - cand[2]));
@@ -449,11 +551,16 @@ __device__ void lm_solve(const RegJob& job, const RegCommon& cm, const Slots& sl
   sum.final_cost = fmin(sum.initial_cost, min_iter_cost);
 }
 
-__global__ __launch_bounds__(kRegThreads) void register_kernel(const RegJob* __restrict__ jobs, const RegCommon cm) {
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void register_kernel(const RegJob* __restrict__ jobs, const RegCommon cm) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   double* part = (double*)smem;                          // [2][4][10]
   int* ipart = (int*)(smem + 640);                       // [2][4]
-  float2* lds_tar = (float2*)(smem + 704);
+  LdsTargets lt;
+  lt.x = (float*)(smem + 704);
+  lt.y = lt.x + cm.lds_targets;
+  lt.idx = (int*)(lt.y + cm.lds_targets);
+  double* lds_dense = (double*)(smem + 704 + reg_lds_targets_bytes(cm.lds_targets));
   const RegJob& job = jobs[blockIdx.x];
   cfear_reg_result* res = cm.results + blockIdx.x;
   const int last = job.n_scans - 1;
@@ -471,6 +578,8 @@ __global__ __launch_bounds__(kRegThreads) void register_kernel(const RegJob* __r
     return;
   }
   const Slots sl = slots_of(cm.scratch + (size_t)blockIdx.x * cm.scratch_stride, cm.slots_cap);
+  double* gl_dense = (double*)(cm.scratch + (size_t)blockIdx.x * cm.scratch_stride + slots_bytes(cm.slots_cap));
+  Dense dn;
   int phase = 0, iphase = 0;
   const int rpb = cm.par.cost == CFEAR_P2L ? 1 : 2;
   // n_scan_normal.cpp:82-185
@@ -480,15 +589,24 @@ __global__ __launch_bounds__(kRegThreads) void register_kernel(const RegJob* __r
   int itr = 1, lm_iters = 0, num_residuals = 0, fail_status = CFEAR_OK;
   LmSummary summary;
   summary.final_cost = 0.0; summary.last_relative_decrease = 0.0; summary.n_pushed = 0; summary.usable = false;
+#ifdef CFEAR_REG_TIMING
+  long long t_assoc = 0, t_total0 = __builtin_readcyclecounter();
+#endif
   for (itr = 1; itr <= cm.par.max_itr_association && success; itr++) {
-    const int mine = associate_all(job, cm, x, itr, sl, lds_tar);
+#ifdef CFEAR_REG_TIMING
+    const long long ta0 = __builtin_readcyclecounter();
+#endif
+    const int mine = associate_all<NW>(job, cm, x, itr, sl, lt);
     __threadfence_block();
-    const int n_blocks = block_sum_i32(mine, ipart, iphase);     // barrier: slot arrays are complete
+    const int n_blocks = compact_slots<NW>(job, cm, sl, n_slots, n_src, mine, lds_dense, gl_dense, dn, ipart, iphase);
+#ifdef CFEAR_REG_TIMING
+    t_assoc += __builtin_readcyclecounter() - ta0;
+#endif
     num_residuals = n_blocks * rpb;
     success = num_residuals > 1;                                  // :368-369
     if (!success) { fail_status = CFEAR_ERR_TOO_FEW_RESIDUALS; break; }
     double xi[3] = {x[0], x[1], x[2]};
-    lm_solve(job, cm, sl, n_slots, n_src, xi, cm.par.max_itr_solver, summary, part, phase);
+    lm_solve<NW>(cm, dn, xi, cm.par.max_itr_solver, summary, part, phase);
     lm_iters += summary.n_pushed - 1;
     success = summary.usable;
     if (success) { x[0] = xi[0]; x[1] = xi[1]; x[2] = xi[2]; } else fail_status = CFEAR_ERR_SOLVER;
@@ -519,6 +637,10 @@ __global__ __launch_bounds__(kRegThreads) void register_kernel(const RegJob* __r
     res->lm_iters = lm_iters;
     res->last_relative_decrease = summary.last_relative_decrease;
     res->reserved = 0;
+#ifdef CFEAR_REG_TIMING
+    res->reserved = (double)t_assoc;
+    res->last_relative_decrease = (double)(__builtin_readcyclecounter() - t_total0);
+#endif
     if (success) { res->score = summary.final_cost / (double)num_residuals; res->status = CFEAR_OK; }   // :162
     else { res->score = 0.0; res->status = fail_status; }
   }
@@ -529,7 +651,10 @@ __global__ __launch_bounds__(kRegThreads) void assoc_kernel(const RegJob* __rest
                                                             int32_t* n_blocks_out) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   int* ipart = (int*)(smem + 640);
-  float2* lds_tar = (float2*)(smem + 704);
+  LdsTargets lt;
+  lt.x = (float*)(smem + 704);
+  lt.y = lt.x + cm.lds_targets;
+  lt.idx = (int*)(lt.y + cm.lds_targets);
   const RegJob& job = jobs[blockIdx.x];
   const int last = job.n_scans - 1;
   const int n_src = *job.scans[last].n_cells;
@@ -541,8 +666,8 @@ __global__ __launch_bounds__(kRegThreads) void assoc_kernel(const RegJob* __rest
   }
   const Slots sl = slots_of(cm.scratch + (size_t)blockIdx.x * cm.scratch_stride, cm.slots_cap);
   int iphase = 0;
-  const int mine = associate_all(job, cm, job.poses[last], itr, sl, lds_tar);
-  const int n_blocks = block_sum_i32(mine, ipart, iphase);
+  const int mine = associate_all<4>(job, cm, job.poses[last], itr, sl, lt);
+  const int n_blocks = block_sum_i32<4>(mine, ipart, iphase);
   if (threadIdx.x == 0) n_blocks_out[blockIdx.x] = n_blocks;
 }
 
@@ -599,12 +724,11 @@ __global__ __launch_bounds__(kRegThreads) void eval_kernel(const RegJob* __restr
     if (o.rob_r) { o.rob_r[slot * 2] = r0 * sr; o.rob_r[slot * 2 + 1] = r1 * sr; }
   }
   int phase = 0;
-  block_reduce10(acc, part, phase);
+  block_reduce10<4>(acc, part, phase);
   if (threadIdx.x == 0 && o.neq) for (int k = 0; k < 10; k++) o.neq[k] = acc[k];
 }
 
-size_t reg_lds_bytes(int lds_targets) { return 704 + (size_t)lds_targets * 8; }
-size_t reg_scratch_bytes(int slots_cap) { return ((size_t)slots_cap * 52 + 255) / 256 * 256; }
+size_t reg_scratch_bytes(int slots_cap) { return slots_bytes(slots_cap) + ((size_t)slots_cap * 64 + 255) / 256 * 256; }
 
 int check_params(cfear_ctx* ctx, const cfear_reg_params* p) {
   if (!p) return cfear_set_error(ctx, CFEAR_ERR_INVALID_ARGUMENT, "null parameters");
@@ -644,19 +768,30 @@ int cfear_register_launch(cfear_ctx* ctx, const void* d_jobs, int n_jobs, const 
   cm.scratch = d_scratch;
   cm.scratch_stride = reg_scratch_bytes(slots_cap);
   cm.slots_cap = slots_cap;
-  cm.lds_targets = lds_targets;
+  cm.lds_targets = (lds_targets + 3) & ~3;
+  cm.dense_fields = reg_dense_fields(par->cost);
   cm.results = d_results;
+  // Geometry: small batches get one 256-thread workgroup per registration (lowest latency, dense
+  // correspondence arrays in LDS); large batches get one wavefront per registration (no barriers, no
+  // LDS exchange, 4x more registrations in flight; dense arrays stay in L2).
+  const bool wave_per_job = n_jobs >= kWavePerJobMinBatch;
+  const size_t fixed = 704 + reg_lds_targets_bytes(cm.lds_targets);
+  const size_t budget = wave_per_job ? kRegLdsBudgetWave : kRegLdsBudget;
+  const size_t avail = fixed < budget ? budget - fixed : 0;
+  cm.dense_cap_lds = (int)std::min<size_t>(avail / ((size_t)cm.dense_fields * 8), (size_t)slots_cap);
+  const size_t lds = reg_lds_bytes(cm.lds_targets, cm.dense_cap_lds, cm.dense_fields);
   static bool attr_set = false;
   if (!attr_set) {
-    CFEAR_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)register_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                             (int)reg_lds_bytes(kMaxTargetsLds)));
-    CFEAR_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)assoc_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                             (int)reg_lds_bytes(kMaxTargetsLds)));
+    CFEAR_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)register_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    CFEAR_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)register_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    CFEAR_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)assoc_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_set = true;
   }
   ProfScope ps(ctx, "register");
-  hipLaunchKernelGGL(register_kernel, dim3(n_jobs), dim3(kRegThreads), reg_lds_bytes(lds_targets), ctx->stream,
-                     (const RegJob*)d_jobs, cm);
+  if (wave_per_job)
+    hipLaunchKernelGGL(register_kernel<1>, dim3(n_jobs), dim3(64), lds, ctx->stream, (const RegJob*)d_jobs, cm);
+  else
+    hipLaunchKernelGGL(register_kernel<4>, dim3(n_jobs), dim3(256), lds, ctx->stream, (const RegJob*)d_jobs, cm);
   CFEAR_HIP_CHECK(ctx, hipGetLastError());
   return CFEAR_OK;
 }
@@ -768,14 +903,15 @@ extern "C" int cfear_cost_prepare(cfear_ctx* ctx, const cfear_scan* const* scans
   RegCommon cm;
   cm.par = *par; cm.angle_outlier = std::cos(M_PI / 6.0);
   cm.scratch = c->d_scratch; cm.scratch_stride = reg_scratch_bytes(c->slots_cap);
-  cm.slots_cap = c->slots_cap; cm.lds_targets = c->lds_targets; cm.results = nullptr;
+  cm.slots_cap = c->slots_cap; cm.lds_targets = (c->lds_targets + 3) & ~3; cm.results = nullptr;
+  cm.dense_cap_lds = 0; cm.dense_fields = reg_dense_fields(par->cost);
   int32_t* d_nb = (int32_t*)((char*)c->d_job + sizeof(RegJob));
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)assoc_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)reg_lds_bytes(kMaxTargetsLds));
+    (void)hipFuncSetAttribute((const void*)assoc_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
-  hipLaunchKernelGGL(assoc_kernel, dim3(1), dim3(kRegThreads), reg_lds_bytes(c->lds_targets), ctx->stream,
+  hipLaunchKernelGGL(assoc_kernel, dim3(1), dim3(kRegThreads), reg_lds_bytes(cm.lds_targets, 0, 0), ctx->stream,
                      (const RegJob*)c->d_job, cm, (int)itr, d_nb);
   if (hipGetLastError() != hipSuccess) return fail(CFEAR_ERR_HIP, "assoc_kernel launch failed");
   c->h_w.assign(std::max(c->n_slots, 1), -1.0);
@@ -808,6 +944,7 @@ int run_eval(cfear_cost* c, const double x[3], bool want_raw) {
   RegCommon cm;
   cm.par = c->par; cm.angle_outlier = 0; cm.scratch = c->d_scratch; cm.scratch_stride = 0;
   cm.slots_cap = c->slots_cap; cm.lds_targets = c->lds_targets; cm.results = nullptr;
+  cm.dense_cap_lds = 0; cm.dense_fields = 0;
   EvalOut o;
   const size_t sc = (size_t)c->slots_cap;
   o.raw_r = want_raw ? c->d_out : nullptr;

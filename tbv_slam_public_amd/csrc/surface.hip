@@ -33,6 +33,7 @@ constexpr int kSurfThreads = 1024;
 constexpr int kMaxPoints = 16384;            // LDS sort capacity (64-bit keys)
 constexpr int kMaxGridRows = 4096;           // rowbeg table
 constexpr int kPerThread = kMaxPoints / kSurfThreads;   // 16 sorted elements per thread
+constexpr int kRadixMaxPoints = 8192;        // radix path: 2 x 32 KiB key buffers + 32 KiB counters in LDS
 // LDS map: [0, 128K) sort keys, later voxel key/start tables; then rowbeg; then small reductions
 constexpr size_t kLdsRowbegOff = (size_t)kMaxPoints * 8 + 16;
 constexpr size_t kLdsSmallOff = (kLdsRowbegOff + (size_t)(kMaxGridRows + 1) * 4 + 15) / 16 * 16;
@@ -66,7 +67,7 @@ struct TmpCell {                              // one candidate cell per voxel (b
 
 __host__ __device__ inline size_t scratch_bytes_per_scan() {
   size_t b = 0;
-  b += (size_t)kMaxPoints * 4 * 3;            // sx, sy, si
+  b += (size_t)kMaxPoints * 16;               // sorted points float4
   b += (size_t)kMaxPoints * 8;                // centroids
   b += (size_t)kMaxPoints * sizeof(TmpCell);
   b += (size_t)kMaxPoints * 4;                // compaction offsets
@@ -130,6 +131,48 @@ __device__ __forceinline__ int upper_bound_u32(const uint32_t* a, int lo, int hi
   return lo;
 }
 
+// Sorts the n float means of a scan by (x, cell index) into v.sorted_{x,y,idx}; block-wide collective.
+// keys: LDS scratch for at least next_pow2(n) 64-bit keys.
+__device__ void sort_cells_block(const ScanView& v, int n, unsigned long long* keys) {
+  const int tid = threadIdx.x, nth = blockDim.x;
+  int npad = 64;
+  while (npad < n) npad <<= 1;
+  for (int i = tid; i < npad; i += nth) {
+    unsigned long long key = ~0ull;
+    if (i < n) {
+      unsigned u = __float_as_uint(v.mean_f[i].x);
+      u ^= (u >> 31) ? 0xFFFFFFFFu : 0x80000000u;           // order-preserving float -> uint
+      key = ((unsigned long long)u << 32) | (unsigned)i;
+    }
+    keys[i] = key;
+  }
+  __syncthreads();
+  for (int k = 2; k <= npad; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int t = tid; t < (npad >> 1); t += nth) {
+        const int lo = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+        const int hi = lo | j;
+        const bool asc = (lo & k) == 0;
+        const unsigned long long a = keys[lo], b = keys[hi];
+        if ((a > b) == asc) { keys[lo] = b; keys[hi] = a; }
+      }
+      __syncthreads();
+    }
+  }
+  for (int i = tid; i < n; i += nth) {
+    const int idx = (int)(keys[i] & 0xFFFFFFFFu);
+    const float2 m = v.mean_f[idx];
+    v.sorted_x[i] = m.x;
+    v.sorted_y[i] = m.y;
+    v.sorted_idx[i] = idx;
+  }
+}
+
+__global__ __launch_bounds__(kSurfThreads) void scan_sort_kernel(ScanView v) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  sort_cells_block(v, *v.n_cells, (unsigned long long*)smem);
+}
+
 __global__ __launch_bounds__(kSurfThreads) void surface_points_kernel(const SurfJob* __restrict__ jobs, const SurfCommon cm) {
   // all LDS is carved from the dynamic region so its base stays 16-byte aligned (64-bit keys)
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -150,13 +193,17 @@ __global__ __launch_bounds__(kSurfThreads) void surface_points_kernel(const Surf
   }
   float4* pts = job.xyzi;
   char* scr = cm.scratch + (size_t)blockIdx.x * cm.scratch_stride;
-  float* sx = (float*)scr;
-  float* sy = sx + kMaxPoints;
-  float* si = sy + kMaxPoints;
-  float2* cen = (float2*)(si + kMaxPoints);
+  float4* spt = (float4*)scr;                 // sorted points (x, y, intensity, -)
+  float2* cen = (float2*)(spt + kMaxPoints);
   TmpCell* tmp = (TmpCell*)(cen + kMaxPoints);
   int32_t* coff = (int32_t*)(tmp + kMaxPoints);
+#ifdef CFEAR_SURF_TIMING
+  long long* tstamp = (long long*)(coff + kMaxPoints - 64);   // debug only: tail of the compaction array
+#endif
 
+#ifdef CFEAR_SURF_TIMING
+  if (tid == 0) tstamp[0] = __builtin_readcyclecounter();
+#endif
   // ---- 1. compensation + bounding box -------------------------------------------------------
   float mnx = FLT_MAX, mny = FLT_MAX, mxx = -FLT_MAX, mxy = -FLT_MAX;
   for (int i = tid; i < n; i += kSurfThreads) {
@@ -189,35 +236,112 @@ __global__ __launch_bounds__(kSurfThreads) void surface_points_kernel(const Surf
   }
   const int dbx = (int)div_bx, dby = (int)div_by;
 
-  // ---- 2. (voxel, point) keys -> LDS bitonic sort ---------------------------------------------
+#ifdef CFEAR_SURF_TIMING
+  if (tid == 0) tstamp[1] = __builtin_readcyclecounter();
+#endif
+  // ---- 2. (voxel, point) keys -> LDS sort: voxels ascending, points of a voxel in input order --
   unsigned long long* keys = (unsigned long long*)smem;
   int npad = 1024;
   while (npad < n) npad <<= 1;
-  for (int i = tid; i < npad; i += kSurfThreads) {
-    unsigned long long key = ~0ull;
-    if (i < n) {
-      const float4 p = pts[i];
-      const int ijk0 = (int)(floorf(p.x * cm.inv_leaf) - (float)min_bx);
-      const int ijk1 = (int)(floorf(p.y * cm.inv_leaf) - (float)min_by);
-      const unsigned idx = (unsigned)(ijk0 + ijk1 * dbx);
-      key = ((unsigned long long)idx << 32) | (unsigned)i;
+  int ib = 10;                                             // index bits: 2^ib == npad
+  while ((1 << ib) < npad) ib++;
+  int vb = 1;                                              // voxel-index bits
+  while (((long long)1 << vb) < (long long)dbx * dby) vb++;
+  // Fast path: packed 32-bit keys (voxel << ib | index) and a stable LSD radix sort on the voxel
+  // digits (4 bits per pass, thread-contiguous chunks keep input order) in two LDS buffers.
+  const bool radix = (npad <= kRadixMaxPoints) && (vb + ib <= 32);
+  if (radix) {
+    uint32_t* kA = (uint32_t*)smem;
+    uint32_t* kB = kA + npad;
+    unsigned short* cnt = (unsigned short*)(kB + npad);   // [16][1024]
+    const int per = npad / kSurfThreads;                   // 1..8 consecutive elements per thread
+    for (int i = tid; i < npad; i += kSurfThreads) {
+      uint32_t key = 0xFFFFFFFFu;
+      if (i < n) {
+        const float4 p = pts[i];
+        const int ijk0 = (int)(floorf(p.x * cm.inv_leaf) - (float)min_bx);
+        const int ijk1 = (int)(floorf(p.y * cm.inv_leaf) - (float)min_by);
+        key = ((uint32_t)(ijk0 + ijk1 * dbx) << ib) | (uint32_t)i;
+      }
+      kA[i] = key;
     }
-    keys[i] = key;
-  }
-  __syncthreads();
-  for (int k = 2; k <= npad; k <<= 1) {
-    for (int j = k >> 1; j > 0; j >>= 1) {
-      for (int t = tid; t < (npad >> 1); t += kSurfThreads) {
-        const int lo = ((t & ~(j - 1)) << 1) | (t & (j - 1));
-        const int hi = lo | j;
-        const bool asc = (lo & k) == 0;
-        const unsigned long long a = keys[lo], b = keys[hi];
-        if ((a > b) == asc) { keys[lo] = b; keys[hi] = a; }
+    __syncthreads();
+    uint32_t* src = kA;
+    uint32_t* dst = kB;
+    for (int shift = ib; shift < ib + vb; shift += 4) {
+#pragma unroll
+      for (int d = 0; d < 16; d++) cnt[d * kSurfThreads + tid] = 0;
+      for (int q = 0; q < per; q++) {
+        const uint32_t dg = (src[tid * per + q] >> shift) & 15u;
+        cnt[dg * kSurfThreads + tid]++;
       }
       __syncthreads();
+      // exclusive scan of the 16 x 1024 counters in (digit, thread) order: 16 consecutive per thread
+      unsigned short local[16];
+      int tot = 0;
+#pragma unroll
+      for (int q = 0; q < 16; q++) { local[q] = cnt[tid * 16 + q]; tot += local[q]; }
+      const int inc = wave_incl_scan_i32(tot);
+      if (lane == 63) red_i[wave] = inc;
+      __syncthreads();
+      int run = inc - tot;
+      for (int wv = 0; wv < wave; wv++) run += red_i[wv];
+#pragma unroll
+      for (int q = 0; q < 16; q++) { cnt[tid * 16 + q] = (unsigned short)run; run += local[q]; }
+      __syncthreads();
+      for (int q = 0; q < per; q++) {
+        const uint32_t key = src[tid * per + q];
+        const uint32_t dg = (key >> shift) & 15u;
+        const int pos = cnt[dg * kSurfThreads + tid]++;
+        dst[pos] = key;
+      }
+      __syncthreads();
+      uint32_t* t = src; src = dst; dst = t;
+    }
+    // widen to the 64-bit (voxel, index) form the next step reads; registers bridge the overlap
+    uint32_t mine32[kRadixMaxPoints / kSurfThreads];
+#pragma unroll
+    for (int q = 0; q < kRadixMaxPoints / kSurfThreads; q++) mine32[q] = (q < per) ? src[tid * per + q] : 0xFFFFFFFFu;
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < kRadixMaxPoints / kSurfThreads; q++)
+      if (q < per) {
+        const uint32_t key = mine32[q];
+        keys[tid * per + q] = key == 0xFFFFFFFFu ? ~0ull
+                                                 : (((unsigned long long)(key >> ib)) << 32) | (key & ((1u << ib) - 1u));
+      }
+    __syncthreads();
+  } else {
+    // General path: bitonic sort of 64-bit (voxel, index) keys.
+    for (int i = tid; i < npad; i += kSurfThreads) {
+      unsigned long long key = ~0ull;
+      if (i < n) {
+        const float4 p = pts[i];
+        const int ijk0 = (int)(floorf(p.x * cm.inv_leaf) - (float)min_bx);
+        const int ijk1 = (int)(floorf(p.y * cm.inv_leaf) - (float)min_by);
+        const unsigned idx = (unsigned)(ijk0 + ijk1 * dbx);
+        key = ((unsigned long long)idx << 32) | (unsigned)i;
+      }
+      keys[i] = key;
+    }
+    __syncthreads();
+    for (int k = 2; k <= npad; k <<= 1) {
+      for (int j = k >> 1; j > 0; j >>= 1) {
+        for (int t = tid; t < (npad >> 1); t += kSurfThreads) {
+          const int lo = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+          const int hi = lo | j;
+          const bool asc = (lo & k) == 0;
+          const unsigned long long a = keys[lo], b = keys[hi];
+          if ((a > b) == asc) { keys[lo] = b; keys[hi] = a; }
+        }
+        __syncthreads();
+      }
     }
   }
 
+#ifdef CFEAR_SURF_TIMING
+  if (tid == 0) tstamp[2] = __builtin_readcyclecounter();
+#endif
   // ---- 3. sorted points -> global scratch; voxel table (key, start) -> LDS --------------------
   // each thread owns kPerThread consecutive sorted elements, held in registers across the barrier
   // because the voxel tables overwrite the key region.
@@ -265,7 +389,7 @@ __global__ __launch_bounds__(kSurfThreads) void surface_points_kernel(const Surf
         if (e == 0 || vx != pv) { vox_key[ord] = vx; vox_start[ord] = e; ord++; }
         pv = vx;
         const float4 p = pts[pi];
-        sx[e] = p.x; sy[e] = p.y; si[e] = p.w;
+        spt[e] = make_float4(p.x, p.y, p.w, 0.f);
       }
     }
   }
@@ -274,91 +398,95 @@ __global__ __launch_bounds__(kSurfThreads) void surface_points_kernel(const Surf
   // rowbeg[y] = first voxel ordinal whose grid row is >= y
   for (int y = tid; y <= dby; y += kSurfThreads)
     rowbeg[y] = lower_bound_u32(vox_key, 0, V, (uint32_t)((long long)y * dbx));
+#ifdef CFEAR_SURF_TIMING
+  if (tid == 0) tstamp[3] = __builtin_readcyclecounter();
+#endif
   // ---- 4a. voxel centroids: sequential float sums in sorted (= input) order -------------------
   __threadfence_block();
   __syncthreads();
   for (int v = tid; v < V; v += kSurfThreads) {
     const int s = vox_start[v], e = vox_start[v + 1];
     float ax = 0.f, ay = 0.f;
-    for (int p = s; p < e; p++) { ax = __fadd_rn(ax, sx[p]); ay = __fadd_rn(ay, sy[p]); }
+    for (int p = s; p < e; p++) { const float4 q = spt[p]; ax = __fadd_rn(ax, q.x); ay = __fadd_rn(ay, q.y); }
     const float cnt = (float)(e - s);
     cen[v] = make_float2(__fdiv_rn(ax, cnt), __fdiv_rn(ay, cnt));
   }
   __threadfence_block();
   __syncthreads();
 
-  // ---- 4b. one 16-lane group per voxel: radius gather + weighted mean / covariance ------------
-  const int grp = tid >> 4, gl = tid & 15, gbase = lane & 48;
-  const int nrows_n = 2 * cm.reach + 1;                 // <= 16 neighbour grid rows
-  for (int v = grp; v < V; v += kSurfThreads / 16) {
+#ifdef CFEAR_SURF_TIMING
+  if (tid == 0) tstamp[4] = __builtin_readcyclecounter();
+#endif
+  // ---- 4b. one LANE per voxel: radius gather + weighted mean / covariance ----------------------
+  // Neighbouring voxels (adjacent lanes) share most of their candidate points, so the per-lane
+  // 16-byte loads hit L1; every lane keeps its own fp64 moments (no cross-lane reduction) and
+  // voxels that cannot reach 6 neighbours cost nothing.
+  for (int v = tid; v < V; v += kSurfThreads) {
     const float2 c = cen[v];
     const uint32_t key = vox_key[v];
     const int iy = (int)(key / (uint32_t)dbx), ix = (int)(key - (uint32_t)iy * (uint32_t)dbx);
-    // lane j < nrows_n finds the sorted-point run [p0, p1) of grid row iy + j - reach
-    int p0 = 0, p1 = 0;
-    if (gl < nrows_n) {
-      const int yy = iy + gl - cm.reach;
-      if (yy >= 0 && yy < dby) {
-        const int x0 = max(ix - cm.reach, 0), x1 = min(ix + cm.reach, dbx - 1);
-        const uint32_t klo = (uint32_t)(yy * dbx + x0), khi = (uint32_t)(yy * dbx + x1);
-        const int a = lower_bound_u32(vox_key, rowbeg[yy], rowbeg[yy + 1], klo);
-        const int b = upper_bound_u32(vox_key, rowbeg[yy], rowbeg[yy + 1], khi);
-        p0 = vox_start[a];
-        p1 = vox_start[b];
-      }
-    }
-    // pass 1: neighbour count and weight sum
+    const int x0 = max(ix - cm.reach, 0), x1 = min(ix + cm.reach, dbx - 1);
+    auto run_of = [&](int yy, int& p0, int& p1) {       // sorted-point run of grid row yy, columns x0..x1
+      p0 = p1 = 0;
+      if (yy < 0 || yy >= dby) return;
+      const uint32_t klo = (uint32_t)(yy * dbx + x0), khi = (uint32_t)(yy * dbx + x1);
+      const int a = lower_bound_u32(vox_key, rowbeg[yy], rowbeg[yy + 1], klo);
+      const int b = upper_bound_u32(vox_key, rowbeg[yy], rowbeg[yy + 1], khi);
+      p0 = vox_start[a];
+      p1 = vox_start[b];
+    };
+    const double cx = (double)c.x, cy = (double)c.y;
     int cnt = 0;
-    double wsum = 0.0;
-    for (int j = 0; j < nrows_n; j++) {
-      const int q0 = __shfl(p0, gbase + j), q1 = __shfl(p1, gbase + j);
-      for (int p = q0 + gl; p < q1; p += 16) {
-        const float dx = __fsub_rn(c.x, sx[p]), dy = __fsub_rn(c.y, sy[p]);
-        const float d2 = __fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy));     // FLANN L2_Simple
-        if (d2 < cm.r2) {                                                      // RadiusResultSet: strict <
-          cnt++;
-          wsum += cm.weight_intensity ? fmax((double)si[p] - 60.0, 0.0) : 1.0; // pointnormal.cpp:15
-        }
+    double s0 = 0.0, s1x = 0.0, s1y = 0.0, sxx = 0.0, sxy = 0.0, syy = 0.0;
+    // ONE pass over the candidates: weighted raw moments about the voxel centroid (|x'| <= radius, so
+    // forming mean/covariance from them loses a few ulp at most; the reference's normalise-then-two-
+    // pass form, pointnormal.cpp:18-33, is algebraically the same).
+    auto accum = [&](const float4 q) {
+      const float dx = __fsub_rn(c.x, q.x), dy = __fsub_rn(c.y, q.y);
+      const float d2 = __fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy));         // FLANN L2_Simple
+      if (d2 < cm.r2) {                                                          // RadiusResultSet: strict <
+        const double w = cm.weight_intensity ? fmax((double)q.z - 60.0, 0.0) : 1.0;     // pointnormal.cpp:15
+        const double xr = (double)q.x - cx, yr = (double)q.y - cy;
+        const double wx = w * xr, wy = w * yr;
+        cnt++;
+        s0 += w; s1x += wx; s1y += wy;
+        sxx += wx * xr; sxy += wx * yr; syy += wy * yr;
+      }
+    };
+    auto scan_run = [&](int p0, int p1) {
+      int p = p0;
+      for (; p + 3 < p1; p += 4) {                        // four independent loads in flight
+        const float4 qa = spt[p], qb = spt[p + 1], qc = spt[p + 2], qd = spt[p + 3];
+        accum(qa); accum(qb); accum(qc); accum(qd);
+      }
+      for (; p < p1; p++) accum(spt[p]);
+    };
+    if (cm.reach == 1) {
+      int a0, a1, b0, b1, c0, c1;
+      run_of(iy - 1, a0, a1);
+      run_of(iy, b0, b1);
+      run_of(iy + 1, c0, c1);
+      if ((a1 - a0) + (b1 - b0) + (c1 - c0) >= 6) {       // upper bound on the neighbour count
+        scan_run(a0, a1);
+        scan_run(b0, b1);
+        scan_run(c0, c1);
+      }
+    } else {
+      for (int yy = iy - cm.reach; yy <= iy + cm.reach; yy++) {
+        int p0, p1;
+        run_of(yy, p0, p1);
+        scan_run(p0, p1);
       }
     }
-    cnt = row16_sum_i32(cnt);
     int valid = 0;
-    TmpCell tc;
-    if (cnt >= 6) {                                                            // pointnormal.cpp:291
-      const double sum_intensity = row16_sum_f64(wsum);
-      // pass 2: weighted mean (weights normalised first, pointnormal.cpp:21-24)
-      double u0 = 0.0, u1 = 0.0;
-      for (int j = 0; j < nrows_n; j++) {
-        const int q0 = __shfl(p0, gbase + j), q1 = __shfl(p1, gbase + j);
-        for (int p = q0 + gl; p < q1; p += 16) {
-          const float dx = __fsub_rn(c.x, sx[p]), dy = __fsub_rn(c.y, sy[p]);
-          const float d2 = __fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy));
-          if (d2 < cm.r2) {
-            const double w = (cm.weight_intensity ? fmax((double)si[p] - 60.0, 0.0) : 1.0) / sum_intensity;
-            u0 += w * (double)sx[p];
-            u1 += w * (double)sy[p];
-          }
-        }
-      }
-      u0 = row16_sum_f64(u0);
-      u1 = row16_sum_f64(u1);
-      // pass 3: covariance x^T (w .* x) about the mean (pointnormal.cpp:26-33)
-      double c00 = 0, c01 = 0, c10 = 0, c11 = 0;
-      for (int j = 0; j < nrows_n; j++) {
-        const int q0 = __shfl(p0, gbase + j), q1 = __shfl(p1, gbase + j);
-        for (int p = q0 + gl; p < q1; p += 16) {
-          const float dx = __fsub_rn(c.x, sx[p]), dy = __fsub_rn(c.y, sy[p]);
-          const float d2 = __fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy));
-          if (d2 < cm.r2) {
-            const double w = (cm.weight_intensity ? fmax((double)si[p] - 60.0, 0.0) : 1.0) / sum_intensity;
-            const double x0 = (double)sx[p] - u0, x1 = (double)sy[p] - u1;
-            const double xw0 = w * x0, xw1 = w * x1;
-            c00 += x0 * xw0; c01 += x0 * xw1; c10 += x1 * xw0; c11 += x1 * xw1;
-          }
-        }
-      }
-      c00 = row16_sum_f64(c00); c01 = row16_sum_f64(c01);
-      c10 = row16_sum_f64(c10); c11 = row16_sum_f64(c11);
+    if (cnt >= 6) {                                                              // pointnormal.cpp:291
+      const double sum_intensity = s0;
+      const double mx = s1x / sum_intensity, my = s1y / sum_intensity;
+      const double u0 = cx + mx, u1 = cy + my;
+      const double c00 = sxx / sum_intensity - mx * mx;
+      const double c10 = sxy / sum_intensity - mx * my;
+      const double c01 = c10;
+      const double c11 = syy / sum_intensity - my * my;
       double lmin, lmax, vmin[2];
       sym2_eig(c00, c10, c11, lmin, lmax, vmin);                               // pointnormal.cpp:39-45
       const double condition_number = fabs(lmax / lmin);                       // :53
@@ -368,21 +496,27 @@ __global__ __launch_bounds__(kSurfThreads) void surface_points_kernel(const Surf
       double n0 = vmin[0], n1 = vmin[1];
       if (n0 * (cm.origin[0] - u0) + n1 * (cm.origin[1] - u1) < 0) { n0 = -n0; n1 = -n1; }   // :59-61
       valid = cov_reasonable ? 1 : 0;
-      tc.mean[0] = u0; tc.mean[1] = u1;
-      tc.normal[0] = n0; tc.normal[1] = n1;
-      tc.cov[0] = c00; tc.cov[1] = c01; tc.cov[2] = c10; tc.cov[3] = c11;
-      tc.scale = log(1.0 + condition_number / 2);                              // :57
-      tc.avg_intensity = sum_intensity / (double)cnt;                          // :19
-      tc.lmin = lmin; tc.lmax = lmax;
-      tc.nsamples = cnt;
-      tc.valid = valid;
-      if (gl == 0 && valid) tmp[v] = tc;
+      if (valid) {
+        TmpCell tc;
+        tc.mean[0] = u0; tc.mean[1] = u1;
+        tc.normal[0] = n0; tc.normal[1] = n1;
+        tc.cov[0] = c00; tc.cov[1] = c01; tc.cov[2] = c10; tc.cov[3] = c11;
+        tc.scale = log(1.0 + condition_number / 2);                            // :57
+        tc.avg_intensity = sum_intensity / (double)cnt;                        // :19
+        tc.lmin = lmin; tc.lmax = lmax;
+        tc.nsamples = cnt;
+        tc.valid = valid;
+        tmp[v] = tc;
+      }
     }
-    if (gl == 0) coff[v] = valid;
+    coff[v] = valid;
   }
   __threadfence_block();
   __syncthreads();
 
+#ifdef CFEAR_SURF_TIMING
+  if (tid == 0) tstamp[5] = __builtin_readcyclecounter();
+#endif
   // ---- 5. compaction in voxel order -----------------------------------------------------------
   if (tid == 0) sh_misc[0] = 0;
   __syncthreads();
@@ -411,6 +545,16 @@ __global__ __launch_bounds__(kSurfThreads) void surface_points_kernel(const Surf
     if (tid == 0) { int tot = 0; for (int wv = 0; wv < 16; wv++) tot += red_i[wv]; sh_misc[0] += tot; }
     __syncthreads();
   }
+#ifdef CFEAR_SURF_TIMING
+  if (tid == 0) tstamp[6] = __builtin_readcyclecounter();
+#endif
+  // ---- 6. x-sorted copy of the float means for the matcher's windowed exact 1-NN -----------------
+  __threadfence_block();
+  __syncthreads();
+  sort_cells_block(job.out, min(sh_misc[0], job.out.cap), (unsigned long long*)smem);
+#ifdef CFEAR_SURF_TIMING
+  if (tid == 0) { tstamp[7] = __builtin_readcyclecounter(); tstamp[8] = n; tstamp[9] = sh_misc[0]; }
+#endif
   if (tid == 0) {
     const int total = sh_misc[0];
     *job.out.n_cells = total <= job.out.cap ? total : job.out.cap;
@@ -586,6 +730,21 @@ extern "C" int cfear_scan_from_cells(cfear_ctx* ctx, const cfear_cell* cells, in
     CFEAR_HIP_CHECK(ctx, hipMemcpyAsync(d, cells, (size_t)n_cells * sizeof(cfear_cell), hipMemcpyHostToDevice, ctx->stream));
   hipLaunchKernelGGL(cells_to_slab_kernel, dim3((n_cells + 255) / 256 + 1), dim3(256), 0, ctx->stream, d, n_cells, s->view);
   CFEAR_HIP_CHECK(ctx, hipGetLastError());
+  {
+    int npad = 64;
+    while (npad < n_cells) npad <<= 1;
+    if ((size_t)npad * 8 > 64 * 1024) {
+      static bool attr_set = false;
+      if (!attr_set) {
+        CFEAR_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)scan_sort_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                 (int)((size_t)kMaxPoints * 8)));
+        attr_set = true;
+      }
+    }
+    if (npad > kMaxPoints) { cfear_scan_destroy(s); return cfear_set_error(ctx, CFEAR_ERR_CAPACITY, "more than %d cells", kMaxPoints); }
+    hipLaunchKernelGGL(scan_sort_kernel, dim3(1), dim3(kSurfThreads), (size_t)npad * 8, ctx->stream, s->view);
+    CFEAR_HIP_CHECK(ctx, hipGetLastError());
+  }
   CFEAR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));     // caller's host array may go away
   s->n_cells_host = n_cells;
   *out = s;
@@ -608,3 +767,15 @@ extern "C" int cfear_scan_get_cells(const cfear_scan* scan, cfear_cell* out_host
   CFEAR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   return n;
 }
+
+#ifdef CFEAR_SURF_TIMING
+// debug only (not in the header): cycle stamps of the last single-scan cfear_scan_create
+extern "C" int cfear_debug_surface_stamps(cfear_ctx* ctx, long long* out16) {
+  char* ws = (char*)ctx->ws[5].p;
+  if (!ws) return -1;
+  const size_t off = 1024 + (size_t)kMaxPoints * 16 + (size_t)kMaxPoints * 8 + (size_t)kMaxPoints * sizeof(TmpCell) +
+                     (size_t)(kMaxPoints - 64) * 4;
+  (void)hipStreamSynchronize(ctx->stream);
+  return hipMemcpy(out16, ws + off, 16 * 8, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -2;
+}
+#endif
