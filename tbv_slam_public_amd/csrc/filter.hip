@@ -43,24 +43,26 @@ struct KStrongArgs {
   uint8_t* is_peak;
 };
 
-// bit 7 of every byte of the result is set iff that byte of x is >= t (0 <= t <= 255), given the
-// two precomputed halves xlo = (x & 0x7f7f7f7f) | 0x80808080 and xh = x & 0x80808080.
+// bit 7 of every byte of the result is set iff that byte of x is >= t (0 <= t <= 255).
 // Per byte (0x80 + low7) - (t & 0x7f) stays in [1, 0xff]: no borrow crosses a byte boundary.
-__device__ __forceinline__ uint32_t swar_ge(uint32_t xlo, uint32_t xh, uint32_t tl4, bool thi) {
-  const uint32_t g = xlo - tl4;
+__device__ __forceinline__ uint32_t swar_ge(uint32_t x, uint32_t tl4, bool thi) {
+  const uint32_t g = ((x & 0x7f7f7f7fu) | 0x80808080u) - tl4;
+  const uint32_t xh = x & 0x80808080u;
   return thi ? (xh & g) : ((g & 0x80808080u) | xh);
 }
 
-// Reads the row into registers: lane L of chunk c owns bytes [(c*64+L)*16, +16).
+// Reads the row into registers: lane L of chunk c owns bytes [(c*64+L)*16, +16).  Lanes whose chunk
+// lies entirely past the row end hold zeros and issue no loads.
 template <int NCHUNK, bool VEC>
 __device__ __forceinline__ void load_row(const uint8_t* rowp, int cols, int lane, uint32_t (&w)[NCHUNK * 4]) {
 #pragma unroll
   for (int c = 0; c < NCHUNK; c++) {
     const int pos = (c * 64 + lane) * 16;
+    w[c * 4 + 0] = w[c * 4 + 1] = w[c * 4 + 2] = w[c * 4 + 3] = 0u;
     if (VEC && pos + 16 <= cols) {
       const u32x4 v = __builtin_nontemporal_load((const u32x4*)(rowp + pos));
       w[c * 4 + 0] = v.x; w[c * 4 + 1] = v.y; w[c * 4 + 2] = v.z; w[c * 4 + 3] = v.w;
-    } else {
+    } else if (pos < cols) {                       // unaligned image or the partial tail chunk
 #pragma unroll
       for (int d = 0; d < 4; d++) {
         uint32_t word = 0;
@@ -131,129 +133,148 @@ __global__ __launch_bounds__(256) void kstrongest_rows_kernel(const KStrongArgs 
   const uint8_t* img = a.polar + (long long)b * a.batch_stride;
   const long long row_lin = (long long)r * a.stride;
   const uint8_t* rowp = img + row_lin;
-  const int kpad = (a.k + 3) & ~3;
-  const int per_wave = kpad * 4 + (a.want_peaks ? NCHUNK * 1024 : 0);
-  uint32_t* list = (uint32_t*)(smem + wave * per_wave);
-  uint8_t* rowbuf = smem + wave * per_wave + kpad * 4;
+  const int k = a.k;
+  const int kpad = (k + 3) & ~3;
+  const int per_wave = 1024 + kpad * 4 + (a.want_peaks ? NCHUNK * 1024 : 0);
+  uint32_t* hist = (uint32_t*)(smem + wave * per_wave);            // [256] per-row intensity histogram
+  uint32_t* list = (uint32_t*)(smem + wave * per_wave + 1024);     // [kpad] survivors (packed keys)
+  uint8_t* rowbuf = smem + wave * per_wave + 1024 + kpad * 4;
 
   uint32_t w[NCHUNK * 4];
   load_row<NCHUNK, VEC>(rowp, a.cols, lane, w);
-
-  uint32_t xlo[NCHUNK * 4], xh[NCHUNK * 4], vm[NCHUNK * 4];
-#pragma unroll
-  for (int i = 0; i < NCHUNK * 4; i++) {
-    xlo[i] = (w[i] & 0x7f7f7f7fu) | 0x80808080u;
-    xh[i] = w[i] & 0x80808080u;
-    if (MASK) {                                    // validity of each byte position (tail / z_min==0)
-      const int pos = ((i >> 2) * 64 + lane) * 16 + (i & 3) * 4;
-      const int rem = a.cols - pos;
-      vm[i] = rem >= 4 ? 0x80808080u : (rem <= 0 ? 0u : (0x80808080u & ((1u << (8 * rem)) - 1u)));
-    } else {
-      vm[i] = 0x80808080u;
-    }
-  }
   if (a.want_peaks) {                              // stage the raw row for the 7-tap box sums
 #pragma unroll
     for (int c = 0; c < NCHUNK; c++)
       *(uint4*)(rowbuf + (c * 64 + lane) * 16) = make_uint4(w[c * 4], w[c * 4 + 1], w[c * 4 + 2], w[c * 4 + 3]);
   }
 
-  // number of bins with intensity >= t (wave-uniform t in [0,256])
-  auto count_ge = [&](int t) -> int {
-    if (t > 255) return 0;
-    const uint32_t tl4 = (uint32_t)(t & 0x7f) * 0x01010101u;
-    const bool thi = (t & 0x80) != 0;
-    int c0 = 0, c1 = 0;
+  // ---- candidates: bins with intensity >= uchar(z_min) (radar_filters.cpp:217) ---------------------
+  const uint32_t tz4 = (uint32_t)(a.u_zmin & 0x7f) * 0x01010101u;
+  const bool tzhi = (a.u_zmin & 0x80) != 0;
+  uint32_t mz[NCHUNK * 4];                         // bit 7 of byte j set <=> bin is a candidate
+  int c_lane = 0;
 #pragma unroll
-    for (int i = 0; i < NCHUNK * 4; i += 2) {
-      uint32_t m0 = swar_ge(xlo[i], xh[i], tl4, thi), m1 = swar_ge(xlo[i + 1], xh[i + 1], tl4, thi);
-      if (MASK) { m0 &= vm[i]; m1 &= vm[i + 1]; }
-      c0 += __popc(m0);
-      c1 += __popc(m1);
+  for (int i = 0; i < NCHUNK * 4; i++) {
+    uint32_t m = swar_ge(w[i], tz4, tzhi);
+    if (MASK) {                                    // byte validity (row tail / z_min == 0)
+      const int rem = a.cols - (((i >> 2) * 64 + lane) * 16 + (i & 3) * 4);
+      m &= rem >= 4 ? 0x80808080u : (rem <= 0 ? 0u : (0x80808080u & ((1u << (8 * rem)) - 1u)));
     }
-    return wave_sum_i32(c0 + c1);
-  };
-
-  // ---- threshold search: T = largest intensity with count(>= T) >= k ----------------------
-  const int k = a.k;
-  const int n_ge = count_ge(a.u_zmin);
-  int thr_gt, T, skip_eq;          // select all >= thr_gt, plus the (n_eq - skip_eq) largest ranges == T
-  bool ties;
-  if (n_ge <= k) {
-    thr_gt = a.u_zmin; T = -1; skip_eq = 0; ties = false;
-  } else {
-    int lo = a.u_zmin, hi = 255, n_lo = n_ge;
-    while (lo < hi) {              // invariant: count(>= lo) >= k, count(>= hi+1) < k
-      const int mid = (lo + hi + 1) >> 1;
-      const int c = count_ge(mid);
-      if (c >= k) { lo = mid; n_lo = c; } else { hi = mid - 1; }
-    }
-    T = lo;
-    const int n_gt = count_ge(T + 1);
-    const int n_eq = n_lo - n_gt;
-    skip_eq = n_eq - (k - n_gt);   // drop the lowest-range ties (lexicographic (intensity,range))
-    thr_gt = T + 1;
-    ties = true;
+    mz[i] = m;
+    c_lane += __popc(m);
   }
+  const int c_incl = wave_incl_scan_i32(c_lane);
+  const int n_ge = __builtin_amdgcn_readlane(c_incl, 63);
+  int n_sel;
 
-  // ---- ordered compaction of the survivors into list[] (position order) --------------------
-  int g_base = 0, e_base = 0;      // survivors with intensity > T / == T before the current chunk
-  const uint32_t tg4 = (uint32_t)(thr_gt & 0x7f) * 0x01010101u;
-  const bool tghi = (thr_gt & 0x80) != 0;
-  const uint32_t te4 = (uint32_t)(T & 0x7f) * 0x01010101u;
-  const bool tehi = (T & 0x80) != 0;
+  if (n_ge <= k) {
+    // ---- every candidate survives: compact in (lane, position) order; ranking below restores
+    //      the reference's ascending (intensity, range) order ------------------------------------------
+    n_sel = n_ge;
+    if (c_lane) {
+      int slot = c_incl - c_lane;
 #pragma unroll
-  for (int c = 0; c < NCHUNK; c++) {
-    uint32_t mg[4], me[4];
-    int cg = 0, ce = 0;
-#pragma unroll
-    for (int d = 0; d < 4; d++) {
-      const int i = c * 4 + d;
-      mg[d] = thr_gt > 255 ? 0u : swar_ge(xlo[i], xh[i], tg4, tghi);
-      if (MASK) mg[d] &= vm[i];
-      me[d] = 0;
-      if (ties) {
-        uint32_t ge_t = swar_ge(xlo[i], xh[i], te4, tehi);
-        if (MASK) ge_t &= vm[i];
-        me[d] = ge_t & ~mg[d];
-      }
-      cg += __popc(mg[d]);
-      ce += __popc(me[d]);
-    }
-    const int packed = (ce << 16) | cg;            // one scan carries both prefixes (totals < 65536)
-    const int incl = wave_incl_scan_i32(packed);
-    const int tot = __builtin_amdgcn_readlane(incl, 63);
-    const int excl = incl - packed;
-    int g_run = g_base + (excl & 0xFFFF);
-    int e_run = e_base + (excl >> 16);
-    if (cg + ce) {
-#pragma unroll
-      for (int d = 0; d < 4; d++) {
-        uint32_t mm = mg[d] | me[d];
+      for (int i = 0; i < NCHUNK * 4; i++) {
+        uint32_t mm = mz[i];
         while (mm) {
-          const int bit = __ffs(mm) - 1;           // bit 7 of byte (bit >> 3)
+          const int bit = __ffs(mm) - 1;
           mm &= mm - 1;
           const int by = bit >> 3;
-          const bool is_eq = (me[d] >> bit) & 1u;
-          bool selected = true;
-          if (is_eq) { selected = e_run >= skip_eq; }
-          // slot = #(> T) before + #(selected == T) before
-          const int e_sel_before = e_run > skip_eq ? e_run - skip_eq : 0;
-          if (selected) {
-            const int slot = g_run + e_sel_before;
-            const int pos = (c * 64 + lane) * 16 + d * 4 + by;
-            const uint32_t inten = (w[c * 4 + d] >> (8 * by)) & 0xffu;
-            list[slot] = (inten << 24) | (uint32_t)pos;
-          }
-          if (is_eq) e_run++; else g_run++;
+          const int pos = ((i >> 2) * 64 + lane) * 16 + (i & 3) * 4 + by;
+          list[slot++] = (((w[i] >> (8 * by)) & 0xffu) << 24) | (uint32_t)pos;
         }
       }
     }
-    g_base += tot & 0xFFFF;
-    e_base += tot >> 16;
+  } else {
+    // ---- more than k candidates: cut intensity T from an LDS histogram of the candidates ----------
+    n_sel = k;
+    *(uint4*)(hist + lane * 4) = make_uint4(0, 0, 0, 0);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (c_lane) {
+#pragma unroll
+      for (int i = 0; i < NCHUNK * 4; i++) {
+        uint32_t mm = mz[i];
+        while (mm) {
+          const int bit = __ffs(mm) - 1;
+          mm &= mm - 1;
+          atomicAdd(&hist[(w[i] >> (bit & ~7)) & 0xffu], 1u);
+        }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // lane L owns intensities 4*(63-L)+{0..3}: an inclusive scan over lanes counts from 255 downward
+    const uint4 h = *(const uint4*)(hist + (63 - lane) * 4);
+    const int s_lane = (int)(h.x + h.y + h.z + h.w);
+    const int s_incl = wave_incl_scan_i32(s_lane);
+    const unsigned long long reach = __ballot(s_incl >= k);
+    const int lc = __ffsll((long long)reach) - 1;                  // first lane whose cumulative count reaches k
+    int T = 0, n_gt = 0, n_eq = 0;
+    {
+      int cum = s_incl - s_lane;
+      const int hv[4] = {(int)h.w, (int)h.z, (int)h.y, (int)h.x};  // descending intensity
+      bool found = false;
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        if (!found && cum + hv[j] >= k) { T = 4 * (63 - lane) + 3 - j; n_gt = cum; n_eq = hv[j]; found = true; }
+        cum += hv[j];
+      }
+    }
+    T = __builtin_amdgcn_readlane(T, lc);
+    n_gt = __builtin_amdgcn_readlane(n_gt, lc);
+    n_eq = __builtin_amdgcn_readlane(n_eq, lc);
+    const int skip_eq = n_eq - (k - n_gt);         // drop the lowest-range ties: lexicographic (intensity, range)
+    // ---- ordered compaction: all (> T) plus the (== T) bins of rank >= skip_eq in position order -----
+    const int thr_gt = T + 1;
+    const uint32_t tg4 = (uint32_t)(thr_gt & 0x7f) * 0x01010101u;
+    const bool tghi = (thr_gt & 0x80) != 0;
+    const uint32_t te4 = (uint32_t)(T & 0x7f) * 0x01010101u;
+    const bool tehi = (T & 0x80) != 0;
+    int g_base = 0, e_base = 0;                    // survivors > T / bins == T before the current chunk
+#pragma unroll
+    for (int c = 0; c < NCHUNK; c++) {
+      uint32_t mg[4], me[4];
+      int cg = 0, ce = 0;
+#pragma unroll
+      for (int d = 0; d < 4; d++) {
+        const int i = c * 4 + d;
+        mg[d] = thr_gt > 255 ? 0u : (swar_ge(w[i], tg4, tghi) & mz[i]);
+        me[d] = swar_ge(w[i], te4, tehi) & mz[i] & ~mg[d];
+        cg += __popc(mg[d]);
+        ce += __popc(me[d]);
+      }
+      const int packed = (ce << 16) | cg;          // one scan carries both prefixes (totals < 65536)
+      const int incl = wave_incl_scan_i32(packed);
+      const int tot = __builtin_amdgcn_readlane(incl, 63);
+      const int excl = incl - packed;
+      int g_run = g_base + (excl & 0xFFFF);
+      int e_run = e_base + (excl >> 16);
+      if (cg + ce) {
+#pragma unroll
+        for (int d = 0; d < 4; d++) {
+          uint32_t mm = mg[d] | me[d];
+          while (mm) {
+            const int bit = __ffs(mm) - 1;         // bit 7 of byte (bit >> 3)
+            mm &= mm - 1;
+            const int by = bit >> 3;
+            const bool is_eq = (me[d] >> bit) & 1u;
+            const bool selected = !is_eq || e_run >= skip_eq;
+            const int e_sel_before = e_run > skip_eq ? e_run - skip_eq : 0;
+            if (selected) {
+              const int pos = (c * 64 + lane) * 16 + d * 4 + by;
+              list[g_run + e_sel_before] = (((w[c * 4 + d] >> (8 * by)) & 0xffu) << 24) | (uint32_t)pos;
+            }
+            if (is_eq) e_run++; else g_run++;
+          }
+        }
+      }
+      g_base += tot & 0xFFFF;
+      e_base += tot >> 16;
+    }
   }
-  const int n_sel = ties ? k : n_ge;
-  for (int j = n_sel + lane; j < kpad; j += 64) list[j] = 0xFFFFFFFFu;    // pad for the b128 reads
+  const int nq = (n_sel + 3) & ~3;
+  for (int j = n_sel + lane; j < nq; j += 64) list[j] = 0xFFFFFFFFu;      // pad for the b128 reads
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -264,7 +285,7 @@ __global__ __launch_bounds__(256) void kstrongest_rows_kernel(const KStrongArgs 
     if (j < n_sel) {
       const uint32_t key = list[j];
       int rank = 0;
-      for (int i = 0; i < kpad; i += 4) {
+      for (int i = 0; i < nq; i += 4) {
         const uint4 q = *(const uint4*)(list + i);  // same address in every lane: LDS broadcast
         rank += (q.x < key) + (q.y < key) + (q.z < key) + (q.w < key);
       }
@@ -568,10 +589,10 @@ int cfear_kstrong_device(cfear_ctx* ctx, const uint8_t* d_polar, const cfear_pol
   const int kpad = (a.k + 3) & ~3;
   {
     ProfScope ps(ctx, "kstrongest_rows");
-    if (nchunk <= 1) launch_kstrong<1>(ctx, a, vec, mask, grid, (size_t)kRowsPerBlock * (kpad * 4 + (a.want_peaks ? 1 * 1024 : 0)));
-    else if (nchunk <= 2) launch_kstrong<2>(ctx, a, vec, mask, grid, (size_t)kRowsPerBlock * (kpad * 4 + (a.want_peaks ? 2 * 1024 : 0)));
-    else if (nchunk <= 4) launch_kstrong<4>(ctx, a, vec, mask, grid, (size_t)kRowsPerBlock * (kpad * 4 + (a.want_peaks ? 4 * 1024 : 0)));
-    else launch_kstrong<8>(ctx, a, vec, mask, grid, (size_t)kRowsPerBlock * (kpad * 4 + (a.want_peaks ? 8 * 1024 : 0)));
+    if (nchunk <= 1) launch_kstrong<1>(ctx, a, vec, mask, grid, (size_t)kRowsPerBlock * (1024 + kpad * 4 + (a.want_peaks ? 1 * 1024 : 0)));
+    else if (nchunk <= 2) launch_kstrong<2>(ctx, a, vec, mask, grid, (size_t)kRowsPerBlock * (1024 + kpad * 4 + (a.want_peaks ? 2 * 1024 : 0)));
+    else if (nchunk <= 4) launch_kstrong<4>(ctx, a, vec, mask, grid, (size_t)kRowsPerBlock * (1024 + kpad * 4 + (a.want_peaks ? 4 * 1024 : 0)));
+    else launch_kstrong<8>(ctx, a, vec, mask, grid, (size_t)kRowsPerBlock * (1024 + kpad * 4 + (a.want_peaks ? 8 * 1024 : 0)));
   }
   CFEAR_HIP_CHECK(ctx, hipGetLastError());
   if (o->xyzi || o->n_points || o->xyzi_peaks || o->n_peaks) {
