@@ -43,8 +43,9 @@ struct RegCommon {
   size_t scratch_stride;
   int32_t slots_cap;
   int32_t lds_targets;                        // capacity of the staged (x-sorted) target arrays
-  int32_t dense_cap_lds;                      // correspondences that fit the LDS dense arrays
+  int32_t dense_cap_lds;                      // correspondences that fit the LDS dense arrays (slot path)
   int32_t dense_fields;                       // doubles per correspondence (5 P2P, 7 P2L, 8 P2D)
+  uint32_t lds_total;                         // dynamic LDS bytes of the launch
   cfear_reg_result* results;
 };
 
@@ -55,7 +56,7 @@ __host__ __device__ inline size_t reg_lds_targets_bytes(int lds_targets) { retur
 size_t reg_lds_bytes(int lds_targets, int dense_cap, int dense_fields) {
   return 704 + reg_lds_targets_bytes(lds_targets) + (size_t)dense_cap * dense_fields * 8;
 }
-constexpr size_t kRegLdsBudget = 72 * 1024;          // keeps >= 2 workgroups per CU (160 KiB LDS)
+constexpr size_t kRegLdsBudget = 80 * 1024 - 256;    // keeps 2 workgroups per CU (160 KiB LDS)
 constexpr size_t kRegLdsBudgetWave = 16 * 1024;      // wave-per-job geometry: >= 8 wavefronts per CU
 // Measured on MI355X (round 1): with ~190 VGPRs only 2 wavefronts fit a SIMD, so the wave-per-job
 // geometry is latency-bound on its 4x longer per-lane loops (4096 jobs: 6.7 ms vs 6.0 ms); disabled.
@@ -412,6 +413,210 @@ __device__ int compact_slots(const RegJob& job, const RegCommon& cm, const Slots
   return total;
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Fused association for register_kernel: everything the association touches repeatedly is staged in
+// LDS once per registration (x-sorted float means of ALL fixed keyframes, the source cells, the
+// keyframe transforms); each outer iteration then runs two passes over the flattened (keyframe,
+// source cell) pairs -- match + normal gate, block scan, then gather of the matched target's
+// attributes straight into the dense correspondence arrays -- with no global scratch in between.
+// ---------------------------------------------------------------------------------------------------
+struct FusedLds {
+  double* kf;          // [16][12]: Ttar (l0..l3,t0,t1), Tst (l0..l3,t0,t1)
+  int* koff;           // [17] prefix of target counts
+  float* tx; float* ty; int* tidx;     // [sum targets]
+  double2* smean; double2* snormal; double* sscale; int* sns;   // [n_src]
+  int* match;          // [n_pairs]
+  double* dense;       // rest
+  int dense_cap;
+};
+
+// Carves the workgroup's dynamic LDS (bytes `lds_total`) for the actual sizes; returns false when the
+// fixed parts leave no room (the caller then uses the slot-array path).
+__device__ __forceinline__ bool fused_carve(uint8_t* smem, size_t lds_total, int sum_tar, int n_src, int n_pairs,
+                                            int fields, FusedLds& f) {
+  size_t off = 704;
+  f.kf = (double*)(smem + off); off += 16 * 12 * 8;
+  f.koff = (int*)(smem + off); off += 80;
+  const size_t tt = ((size_t)sum_tar + 3) & ~(size_t)3;
+  f.tx = (float*)(smem + off); off += tt * 4;
+  f.ty = (float*)(smem + off); off += tt * 4;
+  f.tidx = (int*)(smem + off); off += tt * 4;
+  off = (off + 15) & ~(size_t)15;
+  const size_t ns = ((size_t)n_src + 1) & ~(size_t)1;
+  f.smean = (double2*)(smem + off); off += ns * 16;
+  f.snormal = (double2*)(smem + off); off += ns * 16;
+  f.sscale = (double*)(smem + off); off += ns * 8;
+  f.sns = (int*)(smem + off); off += ns * 4;
+  f.match = (int*)(smem + off); off += (((size_t)n_pairs + 3) & ~(size_t)3) * 4;
+  off = (off + 15) & ~(size_t)15;
+  if (off + 1024 > lds_total) return false;
+  f.dense = (double*)(smem + off);
+  f.dense_cap = (int)((lds_total - off) / ((size_t)fields * 8));
+  return true;
+}
+
+template <int NW>
+__device__ void fused_stage(const RegJob& job, const FusedLds& f) {
+  const int tid = threadIdx.x, last = job.n_scans - 1;
+  if (tid == 0) {
+    int acc = 0;
+    for (int i = 0; i < last; i++) { f.koff[i] = acc; acc += *job.scans[i].n_cells; }
+    f.koff[last] = acc;
+  }
+  if (tid < last) {                                      // Ttar_i = vectorToAffine(pose_i), fixed
+    const Aff2 T = aff_from_xyt(job.poses[tid]);
+    double* k = f.kf + tid * 12;
+    k[0] = T.l0; k[1] = T.l1; k[2] = T.l2; k[3] = T.l3; k[4] = T.t0; k[5] = T.t1;
+  }
+  __syncthreads();
+  for (int i = 0; i < last; i++) {
+    const ScanView& tar = job.scans[i];
+    const int n = f.koff[i + 1] - f.koff[i], o = f.koff[i];
+    for (int j = tid; j < n; j += NW * 64) {
+      f.tx[o + j] = tar.sorted_x[j];
+      f.ty[o + j] = tar.sorted_y[j];
+      f.tidx[o + j] = tar.sorted_idx[j];
+    }
+  }
+  const ScanView& src = job.scans[last];
+  const int n_src = *src.n_cells;
+  for (int s = tid; s < n_src; s += NW * 64) {
+    f.smean[s] = src.mean[s];
+    f.snormal[s] = src.normal[s];
+    f.sscale[s] = src.scale[s];
+    f.sns[s] = src.nsamples[s];
+  }
+  __syncthreads();
+}
+
+// One association pass (n_scan_normal.cpp:213-318) at source pose xsrc; fills `dn`; returns #blocks.
+template <int NW>
+__device__ int associate_fused(const RegJob& job, const RegCommon& cm, const double* xsrc, int itr, const FusedLds& f,
+                               double* gl_dense, Dense& dn, int* ipart, int& iphase) {
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int last = job.n_scans - 1;
+  const int n_src = *job.scans[last].n_cells;
+  const int n_pairs = last * n_src;
+  const double curr_radius = (itr == 1) ? 2 * cm.par.radius : cm.par.radius;    // :220
+  const double r2 = curr_radius * curr_radius;
+  const float rwin = (float)curr_radius + 1e-3f;
+  if (tid < last) {                                      // Tsrctotar_i = Ttar_i^-1 * Tsrc  (:222)
+    const double* k = f.kf + tid * 12;
+    const Aff2 Ttar{k[0], k[1], k[2], k[3], k[4], k[5]};
+    const Aff2 Tst = aff_mul(aff_inv(Ttar), aff_from_xyt(xsrc));
+    double* o = f.kf + tid * 12 + 6;
+    o[0] = Tst.l0; o[1] = Tst.l1; o[2] = Tst.l2; o[3] = Tst.l3; o[4] = Tst.t0; o[5] = Tst.t1;
+  }
+  __syncthreads();
+  // ---- pass 1: exact windowed 1-NN + normal gate -> match[] --------------------------------------
+  int accepted = 0;
+  {
+    int i = 0, s = tid;
+    while (s >= n_src && i < last) { s -= n_src; i++; }
+    for (int p = tid; p < n_pairs; p += NW * 64) {
+      const double* T = f.kf + i * 12 + 6;
+      const double2 u = f.smean[s];
+      const double px = T[0] * u.x + T[1] * u.y + T[4];
+      const double py = T[2] * u.x + T[3] * u.y + T[5];
+      const float qx = (float)px, qy = (float)py;                               // pointnormal.cpp:240-242
+      // Exact 1-NN (FLANN L2_Simple float distance, lowest index on ties) restricted to the window
+      // |x - qx| <= radius of the x-sorted order: nothing outside it can pass `dist < radius^2`.
+      const float xlo = qx - rwin, xhi = qx + rwin;
+      const int t0 = f.koff[i], t1 = f.koff[i + 1];
+      int lo = t0, hi = t1;
+      while (lo < hi) { const int mid = (lo + hi) >> 1; if (f.tx[mid] < xlo) lo = mid + 1; else hi = mid; }
+      int best = -1;
+      float bestd = FLT_MAX;
+      for (int q = lo; q < t1; q++) {
+        const float tx = f.tx[q];
+        if (tx > xhi) break;
+        const float dx = __fsub_rn(qx, tx), dy = __fsub_rn(qy, f.ty[q]);
+        const float d = __fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy));
+        const int idx = f.tidx[q];
+        if (d < bestd || (d == bestd && idx < best)) { best = idx; bestd = d; }
+      }
+      int m = -1;
+      if (best >= 0 && (double)bestd < r2) {                                    // pointnormal.cpp:250
+        const double2 ns = f.snormal[s];
+        const double2 nt = job.scans[i].normal[best];
+        const double nsx = T[0] * ns.x + T[1] * ns.y, nsy = T[2] * ns.x + T[3] * ns.y;
+        if (fmax(nsx * nt.x + nsy * nt.y, 0.0) > cm.angle_outlier) m = best;    // :244-245
+      }
+      f.match[p] = m;
+      accepted += (m >= 0);
+      s += NW * 64;
+      while (s >= n_src && i < last) { s -= n_src; i++; }
+    }
+  }
+  // ---- block scan of the accepted counts (thread-major order, deterministic) ----------------------
+  const int incl = wave_incl_scan_i32(accepted);
+  int base = incl - accepted, total;
+  if (NW == 1) {
+    total = __builtin_amdgcn_readlane(incl, 63);
+  } else {
+    int* buf = ipart + iphase * 4;
+    if (lane == 63) buf[wave] = incl;
+    __syncthreads();
+    for (int wv = 0; wv < wave; wv++) base += buf[wv];
+    int tt = buf[0];
+#pragma unroll
+    for (int wv = 1; wv < NW; wv++) tt += buf[wv];
+    total = __builtin_amdgcn_readfirstlane(tt);
+    iphase ^= 1;
+  }
+  const bool in_lds = total <= f.dense_cap;
+  dn.p = in_lds ? f.dense : gl_dense;
+  dn.cap = in_lds ? f.dense_cap : cm.slots_cap;
+  dn.n = total;
+  const size_t cap = (size_t)dn.cap;
+  // ---- pass 2: matched target attributes -> weights + world-frame block data -> dense arrays ------
+  {
+    int c = base, i = 0, s = tid;
+    while (s >= n_src && i < last) { s -= n_src; i++; }
+    for (int p = tid; p < n_pairs; p += NW * 64) {
+      const int best = f.match[p];
+      if (best >= 0) {
+        const ScanView& tar = job.scans[i];
+        const double* K = f.kf + i * 12;                  // Ttar
+        const double* T = K + 6;                          // Tsrctotar
+        const double2 nt = tar.normal[best];
+        const double2 tm = tar.mean[best];
+        const double2 ns = f.snormal[s];
+        const double nsx = T[0] * ns.x + T[1] * ns.y, nsy = T[2] * ns.x + T[3] * ns.y;
+        const double direction_similarity = fmax(nsx * nt.x + nsy * nt.y, 0.0);   // :244
+        const double w = get_weight(cm.par.weight_opt, (double)f.sns[s], (double)tar.nsamples[best],
+                                    direction_similarity, f.sscale[s], tar.scale[best]);   // :247-253, :273
+        const double2 sm = f.smean[s];
+        dn.p[c] = sm.x; dn.p[cap + c] = sm.y;
+        dn.p[2 * cap + c] = K[0] * tm.x + K[1] * tm.y + K[4];                     // Ttar * tar_mean
+        dn.p[3 * cap + c] = K[2] * tm.x + K[3] * tm.y + K[5];
+        dn.p[4 * cap + c] = w;
+        if (cm.par.cost == CFEAR_P2D) {                                           // :288-297
+          const double4 S = tar.cov[best];
+          const double a00 = K[0] * S.x + K[1] * S.z, a01 = K[0] * S.y + K[1] * S.w;
+          const double a10 = K[2] * S.x + K[3] * S.z, a11 = K[2] * S.y + K[3] * S.w;
+          const double c00 = (cm.par.regularization + (a00 * K[0] + a01 * K[1])) * cm.par.cov_scale;
+          const double c01 = (0.0 + (a00 * K[2] + a01 * K[3])) * cm.par.cov_scale;
+          const double c10 = (0.0 + (a10 * K[0] + a11 * K[1])) * cm.par.cov_scale;
+          const double c11 = (cm.par.regularization + (a10 * K[2] + a11 * K[3])) * cm.par.cov_scale;
+          const double det = c00 * c11 - c10 * c01, invdet = 1.0 / det;
+          const double i00 = c11 * invdet, i10 = -c10 * invdet, i11 = c00 * invdet;
+          const double l00 = sqrt(i00), l10 = i10 / l00;
+          dn.p[5 * cap + c] = l00; dn.p[6 * cap + c] = l10; dn.p[7 * cap + c] = sqrt(i11 - l10 * l10);
+        } else if (cm.par.cost == CFEAR_P2L) {
+          dn.p[5 * cap + c] = K[0] * nt.x + K[1] * nt.y;                          // Ttar.linear() * tar_normal
+          dn.p[6 * cap + c] = K[2] * nt.x + K[3] * nt.y;
+        }
+        c++;
+      }
+      s += NW * 64;
+      while (s >= n_src && i < last) { s -= n_src; i++; }
+    }
+  }
+  __syncthreads();
+  return total;
+}
+
 // Solves the SPD system A y = b (3x3, A = J^T J + D^2) by LDL^T: three divisions, no square roots.
 // Ceres factorises the same matrix with a sparse Cholesky; the solutions agree to rounding.
 __device__ __forceinline__ bool chol3_solve(const double A[9], const double b[3], double y[3]) {
@@ -581,6 +786,11 @@ __global__ __launch_bounds__(NW * 64) void register_kernel(const RegJob* __restr
   double* gl_dense = (double*)(cm.scratch + (size_t)blockIdx.x * cm.scratch_stride + slots_bytes(cm.slots_cap));
   Dense dn;
   int phase = 0, iphase = 0;
+  int sum_tar = 0;
+  for (int i = 0; i < last; i++) sum_tar += *job.scans[i].n_cells;
+  FusedLds fl;
+  const bool fused = fused_carve(smem, cm.lds_total, sum_tar, n_src, n_slots, cm.dense_fields, fl);
+  if (fused) fused_stage<NW>(job, fl);
   const int rpb = cm.par.cost == CFEAR_P2L ? 1 : 2;
   // n_scan_normal.cpp:82-185
   double prev_par[3] = {x[0], x[1], x[2]};
@@ -596,9 +806,14 @@ __global__ __launch_bounds__(NW * 64) void register_kernel(const RegJob* __restr
 #ifdef CFEAR_REG_TIMING
     const long long ta0 = __builtin_readcyclecounter();
 #endif
-    const int mine = associate_all<NW>(job, cm, x, itr, sl, lt);
-    __threadfence_block();
-    const int n_blocks = compact_slots<NW>(job, cm, sl, n_slots, n_src, mine, lds_dense, gl_dense, dn, ipart, iphase);
+    int n_blocks;
+    if (fused) {
+      n_blocks = associate_fused<NW>(job, cm, x, itr, fl, gl_dense, dn, ipart, iphase);
+    } else {
+      const int mine = associate_all<NW>(job, cm, x, itr, sl, lt);
+      __threadfence_block();
+      n_blocks = compact_slots<NW>(job, cm, sl, n_slots, n_src, mine, lds_dense, gl_dense, dn, ipart, iphase);
+    }
 #ifdef CFEAR_REG_TIMING
     t_assoc += __builtin_readcyclecounter() - ta0;
 #endif
@@ -779,7 +994,9 @@ int cfear_register_launch(cfear_ctx* ctx, const void* d_jobs, int n_jobs, const 
   const size_t budget = wave_per_job ? kRegLdsBudgetWave : kRegLdsBudget;
   const size_t avail = fixed < budget ? budget - fixed : 0;
   cm.dense_cap_lds = (int)std::min<size_t>(avail / ((size_t)cm.dense_fields * 8), (size_t)slots_cap);
-  const size_t lds = reg_lds_bytes(cm.lds_targets, cm.dense_cap_lds, cm.dense_fields);
+  size_t lds = reg_lds_bytes(cm.lds_targets, cm.dense_cap_lds, cm.dense_fields);
+  if (lds < budget) lds = budget;
+  cm.lds_total = (uint32_t)lds;
   static bool attr_set = false;
   if (!attr_set) {
     CFEAR_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)register_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
