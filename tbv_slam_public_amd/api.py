@@ -309,20 +309,27 @@ class n_scan_normal_reg:
         cov = np.diag([0.1 * 0.1, 0.1 * 0.1, 0, 0, 0, 0.01 * 0.01])        # n_scan_normal.cpp:171-175
         return rc == L.OK, p, cov
 
-    def RegisterBatch(self, jobs):
-        """jobs: list of (scans, Tsrc).  One launch; returns a RESULT_DTYPE array."""
+    def PrepareBatch(self, jobs):
+        """Marshals a list of (scans, Tsrc) once; the result can be passed to RegisterBatch repeatedly."""
         n = len(jobs)
         arr = (L.RegJob * n)()
         keep = []
         for i, (scans, T) in enumerate(jobs):
             hs = self._handles(scans)
             p = np.ascontiguousarray(T, dtype=np.float64)
-            keep.append((hs, p))
+            keep.append((hs, p, scans))
             arr[i].scans = C.cast(hs, C.POINTER(C.c_void_p))
             arr[i].n_scans = len(scans)
             arr[i].poses_xyt = p.ctypes.data_as(C.POINTER(C.c_double))
+        return (arr, n, keep)
+
+    def RegisterBatch(self, jobs):
+        """jobs: list of (scans, Tsrc) or a PrepareBatch result.  One launch; returns a RESULT_DTYPE array
+        (loop-closure candidate batches, tbv_slam/src/tbv_slam/loopclosure.cpp:35-97 per candidate)."""
+        arr, n, _keep = jobs if isinstance(jobs, tuple) else self.PrepareBatch(jobs)
         out = np.zeros(n, L.RESULT_DTYPE)
-        self.ctx.check(self.ctx._lib.cfear_register_batch(self.ctx.h, arr, n, C.byref(self.par), out.ctypes.data))
+        if n:
+            self.ctx.check(self.ctx._lib.cfear_register_batch(self.ctx.h, arr, n, C.byref(self.par), out.ctypes.data))
         return out
 
     def GetCost(self, scans, Tsrc):

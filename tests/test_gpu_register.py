@@ -191,3 +191,29 @@ def test_register_batch_matches_single_calls():
         assert (r["status"] == 0) == ok_o
         assert r["outer_iters"] == ro.outer_iters and r["lm_iters"] == ro.lm_iters
         assert np.abs(r["pose"][:2] - po[-1, :2]).max() <= POS_TOL and abs(r["pose"][2] - po[-1, 2]) <= ROT_TOL
+
+
+def test_sharded_candidates_single_rank_through_the_library():
+    """dist.register_candidates_sharded with the real per-rank compute (no process group = 1 rank)."""
+    from oracle import pyoracle as O
+    from tbv_slam_public_amd import api
+    from tbv_slam_public_amd import dist as cdist
+    cells, gt = _cells(7, [0, 2, 4])
+    scans = [api.MapPointNormal(cells=c) for c in cells]
+    reg = api.n_scan_normal_reg("P2L")
+    reg.SetParameters(4, 10)
+    rng = np.random.default_rng(3)
+    jobs, ojobs = [], []
+    for _ in range(9):
+        a, b = rng.choice(3, size=2, replace=False)
+        T = np.array([[0, 0, 0], _rel(gt[2 * a], gt[2 * b]) + rng.normal(0, 0.3, 3) * [1, 1, 0.05]])
+        jobs.append(([scans[a], scans[b]], T))
+        ojobs.append(([cells[a], cells[b]], T))
+    prepared = reg.PrepareBatch(jobs)
+    out = cdist.register_candidates_sharded(jobs, lambda local: reg.RegisterBatch(prepared))
+    out2 = cdist.register_candidates_sharded(jobs, cdist.default_register_fn(reg))
+    np.testing.assert_array_equal(out["pose"], out2["pose"])
+    for r, (c, T) in zip(out, ojobs):
+        ok_o, po, ro = O.register(c, T, _oracle_par(reg))
+        assert (r["status"] == 0) == ok_o and r["outer_iters"] == ro.outer_iters
+        assert np.abs(r["pose"][:2] - po[-1, :2]).max() <= POS_TOL and abs(r["pose"][2] - po[-1, 2]) <= ROT_TOL
