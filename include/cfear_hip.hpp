@@ -1,0 +1,172 @@
+// cfear_hip.hpp -- header-only C++ mirror of the reference's cfear_radarodometry classes over the C-ABI
+// (include/cfear_hip.h).  Same class and method names as namespace CFEAR_Radarodometry:
+//   radarDriver            radar_driver.h:32-118       CallbackOffline -> filtered cloud + peaks cloud
+//   MapPointNormal         pointnormal.h:110-243       GetSize / GetCells / device handle
+//   n_scan_normal_reg      n_scan_normal.h:27-85       SetParameters / Register / GetCost / getScore
+// ROS / PCL / Eigen types are replaced by PODs so the header compiles anywhere a C++14 compiler and
+// libcfear_hip.so exist; the Eigen/PCL adapters at the bottom are compiled only where those headers are
+// installed (they are not in this image).  Errors are C++ exceptions carrying the C status code.
+#pragma once
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "cfear_hip.h"
+
+namespace CFEAR_Radarodometry {
+
+struct PointXYZI { float x, y, z, intensity; };            // 16-byte PointXYZI payload
+typedef std::vector<PointXYZI> PointCloud;
+struct Pose2d { double x, y, theta; };                     // Affine3dToVectorXYeZ (utils.cpp:115-122)
+
+struct CfearError : std::runtime_error {
+  int status;
+  CfearError(int st, const std::string& msg) : std::runtime_error(msg), status(st) {}
+};
+
+class Context {                                            // one per host thread
+ public:
+  explicit Context(int device = 0, void* hip_stream = nullptr) {
+    const int st = cfear_ctx_create(device, hip_stream, &ctx_);
+    if (st != CFEAR_OK) throw CfearError(st, cfear_status_string(st));
+  }
+  ~Context() { cfear_ctx_destroy(ctx_); }
+  Context(const Context&) = delete;
+  Context& operator=(const Context&) = delete;
+  cfear_ctx* get() const { return ctx_; }
+  void check(int st) const { if (st != CFEAR_OK) throw CfearError(st, cfear_last_error(ctx_)); }
+ private:
+  cfear_ctx* ctx_ = nullptr;
+};
+
+enum filtertype { kstrong, CACFAR };                       // radar_driver.h:25
+
+class radarDriver {
+ public:
+  struct Parameters {                                      // radar_driver.h:35-84
+    float z_min = 60; float range_res = 0.0438f; int azimuths = 400, k_strongest = 12;
+    int nb_guard_cells = 20, window_size = 10; float false_alarm_rate = 0.01f;
+    float min_distance = 2.5f, max_distance = 200; filtertype filter_type_ = kstrong;
+  };
+  radarDriver(Context& ctx, const Parameters& pars) : ctx_(ctx), par(pars) {}
+  // image: row-major uint8, rows = azimuth (Oxford layout, radar_driver.cpp:99-111)
+  void CallbackOffline(const uint8_t* image, int rows, int cols, int stride, PointCloud& cloud, PointCloud& cloud_peaks) {
+    cfear_polar_desc d{rows, cols, stride, 1, 0};
+    int32_t n = 0, n_pk = 0;
+    if (par.filter_type_ == CACFAR) {                      // radar_driver.cpp:52-56
+      cfear_cacfar_params p{par.window_size, par.nb_guard_cells, par.false_alarm_rate, par.range_res, par.z_min,
+                            par.min_distance, 400.0};
+      cloud.resize((size_t)rows * cols);
+      ctx_.check(cfear_filter_cacfar(ctx_.get(), image, &d, &p, &cloud[0].x, &n, rows * cols, nullptr));
+      cloud.resize(n);
+      cloud_peaks.clear();
+      return;
+    }
+    cfear_kstrong_params p{par.k_strongest, par.z_min, par.range_res, par.min_distance, 1};
+    cloud.resize((size_t)rows * par.k_strongest);
+    cloud_peaks.resize((size_t)rows * par.k_strongest);
+    cfear_kstrong_out o{};
+    o.xyzi = &cloud[0].x; o.n_points = &n; o.xyzi_peaks = &cloud_peaks[0].x; o.n_peaks = &n_pk;
+    ctx_.check(cfear_filter_kstrongest(ctx_.get(), image, &d, &p, &o));
+    cloud.resize(n);
+    cloud_peaks.resize(n_pk);
+  }
+ private:
+  Context& ctx_;
+  Parameters par;
+};
+
+inline void Compensate(Context& ctx, PointCloud& cloud, const Pose2d& mot, bool ccw) {     // utils.cpp:96-107
+  const double m[3] = {mot.x, mot.y, mot.theta};
+  if (!cloud.empty()) ctx.check(cfear_compensate(ctx.get(), &cloud[0].x, (int32_t)cloud.size(), m, ccw ? 1 : 0));
+}
+
+class MapPointNormal {
+ public:
+  static double& downsample_factor() { static double f = 1.0; return f; }                   // pointnormal.cpp:5
+  MapPointNormal(Context& ctx, PointCloud& cld, float radius, double ox = 0, double oy = 0, bool weight_intensity = false)
+      : ctx_(ctx) {
+    cfear_feature_params fp{};
+    fp.radius = radius; fp.downsample_factor = downsample_factor(); fp.origin[0] = ox; fp.origin[1] = oy;
+    fp.weight_intensity = weight_intensity ? 1 : 0;
+    ctx_.check(cfear_scan_create(ctx_.get(), cld.empty() ? nullptr : &cld[0].x, (int32_t)cld.size(), &fp, &scan_));
+  }
+  MapPointNormal(Context& ctx, const std::vector<cfear_cell>& cells) : ctx_(ctx) {           // Boost load() path
+    ctx_.check(cfear_scan_from_cells(ctx_.get(), cells.data(), (int32_t)cells.size(), &scan_));
+  }
+  ~MapPointNormal() { cfear_scan_destroy(scan_); }
+  MapPointNormal(const MapPointNormal&) = delete;
+  MapPointNormal& operator=(const MapPointNormal&) = delete;
+  size_t GetSize() const { return (size_t)cfear_scan_size(scan_); }
+  std::vector<cfear_cell> GetCells() const {
+    std::vector<cfear_cell> c(GetSize());
+    if (!c.empty()) { const int n = cfear_scan_get_cells(scan_, c.data(), (int32_t)c.size()); if (n < 0) ctx_.check(n); }
+    return c;
+  }
+  const cfear_scan* device() const { return scan_; }
+ private:
+  Context& ctx_;
+  cfear_scan* scan_ = nullptr;
+};
+
+class n_scan_normal_reg {
+ public:
+  explicit n_scan_normal_reg(Context& ctx, int cost = CFEAR_P2L, int loss = CFEAR_LOSS_HUBER, double loss_limit = 0.1,
+                             int opt = CFEAR_W_UNIFORM) : ctx_(ctx) {                         // n_scan_normal.h:35
+    cfear_reg_params_default(&par_);
+    par_.cost = cost; par_.loss = loss; par_.loss_limit = loss_limit; par_.weight_opt = opt;
+  }
+  void SetParameters(unsigned max_itr_association, unsigned max_itr_solver) {                 // n_scan_normal.cpp:15-19
+    par_.max_itr_association = (int32_t)max_itr_association; par_.max_itr_solver = (int32_t)max_itr_solver;
+  }
+  void SetD2dPar(double cov_scale, double regularization) { par_.cov_scale = cov_scale; par_.regularization = regularization; }
+  // Register (n_scan_normal.cpp:82-185): Tsrc in/out; returns false exactly where the reference does.
+  bool Register(const std::vector<const MapPointNormal*>& scans, std::vector<Pose2d>& Tsrc) {
+    std::vector<const cfear_scan*> h(scans.size());
+    for (size_t i = 0; i < scans.size(); i++) h[i] = scans[i]->device();
+    const int st = cfear_register(ctx_.get(), h.data(), (int32_t)h.size(), &Tsrc[0].x, &par_, &summary_);
+    if (st != CFEAR_OK && st != CFEAR_ERR_TOO_FEW_RESIDUALS && st != CFEAR_ERR_SOLVER) ctx_.check(st);
+    par_.itr = summary_.outer_iters;                       // itr_ stays behind for GetCost (n_scan_normal.cpp:220)
+    score_ = summary_.score;
+    return st == CFEAR_OK;
+  }
+  bool GetCost(const std::vector<const MapPointNormal*>& scans, const std::vector<Pose2d>& Tsrc, double& score,
+               std::vector<double>& residuals) {                                              // n_scan_normal.cpp:186-211
+    std::vector<const cfear_scan*> h(scans.size());
+    size_t total = 2;
+    for (size_t i = 0; i < scans.size(); i++) { h[i] = scans[i]->device(); total += 2 * scans[i]->GetSize(); }
+    residuals.resize(total);
+    int32_t n = 0;
+    double s = 0;
+    const int st = cfear_get_cost(ctx_.get(), h.data(), (int32_t)h.size(), &Tsrc[0].x, &par_, &score, residuals.data(),
+                                  (int32_t)total, &n, &s);
+    if (st != CFEAR_OK && st != CFEAR_ERR_TOO_FEW_RESIDUALS) ctx_.check(st);
+    residuals.resize(n);
+    score_ = s;
+    return st == CFEAR_OK;
+  }
+  double getScore() const { return score_; }
+  cfear_reg_result summary_{};
+ private:
+  Context& ctx_;
+  cfear_reg_params par_;
+  double score_ = 0;
+};
+
+}  // namespace CFEAR_Radarodometry
+
+#if defined(__has_include)
+#if __has_include(<Eigen/Geometry>)
+#include <Eigen/Geometry>
+namespace CFEAR_Radarodometry {
+inline Pose2d Affine3dToPose2d(const Eigen::Affine3d& T) {                                    // utils.cpp:115-122
+  const Eigen::Vector3d eul = T.linear().eulerAngles(0, 1, 2);
+  return Pose2d{T.translation()(0), T.translation()(1), eul(2)};
+}
+inline Eigen::Affine3d Pose2dToAffine3d(const Pose2d& p) {                                    // registration.cpp:128-135
+  return Eigen::Translation3d(p.x, p.y, 0) * Eigen::AngleAxisd(p.theta, Eigen::Vector3d::UnitZ());
+}
+}  // namespace CFEAR_Radarodometry
+#endif
+#endif

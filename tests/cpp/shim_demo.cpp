@@ -1,0 +1,40 @@
+// A C++ caller of libcfear_hip.so through the header-only mirror of the reference classes
+// (include/cfear_hip.hpp).  Reads a raw uint8 polar image pair [2][rows][cols] from argv[1], registers
+// frame 1 against frame 0 (P2L, loop-closure settings 4 x 10) and prints the result as one line:
+//   n_points0 n_points1 n_cells0 n_cells1 ok x y theta score
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "cfear_hip.hpp"
+
+using namespace CFEAR_Radarodometry;
+
+int main(int argc, char** argv) {
+  if (argc < 4) return 2;
+  const int rows = atoi(argv[2]), cols = atoi(argv[3]);
+  std::vector<uint8_t> img((size_t)2 * rows * cols);
+  FILE* f = fopen(argv[1], "rb");
+  if (!f || fread(img.data(), 1, img.size(), f) != img.size()) return 3;
+  fclose(f);
+  try {
+    Context ctx(0);
+    radarDriver::Parameters p;
+    p.k_strongest = 40;
+    radarDriver driver(ctx, p);
+    PointCloud c0, c1, pk;
+    driver.CallbackOffline(img.data(), rows, cols, cols, c0, pk);
+    driver.CallbackOffline(img.data() + (size_t)rows * cols, rows, cols, cols, c1, pk);
+    MapPointNormal m0(ctx, c0, 3.0f, 0, 0, true), m1(ctx, c1, 3.0f, 0, 0, true);
+    n_scan_normal_reg reg(ctx, CFEAR_P2L);
+    reg.SetParameters(4, 10);
+    std::vector<Pose2d> T = {{0, 0, 0}, {2.0, 0.0, 0.0}};
+    const bool ok = reg.Register({&m0, &m1}, T);
+    printf("%zu %zu %zu %zu %d %.12g %.12g %.12g %.12g\n", c0.size(), c1.size(), m0.GetSize(), m1.GetSize(), ok ? 1 : 0,
+           T[1].x, T[1].y, T[1].theta, reg.getScore());
+  } catch (const CfearError& e) {
+    fprintf(stderr, "cfear error %d: %s\n", e.status, e.what());
+    return 1;
+  }
+  return 0;
+}

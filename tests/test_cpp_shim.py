@@ -1,0 +1,57 @@
+"""The header-only C++ mirror of the reference classes (include/cfear_hip.hpp) over the C-ABI.
+CPU: it compiles with plain g++ against the header and links libcfear_hip.so (no HIP headers needed).
+GPU: the compiled C++ program produces the oracle's registration."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _build(tmp_path):
+    exe = str(tmp_path / "shim_demo")
+    so_dir = os.path.join(ROOT, "tbv_slam_public_amd")
+    subprocess.check_call(["g++", "-std=c++14", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "cpp", "shim_demo.cpp"), "-o", exe, "-L", so_dir, "-lcfear_hip",
+                           "-Wl,-rpath," + so_dir])
+    return exe
+
+
+def test_cpp_mirror_compiles_and_fails_loudly_without_gpu(tmp_path):
+    import torch
+    exe = _build(tmp_path)
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    img = np.zeros((2, 8, 64), np.uint8)
+    p = tmp_path / "img.bin"
+    img.tofile(p)
+    r = subprocess.run([exe, str(p), "8", "64"], capture_output=True, text=True)
+    assert r.returncode == 1 and "no HIP device" in r.stderr
+
+
+@pytest.mark.gpu
+def test_cpp_mirror_matches_oracle(tmp_path):
+    from oracle import pyoracle as O
+    from tbv_slam_public_amd import synth
+    exe = _build(tmp_path)
+    imgs, gt, _ = synth.scene_v1(31, 2)
+    p = tmp_path / "img.bin"
+    imgs.tofile(p)
+    r = subprocess.run([exe, str(p), "400", "3360"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    v = r.stdout.split()
+    cells = []
+    for f in range(2):
+        sr, si, sc = O.kstrongest(imgs[f], 40, 60)
+        cloud = O.kstrongest_cloud(sr, si, sc, 0.0438, 2.5)
+        assert int(v[f]) == cloud.shape[0]
+        cells.append(O.surface_points(cloud, 3.0, 1.0, (0, 0), True))
+        assert int(v[2 + f]) == cells[f].shape[0]
+    ok, po, ro = O.register(cells, np.array([[0, 0, 0], [2.0, 0.0, 0.0]]), O.reg_params(cost="P2L", max_outer=4, max_inner=10))
+    assert int(v[4]) == int(ok)
+    got = np.array([float(x) for x in v[5:8]])
+    assert np.abs(got[:2] - po[-1, :2]).max() <= 1e-4 and abs(got[2] - po[-1, 2]) <= 1e-5
+    np.testing.assert_allclose(float(v[8]), ro.score, rtol=1e-9)
