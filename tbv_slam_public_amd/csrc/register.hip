@@ -108,10 +108,14 @@ __device__ __forceinline__ double get_weight(int opt, double N1, double N2, doub
 __device__ __forceinline__ void loss_eval(int loss, double a, double w, double s, double& rho0, double& rho1) {
   const double dmin = DBL_MIN;
   switch (loss) {
-    case 1: {  // Huber
+    case 1: {  // Huber: rho = 2 a sqrt(s) - a^2, rho' = a / sqrt(s) for s > a^2
       const double b = a * a;
-      if (s > b) { const double r = sqrt(s); rho0 = 2.0 * a * r - b; rho1 = fmax(dmin, a / r); }
-      else { rho0 = s; rho1 = 1.0; }
+      if (s > b) {
+        // one reciprocal square root instead of sqrt + divide (r = s * rsqrt(s), a / r = a * rsqrt(s));
+        // agrees with ceres::HuberLoss to rounding
+        const double q = rsqrt(s);
+        rho0 = 2.0 * a * (s * q) - b; rho1 = fmax(dmin, a * q);
+      } else { rho0 = s; rho1 = 1.0; }
       break;
     }
     case 2: {  // Cauchy

@@ -147,6 +147,20 @@ __device__ void sort_cells_block(const ScanView& v, int n, unsigned long long* k
     keys[i] = key;
   }
   __syncthreads();
+  if (n <= 2048) {
+    // rank sort: keys are unique, so rank = #smaller keys; every lane reads the same LDS address per
+    // step (broadcast), no barriers -- far cheaper than ~50 bitonic passes for a few hundred cells
+    for (int i = tid; i < n; i += nth) {
+      const unsigned long long key = keys[i];
+      int rank = 0;
+      for (int j = 0; j < n; j++) rank += keys[j] < key;
+      const float2 m = v.mean_f[i];
+      v.sorted_x[rank] = m.x;
+      v.sorted_y[rank] = m.y;
+      v.sorted_idx[rank] = i;
+    }
+    return;
+  }
   for (int k = 2; k <= npad; k <<= 1) {
     for (int j = k >> 1; j > 0; j >>= 1) {
       for (int t = tid; t < (npad >> 1); t += nth) {
@@ -374,8 +388,14 @@ __global__ __launch_bounds__(kSurfThreads) void surface_points_kernel(const Surf
   for (int wv = 0; wv < wave; wv++) voff += red_i[wv];
   int V = 0;
   for (int wv = 0; wv < 16; wv++) V += red_i[wv];
+  // LDS map from here on (compact, by V and n): voxel keys | voxel starts | [sorted points x,y | intensity]
+  const size_t Vp = ((size_t)V + 4) & ~(size_t)3;
   uint32_t* vox_key = (uint32_t*)smem;                  // [V]
-  int32_t* vox_start = (int32_t*)(smem + (size_t)npad * 4);   // [V + 1]
+  int32_t* vox_start = (int32_t*)(smem + Vp * 4);       // [V + 1]
+  const size_t pts_off = (Vp * 8 + 15) & ~(size_t)15;
+  const bool lds_pts = pts_off + (size_t)n * 12 + 16 <= kLdsRowbegOff - 16;   // points fit next to the tables
+  float2* lxy = (float2*)(smem + pts_off);              // [n] sorted x,y
+  float* lin = (float*)(smem + pts_off + (((size_t)n * 8 + 15) & ~(size_t)15));   // [n] sorted intensity
   int32_t* rowbeg = (int32_t*)(smem + kLdsRowbegOff);          // [dby + 1]
   {
     unsigned pv = prev_vox;
@@ -390,6 +410,7 @@ __global__ __launch_bounds__(kSurfThreads) void surface_points_kernel(const Surf
         pv = vx;
         const float4 p = pts[pi];
         spt[e] = make_float4(p.x, p.y, p.w, 0.f);
+        if (lds_pts) { lxy[e] = make_float2(p.x, p.y); lin[e] = p.w; }
       }
     }
   }
@@ -407,7 +428,11 @@ __global__ __launch_bounds__(kSurfThreads) void surface_points_kernel(const Surf
   for (int v = tid; v < V; v += kSurfThreads) {
     const int s = vox_start[v], e = vox_start[v + 1];
     float ax = 0.f, ay = 0.f;
-    for (int p = s; p < e; p++) { const float4 q = spt[p]; ax = __fadd_rn(ax, q.x); ay = __fadd_rn(ay, q.y); }
+    if (lds_pts) {
+      for (int p = s; p < e; p++) { const float2 q = lxy[p]; ax = __fadd_rn(ax, q.x); ay = __fadd_rn(ay, q.y); }
+    } else {
+      for (int p = s; p < e; p++) { const float4 q = spt[p]; ax = __fadd_rn(ax, q.x); ay = __fadd_rn(ay, q.y); }
+    }
     const float cnt = (float)(e - s);
     cen[v] = make_float2(__fdiv_rn(ax, cnt), __fdiv_rn(ay, cnt));
   }
@@ -454,6 +479,21 @@ __global__ __launch_bounds__(kSurfThreads) void surface_points_kernel(const Surf
       }
     };
     auto scan_run = [&](int p0, int p1) {
+      if (lds_pts) {                                      // candidates from LDS (no L1/TA traffic)
+        int p = p0;
+        for (; p + 3 < p1; p += 4) {                      // four independent LDS reads in flight
+          const float2 qa = lxy[p], qb = lxy[p + 1], qc = lxy[p + 2], qd = lxy[p + 3];
+          float ia = 0.f, ib = 0.f, ic = 0.f, id = 0.f;
+          if (cm.weight_intensity) { ia = lin[p]; ib = lin[p + 1]; ic = lin[p + 2]; id = lin[p + 3]; }
+          accum(make_float4(qa.x, qa.y, ia, 0.f)); accum(make_float4(qb.x, qb.y, ib, 0.f));
+          accum(make_float4(qc.x, qc.y, ic, 0.f)); accum(make_float4(qd.x, qd.y, id, 0.f));
+        }
+        for (; p < p1; p++) {
+          const float2 q = lxy[p];
+          accum(make_float4(q.x, q.y, cm.weight_intensity ? lin[p] : 0.f, 0.f));
+        }
+        return;
+      }
       int p = p0;
       for (; p + 3 < p1; p += 4) {                        // four independent loads in flight
         const float4 qa = spt[p], qb = spt[p + 1], qc = spt[p + 2], qd = spt[p + 3];
@@ -464,7 +504,12 @@ __global__ __launch_bounds__(kSurfThreads) void surface_points_kernel(const Surf
     if (cm.reach == 1) {
       int a0, a1, b0, b1, c0, c1;
       run_of(iy - 1, a0, a1);
-      run_of(iy, b0, b1);
+      {                                                   // centre row: the neighbours are v-1 / v+1 if occupied
+        const int va = (v > 0 && ix > 0 && vox_key[v - 1] == key - 1) ? v - 1 : v;
+        const int vb = (v + 1 < V && ix < dbx - 1 && vox_key[v + 1] == key + 1) ? v + 2 : v + 1;
+        b0 = vox_start[va];
+        b1 = vox_start[vb];
+      }
       run_of(iy + 1, c0, c1);
       if ((a1 - a0) + (b1 - b0) + (c1 - c0) >= 6) {       // upper bound on the neighbour count
         scan_run(a0, a1);
