@@ -298,7 +298,10 @@ __device__ int associate_all(const RegJob& job, const RegCommon& cm, const doubl
 }
 
 // Residual block of one slot at pose x (c = cos th, s = sin th): adds to acc[10].
-template <bool WITH_JAC>
+// COST / LOSS are compile-time (LOSS = -1: runtime switch) so the hot P2P/P2L + Huber kernels carry no
+// per-correspondence branching and constant Jacobian entries fold away.  The accumulations use fma():
+// these sums are already reduced in a different order than Ceres', agreement is to rounding either way.
+template <int COST, int LOSS, bool WITH_JAC>
 __device__ __forceinline__ void eval_slot(const cfear_reg_params& par, double smx, double smy, double tmx, double tmy,
                                           double a0, double a1, double a2, double w, double tx, double ty, double c,
                                           double s, double acc[10]) {
@@ -306,11 +309,11 @@ __device__ __forceinline__ void eval_slot(const cfear_reg_params& par, double sm
   const double sy = (s * smx + c * smy) + ty;
   const double dx = -s * smx - c * smy, dy = c * smx - s * smy;   // d(R s)/dtheta
   double r0, r1 = 0.0, j00, j01, j02, j10 = 0.0, j11 = 0.0, j12 = 0.0;
-  if (par.cost == CFEAR_P2L) {                          // n_scan_normal.h:180-213
+  if (COST == CFEAR_P2L) {                              // n_scan_normal.h:180-213
     const double v0 = sx - tmx, v1 = sy - tmy;
     r0 = v0 * a0 + v1 * a1;
     j00 = a0; j01 = a1; j02 = dx * a0 + dy * a1;
-  } else if (par.cost == CFEAR_P2P) {                   // n_scan_normal.h:330-361
+  } else if (COST == CFEAR_P2P) {                       // n_scan_normal.h:330-361
     r0 = tmx - sx; r1 = tmy - sy;
     j00 = -1.0; j01 = 0.0; j02 = -dx; j10 = 0.0; j11 = -1.0; j12 = -dy;
   } else {                                              // n_scan_normal.h:216-255, L = [a0 0; a1 a2]
@@ -320,26 +323,36 @@ __device__ __forceinline__ void eval_slot(const cfear_reg_params& par, double sm
     j00 = a0; j01 = 0.0; j02 = a0 * dx + 0.0 * dy;
     j10 = a1; j11 = a2; j12 = a1 * dx + a2 * dy;
   }
-  const double sq = (par.cost == CFEAR_P2L) ? r0 * r0 : (r0 * r0 + r1 * r1);
+  const double sq = (COST == CFEAR_P2L) ? r0 * r0 : (r0 * r0 + r1 * r1);
   double rho0, rho1;
-  loss_eval(par.loss, par.loss_limit, w, sq, rho0, rho1);
-  acc[0] += 0.5 * rho0;
+  loss_eval(LOSS >= 0 ? LOSS : par.loss, par.loss_limit, w, sq, rho0, rho1);
+  acc[0] = fma(0.5, rho0, acc[0]);
   if (WITH_JAC) {
     // Corrector with alpha = 0 scales residual and Jacobian rows by sqrt(rho'); the normal equations
     // only need the products, (sqrt(rho') J)^T (sqrt(rho') r) = rho' J^T r, so no square root here.
     const double g0 = rho1 * r0;
-    acc[1] += j00 * g0; acc[2] += j01 * g0; acc[3] += j02 * g0;
+    acc[1] = fma(j00, g0, acc[1]); acc[2] = fma(j01, g0, acc[2]); acc[3] = fma(j02, g0, acc[3]);
     const double h00 = rho1 * j00, h01 = rho1 * j01, h02 = rho1 * j02;
-    acc[4] += h00 * j00; acc[5] += h00 * j01; acc[6] += h00 * j02;
-    acc[7] += h01 * j01; acc[8] += h01 * j02; acc[9] += h02 * j02;
-    if (par.cost != CFEAR_P2L) {
+    acc[4] = fma(h00, j00, acc[4]); acc[5] = fma(h00, j01, acc[5]); acc[6] = fma(h00, j02, acc[6]);
+    acc[7] = fma(h01, j01, acc[7]); acc[8] = fma(h01, j02, acc[8]); acc[9] = fma(h02, j02, acc[9]);
+    if (COST != CFEAR_P2L) {
       const double g1 = rho1 * r1;
-      acc[1] += j10 * g1; acc[2] += j11 * g1; acc[3] += j12 * g1;
+      acc[1] = fma(j10, g1, acc[1]); acc[2] = fma(j11, g1, acc[2]); acc[3] = fma(j12, g1, acc[3]);
       const double h10 = rho1 * j10, h11 = rho1 * j11, h12 = rho1 * j12;
-      acc[4] += h10 * j10; acc[5] += h10 * j11; acc[6] += h10 * j12;
-      acc[7] += h11 * j11; acc[8] += h11 * j12; acc[9] += h12 * j12;
+      acc[4] = fma(h10, j10, acc[4]); acc[5] = fma(h10, j11, acc[5]); acc[6] = fma(h10, j12, acc[6]);
+      acc[7] = fma(h11, j11, acc[7]); acc[8] = fma(h11, j12, acc[8]); acc[9] = fma(h12, j12, acc[9]);
     }
   }
+}
+
+// runtime-cost dispatch for the non-hot callers (eval_kernel)
+template <bool WITH_JAC>
+__device__ __forceinline__ void eval_slot_rt(const cfear_reg_params& par, double smx, double smy, double tmx, double tmy,
+                                             double a0, double a1, double a2, double w, double tx, double ty, double c,
+                                             double s, double acc[10]) {
+  if (par.cost == CFEAR_P2L) eval_slot<CFEAR_P2L, -1, WITH_JAC>(par, smx, smy, tmx, tmy, a0, a1, a2, w, tx, ty, c, s, acc);
+  else if (par.cost == CFEAR_P2P) eval_slot<CFEAR_P2P, -1, WITH_JAC>(par, smx, smy, tmx, tmy, a0, a1, a2, w, tx, ty, c, s, acc);
+  else eval_slot<CFEAR_P2D, -1, WITH_JAC>(par, smx, smy, tmx, tmy, a0, a1, a2, w, tx, ty, c, s, acc);
 }
 
 // Dense correspondence arrays (SoA, stride dcap): 0 smx, 1 smy, 2 tmx, 3 tmy, 4 w, 5 a0, 6 a1, 7 a2.
@@ -348,7 +361,7 @@ __device__ __forceinline__ void eval_slot(const cfear_reg_params& par, double sm
 struct Dense { double* p; int cap; int n; };
 
 // cost, gradient and Gauss-Newton matrix of all correspondences at x (block-wide collective)
-template <int NW>
+template <int NW, int COST, int LOSS>
 __device__ void eval_all(const RegCommon& cm, const Dense& dn, const double x[3], double out[10], double* part, int& phase) {
   double s, c;
   sincos(x[2], &s, &c);
@@ -360,9 +373,9 @@ __device__ void eval_all(const RegCommon& cm, const Dense& dn, const double x[3]
     const double smx = dn.p[i], smy = dn.p[cap + i], tmx = dn.p[2 * cap + i], tmy = dn.p[3 * cap + i];
     const double w = dn.p[4 * cap + i];
     double a0 = 0.0, a1 = 0.0, a2 = 0.0;
-    if (cm.par.cost != CFEAR_P2P) { a0 = dn.p[5 * cap + i]; a1 = dn.p[6 * cap + i]; }
-    if (cm.par.cost == CFEAR_P2D) a2 = dn.p[7 * cap + i];
-    eval_slot<true>(cm.par, smx, smy, tmx, tmy, a0, a1, a2, w, x[0], x[1], c, s, acc);
+    if (COST != CFEAR_P2P) { a0 = dn.p[5 * cap + i]; a1 = dn.p[6 * cap + i]; }
+    if (COST == CFEAR_P2D) a2 = dn.p[7 * cap + i];
+    eval_slot<COST, LOSS, true>(cm.par, smx, smy, tmx, tmy, a0, a1, a2, w, x[0], x[1], c, s, acc);
   }
   block_reduce10<NW>(acc, part, phase);
 #pragma unroll
@@ -653,7 +666,7 @@ struct LmSummary {
 
 // ceres::Solve as configured by the reference (Ceres 2.1 defaults, max_num_iterations = max_iter):
 // same bookkeeping as the oracle's lm_solve / SURVEY Appendix B.4.  Block-wide collective.
-template <int NW>
+template <int NW, int COST, int LOSS>
 __device__ void lm_solve(const RegCommon& cm, const Dense& dn, double x[3], int max_iter, LmSummary& sum, double* part,
                          int& phase) {
   const double function_tolerance = 1e-6, gradient_tolerance = 1e-10, parameter_tolerance = 1e-8;
@@ -665,7 +678,7 @@ __device__ void lm_solve(const RegCommon& cm, const Dense& dn, double x[3], int 
   int num_consecutive_invalid_steps = 0;
 
   double cur[10];                                        // cost, g, H at the accepted x
-  eval_all<NW>(cm, dn, x, cur, part, phase);
+  eval_all<NW, COST, LOSS>(cm, dn, x, cur, part, phase);
   double x_cost = cur[0];
   double scale[3];
   scale[0] = 1.0 / (1.0 + sqrt(cur[4]));                 // jacobi scaling from iteration 0
@@ -732,7 +745,7 @@ __device__ void lm_solve(const RegCommon& cm, const Dense& dn, double x[3], int 
 #pragma unroll
     for (int k = 0; k < 3; k++) cand[k] = x[k] + step[k] * scale[k];
     double cnd[10];                                      // cost (and, speculatively, g and H) at cand
-    eval_all<NW>(cm, dn, cand, cnd, part, phase);
+    eval_all<NW, COST, LOSS>(cm, dn, cand, cnd, part, phase);
     const double cand_cost = cnd[0];
     const double step_norm = sqrt((x[0] - cand[0]) * (x[0] - cand[0]) + (x[1] - cand[1]) * (x[1] - cand[1]) +
                                   (x[2] - cand[2]) * (x[2] - cand[2]));
@@ -760,7 +773,7 @@ __device__ void lm_solve(const RegCommon& cm, const Dense& dn, double x[3], int 
   sum.final_cost = fmin(sum.initial_cost, min_iter_cost);
 }
 
-template <int NW>
+template <int NW, int COST, int LOSS>
 __global__ __launch_bounds__(NW * 64) void register_kernel(const RegJob* __restrict__ jobs, const RegCommon cm) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   double* part = (double*)smem;                          // [2][4][10]
@@ -825,7 +838,7 @@ __global__ __launch_bounds__(NW * 64) void register_kernel(const RegJob* __restr
     success = num_residuals > 1;                                  // :368-369
     if (!success) { fail_status = CFEAR_ERR_TOO_FEW_RESIDUALS; break; }
     double xi[3] = {x[0], x[1], x[2]};
-    lm_solve<NW>(cm, dn, xi, cm.par.max_itr_solver, summary, part, phase);
+    lm_solve<NW, COST, LOSS>(cm, dn, xi, cm.par.max_itr_solver, summary, part, phase);
     lm_iters += summary.n_pushed - 1;
     success = summary.usable;
     if (success) { x[0] = xi[0]; x[1] = xi[1]; x[2] = xi[2]; } else fail_status = CFEAR_ERR_SOLVER;
@@ -919,7 +932,7 @@ __global__ __launch_bounds__(kRegThreads) void eval_kernel(const RegJob* __restr
     const double2 sm = smean[slot % n_src];
     const double tmx = sl.tmx[slot], tmy = sl.tmy[slot], a0 = sl.a0[slot], a1 = sl.a1[slot];
     const double a2 = cm.par.cost == CFEAR_P2D ? sl.a2[slot] : 0.0;
-    eval_slot<true>(cm.par, sm.x, sm.y, tmx, tmy, a0, a1, a2, w, x0, x1, c, s, acc);
+    eval_slot_rt<true>(cm.par, sm.x, sm.y, tmx, tmy, a0, a1, a2, w, x0, x1, c, s, acc);
     // raw values, recomputed exactly as eval_slot does
     const double sx = (c * sm.x + (-s) * sm.y) + x0, sy = (s * sm.x + c * sm.y) + x1;
     const double dx = -s * sm.x - c * sm.y, dy = c * sm.x - s * sm.y;
@@ -1001,18 +1014,19 @@ int cfear_register_launch(cfear_ctx* ctx, const void* d_jobs, int n_jobs, const 
   size_t lds = reg_lds_bytes(cm.lds_targets, cm.dense_cap_lds, cm.dense_fields);
   if (lds < budget) lds = budget;
   cm.lds_total = (uint32_t)lds;
-  static bool attr_set = false;
-  if (!attr_set) {
-    CFEAR_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)register_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    CFEAR_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)register_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    CFEAR_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)assoc_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr_set = true;
+  (void)wave_per_job;
+  typedef void (*KernelFn)(const RegJob*, RegCommon);
+  // compile-time specialisations: cost metric x {Huber, any other loss}
+  const bool huber = par->loss == CFEAR_LOSS_HUBER;
+  KernelFn fn;
+  switch (par->cost) {
+    case CFEAR_P2P: fn = huber ? register_kernel<4, CFEAR_P2P, CFEAR_LOSS_HUBER> : register_kernel<4, CFEAR_P2P, -1>; break;
+    case CFEAR_P2L: fn = huber ? register_kernel<4, CFEAR_P2L, CFEAR_LOSS_HUBER> : register_kernel<4, CFEAR_P2L, -1>; break;
+    default: fn = huber ? register_kernel<4, CFEAR_P2D, CFEAR_LOSS_HUBER> : register_kernel<4, CFEAR_P2D, -1>; break;
   }
+  CFEAR_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   ProfScope ps(ctx, "register");
-  if (wave_per_job)
-    hipLaunchKernelGGL(register_kernel<1>, dim3(n_jobs), dim3(64), lds, ctx->stream, (const RegJob*)d_jobs, cm);
-  else
-    hipLaunchKernelGGL(register_kernel<4>, dim3(n_jobs), dim3(256), lds, ctx->stream, (const RegJob*)d_jobs, cm);
+  hipLaunchKernelGGL(fn, dim3(n_jobs), dim3(256), lds, ctx->stream, (const RegJob*)d_jobs, cm);
   CFEAR_HIP_CHECK(ctx, hipGetLastError());
   return CFEAR_OK;
 }
