@@ -12,7 +12,7 @@ mkdir -p "$OUT" "$SUM"
 export TMPDIR=/tmp
 make -C oracle -s
 # 1. kernel trace + stats of the bench command
-( cd /tmp && rocprofv3 --output-format csv --kernel-trace --stats -d "$OUT/bench" -o bench -- python "$ROOT/bench.py" --no-cpu-baseline > "$SUM/bench_stdout.json" 2> "$OUT/bench.err" )
+( cd /tmp && rocprofv3 --output-format csv --kernel-trace --stats -d "$OUT/bench" -o bench -- python "$ROOT/bench.py" --no-cpu-baseline --steps 10 > "$SUM/bench_stdout.json" 2> "$OUT/bench.err" )
 find "$OUT/bench" -name "*kernel_stats.csv" -exec cp {} "$SUM/bench_kernel_stats.csv" \;
 # 2. polar sweep alone: kernel trace, then PMC passes (FETCH_SIZE and WRITE_SIZE do not fit one pass)
 for DATA in scene uniform; do
@@ -22,5 +22,7 @@ done
 ( cd /tmp && rocprofv3 --output-format csv --pmc FETCH_SIZE -d "$OUT/pmc_fetch" -o p -- python "$ROOT/tools/bench_filter.py" --iters 5 > /dev/null 2> "$OUT/pmc_fetch.err" )
 ( cd /tmp && rocprofv3 --output-format csv --pmc WRITE_SIZE -d "$OUT/pmc_write" -o p -- python "$ROOT/tools/bench_filter.py" --iters 5 > /dev/null 2> "$OUT/pmc_write.err" )
 ( cd /tmp && rocprofv3 --output-format csv --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU -d "$OUT/pmc_sq" -o p -- python "$ROOT/tools/bench_filter.py" --iters 5 > /dev/null 2> "$OUT/pmc_sq.err" )
+# whole pipeline under the SQ counters, SMALL run (counter collection serialises every dispatch)
+( cd /tmp && timeout 300 rocprofv3 --output-format csv --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU -d "$OUT/pmc_pipe" -o p -- python "$ROOT/bench.py" --no-cpu-baseline --steps 3 --warmup 2 --streams 256 > /dev/null 2> "$OUT/pmc_pipe.err" )
 python "$ROOT/tools/summarize_pmc.py" "$OUT" > "$SUM/pmc_summary.txt" 2>&1
 ls -la "$SUM"
