@@ -134,7 +134,7 @@ def main():
     dev = torch.device("cuda", local_rank)
 
     B, K, W = args.streams, args.steps, max(args.warmup, 1)   # frame 0 of a stream is not a registration
-    F = W + K
+    F = W + K + 1                 # one extra frame: the last timed step prefetches (filters) it
     # ---- synthetic input, resident in HBM: [F][B][ROWS][COLS] uint8 -------------------------------
     t0 = time.time()
     base = []
@@ -160,7 +160,7 @@ def main():
             dist.barrier()
 
     for f in range(W):
-        info = od.process(frames[f])
+        info = od.process(frames[f], frames[f + 1])      # warm-up; also primes the filter prefetch of frame W
     barrier()
     ctx.profile_enable(True)
     ctx.profile_read(reset=True)
@@ -170,7 +170,10 @@ def main():
     status_bad = 0
     t1 = time.perf_counter()
     for s in range(K):
-        info = od.process(frames[W + s])
+        # The filter of the next frame is enqueued behind this frame's kernels (it needs no state of this
+        # frame).  Frame W's sweep ran during warm-up and frame W+K's sweep runs inside the timed region,
+        # so exactly K filter sweeps (and K of every other kernel) are timed.
+        info = od.process(frames[W + s], frames[W + s + 1])
         poses[s] = info["pose"]
         n_points[s] = info["n_points"]
         n_cells[s] = info["n_cells"]
@@ -211,29 +214,32 @@ def main():
     pose_err = None
     if not args.no_cpu_baseline and world == 1:        # rank 0 at N=1 only
         from oracle import pyoracle as O
-        n_seq = min(base.shape[0], 4)
-        budget_frames = args.cpu_frames or n_seq * F
+        n_seq = base.shape[0]
+        passes = 3 if not args.cpu_frames else 1          # ~10 s of single-thread CPU work at the defaults
+        budget_frames = args.cpu_frames or passes * n_seq * F
         reg = O.reg_params(cost="P2P", loss="Huber", loss_limit=0.1, weight_opt=4, regularization=0.0)
-        done, tc0 = 0, time.perf_counter()
+        done, compared, tc0 = 0, 0, time.perf_counter()
         err_xy, err_th = 0.0, 0.0
-        for sd in range(n_seq):
-            fz = O.Fuser(reg, res=3.0, submap_scan_size=4, weight_intensity=True)
-            for f in range(F):
-                if done >= budget_frames:
-                    break
-                sr, si, scn = O.kstrongest(base[sd, f], K_STRONGEST, 60)
-                cloud = O.kstrongest_cloud(sr, si, scn, 0.0438, 2.5)
-                pose, oi = fz.process(cloud)
-                done += 1
-                if f >= W:
-                    d = np.abs(poses[f - W, sd] - pose)
-                    err_xy, err_th = max(err_xy, d[:2].max()), max(err_th, d[2])
+        for ps in range(passes):
+            for sd in range(n_seq):
+                fz = O.Fuser(reg, res=3.0, submap_scan_size=4, weight_intensity=True)
+                for f in range(F):
+                    if done >= budget_frames:
+                        break
+                    sr, si, scn = O.kstrongest(base[sd, f], K_STRONGEST, 60)
+                    cloud = O.kstrongest_cloud(sr, si, scn, 0.0438, 2.5)
+                    pose, oi = fz.process(cloud)
+                    done += 1
+                    if ps == 0 and W <= f < W + K:
+                        d = np.abs(poses[f - W, sd] - pose)
+                        err_xy, err_th = max(err_xy, d[:2].max()), max(err_th, d[2])
+                        compared += 1
         tc = time.perf_counter() - tc0
         cpu = {"value": done / tc, "unit": "registrations/s", "cores": 1, "kind": "port",
-               "sample": "%d frames (%d sequences x %d frames of this run's input), full path filter->pose, "
-                         "oracle/liboracle.so g++ -O3, 1 thread; host has %d cores"
-                         % (done, n_seq, F, os.cpu_count())}
-        pose_err = {"max_abs_xy_m": err_xy, "max_abs_theta_rad": err_th, "frames_compared": int(min(done, n_seq * K))}
+               "sample": "%d frames = %d pass(es) over %d sequences x %d frames of this run's input, full path "
+                         "filter->pose, oracle/liboracle.so g++ -O3, 1 thread, %.1f s; host has %d cores"
+                         % (done, passes, n_seq, F, tc, os.cpu_count())}
+        pose_err = {"max_abs_xy_m": err_xy, "max_abs_theta_rad": err_th, "frames_compared": compared}
 
     out = {
         "metric": "radar scan registrations/sec (400x3360 polar)",

@@ -289,6 +289,11 @@ int cfear_odometry_create(cfear_ctx* ctx, int32_t n_streams, const cfear_polar_d
 /* polar: [n_streams] images laid out per desc (desc.batch must equal n_streams), host or device.
  * info: host array [n_streams].                                                               */
 int cfear_odometry_process(cfear_odometry* od, const uint8_t* polar, cfear_frame_info* info);
+/* Same, and additionally enqueues the FILTER of the next frame's images (polar_next, may be NULL) behind
+ * this frame's kernels, so the GPU sweeps the next polar batch while the host applies this frame's
+ * keyframe policy.  The next call must then pass that same pointer as `polar`.                   */
+int cfear_odometry_process_prefetch(cfear_odometry* od, const uint8_t* polar, const uint8_t* polar_next,
+                                    cfear_frame_info* info);
 int cfear_odometry_destroy(cfear_odometry* od);
 
 #ifdef __cplusplus

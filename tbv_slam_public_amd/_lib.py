@@ -122,7 +122,7 @@ EXPORTS = [
     "cfear_cost_prepare", "cfear_cost_num_blocks", "cfear_cost_num_residuals", "cfear_cost_get_blocks",
     "cfear_cost_evaluate", "cfear_cost_normal_eq", "cfear_cost_destroy",
     "cfear_odometry_params_default", "cfear_odometry_create", "cfear_odometry_process",
-    "cfear_odometry_destroy",
+    "cfear_odometry_process_prefetch", "cfear_odometry_destroy",
 ]
 
 _LIB = None
@@ -187,6 +187,7 @@ def lib():
     L.cfear_odometry_create.argtypes = [vp, C.c_int32, C.POINTER(PolarDesc), C.POINTER(OdometryParams),
                                         C.POINTER(vp)]
     L.cfear_odometry_process.argtypes = [vp, vp, vp]
+    L.cfear_odometry_process_prefetch.argtypes = [vp, vp, vp, vp]
     L.cfear_odometry_destroy.argtypes = [vp]
     _LIB = L
     return L

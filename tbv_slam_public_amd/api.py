@@ -432,9 +432,14 @@ class OdometryKeyframeFuser:
                                                            C.byref(self._h)))
         self._info = np.zeros(n_streams, L.FRAMEINFO_DTYPE)
 
-    def process(self, polar):
-        """polar: uint8 [n_streams, rows, cols] (NumPy or torch CUDA).  Returns a FRAMEINFO_DTYPE array."""
-        self.ctx.check(self.ctx._lib.cfear_odometry_process(self._h, _ptr(polar)[0], self._info.ctypes.data))
+    def process(self, polar, polar_next=None):
+        """polar: uint8 [n_streams, rows, cols] (NumPy or torch CUDA).  Returns a FRAMEINFO_DTYPE array.
+        polar_next (optional): the NEXT frame's images; their filter is enqueued behind this frame's
+        kernels so the GPU works while the host applies this frame's keyframe policy.  The next call
+        must pass that same buffer as `polar`."""
+        self._keep = (polar, polar_next)
+        self.ctx.check(self.ctx._lib.cfear_odometry_process_prefetch(self._h, _ptr(polar)[0], _ptr(polar_next)[0],
+                                                                     self._info.ctypes.data))
         return self._info.copy()
 
     def close(self):

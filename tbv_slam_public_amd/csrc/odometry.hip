@@ -68,8 +68,13 @@ struct cfear_odometry {
   // device memory (one allocation each)
   uint8_t* d_polar = nullptr;          // staging when the caller passes host images
   char* d_sel = nullptr;               // sel_range | sel_intensity | sel_count
-  float* d_xyzi = nullptr;
+  float* d_xyzi2[2] = {nullptr, nullptr};    // filter outputs are double-buffered: the next frame's filter
+  int32_t* d_npts2[2] = {nullptr, nullptr};  //   may run while the host applies this frame's policy
+  float* d_xyzi = nullptr;                   // buffer of the frame being processed
   int32_t* d_npts = nullptr;
+  int cur_buf = 0;
+  const uint8_t* prefetched = nullptr;       // polar pointer whose filter output sits in buffer cur_buf ^ 1
+  hipEvent_t ev_results = nullptr;
   char* d_slabs = nullptr;
   char* d_surf_jobs = nullptr;
   char* d_reg_jobs = nullptr;
@@ -108,7 +113,8 @@ extern "C" int cfear_odometry_destroy(cfear_odometry* od) {
   if (!od) return CFEAR_OK;
   (void)hipSetDevice(od->ctx->device);
   (void)hipStreamSynchronize(od->ctx->stream);
-  void* dev[] = {od->d_polar, od->d_sel, od->d_xyzi, od->d_npts, od->d_slabs, od->d_surf_jobs, od->d_reg_jobs,
+  if (od->ev_results) (void)hipEventDestroy(od->ev_results);
+  void* dev[] = {od->d_polar, od->d_sel, od->d_xyzi2[0], od->d_xyzi2[1], od->d_npts2[0], od->d_npts2[1], od->d_slabs, od->d_surf_jobs, od->d_reg_jobs,
                  od->d_results, od->d_status, od->d_ncells, od->d_surf_scratch, od->d_reg_scratch};
   for (void* p : dev) if (p) (void)hipFree(p);
   void* host[] = {od->h_surf_jobs, od->h_reg_jobs, od->h_results, od->h_status, od->h_npts, od->h_ncells};
@@ -138,8 +144,11 @@ extern "C" int cfear_odometry_create(cfear_ctx* ctx, int32_t n_streams, const cf
   const size_t nsel = (size_t)B * rows * std::max(k, 1);
   bool ok = true;
   ok = ok && dalloc(&od->d_sel, nsel * 4 + nsel + (size_t)B * rows * 4 + 1024);
-  ok = ok && dalloc(&od->d_xyzi, (size_t)B * od->cap_points * 16);
-  ok = ok && dalloc(&od->d_npts, (size_t)B * 4);
+  for (int i = 0; i < 2; i++) {
+    ok = ok && dalloc(&od->d_xyzi2[i], (size_t)B * od->cap_points * 16);
+    ok = ok && dalloc(&od->d_npts2[i], (size_t)B * 4);
+  }
+  ok = ok && hipEventCreateWithFlags(&od->ev_results, hipEventDisableTiming) == hipSuccess;
   ok = ok && dalloc(&od->d_slabs, (size_t)B * od->slabs_per_stream * od->slab_bytes);
   ok = ok && dalloc(&od->d_surf_jobs, (size_t)B * cfear_surface_job_bytes());
   ok = ok && dalloc(&od->d_reg_jobs, (size_t)B * cfear_reg_job_bytes());
@@ -168,13 +177,11 @@ extern "C" int cfear_odometry_create(cfear_ctx* ctx, int32_t n_streams, const cf
   return CFEAR_OK;
 }
 
-extern "C" int cfear_odometry_process(cfear_odometry* od, const uint8_t* polar, cfear_frame_info* info) {
-  if (!od || !polar || !info) return CFEAR_ERR_INVALID_ARGUMENT;
+// ---- F: filter (radar_driver.cpp:48-73) of one batch of polar images into filter buffer `buf` -------
+static int run_filter(cfear_odometry* od, const uint8_t* polar, int buf) {
   cfear_ctx* ctx = od->ctx;
-  CFEAR_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   const int B = od->n_streams, rows = od->desc.rows, k = od->par.kstrong.k_strongest;
   const cfear_odometry_params& par = od->par;
-  // ---- F: filter (radar_driver.cpp:48-73) -----------------------------------------------------
   const uint8_t* d_polar = polar;
   cfear_polar_desc dd = od->desc;
   if (!cfear_is_device_ptr(polar)) {
@@ -187,25 +194,45 @@ extern "C" int cfear_odometry_process(cfear_odometry* od, const uint8_t* polar, 
     d_polar = od->d_polar;
     dd.batch_stride = (int64_t)img_bytes;
   }
-  int rc;
   if (par.filter_type == CFEAR_FILTER_CACFAR) {
     cfear_cacfar_params cp = par.cacfar;
-    rc = cfear_cacfar_device(ctx, d_polar, &dd, &cp, od->d_xyzi, od->d_npts, od->cap_points, nullptr);
-  } else {
-    const size_t nsel = (size_t)B * rows * k;
-    cfear_kstrong_out o{};
-    o.sel_range = (int32_t*)od->d_sel;
-    o.sel_intensity = (uint8_t*)(od->d_sel + nsel * 4);
-    o.sel_count = (int32_t*)(od->d_sel + nsel * 4 + (nsel + 255) / 256 * 256);
-    o.xyzi = od->d_xyzi;
-    o.n_points = od->d_npts;
-    cfear_kstrong_params kp = par.kstrong;
-    kp.want_peaks = 0;     // the peaks cloud feeds CorAl / Scan Context, not the matcher
-    if (od->cap_points != rows * k)
-      return cfear_set_error(ctx, CFEAR_ERR_CAPACITY, "rows*k = %d exceeds %d points per scan", rows * k, od->cap_points);
-    rc = cfear_kstrong_device(ctx, d_polar, &dd, &kp, &o);
+    return cfear_cacfar_device(ctx, d_polar, &dd, &cp, od->d_xyzi2[buf], od->d_npts2[buf], od->cap_points, nullptr);
   }
-  if (rc != CFEAR_OK) return rc;
+  const size_t nsel = (size_t)B * rows * k;
+  cfear_kstrong_out o{};
+  o.sel_range = (int32_t*)od->d_sel;
+  o.sel_intensity = (uint8_t*)(od->d_sel + nsel * 4);
+  o.sel_count = (int32_t*)(od->d_sel + nsel * 4 + (nsel + 255) / 256 * 256);
+  o.xyzi = od->d_xyzi2[buf];
+  o.n_points = od->d_npts2[buf];
+  cfear_kstrong_params kp = par.kstrong;
+  kp.want_peaks = 0;     // the peaks cloud feeds CorAl / Scan Context, not the matcher
+  if (od->cap_points != rows * k)
+    return cfear_set_error(ctx, CFEAR_ERR_CAPACITY, "rows*k = %d exceeds %d points per scan", rows * k, od->cap_points);
+  return cfear_kstrong_device(ctx, d_polar, &dd, &kp, &o);
+}
+
+extern "C" int cfear_odometry_process(cfear_odometry* od, const uint8_t* polar, cfear_frame_info* info) {
+  return cfear_odometry_process_prefetch(od, polar, nullptr, info);
+}
+
+extern "C" int cfear_odometry_process_prefetch(cfear_odometry* od, const uint8_t* polar, const uint8_t* polar_next,
+                                               cfear_frame_info* info) {
+  if (!od || !polar || !info) return CFEAR_ERR_INVALID_ARGUMENT;
+  cfear_ctx* ctx = od->ctx;
+  CFEAR_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  const int B = od->n_streams;
+  const cfear_odometry_params& par = od->par;
+  int rc;
+  if (od->prefetched == polar) {                   // this frame's filter already ran (or is running)
+    od->cur_buf ^= 1;
+  } else {
+    rc = run_filter(od, polar, od->cur_buf);
+    if (rc != CFEAR_OK) return rc;
+  }
+  od->prefetched = nullptr;
+  od->d_xyzi = od->d_xyzi2[od->cur_buf];
+  od->d_npts = od->d_npts2[od->cur_buf];
   // ---- C + N: compensate with the previous motion, surface points (odometrykeyframefuser.cpp:146-161)
   const size_t sjb = cfear_surface_job_bytes();
   for (int b = 0; b < B; b++) {
@@ -257,7 +284,15 @@ extern "C" int cfear_odometry_process(cfear_odometry* od, const uint8_t* polar, 
   CFEAR_HIP_CHECK(ctx, hipMemcpyAsync(od->h_status, od->d_status, (size_t)B * 4, hipMemcpyDeviceToHost, ctx->stream));
   CFEAR_HIP_CHECK(ctx, hipMemcpyAsync(od->h_npts, od->d_npts, (size_t)B * 4, hipMemcpyDeviceToHost, ctx->stream));
   CFEAR_HIP_CHECK(ctx, hipMemcpyAsync(od->h_ncells, od->d_ncells, (size_t)B * 4, hipMemcpyDeviceToHost, ctx->stream));
-  CFEAR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  CFEAR_HIP_CHECK(ctx, hipEventRecord(od->ev_results, ctx->stream));
+  if (polar_next) {
+    // The next frame's filter needs no state of this frame: enqueue it now so the GPU sweeps the next
+    // polar batch while the host applies the keyframe policy below.
+    rc = run_filter(od, polar_next, od->cur_buf ^ 1);
+    if (rc != CFEAR_OK) return rc;
+    od->prefetched = polar_next;
+  }
+  CFEAR_HIP_CHECK(ctx, hipEventSynchronize(od->ev_results));
   // ---- frame policy (:195-257) ------------------------------------------------------------------
   int first_error = CFEAR_OK;
   for (int b = 0; b < B; b++) {

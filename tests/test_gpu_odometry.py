@@ -34,10 +34,14 @@ def _run(seeds, n_frames, device_input, **kw):
                             bool(par.weight_intensity), bool(par.radar_ccw)) for seq in seqs]
     for f in range(n_frames):
         batch = np.stack([seq[f] for seq in seqs])
+        nxt = None
         if device_input:
             import torch
-            batch = torch.from_numpy(batch).cuda()
-        info = od.process(batch)
+            if f == 0:
+                dev_frames = [torch.from_numpy(np.stack([seq[g] for seq in seqs])).cuda() for g in range(n_frames)]
+            batch = dev_frames[f]
+            nxt = dev_frames[f + 1] if (f + 1 < n_frames and f % 3 != 2) else None   # exercise prefetch on/off
+        info = od.process(batch, nxt)
         for b in range(len(seeds)):
             pose_o, info_o, npts_o = exp[b][f]
             assert info["n_points"][b] == npts_o
