@@ -41,6 +41,8 @@ struct KStrongArgs {
   uint8_t* sel_intensity;
   int32_t* sel_count;
   uint8_t* is_peak;
+  int32_t* row_valid;      // [batch][rows][2]: kept bins beyond min_range_bin (all, peaks) -> cloud offsets
+  int min_range_bin;
 };
 
 // bit 7 of every byte of the result is set iff that byte of x is >= t (0 <= t <= 255).
@@ -281,6 +283,7 @@ __global__ __launch_bounds__(256) void kstrongest_rows_kernel(const KStrongArgs 
 
   // ---- rank the <= k survivors: ascending (intensity, range) == ascending packed key --------
   const long long obase = ((long long)b * a.rows + r) * k;
+  int nvalid = 0, nvalid_pk = 0;
   for (int j = lane; j < k; j += 64) {
     if (j < n_sel) {
       const uint32_t key = list[j];
@@ -292,13 +295,25 @@ __global__ __launch_bounds__(256) void kstrongest_rows_kernel(const KStrongArgs 
       const int range = (int)(key & 0xFFFFFFu);
       if (a.sel_range) a.sel_range[obase + rank] = range;
       if (a.sel_intensity) a.sel_intensity[obase + rank] = (uint8_t)(key >> 24);
-      if (a.want_peaks && a.is_peak)
-        a.is_peak[obase + rank] = peak_is_largest(range, a.cols, rowbuf, img, row_lin,
-                                                  (long long)a.rows * a.stride, list, n_sel) ? 1 : 0;
+      const bool beyond = range > a.min_range_bin;                  // radar_filters.cpp:327
+      nvalid += beyond;
+      if (a.want_peaks && a.is_peak) {
+        const bool pk = peak_is_largest(range, a.cols, rowbuf, img, row_lin, (long long)a.rows * a.stride, list, n_sel);
+        a.is_peak[obase + rank] = pk ? 1 : 0;
+        nvalid_pk += (beyond && pk);
+      }
     } else {
       if (a.sel_range) a.sel_range[obase + j] = -1;
       if (a.sel_intensity) a.sel_intensity[obase + j] = 0;
       if (a.want_peaks && a.is_peak) a.is_peak[obase + j] = 0;
+    }
+  }
+  if (a.row_valid) {
+    nvalid = wave_sum_i32(nvalid);
+    nvalid_pk = wave_sum_i32(nvalid_pk);
+    if (lane == 0) {
+      a.row_valid[((long long)b * a.rows + r) * 2] = nvalid;
+      a.row_valid[((long long)b * a.rows + r) * 2 + 1] = nvalid_pk;
     }
   }
   if (lane == 0 && a.sel_count) a.sel_count[(long long)b * a.rows + r] = n_sel;
@@ -312,6 +327,7 @@ struct CloudArgs {
   const uint8_t* sel_intensity;
   const int32_t* sel_count;
   const uint8_t* is_peak;
+  const int32_t* row_valid;  // [batch][rows][2] written by kstrongest_rows_kernel
   const double* cos_t;      // [rows]
   const double* sin_t;
   int rows, k, min_range_bin;
@@ -321,6 +337,8 @@ struct CloudArgs {
   float* xyzi_peaks;
   int32_t* n_peaks;
 };
+
+constexpr int kCloudSplit = 8;   // workgroups per image: each scans all row counts, writes its row slice
 
 __global__ __launch_bounds__(256) void kstrong_cloud_kernel(const CloudArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -334,23 +352,12 @@ __global__ __launch_bounds__(256) void kstrong_cloud_kernel(const CloudArgs a) {
   if (!out && !nout) return;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const long long ibase = (long long)b * a.rows * a.k;
-  // pass 1: survivors per row
-  for (int r = threadIdx.x; r < a.rows; r += blockDim.x) {
-    const int cnt = a.sel_count[(long long)b * a.rows + r];
-    int n = 0;
-    for (int j = 0; j < cnt; j++) {
-      const bool ok = a.sel_range[ibase + (long long)r * a.k + j] > a.min_range_bin &&
-                      (!peaks || a.is_peak[ibase + (long long)r * a.k + j]);
-      n += ok;
-    }
-    row_off[r] = n;
-  }
   if (threadIdx.x == 0) run_base = 0;
   __syncthreads();
-  // pass 2: exclusive scan of row_off (chunks of 256 rows)
+  // exclusive scan of the per-row survivor counts (chunks of 256 rows)
   for (int r0 = 0; r0 < a.rows; r0 += 256) {
     const int r = r0 + threadIdx.x;
-    const int v = r < a.rows ? row_off[r] : 0;
+    const int v = r < a.rows ? a.row_valid[((long long)b * a.rows + r) * 2 + (peaks ? 1 : 0)] : 0;
     const int incl = wave_incl_scan_i32(v);
     if (lane == 63) wave_tot[wave] = incl;
     __syncthreads();
@@ -361,11 +368,13 @@ __global__ __launch_bounds__(256) void kstrong_cloud_kernel(const CloudArgs a) {
     if (threadIdx.x == 0) run_base += wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
     __syncthreads();
   }
-  if (threadIdx.x == 0 && nout) nout[b] = run_base;
+  if (threadIdx.x == 0 && nout && blockIdx.z == 0) nout[b] = run_base;
   if (!out) return;
-  // pass 3: one wavefront per row writes its points in (intensity,range) order
+  // one wavefront per row of this workgroup's slice writes its points in (intensity,range) order
   const double range_res_half = a.range_res / 2.0;
-  for (int r = wave; r < a.rows; r += 4) {
+  const int rows_per = (a.rows + kCloudSplit - 1) / kCloudSplit;
+  const int rbeg = blockIdx.z * rows_per, rend = min(a.rows, rbeg + rows_per);
+  for (int r = rbeg + wave; r < rend; r += 4) {
     const int cnt = a.sel_count[(long long)b * a.rows + r];
     const double cos_t = a.cos_t[r], sin_t = a.sin_t[r];
     int base = row_off[r];
@@ -581,6 +590,16 @@ int cfear_kstrong_device(cfear_ctx* ctx, const uint8_t* d_polar, const cfear_pol
   a.want_peaks = par->want_peaks && (o->is_peak != nullptr);
   a.sel_range = o->sel_range; a.sel_intensity = o->sel_intensity; a.sel_count = o->sel_count;
   a.is_peak = o->is_peak;
+  const bool want_cloud = o->xyzi || o->n_points || o->xyzi_peaks || o->n_peaks;
+  a.row_valid = nullptr;
+  {
+    const double range_res_ = (double)par->range_res, min_distance_ = (double)par->min_distance;
+    a.min_range_bin = (int)std::ceil(min_distance_ / range_res_);            // radar_filters.cpp:315
+  }
+  if (want_cloud) {
+    a.row_valid = (int32_t*)cfear_workspace(ctx, 3, (size_t)desc->batch * desc->rows * 8);
+    if (!a.row_valid) return cfear_set_error(ctx, CFEAR_ERR_HIP, "workspace allocation failed");
+  }
   const bool vec = (((uintptr_t)d_polar) % 4 == 0) && (a.stride % 4 == 0) && (a.batch_stride % 4 == 0);
   const bool mask = (a.cols % 16 != 0) || a.u_zmin == 0;
   const int nchunk = (a.cols + 1023) / 1024;
@@ -595,24 +614,24 @@ int cfear_kstrong_device(cfear_ctx* ctx, const uint8_t* d_polar, const cfear_pol
     else launch_kstrong<8>(ctx, a, vec, mask, grid, (size_t)kRowsPerBlock * (1024 + kpad * 4 + (a.want_peaks ? 8 * 1024 : 0)));
   }
   CFEAR_HIP_CHECK(ctx, hipGetLastError());
-  if (o->xyzi || o->n_points || o->xyzi_peaks || o->n_peaks) {
+  if (want_cloud) {
     double *d_cos = nullptr, *d_sin = nullptr;
     int rc = upload_trig(ctx, a.rows, &d_cos, &d_sin);
     if (rc != CFEAR_OK) return rc;
     CloudArgs c;
     c.sel_range = o->sel_range; c.sel_intensity = o->sel_intensity; c.sel_count = o->sel_count;
     c.is_peak = o->is_peak;
+    c.row_valid = a.row_valid;
     c.cos_t = d_cos; c.sin_t = d_sin;
     c.rows = a.rows; c.k = a.k;
-    const double range_res_ = (double)par->range_res, min_distance_ = (double)par->min_distance;
-    c.min_range_bin = (int)std::ceil(min_distance_ / range_res_);            // radar_filters.cpp:315
-    c.range_res = range_res_;
+    c.min_range_bin = a.min_range_bin;
+    c.range_res = (double)par->range_res;
     c.xyzi = o->xyzi; c.n_points = o->n_points;
     const bool pk = a.want_peaks && (o->xyzi_peaks || o->n_peaks);
     c.xyzi_peaks = pk ? o->xyzi_peaks : nullptr;
     c.n_peaks = pk ? o->n_peaks : nullptr;
     ProfScope ps(ctx, "kstrong_cloud");
-    hipLaunchKernelGGL(kstrong_cloud_kernel, dim3(a.batch, pk ? 2 : 1), dim3(256),
+    hipLaunchKernelGGL(kstrong_cloud_kernel, dim3(a.batch, pk ? 2 : 1, kCloudSplit), dim3(256),
                        (size_t)(a.rows + 1) * 4, ctx->stream, c);
     CFEAR_HIP_CHECK(ctx, hipGetLastError());
   }
