@@ -208,6 +208,13 @@ def main():
     bytes_per_scan = ROWS * COLS + 16.0 * nf + 4 * ROWS
     achieved = (bytes_per_scan * B) / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
     breakdown = {k: {"ms_per_step": v[0] / max(K, 1), "launches": int(v[1])} for k, v in prof.items()}
+    # HBM traffic of that kernel from the committed PMC passes (rocprofv3 cannot run inside this process):
+    # per-scan FETCH_SIZE x2 + WRITE_SIZE measured by tools/profile.sh, scaled to this launch's batch
+    traffic = None
+    tj = os.path.join(ROOT, "profiles", "r01", "pmc_traffic.json")
+    if os.path.exists(tj):
+        t = json.load(open(tj))
+        traffic = (t["fetch_bytes_per_scan"] + t["write_bytes_per_scan"]) * B
 
     # ---- CPU baseline: the oracle (port), 1 thread, bounded sample of the same frames -----------------
     cpu = None
@@ -259,7 +266,8 @@ def main():
                                "4-keyframe window), polar image -> pose, %d streams in flight per GPU" % B,
                    "streams_per_gpu": B, "rows": ROWS, "cols": COLS, "parallelism": "replicas x%d" % world},
         "roofline": {"bound": "hbm", "kernel": "kstrongest_rows", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                     "traffic_source": "profiles/r01/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, per scan x batch)",
                      "avg_launch_ms": avg_ms, "algorithmic_bytes_per_launch": bytes_per_scan * B,
                      "mean_points_per_scan": nf},
         "cpu_baseline": cpu,
