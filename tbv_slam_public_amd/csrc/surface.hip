@@ -153,7 +153,10 @@ __device__ void sort_cells_block(const ScanView& v, int n, unsigned long long* k
     for (int i = tid; i < n; i += nth) {
       const unsigned long long key = keys[i];
       int rank = 0;
-      for (int j = 0; j < n; j++) rank += keys[j] < key;
+      for (int j = 0; j < npad; j += 2) {                // padded keys are ~0: never smaller
+        const ulonglong2 kk = *(const ulonglong2*)(keys + j);
+        rank += (kk.x < key) + (kk.y < key);
+      }
       const float2 m = v.mean_f[i];
       v.sorted_x[rank] = m.x;
       v.sorted_y[rank] = m.y;
@@ -220,14 +223,25 @@ __global__ __launch_bounds__(kSurfThreads) void surface_points_kernel(const Surf
 #endif
   // ---- 1. compensation + bounding box -------------------------------------------------------
   float mnx = FLT_MAX, mny = FLT_MAX, mxx = -FLT_MAX, mxy = -FLT_MAX;
-  for (int i = tid; i < n; i += kSurfThreads) {
-    float4 p = pts[i];
-    if (job.compensate) {
-      p = compensate_point(p, job.mot, cm.ccw != 0);
-      pts[i] = p;
+  for (int i0 = tid; i0 < n; i0 += 4 * kSurfThreads) {  // four loads in flight per thread
+    float4 p[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int i = i0 + u * kSurfThreads;
+      if (i < n) p[u] = pts[i];
     }
-    mnx = fminf(mnx, p.x); mxx = fmaxf(mxx, p.x);
-    mny = fminf(mny, p.y); mxy = fmaxf(mxy, p.y);
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int i = i0 + u * kSurfThreads;
+      if (i < n) {
+        if (job.compensate) {
+          p[u] = compensate_point(p[u], job.mot, cm.ccw != 0);
+          pts[i] = p[u];
+        }
+        mnx = fminf(mnx, p[u].x); mxx = fmaxf(mxx, p[u].x);
+        mny = fminf(mny, p[u].y); mxy = fmaxf(mxy, p[u].y);
+      }
+    }
   }
   for (int o = 32; o > 0; o >>= 1) {
     mnx = fminf(mnx, __shfl_xor(mnx, o)); mxx = fmaxf(mxx, __shfl_xor(mxx, o));
@@ -400,15 +414,20 @@ __global__ __launch_bounds__(kSurfThreads) void surface_points_kernel(const Surf
   {
     unsigned pv = prev_vox;
     int ord = voff;
+    float4 gp[kPerThread];
+#pragma unroll
+    for (int q = 0; q < kPerThread; q++) {                // all gathers of this thread in flight together
+      const int e = tid * per + q;
+      if (q < per && e < n) gp[q] = pts[(unsigned)(mine[q] & 0xFFFFFFFFu)];
+    }
 #pragma unroll
     for (int q = 0; q < kPerThread; q++) {
       const int e = tid * per + q;
       if (q < per && e < n) {
         const unsigned vx = (unsigned)(mine[q] >> 32);
-        const unsigned pi = (unsigned)(mine[q] & 0xFFFFFFFFu);
         if (e == 0 || vx != pv) { vox_key[ord] = vx; vox_start[ord] = e; ord++; }
         pv = vx;
-        const float4 p = pts[pi];
+        const float4 p = gp[q];
         spt[e] = make_float4(p.x, p.y, p.w, 0.f);
         if (lds_pts) { lxy[e] = make_float2(p.x, p.y); lin[e] = p.w; }
       }
