@@ -50,11 +50,12 @@ struct RegCommon {
 };
 
 __host__ __device__ inline size_t slots_bytes(int slots_cap) { return ((size_t)slots_cap * 52 + 255) / 256 * 256; }
-// LDS map: [0,640) reduction partials, [640,704) int partials, then x-sorted targets (x, y, idx:
+constexpr size_t kRegFixedLds = 832;   // [0,640) reduction partials, [640,704) int partials, [704,832) LM control
+// LDS map: fixed block above, then x-sorted targets (x, y, idx:
 // 12 B each), then the dense correspondence arrays (dense_fields doubles each).
 __host__ __device__ inline size_t reg_lds_targets_bytes(int lds_targets) { return ((size_t)lds_targets * 12 + 15) / 16 * 16; }
 size_t reg_lds_bytes(int lds_targets, int dense_cap, int dense_fields) {
-  return 704 + reg_lds_targets_bytes(lds_targets) + (size_t)dense_cap * dense_fields * 8;
+  return kRegFixedLds + reg_lds_targets_bytes(lds_targets) + (size_t)dense_cap * dense_fields * 8;
 }
 constexpr size_t kRegLdsBudget = 80 * 1024 - 256;    // keeps 2 workgroups per CU (160 KiB LDS)
 constexpr size_t kRegLdsBudgetWave = 16 * 1024;      // wave-per-job geometry: >= 8 wavefronts per CU
@@ -451,7 +452,7 @@ struct FusedLds {
 // fixed parts leave no room (the caller then uses the slot-array path).
 __device__ __forceinline__ bool fused_carve(uint8_t* smem, size_t lds_total, int sum_tar, int n_src, int n_pairs,
                                             int fields, FusedLds& f) {
-  size_t off = 704;
+  size_t off = kRegFixedLds;
   f.kf = (double*)(smem + off); off += 16 * 12 * 8;
   f.koff = (int*)(smem + off); off += 80;
   const size_t tt = ((size_t)sum_tar + 3) & ~(size_t)3;
@@ -666,12 +667,18 @@ struct LmSummary {
 
 // ceres::Solve as configured by the reference (Ceres 2.1 defaults, max_num_iterations = max_iter):
 // same bookkeeping as the oracle's lm_solve / SURVEY Appendix B.4.  Block-wide collective.
+// The trust-region bookkeeping (a few hundred dependent fp64 instructions per iteration) runs on
+// wavefront 0 only; the next evaluation point and the stop flag are broadcast through a small LDS
+// control block, so the other wavefronts of the workgroup -- and the second workgroup sharing their
+// SIMDs -- do not spend issue slots on redundant scalar math.
 template <int NW, int COST, int LOSS>
 __device__ void lm_solve(const RegCommon& cm, const Dense& dn, double x[3], int max_iter, LmSummary& sum, double* part,
-                         int& phase) {
+                         int& phase, double* ctrl /* LDS [16] */) {
   const double function_tolerance = 1e-6, gradient_tolerance = 1e-10, parameter_tolerance = 1e-8;
   const double min_relative_decrease = 1e-3, min_lm_diagonal = 1e-6, max_lm_diagonal = 1e32;
   const double max_radius = 1e16, min_radius = 1e-32;
+  const bool w0 = NW == 1 || (threadIdx.x >> 6) == 0;
+  const bool writer = threadIdx.x == 0;
   double radius = 1e4, decrease_factor = 2.0;
   bool reuse_diagonal = false;
   double diagonal[3] = {0, 0, 0};
@@ -680,97 +687,135 @@ __device__ void lm_solve(const RegCommon& cm, const Dense& dn, double x[3], int 
   double cur[10];                                        // cost, g, H at the accepted x
   eval_all<NW, COST, LOSS>(cm, dn, x, cur, part, phase);
   double x_cost = cur[0];
-  double scale[3];
-  scale[0] = 1.0 / (1.0 + sqrt(cur[4]));                 // jacobi scaling from iteration 0
-  scale[1] = 1.0 / (1.0 + sqrt(cur[7]));
-  scale[2] = 1.0 / (1.0 + sqrt(cur[9]));
-  double gradient_max_norm = fmax(fabs(cur[1]), fmax(fabs(cur[2]), fabs(cur[3])));
-  double x_norm = sqrt(x[0] * x[0] + x[1] * x[1] + x[2] * x[2]);
-  sum.initial_cost = x_cost;
-  double min_iter_cost = x_cost;                         // SetSummaryFinalCost: min over pushed costs
-  double it_cost = x_cost, it_rel = 0.0;
+  double scale[3] = {1, 1, 1};
+  double gradient_max_norm = 0, x_norm = 0, min_iter_cost = x_cost, it_cost = x_cost, it_rel = 0.0;
+  double model_cost_change = 0.0;
   bool it_success = true;
   int iteration = 0;
+  sum.initial_cost = x_cost;
   sum.n_pushed = 0;
   sum.usable = true;
-  for (;;) {
-    // FinalizeIterationAndCheckIfMinimizerCanContinue
-    sum.n_pushed++;
-    sum.last_relative_decrease = it_rel;
-    min_iter_cost = fmin(min_iter_cost, it_cost);
-    if (iteration >= max_iter) break;
-    if (it_success && gradient_max_norm <= gradient_tolerance) break;
-    if (radius <= min_radius) break;
-    iteration++;
-    it_cost = 0.0; it_rel = 0.0; it_success = false;
-    // scaled quantities: J_s = J diag(scale)
-    const double gs[3] = {cur[1] * scale[0], cur[2] * scale[1], cur[3] * scale[2]};
-    double Hs[9];
-    Hs[0] = cur[4] * scale[0] * scale[0]; Hs[1] = cur[5] * scale[0] * scale[1]; Hs[2] = cur[6] * scale[0] * scale[2];
-    Hs[3] = Hs[1]; Hs[4] = cur[7] * scale[1] * scale[1]; Hs[5] = cur[8] * scale[1] * scale[2];
-    Hs[6] = Hs[2]; Hs[7] = Hs[5]; Hs[8] = cur[9] * scale[2] * scale[2];
-    if (!reuse_diagonal) {
-      diagonal[0] = fmin(fmax(Hs[0], min_lm_diagonal), max_lm_diagonal);
-      diagonal[1] = fmin(fmax(Hs[4], min_lm_diagonal), max_lm_diagonal);
-      diagonal[2] = fmin(fmax(Hs[8], min_lm_diagonal), max_lm_diagonal);
-    }
-    double A[9];
-#pragma unroll
-    for (int k = 0; k < 9; k++) A[k] = Hs[k];
-#pragma unroll
-    for (int k = 0; k < 3; k++) { const double lm = sqrt(diagonal[k] / radius); A[k * 3 + k] += lm * lm; }
-    double y[3], step[3];
-    const bool solved = chol3_solve(A, gs, y);
-    reuse_diagonal = true;
-    bool step_is_valid = false;
-    double model_cost_change = 0.0;
-    if (solved) {
-      step[0] = -y[0]; step[1] = -y[1]; step[2] = -y[2];
-      // -(J step)^T (r + J step / 2) = -step^T g_s - 1/2 step^T H_s step
-      const double sg = step[0] * gs[0] + step[1] * gs[1] + step[2] * gs[2];
-      const double hs0 = Hs[0] * step[0] + Hs[1] * step[1] + Hs[2] * step[2];
-      const double hs1 = Hs[3] * step[0] + Hs[4] * step[1] + Hs[5] * step[2];
-      const double hs2 = Hs[6] * step[0] + Hs[7] * step[1] + Hs[8] * step[2];
-      model_cost_change = -sg - (step[0] * hs0 + step[1] * hs1 + step[2] * hs2) / 2.0;
-      step_is_valid = model_cost_change > 0.0;
-    }
-    if (!step_is_valid) {
-      if (++num_consecutive_invalid_steps >= 5) { sum.usable = false; break; }
-      radius = radius / decrease_factor; decrease_factor *= 2.0; reuse_diagonal = true;
-      it_cost = x_cost; it_success = false; it_rel = 0.0;
-      continue;
-    }
-    num_consecutive_invalid_steps = 0;
-    double cand[3];
-#pragma unroll
-    for (int k = 0; k < 3; k++) cand[k] = x[k] + step[k] * scale[k];
-    double cnd[10];                                      // cost (and, speculatively, g and H) at cand
-    eval_all<NW, COST, LOSS>(cm, dn, cand, cnd, part, phase);
-    const double cand_cost = cnd[0];
-    const double step_norm = sqrt((x[0] - cand[0]) * (x[0] - cand[0]) + (x[1] - cand[1]) * (x[1] - cand[1]) +
-                                  (x[2] - cand[2]) * (x[2] - cand[2]));
-    if (step_norm <= parameter_tolerance * (x_norm + parameter_tolerance)) break;
-    const double cost_change = x_cost - cand_cost;
-    if (fabs(cost_change) <= function_tolerance * x_cost) break;
-    it_rel = cost_change / model_cost_change;
-    if (it_rel > min_relative_decrease) {
-      x[0] = cand[0]; x[1] = cand[1]; x[2] = cand[2];
-      x_norm = sqrt(x[0] * x[0] + x[1] * x[1] + x[2] * x[2]);
-#pragma unroll
-      for (int k = 0; k < 10; k++) cur[k] = cnd[k];
-      x_cost = cand_cost;
-      gradient_max_norm = fmax(fabs(cur[1]), fmax(fabs(cur[2]), fabs(cur[3])));
-      it_cost = x_cost; it_success = true;
-      const double q = 2.0 * it_rel - 1.0;
-      radius = radius / fmax(1.0 / 3.0, 1.0 - q * q * q);
-      radius = fmin(max_radius, radius);
-      decrease_factor = 2.0; reuse_diagonal = false;
-    } else {
-      it_cost = cand_cost; it_success = false;
-      radius = radius / decrease_factor; decrease_factor *= 2.0; reuse_diagonal = true;
-    }
+  sum.last_relative_decrease = 0.0;
+  if (w0) {
+    scale[0] = 1.0 / (1.0 + sqrt(cur[4]));               // jacobi scaling from iteration 0
+    scale[1] = 1.0 / (1.0 + sqrt(cur[7]));
+    scale[2] = 1.0 / (1.0 + sqrt(cur[9]));
+    gradient_max_norm = fmax(fabs(cur[1]), fmax(fabs(cur[2]), fabs(cur[3])));
+    x_norm = sqrt(x[0] * x[0] + x[1] * x[1] + x[2] * x[2]);
   }
-  sum.final_cost = fmin(sum.initial_cost, min_iter_cost);
+  double cand[3] = {x[0], x[1], x[2]};
+  double cnd[10];                                        // cost (and, speculatively, g and H) at cand
+  bool have_cnd = false;
+  for (;;) {
+    int done = 0;
+    if (w0) {
+      bool proceed = true;
+      if (have_cnd) {                                    // the candidate of the previous round was evaluated
+        const double cand_cost = cnd[0];
+        const double step_norm = sqrt((x[0] - cand[0]) * (x[0] - cand[0]) + (x[1] - cand[1]) * (x[1] - cand[1]) +
+                                      (x[2] - cand[2]) * (x[2] - cand[2]));
+        const double cost_change = x_cost - cand_cost;
+        if (step_norm <= parameter_tolerance * (x_norm + parameter_tolerance)) { done = 1; proceed = false; }
+        else if (fabs(cost_change) <= function_tolerance * x_cost) { done = 1; proceed = false; }
+        else {
+          it_rel = cost_change / model_cost_change;
+          if (it_rel > min_relative_decrease) {
+            x[0] = cand[0]; x[1] = cand[1]; x[2] = cand[2];
+            x_norm = sqrt(x[0] * x[0] + x[1] * x[1] + x[2] * x[2]);
+#pragma unroll
+            for (int k = 0; k < 10; k++) cur[k] = cnd[k];
+            x_cost = cand_cost;
+            gradient_max_norm = fmax(fabs(cur[1]), fmax(fabs(cur[2]), fabs(cur[3])));
+            it_cost = x_cost; it_success = true;
+            const double q = 2.0 * it_rel - 1.0;
+            radius = radius / fmax(1.0 / 3.0, 1.0 - q * q * q);
+            radius = fmin(max_radius, radius);
+            decrease_factor = 2.0; reuse_diagonal = false;
+          } else {
+            it_cost = cand_cost; it_success = false;
+            radius = radius / decrease_factor; decrease_factor *= 2.0; reuse_diagonal = true;
+          }
+        }
+      }
+      while (proceed) {
+        // FinalizeIterationAndCheckIfMinimizerCanContinue
+        sum.n_pushed++;
+        sum.last_relative_decrease = it_rel;
+        min_iter_cost = fmin(min_iter_cost, it_cost);
+        if (iteration >= max_iter || (it_success && gradient_max_norm <= gradient_tolerance) || radius <= min_radius) {
+          done = 1;
+          break;
+        }
+        iteration++;
+        it_cost = 0.0; it_rel = 0.0; it_success = false;
+        // scaled quantities: J_s = J diag(scale)
+        const double gs[3] = {cur[1] * scale[0], cur[2] * scale[1], cur[3] * scale[2]};
+        double Hs[9];
+        Hs[0] = cur[4] * scale[0] * scale[0]; Hs[1] = cur[5] * scale[0] * scale[1]; Hs[2] = cur[6] * scale[0] * scale[2];
+        Hs[3] = Hs[1]; Hs[4] = cur[7] * scale[1] * scale[1]; Hs[5] = cur[8] * scale[1] * scale[2];
+        Hs[6] = Hs[2]; Hs[7] = Hs[5]; Hs[8] = cur[9] * scale[2] * scale[2];
+        if (!reuse_diagonal) {
+          diagonal[0] = fmin(fmax(Hs[0], min_lm_diagonal), max_lm_diagonal);
+          diagonal[1] = fmin(fmax(Hs[4], min_lm_diagonal), max_lm_diagonal);
+          diagonal[2] = fmin(fmax(Hs[8], min_lm_diagonal), max_lm_diagonal);
+        }
+        double A[9];
+#pragma unroll
+        for (int k = 0; k < 9; k++) A[k] = Hs[k];
+#pragma unroll
+        for (int k = 0; k < 3; k++) A[k * 3 + k] += diagonal[k] / radius;    // D^2 = diag / radius
+        double y[3], step[3] = {0, 0, 0};
+        const bool solved = chol3_solve(A, gs, y);
+        reuse_diagonal = true;
+        bool step_is_valid = false;
+        model_cost_change = 0.0;
+        if (solved) {
+          step[0] = -y[0]; step[1] = -y[1]; step[2] = -y[2];
+          // -(J step)^T (r + J step / 2) = -step^T g_s - 1/2 step^T H_s step
+          const double sg = step[0] * gs[0] + step[1] * gs[1] + step[2] * gs[2];
+          const double hs0 = Hs[0] * step[0] + Hs[1] * step[1] + Hs[2] * step[2];
+          const double hs1 = Hs[3] * step[0] + Hs[4] * step[1] + Hs[5] * step[2];
+          const double hs2 = Hs[6] * step[0] + Hs[7] * step[1] + Hs[8] * step[2];
+          model_cost_change = -sg - (step[0] * hs0 + step[1] * hs1 + step[2] * hs2) / 2.0;
+          step_is_valid = model_cost_change > 0.0;
+        }
+        if (!step_is_valid) {
+          if (++num_consecutive_invalid_steps >= 5) { sum.usable = false; done = 1; break; }
+          radius = radius / decrease_factor; decrease_factor *= 2.0; reuse_diagonal = true;
+          it_cost = x_cost; it_success = false; it_rel = 0.0;
+          continue;                                      // no evaluation for an invalid step
+        }
+        num_consecutive_invalid_steps = 0;
+#pragma unroll
+        for (int k = 0; k < 3; k++) cand[k] = x[k] + step[k] * scale[k];
+        break;
+      }
+      if (writer) {
+        ctrl[0] = cand[0]; ctrl[1] = cand[1]; ctrl[2] = cand[2];
+        ((int*)(ctrl + 3))[0] = done;
+      }
+    }
+    __syncthreads();
+    done = __builtin_amdgcn_readfirstlane(((const int*)(ctrl + 3))[0]);
+    if (done) break;
+    cand[0] = ctrl[0]; cand[1] = ctrl[1]; cand[2] = ctrl[2];
+    eval_all<NW, COST, LOSS>(cm, dn, cand, cnd, part, phase);     // its barrier also protects ctrl
+    have_cnd = true;
+  }
+  // results of wavefront 0 -> every wavefront (the outer association loop is wave-uniform)
+  if (writer) {
+    ctrl[4] = x[0]; ctrl[5] = x[1]; ctrl[6] = x[2];
+    ctrl[7] = fmin(sum.initial_cost, min_iter_cost);     // solver.cc SetSummaryFinalCost
+    ctrl[8] = sum.last_relative_decrease;
+    ((int*)(ctrl + 9))[0] = sum.n_pushed;
+    ((int*)(ctrl + 9))[1] = sum.usable ? 1 : 0;
+  }
+  __syncthreads();
+  x[0] = ctrl[4]; x[1] = ctrl[5]; x[2] = ctrl[6];
+  sum.final_cost = ctrl[7];
+  sum.last_relative_decrease = ctrl[8];
+  sum.n_pushed = __builtin_amdgcn_readfirstlane(((const int*)(ctrl + 9))[0]);
+  sum.usable = __builtin_amdgcn_readfirstlane(((const int*)(ctrl + 9))[1]) != 0;
 }
 
 template <int NW, int COST, int LOSS>
@@ -778,11 +823,12 @@ __global__ __launch_bounds__(NW * 64) void register_kernel(const RegJob* __restr
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   double* part = (double*)smem;                          // [2][4][10]
   int* ipart = (int*)(smem + 640);                       // [2][4]
+  double* ctrl = (double*)(smem + 704);                  // [16] LM control block
   LdsTargets lt;
-  lt.x = (float*)(smem + 704);
+  lt.x = (float*)(smem + kRegFixedLds);
   lt.y = lt.x + cm.lds_targets;
   lt.idx = (int*)(lt.y + cm.lds_targets);
-  double* lds_dense = (double*)(smem + 704 + reg_lds_targets_bytes(cm.lds_targets));
+  double* lds_dense = (double*)(smem + kRegFixedLds + reg_lds_targets_bytes(cm.lds_targets));
   const RegJob& job = jobs[blockIdx.x];
   cfear_reg_result* res = cm.results + blockIdx.x;
   const int last = job.n_scans - 1;
@@ -838,7 +884,7 @@ __global__ __launch_bounds__(NW * 64) void register_kernel(const RegJob* __restr
     success = num_residuals > 1;                                  // :368-369
     if (!success) { fail_status = CFEAR_ERR_TOO_FEW_RESIDUALS; break; }
     double xi[3] = {x[0], x[1], x[2]};
-    lm_solve<NW, COST, LOSS>(cm, dn, xi, cm.par.max_itr_solver, summary, part, phase);
+    lm_solve<NW, COST, LOSS>(cm, dn, xi, cm.par.max_itr_solver, summary, part, phase, ctrl);
     lm_iters += summary.n_pushed - 1;
     success = summary.usable;
     if (success) { x[0] = xi[0]; x[1] = xi[1]; x[2] = xi[2]; } else fail_status = CFEAR_ERR_SOLVER;
@@ -884,7 +930,7 @@ __global__ __launch_bounds__(kRegThreads) void assoc_kernel(const RegJob* __rest
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   int* ipart = (int*)(smem + 640);
   LdsTargets lt;
-  lt.x = (float*)(smem + 704);
+  lt.x = (float*)(smem + kRegFixedLds);
   lt.y = lt.x + cm.lds_targets;
   lt.idx = (int*)(lt.y + cm.lds_targets);
   const RegJob& job = jobs[blockIdx.x];
@@ -1007,7 +1053,7 @@ int cfear_register_launch(cfear_ctx* ctx, const void* d_jobs, int n_jobs, const 
   // correspondence arrays in LDS); large batches get one wavefront per registration (no barriers, no
   // LDS exchange, 4x more registrations in flight; dense arrays stay in L2).
   const bool wave_per_job = n_jobs >= kWavePerJobMinBatch;
-  const size_t fixed = 704 + reg_lds_targets_bytes(cm.lds_targets);
+  const size_t fixed = kRegFixedLds + reg_lds_targets_bytes(cm.lds_targets);
   const size_t budget = wave_per_job ? kRegLdsBudgetWave : kRegLdsBudget;
   const size_t avail = fixed < budget ? budget - fixed : 0;
   cm.dense_cap_lds = (int)std::min<size_t>(avail / ((size_t)cm.dense_fields * 8), (size_t)slots_cap);
@@ -1186,7 +1232,7 @@ int run_eval(cfear_cost* c, const double x[3], bool want_raw) {
   o.raw_j = want_raw ? c->d_out + 2 * sc : nullptr;
   o.rob_r = c->d_out + 8 * sc;
   o.neq = c->d_out + 10 * sc;
-  hipLaunchKernelGGL(eval_kernel, dim3(1), dim3(kRegThreads), 704, ctx->stream, (const RegJob*)c->d_job, cm, x[0], x[1],
+  hipLaunchKernelGGL(eval_kernel, dim3(1), dim3(kRegThreads), kRegFixedLds, ctx->stream, (const RegJob*)c->d_job, cm, x[0], x[1],
                      x[2], o);
   CFEAR_HIP_CHECK(ctx, hipGetLastError());
   return CFEAR_OK;
