@@ -441,7 +441,8 @@ __device__ int compact_slots(const RegJob& job, const RegCommon& cm, const Slots
 struct FusedLds {
   double* kf;          // [16][12]: Ttar (l0..l3,t0,t1), Tst (l0..l3,t0,t1)
   int* koff;           // [17] prefix of target counts
-  float* tx; float* ty; int* tidx;     // [sum targets]
+  float4* txyi;        // [sum targets] x-sorted (x, y, index-as-int-bits, -): one 16-byte LDS read per candidate
+  const void** tptr;   // [16][5] per keyframe: mean, normal, nsamples, scale, cov arrays (global pointers)
   double2* smean; double2* snormal; double* sscale; int* sns;   // [n_src]
   int* match;          // [n_pairs]
   double* dense;       // rest
@@ -455,11 +456,9 @@ __device__ __forceinline__ bool fused_carve(uint8_t* smem, size_t lds_total, int
   size_t off = kRegFixedLds;
   f.kf = (double*)(smem + off); off += 16 * 12 * 8;
   f.koff = (int*)(smem + off); off += 80;
-  const size_t tt = ((size_t)sum_tar + 3) & ~(size_t)3;
-  f.tx = (float*)(smem + off); off += tt * 4;
-  f.ty = (float*)(smem + off); off += tt * 4;
-  f.tidx = (int*)(smem + off); off += tt * 4;
+  f.tptr = (const void**)(smem + off); off += 16 * 5 * 8;
   off = (off + 15) & ~(size_t)15;
+  f.txyi = (float4*)(smem + off); off += (size_t)sum_tar * 16;
   const size_t ns = ((size_t)n_src + 1) & ~(size_t)1;
   f.smean = (double2*)(smem + off); off += ns * 16;
   f.snormal = (double2*)(smem + off); off += ns * 16;
@@ -485,16 +484,16 @@ __device__ void fused_stage(const RegJob& job, const FusedLds& f) {
     const Aff2 T = aff_from_xyt(job.poses[tid]);
     double* k = f.kf + tid * 12;
     k[0] = T.l0; k[1] = T.l1; k[2] = T.l2; k[3] = T.l3; k[4] = T.t0; k[5] = T.t1;
+    const ScanView& tv = job.scans[tid];
+    const void** tp = f.tptr + tid * 5;
+    tp[0] = tv.mean; tp[1] = tv.normal; tp[2] = tv.nsamples; tp[3] = tv.scale; tp[4] = tv.cov;
   }
   __syncthreads();
   for (int i = 0; i < last; i++) {
     const ScanView& tar = job.scans[i];
     const int n = f.koff[i + 1] - f.koff[i], o = f.koff[i];
-    for (int j = tid; j < n; j += NW * 64) {
-      f.tx[o + j] = tar.sorted_x[j];
-      f.ty[o + j] = tar.sorted_y[j];
-      f.tidx[o + j] = tar.sorted_idx[j];
-    }
+    for (int j = tid; j < n; j += NW * 64)
+      f.txyi[o + j] = make_float4(tar.sorted_x[j], tar.sorted_y[j], __int_as_float(tar.sorted_idx[j]), 0.f);
   }
   const ScanView& src = job.scans[last];
   const int n_src = *src.n_cells;
@@ -542,21 +541,28 @@ __device__ int associate_fused(const RegJob& job, const RegCommon& cm, const dou
       const float xlo = qx - rwin, xhi = qx + rwin;
       const int t0 = f.koff[i], t1 = f.koff[i + 1];
       int lo = t0, hi = t1;
-      while (lo < hi) { const int mid = (lo + hi) >> 1; if (f.tx[mid] < xlo) lo = mid + 1; else hi = mid; }
+      while (lo < hi) { const int mid = (lo + hi) >> 1; if (f.txyi[mid].x < xlo) lo = mid + 1; else hi = mid; }
       int best = -1;
       float bestd = FLT_MAX;
-      for (int q = lo; q < t1; q++) {
-        const float tx = f.tx[q];
-        if (tx > xhi) break;
-        const float dx = __fsub_rn(qx, tx), dy = __fsub_rn(qy, f.ty[q]);
+      auto visit = [&](const float4 c) {
+        const float dx = __fsub_rn(qx, c.x), dy = __fsub_rn(qy, c.y);
         const float d = __fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy));
-        const int idx = f.tidx[q];
+        const int idx = __float_as_int(c.z);
         if (d < bestd || (d == bestd && idx < best)) { best = idx; bestd = d; }
+      };
+      int q = lo;
+      for (; q + 1 < t1; q += 2) {                        // two candidates per step: independent LDS reads
+        const float4 ca = f.txyi[q], cb = f.txyi[q + 1];
+        if (ca.x > xhi) { q = t1; break; }
+        visit(ca);
+        if (cb.x > xhi) { q = t1; break; }
+        visit(cb);
       }
+      if (q < t1) { const float4 ca = f.txyi[q]; if (!(ca.x > xhi)) visit(ca); }
       int m = -1;
       if (best >= 0 && (double)bestd < r2) {                                    // pointnormal.cpp:250
         const double2 ns = f.snormal[s];
-        const double2 nt = job.scans[i].normal[best];
+        const double2 nt = ((const double2*)f.tptr[i * 5 + 1])[best];
         const double nsx = T[0] * ns.x + T[1] * ns.y, nsy = T[2] * ns.x + T[3] * ns.y;
         if (fmax(nsx * nt.x + nsy * nt.y, 0.0) > cm.angle_outlier) m = best;    // :244-245
       }
@@ -594,23 +600,25 @@ __device__ int associate_fused(const RegJob& job, const RegCommon& cm, const dou
     for (int p = tid; p < n_pairs; p += NW * 64) {
       const int best = f.match[p];
       if (best >= 0) {
-        const ScanView& tar = job.scans[i];
+        const void* const* tp = f.tptr + i * 5;           // matched target's attribute arrays
         const double* K = f.kf + i * 12;                  // Ttar
         const double* T = K + 6;                          // Tsrctotar
-        const double2 nt = tar.normal[best];
-        const double2 tm = tar.mean[best];
+        const double2 nt = ((const double2*)tp[1])[best];
+        const double2 tm = ((const double2*)tp[0])[best];
+        const int tns = ((const int32_t*)tp[2])[best];
+        const double tsc = ((const double*)tp[3])[best];
         const double2 ns = f.snormal[s];
         const double nsx = T[0] * ns.x + T[1] * ns.y, nsy = T[2] * ns.x + T[3] * ns.y;
         const double direction_similarity = fmax(nsx * nt.x + nsy * nt.y, 0.0);   // :244
-        const double w = get_weight(cm.par.weight_opt, (double)f.sns[s], (double)tar.nsamples[best],
-                                    direction_similarity, f.sscale[s], tar.scale[best]);   // :247-253, :273
+        const double w = get_weight(cm.par.weight_opt, (double)f.sns[s], (double)tns,
+                                    direction_similarity, f.sscale[s], tsc);   // :247-253, :273
         const double2 sm = f.smean[s];
         dn.p[c] = sm.x; dn.p[cap + c] = sm.y;
         dn.p[2 * cap + c] = K[0] * tm.x + K[1] * tm.y + K[4];                     // Ttar * tar_mean
         dn.p[3 * cap + c] = K[2] * tm.x + K[3] * tm.y + K[5];
         dn.p[4 * cap + c] = w;
         if (cm.par.cost == CFEAR_P2D) {                                           // :288-297
-          const double4 S = tar.cov[best];
+          const double4 S = ((const double4*)tp[4])[best];
           const double a00 = K[0] * S.x + K[1] * S.z, a01 = K[0] * S.y + K[1] * S.w;
           const double a10 = K[2] * S.x + K[3] * S.z, a11 = K[2] * S.y + K[3] * S.w;
           const double c00 = (cm.par.regularization + (a00 * K[0] + a01 * K[1])) * cm.par.cov_scale;
