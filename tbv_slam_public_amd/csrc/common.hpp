@@ -150,6 +150,17 @@ __device__ __forceinline__ int wave_incl_scan_i32(int v) {
   return v;
 }
 
+// Inclusive prefix maximum of non-negative values (same DPP ladder).
+__device__ __forceinline__ int wave_incl_scan_max_i32(int v) {
+  v = max(v, dpp_mov<0x111>(v));
+  v = max(v, dpp_mov<0x112>(v));
+  v = max(v, dpp_mov<0x114>(v));
+  v = max(v, dpp_mov<0x118>(v));
+  v = max(v, dpp_mov<0x142, 0xa, 0xf, false>(v));
+  v = max(v, dpp_mov<0x143, 0xc, 0xf, false>(v));
+  return v;
+}
+
 // Wave-uniform sum (result in an SGPR).
 __device__ __forceinline__ int wave_sum_i32(int v) {
   return __builtin_amdgcn_readlane(wave_incl_scan_i32(v), 63);

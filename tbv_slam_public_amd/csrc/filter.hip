@@ -36,7 +36,7 @@ struct KStrongArgs {
   const uint8_t* polar;
   int rows, cols, stride, batch;
   long long batch_stride;
-  int k, u_zmin, want_peaks;
+  int k, u_zmin, want_peaks, batch0;
   int32_t* sel_range;
   uint8_t* sel_intensity;
   int32_t* sel_count;
@@ -125,67 +125,137 @@ __device__ bool peak_is_largest(int m, int cols, const uint8_t* rowbuf, const ui
   return largest;
 }
 
+// Candidate bitmaps.  For each 16-byte chunk c of this lane, bit (8*by + 4 + d) of bm[c] is set iff
+// byte `by` of word d is >= t.  The SWAR compare leaves its verdict in bit 7 of every byte; a
+// v_bfi per word shifts the running bitmap down one bit and inserts the new verdicts, so the
+// bitmap costs nothing over the masks themselves (5 VALU per 4 bins).
+template <int NCHUNK, bool MASK, bool THI>
+__device__ __forceinline__ void candidate_bitmaps(const uint32_t (&w)[NCHUNK * 4], uint32_t tl4, int cols, int lane,
+                                                  uint32_t (&bm)[NCHUNK]) {
+  constexpr uint32_t M = 0x80808080u;
+#pragma unroll
+  for (int c = 0; c < NCHUNK; c++) {
+    uint32_t acc = 0;
+#pragma unroll
+    for (int d = 0; d < 4; d++) {
+      const uint32_t x = w[c * 4 + d];
+      const uint32_t g = ((x & 0x7f7f7f7fu) | M) - tl4;   // per byte in [1, 0xff]: no borrow crosses bytes
+      uint32_t raw = THI ? (g & x) : (g | x);              // bit 7 of each byte: byte >= t
+      if (MASK) {                                          // byte validity (row tail / z_min == 0)
+        const int rem = cols - ((c * 64 + lane) * 16 + d * 4);
+        raw &= rem >= 4 ? 0xffffffffu : (rem <= 0 ? 0u : ((1u << (8 * rem)) - 1u));
+      }
+      acc = (raw & M) | ((acc >> 1) & ~M);
+    }
+    bm[c] = acc;
+  }
+}
+
+// Calls f(pos) for every candidate bin of this lane.  Two chunks share one loop (their bitmaps
+// occupy disjoint nibbles), so a row of <= 2048 bins costs one divergent loop, 4096 bins two.
+template <int NCHUNK, typename F>
+__device__ __forceinline__ void for_each_candidate(const uint32_t (&bm)[NCHUNK], int lane, F&& f) {
+#pragma unroll
+  for (int c = 0; c < NCHUNK; c += 2) {
+    uint32_t mm = (bm[c] >> 4) | (c + 1 < NCHUNK ? bm[c + 1] : 0u);
+    const int base = c * 1024 + lane * 16;
+    while (mm) {
+      const int t = __ffs(mm) - 1;
+      mm &= mm - 1;
+      f(base + ((t & 4) << 8) + ((t & 3) << 2) + (t >> 3));
+    }
+  }
+}
+
 template <int NCHUNK, bool VEC, bool MASK>
 __global__ __launch_bounds__(256) void kstrongest_rows_kernel(const KStrongArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const long long grow = (long long)blockIdx.x * kRowsPerBlock + wave;
-  if (grow >= (long long)a.batch * a.rows) return;          // no workgroup barrier below
-  const int b = (int)(grow / a.rows), r = (int)(grow - (long long)b * a.rows);
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int r = blockIdx.x * kRowsPerBlock + wave;          // grid = (row quads, images): no division
+  if (r >= a.rows) return;                                  // no workgroup barrier below
+  const int b = a.batch0 + blockIdx.y;
   const uint8_t* img = a.polar + (long long)b * a.batch_stride;
   const long long row_lin = (long long)r * a.stride;
   const uint8_t* rowp = img + row_lin;
   const int k = a.k;
   const int kpad = (k + 3) & ~3;
-  const int per_wave = 1024 + kpad * 4 + (a.want_peaks ? NCHUNK * 1024 : 0);
-  uint32_t* hist = (uint32_t*)(smem + wave * per_wave);            // [256] per-row intensity histogram
-  uint32_t* list = (uint32_t*)(smem + wave * per_wave + 1024);     // [kpad] survivors (packed keys)
-  uint8_t* rowbuf = smem + wave * per_wave + 1024 + kpad * 4;
+  constexpr int NP = (NCHUNK + 1) / 2;             // bitmap words per lane (two chunks per word)
+  constexpr int kScratch = (NP + 2) * 256 > 1024 ? (NP + 2) * 256 : 1024;
+  const int per_wave = NCHUNK * 1024 + kScratch + kpad * 4;
+  uint8_t* rowbuf = smem + wave * per_wave;                                       // the raw row
+  uint32_t* hist = (uint32_t*)(smem + wave * per_wave + NCHUNK * 1024);           // [256] histogram / scatter scratch
+  uint32_t* list = (uint32_t*)(smem + wave * per_wave + NCHUNK * 1024 + kScratch);   // [kpad] survivors (packed keys)
 
   uint32_t w[NCHUNK * 4];
   load_row<NCHUNK, VEC>(rowp, a.cols, lane, w);
-  if (a.want_peaks) {                              // stage the raw row for the 7-tap box sums
 #pragma unroll
-    for (int c = 0; c < NCHUNK; c++)
-      *(uint4*)(rowbuf + (c * 64 + lane) * 16) = make_uint4(w[c * 4], w[c * 4 + 1], w[c * 4 + 2], w[c * 4 + 3]);
-  }
+  for (int c = 0; c < NCHUNK; c++)                 // stage the row: candidate bytes are fetched by position
+    *(uint4*)(rowbuf + (c * 64 + lane) * 16) = make_uint4(w[c * 4], w[c * 4 + 1], w[c * 4 + 2], w[c * 4 + 3]);
 
   // ---- candidates: bins with intensity >= uchar(z_min) (radar_filters.cpp:217) ---------------------
-  const uint32_t tz4 = (uint32_t)(a.u_zmin & 0x7f) * 0x01010101u;
-  const bool tzhi = (a.u_zmin & 0x80) != 0;
-  uint32_t mz[NCHUNK * 4];                         // bit 7 of byte j set <=> bin is a candidate
+  uint32_t bm[NCHUNK];
+  {
+    const uint32_t tz4 = (uint32_t)(a.u_zmin & 0x7f) * 0x01010101u;
+    if (a.u_zmin & 0x80) candidate_bitmaps<NCHUNK, MASK, true>(w, tz4, a.cols, lane, bm);
+    else candidate_bitmaps<NCHUNK, MASK, false>(w, tz4, a.cols, lane, bm);
+  }
   int c_lane = 0;
 #pragma unroll
-  for (int i = 0; i < NCHUNK * 4; i++) {
-    uint32_t m = swar_ge(w[i], tz4, tzhi);
-    if (MASK) {                                    // byte validity (row tail / z_min == 0)
-      const int rem = a.cols - (((i >> 2) * 64 + lane) * 16 + (i & 3) * 4);
-      m &= rem >= 4 ? 0x80808080u : (rem <= 0 ? 0u : (0x80808080u & ((1u << (8 * rem)) - 1u)));
-    }
-    mz[i] = m;
-    c_lane += __popc(m);
-  }
+  for (int c = 0; c < NCHUNK; c++) c_lane += __popc(bm[c]);
   const int c_incl = wave_incl_scan_i32(c_lane);
   const int n_ge = __builtin_amdgcn_readlane(c_incl, 63);
   int n_sel;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
   if (n_ge <= k) {
-    // ---- every candidate survives: compact in (lane, position) order; ranking below restores
-    //      the reference's ascending (intensity, range) order ------------------------------------------
+    // ---- every candidate survives: compact in any order; the ranking below restores the
+    //      reference's ascending (intensity, range) order ----------------------------------------------
     n_sel = n_ge;
-    if (c_lane) {
-      int slot = c_incl - c_lane;
+    if (n_ge <= 64) {
+      // One candidate per lane, however the candidates cluster (a wall return fills adjacent bins of
+      // ONE lane).  Owner lanes mark the first slot of their run; a max-scan spreads the owner id over
+      // the run; lane j then selects bit (j - first slot) of its owner's bitmap by popcount bisection.
+      uint32_t* marker = hist;                     // [64]
+      uint32_t* sexcl = hist + 64;                 // [64] first slot of each lane's run
+      uint32_t* spw = hist + 128;                  // [NP][64] bitmaps
+      uint32_t pw[NP];
 #pragma unroll
-      for (int i = 0; i < NCHUNK * 4; i++) {
-        uint32_t mm = mz[i];
-        while (mm) {
-          const int bit = __ffs(mm) - 1;
-          mm &= mm - 1;
-          const int by = bit >> 3;
-          const int pos = ((i >> 2) * 64 + lane) * 16 + (i & 3) * 4 + by;
-          list[slot++] = (((w[i] >> (8 * by)) & 0xffu) << 24) | (uint32_t)pos;
+      for (int p = 0; p < NP; p++) pw[p] = (bm[2 * p] >> 4) | (2 * p + 1 < NCHUNK ? bm[2 * p + 1] : 0u);
+      const int excl = c_incl - c_lane;
+      marker[lane] = 0;
+      sexcl[lane] = excl;
+#pragma unroll
+      for (int p = 0; p < NP; p++) spw[p * 64 + lane] = pw[p];
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      if (c_lane) marker[excl] = lane;
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      const int own = wave_incl_scan_max_i32((int)marker[lane]);
+      if (lane < n_ge) {
+        int q = lane - (int)sexcl[own];
+        uint32_t word = spw[own];
+        int p = 0;
+#pragma unroll
+        for (int pp = 1; pp < NP; pp++) {
+          const int c = __popc(word);
+          const uint32_t nxt = spw[pp * 64 + own];
+          if (p == pp - 1 && q >= c) { q -= c; word = nxt; p = pp; }
         }
+        int t = 0;
+        { const int c = __popc(word & 0xFFFFu); if (q >= c) { q -= c; t = 16; word >>= 16; } }
+        { const int c = __popc(word & 0xFFu);   if (q >= c) { q -= c; t += 8; word >>= 8; } }
+        { const int c = __popc(word & 0xFu);    if (q >= c) { q -= c; t += 4; word >>= 4; } }
+        { const int c = __popc(word & 0x3u);    if (q >= c) { q -= c; t += 2; word >>= 2; } }
+        if (q >= (int)(word & 1u)) t += 1;
+        const int pos = p * 2048 + own * 16 + ((t & 4) << 8) + ((t & 3) << 2) + (t >> 3);
+        list[lane] = ((uint32_t)rowbuf[pos] << 24) | (uint32_t)pos;
       }
+    } else {
+      int slot = c_incl - c_lane;
+      for_each_candidate<NCHUNK>(bm, lane, [&](int pos) { list[slot++] = ((uint32_t)rowbuf[pos] << 24) | (uint32_t)pos; });
     }
   } else {
     // ---- more than k candidates: cut intensity T from an LDS histogram of the candidates ----------
@@ -193,17 +263,7 @@ __global__ __launch_bounds__(256) void kstrongest_rows_kernel(const KStrongArgs 
     *(uint4*)(hist + lane * 4) = make_uint4(0, 0, 0, 0);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    if (c_lane) {
-#pragma unroll
-      for (int i = 0; i < NCHUNK * 4; i++) {
-        uint32_t mm = mz[i];
-        while (mm) {
-          const int bit = __ffs(mm) - 1;
-          mm &= mm - 1;
-          atomicAdd(&hist[(w[i] >> (bit & ~7)) & 0xffu], 1u);
-        }
-      }
-    }
+    for_each_candidate<NCHUNK>(bm, lane, [&](int pos) { atomicAdd(&hist[rowbuf[pos]], 1u); });
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
     // lane L owns intensities 4*(63-L)+{0..3}: an inclusive scan over lanes counts from 255 downward
@@ -228,6 +288,7 @@ __global__ __launch_bounds__(256) void kstrongest_rows_kernel(const KStrongArgs 
     n_eq = __builtin_amdgcn_readlane(n_eq, lc);
     const int skip_eq = n_eq - (k - n_gt);         // drop the lowest-range ties: lexicographic (intensity, range)
     // ---- ordered compaction: all (> T) plus the (== T) bins of rank >= skip_eq in position order -----
+    // (T >= z_min, so ">= T" implies candidacy; only the MASK variant needs the validity bits)
     const int thr_gt = T + 1;
     const uint32_t tg4 = (uint32_t)(thr_gt & 0x7f) * 0x01010101u;
     const bool tghi = (thr_gt & 0x80) != 0;
@@ -241,8 +302,9 @@ __global__ __launch_bounds__(256) void kstrongest_rows_kernel(const KStrongArgs 
 #pragma unroll
       for (int d = 0; d < 4; d++) {
         const int i = c * 4 + d;
-        mg[d] = thr_gt > 255 ? 0u : (swar_ge(w[i], tg4, tghi) & mz[i]);
-        me[d] = swar_ge(w[i], te4, tehi) & mz[i] & ~mg[d];
+        const uint32_t valid = MASK ? ((bm[c] << (3 - d)) & 0x80808080u) : 0x80808080u;
+        mg[d] = thr_gt > 255 ? 0u : (swar_ge(w[i], tg4, tghi) & valid);
+        me[d] = swar_ge(w[i], te4, tehi) & valid & ~mg[d];
         cg += __popc(mg[d]);
         ce += __popc(me[d]);
       }
@@ -283,8 +345,9 @@ __global__ __launch_bounds__(256) void kstrongest_rows_kernel(const KStrongArgs 
 
   // ---- rank the <= k survivors: ascending (intensity, range) == ascending packed key --------
   const long long obase = ((long long)b * a.rows + r) * k;
-  int nvalid = 0, nvalid_pk = 0;
+  int nvalid = 0, nvalid_pk = 0;                   // wave-uniform (ballot popcounts)
   for (int j = lane; j < k; j += 64) {
+    bool beyond = false, beyond_pk = false;
     if (j < n_sel) {
       const uint32_t key = list[j];
       int rank = 0;
@@ -295,28 +358,27 @@ __global__ __launch_bounds__(256) void kstrongest_rows_kernel(const KStrongArgs 
       const int range = (int)(key & 0xFFFFFFu);
       if (a.sel_range) a.sel_range[obase + rank] = range;
       if (a.sel_intensity) a.sel_intensity[obase + rank] = (uint8_t)(key >> 24);
-      const bool beyond = range > a.min_range_bin;                  // radar_filters.cpp:327
-      nvalid += beyond;
+      beyond = range > a.min_range_bin;                             // radar_filters.cpp:327
       if (a.want_peaks && a.is_peak) {
         const bool pk = peak_is_largest(range, a.cols, rowbuf, img, row_lin, (long long)a.rows * a.stride, list, n_sel);
         a.is_peak[obase + rank] = pk ? 1 : 0;
-        nvalid_pk += (beyond && pk);
+        beyond_pk = beyond && pk;
       }
     } else {
       if (a.sel_range) a.sel_range[obase + j] = -1;
       if (a.sel_intensity) a.sel_intensity[obase + j] = 0;
       if (a.want_peaks && a.is_peak) a.is_peak[obase + j] = 0;
     }
+    nvalid += __popcll(__ballot(beyond));
+    nvalid_pk += __popcll(__ballot(beyond_pk));
   }
-  if (a.row_valid) {
-    nvalid = wave_sum_i32(nvalid);
-    nvalid_pk = wave_sum_i32(nvalid_pk);
-    if (lane == 0) {
+  if (lane == 0) {
+    if (a.row_valid) {
       a.row_valid[((long long)b * a.rows + r) * 2] = nvalid;
       a.row_valid[((long long)b * a.rows + r) * 2 + 1] = nvalid_pk;
     }
+    if (a.sel_count) a.sel_count[(long long)b * a.rows + r] = n_sel;
   }
-  if (lane == 0 && a.sel_count) a.sel_count[(long long)b * a.rows + r] = n_sel;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -603,15 +665,21 @@ int cfear_kstrong_device(cfear_ctx* ctx, const uint8_t* d_polar, const cfear_pol
   const bool vec = (((uintptr_t)d_polar) % 4 == 0) && (a.stride % 4 == 0) && (a.batch_stride % 4 == 0);
   const bool mask = (a.cols % 16 != 0) || a.u_zmin == 0;
   const int nchunk = (a.cols + 1023) / 1024;
-  const long long nrows = (long long)a.batch * a.rows;
-  dim3 grid((unsigned)((nrows + kRowsPerBlock - 1) / kRowsPerBlock));
   const int kpad = (a.k + 3) & ~3;
   {
     ProfScope ps(ctx, "kstrongest_rows");
-    if (nchunk <= 1) launch_kstrong<1>(ctx, a, vec, mask, grid, (size_t)kRowsPerBlock * (1024 + kpad * 4 + (a.want_peaks ? 1 * 1024 : 0)));
-    else if (nchunk <= 2) launch_kstrong<2>(ctx, a, vec, mask, grid, (size_t)kRowsPerBlock * (1024 + kpad * 4 + (a.want_peaks ? 2 * 1024 : 0)));
-    else if (nchunk <= 4) launch_kstrong<4>(ctx, a, vec, mask, grid, (size_t)kRowsPerBlock * (1024 + kpad * 4 + (a.want_peaks ? 4 * 1024 : 0)));
-    else launch_kstrong<8>(ctx, a, vec, mask, grid, (size_t)kRowsPerBlock * (1024 + kpad * 4 + (a.want_peaks ? 8 * 1024 : 0)));
+    for (int b0 = 0; b0 < a.batch; b0 += 65535) {             // gridDim.y limit
+      a.batch0 = b0;
+      dim3 grid((unsigned)((a.rows + kRowsPerBlock - 1) / kRowsPerBlock), (unsigned)std::min(65535, a.batch - b0));
+      auto lds = [&](int nchunk_t) {
+        const int np = (nchunk_t + 1) / 2;
+        return (size_t)kRowsPerBlock * (nchunk_t * 1024 + std::max(1024, (np + 2) * 256) + kpad * 4);
+      };
+      if (nchunk <= 1) launch_kstrong<1>(ctx, a, vec, mask, grid, lds(1));
+      else if (nchunk <= 2) launch_kstrong<2>(ctx, a, vec, mask, grid, lds(2));
+      else if (nchunk <= 4) launch_kstrong<4>(ctx, a, vec, mask, grid, lds(4));
+      else launch_kstrong<8>(ctx, a, vec, mask, grid, lds(8));
+    }
   }
   CFEAR_HIP_CHECK(ctx, hipGetLastError());
   if (want_cloud) {
