@@ -182,6 +182,23 @@ __device__ __forceinline__ double row16_sum_f64(double v) {
   v += dpp_f64<0x140>(v);   // row_mirror
   return v;
 }
+// Wave total in lane 63 only: row sums, then (R3 + R2) + (R1 + R0) through row_bcast -- no readlanes.
+__device__ __forceinline__ double wave_sum_lane63_f64(double v) {
+  v = row16_sum_f64(v);
+  {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, 0x142, 0xa, 0xf, false);   // row_bcast:15 -> rows 1,3
+    hi = __builtin_amdgcn_update_dpp(0, hi, 0x142, 0xa, 0xf, false);
+    v += __hiloint2double(hi, lo);
+  }
+  {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, 0x143, 0xc, 0xf, false);   // row_bcast:31 -> rows 2,3
+    hi = __builtin_amdgcn_update_dpp(0, hi, 0x143, 0xc, 0xf, false);
+    v += __hiloint2double(hi, lo);
+  }
+  return v;
+}
 __device__ __forceinline__ double readlane_f64(double v, int lane) {
   int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
   int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);

@@ -25,6 +25,16 @@
 
 namespace {
 
+#ifdef CFEAR_REG_TIMING   // debug build only: cycle split of workgroup 0, printed at kernel end
+__device__ long long g_reg_t[16];
+#define REG_T0() long long _t0 = __builtin_readcyclecounter()
+#define REG_TACC(k) do { const long long _t1 = __builtin_readcyclecounter(); \
+    if (threadIdx.x == 0 && blockIdx.x == 0) g_reg_t[k] += _t1 - _t0; _t0 = _t1; } while (0)
+#else
+#define REG_T0()
+#define REG_TACC(k)
+#endif
+
 constexpr int kRegThreads = 256;
 constexpr int kMaxScans = 16;
 constexpr int kMaxTargetsLds = 8192;         // float2 targets staged in LDS (64 KiB)
@@ -44,25 +54,35 @@ struct RegCommon {
   int32_t slots_cap;
   int32_t lds_targets;                        // capacity of the staged (x-sorted) target arrays
   int32_t dense_cap_lds;                      // correspondences that fit the LDS dense arrays (slot path)
-  int32_t dense_fields;                       // doubles per correspondence (5 P2P, 7 P2L, 8 P2D)
+  int32_t dense_fields;                       // doubles per correspondence (3 P2P, 5 P2L, 6 P2D) + one int32
   uint32_t lds_total;                         // dynamic LDS bytes of the launch
   cfear_reg_result* results;
 };
 
 __host__ __device__ inline size_t slots_bytes(int slots_cap) { return ((size_t)slots_cap * 52 + 255) / 256 * 256; }
-constexpr size_t kRegFixedLds = 832;   // [0,640) reduction partials, [640,704) int partials, [704,832) LM control
+#ifndef REG_NW
+#define REG_NW 4
+#endif
+#ifndef REG_LDS_KB
+#define REG_LDS_KB 80
+#endif
+constexpr int kRegNW = REG_NW;         // wavefronts per registration workgroup (register_kernel)
+constexpr int kRegMaxNW = 16;
+// fixed LDS: [0,2560) reduction partials [2][16][10], [2560,2688) int partials [2][16], [2688,2816) LM control
+constexpr size_t kRegIpartOff = 2560, kRegCtrlOff = 2688;
+constexpr size_t kRegFixedLds = 2816;
 // LDS map: fixed block above, then x-sorted targets (x, y, idx:
 // 12 B each), then the dense correspondence arrays (dense_fields doubles each).
 __host__ __device__ inline size_t reg_lds_targets_bytes(int lds_targets) { return ((size_t)lds_targets * 12 + 15) / 16 * 16; }
 size_t reg_lds_bytes(int lds_targets, int dense_cap, int dense_fields) {
-  return kRegFixedLds + reg_lds_targets_bytes(lds_targets) + (size_t)dense_cap * dense_fields * 8;
+  return kRegFixedLds + reg_lds_targets_bytes(lds_targets) + (size_t)dense_cap * (dense_fields * 8 + 4);
 }
-constexpr size_t kRegLdsBudget = 80 * 1024 - 256;    // keeps 2 workgroups per CU (160 KiB LDS)
+constexpr size_t kRegLdsBudget = REG_LDS_KB * 1024 - 256;    // keeps 2 workgroups per CU (160 KiB LDS)
 constexpr size_t kRegLdsBudgetWave = 16 * 1024;      // wave-per-job geometry: >= 8 wavefronts per CU
 // Measured on MI355X (round 1): with ~190 VGPRs only 2 wavefronts fit a SIMD, so the wave-per-job
 // geometry is latency-bound on its 4x longer per-lane loops (4096 jobs: 6.7 ms vs 6.0 ms); disabled.
 constexpr int kWavePerJobMinBatch = 1 << 30;
-int reg_dense_fields(int cost) { return cost == CFEAR_P2P ? 5 : (cost == CFEAR_P2L ? 7 : 8); }
+int reg_dense_fields(int cost) { return cost == CFEAR_P2P ? 3 : (cost == CFEAR_P2L ? 5 : 6); }
 
 struct Aff2 { double l0, l1, l2, l3, t0, t1; };
 
@@ -167,30 +187,40 @@ __device__ __forceinline__ Slots slots_of(char* scratch, int cap) {
 // 10 accumulators: cost, g[3], H upper triangle (00,01,02,11,12,22)
 // NW = wavefronts per registration: 4 (one 256-thread workgroup per job, lowest latency) or 1 (one
 // wavefront per job: no barriers or LDS exchange at all, 4x more jobs in flight -- large batches).
-template <int NW>
-__device__ __forceinline__ void block_reduce10(double v[10], double* part /*[2][4][10]*/, int& phase) {
+// ALL = false: only wavefront 0 (the LM bookkeeping wavefront) receives the totals.
+template <int NW, bool ALL = true>
+__device__ __forceinline__ void block_reduce10(double v[10], double* part /*[2][16][10]*/, int& phase) {
   if (NW == 1) {
 #pragma unroll
     for (int k = 0; k < 10; k++) v[k] = wave_sum_f64(v[k]);     // already wave-uniform (readlane)
     return;
   }
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  double* buf = part + phase * 40;
+  double* buf = part + phase * (kRegMaxNW * 10);       // k-major: buf[k * NW + wave]
 #pragma unroll
   for (int k = 0; k < 10; k++) {
-    const double t = wave_sum_f64(v[k]);
-    if (lane == 0) buf[wave * 10 + k] = t;
+    const double t = wave_sum_lane63_f64(v[k]);
+    if (lane == 63) buf[k * NW + wave] = t;
   }
   __syncthreads();
+  if (ALL || wave == 0) {
+    // lane-parallel cross-wave sum: partial j = k * NW + wave sits in lane j % 64 of register j / 64;
+    // aligned groups of NW lanes are summed by a DPP butterfly (fixed order), totals read back by
+    // readlane so they are wave-uniform: every decision derived from them compiles to scalar branches.
+    constexpr int NR = (10 * NW + 63) / 64;
+    double r[NR];
 #pragma unroll
-  for (int k = 0; k < 10; k++) {
-    // readfirstlane: tell the compiler the totals are wave-uniform, so every decision derived from
-    // them compiles to scalar branches instead of exec-masked (structurized) control flow
-    double t = buf[k];
+    for (int q = 0; q < NR; q++) {
+      const int j = q * 64 + lane;
+      double t = j < 10 * NW ? buf[j] : 0.0;
+      if (NW >= 2) t += dpp_f64<0xB1>(t);      // quad_perm [1,0,3,2]
+      if (NW >= 4) t += dpp_f64<0x4E>(t);      // quad_perm [2,3,0,1]
+      if (NW >= 8) t += dpp_f64<0x141>(t);     // row_half_mirror
+      if (NW >= 16) t += dpp_f64<0x140>(t);    // row_mirror
+      r[q] = t;
+    }
 #pragma unroll
-    for (int wv = 1; wv < NW; wv++) t += buf[wv * 10 + k];
-    v[k] = __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(t)),
-                            __builtin_amdgcn_readfirstlane(__double2loint(t)));
+    for (int k = 0; k < 10; k++) v[k] = readlane_f64(r[(k * NW) / 64], (k * NW) % 64);
   }
   phase ^= 1;
 }
@@ -199,7 +229,7 @@ __device__ __forceinline__ int block_sum_i32(int v, int* part /*[2][4]*/, int& p
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int t = wave_sum_i32(v);
   if (NW == 1) { __syncthreads(); return t; }
-  int* buf = part + phase * 4;
+  int* buf = part + phase * kRegMaxNW;
   if (lane == 0) buf[wave] = t;
   __syncthreads();
   int r = buf[0];
@@ -356,29 +386,37 @@ __device__ __forceinline__ void eval_slot_rt(const cfear_reg_params& par, double
   else eval_slot<CFEAR_P2D, -1, WITH_JAC>(par, smx, smy, tmx, tmy, a0, a1, a2, w, tx, ty, c, s, acc);
 }
 
-// Dense correspondence arrays (SoA, stride dcap): 0 smx, 1 smy, 2 tmx, 3 tmy, 4 w, 5 a0, 6 a1, 7 a2.
-// They live in LDS when they fit (cm.dense_cap_lds), otherwise in the job's global scratch; the
-// pointer is generic, so one code path serves both.
-struct Dense { double* p; int cap; int n; };
+// Dense correspondence arrays (SoA, stride cap): doubles 0 tmx, 1 tmy, 2 w, 3 a0, 4 a1, 5 a2, then the
+// int32 source-cell index (the source mean is read through it instead of being copied per block).
+// They live in LDS when they fit, otherwise in the job's global scratch; the pointers are generic, so
+// one code path serves both.
+struct Dense { double* p; int* sidx; const double2* smean; int cap; int n; };
+__device__ __forceinline__ void dense_bind(Dense& dn, double* base, int cap, int fields, const double2* smean) {
+  dn.p = base; dn.cap = cap; dn.sidx = (int*)(base + (size_t)fields * cap); dn.smean = smean;
+}
 
 // cost, gradient and Gauss-Newton matrix of all correspondences at x (block-wide collective)
 template <int NW, int COST, int LOSS>
 __device__ void eval_all(const RegCommon& cm, const Dense& dn, const double x[3], double out[10], double* part, int& phase) {
+  REG_T0();
   double s, c;
   sincos(x[2], &s, &c);
   double acc[10];
 #pragma unroll
   for (int k = 0; k < 10; k++) acc[k] = 0.0;
   const size_t cap = (size_t)dn.cap;
+  REG_TACC(7);
   for (int i = threadIdx.x; i < dn.n; i += NW * 64) {
-    const double smx = dn.p[i], smy = dn.p[cap + i], tmx = dn.p[2 * cap + i], tmy = dn.p[3 * cap + i];
-    const double w = dn.p[4 * cap + i];
+    const double2 sm = dn.smean[dn.sidx[i]];
+    const double tmx = dn.p[i], tmy = dn.p[cap + i], w = dn.p[2 * cap + i];
     double a0 = 0.0, a1 = 0.0, a2 = 0.0;
-    if (COST != CFEAR_P2P) { a0 = dn.p[5 * cap + i]; a1 = dn.p[6 * cap + i]; }
-    if (COST == CFEAR_P2D) a2 = dn.p[7 * cap + i];
-    eval_slot<COST, LOSS, true>(cm.par, smx, smy, tmx, tmy, a0, a1, a2, w, x[0], x[1], c, s, acc);
+    if (COST != CFEAR_P2P) { a0 = dn.p[3 * cap + i]; a1 = dn.p[4 * cap + i]; }
+    if (COST == CFEAR_P2D) a2 = dn.p[5 * cap + i];
+    eval_slot<COST, LOSS, true>(cm.par, sm.x, sm.y, tmx, tmy, a0, a1, a2, w, x[0], x[1], c, s, acc);
   }
-  block_reduce10<NW>(acc, part, phase);
+  REG_TACC(4);
+  block_reduce10<NW, false>(acc, part, phase);
+  REG_TACC(5);
 #pragma unroll
   for (int k = 0; k < 10; k++) out[k] = acc[k];
 }
@@ -394,7 +432,7 @@ __device__ int compact_slots(const RegJob& job, const RegCommon& cm, const Slots
     __syncthreads();                                     // every slot array is complete
     total = __builtin_amdgcn_readlane(incl, 63);
   } else {
-    int* buf = ipart + iphase * 4;
+    int* buf = ipart + iphase * kRegMaxNW;
     if (lane == 63) buf[wave] = incl;
     __syncthreads();                                     // also: every slot array is complete
     for (int wv = 0; wv < wave; wv++) base += buf[wv];
@@ -405,11 +443,10 @@ __device__ int compact_slots(const RegJob& job, const RegCommon& cm, const Slots
     iphase ^= 1;
   }
   const bool in_lds = total <= cm.dense_cap_lds;
-  dn.p = in_lds ? lds_dense : gl_dense;
-  dn.cap = in_lds ? cm.dense_cap_lds : cm.slots_cap;
+  dense_bind(dn, in_lds ? lds_dense : gl_dense, in_lds ? cm.dense_cap_lds : cm.slots_cap, cm.dense_fields,
+             job.scans[job.n_scans - 1].mean);
   dn.n = total;
   const size_t cap = (size_t)dn.cap;
-  const double2* smean = job.scans[job.n_scans - 1].mean;
   int c = base;
   // same visiting order as associate_all: keyframes outer, this thread's source cells inner
   const int last = job.n_scans - 1;
@@ -418,12 +455,11 @@ __device__ int compact_slots(const RegJob& job, const RegCommon& cm, const Slots
       const int slot = i * n_src + s;
       const double w = sl.w[slot];
       if (w < 0.0) continue;
-      const double2 sm = smean[s];
-      dn.p[c] = sm.x; dn.p[cap + c] = sm.y;
-      dn.p[2 * cap + c] = sl.tmx[slot]; dn.p[3 * cap + c] = sl.tmy[slot];
-      dn.p[4 * cap + c] = w;
-      if (cm.par.cost != CFEAR_P2P) { dn.p[5 * cap + c] = sl.a0[slot]; dn.p[6 * cap + c] = sl.a1[slot]; }
-      if (cm.par.cost == CFEAR_P2D) dn.p[7 * cap + c] = sl.a2[slot];
+      dn.sidx[c] = s;
+      dn.p[c] = sl.tmx[slot]; dn.p[cap + c] = sl.tmy[slot];
+      dn.p[2 * cap + c] = w;
+      if (cm.par.cost != CFEAR_P2P) { dn.p[3 * cap + c] = sl.a0[slot]; dn.p[4 * cap + c] = sl.a1[slot]; }
+      if (cm.par.cost == CFEAR_P2D) dn.p[5 * cap + c] = sl.a2[slot];
       c++;
     }
   __syncthreads();
@@ -468,7 +504,7 @@ __device__ __forceinline__ bool fused_carve(uint8_t* smem, size_t lds_total, int
   off = (off + 15) & ~(size_t)15;
   if (off + 1024 > lds_total) return false;
   f.dense = (double*)(smem + off);
-  f.dense_cap = (int)((lds_total - off) / ((size_t)fields * 8));
+  f.dense_cap = (int)((lds_total - off) / ((size_t)fields * 8 + 4)) & ~1;   // even: keeps the int array 8-byte aligned
   return true;
 }
 
@@ -517,6 +553,7 @@ __device__ int associate_fused(const RegJob& job, const RegCommon& cm, const dou
   const double curr_radius = (itr == 1) ? 2 * cm.par.radius : cm.par.radius;    // :220
   const double r2 = curr_radius * curr_radius;
   const float rwin = (float)curr_radius + 1e-3f;
+  REG_T0();
   if (tid < last) {                                      // Tsrctotar_i = Ttar_i^-1 * Tsrc  (:222)
     const double* k = f.kf + tid * 12;
     const Aff2 Ttar{k[0], k[1], k[2], k[3], k[4], k[5]};
@@ -525,6 +562,7 @@ __device__ int associate_fused(const RegJob& job, const RegCommon& cm, const dou
     o[0] = Tst.l0; o[1] = Tst.l1; o[2] = Tst.l2; o[3] = Tst.l3; o[4] = Tst.t0; o[5] = Tst.t1;
   }
   __syncthreads();
+  REG_TACC(0);
   // ---- pass 1: exact windowed 1-NN + normal gate -> match[] --------------------------------------
   int accepted = 0;
   {
@@ -572,13 +610,14 @@ __device__ int associate_fused(const RegJob& job, const RegCommon& cm, const dou
       while (s >= n_src && i < last) { s -= n_src; i++; }
     }
   }
+  REG_TACC(1);
   // ---- block scan of the accepted counts (thread-major order, deterministic) ----------------------
   const int incl = wave_incl_scan_i32(accepted);
   int base = incl - accepted, total;
   if (NW == 1) {
     total = __builtin_amdgcn_readlane(incl, 63);
   } else {
-    int* buf = ipart + iphase * 4;
+    int* buf = ipart + iphase * kRegMaxNW;
     if (lane == 63) buf[wave] = incl;
     __syncthreads();
     for (int wv = 0; wv < wave; wv++) base += buf[wv];
@@ -589,10 +628,10 @@ __device__ int associate_fused(const RegJob& job, const RegCommon& cm, const dou
     iphase ^= 1;
   }
   const bool in_lds = total <= f.dense_cap;
-  dn.p = in_lds ? f.dense : gl_dense;
-  dn.cap = in_lds ? f.dense_cap : cm.slots_cap;
+  dense_bind(dn, in_lds ? f.dense : gl_dense, in_lds ? f.dense_cap : cm.slots_cap, cm.dense_fields, f.smean);
   dn.n = total;
   const size_t cap = (size_t)dn.cap;
+  REG_TACC(2);
   // ---- pass 2: matched target attributes -> weights + world-frame block data -> dense arrays ------
   {
     int c = base, i = 0, s = tid;
@@ -612,11 +651,10 @@ __device__ int associate_fused(const RegJob& job, const RegCommon& cm, const dou
         const double direction_similarity = fmax(nsx * nt.x + nsy * nt.y, 0.0);   // :244
         const double w = get_weight(cm.par.weight_opt, (double)f.sns[s], (double)tns,
                                     direction_similarity, f.sscale[s], tsc);   // :247-253, :273
-        const double2 sm = f.smean[s];
-        dn.p[c] = sm.x; dn.p[cap + c] = sm.y;
-        dn.p[2 * cap + c] = K[0] * tm.x + K[1] * tm.y + K[4];                     // Ttar * tar_mean
-        dn.p[3 * cap + c] = K[2] * tm.x + K[3] * tm.y + K[5];
-        dn.p[4 * cap + c] = w;
+        dn.sidx[c] = s;
+        dn.p[c] = K[0] * tm.x + K[1] * tm.y + K[4];                               // Ttar * tar_mean
+        dn.p[cap + c] = K[2] * tm.x + K[3] * tm.y + K[5];
+        dn.p[2 * cap + c] = w;
         if (cm.par.cost == CFEAR_P2D) {                                           // :288-297
           const double4 S = ((const double4*)tp[4])[best];
           const double a00 = K[0] * S.x + K[1] * S.z, a01 = K[0] * S.y + K[1] * S.w;
@@ -628,10 +666,10 @@ __device__ int associate_fused(const RegJob& job, const RegCommon& cm, const dou
           const double det = c00 * c11 - c10 * c01, invdet = 1.0 / det;
           const double i00 = c11 * invdet, i10 = -c10 * invdet, i11 = c00 * invdet;
           const double l00 = sqrt(i00), l10 = i10 / l00;
-          dn.p[5 * cap + c] = l00; dn.p[6 * cap + c] = l10; dn.p[7 * cap + c] = sqrt(i11 - l10 * l10);
+          dn.p[3 * cap + c] = l00; dn.p[4 * cap + c] = l10; dn.p[5 * cap + c] = sqrt(i11 - l10 * l10);
         } else if (cm.par.cost == CFEAR_P2L) {
-          dn.p[5 * cap + c] = K[0] * nt.x + K[1] * nt.y;                          // Ttar.linear() * tar_normal
-          dn.p[6 * cap + c] = K[2] * nt.x + K[3] * nt.y;
+          dn.p[3 * cap + c] = K[0] * nt.x + K[1] * nt.y;                          // Ttar.linear() * tar_normal
+          dn.p[4 * cap + c] = K[2] * nt.x + K[3] * nt.y;
         }
         c++;
       }
@@ -640,6 +678,7 @@ __device__ int associate_fused(const RegJob& job, const RegCommon& cm, const dou
     }
   }
   __syncthreads();
+  REG_TACC(3);
   return total;
 }
 
@@ -830,8 +869,8 @@ template <int NW, int COST, int LOSS>
 __global__ __launch_bounds__(NW * 64) void register_kernel(const RegJob* __restrict__ jobs, const RegCommon cm) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   double* part = (double*)smem;                          // [2][4][10]
-  int* ipart = (int*)(smem + 640);                       // [2][4]
-  double* ctrl = (double*)(smem + 704);                  // [16] LM control block
+  int* ipart = (int*)(smem + kRegIpartOff);              // [2][16]
+  double* ctrl = (double*)(smem + kRegCtrlOff);          // [16] LM control block
   LdsTargets lt;
   lt.x = (float*)(smem + kRegFixedLds);
   lt.y = lt.x + cm.lds_targets;
@@ -861,7 +900,9 @@ __global__ __launch_bounds__(NW * 64) void register_kernel(const RegJob* __restr
   for (int i = 0; i < last; i++) sum_tar += *job.scans[i].n_cells;
   FusedLds fl;
   const bool fused = fused_carve(smem, cm.lds_total, sum_tar, n_src, n_slots, cm.dense_fields, fl);
+  REG_T0();
   if (fused) fused_stage<NW>(job, fl);
+  REG_TACC(6);
   const int rpb = cm.par.cost == CFEAR_P2L ? 1 : 2;
   // n_scan_normal.cpp:82-185
   double prev_par[3] = {x[0], x[1], x[2]};
@@ -926,6 +967,12 @@ __global__ __launch_bounds__(NW * 64) void register_kernel(const RegJob* __restr
 #ifdef CFEAR_REG_TIMING
     res->reserved = (double)t_assoc;
     res->last_relative_decrease = (double)(__builtin_readcyclecounter() - t_total0);
+    if (blockIdx.x == 0) {
+      printf("reg cycles: total %lld | stage %lld | Tst %lld nn+gate %lld scan %lld gather %lld | sincos %lld eval %lld reduce %lld | outer %d lm %d n %d\n",
+             (long long)res->last_relative_decrease + g_reg_t[6], g_reg_t[6], g_reg_t[0], g_reg_t[1], g_reg_t[2], g_reg_t[3],
+             g_reg_t[7], g_reg_t[4], g_reg_t[5], itr, lm_iters, num_residuals);
+      for (int k = 0; k < 16; k++) g_reg_t[k] = 0;
+    }
 #endif
     if (success) { res->score = summary.final_cost / (double)num_residuals; res->status = CFEAR_OK; }   // :162
     else { res->score = 0.0; res->status = fail_status; }
@@ -936,7 +983,7 @@ __global__ __launch_bounds__(NW * 64) void register_kernel(const RegJob* __restr
 __global__ __launch_bounds__(kRegThreads) void assoc_kernel(const RegJob* __restrict__ jobs, const RegCommon cm, int itr,
                                                             int32_t* n_blocks_out) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-  int* ipart = (int*)(smem + 640);
+  int* ipart = (int*)(smem + kRegIpartOff);
   LdsTargets lt;
   lt.x = (float*)(smem + kRegFixedLds);
   lt.y = lt.x + cm.lds_targets;
@@ -1064,7 +1111,7 @@ int cfear_register_launch(cfear_ctx* ctx, const void* d_jobs, int n_jobs, const 
   const size_t fixed = kRegFixedLds + reg_lds_targets_bytes(cm.lds_targets);
   const size_t budget = wave_per_job ? kRegLdsBudgetWave : kRegLdsBudget;
   const size_t avail = fixed < budget ? budget - fixed : 0;
-  cm.dense_cap_lds = (int)std::min<size_t>(avail / ((size_t)cm.dense_fields * 8), (size_t)slots_cap);
+  cm.dense_cap_lds = (int)std::min<size_t>(avail / ((size_t)cm.dense_fields * 8 + 4), (size_t)slots_cap) & ~1;
   size_t lds = reg_lds_bytes(cm.lds_targets, cm.dense_cap_lds, cm.dense_fields);
   if (lds < budget) lds = budget;
   cm.lds_total = (uint32_t)lds;
@@ -1074,13 +1121,13 @@ int cfear_register_launch(cfear_ctx* ctx, const void* d_jobs, int n_jobs, const 
   const bool huber = par->loss == CFEAR_LOSS_HUBER;
   KernelFn fn;
   switch (par->cost) {
-    case CFEAR_P2P: fn = huber ? register_kernel<4, CFEAR_P2P, CFEAR_LOSS_HUBER> : register_kernel<4, CFEAR_P2P, -1>; break;
-    case CFEAR_P2L: fn = huber ? register_kernel<4, CFEAR_P2L, CFEAR_LOSS_HUBER> : register_kernel<4, CFEAR_P2L, -1>; break;
-    default: fn = huber ? register_kernel<4, CFEAR_P2D, CFEAR_LOSS_HUBER> : register_kernel<4, CFEAR_P2D, -1>; break;
+    case CFEAR_P2P: fn = huber ? register_kernel<kRegNW, CFEAR_P2P, CFEAR_LOSS_HUBER> : register_kernel<kRegNW, CFEAR_P2P, -1>; break;
+    case CFEAR_P2L: fn = huber ? register_kernel<kRegNW, CFEAR_P2L, CFEAR_LOSS_HUBER> : register_kernel<kRegNW, CFEAR_P2L, -1>; break;
+    default: fn = huber ? register_kernel<kRegNW, CFEAR_P2D, CFEAR_LOSS_HUBER> : register_kernel<kRegNW, CFEAR_P2D, -1>; break;
   }
   CFEAR_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   ProfScope ps(ctx, "register");
-  hipLaunchKernelGGL(fn, dim3(n_jobs), dim3(256), lds, ctx->stream, (const RegJob*)d_jobs, cm);
+  hipLaunchKernelGGL(fn, dim3(n_jobs), dim3(kRegNW * 64), lds, ctx->stream, (const RegJob*)d_jobs, cm);
   CFEAR_HIP_CHECK(ctx, hipGetLastError());
   return CFEAR_OK;
 }
