@@ -175,6 +175,13 @@ __device__ __forceinline__ double dpp_f64(double v) {
   hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
   return __hiloint2double(hi, lo);
 }
+// DPP move with a bank mask: lanes of disabled banks (lane quads of each row) keep `old`.
+template <int CTRL, int BANK>
+__device__ __forceinline__ double dpp_sel_f64(double old, double src) {
+  const int lo = __builtin_amdgcn_update_dpp(__double2loint(old), __double2loint(src), CTRL, 0xf, BANK, false);
+  const int hi = __builtin_amdgcn_update_dpp(__double2hiint(old), __double2hiint(src), CTRL, 0xf, BANK, false);
+  return __hiloint2double(hi, lo);
+}
 __device__ __forceinline__ double row16_sum_f64(double v) {
   v += dpp_f64<0xB1>(v);    // quad_perm [1,0,3,2]
   v += dpp_f64<0x4E>(v);    // quad_perm [2,3,0,1]

@@ -196,7 +196,48 @@ __device__ __forceinline__ void block_reduce10(double v[10], double* part /*[2][
     return;
   }
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  double* buf = part + phase * (kRegMaxNW * 10);       // k-major: buf[k * NW + wave]
+  double* buf = part + phase * (kRegMaxNW * 10);
+  if (NW == 4) {
+    // Value-splitting butterfly inside each 16-lane DPP row: a step that pairs lanes l and P(l) lets
+    // one class of lanes keep value p and the other value q of a pair, so every step halves the
+    // number of live values (10 -> 5 -> 3, then two plain steps): 56 instructions instead of 180.
+    // bank_mask performs the class select (banks = lane quads): row_mirror splits on lane bit 3
+    // (banks 0,1 | 2,3), row_half_mirror on bit 2 (banks 0,2 | 1,3).
+    double v1[5];
+#pragma unroll
+    for (int j = 0; j < 5; j++)
+      v1[j] = dpp_sel_f64<0x140, 0x3>(v[j + 5], v[j]) + dpp_sel_f64<0x140, 0xC>(v[j], v[j + 5]);
+    double w0 = dpp_sel_f64<0x141, 0x5>(v1[1], v1[0]) + dpp_sel_f64<0x141, 0xA>(v1[0], v1[1]);
+    double w1 = dpp_sel_f64<0x141, 0x5>(v1[3], v1[2]) + dpp_sel_f64<0x141, 0xA>(v1[2], v1[3]);
+    double w2 = v1[4] + dpp_f64<0x141>(v1[4]);
+    w0 += dpp_f64<0x4E>(w0); w1 += dpp_f64<0x4E>(w1); w2 += dpp_f64<0x4E>(w2);
+    w0 += dpp_f64<0xB1>(w0); w1 += dpp_f64<0xB1>(w1); w2 += dpp_f64<0xB1>(w2);
+    // the quad with lane bits (b3, b2) now holds the row sums of k = b2 + 5 b3 (w0), 2 + b2 + 5 b3 (w1)
+    // and 4 + 5 b3 (w2); partial (k, wave, row) goes to buf[k * 16 + wave * 4 + row]
+    const int row = lane >> 4, b3 = (lane >> 3) & 1, b2 = (lane >> 2) & 1;
+    const int slot = wave * 4 + row;
+    if ((lane & 3) == 0) {
+      buf[(b2 + 5 * b3) * 16 + slot] = w0;
+      buf[(2 + b2 + 5 * b3) * 16 + slot] = w1;
+      if (b2 == 0) buf[(4 + 5 * b3) * 16 + slot] = w2;
+    }
+    __syncthreads();
+    if (ALL || wave == 0) {
+      // 16 partials per k = one DPP row per k: three registers cover the 160 partials; the totals are
+      // read back with readlane, so they are wave-uniform (scalar branches downstream)
+      double r[3];
+#pragma unroll
+      for (int q = 0; q < 3; q++) {
+        const int j = q * 64 + lane;
+        r[q] = row16_sum_f64(j < 160 ? buf[j] : 0.0);
+      }
+#pragma unroll
+      for (int k = 0; k < 10; k++) v[k] = readlane_f64(r[k / 4], (k % 4) * 16);
+    }
+    phase ^= 1;
+    return;
+  }
+  // generic NW: k-major buf[k * NW + wave]
 #pragma unroll
   for (int k = 0; k < 10; k++) {
     const double t = wave_sum_lane63_f64(v[k]);
@@ -205,8 +246,7 @@ __device__ __forceinline__ void block_reduce10(double v[10], double* part /*[2][
   __syncthreads();
   if (ALL || wave == 0) {
     // lane-parallel cross-wave sum: partial j = k * NW + wave sits in lane j % 64 of register j / 64;
-    // aligned groups of NW lanes are summed by a DPP butterfly (fixed order), totals read back by
-    // readlane so they are wave-uniform: every decision derived from them compiles to scalar branches.
+    // aligned groups of NW lanes are summed by a DPP butterfly (fixed order)
     constexpr int NR = (10 * NW + 63) / 64;
     double r[NR];
 #pragma unroll
