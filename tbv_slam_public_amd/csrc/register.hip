@@ -437,10 +437,9 @@ __device__ __forceinline__ void dense_bind(Dense& dn, double* base, int cap, int
 
 // cost, gradient and Gauss-Newton matrix of all correspondences at x (block-wide collective)
 template <int NW, int COST, int LOSS>
-__device__ void eval_all(const RegCommon& cm, const Dense& dn, const double x[3], double out[10], double* part, int& phase) {
+__device__ void eval_all(const RegCommon& cm, const Dense& dn, const double x[3], double c, double s, double out[10],
+                         double* part, int& phase) {
   REG_T0();
-  double s, c;
-  sincos(x[2], &s, &c);
   double acc[10];
 #pragma unroll
   for (int k = 0; k < 10; k++) acc[k] = 0.0;
@@ -772,7 +771,11 @@ __device__ void lm_solve(const RegCommon& cm, const Dense& dn, double x[3], int 
   int num_consecutive_invalid_steps = 0;
 
   double cur[10];                                        // cost, g, H at the accepted x
-  eval_all<NW, COST, LOSS>(cm, dn, x, cur, part, phase);
+  {
+    double s0, c0;
+    sincos(x[2], &s0, &c0);
+    eval_all<NW, COST, LOSS>(cm, dn, x, c0, s0, cur, part, phase);
+  }
   double x_cost = cur[0];
   double scale[3] = {1, 1, 1};
   double gradient_max_norm = 0, x_norm = 0, min_iter_cost = x_cost, it_cost = x_cost, it_rel = 0.0;
@@ -877,6 +880,11 @@ __device__ void lm_solve(const RegCommon& cm, const Dense& dn, double x[3], int 
         for (int k = 0; k < 3; k++) cand[k] = x[k] + step[k] * scale[k];
         break;
       }
+      if (!done) {                                       // the rotation of the next evaluation point, once per
+        double sn, cs;                                   // workgroup instead of once per wavefront
+        sincos(cand[2], &sn, &cs);
+        if (writer) { ctrl[10] = cs; ctrl[11] = sn; }
+      }
       if (writer) {
         ctrl[0] = cand[0]; ctrl[1] = cand[1]; ctrl[2] = cand[2];
         ((int*)(ctrl + 3))[0] = done;
@@ -886,7 +894,7 @@ __device__ void lm_solve(const RegCommon& cm, const Dense& dn, double x[3], int 
     done = __builtin_amdgcn_readfirstlane(((const int*)(ctrl + 3))[0]);
     if (done) break;
     cand[0] = ctrl[0]; cand[1] = ctrl[1]; cand[2] = ctrl[2];
-    eval_all<NW, COST, LOSS>(cm, dn, cand, cnd, part, phase);     // its barrier also protects ctrl
+    eval_all<NW, COST, LOSS>(cm, dn, cand, ctrl[10], ctrl[11], cnd, part, phase);   // its barrier also protects ctrl
     have_cnd = true;
   }
   // results of wavefront 0 -> every wavefront (the outer association loop is wave-uniform)
