@@ -376,9 +376,12 @@ template <int COST, int LOSS, bool WITH_JAC>
 __device__ __forceinline__ void eval_slot(const cfear_reg_params& par, double smx, double smy, double tmx, double tmy,
                                           double a0, double a1, double a2, double w, double tx, double ty, double c,
                                           double s, double acc[10]) {
-  const double sx = (c * smx + (-s) * smy) + tx;        // n_scan_normal.h:194-197
-  const double sy = (s * smx + c * smy) + ty;
-  const double dx = -s * smx - c * smy, dy = c * smx - s * smy;   // d(R s)/dtheta
+  // R s is shared by the transformed point and its derivative: -s smx - c smy == -(s smx + c smy) and
+  // c smx - s smy == c smx + (-s) smy bit for bit, so the reference's four expressions need two.
+  const double ru = c * smx + (-s) * smy, rv = s * smx + c * smy;
+  const double sx = ru + tx;                            // n_scan_normal.h:194-197
+  const double sy = rv + ty;
+  const double dx = -rv, dy = ru;                       // d(R s)/dtheta
   double r0, r1 = 0.0, j00, j01, j02, j10 = 0.0, j11 = 0.0, j12 = 0.0;
   if (COST == CFEAR_P2L) {                              // n_scan_normal.h:180-213
     const double v0 = sx - tmx, v1 = sy - tmy;
@@ -398,7 +401,16 @@ __device__ __forceinline__ void eval_slot(const cfear_reg_params& par, double sm
   double rho0, rho1;
   loss_eval(LOSS >= 0 ? LOSS : par.loss, par.loss_limit, w, sq, rho0, rho1);
   acc[0] = fma(0.5, rho0, acc[0]);
-  if (WITH_JAC) {
+  if (WITH_JAC && COST == CFEAR_P2P) {
+    // J = [-1 0 -dx; 0 -1 -dy]: the products with the constant entries are exact (x * -1, x * 0), so
+    // the generic accumulation below reduces to these terms; acc[5] (H01) stays exactly zero.
+    const double g0 = rho1 * r0, g1 = rho1 * r1;
+    acc[1] -= g0; acc[2] -= g1;
+    acc[3] = fma(j02, g0, acc[3]); acc[3] = fma(j12, g1, acc[3]);
+    const double h02 = rho1 * j02, h12 = rho1 * j12;
+    acc[4] += rho1; acc[6] = fma(-rho1, j02, acc[6]); acc[9] = fma(h02, j02, acc[9]);
+    acc[7] += rho1; acc[8] = fma(-rho1, j12, acc[8]); acc[9] = fma(h12, j12, acc[9]);
+  } else if (WITH_JAC) {
     // Corrector with alpha = 0 scales residual and Jacobian rows by sqrt(rho'); the normal equations
     // only need the products, (sqrt(rho') J)^T (sqrt(rho') r) = rho' J^T r, so no square root here.
     const double g0 = rho1 * r0;
