@@ -222,7 +222,7 @@ def main():
     if not args.no_cpu_baseline and world == 1:        # rank 0 at N=1 only
         from oracle import pyoracle as O
         n_seq = base.shape[0]
-        passes = 3 if not args.cpu_frames else 1          # ~10 s of single-thread CPU work at the defaults
+        passes = 5 if not args.cpu_frames else 1          # ~15 s of single-thread CPU work at the defaults
         budget_frames = args.cpu_frames or passes * n_seq * F
         reg = O.reg_params(cost="P2P", loss="Huber", loss_limit=0.1, weight_opt=4, regularization=0.0)
         done, compared, tc0 = 0, 0, time.perf_counter()
