@@ -238,6 +238,44 @@ int cfear_get_cost(cfear_ctx* ctx, const cfear_scan* const* scans, int32_t n_sca
                    const double* poses_xyt, const cfear_reg_params* par, double* cost,
                    double* residuals, int32_t cap, int32_t* n_residuals, double* score);
 
+/* GetCost for many (scan list, pose list) pairs in one launch (the 27 evaluations per registration of
+ * approximateCovarianceBySampling, CFEARQuality over candidate batches).  results[j]: final_cost = robust
+ * cost, score = cost / n_residuals, num_residuals, status (CFEAR_OK / CFEAR_ERR_TOO_FEW_RESIDUALS /
+ * CFEAR_ERR_CAPACITY); pose echoes the evaluated source pose.  par->itr selects the radius as above. */
+int cfear_get_cost_batch(cfear_ctx* ctx, const cfear_reg_job* jobs, int32_t n_jobs,
+                         const cfear_reg_params* par, cfear_reg_result* results);
+
+/* Covariance of a registration by cost sampling.  Replaces
+ * OdometryKeyframeFuser::approximateCovarianceBySampling (odometrykeyframefuser.cpp:261-380) and
+ * loopclosure::approximateCovarianceBySampling (tbv_slam/src/tbv_slam/loopclosure.cpp:99-208):
+ * samples_per_axis^3 GetCost evaluations on a (yaw, x, y) grid around the registered source pose (one
+ * kernel launch for all of them), quadratic least-squares fit, cov = 2 H^-1 * GetCovarianceScaler() *
+ * covariance_scaler embedded in a 6x6 (x, y, -, -, -, yaw).                                       */
+typedef struct cfear_cov_sampling_params {
+  double xy_range;                      /* cov_sampling_xy_range: samples span +- xy_range / 2        */
+  double yaw_range;                     /* cov_sampling_yaw_range                                     */
+  int32_t samples_per_axis;             /* cov_sampling_samples_per_axis (3)                          */
+  int32_t pad;
+  double covariance_scaler;             /* cov_sampling_covariance_scaler (4.0)                       */
+} cfear_cov_sampling_params;            /* 32 bytes */
+void cfear_cov_sampling_params_default(cfear_cov_sampling_params* p);   /* odometrykeyframefuser.h:107-110 */
+/* poses_xyt: the poses AFTER Register (T_vek); par: the registration parameters that produced them;
+ * reg: that Register's result (final_cost, num_residuals -> GetCovarianceScaler; outer_iters -> the
+ * radius GetCost uses).  cov36: row-major 6x6; samples (optional): [n^3][4] = x, y, yaw offset, cost in
+ * the reference's loop order (yaw outer, x, y inner).  *success = 1 when the fit is convex and the
+ * scaler defined (the reference then replaces reg_cov); otherwise cov36 holds Register's constant
+ * diag(0.01, 0.01, 0, 0, 0, 1e-4).                                                                  */
+int cfear_covariance_by_sampling(cfear_ctx* ctx, const cfear_scan* const* scans, int32_t n_scans,
+                                 const double* poses_xyt, const cfear_reg_params* par,
+                                 const cfear_reg_result* reg, const cfear_cov_sampling_params* sp,
+                                 double* cov36, double* samples, int32_t* success);
+/* Same for a batch (loop-closure candidates): regs [n_jobs], cov36 [n_jobs][36], samples (optional)
+ * [n_jobs][n^3][4], success [n_jobs].                                                               */
+int cfear_covariance_by_sampling_batch(cfear_ctx* ctx, const cfear_reg_job* jobs, int32_t n_jobs,
+                                       const cfear_reg_params* par, const cfear_reg_result* regs,
+                                       const cfear_cov_sampling_params* sp, double* cov36, double* samples,
+                                       int32_t* success);
+
 /* Ceres-compatible evaluation of one association set (what AddScanPairCost would hand to
  * ceres::Problem, n_scan_normal.cpp:264-318): prepare associates once at `poses_xyt`;
  * evaluate returns the RAW residuals r [n_res] and Jacobian J [n_res][3] (row-major, like
@@ -271,6 +309,9 @@ typedef struct cfear_odometry_params {
   int32_t weight_intensity, use_guess, compensate, radar_ccw, use_keyframe;
   int32_t pad;
   double min_keyframe_dist, min_keyframe_rot_deg, downsample_factor;
+  int32_t estimate_cov_by_sampling;     /* par.estimate_cov_by_sampling (false), odometrykeyframefuser.h:104 */
+  int32_t pad2;
+  cfear_cov_sampling_params cov_sampling;   /* cov_sampling_* (:107-110) */
 } cfear_odometry_params;
 void cfear_odometry_params_default(cfear_odometry_params* p);   /* CFEAR-3 preset, Oxford */
 
@@ -294,6 +335,12 @@ int cfear_odometry_process(cfear_odometry* od, const uint8_t* polar, cfear_frame
  * keyframe policy.  The next call must then pass that same pointer as `polar`.                   */
 int cfear_odometry_process_prefetch(cfear_odometry* od, const uint8_t* polar, const uint8_t* polar_next,
                                     cfear_frame_info* info);
+/* cov_current of every stream after the last processed frame (row-major 6x6, host [n_streams][36]):
+ * Identity before the first registration and after a failed one (FormatScans' initial value survives),
+ * Register's constant diag(0.01, 0.01, 0, 0, 0, 1e-4) otherwise, or the sampled covariance when
+ * estimate_cov_by_sampling is set and the fit succeeded (odometrykeyframefuser.cpp:196, 203-208).
+ * sampled (optional, [n_streams]) receives 1 where the sampled covariance was used.                */
+int cfear_odometry_get_covariance(cfear_odometry* od, double* cov, int32_t* sampled);
 int cfear_odometry_destroy(cfear_odometry* od);
 
 #ifdef __cplusplus

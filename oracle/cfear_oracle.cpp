@@ -904,6 +904,221 @@ extern "C" int orc_normal_eq(const orc_cell* const* scans, const int32_t* n_cell
 }
 
 // ==========================================================================================
+// covariance by cost sampling: OdometryKeyframeFuser::approximateCovarianceBySampling
+// (odometrykeyframefuser.cpp:261-380) == loopclosure::approximateCovarianceBySampling
+// (tbv_slam/src/tbv_slam/loopclosure.cpp:99-208, with its constants as arguments)
+// ==========================================================================================
+namespace {
+
+// linspace<double>(start, end, num)  (loopclosure.cpp:866-890)
+std::vector<double> linspace_ref(double start, double end, int num_in) {
+  std::vector<double> v;
+  const double num = (double)num_in;
+  if (num == 0) return v;
+  if (num == 1) { v.push_back(start); return v; }
+  const double delta = (end - start) / (num - 1);
+  for (int i = 0; i < num - 1; ++i) v.push_back(start + delta * i);
+  v.push_back(end);
+  return v;
+}
+
+// Minimum-norm least squares  argmin |A x - b|  (A: m x n, row-major) -- what Eigen's
+// A.bdcSvd(ComputeThinU | ComputeThinV).solve(b) returns.  Restated with a complete orthogonal
+// decomposition: Householder QR with column pivoting, numerical rank by the SVD-style threshold
+// min(m,n) * eps relative to the largest pivot, then a second Householder pass on R's rows so that
+// the basic solution becomes the minimum-norm one.  (Different algorithm than the product's Jacobi
+// SVD on purpose; tests pin both against numpy.linalg.lstsq.)
+std::vector<double> lstsq_min_norm(std::vector<double> A, std::vector<double> b, int m, int n) {
+  std::vector<int> perm(n);
+  for (int j = 0; j < n; j++) perm[j] = j;
+  const int kmax = std::min(m, n);
+  std::vector<double> colnorm(n);
+  int rank = 0;
+  double first_pivot = 0.0;
+  for (int k = 0; k < kmax; k++) {
+    int piv = k;
+    double best = -1.0;
+    for (int j = k; j < n; j++) {
+      double sq = 0.0;
+      for (int i = k; i < m; i++) sq += A[i * n + j] * A[i * n + j];
+      if (sq > best) { best = sq; piv = j; }
+    }
+    const double nrm = std::sqrt(std::max(best, 0.0));
+    if (k == 0) first_pivot = nrm;
+    if (!(nrm > first_pivot * (double)kmax * std::numeric_limits<double>::epsilon())) break;
+    if (piv != k) {
+      for (int i = 0; i < m; i++) std::swap(A[i * n + k], A[i * n + piv]);
+      std::swap(perm[k], perm[piv]);
+    }
+    // Householder vector for column k (rows k..m-1)
+    const double alpha = A[k * n + k] > 0 ? -nrm : nrm;
+    std::vector<double> v(m - k);
+    for (int i = k; i < m; i++) v[i - k] = A[i * n + k];
+    v[0] -= alpha;
+    double vv = 0.0;
+    for (double t : v) vv += t * t;
+    if (vv > 0.0) {
+      for (int j = k; j < n; j++) {
+        double dot = 0.0;
+        for (int i = k; i < m; i++) dot += v[i - k] * A[i * n + j];
+        const double f = 2.0 * dot / vv;
+        for (int i = k; i < m; i++) A[i * n + j] -= f * v[i - k];
+      }
+      double dot = 0.0;
+      for (int i = k; i < m; i++) dot += v[i - k] * b[i];
+      const double f = 2.0 * dot / vv;
+      for (int i = k; i < m; i++) b[i] -= f * v[i - k];
+    }
+    rank++;
+  }
+  // R = A[0:rank, 0:n] (upper trapezoidal), c = b[0:rank].  Reduce [R11 R12] to [T 0] from the right
+  // (Householder on rows, last to first) so that y = T^-1 c, x = Z^T [y; 0] has minimum norm.
+  const int r = rank;
+  std::vector<std::vector<double>> zv(r);          // Householder vectors acting on columns {k, r..n-1}
+  std::vector<double> zbeta(r, 0.0);
+  if (r < n) {
+    for (int k = r - 1; k >= 0; k--) {
+      // annihilate A[k, r..n-1] using column k
+      double sq = A[k * n + k] * A[k * n + k];
+      for (int j = r; j < n; j++) sq += A[k * n + j] * A[k * n + j];
+      const double nrm = std::sqrt(sq);
+      const double alpha = A[k * n + k] > 0 ? -nrm : nrm;
+      std::vector<double> v(1 + n - r);
+      v[0] = A[k * n + k] - alpha;
+      for (int j = r; j < n; j++) v[1 + j - r] = A[k * n + j];
+      double vv = 0.0;
+      for (double t : v) vv += t * t;
+      zv[k] = v;
+      zbeta[k] = vv > 0.0 ? 2.0 / vv : 0.0;
+      for (int i = 0; i <= k; i++) {               // apply to rows 0..k
+        double dot = v[0] * A[i * n + k];
+        for (int j = r; j < n; j++) dot += v[1 + j - r] * A[i * n + j];
+        const double f = zbeta[k] * dot;
+        A[i * n + k] -= f * v[0];
+        for (int j = r; j < n; j++) A[i * n + j] -= f * v[1 + j - r];
+      }
+    }
+  }
+  // back substitution with the r x r upper triangular T
+  std::vector<double> y(n, 0.0);
+  for (int i = r - 1; i >= 0; i--) {
+    double t = b[i];
+    for (int j = i + 1; j < r; j++) t -= A[i * n + j] * y[j];
+    y[i] = t / A[i * n + i];
+  }
+  if (r < n) {                                     // x_p = Z^T y : reflectors in reverse order of creation
+    for (int k = 0; k < r; k++) {
+      const std::vector<double>& v = zv[k];
+      double dot = v[0] * y[k];
+      for (int j = r; j < n; j++) dot += v[1 + j - r] * y[j];
+      const double f = zbeta[k] * dot;
+      y[k] -= f * v[0];
+      for (int j = r; j < n; j++) y[j] -= f * v[1 + j - r];
+    }
+  }
+  std::vector<double> x(n, 0.0);
+  for (int j = 0; j < n; j++) x[perm[j]] = y[j];
+  return x;
+}
+
+// eigenvalues of a symmetric 3x3 matrix, ascending (Eigen::SelfAdjointEigenSolver<Matrix3d>::eigenvalues());
+// closed form (trigonometric), only the signs are consumed by the caller.
+void sym3_eigenvalues(const double H[9], double ev[3]) {
+  const double a = H[0], b = H[4], c = H[8], d = H[1], e = H[5], f = H[2];
+  const double p1 = d * d + e * e + f * f;
+  if (p1 == 0.0) {
+    ev[0] = a; ev[1] = b; ev[2] = c;
+    std::sort(ev, ev + 3);
+    return;
+  }
+  const double q = (a + b + c) / 3.0;
+  const double p2 = (a - q) * (a - q) + (b - q) * (b - q) + (c - q) * (c - q) + 2.0 * p1;
+  const double p = std::sqrt(p2 / 6.0);
+  const double B[9] = {(a - q) / p, d / p, f / p, d / p, (b - q) / p, e / p, f / p, e / p, (c - q) / p};
+  const double detB = B[0] * (B[4] * B[8] - B[5] * B[7]) - B[1] * (B[3] * B[8] - B[5] * B[6]) +
+                      B[2] * (B[3] * B[7] - B[4] * B[6]);
+  double r = detB / 2.0;
+  r = std::min(1.0, std::max(-1.0, r));
+  const double phi = std::acos(r) / 3.0;
+  const double e1 = q + 2.0 * p * std::cos(phi);
+  const double e3 = q + 2.0 * p * std::cos(phi + 2.0 * M_PI / 3.0);
+  const double e2 = 3.0 * q - e1 - e3;
+  ev[0] = e3; ev[1] = e2; ev[2] = e1;
+}
+
+}  // namespace
+
+// Returns 1 when the sampled covariance is valid (cov36 filled, row-major 6x6), else 0.
+// par->first_itr must hold the registration object's leftover itr_ (GetCost picks its radius
+// from it, n_scan_normal.cpp:220); final_cost / num_residuals are summary_.final_cost and
+// summary_.num_residuals_reduced of the Register call that produced `poses_xyt`
+// (GetCovarianceScaler, n_scan_normal.cpp:433-439; num_parameters_reduced = 3).
+extern "C" int orc_cov_by_sampling(const orc_cell* const* scans, const int32_t* n_cells, int n_scans,
+                                   const double* poses_xyt, const orc_reg_params* par, double final_cost,
+                                   int32_t num_residuals, double xy_range, double yaw_range,
+                                   int32_t samples_per_axis, double covariance_scaler, double* cov36,
+                                   double* samples_out /* [n^3][4] x, y, yaw, cost; may be null */) {
+  std::vector<double> T_copy(poses_xyt, poses_xyt + 3 * n_scans);
+  const double* best = poses_xyt + 3 * (n_scans - 1);
+  const double xy_sample_range = xy_range * 0.5, theta_range = yaw_range * 0.5;          // :276-277
+  const int n = samples_per_axis, m = n * n * n;
+  const std::vector<double> xy_samples = linspace_ref(-xy_sample_range, xy_sample_range, n);
+  const std::vector<double> theta_samples = linspace_ref(-theta_range, theta_range, n);
+  std::vector<double> sx(m), sy(m), syaw(m), sc(m);
+  double sample_cost = 0;                                                                 // :282
+  int vp = 0;
+  for (int t = 0; t < n; t++)                                                             // :294-316
+    for (int ix = 0; ix < n; ix++)
+      for (int iy = 0; iy < n; iy++) {
+        double* last = T_copy.data() + 3 * (n_scans - 1);
+        last[0] = xy_samples[ix] + best[0];
+        last[1] = xy_samples[iy] + best[1];
+        last[2] = theta_samples[t] + best[2];          // AngleAxis(theta, z) * R(best): yaw angles add
+        double c = 0, score = 0;
+        int32_t nres = 0;
+        if (orc_get_cost(scans, n_cells, n_scans, T_copy.data(), par, &c, nullptr, &nres, &score))
+          sample_cost = c;                             // a failed GetCost leaves sample_cost untouched
+        sx[vp] = xy_samples[ix]; sy[vp] = xy_samples[iy]; syaw[vp] = theta_samples[t]; sc[vp] = sample_cost;
+        vp++;
+      }
+  if (samples_out)
+    for (int i = 0; i < m; i++) {
+      samples_out[4 * i] = sx[i]; samples_out[4 * i + 1] = sy[i]; samples_out[4 * i + 2] = syaw[i];
+      samples_out[4 * i + 3] = sc[i];
+    }
+  // f = a x^2 + b y^2 + c z^2 + d xy + e yz + f zx + g x + h y + i z + j   (:321-337)
+  std::vector<double> A((size_t)m * 10);
+  for (int i = 0; i < m; i++) {
+    double* r = A.data() + (size_t)i * 10;
+    r[0] = sx[i] * sx[i]; r[1] = sy[i] * sy[i]; r[2] = syaw[i] * syaw[i];
+    r[3] = sx[i] * sy[i]; r[4] = sy[i] * syaw[i]; r[5] = syaw[i] * sx[i];
+    r[6] = sx[i]; r[7] = sy[i]; r[8] = syaw[i]; r[9] = 1.0;
+  }
+  const std::vector<double> q = lstsq_min_norm(A, sc, m, 10);
+  const double H[9] = {2 * q[0], q[3], q[5], q[3], 2 * q[1], q[4], q[5], q[4], 2 * q[2]};   // :340-343
+  double ev[3];
+  sym3_eigenvalues(H, ev);
+  if (!(ev[0] == ev[0]) || ev[0] <= 0.0 || ev[1] <= 0.0 || ev[2] <= 0.0) return 0;        // :355-358
+  if (num_residuals - 3 == 0) return 0;                                                   // GetCovarianceScaler
+  const double score_scale = final_cost / (double)(num_residuals - 3);
+  // covariance_3x3 = 2.0 * hessian.inverse() * score_scale * scaler  (:365)
+  const double det = H[0] * (H[4] * H[8] - H[5] * H[7]) - H[1] * (H[3] * H[8] - H[5] * H[6]) +
+                     H[2] * (H[3] * H[7] - H[4] * H[6]);
+  double inv[9];
+  inv[0] = (H[4] * H[8] - H[5] * H[7]) / det; inv[1] = (H[2] * H[7] - H[1] * H[8]) / det; inv[2] = (H[1] * H[5] - H[2] * H[4]) / det;
+  inv[3] = (H[5] * H[6] - H[3] * H[8]) / det; inv[4] = (H[0] * H[8] - H[2] * H[6]) / det; inv[5] = (H[2] * H[3] - H[0] * H[5]) / det;
+  inv[6] = (H[3] * H[7] - H[4] * H[6]) / det; inv[7] = (H[1] * H[6] - H[0] * H[7]) / det; inv[8] = (H[0] * H[4] - H[1] * H[3]) / det;
+  double c3[9];
+  for (int k = 0; k < 9; k++) c3[k] = 2.0 * inv[k] * score_scale * covariance_scaler;
+  for (int k = 0; k < 36; k++) cov36[k] = 0.0;                                             // :368-374
+  for (int k = 0; k < 6; k++) cov36[k * 6 + k] = 1.0;
+  cov36[0] = c3[0]; cov36[1] = c3[1]; cov36[6] = c3[3]; cov36[7] = c3[4];
+  cov36[35] = c3[8];
+  cov36[5] = c3[2]; cov36[11] = c3[5]; cov36[30] = c3[6]; cov36[31] = c3[7];
+  return 1;
+}
+
+// ==========================================================================================
 // caller: OdometryKeyframeFuser  (odometrykeyframefuser.cpp:62-94, 143-259, 470-494)
 // ==========================================================================================
 struct orc_fuser {
@@ -911,13 +1126,20 @@ struct orc_fuser {
   Aff2 T_prev, Tmot, Tcurrent;
   struct Keyframe { Aff2 pose; std::vector<orc_cell> cells; };
   std::vector<Keyframe> keyframes;
+  double cov_current[36];
+  int cov_sampled = 0;
 };
 
 extern "C" orc_fuser* orc_fuser_create(const orc_fuser_params* p) {
   orc_fuser* f = new orc_fuser();
   f->par = *p;
   f->T_prev = f->Tmot = f->Tcurrent = aff_identity();                       // :35-39
+  for (int k = 0; k < 36; k++) f->cov_current[k] = (k % 7 == 0) ? 1.0 : 0.0;   // cov_current = Identity (:36)
   return f;
+}
+extern "C" void orc_fuser_last_cov(const orc_fuser* f, double cov36[36], int32_t* sampled) {
+  std::memcpy(cov36, f->cov_current, sizeof(f->cov_current));
+  if (sampled) *sampled = f->cov_sampled;
 }
 extern "C" void orc_fuser_destroy(orc_fuser* f) { delete f; }
 
@@ -960,6 +1182,22 @@ extern "C" int orc_fuser_process(orc_fuser* f, float* xyzi, int n, double pose_o
   orc_reg_result rr;
   orc_register(scans.data(), ncells.data(), ns, poses.data(), &par.reg, &rr);   // :186 (result shadowed)
   info[2] = rr.status; info[3] = rr.outer_iters;
+  // cov_current = cov_vek.back() (:196): Register's constant diagonal on success (n_scan_normal.cpp:171-175),
+  // FormatScans' Identity66 otherwise; replaced by the sampled covariance when enabled and valid (:203-208)
+  for (int k = 0; k < 36; k++) f->cov_current[k] = 0.0;
+  if (rr.status) { f->cov_current[0] = 0.1 * 0.1; f->cov_current[7] = 0.1 * 0.1; f->cov_current[35] = 0.01 * 0.01; }
+  else for (int k = 0; k < 6; k++) f->cov_current[k * 7] = 1.0;
+  f->cov_sampled = 0;
+  if (par.estimate_cov_by_sampling) {
+    orc_reg_params gp = par.reg;
+    gp.first_itr = rr.outer_iters;                                          // GetCost sees the leftover itr_
+    double c36[36];
+    if (orc_cov_by_sampling(scans.data(), ncells.data(), ns, poses.data(), &gp, rr.final_cost, rr.num_residuals,
+                            par.cov_xy_range, par.cov_yaw_range, par.cov_samples_per_axis, par.cov_scaler, c36, nullptr)) {
+      std::memcpy(f->cov_current, c36, sizeof(c36));
+      f->cov_sampled = 1;
+    }
+  }
   // Tcurrent = T_vek.back(): Register rewrites Tsrc from the parameters via vectorToAffine3d
   // whenever a solve was usable; if nothing was solved the guess is kept as given.
   Aff2 Tcurrent = aff_from_xyt(poses[3 * (ns - 1)], poses[3 * (ns - 1) + 1], poses[3 * (ns - 1) + 2]);

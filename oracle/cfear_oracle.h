@@ -105,6 +105,16 @@ int orc_normal_eq(const orc_cell* const* scans, const int32_t* n_cells, int n_sc
                   const double* poses_xyt, const orc_reg_params* par, int itr, const double x[3],
                   double H[9], double g[3], double* cost, int32_t* n_res);
 
+/* Covariance by cost sampling (odometrykeyframefuser.cpp:261-380, loopclosure.cpp:99-208): n^3
+ * GetCost samples around the registered pose, quadratic least-squares fit, 2 H^-1 scaled by
+ * GetCovarianceScaler.  par->first_itr = leftover itr_; final_cost / num_residuals from the
+ * Register summary.  cov36 row-major 6x6; samples_out [n^3][4] optional.  Returns 1 = valid. */
+int orc_cov_by_sampling(const orc_cell* const* scans, const int32_t* n_cells, int n_scans,
+                        const double* poses_xyt, const orc_reg_params* par, double final_cost,
+                        int32_t num_residuals, double xy_range, double yaw_range,
+                        int32_t samples_per_axis, double covariance_scaler, double* cov36,
+                        double* samples_out);
+
 /* ---- caller: OdometryKeyframeFuser (odometrykeyframefuser.cpp:62-94,143-259,470-494) ----- */
 typedef struct orc_fuser_params {
   orc_reg_params reg;
@@ -113,10 +123,15 @@ typedef struct orc_fuser_params {
   int32_t weight_intensity, use_guess, compensate, radar_ccw, use_keyframe;
   double min_keyframe_dist, min_keyframe_rot_deg;
   double downsample_factor;
+  int32_t estimate_cov_by_sampling;  /* par.estimate_cov_by_sampling (odometrykeyframefuser.h:104)      */
+  int32_t cov_samples_per_axis;      /* :109 */
+  double cov_xy_range, cov_yaw_range, cov_scaler;   /* :107, :108, :110 */
 } orc_fuser_params;
 typedef struct orc_fuser orc_fuser;
 orc_fuser* orc_fuser_create(const orc_fuser_params* p);
 void orc_fuser_destroy(orc_fuser* f);
+/* cov_current after the last processed frame (row-major 6x6); *sampled = 1 if it is the sampled one. */
+void orc_fuser_last_cov(const orc_fuser* f, double cov36[36], int32_t* sampled);
 /* Feeds one filtered cloud (modified in place by compensation).  pose_out = Tcurrent (x,y,th).
  * info[0]=n_cells, info[1]=keyframe added, info[2]=register status, info[3]=outer iters.   */
 int orc_fuser_process(orc_fuser* f, float* xyzi, int n, double pose_out[3], int32_t info[4]);

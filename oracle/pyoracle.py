@@ -49,7 +49,9 @@ class OrcFuserParams(C.Structure):
                 ("weight_intensity", C.c_int32), ("use_guess", C.c_int32),
                 ("compensate", C.c_int32), ("radar_ccw", C.c_int32), ("use_keyframe", C.c_int32),
                 ("min_keyframe_dist", C.c_double), ("min_keyframe_rot_deg", C.c_double),
-                ("downsample_factor", C.c_double)]
+                ("downsample_factor", C.c_double),
+                ("estimate_cov_by_sampling", C.c_int32), ("cov_samples_per_axis", C.c_int32),
+                ("cov_xy_range", C.c_double), ("cov_yaw_range", C.c_double), ("cov_scaler", C.c_double)]
 
 
 def reg_params(cost="P2L", loss="Huber", loss_limit=0.1, weight_opt=0, max_outer=8, max_inner=20,
@@ -93,6 +95,8 @@ def lib():
         pp = C.POINTER(C.c_void_p)
         L.orc_register.argtypes = [pp, i32p, C.c_int, f64p, C.POINTER(OrcRegParams), C.POINTER(OrcRegResult)]
         L.orc_get_cost.argtypes = [pp, i32p, C.c_int, f64p, C.POINTER(OrcRegParams), f64p, f64p, i32p, f64p]
+        L.orc_cov_by_sampling.argtypes = [pp, i32p, C.c_int, f64p, C.POINTER(OrcRegParams), C.c_double, C.c_int32,
+                                          C.c_double, C.c_double, C.c_int32, C.c_double, f64p, f64p]
         L.orc_associate.argtypes = [pp, i32p, C.c_int, f64p, C.POINTER(OrcRegParams), C.c_int, i32p, f64p, C.c_int]
         L.orc_normal_eq.argtypes = [pp, i32p, C.c_int, f64p, C.POINTER(OrcRegParams), C.c_int, f64p,
                                     f64p, f64p, f64p, i32p]
@@ -101,6 +105,8 @@ def lib():
         L.orc_fuser_destroy.argtypes = [C.c_void_p]
         L.orc_fuser_destroy.restype = None
         L.orc_fuser_process.argtypes = [C.c_void_p, f32p, C.c_int, f64p, i32p]
+        L.orc_fuser_last_cov.argtypes = [C.c_void_p, f64p, i32p]
+        L.orc_fuser_last_cov.restype = None
         _LIB = L
     return _LIB
 
@@ -205,6 +211,21 @@ def get_cost(scans, poses, par):
     return bool(ok), cost.value, r[:nres.value].copy(), score.value
 
 
+def cov_by_sampling(scans, poses, par, final_cost, num_residuals, xy_range=0.4, yaw_range=0.0043625,
+                    samples_per_axis=3, covariance_scaler=4.0):
+    """odometrykeyframefuser.cpp:261-380.  par.first_itr must be the leftover itr_ of the Register call.
+    -> (success, cov 6x6, samples [n^3, 4])."""
+    keep, ptrs, n = _scan_args(scans)
+    p = np.ascontiguousarray(poses, dtype=np.float64).copy()
+    cov = np.zeros((6, 6), np.float64)
+    smp = np.zeros((samples_per_axis ** 3, 4), np.float64)
+    ok = lib().orc_cov_by_sampling(ptrs, _p(n, C.c_int32), len(keep), _p(p, C.c_double), C.byref(par),
+                                   float(final_cost), int(num_residuals), float(xy_range), float(yaw_range),
+                                   int(samples_per_axis), float(covariance_scaler), _p(cov, C.c_double),
+                                   _p(smp, C.c_double))
+    return bool(ok), cov, smp
+
+
 def associate(scans, poses, par, itr):
     keep, ptrs, n = _scan_args(scans)
     p = np.ascontiguousarray(poses, dtype=np.float64).copy()
@@ -235,7 +256,8 @@ class Fuser:
 
     def __init__(self, reg, res=3.0, submap_scan_size=4, weight_intensity=True, use_guess=True,
                  compensate=True, radar_ccw=False, use_keyframe=True, min_keyframe_dist=1.5,
-                 min_keyframe_rot_deg=5.0, downsample_factor=1.0):
+                 min_keyframe_rot_deg=5.0, downsample_factor=1.0, estimate_cov_by_sampling=False,
+                 cov_xy_range=0.4, cov_yaw_range=0.0043625, cov_samples_per_axis=3, cov_scaler=4.0):
         p = OrcFuserParams()
         p.reg = reg
         p.res = res
@@ -244,6 +266,8 @@ class Fuser:
         p.radar_ccw, p.use_keyframe = int(radar_ccw), int(use_keyframe)
         p.min_keyframe_dist, p.min_keyframe_rot_deg = min_keyframe_dist, min_keyframe_rot_deg
         p.downsample_factor = downsample_factor
+        p.estimate_cov_by_sampling, p.cov_samples_per_axis = int(estimate_cov_by_sampling), int(cov_samples_per_axis)
+        p.cov_xy_range, p.cov_yaw_range, p.cov_scaler = cov_xy_range, cov_yaw_range, cov_scaler
         self._h = lib().orc_fuser_create(C.byref(p))
 
     def process(self, xyzi):
@@ -254,6 +278,13 @@ class Fuser:
                                      _p(info, C.c_int32))
         assert rc == 0
         return pose, info
+
+    def last_cov(self):
+        """cov_current after the last frame -> (cov 6x6, sampled flag)."""
+        cov = np.zeros((6, 6), np.float64)
+        flag = C.c_int32()
+        lib().orc_fuser_last_cov(self._h, _p(cov, C.c_double), C.byref(flag))
+        return cov, bool(flag.value)
 
     def __del__(self):
         if getattr(self, "_h", None):

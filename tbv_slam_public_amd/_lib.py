@@ -92,13 +92,19 @@ class RegJob(C.Structure):
                 ("poses_xyt", C.POINTER(C.c_double))]
 
 
+class CovSamplingParams(C.Structure):
+    _fields_ = [("xy_range", C.c_double), ("yaw_range", C.c_double), ("samples_per_axis", C.c_int32),
+                ("pad", C.c_int32), ("covariance_scaler", C.c_double)]
+
+
 class OdometryParams(C.Structure):
     _fields_ = [("filter_type", C.c_int32), ("kstrong", KStrongParams), ("cacfar", CacfarParams),
                 ("reg", RegParams), ("res", C.c_float), ("submap_scan_size", C.c_int32),
                 ("weight_intensity", C.c_int32), ("use_guess", C.c_int32), ("compensate", C.c_int32),
                 ("radar_ccw", C.c_int32), ("use_keyframe", C.c_int32), ("pad", C.c_int32),
                 ("min_keyframe_dist", C.c_double), ("min_keyframe_rot_deg", C.c_double),
-                ("downsample_factor", C.c_double)]
+                ("downsample_factor", C.c_double), ("estimate_cov_by_sampling", C.c_int32), ("pad2", C.c_int32),
+                ("cov_sampling", CovSamplingParams)]
 
 
 class FrameInfo(C.Structure):
@@ -119,10 +125,12 @@ EXPORTS = [
     "cfear_filter_kstrongest", "cfear_filter_cacfar", "cfear_compensate", "cfear_scan_create",
     "cfear_scan_from_cells", "cfear_scan_size", "cfear_scan_get_cells", "cfear_scan_destroy",
     "cfear_reg_params_default", "cfear_register", "cfear_register_batch", "cfear_get_cost",
+    "cfear_get_cost_batch", "cfear_cov_sampling_params_default", "cfear_covariance_by_sampling",
+    "cfear_covariance_by_sampling_batch",
     "cfear_cost_prepare", "cfear_cost_num_blocks", "cfear_cost_num_residuals", "cfear_cost_get_blocks",
     "cfear_cost_evaluate", "cfear_cost_normal_eq", "cfear_cost_destroy",
     "cfear_odometry_params_default", "cfear_odometry_create", "cfear_odometry_process",
-    "cfear_odometry_process_prefetch", "cfear_odometry_destroy",
+    "cfear_odometry_process_prefetch", "cfear_odometry_get_covariance", "cfear_odometry_destroy",
 ]
 
 _LIB = None
@@ -170,6 +178,15 @@ def lib():
     L.cfear_register.argtypes = [vp, C.POINTER(vp), C.c_int32, C.POINTER(C.c_double),
                                  C.POINTER(RegParams), C.POINTER(RegResult)]
     L.cfear_register_batch.argtypes = [vp, C.POINTER(RegJob), C.c_int32, C.POINTER(RegParams), vp]
+    L.cfear_get_cost_batch.argtypes = [vp, C.POINTER(RegJob), C.c_int32, C.POINTER(RegParams), vp]
+    L.cfear_cov_sampling_params_default.argtypes = [C.POINTER(CovSamplingParams)]
+    L.cfear_cov_sampling_params_default.restype = None
+    L.cfear_covariance_by_sampling.argtypes = [vp, C.POINTER(vp), C.c_int32, C.POINTER(C.c_double),
+                                               C.POINTER(RegParams), C.POINTER(RegResult),
+                                               C.POINTER(CovSamplingParams), C.POINTER(C.c_double),
+                                               C.POINTER(C.c_double), C.POINTER(C.c_int32)]
+    L.cfear_covariance_by_sampling_batch.argtypes = [vp, C.POINTER(RegJob), C.c_int32, C.POINTER(RegParams), vp,
+                                                     C.POINTER(CovSamplingParams), vp, vp, vp]
     L.cfear_get_cost.argtypes = [vp, C.POINTER(vp), C.c_int32, C.POINTER(C.c_double), C.POINTER(RegParams),
                                  C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int32,
                                  C.POINTER(C.c_int32), C.POINTER(C.c_double)]
@@ -188,6 +205,7 @@ def lib():
                                         C.POINTER(vp)]
     L.cfear_odometry_process.argtypes = [vp, vp, vp]
     L.cfear_odometry_process_prefetch.argtypes = [vp, vp, vp, vp]
+    L.cfear_odometry_get_covariance.argtypes = [vp, vp, vp]
     L.cfear_odometry_destroy.argtypes = [vp]
     _LIB = L
     return L

@@ -348,6 +348,71 @@ class n_scan_normal_reg:
     def getScore(self):
         return self.score_
 
+    def GetCostBatch(self, jobs):
+        """GetCost for a list of (scans, Tsrc) in one launch -> RESULT_DTYPE array (final_cost = robust cost,
+        score, num_residuals, status).  The radius follows self.par.itr like GetCost."""
+        arr, n, _keep = jobs if isinstance(jobs, tuple) else self.PrepareBatch(jobs)
+        out = np.zeros(n, L.RESULT_DTYPE)
+        if n:
+            self.ctx.check(self.ctx._lib.cfear_get_cost_batch(self.ctx.h, arr, n, C.byref(self.par), out.ctypes.data))
+        return out
+
+    def GetCovarianceScaler(self):
+        """GetCovarianceScaler (n_scan_normal.cpp:433-439) of the last Register -> (ok, scale)."""
+        r = self.summary_
+        if r is None or r.num_residuals - 3 == 0:
+            return False, 1.0
+        return True, r.final_cost / (r.num_residuals - 3)
+
+    @staticmethod
+    def sampling_params(xy_range=0.4, yaw_range=0.0043625, samples_per_axis=3, covariance_scaler=4.0):
+        """OdometryKeyframeFuser::Parameters cov_sampling_* (odometrykeyframefuser.h:107-110); the loop-closure
+        copy uses xy_range=0.4, yaw_range=0.0044 (loopclosure.cpp:108-112)."""
+        sp = L.CovSamplingParams()
+        sp.xy_range, sp.yaw_range = float(xy_range), float(yaw_range)
+        sp.samples_per_axis, sp.covariance_scaler = int(samples_per_axis), float(covariance_scaler)
+        return sp
+
+    def approximateCovarianceBySampling(self, scans, T_vek, reg_result=None, sampling=None, want_samples=False):
+        """OdometryKeyframeFuser::approximateCovarianceBySampling (odometrykeyframefuser.cpp:261-380) /
+        loopclosure::approximateCovarianceBySampling (loopclosure.cpp:99-208).  T_vek: poses after Register;
+        reg_result: that Register's summary (defaults to this object's last one).
+        Returns (success, cov 6x6[, samples [n^3,4]])."""
+        res = reg_result if reg_result is not None else self.summary_
+        if res is None:
+            raise ValueError("approximateCovarianceBySampling needs the result of a Register call")
+        if not isinstance(res, L.RegResult):
+            r = L.RegResult()
+            for k in ("score", "final_cost", "num_residuals", "outer_iters", "lm_iters", "status"):
+                setattr(r, k, res[k].item() if hasattr(res[k], "item") else res[k])
+            res = r
+        sp = sampling or self.sampling_params()
+        p = np.ascontiguousarray(T_vek, dtype=np.float64)
+        cov = np.zeros((6, 6), np.float64)
+        m = sp.samples_per_axis ** 3
+        smp = np.zeros((m, 4), np.float64)
+        ok = C.c_int32()
+        rc = self.ctx._lib.cfear_covariance_by_sampling(
+            self.ctx.h, self._handles(scans), len(scans), p.ctypes.data_as(C.POINTER(C.c_double)), C.byref(self.par),
+            C.byref(res), C.byref(sp), cov.ctypes.data_as(C.POINTER(C.c_double)),
+            smp.ctypes.data_as(C.POINTER(C.c_double)), C.byref(ok))
+        self.ctx.check(rc)
+        return (bool(ok.value), cov, smp) if want_samples else (bool(ok.value), cov)
+
+    def approximateCovarianceBySamplingBatch(self, jobs, reg_results, sampling=None):
+        """Batch form: jobs as for RegisterBatch (poses AFTER registration), reg_results the RESULT_DTYPE array
+        RegisterBatch returned.  -> (success [n] bool, cov [n,6,6])."""
+        arr, n, _keep = jobs if isinstance(jobs, tuple) else self.PrepareBatch(jobs)
+        sp = sampling or self.sampling_params()
+        regs = np.ascontiguousarray(reg_results, dtype=L.RESULT_DTYPE)
+        cov = np.zeros((n, 6, 6), np.float64)
+        ok = np.zeros(n, np.int32)
+        if n:
+            self.ctx.check(self.ctx._lib.cfear_covariance_by_sampling_batch(
+                self.ctx.h, arr, n, C.byref(self.par), regs.ctypes.data, C.byref(sp), cov.ctypes.data, None,
+                ok.ctypes.data))
+        return ok.astype(bool), cov
+
 
 class CeresCost:
     """cfear_cost: Ceres-compatible evaluation of one association set (n_scan_normal.cpp:264-318)."""
@@ -401,11 +466,12 @@ class CeresCost:
 # ------------------------------------------------------------------------------------------------
 def odometry_params(**kw):
     """cfear_odometry_params with the CFEAR-3 / Oxford preset; keyword overrides use the C field names
-    (nested: kstrong_k_strongest, cacfar_window_size, reg_cost, ...)."""
+    (nested: kstrong_k_strongest, cacfar_window_size, reg_cost, cov_sampling_xy_range, ...)."""
     p = L.OdometryParams()
     L.lib().cfear_odometry_params_default(C.byref(p))
     for k, v in kw.items():
-        for prefix, sub in (("kstrong_", p.kstrong), ("cacfar_", p.cacfar), ("reg_", p.reg)):
+        for prefix, sub in (("kstrong_", p.kstrong), ("cacfar_", p.cacfar), ("reg_", p.reg),
+                            ("cov_sampling_", p.cov_sampling)):
             if k.startswith(prefix) and hasattr(sub, k[len(prefix):]):
                 setattr(sub, k[len(prefix):], v)
                 break
@@ -441,6 +507,15 @@ class OdometryKeyframeFuser:
         self.ctx.check(self.ctx._lib.cfear_odometry_process_prefetch(self._h, _ptr(polar)[0], _ptr(polar_next)[0],
                                                                      self._info.ctypes.data))
         return self._info.copy()
+
+    def covariance(self):
+        """cov_current of every stream after the last frame -> (cov [n_streams,6,6], sampled [n_streams] bool):
+        Register's constant diagonal, Identity after a failed registration, or the sampled covariance when
+        par.estimate_cov_by_sampling is set (odometrykeyframefuser.cpp:196, 203-208)."""
+        cov = np.zeros((self.n_streams, 6, 6), np.float64)
+        flag = np.zeros(self.n_streams, np.int32)
+        self.ctx.check(self.ctx._lib.cfear_odometry_get_covariance(self._h, cov.ctypes.data, flag.ctypes.data))
+        return cov, flag.astype(bool)
 
     def close(self):
         if getattr(self, "_h", None):

@@ -124,8 +124,26 @@ size_t cfear_reg_job_bytes();
 int cfear_reg_max_scans();
 void cfear_reg_fill_job(void* dst, const ScanView* views, int n_scans, const double* poses_xyt);
 size_t cfear_register_scratch_bytes(int slots_cap);
+// Cost-only launches of the registration kernel (GetCost / cost sampling): n_samples = 0 evaluates each job
+// at its own source pose, n_samples = samples_per_axis^3 at the sampling grid around it; results then holds
+// max(n_samples, 1) records per job.  blocks_per_job workgroups share a job's samples (scratch: n_jobs x
+// blocks_per_job x cfear_register_scratch_bytes).
+struct RegCostMode {
+  int n_samples = 0, samples_per_axis = 0, blocks_per_job = 1;
+  double xy_half = 0.0, yaw_half = 0.0;
+  const cfear_reg_result* prior = nullptr;   // device, [n_jobs]: evaluate around prior[j].pose with itr = prior[j].outer_iters
+};
 int cfear_register_launch(cfear_ctx* ctx, const void* d_jobs, int n_jobs, const cfear_reg_params* par, int slots_cap,
-                          int lds_targets, char* d_scratch, cfear_reg_result* d_results);
+                          int lds_targets, char* d_scratch, cfear_reg_result* d_results, const RegCostMode* mode = nullptr);
+void cfear_reg_job_set_itr(void* job, int itr);
+// quadratic fit of the cost samples -> 6x6 covariance (covariance.hip, host)
+struct CovFit {
+  int n = 0, m = 0;
+  std::vector<double> offsets;   // [m][3] sample offsets (x, y, yaw) in the reference's loop order
+  std::vector<double> pinv;      // [10][m] pseudo-inverse of the design matrix
+  void prepare(int samples_per_axis, double xy_half, double yaw_half);
+  bool solve(const double* costs /*[m]*/, double score_scale, double covariance_scaler, double cov36[36]) const;
+};
 
 // ---------------------------------------------------------------------------------------------
 // device helpers

@@ -301,6 +301,8 @@ void cfear_odometry_params_default(cfear_odometry_params* p) {
   p->min_keyframe_dist = 1.5;
   p->min_keyframe_rot_deg = 5.0;
   p->downsample_factor = 1.0;
+  p->estimate_cov_by_sampling = 0;
+  cfear_cov_sampling_params_default(&p->cov_sampling);
 }
 
 int cfear_scan_size(const cfear_scan* scan) {

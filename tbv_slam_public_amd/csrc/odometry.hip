@@ -90,6 +90,12 @@ struct cfear_odometry {
   int32_t* h_status = nullptr;
   int32_t* h_npts = nullptr;
   int32_t* h_ncells = nullptr;
+  // covariance by cost sampling (optional): n^3 GetCost records per stream and the cached fit
+  cfear_reg_result* d_samples = nullptr;
+  cfear_reg_result* h_samples = nullptr;
+  CovFit fit;
+  std::vector<double> cov;             // [n_streams][36] cov_current
+  std::vector<int32_t> cov_sampled;    // [n_streams]
   std::vector<Stream> streams;
   std::vector<ScanView> views;         // [n_streams * slabs_per_stream]
 };
@@ -115,9 +121,9 @@ extern "C" int cfear_odometry_destroy(cfear_odometry* od) {
   (void)hipStreamSynchronize(od->ctx->stream);
   if (od->ev_results) (void)hipEventDestroy(od->ev_results);
   void* dev[] = {od->d_polar, od->d_sel, od->d_xyzi2[0], od->d_xyzi2[1], od->d_npts2[0], od->d_npts2[1], od->d_slabs, od->d_surf_jobs, od->d_reg_jobs,
-                 od->d_results, od->d_status, od->d_ncells, od->d_surf_scratch, od->d_reg_scratch};
+                 od->d_results, od->d_status, od->d_ncells, od->d_surf_scratch, od->d_reg_scratch, od->d_samples};
   for (void* p : dev) if (p) (void)hipFree(p);
-  void* host[] = {od->h_surf_jobs, od->h_reg_jobs, od->h_results, od->h_status, od->h_npts, od->h_ncells};
+  void* host[] = {od->h_surf_jobs, od->h_reg_jobs, od->h_results, od->h_status, od->h_npts, od->h_ncells, od->h_samples};
   for (void* p : host) if (p) (void)hipHostFree(p);
   delete od;
   return CFEAR_OK;
@@ -132,6 +138,8 @@ extern "C" int cfear_odometry_create(cfear_ctx* ctx, int32_t n_streams, const cf
   if (par->submap_scan_size < 1 || par->submap_scan_size + 1 > cfear_reg_max_scans())
     return cfear_set_error(ctx, CFEAR_ERR_INVALID_ARGUMENT, "submap_scan_size must be in [1,%d]", cfear_reg_max_scans() - 1);
   if (!(par->res > 0.05f)) return cfear_set_error(ctx, CFEAR_ERR_INVALID_ARGUMENT, "res must be > 0.05");   // odometrykeyframefuser.cpp:25
+  if (par->estimate_cov_by_sampling && (par->cov_sampling.samples_per_axis < 1 || par->cov_sampling.samples_per_axis > 15))
+    return cfear_set_error(ctx, CFEAR_ERR_INVALID_ARGUMENT, "cov_sampling.samples_per_axis must be in [1,15]");
   CFEAR_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   cfear_odometry* od = new cfear_odometry();
   od->ctx = ctx; od->n_streams = n_streams; od->desc = *desc; od->par = *par;
@@ -163,6 +171,15 @@ extern "C" int cfear_odometry_create(cfear_ctx* ctx, int32_t n_streams, const cf
   ok = ok && halloc(&od->h_status, (size_t)B * 4);
   ok = ok && halloc(&od->h_npts, (size_t)B * 4);
   ok = ok && halloc(&od->h_ncells, (size_t)B * 4);
+  if (par->estimate_cov_by_sampling) {
+    od->fit.prepare(par->cov_sampling.samples_per_axis, par->cov_sampling.xy_range * 0.5, par->cov_sampling.yaw_range * 0.5);
+    ok = ok && dalloc(&od->d_samples, (size_t)B * od->fit.m * sizeof(cfear_reg_result));
+    ok = ok && halloc(&od->h_samples, (size_t)B * od->fit.m * sizeof(cfear_reg_result));
+  }
+  od->cov.assign((size_t)B * 36, 0.0);
+  for (int b = 0; b < B; b++)
+    for (int k = 0; k < 6; k++) od->cov[(size_t)b * 36 + k * 7] = 1.0;       // cov_current = Identity (:36)
+  od->cov_sampled.assign(B, 0);
   if (!ok) { cfear_odometry_destroy(od); return cfear_set_error(ctx, CFEAR_ERR_HIP, "odometry buffers: allocation failed"); }
   od->streams.resize(B);
   od->views.resize((size_t)B * od->slabs_per_stream);
@@ -210,6 +227,13 @@ static int run_filter(cfear_odometry* od, const uint8_t* polar, int buf) {
   if (od->cap_points != rows * k)
     return cfear_set_error(ctx, CFEAR_ERR_CAPACITY, "rows*k = %d exceeds %d points per scan", rows * k, od->cap_points);
   return cfear_kstrong_device(ctx, d_polar, &dd, &kp, &o);
+}
+
+extern "C" int cfear_odometry_get_covariance(cfear_odometry* od, double* cov, int32_t* sampled) {
+  if (!od || !cov) return CFEAR_ERR_INVALID_ARGUMENT;
+  memcpy(cov, od->cov.data(), od->cov.size() * sizeof(double));
+  if (sampled) memcpy(sampled, od->cov_sampled.data(), od->cov_sampled.size() * sizeof(int32_t));
+  return CFEAR_OK;
 }
 
 extern "C" int cfear_odometry_process(cfear_odometry* od, const uint8_t* polar, cfear_frame_info* info) {
@@ -280,6 +304,23 @@ extern "C" int cfear_odometry_process_prefetch(cfear_odometry* od, const uint8_t
     if (rc != CFEAR_OK) return rc;
     CFEAR_HIP_CHECK(ctx, hipMemcpyAsync(od->h_results, od->d_results, (size_t)n_jobs * sizeof(cfear_reg_result),
                                         hipMemcpyDeviceToHost, ctx->stream));
+    if (par.estimate_cov_by_sampling) {
+      // approximateCovarianceBySampling (:203-208, 261-316): n^3 GetCost evaluations around the pose the
+      // registration just produced; pose and leftover itr_ are read from d_results on the device, so no host
+      // round trip separates the two launches.
+      RegCostMode mode;
+      mode.samples_per_axis = od->fit.n;
+      mode.n_samples = od->fit.m;
+      mode.xy_half = par.cov_sampling.xy_range * 0.5;
+      mode.yaw_half = par.cov_sampling.yaw_range * 0.5;
+      mode.blocks_per_job = 1;                                    // one workgroup per stream: its scratch is reused
+      mode.prior = od->d_results;
+      rc = cfear_register_launch(ctx, od->d_reg_jobs, n_jobs, &par.reg, par.submap_scan_size * od->cell_cap, od->cell_cap,
+                                 od->d_reg_scratch, od->d_samples, &mode);
+      if (rc != CFEAR_OK) return rc;
+      CFEAR_HIP_CHECK(ctx, hipMemcpyAsync(od->h_samples, od->d_samples, (size_t)n_jobs * od->fit.m * sizeof(cfear_reg_result),
+                                          hipMemcpyDeviceToHost, ctx->stream));
+    }
   }
   CFEAR_HIP_CHECK(ctx, hipMemcpyAsync(od->h_status, od->d_status, (size_t)B * 4, hipMemcpyDeviceToHost, ctx->stream));
   CFEAR_HIP_CHECK(ctx, hipMemcpyAsync(od->h_npts, od->d_npts, (size_t)B * 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -319,6 +360,28 @@ extern "C" int cfear_odometry_process_prefetch(cfear_odometry* od, const uint8_t
     }
     const cfear_reg_result& rr = od->h_results[st.job];
     fi.reg_status = rr.status; fi.outer_iters = rr.outer_iters; fi.lm_iters = rr.lm_iters; fi.score = rr.score;
+    {                                                             // cov_current = cov_vek.back() (:196)
+      double* cv = od->cov.data() + (size_t)b * 36;
+      for (int k = 0; k < 36; k++) cv[k] = 0.0;
+      if (rr.status == CFEAR_OK) { cv[0] = 0.1 * 0.1; cv[7] = 0.1 * 0.1; cv[35] = 0.01 * 0.01; }   // n_scan_normal.cpp:171-175
+      else for (int k = 0; k < 6; k++) cv[k * 7] = 1.0;          // FormatScans' Identity66 survives a failed Register
+      od->cov_sampled[b] = 0;
+      if (par.estimate_cov_by_sampling && rr.num_residuals - 3 != 0) {         // GetCovarianceScaler (:433-439)
+        const int m = od->fit.m;
+        std::vector<double> costs(m);
+        double sample_cost = 0.0;                                 // a failed GetCost keeps the previous value (:282, 307)
+        for (int s = 0; s < m; s++) {
+          const cfear_reg_result& sr = od->h_samples[(size_t)st.job * m + s];
+          if (sr.status == CFEAR_OK) sample_cost = sr.final_cost;
+          costs[s] = sample_cost;
+        }
+        double c36[36];
+        if (od->fit.solve(costs.data(), rr.final_cost / (double)(rr.num_residuals - 3), par.cov_sampling.covariance_scaler, c36)) {
+          memcpy(cv, c36, sizeof(c36));
+          od->cov_sampled[b] = 1;
+        }
+      }
+    }
     // Tcurrent = T_vek.back(): Register rewrites Tsrc via vectorToAffine3d (registration failures are
     // ignored by the reference: `bool success` is shadowed, odometrykeyframefuser.cpp:184-193)
     Aff2 Tcurrent = aff_from_xyt(rr.pose[0], rr.pose[1], rr.pose[2]);

@@ -41,7 +41,7 @@ constexpr int kMaxTargetsLds = 8192;         // float2 targets staged in LDS (64
 
 struct RegJob {
   int32_t n_scans;
-  int32_t pad;
+  int32_t itr;                                // cost-only launches: this job's leftover itr_ (0: use par.itr)
   ScanView scans[kMaxScans];
   double poses[kMaxScans][3];
 };
@@ -57,6 +57,14 @@ struct RegCommon {
   int32_t dense_fields;                       // doubles per correspondence (3 P2P, 5 P2L, 6 P2D) + one int32
   uint32_t lds_total;                         // dynamic LDS bytes of the launch
   cfear_reg_result* results;
+  // cost-only launches (GetCost / cost sampling): no solve; n_samples > 0 evaluates the samples_per_axis^3
+  // pose grid of approximateCovarianceBySampling around each job's source pose
+  int32_t cost_only;
+  int32_t n_samples;
+  int32_t samples_per_axis;
+  int32_t pad;
+  double xy_half, yaw_half;
+  const cfear_reg_result* prior;              // cost-only: source pose and itr_ come from these records (device)
 };
 
 __host__ __device__ inline size_t slots_bytes(int slots_cap) { return ((size_t)slots_cap * 52 + 255) / 256 * 256; }
@@ -945,6 +953,16 @@ __global__ __launch_bounds__(NW * 64) void register_kernel(const RegJob* __restr
   const int n_slots = last * n_src;
   double x[3] = {job.poses[last][0], job.poses[last][1], job.poses[last][2]};
   if (n_slots > cm.slots_cap || max_tar > cm.lds_targets) {
+    if (cm.cost_only) {
+      const int m = cm.n_samples > 0 ? cm.n_samples : 1;
+      for (int sidx = blockIdx.y * (int)blockDim.x + (int)threadIdx.x; sidx < m; sidx += (int)(gridDim.y * blockDim.x)) {
+        cfear_reg_result* r = cm.results + (size_t)blockIdx.x * m + sidx;
+        r->pose[0] = x[0]; r->pose[1] = x[1]; r->pose[2] = x[2];
+        r->score = 0; r->final_cost = 0; r->num_residuals = 0; r->outer_iters = 0; r->lm_iters = 0;
+        r->status = CFEAR_ERR_CAPACITY; r->last_relative_decrease = 0; r->reserved = 0;
+      }
+      return;
+    }
     if (threadIdx.x == 0) {
       res->pose[0] = x[0]; res->pose[1] = x[1]; res->pose[2] = x[2];
       res->score = 0; res->final_cost = 0; res->num_residuals = 0; res->outer_iters = 0; res->lm_iters = 0;
@@ -952,8 +970,9 @@ __global__ __launch_bounds__(NW * 64) void register_kernel(const RegJob* __restr
     }
     return;
   }
-  const Slots sl = slots_of(cm.scratch + (size_t)blockIdx.x * cm.scratch_stride, cm.slots_cap);
-  double* gl_dense = (double*)(cm.scratch + (size_t)blockIdx.x * cm.scratch_stride + slots_bytes(cm.slots_cap));
+  const size_t scr_idx = (size_t)blockIdx.x * gridDim.y + blockIdx.y;
+  const Slots sl = slots_of(cm.scratch + scr_idx * cm.scratch_stride, cm.slots_cap);
+  double* gl_dense = (double*)(cm.scratch + scr_idx * cm.scratch_stride + slots_bytes(cm.slots_cap));
   Dense dn;
   int phase = 0, iphase = 0;
   int sum_tar = 0;
@@ -964,6 +983,60 @@ __global__ __launch_bounds__(NW * 64) void register_kernel(const RegJob* __restr
   if (fused) fused_stage<NW>(job, fl);
   REG_TACC(6);
   const int rpb = cm.par.cost == CFEAR_P2L ? 1 : 2;
+  if (cm.cost_only) {
+    // n_scan_normal_reg::GetCost (n_scan_normal.cpp:186-211): one association pass (radius by the leftover
+    // itr_, :220) + the robust cost at the given pose; with n_samples > 0 once per pose of the sampling
+    // grid of approximateCovarianceBySampling (odometrykeyframefuser.cpp:287-303: theta outer, x, y inner).
+    int git = job.itr ? job.itr : cm.par.itr;
+    if (cm.prior) {                                      // sample around the pose a Register launch just produced
+      const cfear_reg_result& pr = cm.prior[blockIdx.x];
+      x[0] = pr.pose[0]; x[1] = pr.pose[1]; x[2] = pr.pose[2];
+      git = pr.outer_iters;
+    }
+    const int m = cm.n_samples > 0 ? cm.n_samples : 1;
+    for (int sidx = blockIdx.y; sidx < m; sidx += gridDim.y) {
+      double xs[3] = {x[0], x[1], x[2]};
+      if (cm.n_samples > 0) {
+        const int n = cm.samples_per_axis;
+        auto lin = [n](double half, int i) {             // linspace(-half, half, n)[i] (loopclosure.cpp:866-890)
+          if (n == 1) return -half;
+          const double delta = (half - (-half)) / ((double)n - 1.0);
+          return i < n - 1 ? -half + delta * (double)i : half;
+        };
+        xs[0] = lin(cm.xy_half, (sidx / n) % n) + x[0];
+        xs[1] = lin(cm.xy_half, sidx % n) + x[1];
+        xs[2] = lin(cm.yaw_half, sidx / (n * n)) + x[2];
+      }
+      int n_blocks;
+      if (fused) {
+        n_blocks = associate_fused<NW>(job, cm, xs, git, fl, gl_dense, dn, ipart, iphase);
+      } else {
+        const int mine = associate_all<NW>(job, cm, xs, git, sl, lt);
+        __threadfence_block();
+        n_blocks = compact_slots<NW>(job, cm, sl, n_slots, n_src, mine, lds_dense, gl_dense, dn, ipart, iphase);
+      }
+      const int nres = n_blocks * rpb;
+      double cur[10];
+#pragma unroll
+      for (int k = 0; k < 10; k++) cur[k] = 0.0;
+      if (nres > 1) {
+        double s0, c0;
+        sincos(xs[2], &s0, &c0);
+        eval_all<NW, COST, LOSS>(cm, dn, xs, c0, s0, cur, part, phase);
+      }
+      __syncthreads();                                   // the dense arrays are rewritten by the next sample
+      if (threadIdx.x == 0) {
+        cfear_reg_result* r = cm.results + (size_t)blockIdx.x * m + sidx;
+        r->pose[0] = xs[0]; r->pose[1] = xs[1]; r->pose[2] = xs[2];
+        r->final_cost = cur[0];
+        r->score = nres > 1 ? cur[0] / (double)nres : 0.0;                  // score_ (:209)
+        r->num_residuals = nres; r->outer_iters = git; r->lm_iters = 0;
+        r->status = nres > 1 ? CFEAR_OK : CFEAR_ERR_TOO_FEW_RESIDUALS;      // :200-203
+        r->last_relative_decrease = 0.0; r->reserved = 0.0;
+      }
+    }
+    return;
+  }
   // n_scan_normal.cpp:82-185
   double prev_par[3] = {x[0], x[1], x[2]};
   double prev_score = DBL_MAX;
@@ -1137,6 +1210,8 @@ int check_params(cfear_ctx* ctx, const cfear_reg_params* p) {
 size_t cfear_reg_job_bytes() { return sizeof(RegJob); }
 int cfear_reg_max_scans() { return kMaxScans; }
 
+void cfear_reg_job_set_itr(void* job, int itr) { ((RegJob*)job)->itr = itr; }
+
 void cfear_reg_fill_job(void* dst, const ScanView* views, int n_scans, const double* poses_xyt) {
   RegJob j;
   memset(&j, 0, sizeof(j));
@@ -1151,11 +1226,11 @@ void cfear_reg_fill_job(void* dst, const ScanView* views, int n_scans, const dou
 // Enqueues the batched registration kernel: d_jobs [n_jobs] RegJob records (device), d_results
 // [n_jobs] (device).  slots_cap bounds (n_scans-1)*n_src per job, lds_targets the largest target.
 int cfear_register_launch(cfear_ctx* ctx, const void* d_jobs, int n_jobs, const cfear_reg_params* par, int slots_cap,
-                          int lds_targets, char* d_scratch, cfear_reg_result* d_results) {
+                          int lds_targets, char* d_scratch, cfear_reg_result* d_results, const RegCostMode* mode) {
   if (lds_targets > kMaxTargetsLds)
     return cfear_set_error(ctx, CFEAR_ERR_CAPACITY, "target scan with more than %d cells", kMaxTargetsLds);
   if (lds_targets < 1) lds_targets = 1;
-  RegCommon cm;
+  RegCommon cm{};
   cm.par = *par;
   cm.angle_outlier = std::cos(M_PI / 6.0);                                     // n_scan_normal.cpp:217
   cm.scratch = d_scratch;
@@ -1164,6 +1239,13 @@ int cfear_register_launch(cfear_ctx* ctx, const void* d_jobs, int n_jobs, const 
   cm.lds_targets = (lds_targets + 3) & ~3;
   cm.dense_fields = reg_dense_fields(par->cost);
   cm.results = d_results;
+  cm.cost_only = mode ? 1 : 0;
+  cm.n_samples = mode ? mode->n_samples : 0;
+  cm.samples_per_axis = mode ? mode->samples_per_axis : 0;
+  cm.pad = 0;
+  cm.xy_half = mode ? mode->xy_half : 0.0;
+  cm.yaw_half = mode ? mode->yaw_half : 0.0;
+  cm.prior = mode ? mode->prior : nullptr;
   // Geometry: small batches get one 256-thread workgroup per registration (lowest latency, dense
   // correspondence arrays in LDS); large batches get one wavefront per registration (no barriers, no
   // LDS exchange, 4x more registrations in flight; dense arrays stay in L2).
@@ -1186,8 +1268,9 @@ int cfear_register_launch(cfear_ctx* ctx, const void* d_jobs, int n_jobs, const 
     default: fn = huber ? register_kernel<kRegNW, CFEAR_P2D, CFEAR_LOSS_HUBER> : register_kernel<kRegNW, CFEAR_P2D, -1>; break;
   }
   CFEAR_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-  ProfScope ps(ctx, "register");
-  hipLaunchKernelGGL(fn, dim3(n_jobs), dim3(kRegNW * 64), lds, ctx->stream, (const RegJob*)d_jobs, cm);
+  ProfScope ps(ctx, mode ? "get_cost" : "register");
+  hipLaunchKernelGGL(fn, dim3(n_jobs, mode ? std::max(mode->blocks_per_job, 1) : 1), dim3(kRegNW * 64), lds, ctx->stream,
+                     (const RegJob*)d_jobs, cm);
   CFEAR_HIP_CHECK(ctx, hipGetLastError());
   return CFEAR_OK;
 }
@@ -1262,6 +1345,133 @@ extern "C" int cfear_register(cfear_ctx* ctx, const cfear_scan* const* scans, in
   return result->status;
 }
 
+// ---- GetCost for batches and covariance by cost sampling ---------------------------------------------
+namespace {
+
+// Runs the cost-only kernel over `jobs`; out receives max(mode.n_samples, 1) records per job.
+// itrs (nullable) = per-job leftover itr_; otherwise par->itr applies to every job.
+int run_cost_batch(cfear_ctx* ctx, const cfear_reg_job* jobs, int n_jobs, const cfear_reg_params* par,
+                   const int32_t* itrs, RegCostMode mode, std::vector<cfear_reg_result>& out) {
+  int rc = check_params(ctx, par);
+  if (rc != CFEAR_OK) return rc;
+  const int m = mode.n_samples > 0 ? mode.n_samples : 1;
+  out.assign((size_t)n_jobs * m, cfear_reg_result{});
+  if (n_jobs == 0) return CFEAR_OK;
+  CFEAR_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  std::vector<unsigned char> hjobs((size_t)n_jobs * sizeof(RegJob));
+  JobSizes sz;
+  for (int j = 0; j < n_jobs; j++) {
+    unsigned char* dst = hjobs.data() + (size_t)j * sizeof(RegJob);
+    rc = gather_job(ctx, jobs[j].scans, jobs[j].n_scans, jobs[j].poses_xyt, dst, sz);
+    if (rc != CFEAR_OK) return rc;
+    if (itrs) cfear_reg_job_set_itr(dst, itrs[j]);
+  }
+  // a few workgroups per job when the batch alone cannot fill the GPU; scratch bounded to 1 GiB per launch
+  mode.blocks_per_job = std::max(1, std::min(m, (1024 + n_jobs - 1) / n_jobs));
+  const size_t per = reg_scratch_bytes(sz.slots_cap) * (size_t)mode.blocks_per_job;
+  const int chunk = (int)std::max<size_t>(1, std::min<size_t>((size_t)n_jobs, ((size_t)1 << 30) / per));
+  const size_t jb = hjobs.size(), rb = out.size() * sizeof(cfear_reg_result);
+  char* ws = (char*)cfear_workspace(ctx, 6, (jb + 255) / 256 * 256 + rb + 512);
+  char* scr = (char*)cfear_workspace(ctx, 7, per * (size_t)chunk);
+  if (!ws || !scr) return cfear_set_error(ctx, CFEAR_ERR_HIP, "workspace allocation failed");
+  char* d_jobs = ws;
+  cfear_reg_result* d_res = (cfear_reg_result*)(ws + (jb + 255) / 256 * 256);
+  CFEAR_HIP_CHECK(ctx, hipMemcpyAsync(d_jobs, hjobs.data(), jb, hipMemcpyHostToDevice, ctx->stream));
+  for (int j0 = 0; j0 < n_jobs; j0 += chunk) {
+    const int nj = std::min(chunk, n_jobs - j0);
+    rc = cfear_register_launch(ctx, d_jobs + (size_t)j0 * sizeof(RegJob), nj, par, sz.slots_cap, sz.lds_targets, scr,
+                               d_res + (size_t)j0 * m, &mode);
+    if (rc != CFEAR_OK) { (void)hipStreamSynchronize(ctx->stream); return rc; }
+  }
+  CFEAR_HIP_CHECK(ctx, hipMemcpyAsync(out.data(), d_res, rb, hipMemcpyDeviceToHost, ctx->stream));
+  CFEAR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  return CFEAR_OK;
+}
+
+}  // namespace
+
+extern "C" int cfear_get_cost_batch(cfear_ctx* ctx, const cfear_reg_job* jobs, int32_t n_jobs,
+                                    const cfear_reg_params* par, cfear_reg_result* results) {
+  if (!ctx) return CFEAR_ERR_INVALID_ARGUMENT;
+  if (!jobs || !results || n_jobs < 0) return cfear_set_error(ctx, CFEAR_ERR_INVALID_ARGUMENT, "null argument");
+  std::vector<cfear_reg_result> out;
+  const int rc = run_cost_batch(ctx, jobs, n_jobs, par, nullptr, RegCostMode{}, out);
+  if (rc != CFEAR_OK) return rc;
+  std::copy(out.begin(), out.end(), results);
+  return CFEAR_OK;
+}
+
+extern "C" void cfear_cov_sampling_params_default(cfear_cov_sampling_params* p) {
+  if (!p) return;
+  p->xy_range = 0.4;                  // odometrykeyframefuser.h:107 (loopclosure.cpp:108: +-0.2)
+  p->yaw_range = 0.0043625;           // :108 (loopclosure.cpp:109 uses +-0.0022)
+  p->samples_per_axis = 3;            // :109
+  p->pad = 0;
+  p->covariance_scaler = 4.0;         // :110
+}
+
+extern "C" int cfear_covariance_by_sampling_batch(cfear_ctx* ctx, const cfear_reg_job* jobs, int32_t n_jobs,
+                                                  const cfear_reg_params* par, const cfear_reg_result* regs,
+                                                  const cfear_cov_sampling_params* sp, double* cov36, double* samples,
+                                                  int32_t* success) {
+  if (!ctx) return CFEAR_ERR_INVALID_ARGUMENT;
+  if (!jobs || !regs || !sp || !cov36 || !success || n_jobs < 0)
+    return cfear_set_error(ctx, CFEAR_ERR_INVALID_ARGUMENT, "null argument");
+  const int n = sp->samples_per_axis;
+  if (n < 1 || n > 15) return cfear_set_error(ctx, CFEAR_ERR_INVALID_ARGUMENT, "samples_per_axis must be in [1,15]");
+  RegCostMode mode;
+  mode.samples_per_axis = n;
+  mode.n_samples = n * n * n;
+  mode.xy_half = sp->xy_range * 0.5;                       // odometrykeyframefuser.cpp:276-277
+  mode.yaw_half = sp->yaw_range * 0.5;
+  std::vector<int32_t> itrs(n_jobs);
+  for (int j = 0; j < n_jobs; j++) itrs[j] = regs[j].outer_iters;      // GetCost's radius follows the leftover itr_
+  std::vector<cfear_reg_result> out;
+  const int rc = run_cost_batch(ctx, jobs, n_jobs, par, itrs.data(), mode, out);
+  if (rc != CFEAR_OK) return rc;
+  const int m = mode.n_samples;
+  CovFit fit;
+  fit.prepare(n, mode.xy_half, mode.yaw_half);
+  std::vector<double> costs(m);
+  for (int j = 0; j < n_jobs; j++) {
+    double sample_cost = 0.0;                              // :282; a failed GetCost leaves the previous value (:307)
+    for (int s = 0; s < m; s++) {
+      const cfear_reg_result& r = out[(size_t)j * m + s];
+      if (r.status == CFEAR_OK) sample_cost = r.final_cost;
+      costs[s] = sample_cost;
+      if (samples) {
+        double* o = samples + ((size_t)j * m + s) * 4;
+        o[0] = fit.offsets[3 * (size_t)s]; o[1] = fit.offsets[3 * (size_t)s + 1]; o[2] = fit.offsets[3 * (size_t)s + 2];
+        o[3] = sample_cost;
+      }
+    }
+    // GetCovarianceScaler (n_scan_normal.cpp:433-439): final_cost / (num_residuals_reduced - num_parameters_reduced)
+    bool ok = regs[j].num_residuals - 3 != 0;
+    if (ok) {
+      const double score_scale = regs[j].final_cost / (double)(regs[j].num_residuals - 3);
+      ok = fit.solve(costs.data(), score_scale, sp->covariance_scaler, cov36 + (size_t)j * 36);
+    }
+    success[j] = ok ? 1 : 0;
+    if (!ok) {                                             // caller keeps Register's reg_cov (n_scan_normal.cpp:171-175)
+      double* c = cov36 + (size_t)j * 36;
+      for (int k = 0; k < 36; k++) c[k] = 0.0;
+      c[0] = 0.01; c[7] = 0.01; c[35] = 1e-4;
+    }
+  }
+  return CFEAR_OK;
+}
+
+extern "C" int cfear_covariance_by_sampling(cfear_ctx* ctx, const cfear_scan* const* scans, int32_t n_scans,
+                                            const double* poses_xyt, const cfear_reg_params* par,
+                                            const cfear_reg_result* reg, const cfear_cov_sampling_params* sp,
+                                            double* cov36, double* samples, int32_t* success) {
+  if (!ctx) return CFEAR_ERR_INVALID_ARGUMENT;
+  if (!scans || !poses_xyt) return cfear_set_error(ctx, CFEAR_ERR_INVALID_ARGUMENT, "null argument");
+  cfear_reg_job job;
+  job.scans = scans; job.n_scans = n_scans; job.pad = 0; job.poses_xyt = poses_xyt;
+  return cfear_covariance_by_sampling_batch(ctx, &job, 1, par, reg, sp, cov36, samples, success);
+}
+
 // ---- cfear_cost: one association set kept on the device -------------------------------------------
 struct cfear_cost {
   cfear_ctx* ctx;
@@ -1296,7 +1506,7 @@ extern "C" int cfear_cost_prepare(cfear_ctx* ctx, const cfear_scan* const* scans
   if (hipMalloc((void**)&c->d_scratch, reg_scratch_bytes(c->slots_cap)) != hipSuccess) return fail(CFEAR_ERR_HIP, "hipMalloc failed");
   if (hipMalloc((void**)&c->d_out, ((size_t)c->slots_cap * 10 + 16) * sizeof(double)) != hipSuccess) return fail(CFEAR_ERR_HIP, "hipMalloc failed");
   if (hipMemcpyAsync(c->d_job, hjob, sizeof(RegJob), hipMemcpyHostToDevice, ctx->stream) != hipSuccess) return fail(CFEAR_ERR_HIP, "memcpy failed");
-  RegCommon cm;
+  RegCommon cm{};
   cm.par = *par; cm.angle_outlier = std::cos(M_PI / 6.0);
   cm.scratch = c->d_scratch; cm.scratch_stride = reg_scratch_bytes(c->slots_cap);
   cm.slots_cap = c->slots_cap; cm.lds_targets = (c->lds_targets + 3) & ~3; cm.results = nullptr;
@@ -1337,7 +1547,7 @@ namespace {
 // blocks are ordered (target scan i, source cell s) exactly like AddScanPairCost builds them
 int run_eval(cfear_cost* c, const double x[3], bool want_raw) {
   cfear_ctx* ctx = c->ctx;
-  RegCommon cm;
+  RegCommon cm{};
   cm.par = c->par; cm.angle_outlier = 0; cm.scratch = c->d_scratch; cm.scratch_stride = 0;
   cm.slots_cap = c->slots_cap; cm.lds_targets = c->lds_targets; cm.results = nullptr;
   cm.dense_cap_lds = 0; cm.dense_fields = 0;

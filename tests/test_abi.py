@@ -28,6 +28,7 @@ def test_struct_sizes():
     assert C.sizeof(L.FrameInfo) == 56
     assert C.sizeof(L.PolarDesc) == 24
     assert C.sizeof(L.RegParams) == 72
+    assert C.sizeof(L.CovSamplingParams) == 32
 
 
 def test_defaults_follow_reference():
@@ -41,6 +42,10 @@ def test_defaults_follow_reference():
     lib.cfear_odometry_params_default(C.byref(o))
     # CFEAR-3 preset
     assert (o.kstrong.k_strongest, o.kstrong.z_min, o.res, o.submap_scan_size) == (40, 60.0, 3.0, 4)
+    # cost-sampling defaults (odometrykeyframefuser.h:104-110)
+    assert o.estimate_cov_by_sampling == 0
+    assert (o.cov_sampling.xy_range, o.cov_sampling.yaw_range, o.cov_sampling.samples_per_axis,
+            o.cov_sampling.covariance_scaler) == (0.4, 0.0043625, 3, 4.0)
     assert (o.reg.cost, o.reg.weight_opt, o.weight_intensity) == (L.P2P, 4, 1)
     assert lib.cfear_status_string(-4) == b"too few residuals"
 
