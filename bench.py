@@ -115,6 +115,9 @@ def main():
                          "a batch of candidate registrations from cached features, sharded over the ranks "
                          "with one RCCL all_gather of the result records per step")
     ap.add_argument("--candidates", type=int, default=4096)
+    ap.add_argument("--cov-sampling", action="store_true",
+                    help="odometry: also estimate every frame's covariance by cost sampling (27 GetCost per "
+                         "registration, odometrykeyframefuser.cpp:203-208; off in the reference's presets)")
     args = ap.parse_args()
     if args.workload == "loopclosure":
         return loopclosure_main(args)
@@ -152,7 +155,8 @@ def main():
 
     stream = torch.cuda.current_stream().cuda_stream
     ctx = api.Context(local_rank, stream=stream)
-    od = api.OdometryKeyframeFuser(B, ROWS, COLS, api.odometry_params(), ctx=ctx)
+    od = api.OdometryKeyframeFuser(B, ROWS, COLS, api.odometry_params(estimate_cov_by_sampling=int(args.cov_sampling)),
+                                   ctx=ctx)
 
     def barrier():
         torch.cuda.synchronize()
@@ -263,7 +267,8 @@ def main():
         "data": "synthetic (scene_v1 walls+scatterers, %d distinct sequences replicated to %d streams per GPU, "
                 "each stream its own HBM copy)" % (base.shape[0], B),
         "config": {"workload": "configs[1]: per-frame CFEAR-3 odometry registration (k=40, z_min=60, r=3, P2P, "
-                               "4-keyframe window), polar image -> pose, %d streams in flight per GPU" % B,
+                               "4-keyframe window%s), polar image -> pose, %d streams in flight per GPU"
+                               % (", + covariance by cost sampling" if args.cov_sampling else "", B),
                    "streams_per_gpu": B, "rows": ROWS, "cols": COLS, "parallelism": "replicas x%d" % world},
         "roofline": {"bound": "hbm", "kernel": "kstrongest_rows", "achieved": achieved, "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,

@@ -147,6 +147,25 @@ class n_scan_normal_reg {
     return st == CFEAR_OK;
   }
   double getScore() const { return score_; }
+  bool GetCovarianceScaler(double& cov_scale) const {                                         // n_scan_normal.cpp:433-439
+    if (summary_.num_residuals - 3 == 0) return false;
+    cov_scale = summary_.final_cost / (double)(summary_.num_residuals - 3);
+    return true;
+  }
+  // OdometryKeyframeFuser::approximateCovarianceBySampling (odometrykeyframefuser.cpp:261-380) /
+  // loopclosure::approximateCovarianceBySampling (loopclosure.cpp:99-208): T_vek = poses after Register of
+  // THIS object; cov_sampled row-major 6x6.  Returns cov_sampled_success.
+  bool approximateCovarianceBySampling(const std::vector<const MapPointNormal*>& scans, const std::vector<Pose2d>& T_vek,
+                                       double cov_sampled[36], const cfear_cov_sampling_params* sp = nullptr) {
+    cfear_cov_sampling_params def;
+    cfear_cov_sampling_params_default(&def);
+    std::vector<const cfear_scan*> h(scans.size());
+    for (size_t i = 0; i < scans.size(); i++) h[i] = scans[i]->device();
+    int32_t ok = 0;
+    ctx_.check(cfear_covariance_by_sampling(ctx_.get(), h.data(), (int32_t)h.size(), &T_vek[0].x, &par_, &summary_,
+                                            sp ? sp : &def, cov_sampled, nullptr, &ok));
+    return ok != 0;
+  }
   cfear_reg_result summary_{};
  private:
   Context& ctx_;

@@ -1,7 +1,8 @@
 // A C++ caller of libcfear_hip.so through the header-only mirror of the reference classes
 // (include/cfear_hip.hpp).  Reads a raw uint8 polar image pair [2][rows][cols] from argv[1], registers
 // frame 1 against frame 0 (P2L, loop-closure settings 4 x 10) and prints the result as one line:
-//   n_points0 n_points1 n_cells0 n_cells1 ok x y theta score
+//   n_points0 n_points1 n_cells0 n_cells1 ok x y theta score cov_ok cov_xx cov_yy cov_tt
+// (the last four: covariance by cost sampling with the loop-closure constants, loopclosure.cpp:108-112)
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
@@ -30,8 +31,13 @@ int main(int argc, char** argv) {
     reg.SetParameters(4, 10);
     std::vector<Pose2d> T = {{0, 0, 0}, {2.0, 0.0, 0.0}};
     const bool ok = reg.Register({&m0, &m1}, T);
-    printf("%zu %zu %zu %zu %d %.12g %.12g %.12g %.12g\n", c0.size(), c1.size(), m0.GetSize(), m1.GetSize(), ok ? 1 : 0,
-           T[1].x, T[1].y, T[1].theta, reg.getScore());
+    double cov[36];
+    cfear_cov_sampling_params sp;
+    cfear_cov_sampling_params_default(&sp);
+    sp.xy_range = 0.4; sp.yaw_range = 0.0044;
+    const bool cov_ok = reg.approximateCovarianceBySampling({&m0, &m1}, T, cov, &sp);
+    printf("%zu %zu %zu %zu %d %.12g %.12g %.12g %.12g %d %.12g %.12g %.12g\n", c0.size(), c1.size(), m0.GetSize(),
+           m1.GetSize(), ok ? 1 : 0, T[1].x, T[1].y, T[1].theta, reg.getScore(), cov_ok ? 1 : 0, cov[0], cov[7], cov[35]);
   } catch (const CfearError& e) {
     fprintf(stderr, "cfear error %d: %s\n", e.status, e.what());
     return 1;

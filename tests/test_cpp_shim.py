@@ -55,3 +55,9 @@ def test_cpp_mirror_matches_oracle(tmp_path):
     got = np.array([float(x) for x in v[5:8]])
     assert np.abs(got[:2] - po[-1, :2]).max() <= 1e-4 and abs(got[2] - po[-1, 2]) <= 1e-5
     np.testing.assert_allclose(float(v[8]), ro.score, rtol=1e-9)
+    # covariance by cost sampling through the C++ mirror (loop-closure constants)
+    par = O.reg_params(cost="P2L", max_outer=4, max_inner=10, first_itr=ro.outer_iters)
+    cok, cov, _ = O.cov_by_sampling(cells, po, par, ro.final_cost, ro.num_residuals, 0.4, 0.0044, 3, 4.0)
+    assert int(v[9]) == int(cok)
+    if cok:
+        np.testing.assert_allclose([float(x) for x in v[10:13]], [cov[0, 0], cov[1, 1], cov[5, 5]], rtol=1e-4)
