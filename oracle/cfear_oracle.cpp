@@ -1119,6 +1119,130 @@ extern "C" int orc_cov_by_sampling(const orc_cell* const* scans, const int32_t* 
 }
 
 // ==========================================================================================
+// CorAl alignment quality on radar peak clouds: CorAlRadarQuality
+// (coral_alignment_quality/src/alignment_checker/AlignmentQuality.cpp:8-230) as TBV calls it
+// (alignmentinterface.cpp:437-456: kstrongStructuredRadar scans built from the stored peak clouds,
+// radius 1.0, ent_cfg = any -> ComputeEntropy, weight_res_intensity = false, output_overlap = true).
+// Third-party semantics restated: pcl::transformPointCloud<PointXYZI, double> (PCL 1.10
+// common/impl/transforms.hpp: per coordinate float(((t_i0 x + t_i1 y) + t_i2 z) + t_i3) in double),
+// pcl::KdTreeFLANN<PointXY>::radiusSearch (FLANN L2_Simple float distance, RadiusResultSet keeps
+// dist < r^2 strictly, results sorted by distance; equal distances by index -- canonical choice),
+// Eigen colwise().mean() / x^T x as sequential sums in that order.
+// ==========================================================================================
+namespace {
+
+struct Pt2 { float x, y; double intensity; };
+
+// PoseScan::GetCloudCopy(T) (ScanType.cpp:211-215) for a planar pose (x, y, theta) followed by pcl3dto2d
+std::vector<Pt2> coral_transform(const float* xyzi, int n, const Aff2& T) {
+  std::vector<Pt2> out(n);
+  for (int i = 0; i < n; i++) {
+    const double x = (double)xyzi[4 * i], y = (double)xyzi[4 * i + 1], z = (double)xyzi[4 * i + 2];
+    out[i].x = (float)(((T.l[0] * x + T.l[1] * y) + 0.0 * z) + T.t[0]);
+    out[i].y = (float)(((T.l[2] * x + T.l[3] * y) + 0.0 * z) + T.t[1]);
+    out[i].intensity = (double)xyzi[4 * i + 3];
+  }
+  return out;
+}
+
+// kd.radiusSearch(query, radius, idx, sqdist): indices sorted by (distance, index)
+void coral_radius(const std::vector<Pt2>& cloud, float qx, float qy, double radius, std::vector<int>& idx) {
+  const float r2 = (float)(radius * radius);
+  std::vector<std::pair<float, int>> hits;
+  for (int i = 0; i < (int)cloud.size(); i++) {
+    const float dx = qx - cloud[i].x, dy = qy - cloud[i].y;
+    const float d = dx * dx + dy * dy;                                       // L2_Simple
+    if (d < r2) hits.emplace_back(d, i);                                     // RadiusResultSet::addPoint
+  }
+  std::sort(hits.begin(), hits.end());
+  idx.clear();
+  for (auto& h : hits) idx.push_back(h.second);
+}
+
+// CorAlRadarQuality::Covariance (AlignmentQuality.cpp:30-53); x: rows of (x, y)
+bool coral_covariance(std::vector<double>& x, double cov[4], double mean[2]) {
+  const int rows = (int)x.size() / 2;
+  if (rows <= 2) return false;
+  double sx = 0, sy = 0;
+  for (int i = 0; i < rows; i++) { sx += x[2 * i]; sy += x[2 * i + 1]; }
+  mean[0] = sx / rows; mean[1] = sy / rows;
+  for (int i = 0; i < rows; i++) { x[2 * i] -= mean[0]; x[2 * i + 1] -= mean[1]; }
+  double c00 = 0, c01 = 0, c11 = 0;
+  for (int i = 0; i < rows; i++) { c00 += x[2 * i] * x[2 * i]; c01 += x[2 * i] * x[2 * i + 1]; c11 += x[2 * i + 1] * x[2 * i + 1]; }
+  const float n = (float)rows;                                               // `float n = x.rows()`
+  const double den = (double)n - 1.0;
+  cov[0] = c00 * 1.0 / den; cov[1] = c01 * 1.0 / den; cov[2] = cov[1]; cov[3] = c11 * 1.0 / den;
+  return true;
+}
+
+// CorAlRadarQuality::ComputeEntropy (:80-98)
+bool coral_entropy(const double cs[4], const double cj[4], double& sep, double& joint) {
+  const double det_j = cj[0] * cj[3] - cj[1] * cj[2];
+  const double det_s = cs[0] * cs[3] - cs[1] * cs[2];
+  if (std::isnan(det_s) || std::isnan(det_j)) return false;
+  const double sep_entropy = 1.0 / 2.0 * std::log(2.0 * M_PI * std::exp(1.0) * det_s + 0.00000001);
+  const double joint_entropy = 1.0 / 2.0 * std::log(2.0 * M_PI * std::exp(1.0) * det_j + 0.00000001);
+  if (std::isnan(sep_entropy) || std::isnan(joint_entropy)) return false;
+  sep = sep_entropy; joint = joint_entropy;
+  return true;
+}
+
+}  // namespace
+
+// quality = {joint_, sep_, overlap_}; returns valid_ (overlap >= 0.1).  per_point (optional)
+// [n_src + n_ref][3] = joint_res_, sep_res_, sep_valid in the reference's index order (src first).
+extern "C" int orc_coral_quality(const float* ref_xyzi, int n_ref, const float* src_xyzi, int n_src,
+                                 const double ref_pose[3], const double src_pose[3], const double offset[3],
+                                 double radius, int weight_res_intensity, double quality[3], double* per_point) {
+  const Aff2 Tref = aff_from_xyt(ref_pose[0], ref_pose[1], ref_pose[2]);
+  const Aff2 Tsrc = aff_mul(aff_from_xyt(src_pose[0], src_pose[1], src_pose[2]),
+                            aff_from_xyt(offset[0], offset[1], offset[2]));     // src->GetAffine()*Toffset (:101)
+  const std::vector<Pt2> src = coral_transform(src_xyzi, n_src, Tsrc);
+  const std::vector<Pt2> ref = coral_transform(ref_xyzi, n_ref, Tref);
+  const int merged = n_src + n_ref;
+  std::vector<double> sep_res(merged, 100.0), joint_res(merged, 100.0);
+  std::vector<char> valid(merged, 0);
+  std::vector<int> is, ir;
+  const int overlap_req = 1;                                                 // AlignmentQuality.h:244
+  for (int pass = 0; pass < 2; pass++) {                                     // :132-176 src queries, then ref queries
+    const std::vector<Pt2>& q = pass == 0 ? src : ref;
+    for (int k = 0; k < (int)q.size(); k++) {
+      const int index = pass == 0 ? k : n_src + k;
+      coral_radius(src, q[k].x, q[k].y, radius, is);                         // GetNearby (:8-29)
+      coral_radius(ref, q[k].x, q[k].y, radius, ir);
+      if ((pass == 0 ? (int)ir.size() : (int)is.size()) < overlap_req) continue;
+      std::vector<double> msep, mjoint;
+      for (int i : is) { mjoint.push_back(src[i].x); mjoint.push_back(src[i].y); }
+      for (int i : ir) { mjoint.push_back(ref[i].x); mjoint.push_back(ref[i].y); }
+      const std::vector<Pt2>& own = pass == 0 ? src : ref;
+      for (int i : (pass == 0 ? is : ir)) { msep.push_back(own[i].x); msep.push_back(own[i].y); }
+      double cs[4], cj[4], ms[2], mj[2];
+      if (coral_covariance(msep, cs, ms) && coral_covariance(mjoint, cj, mj)) {
+        double se, je;
+        if (coral_entropy(cs, cj, se, je)) { sep_res[index] = se; joint_res[index] = je; valid[index] = 1; }
+      }
+    }
+  }
+  double sep = 0, joint = 0, w_sum = 0;                                      // :178-194
+  int count_valid = 0;
+  for (int i = 0; i < merged; i++) {
+    if (!valid[i]) continue;
+    const double w = weight_res_intensity ? (i < n_src ? src[i].intensity : ref[i - n_src].intensity) : 1.0;
+    w_sum += w;
+    joint_res[i] = w * joint_res[i];
+    sep_res[i] = w * sep_res[i];
+    joint += joint_res[i]; sep += sep_res[i];
+    count_valid++;
+  }
+  if (count_valid > 0) { sep /= w_sum; joint /= w_sum; }
+  const double overlap = count_valid / ((double)merged);
+  quality[0] = joint; quality[1] = sep; quality[2] = overlap;                // output_overlap = true
+  if (per_point)
+    for (int i = 0; i < merged; i++) { per_point[3 * i] = joint_res[i]; per_point[3 * i + 1] = sep_res[i]; per_point[3 * i + 2] = valid[i]; }
+  return overlap < 0.1 ? 0 : 1;                                              // :197-204
+}
+
+// ==========================================================================================
 // caller: OdometryKeyframeFuser  (odometrykeyframefuser.cpp:62-94, 143-259, 470-494)
 // ==========================================================================================
 struct orc_fuser {

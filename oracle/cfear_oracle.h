@@ -115,6 +115,14 @@ int orc_cov_by_sampling(const orc_cell* const* scans, const int32_t* n_cells, in
                         int32_t samples_per_axis, double covariance_scaler, double* cov36,
                         double* samples_out);
 
+/* CorAl alignment quality of two peak clouds (AlignmentQuality.cpp:8-230 as called from
+ * alignmentinterface.cpp:437-456): ref/src clouds [n][4] (x,y,z,intensity) in their sensor frames,
+ * planar poses, Toffset applied to the source.  quality = {joint, sep, overlap}; returns valid_.
+ * per_point optional [n_src+n_ref][3] = joint_res, sep_res, valid (src points first).          */
+int orc_coral_quality(const float* ref_xyzi, int n_ref, const float* src_xyzi, int n_src,
+                      const double ref_pose[3], const double src_pose[3], const double offset[3],
+                      double radius, int weight_res_intensity, double quality[3], double* per_point);
+
 /* ---- caller: OdometryKeyframeFuser (odometrykeyframefuser.cpp:62-94,143-259,470-494) ----- */
 typedef struct orc_fuser_params {
   orc_reg_params reg;

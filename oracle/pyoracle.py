@@ -95,6 +95,7 @@ def lib():
         pp = C.POINTER(C.c_void_p)
         L.orc_register.argtypes = [pp, i32p, C.c_int, f64p, C.POINTER(OrcRegParams), C.POINTER(OrcRegResult)]
         L.orc_get_cost.argtypes = [pp, i32p, C.c_int, f64p, C.POINTER(OrcRegParams), f64p, f64p, i32p, f64p]
+        L.orc_coral_quality.argtypes = [f32p, C.c_int, f32p, C.c_int, f64p, f64p, f64p, C.c_double, C.c_int, f64p, f64p]
         L.orc_cov_by_sampling.argtypes = [pp, i32p, C.c_int, f64p, C.POINTER(OrcRegParams), C.c_double, C.c_int32,
                                           C.c_double, C.c_double, C.c_int32, C.c_double, f64p, f64p]
         L.orc_associate.argtypes = [pp, i32p, C.c_int, f64p, C.POINTER(OrcRegParams), C.c_int, i32p, f64p, C.c_int]
@@ -224,6 +225,23 @@ def cov_by_sampling(scans, poses, par, final_cost, num_residuals, xy_range=0.4, 
                                    int(samples_per_axis), float(covariance_scaler), _p(cov, C.c_double),
                                    _p(smp, C.c_double))
     return bool(ok), cov, smp
+
+
+def coral_quality(ref_xyzi, src_xyzi, ref_pose, src_pose, offset=(0.0, 0.0, 0.0), radius=1.0,
+                  weight_res_intensity=False):
+    """CorAlRadarQuality (AlignmentQuality.cpp:8-230) as alignmentinterface.cpp:437-456 calls it.
+    -> (valid, quality [joint, sep, overlap], per_point [n_src + n_ref, 3] (joint_res, sep_res, valid))."""
+    r = np.ascontiguousarray(ref_xyzi, dtype=np.float32)
+    s = np.ascontiguousarray(src_xyzi, dtype=np.float32)
+    rp = np.ascontiguousarray(ref_pose, dtype=np.float64)
+    sp = np.ascontiguousarray(src_pose, dtype=np.float64)
+    of = np.ascontiguousarray(offset, dtype=np.float64)
+    q = np.zeros(3, np.float64)
+    pp = np.zeros((r.shape[0] + s.shape[0], 3), np.float64)
+    ok = lib().orc_coral_quality(_p(r, C.c_float), r.shape[0], _p(s, C.c_float), s.shape[0], _p(rp, C.c_double),
+                                 _p(sp, C.c_double), _p(of, C.c_double), float(radius), int(weight_res_intensity),
+                                 _p(q, C.c_double), _p(pp, C.c_double))
+    return bool(ok), q, pp
 
 
 def associate(scans, poses, par, itr):
