@@ -26,14 +26,14 @@
 #include <cmath>
 
 #include "common.hpp"
+#include "gridsort.hpp"
 
 namespace {
 
-constexpr int kSurfThreads = 1024;
-constexpr int kMaxPoints = 16384;            // LDS sort capacity (64-bit keys)
+constexpr int kSurfThreads = kGridSortThreads;
+constexpr int kMaxPoints = kGridSortMaxPoints;   // LDS sort capacity (64-bit keys)
 constexpr int kMaxGridRows = 4096;           // rowbeg table
 constexpr int kPerThread = kMaxPoints / kSurfThreads;   // 16 sorted elements per thread
-constexpr int kRadixMaxPoints = 8192;        // radix path: 2 x 32 KiB key buffers + 32 KiB counters in LDS
 // LDS map: [0, 128K) sort keys, later voxel key/start tables; then rowbeg; then small reductions
 constexpr size_t kLdsRowbegOff = (size_t)kMaxPoints * 8 + 16;
 constexpr size_t kLdsSmallOff = (kLdsRowbegOff + (size_t)(kMaxGridRows + 1) * 4 + 15) / 16 * 16;
@@ -269,103 +269,12 @@ __global__ __launch_bounds__(kSurfThreads) void surface_points_kernel(const Surf
 #endif
   // ---- 2. (voxel, point) keys -> LDS sort: voxels ascending, points of a voxel in input order --
   unsigned long long* keys = (unsigned long long*)smem;
-  int npad = 1024;
-  while (npad < n) npad <<= 1;
-  int ib = 10;                                             // index bits: 2^ib == npad
-  while ((1 << ib) < npad) ib++;
-  int vb = 1;                                              // voxel-index bits
-  while (((long long)1 << vb) < (long long)dbx * dby) vb++;
-  // Fast path: packed 32-bit keys (voxel << ib | index) and a stable LSD radix sort on the voxel
-  // digits (4 bits per pass, thread-contiguous chunks keep input order) in two LDS buffers.
-  const bool radix = (npad <= kRadixMaxPoints) && (vb + ib <= 32);
-  if (radix) {
-    uint32_t* kA = (uint32_t*)smem;
-    uint32_t* kB = kA + npad;
-    unsigned short* cnt = (unsigned short*)(kB + npad);   // [16][1024]
-    const int per = npad / kSurfThreads;                   // 1..8 consecutive elements per thread
-    for (int i = tid; i < npad; i += kSurfThreads) {
-      uint32_t key = 0xFFFFFFFFu;
-      if (i < n) {
-        const float4 p = pts[i];
-        const int ijk0 = (int)(floorf(p.x * cm.inv_leaf) - (float)min_bx);
-        const int ijk1 = (int)(floorf(p.y * cm.inv_leaf) - (float)min_by);
-        key = ((uint32_t)(ijk0 + ijk1 * dbx) << ib) | (uint32_t)i;
-      }
-      kA[i] = key;
-    }
-    __syncthreads();
-    uint32_t* src = kA;
-    uint32_t* dst = kB;
-    for (int shift = ib; shift < ib + vb; shift += 4) {
-#pragma unroll
-      for (int d = 0; d < 16; d++) cnt[d * kSurfThreads + tid] = 0;
-      for (int q = 0; q < per; q++) {
-        const uint32_t dg = (src[tid * per + q] >> shift) & 15u;
-        cnt[dg * kSurfThreads + tid]++;
-      }
-      __syncthreads();
-      // exclusive scan of the 16 x 1024 counters in (digit, thread) order: 16 consecutive per thread
-      unsigned short local[16];
-      int tot = 0;
-#pragma unroll
-      for (int q = 0; q < 16; q++) { local[q] = cnt[tid * 16 + q]; tot += local[q]; }
-      const int inc = wave_incl_scan_i32(tot);
-      if (lane == 63) red_i[wave] = inc;
-      __syncthreads();
-      int run = inc - tot;
-      for (int wv = 0; wv < wave; wv++) run += red_i[wv];
-#pragma unroll
-      for (int q = 0; q < 16; q++) { cnt[tid * 16 + q] = (unsigned short)run; run += local[q]; }
-      __syncthreads();
-      for (int q = 0; q < per; q++) {
-        const uint32_t key = src[tid * per + q];
-        const uint32_t dg = (key >> shift) & 15u;
-        const int pos = cnt[dg * kSurfThreads + tid]++;
-        dst[pos] = key;
-      }
-      __syncthreads();
-      uint32_t* t = src; src = dst; dst = t;
-    }
-    // widen to the 64-bit (voxel, index) form the next step reads; registers bridge the overlap
-    uint32_t mine32[kRadixMaxPoints / kSurfThreads];
-#pragma unroll
-    for (int q = 0; q < kRadixMaxPoints / kSurfThreads; q++) mine32[q] = (q < per) ? src[tid * per + q] : 0xFFFFFFFFu;
-    __syncthreads();
-#pragma unroll
-    for (int q = 0; q < kRadixMaxPoints / kSurfThreads; q++)
-      if (q < per) {
-        const uint32_t key = mine32[q];
-        keys[tid * per + q] = key == 0xFFFFFFFFu ? ~0ull
-                                                 : (((unsigned long long)(key >> ib)) << 32) | (key & ((1u << ib) - 1u));
-      }
-    __syncthreads();
-  } else {
-    // General path: bitonic sort of 64-bit (voxel, index) keys.
-    for (int i = tid; i < npad; i += kSurfThreads) {
-      unsigned long long key = ~0ull;
-      if (i < n) {
-        const float4 p = pts[i];
-        const int ijk0 = (int)(floorf(p.x * cm.inv_leaf) - (float)min_bx);
-        const int ijk1 = (int)(floorf(p.y * cm.inv_leaf) - (float)min_by);
-        const unsigned idx = (unsigned)(ijk0 + ijk1 * dbx);
-        key = ((unsigned long long)idx << 32) | (unsigned)i;
-      }
-      keys[i] = key;
-    }
-    __syncthreads();
-    for (int k = 2; k <= npad; k <<= 1) {
-      for (int j = k >> 1; j > 0; j >>= 1) {
-        for (int t = tid; t < (npad >> 1); t += kSurfThreads) {
-          const int lo = ((t & ~(j - 1)) << 1) | (t & (j - 1));
-          const int hi = lo | j;
-          const bool asc = (lo & k) == 0;
-          const unsigned long long a = keys[lo], b = keys[hi];
-          if ((a > b) == asc) { keys[lo] = b; keys[hi] = a; }
-        }
-        __syncthreads();
-      }
-    }
-  }
+  const int npad = grid_sort_block(smem, n, (long long)dbx * dby, red_i, [&](int i) {
+    const float4 p = pts[i];
+    const int ijk0 = (int)(floorf(p.x * cm.inv_leaf) - (float)min_bx);
+    const int ijk1 = (int)(floorf(p.y * cm.inv_leaf) - (float)min_by);
+    return (uint32_t)(ijk0 + ijk1 * dbx);
+  });
 
 #ifdef CFEAR_SURF_TIMING
   if (tid == 0) tstamp[2] = __builtin_readcyclecounter();
