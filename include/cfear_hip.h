@@ -293,6 +293,46 @@ int cfear_cost_evaluate(cfear_cost* c, const double x[3], double* residuals, dou
 int cfear_cost_normal_eq(cfear_cost* c, const double x[3], double H[9], double g[3], double* cost);
 int cfear_cost_destroy(cfear_cost* c);
 
+/* ---- caller: CorAl alignment quality (loop-closure verification) ---------------------------------
+ * Replaces CorAlRadarQuality (coral_alignment_quality/src/alignment_checker/AlignmentQuality.cpp:8-230)
+ * as ScanLearningInterface::getCorAlQualityMeasure builds it (alignmentinterface.cpp:437-456): both
+ * scans are kstrongStructuredRadar objects over the stored PEAK clouds, the source is placed at
+ * src_pose * Toffset, every point of the merged cloud gets the entropy of its radius-neighbourhood in
+ * its own cloud (sep) and in both clouds (joint).  quality_ = {joint, sep, overlap}; valid_ = overlap
+ * >= 0.1.  Only ent_cfg = any (ComputeEntropy) is built: TBV never selects the kl variant.          */
+typedef struct cfear_coral_params {
+  double radius;                        /* AlignmentQuality::parameters::radius; TBV: 1.0              */
+  int32_t weight_res_intensity;         /* weight_res_intensity; TBV: false                            */
+  int32_t pad;
+} cfear_coral_params;
+void cfear_coral_params_default(cfear_coral_params* p);
+
+typedef struct cfear_coral_job {
+  const float* ref_xyzi;                /* [n_ref][4] x,y,z,intensity in the reference scan's sensor frame; host or device */
+  const float* src_xyzi;                /* [n_src][4]                                                   */
+  int32_t n_ref, n_src;
+  double ref_pose[3];                   /* ref->GetAffine() as (x, y, theta)                           */
+  double src_pose[3];                   /* src->GetAffine()                                            */
+  double offset[3];                     /* Toffset (perturbation), applied as src_pose * Toffset       */
+} cfear_coral_job;
+
+typedef struct cfear_coral_result {
+  double joint, sep, overlap;           /* quality_[0..2] (output_overlap = true)                      */
+  int32_t valid;                        /* valid_                                                      */
+  int32_t count_valid;                  /* points with both covariances and finite entropies           */
+  int32_t status;                       /* CFEAR_OK / CFEAR_ERR_EMPTY_CLOUD / CFEAR_ERR_CAPACITY       */
+  int32_t pad;
+} cfear_coral_result;                   /* 40 bytes */
+
+/* per_point (optional, host): [n_src + n_ref][3] = joint_res_, sep_res_, sep_valid in the reference's
+ * index order (source points first); invalid points hold the reference's initial 100.0.             */
+int cfear_coral_quality(cfear_ctx* ctx, const cfear_coral_job* job, const cfear_coral_params* par,
+                        cfear_coral_result* result, double* per_point);
+/* One launch for a batch (the 13 perturbations of a training pair, a loop-closure candidate list);
+ * clouds shared between jobs are uploaded once.  per_point (optional): jobs' arrays back to back.     */
+int cfear_coral_quality_batch(cfear_ctx* ctx, const cfear_coral_job* jobs, int32_t n_jobs,
+                              const cfear_coral_params* par, cfear_coral_result* results, double* per_point);
+
 /* ---- caller: batched radarDriver + OdometryKeyframeFuser --------------------------------------
  * n_streams independent sequences advance one frame per call: filter (F) -> compensate (C) ->
  * surface points (N) -> Register against the keyframe window (M) -> keyframe policy.  Restates

@@ -97,6 +97,24 @@ class CovSamplingParams(C.Structure):
                 ("pad", C.c_int32), ("covariance_scaler", C.c_double)]
 
 
+class CoralParams(C.Structure):
+    _fields_ = [("radius", C.c_double), ("weight_res_intensity", C.c_int32), ("pad", C.c_int32)]
+
+
+class CoralJob(C.Structure):
+    _fields_ = [("ref_xyzi", C.c_void_p), ("src_xyzi", C.c_void_p), ("n_ref", C.c_int32), ("n_src", C.c_int32),
+                ("ref_pose", C.c_double * 3), ("src_pose", C.c_double * 3), ("offset", C.c_double * 3)]
+
+
+class CoralResult(C.Structure):
+    _fields_ = [("joint", C.c_double), ("sep", C.c_double), ("overlap", C.c_double), ("valid", C.c_int32),
+                ("count_valid", C.c_int32), ("status", C.c_int32), ("pad", C.c_int32)]
+
+
+CORAL_RESULT_DTYPE = np.dtype([("joint", "<f8"), ("sep", "<f8"), ("overlap", "<f8"), ("valid", "<i4"),
+                               ("count_valid", "<i4"), ("status", "<i4"), ("pad", "<i4")])
+
+
 class OdometryParams(C.Structure):
     _fields_ = [("filter_type", C.c_int32), ("kstrong", KStrongParams), ("cacfar", CacfarParams),
                 ("reg", RegParams), ("res", C.c_float), ("submap_scan_size", C.c_int32),
@@ -126,7 +144,8 @@ EXPORTS = [
     "cfear_scan_from_cells", "cfear_scan_size", "cfear_scan_get_cells", "cfear_scan_destroy",
     "cfear_reg_params_default", "cfear_register", "cfear_register_batch", "cfear_get_cost",
     "cfear_get_cost_batch", "cfear_cov_sampling_params_default", "cfear_covariance_by_sampling",
-    "cfear_covariance_by_sampling_batch",
+    "cfear_covariance_by_sampling_batch", "cfear_coral_params_default", "cfear_coral_quality",
+    "cfear_coral_quality_batch",
     "cfear_cost_prepare", "cfear_cost_num_blocks", "cfear_cost_num_residuals", "cfear_cost_get_blocks",
     "cfear_cost_evaluate", "cfear_cost_normal_eq", "cfear_cost_destroy",
     "cfear_odometry_params_default", "cfear_odometry_create", "cfear_odometry_process",
@@ -187,6 +206,10 @@ def lib():
                                                C.POINTER(C.c_double), C.POINTER(C.c_int32)]
     L.cfear_covariance_by_sampling_batch.argtypes = [vp, C.POINTER(RegJob), C.c_int32, C.POINTER(RegParams), vp,
                                                      C.POINTER(CovSamplingParams), vp, vp, vp]
+    L.cfear_coral_params_default.argtypes = [C.POINTER(CoralParams)]
+    L.cfear_coral_params_default.restype = None
+    L.cfear_coral_quality.argtypes = [vp, C.POINTER(CoralJob), C.POINTER(CoralParams), vp, vp]
+    L.cfear_coral_quality_batch.argtypes = [vp, C.POINTER(CoralJob), C.c_int32, C.POINTER(CoralParams), vp, vp]
     L.cfear_get_cost.argtypes = [vp, C.POINTER(vp), C.c_int32, C.POINTER(C.c_double), C.POINTER(RegParams),
                                  C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int32,
                                  C.POINTER(C.c_int32), C.POINTER(C.c_double)]

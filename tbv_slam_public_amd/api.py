@@ -464,6 +464,69 @@ class CeresCost:
 # ------------------------------------------------------------------------------------------------
 # batched radarDriver + OdometryKeyframeFuser
 # ------------------------------------------------------------------------------------------------
+# ------------------------------------------------------------------------------------------------
+# CorAl alignment quality
+# ------------------------------------------------------------------------------------------------
+class CorAlRadarQuality:
+    """CorAlRadarQuality(ref, src, par, Toffset) (coral_alignment_quality AlignmentQuality.cpp:99-230) over
+    peak clouds, as ScanLearningInterface::getCorAlQualityMeasure builds it (alignmentinterface.cpp:437-456).
+
+    ref / src: float32 [n, 4] clouds (NumPy or torch CUDA) in their sensor frames; poses (x, y, theta).
+    GetQualityMeasure() -> [joint, sep, overlap]; .valid_ as in the reference."""
+
+    def __init__(self, ref_cloud, ref_pose, src_cloud, src_pose, Toffset=(0.0, 0.0, 0.0), radius=1.0,
+                 weight_res_intensity=False, want_per_point=False, ctx=None):
+        out, pp = coral_quality_batch([(ref_cloud, ref_pose, src_cloud, src_pose, Toffset)], radius,
+                                      weight_res_intensity, want_per_point, ctx)
+        r = out[0]
+        self.quality_ = [float(r["joint"]), float(r["sep"]), float(r["overlap"])]
+        self.valid_ = bool(r["valid"])
+        self.count_valid = int(r["count_valid"])
+        self.per_point = pp[0] if want_per_point else None
+
+    def GetQualityMeasure(self):
+        return list(self.quality_)
+
+
+def coral_quality_batch(jobs, radius=1.0, weight_res_intensity=False, want_per_point=False, ctx=None):
+    """jobs: list of (ref_cloud, ref_pose, src_cloud, src_pose, Toffset).  One launch.
+    -> (CORAL_RESULT_DTYPE array, per-point list or None)."""
+    ctx = ctx or default_context()
+    n = len(jobs)
+    arr = (L.CoralJob * n)()
+    keep, sizes = [], []
+    for i, (rc, rp, sc, sp, off) in enumerate(jobs):
+        pr, nr, kr = _cloud_ptr(rc)
+        ps, ns, ks = _cloud_ptr(sc)
+        keep += [kr, ks]
+        arr[i].ref_xyzi, arr[i].src_xyzi, arr[i].n_ref, arr[i].n_src = pr, ps, nr, ns
+        for k in range(3):
+            arr[i].ref_pose[k], arr[i].src_pose[k], arr[i].offset[k] = float(rp[k]), float(sp[k]), float(off[k])
+        sizes.append(nr + ns)
+    par = L.CoralParams()
+    ctx._lib.cfear_coral_params_default(C.byref(par))
+    par.radius, par.weight_res_intensity = float(radius), int(weight_res_intensity)
+    out = np.zeros(n, L.CORAL_RESULT_DTYPE)
+    pp = np.zeros((sum(sizes), 3), np.float64) if want_per_point else None
+    if n:
+        ctx.check(ctx._lib.cfear_coral_quality_batch(ctx.h, arr, n, C.byref(par), out.ctypes.data,
+                                                     pp.ctypes.data if want_per_point else None))
+    if not want_per_point:
+        return out, None
+    offs = np.cumsum([0] + sizes)
+    return out, [pp[offs[i]:offs[i + 1]] for i in range(n)]
+
+
+def _cloud_ptr(cloud):
+    """float32 [n, 4] NumPy array or torch CUDA tensor -> (pointer, n, keep-alive)."""
+    if isinstance(cloud, np.ndarray):
+        c = np.ascontiguousarray(cloud, dtype=np.float32)
+        assert c.ndim == 2 and c.shape[1] == 4
+        return c.ctypes.data, c.shape[0], c
+    assert cloud.dim() == 2 and cloud.shape[1] == 4 and cloud.is_contiguous()
+    return cloud.data_ptr(), int(cloud.shape[0]), cloud
+
+
 def odometry_params(**kw):
     """cfear_odometry_params with the CFEAR-3 / Oxford preset; keyword overrides use the C field names
     (nested: kstrong_k_strongest, cacfar_window_size, reg_cost, cov_sampling_xy_range, ...)."""

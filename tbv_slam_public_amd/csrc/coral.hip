@@ -1,0 +1,424 @@
+// coral.hip -- CorAl alignment quality of two radar peak clouds on gfx950.
+//
+// Replaces CorAlRadarQuality (coral_alignment_quality/src/alignment_checker/AlignmentQuality.cpp:8-230)
+// as TBV calls it for loop-closure verification and classifier training
+// (alignmentinterface.cpp:296-347, 437-456: kstrongStructuredRadar scans from the stored peak clouds,
+// radius 1.0, ent_cfg = any -> ComputeEntropy, output_overlap = true):
+//   PoseScan::GetCloudCopy + pcl3dto2d            ScanType.cpp:211-215, Utils.cpp:200-212
+//   GetNearby (two pcl::KdTreeFLANN radius searches)  AlignmentQuality.cpp:8-29
+//   Covariance / ComputeEntropy                   :30-53, :80-98
+//   per-point loops and aggregation               :132-204
+// The ent_cfg = kl branch (ComputeKLDiv, :54-78) is never selected by TBV and is not built.
+//
+// Kernel design: ONE 1024-thread workgroup per (ref, src, Toffset) job, one launch per batch.  The two
+// kd-trees are replaced by ONE sort-based uniform grid over the merged cloud (cell >= radius, so every
+// neighbour of a query lies in the 3 x 3 cells around it; gridsort.hpp): each merged point is a query
+// once and accumulates, in a single pass over the contiguous runs of the sorted array, the fp64 moments
+// of its source-cloud and reference-cloud neighbours separately -- the joint neighbourhood is their sum,
+// so the reference's two radius searches + three matrix copies per point become one sweep.  The float
+// squared distance test is FLANN's L2_Simple (`dist < r^2`, strict).  Per-point entropies are written by
+// original index and reduced in index order (fixed tree), so results do not depend on scheduling.
+// Working set per job: a few hundred KB in LDS + L2; nothing here is HBM-bound.
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <map>
+#include <vector>
+
+#include "common.hpp"
+#include "gridsort.hpp"
+
+namespace {
+
+constexpr int kCoralThreads = kGridSortThreads;
+constexpr int kCoralMaxPoints = kGridSortMaxPoints;      // merged points per job
+constexpr int kCoralMaxGridRows = 4096;
+constexpr int kCoralPerThread = kCoralMaxPoints / kCoralThreads;
+constexpr size_t kCoralRowbegOff = (size_t)kCoralMaxPoints * 8 + 16;
+constexpr size_t kCoralSmallOff = (kCoralRowbegOff + (size_t)(kCoralMaxGridRows + 1) * 4 + 15) / 16 * 16;
+constexpr size_t kCoralLdsTotal = kCoralSmallOff + 1024;
+
+struct CoralJob {
+  const float4* ref;
+  const float4* src;
+  const int32_t* n_ref_ptr;           // device-side counts (pipelines), or nullptr -> the host values
+  const int32_t* n_src_ptr;
+  int32_t n_ref, n_src;
+  double ref_pose[3], src_pose[3], offset[3];
+};
+
+struct CoralCommon {
+  double radius;
+  float r2, inv_cell;
+  int32_t weight_res_intensity;
+  int32_t cap;                        // merged-point capacity of the per-job scratch
+  char* scratch;
+  size_t scratch_stride;
+  cfear_coral_result* results;
+  double* per_point;                  // nullable: [n_jobs][cap][3] joint_res, sep_res, valid
+};
+
+__host__ __device__ inline size_t coral_scratch_bytes(int cap) {
+  // sorted points float4 | joint_res f64 | sep_res f64 | weight f64 (0 = invalid) | valid i32
+  return ((size_t)cap * (16 + 8 + 8 + 8 + 4) + 255) / 256 * 256;
+}
+
+struct Aff2d { double l0, l1, l2, l3, t0, t1; };
+__device__ __forceinline__ Aff2d aff_xyt(const double* p) {
+  double s, c;
+  sincos(p[2], &s, &c);
+  return Aff2d{c, -s, s, c, p[0], p[1]};
+}
+__device__ __forceinline__ Aff2d aff_compose(const Aff2d& a, const Aff2d& b) {     // Eigen Transform * Transform
+  Aff2d r;
+  r.l0 = a.l0 * b.l0 + a.l1 * b.l2; r.l1 = a.l0 * b.l1 + a.l1 * b.l3;
+  r.l2 = a.l2 * b.l0 + a.l3 * b.l2; r.l3 = a.l2 * b.l1 + a.l3 * b.l3;
+  r.t0 = a.l0 * b.t0 + a.l1 * b.t1 + a.t0;
+  r.t1 = a.l2 * b.t0 + a.l3 * b.t1 + a.t1;
+  return r;
+}
+// pcl::transformPointCloud<PointXYZI, double> (PCL 1.10 common/impl/transforms.hpp): float(((t0 x + t1 y) + t2 z) + t3)
+__device__ __forceinline__ float2 tf_point(const float4 p, const Aff2d& T) {
+  const double x = (double)p.x, y = (double)p.y, z = (double)p.z;
+  return make_float2((float)(((T.l0 * x + T.l1 * y) + 0.0 * z) + T.t0), (float)(((T.l2 * x + T.l3 * y) + 0.0 * z) + T.t1));
+}
+
+__device__ __forceinline__ int lower_bound_u32(const uint32_t* a, int lo, int hi, uint32_t key) {
+  while (lo < hi) { const int mid = (lo + hi) >> 1; if (a[mid] < key) lo = mid + 1; else hi = mid; }
+  return lo;
+}
+__device__ __forceinline__ int upper_bound_u32(const uint32_t* a, int lo, int hi, uint32_t key) {
+  while (lo < hi) { const int mid = (lo + hi) >> 1; if (a[mid] <= key) lo = mid + 1; else hi = mid; }
+  return lo;
+}
+
+struct Moments { int n; double sx, sy, sxx, sxy, syy; };
+
+// CorAlRadarQuality::Covariance (:30-53) from the moments of d = p - q about the query q: the mean shift
+// cancels in the covariance, |d| < radius keeps the one-pass form accurate to a few ulp.
+__device__ __forceinline__ bool cov_from_moments(const Moments& m, double& c00, double& c01, double& c11) {
+  if (m.n <= 2) return false;                                                  // x.rows() <= 2
+  const double n = (double)m.n;
+  const double mx = m.sx / n, my = m.sy / n;
+  const double den = (double)(float)m.n - 1.0;                                 // `float n = x.rows()`; cov = covSum*1.0/(n-1.0)
+  c00 = (m.sxx - n * mx * mx) * 1.0 / den;
+  c01 = (m.sxy - n * mx * my) * 1.0 / den;
+  c11 = (m.syy - n * my * my) * 1.0 / den;
+  return true;
+}
+
+__device__ __forceinline__ void fail_job(const CoralCommon& cm, int status) {
+  if (threadIdx.x == 0) {
+    cfear_coral_result& r = cm.results[blockIdx.x];
+    r.joint = r.sep = r.overlap = 0.0; r.valid = 0; r.count_valid = 0; r.status = status; r.pad = 0;
+  }
+}
+
+__global__ __launch_bounds__(kCoralThreads) void coral_kernel(const CoralJob* __restrict__ jobs, const CoralCommon cm) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  float (*red_f)[16] = (float (*)[16])(smem + kCoralSmallOff);          // [4][16]
+  int* red_i = (int*)(smem + kCoralSmallOff + 256);                     // [16]
+  double* red_d = (double*)(smem + kCoralSmallOff + 384);               // [16][3] + counts
+  int* red_c = (int*)(smem + kCoralSmallOff + 384 + 16 * 3 * 8);        // [16]
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const CoralJob job = jobs[blockIdx.x];
+  const int n_src = job.n_src_ptr ? *job.n_src_ptr : job.n_src;
+  const int n_ref = job.n_ref_ptr ? *job.n_ref_ptr : job.n_ref;
+  const int n = n_src + n_ref;
+  if (n_src <= 0 || n_ref <= 0) { fail_job(cm, CFEAR_ERR_EMPTY_CLOUD); return; }         // assert(size() > 0) (:118)
+  if (n > cm.cap || n > kCoralMaxPoints) { fail_job(cm, CFEAR_ERR_CAPACITY); return; }
+  char* scr = cm.scratch + (size_t)blockIdx.x * cm.scratch_stride;
+  float4* spt = (float4*)scr;                                  // sorted merged points (x, y, intensity, original index)
+  double* jres = (double*)(spt + cm.cap);
+  double* sres = jres + cm.cap;
+  double* wres = sres + cm.cap;
+  int32_t* vres = (int32_t*)(wres + cm.cap);
+
+  const Aff2d Tref = aff_xyt(job.ref_pose);
+  const Aff2d Tsrc = aff_compose(aff_xyt(job.src_pose), aff_xyt(job.offset));            // src->GetAffine() * Toffset (:101)
+  auto point = [&](int i) -> float2 {                          // merged index: source points first (:132, :155)
+    return i < n_src ? tf_point(job.src[i], Tsrc) : tf_point(job.ref[i - n_src], Tref);
+  };
+  // ---- 1. bounding box of the merged cloud ------------------------------------------------------
+  float mnx = FLT_MAX, mny = FLT_MAX, mxx = -FLT_MAX, mxy = -FLT_MAX;
+  for (int i = tid; i < n; i += kCoralThreads) {
+    const float2 p = point(i);
+    mnx = fminf(mnx, p.x); mxx = fmaxf(mxx, p.x);
+    mny = fminf(mny, p.y); mxy = fmaxf(mxy, p.y);
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    mnx = fminf(mnx, __shfl_xor(mnx, o)); mxx = fmaxf(mxx, __shfl_xor(mxx, o));
+    mny = fminf(mny, __shfl_xor(mny, o)); mxy = fmaxf(mxy, __shfl_xor(mxy, o));
+  }
+  if (lane == 0) { red_f[0][wave] = mnx; red_f[1][wave] = mxx; red_f[2][wave] = mny; red_f[3][wave] = mxy; }
+  __syncthreads();
+  mnx = red_f[0][0]; mxx = red_f[1][0]; mny = red_f[2][0]; mxy = red_f[3][0];
+  for (int wv = 1; wv < 16; wv++) {
+    mnx = fminf(mnx, red_f[0][wv]); mxx = fmaxf(mxx, red_f[1][wv]);
+    mny = fminf(mny, red_f[2][wv]); mxy = fmaxf(mxy, red_f[3][wv]);
+  }
+  const int min_bx = (int)floorf(mnx * cm.inv_cell), max_bx = (int)floorf(mxx * cm.inv_cell);
+  const int min_by = (int)floorf(mny * cm.inv_cell), max_by = (int)floorf(mxy * cm.inv_cell);
+  const long long div_bx = (long long)max_bx - min_bx + 1, div_by = (long long)max_by - min_by + 1;
+  if (!(mnx == mnx) || !(mny == mny) || div_bx * div_by > 0x7fffffffLL || div_by > kCoralMaxGridRows) {
+    fail_job(cm, CFEAR_ERR_CAPACITY);
+    return;
+  }
+  const int dbx = (int)div_bx, dby = (int)div_by;
+  auto cell_xy = [&](float2 p, int& ix, int& iy) {
+    ix = (int)(floorf(p.x * cm.inv_cell) - (float)min_bx);
+    iy = (int)(floorf(p.y * cm.inv_cell) - (float)min_by);
+  };
+  // ---- 2. sort by (cell, index) ------------------------------------------------------------------
+  unsigned long long* keys = (unsigned long long*)smem;
+  const int npad = grid_sort_block(smem, n, (long long)dbx * dby, red_i, [&](int i) {
+    int ix, iy;
+    cell_xy(point(i), ix, iy);
+    return (uint32_t)(ix + iy * dbx);
+  });
+  // ---- 3. sorted points -> scratch; cell table (key, start) -> LDS ---------------------------------
+  const int per = npad / kCoralThreads;                 // 1..16 consecutive sorted elements per thread
+  unsigned long long mine[kCoralPerThread];
+  const unsigned prev_cell = (tid * per > 0) ? (unsigned)(keys[tid * per - 1] >> 32) : 0xFFFFFFFFu;
+  int heads = 0;
+#pragma unroll
+  for (int q = 0; q < kCoralPerThread; q++) {
+    const int e = tid * per + q;
+    mine[q] = (q < per && e < n) ? keys[e] : ~0ull;
+  }
+  {
+    unsigned pv = prev_cell;
+#pragma unroll
+    for (int q = 0; q < kCoralPerThread; q++) {
+      const int e = tid * per + q;
+      if (q < per && e < n) {
+        const unsigned vx = (unsigned)(mine[q] >> 32);
+        heads += (e == 0 || vx != pv);
+        pv = vx;
+      }
+    }
+  }
+  const int incl = wave_incl_scan_i32(heads);
+  if (lane == 63) red_i[wave] = incl;
+  __syncthreads();                                      // also: every thread has read its keys
+  int voff = incl - heads;
+  for (int wv = 0; wv < wave; wv++) voff += red_i[wv];
+  int V = 0;
+  for (int wv = 0; wv < 16; wv++) V += red_i[wv];
+  const size_t Vp = ((size_t)V + 4) & ~(size_t)3;
+  uint32_t* cell_key = (uint32_t*)smem;                 // [V]
+  int32_t* cell_start = (int32_t*)(smem + Vp * 4);      // [V + 1]
+  int32_t* rowbeg = (int32_t*)(smem + kCoralRowbegOff); // [dby + 1]
+  {
+    unsigned pv = prev_cell;
+    int ord = voff;
+#pragma unroll
+    for (int q = 0; q < kCoralPerThread; q++) {
+      const int e = tid * per + q;
+      if (q < per && e < n) {
+        const unsigned vx = (unsigned)(mine[q] >> 32);
+        const int idx = (int)(unsigned)(mine[q] & 0xFFFFFFFFu);
+        if (e == 0 || vx != pv) { cell_key[ord] = vx; cell_start[ord] = e; ord++; }
+        pv = vx;
+        const float2 p = point(idx);
+        const float inten = idx < n_src ? job.src[idx].w : job.ref[idx - n_src].w;
+        spt[e] = make_float4(p.x, p.y, inten, __int_as_float(idx));
+      }
+    }
+  }
+  if (tid == 0) cell_start[V] = n;
+  __syncthreads();
+  for (int y = tid; y <= dby; y += kCoralThreads)
+    rowbeg[y] = lower_bound_u32(cell_key, 0, V, (uint32_t)((long long)y * dbx));
+  __threadfence_block();
+  __syncthreads();
+  // ---- 4. one lane per merged point: moments of its source / reference neighbours -> entropies ----
+  for (int e = tid; e < n; e += kCoralThreads) {
+    const float4 q = spt[e];
+    const int idx = __float_as_int(q.w);
+    const bool q_is_src = idx < n_src;
+    int ix, iy;
+    cell_xy(make_float2(q.x, q.y), ix, iy);
+    const int x0 = max(ix - 1, 0), x1 = min(ix + 1, dbx - 1);
+    Moments ms{0, 0, 0, 0, 0, 0}, mr{0, 0, 0, 0, 0, 0};
+    const double qx = (double)q.x, qy = (double)q.y;
+    for (int yy = max(iy - 1, 0); yy <= min(iy + 1, dby - 1); yy++) {
+      const uint32_t klo = (uint32_t)(yy * dbx + x0), khi = (uint32_t)(yy * dbx + x1);
+      const int a = lower_bound_u32(cell_key, rowbeg[yy], rowbeg[yy + 1], klo);
+      const int b = upper_bound_u32(cell_key, rowbeg[yy], rowbeg[yy + 1], khi);
+      const int p0 = cell_start[a], p1 = cell_start[b];
+      for (int p = p0; p < p1; p++) {
+        const float4 c = spt[p];
+        const float dxf = __fsub_rn(q.x, c.x), dyf = __fsub_rn(q.y, c.y);
+        const float d2 = __fadd_rn(__fmul_rn(dxf, dxf), __fmul_rn(dyf, dyf));  // FLANN L2_Simple
+        if (d2 < cm.r2) {                                                       // RadiusResultSet: strict <
+          const double dx = (double)c.x - qx, dy = (double)c.y - qy;
+          Moments& m = (__float_as_int(c.w) < n_src) ? ms : mr;
+          m.n++; m.sx += dx; m.sy += dy; m.sxx += dx * dx; m.sxy += dx * dy; m.syy += dy * dy;
+        }
+      }
+    }
+    double jr = 100.0, sr = 100.0, w = 0.0;
+    int valid = 0;
+    const Moments& own = q_is_src ? ms : mr;
+    const Moments& other = q_is_src ? mr : ms;
+    if (other.n >= 1) {                                                         // overlap_req_ = 1 (:138, :160)
+      const Moments mj{ms.n + mr.n, ms.sx + mr.sx, ms.sy + mr.sy, ms.sxx + mr.sxx, ms.sxy + mr.sxy, ms.syy + mr.syy};
+      double s00, s01, s11, j00, j01, j11;
+      if (cov_from_moments(own, s00, s01, s11) && cov_from_moments(mj, j00, j01, j11)) {
+        const double det_j = j00 * j11 - j01 * j01;                             // ComputeEntropy (:80-98)
+        const double det_s = s00 * s11 - s01 * s01;
+        if (!(isnan(det_s) || isnan(det_j))) {
+          const double sep_entropy = 1.0 / 2.0 * log(2.0 * M_PI * exp(1.0) * det_s + 0.00000001);
+          const double joint_entropy = 1.0 / 2.0 * log(2.0 * M_PI * exp(1.0) * det_j + 0.00000001);
+          if (!(isnan(sep_entropy) || isnan(joint_entropy))) {
+            w = cm.weight_res_intensity ? (double)q.z : 1.0;                    // :180
+            jr = w * joint_entropy; sr = w * sep_entropy; valid = 1;
+          }
+        }
+      }
+    }
+    jres[idx] = jr; sres[idx] = sr; wres[idx] = valid ? w : 0.0; vres[idx] = valid;
+  }
+  __threadfence_block();
+  __syncthreads();
+  // ---- 5. aggregation in index order (:178-204): contiguous chunk per thread, then a fixed tree ------
+  {
+    const int chunk = (n + kCoralThreads - 1) / kCoralThreads;
+    double sj = 0.0, ss = 0.0, sw = 0.0;
+    int cnt = 0;
+    for (int i = tid * chunk; i < min(n, (tid + 1) * chunk); i++)
+      if (vres[i]) { sw += wres[i]; sj += jres[i]; ss += sres[i]; cnt++; }
+    sj = wave_sum_lane63_f64(sj); ss = wave_sum_lane63_f64(ss); sw = wave_sum_lane63_f64(sw);
+    cnt = wave_sum_i32(cnt);
+    if (lane == 63) { red_d[wave * 3] = sj; red_d[wave * 3 + 1] = ss; red_d[wave * 3 + 2] = sw; red_c[wave] = cnt; }
+    __syncthreads();
+    if (tid == 0) {
+      double joint = 0.0, sep = 0.0, w_sum = 0.0;
+      int count_valid = 0;
+      for (int wv = 0; wv < 16; wv++) { joint += red_d[wv * 3]; sep += red_d[wv * 3 + 1]; w_sum += red_d[wv * 3 + 2]; count_valid += red_c[wv]; }
+      if (count_valid > 0) { sep /= w_sum; joint /= w_sum; }
+      const double overlap = count_valid / ((double)n);
+      cfear_coral_result& r = cm.results[blockIdx.x];
+      r.joint = joint; r.sep = sep; r.overlap = overlap;                        // quality_ = {joint_, sep_, overlap_}
+      r.valid = overlap < 0.1 ? 0 : 1;                                          // :197-204
+      r.count_valid = count_valid; r.status = CFEAR_OK; r.pad = 0;
+    }
+  }
+  if (cm.per_point) {
+    double* pp = cm.per_point + (size_t)blockIdx.x * cm.cap * 3;
+    for (int i = tid; i < n; i += kCoralThreads) { pp[3 * i] = jres[i]; pp[3 * i + 1] = sres[i]; pp[3 * i + 2] = (double)vres[i]; }
+  }
+}
+
+}  // namespace
+
+extern "C" void cfear_coral_params_default(cfear_coral_params* p) {
+  if (!p) return;
+  p->radius = 1.0;                    // alignmentinterface.cpp:444
+  p->weight_res_intensity = 0;
+  p->pad = 0;
+}
+
+extern "C" int cfear_coral_quality_batch(cfear_ctx* ctx, const cfear_coral_job* jobs, int32_t n_jobs,
+                                         const cfear_coral_params* par, cfear_coral_result* results, double* per_point) {
+  if (!ctx) return CFEAR_ERR_INVALID_ARGUMENT;
+  if (!jobs || !par || !results || n_jobs < 0) return cfear_set_error(ctx, CFEAR_ERR_INVALID_ARGUMENT, "null argument");
+  if (!(par->radius > 0.0)) return cfear_set_error(ctx, CFEAR_ERR_INVALID_ARGUMENT, "radius must be > 0");
+  if (n_jobs == 0) return CFEAR_OK;
+  CFEAR_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  // stage host clouds once each (perturbation sets and candidate lists share clouds)
+  std::map<const float*, size_t> staged;                 // host pointer -> offset (floats) in the staging buffer
+  size_t stage_floats = 0;
+  int cap = 1;
+  for (int j = 0; j < n_jobs; j++) {
+    const cfear_coral_job& jb = jobs[j];
+    if (!jb.ref_xyzi || !jb.src_xyzi || jb.n_ref < 0 || jb.n_src < 0)
+      return cfear_set_error(ctx, CFEAR_ERR_INVALID_ARGUMENT, "job %d: null cloud", j);
+    if ((long long)jb.n_ref + jb.n_src > kCoralMaxPoints)
+      return cfear_set_error(ctx, CFEAR_ERR_CAPACITY, "job %d: %d + %d points exceed %d", j, jb.n_ref, jb.n_src, kCoralMaxPoints);
+    cap = std::max(cap, jb.n_ref + jb.n_src);
+    const float* ptrs[2] = {jb.ref_xyzi, jb.src_xyzi};
+    const int ns[2] = {jb.n_ref, jb.n_src};
+    for (int c = 0; c < 2; c++)
+      if (!cfear_is_device_ptr(ptrs[c]) && !staged.count(ptrs[c])) {
+        staged[ptrs[c]] = stage_floats;
+        stage_floats += ((size_t)ns[c] * 4 + 3) & ~(size_t)3;
+      }
+  }
+  float* d_stage = nullptr;
+  if (stage_floats) {
+    d_stage = (float*)cfear_workspace(ctx, 8, stage_floats * 4);
+    if (!d_stage) return cfear_set_error(ctx, CFEAR_ERR_HIP, "workspace allocation failed");
+    std::map<const float*, int> len;
+    for (int j = 0; j < n_jobs; j++) { len[jobs[j].ref_xyzi] = jobs[j].n_ref; len[jobs[j].src_xyzi] = jobs[j].n_src; }
+    for (auto& kv : staged)
+      if (len[kv.first] > 0)
+        CFEAR_HIP_CHECK(ctx, hipMemcpyAsync(d_stage + kv.second, kv.first, (size_t)len[kv.first] * 16, hipMemcpyHostToDevice, ctx->stream));
+  }
+  std::vector<CoralJob> hj(n_jobs);
+  for (int j = 0; j < n_jobs; j++) {
+    const cfear_coral_job& jb = jobs[j];
+    CoralJob& o = hj[j];
+    o.ref = (const float4*)(staged.count(jb.ref_xyzi) ? d_stage + staged[jb.ref_xyzi] : jb.ref_xyzi);
+    o.src = (const float4*)(staged.count(jb.src_xyzi) ? d_stage + staged[jb.src_xyzi] : jb.src_xyzi);
+    o.n_ref_ptr = o.n_src_ptr = nullptr;
+    o.n_ref = jb.n_ref; o.n_src = jb.n_src;
+    for (int k = 0; k < 3; k++) { o.ref_pose[k] = jb.ref_pose[k]; o.src_pose[k] = jb.src_pose[k]; o.offset[k] = jb.offset[k]; }
+  }
+  CoralCommon cm;
+  cm.radius = par->radius;
+  cm.r2 = (float)(par->radius * par->radius);            // radiusSearch passes float(radius * radius) to FLANN
+  cm.inv_cell = (float)(1.0 / (par->radius * 1.0001));   // cell a hair wider than the radius: float rounding of
+                                                         // x * inv_cell can never put a neighbour two cells away
+  cm.weight_res_intensity = par->weight_res_intensity;
+  cm.cap = cap;
+  cm.scratch_stride = coral_scratch_bytes(cap);
+  // scratch bounded to 1 GiB per launch
+  const int chunk = (int)std::max<size_t>(1, std::min<size_t>((size_t)n_jobs, ((size_t)1 << 30) / cm.scratch_stride));
+  const size_t jb_bytes = (size_t)n_jobs * sizeof(CoralJob), rb = (size_t)n_jobs * sizeof(cfear_coral_result);
+  const size_t pp_bytes = per_point ? (size_t)n_jobs * cap * 3 * sizeof(double) : 0;
+  char* ws = (char*)cfear_workspace(ctx, 9, (jb_bytes + 255) / 256 * 256 + (rb + 255) / 256 * 256 + pp_bytes + 512);
+  char* scr = (char*)cfear_workspace(ctx, 10, cm.scratch_stride * (size_t)chunk);
+  if (!ws || !scr) return cfear_set_error(ctx, CFEAR_ERR_HIP, "workspace allocation failed");
+  CoralJob* d_jobs = (CoralJob*)ws;
+  cfear_coral_result* d_res = (cfear_coral_result*)(ws + (jb_bytes + 255) / 256 * 256);
+  double* d_pp = per_point ? (double*)((char*)d_res + (rb + 255) / 256 * 256) : nullptr;
+  cm.scratch = scr;
+  CFEAR_HIP_CHECK(ctx, hipMemcpyAsync(d_jobs, hj.data(), jb_bytes, hipMemcpyHostToDevice, ctx->stream));
+  CFEAR_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)coral_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  {
+    ProfScope ps(ctx, "coral_quality");
+    for (int j0 = 0; j0 < n_jobs; j0 += chunk) {
+      const int nj = std::min(chunk, n_jobs - j0);
+      cm.results = d_res + j0;
+      cm.per_point = d_pp ? d_pp + (size_t)j0 * cap * 3 : nullptr;
+      hipLaunchKernelGGL(coral_kernel, dim3(nj), dim3(kCoralThreads), kCoralLdsTotal, ctx->stream, d_jobs + j0, cm);
+    }
+  }
+  CFEAR_HIP_CHECK(ctx, hipGetLastError());
+  CFEAR_HIP_CHECK(ctx, hipMemcpyAsync(results, d_res, rb, hipMemcpyDeviceToHost, ctx->stream));
+  std::vector<double> hpp;
+  if (per_point) {
+    hpp.resize((size_t)n_jobs * cap * 3);
+    CFEAR_HIP_CHECK(ctx, hipMemcpyAsync(hpp.data(), d_pp, pp_bytes, hipMemcpyDeviceToHost, ctx->stream));
+  }
+  CFEAR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  if (per_point) {                                       // compact [job][n_src + n_ref][3]
+    size_t o = 0;
+    for (int j = 0; j < n_jobs; j++) {
+      const size_t nn = (size_t)jobs[j].n_ref + jobs[j].n_src;
+      std::copy(hpp.begin() + (size_t)j * cap * 3, hpp.begin() + (size_t)j * cap * 3 + nn * 3, per_point + o);
+      o += nn * 3;
+    }
+  }
+  for (int j = 0; j < n_jobs; j++)
+    if (results[j].status != CFEAR_OK && results[j].status != CFEAR_ERR_EMPTY_CLOUD)
+      return cfear_set_error(ctx, results[j].status, "job %d: %s", j, cfear_status_string(results[j].status));
+  return CFEAR_OK;
+}
+
+extern "C" int cfear_coral_quality(cfear_ctx* ctx, const cfear_coral_job* job, const cfear_coral_params* par,
+                                   cfear_coral_result* result, double* per_point) {
+  return cfear_coral_quality_batch(ctx, job, 1, par, result, per_point);
+}

@@ -1,0 +1,73 @@
+"""GPU: CorAl alignment quality (AlignmentQuality.cpp:8-230) through the C-ABI vs the CPU oracle.
+
+Integer outcomes (per-point validity, count_valid, valid_) must be identical.  Entropies are
+1/2 log(2 pi e det + 1e-8) of a 2x2 covariance whose determinant cancels for near-collinear
+neighbourhoods, so individual points agree to 1e-6 absolute (the same spread separates the oracle from
+NumPy, tests/test_oracle_coral.py); the aggregated quality {joint, sep, overlap} agrees to rtol 1e-8."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from tests.test_oracle_coral import _peaks, _rel   # noqa: E402
+
+
+def _check(ref, src, rp, sp, off, radius=1.0, weight=False):
+    from oracle import pyoracle as O
+    from tbv_slam_public_amd import api
+    q = api.CorAlRadarQuality(ref, rp, src, sp, off, radius, weight, want_per_point=True)
+    ok, eq, pp = O.coral_quality(ref, src, rp, sp, off, radius, weight)
+    got = q.per_point
+    np.testing.assert_array_equal(got[:, 2], pp[:, 2])
+    v = pp[:, 2] > 0
+    assert q.count_valid == int(v.sum())
+    np.testing.assert_allclose(got[v, 0], pp[v, 0], rtol=1e-9, atol=1e-6)
+    np.testing.assert_allclose(got[v, 1], pp[v, 1], rtol=1e-9, atol=1e-6)
+    np.testing.assert_array_equal(got[~v, :2], 100.0)
+    np.testing.assert_allclose(q.GetQualityMeasure(), eq, rtol=1e-8, atol=1e-12)
+    assert q.valid_ == ok
+    return q
+
+
+@pytest.mark.parametrize("k,frames", [(12, (0, 2)), (40, (1, 2))])
+def test_coral_matches_oracle_aligned_and_perturbed(k, frames):
+    clouds, gt = _peaks(8, list(frames), k=k)
+    sp = _rel(gt[frames[0]], gt[frames[1]])
+    # aligned + the perturbation set of the training interface (alignmentinterface.cpp:479-495)
+    for off in [(0, 0, 0), (0.5, 0, 0.0087), (0, -1.0, 0.035), (2.0, 0, 0.26), (-2.0, 2.0, -0.26)]:
+        _check(clouds[0], clouds[1], np.zeros(3), sp, off)
+
+
+def test_coral_radius_weight_and_world_poses():
+    clouds, gt = _peaks(10, [0, 1, 3])
+    # both scans placed with world poses; radius 0.6; intensity weighting
+    _check(clouds[1], clouds[2], gt[1], gt[3], (0.2, -0.1, 0.01), radius=0.6)
+    _check(clouds[0], clouds[2], gt[0], gt[3], (0, 0, 0), radius=1.0, weight=True)
+
+
+def test_coral_batch_shares_clouds_and_handles_no_overlap():
+    from oracle import pyoracle as O
+    from tbv_slam_public_amd import api
+    clouds, gt = _peaks(11, [0, 1, 2])
+    rng = np.random.default_rng(0)
+    jobs = []
+    for a, b in [(0, 1), (0, 2), (1, 2)]:
+        for _ in range(4):
+            jobs.append((clouds[a], gt[a], clouds[b], gt[b], rng.normal(0, [0.5, 0.5, 0.02])))
+    jobs.append((clouds[0], gt[0], clouds[1], gt[1] + np.array([500.0, 0, 0]), (0, 0, 0)))     # disjoint
+    out, _ = api.coral_quality_batch(jobs)
+    for (rc, rp, sc, sp, off), r in zip(jobs, out):
+        ok, eq, _ = O.coral_quality(rc, sc, rp, sp, off, 1.0)
+        np.testing.assert_allclose([r["joint"], r["sep"], r["overlap"]], eq, rtol=1e-8, atol=1e-12)
+        assert bool(r["valid"]) == ok
+    assert out[-1]["overlap"] == 0.0 and out[-1]["valid"] == 0 and out[-1]["count_valid"] == 0
+
+
+def test_coral_device_clouds():
+    import torch
+    from tbv_slam_public_amd import api
+    clouds, gt = _peaks(12, [0, 1])
+    sp = _rel(gt[0], gt[1])
+    host = api.CorAlRadarQuality(clouds[0], np.zeros(3), clouds[1], sp)
+    dev = api.CorAlRadarQuality(torch.from_numpy(clouds[0]).cuda(), np.zeros(3), torch.from_numpy(clouds[1]).cuda(), sp)
+    assert host.GetQualityMeasure() == dev.GetQualityMeasure() and host.valid_ == dev.valid_
