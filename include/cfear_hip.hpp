@@ -175,6 +175,34 @@ class n_scan_normal_reg {
 
 }  // namespace CFEAR_Radarodometry
 
+// CorAlRadarQuality (coral_alignment_quality AlignmentQuality.cpp:99-230) over two peak clouds.
+namespace CorAlignment {
+class CorAlRadarQuality {
+ public:
+  CorAlRadarQuality(CFEAR_Radarodometry::Context& ctx, const CFEAR_Radarodometry::PointCloud& ref,
+                    const CFEAR_Radarodometry::Pose2d& ref_pose, const CFEAR_Radarodometry::PointCloud& src,
+                    const CFEAR_Radarodometry::Pose2d& src_pose,
+                    const CFEAR_Radarodometry::Pose2d& Toffset = CFEAR_Radarodometry::Pose2d{0, 0, 0}, double radius = 1.0,
+                    bool weight_res_intensity = false) {
+    cfear_coral_job j{};
+    j.ref_xyzi = &ref[0].x; j.src_xyzi = &src[0].x;
+    j.n_ref = (int32_t)ref.size(); j.n_src = (int32_t)src.size();
+    j.ref_pose[0] = ref_pose.x; j.ref_pose[1] = ref_pose.y; j.ref_pose[2] = ref_pose.theta;
+    j.src_pose[0] = src_pose.x; j.src_pose[1] = src_pose.y; j.src_pose[2] = src_pose.theta;
+    j.offset[0] = Toffset.x; j.offset[1] = Toffset.y; j.offset[2] = Toffset.theta;
+    cfear_coral_params p;
+    cfear_coral_params_default(&p);
+    p.radius = radius; p.weight_res_intensity = weight_res_intensity ? 1 : 0;
+    ctx.check(cfear_coral_quality(ctx.get(), &j, &p, &res_, nullptr));
+    valid_ = res_.valid != 0;
+  }
+  std::vector<double> GetQualityMeasure() const { return {res_.joint, res_.sep, res_.overlap}; }
+  bool valid_ = false;
+ private:
+  cfear_coral_result res_{};
+};
+}  // namespace CorAlignment
+
 #if defined(__has_include)
 #if __has_include(<Eigen/Geometry>)
 #include <Eigen/Geometry>

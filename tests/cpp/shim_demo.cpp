@@ -1,7 +1,7 @@
 // A C++ caller of libcfear_hip.so through the header-only mirror of the reference classes
 // (include/cfear_hip.hpp).  Reads a raw uint8 polar image pair [2][rows][cols] from argv[1], registers
 // frame 1 against frame 0 (P2L, loop-closure settings 4 x 10) and prints the result as one line:
-//   n_points0 n_points1 n_cells0 n_cells1 ok x y theta score cov_ok cov_xx cov_yy cov_tt
+//   n_points0 n_points1 n_cells0 n_cells1 ok x y theta score cov_ok cov_xx cov_yy cov_tt coral_valid joint sep overlap
 // (the last four: covariance by cost sampling with the loop-closure constants, loopclosure.cpp:108-112)
 #include <cstdio>
 #include <cstdlib>
@@ -23,9 +23,10 @@ int main(int argc, char** argv) {
     radarDriver::Parameters p;
     p.k_strongest = 40;
     radarDriver driver(ctx, p);
-    PointCloud c0, c1, pk;
-    driver.CallbackOffline(img.data(), rows, cols, cols, c0, pk);
-    driver.CallbackOffline(img.data() + (size_t)rows * cols, rows, cols, cols, c1, pk);
+    PointCloud c0, c1;
+    PointCloud pk0, pk1;
+    driver.CallbackOffline(img.data(), rows, cols, cols, c0, pk0);
+    driver.CallbackOffline(img.data() + (size_t)rows * cols, rows, cols, cols, c1, pk1);
     MapPointNormal m0(ctx, c0, 3.0f, 0, 0, true), m1(ctx, c1, 3.0f, 0, 0, true);
     n_scan_normal_reg reg(ctx, CFEAR_P2L);
     reg.SetParameters(4, 10);
@@ -36,8 +37,12 @@ int main(int argc, char** argv) {
     cfear_cov_sampling_params_default(&sp);
     sp.xy_range = 0.4; sp.yaw_range = 0.0044;
     const bool cov_ok = reg.approximateCovarianceBySampling({&m0, &m1}, T, cov, &sp);
-    printf("%zu %zu %zu %zu %d %.12g %.12g %.12g %.12g %d %.12g %.12g %.12g\n", c0.size(), c1.size(), m0.GetSize(),
-           m1.GetSize(), ok ? 1 : 0, T[1].x, T[1].y, T[1].theta, reg.getScore(), cov_ok ? 1 : 0, cov[0], cov[7], cov[35]);
+    // loop-closure verification feature: CorAl quality of the two peak clouds at the registered pose
+    CorAlignment::CorAlRadarQuality coral(ctx, pk0, T[0], pk1, T[1]);
+    const std::vector<double> q = coral.GetQualityMeasure();
+    printf("%zu %zu %zu %zu %d %.12g %.12g %.12g %.12g %d %.12g %.12g %.12g %d %.12g %.12g %.12g\n", c0.size(), c1.size(),
+           m0.GetSize(), m1.GetSize(), ok ? 1 : 0, T[1].x, T[1].y, T[1].theta, reg.getScore(), cov_ok ? 1 : 0, cov[0], cov[7],
+           cov[35], coral.valid_ ? 1 : 0, q[0], q[1], q[2]);
   } catch (const CfearError& e) {
     fprintf(stderr, "cfear error %d: %s\n", e.status, e.what());
     return 1;

@@ -61,3 +61,11 @@ def test_cpp_mirror_matches_oracle(tmp_path):
     assert int(v[9]) == int(cok)
     if cok:
         np.testing.assert_allclose([float(x) for x in v[10:13]], [cov[0, 0], cov[1, 1], cov[5, 5]], rtol=1e-4)
+    # CorAl quality of the two peak clouds at the registered pose (the driver's second output cloud)
+    pk = []
+    for f in range(2):
+        sr, si, sc = O.kstrongest(imgs[f], 40, 60)
+        pk.append(O.kstrongest_cloud(sr, si, sc, 0.0438, 2.5, mask=O.peaks(imgs[f], 40, sr, sc)))
+    qok, q, _ = O.coral_quality(pk[0], pk[1], np.zeros(3), got, (0, 0, 0), 1.0)
+    assert int(v[13]) == int(qok)
+    np.testing.assert_allclose([float(x) for x in v[14:17]], q, rtol=1e-7)
