@@ -488,6 +488,27 @@ class CorAlRadarQuality:
         return list(self.quality_)
 
 
+def _compose_xyt(a, b):
+    """Eigen Affine3d product of two planar poses (x, y, theta): a * b."""
+    c, s = np.cos(a[2]), np.sin(a[2])
+    return np.array([c * b[0] - s * b[1] + a[0], s * b[0] + c * b[1] + a[1], a[2] + b[2]], np.float64)
+
+
+def cfear_quality_batch(jobs, method="P2L", ctx=None):
+    """CFEARQuality (AlignmentQuality.cpp:330-354) for a list of (ref_scan, ref_pose, src_scan, src_pose, Toffset):
+    a fresh n_scan_normal_reg(method, Huber, 0.3).GetCost on {ref, src} at {T_ref, T_src * Toffset}, one launch.
+    -> float64 [n, 3] quality_ = {cost, #residuals, (N_src + N_ref) / 2} ({0, 0, 0} where GetCost fails)."""
+    reg = n_scan_normal_reg(method, "Huber", 0.3, 0, ctx=ctx)
+    gj = [([rs, ss], np.stack([np.asarray(rp, np.float64), _compose_xyt(np.asarray(sp, np.float64), np.asarray(off, np.float64))]))
+          for rs, rp, ss, sp, off in jobs]
+    out = reg.GetCostBatch(gj)
+    q = np.zeros((len(jobs), 3), np.float64)
+    for i, ((rs, _rp, ss, _sp, _off), r) in enumerate(zip(jobs, out)):
+        if r["status"] == L.OK:
+            q[i] = [r["final_cost"], r["num_residuals"], (ss.GetSize() + rs.GetSize()) / 2.0]
+    return q
+
+
 def coral_quality_batch(jobs, radius=1.0, weight_res_intensity=False, want_per_point=False, ctx=None):
     """jobs: list of (ref_cloud, ref_pose, src_cloud, src_pose, Toffset).  One launch.
     -> (CORAL_RESULT_DTYPE array, per-point list or None)."""
