@@ -53,7 +53,30 @@ def main():
         out[name + "_weights"] = w
     np.savez_compressed(os.path.join(HERE, "registration.npz"), cloud0=clouds[0], cloud1=clouds[1], cloud2=clouds[2],
                         mot=mot, comp1=comp, cells0=cells[0], cells1=cells[1], cells2=cells[2], poses=poses, **out)
-    for f in ("filters.npz", "registration.npz"):
+    # ---- verification features: covariance by cost sampling + CorAl / CFEAR alignment quality ---------------
+    ver = {}
+    for name, kw, mo, mi in [("p2l_4x10", dict(cost="P2L"), 4, 10), ("p2p_w4", dict(cost="P2P", weight_opt=4), 8, 20)]:
+        par = O.reg_params(max_outer=mo, max_inner=mi, **kw)
+        ok, p, r = O.register(cells, poses, par)
+        par.first_itr = r.outer_iters
+        cok, cov, smp = O.cov_by_sampling(cells, p, par, r.final_cost, r.num_residuals, 0.4, 0.0043625, 3, 4.0)
+        ver[name + "_cov_ok"] = np.array([cok, r.outer_iters, r.num_residuals], np.int64)
+        ver[name + "_cov"] = cov
+        ver[name + "_samples"] = smp
+        ver[name + "_reg"] = np.array([r.final_cost] + list(p[-1]))
+    peaks = []
+    for f in range(2):
+        a, b, c = O.kstrongest(imgs[f], 40, 60)
+        peaks.append(O.kstrongest_cloud(a, b, c, 0.0438, 2.5, mask=O.peaks(imgs[f], 40, a, c)))
+    offs = np.array([[0, 0, 0], [0.5, 0, 0.0087], [0, -2.0, 0.26]])
+    src_pose = np.array([2.45, 0.03, 0.011])
+    cq, cv = [], []
+    for o in offs:
+        okq, q, _ = O.coral_quality(peaks[0], peaks[1], np.zeros(3), src_pose, o, 1.0)
+        cq.append(q); cv.append(okq)
+    np.savez_compressed(os.path.join(HERE, "verification.npz"), peaks0=peaks[0], peaks1=peaks[1], offsets=offs,
+                        src_pose=src_pose, coral_quality=np.array(cq), coral_valid=np.array(cv), **ver)
+    for f in ("filters.npz", "registration.npz", "verification.npz"):
         print(f, os.path.getsize(os.path.join(HERE, f)) // 1024, "KiB")
 
 

@@ -92,3 +92,51 @@ def test_hip_registration_golden(reg):
         np.testing.assert_array_equal(pairs, reg[name + "_pairs"])
         np.testing.assert_allclose(w, reg[name + "_weights"], rtol=1e-9)
         okc, cost, res = r.GetCost(m, reg["poses"])
+
+
+@pytest.fixture(scope="module")
+def ver():
+    return np.load(os.path.join(HERE, "golden", "verification.npz"))
+
+
+def _golden_cells(reg):
+    return [reg["cells%d" % i] for i in range(3)]
+
+
+def test_oracle_verification_golden(reg, ver):
+    from oracle import pyoracle as O
+    cells = _golden_cells(reg)
+    for name, kw, mo, mi in CASES[:2]:
+        par = O.reg_params(max_outer=mo, max_inner=mi, **kw)
+        ok, p, r = O.register(cells, reg["poses"], par)
+        par.first_itr = r.outer_iters
+        cok, cov, smp = O.cov_by_sampling(cells, p, par, r.final_cost, r.num_residuals, 0.4, 0.0043625, 3, 4.0)
+        np.testing.assert_array_equal([cok, r.outer_iters, r.num_residuals], ver[name + "_cov_ok"])
+        np.testing.assert_allclose(smp, ver[name + "_samples"], rtol=1e-12)
+        np.testing.assert_allclose(cov, ver[name + "_cov"], rtol=1e-7, atol=1e-15)
+    for o, q, v in zip(ver["offsets"], ver["coral_quality"], ver["coral_valid"]):
+        okq, got, _ = O.coral_quality(ver["peaks0"], ver["peaks1"], np.zeros(3), ver["src_pose"], o, 1.0)
+        np.testing.assert_allclose(got, q, rtol=1e-12)
+        assert okq == bool(v)
+
+
+@pytest.mark.gpu
+def test_hip_verification_golden(reg, ver):
+    from tbv_slam_public_amd import api
+    scans = [api.MapPointNormal(cells=c) for c in _golden_cells(reg)]
+    for name, kw, mo, mi in CASES[:2]:
+        r = api.n_scan_normal_reg(kw["cost"], "Huber", 0.1, kw.get("weight_opt", 0))
+        r.SetParameters(mo, mi)
+        ok, pg, _ = r.Register(scans, reg["poses"])
+        assert ok and r.summary_.outer_iters == ver[name + "_cov_ok"][1] and r.summary_.num_residuals == ver[name + "_cov_ok"][2]
+        cok, cov, smp = r.approximateCovarianceBySampling(scans, pg, want_samples=True)
+        assert int(cok) == ver[name + "_cov_ok"][0]
+        np.testing.assert_array_equal(smp[:, :3], ver[name + "_samples"][:, :3])
+        np.testing.assert_allclose(smp[:, 3], ver[name + "_samples"][:, 3], rtol=1e-9)
+        if cok:
+            idx = np.ix_([0, 1, 5], [0, 1, 5])
+            np.testing.assert_allclose(cov[idx], ver[name + "_cov"][idx], rtol=1e-4)
+    jobs = [(ver["peaks0"], np.zeros(3), ver["peaks1"], ver["src_pose"], o) for o in ver["offsets"]]
+    out, _ = api.coral_quality_batch(jobs)
+    np.testing.assert_allclose(np.stack([out["joint"], out["sep"], out["overlap"]], 1), ver["coral_quality"], rtol=1e-8)
+    np.testing.assert_array_equal(out["valid"].astype(bool), ver["coral_valid"].astype(bool))
