@@ -134,3 +134,59 @@ def test_invalid_arguments_return_status():
     assert e.value.status == L.ERR_INVALID_ARGUMENT
     with pytest.raises(L.CfearError):
         api.filter_kstrongest(np.zeros((4, 9000), np.uint8), 12, 60, 0.0438, 2.5)
+
+
+@pytest.mark.parametrize("k,z_min,cols", [(200, 200, 512), (1024, 215, 4096), (300, 250, 8192)])
+def test_kstrongest_large_k_between_64_and_k_candidates(k, z_min, cols):
+    """More than 64 candidates but not more than k: every candidate survives, compacted by the per-lane
+    loops instead of the one-candidate-per-lane scatter."""
+    from tbv_slam_public_amd import synth
+    img = synth.uniform_v1(5, rows=6, cols=cols)[0]
+    cnt = (img >= z_min).sum(1)
+    assert ((cnt > 64) & (cnt <= k)).any()
+    _check(img, k, z_min)
+
+
+def test_kstrongest_more_images_than_grid_rows():
+    """batch > 65535 images: the launch is split over gridDim.y chunks (tiny images keep this cheap)."""
+    from oracle import pyoracle as O
+    from tbv_slam_public_amd import api
+    rng = np.random.default_rng(2)
+    imgs = rng.integers(0, 256, (65535 + 70, 2, 48), dtype=np.uint8)
+    r = api.filter_kstrongest(imgs, 5, 100, 0.0438, 0.0)
+    for b in (0, 1, 65534, 65535, 65536, imgs.shape[0] - 1):
+        sr, si, sc = O.kstrongest(imgs[b], 5, 100)
+        np.testing.assert_array_equal(r["sel_range"][b], sr)
+        np.testing.assert_array_equal(r["sel_intensity"][b], si)
+        cloud = O.kstrongest_cloud(sr, si, sc, 0.0438, 0.0)
+        assert r["n_points"][b] == cloud.shape[0]
+        np.testing.assert_array_equal(r["xyzi"][b, :cloud.shape[0]], cloud)
+    # every image is filtered: the per-image counts equal the brute-force counts
+    np.testing.assert_array_equal(r["sel_count"], np.minimum((imgs >= 100).sum(2), 5))
+
+
+@pytest.mark.parametrize("pad,offset", [(5, 0), (3, 1), (12, 2), (64, 0)])
+def test_kstrongest_strided_and_unaligned_images(pad, offset):
+    """Row stride > cols and a base pointer that is not 4-byte aligned (a cv::Mat ROI): the byte-load path."""
+    import ctypes as C
+    from oracle import pyoracle as O
+    from tbv_slam_public_amd import api, _lib as L
+    rng = np.random.default_rng(pad)
+    rows, cols, k = 7, 1000, 12
+    stride = cols + pad
+    buf = rng.integers(0, 256, rows * stride + 8, dtype=np.uint8)
+    view = np.lib.stride_tricks.as_strided(buf[offset:], (rows, cols), (stride, 1))
+    ctx = api.default_context()
+    d = L.PolarDesc()
+    d.rows, d.cols, d.stride, d.batch, d.batch_stride = rows, cols, stride, 1, rows * stride
+    par = L.KStrongParams(k, 90.0, 0.0438, 2.5, 0)
+    sr = np.empty((rows, k), np.int32)
+    si = np.empty((rows, k), np.uint8)
+    sc = np.empty(rows, np.int32)
+    out = L.KStrongOut()
+    out.sel_range, out.sel_intensity, out.sel_count = sr.ctypes.data, si.ctypes.data, sc.ctypes.data
+    ctx.check(ctx._lib.cfear_filter_kstrongest(ctx.h, buf.ctypes.data + offset, C.byref(d), C.byref(par), C.byref(out)))
+    er, ei, ec = O.kstrongest(np.ascontiguousarray(view), k, 90)
+    np.testing.assert_array_equal(sr, er)
+    np.testing.assert_array_equal(si, ei)
+    np.testing.assert_array_equal(sc, ec)
