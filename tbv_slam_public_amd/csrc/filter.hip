@@ -79,52 +79,6 @@ __device__ __forceinline__ void load_row(const uint8_t* rowp, int cols, int lane
   }
 }
 
-// AxialNonMaxSupress for one kept bin m (radar_filters.cpp:238-298).
-__device__ bool peak_is_largest(int m, int cols, const uint8_t* rowbuf, const uint8_t* img, long long row_lin,
-                                long long total, const uint32_t* list, int n_sel) {
-  auto raw = [&](int q) -> int {
-    if (q >= 0 && q < cols) return rowbuf[q];
-    const long long lin = row_lin + q;            // unchecked cv::Mat::at on a continuous image
-    return (lin >= 0 && lin < total) ? (int)img[lin] : 0;
-  };
-  const bool valid_m = (m >= 3 && m < cols - 3);
-  int sc[7];
-  if (valid_m) {
-    int v[13];
-#pragma unroll
-    for (int i = 0; i < 13; i++) v[i] = raw(m - 6 + i);
-#pragma unroll
-    for (int i = 0; i < 7; i++) {
-      int s = 0;
-#pragma unroll
-      for (int j = 0; j < 7; j++) s += v[i + j];
-      sc[i] = s;
-    }
-  } else {
-    // m itself was never scored: a neighbour key exists only if another kept, valid bin created it
-    for (int i = 0; i < 7; i++) {
-      const int r = m - 3 + i;
-      bool covered = false;
-      for (int t = 0; t < n_sel; t++) {
-        const int mm = (int)(list[t] & 0xFFFFFFu);
-        if (mm >= 3 && mm < cols - 3 && r >= mm - 3 && r <= mm + 3) { covered = true; break; }
-      }
-      int s = 0;
-      if (covered)
-        for (int q = r - 3; q <= r + 3; q++) s += raw(q);
-      sc[i] = s & 0xFFFF;
-    }
-  }
-  const int pthis = sc[3];
-  bool largest = true;
-#pragma unroll
-  for (int i = 1; i <= 3; i++) {
-    const int pnext = sc[3 + i], pprev = sc[3 - i];
-    if (pprev > pthis || pthis < pnext) largest = false;
-  }
-  return largest;
-}
-
 // Candidate bitmaps.  For each 16-byte chunk c of this lane, bit (8*by + 4 + d) of bm[c] is set iff
 // byte `by` of word d is >= t.  The SWAR compare leaves its verdict in bit 7 of every byte; a
 // v_bfi per word shifts the running bitmap down one bit and inserts the new verdicts, so the
@@ -181,10 +135,10 @@ __global__ __launch_bounds__(256) void kstrongest_rows_kernel(const KStrongArgs 
   const int kpad = (k + 3) & ~3;
   constexpr int NP = (NCHUNK + 1) / 2;             // bitmap words per lane (two chunks per word)
   constexpr int kScratch = (NP + 2) * 256 > 1024 ? (NP + 2) * 256 : 1024;
-  const int per_wave = NCHUNK * 1024 + kScratch + kpad * 4;
-  uint8_t* rowbuf = smem + wave * per_wave;                                       // the raw row
-  uint32_t* hist = (uint32_t*)(smem + wave * per_wave + NCHUNK * 1024);           // [256] histogram / scatter scratch
-  uint32_t* list = (uint32_t*)(smem + wave * per_wave + NCHUNK * 1024 + kScratch);   // [kpad] survivors (packed keys)
+  const int per_wave = NCHUNK * 1024 + 32 + kScratch + kpad * 4;
+  uint8_t* rowbuf = smem + wave * per_wave + 16;                                  // the raw row, 16-byte halo either side
+  uint32_t* hist = (uint32_t*)(smem + wave * per_wave + NCHUNK * 1024 + 32);      // [256] histogram / scatter scratch
+  uint32_t* list = (uint32_t*)(smem + wave * per_wave + NCHUNK * 1024 + 32 + kScratch);   // [kpad] survivors (packed keys)
 
   uint32_t w[NCHUNK * 4];
   load_row<NCHUNK, VEC>(rowp, a.cols, lane, w);
@@ -343,6 +297,35 @@ __global__ __launch_bounds__(256) void kstrongest_rows_kernel(const KStrongArgs 
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
+  // ---- peaks (AxialNonMaxSupress, radar_filters.cpp:238-298): score[r] = sum of raw[r-3..r+3]
+  //      exists for r within 3 bins of a kept bin m with 3 <= m < cols - 3; a kept bin is a peak iff its
+  //      score is not exceeded by the three scores either side (missing scores are 0).  The reference reads
+  //      raw[] through unchecked cv::Mat::at, i.e. up to 6 bytes before / after the row in image memory:
+  //      those halo bytes are staged next to the row so that every tap is one LDS read. --------------------
+  const bool do_peaks = a.want_peaks && a.is_peak;
+  if (do_peaks) {
+    const long long total = (long long)a.rows * a.stride;
+    if (lane < 6) {
+      const long long lin = row_lin - 6 + lane;
+      rowbuf[-6 + lane] = lin >= 0 ? img[lin] : (uint8_t)0;
+    } else if (lane >= 8 && lane < 14) {
+      const int q = a.cols + (lane - 8);
+      const long long lin = row_lin + q;
+      rowbuf[q] = lin < total ? img[lin] : (uint8_t)0;
+    }
+    if (lane < 2) hist[lane] = 0;                 // kept VALID bins among the first / last 16 bins of the row
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    for (int j = lane; j < n_sel; j += 64) {
+      const int m = (int)(list[j] & 0xFFFFFFu);
+      if (m >= 3 && m < a.cols - 3) {
+        if (m < 16) atomicOr(&hist[0], 1u << m);
+        if (m >= a.cols - 16) atomicOr(&hist[1], 1u << (m - (a.cols - 16)));
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
   // ---- rank the <= k survivors: ascending (intensity, range) == ascending packed key --------
   const long long obase = ((long long)b * a.rows + r) * k;
   int nvalid = 0, nvalid_pk = 0;                   // wave-uniform (ballot popcounts)
@@ -359,15 +342,45 @@ __global__ __launch_bounds__(256) void kstrongest_rows_kernel(const KStrongArgs 
       if (a.sel_range) a.sel_range[obase + rank] = range;
       if (a.sel_intensity) a.sel_intensity[obase + rank] = (uint8_t)(key >> 24);
       beyond = range > a.min_range_bin;                             // radar_filters.cpp:327
-      if (a.want_peaks && a.is_peak) {
-        const bool pk = peak_is_largest(range, a.cols, rowbuf, img, row_lin, (long long)a.rows * a.stride, list, n_sel);
+      if (do_peaks) {
+        int v[13];                                  // raw[range - 6 .. range + 6]
+#pragma unroll
+        for (int i = 0; i < 13; i++) v[i] = rowbuf[range - 6 + i];
+        int sc[7];                                  // score[range - 3 .. range + 3]
+        sc[0] = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + v[6]);
+#pragma unroll
+        for (int i = 1; i < 7; i++) sc[i] = sc[i - 1] - v[i - 1] + v[i + 6];
+        if (!(range >= 3 && range < a.cols - 3)) {
+          // border bin: it created no scores itself; score[r] exists only if another kept valid bin lies
+          // within 3 bins of r (all such bins are among the first / last 16 of the row)
+          const uint32_t klo = hist[0], khi = hist[1];
+          const int base = a.cols - 16;
+#pragma unroll
+          for (int i = 0; i < 7; i++) {
+            const int rr = range - 3 + i;
+            bool covered = false;
+            {                                       // kept valid bins in [rr - 3, rr + 3] among bins 0..15
+              const int lo = max(rr - 3, 0), hi = min(rr + 3, 15);
+              if (hi >= lo) covered = ((klo >> lo) & ((2u << (hi - lo)) - 1u)) != 0u;
+            }
+            {                                       // ... among bins cols - 16 .. cols - 1
+              const int lo = max(rr - 3 - base, 0), hi = min(rr + 3 - base, 15);
+              if (hi >= lo) covered = covered || ((khi >> lo) & ((2u << (hi - lo)) - 1u)) != 0u;
+            }
+            if (!covered) sc[i] = 0;
+          }
+        }
+        bool pk = true;
+#pragma unroll
+        for (int i = 1; i <= 3; i++)
+          if (sc[3 - i] > sc[3] || sc[3] < sc[3 + i]) pk = false;
         a.is_peak[obase + rank] = pk ? 1 : 0;
         beyond_pk = beyond && pk;
       }
     } else {
       if (a.sel_range) a.sel_range[obase + j] = -1;
       if (a.sel_intensity) a.sel_intensity[obase + j] = 0;
-      if (a.want_peaks && a.is_peak) a.is_peak[obase + j] = 0;
+      if (do_peaks) a.is_peak[obase + j] = 0;
     }
     nvalid += __popcll(__ballot(beyond));
     nvalid_pk += __popcll(__ballot(beyond_pk));
@@ -673,7 +686,7 @@ int cfear_kstrong_device(cfear_ctx* ctx, const uint8_t* d_polar, const cfear_pol
       dim3 grid((unsigned)((a.rows + kRowsPerBlock - 1) / kRowsPerBlock), (unsigned)std::min(65535, a.batch - b0));
       auto lds = [&](int nchunk_t) {
         const int np = (nchunk_t + 1) / 2;
-        return (size_t)kRowsPerBlock * (nchunk_t * 1024 + std::max(1024, (np + 2) * 256) + kpad * 4);
+        return (size_t)kRowsPerBlock * (nchunk_t * 1024 + 32 + std::max(1024, (np + 2) * 256) + kpad * 4);
       };
       if (nchunk <= 1) launch_kstrong<1>(ctx, a, vec, mask, grid, lds(1));
       else if (nchunk <= 2) launch_kstrong<2>(ctx, a, vec, mask, grid, lds(2));
