@@ -132,7 +132,7 @@ __global__ __launch_bounds__(256) void kstrongest_rows_kernel(const KStrongArgs 
   const long long row_lin = (long long)r * a.stride;
   const uint8_t* rowp = img + row_lin;
   const int k = a.k;
-  const int kpad = (k + 3) & ~3;
+  const int kpad = max((k + 3) & ~3, 64);          // list capacity: k survivors, or up to 64 candidates to rank
   constexpr int NP = (NCHUNK + 1) / 2;             // bitmap words per lane (two chunks per word)
   constexpr int kScratch = (NP + 2) * 256 > 1024 ? (NP + 2) * 256 : 1024;
   const int per_wave = NCHUNK * 1024 + 32 + kScratch + kpad * 4;
@@ -158,15 +158,19 @@ __global__ __launch_bounds__(256) void kstrongest_rows_kernel(const KStrongArgs 
   for (int c = 0; c < NCHUNK; c++) c_lane += __popc(bm[c]);
   const int c_incl = wave_incl_scan_i32(c_lane);
   const int n_ge = __builtin_amdgcn_readlane(c_incl, 63);
-  int n_sel;
+  int n_sel;                                       // survivors = min(candidates, k)
+  int n_all;                                       // keys placed in list[] (== n_sel unless the cut is made by rank)
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
-  if (n_ge <= k) {
-    // ---- every candidate survives: compact in any order; the ranking below restores the
-    //      reference's ascending (intensity, range) order ----------------------------------------------
-    n_sel = n_ge;
+  if (n_ge <= k || n_ge <= 64) {
+    // ---- at most k candidates, or at most 64: all of them become keys (any order); the ranking below
+    //      restores the reference's ascending (intensity, range) order and, when there are more than k,
+    //      keeps the k largest keys -- the lexicographic (intensity, range) cut of the reference, ties at
+    //      the cut intensity resolved toward the larger range, without building the histogram --------------
+    n_sel = min(n_ge, k);
+    n_all = n_ge;
     if (n_ge <= 64) {
       // One candidate per lane, however the candidates cluster (a wall return fills adjacent bins of
       // ONE lane).  Owner lanes mark the first slot of their run; a max-scan spreads the owner id over
@@ -212,8 +216,9 @@ __global__ __launch_bounds__(256) void kstrongest_rows_kernel(const KStrongArgs 
       for_each_candidate<NCHUNK>(bm, lane, [&](int pos) { list[slot++] = ((uint32_t)rowbuf[pos] << 24) | (uint32_t)pos; });
     }
   } else {
-    // ---- more than k candidates: cut intensity T from an LDS histogram of the candidates ----------
+    // ---- more than k and more than 64 candidates: cut intensity T from an LDS histogram ------------
     n_sel = k;
+    n_all = k;
     *(uint4*)(hist + lane * 4) = make_uint4(0, 0, 0, 0);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -291,11 +296,12 @@ __global__ __launch_bounds__(256) void kstrongest_rows_kernel(const KStrongArgs 
       e_base += tot >> 16;
     }
   }
-  const int nq = (n_sel + 3) & ~3;
-  for (int j = n_sel + lane; j < nq; j += 64) list[j] = 0xFFFFFFFFu;      // pad for the b128 reads
+  const int nq = (n_all + 3) & ~3;
+  for (int j = n_all + lane; j < nq; j += 64) list[j] = 0xFFFFFFFFu;      // pad for the b128 reads
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  const int drop = n_all - n_sel;                  // keys below the cut (only when n_all <= 64)
 
   // ---- peaks (AxialNonMaxSupress, radar_filters.cpp:238-298): score[r] = sum of raw[r-3..r+3]
   //      exists for r within 3 bins of a kept bin m with 3 <= m < cols - 3; a kept bin is a peak iff its
@@ -303,6 +309,12 @@ __global__ __launch_bounds__(256) void kstrongest_rows_kernel(const KStrongArgs 
   //      raw[] through unchecked cv::Mat::at, i.e. up to 6 bytes before / after the row in image memory:
   //      those halo bytes are staged next to the row so that every tap is one LDS read. --------------------
   const bool do_peaks = a.want_peaks && a.is_peak;
+  auto note_kept = [&](int m) {                    // kept VALID bins among the first / last 16 bins of the row
+    if (m >= 3 && m < a.cols - 3) {
+      if (m < 16) atomicOr(&hist[0], 1u << m);
+      if (m >= a.cols - 16) atomicOr(&hist[1], 1u << (m - (a.cols - 16)));
+    }
+  };
   if (do_peaks) {
     const long long total = (long long)a.rows * a.stride;
     if (lane < 6) {
@@ -313,32 +325,39 @@ __global__ __launch_bounds__(256) void kstrongest_rows_kernel(const KStrongArgs 
       const long long lin = row_lin + q;
       rowbuf[q] = lin < total ? img[lin] : (uint8_t)0;
     }
-    if (lane < 2) hist[lane] = 0;                 // kept VALID bins among the first / last 16 bins of the row
+    if (lane < 2) hist[lane] = 0;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    for (int j = lane; j < n_sel; j += 64) {
-      const int m = (int)(list[j] & 0xFFFFFFu);
-      if (m >= 3 && m < a.cols - 3) {
-        if (m < 16) atomicOr(&hist[0], 1u << m);
-        if (m >= a.cols - 16) atomicOr(&hist[1], 1u << (m - (a.cols - 16)));
-      }
+    if (drop == 0) {                               // every key survives: the kept set is known before ranking
+      for (int j = lane; j < n_all; j += 64) note_kept((int)(list[j] & 0xFFFFFFu));
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
   }
-  // ---- rank the <= k survivors: ascending (intensity, range) == ascending packed key --------
+  // ---- rank the keys: ascending (intensity, range) == ascending packed key; survivors have rank >= drop ----
   const long long obase = ((long long)b * a.rows + r) * k;
   int nvalid = 0, nvalid_pk = 0;                   // wave-uniform (ballot popcounts)
-  for (int j = lane; j < k; j += 64) {
+  for (int j0 = 0; j0 < n_all; j0 += 64) {         // one pass unless k > 64
+    const int j = j0 + lane;
     bool beyond = false, beyond_pk = false;
-    if (j < n_sel) {
-      const uint32_t key = list[j];
-      int rank = 0;
+    uint32_t key = 0;
+    int rank = -1;
+    if (j < n_all) {
+      key = list[j];
+      rank = 0;
       for (int i = 0; i < nq; i += 4) {
         const uint4 q = *(const uint4*)(list + i);  // same address in every lane: LDS broadcast
         rank += (q.x < key) + (q.y < key) + (q.z < key) + (q.w < key);
       }
-      const int range = (int)(key & 0xFFFFFFu);
+      rank -= drop;                                 // < 0: below the cut
+    }
+    const int range = (int)(key & 0xFFFFFFu);
+    if (do_peaks && drop != 0) {                    // n_all <= 64: single pass, the kept set follows from the ranks
+      if (rank >= 0) note_kept(range);
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
+    if (rank >= 0) {
       if (a.sel_range) a.sel_range[obase + rank] = range;
       if (a.sel_intensity) a.sel_intensity[obase + rank] = (uint8_t)(key >> 24);
       beyond = range > a.min_range_bin;                             // radar_filters.cpp:327
@@ -377,13 +396,14 @@ __global__ __launch_bounds__(256) void kstrongest_rows_kernel(const KStrongArgs 
         a.is_peak[obase + rank] = pk ? 1 : 0;
         beyond_pk = beyond && pk;
       }
-    } else {
-      if (a.sel_range) a.sel_range[obase + j] = -1;
-      if (a.sel_intensity) a.sel_intensity[obase + j] = 0;
-      if (do_peaks) a.is_peak[obase + j] = 0;
     }
     nvalid += __popcll(__ballot(beyond));
     nvalid_pk += __popcll(__ballot(beyond_pk));
+  }
+  for (int j = n_sel + lane; j < k; j += 64) {     // unused slots
+    if (a.sel_range) a.sel_range[obase + j] = -1;
+    if (a.sel_intensity) a.sel_intensity[obase + j] = 0;
+    if (do_peaks) a.is_peak[obase + j] = 0;
   }
   if (lane == 0) {
     if (a.row_valid) {
@@ -678,7 +698,7 @@ int cfear_kstrong_device(cfear_ctx* ctx, const uint8_t* d_polar, const cfear_pol
   const bool vec = (((uintptr_t)d_polar) % 4 == 0) && (a.stride % 4 == 0) && (a.batch_stride % 4 == 0);
   const bool mask = (a.cols % 16 != 0) || a.u_zmin == 0;
   const int nchunk = (a.cols + 1023) / 1024;
-  const int kpad = (a.k + 3) & ~3;
+  const int kpad = std::max((a.k + 3) & ~3, 64);
   {
     ProfScope ps(ctx, "kstrongest_rows");
     for (int b0 = 0; b0 < a.batch; b0 += 65535) {             // gridDim.y limit
