@@ -533,11 +533,15 @@ __device__ int compact_slots(const RegJob& job, const RegCommon& cm, const Slots
 // source cell) pairs -- match + normal gate, block scan, then gather of the matched target's
 // attributes straight into the dense correspondence arrays -- with no global scratch in between.
 // ---------------------------------------------------------------------------------------------------
+constexpr int kBuckets = 64;           // x buckets per keyframe for the window start
+
 struct FusedLds {
   double* kf;          // [16][12]: Ttar (l0..l3,t0,t1), Tst (l0..l3,t0,t1)
   int* koff;           // [17] prefix of target counts
   float4* txyi;        // [sum targets] x-sorted (x, y, index-as-int-bits, -): one 16-byte LDS read per candidate
   const void** tptr;   // [16][5] per keyframe: mean, normal, nsamples, scale, cov arrays (global pointers)
+  unsigned short* bstart;   // [16][kBuckets + 1]: first x-sorted target of each x bucket (replaces a binary search)
+  float2* bgeo;        // [16] (x of the first target, buckets per metre)
   double2* smean; double2* snormal; double* sscale; int* sns;   // [n_src]
   int* match;          // [n_pairs]
   double* dense;       // rest
@@ -552,6 +556,8 @@ __device__ __forceinline__ bool fused_carve(uint8_t* smem, size_t lds_total, int
   f.kf = (double*)(smem + off); off += 16 * 12 * 8;
   f.koff = (int*)(smem + off); off += 80;
   f.tptr = (const void**)(smem + off); off += 16 * 5 * 8;
+  f.bgeo = (float2*)(smem + off); off += 16 * 8;
+  f.bstart = (unsigned short*)(smem + off); off += 16 * (kBuckets + 1) * 2;
   off = (off + 15) & ~(size_t)15;
   f.txyi = (float4*)(smem + off); off += (size_t)sum_tar * 16;
   const size_t ns = ((size_t)n_src + 1) & ~(size_t)1;
@@ -587,8 +593,20 @@ __device__ void fused_stage(const RegJob& job, const FusedLds& f) {
   for (int i = 0; i < last; i++) {
     const ScanView& tar = job.scans[i];
     const int n = f.koff[i + 1] - f.koff[i], o = f.koff[i];
-    for (int j = tid; j < n; j += NW * 64)
-      f.txyi[o + j] = make_float4(tar.sorted_x[j], tar.sorted_y[j], __int_as_float(tar.sorted_idx[j]), 0.f);
+    // x buckets: bucket(x) = clamp(floor((x - x_first) * scale)) is monotone in x, so every target with
+    // x >= q lies at or after bstart[bucket(q)] -- the window scan may start there without a binary search
+    const float x0 = n > 0 ? tar.sorted_x[0] : 0.f, x1 = n > 0 ? tar.sorted_x[n - 1] : 0.f;
+    const float scale = x1 > x0 ? (float)kBuckets / (x1 - x0) : 0.f;
+    if (tid == 0) { f.bgeo[i] = make_float2(x0, scale); f.bstart[i * (kBuckets + 1) + kBuckets] = (unsigned short)n; }
+    unsigned short* bs = f.bstart + i * (kBuckets + 1);
+    for (int j = tid; j < n; j += NW * 64) {
+      const float xj = tar.sorted_x[j];
+      f.txyi[o + j] = make_float4(xj, tar.sorted_y[j], __int_as_float(tar.sorted_idx[j]), 0.f);
+      const int bj = min(kBuckets - 1, max(0, (int)floorf((xj - x0) * scale)));
+      const int bp = j > 0 ? min(kBuckets - 1, max(0, (int)floorf((tar.sorted_x[j - 1] - x0) * scale))) : -1;
+      for (int b = bp + 1; b <= bj; b++) bs[b] = (unsigned short)j;
+    }
+    if (n == 0 && tid < kBuckets) bs[tid] = 0;
   }
   const ScanView& src = job.scans[last];
   const int n_src = *src.n_cells;
@@ -637,25 +655,33 @@ __device__ int associate_fused(const RegJob& job, const RegCommon& cm, const dou
       // |x - qx| <= radius of the x-sorted order: nothing outside it can pass `dist < radius^2`.
       const float xlo = qx - rwin, xhi = qx + rwin;
       const int t0 = f.koff[i], t1 = f.koff[i + 1];
-      int lo = t0, hi = t1;
-      while (lo < hi) { const int mid = (lo + hi) >> 1; if (f.txyi[mid].x < xlo) lo = mid + 1; else hi = mid; }
+      const float2 bg = f.bgeo[i];
+      const int bq = min(kBuckets - 1, max(0, (int)floorf((xlo - bg.x) * bg.y)));
       int best = -1;
       float bestd = FLT_MAX;
-      auto visit = [&](const float4 c) {
+      auto visit = [&](const float4 c) {            // candidates left of the window cannot win: their d exceeds r^2
         const float dx = __fsub_rn(qx, c.x), dy = __fsub_rn(qy, c.y);
         const float d = __fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy));
         const int idx = __float_as_int(c.z);
         if (d < bestd || (d == bestd && idx < best)) { best = idx; bestd = d; }
       };
-      int q = lo;
-      for (; q + 1 < t1; q += 2) {                        // two candidates per step: independent LDS reads
-        const float4 ca = f.txyi[q], cb = f.txyi[q + 1];
+      int q = t0 + (int)f.bstart[i * (kBuckets + 1) + bq];
+      for (; q + 3 < t1; q += 4) {                        // four candidates per step: independent LDS reads
+        const float4 ca = f.txyi[q], cb = f.txyi[q + 1], cc = f.txyi[q + 2], cd = f.txyi[q + 3];
         if (ca.x > xhi) { q = t1; break; }
         visit(ca);
         if (cb.x > xhi) { q = t1; break; }
         visit(cb);
+        if (cc.x > xhi) { q = t1; break; }
+        visit(cc);
+        if (cd.x > xhi) { q = t1; break; }
+        visit(cd);
       }
-      if (q < t1) { const float4 ca = f.txyi[q]; if (!(ca.x > xhi)) visit(ca); }
+      for (; q < t1; q++) {
+        const float4 ca = f.txyi[q];
+        if (ca.x > xhi) break;
+        visit(ca);
+      }
       int m = -1;
       if (best >= 0 && (double)bestd < r2) {                                    // pointnormal.cpp:250
         const double2 ns = f.snormal[s];
