@@ -533,48 +533,60 @@ __device__ int compact_slots(const RegJob& job, const RegCommon& cm, const Slots
 // source cell) pairs -- match + normal gate, block scan, then gather of the matched target's
 // attributes straight into the dense correspondence arrays -- with no global scratch in between.
 // ---------------------------------------------------------------------------------------------------
-constexpr int kBuckets = 64;           // x buckets per keyframe for the window start
+constexpr int kGridCellsTotal = 4096;   // grid cells of all keyframes of one registration (LDS cell table)
+constexpr int kGridMaxDim = 32;         // cells per axis and keyframe: min(32, floor(sqrt(4096 / keyframes)))
 
 struct FusedLds {
   double* kf;          // [16][12]: Ttar (l0..l3,t0,t1), Tst (l0..l3,t0,t1)
   int* koff;           // [17] prefix of target counts
-  float4* txyi;        // [sum targets] x-sorted (x, y, index-as-int-bits, -): one 16-byte LDS read per candidate
+  float4* txyi;        // [sum targets] (x, y, index-as-int-bits, -) grouped by (keyframe, grid cell): one 16-byte LDS read per candidate
   const void** tptr;   // [16][5] per keyframe: mean, normal, nsamples, scale, cov arrays (global pointers)
-  unsigned short* bstart;   // [16][kBuckets + 1]: first x-sorted target of each x bucket (replaces a binary search)
-  float2* bgeo;        // [16] (x of the first target, buckets per metre)
-  double2* smean; double2* snormal; double* sscale; int* sns;   // [n_src]
+  float4* ggeo;        // [16] per keyframe grid: (x0, y0, cells per metre, -)
+  unsigned* gext;      // [16][4] order-preserving uint images of the y extent (min, max) while the grid is built
+  unsigned short* cstart;   // [keyframes * G * G + 1] first target (absolute index into txyi) of every grid cell
+  unsigned* ccnt;      // [keyframes * G * G] build-time counters (aliases the dense arrays)
+  int G;               // grid cells per axis
+  double2* smean;      // [n_src] source means (read by every evaluation); the source normals / scales / sample
+                       // counts are read from global memory next to the target attributes (accepted pairs only)
   int* match;          // [n_pairs]
   double* dense;       // rest
   int dense_cap;
 };
 
+__host__ __device__ inline int reg_grid_dim(int keyframes) {
+  int g = kGridMaxDim;
+  while (g > 1 && g * g * keyframes > kGridCellsTotal) g--;
+  return g;
+}
+
 // Carves the workgroup's dynamic LDS (bytes `lds_total`) for the actual sizes; returns false when the
 // fixed parts leave no room (the caller then uses the slot-array path).
-__device__ __forceinline__ bool fused_carve(uint8_t* smem, size_t lds_total, int sum_tar, int n_src, int n_pairs,
+__device__ __forceinline__ bool fused_carve(uint8_t* smem, size_t lds_total, int last, int sum_tar, int n_src, int n_pairs,
                                             int fields, FusedLds& f) {
   size_t off = kRegFixedLds;
   f.kf = (double*)(smem + off); off += 16 * 12 * 8;
   f.koff = (int*)(smem + off); off += 80;
   f.tptr = (const void**)(smem + off); off += 16 * 5 * 8;
-  f.bgeo = (float2*)(smem + off); off += 16 * 8;
-  f.bstart = (unsigned short*)(smem + off); off += 16 * (kBuckets + 1) * 2;
+  f.ggeo = (float4*)(smem + off); off += 16 * 16;
+  f.gext = (unsigned*)(smem + off); off += 16 * 4 * 4;
+  f.G = reg_grid_dim(last);
+  const size_t n_cells = (size_t)last * f.G * f.G;
+  f.cstart = (unsigned short*)(smem + off); off += ((n_cells + 1) * 2 + 15) & ~(size_t)15;
   off = (off + 15) & ~(size_t)15;
   f.txyi = (float4*)(smem + off); off += (size_t)sum_tar * 16;
   const size_t ns = ((size_t)n_src + 1) & ~(size_t)1;
   f.smean = (double2*)(smem + off); off += ns * 16;
-  f.snormal = (double2*)(smem + off); off += ns * 16;
-  f.sscale = (double*)(smem + off); off += ns * 8;
-  f.sns = (int*)(smem + off); off += ns * 4;
   f.match = (int*)(smem + off); off += (((size_t)n_pairs + 3) & ~(size_t)3) * 4;
   off = (off + 15) & ~(size_t)15;
-  if (off + 1024 > lds_total) return false;
+  if (sum_tar > 65535 || off + n_cells * 4 + 1024 > lds_total) return false;   // cell table is u16; counters alias dense
   f.dense = (double*)(smem + off);
+  f.ccnt = (unsigned*)(smem + off);
   f.dense_cap = (int)((lds_total - off) / ((size_t)fields * 8 + 4)) & ~1;   // even: keeps the int array 8-byte aligned
   return true;
 }
 
 template <int NW>
-__device__ void fused_stage(const RegJob& job, const FusedLds& f) {
+__device__ void fused_stage(const RegJob& job, const FusedLds& f, float cm_radius) {
   const int tid = threadIdx.x, last = job.n_scans - 1;
   if (tid == 0) {
     int acc = 0;
@@ -590,31 +602,85 @@ __device__ void fused_stage(const RegJob& job, const FusedLds& f) {
     tp[0] = tv.mean; tp[1] = tv.normal; tp[2] = tv.nsamples; tp[3] = tv.scale; tp[4] = tv.cov;
   }
   __syncthreads();
-  for (int i = 0; i < last; i++) {
-    const ScanView& tar = job.scans[i];
-    const int n = f.koff[i + 1] - f.koff[i], o = f.koff[i];
-    // x buckets: bucket(x) = clamp(floor((x - x_first) * scale)) is monotone in x, so every target with
-    // x >= q lies at or after bstart[bucket(q)] -- the window scan may start there without a binary search
-    const float x0 = n > 0 ? tar.sorted_x[0] : 0.f, x1 = n > 0 ? tar.sorted_x[n - 1] : 0.f;
-    const float scale = x1 > x0 ? (float)kBuckets / (x1 - x0) : 0.f;
-    if (tid == 0) { f.bgeo[i] = make_float2(x0, scale); f.bstart[i * (kBuckets + 1) + kBuckets] = (unsigned short)n; }
-    unsigned short* bs = f.bstart + i * (kBuckets + 1);
-    for (int j = tid; j < n; j += NW * 64) {
-      const float xj = tar.sorted_x[j];
-      f.txyi[o + j] = make_float4(xj, tar.sorted_y[j], __int_as_float(tar.sorted_idx[j]), 0.f);
-      const int bj = min(kBuckets - 1, max(0, (int)floorf((xj - x0) * scale)));
-      const int bp = j > 0 ? min(kBuckets - 1, max(0, (int)floorf((tar.sorted_x[j - 1] - x0) * scale))) : -1;
-      for (int b = bp + 1; b <= bj; b++) bs[b] = (unsigned short)j;
+  // ---- uniform grid per keyframe (replaces the reference's kd-tree): targets grouped by cell -------------
+  // The float means cluster along walls, so a window in one coordinate alone can hold a hundred candidates;
+  // with cells no smaller than the search radius a query touches the few cells its square overlaps.
+  const int G = f.G, GG = G * G, sum_tar = f.koff[last];
+  auto ordered = [](float v) { unsigned u = __float_as_uint(v); return (u >> 31) ? ~u : (u | 0x80000000u); };
+  auto unordered = [](unsigned u) { return __uint_as_float((u >> 31) ? (u & 0x7fffffffu) : ~u); };
+  if (tid < last) { f.gext[tid * 4] = 0xFFFFFFFFu; f.gext[tid * 4 + 1] = 0u; }
+  for (int c = tid; c < last * GG; c += NW * 64) f.ccnt[c] = 0;
+  __syncthreads();
+  auto keyframe_of = [&](int t, int& i, int& j) {        // merged target index -> (keyframe, x-sorted position)
+    i = 0;
+    while (i + 1 < last && t >= f.koff[i + 1]) i++;
+    j = t - f.koff[i];
+  };
+  for (int t = tid; t < sum_tar; t += NW * 64) {          // y extent (x is already sorted: first / last entry)
+    int i, j;
+    keyframe_of(t, i, j);
+    const unsigned u = ordered(job.scans[i].sorted_y[j]);
+    atomicMin(&f.gext[i * 4], u);
+    atomicMax(&f.gext[i * 4 + 1], u);
+  }
+  __syncthreads();
+  if (tid < last) {
+    const ScanView& tar = job.scans[tid];
+    const int n = f.koff[tid + 1] - f.koff[tid];
+    float x0 = 0.f, y0 = 0.f, span = 0.f;
+    if (n > 0) {
+      x0 = tar.sorted_x[0];
+      y0 = unordered(f.gext[tid * 4]);
+      span = fmaxf(tar.sorted_x[n - 1] - x0, unordered(f.gext[tid * 4 + 1]) - y0);
     }
-    if (n == 0 && tid < kBuckets) bs[tid] = 0;
+    // cell edge: the extent split into G cells, never below the matcher's radius
+    const float edge = fmaxf(span / (float)G * 1.0001f, fmaxf(cm_radius, 1e-3f));
+    f.ggeo[tid] = make_float4(x0, y0, 1.0f / edge, 0.f);
+  }
+  __syncthreads();
+  auto cell_of = [&](const float4 g, float x, float y) {
+    const int cx = min(G - 1, max(0, (int)floorf((x - g.x) * g.z)));
+    const int cy = min(G - 1, max(0, (int)floorf((y - g.y) * g.z)));
+    return cy * G + cx;
+  };
+  for (int t = tid; t < sum_tar; t += NW * 64) {          // histogram of the cells
+    int i, j;
+    keyframe_of(t, i, j);
+    atomicAdd(&f.ccnt[i * GG + cell_of(f.ggeo[i], job.scans[i].sorted_x[j], job.scans[i].sorted_y[j])], 1u);
+  }
+  __syncthreads();
+  {                                                      // exclusive scan over (keyframe, cell): absolute starts
+    const int C = last * GG, per = (C + NW * 64 - 1) / (NW * 64);
+    const int c0 = tid * per;
+    int tot = 0;
+    for (int c = c0; c < min(C, c0 + per); c++) tot += (int)f.ccnt[c];
+    int* ip = (int*)(f.gext + 32);                       // [NW] wave totals (second half of the extent array)
+    const int incl = wave_incl_scan_i32(tot);
+    if ((tid & 63) == 63) ip[tid >> 6] = incl;
+    __syncthreads();
+    int run = incl - tot;
+    for (int wv = 0; wv < (tid >> 6); wv++) run += ip[wv];
+    for (int c = c0; c < min(C, c0 + per); c++) {
+      const int cnt = (int)f.ccnt[c];
+      f.cstart[c] = (unsigned short)run;
+      f.ccnt[c] = (unsigned)run;                         // becomes the scatter cursor
+      run += cnt;
+    }
+    if (tid == 0) f.cstart[C] = (unsigned short)sum_tar;
+  }
+  __syncthreads();
+  for (int t = tid; t < sum_tar; t += NW * 64) {          // scatter (order inside a cell is irrelevant: the NN
+    int i, j;                                            // tie rule is by cell index, not by visiting order)
+    keyframe_of(t, i, j);
+    const ScanView& tar = job.scans[i];
+    const float x = tar.sorted_x[j], y = tar.sorted_y[j];
+    const unsigned pos = atomicAdd(&f.ccnt[i * GG + cell_of(f.ggeo[i], x, y)], 1u);
+    f.txyi[pos] = make_float4(x, y, __int_as_float(tar.sorted_idx[j]), 0.f);
   }
   const ScanView& src = job.scans[last];
   const int n_src = *src.n_cells;
   for (int s = tid; s < n_src; s += NW * 64) {
     f.smean[s] = src.mean[s];
-    f.snormal[s] = src.normal[s];
-    f.sscale[s] = src.scale[s];
-    f.sns[s] = src.nsamples[s];
   }
   __syncthreads();
 }
@@ -654,37 +720,31 @@ __device__ int associate_fused(const RegJob& job, const RegCommon& cm, const dou
       // Exact 1-NN (FLANN L2_Simple float distance, lowest index on ties) restricted to the window
       // |x - qx| <= radius of the x-sorted order: nothing outside it can pass `dist < radius^2`.
       const float xlo = qx - rwin, xhi = qx + rwin;
-      const int t0 = f.koff[i], t1 = f.koff[i + 1];
-      const float2 bg = f.bgeo[i];
-      const int bq = min(kBuckets - 1, max(0, (int)floorf((xlo - bg.x) * bg.y)));
+      const float4 gg = f.ggeo[i];
+      const int G = f.G;
+      const int cx0 = min(G - 1, max(0, (int)floorf((xlo - gg.x) * gg.z))), cx1 = min(G - 1, max(0, (int)floorf((xhi - gg.x) * gg.z)));
+      const int cy0 = min(G - 1, max(0, (int)floorf((qy - rwin - gg.y) * gg.z))), cy1 = min(G - 1, max(0, (int)floorf((qy + rwin - gg.y) * gg.z)));
       int best = -1;
       float bestd = FLT_MAX;
-      auto visit = [&](const float4 c) {            // candidates left of the window cannot win: their d exceeds r^2
+      auto visit = [&](const float4 c) {            // candidates outside the radius cannot win: their d exceeds r^2
         const float dx = __fsub_rn(qx, c.x), dy = __fsub_rn(qy, c.y);
         const float d = __fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy));
         const int idx = __float_as_int(c.z);
         if (d < bestd || (d == bestd && idx < best)) { best = idx; bestd = d; }
       };
-      int q = t0 + (int)f.bstart[i * (kBuckets + 1) + bq];
-      for (; q + 3 < t1; q += 4) {                        // four candidates per step: independent LDS reads
-        const float4 ca = f.txyi[q], cb = f.txyi[q + 1], cc = f.txyi[q + 2], cd = f.txyi[q + 3];
-        if (ca.x > xhi) { q = t1; break; }
-        visit(ca);
-        if (cb.x > xhi) { q = t1; break; }
-        visit(cb);
-        if (cc.x > xhi) { q = t1; break; }
-        visit(cc);
-        if (cd.x > xhi) { q = t1; break; }
-        visit(cd);
-      }
-      for (; q < t1; q++) {
-        const float4 ca = f.txyi[q];
-        if (ca.x > xhi) break;
-        visit(ca);
+      const unsigned short* cs = f.cstart + i * G * G;
+      for (int cy = cy0; cy <= cy1; cy++) {               // cells of a grid row are contiguous in txyi
+        int q = (int)cs[cy * G + cx0];
+        const int qe = (int)cs[cy * G + cx1 + 1];
+        for (; q + 3 < qe; q += 4) {                      // four candidates per step: independent LDS reads
+          const float4 ca = f.txyi[q], cb = f.txyi[q + 1], cc = f.txyi[q + 2], cd = f.txyi[q + 3];
+          visit(ca); visit(cb); visit(cc); visit(cd);
+        }
+        for (; q < qe; q++) visit(f.txyi[q]);
       }
       int m = -1;
       if (best >= 0 && (double)bestd < r2) {                                    // pointnormal.cpp:250
-        const double2 ns = f.snormal[s];
+        const double2 ns = job.scans[last].normal[s];
         const double2 nt = ((const double2*)f.tptr[i * 5 + 1])[best];
         const double nsx = T[0] * ns.x + T[1] * ns.y, nsy = T[2] * ns.x + T[3] * ns.y;
         if (fmax(nsx * nt.x + nsy * nt.y, 0.0) > cm.angle_outlier) m = best;    // :244-245
@@ -731,11 +791,11 @@ __device__ int associate_fused(const RegJob& job, const RegCommon& cm, const dou
         const double2 tm = ((const double2*)tp[0])[best];
         const int tns = ((const int32_t*)tp[2])[best];
         const double tsc = ((const double*)tp[3])[best];
-        const double2 ns = f.snormal[s];
+        const double2 ns = job.scans[last].normal[s];
         const double nsx = T[0] * ns.x + T[1] * ns.y, nsy = T[2] * ns.x + T[3] * ns.y;
         const double direction_similarity = fmax(nsx * nt.x + nsy * nt.y, 0.0);   // :244
-        const double w = get_weight(cm.par.weight_opt, (double)f.sns[s], (double)tns,
-                                    direction_similarity, f.sscale[s], tsc);   // :247-253, :273
+        const double w = get_weight(cm.par.weight_opt, (double)job.scans[last].nsamples[s], (double)tns,
+                                    direction_similarity, job.scans[last].scale[s], tsc);   // :247-253, :273
         dn.sidx[c] = s;
         dn.p[c] = K[0] * tm.x + K[1] * tm.y + K[4];                               // Ttar * tar_mean
         dn.p[cap + c] = K[2] * tm.x + K[3] * tm.y + K[5];
@@ -1004,9 +1064,9 @@ __global__ __launch_bounds__(NW * 64) void register_kernel(const RegJob* __restr
   int sum_tar = 0;
   for (int i = 0; i < last; i++) sum_tar += *job.scans[i].n_cells;
   FusedLds fl;
-  const bool fused = fused_carve(smem, cm.lds_total, sum_tar, n_src, n_slots, cm.dense_fields, fl);
+  const bool fused = fused_carve(smem, cm.lds_total, last, sum_tar, n_src, n_slots, cm.dense_fields, fl);
   REG_T0();
-  if (fused) fused_stage<NW>(job, fl);
+  if (fused) fused_stage<NW>(job, fl, (float)cm.par.radius);
   REG_TACC(6);
   const int rpb = cm.par.cost == CFEAR_P2L ? 1 : 2;
   if (cm.cost_only) {
