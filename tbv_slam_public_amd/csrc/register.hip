@@ -733,14 +733,25 @@ __device__ int associate_fused(const RegJob& job, const RegCommon& cm, const dou
         if (d < bestd || (d == bestd && idx < best)) { best = idx; bestd = d; }
       };
       const unsigned short* cs = f.cstart + i * G * G;
-      for (int cy = cy0; cy <= cy1; cy++) {               // cells of a grid row are contiguous in txyi
-        int q = (int)cs[cy * G + cx0];
-        const int qe = (int)cs[cy * G + cx1 + 1];
-        for (; q + 3 < qe; q += 4) {                      // four candidates per step: independent LDS reads
-          const float4 ca = f.txyi[q], cb = f.txyi[q + 1], cc = f.txyi[q + 2], cd = f.txyi[q + 3];
+      // cells of a grid row are contiguous in txyi.  The bounds of the (at most three, unless the radius
+      // exceeds the cell edge) rows are fetched together; candidates are visited four per step with the
+      // indices clamped to the run -- revisiting the last candidate is harmless (same d, same index).
+      auto scan_run = [&](int qb, int qe) {
+        for (int q = qb; q < qe; q += 4) {
+          const int l = qe - 1;
+          const float4 ca = f.txyi[q], cb = f.txyi[min(q + 1, l)], cc = f.txyi[min(q + 2, l)], cd = f.txyi[min(q + 3, l)];
           visit(ca); visit(cb); visit(cc); visit(cd);
         }
-        for (; q < qe; q++) visit(f.txyi[q]);
+      };
+      {
+        const int r1 = min(cy0 + 1, cy1), r2 = min(cy0 + 2, cy1);
+        const int b0 = cs[cy0 * G + cx0], e0 = cs[cy0 * G + cx1 + 1];
+        const int b1 = cs[r1 * G + cx0], e1 = cs[r1 * G + cx1 + 1];
+        const int b2 = cs[r2 * G + cx0], e2 = cs[r2 * G + cx1 + 1];
+        scan_run(b0, e0);
+        if (cy1 > cy0) scan_run(b1, e1);
+        if (cy1 > cy0 + 1) scan_run(b2, e2);
+        for (int cy = cy0 + 3; cy <= cy1; cy++) scan_run((int)cs[cy * G + cx0], (int)cs[cy * G + cx1 + 1]);
       }
       int m = -1;
       if (best >= 0 && (double)bestd < r2) {                                    // pointnormal.cpp:250
