@@ -616,13 +616,37 @@ __device__ void fused_stage(const RegJob& job, const FusedLds& f, float cm_radiu
     while (i + 1 < last && t >= f.koff[i + 1]) i++;
     j = t - f.koff[i];
   };
-  for (int t = tid; t < sum_tar; t += NW * 64) {          // y extent (x is already sorted: first / last entry)
-    int i, j;
-    keyframe_of(t, i, j);
-    const unsigned u = ordered(job.scans[i].sorted_y[j]);
+  // every thread keeps its (up to kStageRegs) targets in registers across the three sweeps below
+  constexpr int kStageRegs = 8;
+  float tx[kStageRegs], ty[kStageRegs];
+  int tidx[kStageRegs], tkf[kStageRegs];
+#pragma unroll
+  for (int k = 0; k < kStageRegs; k++) {
+    const int t = tid + k * NW * 64;
+    tkf[k] = -1; tx[k] = ty[k] = 0.f; tidx[k] = 0;
+    if (t < sum_tar) {
+      int i, j;
+      keyframe_of(t, i, j);
+      const ScanView& tar = job.scans[i];
+      tkf[k] = i; tx[k] = tar.sorted_x[j]; ty[k] = tar.sorted_y[j]; tidx[k] = tar.sorted_idx[j];
+    }
+  }
+  auto for_targets = [&](auto&& fn) {                     // fn(keyframe, x, y, idx) over this thread's targets
+#pragma unroll
+    for (int k = 0; k < kStageRegs; k++)
+      if (tkf[k] >= 0) fn(tkf[k], tx[k], ty[k], tidx[k]);
+    for (int t = tid + kStageRegs * NW * 64; t < sum_tar; t += NW * 64) {   // oversize jobs: re-read
+      int i, j;
+      keyframe_of(t, i, j);
+      const ScanView& tar = job.scans[i];
+      fn(i, tar.sorted_x[j], tar.sorted_y[j], tar.sorted_idx[j]);
+    }
+  };
+  for_targets([&](int i, float, float y, int) {           // y extent (x is already sorted: first / last entry)
+    const unsigned u = ordered(y);
     atomicMin(&f.gext[i * 4], u);
     atomicMax(&f.gext[i * 4 + 1], u);
-  }
+  });
   __syncthreads();
   if (tid < last) {
     const ScanView& tar = job.scans[tid];
@@ -643,11 +667,9 @@ __device__ void fused_stage(const RegJob& job, const FusedLds& f, float cm_radiu
     const int cy = min(G - 1, max(0, (int)floorf((y - g.y) * g.z)));
     return cy * G + cx;
   };
-  for (int t = tid; t < sum_tar; t += NW * 64) {          // histogram of the cells
-    int i, j;
-    keyframe_of(t, i, j);
-    atomicAdd(&f.ccnt[i * GG + cell_of(f.ggeo[i], job.scans[i].sorted_x[j], job.scans[i].sorted_y[j])], 1u);
-  }
+  for_targets([&](int i, float x, float y, int) {         // histogram of the cells
+    atomicAdd(&f.ccnt[i * GG + cell_of(f.ggeo[i], x, y)], 1u);
+  });
   __syncthreads();
   {                                                      // exclusive scan over (keyframe, cell): absolute starts
     const int C = last * GG, per = (C + NW * 64 - 1) / (NW * 64);
@@ -669,14 +691,10 @@ __device__ void fused_stage(const RegJob& job, const FusedLds& f, float cm_radiu
     if (tid == 0) f.cstart[C] = (unsigned short)sum_tar;
   }
   __syncthreads();
-  for (int t = tid; t < sum_tar; t += NW * 64) {          // scatter (order inside a cell is irrelevant: the NN
-    int i, j;                                            // tie rule is by cell index, not by visiting order)
-    keyframe_of(t, i, j);
-    const ScanView& tar = job.scans[i];
-    const float x = tar.sorted_x[j], y = tar.sorted_y[j];
-    const unsigned pos = atomicAdd(&f.ccnt[i * GG + cell_of(f.ggeo[i], x, y)], 1u);
-    f.txyi[pos] = make_float4(x, y, __int_as_float(tar.sorted_idx[j]), 0.f);
-  }
+  for_targets([&](int i, float x, float y, int idx) {     // scatter (order inside a cell is irrelevant: the NN
+    const unsigned pos = atomicAdd(&f.ccnt[i * GG + cell_of(f.ggeo[i], x, y)], 1u);   // tie rule is by cell index)
+    f.txyi[pos] = make_float4(x, y, __int_as_float(idx), 0.f);
+  });
   const ScanView& src = job.scans[last];
   const int n_src = *src.n_cells;
   for (int s = tid; s < n_src; s += NW * 64) {
