@@ -807,30 +807,54 @@ __device__ int associate_fused(const RegJob& job, const RegCommon& cm, const dou
   const size_t cap = (size_t)dn.cap;
   REG_TACC(2);
   // ---- pass 2: matched target attributes -> weights + world-frame block data -> dense arrays ------
+  // Software-pipelined: the (L2-resident) attribute gathers of this thread's next pair are issued before the
+  // arithmetic of the current one, so their latency overlaps it instead of adding to it.
   {
+    struct Gathered {
+      int best, i, s, tns, sns;
+      double2 nt, tm, ns;
+      double tsc, ssc;
+      double4 S;
+    };
+    const ScanView& srcv = job.scans[last];
+    auto gather = [&](int p, int i, int s) {
+      Gathered g;
+      g.best = p < n_pairs ? f.match[p] : -1;
+      g.i = i; g.s = s;
+      if (g.best >= 0) {
+        const void* const* tp = f.tptr + i * 5;           // matched target's attribute arrays
+        g.nt = ((const double2*)tp[1])[g.best];
+        g.tm = ((const double2*)tp[0])[g.best];
+        g.tns = ((const int32_t*)tp[2])[g.best];
+        g.tsc = ((const double*)tp[3])[g.best];
+        g.ns = srcv.normal[s];
+        g.sns = srcv.nsamples[s];
+        g.ssc = srcv.scale[s];
+        if (cm.par.cost == CFEAR_P2D) g.S = ((const double4*)tp[4])[g.best];
+      }
+      return g;
+    };
     int c = base, i = 0, s = tid;
     while (s >= n_src && i < last) { s -= n_src; i++; }
+    Gathered cur = gather(tid, i, s);
     for (int p = tid; p < n_pairs; p += NW * 64) {
-      const int best = f.match[p];
-      if (best >= 0) {
-        const void* const* tp = f.tptr + i * 5;           // matched target's attribute arrays
-        const double* K = f.kf + i * 12;                  // Ttar
+      s += NW * 64;
+      while (s >= n_src && i < last) { s -= n_src; i++; }
+      const Gathered nxt = gather(p + NW * 64, i, s);
+      if (cur.best >= 0) {
+        const double* K = f.kf + cur.i * 12;              // Ttar
         const double* T = K + 6;                          // Tsrctotar
-        const double2 nt = ((const double2*)tp[1])[best];
-        const double2 tm = ((const double2*)tp[0])[best];
-        const int tns = ((const int32_t*)tp[2])[best];
-        const double tsc = ((const double*)tp[3])[best];
-        const double2 ns = job.scans[last].normal[s];
+        const double2 nt = cur.nt, tm = cur.tm, ns = cur.ns;
         const double nsx = T[0] * ns.x + T[1] * ns.y, nsy = T[2] * ns.x + T[3] * ns.y;
         const double direction_similarity = fmax(nsx * nt.x + nsy * nt.y, 0.0);   // :244
-        const double w = get_weight(cm.par.weight_opt, (double)job.scans[last].nsamples[s], (double)tns,
-                                    direction_similarity, job.scans[last].scale[s], tsc);   // :247-253, :273
-        dn.sidx[c] = s;
+        const double w = get_weight(cm.par.weight_opt, (double)cur.sns, (double)cur.tns,
+                                    direction_similarity, cur.ssc, cur.tsc);       // :247-253, :273
+        dn.sidx[c] = cur.s;
         dn.p[c] = K[0] * tm.x + K[1] * tm.y + K[4];                               // Ttar * tar_mean
         dn.p[cap + c] = K[2] * tm.x + K[3] * tm.y + K[5];
         dn.p[2 * cap + c] = w;
         if (cm.par.cost == CFEAR_P2D) {                                           // :288-297
-          const double4 S = ((const double4*)tp[4])[best];
+          const double4 S = cur.S;
           const double a00 = K[0] * S.x + K[1] * S.z, a01 = K[0] * S.y + K[1] * S.w;
           const double a10 = K[2] * S.x + K[3] * S.z, a11 = K[2] * S.y + K[3] * S.w;
           const double c00 = (cm.par.regularization + (a00 * K[0] + a01 * K[1])) * cm.par.cov_scale;
@@ -847,8 +871,7 @@ __device__ int associate_fused(const RegJob& job, const RegCommon& cm, const dou
         }
         c++;
       }
-      s += NW * 64;
-      while (s >= n_src && i < last) { s -= n_src; i++; }
+      cur = nxt;
     }
   }
   __syncthreads();
