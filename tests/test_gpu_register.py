@@ -217,3 +217,28 @@ def test_sharded_candidates_single_rank_through_the_library():
         ok_o, po, ro = O.register(c, T, _oracle_par(reg))
         assert (r["status"] == 0) == ok_o and r["outer_iters"] == ro.outer_iters
         assert np.abs(r["pose"][:2] - po[-1, :2]).max() <= POS_TOL and abs(r["pose"][2] - po[-1, 2]) <= ROT_TOL
+
+
+def test_sixteen_scans_slot_path_and_small_grid():
+    """n_scans = 16 (the C-ABI maximum): 15 keyframes x ~350 cells do not fit the workgroup's LDS, so the
+    registration runs on the global slot arrays (the non-fused path); with 8 keyframes it fits and uses a
+    22 x 22 grid per keyframe.  Both must reproduce the oracle."""
+    from tbv_slam_public_amd import api
+    frames = [0, 1, 2, 3, 4, 5]
+    cells, gt = _cells(6, frames)
+    rel = [_rel(gt[0], gt[f]) for f in frames]
+    for n_key in (15, 8):
+        cs, ps = [], []
+        for j in range(n_key):
+            f = j % 5
+            cs.append(cells[f])
+            ps.append(rel[f])
+        cs.append(cells[5])
+        ps.append(rel[5] + np.array([0.3, -0.2, 0.008]))
+        reg = api.n_scan_normal_reg("P2L", "Huber", 0.1, 0)
+        _compare_register(reg, cs, np.array(ps))
+        ok, c, res, _ = __import__("oracle.pyoracle", fromlist=["x"]).get_cost(cs, np.array(ps), _oracle_par(reg))
+        scans = [api.MapPointNormal(cells=c_) for c_ in cs]
+        okg, cg, resg = reg.GetCost(scans, np.array(ps))
+        assert okg == ok and len(resg) == len(res)
+        np.testing.assert_allclose(cg, c, rtol=1e-10)

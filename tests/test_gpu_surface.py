@@ -109,3 +109,37 @@ def test_surface_points_edge_cases():
     np.testing.assert_array_equal(c["mean"], blob[:100, :2].astype(np.float64))
     back = api.MapPointNormal(cells=exp)
     np.testing.assert_array_equal(back.GetCells(), exp)
+
+
+@pytest.mark.parametrize("n", [8192, 8193, 12000, 16384])
+def test_surface_points_large_clouds(n):
+    """Clouds beyond the radix-sort capacity (8192) take the 64-bit bitonic path; 16384 is the maximum."""
+    from oracle import pyoracle as O
+    from tbv_slam_public_amd import api
+    rng = np.random.default_rng(n)
+    pts = np.zeros((n, 4), np.float32)
+    ang = rng.uniform(0, 2 * np.pi, n)
+    rad = rng.uniform(3, 120, n) ** 1.0
+    # points along 40 wall-like segments plus clutter, like a dense scan
+    seg = rng.integers(0, 40, n)
+    a0 = rng.uniform(0, 2 * np.pi, 40)[seg]
+    d0 = rng.uniform(10, 110, 40)[seg]
+    t = rng.uniform(-25, 25, n)
+    wall = np.stack([d0 * np.cos(a0) - t * np.sin(a0), d0 * np.sin(a0) + t * np.cos(a0)], 1)
+    clutter = np.stack([rad * np.cos(ang), rad * np.sin(ang)], 1)
+    use_wall = rng.random(n) < 0.8
+    pts[:, :2] = np.where(use_wall[:, None], wall + rng.normal(0, 0.15, (n, 2)), clutter)
+    pts[:, 3] = rng.uniform(61, 255, n).round()
+    exp = O.surface_points(pts, 3.0, 1.0, (0, 0), True)
+    got = api.MapPointNormal(pts, 3.0, (0, 0), True).GetCells()
+    assert exp.shape[0] > 200
+    _cmp_cells(got, exp)
+
+
+def test_surface_points_too_many_points_is_an_error():
+    from tbv_slam_public_amd import api, _lib as L
+    pts = np.zeros((16385, 4), np.float32)
+    pts[:, 0] = np.linspace(0, 100, 16385)
+    with pytest.raises(L.CfearError) as e:
+        api.MapPointNormal(pts, 3.0)
+    assert e.value.status == L.ERR_CAPACITY
