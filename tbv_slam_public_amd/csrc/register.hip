@@ -1650,11 +1650,8 @@ extern "C" int cfear_cost_prepare(cfear_ctx* ctx, const cfear_scan* const* scans
   cm.slots_cap = c->slots_cap; cm.lds_targets = (c->lds_targets + 3) & ~3; cm.results = nullptr;
   cm.dense_cap_lds = 0; cm.dense_fields = reg_dense_fields(par->cost);
   int32_t* d_nb = (int32_t*)((char*)c->d_job + sizeof(RegJob));
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)assoc_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    attr_set = true;
-  }
+  // per launch: the attribute is per device, and contexts on other threads / devices share this code
+  (void)hipFuncSetAttribute((const void*)assoc_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   hipLaunchKernelGGL(assoc_kernel, dim3(1), dim3(kRegThreads), reg_lds_bytes(cm.lds_targets, 0, 0), ctx->stream,
                      (const RegJob*)c->d_job, cm, (int)itr, d_nb);
   if (hipGetLastError() != hipSuccess) return fail(CFEAR_ERR_HIP, "assoc_kernel launch failed");

@@ -609,12 +609,9 @@ int cfear_surface_launch(cfear_ctx* ctx, const void* d_jobs, int n_jobs, const c
   cm.scratch_stride = scratch_bytes_per_scan();
   cm.status = d_status;
   cm.ncells_out = d_ncells_out;
-  static bool attr_set = false;
-  if (!attr_set) {
-    CFEAR_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)surface_points_kernel,
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)cfear_surface_lds_bytes()));
-    attr_set = true;
-  }
+  // per launch: the attribute is per device, and contexts on other threads / devices share this code
+  CFEAR_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)surface_points_kernel,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)cfear_surface_lds_bytes()));
   ProfScope ps(ctx, "surface_points");
   hipLaunchKernelGGL(surface_points_kernel, dim3(n_jobs), dim3(kSurfThreads), cfear_surface_lds_bytes(), ctx->stream,
                      (const SurfJob*)d_jobs, cm);
@@ -706,14 +703,9 @@ extern "C" int cfear_scan_from_cells(cfear_ctx* ctx, const cfear_cell* cells, in
   {
     int npad = 64;
     while (npad < n_cells) npad <<= 1;
-    if ((size_t)npad * 8 > 64 * 1024) {
-      static bool attr_set = false;
-      if (!attr_set) {
-        CFEAR_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)scan_sort_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                 (int)((size_t)kMaxPoints * 8)));
-        attr_set = true;
-      }
-    }
+    if ((size_t)npad * 8 > 64 * 1024)
+      CFEAR_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)scan_sort_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                               (int)((size_t)kMaxPoints * 8)));
     if (npad > kMaxPoints) { cfear_scan_destroy(s); return cfear_set_error(ctx, CFEAR_ERR_CAPACITY, "more than %d cells", kMaxPoints); }
     hipLaunchKernelGGL(scan_sort_kernel, dim3(1), dim3(kSurfThreads), (size_t)npad * 8, ctx->stream, s->view);
     CFEAR_HIP_CHECK(ctx, hipGetLastError());
