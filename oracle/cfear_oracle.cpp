@@ -1243,6 +1243,125 @@ extern "C" int orc_coral_quality(const float* ref_xyzi, int n_ref, const float* 
 }
 
 // ==========================================================================================
+// Scan Context on radar clouds: RSCManager::MakeRadarCloudContext and the SCManager distance
+// (place_recognition_radar/src/place_recognition_radar/RadarScancontext.cpp:59-131,
+//  Scancontext.cpp:60-268) -- the descriptor TBV builds per pose-graph node from the local map of
+// peak clouds (tbv_slam loopclosure.cpp:552-590) and the column-shift distance of detectLoopClosureID.
+// Descriptors are row-major [ring][sector] here (Eigen's MatrixXd is column-major; indices agree).
+// ==========================================================================================
+namespace {
+
+// Scancontext.cpp:60-76 (float in, float out; atan is the float overload)
+float sc_xy2theta(float x, float y) {
+  if ((x >= 0) & (y >= 0)) return (float)((180 / M_PI) * std::atan(y / x));
+  if ((x < 0) & (y >= 0)) return (float)(180 - ((180 / M_PI) * std::atan(y / (-x))));
+  if ((x < 0) & (y < 0)) return (float)(180 + ((180 / M_PI) * std::atan(y / x)));
+  if ((x >= 0) & (y < 0)) return (float)(360 - ((180 / M_PI) * std::atan((-y) / x)));
+  return 0;
+}
+
+}  // namespace
+
+// RSCManager::MakeRadarCloudContext (RadarScancontext.cpp:59-131) of the cloud translated by (0, shift_y):
+// shift_y != 0 restates the augmentation pcl::transformPointCloud(cloud, VectorToAffine3dxyez({0, dy, 0}))
+// (:163-170; identity rotation: x stays, y' = float(double(y) + dy)).
+// desc_function: 0 = "sum", 1 = "max".  desc [num_ring * num_sector].
+extern "C" void orc_sc_descriptor(const float* xyzi, int n, int num_ring, int num_sector, double max_radius,
+                                  int desc_function, double desc_divider, double no_point, double shift_y,
+                                  double* desc) {
+  const int NO_POINT = -1000;
+  const int cells = num_ring * num_sector;
+  for (int i = 0; i < cells; i++) desc[i] = NO_POINT;
+  for (int k = 0; k < n; k++) {
+    float px = xyzi[4 * k], py = xyzi[4 * k + 1];
+    if (shift_y != 0.0) {
+      px = (float)(((1.0 * (double)px + 0.0 * (double)py) + 0.0 * (double)xyzi[4 * k + 2]) + 0.0);
+      py = (float)(((0.0 * (double)xyzi[4 * k] + 1.0 * (double)py) + 0.0 * (double)xyzi[4 * k + 2]) + shift_y);
+    }
+    const float intensity = xyzi[4 * k + 3];
+    const float azim_range = std::sqrt(px * px + py * py);
+    const float azim_angle = sc_xy2theta(px, py);
+    if (azim_range > max_radius) continue;
+    double rr = std::ceil((azim_range / max_radius) * num_ring), ss = std::ceil((azim_angle / 360.0) * num_sector);
+    // int(NaN) is undefined; the origin itself (0/0) is put in the first sector
+    const int ring_idx = std::max(std::min(num_ring, rr == rr ? (int)rr : 1), 1);
+    const int sctor_idx = std::max(std::min(num_sector, ss == ss ? (int)ss : 1), 1);
+    double& d = desc[(ring_idx - 1) * num_sector + (sctor_idx - 1)];
+    if (d == NO_POINT) d = intensity;
+    else if (desc_function == 0) d += intensity;
+    else d = std::max(d, (double)intensity);
+  }
+  for (int i = 0; i < cells; i++) desc[i] = desc[i] / desc_divider;       // "Divison before no_point check" (:113)
+  for (int i = 0; i < cells; i++)
+    if (desc[i] == NO_POINT) desc[i] = no_point;                          // only reachable when desc_divider == 1
+}
+
+// makeRingkeyFromScancontext / makeSectorkeyFromScancontext (Scancontext.cpp:239-268): row / column means
+extern "C" void orc_sc_keys(const double* desc, int num_ring, int num_sector, double* ringkey, double* sectorkey) {
+  for (int r = 0; r < num_ring; r++) {
+    double s = 0;
+    for (int c = 0; c < num_sector; c++) s += desc[r * num_sector + c];
+    ringkey[r] = s / num_sector;
+  }
+  for (int c = 0; c < num_sector; c++) {
+    double s = 0;
+    for (int r = 0; r < num_ring; r++) s += desc[r * num_sector + c];
+    sectorkey[c] = s / num_ring;
+  }
+}
+
+// distanceBtnScanContext (Scancontext.cpp:157-189) incl. fastAlignUsingVkey (:134-154), distDirectSC (:110-131)
+// and circshift (:80-100).  Returns the minimum distance; *argmin_shift the column shift of sc2.
+extern "C" double orc_sc_distance(const double* sc1, const double* sc2, int num_ring, int num_sector,
+                                  double search_ratio, int32_t* argmin_shift) {
+  const int R = num_ring, S = num_sector;
+  std::vector<double> rk(R), v1(S), v2(S);
+  orc_sc_keys(sc1, R, S, rk.data(), v1.data());
+  orc_sc_keys(sc2, R, S, rk.data(), v2.data());
+  int argmin_vkey_shift = 0;
+  double min_vkey = 10000000;
+  for (int sh = 0; sh < S; sh++) {                       // vkey2 shifted right by sh: shifted[(c + sh) % S] = v2[c]
+    double sq = 0;
+    for (int c = 0; c < S; c++) {
+      const double d = v1[(c + sh) % S] - v2[c];
+      sq += d * d;
+    }
+    const double nrm = std::sqrt(sq);
+    if (nrm < min_vkey) { argmin_vkey_shift = sh; min_vkey = nrm; }
+  }
+  const int SEARCH_RADIUS = (int)std::round(0.5 * search_ratio * S);
+  std::vector<int> space{argmin_vkey_shift};
+  for (int ii = 1; ii < SEARCH_RADIUS + 1; ii++) {
+    space.push_back((argmin_vkey_shift + ii + S) % S);
+    space.push_back((argmin_vkey_shift - ii + S) % S);
+  }
+  std::sort(space.begin(), space.end());
+  int best_shift = 0;
+  double min_dist = 10000000;
+  for (int sh : space) {
+    int eff = 0;
+    double sum_sim = 0;
+    for (int c = 0; c < S; c++) {                        // column c of sc1 against column (c - sh) of sc2
+      const int c2 = ((c - sh) % S + S) % S;
+      double n1 = 0, n2 = 0, dot = 0;
+      for (int r = 0; r < R; r++) {
+        const double a = sc1[r * S + c], b = sc2[r * S + c2];
+        n1 += a * a; n2 += b * b; dot += a * b;
+      }
+      n1 = std::sqrt(n1); n2 = std::sqrt(n2);
+      if ((n1 == 0) | (n2 == 0)) continue;
+      sum_sim += dot / (n1 * n2);
+      eff++;
+    }
+    eff = std::max(eff, 1);
+    const double dist = 1.0 - sum_sim / eff;
+    if (dist < min_dist) { best_shift = sh; min_dist = dist; }
+  }
+  *argmin_shift = best_shift;
+  return min_dist;
+}
+
+// ==========================================================================================
 // caller: OdometryKeyframeFuser  (odometrykeyframefuser.cpp:62-94, 143-259, 470-494)
 // ==========================================================================================
 struct orc_fuser {

@@ -123,6 +123,14 @@ int orc_coral_quality(const float* ref_xyzi, int n_ref, const float* src_xyzi, i
                       const double ref_pose[3], const double src_pose[3], const double offset[3],
                       double radius, int weight_res_intensity, double quality[3], double* per_point);
 
+/* Scan Context on radar clouds (RadarScancontext.cpp:59-131, Scancontext.cpp:60-268).  Descriptors are
+ * row-major [ring][sector].  desc_function 0 = sum, 1 = max; shift_y = the y offset of an augmentation. */
+void orc_sc_descriptor(const float* xyzi, int n, int num_ring, int num_sector, double max_radius,
+                       int desc_function, double desc_divider, double no_point, double shift_y, double* desc);
+void orc_sc_keys(const double* desc, int num_ring, int num_sector, double* ringkey, double* sectorkey);
+double orc_sc_distance(const double* sc1, const double* sc2, int num_ring, int num_sector,
+                       double search_ratio, int32_t* argmin_shift);
+
 /* ---- caller: OdometryKeyframeFuser (odometrykeyframefuser.cpp:62-94,143-259,470-494) ----- */
 typedef struct orc_fuser_params {
   orc_reg_params reg;

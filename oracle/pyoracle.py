@@ -95,6 +95,13 @@ def lib():
         pp = C.POINTER(C.c_void_p)
         L.orc_register.argtypes = [pp, i32p, C.c_int, f64p, C.POINTER(OrcRegParams), C.POINTER(OrcRegResult)]
         L.orc_get_cost.argtypes = [pp, i32p, C.c_int, f64p, C.POINTER(OrcRegParams), f64p, f64p, i32p, f64p]
+        L.orc_sc_descriptor.argtypes = [f32p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, C.c_double, C.c_double,
+                                        C.c_double, f64p]
+        L.orc_sc_descriptor.restype = None
+        L.orc_sc_keys.argtypes = [f64p, C.c_int, C.c_int, f64p, f64p]
+        L.orc_sc_keys.restype = None
+        L.orc_sc_distance.argtypes = [f64p, f64p, C.c_int, C.c_int, C.c_double, i32p]
+        L.orc_sc_distance.restype = C.c_double
         L.orc_coral_quality.argtypes = [f32p, C.c_int, f32p, C.c_int, f64p, f64p, f64p, C.c_double, C.c_int, f64p, f64p]
         L.orc_cov_by_sampling.argtypes = [pp, i32p, C.c_int, f64p, C.POINTER(OrcRegParams), C.c_double, C.c_int32,
                                           C.c_double, C.c_double, C.c_int32, C.c_double, f64p, f64p]
@@ -225,6 +232,35 @@ def cov_by_sampling(scans, poses, par, final_cost, num_residuals, xy_range=0.4, 
                                    int(samples_per_axis), float(covariance_scaler), _p(cov, C.c_double),
                                    _p(smp, C.c_double))
     return bool(ok), cov, smp
+
+
+def sc_descriptor(xyzi, num_ring=40, num_sector=120, max_radius=80.0, desc_function="sum", desc_divider=1000.0,
+                  no_point=0.0, shift_y=0.0):
+    """RSCManager::MakeRadarCloudContext (RadarScancontext.cpp:59-131) -> desc [num_ring, num_sector]."""
+    c = np.ascontiguousarray(xyzi, dtype=np.float32)
+    desc = np.zeros((num_ring, num_sector), np.float64)
+    lib().orc_sc_descriptor(_p(c, C.c_float), c.shape[0], num_ring, num_sector, float(max_radius),
+                            0 if desc_function == "sum" else 1, float(desc_divider), float(no_point), float(shift_y),
+                            _p(desc, C.c_double))
+    return desc
+
+
+def sc_keys(desc):
+    """(ring key [R], sector key [S]) (Scancontext.cpp:239-268)."""
+    d = np.ascontiguousarray(desc, dtype=np.float64)
+    rk, sk = np.zeros(d.shape[0]), np.zeros(d.shape[1])
+    lib().orc_sc_keys(_p(d, C.c_double), d.shape[0], d.shape[1], _p(rk, C.c_double), _p(sk, C.c_double))
+    return rk, sk
+
+
+def sc_distance(sc1, sc2, search_ratio=0.1):
+    """distanceBtnScanContext (Scancontext.cpp:157-189) -> (distance, argmin column shift of sc2)."""
+    a = np.ascontiguousarray(sc1, dtype=np.float64)
+    b = np.ascontiguousarray(sc2, dtype=np.float64)
+    sh = C.c_int32()
+    d = lib().orc_sc_distance(_p(a, C.c_double), _p(b, C.c_double), a.shape[0], a.shape[1], float(search_ratio),
+                              C.byref(sh))
+    return d, sh.value
 
 
 def coral_quality(ref_xyzi, src_xyzi, ref_pose, src_pose, offset=(0.0, 0.0, 0.0), radius=1.0,
