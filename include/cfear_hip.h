@@ -333,6 +333,38 @@ int cfear_coral_quality(cfear_ctx* ctx, const cfear_coral_job* job, const cfear_
 int cfear_coral_quality_batch(cfear_ctx* ctx, const cfear_coral_job* jobs, int32_t n_jobs,
                               const cfear_coral_params* par, cfear_coral_result* results, double* per_point);
 
+/* ---- before the path: radar Scan Context (loop-candidate generation) ------------------------------
+ * Replaces the arithmetic of RSCManager / SCManager (place_recognition_radar/src/place_recognition_radar/
+ * RadarScancontext.cpp:59-131, 156-180; Scancontext.cpp:60-268): the ring x sector descriptor of a
+ * local-map cloud (TBV: merged peak clouds of 2 N_aggregate + 1 nodes in the node's frame, loopclosure.cpp:
+ * 552-590), its ring / sector keys, and distanceBtnScanContext.  The descriptor database, the odometry-
+ * coupled ring-key search and the candidate ranking stay on the host (api.py RSCManager mirrors them). */
+typedef struct cfear_sc_params {
+  int32_t num_ring, num_sector;         /* PC_NUM_RING 40, PC_NUM_SECTORS 120                          */
+  double max_radius;                    /* PC_MAX_RADIUS 80                                            */
+  double search_ratio;                  /* SEARCH_RATIO 0.1                                            */
+  int32_t desc_function;                /* 0 = "sum", 1 = "max"                                        */
+  int32_t pad;
+  double desc_divider;                  /* 1000 in TBV's launch defaults                               */
+  double no_point;                      /* value of empty bins (reached only when desc_divider == 1)   */
+} cfear_sc_params;
+void cfear_sc_params_default(cfear_sc_params* p);
+typedef struct cfear_sc_cloud {
+  const float* xyzi;                    /* [n][4] x,y,z,intensity in the node's frame; host or device   */
+  int32_t n, pad;
+} cfear_sc_cloud;
+/* MakeRadarCloudContext for n_clouds clouds x n_aug lateral shifts (shifts_y[0] is normally 0; TBV augments
+ * with {-2, 2, -4, 4}).  desc [n_clouds][n_aug][num_ring * num_sector] row-major (ring, sector); ringkey
+ * [..][num_ring] and sectorkey [..][num_sector] optional.  All outputs host.                           */
+int cfear_sc_descriptors(cfear_ctx* ctx, const cfear_sc_cloud* clouds, int32_t n_clouds,
+                         const cfear_sc_params* par, const double* shifts_y, int32_t n_aug, double* desc,
+                         double* ringkey, double* sectorkey);
+/* distanceBtnScanContext for pairs[i] = (query index into desc_q, candidate index into desc_c); descriptors
+ * host or device; dist / shift host [n_pairs] (shift = argmin column shift of the candidate).          */
+int cfear_sc_distance_batch(cfear_ctx* ctx, const double* desc_q, int32_t n_q, const double* desc_c, int32_t n_c,
+                            const int32_t* pairs, int32_t n_pairs, const cfear_sc_params* par, double* dist,
+                            int32_t* shift);
+
 /* ---- caller: batched radarDriver + OdometryKeyframeFuser --------------------------------------
  * n_streams independent sequences advance one frame per call: filter (F) -> compensate (C) ->
  * surface points (N) -> Register against the keyframe window (M) -> keyframe policy.  Restates

@@ -115,6 +115,16 @@ CORAL_RESULT_DTYPE = np.dtype([("joint", "<f8"), ("sep", "<f8"), ("overlap", "<f
                                ("count_valid", "<i4"), ("status", "<i4"), ("pad", "<i4")])
 
 
+class ScParams(C.Structure):
+    _fields_ = [("num_ring", C.c_int32), ("num_sector", C.c_int32), ("max_radius", C.c_double),
+                ("search_ratio", C.c_double), ("desc_function", C.c_int32), ("pad", C.c_int32),
+                ("desc_divider", C.c_double), ("no_point", C.c_double)]
+
+
+class ScCloud(C.Structure):
+    _fields_ = [("xyzi", C.c_void_p), ("n", C.c_int32), ("pad", C.c_int32)]
+
+
 class OdometryParams(C.Structure):
     _fields_ = [("filter_type", C.c_int32), ("kstrong", KStrongParams), ("cacfar", CacfarParams),
                 ("reg", RegParams), ("res", C.c_float), ("submap_scan_size", C.c_int32),
@@ -145,7 +155,7 @@ EXPORTS = [
     "cfear_reg_params_default", "cfear_register", "cfear_register_batch", "cfear_get_cost",
     "cfear_get_cost_batch", "cfear_cov_sampling_params_default", "cfear_covariance_by_sampling",
     "cfear_covariance_by_sampling_batch", "cfear_coral_params_default", "cfear_coral_quality",
-    "cfear_coral_quality_batch",
+    "cfear_coral_quality_batch", "cfear_sc_params_default", "cfear_sc_descriptors", "cfear_sc_distance_batch",
     "cfear_cost_prepare", "cfear_cost_num_blocks", "cfear_cost_num_residuals", "cfear_cost_get_blocks",
     "cfear_cost_evaluate", "cfear_cost_normal_eq", "cfear_cost_destroy",
     "cfear_odometry_params_default", "cfear_odometry_create", "cfear_odometry_process",
@@ -210,6 +220,11 @@ def lib():
     L.cfear_coral_params_default.restype = None
     L.cfear_coral_quality.argtypes = [vp, C.POINTER(CoralJob), C.POINTER(CoralParams), vp, vp]
     L.cfear_coral_quality_batch.argtypes = [vp, C.POINTER(CoralJob), C.c_int32, C.POINTER(CoralParams), vp, vp]
+    L.cfear_sc_params_default.argtypes = [C.POINTER(ScParams)]
+    L.cfear_sc_params_default.restype = None
+    L.cfear_sc_descriptors.argtypes = [vp, C.POINTER(ScCloud), C.c_int32, C.POINTER(ScParams), C.POINTER(C.c_double),
+                                       C.c_int32, vp, vp, vp]
+    L.cfear_sc_distance_batch.argtypes = [vp, vp, C.c_int32, vp, C.c_int32, vp, C.c_int32, C.POINTER(ScParams), vp, vp]
     L.cfear_get_cost.argtypes = [vp, C.POINTER(vp), C.c_int32, C.POINTER(C.c_double), C.POINTER(RegParams),
                                  C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int32,
                                  C.POINTER(C.c_int32), C.POINTER(C.c_double)]

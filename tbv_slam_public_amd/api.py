@@ -548,6 +548,177 @@ def _cloud_ptr(cloud):
     return cloud.data_ptr(), int(cloud.shape[0]), cloud
 
 
+# ------------------------------------------------------------------------------------------------
+# radar Scan Context (loop-candidate generation; place_recognition_radar)
+# ------------------------------------------------------------------------------------------------
+def sc_params(**kw):
+    """cfear_sc_params with TBV's defaults (40 x 120, 80 m, search ratio 0.1, sum / 1000)."""
+    p = L.ScParams()
+    L.lib().cfear_sc_params_default(C.byref(p))
+    for k, v in kw.items():
+        if k == "desc_function" and isinstance(v, str):
+            v = {"sum": 0, "max": 1}[v]
+        if not hasattr(p, k):
+            raise KeyError(k)
+        setattr(p, k, v)
+    return p
+
+
+def sc_descriptors(clouds, par=None, shifts_y=(0.0,), ctx=None):
+    """MakeRadarCloudContext (RadarScancontext.cpp:59-131) for a list of clouds and lateral shifts.
+    -> (desc [n, A, R, S], ringkey [n, A, R], sectorkey [n, A, S])."""
+    ctx = ctx or default_context()
+    par = par or sc_params()
+    n, A = len(clouds), len(shifts_y)
+    arr = (L.ScCloud * max(n, 1))()
+    keep = []
+    for i, c in enumerate(clouds):
+        ptr, m, k = _cloud_ptr(c)
+        keep.append(k)
+        arr[i].xyzi, arr[i].n = ptr, m
+    R, S = par.num_ring, par.num_sector
+    desc = np.zeros((n, A, R, S), np.float64)
+    rk = np.zeros((n, A, R), np.float64)
+    sk = np.zeros((n, A, S), np.float64)
+    sh = (C.c_double * A)(*[float(v) for v in shifts_y])
+    ctx.check(ctx._lib.cfear_sc_descriptors(ctx.h, arr, n, C.byref(par), sh, A, desc.ctypes.data, rk.ctypes.data,
+                                            sk.ctypes.data))
+    return desc, rk, sk
+
+
+def sc_distance_batch(desc_q, desc_c, pairs, par=None, ctx=None):
+    """distanceBtnScanContext (Scancontext.cpp:157-189) for pairs (query index, candidate index).
+    desc_q [nq, R, S], desc_c [nc, R, S] float64 -> (dist [n_pairs], argmin_shift [n_pairs])."""
+    ctx = ctx or default_context()
+    par = par or sc_params()
+    q = np.ascontiguousarray(desc_q, dtype=np.float64)
+    c = np.ascontiguousarray(desc_c, dtype=np.float64)
+    pr = np.ascontiguousarray(pairs, dtype=np.int32).reshape(-1, 2)
+    dist = np.zeros(pr.shape[0], np.float64)
+    shift = np.zeros(pr.shape[0], np.int32)
+    if pr.shape[0]:
+        ctx.check(ctx._lib.cfear_sc_distance_batch(ctx.h, q.ctypes.data, q.shape[0], c.ctypes.data, c.shape[0],
+                                                   pr.ctypes.data, pr.shape[0], C.byref(par), dist.ctypes.data,
+                                                   shift.ctypes.data))
+    return dist, shift
+
+
+class RSCManager:
+    """RSCManager (place_recognition_radar RadarScancontext.{h,cpp}) for cloud descriptors: the descriptor
+    database, the recent-node exclusion, the odometry similarity and the candidate ranking are host policy
+    restated here; descriptors and scan-context distances run on the GPU."""
+
+    DISTANCE_EXCLUDE_RECENT = 10.0                    # Scancontext.h:108
+    AUGMENTS_Y = (-2.0, 2.0, -4.0, 4.0)               # RadarScancontext.cpp:164
+
+    def __init__(self, par=None, num_candidates_from_tree=10, n_candidates=3, odom_sigma_error=0.05,
+                 odometry_coupled_closure=True, augment_sc=True, ctx=None):
+        self.ctx = ctx or default_context()
+        self.par = par or sc_params()
+        self.NUM_CANDIDATES_FROM_TREE = int(num_candidates_from_tree)
+        self.N_candidates = int(n_candidates)
+        self.odom_sigma_error = float(odom_sigma_error)
+        self.odometry_coupled_closure = bool(odometry_coupled_closure)
+        self.augment_sc = bool(augment_sc)
+        self.polarcontexts_ = []                      # [R, S] float64 per node
+        self.polarcontext_invkeys_mat_ = []           # float32 ring keys (eig2stdvec), [R] per node
+        self.odom_poses_ = []                         # (x, y, theta)
+        self.odom_similarity = np.zeros(0)
+        self.NUM_EXCLUDE_RECENT = 0
+        self.current_and_augments_ = []               # (desc, ring key float32, (tx, ty, theta) of the augmentation)
+
+    def makeAndSaveScancontextAndKeysRadarCloud(self, cloud, Todom):
+        """RadarScancontext.cpp:156-180 (+ :133-146, :181-225)."""
+        shifts = (0.0,) + (self.AUGMENTS_Y if self.augment_sc else ())
+        desc, rk, _ = sc_descriptors([cloud], self.par, shifts, self.ctx)
+        self.polarcontexts_.append(desc[0, 0].copy())
+        self.polarcontext_invkeys_mat_.append(rk[0, 0].astype(np.float32))
+        self.current_and_augments_ = [(desc[0, k].copy(), rk[0, k].astype(np.float32), (0.0, float(shifts[k]), 0.0))
+                                      for k in range(len(shifts))]
+        self._exclude_and_update_likelihood(np.asarray(Todom, np.float64))
+
+    def _exclude_and_update_likelihood(self, Todom):                       # RadarScancontext.cpp:181-222
+        self.odom_poses_.append(Todom)
+        P = np.asarray(self.odom_poses_)
+        if len(P) <= 2:
+            self.NUM_EXCLUDE_RECENT = 2
+        else:
+            distance, n_ex, prev = 0.0, 0, P[-1]
+            i = len(P) - 1
+            while i >= 0 and distance < self.DISTANCE_EXCLUDE_RECENT:
+                distance = distance + float(np.hypot(*(P[i][:2] - prev[:2])))   # |(Tprev^-1 T_i).translation()|
+                prev = P[i]
+                n_ex += 1
+                i -= 1
+            self.NUM_EXCLUDE_RECENT = n_ex
+        idx_current = len(P) - 1
+        self.odom_similarity = np.zeros(idx_current)
+        tprev = Todom[:2].copy()
+        trav = 0.0
+        for i in range(idx_current - 1, -1, -1):
+            t_i = P[i][:2]
+            trav += float(np.hypot(*(tprev - t_i)))
+            tprev = t_i
+            est = float(np.hypot(*(Todom[:2] - t_i)))
+            error = max(est - 5.0, 0.0)
+            with np.errstate(divide="ignore", invalid="ignore"):
+                rel = np.float64(error) / np.float64(trav)
+            prob = np.exp(-rel * rel / (2 * self.odom_sigma_error * self.odom_sigma_error))
+            self.odom_similarity[i] = 1.0 - prob
+
+    def _odometry_nn_search(self, curr_key):                                # RadarScancontext.cpp:259-284
+        key = np.append(curr_key.astype(np.float32), np.float32(0.0))
+        idx_current = len(self.polarcontext_invkeys_mat_) - 1
+        cands = []
+        for idx in range(0, max(idx_current - 1 - self.NUM_EXCLUDE_RECENT, 0)):
+            other = np.append(self.polarcontext_invkeys_mat_[idx], np.float32(10 * self.odom_similarity[idx]))
+            l2 = np.float32(0.0)                      # `float l2`, err in double (L2norm, :250-257)
+            for a_, b_ in zip(key, other):
+                err = np.float64(a_ - b_)             # float subtraction promoted to double
+                l2 = np.float32(np.float64(l2) + err * err)
+            cands.append((float(l2), idx))
+        cands.sort()                                  # lower_bound insertion == sort by (distance, index)
+        return [i for _, i in cands[:self.NUM_CANDIDATES_FROM_TREE]]
+
+    def _vanilla_nn_search(self, curr_key):                                 # RadarScancontext.cpp:225-248 (exact KNN)
+        n = len(self.polarcontext_invkeys_mat_) - self.NUM_EXCLUDE_RECENT
+        if n <= 0:
+            return []
+        K = np.asarray(self.polarcontext_invkeys_mat_[:n], np.float32)
+        d = ((K - curr_key.astype(np.float32)[None]) ** 2).sum(1)
+        order = np.argsort(d, kind="stable")[:self.NUM_CANDIDATES_FROM_TREE]
+        return [int(i) for i in order]
+
+    def detectLoopClosureID(self):
+        """RadarScancontext.cpp:286-345 -> list of candidates dict(min_dist, min_dist_sc, min_dist_odom,
+        yaw_diff_rad, nn_idx, argmin_shift, Taug), closest first."""
+        if len(self.polarcontext_invkeys_mat_) < self.NUM_EXCLUDE_RECENT + 1:
+            return []
+        jobs = []                                     # (query k, candidate idx) in the reference's visiting order
+        for k, (_d, rk, _T) in enumerate(self.current_and_augments_):
+            idxs = self._odometry_nn_search(rk) if self.odometry_coupled_closure else self._vanilla_nn_search(rk)
+            jobs += [(k, i) for i in idxs]
+        if not jobs:
+            return []
+        qd = np.stack([d for d, _, _ in self.current_and_augments_])
+        uniq = sorted({i for _, i in jobs})
+        pos = {i: p for p, i in enumerate(uniq)}
+        cd = np.stack([self.polarcontexts_[i] for i in uniq])
+        dist, shift = sc_distance_batch(qd, cd, [(k, pos[i]) for k, i in jobs], self.par, self.ctx)
+        unit = 360.0 / float(self.par.num_sector)
+        similar = []
+        for (k, i), d_sc, sh in zip(jobs, dist, shift):
+            d_odom = float(self.odom_similarity[i]) if self.odometry_coupled_closure else 0.0
+            d_tot = float(d_sc) + d_odom if self.odometry_coupled_closure else float(d_sc)
+            similar.append(dict(min_dist=d_tot, min_dist_sc=float(d_sc), min_dist_odom=d_odom,
+                                yaw_diff_rad=float(np.float32(np.float32(sh * unit) * np.pi / 180.0)), nn_idx=int(i),
+                                argmin_shift=int(sh), Taug=self.current_and_augments_[k][2]))
+            similar.sort(key=lambda c: c["min_dist"])     # std::sort + erase of the worst (:317-320)
+            if len(similar) > self.N_candidates:
+                similar.pop()
+        return similar
+
+
 def odometry_params(**kw):
     """cfear_odometry_params with the CFEAR-3 / Oxford preset; keyword overrides use the C field names
     (nested: kstrong_k_strongest, cacfar_window_size, reg_cost, cov_sampling_xy_range, ...)."""

@@ -1,0 +1,325 @@
+// scancontext.hip -- radar Scan Context descriptors and their column-shift distance on gfx950.
+//
+// Replaces (place_recognition_radar/src/place_recognition_radar/):
+//   RSCManager::MakeRadarCloudContext (+ the 4 lateral augmentations)   RadarScancontext.cpp:59-131, 156-180
+//   makeRingkeyFromScancontext / makeSectorkeyFromScancontext           Scancontext.cpp:239-268
+//   distanceBtnScanContext = fastAlignUsingVkey + distDirectSC + circshift   Scancontext.cpp:80-189
+// i.e. the arithmetic of the step BEFORE the registration path (loop-candidate generation).
+// The database, the odometry-coupled key search and the candidate ranking (RadarScancontext.cpp:181-345)
+// are host policy and live in the caller (tbv_slam_public_amd/api.py RSCManager mirrors them).
+//
+// sc_descriptor_kernel: one workgroup per (cloud, augmentation); the ring x sector accumulator lives in LDS
+//   (fp64 sum + hit count, or order-preserving integer max); ceil-indexed polar binning with the reference's
+//   float arithmetic; the "division before the NO_POINT check" quirk is kept (empty bins hold -1000 / divider
+//   unless the divider is 1).  Intensities of radar clouds are integer valued, so the LDS fp64 atomics sum
+//   exactly and the result does not depend on the order of arrival.
+// sc_distance_kernel: one workgroup per (query, candidate) pair; both descriptors in LDS (2 x 38 KiB at
+//   40 x 120); one thread per column / per shift, every inner sum sequential in the reference's order, so
+//   distances and argmin shifts are bit-identical with the CPU restatement.
+#include <algorithm>
+#include <cmath>
+#include <vector>
+
+#include "common.hpp"
+
+namespace {
+
+constexpr int kScMaxCells = 5120;        // ring x sector capacity of the LDS accumulators (reference: 40 x 120)
+constexpr int kScMaxAug = 8;
+
+struct ScCloud { const float4* xyzi; int32_t n; int32_t pad; };
+
+struct ScDescArgs {
+  const ScCloud* clouds;
+  int num_ring, num_sector, desc_function, n_aug;
+  double max_radius, desc_divider, no_point;
+  double shift_y[kScMaxAug];
+  double* desc;          // [n_clouds][n_aug][R * S]
+  double* ringkey;       // [n_clouds][n_aug][R]
+  double* sectorkey;     // [n_clouds][n_aug][S]
+};
+
+// Scancontext.cpp:60-76; the reference calls the float overload of atan: the correctly rounded float
+// arctangent is taken from the fp64 routine
+__device__ __forceinline__ float sc_xy2theta(float x, float y) {
+  auto atan_f = [](float v) { return (float)atan((double)v); };
+  if ((x >= 0) & (y >= 0)) return (float)((180 / M_PI) * atan_f(y / x));
+  if ((x < 0) & (y >= 0)) return (float)(180 - ((180 / M_PI) * atan_f(y / (-x))));
+  if ((x < 0) & (y < 0)) return (float)(180 + ((180 / M_PI) * atan_f(y / x)));
+  if ((x >= 0) & (y < 0)) return (float)(360 - ((180 / M_PI) * atan_f((-y) / x)));
+  return 0;
+}
+
+__global__ __launch_bounds__(256) void sc_descriptor_kernel(const ScDescArgs a) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  const int R = a.num_ring, S = a.num_sector, cells = R * S;
+  double* acc = (double*)smem;                       // [cells] sum
+  int* hit = (int*)(acc + cells);                    // [cells] count (sum) / float-ordered max (max)
+  const ScCloud cl = a.clouds[blockIdx.x];
+  const double shift_y = a.shift_y[blockIdx.y];
+  for (int i = threadIdx.x; i < cells; i += blockDim.x) { acc[i] = 0.0; hit[i] = a.desc_function == 0 ? 0 : (int)0x80000000; }
+  __syncthreads();
+  for (int k = threadIdx.x; k < cl.n; k += blockDim.x) {
+    const float4 p = cl.xyzi[k];
+    float px = p.x, py = p.y;
+    if (shift_y != 0.0) {                            // pcl::transformPointCloud with an identity rotation (:163-170)
+      px = (float)(((1.0 * (double)p.x + 0.0 * (double)p.y) + 0.0 * (double)p.z) + 0.0);
+      py = (float)(((0.0 * (double)p.x + 1.0 * (double)p.y) + 0.0 * (double)p.z) + shift_y);
+    }
+    const float azim_range = sqrtf(__fadd_rn(__fmul_rn(px, px), __fmul_rn(py, py)));
+    const float azim_angle = sc_xy2theta(px, py);
+    if ((double)azim_range > a.max_radius) continue;
+    const double rr = ceil(((double)azim_range / a.max_radius) * R), ss = ceil(((double)azim_angle / 360.0) * S);
+    const int ring_idx = max(min(R, rr == rr ? (int)rr : 1), 1);
+    const int sctor_idx = max(min(S, ss == ss ? (int)ss : 1), 1);
+    const int cell = (ring_idx - 1) * S + (sctor_idx - 1);
+    if (a.desc_function == 0) {
+      atomicAdd(&acc[cell], (double)p.w);
+      atomicAdd(&hit[cell], 1);
+    } else {                                         // max: order-preserving int image of the float intensity
+      int u = __float_as_int(p.w);
+      u = u >= 0 ? u : (u ^ 0x7fffffff);
+      atomicMax(&hit[cell], u);
+    }
+  }
+  __syncthreads();
+  const int NO_POINT = -1000;
+  double* out = a.desc + ((size_t)blockIdx.x * a.n_aug + blockIdx.y) * cells;
+  for (int i = threadIdx.x; i < cells; i += blockDim.x) {
+    double d;
+    if (a.desc_function == 0) d = hit[i] > 0 ? acc[i] : (double)NO_POINT;
+    else {
+      const int u = hit[i];
+      d = u == (int)0x80000000 ? (double)NO_POINT : (double)__int_as_float(u >= 0 ? u : (u ^ 0x7fffffff));
+    }
+    d = d / a.desc_divider;                          // "Divison before no_point check" (:113)
+    if (d == NO_POINT) d = a.no_point;
+    acc[i] = d;
+    out[i] = d;
+  }
+  __syncthreads();
+  double* rk = a.ringkey + ((size_t)blockIdx.x * a.n_aug + blockIdx.y) * R;
+  double* sk = a.sectorkey + ((size_t)blockIdx.x * a.n_aug + blockIdx.y) * S;
+  for (int r = threadIdx.x; r < R; r += blockDim.x) {  // row means, sequential like Eigen's row.mean() restatement
+    double s = 0;
+    for (int c = 0; c < S; c++) s += acc[r * S + c];
+    rk[r] = s / S;
+  }
+  for (int c = threadIdx.x; c < S; c += blockDim.x) {
+    double s = 0;
+    for (int r = 0; r < R; r++) s += acc[r * S + c];
+    sk[c] = s / R;
+  }
+}
+
+struct ScDistArgs {
+  const double* desc_q;      // [nq][R * S]
+  const double* desc_c;      // [nc][R * S]
+  const int32_t* pairs;      // [n_pairs][2] (query index, candidate index)
+  int num_ring, num_sector;
+  double search_ratio;
+  double* dist;              // [n_pairs]
+  int32_t* shift;            // [n_pairs]
+};
+
+__global__ __launch_bounds__(256) void sc_distance_kernel(const ScDistArgs a) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  const int R = a.num_ring, S = a.num_sector, cells = R * S;
+  double* sc1 = (double*)smem;
+  double* sc2 = sc1 + cells;
+  double* n1 = sc2 + cells;            // [S] column norms of sc1
+  double* n2 = n1 + S;
+  double* v1 = n2 + S;                 // [S] sector keys
+  double* v2 = v1 + S;
+  double* tmp = v2 + S;                // [S] per-shift / per-column results
+  int* ctl = (int*)(tmp + S);          // [2 + 2 * S] argmin, count, search space
+  const int qi = a.pairs[2 * blockIdx.x], ci = a.pairs[2 * blockIdx.x + 1];
+  const double* gq = a.desc_q + (size_t)qi * cells;
+  const double* gc = a.desc_c + (size_t)ci * cells;
+  for (int i = threadIdx.x; i < cells; i += blockDim.x) { sc1[i] = gq[i]; sc2[i] = gc[i]; }
+  __syncthreads();
+  for (int c = threadIdx.x; c < S; c += blockDim.x) {
+    double s1 = 0, s2 = 0, q1 = 0, q2 = 0;
+    for (int r = 0; r < R; r++) {
+      const double x = sc1[r * S + c], y = sc2[r * S + c];
+      s1 += x; s2 += y; q1 += x * x; q2 += y * y;
+    }
+    v1[c] = s1 / R; v2[c] = s2 / R; n1[c] = sqrt(q1); n2[c] = sqrt(q2);
+  }
+  __syncthreads();
+  // fastAlignUsingVkey (Scancontext.cpp:134-154): |vkey1 - circshift(vkey2, sh)| for every shift
+  for (int sh = threadIdx.x; sh < S; sh += blockDim.x) {
+    double sq = 0;
+    for (int c = 0; c < S; c++) {
+      const double d = v1[(c + sh) % S] - v2[c];
+      sq += d * d;
+    }
+    tmp[sh] = sqrt(sq);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int arg = 0;
+    double mn = 10000000;
+    for (int sh = 0; sh < S; sh++)
+      if (tmp[sh] < mn) { arg = sh; mn = tmp[sh]; }
+    // search space around it, ascending (:166-174)
+    const int rad = (int)round(0.5 * a.search_ratio * S);
+    int* space = ctl + 2;
+    int m = 0;
+    space[m++] = arg;
+    for (int ii = 1; ii < rad + 1; ii++) { space[m++] = (arg + ii + S) % S; space[m++] = (arg - ii + S) % S; }
+    for (int i = 1; i < m; i++) {                    // insertion sort (m <= 2 rad + 1)
+      const int v = space[i];
+      int j = i - 1;
+      while (j >= 0 && space[j] > v) { space[j + 1] = space[j]; j--; }
+      space[j + 1] = v;
+    }
+    ctl[0] = m;
+  }
+  __syncthreads();
+  const int m = ctl[0];
+  const int* space = ctl + 2;
+  double best = 10000000;
+  int best_shift = 0;
+  for (int k = 0; k < m; k++) {                      // distDirectSC(sc1, circshift(sc2, sh)) (:110-131)
+    const int sh = space[k];
+    for (int c = threadIdx.x; c < S; c += blockDim.x) {
+      const int c2 = ((c - sh) % S + S) % S;
+      double dot = 0;
+      for (int r = 0; r < R; r++) dot += sc1[r * S + c] * sc2[r * S + c2];
+      const bool skip = (n1[c] == 0) | (n2[c2] == 0);
+      tmp[c] = skip ? -2.0 : dot / (n1[c] * n2[c2]);  // cosine similarities lie in [-1, 1]: -2 marks "not counted"
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      int eff = 0;
+      double sum = 0;
+      for (int c = 0; c < S; c++)
+        if (tmp[c] != -2.0) { sum = sum + tmp[c]; eff = eff + 1; }
+      eff = max(eff, 1);
+      const double d = 1.0 - sum / eff;
+      if (d < best) { best_shift = sh; best = d; }
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { a.dist[blockIdx.x] = best; a.shift[blockIdx.x] = best_shift; }
+}
+
+int check_sc_params(cfear_ctx* ctx, const cfear_sc_params* p) {
+  if (!p) return cfear_set_error(ctx, CFEAR_ERR_INVALID_ARGUMENT, "null parameters");
+  if (p->num_ring < 1 || p->num_sector < 1 || (long long)p->num_ring * p->num_sector > kScMaxCells)
+    return cfear_set_error(ctx, CFEAR_ERR_CAPACITY, "num_ring x num_sector must be in [1, %d]", kScMaxCells);
+  if (!(p->max_radius > 0) || p->desc_divider == 0.0 || p->desc_function < 0 || p->desc_function > 1)
+    return cfear_set_error(ctx, CFEAR_ERR_INVALID_ARGUMENT, "bad scan-context parameters");
+  return CFEAR_OK;
+}
+
+}  // namespace
+
+extern "C" void cfear_sc_params_default(cfear_sc_params* p) {
+  if (!p) return;
+  p->num_ring = 40; p->num_sector = 120;           // RadarScancontext.h:37-38
+  p->max_radius = 80.0;                            // :39
+  p->search_ratio = 0.1;                           // :40
+  p->desc_function = 0;                            // "sum" (:52)
+  p->pad = 0;
+  p->desc_divider = 1000.0;                        // tbv_slam_offline.cpp:88 (the struct default is 1)
+  p->no_point = 0.0;                               // :51
+}
+
+extern "C" int cfear_sc_descriptors(cfear_ctx* ctx, const cfear_sc_cloud* clouds, int32_t n_clouds,
+                                    const cfear_sc_params* par, const double* shifts_y, int32_t n_aug, double* desc,
+                                    double* ringkey, double* sectorkey) {
+  if (!ctx) return CFEAR_ERR_INVALID_ARGUMENT;
+  if (!clouds || !desc || n_clouds < 0) return cfear_set_error(ctx, CFEAR_ERR_INVALID_ARGUMENT, "null argument");
+  int rc = check_sc_params(ctx, par);
+  if (rc != CFEAR_OK) return rc;
+  if (n_aug < 1 || n_aug > kScMaxAug || (n_aug > 1 && !shifts_y))
+    return cfear_set_error(ctx, CFEAR_ERR_INVALID_ARGUMENT, "n_aug must be in [1, %d]", kScMaxAug);
+  if (n_clouds == 0) return CFEAR_OK;
+  CFEAR_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  const int R = par->num_ring, S = par->num_sector, cells = R * S;
+  // stage host clouds
+  size_t stage = 0;
+  for (int i = 0; i < n_clouds; i++) {
+    if (clouds[i].n < 0 || (clouds[i].n > 0 && !clouds[i].xyzi)) return cfear_set_error(ctx, CFEAR_ERR_INVALID_ARGUMENT, "cloud %d: null", i);
+    if (!cfear_is_device_ptr(clouds[i].xyzi)) stage += ((size_t)clouds[i].n * 16 + 255) / 256 * 256;
+  }
+  const size_t nd = (size_t)n_clouds * n_aug;
+  const size_t out_bytes = nd * (cells + R + S) * sizeof(double);
+  const size_t head = ((size_t)n_clouds * sizeof(ScCloud) + 255) / 256 * 256;
+  char* ws = (char*)cfear_workspace(ctx, 8, head + stage + 256);
+  char* wo = (char*)cfear_workspace(ctx, 9, out_bytes + 256);
+  if (!ws || !wo) return cfear_set_error(ctx, CFEAR_ERR_HIP, "workspace allocation failed");
+  std::vector<ScCloud> h(n_clouds);
+  size_t off = head;
+  for (int i = 0; i < n_clouds; i++) {
+    h[i].n = clouds[i].n; h[i].pad = 0;
+    if (cfear_is_device_ptr(clouds[i].xyzi) || clouds[i].n == 0) h[i].xyzi = (const float4*)clouds[i].xyzi;
+    else {
+      CFEAR_HIP_CHECK(ctx, hipMemcpyAsync(ws + off, clouds[i].xyzi, (size_t)clouds[i].n * 16, hipMemcpyHostToDevice, ctx->stream));
+      h[i].xyzi = (const float4*)(ws + off);
+      off += ((size_t)clouds[i].n * 16 + 255) / 256 * 256;
+    }
+  }
+  CFEAR_HIP_CHECK(ctx, hipMemcpyAsync(ws, h.data(), h.size() * sizeof(ScCloud), hipMemcpyHostToDevice, ctx->stream));
+  ScDescArgs a;
+  a.clouds = (const ScCloud*)ws;
+  a.num_ring = R; a.num_sector = S; a.desc_function = par->desc_function; a.n_aug = n_aug;
+  a.max_radius = par->max_radius; a.desc_divider = par->desc_divider; a.no_point = par->no_point;
+  for (int k = 0; k < kScMaxAug; k++) a.shift_y[k] = (k < n_aug && shifts_y) ? shifts_y[k] : 0.0;
+  a.desc = (double*)wo;
+  a.ringkey = a.desc + nd * cells;
+  a.sectorkey = a.ringkey + nd * R;
+  {
+    ProfScope ps(ctx, "sc_descriptor");
+    hipLaunchKernelGGL(sc_descriptor_kernel, dim3(n_clouds, n_aug), dim3(256), (size_t)cells * 12, ctx->stream, a);
+  }
+  CFEAR_HIP_CHECK(ctx, hipGetLastError());
+  CFEAR_HIP_CHECK(ctx, hipMemcpyAsync(desc, a.desc, nd * cells * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  if (ringkey) CFEAR_HIP_CHECK(ctx, hipMemcpyAsync(ringkey, a.ringkey, nd * R * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  if (sectorkey) CFEAR_HIP_CHECK(ctx, hipMemcpyAsync(sectorkey, a.sectorkey, nd * S * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  CFEAR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  return CFEAR_OK;
+}
+
+extern "C" int cfear_sc_distance_batch(cfear_ctx* ctx, const double* desc_q, int32_t n_q, const double* desc_c,
+                                       int32_t n_c, const int32_t* pairs, int32_t n_pairs, const cfear_sc_params* par,
+                                       double* dist, int32_t* shift) {
+  if (!ctx) return CFEAR_ERR_INVALID_ARGUMENT;
+  if (!desc_q || !desc_c || !pairs || !dist || !shift || n_pairs < 0 || n_q < 0 || n_c < 0)
+    return cfear_set_error(ctx, CFEAR_ERR_INVALID_ARGUMENT, "null argument");
+  int rc = check_sc_params(ctx, par);
+  if (rc != CFEAR_OK) return rc;
+  if (n_pairs == 0) return CFEAR_OK;
+  for (int i = 0; i < n_pairs; i++)
+    if (pairs[2 * i] < 0 || pairs[2 * i] >= n_q || pairs[2 * i + 1] < 0 || pairs[2 * i + 1] >= n_c)
+      return cfear_set_error(ctx, CFEAR_ERR_INVALID_ARGUMENT, "pair %d out of range", i);
+  CFEAR_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  const int R = par->num_ring, S = par->num_sector, cells = R * S;
+  const size_t qb = (size_t)n_q * cells * 8, cb = (size_t)n_c * cells * 8, pb = (size_t)n_pairs * 8;
+  const bool qdev = cfear_is_device_ptr(desc_q), cdev = cfear_is_device_ptr(desc_c);
+  auto r256 = [](size_t b) { return (b + 255) / 256 * 256; };
+  char* ws = (char*)cfear_workspace(ctx, 8, (qdev ? 0 : r256(qb)) + (cdev ? 0 : r256(cb)) + r256(pb) + r256((size_t)n_pairs * 12) + 256);
+  if (!ws) return cfear_set_error(ctx, CFEAR_ERR_HIP, "workspace allocation failed");
+  size_t off = 0;
+  ScDistArgs a;
+  if (qdev) a.desc_q = desc_q; else { CFEAR_HIP_CHECK(ctx, hipMemcpyAsync(ws + off, desc_q, qb, hipMemcpyHostToDevice, ctx->stream)); a.desc_q = (const double*)(ws + off); off += r256(qb); }
+  if (cdev) a.desc_c = desc_c; else { CFEAR_HIP_CHECK(ctx, hipMemcpyAsync(ws + off, desc_c, cb, hipMemcpyHostToDevice, ctx->stream)); a.desc_c = (const double*)(ws + off); off += r256(cb); }
+  CFEAR_HIP_CHECK(ctx, hipMemcpyAsync(ws + off, pairs, pb, hipMemcpyHostToDevice, ctx->stream));
+  a.pairs = (const int32_t*)(ws + off); off += r256(pb);
+  a.dist = (double*)(ws + off);
+  a.shift = (int32_t*)(ws + off + (size_t)n_pairs * 8);
+  a.num_ring = R; a.num_sector = S; a.search_ratio = par->search_ratio;
+  const size_t lds = ((size_t)2 * cells + 5 * S) * 8 + (size_t)(2 + 2 * S + 2) * 4 + 16;
+  CFEAR_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)sc_distance_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  {
+    ProfScope ps(ctx, "sc_distance");
+    hipLaunchKernelGGL(sc_distance_kernel, dim3(n_pairs), dim3(256), lds, ctx->stream, a);
+  }
+  CFEAR_HIP_CHECK(ctx, hipGetLastError());
+  CFEAR_HIP_CHECK(ctx, hipMemcpyAsync(dist, a.dist, (size_t)n_pairs * 8, hipMemcpyDeviceToHost, ctx->stream));
+  CFEAR_HIP_CHECK(ctx, hipMemcpyAsync(shift, a.shift, (size_t)n_pairs * 4, hipMemcpyDeviceToHost, ctx->stream));
+  CFEAR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  return CFEAR_OK;
+}

@@ -30,6 +30,7 @@ def test_struct_sizes():
     assert C.sizeof(L.RegParams) == 72
     assert C.sizeof(L.CovSamplingParams) == 32
     assert C.sizeof(L.CoralParams) == 16
+    assert C.sizeof(L.ScParams) == 48 and C.sizeof(L.ScCloud) == 16
     assert C.sizeof(L.CoralJob) == 96
     assert C.sizeof(L.CoralResult) == 40 == L.CORAL_RESULT_DTYPE.itemsize
 
