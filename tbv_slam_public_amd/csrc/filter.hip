@@ -164,6 +164,48 @@ __global__ __launch_bounds__(256) void kstrongest_rows_kernel(const KStrongArgs 
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
+  // One candidate per lane, however the candidates cluster (a wall return fills adjacent bins of ONE lane).
+  // Owner lanes mark the first slot of their run; a max-scan spreads the owner id over the run; lane j then
+  // selects bit (j - first slot) of its owner's bitmap by popcount bisection.  n <= 64 candidates.
+  auto scatter_to_lanes = [&](const uint32_t (&bmx)[NCHUNK], int cnt_lane, int cnt_incl, int n) {
+    uint32_t* marker = hist;                       // [64]
+    uint32_t* sexcl = hist + 64;                   // [64] first slot of each lane's run
+    uint32_t* spw = hist + 128;                    // [NP][64] bitmaps
+    uint32_t pw[NP];
+#pragma unroll
+    for (int p = 0; p < NP; p++) pw[p] = (bmx[2 * p] >> 4) | (2 * p + 1 < NCHUNK ? bmx[2 * p + 1] : 0u);
+    const int excl = cnt_incl - cnt_lane;
+    marker[lane] = 0;
+    sexcl[lane] = excl;
+#pragma unroll
+    for (int p = 0; p < NP; p++) spw[p * 64 + lane] = pw[p];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (cnt_lane) marker[excl] = lane;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const int own = wave_incl_scan_max_i32((int)marker[lane]);
+    if (lane < n) {
+      int q = lane - (int)sexcl[own];
+      uint32_t word = spw[own];
+      int p = 0;
+#pragma unroll
+      for (int pp = 1; pp < NP; pp++) {
+        const int c = __popc(word);
+        const uint32_t nxt = spw[pp * 64 + own];
+        if (p == pp - 1 && q >= c) { q -= c; word = nxt; p = pp; }
+      }
+      int t = 0;
+      { const int c = __popc(word & 0xFFFFu); if (q >= c) { q -= c; t = 16; word >>= 16; } }
+      { const int c = __popc(word & 0xFFu);   if (q >= c) { q -= c; t += 8; word >>= 8; } }
+      { const int c = __popc(word & 0xFu);    if (q >= c) { q -= c; t += 4; word >>= 4; } }
+      { const int c = __popc(word & 0x3u);    if (q >= c) { q -= c; t += 2; word >>= 2; } }
+      if (q >= (int)(word & 1u)) t += 1;
+      const int pos = p * 2048 + own * 16 + ((t & 4) << 8) + ((t & 3) << 2) + (t >> 3);
+      list[lane] = ((uint32_t)rowbuf[pos] << 24) | (uint32_t)pos;
+    }
+  };
+
   if (n_ge <= k || n_ge <= 64) {
     // ---- at most k candidates, or at most 64: all of them become keys (any order); the ranking below
     //      restores the reference's ascending (intensity, range) order and, when there are more than k,
@@ -172,45 +214,7 @@ __global__ __launch_bounds__(256) void kstrongest_rows_kernel(const KStrongArgs 
     n_sel = min(n_ge, k);
     n_all = n_ge;
     if (n_ge <= 64) {
-      // One candidate per lane, however the candidates cluster (a wall return fills adjacent bins of
-      // ONE lane).  Owner lanes mark the first slot of their run; a max-scan spreads the owner id over
-      // the run; lane j then selects bit (j - first slot) of its owner's bitmap by popcount bisection.
-      uint32_t* marker = hist;                     // [64]
-      uint32_t* sexcl = hist + 64;                 // [64] first slot of each lane's run
-      uint32_t* spw = hist + 128;                  // [NP][64] bitmaps
-      uint32_t pw[NP];
-#pragma unroll
-      for (int p = 0; p < NP; p++) pw[p] = (bm[2 * p] >> 4) | (2 * p + 1 < NCHUNK ? bm[2 * p + 1] : 0u);
-      const int excl = c_incl - c_lane;
-      marker[lane] = 0;
-      sexcl[lane] = excl;
-#pragma unroll
-      for (int p = 0; p < NP; p++) spw[p * 64 + lane] = pw[p];
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      if (c_lane) marker[excl] = lane;
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      const int own = wave_incl_scan_max_i32((int)marker[lane]);
-      if (lane < n_ge) {
-        int q = lane - (int)sexcl[own];
-        uint32_t word = spw[own];
-        int p = 0;
-#pragma unroll
-        for (int pp = 1; pp < NP; pp++) {
-          const int c = __popc(word);
-          const uint32_t nxt = spw[pp * 64 + own];
-          if (p == pp - 1 && q >= c) { q -= c; word = nxt; p = pp; }
-        }
-        int t = 0;
-        { const int c = __popc(word & 0xFFFFu); if (q >= c) { q -= c; t = 16; word >>= 16; } }
-        { const int c = __popc(word & 0xFFu);   if (q >= c) { q -= c; t += 8; word >>= 8; } }
-        { const int c = __popc(word & 0xFu);    if (q >= c) { q -= c; t += 4; word >>= 4; } }
-        { const int c = __popc(word & 0x3u);    if (q >= c) { q -= c; t += 2; word >>= 2; } }
-        if (q >= (int)(word & 1u)) t += 1;
-        const int pos = p * 2048 + own * 16 + ((t & 4) << 8) + ((t & 3) << 2) + (t >> 3);
-        list[lane] = ((uint32_t)rowbuf[pos] << 24) | (uint32_t)pos;
-      }
+      scatter_to_lanes(bm, c_lane, c_incl, n_ge);
     } else {
       int slot = c_incl - c_lane;
       for_each_candidate<NCHUNK>(bm, lane, [&](int pos) { list[slot++] = ((uint32_t)rowbuf[pos] << 24) | (uint32_t)pos; });
@@ -245,6 +249,20 @@ __global__ __launch_bounds__(256) void kstrongest_rows_kernel(const KStrongArgs 
     T = __builtin_amdgcn_readlane(T, lc);
     n_gt = __builtin_amdgcn_readlane(n_gt, lc);
     n_eq = __builtin_amdgcn_readlane(n_eq, lc);
+    if (n_gt + n_eq <= 64) {
+      // the bins >= T (all survivors plus the ties at the cut) fit one per lane: key them and let the rank cut
+      // below drop the lowest (intensity, range) keys -- the same tie rule, without the chunked tie scan
+      uint32_t bt[NCHUNK];
+      const uint32_t tt4 = (uint32_t)(T & 0x7f) * 0x01010101u;
+      if (T & 0x80) candidate_bitmaps<NCHUNK, MASK, true>(w, tt4, a.cols, lane, bt);
+      else candidate_bitmaps<NCHUNK, MASK, false>(w, tt4, a.cols, lane, bt);
+      int t_lane = 0;
+#pragma unroll
+      for (int c = 0; c < NCHUNK; c++) t_lane += __popc(bt[c]);
+      const int t_incl = wave_incl_scan_i32(t_lane);
+      n_all = n_gt + n_eq;
+      scatter_to_lanes(bt, t_lane, t_incl, n_all);
+    } else {
     const int skip_eq = n_eq - (k - n_gt);         // drop the lowest-range ties: lexicographic (intensity, range)
     // ---- ordered compaction: all (> T) plus the (== T) bins of rank >= skip_eq in position order -----
     // (T >= z_min, so ">= T" implies candidacy; only the MASK variant needs the validity bits)
@@ -294,6 +312,7 @@ __global__ __launch_bounds__(256) void kstrongest_rows_kernel(const KStrongArgs 
       }
       g_base += tot & 0xFFFF;
       e_base += tot >> 16;
+    }
     }
   }
   const int nq = (n_all + 3) & ~3;
