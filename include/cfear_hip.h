@@ -7,6 +7,9 @@
  * the reference function(s) it replaces (paths relative to
  * cfear_radarodometry/{include,src}/cfear_radarodometry/).  INTEGRATION.md shows the shim a
  * maintainer adds inside radarDriver / MapPointNormal / n_scan_normal_reg to call them.
+ * Three neighbours of the path follow the same rules further down: covariance by cost sampling
+ * (odometrykeyframefuser.cpp:261-380), CorAl alignment quality (coral_alignment_quality) and the radar
+ * Scan Context arithmetic (place_recognition_radar) -- SURVEY.md 8(f).
  *
  * Conventions
  *   - plain C: pointers + sizes, caller-owned buffers, opaque handles, no C++/torch types;
