@@ -403,7 +403,7 @@ __global__ __launch_bounds__(kSurfThreads) void surface_points_kernel(const Surf
         const double wx = w * xr, wy = w * yr;
         cnt++;
         s0 += w; s1x += wx; s1y += wy;
-        sxx += wx * xr; sxy += wx * yr; syy += wy * yr;
+        sxx = fma(wx, xr, sxx); sxy = fma(wx, yr, sxy); syy = fma(wy, yr, syy);   // own one-pass form: fusing is free
       }
     };
     auto scan_run = [&](int p0, int p1) {
