@@ -337,8 +337,12 @@ __global__ __launch_bounds__(kSurfThreads) void surface_points_kernel(const Surf
         if (e == 0 || vx != pv) { vox_key[ord] = vx; vox_start[ord] = e; ord++; }
         pv = vx;
         const float4 p = gp[q];
-        spt[e] = make_float4(p.x, p.y, p.w, 0.f);
-        if (lds_pts) { lxy[e] = make_float2(p.x, p.y); lin[e] = p.w; }
+        // the sorted copies carry the point's WEIGHT max(I - 60, 0) (pointnormal.cpp:15), not its intensity:
+        // float(I) - 60 is exact for I >= 60 (the difference of two floats is representable whenever it is not
+        // larger in magnitude than both), so the fp64 weight of the reference is just its widening
+        const float wgt = fmaxf(__fsub_rn(p.w, 60.0f), 0.0f);
+        spt[e] = make_float4(p.x, p.y, wgt, 0.f);
+        if (lds_pts) { lxy[e] = make_float2(p.x, p.y); lin[e] = wgt; }
       }
     }
   }
@@ -398,7 +402,7 @@ __global__ __launch_bounds__(kSurfThreads) void surface_points_kernel(const Surf
       const float dx = __fsub_rn(c.x, q.x), dy = __fsub_rn(c.y, q.y);
       const float d2 = __fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy));         // FLANN L2_Simple
       if (d2 < cm.r2) {                                                          // RadiusResultSet: strict <
-        const double w = cm.weight_intensity ? fmax((double)q.z - 60.0, 0.0) : 1.0;     // pointnormal.cpp:15
+        const double w = cm.weight_intensity ? (double)q.z : 1.0;                 // q.z = max(I - 60, 0), pointnormal.cpp:15
         const double xr = (double)q.x - cx, yr = (double)q.y - cy;
         const double wx = w * xr, wy = w * yr;
         cnt++;
