@@ -92,7 +92,8 @@ __device__ __forceinline__ double get_rel_time_stamp(double x, double y, bool cc
 // utils.cpp:96-107
 __device__ __forceinline__ float4 compensate_point(float4 p, const double mot[3], bool ccw) {
   const double d = get_rel_time_stamp((double)p.x, (double)p.y, ccw);
-  const double s_1 = sin(d * mot[2]), c_1 = cos(d * mot[2]);
+  double s_1, c_1;
+  sincos(d * mot[2], &s_1, &c_1);                        // one range reduction for both
   const double tx = d * mot[0], ty = d * mot[1];
   const double x = (double)p.x, y = (double)p.y;
   p.x = (float)((c_1 * x + (-s_1) * y) + tx);
