@@ -75,6 +75,8 @@ struct cfear_odometry {
   int cur_buf = 0;
   const uint8_t* prefetched = nullptr;       // polar pointer whose filter output sits in buffer cur_buf ^ 1
   hipEvent_t ev_results = nullptr;
+  hipStream_t copy_stream = nullptr;         // uploads the registration jobs while the surface kernel runs
+  hipEvent_t ev_jobs = nullptr;
   char* d_slabs = nullptr;
   char* d_surf_jobs = nullptr;
   char* d_reg_jobs = nullptr;
@@ -120,6 +122,8 @@ extern "C" int cfear_odometry_destroy(cfear_odometry* od) {
   (void)hipSetDevice(od->ctx->device);
   (void)hipStreamSynchronize(od->ctx->stream);
   if (od->ev_results) (void)hipEventDestroy(od->ev_results);
+  if (od->ev_jobs) (void)hipEventDestroy(od->ev_jobs);
+  if (od->copy_stream) (void)hipStreamDestroy(od->copy_stream);
   void* dev[] = {od->d_polar, od->d_sel, od->d_xyzi2[0], od->d_xyzi2[1], od->d_npts2[0], od->d_npts2[1], od->d_slabs, od->d_surf_jobs, od->d_reg_jobs,
                  od->d_results, od->d_status, od->d_ncells, od->d_surf_scratch, od->d_reg_scratch, od->d_samples};
   for (void* p : dev) if (p) (void)hipFree(p);
@@ -157,6 +161,8 @@ extern "C" int cfear_odometry_create(cfear_ctx* ctx, int32_t n_streams, const cf
     ok = ok && dalloc(&od->d_npts2[i], (size_t)B * 4);
   }
   ok = ok && hipEventCreateWithFlags(&od->ev_results, hipEventDisableTiming) == hipSuccess;
+  ok = ok && hipEventCreateWithFlags(&od->ev_jobs, hipEventDisableTiming) == hipSuccess;
+  ok = ok && hipStreamCreateWithFlags(&od->copy_stream, hipStreamNonBlocking) == hipSuccess;
   ok = ok && dalloc(&od->d_slabs, (size_t)B * od->slabs_per_stream * od->slab_bytes);
   ok = ok && dalloc(&od->d_surf_jobs, (size_t)B * cfear_surface_job_bytes());
   ok = ok && dalloc(&od->d_reg_jobs, (size_t)B * cfear_reg_job_bytes());
@@ -268,16 +274,8 @@ extern "C" int cfear_odometry_process_prefetch(cfear_odometry* od, const uint8_t
     cfear_surface_fill_job(od->h_surf_jobs + (size_t)b * sjb, od->d_xyzi + (size_t)b * od->cap_points * 4,
                            od->d_npts + b, 0, par.compensate, mot, od->views[(size_t)b * od->slabs_per_stream + st.cur_slab]);
   }
-  CFEAR_HIP_CHECK(ctx, hipMemcpyAsync(od->d_surf_jobs, od->h_surf_jobs, (size_t)B * sjb, hipMemcpyHostToDevice, ctx->stream));
-  cfear_feature_params fp{};
-  fp.radius = par.res;
-  fp.downsample_factor = par.downsample_factor;
-  fp.origin[0] = fp.origin[1] = 0.0;                              // Eigen::Vector2d(0,0), :161
-  fp.weight_intensity = par.weight_intensity;
-  fp.ccw = par.radar_ccw;
-  rc = cfear_surface_launch(ctx, od->d_surf_jobs, B, &fp, od->d_surf_scratch, od->d_status, od->d_ncells);
-  if (rc != CFEAR_OK) return rc;
-  // ---- M: Register against the keyframe window (:164-186) --------------------------------------
+  // ---- M: the registration jobs depend on host state only: they are built and uploaded (copy stream) now,
+  //      so the 2.3 KB per stream travel while the surface kernel runs (:164-186) ---------------------------
   const size_t rjb = cfear_reg_job_bytes();
   int n_jobs = 0;
   std::vector<ScanView> views(cfear_reg_max_scans());
@@ -298,7 +296,20 @@ extern "C" int cfear_odometry_process_prefetch(cfear_odometry* od, const uint8_t
     st.job = n_jobs++;
   }
   if (n_jobs > 0) {
-    CFEAR_HIP_CHECK(ctx, hipMemcpyAsync(od->d_reg_jobs, od->h_reg_jobs, (size_t)n_jobs * rjb, hipMemcpyHostToDevice, ctx->stream));
+    CFEAR_HIP_CHECK(ctx, hipMemcpyAsync(od->d_reg_jobs, od->h_reg_jobs, (size_t)n_jobs * rjb, hipMemcpyHostToDevice, od->copy_stream));
+    CFEAR_HIP_CHECK(ctx, hipEventRecord(od->ev_jobs, od->copy_stream));
+  }
+  CFEAR_HIP_CHECK(ctx, hipMemcpyAsync(od->d_surf_jobs, od->h_surf_jobs, (size_t)B * sjb, hipMemcpyHostToDevice, ctx->stream));
+  cfear_feature_params fp{};
+  fp.radius = par.res;
+  fp.downsample_factor = par.downsample_factor;
+  fp.origin[0] = fp.origin[1] = 0.0;                              // Eigen::Vector2d(0,0), :161
+  fp.weight_intensity = par.weight_intensity;
+  fp.ccw = par.radar_ccw;
+  rc = cfear_surface_launch(ctx, od->d_surf_jobs, B, &fp, od->d_surf_scratch, od->d_status, od->d_ncells);
+  if (rc != CFEAR_OK) return rc;
+  if (n_jobs > 0) {
+    CFEAR_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream, od->ev_jobs, 0));
     rc = cfear_register_launch(ctx, od->d_reg_jobs, n_jobs, &par.reg, par.submap_scan_size * od->cell_cap, od->cell_cap,
                                od->d_reg_scratch, od->d_results);
     if (rc != CFEAR_OK) return rc;
