@@ -488,17 +488,32 @@ __global__ __launch_bounds__(256) void kstrong_cloud_kernel(const CloudArgs a) {
   const double range_res_half = a.range_res / 2.0;
   const int rows_per = (a.rows + kCloudSplit - 1) / kCloudSplit;
   const int rbeg = blockIdx.z * rows_per, rend = min(a.rows, rbeg + rows_per);
+  // Every load of a row's first 64 slots is issued before any of them is used (the slots past the row's count
+  // exist and are simply ignored), so a row costs one memory round trip instead of three dependent ones.
   for (int r = rbeg + wave; r < rend; r += 4) {
+    const long long rb = ibase + (long long)r * a.k;
     const int cnt = a.sel_count[(long long)b * a.rows + r];
     const double cos_t = a.cos_t[r], sin_t = a.sin_t[r];
+    int range0 = 0;
+    uint8_t inten0 = 0, pk0 = 1;
+    if (lane < a.k) {
+      range0 = a.sel_range[rb + lane];
+      inten0 = a.sel_intensity[rb + lane];
+      if (peaks) pk0 = a.is_peak[rb + lane];
+    }
     int base = row_off[r];
     for (int j0 = 0; j0 < cnt; j0 += 64) {
       const int j = j0 + lane;
       bool ok = false;
       int range = 0;
+      uint8_t inten = 0;
       if (j < cnt) {
-        range = a.sel_range[ibase + (long long)r * a.k + j];
-        ok = range > a.min_range_bin && (!peaks || a.is_peak[ibase + (long long)r * a.k + j]);
+        if (j0 == 0) { range = range0; inten = inten0; ok = range > a.min_range_bin && pk0; }
+        else {
+          range = a.sel_range[rb + j];
+          inten = a.sel_intensity[rb + j];
+          ok = range > a.min_range_bin && (!peaks || a.is_peak[rb + j]);
+        }
       }
       const unsigned long long bal = __ballot(ok);
       if (ok) {
@@ -508,7 +523,7 @@ __global__ __launch_bounds__(256) void kstrong_cloud_kernel(const CloudArgs a) {
         p.x = (float)(rho * cos_t);
         p.y = (float)(rho * sin_t);
         p.z = 0.f;
-        p.w = (float)a.sel_intensity[ibase + (long long)r * a.k + j];
+        p.w = (float)inten;
         ((float4*)out)[(long long)b * a.rows * a.k + idx] = p;
       }
       base += __popcll(bal);
