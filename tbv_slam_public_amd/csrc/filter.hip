@@ -457,8 +457,7 @@ constexpr int kCloudSplit = 8;   // workgroups per image: each scans all row cou
 __global__ __launch_bounds__(256) void kstrong_cloud_kernel(const CloudArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   int32_t* row_off = (int32_t*)smem;                 // [rows + 1]
-  __shared__ int32_t wave_tot[4];
-  __shared__ int32_t run_base;
+  __shared__ int32_t wave_tot[8];
   const int b = blockIdx.x;
   const bool peaks = blockIdx.y == 1;
   float* out = peaks ? a.xyzi_peaks : a.xyzi;
@@ -466,28 +465,38 @@ __global__ __launch_bounds__(256) void kstrong_cloud_kernel(const CloudArgs a) {
   if (!out && !nout) return;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const long long ibase = (long long)b * a.rows * a.k;
-  if (threadIdx.x == 0) run_base = 0;
-  __syncthreads();
-  // exclusive scan of the per-row survivor counts (chunks of 256 rows)
-  for (int r0 = 0; r0 < a.rows; r0 += 256) {
-    const int r = r0 + threadIdx.x;
-    const int v = r < a.rows ? a.row_valid[((long long)b * a.rows + r) * 2 + (peaks ? 1 : 0)] : 0;
-    const int incl = wave_incl_scan_i32(v);
-    if (lane == 63) wave_tot[wave] = incl;
-    __syncthreads();
-    int off = run_base;
-    for (int wv = 0; wv < wave; wv++) off += wave_tot[wv];
-    if (r < a.rows) row_off[r] = off + incl - v;
-    __syncthreads();
-    if (threadIdx.x == 0) run_base += wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
-    __syncthreads();
-  }
-  if (threadIdx.x == 0 && nout && blockIdx.z == 0) nout[b] = run_base;
-  if (!out) return;
-  // one wavefront per row of this workgroup's slice writes its points in (intensity,range) order
-  const double range_res_half = a.range_res / 2.0;
+  // This workgroup writes the rows [rbeg, rend) of the image: it needs the number of points in the rows before
+  // its slice (one block reduction over all row counts) and a prefix inside the slice (one wavefront).
   const int rows_per = (a.rows + kCloudSplit - 1) / kCloudSplit;
   const int rbeg = blockIdx.z * rows_per, rend = min(a.rows, rbeg + rows_per);
+  const int which = peaks ? 1 : 0;
+  int before = 0, total = 0;
+  for (int r = threadIdx.x; r < a.rows; r += 256) {
+    const int v = a.row_valid[((long long)b * a.rows + r) * 2 + which];
+    total += v;
+    before += r < rbeg ? v : 0;
+  }
+  before = wave_sum_i32(before);
+  total = wave_sum_i32(total);
+  if (lane == 0) { wave_tot[wave] = before; wave_tot[4 + wave] = total; }
+  __syncthreads();
+  before = wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
+  total = wave_tot[4] + wave_tot[5] + wave_tot[6] + wave_tot[7];
+  if (threadIdx.x == 0 && nout && blockIdx.z == 0) nout[b] = total;
+  if (!out) return;
+  if (wave == 0) {
+    int run = before;
+    for (int r0 = rbeg; r0 < rend; r0 += 64) {
+      const int r = r0 + lane;
+      const int v = r < rend ? a.row_valid[((long long)b * a.rows + r) * 2 + which] : 0;
+      const int incl = wave_incl_scan_i32(v);
+      if (r < rend) row_off[r] = run + incl - v;
+      run += __builtin_amdgcn_readlane(incl, 63);
+    }
+  }
+  __syncthreads();
+  // one wavefront per row of this workgroup's slice writes its points in (intensity,range) order
+  const double range_res_half = a.range_res / 2.0;
   // Every load of a row's first 64 slots is issued before any of them is used (the slots past the row's count
   // exist and are simply ignored), so a row costs one memory round trip instead of three dependent ones.
   for (int r = rbeg + wave; r < rend; r += 4) {
