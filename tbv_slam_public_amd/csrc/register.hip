@@ -742,13 +742,14 @@ __device__ int associate_fused(const RegJob& job, const RegCommon& cm, const dou
       const int G = f.G;
       const int cx0 = min(G - 1, max(0, (int)floorf((xlo - gg.x) * gg.z))), cx1 = min(G - 1, max(0, (int)floorf((xhi - gg.x) * gg.z)));
       const int cy0 = min(G - 1, max(0, (int)floorf((qy - rwin - gg.y) * gg.z))), cy1 = min(G - 1, max(0, (int)floorf((qy + rwin - gg.y) * gg.z)));
-      int best = -1;
-      float bestd = FLT_MAX;
+      // (distance, index) packed into one 64-bit key: squared distances are non-negative floats, whose bit
+      // patterns order like the values, so "nearest, lowest index on ties" is a single unsigned minimum
+      unsigned long long bestkey = ~0ull;
       auto visit = [&](const float4 c) {            // candidates outside the radius cannot win: their d exceeds r^2
         const float dx = __fsub_rn(qx, c.x), dy = __fsub_rn(qy, c.y);
         const float d = __fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy));
-        const int idx = __float_as_int(c.z);
-        if (d < bestd || (d == bestd && idx < best)) { best = idx; bestd = d; }
+        const unsigned long long key = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)__float_as_int(c.z);
+        bestkey = key < bestkey ? key : bestkey;
       };
       const unsigned short* cs = f.cstart + i * G * G;
       // cells of a grid row are contiguous in txyi.  The bounds of the (at most three, unless the radius
@@ -771,6 +772,8 @@ __device__ int associate_fused(const RegJob& job, const RegCommon& cm, const dou
         if (cy1 > cy0 + 1) scan_run(b2, e2);
         for (int cy = cy0 + 3; cy <= cy1; cy++) scan_run((int)cs[cy * G + cx0], (int)cs[cy * G + cx1 + 1]);
       }
+      const int best = bestkey == ~0ull ? -1 : (int)(unsigned)(bestkey & 0xFFFFFFFFu);
+      const float bestd = __uint_as_float((unsigned)(bestkey >> 32));
       int m = -1;
       if (best >= 0 && (double)bestd < r2) {                                    // pointnormal.cpp:250
         const double2 ns = job.scans[last].normal[s];
