@@ -9,7 +9,7 @@ constexpr int kGridSortRadixMaxPoints = 8192;    // radix path: 2 x 32 KiB key b
 
 #if defined(__HIPCC__)
 // Sorts the n points of a 1024-thread workgroup by (cell, index): cells ascending, points of a cell in input
-// order (stable).  cell_of(i) -> uint32 cell id < n_cells.  On return smem holds npad (>= n, power of two >=
+// order (stable).  cell_of(i) -> uint32 cell id < n_cells.  On return smem holds npad (>= n, a multiple of
 // 1024) 64-bit keys (cell << 32 | index), padding = ~0; thread t owns elements [t * npad/1024, ...).
 // red_i: 16 ints of LDS outside the key region.  Returns npad.  Block-wide collective (ends with a barrier).
 //   n <= 8192 and cell bits + index bits <= 32: packed 32-bit keys, stable LSD radix sort on the cell digits
@@ -19,13 +19,17 @@ template <typename CellFn>
 __device__ int grid_sort_block(uint8_t* smem, int n, long long n_cells, int* red_i, CellFn cell_of) {
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   unsigned long long* keys = (unsigned long long*)smem;
-  int npad = 1024;
-  while (npad < n) npad <<= 1;
-  int ib = 10;                                             // index bits: 2^ib == npad
+  int npad = (n + kGridSortThreads - 1) / kGridSortThreads * kGridSortThreads;   // radix path: any multiple of 1024
+  if (npad < kGridSortThreads) npad = kGridSortThreads;
+  int ib = 10;                                             // index bits: 2^ib >= npad
   while ((1 << ib) < npad) ib++;
   int vb = 1;                                              // cell-index bits
   while (((long long)1 << vb) < n_cells) vb++;
   const bool radix = (npad <= kGridSortRadixMaxPoints) && (vb + ib <= 32);
+  if (!radix) {                                            // the bitonic network needs a power of two
+    npad = 1024;
+    while (npad < n) npad <<= 1;
+  }
   if (radix) {
     uint32_t* kA = (uint32_t*)smem;
     uint32_t* kB = kA + npad;
