@@ -154,7 +154,8 @@ __device__ void sort_cells_block(const ScanView& v, int n, unsigned long long* k
     for (int i = tid; i < n; i += nth) {
       const unsigned long long key = keys[i];
       int rank = 0;
-      for (int j = 0; j < npad; j += 2) {                // padded keys are ~0: never smaller
+      const int nl = (n + 1) & ~1;                        // keys past n are ~0 (never smaller): stop at n
+      for (int j = 0; j < nl; j += 2) {
         const ulonglong2 kk = *(const ulonglong2*)(keys + j);
         rank += (kk.x < key) + (kk.y < key);
       }
