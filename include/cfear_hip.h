@@ -368,6 +368,64 @@ int cfear_sc_distance_batch(cfear_ctx* ctx, const double* desc_q, int32_t n_q, c
                             const int32_t* pairs, int32_t n_pairs, const cfear_sc_params* par, double* dist,
                             int32_t* shift);
 
+/* ---- caller: loop-candidate verification --------------------------------------------------------------
+ * What the loop-closure thread does per candidate (tbv_slam/src/tbv_slam/loopclosure.cpp:658-725), for a batch:
+ * RegisterLoopCandidate (:320-364, loopclosure::Register :35-97), VerifyLoopCandidate (:365-384) =
+ * ScanLearningInterface::PredAlignment (coral_alignment_quality/src/alignment_checker/alignmentinterface.cpp:349-367:
+ * CorAl + CFEAR quality -> combined logistic score "alignment_quality") + VerificationModel (:220-238), then
+ * ApplyConstratins (:261-274).  One registration launch, one CorAl launch, one GetCost launch for all candidates. */
+typedef struct cfear_verify_params {
+  double align_intercept;               /* combined_class: file format "intercept,coef..." (alignmentinterface.cpp:224-269) */
+  double align_coef[6];                 /* over {CorAl joint, sep, overlap, CFEAR cost, #residuals, mean #cells} (:357-360)  */
+  double loop_intercept;                /* verification model over par_.model_features = {odom-bounds, sc-sim,               */
+  double loop_coef[3];                  /*   alignment_quality} (loopclosure.h:138); preset loopclosure.cpp:224-232          */
+  double model_threshold;               /* par_.model_threshold (0.8)                                                        */
+  int32_t all_candidates;               /* par_.all_candidates (true): every candidate above threshold, else only the best   */
+  int32_t verification_disabled;        /* probability 0 for everything (loopclosure.cpp:377)                                */
+  int32_t use_covariance_sampling;      /* par_.use_covariance_sampling_in_loop_closure (false)                              */
+  int32_t pad;
+  cfear_coral_params coral;             /* radius 1.0, weight_res_intensity false (alignmentinterface.cpp:444)               */
+  cfear_cov_sampling_params sampling;   /* loopclosure.cpp:108-112: +-0.2 m, +-0.0022 rad, 3 per axis, scaler 4              */
+} cfear_verify_params;                  /* 160 bytes */
+void cfear_verify_params_default(cfear_verify_params* p);
+
+typedef struct cfear_verify_job {
+  const cfear_scan* from_scan;          /* (*graph_)[from].cloud_normal_  (the query node: source of the registration)       */
+  const cfear_scan* to_scan;            /* (*graph_)[to].cloud_normal_    (the candidate: fixed target)                      */
+  const float* from_peaks;              /* (*graph_)[from].cloud_peaks_ [n_from][4], sensor frame; host or device            */
+  const float* to_peaks;                /* (*graph_)[to].cloud_peaks_                                                        */
+  int32_t n_from, n_to;
+  double from_pose[3];                  /* (*graph_)[from].GetPose() as (x, y, theta)                                        */
+  double t_be_guess[3];                 /* constraint.t_be on entry (Scan Context yaw / lateral guess): Tto = Tfrom * t_be   */
+  double sc_sim;                        /* quality["sc-sim"]                                                                 */
+  double odom_bounds;                   /* quality["odom-bounds"], e.g. from cfear_verify_by_odometry                        */
+  int32_t group;                        /* candidates of one query node share a group (ApplyConstratins runs per query)      */
+  int32_t pad;
+} cfear_verify_job;                     /* 112 bytes */
+
+typedef struct cfear_verify_result {
+  double t_be[3];                       /* constraint.t_be after registration = Trevised^-1 * Tto; Identity if it failed     */
+  double cov[36];                       /* Cov (the reference stores information = Cov.inverse()); Identity if it failed     */
+  double coral[3];                      /* X_CorAl = {joint, sep, overlap}                                                   */
+  double cfear[3];                      /* X_CFEAR = {cost, #residuals, mean #cells}                                         */
+  double alignment_quality;             /* quality["alignment_quality"]                                                      */
+  double odom_bounds, sc_sim;           /* echoed features                                                                   */
+  double probability;                   /* VerifyLoopCandidate                                                               */
+  int32_t reg_ok;                       /* RegisterLoopCandidate's return                                                    */
+  int32_t cov_sampled;                  /* the sampled covariance replaced Register's constant one                           */
+  int32_t accepted;                     /* ApplyConstratins added the loop constraint                                        */
+  int32_t rank;                         /* position in the query's probability-sorted candidate list                         */
+  cfear_reg_result reg;                 /* the registration's own record                                                     */
+} cfear_verify_result;                  /* 480 bytes */
+
+int cfear_verify_loop_candidates(cfear_ctx* ctx, const cfear_verify_job* jobs, int32_t n_jobs,
+                                 const cfear_verify_params* par, cfear_verify_result* results);
+/* loopclosure::VerifyByOdometry (loopclosure.cpp:776-808).  rel_xyt [n][3]: the odometry constraints'
+ * RelativeMotion(i, i+1), i = to .. from-1.  similarity = 1 - exp(-(max(|T_odom| - 5, 0) / travelled)^2 / 2 sigma^2);
+ * 1 when verify_via_odometry is 0.  No context: pure host arithmetic.                                               */
+int cfear_verify_by_odometry(const double* rel_xyt, int32_t n, double odom_sigma_error, int32_t verify_via_odometry,
+                             double* similarity);
+
 /* ---- caller: batched radarDriver + OdometryKeyframeFuser --------------------------------------
  * n_streams independent sequences advance one frame per call: filter (F) -> compensate (C) ->
  * surface points (N) -> Register against the keyframe window (M) -> keyframe policy.  Restates

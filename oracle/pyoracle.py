@@ -280,6 +280,87 @@ def coral_quality(ref_xyzi, src_xyzi, ref_pose, src_pose, offset=(0.0, 0.0, 0.0)
     return bool(ok), q, pp
 
 
+def xyt_compose(a, b):
+    c, s = np.cos(a[2]), np.sin(a[2])
+    return np.array([c * b[0] - s * b[1] + a[0], s * b[0] + c * b[1] + a[1], a[2] + b[2]], np.float64)
+
+
+def xyt_inverse(a):
+    c, s = np.cos(a[2]), np.sin(a[2])
+    return np.array([-(c * a[0] + s * a[1]), s * a[0] - c * a[1], -a[2]], np.float64)
+
+
+ALIGN_MODEL = (-8.42595, (-15.2287, 7.47573, -0.0680198, -1.74182, 0.0945444, 0.022217))   # trained_alignment_classifier.txt
+LOOP_MODEL = (2.67958289, (-2.89398535, -9.40230684, 0.23891265))                         # loopclosure.cpp:224-232
+
+
+def verify_by_odometry(rel_xyt, odom_sigma_error=0.03, verify_via_odometry=True):
+    """loopclosure::VerifyByOdometry (tbv_slam/src/tbv_slam/loopclosure.cpp:776-808)."""
+    if not verify_via_odometry:
+        return 1.0
+    T, trav = np.zeros(3), 0.0
+    for d in np.asarray(rel_xyt, np.float64).reshape(-1, 3):
+        trav += float(np.hypot(d[0], d[1]))
+        T = xyt_compose(T, d)
+    error = max(float(np.hypot(T[0], T[1])) - 5.0, 0.0)
+    with np.errstate(invalid="ignore", divide="ignore"):
+        rel = np.float64(error) / np.float64(trav)
+        return float(1.0 - np.exp(-rel * rel / (2.0 * odom_sigma_error * odom_sigma_error)))
+
+
+def verify_loop_candidate(from_cells, from_peaks, from_pose, to_cells, to_peaks, t_be_guess, sc_sim, odom_bounds,
+                          align_model=ALIGN_MODEL, loop_model=LOOP_MODEL, use_covariance_sampling=False,
+                          verification_disabled=False):
+    """One candidate through RegisterLoopCandidate + VerifyLoopCandidate (loopclosure.cpp:320-384; Register :35-97;
+    PredAlignment alignmentinterface.cpp:349-367; VerificationModel loopclosure.cpp:220-238).  -> dict."""
+    from_pose = np.asarray(from_pose, np.float64)
+    Tto = xyt_compose(from_pose, np.asarray(t_be_guess, np.float64))
+    par = reg_params("P2L", "Huber", 0.1, 0, 4, 10)                      # :56-57
+    ok, p, res = register([to_cells, from_cells], np.stack([Tto, from_pose]), par)
+    out = {"reg_ok": ok, "cov_sampled": False}
+    if ok:
+        Trev = p[1]
+        inv = xyt_inverse(Trev)
+        out["t_be"] = xyt_compose(inv, Tto)                              # :91
+        cov = np.diag([0.01, 0.01, 0.0, 0.0, 0.0, 1e-4])                 # n_scan_normal.cpp:171
+        if use_covariance_sampling:                                      # :62-71, ranges :108-112
+            par.first_itr = res.outer_iters
+            cok, csamp, _ = cov_by_sampling([to_cells, from_cells], np.stack([Tto, Trev]), par, res.final_cost,
+                                            res.num_residuals, 0.4, 0.0044, 3, 4.0)
+            if cok:
+                cov, out["cov_sampled"] = csamp, True
+        c, s = np.cos(inv[2]), np.sin(inv[2])
+        R = np.array([[c, -s, 0.0], [s, c, 0.0], [0.0, 0.0, 1.0]])
+        cov = cov.copy()
+        cov[:3, :3] = R @ cov[:3, :3] @ R.T                              # :93
+        out["cov"] = cov
+    else:
+        out["t_be"] = np.zeros(3)                                        # :351-352 initial values survive
+        out["cov"] = np.eye(6)
+    Tto2 = xyt_compose(from_pose, out["t_be"])                           # :367-368
+    _, q, _ = coral_quality(from_peaks, to_peaks, from_pose, Tto2)       # ref = current = from
+    out["coral"] = q
+    qpar = reg_params("P2L", "Huber", 0.3)
+    gok, cost, r, _ = get_cost([from_cells, to_cells], np.stack([from_pose, Tto2]), qpar)
+    out["cfear"] = np.array([cost, float(r.shape[0]), (len(from_cells) + len(to_cells)) / 2.0]) if gok else np.zeros(3)
+    out["alignment_quality"] = float(align_model[0] + np.dot(align_model[1], np.concatenate([out["coral"], out["cfear"]])))
+    z = loop_model[0] + np.dot(loop_model[1], [odom_bounds, sc_sim, out["alignment_quality"]])
+    out["probability"] = 0.0 if verification_disabled else float(1.0 / (1.0 + np.exp(-z)))
+    return out
+
+
+def apply_constraints(prob, group, model_threshold=0.8, all_candidates=True):
+    """loopclosure::ApplyConstratins (loopclosure.cpp:261-274) per query group -> accepted flags."""
+    prob, group = np.asarray(prob, np.float64), np.asarray(group)
+    acc = np.zeros(prob.shape[0], bool)
+    for g in np.unique(group):
+        idx = np.nonzero(group == g)[0]
+        order = idx[np.argsort(-prob[idx], kind="stable")]
+        use = order if all_candidates else order[:1]
+        acc[use] = prob[use] > model_threshold
+    return acc
+
+
 def associate(scans, poses, par, itr):
     keep, ptrs, n = _scan_args(scans)
     p = np.ascontiguousarray(poses, dtype=np.float64).copy()

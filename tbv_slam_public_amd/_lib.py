@@ -125,6 +125,34 @@ class ScCloud(C.Structure):
     _fields_ = [("xyzi", C.c_void_p), ("n", C.c_int32), ("pad", C.c_int32)]
 
 
+class VerifyParams(C.Structure):
+    _fields_ = [("align_intercept", C.c_double), ("align_coef", C.c_double * 6), ("loop_intercept", C.c_double),
+                ("loop_coef", C.c_double * 3), ("model_threshold", C.c_double), ("all_candidates", C.c_int32),
+                ("verification_disabled", C.c_int32), ("use_covariance_sampling", C.c_int32), ("pad", C.c_int32),
+                ("coral", CoralParams), ("sampling", CovSamplingParams)]
+
+
+class VerifyJob(C.Structure):
+    _fields_ = [("from_scan", C.c_void_p), ("to_scan", C.c_void_p), ("from_peaks", C.c_void_p),
+                ("to_peaks", C.c_void_p), ("n_from", C.c_int32), ("n_to", C.c_int32), ("from_pose", C.c_double * 3),
+                ("t_be_guess", C.c_double * 3), ("sc_sim", C.c_double), ("odom_bounds", C.c_double),
+                ("group", C.c_int32), ("pad", C.c_int32)]
+
+
+class VerifyResult(C.Structure):
+    _fields_ = [("t_be", C.c_double * 3), ("cov", C.c_double * 36), ("coral", C.c_double * 3),
+                ("cfear", C.c_double * 3), ("alignment_quality", C.c_double), ("odom_bounds", C.c_double),
+                ("sc_sim", C.c_double), ("probability", C.c_double), ("reg_ok", C.c_int32),
+                ("cov_sampled", C.c_int32), ("accepted", C.c_int32), ("rank", C.c_int32), ("reg", RegResult)]
+
+
+VERIFY_RESULT_DTYPE = np.dtype([("t_be", "<f8", (3,)), ("cov", "<f8", (6, 6)), ("coral", "<f8", (3,)),
+                                ("cfear", "<f8", (3,)), ("alignment_quality", "<f8"), ("odom_bounds", "<f8"),
+                                ("sc_sim", "<f8"), ("probability", "<f8"), ("reg_ok", "<i4"), ("cov_sampled", "<i4"),
+                                ("accepted", "<i4"), ("rank", "<i4"), ("reg", RESULT_DTYPE)])
+assert VERIFY_RESULT_DTYPE.itemsize == C.sizeof(VerifyResult) == 480
+
+
 class OdometryParams(C.Structure):
     _fields_ = [("filter_type", C.c_int32), ("kstrong", KStrongParams), ("cacfar", CacfarParams),
                 ("reg", RegParams), ("res", C.c_float), ("submap_scan_size", C.c_int32),
@@ -156,6 +184,7 @@ EXPORTS = [
     "cfear_get_cost_batch", "cfear_cov_sampling_params_default", "cfear_covariance_by_sampling",
     "cfear_covariance_by_sampling_batch", "cfear_coral_params_default", "cfear_coral_quality",
     "cfear_coral_quality_batch", "cfear_sc_params_default", "cfear_sc_descriptors", "cfear_sc_distance_batch",
+    "cfear_verify_params_default", "cfear_verify_loop_candidates", "cfear_verify_by_odometry",
     "cfear_cost_prepare", "cfear_cost_num_blocks", "cfear_cost_num_residuals", "cfear_cost_get_blocks",
     "cfear_cost_evaluate", "cfear_cost_normal_eq", "cfear_cost_destroy",
     "cfear_odometry_params_default", "cfear_odometry_create", "cfear_odometry_process",
@@ -225,6 +254,10 @@ def lib():
     L.cfear_sc_descriptors.argtypes = [vp, C.POINTER(ScCloud), C.c_int32, C.POINTER(ScParams), C.POINTER(C.c_double),
                                        C.c_int32, vp, vp, vp]
     L.cfear_sc_distance_batch.argtypes = [vp, vp, C.c_int32, vp, C.c_int32, vp, C.c_int32, C.POINTER(ScParams), vp, vp]
+    L.cfear_verify_params_default.argtypes = [C.POINTER(VerifyParams)]
+    L.cfear_verify_params_default.restype = None
+    L.cfear_verify_loop_candidates.argtypes = [vp, C.POINTER(VerifyJob), C.c_int32, C.POINTER(VerifyParams), vp]
+    L.cfear_verify_by_odometry.argtypes = [vp, C.c_int32, C.c_double, C.c_int32, C.POINTER(C.c_double)]
     L.cfear_get_cost.argtypes = [vp, C.POINTER(vp), C.c_int32, C.POINTER(C.c_double), C.POINTER(RegParams),
                                  C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int32,
                                  C.POINTER(C.c_int32), C.POINTER(C.c_double)]

@@ -538,6 +538,237 @@ def coral_quality_batch(jobs, radius=1.0, weight_res_intensity=False, want_per_p
     return out, [pp[offs[i]:offs[i + 1]] for i in range(n)]
 
 
+# ------------------------------------------------------------------------------------------------
+# loop-candidate verification (tbv_slam loopclosure + alignment_checker ScanLearningInterface)
+# ------------------------------------------------------------------------------------------------
+ODOM_BOUNDS, SC_SIM, CFEAR_COST, CORAL_COST, COMBINED_COST = "odom-bounds", "sc-sim", "CFEAR", "coral", "alignment_quality"
+
+
+def verify_params(ctx=None, **kw):
+    """cfear_verify_params with loopclosure::BaseParameters' defaults (tbv_slam/include/tbv_slam/loopclosure.h:117-138);
+    align_coef / loop_coef accept sequences (6 and 3 values)."""
+    ctx = ctx or default_context()
+    p = L.VerifyParams()
+    ctx._lib.cfear_verify_params_default(C.byref(p))
+    for k, v in kw.items():
+        if k in ("align_coef", "loop_coef"):
+            arr = getattr(p, k)
+            assert len(v) == len(arr), k
+            for i, x in enumerate(v):
+                arr[i] = float(x)
+        elif k in ("coral_radius",):
+            p.coral.radius = float(v)
+        else:
+            assert hasattr(p, k), k
+            setattr(p, k, type(getattr(p, k))(v))
+    return p
+
+
+def VerifyByOdometry(rel_xyt, odom_sigma_error=0.03, verify_via_odometry=True, ctx=None):
+    """loopclosure::VerifyByOdometry (loopclosure.cpp:776-808): rel_xyt [n, 3] = RelativeMotion(i, i+1) for
+    i = to .. from-1 -> similarity (quality["odom-bounds"])."""
+    ctx = ctx or default_context()
+    r = np.ascontiguousarray(rel_xyt, dtype=np.float64).reshape(-1, 3)
+    out = C.c_double()
+    ctx.check(ctx._lib.cfear_verify_by_odometry(r.ctypes.data, int(r.shape[0]), float(odom_sigma_error),
+                                               int(bool(verify_via_odometry)), C.byref(out)))
+    return out.value
+
+
+def verify_loop_candidates(cands, par=None, ctx=None):
+    """RegisterLoopCandidate + VerifyLoopCandidate + ApplyConstratins (loopclosure.cpp:320-384, 261-274) for a batch.
+    cands: list of dicts with keys from_scan, to_scan (MapPointNormal), from_peaks, to_peaks (float32 [n, 4], NumPy
+    or torch CUDA), from_pose (x, y, theta), t_be_guess, sc_sim, odom_bounds, group -- or a prepare_verify_batch
+    result.  -> VERIFY_RESULT_DTYPE array."""
+    ctx = ctx or default_context()
+    par = par or verify_params(ctx)
+    arr, n, _keep = cands if isinstance(cands, tuple) else prepare_verify_batch(cands)
+    out = np.zeros(n, L.VERIFY_RESULT_DTYPE)
+    if n:
+        ctx.check(ctx._lib.cfear_verify_loop_candidates(ctx.h, arr, n, C.byref(par), out.ctypes.data))
+    return out
+
+
+def prepare_verify_batch(cands):
+    """Marshals a candidate list once; the result can be passed to verify_loop_candidates repeatedly."""
+    n = len(cands)
+    arr = (L.VerifyJob * n)()
+    keep = []
+    for i, c in enumerate(cands):
+        pf, nf, kf = _cloud_ptr(c["from_peaks"])
+        pt, nt, kt = _cloud_ptr(c["to_peaks"])
+        keep += [kf, kt]
+        j = arr[i]
+        j.from_scan, j.to_scan = c["from_scan"]._h, c["to_scan"]._h
+        j.from_peaks, j.to_peaks, j.n_from, j.n_to = pf, pt, nf, nt
+        for k in range(3):
+            j.from_pose[k] = float(c["from_pose"][k])
+            j.t_be_guess[k] = float(c.get("t_be_guess", (0.0, 0.0, 0.0))[k])
+        j.sc_sim, j.odom_bounds = float(c.get("sc_sim", 0.0)), float(c.get("odom_bounds", 0.0))
+        j.group = int(c.get("group", 0))
+    return (arr, n, keep + [cands])
+
+
+class LogisticRegression:
+    """PythonClassifierInterface + LogisticRegression (alignmentinterface.cpp:14-279): training rows, the two text
+    formats, predict_linear.  fit() is sklearn's LogisticRegression(class_weight="balanced", max_iter=1000), the
+    call the reference makes through pybind11 (:192-222)."""
+
+    def __init__(self):
+        self.X_ = np.zeros((0, 0))
+        self.y_ = np.zeros((0,))
+        self.coef_ = None
+        self.intercept_ = 0.0
+        self.is_fit_ = False
+
+    def IsFit(self):
+        return self.is_fit_
+
+    def AddDataPoint(self, X_i, y_i):                                   # :51-67
+        X_i = np.atleast_2d(np.asarray(X_i, np.float64))
+        y_i = np.atleast_1d(np.asarray(y_i, np.float64))
+        self.X_ = X_i if self.X_.shape[0] == 0 else np.vstack([self.X_, X_i])
+        self.y_ = y_i if self.y_.shape[0] == 0 else np.concatenate([self.y_, y_i])
+
+    def DataValid(self):                                                # :175-187
+        return (self.X_.shape[0] == self.y_.shape[0] and self.y_.shape[0] >= 1 and np.isfinite(self.X_).all()
+                and np.isfinite(self.y_).all())
+
+    def fit(self):
+        if not self.DataValid():
+            raise ValueError("training data invalid")                   # the reference calls exit(0) (:194-196)
+        from sklearn.linear_model import LogisticRegression as SkLR
+        clf = SkLR(class_weight="balanced", max_iter=1000).fit(self.X_, self.y_)
+        self.coef_ = np.asarray(clf.coef_[0], np.float64).copy()
+        self.intercept_ = float(clf.intercept_[0])
+        self.is_fit_ = True
+
+    def LoadData(self, path):                                           # :103-134: "y,x0,x1,..." per line
+        rows = [ln.strip().split(",") for ln in open(path) if ln.strip()]
+        if rows:
+            a = np.array(rows, dtype=np.float64)
+            self.y_, self.X_ = a[:, 0].copy(), a[:, 1:].copy()
+
+    def SaveData(self, path):                                           # :152-173, default ostream precision (%g)
+        with open(path, "w") as f:
+            for y, x in zip(self.y_, self.X_):
+                f.write(",".join(["%g" % y] + ["%g" % v for v in x]) + "\n")
+
+    def LoadCoefficients(self, path):                                   # :224-253: "intercept,c0,c1,..."
+        for ln in open(path):
+            v = [float(t) for t in ln.strip().split(",") if t]
+            if v:
+                self.intercept_, self.coef_ = v[0], np.array(v[1:], np.float64)
+        self.is_fit_ = True
+
+    def SaveCoefficients(self, path):                                   # :255-269
+        with open(path, "w") as f:
+            f.write(",".join(["%g" % self.intercept_] + ["%g" % c for c in self.coef_]) + "\n")
+
+    def predict_linear(self, X):                                        # :271-279
+        return np.atleast_2d(np.asarray(X, np.float64)) @ self.coef_ + self.intercept_
+
+    def predict_proba(self, X):                                         # :21-33: P(y = 1); zeros when not fitted
+        if not self.is_fit_:
+            return np.zeros(np.atleast_2d(X).shape[0])
+        return 1.0 / (1.0 + np.exp(-self.predict_linear(X)))
+
+
+class ScanLearningInterface:
+    """ScanLearningInterface (alignment_checker/alignmentinterface.h:96-213, alignmentinterface.cpp:288-510).
+    A scan is a dict {"T": (x, y, theta), "cldPeaks": float32 [n, 4], "CFEAR": MapPointNormal} (s_scan, :103-109).
+    Every CorAl / CFEAR quality evaluation of one call -- the 13 perturbations of AddTrainingData -- is one launch."""
+
+    range_error_, min_dist_btw_scans_ = 0.5, 0.5                         # alignmentinterface.h:196-197
+    small_th_err, medium_th_err, large_th_err = 0.5 * np.pi / 180.0, 2 * np.pi / 180.0, 15 * np.pi / 180.0
+
+    def __init__(self, combined=True, ctx=None):
+        self.ctx = ctx or default_context()
+        self.combined_ = combined
+        self.cfear_class, self.coral_class, self.combined_class = LogisticRegression(), LogisticRegression(), LogisticRegression()
+        self.frame_ = 0
+        self.prev_ = None
+        e = self.range_error_                                            # CreatePerturbations (:479-495)
+        self.vek_perturbation_ = [(0.0, 0.0, 0.0)]
+        for m, th in ((1, self.small_th_err), (2, self.medium_th_err), (4, self.large_th_err)):
+            self.vek_perturbation_ += [(m * e, 0.0, th), (0.0, m * e, th), (-m * e, 0.0, th), (0.0, -m * e, th)]
+
+    def _quality(self, current, prev, offsets):
+        """X_CorAl, X_CFEAR [len(offsets), 3] for ref = current, src = prev * Toffset (getCorAlQualityMeasure :437-456,
+        getCFEARQualityMeasure :459-478)."""
+        cj = [(current["cldPeaks"], current["T"], prev["cldPeaks"], prev["T"], o) for o in offsets]
+        qj = [(current["CFEAR"], current["T"], prev["CFEAR"], prev["T"], o) for o in offsets]
+        co, _ = coral_quality_batch(cj, 1.0, False, False, self.ctx)
+        X_coral = np.stack([co["joint"], co["sep"], co["overlap"]], 1).astype(np.float64)
+        X_cfear = cfear_quality_batch(qj, "P2L", self.ctx)
+        return X_coral, X_cfear
+
+    def AddTrainingData(self, current):                                  # :296-347
+        first = self.frame_ == 0
+        self.frame_ += 1
+        if first:
+            self.prev_ = current
+            return
+        d = np.hypot(current["T"][0] - self.prev_["T"][0], current["T"][1] - self.prev_["T"][1])
+        if d < self.min_dist_btw_scans_:
+            return
+        Xc, Xf = self._quality(current, self.prev_, self.vek_perturbation_)
+        for verr, xc, xf in zip(self.vek_perturbation_, Xc, Xf):
+            y = float(sum(abs(v) for v in verr) < 0.0001)
+            if self.combined_:
+                self.combined_class.AddDataPoint(np.concatenate([xc, xf]), y)
+            else:
+                self.coral_class.AddDataPoint(xc, y)
+                self.cfear_class.AddDataPoint(xf, y)
+        self.prev_ = current
+
+    def PredAlignment(self, current, prev, quality=None):                # :349-367
+        """-> (quality dict, X_CorAl, X_CFEAR); `valid` of the reference is valid1 && valid2 of two locals that
+        are never written, i.e. always false, and unused by its callers."""
+        quality = {} if quality is None else quality
+        Xc, Xf = self._quality(current, prev, [(0.0, 0.0, 0.0)])
+        if self.combined_:
+            quality[COMBINED_COST] = float(self.combined_class.predict_linear(np.concatenate([Xc[0], Xf[0]]))[0])
+        else:
+            quality[CORAL_COST] = float(self.coral_class.predict_proba(Xc)[0])
+            quality[CFEAR_COST] = float(self.cfear_class.predict_proba(Xf)[0])
+        return quality, Xc, Xf
+
+    def _files(self, d, combined_name, coral_name, cfear_name):
+        d = str(d)
+        if self.combined_:
+            return [(self.combined_class, d + combined_name)]
+        return [(self.coral_class, d + coral_name), (self.cfear_class, d + cfear_name)]
+
+    def LoadData(self, d):                                               # :376-383
+        for clf, f in self._files(d, "/combined.txt", "/CorAl.txt", "/CFEAR.txt"):
+            clf.LoadData(f)
+
+    def SaveData(self, d):                                               # :386-393
+        for clf, f in self._files(d, "/combined.txt", "/CorAl.txt", "/CFEAR.txt"):
+            clf.SaveData(f)
+
+    def LoadCoefficients(self, d):                                       # :396-403 (dir is concatenated without "/")
+        for clf, f in self._files(d, "trained_alignment_classifier.txt", "trained_alignment_classifier_CorAl.txt",
+                                  "trained_alignment_classifier_CFEAR.txt"):
+            clf.LoadCoefficients(f)
+
+    def SaveCoefficients(self, d):                                       # :405-412
+        for clf, f in self._files(d, "/trained_alignment_classifier.txt", "/trained_alignment_classifier_CorAl.txt",
+                                  "/trained_alignment_classifier_CFEAR.txt"):
+            clf.SaveCoefficients(f)
+
+    def FitModels(self, model="LogisticRegression"):                     # :423-434
+        for clf, _ in self._files("", "", "", ""):
+            clf.fit()
+
+    def verify_params(self, **kw):
+        """cfear_verify_params carrying this interface's combined classifier."""
+        assert self.combined_ and self.combined_class.IsFit()
+        return verify_params(self.ctx, align_intercept=self.combined_class.intercept_,
+                             align_coef=list(self.combined_class.coef_), **kw)
+
+
 def _cloud_ptr(cloud):
     """float32 [n, 4] NumPy array or torch CUDA tensor -> (pointer, n, keep-alive)."""
     if isinstance(cloud, np.ndarray):

@@ -8,6 +8,10 @@ so the host can apply its ApplyConstratins-style selection deterministically.  O
 torch.distributed backend "nccl" (= RCCL over xGMI on MI355X); the message is 72 B x ceil(n/world) per
 rank (36 KiB for 4096 candidates on 8 ranks): latency-bound, far below the per-link ring bound.
 
+Full candidate verification (registration + CorAl + CFEAR quality + classifiers, api.verify_loop_candidates)
+shards the same way with 480-byte records; its accept / reject step runs after the gather because the candidates
+of one query may straddle a rank boundary.
+
 `register_fn(local_jobs) -> RESULT_DTYPE array` is the per-rank compute; the default runs
 libcfear_hip.so on this rank's GPU.  The CPU tests inject another function (there is no CPU path in
 the product).
@@ -30,27 +34,67 @@ def default_register_fn(reg):
     return fn
 
 
-def register_candidates_sharded(jobs, register_fn, group=None):
-    """jobs: the FULL candidate list (same on every rank).  Returns the results of all candidates, in
-    candidate order, on every rank."""
+def _gather_records(local, n, group):
+    """all_gather of one fixed-size record per candidate: every rank contributes ceil(n / world) records (its block,
+    zero-padded), rank order = candidate order; returns the n real records on every rank."""
     import torch
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()):
-        return register_fn(jobs)
     world, rank = dist.get_world_size(group), dist.get_rank(group)
-    n = len(jobs)
     lo, hi, per = shard_range(n, world, rank)
-    local = register_fn(jobs[lo:hi])
-    assert local.dtype == L.RESULT_DTYPE and local.shape[0] == hi - lo
-    padded = np.zeros(per, L.RESULT_DTYPE)
-    padded["status"] = L.ERR_INVALID_ARGUMENT          # padding slots are never returned
+    assert local.shape[0] == hi - lo
+    padded = np.zeros(per, local.dtype)                 # padding slots are never returned
     padded[:hi - lo] = local
     backend = dist.get_backend(group)
     dev = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
     send = torch.from_numpy(padded.view(np.uint8).reshape(-1).copy()).to(dev)
     recv = torch.empty(world * send.numel(), dtype=torch.uint8, device=dev)
     dist.all_gather_into_tensor(recv, send, group=group)
-    allr = recv.cpu().numpy().view(L.RESULT_DTYPE).reshape(world, per)
+    allr = recv.cpu().numpy().view(local.dtype).reshape(world, per)
     out = np.concatenate([allr[r, :shard_range(n, world, r)[1] - shard_range(n, world, r)[0]] for r in range(world)])
     assert out.shape[0] == n
     return out
+
+
+def register_candidates_sharded(jobs, register_fn, group=None):
+    """jobs: the FULL candidate list (same on every rank).  Returns the results of all candidates, in
+    candidate order, on every rank."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return register_fn(jobs)
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    lo, hi, _per = shard_range(len(jobs), world, rank)
+    local = register_fn(jobs[lo:hi])
+    assert local.dtype == L.RESULT_DTYPE
+    return _gather_records(local, len(jobs), group)
+
+
+def apply_constraints(results, groups, model_threshold=0.8, all_candidates=True):
+    """loopclosure::ApplyConstratins (tbv_slam/src/tbv_slam/loopclosure.cpp:261-274) over gathered records: per
+    query (group) sort by probability, larger first; accept above the threshold, every candidate or only the best.
+    Rewrites results["accepted"] / results["rank"] in place -- a query's candidates may sit on different ranks, so
+    the selection the library made inside one rank's block is redone over the whole list."""
+    groups = np.asarray(groups)
+    for g in np.unique(groups):
+        idx = np.nonzero(groups == g)[0]
+        order = idx[np.argsort(-results["probability"][idx], kind="stable")]
+        results["rank"][order] = np.arange(order.shape[0])
+        considered = np.ones(order.shape[0], bool) if all_candidates else np.arange(order.shape[0]) == 0
+        results["accepted"][order] = considered & (results["probability"][order] > model_threshold)
+    return results
+
+
+def verify_candidates_sharded(cands, verify_fn, model_threshold=0.8, all_candidates=True, group=None):
+    """Loop-candidate verification (api.verify_loop_candidates) for the FULL candidate list `cands` (dicts with a
+    "group" key, same on every rank): each rank verifies its contiguous block, one all_gather of the 480-byte
+    cfear_verify_result records, then ApplyConstratins over the whole list.  `verify_fn(local_cands) ->
+    VERIFY_RESULT_DTYPE array`."""
+    import torch.distributed as dist
+    groups = [int(c.get("group", 0)) for c in cands]
+    if not (dist.is_available() and dist.is_initialized()):
+        return apply_constraints(verify_fn(cands), groups, model_threshold, all_candidates)
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    lo, hi, _per = shard_range(len(cands), world, rank)
+    local = verify_fn(cands[lo:hi])
+    assert local.dtype == L.VERIFY_RESULT_DTYPE
+    out = _gather_records(local, len(cands), group)
+    return apply_constraints(out, groups, model_threshold, all_candidates)

@@ -33,6 +33,8 @@ def test_struct_sizes():
     assert C.sizeof(L.ScParams) == 48 and C.sizeof(L.ScCloud) == 16
     assert C.sizeof(L.CoralJob) == 96
     assert C.sizeof(L.CoralResult) == 40 == L.CORAL_RESULT_DTYPE.itemsize
+    assert C.sizeof(L.VerifyParams) == 160 and C.sizeof(L.VerifyJob) == 112
+    assert C.sizeof(L.VerifyResult) == 480 == L.VERIFY_RESULT_DTYPE.itemsize
 
 
 def test_defaults_follow_reference():
