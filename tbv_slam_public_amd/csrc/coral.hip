@@ -93,6 +93,8 @@ __device__ __forceinline__ int upper_bound_u32(const uint32_t* a, int lo, int hi
 }
 
 struct Moments { int n; double sx, sy, sxx, sxy, syy; };
+typedef float v4f __attribute__((ext_vector_type(4)));
+#define CFEAR_LDS __attribute__((address_space(3)))
 
 // CorAlRadarQuality::Covariance (:30-53) from the moments of d = p - q about the query q: the mean shift
 // cancels in the covariance, |d| < radius keeps the one-pass form accurate to a few ulp.
@@ -209,6 +211,11 @@ __global__ __launch_bounds__(kCoralThreads) void coral_kernel(const CoralJob* __
   uint32_t* cell_key = (uint32_t*)smem;                 // [V]
   int32_t* cell_start = (int32_t*)(smem + Vp * 4);      // [V + 1]
   int32_t* rowbeg = (int32_t*)(smem + kCoralRowbegOff); // [dby + 1]
+  // The sorted points follow the cell table in LDS when they fit (the usual case: a few thousand peaks), so the
+  // neighbour sweep of step 4 reads them at LDS latency; larger clouds keep them in the per-job global scratch.
+  const size_t spt_off = (Vp * 4 + ((size_t)V + 1) * 4 + 15) & ~(size_t)15;
+  const bool spt_in_lds = spt_off + (size_t)n * 16 <= kCoralRowbegOff;
+  if (spt_in_lds) spt = (float4*)(smem + spt_off);
   {
     unsigned pv = prev_cell;
     int ord = voff;
@@ -233,53 +240,68 @@ __global__ __launch_bounds__(kCoralThreads) void coral_kernel(const CoralJob* __
   __threadfence_block();
   __syncthreads();
   // ---- 4. one lane per merged point: moments of its source / reference neighbours -> entropies ----
-  for (int e = tid; e < n; e += kCoralThreads) {
-    const float4 q = spt[e];
-    const int idx = __float_as_int(q.w);
-    const bool q_is_src = idx < n_src;
-    int ix, iy;
-    cell_xy(make_float2(q.x, q.y), ix, iy);
-    const int x0 = max(ix - 1, 0), x1 = min(ix + 1, dbx - 1);
-    Moments ms{0, 0, 0, 0, 0, 0}, mr{0, 0, 0, 0, 0, 0};
-    const double qx = (double)q.x, qy = (double)q.y;
-    for (int yy = max(iy - 1, 0); yy <= min(iy + 1, dby - 1); yy++) {
-      const uint32_t klo = (uint32_t)(yy * dbx + x0), khi = (uint32_t)(yy * dbx + x1);
-      const int a = lower_bound_u32(cell_key, rowbeg[yy], rowbeg[yy + 1], klo);
-      const int b = upper_bound_u32(cell_key, rowbeg[yy], rowbeg[yy + 1], khi);
-      const int p0 = cell_start[a], p1 = cell_start[b];
-      for (int p = p0; p < p1; p++) {
-        const float4 c = spt[p];
+  // Instantiated per address space of the sorted points (ds_read_b128 when they sit in LDS); candidates are fetched
+  // two at a time so the second load is in flight while the first is tested.
+  auto sweep = [&](auto* SP) {
+    for (int e = tid; e < n; e += kCoralThreads) {
+      const v4f q = SP[e];
+      const int idx = __float_as_int(q.w);
+      const bool q_is_src = idx < n_src;
+      int ix, iy;
+      cell_xy(make_float2(q.x, q.y), ix, iy);
+      const int x0 = max(ix - 1, 0), x1 = min(ix + 1, dbx - 1);
+      Moments ms{0, 0, 0, 0, 0, 0}, mr{0, 0, 0, 0, 0, 0};
+      const double qx = (double)q.x, qy = (double)q.y;
+      auto visit = [&](const v4f c) {
         const float dxf = __fsub_rn(q.x, c.x), dyf = __fsub_rn(q.y, c.y);
         const float d2 = __fadd_rn(__fmul_rn(dxf, dxf), __fmul_rn(dyf, dyf));  // FLANN L2_Simple
         if (d2 < cm.r2) {                                                       // RadiusResultSet: strict <
           const double dx = (double)c.x - qx, dy = (double)c.y - qy;
-          Moments& m = (__float_as_int(c.w) < n_src) ? ms : mr;
-          m.n++; m.sx += dx; m.sy += dy; m.sxx += dx * dx; m.sxy += dx * dy; m.syy += dy * dy;
+          if (__float_as_int(c.w) < n_src) {
+            ms.n++; ms.sx += dx; ms.sy += dy; ms.sxx += dx * dx; ms.sxy += dx * dy; ms.syy += dy * dy;
+          } else {
+            mr.n++; mr.sx += dx; mr.sy += dy; mr.sxx += dx * dx; mr.sxy += dx * dy; mr.syy += dy * dy;
+          }
         }
+      };
+      for (int yy = max(iy - 1, 0); yy <= min(iy + 1, dby - 1); yy++) {
+        const uint32_t klo = (uint32_t)(yy * dbx + x0), khi = (uint32_t)(yy * dbx + x1);
+        const int a = lower_bound_u32(cell_key, rowbeg[yy], rowbeg[yy + 1], klo);
+        const int b = upper_bound_u32(cell_key, rowbeg[yy], rowbeg[yy + 1], khi);
+        const int p1 = cell_start[b];
+        int p = cell_start[a];
+        for (; p + 1 < p1; p += 2) {
+          const v4f c0 = SP[p], c1 = SP[p + 1];
+          visit(c0);
+          visit(c1);
+        }
+        if (p < p1) visit(SP[p]);
       }
-    }
-    double jr = 100.0, sr = 100.0, w = 0.0;
-    int valid = 0;
-    const Moments& own = q_is_src ? ms : mr;
-    const Moments& other = q_is_src ? mr : ms;
-    if (other.n >= 1) {                                                         // overlap_req_ = 1 (:138, :160)
-      const Moments mj{ms.n + mr.n, ms.sx + mr.sx, ms.sy + mr.sy, ms.sxx + mr.sxx, ms.sxy + mr.sxy, ms.syy + mr.syy};
-      double s00, s01, s11, j00, j01, j11;
-      if (cov_from_moments(own, s00, s01, s11) && cov_from_moments(mj, j00, j01, j11)) {
-        const double det_j = j00 * j11 - j01 * j01;                             // ComputeEntropy (:80-98)
-        const double det_s = s00 * s11 - s01 * s01;
-        if (!(isnan(det_s) || isnan(det_j))) {
-          const double sep_entropy = 1.0 / 2.0 * log(2.0 * M_PI * exp(1.0) * det_s + 0.00000001);
-          const double joint_entropy = 1.0 / 2.0 * log(2.0 * M_PI * exp(1.0) * det_j + 0.00000001);
-          if (!(isnan(sep_entropy) || isnan(joint_entropy))) {
-            w = cm.weight_res_intensity ? (double)q.z : 1.0;                    // :180
-            jr = w * joint_entropy; sr = w * sep_entropy; valid = 1;
+      double jr = 100.0, sr = 100.0, w = 0.0;
+      int valid = 0;
+      const Moments& own = q_is_src ? ms : mr;
+      const Moments& other = q_is_src ? mr : ms;
+      if (other.n >= 1) {                                                         // overlap_req_ = 1 (:138, :160)
+        const Moments mj{ms.n + mr.n, ms.sx + mr.sx, ms.sy + mr.sy, ms.sxx + mr.sxx, ms.sxy + mr.sxy, ms.syy + mr.syy};
+        double s00, s01, s11, j00, j01, j11;
+        if (cov_from_moments(own, s00, s01, s11) && cov_from_moments(mj, j00, j01, j11)) {
+          const double det_j = j00 * j11 - j01 * j01;                             // ComputeEntropy (:80-98)
+          const double det_s = s00 * s11 - s01 * s01;
+          if (!(isnan(det_s) || isnan(det_j))) {
+            const double sep_entropy = 1.0 / 2.0 * log(2.0 * M_PI * exp(1.0) * det_s + 0.00000001);
+            const double joint_entropy = 1.0 / 2.0 * log(2.0 * M_PI * exp(1.0) * det_j + 0.00000001);
+            if (!(isnan(sep_entropy) || isnan(joint_entropy))) {
+              w = cm.weight_res_intensity ? (double)q.z : 1.0;                    // :180
+              jr = w * joint_entropy; sr = w * sep_entropy; valid = 1;
+            }
           }
         }
       }
+      jres[idx] = jr; sres[idx] = sr; wres[idx] = valid ? w : 0.0; vres[idx] = valid;
     }
-    jres[idx] = jr; sres[idx] = sr; wres[idx] = valid ? w : 0.0; vres[idx] = valid;
-  }
+  };
+  if (spt_in_lds) sweep((CFEAR_LDS const v4f*)spt);
+  else sweep((const v4f*)spt);
   __threadfence_block();
   __syncthreads();
   // ---- 5. aggregation in index order (:178-204): contiguous chunk per thread, then a fixed tree ------
@@ -329,6 +351,7 @@ extern "C" int cfear_coral_quality_batch(cfear_ctx* ctx, const cfear_coral_job* 
   CFEAR_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   // stage host clouds once each (perturbation sets and candidate lists share clouds)
   std::map<const float*, size_t> staged;                 // host pointer -> offset (floats) in the staging buffer
+  std::map<const float*, bool> on_device;                // one hipPointerGetAttributes per distinct cloud, not per job
   size_t stage_floats = 0;
   int cap = 1;
   for (int j = 0; j < n_jobs; j++) {
@@ -340,11 +363,16 @@ extern "C" int cfear_coral_quality_batch(cfear_ctx* ctx, const cfear_coral_job* 
     cap = std::max(cap, jb.n_ref + jb.n_src);
     const float* ptrs[2] = {jb.ref_xyzi, jb.src_xyzi};
     const int ns[2] = {jb.n_ref, jb.n_src};
-    for (int c = 0; c < 2; c++)
-      if (!cfear_is_device_ptr(ptrs[c]) && !staged.count(ptrs[c])) {
+    for (int c = 0; c < 2; c++) {
+      auto it = on_device.find(ptrs[c]);
+      if (it != on_device.end()) continue;
+      const bool dev = cfear_is_device_ptr(ptrs[c]);
+      on_device[ptrs[c]] = dev;
+      if (!dev) {
         staged[ptrs[c]] = stage_floats;
         stage_floats += ((size_t)ns[c] * 4 + 3) & ~(size_t)3;
       }
+    }
   }
   float* d_stage = nullptr;
   if (stage_floats) {

@@ -74,12 +74,16 @@ def apply_constraints(results, groups, model_threshold=0.8, all_candidates=True)
     Rewrites results["accepted"] / results["rank"] in place -- a query's candidates may sit on different ranks, so
     the selection the library made inside one rank's block is redone over the whole list."""
     groups = np.asarray(groups)
-    for g in np.unique(groups):
-        idx = np.nonzero(groups == g)[0]
-        order = idx[np.argsort(-results["probability"][idx], kind="stable")]
-        results["rank"][order] = np.arange(order.shape[0])
-        considered = np.ones(order.shape[0], bool) if all_candidates else np.arange(order.shape[0]) == 0
-        results["accepted"][order] = considered & (results["probability"][order] > model_threshold)
+    if results.shape[0] == 0:
+        return results
+    prob = results["probability"]
+    order = np.lexsort((-prob, groups))                 # stable: by query, then probability descending
+    gs = groups[order]
+    first = np.concatenate([[True], gs[1:] != gs[:-1]])
+    start = np.maximum.accumulate(np.where(first, np.arange(order.shape[0]), 0))
+    rank = np.arange(order.shape[0]) - start
+    results["rank"][order] = rank
+    results["accepted"][order] = ((rank == 0) | bool(all_candidates)) & (prob[order] > model_threshold)
     return results
 
 
