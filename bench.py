@@ -189,6 +189,9 @@ def main():
                          "a batch of candidate registrations from cached features, sharded over the ranks "
                          "with one RCCL all_gather of the result records per step")
     ap.add_argument("--candidates", type=int, default=4096)
+    ap.add_argument("--bins-major", action="store_true",
+                    help="feed the images as [range bins][azimuths] (non-Oxford drivers): adds the GPU rotation of "
+                         "radarDriver::Callback (radar_driver.cpp:74-90) to every step; not the BASELINE layout")
     ap.add_argument("--cov-sampling", action="store_true",
                     help="odometry: also estimate every frame's covariance by cost sampling (27 GetCost per "
                          "registration, odometrykeyframefuser.cpp:203-208; off in the reference's presets)")
@@ -231,8 +234,10 @@ def main():
 
     stream = torch.cuda.current_stream().cuda_stream
     ctx = api.Context(local_rank, stream=stream)
-    od = api.OdometryKeyframeFuser(B, ROWS, COLS, api.odometry_params(estimate_cov_by_sampling=int(args.cov_sampling)),
-                                   ctx=ctx)
+    if args.bins_major:
+        frames = torch.rot90(frames, -1, dims=(2, 3)).contiguous()   # [F][B][COLS][ROWS]: what such a driver publishes
+    od = api.OdometryKeyframeFuser(B, *frames.shape[2:], api.odometry_params(estimate_cov_by_sampling=int(args.cov_sampling),
+                                                                             rotate_ccw=int(args.bins_major)), ctx=ctx)
 
     def barrier():
         torch.cuda.synchronize()

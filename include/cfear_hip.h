@@ -61,7 +61,8 @@ typedef struct cfear_ctx cfear_ctx;
 
 int cfear_abi_version(void);
 const char* cfear_status_string(int status);
-/* hip_stream: a hipStream_t to enqueue on (e.g. torch's current stream), or NULL to create one. */
+/* hip_stream: a hipStream_t to enqueue on (e.g. torch's current stream; hipStreamLegacy / hipStreamPerThread are
+ * accepted too), or NULL to create a private non-blocking stream.                                   */
 int cfear_ctx_create(int device, void* hip_stream, cfear_ctx** out);
 int cfear_ctx_destroy(cfear_ctx* ctx);
 int cfear_ctx_synchronize(cfear_ctx* ctx);
@@ -86,6 +87,14 @@ typedef struct cfear_polar_desc {
   int32_t rows, cols, stride, batch;
   int64_t batch_stride;
 } cfear_polar_desc;
+
+/* Image decode of the non-Oxford sensors.  Replaces cv::rotate(image, image, ROTATE_90_COUNTERCLOCKWISE) in
+ * radarDriver::Callback (radar_driver.cpp:74-90): those drivers publish the sweep as [range bins][azimuths];
+ * the filters want rows = azimuths.  src_desc describes the SOURCE images (rows = range bins, cols = azimuths);
+ * dst holds batch images of cols x rows bytes, dst[i][j] = src[j][cols - 1 - i].  src and dst both host or both
+ * device; they must not overlap.                                                                             */
+int cfear_polar_rotate_ccw(cfear_ctx* ctx, const uint8_t* src, const cfear_polar_desc* src_desc, uint8_t* dst,
+                           int32_t dst_stride, int64_t dst_batch_stride);
 
 typedef struct cfear_kstrong_params {   /* radarDriver::Parameters, radar_driver.h:40-45 */
   int32_t k_strongest;                  /* >= 1, <= 1024 */
@@ -440,7 +449,8 @@ typedef struct cfear_odometry_params {
   float res;                            /* par.res */
   int32_t submap_scan_size;
   int32_t weight_intensity, use_guess, compensate, radar_ccw, use_keyframe;
-  int32_t pad;
+  int32_t rotate_ccw;                   /* 1: the incoming images are [range bins][azimuths] (dataset != oxford) and are
+                                           rotated first, radar_driver.cpp:74-90; desc then describes that source layout */
   double min_keyframe_dist, min_keyframe_rot_deg, downsample_factor;
   int32_t estimate_cov_by_sampling;     /* par.estimate_cov_by_sampling (false), odometrykeyframefuser.h:104 */
   int32_t pad2;

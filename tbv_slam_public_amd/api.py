@@ -81,9 +81,20 @@ _DEFAULT_CTX = None
 
 
 def default_context():
+    """The process-wide context on device 0.  It enqueues on torch's current stream, so kernels launched through
+    the mirror are ordered with torch work on the tensors they read and write (device-pointer calls are
+    asynchronous, include/cfear_hip.h)."""
     global _DEFAULT_CTX
     if _DEFAULT_CTX is None:
-        _DEFAULT_CTX = Context(0)
+        stream = None
+        try:
+            import torch
+            if torch.cuda.is_available():
+                # torch's default stream is the null stream (handle 0): address it as hipStreamLegacy (1)
+                stream = torch.cuda.current_stream(0).cuda_stream or 1
+        except ImportError:
+            pass
+        _DEFAULT_CTX = Context(0, stream)
     return _DEFAULT_CTX
 
 
@@ -112,6 +123,24 @@ def _desc(img):
     d.rows, d.cols, d.stride, d.batch = rows, cols, cols, batch
     d.batch_stride = rows * cols
     return d, batch, rows, cols
+
+
+def polar_rotate_ccw(img, ctx=None):
+    """cv::rotate(ROTATE_90_COUNTERCLOCKWISE) of radarDriver::Callback (radar_driver.cpp:74-90) for a uint8 image
+    [bins, azimuths] or a batch [b, bins, azimuths] -> [azimuths, bins] / [b, azimuths, bins] (NumPy -> NumPy,
+    torch CUDA -> torch CUDA); out[i, j] = img[j, azimuths - 1 - i]."""
+    ctx = ctx or default_context()
+    d, batch, rows, cols = _desc(img)
+    shape = (cols, rows) if img.ndim == 2 else (batch, cols, rows)
+    if _is_torch(img):
+        import torch
+        img = img.contiguous()
+        out = torch.empty(shape, dtype=torch.uint8, device=img.device)
+    else:
+        img = np.ascontiguousarray(img, dtype=np.uint8)
+        out = np.empty(shape, np.uint8)
+    ctx.check(ctx._lib.cfear_polar_rotate_ccw(ctx.h, _ptr(img)[0], C.byref(d), _ptr(out)[0], rows, rows * cols))
+    return out
 
 
 def filter_kstrongest(img, k, z_min, range_res, min_distance, want_peaks=False, ctx=None):
@@ -185,7 +214,7 @@ class radarDriver:
         img = radar_image_polar
         if self.par.dataset != "oxford":
             # Callback (radar_driver.cpp:74-90): MONO8 + rotate 90 deg CCW so rows = azimuth
-            img = np.ascontiguousarray(np.rot90(np.asarray(img), 1))
+            img = polar_rotate_ccw(img, self.ctx)
         self.cv_polar_image = img
         p = self.par
         if p.filter_type == "CA-CFAR":                                      # radar_driver.cpp:52-56
@@ -973,6 +1002,8 @@ class OdometryKeyframeFuser:
     (radar_driver.cpp:163-176 + odometrykeyframefuser.cpp:143-259), everything on the GPU."""
 
     def __init__(self, n_streams, rows, cols, par=None, ctx=None):
+        """rows x cols: the layout of the images passed to process() -- azimuths x range bins, or range bins x
+        azimuths when par.rotate_ccw is set (non-Oxford drivers, radar_driver.cpp:74-90)."""
         self.ctx = ctx or default_context()
         self.par = par or odometry_params()
         d = L.PolarDesc()

@@ -109,6 +109,8 @@ int cfear_scan_alloc(cfear_ctx* ctx, int cap, cfear_scan** out);
 // ---------------------------------------------------------------------------------------------
 int cfear_kstrong_device(cfear_ctx* ctx, const uint8_t* d_polar, const cfear_polar_desc* desc,
                          const cfear_kstrong_params* par, const cfear_kstrong_out* o);
+int cfear_rotate_ccw_device(cfear_ctx* ctx, const uint8_t* d_src, const cfear_polar_desc* src_desc, uint8_t* d_dst,
+                            int dst_stride, int64_t dst_batch_stride);
 int cfear_cacfar_device(cfear_ctx* ctx, const uint8_t* d_polar, const cfear_polar_desc* desc,
                         const cfear_cacfar_params* par, float* d_xyzi, int32_t* d_n_points,
                         int32_t cap_points, uint8_t* d_det_mask);

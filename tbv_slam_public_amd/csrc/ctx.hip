@@ -298,6 +298,7 @@ void cfear_odometry_params_default(cfear_odometry_params* p) {
   p->compensate = 1;
   p->radar_ccw = 0;
   p->use_keyframe = 1;
+  p->rotate_ccw = 0;                   // Oxford images arrive with rows = azimuths (CallbackOxford)
   p->min_keyframe_dist = 1.5;
   p->min_keyframe_rot_deg = 5.0;
   p->downsample_factor = 1.0;

@@ -946,3 +946,211 @@ extern "C" int cfear_filter_cacfar(cfear_ctx* ctx, const uint8_t* polar, const c
       return cfear_set_error(ctx, CFEAR_ERR_CAPACITY, "image %d: %d detections > cap_points %d", b, n_points[b], cap_points);
   return CFEAR_OK;
 }
+
+// ---- image decode of the non-Oxford sensors: rotate 90 degrees counter-clockwise ------------------------
+// radarDriver::Callback (radar_driver.cpp:74-90): Navtech drivers other than Oxford's publish the sweep as
+// [range bins][azimuths]; cv::rotate(ROTATE_90_COUNTERCLOCKWISE) turns it into the rows = azimuth layout that
+// Process() and every filter expect:  dst[i][j] = src[j][src.cols - 1 - i].
+// HBM-bound byte transpose: tiles through LDS, 16-byte loads along the source rows, 4 x 4 byte blocks
+// transposed in registers, dword stores along the destination rows (byte accesses only on ragged edges /
+// unaligned strides).
+namespace {
+
+constexpr int kRotTile = 64;                  // general kernel (wide sources): 64 x 64 byte tiles
+constexpr int kRotPitchW = kRotTile / 4 + 1;  // LDS row pitch in dwords: odd, spreads the 4 x 4 block reads over the banks
+
+struct RotArgs {
+  const uint8_t* src; uint8_t* dst;
+  int rows_in, cols_in, stride_in, stride_out;
+  long long bs_in, bs_out;
+  int batch0, vec_in, vec_out;
+};
+
+// General kernel: one 64 x 64 byte tile per workgroup.  Load: 16-byte pieces along the source rows -> LDS.  Each thread then owns
+// 4 x 4 byte blocks: 4 dword reads down a column of blocks, a byte transpose in registers (v_perm_b32) and 4 dword
+// stores; 16 consecutive lanes write 64 contiguous bytes of one destination row.
+__global__ __launch_bounds__(256) void rotate_ccw_kernel(const RotArgs a) {
+  __shared__ uint32_t tile[kRotTile][kRotPitchW];
+  const int t = threadIdx.x;
+  const int C0 = blockIdx.x * kRotTile, R0 = blockIdx.y * kRotTile;
+  const size_t img = (size_t)a.batch0 + blockIdx.z;
+  const uint8_t* src = a.src + img * (size_t)a.bs_in;
+  uint8_t* dst = a.dst + img * (size_t)a.bs_out;
+  constexpr int kSeg = kRotTile / 16;            // 16-byte pieces per tile row
+#pragma unroll
+  for (int q = 0; q < kRotTile * kSeg / 256; q++) {
+    const int idx = t + 256 * q, r = idx / kSeg, s = idx % kSeg;
+    const int row = R0 + r, col = C0 + 16 * s;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (row < a.rows_in && col < a.cols_in) {
+      const uint8_t* p = src + (size_t)row * a.stride_in + col;
+      if (a.vec_in && col + 16 <= a.cols_in) {
+        v = *(const uint4*)p;
+      } else {
+        uint32_t w[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int k = 0; k < 16; k++)
+          if (col + k < a.cols_in) w[k >> 2] |= (uint32_t)p[k] << (8 * (k & 3));
+        v = make_uint4(w[0], w[1], w[2], w[3]);
+      }
+    }
+    tile[r][4 * s] = v.x; tile[r][4 * s + 1] = v.y; tile[r][4 * s + 2] = v.z; tile[r][4 * s + 3] = v.w;
+  }
+  __syncthreads();
+  constexpr int kBlk = kRotTile / 4;             // 4 x 4 blocks per tile side
+#pragma unroll
+  for (int q = 0; q < kBlk * kBlk / 256; q++) {
+    const int blk = t + 256 * q, br = blk % kBlk, bc = blk / kBlk;   // source rows 4 br .. +3, source columns 4 bc .. +3
+    const int j0 = R0 + 4 * br;                  // destination columns j0 .. j0 + 3 = source rows
+    if (j0 >= a.rows_in || C0 + 4 * bc >= a.cols_in) continue;
+    const uint32_t w0 = tile[4 * br][bc], w1 = tile[4 * br + 1][bc], w2 = tile[4 * br + 2][bc], w3 = tile[4 * br + 3][bc];
+    const uint32_t t0 = __builtin_amdgcn_perm(w1, w0, 0x05010400u), t1 = __builtin_amdgcn_perm(w1, w0, 0x07030602u);
+    const uint32_t t2 = __builtin_amdgcn_perm(w3, w2, 0x05010400u), t3 = __builtin_amdgcn_perm(w3, w2, 0x07030602u);
+    uint32_t colw[4];                            // colw[b] = source column 4 bc + b as {row0, row1, row2, row3}
+    colw[0] = __builtin_amdgcn_perm(t2, t0, 0x05040100u); colw[1] = __builtin_amdgcn_perm(t2, t0, 0x07060302u);
+    colw[2] = __builtin_amdgcn_perm(t3, t1, 0x05040100u); colw[3] = __builtin_amdgcn_perm(t3, t1, 0x07060302u);
+#pragma unroll
+    for (int b = 0; b < 4; b++) {
+      const int c = C0 + 4 * bc + b;             // source column -> destination row cols_in - 1 - c
+      if (c < a.cols_in) {
+        uint8_t* p = dst + (size_t)(a.cols_in - 1 - c) * a.stride_out + j0;
+        if (a.vec_out && j0 + 4 <= a.rows_in) {
+          *(uint32_t*)p = colw[b];
+        } else {
+#pragma unroll
+          for (int k = 0; k < 4; k++) if (j0 + k < a.rows_in) p[k] = (uint8_t)(colw[b] >> (8 * k));
+        }
+      }
+    }
+  }
+}
+
+// Narrow sources (cols <= 512: a radar sweep has 400 azimuths): the tile spans whole source rows, so the loads walk
+// 128 x cols contiguous bytes and every destination row receives 128 contiguous bytes -- full cache lines both ways.
+constexpr int kRotRows = 128;
+constexpr int kRotMaxCols = 512;
+
+__global__ __launch_bounds__(256) void rotate_ccw_rows_kernel(const RotArgs a) {
+  extern __shared__ uint32_t rtile[];            // [kRotRows][pitch]
+  const int t = threadIdx.x;
+  const int R0 = blockIdx.x * kRotRows;
+  const size_t img = (size_t)a.batch0 + blockIdx.y;
+  const uint8_t* src = a.src + img * (size_t)a.bs_in;
+  uint8_t* dst = a.dst + img * (size_t)a.bs_out;
+  const int ppr = (a.cols_in + 15) >> 4;         // 16-byte pieces per row
+  const int pitch = (ppr * 4) | 1;               // dwords, odd
+  const int rows_here = min(kRotRows, a.rows_in - R0);
+  for (int idx = t; idx < rows_here * ppr; idx += 256) {
+    const int r = idx / ppr, s = idx - r * ppr, col = 16 * s;
+    const uint8_t* p = src + (size_t)(R0 + r) * a.stride_in + col;
+    uint4 v;
+    if (a.vec_in && col + 16 <= a.cols_in) {
+      v = *(const uint4*)p;
+    } else {
+      uint32_t w[4] = {0, 0, 0, 0};
+#pragma unroll
+      for (int k = 0; k < 16; k++)
+        if (col + k < a.cols_in) w[k >> 2] |= (uint32_t)p[k] << (8 * (k & 3));
+      v = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+    uint32_t* o = rtile + (size_t)r * pitch + 4 * s;
+    o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
+  }
+  __syncthreads();
+  const int nbc = (a.cols_in + 3) >> 2;          // 4 x 4 blocks along the source columns
+  for (int blk = t; blk < (kRotRows / 4) * nbc; blk += 256) {
+    const int br = blk & (kRotRows / 4 - 1), bc = blk / (kRotRows / 4);
+    const int j0 = R0 + 4 * br;
+    if (j0 >= a.rows_in) continue;
+    const uint32_t* c0 = rtile + (size_t)(4 * br) * pitch + bc;
+    // rows beyond rows_here were never written: mask them instead of reading garbage into valid bytes
+    const uint32_t w0 = c0[0], w1 = (4 * br + 1 < rows_here) ? c0[pitch] : 0u;
+    const uint32_t w2 = (4 * br + 2 < rows_here) ? c0[2 * pitch] : 0u, w3 = (4 * br + 3 < rows_here) ? c0[3 * pitch] : 0u;
+    const uint32_t t0 = __builtin_amdgcn_perm(w1, w0, 0x05010400u), t1 = __builtin_amdgcn_perm(w1, w0, 0x07030602u);
+    const uint32_t t2 = __builtin_amdgcn_perm(w3, w2, 0x05010400u), t3 = __builtin_amdgcn_perm(w3, w2, 0x07030602u);
+    uint32_t colw[4];
+    colw[0] = __builtin_amdgcn_perm(t2, t0, 0x05040100u); colw[1] = __builtin_amdgcn_perm(t2, t0, 0x07060302u);
+    colw[2] = __builtin_amdgcn_perm(t3, t1, 0x05040100u); colw[3] = __builtin_amdgcn_perm(t3, t1, 0x07060302u);
+#pragma unroll
+    for (int b = 0; b < 4; b++) {
+      const int c = 4 * bc + b;
+      if (c < a.cols_in) {
+        uint8_t* p = dst + (size_t)(a.cols_in - 1 - c) * a.stride_out + j0;
+        if (a.vec_out && j0 + 4 <= a.rows_in) {
+          *(uint32_t*)p = colw[b];
+        } else {
+#pragma unroll
+          for (int k = 0; k < 4; k++) if (j0 + k < a.rows_in) p[k] = (uint8_t)(colw[b] >> (8 * k));
+        }
+      }
+    }
+  }
+}
+
+}  // namespace
+
+// src_desc describes the SOURCE images (rows = range bins, cols = azimuths); dst images are cols x rows.
+int cfear_rotate_ccw_device(cfear_ctx* ctx, const uint8_t* d_src, const cfear_polar_desc* sd, uint8_t* d_dst,
+                            int dst_stride, int64_t dst_batch_stride) {
+  RotArgs a;
+  a.src = d_src; a.dst = d_dst;
+  a.rows_in = sd->rows; a.cols_in = sd->cols; a.stride_in = sd->stride; a.stride_out = dst_stride;
+  a.bs_in = sd->batch > 1 ? sd->batch_stride : 0; a.bs_out = sd->batch > 1 ? dst_batch_stride : 0;
+  a.vec_in = ((uintptr_t)d_src % 16 == 0) && (sd->stride % 16 == 0) && (a.bs_in % 16 == 0);
+  a.vec_out = ((uintptr_t)d_dst % 4 == 0) && (dst_stride % 4 == 0) && (a.bs_out % 4 == 0);
+  ProfScope ps(ctx, "rotate_ccw");
+  if (sd->cols <= kRotMaxCols) {
+    const int ppr = (sd->cols + 15) >> 4;
+    const size_t lds = (size_t)kRotRows * ((ppr * 4) | 1) * 4;
+    CFEAR_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)rotate_ccw_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    for (int b0 = 0; b0 < sd->batch; b0 += 65535) {
+      a.batch0 = b0;
+      const dim3 grid((sd->rows + kRotRows - 1) / kRotRows, std::min(65535, sd->batch - b0));
+      hipLaunchKernelGGL(rotate_ccw_rows_kernel, grid, dim3(256), lds, ctx->stream, a);
+    }
+    CFEAR_HIP_CHECK(ctx, hipGetLastError());
+    return CFEAR_OK;
+  }
+  for (int b0 = 0; b0 < sd->batch; b0 += 65535) {
+    a.batch0 = b0;
+    const dim3 grid((sd->cols + kRotTile - 1) / kRotTile, (sd->rows + kRotTile - 1) / kRotTile, std::min(65535, sd->batch - b0));
+    hipLaunchKernelGGL(rotate_ccw_kernel, grid, dim3(256), 0, ctx->stream, a);
+  }
+  CFEAR_HIP_CHECK(ctx, hipGetLastError());
+  return CFEAR_OK;
+}
+
+extern "C" int cfear_polar_rotate_ccw(cfear_ctx* ctx, const uint8_t* src, const cfear_polar_desc* src_desc, uint8_t* dst,
+                                      int32_t dst_stride, int64_t dst_batch_stride) {
+  if (!ctx) return CFEAR_ERR_INVALID_ARGUMENT;
+  if (!src || !dst || !src_desc) return cfear_set_error(ctx, CFEAR_ERR_INVALID_ARGUMENT, "null argument");
+  const cfear_polar_desc& d = *src_desc;
+  if (d.rows <= 0 || d.cols <= 0 || d.stride < d.cols || d.batch <= 0 || dst_stride < d.rows ||
+      (d.batch > 1 && (d.batch_stride < (int64_t)d.rows * d.stride || dst_batch_stride < (int64_t)d.cols * dst_stride)))
+    return cfear_set_error(ctx, CFEAR_ERR_INVALID_ARGUMENT, "bad polar descriptor");
+  CFEAR_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  const bool dev = cfear_is_device_ptr(src);
+  if (dev != cfear_is_device_ptr(dst))
+    return cfear_set_error(ctx, CFEAR_ERR_INVALID_ARGUMENT, "src and dst must both be host or both be device memory");
+  if (dev) return cfear_rotate_ccw_device(ctx, src, src_desc, dst, dst_stride, dst_batch_stride);
+  // host images: stage densely, rotate, copy back row by row into the caller's pitch
+  const size_t in_bytes = (size_t)d.rows * d.stride;
+  const int ostride = (d.rows + 15) / 16 * 16;
+  const size_t out_bytes = (size_t)d.cols * ostride;
+  uint8_t* st = (uint8_t*)cfear_workspace(ctx, 0, in_bytes * d.batch);
+  uint8_t* ot = (uint8_t*)cfear_workspace(ctx, 1, out_bytes * d.batch);
+  if (!st || !ot) return cfear_set_error(ctx, CFEAR_ERR_HIP, "workspace allocation failed");
+  const int64_t bs = d.batch > 1 ? d.batch_stride : (int64_t)in_bytes;
+  for (int b = 0; b < d.batch; b++)
+    CFEAR_HIP_CHECK(ctx, hipMemcpyAsync(st + (size_t)b * in_bytes, src + (size_t)b * bs, in_bytes, hipMemcpyHostToDevice, ctx->stream));
+  cfear_polar_desc dd = d;
+  dd.batch_stride = (int64_t)in_bytes;
+  const int rc = cfear_rotate_ccw_device(ctx, st, &dd, ot, ostride, (int64_t)out_bytes);
+  if (rc != CFEAR_OK) return rc;
+  const int64_t obs = d.batch > 1 ? dst_batch_stride : 0;
+  for (int b = 0; b < d.batch; b++)
+    CFEAR_HIP_CHECK(ctx, hipMemcpy2DAsync(dst + (size_t)b * obs, dst_stride, ot + (size_t)b * out_bytes, ostride, d.rows, d.cols,
+                                          hipMemcpyDeviceToHost, ctx->stream));
+  CFEAR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  return CFEAR_OK;
+}

@@ -61,12 +61,14 @@ struct Stream {
 struct cfear_odometry {
   cfear_ctx* ctx = nullptr;
   int n_streams = 0;
-  cfear_polar_desc desc{};
+  cfear_polar_desc desc{};             // layout the filters see: rows = azimuths
+  cfear_polar_desc in_desc{};          // layout of the caller's images (differs when par.rotate_ccw)
   cfear_odometry_params par{};
   int cap_points = 0, cell_cap = 0, slabs_per_stream = 0;
   size_t slab_bytes = 0;
   // device memory (one allocation each)
   uint8_t* d_polar = nullptr;          // staging when the caller passes host images
+  uint8_t* d_rot = nullptr;            // rotated images (par.rotate_ccw)
   char* d_sel = nullptr;               // sel_range | sel_intensity | sel_count
   float* d_xyzi2[2] = {nullptr, nullptr};    // filter outputs are double-buffered: the next frame's filter
   int32_t* d_npts2[2] = {nullptr, nullptr};  //   may run while the host applies this frame's policy
@@ -124,7 +126,7 @@ extern "C" int cfear_odometry_destroy(cfear_odometry* od) {
   if (od->ev_results) (void)hipEventDestroy(od->ev_results);
   if (od->ev_jobs) (void)hipEventDestroy(od->ev_jobs);
   if (od->copy_stream) (void)hipStreamDestroy(od->copy_stream);
-  void* dev[] = {od->d_polar, od->d_sel, od->d_xyzi2[0], od->d_xyzi2[1], od->d_npts2[0], od->d_npts2[1], od->d_slabs, od->d_surf_jobs, od->d_reg_jobs,
+  void* dev[] = {od->d_polar, od->d_rot, od->d_sel, od->d_xyzi2[0], od->d_xyzi2[1], od->d_npts2[0], od->d_npts2[1], od->d_slabs, od->d_surf_jobs, od->d_reg_jobs,
                  od->d_results, od->d_status, od->d_ncells, od->d_surf_scratch, od->d_reg_scratch, od->d_samples};
   for (void* p : dev) if (p) (void)hipFree(p);
   void* host[] = {od->h_surf_jobs, od->h_reg_jobs, od->h_results, od->h_status, od->h_npts, od->h_ncells, od->h_samples};
@@ -146,8 +148,14 @@ extern "C" int cfear_odometry_create(cfear_ctx* ctx, int32_t n_streams, const cf
     return cfear_set_error(ctx, CFEAR_ERR_INVALID_ARGUMENT, "cov_sampling.samples_per_axis must be in [1,15]");
   CFEAR_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   cfear_odometry* od = new cfear_odometry();
-  od->ctx = ctx; od->n_streams = n_streams; od->desc = *desc; od->par = *par;
-  const int B = n_streams, rows = desc->rows, k = par->kstrong.k_strongest;
+  od->ctx = ctx; od->n_streams = n_streams; od->desc = *desc; od->in_desc = *desc; od->par = *par;
+  if (par->rotate_ccw) {               // radarDriver::Callback (radar_driver.cpp:74-90): [bins][azimuths] -> rows = azimuths
+    od->desc.rows = desc->cols;
+    od->desc.cols = desc->rows;
+    od->desc.stride = (desc->rows + 127) / 128 * 128;    // rows on 128-byte lines: the rotation then writes whole lines
+    od->desc.batch_stride = (int64_t)od->desc.rows * od->desc.stride;
+  }
+  const int B = n_streams, rows = od->desc.rows, k = par->kstrong.k_strongest;
   od->cap_points = par->filter_type == CFEAR_FILTER_CACFAR ? cfear_surface_max_points()
                                                            : std::min(rows * k, cfear_surface_max_points());
   od->cell_cap = 2048;
@@ -206,16 +214,24 @@ static int run_filter(cfear_odometry* od, const uint8_t* polar, int buf) {
   const int B = od->n_streams, rows = od->desc.rows, k = od->par.kstrong.k_strongest;
   const cfear_odometry_params& par = od->par;
   const uint8_t* d_polar = polar;
-  cfear_polar_desc dd = od->desc;
+  cfear_polar_desc dd = od->in_desc;
   if (!cfear_is_device_ptr(polar)) {
-    const size_t img_bytes = (size_t)rows * od->desc.stride;
+    const size_t img_bytes = (size_t)od->in_desc.rows * od->in_desc.stride;
     if (!od->d_polar && !dalloc(&od->d_polar, img_bytes * B)) return cfear_set_error(ctx, CFEAR_ERR_HIP, "staging allocation failed");
-    const int64_t bs = B > 1 ? od->desc.batch_stride : (int64_t)img_bytes;
+    const int64_t bs = B > 1 ? od->in_desc.batch_stride : (int64_t)img_bytes;
     for (int b = 0; b < B; b++)
       CFEAR_HIP_CHECK(ctx, hipMemcpyAsync(od->d_polar + (size_t)b * img_bytes, polar + (size_t)b * bs, img_bytes,
                                           hipMemcpyHostToDevice, ctx->stream));
     d_polar = od->d_polar;
     dd.batch_stride = (int64_t)img_bytes;
+  }
+  if (par.rotate_ccw) {
+    const size_t rot_bytes = (size_t)od->desc.rows * od->desc.stride;
+    if (!od->d_rot && !dalloc(&od->d_rot, rot_bytes * B)) return cfear_set_error(ctx, CFEAR_ERR_HIP, "rotation buffer allocation failed");
+    const int rc = cfear_rotate_ccw_device(ctx, d_polar, &dd, od->d_rot, od->desc.stride, (int64_t)rot_bytes);
+    if (rc != CFEAR_OK) return rc;
+    d_polar = od->d_rot;
+    dd = od->desc;
   }
   if (par.filter_type == CFEAR_FILTER_CACFAR) {
     cfear_cacfar_params cp = par.cacfar;

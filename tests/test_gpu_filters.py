@@ -190,3 +190,56 @@ def test_kstrongest_strided_and_unaligned_images(pad, offset):
     np.testing.assert_array_equal(sr, er)
     np.testing.assert_array_equal(si, ei)
     np.testing.assert_array_equal(sc, ec)
+
+
+@pytest.mark.parametrize("shape", [(3360, 400), (100, 37), (65, 64), (64, 130), (1, 1), (17, 1), (3, 3360, 400), (5, 70, 33)])
+def test_polar_rotate_ccw_matches_cv_rotate(shape):
+    """radarDriver::Callback's cv::rotate(ROTATE_90_COUNTERCLOCKWISE) (radar_driver.cpp:74-90) == np.rot90(img, 1):
+    bit-exact for full, ragged and tiny tiles, single images and batches, host and device memory."""
+    import torch
+    from tbv_slam_public_amd import api
+    rng = np.random.default_rng(sum(shape))
+    img = rng.integers(0, 256, size=shape, dtype=np.uint8)
+    exp = np.rot90(img, 1, axes=(-2, -1))
+    np.testing.assert_array_equal(api.polar_rotate_ccw(img), exp)
+    got = api.polar_rotate_ccw(torch.from_numpy(img).cuda())
+    np.testing.assert_array_equal(got.cpu().numpy(), exp)
+
+
+def test_polar_rotate_ccw_strided_views_and_errors():
+    """Unaligned device views take the byte path; mixed host/device and bad descriptors are refused."""
+    import ctypes as C
+    import torch
+    from tbv_slam_public_amd import api, _lib as L
+    ctx = api.default_context()
+    rng = np.random.default_rng(3)
+    big = torch.from_numpy(rng.integers(0, 256, size=(2, 90, 77), dtype=np.uint8)).cuda()
+    flat = big.reshape(-1)
+    d = L.PolarDesc()
+    d.rows, d.cols, d.stride, d.batch, d.batch_stride = 88, 70, 77, 2, 90 * 77           # interior window, offset 3
+    out = torch.zeros((2, 70, 91), dtype=torch.uint8, device="cuda")                      # pitch 91 > 88
+    ctx.check(ctx._lib.cfear_polar_rotate_ccw(ctx.h, flat.data_ptr() + 3, C.byref(d), out.data_ptr(), 91, 70 * 91))
+    ctx.synchronize()
+    src = flat.cpu().numpy()
+    for b in range(2):
+        win = np.stack([src[b * 90 * 77 + 3 + r * 77: b * 90 * 77 + 3 + r * 77 + 70] for r in range(88)])
+        np.testing.assert_array_equal(out[b, :, :88].cpu().numpy(), np.rot90(win, 1))
+        assert (out[b, :, 88:] == 0).all()                                                # pitch padding untouched
+    host = np.zeros((70, 88), np.uint8)
+    assert ctx._lib.cfear_polar_rotate_ccw(ctx.h, flat.data_ptr(), C.byref(d), host.ctypes.data, 88, 70 * 88) == L.ERR_INVALID_ARGUMENT
+    d.stride = 60
+    assert ctx._lib.cfear_polar_rotate_ccw(ctx.h, flat.data_ptr(), C.byref(d), out.data_ptr(), 91, 70 * 91) == L.ERR_INVALID_ARGUMENT
+
+
+def test_radar_driver_mirror_non_oxford_layout():
+    """dataset != oxford: the driver receives [range bins][azimuths] and rotates first (Callback, radar_driver.cpp:74-90)."""
+    from tbv_slam_public_amd import api, synth
+    imgs, _, _ = synth.scene_v1(7, 1)
+    sent = np.ascontiguousarray(np.rot90(imgs[0], -1))               # what a MulRan-style driver publishes: 3360 x 400
+    assert sent.shape == (3360, 400)
+    drv = api.radarDriver(api.radarDriverParameters(k_strongest=12, z_min=60, range_res=0.0595238, dataset="mulran"))
+    cloud, peaks = drv.CallbackOffline(sent)
+    np.testing.assert_array_equal(drv.cv_polar_image, imgs[0])
+    sr, si, sc, pk, oc, op = _oracle_kstrong(imgs[0], 12, 60, 0.0595238, 2.5)
+    np.testing.assert_array_equal(cloud, oc)
+    np.testing.assert_array_equal(peaks, op)
