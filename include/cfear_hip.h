@@ -457,6 +457,19 @@ typedef struct cfear_odometry_params {
   cfear_cov_sampling_params cov_sampling;   /* cov_sampling_* (:107-110) */
 } cfear_odometry_params;
 void cfear_odometry_params_default(cfear_odometry_params* p);   /* CFEAR-3 preset, Oxford */
+/* The reference's shipped configurations (cfear_radarodometry/launch/oxford/eval/params/baseline/oxford_cfear-{1,2,3,
+ * 3-s10}:13-26) and sensor setups (tbv_slam/script/{oxford,mulran,kvarntorp,volvo}/run_tbv_simple.sh):
+ *   CFEAR-1      P2L, 1 keyframe,  res 3.5, k 12, Huber 0.1, weight option 4, no intensity weights
+ *   CFEAR-2      P2L, 3 keyframes, res 3.5, k 12, Huber 0.1
+ *   CFEAR-3      P2P, 4 keyframes, res 3,   k 40, Huber 0.1, intensity weights (TBV's default)
+ *   CFEAR-3-s10  P2P, 10 keyframes, res 3,  k 40, Cauchy 0.1, regularization 0.1
+ *   Oxford       range_res 0.0438,    clockwise sweep,         rows = azimuths
+ *   MulRan       range_res 0.0595238, counter-clockwise sweep, [range bins][azimuths] images (rotate_ccw)
+ *   Kvarntorp / Volvo  range_res 0.175, counter-clockwise,     [range bins][azimuths] images
+ * Everything else as cfear_odometry_params_default.  Returns CFEAR_ERR_INVALID_ARGUMENT for unknown ids.        */
+enum cfear_preset { CFEAR_PRESET_CFEAR1 = 1, CFEAR_PRESET_CFEAR2 = 2, CFEAR_PRESET_CFEAR3 = 3, CFEAR_PRESET_CFEAR3_S10 = 4 };
+enum cfear_dataset { CFEAR_DATASET_OXFORD = 0, CFEAR_DATASET_MULRAN = 1, CFEAR_DATASET_KVARNTORP = 2, CFEAR_DATASET_VOLVO = 3 };
+int cfear_odometry_params_preset(cfear_odometry_params* p, int preset, int dataset);
 
 typedef struct cfear_odometry cfear_odometry;
 typedef struct cfear_frame_info {

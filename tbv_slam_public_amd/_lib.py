@@ -187,7 +187,7 @@ EXPORTS = [
     "cfear_polar_rotate_ccw", "cfear_verify_params_default", "cfear_verify_loop_candidates", "cfear_verify_by_odometry",
     "cfear_cost_prepare", "cfear_cost_num_blocks", "cfear_cost_num_residuals", "cfear_cost_get_blocks",
     "cfear_cost_evaluate", "cfear_cost_normal_eq", "cfear_cost_destroy",
-    "cfear_odometry_params_default", "cfear_odometry_create", "cfear_odometry_process",
+    "cfear_odometry_params_default", "cfear_odometry_params_preset", "cfear_odometry_create", "cfear_odometry_process",
     "cfear_odometry_process_prefetch", "cfear_odometry_get_covariance", "cfear_odometry_destroy",
 ]
 
@@ -273,6 +273,7 @@ def lib():
     L.cfear_cost_destroy.argtypes = [vp]
     L.cfear_odometry_params_default.argtypes = [C.POINTER(OdometryParams)]
     L.cfear_odometry_params_default.restype = None
+    L.cfear_odometry_params_preset.argtypes = [C.POINTER(OdometryParams), C.c_int32, C.c_int32]
     L.cfear_odometry_create.argtypes = [vp, C.c_int32, C.POINTER(PolarDesc), C.POINTER(OdometryParams),
                                         C.POINTER(vp)]
     L.cfear_odometry_process.argtypes = [vp, vp, vp]

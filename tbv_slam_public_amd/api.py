@@ -984,6 +984,10 @@ def odometry_params(**kw):
     (nested: kstrong_k_strongest, cacfar_window_size, reg_cost, cov_sampling_xy_range, ...)."""
     p = L.OdometryParams()
     L.lib().cfear_odometry_params_default(C.byref(p))
+    return _override_odometry_params(p, kw)
+
+
+def _override_odometry_params(p, kw):
     for k, v in kw.items():
         for prefix, sub in (("kstrong_", p.kstrong), ("cacfar_", p.cacfar), ("reg_", p.reg),
                             ("cov_sampling_", p.cov_sampling)):
@@ -995,6 +999,21 @@ def odometry_params(**kw):
                 raise KeyError(k)
             setattr(p, k, v)
     return p
+
+
+PRESETS = {"CFEAR-1": 1, "CFEAR-2": 2, "CFEAR-3": 3, "CFEAR-3-s10": 4}
+DATASETS = {"oxford": 0, "mulran": 1, "kvarntorp": 2, "volvo": 3}
+
+
+def odometry_preset(preset="CFEAR-3", dataset="oxford", **kw):
+    """cfear_odometry_params of one of the reference's shipped configurations (launch/oxford/eval/params/baseline/
+    oxford_cfear-{1,2,3,3-s10}) on one of its sensor setups (tbv_slam/script/*/run_tbv_simple.sh); keyword overrides
+    as in odometry_params.  Non-Oxford datasets expect [range bins][azimuths] images (rotate_ccw)."""
+    p = L.OdometryParams()
+    rc = L.lib().cfear_odometry_params_preset(C.byref(p), PRESETS[preset], DATASETS[dataset.lower()])
+    if rc != L.OK:
+        raise L.CfearError(rc, "unknown preset / dataset")
+    return _override_odometry_params(p, kw)
 
 
 class OdometryKeyframeFuser:

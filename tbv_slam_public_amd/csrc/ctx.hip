@@ -306,6 +306,42 @@ void cfear_odometry_params_default(cfear_odometry_params* p) {
   cfear_cov_sampling_params_default(&p->cov_sampling);
 }
 
+int cfear_odometry_params_preset(cfear_odometry_params* p, int preset, int dataset) {
+  if (!p) return CFEAR_ERR_INVALID_ARGUMENT;
+  cfear_odometry_params_default(p);
+  switch (preset) {                       // launch/oxford/eval/params/baseline/oxford_cfear-*:13-26
+    case CFEAR_PRESET_CFEAR1:
+    case CFEAR_PRESET_CFEAR2:
+      p->reg.cost = CFEAR_P2L;
+      p->submap_scan_size = preset == CFEAR_PRESET_CFEAR1 ? 1 : 3;
+      p->res = 3.5f;
+      p->kstrong.k_strongest = 12;
+      p->weight_intensity = 0;
+      break;
+    case CFEAR_PRESET_CFEAR3:
+      break;
+    case CFEAR_PRESET_CFEAR3_S10:
+      p->submap_scan_size = 10;
+      p->reg.loss = CFEAR_LOSS_CAUCHY;
+      p->reg.regularization = 0.1;
+      break;
+    default:
+      return CFEAR_ERR_INVALID_ARGUMENT;
+  }
+  float range_res;
+  switch (dataset) {                      // tbv_slam/script/*/run_tbv_simple.sh (range_res, radar_ccw, dataset)
+    case CFEAR_DATASET_OXFORD: range_res = 0.0438f; p->radar_ccw = 0; p->rotate_ccw = 0; break;
+    case CFEAR_DATASET_MULRAN: range_res = 0.0595238f; p->radar_ccw = 1; p->rotate_ccw = 1; break;
+    case CFEAR_DATASET_KVARNTORP:
+    case CFEAR_DATASET_VOLVO: range_res = 0.175f; p->radar_ccw = 1; p->rotate_ccw = 1; break;
+    default:
+      return CFEAR_ERR_INVALID_ARGUMENT;
+  }
+  p->kstrong.range_res = range_res;
+  p->cacfar.range_res = range_res;
+  return CFEAR_OK;
+}
+
 int cfear_scan_size(const cfear_scan* scan) {
   if (!scan) return CFEAR_ERR_INVALID_ARGUMENT;
   cfear_scan* s = const_cast<cfear_scan*>(scan);

@@ -66,3 +66,29 @@ def test_no_gpu_fails_loudly():
     from tbv_slam_public_amd import api
     with pytest.raises(L.CfearError):
         api.Context(0)
+
+
+def test_presets_follow_the_reference_launch_files():
+    """cfear_odometry_params_preset is pure host code: the shipped CFEAR-1/2/3/3-s10 configurations
+    (cfear_radarodometry/launch/oxford/eval/params/baseline/oxford_cfear-*:13-26) on the four sensor setups
+    (tbv_slam/script/*/run_tbv_simple.sh)."""
+    from tbv_slam_public_amd import api
+    want = {"CFEAR-1": (L.COST["P2L"], 1, 3.5, 12, L.LOSS["Huber"], 0, 0.0),
+            "CFEAR-2": (L.COST["P2L"], 3, 3.5, 12, L.LOSS["Huber"], 0, 0.0),
+            "CFEAR-3": (L.COST["P2P"], 4, 3.0, 40, L.LOSS["Huber"], 1, 0.0),
+            "CFEAR-3-s10": (L.COST["P2P"], 10, 3.0, 40, L.LOSS["Cauchy"], 1, 0.1)}
+    for name, (cost, s, res, k, loss, wi, regu) in want.items():
+        p = api.odometry_preset(name)
+        assert (p.reg.cost, p.submap_scan_size, p.res, p.kstrong.k_strongest, p.reg.loss, p.weight_intensity) == (cost, s, res, k, loss, wi)
+        assert p.reg.regularization == regu and p.reg.loss_limit == 0.1 and p.reg.weight_opt == 4 and p.kstrong.z_min == 60.0
+        assert p.min_keyframe_dist == 1.5 and p.min_keyframe_rot_deg == 5.0 and p.compensate == 1 and p.use_guess == 1
+    for ds, (rr, ccw, rot) in {"oxford": (0.0438, 0, 0), "Mulran": (0.0595238, 1, 1), "kvarntorp": (0.175, 1, 1), "Volvo": (0.175, 1, 1)}.items():
+        p = api.odometry_preset("CFEAR-3", ds)
+        assert abs(p.kstrong.range_res - rr) < 1e-7 and p.cacfar.range_res == p.kstrong.range_res
+        assert (p.radar_ccw, p.rotate_ccw) == (ccw, rot)
+    same = api.odometry_params()
+    assert bytes(api.odometry_preset("CFEAR-3", "oxford")) == bytes(same)
+    assert api.odometry_preset("CFEAR-2", submap_scan_size=2).submap_scan_size == 2
+    p = L.OdometryParams()
+    assert L.lib().cfear_odometry_params_preset(C.byref(p), 9, 0) == L.ERR_INVALID_ARGUMENT
+    assert L.lib().cfear_odometry_params_preset(C.byref(p), 1, 7) == L.ERR_INVALID_ARGUMENT

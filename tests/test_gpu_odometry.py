@@ -117,3 +117,18 @@ def test_rotated_input_layout_equals_prerotated(device_input):
         for name in a.dtype.names:
             np.testing.assert_array_equal(a[name], b[name], err_msg=name)
     assert (a["reg_status"] == 0).all() and a["n_cells"].min() > 100
+
+
+def test_cfear3_s10_preset_cauchy_window10():
+    """CFEAR-3-s10 (launch/oxford/eval/params/baseline/oxford_cfear-3-s10): 10-keyframe window, Cauchy loss; 13 frames
+    so that registrations against the full 10 + 1 scan window are exercised."""
+    from tbv_slam_public_amd import api
+    p = api.odometry_preset("CFEAR-3-s10")
+    assert p.submap_scan_size == 10 and p.reg.loss == 2
+    od = _run([5], 13, False, par=dict(submap_scan_size=10, reg_loss=2, reg_regularization=0.1))
+    od.close()
+
+
+def test_cfear2_preset_p2l_window3():
+    """CFEAR-2: P2L, 3 keyframes, res 3.5, k = 12, no intensity weights."""
+    _run([6], 7, True, par=dict(reg_cost=1, submap_scan_size=3, res=3.5, kstrong_k_strongest=12, weight_intensity=0))
