@@ -14,6 +14,12 @@ make -C oracle -s
 # 1. kernel trace + stats of the bench command
 ( cd /tmp && rocprofv3 --output-format csv --kernel-trace --stats -d "$OUT/bench" -o bench -- python "$ROOT/bench.py" --no-cpu-baseline --steps 10 > "$SUM/bench_stdout.json" 2> "$OUT/bench.err" )
 find "$OUT/bench" -name "*kernel_stats.csv" -exec cp {} "$SUM/bench_kernel_stats.csv" \;
+# 1b. the neighbouring workloads: candidate verification (register + coral + cost-only) and the bins-major
+#     input layout (adds rotate_ccw_rows_kernel)
+( cd /tmp && rocprofv3 --output-format csv --kernel-trace --stats -d "$OUT/verify" -o v -- python "$ROOT/bench.py" --workload verify --steps 5 --warmup 2 > "$SUM/verify_stdout.json" 2> "$OUT/verify.err" )
+find "$OUT/verify" -name "*kernel_stats.csv" -exec cp {} "$SUM/verify_kernel_stats.csv" \;
+( cd /tmp && rocprofv3 --output-format csv --kernel-trace --stats -d "$OUT/binsmajor" -o b -- python "$ROOT/bench.py" --no-cpu-baseline --bins-major --steps 5 > "$SUM/bins_major_stdout.json" 2> "$OUT/binsmajor.err" )
+find "$OUT/binsmajor" -name "*kernel_stats.csv" -exec cp {} "$SUM/bins_major_kernel_stats.csv" \;
 # 2. polar sweep alone: kernel trace, then PMC passes (FETCH_SIZE and WRITE_SIZE do not fit one pass)
 for DATA in scene uniform; do
   ( cd /tmp && rocprofv3 --output-format csv --kernel-trace --stats -d "$OUT/filter_$DATA" -o f -- python "$ROOT/tools/bench_filter.py" --data $DATA > "$SUM/filter_${DATA}_stdout.txt" 2> "$OUT/filter_$DATA.err" )
