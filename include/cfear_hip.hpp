@@ -48,10 +48,21 @@ class radarDriver {
     float z_min = 60; float range_res = 0.0438f; int azimuths = 400, k_strongest = 12;
     int nb_guard_cells = 20, window_size = 10; float false_alarm_rate = 0.01f;
     float min_distance = 2.5f, max_distance = 200; filtertype filter_type_ = kstrong;
+    std::string dataset = "oxford";                        // anything else: images arrive as [range bins][azimuths]
   };
   radarDriver(Context& ctx, const Parameters& pars) : ctx_(ctx), par(pars) {}
-  // image: row-major uint8, rows = azimuth (Oxford layout, radar_driver.cpp:99-111)
+  // image: row-major uint8; rows = azimuth for dataset "oxford" (CallbackOxford, radar_driver.cpp:99-111), otherwise
+  // rows = range bins and the image is rotated 90 degrees counter-clockwise first (Callback, :74-90)
+  std::vector<uint8_t> cv_polar_image;                     // the image the filters saw (non-Oxford: rotated copy)
   void CallbackOffline(const uint8_t* image, int rows, int cols, int stride, PointCloud& cloud, PointCloud& cloud_peaks) {
+    if (par.dataset != "oxford") {
+      cv_polar_image.resize((size_t)rows * cols);
+      cfear_polar_desc s{rows, cols, stride, 1, 0};
+      ctx_.check(cfear_polar_rotate_ccw(ctx_.get(), image, &s, cv_polar_image.data(), rows, 0));
+      image = cv_polar_image.data();
+      std::swap(rows, cols);
+      stride = cols;
+    }
     cfear_polar_desc d{rows, cols, stride, 1, 0};
     int32_t n = 0, n_pk = 0;
     if (par.filter_type_ == CACFAR) {                      // radar_driver.cpp:52-56
@@ -202,6 +213,51 @@ class CorAlRadarQuality {
   cfear_coral_result res_{};
 };
 }  // namespace CorAlignment
+
+// Loop-candidate verification of tbv_slam::loopclosure (tbv_slam/src/tbv_slam/loopclosure.cpp:320-384, 261-274,
+// 776-808) for a batch of candidates.
+namespace tbv_slam {
+struct LoopCandidate {
+  const CFEAR_Radarodometry::MapPointNormal* from;         // (*graph_)[from].cloud_normal_
+  const CFEAR_Radarodometry::MapPointNormal* to;
+  const CFEAR_Radarodometry::PointCloud* from_peaks;       // (*graph_)[from].cloud_peaks_
+  const CFEAR_Radarodometry::PointCloud* to_peaks;
+  CFEAR_Radarodometry::Pose2d Tfrom;                       // (*graph_)[from].GetPose()
+  CFEAR_Radarodometry::Pose2d t_be_guess;                  // constraint.t_be on entry
+  double sc_sim, odom_bounds;                              // quality["sc-sim"], quality["odom-bounds"]
+  int query;                                               // candidates of one query node are selected together
+};
+inline double VerifyByOdometry(const std::vector<CFEAR_Radarodometry::Pose2d>& relative_motions, double odom_sigma_error = 0.03,
+                               bool verify_via_odometry = true) {
+  double sim = 0.0;
+  static_assert(sizeof(CFEAR_Radarodometry::Pose2d) == 3 * sizeof(double), "Pose2d must be three packed doubles");
+  const int rc = cfear_verify_by_odometry(relative_motions.empty() ? nullptr : &relative_motions[0].x,
+                                          (int32_t)relative_motions.size(), odom_sigma_error, verify_via_odometry ? 1 : 0, &sim);
+  if (rc != CFEAR_OK) throw CFEAR_Radarodometry::CfearError(rc, cfear_status_string(rc));
+  return sim;
+}
+inline std::vector<cfear_verify_result> VerifyLoopCandidates(CFEAR_Radarodometry::Context& ctx,
+                                                              const std::vector<LoopCandidate>& cands,
+                                                              const cfear_verify_params* par = nullptr) {
+  cfear_verify_params def;
+  if (!par) { cfear_verify_params_default(&def); par = &def; }
+  std::vector<cfear_verify_job> jobs(cands.size());
+  for (size_t i = 0; i < cands.size(); i++) {
+    const LoopCandidate& c = cands[i];
+    cfear_verify_job& j = jobs[i];
+    j = cfear_verify_job{};
+    j.from_scan = c.from->device(); j.to_scan = c.to->device();
+    j.from_peaks = c.from_peaks->empty() ? nullptr : &(*c.from_peaks)[0].x; j.n_from = (int32_t)c.from_peaks->size();
+    j.to_peaks = c.to_peaks->empty() ? nullptr : &(*c.to_peaks)[0].x; j.n_to = (int32_t)c.to_peaks->size();
+    j.from_pose[0] = c.Tfrom.x; j.from_pose[1] = c.Tfrom.y; j.from_pose[2] = c.Tfrom.theta;
+    j.t_be_guess[0] = c.t_be_guess.x; j.t_be_guess[1] = c.t_be_guess.y; j.t_be_guess[2] = c.t_be_guess.theta;
+    j.sc_sim = c.sc_sim; j.odom_bounds = c.odom_bounds; j.group = c.query;
+  }
+  std::vector<cfear_verify_result> res(cands.size());
+  ctx.check(cfear_verify_loop_candidates(ctx.get(), jobs.data(), (int32_t)jobs.size(), par, res.data()));
+  return res;
+}
+}  // namespace tbv_slam
 
 #if defined(__has_include)
 #if __has_include(<Eigen/Geometry>)

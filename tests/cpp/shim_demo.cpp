@@ -2,9 +2,13 @@
 // (include/cfear_hip.hpp).  Reads a raw uint8 polar image pair [2][rows][cols] from argv[1], registers
 // frame 1 against frame 0 (P2L, loop-closure settings 4 x 10) and prints the result as one line:
 //   n_points0 n_points1 n_cells0 n_cells1 ok x y theta score cov_ok cov_xx cov_yy cov_tt coral_valid joint sep overlap
-// (the last four: covariance by cost sampling with the loop-closure constants, loopclosure.cpp:108-112)
+//   reg_ok t_be.x t_be.y t_be.theta alignment_quality probability accepted odom_bounds
+// (cov_*: covariance by cost sampling with the loop-closure constants, loopclosure.cpp:108-112; the last eight: the
+// pair verified as a loop candidate, frame 1 = query, frame 0 = candidate, through tbv_slam::VerifyLoopCandidates).
+// With a fifth argument "bins-major" the file holds [2][cols][rows] images as a non-Oxford driver publishes them.
 #include <cstdio>
 #include <cstdlib>
+#include <string>
 #include <vector>
 
 #include "cfear_hip.hpp"
@@ -22,11 +26,18 @@ int main(int argc, char** argv) {
     Context ctx(0);
     radarDriver::Parameters p;
     p.k_strongest = 40;
+    const bool bins_major = argc > 4 && std::string(argv[4]) == "bins-major";
+    if (bins_major) p.dataset = "mulran";
     radarDriver driver(ctx, p);
     PointCloud c0, c1;
     PointCloud pk0, pk1;
-    driver.CallbackOffline(img.data(), rows, cols, cols, c0, pk0);
-    driver.CallbackOffline(img.data() + (size_t)rows * cols, rows, cols, cols, c1, pk1);
+    if (bins_major) {                                       // the file's images are cols x rows
+      driver.CallbackOffline(img.data(), cols, rows, rows, c0, pk0);
+      driver.CallbackOffline(img.data() + (size_t)rows * cols, cols, rows, rows, c1, pk1);
+    } else {
+      driver.CallbackOffline(img.data(), rows, cols, cols, c0, pk0);
+      driver.CallbackOffline(img.data() + (size_t)rows * cols, rows, cols, cols, c1, pk1);
+    }
     MapPointNormal m0(ctx, c0, 3.0f, 0, 0, true), m1(ctx, c1, 3.0f, 0, 0, true);
     n_scan_normal_reg reg(ctx, CFEAR_P2L);
     reg.SetParameters(4, 10);
@@ -40,9 +51,15 @@ int main(int argc, char** argv) {
     // loop-closure verification feature: CorAl quality of the two peak clouds at the registered pose
     CorAlignment::CorAlRadarQuality coral(ctx, pk0, T[0], pk1, T[1]);
     const std::vector<double> q = coral.GetQualityMeasure();
-    printf("%zu %zu %zu %zu %d %.12g %.12g %.12g %.12g %d %.12g %.12g %.12g %d %.12g %.12g %.12g\n", c0.size(), c1.size(),
+    printf("%zu %zu %zu %zu %d %.12g %.12g %.12g %.12g %d %.12g %.12g %.12g %d %.12g %.12g %.12g", c0.size(), c1.size(),
            m0.GetSize(), m1.GetSize(), ok ? 1 : 0, T[1].x, T[1].y, T[1].theta, reg.getScore(), cov_ok ? 1 : 0, cov[0], cov[7],
            cov[35], coral.valid_ ? 1 : 0, q[0], q[1], q[2]);
+    // the same pair as a loop-closure candidate: query = frame 1 at pose (2.2, 0.1, 0.01), guess for frame 0 relative to it
+    const double odom_bounds = tbv_slam::VerifyByOdometry({{1.0, 0.0, 0.0}, {1.2, 0.1, 0.01}});
+    tbv_slam::LoopCandidate cand{&m1, &m0, &pk1, &pk0, {2.2, 0.1, 0.01}, {-2.0, 0.2, -0.02}, 0.15, odom_bounds, 0};
+    const std::vector<cfear_verify_result> vr = tbv_slam::VerifyLoopCandidates(ctx, {cand});
+    printf(" %d %.12g %.12g %.12g %.12g %.12g %d %.12g\n", vr[0].reg_ok, vr[0].t_be[0], vr[0].t_be[1], vr[0].t_be[2],
+           vr[0].alignment_quality, vr[0].probability, vr[0].accepted, odom_bounds);
   } catch (const CfearError& e) {
     fprintf(stderr, "cfear error %d: %s\n", e.status, e.what());
     return 1;
