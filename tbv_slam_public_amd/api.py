@@ -873,7 +873,7 @@ class RSCManager:
 
     def __init__(self, par=None, num_candidates_from_tree=10, n_candidates=3, odom_sigma_error=0.05,
                  odometry_coupled_closure=True, augment_sc=True, ctx=None):
-        self.ctx = ctx or default_context()
+        self.ctx = ctx
         self.par = par or sc_params()
         self.NUM_CANDIDATES_FROM_TREE = int(num_candidates_from_tree)
         self.N_candidates = int(n_candidates)
@@ -887,10 +887,17 @@ class RSCManager:
         self.NUM_EXCLUDE_RECENT = 0
         self.current_and_augments_ = []               # (desc, ring key float32, (tx, ty, theta) of the augmentation)
 
+    # the two device operations (tests substitute the CPU oracle here to check the host policy around them)
+    def _descriptors(self, clouds, shifts):
+        return sc_descriptors(clouds, self.par, shifts, self.ctx)
+
+    def _distances(self, desc_q, desc_c, pairs):
+        return sc_distance_batch(desc_q, desc_c, pairs, self.par, self.ctx)
+
     def makeAndSaveScancontextAndKeysRadarCloud(self, cloud, Todom):
         """RadarScancontext.cpp:156-180 (+ :133-146, :181-225)."""
         shifts = (0.0,) + (self.AUGMENTS_Y if self.augment_sc else ())
-        desc, rk, _ = sc_descriptors([cloud], self.par, shifts, self.ctx)
+        desc, rk, _ = self._descriptors([cloud], shifts)
         self.polarcontexts_.append(desc[0, 0].copy())
         self.polarcontext_invkeys_mat_.append(rk[0, 0].astype(np.float32))
         self.current_and_augments_ = [(desc[0, k].copy(), rk[0, k].astype(np.float32), (0.0, float(shifts[k]), 0.0))
@@ -964,7 +971,7 @@ class RSCManager:
         uniq = sorted({i for _, i in jobs})
         pos = {i: p for p, i in enumerate(uniq)}
         cd = np.stack([self.polarcontexts_[i] for i in uniq])
-        dist, shift = sc_distance_batch(qd, cd, [(k, pos[i]) for k, i in jobs], self.par, self.ctx)
+        dist, shift = self._distances(qd, cd, [(k, pos[i]) for k, i in jobs])
         unit = 360.0 / float(self.par.num_sector)
         similar = []
         for (k, i), d_sc, sh in zip(jobs, dist, shift):
