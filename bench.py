@@ -236,6 +236,7 @@ def main():
     ctx = api.Context(local_rank, stream=stream)
     if args.bins_major:
         frames = torch.rot90(frames, -1, dims=(2, 3)).contiguous()   # [F][B][COLS][ROWS]: what such a driver publishes
+        torch.cuda.synchronize()                                     # the library enqueues on its own stream
     od = api.OdometryKeyframeFuser(B, *frames.shape[2:], api.odometry_params(estimate_cov_by_sampling=int(args.cov_sampling),
                                                                              rotate_ccw=int(args.bins_major)), ctx=ctx)
 
