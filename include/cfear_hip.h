@@ -367,7 +367,9 @@ typedef struct cfear_sc_cloud {
 } cfear_sc_cloud;
 /* MakeRadarCloudContext for n_clouds clouds x n_aug lateral shifts (shifts_y[0] is normally 0; TBV augments
  * with {-2, 2, -4, 4}).  desc [n_clouds][n_aug][num_ring * num_sector] row-major (ring, sector); ringkey
- * [..][num_ring] and sectorkey [..][num_sector] optional.  All outputs host.                           */
+ * [..][num_ring] and sectorkey [..][num_sector] optional.  desc may be HOST or DEVICE memory (a descriptor
+ * database kept in HBM feeds cfear_sc_distance_batch without crossing PCIe); the keys are host arrays -- the
+ * retrieval policy that consumes them runs on the host.                                                */
 int cfear_sc_descriptors(cfear_ctx* ctx, const cfear_sc_cloud* clouds, int32_t n_clouds,
                          const cfear_sc_params* par, const double* shifts_y, int32_t n_aug, double* desc,
                          double* ringkey, double* sectorkey);

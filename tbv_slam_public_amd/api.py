@@ -824,9 +824,10 @@ def sc_params(**kw):
     return p
 
 
-def sc_descriptors(clouds, par=None, shifts_y=(0.0,), ctx=None):
+def sc_descriptors(clouds, par=None, shifts_y=(0.0,), ctx=None, device_out=False):
     """MakeRadarCloudContext (RadarScancontext.cpp:59-131) for a list of clouds and lateral shifts.
-    -> (desc [n, A, R, S], ringkey [n, A, R], sectorkey [n, A, S])."""
+    -> (desc [n, A, R, S], ringkey [n, A, R], sectorkey [n, A, S]); with device_out the descriptors stay in HBM
+    (torch CUDA float64 tensor, accepted by sc_distance_batch) and only the keys come back to the host."""
     ctx = ctx or default_context()
     par = par or sc_params()
     n, A = len(clouds), len(shifts_y)
@@ -837,11 +838,15 @@ def sc_descriptors(clouds, par=None, shifts_y=(0.0,), ctx=None):
         keep.append(k)
         arr[i].xyzi, arr[i].n = ptr, m
     R, S = par.num_ring, par.num_sector
-    desc = np.zeros((n, A, R, S), np.float64)
+    if device_out:
+        import torch
+        desc = torch.zeros((n, A, R, S), dtype=torch.float64, device="cuda:%d" % ctx.device)
+    else:
+        desc = np.zeros((n, A, R, S), np.float64)
     rk = np.zeros((n, A, R), np.float64)
     sk = np.zeros((n, A, S), np.float64)
     sh = (C.c_double * A)(*[float(v) for v in shifts_y])
-    ctx.check(ctx._lib.cfear_sc_descriptors(ctx.h, arr, n, C.byref(par), sh, A, desc.ctypes.data, rk.ctypes.data,
+    ctx.check(ctx._lib.cfear_sc_descriptors(ctx.h, arr, n, C.byref(par), sh, A, _ptr(desc)[0], rk.ctypes.data,
                                             sk.ctypes.data))
     return desc, rk, sk
 
@@ -851,13 +856,13 @@ def sc_distance_batch(desc_q, desc_c, pairs, par=None, ctx=None):
     desc_q [nq, R, S], desc_c [nc, R, S] float64 -> (dist [n_pairs], argmin_shift [n_pairs])."""
     ctx = ctx or default_context()
     par = par or sc_params()
-    q = np.ascontiguousarray(desc_q, dtype=np.float64)
-    c = np.ascontiguousarray(desc_c, dtype=np.float64)
+    q = desc_q.contiguous() if _is_torch(desc_q) else np.ascontiguousarray(desc_q, dtype=np.float64)
+    c = desc_c.contiguous() if _is_torch(desc_c) else np.ascontiguousarray(desc_c, dtype=np.float64)
     pr = np.ascontiguousarray(pairs, dtype=np.int32).reshape(-1, 2)
     dist = np.zeros(pr.shape[0], np.float64)
     shift = np.zeros(pr.shape[0], np.int32)
     if pr.shape[0]:
-        ctx.check(ctx._lib.cfear_sc_distance_batch(ctx.h, q.ctypes.data, q.shape[0], c.ctypes.data, c.shape[0],
+        ctx.check(ctx._lib.cfear_sc_distance_batch(ctx.h, _ptr(q)[0], q.shape[0], _ptr(c)[0], c.shape[0],
                                                    pr.ctypes.data, pr.shape[0], C.byref(par), dist.ctypes.data,
                                                    shift.ctypes.data))
     return dist, shift
@@ -880,7 +885,7 @@ class RSCManager:
         self.odom_sigma_error = float(odom_sigma_error)
         self.odometry_coupled_closure = bool(odometry_coupled_closure)
         self.augment_sc = bool(augment_sc)
-        self.polarcontexts_ = []                      # [R, S] float64 per node
+        self.polarcontexts_ = []                      # [R, S] float64 per node (device tensors with the GPU hooks)
         self.polarcontext_invkeys_mat_ = []           # float32 ring keys (eig2stdvec), [R] per node
         self.odom_poses_ = []                         # (x, y, theta)
         self.odom_similarity = np.zeros(0)
@@ -889,7 +894,7 @@ class RSCManager:
 
     # the two device operations (tests substitute the CPU oracle here to check the host policy around them)
     def _descriptors(self, clouds, shifts):
-        return sc_descriptors(clouds, self.par, shifts, self.ctx)
+        return sc_descriptors(clouds, self.par, shifts, self.ctx, device_out=True)   # the database lives in HBM
 
     def _distances(self, desc_q, desc_c, pairs):
         return sc_distance_batch(desc_q, desc_c, pairs, self.par, self.ctx)
@@ -898,9 +903,9 @@ class RSCManager:
         """RadarScancontext.cpp:156-180 (+ :133-146, :181-225)."""
         shifts = (0.0,) + (self.AUGMENTS_Y if self.augment_sc else ())
         desc, rk, _ = self._descriptors([cloud], shifts)
-        self.polarcontexts_.append(desc[0, 0].copy())
+        self.polarcontexts_.append(desc[0, 0])
         self.polarcontext_invkeys_mat_.append(rk[0, 0].astype(np.float32))
-        self.current_and_augments_ = [(desc[0, k].copy(), rk[0, k].astype(np.float32), (0.0, float(shifts[k]), 0.0))
+        self.current_and_augments_ = [(desc[0, k], rk[0, k].astype(np.float32), (0.0, float(shifts[k]), 0.0))
                                       for k in range(len(shifts))]
         self._exclude_and_update_likelihood(np.asarray(Todom, np.float64))
 
@@ -967,10 +972,15 @@ class RSCManager:
             jobs += [(k, i) for i in idxs]
         if not jobs:
             return []
-        qd = np.stack([d for d, _, _ in self.current_and_augments_])
+        def stack(xs):
+            if _is_torch(xs[0]):
+                import torch
+                return torch.stack(xs)
+            return np.stack(xs)
+        qd = stack([d for d, _, _ in self.current_and_augments_])
         uniq = sorted({i for _, i in jobs})
         pos = {i: p for p, i in enumerate(uniq)}
-        cd = np.stack([self.polarcontexts_[i] for i in uniq])
+        cd = stack([self.polarcontexts_[i] for i in uniq])
         dist, shift = self._distances(qd, cd, [(k, pos[i]) for k, i in jobs])
         unit = 360.0 / float(self.par.num_sector)
         similar = []

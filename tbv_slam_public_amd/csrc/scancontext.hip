@@ -246,7 +246,8 @@ extern "C" int cfear_sc_descriptors(cfear_ctx* ctx, const cfear_sc_cloud* clouds
     if (!cfear_is_device_ptr(clouds[i].xyzi)) stage += ((size_t)clouds[i].n * 16 + 255) / 256 * 256;
   }
   const size_t nd = (size_t)n_clouds * n_aug;
-  const size_t out_bytes = nd * (cells + R + S) * sizeof(double);
+  const bool desc_dev = cfear_is_device_ptr(desc);          // descriptor database kept in HBM: written in place
+  const size_t out_bytes = nd * ((desc_dev ? 0 : cells) + R + S) * sizeof(double);
   const size_t head = ((size_t)n_clouds * sizeof(ScCloud) + 255) / 256 * 256;
   char* ws = (char*)cfear_workspace(ctx, 8, head + stage + 256);
   char* wo = (char*)cfear_workspace(ctx, 9, out_bytes + 256);
@@ -268,15 +269,15 @@ extern "C" int cfear_sc_descriptors(cfear_ctx* ctx, const cfear_sc_cloud* clouds
   a.num_ring = R; a.num_sector = S; a.desc_function = par->desc_function; a.n_aug = n_aug;
   a.max_radius = par->max_radius; a.desc_divider = par->desc_divider; a.no_point = par->no_point;
   for (int k = 0; k < kScMaxAug; k++) a.shift_y[k] = (k < n_aug && shifts_y) ? shifts_y[k] : 0.0;
-  a.desc = (double*)wo;
-  a.ringkey = a.desc + nd * cells;
+  a.desc = desc_dev ? desc : (double*)wo;
+  a.ringkey = desc_dev ? (double*)wo : a.desc + nd * cells;
   a.sectorkey = a.ringkey + nd * R;
   {
     ProfScope ps(ctx, "sc_descriptor");
     hipLaunchKernelGGL(sc_descriptor_kernel, dim3(n_clouds, n_aug), dim3(256), (size_t)cells * 12, ctx->stream, a);
   }
   CFEAR_HIP_CHECK(ctx, hipGetLastError());
-  CFEAR_HIP_CHECK(ctx, hipMemcpyAsync(desc, a.desc, nd * cells * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+  if (!desc_dev) CFEAR_HIP_CHECK(ctx, hipMemcpyAsync(desc, a.desc, nd * cells * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   if (ringkey) CFEAR_HIP_CHECK(ctx, hipMemcpyAsync(ringkey, a.ringkey, nd * R * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   if (sectorkey) CFEAR_HIP_CHECK(ctx, hipMemcpyAsync(sectorkey, a.sectorkey, nd * S * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
   CFEAR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));

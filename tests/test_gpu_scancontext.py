@@ -45,6 +45,16 @@ def test_device_clouds_and_empty_cloud():
     clouds, _ = _local_maps(21, 2)
     host = api.sc_descriptors(clouds)[0]
     dev = api.sc_descriptors([torch.from_numpy(c).cuda() for c in clouds])[0]
+    # descriptor database kept in HBM: same bits, and sc_distance_batch takes the device tensors as they are
+    resident, rk_r, _ = api.sc_descriptors(clouds, device_out=True)
+    assert resident.is_cuda and resident.dtype == torch.float64
+    np.testing.assert_array_equal(resident.cpu().numpy(), host)
+    np.testing.assert_array_equal(rk_r, api.sc_descriptors(clouds)[1])
+    pairs = [(0, 1), (1, 0), (1, 1)]
+    d_dev, s_dev = api.sc_distance_batch(resident[:, 0], resident[:, 0], pairs)
+    d_host, s_host = api.sc_distance_batch(host[:, 0], host[:, 0], pairs)
+    np.testing.assert_array_equal(d_dev, d_host)
+    np.testing.assert_array_equal(s_dev, s_host)
     np.testing.assert_array_equal(host, dev)
     empty = api.sc_descriptors([np.zeros((0, 4), np.float32)])[0]
     assert (empty == -1.0).all()                                 # NO_POINT / 1000: "division before the check"
