@@ -150,19 +150,29 @@ __device__ void sort_cells_block(const ScanView& v, int n, unsigned long long* k
   __syncthreads();
   if (n <= 2048) {
     // rank sort: keys are unique, so rank = #smaller keys; every lane reads the same LDS address per
-    // step (broadcast), no barriers -- far cheaper than ~50 bitonic passes for a few hundred cells
-    for (int i = tid; i < n; i += nth) {
-      const unsigned long long key = keys[i];
+    // step (broadcast), no barriers -- far cheaper than ~50 bitonic passes for a few hundred cells.
+    // A few hundred keys leave most of the workgroup idle, so 2 or 4 adjacent lanes share a key and
+    // interleave the comparison range.
+    const int lp = (4 * n <= nth) ? 4 : (2 * n <= nth) ? 2 : 1;
+    const int nl = (n + 7) & ~7;                          // keys past n are ~0 (never smaller); npad >= 64 covers the round-up
+    for (int i0 = 0; i0 < n; i0 += nth / lp) {
+      const int i = i0 + tid / lp, part = tid % lp;
+      const unsigned long long key = i < n ? keys[i] : 0ull;
       int rank = 0;
-      const int nl = (n + 1) & ~1;                        // keys past n are ~0 (never smaller): stop at n
-      for (int j = 0; j < nl; j += 2) {
-        const ulonglong2 kk = *(const ulonglong2*)(keys + j);
-        rank += (kk.x < key) + (kk.y < key);
+      for (int j = 8 * part; j < nl; j += 8 * lp) {       // four 16-byte broadcast reads in flight per step
+        const ulonglong2 k0 = *(const ulonglong2*)(keys + j), k1 = *(const ulonglong2*)(keys + j + 2);
+        const ulonglong2 k2 = *(const ulonglong2*)(keys + j + 4), k3 = *(const ulonglong2*)(keys + j + 6);
+        rank += (k0.x < key) + (k0.y < key) + (k1.x < key) + (k1.y < key);
+        rank += (k2.x < key) + (k2.y < key) + (k3.x < key) + (k3.y < key);
       }
-      const float2 m = v.mean_f[i];
-      v.sorted_x[rank] = m.x;
-      v.sorted_y[rank] = m.y;
-      v.sorted_idx[rank] = i;
+      if (lp >= 2) rank += __shfl_xor(rank, 1);
+      if (lp >= 4) rank += __shfl_xor(rank, 2);
+      if (i < n && part == 0) {
+        const float2 m = v.mean_f[i];
+        v.sorted_x[rank] = m.x;
+        v.sorted_y[rank] = m.y;
+        v.sorted_idx[rank] = i;
+      }
     }
     return;
   }
@@ -343,8 +353,8 @@ __global__ __launch_bounds__(kSurfThreads) void surface_points_kernel(const Surf
         // float(I) - 60 is exact for I >= 60 (the difference of two floats is representable whenever it is not
         // larger in magnitude than both), so the fp64 weight of the reference is just its widening
         const float wgt = fmaxf(__fsub_rn(p.w, 60.0f), 0.0f);
-        spt[e] = make_float4(p.x, p.y, wgt, 0.f);
-        if (lds_pts) { lxy[e] = make_float2(p.x, p.y); lin[e] = wgt; }
+        if (lds_pts) { lxy[e] = make_float2(p.x, p.y); lin[e] = wgt; }    // the usual case: no global copy at all
+        else spt[e] = make_float4(p.x, p.y, wgt, 0.f);
       }
     }
   }
