@@ -189,6 +189,10 @@ int cfear_scan_create(cfear_ctx* ctx, float* xyzi, int32_t n, const cfear_featur
 int cfear_scan_from_cells(cfear_ctx* ctx, const cfear_cell* cells, int32_t n_cells, cfear_scan** out);
 int cfear_scan_size(const cfear_scan* scan);                            /* GetSize()  */
 int cfear_scan_get_cells(const cfear_scan* scan, cfear_cell* out_host, int32_t cap);  /* GetCells() */
+/* MapPointNormal::GetClosestIdx (pointnormal.cpp:238-254) for n_queries points p (x, y doubles): idx[i] = index of
+ * the cell whose float mean is nearest to float(p) (FLANN L2_Simple in float, lowest index on ties) if that squared
+ * distance is < d * d, else -1 (the reference returns an empty vector).  queries_xy / idx both host or both device. */
+int cfear_scan_closest_idx(const cfear_scan* scan, const double* queries_xy, int32_t n_queries, double d, int32_t* idx);
 int cfear_scan_destroy(cfear_scan* scan);
 
 /* ---- M: registration -----------------------------------------------------------------------

@@ -115,6 +115,12 @@ class MapPointNormal {
     if (!c.empty()) { const int n = cfear_scan_get_cells(scan_, c.data(), (int32_t)c.size()); if (n < 0) ctx_.check(n); }
     return c;
   }
+  std::vector<int> GetClosestIdx(double px, double py, double d) const {                     // pointnormal.cpp:238-254
+    const double q[2] = {px, py};
+    int32_t idx = -1;
+    ctx_.check(cfear_scan_closest_idx(scan_, q, 1, d, &idx));
+    return idx >= 0 ? std::vector<int>{idx} : std::vector<int>{};
+  }
   const cfear_scan* device() const { return scan_; }
  private:
   Context& ctx_;

@@ -464,6 +464,22 @@ double get_weight(int opt, double N1, double N2, double sim_dir, double plan1, d
   return 1.0;
 }
 
+// MapPointNormal::GetClosestIdx (pointnormal.cpp:238-254): nearest float mean to float(p), accepted iff its float
+// squared distance is < d * d (float promoted to double); lowest index on ties (App. B.3).
+int closest_idx(const std::vector<float>& tx, const std::vector<float>& ty, double px, double py, double d) {
+  const float qx = (float)px, qy = (float)py;                                 // :240-242
+  int best = -1;
+  float bestd = 0.f;
+  for (int j = 0; j < (int)tx.size(); j++) {
+    const float dx = qx - tx[j], dy = qy - ty[j];
+    float dd = 0.f;
+    dd += dx * dx;
+    dd += dy * dy;
+    if (best < 0 || dd < bestd) { best = j; bestd = dd; }
+  }
+  return (best >= 0 && (double)bestd < d * d) ? best : -1;                    // :250
+}
+
 // n_scan_normal.cpp:213-261 AddScanPairCost (association part) + :264-318 (block data)
 void add_scan_pair(const orc_cell* tar, int n_tar, const orc_cell* src, int n_src, const Aff2& Ttar,
                    const Aff2& Tsrc, int scan_idx_tar, int itr, const orc_reg_params& par,
@@ -851,6 +867,13 @@ extern "C" int orc_register(const orc_cell* const* scans, const int32_t* n_cells
   std::memset(res, 0, sizeof(*res));
   if (n_scans < 2) return 0;
   return do_register(scans, n_cells, n_scans, poses_xyt, *par, res);
+}
+
+extern "C" void orc_closest_idx(const orc_cell* cells, int n_cells, const double* queries_xy, int n_queries, double d,
+                                int32_t* idx) {
+  std::vector<float> tx(n_cells), ty(n_cells);             // pointnormal.cpp:151-162: float PointXY of the means
+  for (int j = 0; j < n_cells; j++) { tx[j] = (float)cells[j].mean[0]; ty[j] = (float)cells[j].mean[1]; }
+  for (int i = 0; i < n_queries; i++) idx[i] = closest_idx(tx, ty, queries_xy[2 * i], queries_xy[2 * i + 1], d);
 }
 
 extern "C" int orc_associate(const orc_cell* const* scans, const int32_t* n_cells, int n_scans,

@@ -109,6 +109,8 @@ int orc_normal_eq(const orc_cell* const* scans, const int32_t* n_cells, int n_sc
  * GetCost samples around the registered pose, quadratic least-squares fit, 2 H^-1 scaled by
  * GetCovarianceScaler.  par->first_itr = leftover itr_; final_cost / num_residuals from the
  * Register summary.  cov36 row-major 6x6; samples_out [n^3][4] optional.  Returns 1 = valid. */
+/* MapPointNormal::GetClosestIdx (pointnormal.cpp:238-254) for n_queries points: index of the nearest cell mean or -1 */
+void orc_closest_idx(const orc_cell* cells, int n_cells, const double* queries_xy, int n_queries, double d, int32_t* idx);
 int orc_cov_by_sampling(const orc_cell* const* scans, const int32_t* n_cells, int n_scans,
                         const double* poses_xyt, const orc_reg_params* par, double final_cost,
                         int32_t num_residuals, double xy_range, double yaw_range,

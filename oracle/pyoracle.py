@@ -105,6 +105,8 @@ def lib():
         L.orc_coral_quality.argtypes = [f32p, C.c_int, f32p, C.c_int, f64p, f64p, f64p, C.c_double, C.c_int, f64p, f64p]
         L.orc_cov_by_sampling.argtypes = [pp, i32p, C.c_int, f64p, C.POINTER(OrcRegParams), C.c_double, C.c_int32,
                                           C.c_double, C.c_double, C.c_int32, C.c_double, f64p, f64p]
+        L.orc_closest_idx.argtypes = [C.c_void_p, C.c_int, f64p, C.c_int, C.c_double, i32p]
+        L.orc_closest_idx.restype = None
         L.orc_associate.argtypes = [pp, i32p, C.c_int, f64p, C.POINTER(OrcRegParams), C.c_int, i32p, f64p, C.c_int]
         L.orc_normal_eq.argtypes = [pp, i32p, C.c_int, f64p, C.POINTER(OrcRegParams), C.c_int, f64p,
                                     f64p, f64p, f64p, i32p]
@@ -359,6 +361,16 @@ def apply_constraints(prob, group, model_threshold=0.8, all_candidates=True):
         use = order if all_candidates else order[:1]
         acc[use] = prob[use] > model_threshold
     return acc
+
+
+def closest_idx(cells, queries_xy, d):
+    """MapPointNormal::GetClosestIdx (pointnormal.cpp:238-254) for a batch of points -> int32 [n] (-1 = none)."""
+    c = np.ascontiguousarray(cells, dtype=CELL_DTYPE)
+    q = np.ascontiguousarray(queries_xy, dtype=np.float64).reshape(-1, 2)
+    out = np.zeros(q.shape[0], np.int32)
+    lib().orc_closest_idx(c.ctypes.data_as(C.c_void_p), c.shape[0], _p(q, C.c_double), q.shape[0], C.c_double(d),
+                          _p(out, C.c_int32))
+    return out
 
 
 def associate(scans, poses, par, itr):

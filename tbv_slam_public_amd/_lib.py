@@ -184,7 +184,7 @@ EXPORTS = [
     "cfear_get_cost_batch", "cfear_cov_sampling_params_default", "cfear_covariance_by_sampling",
     "cfear_covariance_by_sampling_batch", "cfear_coral_params_default", "cfear_coral_quality",
     "cfear_coral_quality_batch", "cfear_sc_params_default", "cfear_sc_descriptors", "cfear_sc_distance_batch",
-    "cfear_polar_rotate_ccw", "cfear_verify_params_default", "cfear_verify_loop_candidates", "cfear_verify_by_odometry",
+    "cfear_polar_rotate_ccw", "cfear_scan_closest_idx", "cfear_verify_params_default", "cfear_verify_loop_candidates", "cfear_verify_by_odometry",
     "cfear_cost_prepare", "cfear_cost_num_blocks", "cfear_cost_num_residuals", "cfear_cost_get_blocks",
     "cfear_cost_evaluate", "cfear_cost_normal_eq", "cfear_cost_destroy",
     "cfear_odometry_params_default", "cfear_odometry_params_preset", "cfear_odometry_create", "cfear_odometry_process",
@@ -254,6 +254,7 @@ def lib():
     L.cfear_sc_descriptors.argtypes = [vp, C.POINTER(ScCloud), C.c_int32, C.POINTER(ScParams), C.POINTER(C.c_double),
                                        C.c_int32, vp, vp, vp]
     L.cfear_sc_distance_batch.argtypes = [vp, vp, C.c_int32, vp, C.c_int32, vp, C.c_int32, C.POINTER(ScParams), vp, vp]
+    L.cfear_scan_closest_idx.argtypes = [vp, vp, C.c_int32, C.c_double, vp]
     L.cfear_polar_rotate_ccw.argtypes = [vp, vp, C.POINTER(PolarDesc), vp, C.c_int32, C.c_int64]
     L.cfear_verify_params_default.argtypes = [C.POINTER(VerifyParams)]
     L.cfear_verify_params_default.restype = None

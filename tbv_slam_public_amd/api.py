@@ -277,6 +277,23 @@ class MapPointNormal:
     def GetSize(self):
         return self.ctx._lib.cfear_scan_size(self._h)
 
+    def GetClosestIdx(self, p, d):
+        """GetClosestIdx(p, d) (pointnormal.cpp:238-254): [index of the nearest cell mean] or [] beyond d.
+        p may also be an array [n, 2] of points (NumPy or torch CUDA float64): -> int32 [n], -1 where none."""
+        single = not _is_torch(p) and np.ndim(p) == 1
+        q = p if _is_torch(p) else np.ascontiguousarray(np.atleast_2d(p), dtype=np.float64)
+        n = int(q.shape[0])
+        if _is_torch(q):
+            import torch
+            q = q.contiguous()
+            out = torch.empty(n, dtype=torch.int32, device=q.device)
+        else:
+            out = np.empty(n, np.int32)
+        self.ctx.check(self.ctx._lib.cfear_scan_closest_idx(self._h, _ptr(q)[0], n, float(d), _ptr(out)[0]))
+        if single:
+            return [int(out[0])] if out[0] >= 0 else []
+        return out
+
     def GetCells(self):
         n = self.GetSize()
         out = np.zeros(max(n, 1), L.CELL_DTYPE)

@@ -749,6 +749,66 @@ extern "C" int cfear_scan_get_cells(const cfear_scan* scan, cfear_cell* out_host
   return n;
 }
 
+// ---- MapPointNormal::GetClosestIdx for a batch of queries --------------------------------------------------
+// pointnormal.cpp:238-254: exact 1-NN of float(p) among the float cell means (KdTreeFLANN<PointXY>::nearestKSearch,
+// L2_Simple in float, lowest index on ties -- the rule the matcher uses), returned iff its squared
+// float distance is < d * d (compared in double).  One thread per query; the means are swept from LDS in tiles.
+namespace {
+__global__ __launch_bounds__(256) void closest_idx_kernel(ScanView v, int n_cells, const double2* __restrict__ q, int nq,
+                                                          double d2, int32_t* __restrict__ idx) {
+  __shared__ float2 tile[1024];
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  float qx = 0.f, qy = 0.f;
+  if (i < nq) { const double2 p = q[i]; qx = (float)p.x; qy = (float)p.y; }       // pnt.x = p(0): double -> float
+  int best = -1;
+  float bestd = 0.f;
+  for (int t0 = 0; t0 < n_cells; t0 += 1024) {
+    const int m = min(1024, n_cells - t0);
+    __syncthreads();
+    for (int j = threadIdx.x; j < m; j += 256) tile[j] = v.mean_f[t0 + j];
+    __syncthreads();
+    for (int j = 0; j < m; j++) {
+      const float2 c = tile[j];
+      const float dx = __fsub_rn(qx, c.x), dy = __fsub_rn(qy, c.y);
+      const float dd = __fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy));
+      if (best < 0 || dd < bestd) { best = t0 + j; bestd = dd; }
+    }
+  }
+  if (i < nq) idx[i] = (best >= 0 && (double)bestd < d2) ? best : -1;
+}
+}  // namespace
+
+extern "C" int cfear_scan_closest_idx(const cfear_scan* scan, const double* queries_xy, int32_t n_queries, double d,
+                                      int32_t* idx) {
+  if (!scan) return CFEAR_ERR_INVALID_ARGUMENT;
+  cfear_ctx* ctx = scan->ctx;
+  if (!queries_xy || !idx || n_queries < 0) return cfear_set_error(ctx, CFEAR_ERR_INVALID_ARGUMENT, "null argument");
+  if (n_queries == 0) return CFEAR_OK;
+  const int n = cfear_scan_size(scan);
+  if (n < 0) return n;
+  CFEAR_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  const bool dev = cfear_is_device_ptr(queries_xy);
+  if (dev != cfear_is_device_ptr(idx))
+    return cfear_set_error(ctx, CFEAR_ERR_INVALID_ARGUMENT, "queries and idx must both be host or both be device memory");
+  const double2* dq = (const double2*)queries_xy;
+  int32_t* di = idx;
+  if (!dev) {
+    char* ws = (char*)cfear_workspace(ctx, 4, (size_t)n_queries * 20 + 256);
+    if (!ws) return cfear_set_error(ctx, CFEAR_ERR_HIP, "workspace allocation failed");
+    CFEAR_HIP_CHECK(ctx, hipMemcpyAsync(ws, queries_xy, (size_t)n_queries * 16, hipMemcpyHostToDevice, ctx->stream));
+    dq = (const double2*)ws;
+    di = (int32_t*)(ws + (((size_t)n_queries * 16 + 255) & ~(size_t)255));
+  }
+  hipLaunchKernelGGL(closest_idx_kernel, dim3((n_queries + 255) / 256), dim3(256), 0, ctx->stream, scan->view, n, dq, n_queries,
+                     d * d, di);
+  CFEAR_HIP_CHECK(ctx, hipGetLastError());
+  if (!dev) {
+    CFEAR_HIP_CHECK(ctx, hipMemcpyAsync(idx, di, (size_t)n_queries * 4, hipMemcpyDeviceToHost, ctx->stream));
+    CFEAR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  }
+  return CFEAR_OK;
+}
+
 #ifdef CFEAR_SURF_TIMING
 // debug only (not in the header): cycle stamps of the last single-scan cfear_scan_create
 extern "C" int cfear_debug_surface_stamps(cfear_ctx* ctx, long long* out16) {

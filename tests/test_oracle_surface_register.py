@@ -201,3 +201,30 @@ def test_fuser_keyframe_policy(scene):
     assert infos[0][1][1] == 1 and np.all(infos[0][0] == 0)       # first frame: keyframe at identity
     assert infos[1][1][1] == 1                                    # moved 2.5 m > 1.5 m -> keyframe
     assert 1.5 < infos[1][0][0] < 3.5
+
+
+def test_closest_idx_vs_kdtree(scene):
+    """MapPointNormal::GetClosestIdx (pointnormal.cpp:238-254): float 1-NN of the cell means, accepted below d."""
+    from scipy.spatial import cKDTree
+    clouds, _ = scene
+    cells = O.surface_points(clouds[0], 3.0, 1.0, (0, 0), True)
+    means_f = cells["mean"].astype(np.float32)
+    rng = np.random.default_rng(2)
+    q = np.concatenate([cells["mean"] + rng.normal(0, 0.7, cells["mean"].shape), rng.uniform(-150, 150, (200, 2))])
+    got = O.closest_idx(cells, q, 2.0)
+    dist, idx = cKDTree(means_f.astype(np.float64)).query(q.astype(np.float32).astype(np.float64))
+    clear = np.abs(dist - 2.0) > 1e-4                      # away from the threshold the float rounding cannot matter
+    np.testing.assert_array_equal(got[clear] >= 0, dist[clear] < 2.0)
+    # neighbouring voxels can own identical means (same neighbourhood): the rule is "lowest index among the nearest"
+    qf = q.astype(np.float32)
+    for i in np.nonzero(got >= 0)[0]:
+        d2 = ((means_f - qf[i]) ** 2).sum(1, dtype=np.float32)
+        assert got[i] == int(np.argmin(d2))                # argmin returns the first minimum
+    assert (got >= 0).sum() > 100 and (got < 0).sum() > 50
+    # ties go to the lowest index; an exact hit at distance 0 is accepted for any d > 0, nothing for d = 0
+    five = cells[:5].copy()
+    five["mean"] = np.stack([np.arange(5.0) * 3, np.zeros(5)], 1)
+    dup = np.concatenate([five, five])
+    np.testing.assert_array_equal(O.closest_idx(dup, five["mean"], 0.5), np.arange(5))
+    np.testing.assert_array_equal(O.closest_idx(dup, five["mean"], 0.0), -1)
+    assert O.closest_idx(cells[:0], q[:3], 2.0).tolist() == [-1, -1, -1]
