@@ -32,6 +32,24 @@ N_SEEDS = 16                     # distinct synthetic sequences; streams replica
 HBM_PEAK_GBS = 8000.0            # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
+def _usable_cpus():
+    """Host threads this process may really run at once: the affinity mask, capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]            # cgroup v2
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())               # cgroup v1
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // per))
+        except (OSError, ValueError):
+            pass
+    return max(1, n)
+
+
 def loopclosure_main(args):
     """BASELINE configs[3]: `--candidates` loop-closure candidate registrations (P2L, Huber 0.1, Uniform,
     SetParameters(4,10) -- loopclosure.cpp:56-57) between cached surface-point sets, block-sharded over the
@@ -304,6 +322,7 @@ def main():
 
     # ---- CPU baseline: the oracle (port), 1 thread, bounded sample of the same frames -----------------
     cpu = None
+    cpu_mt = None
     pose_err = None
     if not args.no_cpu_baseline and world == 1:        # rank 0 at N=1 only
         from oracle import pyoracle as O
@@ -333,6 +352,23 @@ def main():
                          "filter->pose, oracle/liboracle.so g++ -O3, 1 thread, %.1f s; host has %d cores"
                          % (done, passes, n_seq, F, tc, os.cpu_count())}
         pose_err = {"max_abs_xy_m": err_xy, "max_abs_theta_rad": err_th, "frames_compared": compared}
+        # the same oracle on the host's cores, one sequence per thread at a time like the reference's NR_WORKERS
+        # processes (one native call per sequence, GIL released; the oracle has no shared state)
+        from concurrent.futures import ThreadPoolExecutor
+        T = _usable_cpus()
+
+        def one_sequence(sd):
+            fz = O.Fuser(reg, res=3.0, submap_scan_size=4, weight_intensity=True)
+            fz.run_sequence(base[sd % n_seq], K_STRONGEST, 60, 0.0438, 2.5)   # one native call per sequence
+            return F
+        n_tasks = 48 * T                                  # ~10 s at ~8 ms per frame
+        tm0 = time.perf_counter()
+        with ThreadPoolExecutor(T) as ex:
+            done_mt = sum(ex.map(one_sequence, range(n_tasks)))
+        tm = time.perf_counter() - tm0
+        cpu_mt = {"value": done_mt / tm, "unit": "registrations/s", "cores": T, "kind": "port",
+                  "sample": "%d sequences x %d frames on %d threads (cgroup quota / affinity of this host: %d of %d CPUs), "
+                            "%.1f s" % (n_tasks, F, T, T, os.cpu_count() or 0, tm)}
 
     out = {
         "metric": "radar scan registrations/sec (400x3360 polar)",
@@ -358,6 +394,7 @@ def main():
                      "avg_launch_ms": avg_ms, "algorithmic_bytes_per_launch": bytes_per_scan * B,
                      "mean_points_per_scan": nf},
         "cpu_baseline": cpu,
+        "cpu_baseline_all_threads": cpu_mt,
         "pose_error_vs_cpu": pose_err,
         "kernel_breakdown": breakdown,
         "mean_cells_per_scan": float(n_cells.mean()),

@@ -1496,3 +1496,21 @@ extern "C" int orc_fuser_process(orc_fuser* f, float* xyzi, int n, double pose_o
   aff_to_xyt(Tcurrent, pose_out);
   return 0;
 }
+
+// radarDriver::CallbackOffline + OdometryKeyframeFuser::pointcloudCallback for a whole sequence in one call (the
+// CPU baseline of bench.py runs one of these per host thread, like the reference's NR_WORKERS processes).
+extern "C" int orc_fuser_run_sequence(orc_fuser* f, const uint8_t* imgs, int n_frames, int rows, int cols, int k, int z_min,
+                                      float range_res, float min_distance, double* poses_out) {
+  std::vector<int32_t> sr((size_t)rows * k), sc(rows);
+  std::vector<uint8_t> si((size_t)rows * k);
+  std::vector<float> xyzi((size_t)rows * k * 4);
+  for (int t = 0; t < n_frames; t++) {
+    const uint8_t* img = imgs + (size_t)t * rows * cols;
+    orc_kstrongest(img, rows, cols, cols, k, z_min, sr.data(), si.data(), sc.data());
+    const int n = orc_kstrongest_cloud(rows, k, sr.data(), si.data(), sc.data(), nullptr, range_res, min_distance, xyzi.data());
+    int32_t info[4];
+    const int rc = orc_fuser_process(f, xyzi.data(), n, poses_out + 3 * (size_t)t, info);
+    if (rc != 0) return rc;
+  }
+  return 0;
+}

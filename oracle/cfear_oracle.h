@@ -153,6 +153,9 @@ void orc_fuser_last_cov(const orc_fuser* f, double cov36[36], int32_t* sampled);
 /* Feeds one filtered cloud (modified in place by compensation).  pose_out = Tcurrent (x,y,th).
  * info[0]=n_cells, info[1]=keyframe added, info[2]=register status, info[3]=outer iters.   */
 int orc_fuser_process(orc_fuser* f, float* xyzi, int n, double pose_out[3], int32_t info[4]);
+/* k-strongest filter + fuser over n_frames images [n_frames][rows][cols] in one call; poses_out [n_frames][3] */
+int orc_fuser_run_sequence(orc_fuser* f, const uint8_t* imgs, int n_frames, int rows, int cols, int k, int z_min,
+                           float range_res, float min_distance, double* poses_out);
 
 #ifdef __cplusplus
 }

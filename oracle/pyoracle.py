@@ -105,6 +105,8 @@ def lib():
         L.orc_coral_quality.argtypes = [f32p, C.c_int, f32p, C.c_int, f64p, f64p, f64p, C.c_double, C.c_int, f64p, f64p]
         L.orc_cov_by_sampling.argtypes = [pp, i32p, C.c_int, f64p, C.POINTER(OrcRegParams), C.c_double, C.c_int32,
                                           C.c_double, C.c_double, C.c_int32, C.c_double, f64p, f64p]
+        L.orc_fuser_run_sequence.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                             C.c_float, C.c_float, f64p]
         L.orc_closest_idx.argtypes = [C.c_void_p, C.c_int, f64p, C.c_int, C.c_double, i32p]
         L.orc_closest_idx.restype = None
         L.orc_associate.argtypes = [pp, i32p, C.c_int, f64p, C.POINTER(OrcRegParams), C.c_int, i32p, f64p, C.c_int]
@@ -425,6 +427,17 @@ class Fuser:
                                      _p(info, C.c_int32))
         assert rc == 0
         return pose, info
+
+    def run_sequence(self, imgs, k, z_min, range_res, min_distance):
+        """k-strongest filter + fuser over uint8 images [n, rows, cols] in ONE native call (no Python per frame; the
+        GIL is released for its whole duration) -> poses [n, 3]."""
+        im = np.ascontiguousarray(imgs, dtype=np.uint8)
+        poses = np.zeros((im.shape[0], 3), np.float64)
+        rc = lib().orc_fuser_run_sequence(self._h, im.ctypes.data_as(C.c_void_p), im.shape[0], im.shape[1], im.shape[2],
+                                          int(k), int(z_min), C.c_float(range_res), C.c_float(min_distance),
+                                          _p(poses, C.c_double))
+        assert rc == 0
+        return poses
 
     def last_cov(self):
         """cov_current after the last frame -> (cov 6x6, sampled flag)."""
