@@ -228,3 +228,16 @@ def test_closest_idx_vs_kdtree(scene):
     np.testing.assert_array_equal(O.closest_idx(dup, five["mean"], 0.5), np.arange(5))
     np.testing.assert_array_equal(O.closest_idx(dup, five["mean"], 0.0), -1)
     assert O.closest_idx(cells[:0], q[:3], 2.0).tolist() == [-1, -1, -1]
+
+
+def test_fuser_run_sequence_equals_frame_by_frame():
+    """orc_fuser_run_sequence (the all-threads CPU baseline of bench.py) is the per-frame path in one native call."""
+    imgs, _, _ = synth.scene_v1(5, 4)
+    reg = O.reg_params(cost="P2P", loss="Huber", loss_limit=0.1, weight_opt=4, regularization=0.0)
+    a = O.Fuser(reg, res=3.0, submap_scan_size=4, weight_intensity=True)
+    b = O.Fuser(reg, res=3.0, submap_scan_size=4, weight_intensity=True)
+    whole = a.run_sequence(imgs, 40, 60, 0.0438, 2.5)
+    for f, img in enumerate(imgs):
+        sr, si, sc = O.kstrongest(img, 40, 60)
+        pose, _ = b.process(O.kstrongest_cloud(sr, si, sc, 0.0438, 2.5))
+        np.testing.assert_array_equal(whole[f], pose)
