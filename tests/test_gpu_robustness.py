@@ -1,0 +1,70 @@
+"""GPU: non-finite and absurd inputs must come back as status codes or flagged results -- never a hang, a crash or an
+exception other than CfearError (the reference exits or asserts on several of these, pointnormal.cpp:72-75)."""
+import numpy as np
+import pytest
+
+pytestmark = [pytest.mark.gpu, pytest.mark.timeout(120)]
+
+
+@pytest.fixture(scope="module")
+def data():
+    from oracle import pyoracle as O
+    from tbv_slam_public_amd import synth
+    imgs, _, _ = synth.scene_v1(21, 1)
+    sr, si, sc = O.kstrongest(imgs[0], 40, 60)
+    cloud = O.kstrongest_cloud(sr, si, sc, 0.0438, 2.5)
+    return cloud, O.surface_points(cloud, 3.0, 1.0, (0, 0), True)
+
+
+def test_surface_points_with_non_finite_or_huge_points(data):
+    from tbv_slam_public_amd import api, _lib as L
+    cloud, cells = data
+    bad = cloud.copy()
+    bad[10, 0] = np.nan                                   # one NaN point: dropped with its voxel, the rest survives
+    assert abs(api.MapPointNormal(bad, 3.0, (0, 0), True).GetSize() - len(cells)) < 20
+    for poison in (np.inf, 1e30):
+        bad = cloud.copy()
+        bad[10, 0] = poison
+        with pytest.raises(L.CfearError) as e:
+            api.MapPointNormal(bad, 3.0, (0, 0), True)
+        assert e.value.status == L.ERR_CAPACITY            # the voxel grid would not fit: reported, not attempted
+
+
+def test_registration_with_non_finite_poses_and_cells(data):
+    from tbv_slam_public_amd import api
+    _, cells = data
+    m0 = api.MapPointNormal(cells=cells)
+    c2 = cells.copy()
+    c2["mean"][5] = np.nan
+    m1 = api.MapPointNormal(cells=c2)
+    reg = api.n_scan_normal_reg("P2L")
+    for pose in (np.nan, np.inf):
+        ok, _, _ = reg.Register([m0, m0], np.array([[0, 0, 0], [pose, 0, 0]]))
+        assert not ok                                      # no correspondences -> too few residuals
+        assert not reg.GetCost([m0, m0], np.array([[0, 0, 0], [pose, 0, 0]]))[0]
+    for scans in ([m1, m0], [m0, m1]):                     # a NaN cell never matches anything; the rest registers
+        ok, T, _ = reg.Register(scans, np.array([[0, 0, 0], [0.1, 0, 0]]))
+        assert ok and np.isfinite(T).all() and np.abs(T[1]).max() < 0.05
+    assert m0.GetClosestIdx(np.array([[np.nan, 0.0], [1e300, 0.0]]), 2.0).tolist() == [-1, -1]
+
+
+def test_alignment_quality_and_descriptors_with_non_finite_input(data):
+    from tbv_slam_public_amd import api, _lib as L
+    cloud, cells = data
+    pk = cloud[:1500]
+    q = api.CorAlRadarQuality(pk, (0, 0, 0), pk, (np.nan, 0, 0))
+    assert q.GetQualityMeasure() == [0.0, 0.0, 0.0] and not q.valid_
+    bp = pk.copy()
+    bp[3, 1] = np.nan
+    assert np.isfinite(api.CorAlRadarQuality(pk, (0, 0, 0), bp, (0.1, 0, 0)).GetQualityMeasure()).all()
+    huge = pk.copy()
+    huge[:, 0] *= 1e20
+    with pytest.raises(L.CfearError):
+        api.CorAlRadarQuality(pk, (0, 0, 0), huge, (0.1, 0, 0))
+    assert np.isfinite(api.sc_descriptors([bp])[0]).all()
+    m0 = api.MapPointNormal(cells=cells)
+    r = api.verify_loop_candidates([dict(from_scan=m0, to_scan=m0, from_peaks=pk, to_peaks=pk, from_pose=(0, 0, 0),
+                                         t_be_guess=(np.nan, 0, 0), sc_sim=0.1, odom_bounds=0.0, group=0)])
+    # the registration fails, t_be stays Identity and is still scored (loopclosure.cpp:351-352) -- here the two nodes
+    # are the same scan, so Identity happens to be a perfect alignment
+    assert r["reg_ok"][0] == 0 and (r["t_be"][0] == 0).all() and np.isfinite(r["probability"][0])
