@@ -68,3 +68,45 @@ def test_alignment_quality_and_descriptors_with_non_finite_input(data):
     # the registration fails, t_be stays Identity and is still scored (loopclosure.cpp:351-352) -- here the two nodes
     # are the same scan, so Identity happens to be a perfect alignment
     assert r["reg_ok"][0] == 0 and (r["t_be"][0] == 0).all() and np.isfinite(r["probability"][0])
+
+
+def test_two_contexts_on_two_host_threads(data):
+    """The reference runs odometry and loop closure on two threads (tbv_slam.cpp); the header promises that calls on
+    different contexts are independent.  Two threads, each with its own context and stream, hammer registration and
+    CorAl batches concurrently; every result must equal the single-threaded one."""
+    import threading
+    from tbv_slam_public_amd import api
+    cloud, cells = data
+    pk = cloud[:1800]
+    rng = np.random.default_rng(0)
+    guesses = rng.normal(0, [0.4, 0.4, 0.02], (64, 3))
+
+    def work(ctx):
+        scan = api.MapPointNormal(cells=cells, ctx=ctx)
+        reg = api.n_scan_normal_reg("P2L", ctx=ctx)
+        reg.SetParameters(4, 10)
+        out = []
+        for rep in range(6):
+            r = reg.RegisterBatch([([scan, scan], np.array([[0.0, 0.0, 0.0], g])) for g in guesses])
+            q, _ = api.coral_quality_batch([(pk, (0, 0, 0), pk, g, (0, 0, 0)) for g in guesses[:16]], ctx=ctx)
+            out.append((r["pose"].copy(), r["outer_iters"].copy(), q["joint"].copy()))
+        return out
+    ref = work(api.Context(0))
+    results, errors = {}, []
+
+    def run(name):
+        try:
+            results[name] = work(api.Context(0))
+        except Exception as e:                            # noqa: BLE001
+            errors.append(e)
+    threads = [threading.Thread(target=run, args=(n,)) for n in ("a", "b")]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(100)
+    assert not errors and set(results) == {"a", "b"}
+    for name in ("a", "b"):
+        for (p, it, j), (p0, it0, j0) in zip(results[name], ref):
+            np.testing.assert_array_equal(p, p0)
+            np.testing.assert_array_equal(it, it0)
+            np.testing.assert_array_equal(j, j0)
