@@ -103,3 +103,35 @@ def test_verification_feature_vector_matches_oracle():
     # the aligned pose has the smallest joint-minus-separate entropy and the smallest robust cost per residual
     d = coral["joint"] - coral["sep"]
     assert np.argmin(d) == 0
+
+
+def test_coral_rigid_frame_invariance_at_batch_scale():
+    """Size-independent property, 2048 jobs in one launch: CorAl depends on the two poses only through the relative
+    pose, so moving both scans by one rigid transform leaves {joint, sep, overlap} unchanged up to the float rounding
+    of pcl::transformPointCloud (points are stored as float after the transform)."""
+    from tbv_slam_public_amd import api
+    clouds, gt = _peaks(8, [0, 1, 2], k=40)
+    rng = np.random.default_rng(3)
+
+    def compose(a, b):
+        c, s = np.cos(a[2]), np.sin(a[2])
+        return np.array([c * b[0] - s * b[1] + a[0], s * b[0] + c * b[1] + a[1], a[2] + b[2]])
+    jobs, moved = [], []
+    for _ in range(2048):
+        a, b = rng.choice(3, 2, replace=False)
+        off = rng.normal(0, [0.4, 0.4, 0.02])
+        G = np.array([rng.uniform(-20, 20), rng.uniform(-20, 20), rng.uniform(-np.pi, np.pi)])
+        jobs.append((clouds[a], gt[a], clouds[b], gt[b], off))
+        moved.append((clouds[a], compose(G, gt[a]), clouds[b], compose(G, gt[b]), off))
+    q0, _ = api.coral_quality_batch(jobs)
+    q1, _ = api.coral_quality_batch(moved)
+    assert (q0["status"] == 0).all() and (q1["status"] == 0).all()
+    # a float-rounded point next to the 1 m radius may enter or leave a neighbourhood: counts move by a few points
+    assert np.abs(q0["count_valid"] - q1["count_valid"]).max() <= 12
+    # the entropies of thin (near-collinear) neighbourhoods amplify the 1e-5 m roundings: typical change 1e-5, worst 1e-2
+    for f in ("joint", "sep", "overlap"):
+        np.testing.assert_allclose(q1[f], q0[f], atol=3e-2)
+        assert np.median(np.abs(q1[f] - q0[f])) < 2e-4
+    q2, _ = api.coral_quality_batch(jobs)
+    for f in ("joint", "sep", "overlap", "count_valid"):
+        np.testing.assert_array_equal(q2[f], q0[f])       # deterministic launch to launch
