@@ -132,3 +132,28 @@ def test_cfear3_s10_preset_cauchy_window10():
 def test_cfear2_preset_p2l_window3():
     """CFEAR-2: P2L, 3 keyframes, res 3.5, k = 12, no intensity weights."""
     _run([6], 7, True, par=dict(reg_cost=1, submap_scan_size=3, res=3.5, kstrong_k_strongest=12, weight_intensity=0))
+
+
+def test_streams_are_independent_and_deterministic():
+    """256 streams = 4 sequences x 64 replicas in one batch: a stream's result may not depend on its slot or on its
+    neighbours (every replica bit-identical), and two runs of the same batch agree bit for bit."""
+    import torch
+    from tbv_slam_public_amd import api, synth
+    n_frames, reps = 4, 64
+    seqs = [synth.scene_v1(sd, n_frames)[0] for sd in (0, 1, 2, 3)]
+    order = np.random.default_rng(0).permutation(4 * reps)          # replicas scattered over the slots
+    frames = [torch.from_numpy(np.stack([seqs[o % 4][f] for o in order])).cuda() for f in range(n_frames)]
+    runs = []
+    for _ in range(2):
+        od = api.OdometryKeyframeFuser(4 * reps, 400, 3360)
+        runs.append([od.process(frames[f], frames[f + 1] if f + 1 < n_frames else None) for f in range(n_frames)])
+        od.close()
+    for f in range(n_frames):
+        a, b = runs[0][f], runs[1][f]
+        for name in a.dtype.names:
+            np.testing.assert_array_equal(a[name], b[name], err_msg=name)
+        for s in range(4):
+            idx = np.nonzero(order % 4 == s)[0]
+            for name in a.dtype.names:
+                assert (a[name][idx] == a[name][idx[0]]).all(), (f, s, name)
+    assert (runs[0][-1]["reg_status"] == 0).all()
