@@ -25,6 +25,7 @@
 namespace {
 
 constexpr int kScMaxCells = 5120;        // ring x sector capacity of the LDS accumulators (reference: 40 x 120)
+constexpr int kScDistThreads = 1024;     // one distance workgroup per CU (two descriptors = 77 KB of LDS): wide blocks
 constexpr int kScMaxAug = 8;
 
 struct ScCloud { const float4* xyzi; int32_t n; int32_t pad; };
@@ -120,9 +121,11 @@ struct ScDistArgs {
   double search_ratio;
   double* dist;              // [n_pairs]
   int32_t* shift;            // [n_pairs]
+  uint32_t sim_off;          // LDS offset of the [chunk][S] similarity matrix
+  int chunk;                 // shifts evaluated together (<= 256, as many as the LDS holds)
 };
 
-__global__ __launch_bounds__(256) void sc_distance_kernel(const ScDistArgs a) {
+__global__ __launch_bounds__(1024) void sc_distance_kernel(const ScDistArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const int R = a.num_ring, S = a.num_sector, cells = R * S;
   double* sc1 = (double*)smem;
@@ -179,27 +182,36 @@ __global__ __launch_bounds__(256) void sc_distance_kernel(const ScDistArgs a) {
   __syncthreads();
   const int m = ctl[0];
   const int* space = ctl + 2;
+  // distDirectSC(sc1, circshift(sc2, sh)) (:110-131) for every shift of the search space at once: the (shift, column)
+  // cosine similarities are independent, so all threads work on them; the per-shift sum over the columns keeps the
+  // reference's sequential order (one thread per shift), as does the dot product over the rings.
+  double* sim = (double*)(smem + a.sim_off);         // [chunk][S]; -2 marks "not counted" (similarities lie in [-1, 1])
   double best = 10000000;
   int best_shift = 0;
-  for (int k = 0; k < m; k++) {                      // distDirectSC(sc1, circshift(sc2, sh)) (:110-131)
-    const int sh = space[k];
-    for (int c = threadIdx.x; c < S; c += blockDim.x) {
-      const int c2 = ((c - sh) % S + S) % S;
+  for (int k0 = 0; k0 < m; k0 += a.chunk) {          // TBV: 13 shifts, one chunk
+    const int mk = min(a.chunk, m - k0);
+    for (int item = threadIdx.x; item < mk * S; item += blockDim.x) {
+      const int k = item / S, c = item - k * S;
+      const int c2 = ((c - space[k0 + k]) % S + S) % S;
       double dot = 0;
       for (int r = 0; r < R; r++) dot += sc1[r * S + c] * sc2[r * S + c2];
       const bool skip = (n1[c] == 0) | (n2[c2] == 0);
-      tmp[c] = skip ? -2.0 : dot / (n1[c] * n2[c2]);  // cosine similarities lie in [-1, 1]: -2 marks "not counted"
+      sim[item] = skip ? -2.0 : dot / (n1[c] * n2[c2]);
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
+    if ((int)threadIdx.x < mk) {
+      const double* row = sim + (size_t)threadIdx.x * S;
       int eff = 0;
       double sum = 0;
       for (int c = 0; c < S; c++)
-        if (tmp[c] != -2.0) { sum = sum + tmp[c]; eff = eff + 1; }
+        if (row[c] != -2.0) { sum = sum + row[c]; eff = eff + 1; }
       eff = max(eff, 1);
-      const double d = 1.0 - sum / eff;
-      if (d < best) { best_shift = sh; best = d; }
+      tmp[threadIdx.x] = 1.0 - sum / eff;
     }
+    __syncthreads();
+    if (threadIdx.x == 0)
+      for (int k = 0; k < mk; k++)
+        if (tmp[k] < best) { best_shift = space[k0 + k]; best = tmp[k]; }
     __syncthreads();
   }
   if (threadIdx.x == 0) { a.dist[blockIdx.x] = best; a.shift[blockIdx.x] = best_shift; }
@@ -312,11 +324,17 @@ extern "C" int cfear_sc_distance_batch(cfear_ctx* ctx, const double* desc_q, int
   a.dist = (double*)(ws + off);
   a.shift = (int32_t*)(ws + off + (size_t)n_pairs * 8);
   a.num_ring = R; a.num_sector = S; a.search_ratio = par->search_ratio;
-  const size_t lds = ((size_t)2 * cells + 5 * S) * 8 + (size_t)(2 + 2 * S + 2) * 4 + 16;
+  const size_t base = (((size_t)2 * cells + 5 * S) * 8 + (size_t)(2 + 2 * S + 2) * 4 + 16 + 15) & ~(size_t)15;
+  const int m_max = 2 * (int)std::round(0.5 * par->search_ratio * S) + 1;
+  const size_t room = base < (size_t)156 * 1024 ? ((size_t)156 * 1024 - base) / ((size_t)S * 8) : 0;
+  // tmp[] holds one distance per shift of a chunk (<= S); one thread sums each shift (<= block size)
+  a.chunk = (int)std::max<size_t>(1, std::min<size_t>({room, (size_t)m_max, (size_t)256, (size_t)S}));
+  a.sim_off = (uint32_t)base;
+  const size_t lds = base + (size_t)a.chunk * S * 8;
   CFEAR_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)sc_distance_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   {
     ProfScope ps(ctx, "sc_distance");
-    hipLaunchKernelGGL(sc_distance_kernel, dim3(n_pairs), dim3(256), lds, ctx->stream, a);
+    hipLaunchKernelGGL(sc_distance_kernel, dim3(n_pairs), dim3(kScDistThreads), lds, ctx->stream, a);
   }
   CFEAR_HIP_CHECK(ctx, hipGetLastError());
   CFEAR_HIP_CHECK(ctx, hipMemcpyAsync(dist, a.dist, (size_t)n_pairs * 8, hipMemcpyDeviceToHost, ctx->stream));
