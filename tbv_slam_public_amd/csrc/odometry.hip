@@ -292,7 +292,7 @@ extern "C" int cfear_odometry_process_prefetch(cfear_odometry* od, const uint8_t
   }
   // ---- M: the registration jobs depend on host state only: they are built and uploaded (copy stream) now,
   //      so the 2.3 KB per stream travel while the surface kernel runs (:164-186) ---------------------------
-  const size_t rjb = cfear_reg_job_bytes();
+  const size_t rjb = cfear_reg_job_stride(par.submap_scan_size + 1);   // records cover the keyframe window + the new scan
   int n_jobs = 0;
   std::vector<ScanView> views(cfear_reg_max_scans());
   std::vector<double> poses(3 * (size_t)cfear_reg_max_scans());
@@ -327,7 +327,7 @@ extern "C" int cfear_odometry_process_prefetch(cfear_odometry* od, const uint8_t
   if (n_jobs > 0) {
     CFEAR_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream, od->ev_jobs, 0));
     rc = cfear_register_launch(ctx, od->d_reg_jobs, n_jobs, &par.reg, par.submap_scan_size * od->cell_cap, od->cell_cap,
-                               od->d_reg_scratch, od->d_results);
+                               od->d_reg_scratch, od->d_results, nullptr, rjb);
     if (rc != CFEAR_OK) return rc;
     CFEAR_HIP_CHECK(ctx, hipMemcpyAsync(od->h_results, od->d_results, (size_t)n_jobs * sizeof(cfear_reg_result),
                                         hipMemcpyDeviceToHost, ctx->stream));
@@ -343,7 +343,7 @@ extern "C" int cfear_odometry_process_prefetch(cfear_odometry* od, const uint8_t
       mode.blocks_per_job = 1;                                    // one workgroup per stream: its scratch is reused
       mode.prior = od->d_results;
       rc = cfear_register_launch(ctx, od->d_reg_jobs, n_jobs, &par.reg, par.submap_scan_size * od->cell_cap, od->cell_cap,
-                                 od->d_reg_scratch, od->d_samples, &mode);
+                                 od->d_reg_scratch, od->d_samples, &mode, rjb);
       if (rc != CFEAR_OK) return rc;
       CFEAR_HIP_CHECK(ctx, hipMemcpyAsync(od->h_samples, od->d_samples, (size_t)n_jobs * od->fit.m * sizeof(cfear_reg_result),
                                           hipMemcpyDeviceToHost, ctx->stream));
