@@ -59,8 +59,8 @@ struct CoralCommon {
 };
 
 __host__ __device__ inline size_t coral_scratch_bytes(int cap) {
-  // sorted points float4 | joint_res f64 | sep_res f64 | weight f64 (0 = invalid) | valid i32
-  return ((size_t)cap * (16 + 8 + 8 + 8 + 4) + 255) / 256 * 256;
+  // sorted points float4 | joint_res f64 | sep_res f64 | weight f64 (0 = invalid) | valid i32 | work list i32
+  return ((size_t)cap * (16 + 8 + 8 + 8 + 4 + 4) + 255) / 256 * 256;
 }
 
 struct Aff2d { double l0, l1, l2, l3, t0, t1; };
@@ -135,6 +135,7 @@ __global__ __launch_bounds__(kCoralThreads) void coral_kernel(const CoralJob* __
   double* sres = jres + cm.cap;
   double* wres = sres + cm.cap;
   int32_t* vres = (int32_t*)(wres + cm.cap);
+  int32_t* work = vres + cm.cap;                               // sorted positions of the points that overlap the other cloud
 
   const Aff2d Tref = aff_xyt(job.ref_pose);
   const Aff2d Tsrc = aff_compose(aff_xyt(job.src_pose), aff_xyt(job.offset));            // src->GetAffine() * Toffset (:101)
@@ -239,11 +240,56 @@ __global__ __launch_bounds__(kCoralThreads) void coral_kernel(const CoralJob* __
     rowbeg[y] = lower_bound_u32(cell_key, 0, V, (uint32_t)((long long)y * dbx));
   __threadfence_block();
   __syncthreads();
-  // ---- 4. one lane per merged point: moments of its source / reference neighbours -> entropies ----
+  // ---- 4. moments of the source / reference neighbours of every point -> entropies -----------------------------
   // Instantiated per address space of the sorted points (ds_read_b128 when they sit in LDS); candidates are fetched
   // two at a time so the second load is in flight while the first is tested.
+  // Pass A (cheap, every point): does the point have ANY neighbour of the other cloud within the radius
+  // (overlap_req_ = 1, :138, :160)?  Float distance tests only, first hit ends the search.  Points without one are
+  // final (100, 100, invalid); the others go to a work list.  Pass B (expensive, work list only): fp64 moments and
+  // entropies -- typically a quarter to a half of the points, spread evenly over the workgroup.
+  int* n_work = red_i;                                          // LDS counter (red_i is free after the sort)
+  if (tid == 0) *n_work = 0;
+  __syncthreads();
+  auto find_overlap = [&](auto* SP) {
+    for (int e0 = 0; e0 < n; e0 += kCoralThreads) {
+      const int e = e0 + tid;
+      bool hit = false;
+      if (e < n) {
+        const v4f q = SP[e];
+        const int idx = __float_as_int(q.w);
+        const bool q_is_src = idx < n_src;
+        int ix, iy;
+        cell_xy(make_float2(q.x, q.y), ix, iy);
+        const int x0 = max(ix - 1, 0), x1 = min(ix + 1, dbx - 1);
+        for (int yy = max(iy - 1, 0); yy <= min(iy + 1, dby - 1) && !hit; yy++) {
+          const uint32_t klo = (uint32_t)(yy * dbx + x0), khi = (uint32_t)(yy * dbx + x1);
+          const int a = lower_bound_u32(cell_key, rowbeg[yy], rowbeg[yy + 1], klo);
+          const int b = upper_bound_u32(cell_key, rowbeg[yy], rowbeg[yy + 1], khi);
+          const int p1 = cell_start[b];
+          for (int p = cell_start[a]; p < p1 && !hit; p++) {
+            const v4f c = SP[p];
+            const float dxf = __fsub_rn(q.x, c.x), dyf = __fsub_rn(q.y, c.y);
+            const float d2 = __fadd_rn(__fmul_rn(dxf, dxf), __fmul_rn(dyf, dyf));
+            hit = (d2 < cm.r2) && ((__float_as_int(c.w) < n_src) != q_is_src);
+          }
+        }
+        if (!hit) { jres[idx] = 100.0; sres[idx] = 100.0; wres[idx] = 0.0; vres[idx] = 0; }
+      }
+      const unsigned long long m = __ballot(hit);                // wave-aggregated append
+      int base = 0;
+      if (lane == 0 && m) base = atomicAdd(n_work, __popcll(m));
+      base = __shfl(base, 0);
+      if (hit) work[base + __popcll(m & ((1ull << lane) - 1ull))] = e;
+    }
+  };
+  if (spt_in_lds) find_overlap((CFEAR_LDS const v4f*)spt);
+  else find_overlap((const v4f*)spt);
+  __threadfence_block();
+  __syncthreads();
+  const int W = *n_work;
   auto sweep = [&](auto* SP) {
-    for (int e = tid; e < n; e += kCoralThreads) {
+    for (int k = tid; k < W; k += kCoralThreads) {
+      const int e = work[k];
       const v4f q = SP[e];
       const int idx = __float_as_int(q.w);
       const bool q_is_src = idx < n_src;
