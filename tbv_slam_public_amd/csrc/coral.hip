@@ -266,12 +266,17 @@ __global__ __launch_bounds__(kCoralThreads) void coral_kernel(const CoralJob* __
           const int a = lower_bound_u32(cell_key, rowbeg[yy], rowbeg[yy + 1], klo);
           const int b = upper_bound_u32(cell_key, rowbeg[yy], rowbeg[yy + 1], khi);
           const int p1 = cell_start[b];
-          for (int p = cell_start[a]; p < p1 && !hit; p++) {
-            const v4f c = SP[p];
+          auto test = [&](const v4f c) {
             const float dxf = __fsub_rn(q.x, c.x), dyf = __fsub_rn(q.y, c.y);
             const float d2 = __fadd_rn(__fmul_rn(dxf, dxf), __fmul_rn(dyf, dyf));
-            hit = (d2 < cm.r2) && ((__float_as_int(c.w) < n_src) != q_is_src);
+            return (d2 < cm.r2) && ((__float_as_int(c.w) < n_src) != q_is_src);
+          };
+          int p = cell_start[a];
+          for (; p + 3 < p1 && !hit; p += 4) {                  // four independent loads per exit test
+            const v4f c0 = SP[p], c1 = SP[p + 1], c2 = SP[p + 2], c3 = SP[p + 3];
+            hit = ((int)test(c0) | (int)test(c1) | (int)test(c2) | (int)test(c3)) != 0;
           }
+          for (; p < p1 && !hit; p++) hit = test(SP[p]);
         }
         if (!hit) { jres[idx] = 100.0; sres[idx] = 100.0; wres[idx] = 0.0; vres[idx] = 0; }
       }
