@@ -383,6 +383,37 @@ int cfear_sc_distance_batch(cfear_ctx* ctx, const double* desc_q, int32_t n_q, c
                             const int32_t* pairs, int32_t n_pairs, const cfear_sc_params* par, double* dist,
                             int32_t* shift);
 
+/* RSCManager as a library object (place_recognition_radar RadarScancontext.cpp:156-345): the descriptor database
+ * lives in HBM; makeAndSaveScancontextAndKeysRadarCloud = add, detectLoopClosureID = detect.  Host policy (recent-node
+ * exclusion, odometry likelihood, ring-key search, candidate ranking) runs in the library's C++.                    */
+typedef struct cfear_sc_manager cfear_sc_manager;
+typedef struct cfear_sc_manager_params {
+  cfear_sc_params sc;
+  int32_t num_candidates_from_tree;     /* NUM_CANDIDATES_FROM_TREE (10)                                 */
+  int32_t n_candidates;                 /* N_CANDIDATES kept after ranking (3)                           */
+  double odom_sigma_error;              /* 0.05                                                          */
+  int32_t odometry_coupled_closure;     /* ring key extended by 10 x odometry similarity (true)          */
+  int32_t augment_sc;                   /* lateral augmentations {-2, 2, -4, 4} m of the query (true)    */
+  double distance_exclude_recent;       /* DISTANCE_EXCLUDE_RECENT (10 m)                                */
+  int64_t pad;
+} cfear_sc_manager_params;              /* 88 bytes */
+void cfear_sc_manager_params_default(cfear_sc_manager_params* p);
+typedef struct cfear_sc_candidate {     /* RSCManager::candidate */
+  double min_dist, min_dist_sc, min_dist_odom;
+  float yaw_diff_rad;
+  int32_t nn_idx;
+  int32_t argmin_shift;
+  int32_t pad;
+  double Taug[3];                       /* augmentation transform of the winning query as (x, y, theta)  */
+} cfear_sc_candidate;                   /* 64 bytes */
+int cfear_sc_manager_create(cfear_ctx* ctx, const cfear_sc_manager_params* par, cfear_sc_manager** out);
+/* cloud: the node's local map [n][4] in the node frame (host or device); Todom: the node's pose (x, y, theta). */
+int cfear_sc_manager_add(cfear_sc_manager* m, const float* xyzi, int32_t n_points, const double Todom[3]);
+/* candidates for the node added last, closest first; *n_out <= n_candidates.                                   */
+int cfear_sc_manager_detect(cfear_sc_manager* m, cfear_sc_candidate* out, int32_t cap, int32_t* n_out);
+int cfear_sc_manager_size(const cfear_sc_manager* m);
+int cfear_sc_manager_destroy(cfear_sc_manager* m);
+
 /* ---- caller: loop-candidate verification --------------------------------------------------------------
  * What the loop-closure thread does per candidate (tbv_slam/src/tbv_slam/loopclosure.cpp:658-725), for a batch:
  * RegisterLoopCandidate (:320-364, loopclosure::Register :35-97), VerifyLoopCandidate (:365-384) =

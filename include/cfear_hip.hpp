@@ -8,6 +8,7 @@
 // installed (they are not in this image).  Errors are C++ exceptions carrying the C status code.
 #pragma once
 #include <cstdint>
+#include <algorithm>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -219,6 +220,36 @@ class CorAlRadarQuality {
   cfear_coral_result res_{};
 };
 }  // namespace CorAlignment
+
+// RSCManager (place_recognition_radar/RadarScancontext.h): descriptor database + candidate retrieval.
+class RSCManager {
+ public:
+  explicit RSCManager(CFEAR_Radarodometry::Context& ctx, const cfear_sc_manager_params* par = nullptr) : ctx_(ctx) {
+    cfear_sc_manager_params def;
+    if (!par) { cfear_sc_manager_params_default(&def); par = &def; }
+    n_candidates_ = par->n_candidates;
+    ctx_.check(cfear_sc_manager_create(ctx_.get(), par, &m_));
+  }
+  ~RSCManager() { cfear_sc_manager_destroy(m_); }
+  RSCManager(const RSCManager&) = delete;
+  RSCManager& operator=(const RSCManager&) = delete;
+  void makeAndSaveScancontextAndKeysRadarCloud(const CFEAR_Radarodometry::PointCloud& cloud,          // RadarScancontext.cpp:156-180
+                                               const CFEAR_Radarodometry::Pose2d& Todom) {
+    const double T[3] = {Todom.x, Todom.y, Todom.theta};
+    ctx_.check(cfear_sc_manager_add(m_, cloud.empty() ? nullptr : &cloud[0].x, (int32_t)cloud.size(), T));
+  }
+  std::vector<cfear_sc_candidate> detectLoopClosureID() {                                             // :286-345
+    std::vector<cfear_sc_candidate> out((size_t)std::max(n_candidates_, 1));
+    int32_t n = 0;
+    ctx_.check(cfear_sc_manager_detect(m_, out.data(), (int32_t)out.size(), &n));
+    out.resize((size_t)n);
+    return out;
+  }
+ private:
+  CFEAR_Radarodometry::Context& ctx_;
+  cfear_sc_manager* m_ = nullptr;
+  int n_candidates_ = 3;
+};
 
 // Loop-candidate verification of tbv_slam::loopclosure (tbv_slam/src/tbv_slam/loopclosure.cpp:320-384, 261-274,
 // 776-808) for a batch of candidates.

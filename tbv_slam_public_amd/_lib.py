@@ -125,6 +125,18 @@ class ScCloud(C.Structure):
     _fields_ = [("xyzi", C.c_void_p), ("n", C.c_int32), ("pad", C.c_int32)]
 
 
+class ScManagerParams(C.Structure):
+    _fields_ = [("sc", ScParams), ("num_candidates_from_tree", C.c_int32), ("n_candidates", C.c_int32),
+                ("odom_sigma_error", C.c_double), ("odometry_coupled_closure", C.c_int32), ("augment_sc", C.c_int32),
+                ("distance_exclude_recent", C.c_double), ("pad", C.c_int64)]
+
+
+SC_CANDIDATE_DTYPE = np.dtype([("min_dist", "<f8"), ("min_dist_sc", "<f8"), ("min_dist_odom", "<f8"),
+                               ("yaw_diff_rad", "<f4"), ("nn_idx", "<i4"), ("argmin_shift", "<i4"), ("pad", "<i4"),
+                               ("Taug", "<f8", (3,))])
+assert SC_CANDIDATE_DTYPE.itemsize == 64
+
+
 class VerifyParams(C.Structure):
     _fields_ = [("align_intercept", C.c_double), ("align_coef", C.c_double * 6), ("loop_intercept", C.c_double),
                 ("loop_coef", C.c_double * 3), ("model_threshold", C.c_double), ("all_candidates", C.c_int32),
@@ -184,7 +196,9 @@ EXPORTS = [
     "cfear_get_cost_batch", "cfear_cov_sampling_params_default", "cfear_covariance_by_sampling",
     "cfear_covariance_by_sampling_batch", "cfear_coral_params_default", "cfear_coral_quality",
     "cfear_coral_quality_batch", "cfear_sc_params_default", "cfear_sc_descriptors", "cfear_sc_distance_batch",
-    "cfear_polar_rotate_ccw", "cfear_scan_closest_idx", "cfear_verify_params_default", "cfear_verify_loop_candidates", "cfear_verify_by_odometry",
+    "cfear_polar_rotate_ccw", "cfear_scan_closest_idx",
+    "cfear_sc_manager_params_default", "cfear_sc_manager_create", "cfear_sc_manager_add", "cfear_sc_manager_detect",
+    "cfear_sc_manager_size", "cfear_sc_manager_destroy", "cfear_verify_params_default", "cfear_verify_loop_candidates", "cfear_verify_by_odometry",
     "cfear_cost_prepare", "cfear_cost_num_blocks", "cfear_cost_num_residuals", "cfear_cost_get_blocks",
     "cfear_cost_evaluate", "cfear_cost_normal_eq", "cfear_cost_destroy",
     "cfear_odometry_params_default", "cfear_odometry_params_preset", "cfear_odometry_create", "cfear_odometry_process",
@@ -254,6 +268,13 @@ def lib():
     L.cfear_sc_descriptors.argtypes = [vp, C.POINTER(ScCloud), C.c_int32, C.POINTER(ScParams), C.POINTER(C.c_double),
                                        C.c_int32, vp, vp, vp]
     L.cfear_sc_distance_batch.argtypes = [vp, vp, C.c_int32, vp, C.c_int32, vp, C.c_int32, C.POINTER(ScParams), vp, vp]
+    L.cfear_sc_manager_params_default.argtypes = [C.POINTER(ScManagerParams)]
+    L.cfear_sc_manager_params_default.restype = None
+    L.cfear_sc_manager_create.argtypes = [vp, C.POINTER(ScManagerParams), C.POINTER(vp)]
+    L.cfear_sc_manager_add.argtypes = [vp, vp, C.c_int32, C.POINTER(C.c_double)]
+    L.cfear_sc_manager_detect.argtypes = [vp, vp, C.c_int32, C.POINTER(C.c_int32)]
+    L.cfear_sc_manager_size.argtypes = [vp]
+    L.cfear_sc_manager_destroy.argtypes = [vp]
     L.cfear_scan_closest_idx.argtypes = [vp, vp, C.c_int32, C.c_double, vp]
     L.cfear_polar_rotate_ccw.argtypes = [vp, vp, C.POINTER(PolarDesc), vp, C.c_int32, C.c_int64]
     L.cfear_verify_params_default.argtypes = [C.POINTER(VerifyParams)]

@@ -304,7 +304,8 @@ class MapPointNormal:
 
     def close(self):
         if getattr(self, "_h", None):
-            self.ctx._lib.cfear_scan_destroy(self._h)
+            if getattr(self.ctx, "h", None):              # the context may already be gone at interpreter exit: its
+                self.ctx._lib.cfear_scan_destroy(self._h)   # objects died with it, destroying them again would be a use after free
             self._h = None
 
     def __del__(self):
@@ -497,7 +498,8 @@ class CeresCost:
 
     def close(self):
         if getattr(self, "_h", None):
-            self.ctx._lib.cfear_cost_destroy(self._h)
+            if getattr(self.ctx, "h", None):              # the context may already be gone at interpreter exit: its
+                self.ctx._lib.cfear_cost_destroy(self._h)   # objects died with it, destroying them again would be a use after free
             self._h = None
 
     def __del__(self):
@@ -1005,12 +1007,60 @@ class RSCManager:
             d_odom = float(self.odom_similarity[i]) if self.odometry_coupled_closure else 0.0
             d_tot = float(d_sc) + d_odom if self.odometry_coupled_closure else float(d_sc)
             similar.append(dict(min_dist=d_tot, min_dist_sc=float(d_sc), min_dist_odom=d_odom,
-                                yaw_diff_rad=float(np.float32(np.float32(sh * unit) * np.pi / 180.0)), nn_idx=int(i),
+                                # deg2rad(float) (RadarScancontext.cpp:6-9): float degrees, double product, float result
+                                yaw_diff_rad=float(np.float32(float(np.float32(sh * unit)) * np.pi / 180.0)), nn_idx=int(i),
                                 argmin_shift=int(sh), Taug=self.current_and_augments_[k][2]))
             similar.sort(key=lambda c: c["min_dist"])     # std::sort + erase of the worst (:317-320)
             if len(similar) > self.N_candidates:
                 similar.pop()
         return similar
+
+
+class RSCManagerNative:
+    """The same manager as a library object (cfear_sc_manager_*): database in HBM, policy in the library's C++.
+    Same two calls as RSCManager; what a C++ host uses (include/cfear_hip.hpp)."""
+
+    def __init__(self, par=None, num_candidates_from_tree=10, n_candidates=3, odom_sigma_error=0.05,
+                 odometry_coupled_closure=True, augment_sc=True, ctx=None):
+        self.ctx = ctx or default_context()
+        p = L.ScManagerParams()
+        self.ctx._lib.cfear_sc_manager_params_default(C.byref(p))
+        if par is not None:
+            p.sc = par
+        p.num_candidates_from_tree, p.n_candidates = int(num_candidates_from_tree), int(n_candidates)
+        p.odom_sigma_error = float(odom_sigma_error)
+        p.odometry_coupled_closure, p.augment_sc = int(odometry_coupled_closure), int(augment_sc)
+        self.par = p
+        self._h = C.c_void_p()
+        self.ctx.check(self.ctx._lib.cfear_sc_manager_create(self.ctx.h, C.byref(p), C.byref(self._h)))
+
+    def makeAndSaveScancontextAndKeysRadarCloud(self, cloud, Todom):
+        ptr, n, _keep = _cloud_ptr(cloud)
+        T = (C.c_double * 3)(*[float(v) for v in Todom])
+        self.ctx.check(self.ctx._lib.cfear_sc_manager_add(self._h, ptr, n, T))
+
+    def detectLoopClosureID(self):
+        out = np.zeros(max(int(self.par.n_candidates), 1), L.SC_CANDIDATE_DTYPE)
+        n = C.c_int32()
+        self.ctx.check(self.ctx._lib.cfear_sc_manager_detect(self._h, out.ctypes.data, out.shape[0], C.byref(n)))
+        return [dict(min_dist=float(c["min_dist"]), min_dist_sc=float(c["min_dist_sc"]), min_dist_odom=float(c["min_dist_odom"]),
+                     yaw_diff_rad=float(c["yaw_diff_rad"]), nn_idx=int(c["nn_idx"]), argmin_shift=int(c["argmin_shift"]),
+                     Taug=tuple(float(v) for v in c["Taug"])) for c in out[:n.value]]
+
+    def size(self):
+        return self.ctx._lib.cfear_sc_manager_size(self._h)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            if getattr(self.ctx, "h", None):              # the context may already be gone at interpreter exit: its
+                self.ctx._lib.cfear_sc_manager_destroy(self._h)   # objects died with it, destroying them again would be a use after free
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def odometry_params(**kw):
@@ -1089,7 +1139,8 @@ class OdometryKeyframeFuser:
 
     def close(self):
         if getattr(self, "_h", None):
-            self.ctx._lib.cfear_odometry_destroy(self._h)
+            if getattr(self.ctx, "h", None):              # the context may already be gone at interpreter exit: its
+                self.ctx._lib.cfear_odometry_destroy(self._h)   # objects died with it, destroying them again would be a use after free
             self._h = None
 
     def __del__(self):

@@ -342,3 +342,198 @@ extern "C" int cfear_sc_distance_batch(cfear_ctx* ctx, const double* desc_q, int
   CFEAR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   return CFEAR_OK;
 }
+
+// ---- RSCManager: descriptor database + retrieval policy (host) around the two kernels ----------------------
+// Restates RSCManager::makeAndSaveScancontextAndKeysRadarCloud (RadarScancontext.cpp:156-180), the recent-node
+// exclusion and odometry likelihood (:181-222), OdometryNNSearch / the ring-key KNN (:225-284) and
+// detectLoopClosureID (:286-345).  The descriptors never leave HBM: the database is one device array, the query and
+// its lateral augmentations another; only ring keys (40 floats per descriptor) and distances cross PCIe.
+struct cfear_sc_manager {
+  cfear_ctx* ctx = nullptr;
+  cfear_sc_manager_params par{};
+  int cells = 0;
+  double* d_db = nullptr;        // [cap][cells]
+  int cap = 0, n = 0;
+  double* d_cur = nullptr;       // [n_aug][cells] current node and its augmentations
+  int n_aug = 1;
+  std::vector<std::vector<float>> ringkeys;          // polarcontext_invkeys_mat_
+  std::vector<std::vector<float>> cur_keys;          // ring keys of current_and_augments_
+  std::vector<double> shifts;                        // lateral shift of every augmentation (Taug = (0, shift, 0))
+  std::vector<double> poses;                         // odom_poses_ (x, y, theta)
+  std::vector<double> odom_similarity;
+  int num_exclude_recent = 0;
+};
+
+extern "C" void cfear_sc_manager_params_default(cfear_sc_manager_params* p) {
+  if (!p) return;
+  cfear_sc_params_default(&p->sc);
+  p->num_candidates_from_tree = 10;   // NUM_CANDIDATES_FROM_TREE (Scancontext.h:117)
+  p->n_candidates = 3;                // par.N_CANDIDATES (tbv_slam launch default)
+  p->odom_sigma_error = 0.05;         // RSCManager::Parameters::odom_sigma_error
+  p->odometry_coupled_closure = 1;
+  p->augment_sc = 1;
+  p->pad = 0;
+  p->distance_exclude_recent = 10.0;  // DISTANCE_EXCLUDE_RECENT (Scancontext.h:108)
+}
+
+extern "C" int cfear_sc_manager_create(cfear_ctx* ctx, const cfear_sc_manager_params* par, cfear_sc_manager** out) {
+  if (!ctx) return CFEAR_ERR_INVALID_ARGUMENT;
+  if (!par || !out) return cfear_set_error(ctx, CFEAR_ERR_INVALID_ARGUMENT, "null argument");
+  *out = nullptr;
+  const int rc = check_sc_params(ctx, &par->sc);
+  if (rc != CFEAR_OK) return rc;
+  if (par->num_candidates_from_tree < 1 || par->n_candidates < 1 || !(par->odom_sigma_error > 0))
+    return cfear_set_error(ctx, CFEAR_ERR_INVALID_ARGUMENT, "bad scan-context manager parameters");
+  cfear_sc_manager* m = new cfear_sc_manager();
+  m->ctx = ctx; m->par = *par;
+  m->cells = par->sc.num_ring * par->sc.num_sector;
+  m->shifts = {0.0};
+  if (par->augment_sc) { m->shifts.push_back(-2.0); m->shifts.push_back(2.0); m->shifts.push_back(-4.0); m->shifts.push_back(4.0); }   // :164
+  m->n_aug = (int)m->shifts.size();
+  CFEAR_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  if (hipMalloc((void**)&m->d_cur, (size_t)m->n_aug * m->cells * sizeof(double)) != hipSuccess) {
+    delete m;
+    return cfear_set_error(ctx, CFEAR_ERR_HIP, "hipMalloc failed");
+  }
+  *out = m;
+  return CFEAR_OK;
+}
+
+extern "C" int cfear_sc_manager_destroy(cfear_sc_manager* m) {
+  if (!m) return CFEAR_OK;
+  (void)hipSetDevice(m->ctx->device);
+  (void)hipStreamSynchronize(m->ctx->stream);
+  if (m->d_db) (void)hipFree(m->d_db);
+  if (m->d_cur) (void)hipFree(m->d_cur);
+  delete m;
+  return CFEAR_OK;
+}
+
+extern "C" int cfear_sc_manager_size(const cfear_sc_manager* m) { return m ? m->n : CFEAR_ERR_INVALID_ARGUMENT; }
+
+extern "C" int cfear_sc_manager_add(cfear_sc_manager* m, const float* xyzi, int32_t n_points, const double Todom[3]) {
+  if (!m || !Todom || n_points < 0 || (n_points > 0 && !xyzi)) return CFEAR_ERR_INVALID_ARGUMENT;
+  cfear_ctx* ctx = m->ctx;
+  CFEAR_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  const int R = m->par.sc.num_ring;
+  cfear_sc_cloud cloud{xyzi, n_points, 0};
+  std::vector<double> rk((size_t)m->n_aug * R);
+  int rc = cfear_sc_descriptors(ctx, &cloud, 1, &m->par.sc, m->shifts.data(), m->n_aug, m->d_cur, rk.data(), nullptr);
+  if (rc != CFEAR_OK) return rc;
+  if (m->n == m->cap) {                                      // grow the database (device to device)
+    const int ncap = std::max(256, m->cap * 2);
+    double* nd = nullptr;
+    if (hipMalloc((void**)&nd, (size_t)ncap * m->cells * sizeof(double)) != hipSuccess)
+      return cfear_set_error(ctx, CFEAR_ERR_HIP, "descriptor database: hipMalloc failed");
+    if (m->n > 0)
+      CFEAR_HIP_CHECK(ctx, hipMemcpyAsync(nd, m->d_db, (size_t)m->n * m->cells * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+    CFEAR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    if (m->d_db) (void)hipFree(m->d_db);
+    m->d_db = nd;
+    m->cap = ncap;
+  }
+  CFEAR_HIP_CHECK(ctx, hipMemcpyAsync(m->d_db + (size_t)m->n * m->cells, m->d_cur, (size_t)m->cells * sizeof(double),
+                                      hipMemcpyDeviceToDevice, ctx->stream));
+  m->n++;
+  m->cur_keys.assign(m->n_aug, std::vector<float>(R));
+  for (int k = 0; k < m->n_aug; k++)
+    for (int r = 0; r < R; r++) m->cur_keys[k][r] = (float)rk[(size_t)k * R + r];      // eig2stdvec: double -> float
+  m->ringkeys.push_back(m->cur_keys[0]);
+  // ExcludeAndUpdateLikelihood (:181-222)
+  m->poses.insert(m->poses.end(), Todom, Todom + 3);
+  const int np = (int)m->poses.size() / 3;
+  auto px = [&](int i) { return m->poses[3 * (size_t)i]; };
+  auto py = [&](int i) { return m->poses[3 * (size_t)i + 1]; };
+  if (np <= 2) {
+    m->num_exclude_recent = 2;
+  } else {
+    double distance = 0.0;
+    int n_ex = 0, prev = np - 1;
+    for (int i = np - 1; i >= 0 && distance < m->par.distance_exclude_recent; i--) {
+      distance = distance + std::hypot(px(i) - px(prev), py(i) - py(prev));
+      prev = i;
+      n_ex++;
+    }
+    m->num_exclude_recent = n_ex;
+  }
+  const int cur = np - 1;
+  m->odom_similarity.assign(cur, 0.0);
+  double tpx = Todom[0], tpy = Todom[1], trav = 0.0;
+  for (int i = cur - 1; i >= 0; i--) {
+    trav += std::hypot(tpx - px(i), tpy - py(i));
+    tpx = px(i); tpy = py(i);
+    const double est = std::hypot(Todom[0] - px(i), Todom[1] - py(i));
+    const double error = std::max(est - 5.0, 0.0);
+    const double rel = error / trav;
+    const double prob = std::exp(-rel * rel / (2 * m->par.odom_sigma_error * m->par.odom_sigma_error));
+    m->odom_similarity[i] = 1.0 - prob;
+  }
+  return CFEAR_OK;
+}
+
+extern "C" int cfear_sc_manager_detect(cfear_sc_manager* m, cfear_sc_candidate* out, int32_t cap, int32_t* n_out) {
+  if (!m || !n_out || cap < 0 || (cap > 0 && !out)) return CFEAR_ERR_INVALID_ARGUMENT;
+  cfear_ctx* ctx = m->ctx;
+  *n_out = 0;
+  if (m->n < m->num_exclude_recent + 1) return CFEAR_OK;                      // :288-291
+  const int R = m->par.sc.num_ring;
+  const int cur = m->n - 1;
+  std::vector<int32_t> pairs;                                                 // (augmentation, candidate) in visiting order
+  for (int k = 0; k < m->n_aug; k++) {
+    const std::vector<float>& key = m->cur_keys[k];
+    std::vector<std::pair<float, int>> cands;
+    if (m->par.odometry_coupled_closure) {                                    // OdometryNNSearch (:259-284)
+      for (int idx = 0; idx < std::max(cur - 1 - m->num_exclude_recent, 0); idx++) {
+        float l2 = 0.f;                                                       // L2norm (:250-257): float sum, double terms
+        for (int r = 0; r <= R; r++) {
+          const float a = r < R ? key[r] : 0.0f;
+          const float b = r < R ? m->ringkeys[idx][r] : (float)(10 * m->odom_similarity[idx]);
+          const double err = (double)(a - b);
+          l2 = (float)((double)l2 + err * err);
+        }
+        cands.emplace_back(l2, idx);
+      }
+    } else {                                                                  // ring-key KNN (:225-248), exact
+      const int nn = m->n - m->num_exclude_recent;
+      for (int idx = 0; idx < nn; idx++) {
+        float d = 0.f;
+        for (int r = 0; r < R; r++) { const float e = m->ringkeys[idx][r] - key[r]; d += e * e; }
+        cands.emplace_back(d, idx);
+      }
+    }
+    std::stable_sort(cands.begin(), cands.end());
+    for (int c = 0; c < (int)cands.size() && c < m->par.num_candidates_from_tree; c++) {
+      pairs.push_back(k);
+      pairs.push_back(cands[c].second);
+    }
+  }
+  const int np = (int)pairs.size() / 2;
+  if (np == 0) return CFEAR_OK;
+  std::vector<double> dist(np);
+  std::vector<int32_t> shift(np);
+  const int rc = cfear_sc_distance_batch(ctx, m->d_cur, m->n_aug, m->d_db, m->n, pairs.data(), np, &m->par.sc, dist.data(),
+                                         shift.data());
+  if (rc != CFEAR_OK) return rc;
+  const double unit = 360.0 / (double)m->par.sc.num_sector;
+  std::vector<cfear_sc_candidate> similar;
+  for (int i = 0; i < np; i++) {                                              // :300-322
+    const int k = pairs[2 * i], idx = pairs[2 * i + 1];
+    cfear_sc_candidate c{};
+    c.min_dist_sc = dist[i];
+    c.min_dist_odom = m->par.odometry_coupled_closure ? m->odom_similarity[idx] : 0.0;
+    c.min_dist = m->par.odometry_coupled_closure ? dist[i] + c.min_dist_odom : dist[i];
+    const float ang = (float)(shift[i] * unit);
+    c.yaw_diff_rad = (float)(ang * M_PI / 180.0);
+    c.nn_idx = idx;
+    c.argmin_shift = shift[i];
+    c.Taug[0] = 0.0; c.Taug[1] = m->shifts[k]; c.Taug[2] = 0.0;
+    similar.push_back(c);
+    std::stable_sort(similar.begin(), similar.end(),
+                     [](const cfear_sc_candidate& a, const cfear_sc_candidate& b) { return a.min_dist < b.min_dist; });
+    if ((int)similar.size() > m->par.n_candidates) similar.pop_back();
+  }
+  *n_out = (int32_t)similar.size();
+  if ((int)similar.size() > cap) return cfear_set_error(ctx, CFEAR_ERR_CAPACITY, "%d candidates > cap %d", (int)similar.size(), cap);
+  for (size_t i = 0; i < similar.size(); i++) out[i] = similar[i];
+  return CFEAR_OK;
+}

@@ -35,6 +35,7 @@ def test_struct_sizes():
     assert C.sizeof(L.CoralResult) == 40 == L.CORAL_RESULT_DTYPE.itemsize
     assert C.sizeof(L.VerifyParams) == 160 and C.sizeof(L.VerifyJob) == 112
     assert C.sizeof(L.VerifyResult) == 480 == L.VERIFY_RESULT_DTYPE.itemsize
+    assert C.sizeof(L.ScManagerParams) == 88 and L.SC_CANDIDATE_DTYPE.itemsize == 64
 
 
 def test_defaults_follow_reference():

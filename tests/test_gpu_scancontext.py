@@ -157,3 +157,44 @@ def test_rsc_manager_finds_the_revisit(odom_coupled, augment):
         best = got[14 + j][0]
         assert best["nn_idx"] == j and best["min_dist_sc"] < 0.15
         assert abs(best["argmin_shift"] - 30) <= 1 or abs(best["argmin_shift"] - 90) <= 1
+
+
+def test_native_manager_equals_python_mirror_over_a_lap():
+    """cfear_sc_manager (database in HBM, policy in the library's C++) against api.RSCManager (policy in Python, same
+    kernels) over the 68 local maps of the synthetic lap: identical candidate lists, distances and guesses for every
+    node, with and without the odometry coupling / the augmentations."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples"))
+    import loop_closure_demo as demo
+    from oracle import pyoracle as O
+    from tbv_slam_public_amd import api
+    sc = demo.circle_scene()
+    n = 68
+    gt = np.stack([sc.pose_at(f, n) for f in range(n)])
+    poses = np.array([demo.xyt_compose(demo.xyt_inverse(gt[0]), g) for g in gt])
+    peaks = []
+    for f in range(n):
+        img = sc.render(f, n)
+        sr, si, cnt = O.kstrongest(img, 40, 60)
+        peaks.append(O.kstrongest_cloud(sr, si, cnt, 0.0438, 2.5, mask=O.peaks(img, 40, sr, cnt)))
+    maps = []
+    for i in range(n - 1):
+        merged = [demo.transform_cloud(peaks[j], poses[j]) for j in (i - 1, i, i + 1) if 0 <= j < n]
+        maps.append(demo.transform_cloud(np.concatenate(merged), demo.xyt_inverse(poses[i])))
+    for kw in (dict(), dict(odometry_coupled_closure=False), dict(augment_sc=False, n_candidates=5)):
+        py, nat = api.RSCManager(**kw), api.RSCManagerNative(**kw)
+        found = 0
+        for i, m in enumerate(maps):
+            py.makeAndSaveScancontextAndKeysRadarCloud(m, poses[i])
+            nat.makeAndSaveScancontextAndKeysRadarCloud(m, poses[i])
+            a, b = py.detectLoopClosureID(), nat.detectLoopClosureID()
+            assert [c["nn_idx"] for c in a] == [c["nn_idx"] for c in b], (kw, i)
+            for ca, cb in zip(a, b):
+                assert ca["argmin_shift"] == cb["argmin_shift"] and ca["yaw_diff_rad"] == cb["yaw_diff_rad"]
+                assert ca["Taug"] == cb["Taug"]
+                for f in ("min_dist", "min_dist_sc", "min_dist_odom"):
+                    np.testing.assert_allclose(ca[f], cb[f], rtol=0, atol=1e-12)
+            found += len(b)
+        assert nat.size() == len(maps) and found > 100
+        nat.close()
