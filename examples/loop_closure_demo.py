@@ -74,7 +74,7 @@ class HipBackend:
         return dict(scan=scan, peaks=np.asarray(peaks))
 
     def scan_context(self):
-        return self.api.RSCManager()
+        return self.api.RSCManagerNative()          # database in HBM, retrieval policy in the library
 
     def odom_bounds(self, rel):
         return self.api.VerifyByOdometry(rel)
