@@ -58,20 +58,19 @@ class HipBackend:
         self.driver = api.radarDriver(api.radarDriverParameters(k_strongest=K, z_min=Z_MIN, range_res=RANGE_RES,
                                                                 min_distance=MIN_DISTANCE))
 
-    def odometry(self, imgs):
-        od = self.api.OdometryKeyframeFuser(1, imgs.shape[1], imgs.shape[2], self.api.odometry_preset("CFEAR-3", "oxford"))
-        poses = []
+    def sequence(self, imgs):
+        """Odometry and graph nodes in one pass: with keep_nodes the pipeline hands out every frame's RadarScan
+        (surface points + compensated peaks cloud), so nothing is filtered or featurised twice."""
+        od = self.api.OdometryKeyframeFuser(1, imgs.shape[1], imgs.shape[2],
+                                            self.api.odometry_preset("CFEAR-3", "oxford", keep_nodes=1))
+        poses, nodes = [], []
         for f in range(imgs.shape[0]):
             info = od.process(imgs[f:f + 1], imgs[f + 1:f + 2] if f + 1 < imgs.shape[0] else None)
             poses.append(info["pose"][0].copy())
+            nd = od.node(0)                                                      # every frame is a keyframe here
+            nodes.append(dict(scan=nd["scan"], peaks=nd["peaks"]))
         od.close()
-        return np.array(poses)
-
-    def node(self, img, mot):
-        cloud, peaks = self.driver.CallbackOffline(img)
-        peaks = self.api.Compensate(np.array(peaks), mot, False)                 # odometrykeyframefuser.cpp:146-150
-        scan = self.api.MapPointNormal(np.array(cloud), RES, (0.0, 0.0), True, compensate=mot, ccw=False)
-        return dict(scan=scan, peaks=np.asarray(peaks))
+        return np.array(poses), nodes
 
     def scan_context(self):
         return self.api.RSCManagerNative()          # database in HBM, retrieval policy in the library
@@ -94,12 +93,8 @@ def run(backend, n_frames=68, scene=None, log=None):
     imgs = np.stack([sc.render(f, n_frames) for f in range(n_frames)])
     gt = np.stack([sc.pose_at(f, n_frames) for f in range(n_frames)])
     gt = np.array([xyt_compose(xyt_inverse(gt[0]), g) for g in gt])             # odometry starts at the identity
-    poses = backend.odometry(imgs)
-    # graph nodes: every frame is a keyframe here (2.5 m between sweeps > 1.5 m); TprevMot = motion of the previous step
-    nodes = []
-    for f in range(n_frames):
-        mot = xyt_compose(xyt_inverse(poses[f - 2]), poses[f - 1]) if f >= 2 else np.zeros(3)
-        nodes.append(backend.node(imgs[f], mot))
+    # graph nodes: every frame is a keyframe here (2.5 m between sweeps > 1.5 m)
+    poses, nodes = backend.sequence(imgs)
     rsc = backend.scan_context()
     cands = []
     for i in range(n_frames - 1):                                                # the closure thread trails the odometry by one node

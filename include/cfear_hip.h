@@ -490,7 +490,9 @@ typedef struct cfear_odometry_params {
                                            rotated first, radar_driver.cpp:74-90; desc then describes that source layout */
   double min_keyframe_dist, min_keyframe_rot_deg, downsample_factor;
   int32_t estimate_cov_by_sampling;     /* par.estimate_cov_by_sampling (false), odometrykeyframefuser.h:104 */
-  int32_t pad2;
+  int32_t keep_nodes;                   /* 1: also build what RadarScan needs (types.h:119-122): the peaks cloud of every
+                                           frame, compensated like the cloud (odometrykeyframefuser.cpp:146-150), so that
+                                           cfear_odometry_get_scan / _get_cloud / _get_peaks can hand out graph nodes */
   cfear_cov_sampling_params cov_sampling;   /* cov_sampling_* (:107-110) */
 } cfear_odometry_params;
 void cfear_odometry_params_default(cfear_odometry_params* p);   /* CFEAR-3 preset, Oxford */
@@ -534,6 +536,15 @@ int cfear_odometry_process_prefetch(cfear_odometry* od, const uint8_t* polar, co
  * estimate_cov_by_sampling is set and the fit succeeded (odometrykeyframefuser.cpp:196, 203-208).
  * sampled (optional, [n_streams]) receives 1 where the sampled covariance was used.                */
 int cfear_odometry_get_covariance(cfear_odometry* od, double* cov, int32_t* sampled);
+/* The RadarScan of a stream's LAST processed frame (scan_, odometrykeyframefuser.cpp:172, 244) -- call after a frame
+ * whose keyframe_added is set to collect a pose-graph node; valid until the next cfear_odometry_process:
+ *   get_scan   a copy of cloud_normal_ (MapPointNormal) as a new handle (cfear_scan_destroy it)
+ *   get_cloud  cloud_nopeaks_: the filtered cloud after Compensate (what the surface points were built from)
+ *   get_peaks  cloud_peaks_: the AxialNonMaxSupress subset after Compensate (needs par.keep_nodes)
+ * xyzi: host or device buffer [cap][4], or NULL to query the count in *n_out.                                  */
+int cfear_odometry_get_scan(cfear_odometry* od, int32_t stream, cfear_scan** out);
+int cfear_odometry_get_cloud(cfear_odometry* od, int32_t stream, float* xyzi, int32_t cap, int32_t* n_out);
+int cfear_odometry_get_peaks(cfear_odometry* od, int32_t stream, float* xyzi, int32_t cap, int32_t* n_out);
 int cfear_odometry_destroy(cfear_odometry* od);
 
 #ifdef __cplusplus

@@ -171,7 +171,7 @@ class OdometryParams(C.Structure):
                 ("weight_intensity", C.c_int32), ("use_guess", C.c_int32), ("compensate", C.c_int32),
                 ("radar_ccw", C.c_int32), ("use_keyframe", C.c_int32), ("rotate_ccw", C.c_int32),
                 ("min_keyframe_dist", C.c_double), ("min_keyframe_rot_deg", C.c_double),
-                ("downsample_factor", C.c_double), ("estimate_cov_by_sampling", C.c_int32), ("pad2", C.c_int32),
+                ("downsample_factor", C.c_double), ("estimate_cov_by_sampling", C.c_int32), ("keep_nodes", C.c_int32),
                 ("cov_sampling", CovSamplingParams)]
 
 
@@ -203,6 +203,7 @@ EXPORTS = [
     "cfear_cost_evaluate", "cfear_cost_normal_eq", "cfear_cost_destroy",
     "cfear_odometry_params_default", "cfear_odometry_params_preset", "cfear_odometry_create", "cfear_odometry_process",
     "cfear_odometry_process_prefetch", "cfear_odometry_get_covariance", "cfear_odometry_destroy",
+    "cfear_odometry_get_scan", "cfear_odometry_get_cloud", "cfear_odometry_get_peaks",
 ]
 
 _LIB = None
@@ -295,6 +296,9 @@ def lib():
     L.cfear_cost_destroy.argtypes = [vp]
     L.cfear_odometry_params_default.argtypes = [C.POINTER(OdometryParams)]
     L.cfear_odometry_params_default.restype = None
+    L.cfear_odometry_get_scan.argtypes = [vp, C.c_int32, C.POINTER(vp)]
+    L.cfear_odometry_get_cloud.argtypes = [vp, C.c_int32, vp, C.c_int32, C.POINTER(C.c_int32)]
+    L.cfear_odometry_get_peaks.argtypes = [vp, C.c_int32, vp, C.c_int32, C.POINTER(C.c_int32)]
     L.cfear_odometry_params_preset.argtypes = [C.POINTER(OdometryParams), C.c_int32, C.c_int32]
     L.cfear_odometry_create.argtypes = [vp, C.c_int32, C.POINTER(PolarDesc), C.POINTER(OdometryParams),
                                         C.POINTER(vp)]

@@ -274,6 +274,13 @@ class MapPointNormal:
         n = int(cld.shape[0])
         self.ctx.check(lib.cfear_scan_create(self.ctx.h, _ptr(cld)[0], n, C.byref(fp), C.byref(self._h)))
 
+    @classmethod
+    def _from_handle(cls, h, ctx):
+        """Wraps a cfear_scan* the library handed out (cfear_odometry_get_scan); the wrapper owns it."""
+        m = cls.__new__(cls)
+        m.ctx, m._h = ctx, h
+        return m
+
     def GetSize(self):
         return self.ctx._lib.cfear_scan_size(self._h)
 
@@ -1127,6 +1134,29 @@ class OdometryKeyframeFuser:
         self.ctx.check(self.ctx._lib.cfear_odometry_process_prefetch(self._h, _ptr(polar)[0], _ptr(polar_next)[0],
                                                                      self._info.ctypes.data))
         return self._info.copy()
+
+    def node(self, stream, device=False):
+        """The RadarScan of `stream`'s last processed frame (scan_, odometrykeyframefuser.cpp:172, 244; types.h:119-122)
+        -> dict(scan=MapPointNormal copy of cloud_normal_, cloud=cloud_nopeaks_, peaks=cloud_peaks_ (par.keep_nodes)).
+        Clouds are NumPy arrays, or torch CUDA tensors with device=True.  Valid until the next process()."""
+        lib = self.ctx._lib
+        h = C.c_void_p()
+        self.ctx.check(lib.cfear_odometry_get_scan(self._h, int(stream), C.byref(h)))
+        out = {"scan": MapPointNormal._from_handle(h, self.ctx)}
+        for name, fn in (("cloud", lib.cfear_odometry_get_cloud), ("peaks", lib.cfear_odometry_get_peaks)):
+            if name == "peaks" and not self.par.keep_nodes:
+                continue
+            n = C.c_int32()
+            self.ctx.check(fn(self._h, int(stream), None, 0, C.byref(n)))
+            if device:
+                import torch
+                buf = torch.empty((n.value, 4), dtype=torch.float32, device="cuda:%d" % self.ctx.device)
+            else:
+                buf = np.empty((n.value, 4), np.float32)
+            if n.value:
+                self.ctx.check(fn(self._h, int(stream), _ptr(buf)[0], n.value, C.byref(n)))
+            out[name] = buf
+        return out
 
     def covariance(self):
         """cov_current of every stream after the last frame -> (cov [n_streams,6,6], sampled [n_streams] bool):

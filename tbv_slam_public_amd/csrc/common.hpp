@@ -103,12 +103,15 @@ struct cfear_scan {
 size_t cfear_scan_slab_bytes(int cap);
 ScanView cfear_scan_view(void* slab, int cap);
 int cfear_scan_alloc(cfear_ctx* ctx, int cap, cfear_scan** out);
+int cfear_scan_clone_view(cfear_ctx* ctx, const ScanView& src, int n_cells, cfear_scan** out);
 
 // ---------------------------------------------------------------------------------------------
 // cross-file entry points (device-pointer level; used by the batched odometry pipeline)
 // ---------------------------------------------------------------------------------------------
 int cfear_kstrong_device(cfear_ctx* ctx, const uint8_t* d_polar, const cfear_polar_desc* desc,
                          const cfear_kstrong_params* par, const cfear_kstrong_out* o);
+int cfear_compensate_batch_device(cfear_ctx* ctx, float* d_xyzi, size_t cloud_stride_points, const int32_t* d_n,
+                                  const double* d_mot, int n_clouds, int max_points, int ccw);
 int cfear_rotate_ccw_device(cfear_ctx* ctx, const uint8_t* d_src, const cfear_polar_desc* src_desc, uint8_t* d_dst,
                             int dst_stride, int64_t dst_batch_stride);
 int cfear_cacfar_device(cfear_ctx* ctx, const uint8_t* d_polar, const cfear_polar_desc* desc,

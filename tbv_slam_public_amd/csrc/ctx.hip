@@ -164,6 +164,34 @@ int cfear_scan_alloc(cfear_ctx* ctx, int cap, cfear_scan** out) {
   return CFEAR_OK;
 }
 
+// Device-to-device copy of a scan (n cells of every array + the counter) into a fresh handle.
+int cfear_scan_clone_view(cfear_ctx* ctx, const ScanView& src, int n, cfear_scan** out) {
+  cfear_scan* s = nullptr;
+  const int rc = cfear_scan_alloc(ctx, std::max(n, 1), &s);
+  if (rc != CFEAR_OK) return rc;
+  const ScanView& d = s->view;
+  const size_t c = (size_t)n;
+  auto cp = [&](void* dst, const void* from, size_t bytes) {
+    return bytes == 0 ? hipSuccess : hipMemcpyAsync(dst, from, bytes, hipMemcpyDeviceToDevice, ctx->stream);
+  };
+  hipError_t e = cp(d.n_cells, src.n_cells, 4);
+  if (e == hipSuccess) e = cp(d.mean_f, src.mean_f, c * sizeof(float2));
+  if (e == hipSuccess) e = cp(d.sorted_x, src.sorted_x, c * 4);
+  if (e == hipSuccess) e = cp(d.sorted_y, src.sorted_y, c * 4);
+  if (e == hipSuccess) e = cp(d.sorted_idx, src.sorted_idx, c * 4);
+  if (e == hipSuccess) e = cp(d.mean, src.mean, c * sizeof(double2));
+  if (e == hipSuccess) e = cp(d.normal, src.normal, c * sizeof(double2));
+  if (e == hipSuccess) e = cp(d.lambda, src.lambda, c * sizeof(double2));
+  if (e == hipSuccess) e = cp(d.cov, src.cov, c * sizeof(double4));
+  if (e == hipSuccess) e = cp(d.scale, src.scale, c * 8);
+  if (e == hipSuccess) e = cp(d.avg_intensity, src.avg_intensity, c * 8);
+  if (e == hipSuccess) e = cp(d.nsamples, src.nsamples, c * 4);
+  if (e != hipSuccess) { cfear_scan_destroy(s); return cfear_set_error(ctx, CFEAR_ERR_HIP, "scan copy failed: %s", hipGetErrorString(e)); }
+  s->n_cells_host = n;
+  *out = s;
+  return CFEAR_OK;
+}
+
 // ---- C-ABI ---------------------------------------------------------------------------------------
 extern "C" {
 
@@ -303,6 +331,7 @@ void cfear_odometry_params_default(cfear_odometry_params* p) {
   p->min_keyframe_rot_deg = 5.0;
   p->downsample_factor = 1.0;
   p->estimate_cov_by_sampling = 0;
+  p->keep_nodes = 0;
   cfear_cov_sampling_params_default(&p->cov_sampling);
 }
 

@@ -74,6 +74,15 @@ struct cfear_odometry {
   int32_t* d_npts2[2] = {nullptr, nullptr};  //   may run while the host applies this frame's policy
   float* d_xyzi = nullptr;                   // buffer of the frame being processed
   int32_t* d_npts = nullptr;
+  // par.keep_nodes: the peaks cloud of every frame (cloud_peaks_ of RadarScan), double-buffered like the cloud
+  float* d_pk2[2] = {nullptr, nullptr};
+  int32_t* d_npk2[2] = {nullptr, nullptr};
+  float* d_pk = nullptr;
+  int32_t* d_npk = nullptr;
+  double* d_mot = nullptr;                   // [B][3] TprevMot of this frame (peaks compensation)
+  double* h_mot = nullptr;
+  int32_t* h_npk = nullptr;
+  std::vector<int> last_slab;                // slab that holds each stream's last processed scan
   int cur_buf = 0;
   const uint8_t* prefetched = nullptr;       // polar pointer whose filter output sits in buffer cur_buf ^ 1
   hipEvent_t ev_results = nullptr;
@@ -126,10 +135,10 @@ extern "C" int cfear_odometry_destroy(cfear_odometry* od) {
   if (od->ev_results) (void)hipEventDestroy(od->ev_results);
   if (od->ev_jobs) (void)hipEventDestroy(od->ev_jobs);
   if (od->copy_stream) (void)hipStreamDestroy(od->copy_stream);
-  void* dev[] = {od->d_polar, od->d_rot, od->d_sel, od->d_xyzi2[0], od->d_xyzi2[1], od->d_npts2[0], od->d_npts2[1], od->d_slabs, od->d_surf_jobs, od->d_reg_jobs,
+  void* dev[] = {od->d_pk2[0], od->d_pk2[1], od->d_npk2[0], od->d_npk2[1], od->d_mot, od->d_polar, od->d_rot, od->d_sel, od->d_xyzi2[0], od->d_xyzi2[1], od->d_npts2[0], od->d_npts2[1], od->d_slabs, od->d_surf_jobs, od->d_reg_jobs,
                  od->d_results, od->d_status, od->d_ncells, od->d_surf_scratch, od->d_reg_scratch, od->d_samples};
   for (void* p : dev) if (p) (void)hipFree(p);
-  void* host[] = {od->h_surf_jobs, od->h_reg_jobs, od->h_results, od->h_status, od->h_npts, od->h_ncells, od->h_samples};
+  void* host[] = {od->h_mot, od->h_npk, od->h_surf_jobs, od->h_reg_jobs, od->h_results, od->h_status, od->h_npts, od->h_ncells, od->h_samples};
   for (void* p : host) if (p) (void)hipHostFree(p);
   delete od;
   return CFEAR_OK;
@@ -163,7 +172,17 @@ extern "C" int cfear_odometry_create(cfear_ctx* ctx, int32_t n_streams, const cf
   od->slab_bytes = cfear_scan_slab_bytes(od->cell_cap);
   const size_t nsel = (size_t)B * rows * std::max(k, 1);
   bool ok = true;
-  ok = ok && dalloc(&od->d_sel, nsel * 4 + nsel + (size_t)B * rows * 4 + 1024);
+  ok = ok && dalloc(&od->d_sel, nsel * 4 + 2 * (nsel + 256) + (size_t)B * rows * 4 + 1024);   // + is_peak (keep_nodes)
+  if (par->keep_nodes) {
+    for (int i = 0; i < 2; i++) {
+      ok = ok && dalloc(&od->d_pk2[i], (size_t)B * od->cap_points * 16);
+      ok = ok && dalloc(&od->d_npk2[i], (size_t)B * 4);
+    }
+    ok = ok && dalloc(&od->d_mot, (size_t)B * 3 * sizeof(double));
+    ok = ok && halloc(&od->h_mot, (size_t)B * 3 * sizeof(double));
+    ok = ok && halloc(&od->h_npk, (size_t)B * 4);
+  }
+  od->last_slab.assign(B, -1);
   for (int i = 0; i < 2; i++) {
     ok = ok && dalloc(&od->d_xyzi2[i], (size_t)B * od->cap_points * 16);
     ok = ok && dalloc(&od->d_npts2[i], (size_t)B * 4);
@@ -235,6 +254,8 @@ static int run_filter(cfear_odometry* od, const uint8_t* polar, int buf) {
   }
   if (par.filter_type == CFEAR_FILTER_CACFAR) {
     cfear_cacfar_params cp = par.cacfar;
+    if (par.keep_nodes)    // CA-CFAR produces no peaks cloud (radar_driver.cpp:52-56)
+      CFEAR_HIP_CHECK(ctx, hipMemsetAsync(od->d_npk2[buf], 0, (size_t)B * 4, ctx->stream));
     return cfear_cacfar_device(ctx, d_polar, &dd, &cp, od->d_xyzi2[buf], od->d_npts2[buf], od->cap_points, nullptr);
   }
   const size_t nsel = (size_t)B * rows * k;
@@ -246,6 +267,12 @@ static int run_filter(cfear_odometry* od, const uint8_t* polar, int buf) {
   o.n_points = od->d_npts2[buf];
   cfear_kstrong_params kp = par.kstrong;
   kp.want_peaks = 0;     // the peaks cloud feeds CorAl / Scan Context, not the matcher
+  if (par.keep_nodes) {  // ... unless the caller builds graph nodes from this pipeline (RadarScan::cloud_peaks_)
+    kp.want_peaks = 1;
+    o.is_peak = (uint8_t*)(od->d_sel + nsel * 4 + (nsel + 255) / 256 * 256 + (size_t)B * rows * 4 + 256);
+    o.xyzi_peaks = od->d_pk2[buf];
+    o.n_peaks = od->d_npk2[buf];
+  }
   if (od->cap_points != rows * k)
     return cfear_set_error(ctx, CFEAR_ERR_CAPACITY, "rows*k = %d exceeds %d points per scan", rows * k, od->cap_points);
   return cfear_kstrong_device(ctx, d_polar, &dd, &kp, &o);
@@ -279,6 +306,8 @@ extern "C" int cfear_odometry_process_prefetch(cfear_odometry* od, const uint8_t
   od->prefetched = nullptr;
   od->d_xyzi = od->d_xyzi2[od->cur_buf];
   od->d_npts = od->d_npts2[od->cur_buf];
+  od->d_pk = od->d_pk2[od->cur_buf];
+  od->d_npk = od->d_npk2[od->cur_buf];
   // ---- C + N: compensate with the previous motion, surface points (odometrykeyframefuser.cpp:146-161)
   const size_t sjb = cfear_surface_job_bytes();
   for (int b = 0; b < B; b++) {
@@ -287,6 +316,8 @@ extern "C" int cfear_odometry_process_prefetch(cfear_odometry* od, const uint8_t
     st.free_slabs.pop_back();
     double mot[3];
     aff_to_xyt(st.Tmot, mot);                                     // Compensate(cloud, TprevMot, ccw)
+    od->last_slab[b] = st.cur_slab;
+    if (par.keep_nodes) { od->h_mot[3 * b] = mot[0]; od->h_mot[3 * b + 1] = mot[1]; od->h_mot[3 * b + 2] = mot[2]; }
     cfear_surface_fill_job(od->h_surf_jobs + (size_t)b * sjb, od->d_xyzi + (size_t)b * od->cap_points * 4,
                            od->d_npts + b, 0, par.compensate, mot, od->views[(size_t)b * od->slabs_per_stream + st.cur_slab]);
   }
@@ -348,6 +379,15 @@ extern "C" int cfear_odometry_process_prefetch(cfear_odometry* od, const uint8_t
       CFEAR_HIP_CHECK(ctx, hipMemcpyAsync(od->h_samples, od->d_samples, (size_t)n_jobs * od->fit.m * sizeof(cfear_reg_result),
                                           hipMemcpyDeviceToHost, ctx->stream));
     }
+  }
+  if (par.keep_nodes) {
+    // Compensate(*cloud_peaks, TprevMot, ccw) (odometrykeyframefuser.cpp:149): off the critical path, behind the matcher
+    if (par.compensate) {
+      CFEAR_HIP_CHECK(ctx, hipMemcpyAsync(od->d_mot, od->h_mot, (size_t)B * 3 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+      rc = cfear_compensate_batch_device(ctx, od->d_pk, (size_t)od->cap_points, od->d_npk, od->d_mot, B, od->cap_points, par.radar_ccw);
+      if (rc != CFEAR_OK) return rc;
+    }
+    CFEAR_HIP_CHECK(ctx, hipMemcpyAsync(od->h_npk, od->d_npk, (size_t)B * 4, hipMemcpyDeviceToHost, ctx->stream));
   }
   CFEAR_HIP_CHECK(ctx, hipMemcpyAsync(od->h_status, od->d_status, (size_t)B * 4, hipMemcpyDeviceToHost, ctx->stream));
   CFEAR_HIP_CHECK(ctx, hipMemcpyAsync(od->h_npts, od->d_npts, (size_t)B * 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -443,4 +483,42 @@ extern "C" int cfear_odometry_process_prefetch(cfear_odometry* od, const uint8_t
     aff_to_xyt(Tcurrent, fi.pose);
   }
   return first_error;
+}
+
+// ---- graph-node export: the RadarScan of the last processed frame (types.h:119-122; scan_ at
+// odometrykeyframefuser.cpp:172, 244) --------------------------------------------------------------------------
+extern "C" int cfear_odometry_get_scan(cfear_odometry* od, int32_t stream, cfear_scan** out) {
+  if (!od || !out || stream < 0 || stream >= od->n_streams) return CFEAR_ERR_INVALID_ARGUMENT;
+  cfear_ctx* ctx = od->ctx;
+  *out = nullptr;
+  if (od->last_slab[stream] < 0) return cfear_set_error(ctx, CFEAR_ERR_INVALID_ARGUMENT, "stream %d: no frame processed yet", stream);
+  CFEAR_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  const ScanView& v = od->views[(size_t)stream * od->slabs_per_stream + od->last_slab[stream]];
+  return cfear_scan_clone_view(ctx, v, od->h_ncells[stream], out);
+}
+
+static int copy_cloud_out(cfear_odometry* od, const float* d_src, int n, float* xyzi, int32_t cap, int32_t* n_out) {
+  cfear_ctx* ctx = od->ctx;
+  if (n_out) *n_out = n;
+  if (!xyzi) return CFEAR_OK;
+  if (n > cap) return cfear_set_error(ctx, CFEAR_ERR_CAPACITY, "%d points > cap %d", n, cap);
+  if (n == 0) return CFEAR_OK;
+  CFEAR_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  const bool dev = cfear_is_device_ptr(xyzi);
+  CFEAR_HIP_CHECK(ctx, hipMemcpyAsync(xyzi, d_src, (size_t)n * 16, dev ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, ctx->stream));
+  if (!dev) CFEAR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  return CFEAR_OK;
+}
+
+extern "C" int cfear_odometry_get_cloud(cfear_odometry* od, int32_t stream, float* xyzi, int32_t cap, int32_t* n_out) {
+  if (!od || stream < 0 || stream >= od->n_streams || cap < 0) return CFEAR_ERR_INVALID_ARGUMENT;
+  if (od->last_slab[stream] < 0) return cfear_set_error(od->ctx, CFEAR_ERR_INVALID_ARGUMENT, "stream %d: no frame processed yet", stream);
+  return copy_cloud_out(od, od->d_xyzi + (size_t)stream * od->cap_points * 4, od->h_npts[stream], xyzi, cap, n_out);
+}
+
+extern "C" int cfear_odometry_get_peaks(cfear_odometry* od, int32_t stream, float* xyzi, int32_t cap, int32_t* n_out) {
+  if (!od || stream < 0 || stream >= od->n_streams || cap < 0) return CFEAR_ERR_INVALID_ARGUMENT;
+  if (!od->par.keep_nodes) return cfear_set_error(od->ctx, CFEAR_ERR_INVALID_ARGUMENT, "peaks clouds are kept only with keep_nodes = 1");
+  if (od->last_slab[stream] < 0) return cfear_set_error(od->ctx, CFEAR_ERR_INVALID_ARGUMENT, "stream %d: no frame processed yet", stream);
+  return copy_cloud_out(od, od->d_pk + (size_t)stream * od->cap_points * 4, od->h_npk[stream], xyzi, cap, n_out);
 }

@@ -108,6 +108,17 @@ __global__ __launch_bounds__(256) void compensate_kernel(float4* xyzi, int n, do
   xyzi[i] = compensate_point(xyzi[i], mot, ccw != 0);
 }
 
+// Compensate for a batch of clouds with their own motion and device-side point counts (the peaks clouds of the
+// batched odometry, odometrykeyframefuser.cpp:146-150): grid (chunks, clouds).
+__global__ __launch_bounds__(256) void compensate_batch_kernel(float4* xyzi, size_t cloud_stride, const int32_t* n_pts,
+                                                               const double* mot3, int ccw) {
+  const int b = blockIdx.y;
+  const int n = n_pts[b];
+  const double mot[3] = {mot3[3 * b], mot3[3 * b + 1], mot3[3 * b + 2]};
+  float4* c = xyzi + (size_t)b * cloud_stride;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) c[i] = compensate_point(c[i], mot, ccw != 0);
+}
+
 // symmetric 2x2 eigen decomposition (one Jacobi rotation), same formula as the oracle's sym2_eig
 __device__ __forceinline__ void sym2_eig(double a, double b, double d, double& l0, double& l1, double v0[2]) {
   double c = 1.0, s = 0.0, e0 = a, e1 = d;
@@ -631,6 +642,18 @@ int cfear_surface_launch(cfear_ctx* ctx, const void* d_jobs, int n_jobs, const c
   ProfScope ps(ctx, "surface_points");
   hipLaunchKernelGGL(surface_points_kernel, dim3(n_jobs), dim3(kSurfThreads), cfear_surface_lds_bytes(), ctx->stream,
                      (const SurfJob*)d_jobs, cm);
+  CFEAR_HIP_CHECK(ctx, hipGetLastError());
+  return CFEAR_OK;
+}
+
+// d_xyzi [n_clouds][cloud_stride_points][4], d_n [n_clouds], d_mot [n_clouds][3] all device
+int cfear_compensate_batch_device(cfear_ctx* ctx, float* d_xyzi, size_t cloud_stride_points, const int32_t* d_n, const double* d_mot,
+                                  int n_clouds, int max_points, int ccw) {
+  if (n_clouds <= 0) return CFEAR_OK;
+  ProfScope ps(ctx, "compensate_peaks");
+  const int chunks = std::max(1, std::min(16, (max_points + 255) / 256));
+  hipLaunchKernelGGL(compensate_batch_kernel, dim3(chunks, n_clouds), dim3(256), 0, ctx->stream, (float4*)d_xyzi, cloud_stride_points,
+                     d_n, d_mot, ccw);
   CFEAR_HIP_CHECK(ctx, hipGetLastError());
   return CFEAR_OK;
 }

@@ -26,6 +26,19 @@ class OracleBackend:
         return dict(scan=O.surface_points(O.compensate(cloud, mot, False), 3.0, 1.0, (0, 0), True),
                     peaks=O.compensate(peaks, mot, False))
 
+    def sequence(self, imgs):
+        poses = self.odometry(imgs)
+        nodes = []
+        for f in range(imgs.shape[0]):                        # TprevMot = the motion of the previous step
+            mot = self._rel(poses[f - 2], poses[f - 1]) if f >= 2 else np.zeros(3)
+            nodes.append(self.node(imgs[f], mot))
+        return poses, nodes
+
+    def _rel(self, a, b):
+        m = self.O.xyt_compose(self.O.xyt_inverse(a), b)
+        m[2] = (m[2] + np.pi) % (2 * np.pi) - np.pi          # the fuser keeps Tmot as a matrix: its yaw is in (-pi, pi]
+        return m
+
     def scan_context(self):
         from tbv_slam_public_amd import api
         O = self.O
