@@ -210,6 +210,9 @@ def main():
     ap.add_argument("--bins-major", action="store_true",
                     help="feed the images as [range bins][azimuths] (non-Oxford drivers): adds the GPU rotation of "
                          "radarDriver::Callback (radar_driver.cpp:74-90) to every step; not the BASELINE layout")
+    ap.add_argument("--keep-nodes", action="store_true",
+                    help="also keep every frame's compensated peaks cloud (pose-graph nodes, cfear_odometry_get_*); "
+                         "off in the BASELINE configuration")
     ap.add_argument("--cov-sampling", action="store_true",
                     help="odometry: also estimate every frame's covariance by cost sampling (27 GetCost per "
                          "registration, odometrykeyframefuser.cpp:203-208; off in the reference's presets)")
@@ -256,7 +259,8 @@ def main():
         frames = torch.rot90(frames, -1, dims=(2, 3)).contiguous()   # [F][B][COLS][ROWS]: what such a driver publishes
         torch.cuda.synchronize()                                     # the library enqueues on its own stream
     od = api.OdometryKeyframeFuser(B, *frames.shape[2:], api.odometry_params(estimate_cov_by_sampling=int(args.cov_sampling),
-                                                                             rotate_ccw=int(args.bins_major)), ctx=ctx)
+                                                                             rotate_ccw=int(args.bins_major),
+                                                                             keep_nodes=int(args.keep_nodes)), ctx=ctx)
 
     def barrier():
         torch.cuda.synchronize()
