@@ -191,6 +191,41 @@ class n_scan_normal_reg {
   double score_ = 0;
 };
 
+// radarDriver + OdometryKeyframeFuser for n independent sequences, one frame per call (cfear_odometry_*): the whole
+// path polar image -> pose on the GPU; with par.keep_nodes the RadarScan of every frame can be collected.
+class OdometryKeyframeFuser {
+ public:
+  OdometryKeyframeFuser(Context& ctx, int n_streams, int rows, int cols, const cfear_odometry_params* par = nullptr)
+      : ctx_(ctx), n_(n_streams) {
+    cfear_odometry_params def;
+    if (!par) { cfear_odometry_params_default(&def); par = &def; }
+    cfear_polar_desc d{rows, cols, cols, n_streams, (int64_t)rows * cols};
+    ctx_.check(cfear_odometry_create(ctx_.get(), n_streams, &d, par, &od_));
+  }
+  ~OdometryKeyframeFuser() { cfear_odometry_destroy(od_); }
+  OdometryKeyframeFuser(const OdometryKeyframeFuser&) = delete;
+  OdometryKeyframeFuser& operator=(const OdometryKeyframeFuser&) = delete;
+  // polar: [n_streams][rows][cols] uint8 (host or device); polar_next (optional): next frame, filtered ahead
+  std::vector<cfear_frame_info> processFrame(const uint8_t* polar, const uint8_t* polar_next = nullptr) {
+    std::vector<cfear_frame_info> info((size_t)n_);
+    ctx_.check(cfear_odometry_process_prefetch(od_, polar, polar_next, info.data()));
+    return info;
+  }
+  // scan_ of a stream's last frame (odometrykeyframefuser.cpp:172, 244): surface points + the two clouds
+  cfear_scan* GetScan(int stream) { cfear_scan* s = nullptr; ctx_.check(cfear_odometry_get_scan(od_, stream, &s)); return s; }
+  PointCloud GetCloud(int stream, bool peaks) {
+    int32_t n = 0;
+    ctx_.check((peaks ? cfear_odometry_get_peaks : cfear_odometry_get_cloud)(od_, stream, nullptr, 0, &n));
+    PointCloud c((size_t)n);
+    if (n) ctx_.check((peaks ? cfear_odometry_get_peaks : cfear_odometry_get_cloud)(od_, stream, &c[0].x, n, &n));
+    return c;
+  }
+ private:
+  Context& ctx_;
+  cfear_odometry* od_ = nullptr;
+  int n_;
+};
+
 }  // namespace CFEAR_Radarodometry
 
 // CorAlRadarQuality (coral_alignment_quality AlignmentQuality.cpp:99-230) over two peak clouds.
