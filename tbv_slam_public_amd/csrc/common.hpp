@@ -109,7 +109,7 @@ int cfear_scan_clone_view(cfear_ctx* ctx, const ScanView& src, int n_cells, cfea
 // cross-file entry points (device-pointer level; used by the batched odometry pipeline)
 // ---------------------------------------------------------------------------------------------
 int cfear_kstrong_device(cfear_ctx* ctx, const uint8_t* d_polar, const cfear_polar_desc* desc,
-                         const cfear_kstrong_params* par, const cfear_kstrong_out* o);
+                         const cfear_kstrong_params* par, const cfear_kstrong_out* o, bool dense_halo = false);
 int cfear_compensate_batch_device(cfear_ctx* ctx, float* d_xyzi, size_t cloud_stride_points, const int32_t* d_n,
                                   const double* d_mot, int n_clouds, int max_points, int ccw);
 int cfear_rotate_ccw_device(cfear_ctx* ctx, const uint8_t* d_src, const cfear_polar_desc* src_desc, uint8_t* d_dst,

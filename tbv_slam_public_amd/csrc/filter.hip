@@ -43,6 +43,8 @@ struct KStrongArgs {
   uint8_t* is_peak;
   int32_t* row_valid;      // [batch][rows][2]: kept bins beyond min_range_bin (all, peaks) -> cloud offsets
   int min_range_bin;
+  int dense_halo;          // 1: the image is a padded copy of a DENSE cv::Mat (the pipeline's rotated buffer): bins read
+                           // past a row end are the first bins of the next row, not the padding
 };
 
 // bit 7 of every byte of the result is set iff that byte of x is >= t (0 <= t <= 255).
@@ -337,11 +339,13 @@ __global__ __launch_bounds__(256) void kstrongest_rows_kernel(const KStrongArgs 
   if (do_peaks) {
     const long long total = (long long)a.rows * a.stride;
     if (lane < 6) {
-      const long long lin = row_lin - 6 + lane;
+      long long lin = row_lin - 6 + lane;
+      if (a.dense_halo) lin = r > 0 ? row_lin - a.stride + a.cols - 6 + lane : -1;       // last bins of the previous row
       rowbuf[-6 + lane] = lin >= 0 ? img[lin] : (uint8_t)0;
     } else if (lane >= 8 && lane < 14) {
       const int q = a.cols + (lane - 8);
-      const long long lin = row_lin + q;
+      long long lin = row_lin + q;
+      if (a.dense_halo) lin = r + 1 < a.rows ? row_lin + a.stride + (lane - 8) : total;   // first bins of the next row
       rowbuf[q] = lin < total ? img[lin] : (uint8_t)0;
     }
     if (lane < 2) hist[lane] = 0;
@@ -717,7 +721,7 @@ void launch_kstrong(cfear_ctx* ctx, const KStrongArgs& a, bool vec, bool mask, d
 // Device-side entry used by cfear_filter_kstrongest and by the odometry pipeline: everything is
 // already in device memory; outputs that are nullptr are skipped.
 int cfear_kstrong_device(cfear_ctx* ctx, const uint8_t* d_polar, const cfear_polar_desc* desc,
-                         const cfear_kstrong_params* par, const cfear_kstrong_out* o) {
+                         const cfear_kstrong_params* par, const cfear_kstrong_out* o, bool dense_halo) {
   const int z_min_i = (int)par->z_min;                         // radar_driver.cpp:58 float -> int
   KStrongArgs a;
   a.polar = d_polar;
@@ -730,6 +734,7 @@ int cfear_kstrong_device(cfear_ctx* ctx, const uint8_t* d_polar, const cfear_pol
   a.is_peak = o->is_peak;
   const bool want_cloud = o->xyzi || o->n_points || o->xyzi_peaks || o->n_peaks;
   a.row_valid = nullptr;
+  a.dense_halo = (dense_halo && desc->stride != desc->cols) ? 1 : 0;
   {
     const double range_res_ = (double)par->range_res, min_distance_ = (double)par->min_distance;
     a.min_range_bin = (int)std::ceil(min_distance_ / range_res_);            // radar_filters.cpp:315

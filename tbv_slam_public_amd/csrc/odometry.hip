@@ -275,7 +275,9 @@ static int run_filter(cfear_odometry* od, const uint8_t* polar, int buf) {
   }
   if (od->cap_points != rows * k)
     return cfear_set_error(ctx, CFEAR_ERR_CAPACITY, "rows*k = %d exceeds %d points per scan", rows * k, od->cap_points);
-  return cfear_kstrong_device(ctx, d_polar, &dd, &kp, &o);
+  // the rotated buffer is a padded copy of what the reference holds as a dense cv::Mat: AxialNonMaxSupress's reads
+  // past a row end must land on the next row's first bins (radar_filters.cpp:238-298), not on the padding
+  return cfear_kstrong_device(ctx, d_polar, &dd, &kp, &o, par.rotate_ccw != 0);
 }
 
 extern "C" int cfear_odometry_get_covariance(cfear_odometry* od, double* cov, int32_t* sampled) {

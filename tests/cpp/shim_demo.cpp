@@ -3,6 +3,7 @@
 // frame 1 against frame 0 (P2L, loop-closure settings 4 x 10) and prints the result as one line:
 //   n_points0 n_points1 n_cells0 n_cells1 ok x y theta score cov_ok cov_xx cov_yy cov_tt coral_valid joint sep overlap
 //   reg_ok t_be.x t_be.y t_be.theta alignment_quality probability accepted odom_bounds
+//   fuser.x fuser.y fuser.theta fuser.n_cells node_cells node_peaks
 // (cov_*: covariance by cost sampling with the loop-closure constants, loopclosure.cpp:108-112; the last eight: the
 // pair verified as a loop candidate, frame 1 = query, frame 0 = candidate, through tbv_slam::VerifyLoopCandidates).
 // With a fifth argument "bins-major" the file holds [2][cols][rows] images as a non-Oxford driver publishes them.
@@ -58,8 +59,21 @@ int main(int argc, char** argv) {
     const double odom_bounds = tbv_slam::VerifyByOdometry({{1.0, 0.0, 0.0}, {1.2, 0.1, 0.01}});
     tbv_slam::LoopCandidate cand{&m1, &m0, &pk1, &pk0, {2.2, 0.1, 0.01}, {-2.0, 0.2, -0.02}, 0.15, odom_bounds, 0};
     const std::vector<cfear_verify_result> vr = tbv_slam::VerifyLoopCandidates(ctx, {cand});
-    printf(" %d %.12g %.12g %.12g %.12g %.12g %d %.12g\n", vr[0].reg_ok, vr[0].t_be[0], vr[0].t_be[1], vr[0].t_be[2],
+    printf(" %d %.12g %.12g %.12g %.12g %.12g %d %.12g", vr[0].reg_ok, vr[0].t_be[0], vr[0].t_be[1], vr[0].t_be[2],
            vr[0].alignment_quality, vr[0].probability, vr[0].accepted, odom_bounds);
+    // the two sweeps as one sequence through the batched pipeline (1 stream), collecting the second frame's node
+    cfear_odometry_params op;
+    cfear_odometry_params_default(&op);
+    op.keep_nodes = 1;
+    op.rotate_ccw = bins_major ? 1 : 0;
+    OdometryKeyframeFuser fuser(ctx, 1, bins_major ? cols : rows, bins_major ? rows : cols, &op);
+    fuser.processFrame(img.data());
+    const std::vector<cfear_frame_info> fi = fuser.processFrame(img.data() + (size_t)rows * cols);
+    const PointCloud node_peaks = fuser.GetCloud(0, true);
+    cfear_scan* node_scan = fuser.GetScan(0);
+    printf(" %.12g %.12g %.12g %d %d %zu\n", fi[0].pose[0], fi[0].pose[1], fi[0].pose[2], fi[0].n_cells,
+           cfear_scan_size(node_scan), node_peaks.size());
+    cfear_scan_destroy(node_scan);
   } catch (const CfearError& e) {
     fprintf(stderr, "cfear error %d: %s\n", e.status, e.what());
     return 1;

@@ -85,3 +85,13 @@ def test_cpp_mirror_matches_oracle(tmp_path, layout):
     np.testing.assert_allclose(float(v[22]), e["probability"], atol=1e-6)
     assert int(v[23]) == int(e["probability"] > 0.8)
     np.testing.assert_allclose(float(v[24]), ob, rtol=1e-12, atol=1e-15)
+    # the same two sweeps through the batched OdometryKeyframeFuser wrapper (CFEAR-3 defaults), node of frame 1
+    regf = O.reg_params(cost="P2P", loss="Huber", loss_limit=0.1, weight_opt=4, regularization=0.0)
+    fz = O.Fuser(regf, res=3.0, submap_scan_size=4, weight_intensity=True)
+    for f in range(2):
+        sr, si, sc = O.kstrongest(imgs[f], 40, 60)
+        pose, finfo = fz.process(O.kstrongest_cloud(sr, si, sc, 0.0438, 2.5))
+    gp = np.array([float(x) for x in v[25:28]])
+    assert np.abs(gp[:2] - pose[:2]).max() <= 1e-4 and abs(gp[2] - pose[2]) <= 1e-5
+    assert int(v[28]) == int(v[29]) == finfo[0]
+    assert int(v[30]) == pk[1].shape[0]                     # second frame, first motion estimate is identity

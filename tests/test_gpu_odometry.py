@@ -198,3 +198,28 @@ def test_graph_nodes_from_the_pipeline():
                 np.testing.assert_array_equal(a[name], c[name], err_msg=name)
     with pytest.raises(Exception):
         api.OdometryKeyframeFuser(1, 400, 3360).node(0)               # nothing processed yet
+
+
+def test_rotated_input_keeps_the_peaks_border_rule():
+    """The pipeline rotates [range bins][azimuths] images into a buffer with a 128-byte row pitch.  The reference's
+    AxialNonMaxSupress reads bins past a row end through unchecked cv::Mat::at (radar_filters.cpp:238-298): in its
+    dense image those are the first bins of the next azimuth, so the padded copy must behave the same -- the peaks
+    clouds of both layouts must be identical, far-range border bins included."""
+    import torch
+    from tbv_slam_public_amd import api, synth
+    imgs, _, _ = synth.scene_v1(9, 3)
+    imgs = imgs.copy()
+    imgs[:, :, -4:] = 200                                         # strong returns in the last bins of every azimuth
+    imgs[:, ::3, :3] = 250
+    kw = dict(keep_nodes=1, kstrong_range_res=0.0595238, radar_ccw=1)
+    ref = api.OdometryKeyframeFuser(1, 400, 3360, api.odometry_params(**kw))
+    rot = api.OdometryKeyframeFuser(1, 3360, 400, api.odometry_params(rotate_ccw=1, **kw))
+    for f in range(3):
+        a = ref.process(imgs[f:f + 1])
+        b = rot.process(np.ascontiguousarray(np.rot90(imgs[f:f + 1], -1, axes=(1, 2))))
+        for name in a.dtype.names:
+            np.testing.assert_array_equal(a[name], b[name], err_msg=name)
+        na, nb = ref.node(0), rot.node(0)
+        assert na["peaks"].shape[0] > 500
+        np.testing.assert_array_equal(na["peaks"], nb["peaks"])
+        np.testing.assert_array_equal(na["cloud"], nb["cloud"])
