@@ -1092,6 +1092,31 @@ def _override_odometry_params(p, kw):
     return p
 
 
+class EvalTrajectory:
+    """The KITTI-style trajectory text of the reference's evaluation (EvalTrajectory::Write, eval_trajectory.cpp:169-183;
+    MatToString, types.cpp:64-73): one pose per line, the top three rows of the 4 x 4 matrix, std::fixed (6 decimals)."""
+
+    @staticmethod
+    def MatToString(pose):
+        x, y, th = (float(v) for v in pose)
+        c, s = np.cos(th), np.sin(th)
+        m = (c, -s, 0.0, x, s, c, 0.0, y, 0.0, 0.0, 1.0, 0.0)
+        return " ".join("%f" % v for v in m)
+
+    @staticmethod
+    def Write(path, poses):
+        with open(path, "w") as f:
+            for p in np.asarray(poses, np.float64).reshape(-1, 3):
+                f.write(EvalTrajectory.MatToString(p) + "\n")
+
+    @staticmethod
+    def Read(path):
+        """-> poses [n, 3] (x, y, theta) of a planar trajectory file."""
+        a = np.loadtxt(path, dtype=np.float64, ndmin=2)
+        assert a.shape[1] == 12
+        return np.stack([a[:, 3], a[:, 7], np.arctan2(a[:, 4], a[:, 0])], 1)
+
+
 PRESETS = {"CFEAR-1": 1, "CFEAR-2": 2, "CFEAR-3": 3, "CFEAR-3-s10": 4}
 DATASETS = {"oxford": 0, "mulran": 1, "kvarntorp": 2, "volvo": 3}
 

@@ -153,3 +153,22 @@ def test_oracle_verify_candidate_chain(pairs):
     assert bad["probability"] < 0.2
     acc = O.apply_constraints([good["probability"], bad["probability"]], [0, 0])
     np.testing.assert_array_equal(acc, [True, False])
+
+
+def test_trajectory_text_format(tmp_path):
+    """EvalTrajectory::Write / MatToString (eval_trajectory.cpp:169-183, types.cpp:64-73): 12 numbers per line, fixed
+    6 decimals.  The three lines below are lines 2, 2000 and 5000 of the reference's
+    evaluation/data/oxford_all_tbv_model_8/job_1/odom/21.txt; the poses are what they decode to."""
+    lines = ["1.000000 -0.000159 0.000000 0.002571 0.000159 1.000000 0.000000 0.001135 0.000000 0.000000 1.000000 0.000000",
+             "-0.992063 0.125738 0.000000 929.870514 -0.125738 -0.992063 0.000000 -176.231360 0.000000 0.000000 1.000000 0.000000",
+             "0.550357 0.834929 0.000000 830.338854 -0.834929 0.550357 0.000000 578.296853 0.000000 0.000000 1.000000 0.000000"]
+    f = tmp_path / "21.txt"
+    f.write_text("\n".join(lines) + "\n")
+    poses = api.EvalTrajectory.Read(str(f))
+    np.testing.assert_allclose(poses[:, :2], [[0.002571, 0.001135], [929.870514, -176.231360], [830.338854, 578.296853]], atol=1e-9)
+    np.testing.assert_allclose(poses[:, 2], [np.arctan2(0.000159, 1.0), np.arctan2(-0.125738, -0.992063), np.arctan2(-0.834929, 0.550357)])
+    g = tmp_path / "out.txt"
+    api.EvalTrajectory.Write(str(g), poses)
+    assert g.read_text().splitlines() == lines                       # these three survive the 6-decimal round trip
+    back = api.EvalTrajectory.Read(str(g))
+    np.testing.assert_allclose(back, poses, atol=1e-6)
