@@ -93,10 +93,13 @@ size_t reg_lds_bytes(int lds_targets, int dense_cap, int dense_fields) {
   return kRegFixedLds + reg_lds_targets_bytes(lds_targets) + (size_t)dense_cap * (dense_fields * 8 + 4);
 }
 constexpr size_t kRegLdsBudget = REG_LDS_KB * 1024 - 256;    // keeps 2 workgroups per CU (160 KiB LDS)
-constexpr size_t kRegLdsBudgetWave = 16 * 1024;      // wave-per-job geometry: >= 8 wavefronts per CU
+// Compact geometry for small registrations (a two-scan loop-closure candidate needs ~37 KB): 2 wavefronts and 40 KB per
+// workgroup, so four registrations share a CU instead of two.  The work of one registration is a chain of short
+// dependent phases, so halving its lanes costs little latency while doubling the registrations in flight.
+constexpr int kRegNWCompact = 2;
+constexpr size_t kRegLdsBudgetCompact = 40 * 1024 - 256;
 // Measured on MI355X (round 1): with ~190 VGPRs only 2 wavefronts fit a SIMD, so the wave-per-job
 // geometry is latency-bound on its 4x longer per-lane loops (4096 jobs: 6.7 ms vs 6.0 ms); disabled.
-constexpr int kWavePerJobMinBatch = 1 << 30;
 int reg_dense_fields(int cost) { return cost == CFEAR_P2P ? 3 : (cost == CFEAR_P2L ? 5 : 6); }
 
 struct Aff2 { double l0, l1, l2, l3, t0, t1; };
@@ -1374,9 +1377,21 @@ size_t cfear_reg_job_stride(int max_scans) { return reg_job_stride(max_scans); }
 
 // Enqueues the batched registration kernel: d_jobs [n_jobs] RegJob records (device), d_results
 // [n_jobs] (device).  slots_cap bounds (n_scans-1)*n_src per job, lds_targets the largest target.
+// LDS the fused association path needs for one registration (mirrors fused_carve): used by the host to decide whether
+// a whole batch fits the compact geometry.
+size_t cfear_reg_fused_lds_need(int n_scans, int sum_targets, int n_src, int cost) {
+  const int last = n_scans - 1, G = reg_grid_dim(std::max(last, 1));
+  const size_t n_pairs = (size_t)last * n_src, fields = (size_t)reg_dense_fields(cost);
+  size_t b = kRegFixedLds + 16 * 12 * 8 + 80 + 16 * 5 * 8 + 16 * 16 + 16 * 4 * 4;
+  b += (((size_t)last * G * G + 1) * 2 + 15) & ~(size_t)15;
+  b += (size_t)sum_targets * 16 + (((size_t)n_src + 1) & ~(size_t)1) * 16 + ((n_pairs + 3) & ~(size_t)3) * 4 + 64;
+  b += n_pairs * (fields * 8 + 4) + 64;                 // every pair matched: upper bound of the dense arrays
+  return b;
+}
+
 int cfear_register_launch(cfear_ctx* ctx, const void* d_jobs, int n_jobs, const cfear_reg_params* par, int slots_cap,
                           int lds_targets, char* d_scratch, cfear_reg_result* d_results, const RegCostMode* mode,
-                          size_t job_stride) {
+                          size_t job_stride, bool compact) {
   if (lds_targets > kMaxTargetsLds)
     return cfear_set_error(ctx, CFEAR_ERR_CAPACITY, "target scan with more than %d cells", kMaxTargetsLds);
   if (lds_targets < 1) lds_targets = 1;
@@ -1397,30 +1412,35 @@ int cfear_register_launch(cfear_ctx* ctx, const void* d_jobs, int n_jobs, const 
   cm.xy_half = mode ? mode->xy_half : 0.0;
   cm.yaw_half = mode ? mode->yaw_half : 0.0;
   cm.prior = mode ? mode->prior : nullptr;
-  // Geometry: small batches get one 256-thread workgroup per registration (lowest latency, dense
-  // correspondence arrays in LDS); large batches get one wavefront per registration (no barriers, no
-  // LDS exchange, 4x more registrations in flight; dense arrays stay in L2).
-  const bool wave_per_job = n_jobs >= kWavePerJobMinBatch;
+  // Geometry: one 256-thread workgroup and 80 KB of LDS per registration (two per CU), or -- when the caller has
+  // checked that every registration of the batch fits -- the compact 128-thread / 40 KB form (four per CU).
   const size_t fixed = kRegFixedLds + reg_lds_targets_bytes(cm.lds_targets);
-  const size_t budget = wave_per_job ? kRegLdsBudgetWave : kRegLdsBudget;
+  const size_t budget = compact ? kRegLdsBudgetCompact : kRegLdsBudget;
   const size_t avail = fixed < budget ? budget - fixed : 0;
   cm.dense_cap_lds = (int)std::min<size_t>(avail / ((size_t)cm.dense_fields * 8 + 4), (size_t)slots_cap) & ~1;
   size_t lds = reg_lds_bytes(cm.lds_targets, cm.dense_cap_lds, cm.dense_fields);
   if (lds < budget) lds = budget;
   cm.lds_total = (uint32_t)lds;
-  (void)wave_per_job;
   typedef void (*KernelFn)(const RegJob*, RegCommon);
   // compile-time specialisations: cost metric x {Huber, any other loss}
   const bool huber = par->loss == CFEAR_LOSS_HUBER;
   KernelFn fn;
-  switch (par->cost) {
-    case CFEAR_P2P: fn = huber ? register_kernel<kRegNW, CFEAR_P2P, CFEAR_LOSS_HUBER> : register_kernel<kRegNW, CFEAR_P2P, -1>; break;
-    case CFEAR_P2L: fn = huber ? register_kernel<kRegNW, CFEAR_P2L, CFEAR_LOSS_HUBER> : register_kernel<kRegNW, CFEAR_P2L, -1>; break;
-    default: fn = huber ? register_kernel<kRegNW, CFEAR_P2D, CFEAR_LOSS_HUBER> : register_kernel<kRegNW, CFEAR_P2D, -1>; break;
+  if (compact) {
+    switch (par->cost) {
+      case CFEAR_P2P: fn = huber ? register_kernel<kRegNWCompact, CFEAR_P2P, CFEAR_LOSS_HUBER> : register_kernel<kRegNWCompact, CFEAR_P2P, -1>; break;
+      case CFEAR_P2L: fn = huber ? register_kernel<kRegNWCompact, CFEAR_P2L, CFEAR_LOSS_HUBER> : register_kernel<kRegNWCompact, CFEAR_P2L, -1>; break;
+      default: fn = huber ? register_kernel<kRegNWCompact, CFEAR_P2D, CFEAR_LOSS_HUBER> : register_kernel<kRegNWCompact, CFEAR_P2D, -1>; break;
+    }
+  } else {
+    switch (par->cost) {
+      case CFEAR_P2P: fn = huber ? register_kernel<kRegNW, CFEAR_P2P, CFEAR_LOSS_HUBER> : register_kernel<kRegNW, CFEAR_P2P, -1>; break;
+      case CFEAR_P2L: fn = huber ? register_kernel<kRegNW, CFEAR_P2L, CFEAR_LOSS_HUBER> : register_kernel<kRegNW, CFEAR_P2L, -1>; break;
+      default: fn = huber ? register_kernel<kRegNW, CFEAR_P2D, CFEAR_LOSS_HUBER> : register_kernel<kRegNW, CFEAR_P2D, -1>; break;
+    }
   }
   CFEAR_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
   ProfScope ps(ctx, mode ? "get_cost" : "register");
-  hipLaunchKernelGGL(fn, dim3(n_jobs, mode ? std::max(mode->blocks_per_job, 1) : 1), dim3(kRegNW * 64), lds, ctx->stream,
+  hipLaunchKernelGGL(fn, dim3(n_jobs, mode ? std::max(mode->blocks_per_job, 1) : 1), dim3((compact ? kRegNWCompact : kRegNW) * 64), lds, ctx->stream,
                      (const RegJob*)d_jobs, cm);
   CFEAR_HIP_CHECK(ctx, hipGetLastError());
   return CFEAR_OK;
@@ -1430,22 +1450,24 @@ size_t cfear_register_scratch_bytes(int slots_cap) { return reg_scratch_bytes(sl
 // ---- host-facing wrappers ----------------------------------------------------------------------
 namespace {
 
-struct JobSizes { int slots_cap = 1; int lds_targets = 1; };
+struct JobSizes { int slots_cap = 1; int lds_targets = 1; size_t fused_need = 0; int cost = CFEAR_P2L; };
 
 int gather_job(cfear_ctx* ctx, const cfear_scan* const* scans, int n_scans, const double* poses, unsigned char* dst,
                JobSizes& sz) {
   if (n_scans < 2 || n_scans > kMaxScans)
     return cfear_set_error(ctx, CFEAR_ERR_INVALID_ARGUMENT, "n_scans must be in [2,%d]", kMaxScans);
   ScanView views[kMaxScans];
+  int sum_tar = 0, n_src = 0;
   for (int i = 0; i < n_scans; i++) {
     if (!scans[i]) return cfear_set_error(ctx, CFEAR_ERR_INVALID_ARGUMENT, "null scan handle");
     if (scans[i]->ctx != ctx) return cfear_set_error(ctx, CFEAR_ERR_INVALID_ARGUMENT, "scan belongs to another context");
     views[i] = scans[i]->view;
     const int nc = cfear_scan_size(scans[i]);
     if (nc < 0) return nc;
-    if (i < n_scans - 1) sz.lds_targets = std::max(sz.lds_targets, nc);
-    else sz.slots_cap = std::max(sz.slots_cap, (n_scans - 1) * std::max(nc, 1));
+    if (i < n_scans - 1) { sz.lds_targets = std::max(sz.lds_targets, nc); sum_tar += nc; }
+    else { sz.slots_cap = std::max(sz.slots_cap, (n_scans - 1) * std::max(nc, 1)); n_src = nc; }
   }
+  sz.fused_need = std::max(sz.fused_need, cfear_reg_fused_lds_need(n_scans, sum_tar, n_src, sz.cost));
   cfear_reg_fill_job(dst, views, n_scans, poses);
   return CFEAR_OK;
 }
@@ -1469,10 +1491,13 @@ extern "C" int cfear_register_batch(cfear_ctx* ctx, const cfear_reg_job* jobs, i
   unsigned char* hjobs = (unsigned char*)cfear_pinned(ctx, jb);
   if (!hjobs) return cfear_set_error(ctx, CFEAR_ERR_HIP, "pinned staging allocation failed");
   JobSizes sz;
+  sz.cost = par->cost;
   for (int j = 0; j < n_jobs; j++) {
     rc = gather_job(ctx, jobs[j].scans, jobs[j].n_scans, jobs[j].poses_xyt, hjobs + (size_t)j * stride, sz);
     if (rc != CFEAR_OK) return rc;
   }
+  // every registration of the batch fits 40 KB of LDS: four per CU instead of two (needs a batch that fills them)
+  const bool compact = sz.fused_need <= kRegLdsBudgetCompact && n_jobs >= 512;
   const size_t sb = reg_scratch_bytes(sz.slots_cap) * (size_t)n_jobs;
   char* ws = (char*)cfear_workspace(ctx, 6, jb + rb + 512);
   char* scr = (char*)cfear_workspace(ctx, 7, sb);
@@ -1480,7 +1505,7 @@ extern "C" int cfear_register_batch(cfear_ctx* ctx, const cfear_reg_job* jobs, i
   char* d_jobs = ws;
   cfear_reg_result* d_res = (cfear_reg_result*)(ws + (jb + 255) / 256 * 256);
   CFEAR_HIP_CHECK(ctx, hipMemcpyAsync(d_jobs, hjobs, jb, hipMemcpyHostToDevice, ctx->stream));
-  rc = cfear_register_launch(ctx, d_jobs, n_jobs, par, sz.slots_cap, sz.lds_targets, scr, d_res, nullptr, stride);
+  rc = cfear_register_launch(ctx, d_jobs, n_jobs, par, sz.slots_cap, sz.lds_targets, scr, d_res, nullptr, stride, compact);
   if (rc != CFEAR_OK) { (void)hipStreamSynchronize(ctx->stream); return rc; }
   CFEAR_HIP_CHECK(ctx, hipMemcpyAsync(results, d_res, rb, hipMemcpyDeviceToHost, ctx->stream));
   CFEAR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
@@ -1522,12 +1547,14 @@ int run_cost_batch(cfear_ctx* ctx, const cfear_reg_job* jobs, int n_jobs, const 
   unsigned char* hjobs = (unsigned char*)cfear_pinned(ctx, jb);          // pinned: see cfear_register_batch
   if (!hjobs) return cfear_set_error(ctx, CFEAR_ERR_HIP, "pinned staging allocation failed");
   JobSizes sz;
+  sz.cost = par->cost;
   for (int j = 0; j < n_jobs; j++) {
     unsigned char* dst = hjobs + (size_t)j * stride;
     rc = gather_job(ctx, jobs[j].scans, jobs[j].n_scans, jobs[j].poses_xyt, dst, sz);
     if (rc != CFEAR_OK) return rc;
     if (itrs) cfear_reg_job_set_itr(dst, itrs[j]);
   }
+  const bool compact = sz.fused_need <= kRegLdsBudgetCompact && (long long)n_jobs * m >= 512;
   // a few workgroups per job when the batch alone cannot fill the GPU; scratch bounded to 1 GiB per launch
   mode.blocks_per_job = std::max(1, std::min(m, (1024 + n_jobs - 1) / n_jobs));
   const size_t per = reg_scratch_bytes(sz.slots_cap) * (size_t)mode.blocks_per_job;
@@ -1542,7 +1569,7 @@ int run_cost_batch(cfear_ctx* ctx, const cfear_reg_job* jobs, int n_jobs, const 
   for (int j0 = 0; j0 < n_jobs; j0 += chunk) {
     const int nj = std::min(chunk, n_jobs - j0);
     rc = cfear_register_launch(ctx, d_jobs + (size_t)j0 * stride, nj, par, sz.slots_cap, sz.lds_targets, scr,
-                               d_res + (size_t)j0 * m, &mode, stride);
+                               d_res + (size_t)j0 * m, &mode, stride, compact);
     if (rc != CFEAR_OK) { (void)hipStreamSynchronize(ctx->stream); return rc; }
   }
   CFEAR_HIP_CHECK(ctx, hipMemcpyAsync(out.data(), d_res, rb, hipMemcpyDeviceToHost, ctx->stream));
