@@ -530,6 +530,12 @@ int cfear_odometry_process(cfear_odometry* od, const uint8_t* polar, cfear_frame
  * keyframe policy.  The next call must then pass that same pointer as `polar`.                   */
 int cfear_odometry_process_prefetch(cfear_odometry* od, const uint8_t* polar, const uint8_t* polar_next,
                                     cfear_frame_info* info);
+/* The same step for callers whose own driver has filtered the sweep: OdometryKeyframeFuser::pointcloudCallback(cloud,
+ * cloud_peaks, Tcurrent, t, cov) (odometrykeyframefuser.cpp:413-426) for every stream.  clouds [n_streams]: the filtered
+ * clouds (x, y, z, intensity; host or device, <= rows * k points each); peaks [n_streams] (may be NULL): the peaks
+ * clouds, kept (and compensated) only with par.keep_nodes.  Everything after the filter is unchanged.            */
+int cfear_odometry_process_clouds(cfear_odometry* od, const cfear_sc_cloud* clouds, const cfear_sc_cloud* peaks,
+                                  cfear_frame_info* info);
 /* cov_current of every stream after the last processed frame (row-major 6x6, host [n_streams][36]):
  * Identity before the first registration and after a failed one (FormatScans' initial value survives),
  * Register's constant diag(0.01, 0.01, 0, 0, 0, 1e-4) otherwise, or the sampled covariance when

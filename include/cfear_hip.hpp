@@ -211,6 +211,18 @@ class OdometryKeyframeFuser {
     ctx_.check(cfear_odometry_process_prefetch(od_, polar, polar_next, info.data()));
     return info;
   }
+  // pointcloudCallback(cloud, cloud_peaks, ...) (odometrykeyframefuser.cpp:413-426) for every stream: filtered clouds in
+  std::vector<cfear_frame_info> pointcloudCallback(const std::vector<const PointCloud*>& clouds,
+                                                   const std::vector<const PointCloud*>& peaks = {}) {
+    std::vector<cfear_sc_cloud> c((size_t)n_), p((size_t)n_);
+    for (int i = 0; i < n_; i++) {
+      c[i] = cfear_sc_cloud{clouds[i]->empty() ? nullptr : &(*clouds[i])[0].x, (int32_t)clouds[i]->size(), 0};
+      if (!peaks.empty()) p[i] = cfear_sc_cloud{peaks[i]->empty() ? nullptr : &(*peaks[i])[0].x, (int32_t)peaks[i]->size(), 0};
+    }
+    std::vector<cfear_frame_info> info((size_t)n_);
+    ctx_.check(cfear_odometry_process_clouds(od_, c.data(), peaks.empty() ? nullptr : p.data(), info.data()));
+    return info;
+  }
   // scan_ of a stream's last frame (odometrykeyframefuser.cpp:172, 244): surface points + the two clouds
   cfear_scan* GetScan(int stream) { cfear_scan* s = nullptr; ctx_.check(cfear_odometry_get_scan(od_, stream, &s)); return s; }
   PointCloud GetCloud(int stream, bool peaks) {

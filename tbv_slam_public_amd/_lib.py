@@ -203,7 +203,7 @@ EXPORTS = [
     "cfear_cost_evaluate", "cfear_cost_normal_eq", "cfear_cost_destroy",
     "cfear_odometry_params_default", "cfear_odometry_params_preset", "cfear_odometry_create", "cfear_odometry_process",
     "cfear_odometry_process_prefetch", "cfear_odometry_get_covariance", "cfear_odometry_destroy",
-    "cfear_odometry_get_scan", "cfear_odometry_get_cloud", "cfear_odometry_get_peaks",
+    "cfear_odometry_get_scan", "cfear_odometry_get_cloud", "cfear_odometry_get_peaks", "cfear_odometry_process_clouds",
 ]
 
 _LIB = None
@@ -296,6 +296,7 @@ def lib():
     L.cfear_cost_destroy.argtypes = [vp]
     L.cfear_odometry_params_default.argtypes = [C.POINTER(OdometryParams)]
     L.cfear_odometry_params_default.restype = None
+    L.cfear_odometry_process_clouds.argtypes = [vp, C.POINTER(ScCloud), C.POINTER(ScCloud), vp]
     L.cfear_odometry_get_scan.argtypes = [vp, C.c_int32, C.POINTER(vp)]
     L.cfear_odometry_get_cloud.argtypes = [vp, C.c_int32, vp, C.c_int32, C.POINTER(C.c_int32)]
     L.cfear_odometry_get_peaks.argtypes = [vp, C.c_int32, vp, C.c_int32, C.POINTER(C.c_int32)]

@@ -1160,6 +1160,24 @@ class OdometryKeyframeFuser:
                                                                      self._info.ctypes.data))
         return self._info.copy()
 
+    def process_clouds(self, clouds, peaks=None):
+        """pointcloudCallback(cloud, cloud_peaks, ...) (odometrykeyframefuser.cpp:413-426) for every stream: the caller's
+        driver has filtered the sweeps already.  clouds / peaks: one float32 [n, 4] array (NumPy or torch CUDA) per
+        stream; peaks are kept only with par.keep_nodes.  Returns a FRAMEINFO_DTYPE array."""
+        def pack(lst):
+            arr = (L.ScCloud * self.n_streams)()
+            keep = []
+            for i, c in enumerate(lst):
+                ptr, n, k = _cloud_ptr(c)
+                arr[i].xyzi, arr[i].n = ptr, n
+                keep.append(k)
+            return arr, keep
+        assert len(clouds) == self.n_streams and (peaks is None or len(peaks) == self.n_streams)
+        ca, k1 = pack(clouds)
+        pa, k2 = pack(peaks) if peaks is not None else (None, None)
+        self.ctx.check(self.ctx._lib.cfear_odometry_process_clouds(self._h, ca, pa, self._info.ctypes.data))
+        return self._info.copy()
+
     def node(self, stream, device=False):
         """The RadarScan of `stream`'s last processed frame (scan_, odometrykeyframefuser.cpp:172, 244; types.h:119-122)
         -> dict(scan=MapPointNormal copy of cloud_normal_, cloud=cloud_nopeaks_, peaks=cloud_peaks_ (par.keep_nodes)).

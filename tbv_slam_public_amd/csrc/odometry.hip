@@ -291,15 +291,60 @@ extern "C" int cfear_odometry_process(cfear_odometry* od, const uint8_t* polar, 
   return cfear_odometry_process_prefetch(od, polar, nullptr, info);
 }
 
+static int process_frame(cfear_odometry* od, const uint8_t* polar, const uint8_t* polar_next, const cfear_sc_cloud* clouds,
+                         const cfear_sc_cloud* peaks, cfear_frame_info* info);
+
 extern "C" int cfear_odometry_process_prefetch(cfear_odometry* od, const uint8_t* polar, const uint8_t* polar_next,
                                                cfear_frame_info* info) {
   if (!od || !polar || !info) return CFEAR_ERR_INVALID_ARGUMENT;
+  return process_frame(od, polar, polar_next, nullptr, nullptr, info);
+}
+
+// OdometryKeyframeFuser::pointcloudCallback(cloud, cloud_peaks, ...) (odometrykeyframefuser.cpp:413-426): the caller's
+// own driver has already filtered the sweep; the clouds enter the pipeline where the filter would have left them.
+extern "C" int cfear_odometry_process_clouds(cfear_odometry* od, const cfear_sc_cloud* clouds, const cfear_sc_cloud* peaks,
+                                             cfear_frame_info* info) {
+  if (!od || !clouds || !info) return CFEAR_ERR_INVALID_ARGUMENT;
+  return process_frame(od, nullptr, nullptr, clouds, peaks, info);
+}
+
+// uploads one cloud per stream into the frame buffers `buf` (what run_filter would have produced)
+static int load_clouds(cfear_odometry* od, const cfear_sc_cloud* clouds, float* d_dst, int32_t* d_n, int32_t* h_tmp) {
+  cfear_ctx* ctx = od->ctx;
+  const int B = od->n_streams;
+  for (int b = 0; b < B; b++) {
+    const int n = clouds ? clouds[b].n : 0;
+    if (n < 0 || (n > 0 && !clouds[b].xyzi)) return cfear_set_error(ctx, CFEAR_ERR_INVALID_ARGUMENT, "stream %d: null cloud", b);
+    if (n > od->cap_points) return cfear_set_error(ctx, CFEAR_ERR_CAPACITY, "stream %d: %d points > %d", b, n, od->cap_points);
+    h_tmp[b] = n;
+    if (n > 0) {
+      const bool dev = cfear_is_device_ptr(clouds[b].xyzi);
+      CFEAR_HIP_CHECK(ctx, hipMemcpyAsync(d_dst + (size_t)b * od->cap_points * 4, clouds[b].xyzi, (size_t)n * 16,
+                                          dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, ctx->stream));
+    }
+  }
+  CFEAR_HIP_CHECK(ctx, hipMemcpyAsync(d_n, h_tmp, (size_t)B * 4, hipMemcpyHostToDevice, ctx->stream));
+  // h_tmp is reused by the next load / the read-back of this frame: make sure the copy has left the host buffer
+  CFEAR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  return CFEAR_OK;
+}
+
+static int process_frame(cfear_odometry* od, const uint8_t* polar, const uint8_t* polar_next, const cfear_sc_cloud* clouds,
+                         const cfear_sc_cloud* peaks, cfear_frame_info* info) {
   cfear_ctx* ctx = od->ctx;
   CFEAR_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   const int B = od->n_streams;
   const cfear_odometry_params& par = od->par;
   int rc;
-  if (od->prefetched == polar) {                   // this frame's filter already ran (or is running)
+  if (clouds) {                                    // filtered clouds from the caller: no filter, no prefetch
+    od->prefetched = nullptr;
+    rc = load_clouds(od, clouds, od->d_xyzi2[od->cur_buf], od->d_npts2[od->cur_buf], od->h_npts);
+    if (rc != CFEAR_OK) return rc;
+    if (par.keep_nodes) {
+      rc = load_clouds(od, peaks, od->d_pk2[od->cur_buf], od->d_npk2[od->cur_buf], od->h_npk);
+      if (rc != CFEAR_OK) return rc;
+    }
+  } else if (od->prefetched == polar) {            // this frame's filter already ran (or is running)
     od->cur_buf ^= 1;
   } else {
     rc = run_filter(od, polar, od->cur_buf);
