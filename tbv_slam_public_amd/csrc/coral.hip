@@ -407,14 +407,15 @@ extern "C" int cfear_coral_quality_batch(cfear_ctx* ctx, const cfear_coral_job* 
   int cap = 1;
   for (int j = 0; j < n_jobs; j++) {
     const cfear_coral_job& jb = jobs[j];
-    if (!jb.ref_xyzi || !jb.src_xyzi || jb.n_ref < 0 || jb.n_src < 0)
-      return cfear_set_error(ctx, CFEAR_ERR_INVALID_ARGUMENT, "job %d: null cloud", j);
+    if (jb.n_ref < 0 || jb.n_src < 0 || (jb.n_ref > 0 && !jb.ref_xyzi) || (jb.n_src > 0 && !jb.src_xyzi))
+      return cfear_set_error(ctx, CFEAR_ERR_INVALID_ARGUMENT, "job %d: null cloud", j);   // empty clouds are a per-job status
     if ((long long)jb.n_ref + jb.n_src > kCoralMaxPoints)
       return cfear_set_error(ctx, CFEAR_ERR_CAPACITY, "job %d: %d + %d points exceed %d", j, jb.n_ref, jb.n_src, kCoralMaxPoints);
     cap = std::max(cap, jb.n_ref + jb.n_src);
     const float* ptrs[2] = {jb.ref_xyzi, jb.src_xyzi};
     const int ns[2] = {jb.n_ref, jb.n_src};
     for (int c = 0; c < 2; c++) {
+      if (ns[c] == 0 || !ptrs[c]) continue;
       auto it = on_device.find(ptrs[c]);
       if (it != on_device.end()) continue;
       const bool dev = cfear_is_device_ptr(ptrs[c]);
@@ -430,7 +431,10 @@ extern "C" int cfear_coral_quality_batch(cfear_ctx* ctx, const cfear_coral_job* 
     d_stage = (float*)cfear_workspace(ctx, 8, stage_floats * 4);
     if (!d_stage) return cfear_set_error(ctx, CFEAR_ERR_HIP, "workspace allocation failed");
     std::map<const float*, int> len;
-    for (int j = 0; j < n_jobs; j++) { len[jobs[j].ref_xyzi] = jobs[j].n_ref; len[jobs[j].src_xyzi] = jobs[j].n_src; }
+    for (int j = 0; j < n_jobs; j++) {
+      len[jobs[j].ref_xyzi] = std::max(len[jobs[j].ref_xyzi], jobs[j].n_ref);
+      len[jobs[j].src_xyzi] = std::max(len[jobs[j].src_xyzi], jobs[j].n_src);
+    }
     for (auto& kv : staged)
       if (len[kv.first] > 0)
         CFEAR_HIP_CHECK(ctx, hipMemcpyAsync(d_stage + kv.second, kv.first, (size_t)len[kv.first] * 16, hipMemcpyHostToDevice, ctx->stream));

@@ -110,3 +110,23 @@ def test_two_contexts_on_two_host_threads(data):
             np.testing.assert_array_equal(p, p0)
             np.testing.assert_array_equal(it, it0)
             np.testing.assert_array_equal(j, j0)
+
+
+def test_verification_with_empty_peak_clouds(data):
+    """Nodes built with the CA-CFAR filter have no peaks cloud (radar_driver.cpp:52-56).  The reference would assert in
+    CorAl (AlignmentQuality.cpp:118); here the CorAl features of such a candidate are {0, 0, 0}, the job status says
+    why, and the rest of the batch is unaffected."""
+    from tbv_slam_public_amd import api
+    cloud, cells = data
+    pk = cloud[:1500]
+    m0 = api.MapPointNormal(cells=cells)
+    empty = np.zeros((0, 4), np.float32)
+    base = dict(from_scan=m0, to_scan=m0, from_pose=(0, 0, 0), t_be_guess=(0.1, 0.0, 0.0), sc_sim=0.1, odom_bounds=0.0)
+    r = api.verify_loop_candidates([dict(base, from_peaks=pk, to_peaks=pk, group=0),
+                                    dict(base, from_peaks=empty, to_peaks=pk, group=1),
+                                    dict(base, from_peaks=pk, to_peaks=empty, group=2)])
+    assert (r["reg_ok"] == 1).all()
+    assert r["accepted"][0] == 1 and r["coral"][0][2] > 0.5
+    assert (r["coral"][1:] == 0).all() and (r["cfear"][1:, 0] > 0).all()
+    q, _ = api.coral_quality_batch([(pk, (0, 0, 0), empty, (0, 0, 0), (0, 0, 0))])
+    assert q["status"][0] != 0 and q["valid"][0] == 0
