@@ -164,13 +164,13 @@ def verify_main(args):
     prepared = api.prepare_verify_batch(cands[lo:hi])
     fn = lambda _local: api.verify_loop_candidates(prepared, par, ctx)
     for _ in range(max(args.warmup, 1)):
-        out = cdist.verify_candidates_sharded(cands, fn)
+        out = cdist.verify_candidates_sharded(cands, fn, par.model_threshold, bool(par.all_candidates), fn_selects=True)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     t1 = time.perf_counter()
     for _ in range(args.steps):
-        out = cdist.verify_candidates_sharded(cands, fn)
+        out = cdist.verify_candidates_sharded(cands, fn, par.model_threshold, bool(par.all_candidates), fn_selects=True)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()

@@ -87,15 +87,19 @@ def apply_constraints(results, groups, model_threshold=0.8, all_candidates=True)
     return results
 
 
-def verify_candidates_sharded(cands, verify_fn, model_threshold=0.8, all_candidates=True, group=None):
+def verify_candidates_sharded(cands, verify_fn, model_threshold=0.8, all_candidates=True, group=None, fn_selects=False):
     """Loop-candidate verification (api.verify_loop_candidates) for the FULL candidate list `cands` (dicts with a
     "group" key, same on every rank): each rank verifies its contiguous block, one all_gather of the 480-byte
     cfear_verify_result records, then ApplyConstratins over the whole list.  `verify_fn(local_cands) ->
-    VERIFY_RESULT_DTYPE array`."""
+    VERIFY_RESULT_DTYPE array`; fn_selects: verify_fn applies the selection itself with the same threshold / policy
+    (api.verify_loop_candidates does), so a single process need not redo it."""
     import torch.distributed as dist
     groups = [int(c.get("group", 0)) for c in cands]
     if not (dist.is_available() and dist.is_initialized()):
-        return apply_constraints(verify_fn(cands), groups, model_threshold, all_candidates)
+        out = verify_fn(cands)                                # one rank sees every candidate of every query: a verify_fn
+        if fn_selects:                                        # that already ran ApplyConstratins (the library does) is final
+            return out
+        return apply_constraints(out, groups, model_threshold, all_candidates)
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     lo, hi, _per = shard_range(len(cands), world, rank)
     local = verify_fn(cands[lo:hi])
