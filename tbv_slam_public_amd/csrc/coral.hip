@@ -174,11 +174,14 @@ __global__ __launch_bounds__(kCoralThreads) void coral_kernel(const CoralJob* __
   };
   // ---- 2. sort by (cell, index) ------------------------------------------------------------------
   unsigned long long* keys = (unsigned long long*)smem;
-  const int npad = grid_sort_block(smem, n, (long long)dbx * dby, red_i, [&](int i) {
-    int ix, iy;
-    cell_xy(point(i), ix, iy);
-    return (uint32_t)(ix + iy * dbx);
-  });
+  int npad = grid_sort_rows_block(smem, n, dbx, dby, (uint32_t*)(smem + kCoralRowbegOff), red_i, red_c, 512,
+                                  [&](int i, int& ix, int& iy) { cell_xy(point(i), ix, iy); });
+  if (npad == 0)                                       // crowded grid row or a large cloud: generic block sort
+    npad = grid_sort_block(smem, n, (long long)dbx * dby, red_i, [&](int i) {
+      int ix, iy;
+      cell_xy(point(i), ix, iy);
+      return (uint32_t)(ix + iy * dbx);
+    });
   // ---- 3. sorted points -> scratch; cell table (key, start) -> LDS ---------------------------------
   const int per = npad / kCoralThreads;                 // 1..16 consecutive sorted elements per thread
   unsigned long long mine[kCoralPerThread];

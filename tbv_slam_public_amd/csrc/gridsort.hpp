@@ -8,6 +8,78 @@ constexpr int kGridSortMaxPoints = 16384;        // 64-bit keys: 128 KiB of LDS
 constexpr int kGridSortRadixMaxPoints = 8192;    // radix path: 2 x 32 KiB key buffers + 32 KiB counters
 
 #if defined(__HIPCC__)
+// Two-level variant for the common case (n <= 8192, no crowded grid row): a counting sort by grid ROW with LDS
+// atomics, then every element finds its rank among the elements of its row.  With 1 m cells a row of two merged peak
+// clouds holds ~80 points: ~80 LDS reads per element replace five radix passes.  The order is the unique order of the
+// (cell, index) keys, so the result equals grid_sort_block's bit for bit.  cell_xy(i, ix, iy) -> column / row of point
+// i (ix < dbx <= 65535, iy < dby <= 4096); rowcnt: dby + 1 uint32 of LDS outside the 128 KiB key region; red_i, red_m:
+// 16 ints each.  Returns npad (like grid_sort_block), or 0 without having sorted when the variant does not apply.
+constexpr int kGridRowSortMaxN = 8192;
+template <typename CellXY>
+__device__ int grid_sort_rows_block(uint8_t* smem, int n, int dbx, int dby, uint32_t* rowcnt, int* red_i, int* red_m,
+                                    int max_row, CellXY cell_xy) {
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  if (n > kGridRowSortMaxN || dbx > 65535 || dby > 4096) return 0;
+  unsigned long long* keys = (unsigned long long*)smem;            // [npad] result
+  uint32_t* tmp = (uint32_t*)(smem + 64 * 1024);                    // [n] (ix << 13 | i), grouped by row
+  unsigned short* rowid = (unsigned short*)(smem + 96 * 1024);      // [n] grid row of tmp[j]
+  for (int y = tid; y <= dby; y += kGridSortThreads) rowcnt[y] = 0;
+  __syncthreads();
+  int cx[kGridRowSortMaxN / kGridSortThreads], cy[kGridRowSortMaxN / kGridSortThreads];
+#pragma unroll
+  for (int q = 0; q < kGridRowSortMaxN / kGridSortThreads; q++) {
+    const int i = tid + q * kGridSortThreads;
+    cx[q] = cy[q] = 0;
+    if (i < n) {
+      cell_xy(i, cx[q], cy[q]);
+      atomicAdd(&rowcnt[cy[q]], 1u);
+    }
+  }
+  __syncthreads();
+  bool ok;
+  {                                                                 // exclusive scan over the rows + largest row
+    const int per_t = (dby + kGridSortThreads) / kGridSortThreads;  // rows per thread (<= 5)
+    const int y0 = tid * per_t;
+    int tot = 0, mx = 0;
+    for (int y = y0; y < min(dby, y0 + per_t); y++) { const int c = (int)rowcnt[y]; tot += c; mx = max(mx, c); }
+    const int incl = wave_incl_scan_i32(tot);
+    for (int o = 32; o > 0; o >>= 1) mx = max(mx, __shfl_xor(mx, o));
+    if (lane == 63) red_i[wave] = incl;
+    if (lane == 0) red_m[wave] = mx;
+    __syncthreads();
+    int run = incl - tot;
+    for (int wv = 0; wv < wave; wv++) run += red_i[wv];
+    int mxall = 0;
+    for (int wv = 0; wv < 16; wv++) mxall = max(mxall, red_m[wv]);
+    ok = mxall <= max_row;
+    for (int y = y0; y < min(dby, y0 + per_t); y++) { const int c = (int)rowcnt[y]; rowcnt[y] = (uint32_t)run; run += c; }
+    __syncthreads();
+  }
+  if (!ok) return 0;
+#pragma unroll
+  for (int q = 0; q < kGridRowSortMaxN / kGridSortThreads; q++) {
+    const int i = tid + q * kGridSortThreads;
+    if (i < n) {
+      const uint32_t pos = atomicAdd(&rowcnt[cy[q]], 1u);           // afterwards rowcnt[y] = end of row y
+      tmp[pos] = ((uint32_t)cx[q] << 13) | (uint32_t)i;
+      rowid[pos] = (unsigned short)cy[q];
+    }
+  }
+  __syncthreads();
+  const int npad = (n + kGridSortThreads - 1) / kGridSortThreads * kGridSortThreads;
+  for (int j = tid; j < npad; j += kGridSortThreads) {
+    if (j >= n) { keys[j] = ~0ull; continue; }
+    const int y = rowid[j];
+    const int s = y > 0 ? (int)rowcnt[y - 1] : 0, e = (int)rowcnt[y];
+    const uint32_t key = tmp[j];
+    int rank = 0;
+    for (int i = s; i < e; i++) rank += tmp[i] < key;
+    keys[s + rank] = ((unsigned long long)((uint32_t)y * (uint32_t)dbx + (key >> 13)) << 32) | (key & 8191u);
+  }
+  __syncthreads();
+  return max(npad, kGridSortThreads);
+}
+
 // Sorts the n points of a 1024-thread workgroup by (cell, index): cells ascending, points of a cell in input
 // order (stable).  cell_of(i) -> uint32 cell id < n_cells.  On return smem holds npad (>= n, a multiple of
 // 1024) 64-bit keys (cell << 32 | index), padding = ~0; thread t owns elements [t * npad/1024, ...).
