@@ -135,3 +135,22 @@ def test_coral_rigid_frame_invariance_at_batch_scale():
     q2, _ = api.coral_quality_batch(jobs)
     for f in ("joint", "sep", "overlap", "count_valid"):
         np.testing.assert_array_equal(q2[f], q0[f])       # deterministic launch to launch
+
+
+def test_coral_crowded_grid_row_takes_the_generic_sort():
+    """More than 512 points in one 1 m grid row (a wall along x): the two-level sort declines and the radix sort runs;
+    a cloud of more than 8192 merged points takes the bitonic path.  Results must not depend on the path."""
+    rng = np.random.default_rng(12)
+    def wall(n, y0):
+        c = np.zeros((n, 4), np.float32)
+        c[:, 0] = rng.uniform(-60, 60, n)
+        c[:, 1] = y0 + rng.uniform(-0.3, 0.3, n)
+        c[:, 3] = rng.uniform(60, 255, n)
+        return c
+    ref = np.concatenate([wall(900, 0.0), wall(300, 7.0)])
+    src = np.concatenate([wall(800, 0.1), wall(200, 7.1)])
+    _check(ref, src, np.zeros(3), np.array([0.2, 0.05, 0.003]), (0, 0, 0))
+    big_ref = np.concatenate([wall(2500, float(y)) for y in (0, 3, 6)])
+    big_src = np.concatenate([wall(2400, float(y) + 0.1) for y in (0, 3, 6)])
+    assert big_ref.shape[0] + big_src.shape[0] > 8192
+    _check(big_ref, big_src, np.zeros(3), np.array([0.1, 0.0, 0.001]), (0, 0, 0))
