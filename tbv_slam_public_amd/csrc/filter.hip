@@ -142,6 +142,26 @@ __global__ __launch_bounds__(256) void kstrongest_rows_kernel(const KStrongArgs 
   uint32_t* hist = (uint32_t*)(smem + wave * per_wave + NCHUNK * 1024 + 32);      // [256] histogram / scatter scratch
   uint32_t* list = (uint32_t*)(smem + wave * per_wave + NCHUNK * 1024 + 32 + kScratch);   // [kpad] survivors (packed keys)
 
+  // Peaks only: the six bytes before and after the row (AxialNonMaxSupress reads them through unchecked cv::Mat::at,
+  // radar_filters.cpp:238-298).  Their loads are issued here, together with the row's, so that they cost no extra
+  // memory round trip later.
+  const bool do_peaks = a.want_peaks && a.is_peak;
+  uint8_t halo = 0;
+  int halo_pos = 0;                                // rowbuf offset this lane's halo byte belongs to (0 = none)
+  if (do_peaks && (lane < 6 || (lane >= 8 && lane < 14))) {
+    const long long total = (long long)a.rows * a.stride;
+    long long lin;
+    if (lane < 6) {
+      halo_pos = -6 + lane;
+      lin = row_lin - 6 + lane;
+      if (a.dense_halo) lin = r > 0 ? row_lin - a.stride + a.cols - 6 + lane : -1;       // last bins of the previous row
+    } else {
+      halo_pos = a.cols + (lane - 8);
+      lin = row_lin + halo_pos;
+      if (a.dense_halo) lin = r + 1 < a.rows ? row_lin + a.stride + (lane - 8) : total;   // first bins of the next row
+    }
+    if (lin >= 0 && lin < total) halo = img[lin];
+  }
   uint32_t w[NCHUNK * 4];
   load_row<NCHUNK, VEC>(rowp, a.cols, lane, w);
 #pragma unroll
@@ -329,7 +349,6 @@ __global__ __launch_bounds__(256) void kstrongest_rows_kernel(const KStrongArgs 
   //      score is not exceeded by the three scores either side (missing scores are 0).  The reference reads
   //      raw[] through unchecked cv::Mat::at, i.e. up to 6 bytes before / after the row in image memory:
   //      those halo bytes are staged next to the row so that every tap is one LDS read. --------------------
-  const bool do_peaks = a.want_peaks && a.is_peak;
   auto note_kept = [&](int m) {                    // kept VALID bins among the first / last 16 bins of the row
     if (m >= 3 && m < a.cols - 3) {
       if (m < 16) atomicOr(&hist[0], 1u << m);
@@ -337,17 +356,7 @@ __global__ __launch_bounds__(256) void kstrongest_rows_kernel(const KStrongArgs 
     }
   };
   if (do_peaks) {
-    const long long total = (long long)a.rows * a.stride;
-    if (lane < 6) {
-      long long lin = row_lin - 6 + lane;
-      if (a.dense_halo) lin = r > 0 ? row_lin - a.stride + a.cols - 6 + lane : -1;       // last bins of the previous row
-      rowbuf[-6 + lane] = lin >= 0 ? img[lin] : (uint8_t)0;
-    } else if (lane >= 8 && lane < 14) {
-      const int q = a.cols + (lane - 8);
-      long long lin = row_lin + q;
-      if (a.dense_halo) lin = r + 1 < a.rows ? row_lin + a.stride + (lane - 8) : total;   // first bins of the next row
-      rowbuf[q] = lin < total ? img[lin] : (uint8_t)0;
-    }
+    if (halo_pos != 0) rowbuf[halo_pos] = halo;    // after the row staging: the tail chunk's zero padding lies there
     if (lane < 2) hist[lane] = 0;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
