@@ -210,6 +210,10 @@ def main():
     ap.add_argument("--bins-major", action="store_true",
                     help="feed the images as [range bins][azimuths] (non-Oxford drivers): adds the GPU rotation of "
                          "radarDriver::Callback (radar_driver.cpp:74-90) to every step; not the BASELINE layout")
+    ap.add_argument("--peaks-pass", action="store_true",
+                    help="after the timed region, time a second pass that also builds the peaks cloud of every sweep and "
+                         "report it as with_peaks_cloud (off by default: it would mix its launches into a kernel trace "
+                         "of this command)")
     ap.add_argument("--keep-nodes", action="store_true",
                     help="also keep every frame's compensated peaks cloud (pose-graph nodes, cfear_odometry_get_*); "
                          "off in the BASELINE configuration")
@@ -293,11 +297,11 @@ def main():
     elapsed = t2 - t1
     prof = ctx.profile_read(reset=True)
     ctx.profile_enable(False)
-    # Second, untimed-for-`value` pass with the peaks cloud switched on (AxialNonMaxSupress + second cloud + its
+    # Optional second pass (--peaks-pass), not part of `value`, with the peaks cloud switched on (AxialNonMaxSupress + second cloud + its
     # compensation): the matcher does not use it, but TBV's driver produces it for every sweep (radar_driver.cpp:59-62)
     # and loop closure consumes it, so the rate of that fuller per-frame job is reported next to the headline.
     with_peaks = None
-    if not args.keep_nodes and not args.cov_sampling:
+    if args.peaks_pass and not args.keep_nodes and not args.cov_sampling:
         od.close()
         od2 = api.OdometryKeyframeFuser(B, *frames.shape[2:], api.odometry_params(rotate_ccw=int(args.bins_major), keep_nodes=1),
                                         ctx=ctx)
