@@ -447,6 +447,9 @@ class Fuser:
         return cov, bool(flag.value)
 
     def __del__(self):
-        if getattr(self, "_h", None):
-            lib().orc_fuser_destroy(self._h)
-            self._h = None
+        try:
+            if getattr(self, "_h", None):
+                lib().orc_fuser_destroy(self._h)
+                self._h = None
+        except Exception:                        # interpreter shutdown: the module globals may already be gone
+            pass
