@@ -3,21 +3,29 @@
 
 Workload (BASELINE.json configs[1], "Oxford 10k sequence, per-frame odometry registration streamed on
 1xMI355X"): `--streams` independent synthetic Oxford-like sequences (400 x 3360 uint8 polar sweeps,
-CFEAR-3 preset: k=40, z_min=60, r=3, P2P/Huber 0.1/weights 4, 4-keyframe window) each advance one
-frame per step.  One step = one pass of the whole hot path over the batch: k-strongest filter ->
-motion compensation -> oriented surface points -> many-to-one registration -> keyframe policy, polar
-image in, SE(2) pose out.  All polar images are resident in HBM before the timed region; every
-stream has its own physical copy of its frames.  value = streams * steps / time, aggregated over
-ranks (weak scaling: every rank runs its own `--streams` sequences, no collective on the data path).
+CFEAR-3 preset: k=40, z_min=60, r=3, P2P/Huber 0.1/weights 4, 4-keyframe window).  Every stream drives a
+closed circle of `--ring` frames, so a ring of frames is an endless sequence; the rings of `--sequences`
+distinct worlds are resident in HBM and every stream is a distinct (world, start frame) pair: no two streams
+ever read the same image in one step, and the ring (>> the 256 MiB Infinity Cache) is re-read from HBM every
+step.  One STEP = `--frames-per-step` consecutive frames of every stream through the whole hot path:
+k-strongest filter -> motion compensation -> oriented surface points -> many-to-one registration -> keyframe
+policy, polar image in, SE(2) pose out (so that the K timed steps last seconds, not milliseconds).
+value = streams * frames_per_step * steps / time, aggregated over ranks (weak scaling: every rank runs its
+own streams, no collective on the data path).
 
-Also reports: roofline of the only kernel that moves compulsory HBM bytes (kstrongest_rows, the
-polar sweep) from hipEvent timings taken inside the timed region, the per-kernel time breakdown,
-the CPU oracle timed on the host (1 thread) on a bounded sample of the same frames, and the pose
-error of the GPU path against that CPU path.
+`python bench.py --gpus N` starts the N ranks itself (one process per GPU under torch.distributed.run, RCCL);
+under an external launcher (WORLD_SIZE set) it is one of the ranks.
+
+Also reported in the same JSON line (1 GPU): the roofline of the only kernel that moves compulsory HBM bytes
+(kstrongest_rows, hipEvent timings from inside the timed region), the same for dense-row scenes
+(roofline_dense + the full-path rate on them), the per-kernel breakdown, one stream alone (single_stream: the
+literal configs[1] latency case), host-resident input (host_input: pinned images, H2D inside the timed region),
+the loop-closure candidate workload (loopclosure), and the CPU oracle timed on the host beside it.
 """
 import argparse
 import json
 import os
+import socket
 import sys
 import time
 
@@ -28,7 +36,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 ROWS, COLS, K_STRONGEST = 400, 3360, 40
-N_SEEDS = 16                     # distinct synthetic sequences; streams replicate them round-robin
+IMG = ROWS * COLS
 HBM_PEAK_GBS = 8000.0            # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
@@ -50,23 +58,165 @@ def _usable_cpus():
     return max(1, n)
 
 
-def loopclosure_main(args):
-    """BASELINE configs[3]: `--candidates` loop-closure candidate registrations (P2L, Huber 0.1, Uniform,
-    SetParameters(4,10) -- loopclosure.cpp:56-57) between cached surface-point sets, block-sharded over the
-    ranks, results all_gathered (RCCL) in candidate order."""
+# ---------------------------------------------------------------------------------------------------------
+# launcher: `python bench.py --gpus N` with N > 1 re-executes itself as N ranks
+# ---------------------------------------------------------------------------------------------------------
+def launch_command(argv, n, port):
+    """The command `python bench.py --gpus n ...` turns itself into (one rank per GPU, RCCL over xGMI)."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def maybe_self_launch(args, argv):
+    if "WORLD_SIZE" in os.environ or args.gpus <= 1:
+        return
+    if not args.dry_run:
+        import torch
+        have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if have < args.gpus:
+            sys.stderr.write("bench.py: --gpus %d requested but %d GPU(s) visible: refusing to run (a run on fewer GPUs "
+                             "would report the wrong n_gpus)\n" % (args.gpus, have))
+            sys.exit(2)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = launch_command(argv, args.gpus, _free_port())
+    os.execvpe(cmd[0], cmd, env)
+
+
+class Dist:
+    """torch.distributed plumbing of one rank: RCCL ("nccl") on GPUs, gloo for the launcher dry run."""
+
+    def __init__(self, args):
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.dry = args.dry_run
+        if self.world != max(args.gpus, 1):
+            raise SystemExit("bench.py: --gpus %d but the launcher started %d rank(s)" % (args.gpus, self.world))
+        import torch
+        self.torch = torch
+        if not self.dry:
+            assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback)"
+            if torch.cuda.device_count() <= self.local_rank:
+                raise SystemExit("bench.py: rank %d has no GPU %d" % (self.rank, self.local_rank))
+            torch.cuda.set_device(self.local_rank)              # rank i <-> GPU i
+        self.dev = torch.device("cpu") if self.dry else torch.device("cuda", self.local_rank)
+        self.dist = None
+        if self.world > 1:
+            import torch.distributed as dist
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            if self.dry:
+                dist.init_process_group("gloo")
+            else:
+                dist.init_process_group("nccl", device_id=self.dev)
+            self.dist = dist
+
+    def barrier(self):
+        if not self.dry:
+            self.torch.cuda.synchronize()
+        if self.dist:
+            self.dist.barrier()
+
+    def max_over_ranks(self, x):
+        if not self.dist:
+            return float(x)
+        t = self.torch.tensor([float(x)], dtype=self.torch.float64, device=self.dev)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def gather(self, x):
+        """[value of every rank] through one all_gather: also the proof of how many ranks RCCL really connects."""
+        if not self.dist:
+            return [float(x)]
+        t = self.torch.tensor([float(x)], dtype=self.torch.float64, device=self.dev)
+        out = self.torch.empty(self.world, dtype=self.torch.float64, device=self.dev)
+        self.dist.all_gather_into_tensor(out, t)
+        return [float(v) for v in out.cpu()]
+
+    def close(self):
+        if self.dist:
+            self.dist.destroy_process_group()
+
+
+# ---------------------------------------------------------------------------------------------------------
+# input: rings of sweeps along closed circles, rendered on the GPU
+# ---------------------------------------------------------------------------------------------------------
+def make_rings(n_seq, ring, seed0, dev, dense=False):
+    """uint8 [n_seq][ring][ROWS][COLS] on the GPU + the Scene objects."""
     import torch
-    import torch.distributed as dist
+    from tbv_slam_public_amd import synth
+    rings = torch.empty((n_seq, ring, ROWS, COLS), dtype=torch.uint8, device=dev)
+    kw = dict(synth.DENSE_KW) if dense else {}
+    for s in range(n_seq):
+        sc = synth.Scene(seed0 + s, circle_frames=ring, **kw)
+        rings[s] = synth.render_frames_torch(sc, list(range(ring)), dev)
+    torch.cuda.synchronize()
+    return rings
+
+
+class StreamSet:
+    """B streams over a ring buffer: stream b = (sequence b % S, start frame (b // S) * F / P)."""
+
+    def __init__(self, B, S, F):
+        P = (B + S - 1) // S
+        assert P <= F, "more streams per sequence than ring frames: streams would share images"
+        b = np.arange(B)
+        self.seq = (b % S).astype(np.int64)
+        self.start = ((b // S) * F // P).astype(np.int64)
+        self.F = F
+
+    def offsets(self, t):
+        return (self.seq * self.F + (self.start + t) % self.F) * IMG
+
+
+def run_odometry(od, rings, ss, n_frames, t0=0, record=None):
+    """Advances every stream by n_frames frames (frame t0 .. t0 + n_frames - 1 of its ring walk); the filter of frame
+    t + 1 is prefetched behind frame t.  record: (array [n_frames, n, 3], n) receives the poses of streams 0 .. n-1."""
+    stats = {"points": 0.0, "cells": 0.0, "bad": 0, "frames": 0}
+    for t in range(t0, t0 + n_frames):
+        info = od.process_offsets(rings, ss.offsets(t), ss.offsets(t + 1))
+        stats["points"] += float(info["n_points"].mean())
+        stats["cells"] += float(info["n_cells"].mean())
+        stats["bad"] += int((info["reg_status"] != 0).sum())
+        stats["frames"] += 1
+        if record is not None:
+            record[0][t - t0] = info["pose"][:record[1]]
+    return stats
+
+
+def roofline_of(prof, n_scans_per_launch, mean_points):
+    """algorithmic bytes per scan filtered = R*C + 16*N_f + 4*R, N_f = points kept."""
+    ms, launches = prof.get("kstrongest_rows", (0.0, 0))
+    avg_ms = ms / max(launches, 1)
+    bytes_per_scan = IMG + 16.0 * mean_points + 4 * ROWS
+    achieved = bytes_per_scan * n_scans_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+    read_only = IMG * n_scans_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+    return {"bound": "hbm", "kernel": "kstrongest_rows", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS, "avg_launch_ms": avg_ms, "launches": int(launches),
+            "algorithmic_bytes_per_launch": bytes_per_scan * n_scans_per_launch, "mean_points_per_scan": mean_points,
+            "polar_read_only_GBs": read_only, "scans_per_launch": n_scans_per_launch}
+
+
+# ---------------------------------------------------------------------------------------------------------
+# neighbouring workloads (functions so that the odometry run can report them in its own line)
+# ---------------------------------------------------------------------------------------------------------
+def loopclosure_run(D, n_cand, steps, warmup):
+    """BASELINE configs[3]: loop-closure candidate registrations (P2L, Huber 0.1, Uniform, SetParameters(4,10) --
+    loopclosure.cpp:56-57) between cached surface-point sets, block-sharded over the ranks, results all_gathered
+    (RCCL) in candidate order."""
+    import torch
     from tbv_slam_public_amd import api, synth
     from tbv_slam_public_amd import dist as cdist
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    torch.cuda.set_device(local_rank)
-    ctx = api.Context(local_rank, stream=torch.cuda.current_stream().cuda_stream)
-    n_frames, n_cand = 40, args.candidates
+    ctx = api.Context(D.local_rank, stream=torch.cuda.current_stream().cuda_stream)
+    n_frames = 40
     sc = synth.Scene(3)
     gt = np.stack([sc.pose_at(f, n_frames) for f in range(n_frames)])
     scans = []
@@ -87,57 +237,37 @@ def loopclosure_main(args):
         jobs.append(([scans[i], scans[j]], np.array([[0.0, 0.0, 0.0], guess])))
     reg = api.n_scan_normal_reg("P2L", ctx=ctx)
     reg.SetParameters(4, 10)
-    lo, hi, _per = cdist.shard_range(n_cand, world, rank)
+    lo, hi, _per = cdist.shard_range(n_cand, D.world, D.rank)
     prepared = reg.PrepareBatch(jobs[lo:hi])
     fn = lambda _local: reg.RegisterBatch(prepared)
-    for _ in range(max(args.warmup, 1)):
+    for _ in range(max(warmup, 1)):
         out = cdist.register_candidates_sharded(jobs, fn)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
+    D.barrier()
     t1 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         out = cdist.register_candidates_sharded(jobs, fn)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t1
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    if rank == 0:
-        print(json.dumps({
-            "metric": "loop-closure candidate registrations/sec (cached features, P2L 4x10)",
-            "value": n_cand * args.steps / elapsed, "unit": "registrations/s", "n_gpus": world, "steps": args.steps,
-            "warmup": max(args.warmup, 1), "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "strong", "vs_baseline": None, "dtype": "f32 search / f64 solve", "data": "synthetic (scene_v1)",
+    D.barrier()
+    elapsed = D.max_over_ranks(time.perf_counter() - t1)
+    return {"metric": "loop-closure candidate registrations/sec (cached features, P2L 4x10)",
+            "value": n_cand * steps / elapsed, "unit": "registrations/s", "n_gpus": D.world, "steps": steps,
+            "warmup": max(warmup, 1), "ms_per_step": elapsed / steps * 1e3, "ms_per_4096": elapsed / steps * 1e3 * 4096.0 / n_cand,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32 search / f64 solve",
+            "data": "synthetic (scene_v1)",
             "config": {"workload": "configs[3]: %d loop-closure candidates sharded over %d rank(s), all_gather of "
-                                   "72-byte result records" % (n_cand, world), "candidates": n_cand},
+                                   "72-byte result records" % (n_cand, D.world), "candidates": n_cand},
             "ok_fraction": float((out["status"] == 0).mean()), "mean_outer_iters": float(out["outer_iters"].mean()),
-            "reference_cpu_ms_per_candidate": "8.3-9.7 (evaluation/data/oxford_all_tbv_model_8/job_*/time_statistics.txt)"}))
-    if world > 1:
-        dist.destroy_process_group()
+            "reference_cpu_ms_per_candidate": "8.3-9.7 (evaluation/data/oxford_all_tbv_model_8/job_*/time_statistics.txt)"}
 
 
-def verify_main(args):
-    """Full loop-candidate verification of `--candidates` candidates per step (RegisterLoopCandidate +
-    VerifyLoopCandidate + ApplyConstratins, tbv_slam/src/tbv_slam/loopclosure.cpp:320-384, 261-274): registration,
-    CorAl and CFEAR alignment quality, both classifiers; 3 candidates per query node; block-sharded over the ranks,
-    one all_gather of 480-byte records."""
+def verify_run(D, n_cand, steps, warmup):
+    """Full loop-candidate verification per step (RegisterLoopCandidate + VerifyLoopCandidate + ApplyConstratins,
+    tbv_slam/src/tbv_slam/loopclosure.cpp:320-384, 261-274): registration, CorAl and CFEAR alignment quality, both
+    classifiers; 3 candidates per query node; block-sharded over the ranks, one all_gather of 480-byte records."""
     import torch
-    import torch.distributed as dist
     from tbv_slam_public_amd import api, synth
     from tbv_slam_public_amd import dist as cdist
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    torch.cuda.set_device(local_rank)
-    ctx = api.Context(local_rank, stream=torch.cuda.current_stream().cuda_stream)
-    n_frames, n_cand = 40, args.candidates
+    ctx = api.Context(D.local_rank, stream=torch.cuda.current_stream().cuda_stream)
+    n_frames = 40
     sc = synth.Scene(3)
     gt = np.stack([sc.pose_at(f, n_frames) for f in range(n_frames)])
     scans, peaks = [], []
@@ -160,48 +290,58 @@ def verify_main(args):
                           t_be_guess=guess, sc_sim=float(rng.uniform(0.05, 0.5)), odom_bounds=float(rng.uniform(0, 0.3)),
                           group=q // 3))
     par = api.verify_params(ctx)
-    lo, hi, _per = cdist.shard_range(n_cand, world, rank)
+    lo, hi, _per = cdist.shard_range(n_cand, D.world, D.rank)
     prepared = api.prepare_verify_batch(cands[lo:hi])
     fn = lambda _local: api.verify_loop_candidates(prepared, par, ctx)
-    for _ in range(max(args.warmup, 1)):
+    for _ in range(max(warmup, 1)):
         out = cdist.verify_candidates_sharded(cands, fn, par.model_threshold, bool(par.all_candidates), fn_selects=True)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
+    D.barrier()
     t1 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         out = cdist.verify_candidates_sharded(cands, fn, par.model_threshold, bool(par.all_candidates), fn_selects=True)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t1
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    if rank == 0:
-        print(json.dumps({
-            "metric": "loop-closure candidate verifications/sec (register P2L 4x10 + CorAl + CFEAR quality + classifiers)",
-            "value": n_cand * args.steps / elapsed, "unit": "candidates/s", "n_gpus": world, "steps": args.steps,
-            "warmup": max(args.warmup, 1), "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+    D.barrier()
+    elapsed = D.max_over_ranks(time.perf_counter() - t1)
+    return {"metric": "loop-closure candidate verifications/sec (register P2L 4x10 + CorAl + CFEAR quality + classifiers)",
+            "value": n_cand * steps / elapsed, "unit": "candidates/s", "n_gpus": D.world, "steps": steps,
+            "warmup": max(warmup, 1), "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "f32 search / f64 solve + entropy", "data": "synthetic (scene_v1)",
             "config": {"workload": "%d loop-closure candidates (3 per query) verified end to end, sharded over %d rank(s), "
-                                   "all_gather of 480-byte records" % (n_cand, world), "candidates": n_cand},
+                                   "all_gather of 480-byte records" % (n_cand, D.world), "candidates": n_cand},
             "reg_ok_fraction": float(out["reg_ok"].mean()), "accepted_fraction": float(out["accepted"].mean()),
             "reference_cpu_ms_per_candidate": "8.3-9.7 Register + 20-22 VerifyByAlignment "
-                                              "(evaluation/data/oxford_all_tbv_model_8/job_*/time_statistics.txt)"}))
-    if world > 1:
-        dist.destroy_process_group()
+                                              "(evaluation/data/oxford_all_tbv_model_8/job_*/time_statistics.txt)"}
 
 
-def main():
+# ---------------------------------------------------------------------------------------------------------
+def dry_run(D, args):
+    """Launcher dry run (no GPU): the ranks rendezvous over gloo, rank 0 prints the line's launch-related keys."""
+    ranks = D.gather(D.rank)
+    if D.rank == 0:
+        print(json.dumps({"metric": "launcher dry run", "n_gpus": D.world, "rccl_ranks": len(ranks), "ranks": ranks,
+                          "per_rank_value": D.gather(0.0), "backend": "gloo", "steps": args.steps, "warmup": args.warmup}))
+    else:
+        D.gather(0.0)
+    D.close()
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--frames-per-step", type=int, default=32,
+                    help="consecutive frames every stream advances per step (a step = one pass of the hot path over "
+                         "streams x frames_per_step sweeps)")
     ap.add_argument("--streams", type=int, default=2048, help="independent sequences per GPU")
+    ap.add_argument("--sequences", type=int, default=256, help="distinct synthetic worlds per GPU (streams = worlds x start frames)")
+    ap.add_argument("--ring", type=int, default=64, help="frames of the closed circle every world is rendered along")
     ap.add_argument("--cpu-frames", type=int, default=0, help="frames of CPU baseline (0 = auto, ~10-30 s)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the passes after the timed region (dense scenes, single stream, host input, loop closure): "
+                         "a kernel trace of the command then holds the headline launches only")
+    ap.add_argument("--dense", action="store_true", help="headline pass on the dense-row scenes (scene_dense) instead")
     ap.add_argument("--workload", choices=["odometry", "loopclosure", "verify"], default="odometry",
                     help="odometry = BASELINE configs[1] (the headline metric); loopclosure = configs[3]: "
                          "a batch of candidate registrations from cached features, sharded over the ranks "
@@ -210,202 +350,120 @@ def main():
     ap.add_argument("--bins-major", action="store_true",
                     help="feed the images as [range bins][azimuths] (non-Oxford drivers): adds the GPU rotation of "
                          "radarDriver::Callback (radar_driver.cpp:74-90) to every step; not the BASELINE layout")
-    ap.add_argument("--peaks-pass", action="store_true",
-                    help="after the timed region, time a second pass that also builds the peaks cloud of every sweep and "
-                         "report it as with_peaks_cloud (off by default: it would mix its launches into a kernel trace "
-                         "of this command)")
     ap.add_argument("--keep-nodes", action="store_true",
                     help="also keep every frame's compensated peaks cloud (pose-graph nodes, cfear_odometry_get_*); "
                          "off in the BASELINE configuration")
     ap.add_argument("--cov-sampling", action="store_true",
                     help="odometry: also estimate every frame's covariance by cost sampling (27 GetCost per "
                          "registration, odometrykeyframefuser.cpp:203-208; off in the reference's presets)")
-    args = ap.parse_args()
-    if args.workload == "loopclosure":
-        return loopclosure_main(args)
-    if args.workload == "verify":
-        return verify_main(args)
+    ap.add_argument("--dry-run", action="store_true", help="launcher test without GPUs: ranks rendezvous over gloo and exit")
+    args = ap.parse_args(argv)
+    maybe_self_launch(args, argv)
+    D = Dist(args)
+    if args.dry_run:
+        return dry_run(D, args)
+    if args.workload in ("loopclosure", "verify"):
+        out = (loopclosure_run if args.workload == "loopclosure" else verify_run)(D, args.candidates, args.steps, args.warmup)
+        vals = D.gather(out["value"])
+        if D.rank == 0:
+            out["rccl_ranks"] = len(vals)
+            print(json.dumps(out))
+        return D.close()
 
     import torch
-    import torch.distributed as dist
-    from tbv_slam_public_amd import api, synth
-
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU fallback)"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-
-    B, K, W = args.streams, args.steps, max(args.warmup, 1)   # frame 0 of a stream is not a registration
-    F = W + K + 1                 # one extra frame: the last timed step prefetches (filters) it
-    # ---- synthetic input, resident in HBM: [F][B][ROWS][COLS] uint8 -------------------------------
+    from tbv_slam_public_amd import api
+    dev = D.dev
+    B, K, W, FPS = args.streams, args.steps, max(args.warmup, 1), max(args.frames_per_step, 1)
+    S, F = min(args.sequences, B), args.ring
+    # ---- synthetic input, resident in HBM ------------------------------------------------------------
     t0 = time.time()
-    base = []
-    for sd in range(min(N_SEEDS, B)):
-        sc = synth.Scene(1000 * rank + sd)
-        base.append(np.stack([sc.render(f, F) for f in range(F)]))
-    base = np.stack(base)                                            # [S][F][R][C]
-    dbase = torch.from_numpy(base).to(dev)
-    frames = torch.empty((F, B, ROWS, COLS), dtype=torch.uint8, device=dev)
-    for b in range(B):
-        frames[:, b] = dbase[b % dbase.shape[0]]                     # a physical copy per stream
-    del dbase
-    torch.cuda.synchronize()
+    rings = make_rings(S, F, 100000 * D.rank + (50000 if args.dense else 0), dev, dense=args.dense)
+    ss = StreamSet(B, S, F)
     t_gen = time.time() - t0
-
     stream = torch.cuda.current_stream().cuda_stream
-    ctx = api.Context(local_rank, stream=stream)
-    if args.bins_major:
-        frames = torch.rot90(frames, -1, dims=(2, 3)).contiguous()   # [F][B][COLS][ROWS]: what such a driver publishes
-        torch.cuda.synchronize()                                     # the library enqueues on its own stream
-    od = api.OdometryKeyframeFuser(B, *frames.shape[2:], api.odometry_params(estimate_cov_by_sampling=int(args.cov_sampling),
-                                                                             rotate_ccw=int(args.bins_major),
-                                                                             keep_nodes=int(args.keep_nodes)), ctx=ctx)
+    ctx = api.Context(D.local_rank, stream=stream)
 
-    def barrier():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
+    def new_fuser(n_streams, **kw):
+        return api.OdometryKeyframeFuser(n_streams, ROWS, COLS, api.odometry_params(**kw), ctx=ctx)
 
-    for f in range(W):
-        info = od.process(frames[f], frames[f + 1])      # warm-up; also primes the filter prefetch of frame W
-    barrier()
+    n_cmp = min(16, S)                     # streams 0 .. n_cmp-1 start at frame 0 of sequences 0 .. n_cmp-1: compared with the CPU
+    if args.bins_major or args.keep_nodes:
+        # these variants go through the strided-batch entry: one [B][rows][cols] batch per ring frame
+        od = new_fuser(B, estimate_cov_by_sampling=int(args.cov_sampling), rotate_ccw=int(args.bins_major),
+                       keep_nodes=int(args.keep_nodes)) if not args.bins_major else \
+            api.OdometryKeyframeFuser(B, COLS, ROWS, api.odometry_params(estimate_cov_by_sampling=int(args.cov_sampling),
+                                                                         rotate_ccw=1, keep_nodes=int(args.keep_nodes)), ctx=ctx)
+
+        def batch_of(t):
+            idx = torch.from_numpy(ss.seq * F + (ss.start + t) % F).to(dev)
+            x = rings.view(S * F, ROWS, COLS).index_select(0, idx)
+            return torch.rot90(x, -1, dims=(1, 2)).contiguous() if args.bins_major else x
+        G = min(F, 4)                      # a few gathered batches cycle (each is B images: 2.75 GB)
+        cache = [batch_of(t) for t in range(G)]
+        if G < F:
+            sys.stderr.write("bench.py: --bins-major/--keep-nodes cycle %d gathered frames (not a continuous trajectory)\n" % G)
+
+        def advance(n, t_first, record=None):
+            st = {"points": 0.0, "cells": 0.0, "bad": 0, "frames": 0}
+            for t in range(t_first, t_first + n):
+                info = od.process(cache[t % G], cache[(t + 1) % G])
+                st["points"] += float(info["n_points"].mean()); st["cells"] += float(info["n_cells"].mean())
+                st["bad"] += int((info["reg_status"] != 0).sum()); st["frames"] += 1
+            return st
+    else:
+        od = new_fuser(B, estimate_cov_by_sampling=int(args.cov_sampling))
+
+        def advance(n, t_first, record=None):
+            return run_odometry(od, rings, ss, n, t_first, record)
+
+    poses = np.zeros(((W + K) * FPS, n_cmp, 3))
+    for w in range(W):
+        advance(FPS, w * FPS, (poses[w * FPS:], n_cmp))
+    D.barrier()
     ctx.profile_enable(True)
     ctx.profile_read(reset=True)
-    poses = np.zeros((K, B, 3))
-    n_points = np.zeros((K, B), np.int64)
-    n_cells = np.zeros((K, B), np.int64)
-    status_bad = 0
     t1 = time.perf_counter()
+    tot = {"points": 0.0, "cells": 0.0, "bad": 0, "frames": 0}
     for s in range(K):
-        # The filter of the next frame is enqueued behind this frame's kernels (it needs no state of this
-        # frame).  Frame W's sweep ran during warm-up and frame W+K's sweep runs inside the timed region,
-        # so exactly K filter sweeps (and K of every other kernel) are timed.
-        info = od.process(frames[W + s], frames[W + s + 1])
-        poses[s] = info["pose"]
-        n_points[s] = info["n_points"]
-        n_cells[s] = info["n_cells"]
-        status_bad += int((info["reg_status"] != 0).sum())
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    t2 = time.perf_counter()
-    elapsed = t2 - t1
+        # The filter of the next frame is enqueued behind each frame's kernels (it needs no state of that frame): the
+        # sweep of the first timed frame ran during warm-up and the sweep of the frame after the last one runs inside
+        # the timed region, so exactly K * frames_per_step filter sweeps (and as many of every other kernel) are timed.
+        st = advance(FPS, (W + s) * FPS, (poses[(W + s) * FPS:], n_cmp))
+        for k_ in tot:
+            tot[k_] += st[k_]
+    D.barrier()
+    elapsed_local = time.perf_counter() - t1
     prof = ctx.profile_read(reset=True)
     ctx.profile_enable(False)
-    # Optional second pass (--peaks-pass), not part of `value`, with the peaks cloud switched on (AxialNonMaxSupress + second cloud + its
-    # compensation): the matcher does not use it, but TBV's driver produces it for every sweep (radar_driver.cpp:59-62)
-    # and loop closure consumes it, so the rate of that fuller per-frame job is reported next to the headline.
-    with_peaks = None
-    if args.peaks_pass and not args.keep_nodes and not args.cov_sampling:
-        od.close()
-        od2 = api.OdometryKeyframeFuser(B, *frames.shape[2:], api.odometry_params(rotate_ccw=int(args.bins_major), keep_nodes=1),
-                                        ctx=ctx)
-        for f in range(W):
-            od2.process(frames[f], frames[f + 1])
-        barrier()
-        tp1 = time.perf_counter()
-        for s_ in range(K):
-            od2.process(frames[W + s_], frames[W + s_ + 1])
-        barrier()
-        tp = time.perf_counter() - tp1
-        if world > 1:
-            t = torch.tensor([tp], dtype=torch.float64, device=dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            tp = float(t.item())
-        with_peaks = {"value": B * K * world / tp, "unit": "registrations/s", "ms_per_step": tp / K * 1e3,
-                      "note": "same job plus the peaks cloud of every sweep (keep_nodes = 1); not the headline"}
-        od2.close()
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        bad = torch.tensor([status_bad], dtype=torch.int64, device=dev)
-        dist.all_reduce(bad)
-        status_bad = int(bad.item())
+    elapsed = D.max_over_ranks(elapsed_local)
+    per_rank = D.gather(B * FPS * K / elapsed_local)
+    bad_total = sum(D.gather(tot["bad"]))
+    if D.rank != 0:
+        return D.close()
 
-    if rank != 0:
-        if world > 1:
-            dist.destroy_process_group()
-        return
-
-    total_units = B * K * world
+    total_units = B * FPS * K * D.world
     value = total_units / elapsed
-    # ---- roofline of the polar sweep (kstrongest_rows) ------------------------------------------------
-    ms, launches = prof.get("kstrongest_rows", (0.0, 0))
-    avg_ms = ms / max(launches, 1)
-    nf = float(n_points.mean())
-    # algorithmic bytes per scan filtered = R*C + 16*N_f + 4*R, N_f = points kept
-    bytes_per_scan = ROWS * COLS + 16.0 * nf + 4 * ROWS
-    achieved = (bytes_per_scan * B) / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-    breakdown = {k: {"ms_per_step": v[0] / max(K, 1), "launches": int(v[1])} for k, v in prof.items()}
+    nf = tot["points"] / max(tot["frames"], 1)
+    roof = roofline_of(prof, B, nf)
+    n_launch = max(tot["frames"], 1)
+    breakdown = {k: {"ms_per_frame_batch": v[0] / n_launch, "launches": int(v[1])} for k, v in prof.items()}
     # HBM traffic of that kernel from the committed PMC passes (rocprofv3 cannot run inside this process):
     # per-scan FETCH_SIZE x2 + WRITE_SIZE measured by tools/profile.sh, scaled to this launch's batch
-    traffic = None
-    tj = os.path.join(ROOT, "profiles", "r01", "pmc_traffic.json")
-    if os.path.exists(tj):
-        t = json.load(open(tj))
-        traffic = (t["fetch_bytes_per_scan"] + t["write_bytes_per_scan"]) * B
-
-    # ---- CPU baseline: the oracle (port), 1 thread, bounded sample of the same frames -----------------
-    cpu = None
-    cpu_mt = None
-    pose_err = None
-    if not args.no_cpu_baseline and world == 1:        # rank 0 at N=1 only
-        from oracle import pyoracle as O
-        n_seq = base.shape[0]
-        passes = 5 if not args.cpu_frames else 1          # ~15 s of single-thread CPU work at the defaults
-        budget_frames = args.cpu_frames or passes * n_seq * F
-        reg = O.reg_params(cost="P2P", loss="Huber", loss_limit=0.1, weight_opt=4, regularization=0.0)
-        done, compared, tc0 = 0, 0, time.perf_counter()
-        err_xy, err_th = 0.0, 0.0
-        for ps in range(passes):
-            for sd in range(n_seq):
-                fz = O.Fuser(reg, res=3.0, submap_scan_size=4, weight_intensity=True)
-                for f in range(F):
-                    if done >= budget_frames:
-                        break
-                    sr, si, scn = O.kstrongest(base[sd, f], K_STRONGEST, 60)
-                    cloud = O.kstrongest_cloud(sr, si, scn, 0.0438, 2.5)
-                    pose, oi = fz.process(cloud)
-                    done += 1
-                    if ps == 0 and W <= f < W + K:
-                        d = np.abs(poses[f - W, sd] - pose)
-                        err_xy, err_th = max(err_xy, d[:2].max()), max(err_th, d[2])
-                        compared += 1
-        tc = time.perf_counter() - tc0
-        cpu = {"value": done / tc, "unit": "registrations/s", "cores": 1, "kind": "port",
-               "sample": "%d frames = %d pass(es) over %d sequences x %d frames of this run's input, full path "
-                         "filter->pose, oracle/liboracle.so g++ -O3, 1 thread, %.1f s; host has %d cores"
-                         % (done, passes, n_seq, F, tc, os.cpu_count())}
-        pose_err = {"max_abs_xy_m": err_xy, "max_abs_theta_rad": err_th, "frames_compared": compared}
-        # the same oracle on the host's cores, one sequence per thread at a time like the reference's NR_WORKERS
-        # processes (one native call per sequence, GIL released; the oracle has no shared state)
-        from concurrent.futures import ThreadPoolExecutor
-        T = _usable_cpus()
-
-        def one_sequence(sd):
-            fz = O.Fuser(reg, res=3.0, submap_scan_size=4, weight_intensity=True)
-            fz.run_sequence(base[sd % n_seq], K_STRONGEST, 60, 0.0438, 2.5)   # one native call per sequence
-            return F
-        n_tasks = 48 * T                                  # ~10 s at ~8 ms per frame
-        tm0 = time.perf_counter()
-        with ThreadPoolExecutor(T) as ex:
-            done_mt = sum(ex.map(one_sequence, range(n_tasks)))
-        tm = time.perf_counter() - tm0
-        cpu_mt = {"value": done_mt / tm, "unit": "registrations/s", "cores": T, "kind": "port",
-                  "sample": "%d sequences x %d frames on %d threads (cgroup quota / affinity of this host: %d of %d CPUs), "
-                            "%.1f s" % (n_tasks, F, T, T, os.cpu_count() or 0, tm)}
+    for tag in ("r02", "r01"):
+        tj = os.path.join(ROOT, "profiles", tag, "pmc_traffic.json")
+        if os.path.exists(tj):
+            t = json.load(open(tj))
+            roof["traffic"] = (t["fetch_bytes_per_scan"] + t["write_bytes_per_scan"]) * B
+            roof["traffic_source"] = "profiles/%s/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, per scan x batch)" % tag
+            break
+    else:
+        roof["traffic"] = None
 
     out = {
         "metric": "radar scan registrations/sec (400x3360 polar)",
         "value": value,
         "unit": "registrations/s",
-        "n_gpus": world,
+        "n_gpus": D.world,
         "steps": K,
         "warmup": W,
         "ms_per_step": elapsed / K * 1e3,
@@ -413,29 +471,146 @@ def main():
         "scaling": "weak",
         "vs_baseline": None,
         "dtype": "u8 filter / f32 search / f64 solve",
-        "data": "synthetic (scene_v1 walls+scatterers, %d distinct sequences replicated to %d streams per GPU, "
-                "each stream its own HBM copy)" % (base.shape[0], B),
+        "data": "synthetic (%s walls+scatterers rendered on the GPU: %d distinct worlds per GPU, each a ring of %d sweeps along a "
+                "closed circle; %d streams per GPU = distinct (world, start frame) pairs; %.1f GB resident, re-read from HBM every "
+                "frame)" % ("scene_dense" if args.dense else "scene_v1", S, F, B, S * F * IMG / 1e9),
         "config": {"workload": "configs[1]: per-frame CFEAR-3 odometry registration (k=40, z_min=60, r=3, P2P, "
-                               "4-keyframe window%s), polar image -> pose, %d streams in flight per GPU"
-                               % (", + covariance by cost sampling" if args.cov_sampling else "", B),
-                   "streams_per_gpu": B, "rows": ROWS, "cols": COLS, "parallelism": "replicas x%d" % world},
-        "roofline": {"bound": "hbm", "kernel": "kstrongest_rows", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                     "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                     "traffic_source": "profiles/r01/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, per scan x batch)",
-                     "avg_launch_ms": avg_ms, "algorithmic_bytes_per_launch": bytes_per_scan * B,
-                     "mean_points_per_scan": nf},
-        "with_peaks_cloud": with_peaks,
-        "cpu_baseline": cpu,
-        "cpu_baseline_all_threads": cpu_mt,
-        "pose_error_vs_cpu": pose_err,
+                               "4-keyframe window%s), polar image -> pose, %d streams in flight per GPU, %d frames per step"
+                               % (", + covariance by cost sampling" if args.cov_sampling else "", B, FPS),
+                   "streams_per_gpu": B, "frames_per_step": FPS, "sequences_per_gpu": S, "ring_frames": F,
+                   "rows": ROWS, "cols": COLS, "parallelism": "replicas x%d" % D.world,
+                   "registrations_per_step": B * FPS * D.world},
+        "ms_per_frame_batch": elapsed / (K * FPS) * 1e3,
+        "timed_region_s": elapsed,
+        "rccl_ranks": len(per_rank),
+        "per_rank_value": per_rank,
+        "roofline": roof,
         "kernel_breakdown": breakdown,
-        "mean_cells_per_scan": float(n_cells.mean()),
-        "failed_registrations": status_bad,
+        "mean_cells_per_scan": tot["cells"] / max(tot["frames"], 1),
+        "failed_registrations": bad_total,
         "input_generation_s": t_gen,
     }
+    if D.world > 1:
+        print(json.dumps(out))
+        return D.close()
+
+    # =====================================================================================================
+    # 1 GPU only, after the timed region: extra passes and the CPU baseline
+    # =====================================================================================================
+    od.close()
+    if not args.no_extras and not (args.bins_major or args.keep_nodes or args.cov_sampling):
+        # ---- dense rows: every azimuth holds >= k bins >= z_min (N_f ~ 16 000, the reference's upper bound) ----
+        if not args.dense:
+            Sd, Bd, nfr = 32, 1024, 24
+            drings = make_rings(Sd, F, 50000, dev, dense=True)
+            dss = StreamSet(Bd, Sd, F)
+            odd = new_fuser(Bd)
+            run_odometry(odd, drings, dss, 4)
+            D.barrier()
+            ctx.profile_enable(True); ctx.profile_read(reset=True)
+            td = time.perf_counter()
+            dst = run_odometry(odd, drings, dss, nfr, 4)
+            D.barrier()
+            td = time.perf_counter() - td
+            dprof = ctx.profile_read(reset=True); ctx.profile_enable(False)
+            cand = float((drings[0, :4] >= 60).sum(dim=2).float().mean().item())
+            rd = roofline_of(dprof, Bd, dst["points"] / dst["frames"])
+            rd.update({"value": Bd * nfr / td, "unit": "registrations/s (full path on the dense scenes)",
+                       "ms_per_frame_batch": td / nfr * 1e3, "streams": Bd, "frames": nfr,
+                       "mean_candidates_per_row": cand, "mean_cells_per_scan": dst["cells"] / dst["frames"],
+                       "failed_registrations": dst["bad"],
+                       "kernel_breakdown": {k: v[0] / max(v[1], 1) for k, v in dprof.items()},
+                       "data": "scene_dense: %d worlds x ring %d, %d streams" % (Sd, F, Bd)})
+            out["roofline_dense"] = rd
+            odd.close()
+            del drings
+        # ---- one sequence alone: the literal configs[1] case (latency-bound) ---------------------------------
+        od1 = new_fuser(1)
+        ss1 = StreamSet(1, 1, F)
+        run_odometry(od1, rings, ss1, 8)
+        D.barrier()
+        n1 = 400
+        ts = time.perf_counter()
+        st1 = run_odometry(od1, rings, ss1, n1, 8)
+        D.barrier()
+        ts = time.perf_counter() - ts
+        out["single_stream"] = {"value": n1 / ts, "unit": "registrations/s", "ms_per_frame": ts / n1 * 1e3, "frames": n1,
+                                "failed_registrations": st1["bad"],
+                                "note": "one sequence, frame t needs pose t-1: the rate is 1 / latency"}
+        od1.close()
+        # ---- host-resident input: pinned images, the H2D copy inside the timed region --------------------------
+        Bh, Gh, nh = 512, 4, 12
+        hod = new_fuser(Bh)
+        hss = StreamSet(Bh, S, F)
+        host = torch.empty((Gh, Bh, ROWS, COLS), dtype=torch.uint8).pin_memory()
+        for g in range(Gh):
+            idx = torch.from_numpy(hss.seq * F + (hss.start + g) % F).to(dev)
+            host[g].copy_(rings.view(S * F, ROWS, COLS).index_select(0, idx))
+        torch.cuda.synchronize()
+        for g in range(Gh):
+            hod.process(host[g], host[(g + 1) % Gh])
+        D.barrier()
+        th = time.perf_counter()
+        for t in range(nh):
+            hod.process(host[t % Gh], host[(t + 1) % Gh])
+        D.barrier()
+        th = time.perf_counter() - th
+        out["host_input"] = {"value": Bh * nh / th, "unit": "registrations/s", "ms_per_frame_batch": th / nh * 1e3, "streams": Bh,
+                             "GBs_over_pcie": Bh * nh * IMG / th / 1e9,
+                             "note": "images in pinned host memory, one H2D copy per frame batch inside the timed region "
+                                     "(PCIe-bound; never `value`); a ring of %d frame batches cycles" % Gh}
+        hod.close()
+        del host
+        # ---- loop-closure candidates from cached features (configs[3]) ---------------------------------------
+        lc = loopclosure_run(D, args.candidates, 20, 3)
+        out["loopclosure"] = {k: lc[k] for k in ("value", "unit", "ms_per_step", "ms_per_4096", "ok_fraction", "mean_outer_iters")}
+        out["loopclosure"]["candidates"] = args.candidates
+
+    # ---- CPU baseline: the oracle (port), 1 thread, bounded sample of the same frames -----------------
+    if not args.no_cpu_baseline and not (args.bins_major or args.keep_nodes):
+        from oracle import pyoracle as O
+        n_frames_cpu = min((W + K) * FPS, max(8, (args.cpu_frames or 1600) // n_cmp))
+        host_rings = rings[:n_cmp].cpu().numpy()                   # sequences 0 .. n_cmp-1, streams 0 .. n_cmp-1 start at frame 0
+        reg = O.reg_params(cost="P2P", loss="Huber", loss_limit=0.1, weight_opt=4, regularization=0.0)
+        done, tc0 = 0, time.perf_counter()
+        err_xy, err_th = 0.0, 0.0
+        for sd in range(n_cmp):
+            fz = O.Fuser(reg, res=3.0, submap_scan_size=4, weight_intensity=True)
+            for f in range(n_frames_cpu):
+                sr, si, scn = O.kstrongest(host_rings[sd, f % F], K_STRONGEST, 60)
+                cloud = O.kstrongest_cloud(sr, si, scn, 0.0438, 2.5)
+                pose, oi = fz.process(cloud)
+                done += 1
+                d = np.abs(poses[f, sd] - pose)
+                d[2] = abs((d[2] + np.pi) % (2 * np.pi) - np.pi)
+                err_xy, err_th = max(err_xy, d[:2].max()), max(err_th, d[2])
+        tc = time.perf_counter() - tc0
+        out["cpu_baseline"] = {"value": done / tc, "unit": "registrations/s", "cores": 1, "kind": "port",
+                               "sample": "%d frames = the first %d frames of %d of this run's streams, full path filter->pose, "
+                                         "oracle/liboracle.so g++ -O3, 1 thread, %.1f s; host has %d cores"
+                                         % (done, n_frames_cpu, n_cmp, tc, os.cpu_count())}
+        out["pose_error_vs_cpu"] = {"max_abs_xy_m": err_xy, "max_abs_theta_rad": err_th, "frames_compared": done}
+        # the same oracle on the host's cores, one sequence per thread at a time like the reference's NR_WORKERS
+        # processes (one native call per sequence, GIL released; the oracle has no shared state)
+        from concurrent.futures import ThreadPoolExecutor
+        T = _usable_cpus()
+        nseq_mt = 40
+
+        def one_sequence(i):
+            fz = O.Fuser(reg, res=3.0, submap_scan_size=4, weight_intensity=True)
+            fz.run_sequence(host_rings[i % n_cmp, :nseq_mt], K_STRONGEST, 60, 0.0438, 2.5)   # one native call per sequence
+            return nseq_mt
+        n_tasks = 3 * T
+        tm0 = time.perf_counter()
+        with ThreadPoolExecutor(T) as ex:
+            done_mt = sum(ex.map(one_sequence, range(n_tasks)))
+        tm = time.perf_counter() - tm0
+        out["cpu_baseline_all_threads"] = {
+            "value": done_mt / tm, "unit": "registrations/s", "cores": T, "kind": "port",
+            "sample": "%d sequences x %d frames on %d threads (cgroup quota / affinity of this host: %d of %d CPUs), %.1f s"
+                      % (n_tasks, nseq_mt, T, T, os.cpu_count() or 0, tm)}
     print(json.dumps(out))
-    if world > 1:
-        dist.destroy_process_group()
+    D.close()
 
 
 if __name__ == "__main__":

@@ -527,9 +527,25 @@ int cfear_odometry_create(cfear_ctx* ctx, int32_t n_streams, const cfear_polar_d
 int cfear_odometry_process(cfear_odometry* od, const uint8_t* polar, cfear_frame_info* info);
 /* Same, and additionally enqueues the FILTER of the next frame's images (polar_next, may be NULL) behind
  * this frame's kernels, so the GPU sweeps the next polar batch while the host applies this frame's
- * keyframe policy.  The next call must then pass that same pointer as `polar`.                   */
+ * keyframe policy.  The next call must then pass that same pointer as `polar`: the hit is decided by the
+ * pointer value only (see cfear_odometry_discard_prefetch).  Return value: per-stream failures (empty sweep,
+ * capacity) do not stop the other streams -- every info[b] is filled, info[b].reg_status holds the stream's
+ * own status and the call returns the first such status; a failed prefetch is reported the same way after
+ * this frame has been completed.                                                                  */
 int cfear_odometry_process_prefetch(cfear_odometry* od, const uint8_t* polar, const uint8_t* polar_next,
                                     cfear_frame_info* info);
+/* The same step for hosts whose sweeps do not sit at a constant stride (one ring buffer per sequence, sensor drivers
+ * with their own allocations): stream b's image starts at base + offsets[b] bytes (device memory, laid out per desc
+ * otherwise); offsets_next (may be NULL) names the next frame's images for the prefetch, which is recognised on the
+ * next call by the same base and the same offsets.  offsets are HOST arrays [n_streams].  Available for the
+ * k-strongest filter with k <= 64, rows = azimuths, keep_nodes = 0 (the fused filter output); otherwise
+ * CFEAR_ERR_INVALID_ARGUMENT.                                                                                   */
+int cfear_odometry_process_offsets(cfear_odometry* od, const uint8_t* base, const int64_t* offsets,
+                                   const int64_t* offsets_next, cfear_frame_info* info);
+/* Forget a prefetched filter output.  A prefetch hit is decided by the address (and offsets) of the images alone: a
+ * host that REUSES a buffer for different content (drops a frame, rewrites a ring slot) must call this first, or the
+ * stale filter output of the earlier content is consumed.                                                        */
+int cfear_odometry_discard_prefetch(cfear_odometry* od);
 /* The same step for callers whose own driver has filtered the sweep: OdometryKeyframeFuser::pointcloudCallback(cloud,
  * cloud_peaks, Tcurrent, t, cov) (odometrykeyframefuser.cpp:413-426) for every stream.  clouds [n_streams]: the filtered
  * clouds (x, y, z, intensity; host or device, <= rows * k points each); peaks [n_streams] (may be NULL): the peaks

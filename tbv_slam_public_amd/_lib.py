@@ -204,6 +204,7 @@ EXPORTS = [
     "cfear_odometry_params_default", "cfear_odometry_params_preset", "cfear_odometry_create", "cfear_odometry_process",
     "cfear_odometry_process_prefetch", "cfear_odometry_get_covariance", "cfear_odometry_destroy",
     "cfear_odometry_get_scan", "cfear_odometry_get_cloud", "cfear_odometry_get_peaks", "cfear_odometry_process_clouds",
+    "cfear_odometry_process_offsets", "cfear_odometry_discard_prefetch",
 ]
 
 _LIB = None
@@ -305,6 +306,8 @@ def lib():
                                         C.POINTER(vp)]
     L.cfear_odometry_process.argtypes = [vp, vp, vp]
     L.cfear_odometry_process_prefetch.argtypes = [vp, vp, vp, vp]
+    L.cfear_odometry_process_offsets.argtypes = [vp, vp, vp, vp, vp]
+    L.cfear_odometry_discard_prefetch.argtypes = [vp]
     L.cfear_odometry_get_covariance.argtypes = [vp, vp, vp]
     L.cfear_odometry_destroy.argtypes = [vp]
     _LIB = L

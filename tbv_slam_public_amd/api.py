@@ -1156,9 +1156,38 @@ class OdometryKeyframeFuser:
         kernels so the GPU works while the host applies this frame's keyframe policy.  The next call
         must pass that same buffer as `polar`."""
         self._keep = (polar, polar_next)
-        self.ctx.check(self.ctx._lib.cfear_odometry_process_prefetch(self._h, _ptr(polar)[0], _ptr(polar_next)[0],
-                                                                     self._info.ctypes.data))
+        # per-stream failures (an empty sweep, a capacity overflow) are results, not exceptions: the other streams
+        # have advanced and their info is filled in -- inspect info["reg_status"]
+        self._info[:] = 0
+        return self._done(self.ctx._lib.cfear_odometry_process_prefetch(self._h, _ptr(polar)[0], _ptr(polar_next)[0],
+                                                                        self._info.ctypes.data))
+
+    _PER_STREAM = (L.ERR_EMPTY_CLOUD, L.ERR_CAPACITY)
+
+    def _done(self, rc):
+        """A status that some stream reports as its own (info.reg_status) is that stream's result; anything else is a
+        failed call."""
+        if rc in self._PER_STREAM and (self._info["reg_status"] == rc).any():
+            return self._info.copy()
+        self.ctx.check(rc)
         return self._info.copy()
+
+    def process_offsets(self, base, offsets, offsets_next=None):
+        """The same step for sweeps that do not sit at a constant stride: stream b's image starts `offsets[b]` bytes
+        into the device buffer `base` (a ring of frames, one buffer per sequence).  offsets / offsets_next: int64
+        [n_streams].  offsets_next prefetches the next frame's filter; pass the same values as `offsets` next time."""
+        self._keep = (base,)
+        o = np.ascontiguousarray(offsets, np.int64)
+        on = None if offsets_next is None else np.ascontiguousarray(offsets_next, np.int64)
+        assert o.shape == (self.n_streams,) and (on is None or on.shape == o.shape)
+        self._info[:] = 0
+        return self._done(self.ctx._lib.cfear_odometry_process_offsets(self._h, _ptr(base)[0], o.ctypes.data,
+                                                                       None if on is None else on.ctypes.data,
+                                                                       self._info.ctypes.data))
+
+    def discard_prefetch(self):
+        """Forget a prefetched filter output (call before REUSING an image buffer for different content)."""
+        self.ctx.check(self.ctx._lib.cfear_odometry_discard_prefetch(self._h))
 
     def process_clouds(self, clouds, peaks=None):
         """pointcloudCallback(cloud, cloud_peaks, ...) (odometrykeyframefuser.cpp:413-426) for every stream: the caller's
@@ -1175,8 +1204,8 @@ class OdometryKeyframeFuser:
         assert len(clouds) == self.n_streams and (peaks is None or len(peaks) == self.n_streams)
         ca, k1 = pack(clouds)
         pa, k2 = pack(peaks) if peaks is not None else (None, None)
-        self.ctx.check(self.ctx._lib.cfear_odometry_process_clouds(self._h, ca, pa, self._info.ctypes.data))
-        return self._info.copy()
+        self._info[:] = 0
+        return self._done(self.ctx._lib.cfear_odometry_process_clouds(self._h, ca, pa, self._info.ctypes.data))
 
     def node(self, stream, device=False):
         """The RadarScan of `stream`'s last processed frame (scan_, odometrykeyframefuser.cpp:172, 244; types.h:119-122)

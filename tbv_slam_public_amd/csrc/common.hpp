@@ -108,8 +108,21 @@ int cfear_scan_clone_view(cfear_ctx* ctx, const ScanView& src, int n_cells, cfea
 // ---------------------------------------------------------------------------------------------
 // cross-file entry points (device-pointer level; used by the batched odometry pipeline)
 // ---------------------------------------------------------------------------------------------
+// Optional extras of the device-side k-strongest entry (the batched odometry pipeline):
+//   row_keys / row_valid    the kept bins beyond min_distance of every row as packed keys (intensity << 24 | range bin)
+//                           at [(b * rows + r) * k + j], j < row_valid[(b * rows + r) * 2], in the reference's cloud
+//                           order (k <= 64); the surface-point kernel compacts the rows and converts them to PointXYZI,
+//                           so neither sel_* arrays nor a cloud kernel are needed;
+//   image_offsets           device [batch] byte offsets of the images from d_polar (streams whose sweeps do not sit at
+//                           a constant stride: ring buffers, one buffer per sequence) instead of b * batch_stride.
+struct cfear_kstrong_fused {
+  uint32_t* row_keys = nullptr;
+  int32_t* row_valid = nullptr;
+  const int64_t* image_offsets = nullptr;
+};
 int cfear_kstrong_device(cfear_ctx* ctx, const uint8_t* d_polar, const cfear_polar_desc* desc,
-                         const cfear_kstrong_params* par, const cfear_kstrong_out* o, bool dense_halo = false);
+                         const cfear_kstrong_params* par, const cfear_kstrong_out* o, bool dense_halo = false,
+                         const cfear_kstrong_fused* fused = nullptr);
 int cfear_compensate_batch_device(cfear_ctx* ctx, float* d_xyzi, size_t cloud_stride_points, const int32_t* d_n,
                                   const double* d_mot, int n_clouds, int max_points, int ccw);
 int cfear_rotate_ccw_device(cfear_ctx* ctx, const uint8_t* d_src, const cfear_polar_desc* src_desc, uint8_t* d_dst,
@@ -123,8 +136,15 @@ size_t cfear_surface_job_bytes();
 int cfear_surface_max_points();
 void cfear_surface_fill_job(void* dst, float* d_xyzi, const int32_t* d_n, int32_t n_host, int compensate,
                             const double mot[3], const ScanView& out);
+// rows mode: the cloud is handed over as the fused filter output (cfear_kstrong_fused) and compacted by the kernel
+// into d_xyzi (capacity cfear_surface_max_points()); d_n_out receives the point count.  rows <= 4096.
+void cfear_surface_fill_job_rows(void* dst, float* d_xyzi, int32_t* d_n_out, const uint32_t* d_row_keys, const int32_t* d_row_cnt,
+                                 int rows, int k, int compensate, const double mot[3], const ScanView& out);
+// rows mode needs the polar -> Cartesian constants: call before cfear_surface_launch (per context)
+struct cfear_surface_polar { const double* cos_t = nullptr; const double* sin_t = nullptr; double range_res = 0.0; };
+int cfear_trig_tables(cfear_ctx* ctx, int rows, double** d_cos, double** d_sin);
 int cfear_surface_launch(cfear_ctx* ctx, const void* d_jobs, int n_jobs, const cfear_feature_params* par,
-                         char* d_scratch, int32_t* d_status, int32_t* d_ncells_out);
+                         char* d_scratch, int32_t* d_status, int32_t* d_ncells_out, const cfear_surface_polar* polar = nullptr);
 size_t cfear_reg_job_bytes();
 int cfear_reg_max_scans();
 void cfear_reg_fill_job(void* dst, const ScanView* views, int n_scans, const double* poses_xyt);

@@ -45,6 +45,12 @@ struct KStrongArgs {
   int min_range_bin;
   int dense_halo;          // 1: the image is a padded copy of a DENSE cv::Mat (the pipeline's rotated buffer): bins read
                            // past a row end are the first bins of the next row, not the padding
+  // Fused cloud output (the batched odometry pipeline, k <= 64): the kept bins beyond min_range_bin of row r as packed
+  // keys (intensity << 24 | range bin) at row_keys[(b * rows + r) * k + j], j < row_valid[..][0], in the reference's
+  // order (ascending (intensity, range), radar_filters.cpp:309-337): 4 bytes per point instead of a PointXYZI; the
+  // surface-point kernel compacts the rows and converts to Cartesian (surface.hip).
+  uint32_t* row_keys;
+  const long long* image_offsets;   // optional [batch]: byte offset of image b from `polar` instead of b * batch_stride
 };
 
 // bit 7 of every byte of the result is set iff that byte of x is >= t (0 <= t <= 255).
@@ -124,19 +130,19 @@ __device__ __forceinline__ void for_each_candidate(const uint32_t (&bm)[NCHUNK],
 }
 
 template <int NCHUNK, bool VEC, bool MASK>
-__global__ __launch_bounds__(256) void kstrongest_rows_kernel(const KStrongArgs a) {
+__global__ __launch_bounds__(256, 7) void kstrongest_rows_kernel(const KStrongArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int r = blockIdx.x * kRowsPerBlock + wave;          // grid = (row quads, images): no division
   if (r >= a.rows) return;                                  // no workgroup barrier below
   const int b = a.batch0 + blockIdx.y;
-  const uint8_t* img = a.polar + (long long)b * a.batch_stride;
+  const uint8_t* img = a.polar + (a.image_offsets ? a.image_offsets[b] : (long long)b * a.batch_stride);
   const long long row_lin = (long long)r * a.stride;
   const uint8_t* rowp = img + row_lin;
   const int k = a.k;
   const int kpad = max((k + 3) & ~3, 64);          // list capacity: k survivors, or up to 64 candidates to rank
   constexpr int NP = (NCHUNK + 1) / 2;             // bitmap words per lane (two chunks per word)
-  constexpr int kScratch = (NP + 2) * 256 > 1024 ? (NP + 2) * 256 : 1024;
+  constexpr int kScratch = (NP + 2) * 256 > 1024 ? (NP + 2) * 256 : 1024;    // marker u8[256] | sexcl[64] | spw[NP][64], or hist[256]
   const int per_wave = NCHUNK * 1024 + 32 + kScratch + kpad * 4;
   uint8_t* rowbuf = smem + wave * per_wave + 16;                                  // the raw row, 16-byte halo either side
   uint32_t* hist = (uint32_t*)(smem + wave * per_wave + NCHUNK * 1024 + 32);      // [256] histogram / scatter scratch
@@ -168,6 +174,15 @@ __global__ __launch_bounds__(256) void kstrongest_rows_kernel(const KStrongArgs 
   for (int c = 0; c < NCHUNK; c++)                 // stage the row: candidate bytes are fetched by position
     *(uint4*)(rowbuf + (c * 64 + lane) * 16) = make_uint4(w[c * 4], w[c * 4 + 1], w[c * 4 + 2], w[c * 4 + 3]);
 
+  // The row lives on in LDS: the (rare) later passes over it re-read it from there instead of keeping 4 NCHUNK
+  // registers alive across the whole kernel (occupancy: 8 wavefronts per SIMD need <= 64 VGPRs).
+  auto reload_row = [&](uint32_t (&x)[NCHUNK * 4]) {
+#pragma unroll
+    for (int c = 0; c < NCHUNK; c++) {
+      const uint4 v = *(const uint4*)(rowbuf + (c * 64 + lane) * 16);
+      x[c * 4] = v.x; x[c * 4 + 1] = v.y; x[c * 4 + 2] = v.z; x[c * 4 + 3] = v.w;
+    }
+  };
   // ---- candidates: bins with intensity >= uchar(z_min) (radar_filters.cpp:217) ---------------------
   uint32_t bm[NCHUNK];
   {
@@ -186,29 +201,37 @@ __global__ __launch_bounds__(256) void kstrongest_rows_kernel(const KStrongArgs 
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
-  // One candidate per lane, however the candidates cluster (a wall return fills adjacent bins of ONE lane).
-  // Owner lanes mark the first slot of their run; a max-scan spreads the owner id over the run; lane j then
-  // selects bit (j - first slot) of its owner's bitmap by popcount bisection.  n <= 64 candidates.
-  auto scatter_to_lanes = [&](const uint32_t (&bmx)[NCHUNK], int cnt_lane, int cnt_incl, int n) {
-    uint32_t* marker = hist;                       // [64]
-    uint32_t* sexcl = hist + 64;                   // [64] first slot of each lane's run
-    uint32_t* spw = hist + 128;                    // [NP][64] bitmaps
+  // One candidate per lane and round, however the candidates cluster (a wall return fills adjacent bins of ONE
+  // lane).  Candidates are numbered lane-major ("slots"); owner lanes mark the first slot of their run, a max-scan
+  // spreads the owner id over the run, and in round rd lane j takes slot 64 rd + j: it selects bit (slot - first
+  // slot) of its owner's bitmap by popcount bisection.  n <= 256 candidates -> at most 4 rounds, no divergent loop.
+  uint8_t* marker = (uint8_t*)hist;                // [256] owner lane of the slot that starts a run, else 0
+  uint32_t* sexcl = hist + 64;                     // [64] first slot of each lane's run
+  uint32_t* spw = hist + 128;                      // [NP][64] bitmaps
+  auto scatter_prepare = [&](const uint32_t (&bmx)[NCHUNK], int cnt_lane, int cnt_incl) {
     uint32_t pw[NP];
 #pragma unroll
     for (int p = 0; p < NP; p++) pw[p] = (bmx[2 * p] >> 4) | (2 * p + 1 < NCHUNK ? bmx[2 * p + 1] : 0u);
     const int excl = cnt_incl - cnt_lane;
-    marker[lane] = 0;
+    ((uint32_t*)marker)[lane] = 0;
     sexcl[lane] = excl;
 #pragma unroll
     for (int p = 0; p < NP; p++) spw[p * 64 + lane] = pw[p];
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    if (cnt_lane) marker[excl] = lane;
+    if (cnt_lane && excl < 256) marker[excl] = (uint8_t)lane;
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    const int own = wave_incl_scan_max_i32((int)marker[lane]);
-    if (lane < n) {
-      int q = lane - (int)sexcl[own];
+  };
+  int scatter_carry = 0;                           // owner of the last slot of the previous round
+  auto scatter_round = [&](int rd, int n, bool& valid) -> uint32_t {
+    const int slot = rd * 64 + lane;
+    const int own = max(scatter_carry, wave_incl_scan_max_i32((int)marker[slot]));
+    scatter_carry = __builtin_amdgcn_readlane(own, 63);
+    valid = slot < n;
+    uint32_t key = 0;
+    if (valid) {
+      int q = slot - (int)sexcl[own];
       uint32_t word = spw[own];
       int p = 0;
 #pragma unroll
@@ -224,8 +247,39 @@ __global__ __launch_bounds__(256) void kstrongest_rows_kernel(const KStrongArgs 
       { const int c = __popc(word & 0x3u);    if (q >= c) { q -= c; t += 2; word >>= 2; } }
       if (q >= (int)(word & 1u)) t += 1;
       const int pos = p * 2048 + own * 16 + ((t & 4) << 8) + ((t & 3) << 2) + (t >> 3);
-      list[lane] = ((uint32_t)rowbuf[pos] << 24) | (uint32_t)pos;
+      key = ((uint32_t)rowbuf[pos] << 24) | (uint32_t)pos;
     }
+    return key;
+  };
+  auto scatter_to_lanes = [&](const uint32_t (&bmx)[NCHUNK], int cnt_lane, int cnt_incl, int n) {   // n <= 64
+    scatter_prepare(bmx, cnt_lane, cnt_incl);
+    scatter_carry = 0;
+    bool valid;
+    const uint32_t key = scatter_round(0, n, valid);
+    if (valid) list[lane] = key;
+  };
+  // The cut intensity T of the k largest among the histogrammed keys: lane L owns intensities 4 (63 - L) + {0..3},
+  // an inclusive scan over lanes counts from 255 downward.
+  auto cut_from_hist = [&](int& T, int& n_gt, int& n_eq) {
+    const uint4 h = *(const uint4*)(hist + (63 - lane) * 4);
+    const int s_lane = (int)(h.x + h.y + h.z + h.w);
+    const int s_incl = wave_incl_scan_i32(s_lane);
+    const unsigned long long reach = __ballot(s_incl >= k);
+    const int lc = __ffsll((long long)reach) - 1;                  // first lane whose cumulative count reaches k
+    int Tl = 0, gl = 0, el = 0;
+    {
+      int cum = s_incl - s_lane;
+      const int hv[4] = {(int)h.w, (int)h.z, (int)h.y, (int)h.x};  // descending intensity
+      bool found = false;
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        if (!found && cum + hv[j] >= k) { Tl = 4 * (63 - lane) + 3 - j; gl = cum; el = hv[j]; found = true; }
+        cum += hv[j];
+      }
+    }
+    T = __builtin_amdgcn_readlane(Tl, lc);
+    n_gt = __builtin_amdgcn_readlane(gl, lc);
+    n_eq = __builtin_amdgcn_readlane(el, lc);
   };
 
   if (n_ge <= k || n_ge <= 64) {
@@ -242,49 +296,88 @@ __global__ __launch_bounds__(256) void kstrongest_rows_kernel(const KStrongArgs 
       for_each_candidate<NCHUNK>(bm, lane, [&](int pos) { list[slot++] = ((uint32_t)rowbuf[pos] << 24) | (uint32_t)pos; });
     }
   } else {
-    // ---- more than k and more than 64 candidates: cut intensity T from an LDS histogram ------------
+    // ---- more than k and more than 64 candidates: the cut intensity T -------------------------------------------
     n_sel = k;
     n_all = k;
-    *(uint4*)(hist + lane * 4) = make_uint4(0, 0, 0, 0);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    for_each_candidate<NCHUNK>(bm, lane, [&](int pos) { atomicAdd(&hist[rowbuf[pos]], 1u); });
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    // lane L owns intensities 4*(63-L)+{0..3}: an inclusive scan over lanes counts from 255 downward
-    const uint4 h = *(const uint4*)(hist + (63 - lane) * 4);
-    const int s_lane = (int)(h.x + h.y + h.z + h.w);
-    const int s_incl = wave_incl_scan_i32(s_lane);
-    const unsigned long long reach = __ballot(s_incl >= k);
-    const int lc = __ffsll((long long)reach) - 1;                  // first lane whose cumulative count reaches k
     int T = 0, n_gt = 0, n_eq = 0;
-    {
-      int cum = s_incl - s_lane;
-      const int hv[4] = {(int)h.w, (int)h.z, (int)h.y, (int)h.x};  // descending intensity
-      bool found = false;
+    bool have_list = false;                        // list[] already holds every bin >= T (n_all of them, <= 64)
+    // (a) very dense rows (> 256 candidates): raise the candidate threshold until between k and 256 bins pass it --
+    //     each trial is one SWAR pass over the register-resident row (5 VALU per 4 bins); the first trial assumes
+    //     a flat intensity distribution above the threshold, later ones bisect.  If two neighbouring thresholds
+    //     bracket k the cut is known exactly (a plateau) and goes to the tie scan below.
+    uint32_t bt[NCHUNK];
+    int t_lane = c_lane, t_incl = c_incl, n_c = n_ge;
 #pragma unroll
-      for (int j = 0; j < 4; j++) {
-        if (!found && cum + hv[j] >= k) { T = 4 * (63 - lane) + 3 - j; n_gt = cum; n_eq = hv[j]; found = true; }
-        cum += hv[j];
+    for (int c = 0; c < NCHUNK; c++) bt[c] = bm[c];
+    bool exact = false;
+    if (n_ge > 256) {
+      int lo = a.u_zmin, c_lo = n_ge, hi = 256, c_hi = 0;
+      bool first = true;
+      while (hi - lo > 1) {
+        int mid = first ? 256 - max(1, ((256 - lo) * 128) / c_lo) : (lo + hi) >> 1;
+        mid = min(max(mid, lo + 1), hi - 1);
+        first = false;
+        const uint32_t tm4 = (uint32_t)(mid & 0x7f) * 0x01010101u;
+        uint32_t bx[NCHUNK];
+        {
+          uint32_t wx[NCHUNK * 4];
+          reload_row(wx);
+          if (mid & 0x80) candidate_bitmaps<NCHUNK, MASK, true>(wx, tm4, a.cols, lane, bx);
+          else candidate_bitmaps<NCHUNK, MASK, false>(wx, tm4, a.cols, lane, bx);
+        }
+        int x_lane = 0;
+#pragma unroll
+        for (int c = 0; c < NCHUNK; c++) x_lane += __popc(bx[c]);
+        const int x_incl = wave_incl_scan_i32(x_lane);
+        const int cnt = __builtin_amdgcn_readlane(x_incl, 63);
+        if (cnt > 256) { lo = mid; c_lo = cnt; }
+        else if (cnt < k) { hi = mid; c_hi = cnt; }
+        else {
+#pragma unroll
+          for (int c = 0; c < NCHUNK; c++) bt[c] = bx[c];
+          t_lane = x_lane; t_incl = x_incl; n_c = cnt;
+          break;
+        }
+      }
+      if (n_c > 256) { exact = true; T = lo; n_gt = c_hi; n_eq = c_lo - c_hi; }
+    }
+    if (!exact) {
+      // (b) 64 < n_c <= 256 candidates: one key per lane and round (registers), an LDS histogram of the keys'
+      //     intensities -> T; the keys >= T (the survivors plus the ties at the cut, <= 64 unless a plateau is
+      //     wider) are packed into list[] by ballot and cut by rank below -- the reference's tie rule.
+      scatter_prepare(bt, t_lane, t_incl);
+      scatter_carry = 0;
+      uint32_t kr[4];
+      bool kv[4];
+      const int rounds = (n_c + 63) >> 6;
+#pragma unroll
+      for (int rd = 0; rd < 4; rd++) { kr[rd] = 0; kv[rd] = false; if (rd < rounds) kr[rd] = scatter_round(rd, n_c, kv[rd]); }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      *(uint4*)(hist + lane * 4) = make_uint4(0, 0, 0, 0);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int rd = 0; rd < 4; rd++) if (kv[rd]) atomicAdd(&hist[kr[rd] >> 24], 1u);
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      cut_from_hist(T, n_gt, n_eq);
+      if (n_gt + n_eq <= 64) {
+        int base = 0;
+#pragma unroll
+        for (int rd = 0; rd < 4; rd++) {
+          const bool sel = kv[rd] && (int)(kr[rd] >> 24) >= T;
+          const unsigned long long bal = __ballot(sel);
+          if (sel) list[base + __popcll(bal & ((1ull << lane) - 1ull))] = kr[rd];
+          base += __popcll(bal);
+        }
+        n_all = n_gt + n_eq;
+        have_list = true;
       }
     }
-    T = __builtin_amdgcn_readlane(T, lc);
-    n_gt = __builtin_amdgcn_readlane(n_gt, lc);
-    n_eq = __builtin_amdgcn_readlane(n_eq, lc);
-    if (n_gt + n_eq <= 64) {
-      // the bins >= T (all survivors plus the ties at the cut) fit one per lane: key them and let the rank cut
-      // below drop the lowest (intensity, range) keys -- the same tie rule, without the chunked tie scan
-      uint32_t bt[NCHUNK];
-      const uint32_t tt4 = (uint32_t)(T & 0x7f) * 0x01010101u;
-      if (T & 0x80) candidate_bitmaps<NCHUNK, MASK, true>(w, tt4, a.cols, lane, bt);
-      else candidate_bitmaps<NCHUNK, MASK, false>(w, tt4, a.cols, lane, bt);
-      int t_lane = 0;
-#pragma unroll
-      for (int c = 0; c < NCHUNK; c++) t_lane += __popc(bt[c]);
-      const int t_incl = wave_incl_scan_i32(t_lane);
-      n_all = n_gt + n_eq;
-      scatter_to_lanes(bt, t_lane, t_incl, n_all);
-    } else {
+    if (!have_list) {
+    uint32_t wt[NCHUNK * 4];
+    reload_row(wt);
     const int skip_eq = n_eq - (k - n_gt);         // drop the lowest-range ties: lexicographic (intensity, range)
     // ---- ordered compaction: all (> T) plus the (== T) bins of rank >= skip_eq in position order -----
     // (T >= z_min, so ">= T" implies candidacy; only the MASK variant needs the validity bits)
@@ -302,8 +395,8 @@ __global__ __launch_bounds__(256) void kstrongest_rows_kernel(const KStrongArgs 
       for (int d = 0; d < 4; d++) {
         const int i = c * 4 + d;
         const uint32_t valid = MASK ? ((bm[c] << (3 - d)) & 0x80808080u) : 0x80808080u;
-        mg[d] = thr_gt > 255 ? 0u : (swar_ge(w[i], tg4, tghi) & valid);
-        me[d] = swar_ge(w[i], te4, tehi) & valid & ~mg[d];
+        mg[d] = thr_gt > 255 ? 0u : (swar_ge(wt[i], tg4, tghi) & valid);
+        me[d] = swar_ge(wt[i], te4, tehi) & valid & ~mg[d];
         cg += __popc(mg[d]);
         ce += __popc(me[d]);
       }
@@ -326,7 +419,7 @@ __global__ __launch_bounds__(256) void kstrongest_rows_kernel(const KStrongArgs 
             const int e_sel_before = e_run > skip_eq ? e_run - skip_eq : 0;
             if (selected) {
               const int pos = (c * 64 + lane) * 16 + d * 4 + by;
-              list[g_run + e_sel_before] = (((w[c * 4 + d] >> (8 * by)) & 0xffu) << 24) | (uint32_t)pos;
+              list[g_run + e_sel_before] = (((wt[c * 4 + d] >> (8 * by)) & 0xffu) << 24) | (uint32_t)pos;
             }
             if (is_eq) e_run++; else g_run++;
           }
@@ -339,6 +432,7 @@ __global__ __launch_bounds__(256) void kstrongest_rows_kernel(const KStrongArgs 
   }
   const int nq = (n_all + 3) & ~3;
   for (int j = n_all + lane; j < nq; j += 64) list[j] = 0xFFFFFFFFu;      // pad for the b128 reads
+  if (a.row_keys && lane < 2) hist[2 + lane] = 0;                       // ranks of the kept bins beyond min_range_bin
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -427,6 +521,18 @@ __global__ __launch_bounds__(256) void kstrongest_rows_kernel(const KStrongArgs 
           if (sc[3 - i] > sc[3] || sc[3] < sc[3 + i]) pk = false;
         a.is_peak[obase + rank] = pk ? 1 : 0;
         beyond_pk = beyond && pk;
+      }
+    }
+    if (a.row_keys) {
+      // fused getPeaksFilteredPointCloud(cloud, false) (radar_filters.cpp:309-337): the row's kept bins in rank order;
+      // a bin's slot = number of kept bins beyond min_range_bin with a lower rank (k <= 64: one pass)
+      if (beyond) atomicOr(&hist[2 + (rank >> 5)], 1u << (rank & 31));
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      if (beyond) {
+        const uint32_t m0 = hist[2], m1 = hist[3];
+        const int idx = rank < 32 ? __popc(m0 & ((1u << rank) - 1u)) : __popc(m0) + __popc(m1 & ((1u << (rank - 32)) - 1u));
+        a.row_keys[obase + idx] = key;
       }
     }
     nvalid += __popcll(__ballot(beyond));
@@ -683,7 +789,10 @@ __global__ __launch_bounds__(256) void cacfar_cloud_kernel(const CfarCloudArgs a
 }
 
 // ---- host helpers --------------------------------------------------------------------------------
-int upload_trig(cfear_ctx* ctx, int rows, double** d_cos, double** d_sin) {
+}  // namespace
+// cos / sin of the azimuths (radar_filters.cpp:317), computed on the host in double so that the device's float
+// coordinates are bit-exact with the reference; cached per context.
+int cfear_trig_tables(cfear_ctx* ctx, int rows, double** d_cos, double** d_sin) {
   if (ctx->trig_rows == rows && ctx->ws[2].p) {      // tables are cached per context
     *d_cos = (double*)ctx->ws[2].p;
     *d_sin = (double*)ctx->ws[2].p + rows;
@@ -704,6 +813,8 @@ int upload_trig(cfear_ctx* ctx, int rows, double** d_cos, double** d_sin) {
   *d_sin = d + rows;
   return CFEAR_OK;
 }
+namespace {
+int upload_trig(cfear_ctx* ctx, int rows, double** d_cos, double** d_sin) { return cfear_trig_tables(ctx, rows, d_cos, d_sin); }
 
 int check_desc(cfear_ctx* ctx, const cfear_polar_desc* d) {
   if (!d || d->rows <= 0 || d->cols <= 0 || d->stride < d->cols || d->batch <= 0 ||
@@ -730,9 +841,16 @@ void launch_kstrong(cfear_ctx* ctx, const KStrongArgs& a, bool vec, bool mask, d
 // Device-side entry used by cfear_filter_kstrongest and by the odometry pipeline: everything is
 // already in device memory; outputs that are nullptr are skipped.
 int cfear_kstrong_device(cfear_ctx* ctx, const uint8_t* d_polar, const cfear_polar_desc* desc,
-                         const cfear_kstrong_params* par, const cfear_kstrong_out* o, bool dense_halo) {
+                         const cfear_kstrong_params* par, const cfear_kstrong_out* o, bool dense_halo,
+                         const cfear_kstrong_fused* fused) {
   const int z_min_i = (int)par->z_min;                         // radar_driver.cpp:58 float -> int
   KStrongArgs a;
+  a.row_keys = nullptr;
+  a.image_offsets = fused ? (const long long*)fused->image_offsets : nullptr;
+  if (fused && fused->row_keys) {
+    if (par->k_strongest > 64) return cfear_set_error(ctx, CFEAR_ERR_INVALID_ARGUMENT, "fused row keys need k <= 64");
+    a.row_keys = fused->row_keys;
+  }
   a.polar = d_polar;
   a.rows = desc->rows; a.cols = desc->cols; a.stride = desc->stride; a.batch = desc->batch;
   a.batch_stride = desc->batch > 1 ? desc->batch_stride : (int64_t)desc->rows * desc->stride;
@@ -748,7 +866,9 @@ int cfear_kstrong_device(cfear_ctx* ctx, const uint8_t* d_polar, const cfear_pol
     const double range_res_ = (double)par->range_res, min_distance_ = (double)par->min_distance;
     a.min_range_bin = (int)std::ceil(min_distance_ / range_res_);            // radar_filters.cpp:315
   }
-  if (want_cloud) {
+  if (fused && fused->row_valid) {
+    a.row_valid = fused->row_valid;
+  } else if (want_cloud) {
     a.row_valid = (int32_t*)cfear_workspace(ctx, 3, (size_t)desc->batch * desc->rows * 8);
     if (!a.row_valid) return cfear_set_error(ctx, CFEAR_ERR_HIP, "workspace allocation failed");
   }

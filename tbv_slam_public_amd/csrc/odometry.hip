@@ -74,6 +74,14 @@ struct cfear_odometry {
   int32_t* d_npts2[2] = {nullptr, nullptr};  //   may run while the host applies this frame's policy
   float* d_xyzi = nullptr;                   // buffer of the frame being processed
   int32_t* d_npts = nullptr;
+  // fused filter output (k-strongest without keep_nodes, k <= 64): per-row points + counts written by the polar sweep
+  // itself; the surface-point kernel compacts them, so neither sel_* arrays nor a cloud kernel exist in this mode
+  bool fused = false;
+  uint32_t* d_rowpts2[2] = {nullptr, nullptr};   // [B][rows][k] packed keys (intensity << 24 | range bin)
+  int32_t* d_rowcnt2[2] = {nullptr, nullptr};   // [B][rows][2]
+  int64_t* d_offsets2[2] = {nullptr, nullptr};  // [B] image offsets of the sweep in each filter buffer (process_offsets)
+  int64_t* h_offsets = nullptr;              // pinned staging, [2][B]
+  std::vector<int64_t> prefetched_offsets;   // offsets the prefetched filter output was computed from
   // par.keep_nodes: the peaks cloud of every frame (cloud_peaks_ of RadarScan), double-buffered like the cloud
   float* d_pk2[2] = {nullptr, nullptr};
   int32_t* d_npk2[2] = {nullptr, nullptr};
@@ -135,6 +143,9 @@ extern "C" int cfear_odometry_destroy(cfear_odometry* od) {
   if (od->ev_results) (void)hipEventDestroy(od->ev_results);
   if (od->ev_jobs) (void)hipEventDestroy(od->ev_jobs);
   if (od->copy_stream) (void)hipStreamDestroy(od->copy_stream);
+  void* dev2[] = {od->d_rowpts2[0], od->d_rowpts2[1], od->d_rowcnt2[0], od->d_rowcnt2[1], od->d_offsets2[0], od->d_offsets2[1]};
+  for (void* p : dev2) if (p) (void)hipFree(p);
+  if (od->h_offsets) (void)hipHostFree(od->h_offsets);
   void* dev[] = {od->d_pk2[0], od->d_pk2[1], od->d_npk2[0], od->d_npk2[1], od->d_mot, od->d_polar, od->d_rot, od->d_sel, od->d_xyzi2[0], od->d_xyzi2[1], od->d_npts2[0], od->d_npts2[1], od->d_slabs, od->d_surf_jobs, od->d_reg_jobs,
                  od->d_results, od->d_status, od->d_ncells, od->d_surf_scratch, od->d_reg_scratch, od->d_samples};
   for (void* p : dev) if (p) (void)hipFree(p);
@@ -155,6 +166,25 @@ extern "C" int cfear_odometry_create(cfear_ctx* ctx, int32_t n_streams, const cf
   if (!(par->res > 0.05f)) return cfear_set_error(ctx, CFEAR_ERR_INVALID_ARGUMENT, "res must be > 0.05");   // odometrykeyframefuser.cpp:25
   if (par->estimate_cov_by_sampling && (par->cov_sampling.samples_per_axis < 1 || par->cov_sampling.samples_per_axis > 15))
     return cfear_set_error(ctx, CFEAR_ERR_INVALID_ARGUMENT, "cov_sampling.samples_per_axis must be in [1,15]");
+  {
+    // the same argument rules as the standalone filter entry points (cfear_filter_kstrongest / cfear_filter_cacfar)
+    const int fcols = par->rotate_ccw ? desc->rows : desc->cols;
+    if (desc->rows <= 0 || desc->cols <= 0 || desc->stride < desc->cols ||
+        (n_streams > 1 && desc->batch_stride < (int64_t)desc->rows * desc->stride))
+      return cfear_set_error(ctx, CFEAR_ERR_INVALID_ARGUMENT, "bad polar descriptor");
+    if (fcols > 8192) return cfear_set_error(ctx, CFEAR_ERR_INVALID_ARGUMENT, "more than 8192 range bins unsupported");
+    if (par->filter_type == CFEAR_FILTER_CACFAR) {
+      if (par->cacfar.window_size < 1 || par->cacfar.nb_guard_cells < 0 || !(par->cacfar.range_res > 0.f))
+        return cfear_set_error(ctx, CFEAR_ERR_INVALID_ARGUMENT, "bad CFAR parameters");
+    } else if (par->filter_type == CFEAR_FILTER_KSTRONG) {
+      if (par->kstrong.k_strongest < 1 || par->kstrong.k_strongest > 1024)
+        return cfear_set_error(ctx, CFEAR_ERR_INVALID_ARGUMENT, "k_strongest must be in [1,1024]");
+      if (!(par->kstrong.range_res > 0.f) || !(par->kstrong.min_distance >= 0.f))
+        return cfear_set_error(ctx, CFEAR_ERR_INVALID_ARGUMENT, "range_res must be > 0 and min_distance >= 0");
+    } else {
+      return cfear_set_error(ctx, CFEAR_ERR_INVALID_ARGUMENT, "unknown filter_type %d", par->filter_type);
+    }
+  }
   CFEAR_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   cfear_odometry* od = new cfear_odometry();
   od->ctx = ctx; od->n_streams = n_streams; od->desc = *desc; od->in_desc = *desc; od->par = *par;
@@ -172,7 +202,18 @@ extern "C" int cfear_odometry_create(cfear_ctx* ctx, int32_t n_streams, const cf
   od->slab_bytes = cfear_scan_slab_bytes(od->cell_cap);
   const size_t nsel = (size_t)B * rows * std::max(k, 1);
   bool ok = true;
-  ok = ok && dalloc(&od->d_sel, nsel * 4 + 2 * (nsel + 256) + (size_t)B * rows * 4 + 1024);   // + is_peak (keep_nodes)
+  od->fused = par->filter_type == CFEAR_FILTER_KSTRONG && !par->keep_nodes && k <= 64 && rows <= 4096 &&
+              rows * k <= cfear_surface_max_points();
+  if (od->fused) {
+    for (int i = 0; i < 2; i++) {
+      ok = ok && dalloc(&od->d_rowpts2[i], nsel * 4);
+      ok = ok && dalloc(&od->d_rowcnt2[i], (size_t)B * rows * 8);
+      ok = ok && dalloc(&od->d_offsets2[i], (size_t)B * 8);
+    }
+    ok = ok && halloc(&od->h_offsets, (size_t)B * 8 * 2);
+  } else {
+    ok = ok && dalloc(&od->d_sel, nsel * 4 + 2 * (nsel + 256) + (size_t)B * rows * 4 + 1024);   // + is_peak (keep_nodes)
+  }
   if (par->keep_nodes) {
     for (int i = 0; i < 2; i++) {
       ok = ok && dalloc(&od->d_pk2[i], (size_t)B * od->cap_points * 16);
@@ -228,12 +269,22 @@ extern "C" int cfear_odometry_create(cfear_ctx* ctx, int32_t n_streams, const cf
 }
 
 // ---- F: filter (radar_driver.cpp:48-73) of one batch of polar images into filter buffer `buf` -------
-static int run_filter(cfear_odometry* od, const uint8_t* polar, int buf) {
+static int run_filter(cfear_odometry* od, const uint8_t* polar, int buf, const int64_t* offsets = nullptr) {
   cfear_ctx* ctx = od->ctx;
   const int B = od->n_streams, rows = od->desc.rows, k = od->par.kstrong.k_strongest;
   const cfear_odometry_params& par = od->par;
   const uint8_t* d_polar = polar;
   cfear_polar_desc dd = od->in_desc;
+  const int64_t* d_offsets = nullptr;
+  if (offsets) {
+    if (!od->fused || par.rotate_ccw || !cfear_is_device_ptr(polar))
+      return cfear_set_error(ctx, CFEAR_ERR_INVALID_ARGUMENT, "image offsets need device images, the k-strongest filter "
+                             "(k <= 64, no keep_nodes) and rows = azimuths");
+    int64_t* h = od->h_offsets + (size_t)buf * B;
+    memcpy(h, offsets, (size_t)B * 8);
+    CFEAR_HIP_CHECK(ctx, hipMemcpyAsync(od->d_offsets2[buf], h, (size_t)B * 8, hipMemcpyHostToDevice, ctx->stream));
+    d_offsets = od->d_offsets2[buf];
+  }
   if (!cfear_is_device_ptr(polar)) {
     const size_t img_bytes = (size_t)od->in_desc.rows * od->in_desc.stride;
     if (!od->d_polar && !dalloc(&od->d_polar, img_bytes * B)) return cfear_set_error(ctx, CFEAR_ERR_HIP, "staging allocation failed");
@@ -260,6 +311,15 @@ static int run_filter(cfear_odometry* od, const uint8_t* polar, int buf) {
   }
   const size_t nsel = (size_t)B * rows * k;
   cfear_kstrong_out o{};
+  if (od->fused) {
+    cfear_kstrong_params kp = par.kstrong;
+    kp.want_peaks = 0;
+    cfear_kstrong_fused fz;
+    fz.row_keys = od->d_rowpts2[buf];
+    fz.row_valid = od->d_rowcnt2[buf];
+    fz.image_offsets = d_offsets;
+    return cfear_kstrong_device(ctx, d_polar, &dd, &kp, &o, par.rotate_ccw != 0, &fz);
+  }
   o.sel_range = (int32_t*)od->d_sel;
   o.sel_intensity = (uint8_t*)(od->d_sel + nsel * 4);
   o.sel_count = (int32_t*)(od->d_sel + nsel * 4 + (nsel + 255) / 256 * 256);
@@ -292,7 +352,21 @@ extern "C" int cfear_odometry_process(cfear_odometry* od, const uint8_t* polar, 
 }
 
 static int process_frame(cfear_odometry* od, const uint8_t* polar, const uint8_t* polar_next, const cfear_sc_cloud* clouds,
-                         const cfear_sc_cloud* peaks, cfear_frame_info* info);
+                         const cfear_sc_cloud* peaks, cfear_frame_info* info, const int64_t* offsets = nullptr,
+                         const int64_t* offsets_next = nullptr);
+
+extern "C" int cfear_odometry_process_offsets(cfear_odometry* od, const uint8_t* base, const int64_t* offsets,
+                                              const int64_t* offsets_next, cfear_frame_info* info) {
+  if (!od || !base || !offsets || !info) return CFEAR_ERR_INVALID_ARGUMENT;
+  return process_frame(od, base, offsets_next ? base : nullptr, nullptr, nullptr, info, offsets, offsets_next);
+}
+
+extern "C" int cfear_odometry_discard_prefetch(cfear_odometry* od) {
+  if (!od) return CFEAR_ERR_INVALID_ARGUMENT;
+  od->prefetched = nullptr;
+  od->prefetched_offsets.clear();
+  return CFEAR_OK;
+}
 
 extern "C" int cfear_odometry_process_prefetch(cfear_odometry* od, const uint8_t* polar, const uint8_t* polar_next,
                                                cfear_frame_info* info) {
@@ -330,7 +404,7 @@ static int load_clouds(cfear_odometry* od, const cfear_sc_cloud* clouds, float* 
 }
 
 static int process_frame(cfear_odometry* od, const uint8_t* polar, const uint8_t* polar_next, const cfear_sc_cloud* clouds,
-                         const cfear_sc_cloud* peaks, cfear_frame_info* info) {
+                         const cfear_sc_cloud* peaks, cfear_frame_info* info, const int64_t* offsets, const int64_t* offsets_next) {
   cfear_ctx* ctx = od->ctx;
   CFEAR_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   const int B = od->n_streams;
@@ -344,19 +418,26 @@ static int process_frame(cfear_odometry* od, const uint8_t* polar, const uint8_t
       rc = load_clouds(od, peaks, od->d_pk2[od->cur_buf], od->d_npk2[od->cur_buf], od->h_npk);
       if (rc != CFEAR_OK) return rc;
     }
-  } else if (od->prefetched == polar) {            // this frame's filter already ran (or is running)
+  } else if (od->prefetched == polar &&
+             (offsets ? (od->prefetched_offsets.size() == (size_t)B &&
+                         memcmp(od->prefetched_offsets.data(), offsets, (size_t)B * 8) == 0)
+                      : od->prefetched_offsets.empty())) {   // this frame's filter already ran (or is running)
     od->cur_buf ^= 1;
   } else {
-    rc = run_filter(od, polar, od->cur_buf);
+    rc = run_filter(od, polar, od->cur_buf, offsets);
     if (rc != CFEAR_OK) return rc;
   }
   od->prefetched = nullptr;
+  od->prefetched_offsets.clear();
   od->d_xyzi = od->d_xyzi2[od->cur_buf];
   od->d_npts = od->d_npts2[od->cur_buf];
   od->d_pk = od->d_pk2[od->cur_buf];
   od->d_npk = od->d_npk2[od->cur_buf];
+  const bool rows_mode = od->fused && !clouds;     // the filter left per-row points: the surface kernel compacts them
   // ---- C + N: compensate with the previous motion, surface points (odometrykeyframefuser.cpp:146-161)
   const size_t sjb = cfear_surface_job_bytes();
+  for (int b = 0; b < B; b++)
+    if (od->streams[b].free_slabs.empty()) return cfear_set_error(ctx, CFEAR_ERR_CAPACITY, "stream %d: no free scan slab", b);
   for (int b = 0; b < B; b++) {
     Stream& st = od->streams[b];
     st.cur_slab = st.free_slabs.back();
@@ -365,9 +446,31 @@ static int process_frame(cfear_odometry* od, const uint8_t* polar, const uint8_t
     aff_to_xyt(st.Tmot, mot);                                     // Compensate(cloud, TprevMot, ccw)
     od->last_slab[b] = st.cur_slab;
     if (par.keep_nodes) { od->h_mot[3 * b] = mot[0]; od->h_mot[3 * b + 1] = mot[1]; od->h_mot[3 * b + 2] = mot[2]; }
-    cfear_surface_fill_job(od->h_surf_jobs + (size_t)b * sjb, od->d_xyzi + (size_t)b * od->cap_points * 4,
-                           od->d_npts + b, 0, par.compensate, mot, od->views[(size_t)b * od->slabs_per_stream + st.cur_slab]);
+    if (rows_mode)
+      cfear_surface_fill_job_rows(od->h_surf_jobs + (size_t)b * sjb, od->d_xyzi + (size_t)b * od->cap_points * 4, od->d_npts + b,
+                                  od->d_rowpts2[od->cur_buf] + (size_t)b * od->desc.rows * par.kstrong.k_strongest,
+                                  od->d_rowcnt2[od->cur_buf] + (size_t)b * od->desc.rows * 2, od->desc.rows,
+                                  par.kstrong.k_strongest, par.compensate, mot,
+                                  od->views[(size_t)b * od->slabs_per_stream + st.cur_slab]);
+    else
+      cfear_surface_fill_job(od->h_surf_jobs + (size_t)b * sjb, od->d_xyzi + (size_t)b * od->cap_points * 4,
+                             od->d_npts + b, 0, par.compensate, mot, od->views[(size_t)b * od->slabs_per_stream + st.cur_slab]);
   }
+  // From here on every stream holds a slab: an error exit must hand the slabs back, or submap_scan_size + 2 failed
+  // calls would drain a stream's free list.
+  auto fail = [&](int code) {
+    for (int b = 0; b < B; b++) {
+      Stream& st = od->streams[b];
+      if (st.cur_slab >= 0) { st.free_slabs.push_back(st.cur_slab); st.cur_slab = -1; }
+    }
+    return code;
+  };
+#define OD_CHECK(expr)                                                                                        \
+  do {                                                                                                        \
+    hipError_t _e = (expr);                                                                                   \
+    if (_e != hipSuccess)                                                                                     \
+      return fail(cfear_set_error(ctx, CFEAR_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__)); \
+  } while (0)
   // ---- M: the registration jobs depend on host state only: they are built and uploaded (copy stream) now,
   //      so the 2.3 KB per stream travel while the surface kernel runs (:164-186) ---------------------------
   const size_t rjb = cfear_reg_job_stride(par.submap_scan_size + 1);   // records cover the keyframe window + the new scan
@@ -390,24 +493,31 @@ static int process_frame(cfear_odometry* od, const uint8_t* polar, const uint8_t
     st.job = n_jobs++;
   }
   if (n_jobs > 0) {
-    CFEAR_HIP_CHECK(ctx, hipMemcpyAsync(od->d_reg_jobs, od->h_reg_jobs, (size_t)n_jobs * rjb, hipMemcpyHostToDevice, od->copy_stream));
-    CFEAR_HIP_CHECK(ctx, hipEventRecord(od->ev_jobs, od->copy_stream));
+    OD_CHECK(hipMemcpyAsync(od->d_reg_jobs, od->h_reg_jobs, (size_t)n_jobs * rjb, hipMemcpyHostToDevice, od->copy_stream));
+    OD_CHECK(hipEventRecord(od->ev_jobs, od->copy_stream));
   }
-  CFEAR_HIP_CHECK(ctx, hipMemcpyAsync(od->d_surf_jobs, od->h_surf_jobs, (size_t)B * sjb, hipMemcpyHostToDevice, ctx->stream));
+  OD_CHECK(hipMemcpyAsync(od->d_surf_jobs, od->h_surf_jobs, (size_t)B * sjb, hipMemcpyHostToDevice, ctx->stream));
   cfear_feature_params fp{};
   fp.radius = par.res;
   fp.downsample_factor = par.downsample_factor;
   fp.origin[0] = fp.origin[1] = 0.0;                              // Eigen::Vector2d(0,0), :161
   fp.weight_intensity = par.weight_intensity;
   fp.ccw = par.radar_ccw;
-  rc = cfear_surface_launch(ctx, od->d_surf_jobs, B, &fp, od->d_surf_scratch, od->d_status, od->d_ncells);
-  if (rc != CFEAR_OK) return rc;
+  cfear_surface_polar sp;
+  if (rows_mode) {
+    double *d_cos = nullptr, *d_sin = nullptr;
+    rc = cfear_trig_tables(ctx, od->desc.rows, &d_cos, &d_sin);
+    if (rc != CFEAR_OK) return fail(rc);
+    sp.cos_t = d_cos; sp.sin_t = d_sin; sp.range_res = (double)par.kstrong.range_res;
+  }
+  rc = cfear_surface_launch(ctx, od->d_surf_jobs, B, &fp, od->d_surf_scratch, od->d_status, od->d_ncells, rows_mode ? &sp : nullptr);
+  if (rc != CFEAR_OK) return fail(rc);
   if (n_jobs > 0) {
-    CFEAR_HIP_CHECK(ctx, hipStreamWaitEvent(ctx->stream, od->ev_jobs, 0));
+    OD_CHECK(hipStreamWaitEvent(ctx->stream, od->ev_jobs, 0));
     rc = cfear_register_launch(ctx, od->d_reg_jobs, n_jobs, &par.reg, par.submap_scan_size * od->cell_cap, od->cell_cap,
                                od->d_reg_scratch, od->d_results, nullptr, rjb);
-    if (rc != CFEAR_OK) return rc;
-    CFEAR_HIP_CHECK(ctx, hipMemcpyAsync(od->h_results, od->d_results, (size_t)n_jobs * sizeof(cfear_reg_result),
+    if (rc != CFEAR_OK) return fail(rc);
+    OD_CHECK(hipMemcpyAsync(od->h_results, od->d_results, (size_t)n_jobs * sizeof(cfear_reg_result),
                                         hipMemcpyDeviceToHost, ctx->stream));
     if (par.estimate_cov_by_sampling) {
       // approximateCovarianceBySampling (:203-208, 261-316): n^3 GetCost evaluations around the pose the
@@ -422,32 +532,37 @@ static int process_frame(cfear_odometry* od, const uint8_t* polar, const uint8_t
       mode.prior = od->d_results;
       rc = cfear_register_launch(ctx, od->d_reg_jobs, n_jobs, &par.reg, par.submap_scan_size * od->cell_cap, od->cell_cap,
                                  od->d_reg_scratch, od->d_samples, &mode, rjb);
-      if (rc != CFEAR_OK) return rc;
-      CFEAR_HIP_CHECK(ctx, hipMemcpyAsync(od->h_samples, od->d_samples, (size_t)n_jobs * od->fit.m * sizeof(cfear_reg_result),
+      if (rc != CFEAR_OK) return fail(rc);
+      OD_CHECK(hipMemcpyAsync(od->h_samples, od->d_samples, (size_t)n_jobs * od->fit.m * sizeof(cfear_reg_result),
                                           hipMemcpyDeviceToHost, ctx->stream));
     }
   }
   if (par.keep_nodes) {
     // Compensate(*cloud_peaks, TprevMot, ccw) (odometrykeyframefuser.cpp:149): off the critical path, behind the matcher
     if (par.compensate) {
-      CFEAR_HIP_CHECK(ctx, hipMemcpyAsync(od->d_mot, od->h_mot, (size_t)B * 3 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+      OD_CHECK(hipMemcpyAsync(od->d_mot, od->h_mot, (size_t)B * 3 * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
       rc = cfear_compensate_batch_device(ctx, od->d_pk, (size_t)od->cap_points, od->d_npk, od->d_mot, B, od->cap_points, par.radar_ccw);
-      if (rc != CFEAR_OK) return rc;
+      if (rc != CFEAR_OK) return fail(rc);
     }
-    CFEAR_HIP_CHECK(ctx, hipMemcpyAsync(od->h_npk, od->d_npk, (size_t)B * 4, hipMemcpyDeviceToHost, ctx->stream));
+    OD_CHECK(hipMemcpyAsync(od->h_npk, od->d_npk, (size_t)B * 4, hipMemcpyDeviceToHost, ctx->stream));
   }
-  CFEAR_HIP_CHECK(ctx, hipMemcpyAsync(od->h_status, od->d_status, (size_t)B * 4, hipMemcpyDeviceToHost, ctx->stream));
-  CFEAR_HIP_CHECK(ctx, hipMemcpyAsync(od->h_npts, od->d_npts, (size_t)B * 4, hipMemcpyDeviceToHost, ctx->stream));
-  CFEAR_HIP_CHECK(ctx, hipMemcpyAsync(od->h_ncells, od->d_ncells, (size_t)B * 4, hipMemcpyDeviceToHost, ctx->stream));
-  CFEAR_HIP_CHECK(ctx, hipEventRecord(od->ev_results, ctx->stream));
+  OD_CHECK(hipMemcpyAsync(od->h_status, od->d_status, (size_t)B * 4, hipMemcpyDeviceToHost, ctx->stream));
+  OD_CHECK(hipMemcpyAsync(od->h_npts, od->d_npts, (size_t)B * 4, hipMemcpyDeviceToHost, ctx->stream));
+  OD_CHECK(hipMemcpyAsync(od->h_ncells, od->d_ncells, (size_t)B * 4, hipMemcpyDeviceToHost, ctx->stream));
+  OD_CHECK(hipEventRecord(od->ev_results, ctx->stream));
+  int prefetch_rc = CFEAR_OK;
   if (polar_next) {
     // The next frame's filter needs no state of this frame: enqueue it now so the GPU sweeps the next
     // polar batch while the host applies the keyframe policy below.
-    rc = run_filter(od, polar_next, od->cur_buf ^ 1);
-    if (rc != CFEAR_OK) return rc;
-    od->prefetched = polar_next;
+    // A failed prefetch does not throw this frame away: its kernels already ran and its policy is applied below;
+    // the error is reported after the frame is complete and the next call simply filters again.
+    prefetch_rc = run_filter(od, polar_next, od->cur_buf ^ 1, offsets_next);
+    if (prefetch_rc == CFEAR_OK) {
+      od->prefetched = polar_next;
+      if (offsets_next) od->prefetched_offsets.assign(offsets_next, offsets_next + B);
+    }
   }
-  CFEAR_HIP_CHECK(ctx, hipEventSynchronize(od->ev_results));
+  OD_CHECK(hipEventSynchronize(od->ev_results));
   // ---- frame policy (:195-257) ------------------------------------------------------------------
   int first_error = CFEAR_OK;
   for (int b = 0; b < B; b++) {
@@ -529,7 +644,9 @@ static int process_frame(cfear_odometry* od, const uint8_t* polar, const uint8_t
     st.T_prev = Tcurrent;                                         // :257
     aff_to_xyt(Tcurrent, fi.pose);
   }
-  return first_error;
+  for (int b = 0; b < B; b++) od->streams[b].cur_slab = -1;      // every slab is a keyframe or back on the free list
+#undef OD_CHECK
+  return first_error != CFEAR_OK ? first_error : prefetch_rc;
 }
 
 // ---- graph-node export: the RadarScan of the last processed frame (types.h:119-122; scan_ at

@@ -46,6 +46,13 @@ struct SurfJob {                              // one scan
   int32_t compensate;
   double mot[3];
   ScanView out;
+  // rows mode (batched odometry, fused filter output): the cloud arrives as per-row lists of packed keys (intensity
+  // << 24 | range bin) -- row r holds row_cnt[2 r] keys at row_keys[r * k ...] -- and is compacted here, in row order,
+  // and converted to PointXYZI (radar_filters.cpp:317-330) into xyzi (n_out receives n)
+  const uint32_t* row_pts;
+  const int32_t* row_cnt;
+  int32_t* n_out;
+  int32_t rows, k;
 };
 
 struct SurfCommon {
@@ -58,6 +65,9 @@ struct SurfCommon {
   size_t scratch_stride;
   int32_t* status;                            // [n_jobs] CFEAR_OK / error
   int32_t* ncells_out;                        // [n_jobs] dense copy of the cell counts (nullable)
+  const double* cos_t;                        // rows mode: [rows] azimuth tables (host-computed doubles) and range_res
+  const double* sin_t;
+  double range_res;
 };
 
 struct TmpCell {                              // one candidate cell per voxel (before compaction)
@@ -223,6 +233,25 @@ __global__ __launch_bounds__(kSurfThreads) void surface_points_kernel(const Surf
   const SurfJob job = jobs[blockIdx.x];
   int n = job.n_ptr ? *job.n_ptr : job.n_host;
   int32_t* status = cm.status + blockIdx.x;
+  int32_t* rowoff = (int32_t*)(smem + kLdsRowbegOff);                 // rows mode: [rows + 1] exclusive prefix of the row counts
+  if (job.row_pts) {
+    int run = 0;
+    for (int r0 = 0; r0 < job.rows; r0 += kSurfThreads) {
+      const int r = r0 + tid;
+      const int v = r < job.rows ? job.row_cnt[2 * r] : 0;
+      const int incl = wave_incl_scan_i32(v);
+      if (lane == 63) red_i[wave] = incl;
+      __syncthreads();
+      int off = run + incl - v;
+      for (int wv = 0; wv < wave; wv++) off += red_i[wv];
+      if (r < job.rows) rowoff[r] = off;
+      for (int wv = 0; wv < 16; wv++) run += red_i[wv];
+      __syncthreads();
+    }
+    n = run;
+    if (tid == 0) { rowoff[job.rows] = n; if (job.n_out) *job.n_out = n; }
+    __syncthreads();
+  }
   if (n <= 0) {
     if (tid == 0) { *job.out.n_cells = 0; *status = CFEAR_ERR_EMPTY_CLOUD; if (cm.ncells_out) cm.ncells_out[blockIdx.x] = 0; }
     return;
@@ -251,16 +280,25 @@ __global__ __launch_bounds__(kSurfThreads) void surface_points_kernel(const Surf
 #pragma unroll
     for (int u = 0; u < 4; u++) {
       const int i = i0 + u * kSurfThreads;
-      if (i < n) p[u] = pts[i];
+      if (i < n) {
+        if (job.row_pts) {                              // row of point i: the last r with rowoff[r] <= i
+          int lo = 0, hi = job.rows;
+          while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (rowoff[mid] <= i) lo = mid; else hi = mid; }
+          const uint32_t key = job.row_pts[(size_t)lo * job.k + (i - rowoff[lo])];
+          const double range_res_half = cm.range_res / 2.0;
+          const double rho = range_res_half + cm.range_res * (double)(int)(key & 0xFFFFFFu);   // radar_filters.cpp:324-330
+          p[u] = make_float4((float)(rho * cm.cos_t[lo]), (float)(rho * cm.sin_t[lo]), 0.f, (float)(key >> 24));
+        } else {
+          p[u] = pts[i];
+        }
+      }
     }
 #pragma unroll
     for (int u = 0; u < 4; u++) {
       const int i = i0 + u * kSurfThreads;
       if (i < n) {
-        if (job.compensate) {
-          p[u] = compensate_point(p[u], job.mot, cm.ccw != 0);
-          pts[i] = p[u];
-        }
+        if (job.compensate) p[u] = compensate_point(p[u], job.mot, cm.ccw != 0);
+        if (job.compensate || job.row_pts) pts[i] = p[u];
         mnx = fminf(mnx, p[u].x); mxx = fmaxf(mxx, p[u].x);
         mny = fminf(mny, p[u].y); mxy = fmaxf(mxy, p[u].y);
       }
@@ -604,9 +642,19 @@ int cfear_surface_max_points() { return kMaxPoints; }
 struct cfear_surf_job_pod { unsigned char bytes[sizeof(SurfJob)]; };
 size_t cfear_surface_job_bytes() { return sizeof(SurfJob); }
 
+void cfear_surface_fill_job_rows(void* dst, float* d_xyzi, int32_t* d_n_out, const uint32_t* d_row_pts, const int32_t* d_row_cnt,
+                                 int rows, int k, int compensate, const double mot[3], const ScanView& out) {
+  cfear_surface_fill_job(dst, d_xyzi, nullptr, 0, compensate, mot, out);
+  SurfJob j;
+  memcpy(&j, dst, sizeof(j));
+  j.row_pts = d_row_pts; j.row_cnt = d_row_cnt; j.n_out = d_n_out; j.rows = rows; j.k = k;
+  memcpy(dst, &j, sizeof(j));
+}
+
 void cfear_surface_fill_job(void* dst, float* d_xyzi, const int32_t* d_n, int32_t n_host, int compensate,
                             const double mot[3], const ScanView& out) {
   SurfJob j;
+  j.row_pts = nullptr; j.row_cnt = nullptr; j.n_out = nullptr; j.rows = 0; j.k = 0;
   j.xyzi = (float4*)d_xyzi;
   j.n_ptr = d_n;
   j.n_host = n_host;
@@ -617,7 +665,7 @@ void cfear_surface_fill_job(void* dst, float* d_xyzi, const int32_t* d_n, int32_
 }
 
 int cfear_surface_launch(cfear_ctx* ctx, const void* d_jobs, int n_jobs, const cfear_feature_params* par,
-                         char* d_scratch, int32_t* d_status, int32_t* d_ncells_out) {
+                         char* d_scratch, int32_t* d_status, int32_t* d_ncells_out, const cfear_surface_polar* polar) {
   if (par->radius <= 0.f || !(par->downsample_factor > 0.0))
     return cfear_set_error(ctx, CFEAR_ERR_INVALID_ARGUMENT, "radius / downsample_factor must be > 0");
   SurfCommon cm;
@@ -636,6 +684,9 @@ int cfear_surface_launch(cfear_ctx* ctx, const void* d_jobs, int n_jobs, const c
   cm.scratch_stride = scratch_bytes_per_scan();
   cm.status = d_status;
   cm.ncells_out = d_ncells_out;
+  cm.cos_t = polar ? polar->cos_t : nullptr;
+  cm.sin_t = polar ? polar->sin_t : nullptr;
+  cm.range_res = polar ? polar->range_res : 0.0;
   // per launch: the attribute is per device, and contexts on other threads / devices share this code
   CFEAR_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)surface_points_kernel,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)cfear_surface_lds_bytes()));

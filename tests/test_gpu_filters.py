@@ -243,3 +243,41 @@ def test_radar_driver_mirror_non_oxford_layout():
     sr, si, sc, pk, oc, op = _oracle_kstrong(imgs[0], 12, 60, 0.0595238, 2.5)
     np.testing.assert_array_equal(cloud, oc)
     np.testing.assert_array_equal(peaks, op)
+
+
+def test_kstrongest_dense_rows_every_selection_path():
+    """Rows with more than 64 candidates: (a) 65..256 candidates -> keys per lane and round + histogram, survivors packed
+    by ballot; a plateau at the cut wider than 64 -> ordered tie scan; (b) more than 256 candidates -> threshold
+    bracketing first, including the case where two neighbouring thresholds bracket k (plateau of > 256 bins)."""
+    rng = np.random.default_rng(21)
+    rows = []
+    for n_c in (65, 100, 129, 192, 255, 256, 257, 300, 700, 1500, 3000):       # n_c candidates, distinct-ish intensities
+        row = rng.integers(0, 60, 3360).astype(np.uint8)
+        pos = rng.choice(3360, n_c, replace=False)
+        row[pos] = rng.integers(60, 256, n_c)
+        rows.append(row)
+    for n_c, val in ((200, 100), (300, 100), (2000, 61), (3360, 255), (3360, 60)):   # plateaus wider than 64 at the cut
+        row = np.full(3360, 10, np.uint8)
+        row[rng.choice(3360, n_c, replace=False)] = val
+        row[rng.choice(3360, 5, replace=False)] = 255                         # a few bins above the plateau
+        rows.append(row)
+    row = rng.integers(0, 60, 3360).astype(np.uint8)                            # one wall return filling whole lanes
+    row[1000:1160] = np.linspace(61, 220, 160).astype(np.uint8)
+    rows.append(row)
+    row = np.full(3360, 10, np.uint8)                                           # skewed: most candidates just above z_min
+    row[::3] = 60 + (rng.random(1120) ** 8 * 190).astype(np.uint8)
+    rows.append(row)
+    img = np.stack(rows)
+    for k in (12, 40, 64, 100):
+        _check(img, k, 60)
+    _check(img, 40, 0)
+    _check(img[:, :1000].copy(), 40, 60)
+    _check(img[:, :5000 - 3360].copy(), 12, 60)
+
+
+def test_kstrongest_dense_scene_vs_oracle():
+    from tbv_slam_public_amd import synth
+    imgs, _, _ = synth.scene_dense(2, 2)
+    assert ((imgs >= 60).sum(2) > 40).all()             # every row is cut by the filter
+    _check(imgs, 40, 60)
+    _check(imgs[0], 12, 60, device=True)

@@ -314,3 +314,54 @@ def test_long_closed_trajectory_keeps_per_frame_parity():
         if f > 0:
             assert (info["reg_status"][0] == 0) == bool(oi[2]) and info["outer_iters"][0] == oi[3], f
     assert worst[:2].max() < 1e-9                             # in fact nowhere near the tolerance
+
+
+def test_image_offsets_entry_equals_the_strided_batch():
+    """cfear_odometry_process_offsets: streams whose sweeps sit anywhere in one device buffer (a ring of frames, here
+    in shuffled order with gaps) advance exactly like the same sweeps handed over as a strided batch."""
+    import torch
+    from tbv_slam_public_amd import api, synth
+    F, B = 6, 3
+    seqs = np.stack([synth.scene_v1(40 + b, F)[0] for b in range(B)])          # [B][F][R][C]
+    img = 400 * 3360
+    slot = img + 4096                                                           # gaps between the images
+    order = np.random.default_rng(0).permutation(B * F)
+    ring = torch.zeros(B * F * slot, dtype=torch.uint8, device="cuda")
+    off = np.zeros((B, F), np.int64)
+    for b in range(B):
+        for f in range(F):
+            o = int(order[b * F + f]) * slot
+            off[b, f] = o
+            ring[o:o + img] = torch.from_numpy(seqs[b, f].reshape(-1)).cuda()
+    a = api.OdometryKeyframeFuser(B, 400, 3360)
+    c = api.OdometryKeyframeFuser(B, 400, 3360)
+    for f in range(F):
+        ia = a.process(torch.from_numpy(np.ascontiguousarray(seqs[:, f])).cuda())
+        ic = c.process_offsets(ring, off[:, f], off[:, f + 1] if f + 1 < F else None)
+        for name in ia.dtype.names:
+            np.testing.assert_array_equal(ia[name], ic[name], err_msg="%s frame %d" % (name, f))
+    assert (ia["reg_status"] == 0).all()
+    # a host that rewrites a prefetched slot must discard the prefetch: after discard the call filters again
+    c.discard_prefetch()
+
+
+def test_dense_scene_pipeline_matches_oracle():
+    """scene_dense: every row is cut at k = 40 (N_f ~ 16 000, ~1 600 cells per scan) -- the per-frame pipeline still
+    agrees with the CPU oracle frame by frame."""
+    import torch
+    from oracle import pyoracle as O
+    from tbv_slam_public_amd import api, synth
+    imgs, _, _ = synth.scene_dense(5, 4)
+    od = api.OdometryKeyframeFuser(1, 400, 3360)
+    reg = O.reg_params(cost="P2P", loss="Huber", loss_limit=0.1, weight_opt=4, regularization=0.0)
+    fz = O.Fuser(reg, res=3.0, submap_scan_size=4, weight_intensity=True)
+    for f in range(4):
+        info = od.process(torch.from_numpy(imgs[f:f + 1]).cuda())
+        sr, si, sc = O.kstrongest(imgs[f], 40, 60)
+        cloud = O.kstrongest_cloud(sr, si, sc, 0.0438, 2.5)
+        pose, oi = fz.process(cloud)
+        assert info["n_points"][0] == cloud.shape[0] > 14000
+        assert info["n_cells"][0] == oi[0] > 1000
+        d = np.abs(info["pose"][0] - pose)
+        assert d[:2].max() <= 1e-4 and d[2] <= 1e-5, (f, d)
+        assert (info["reg_status"][0] == 0) == bool(oi[2]) and info["outer_iters"][0] == oi[3]

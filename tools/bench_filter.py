@@ -15,7 +15,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=512)
     ap.add_argument("--iters", type=int, default=20)
-    ap.add_argument("--data", choices=["scene", "uniform"], default="scene")
+    ap.add_argument("--data", choices=["scene", "dense", "uniform"], default="scene")
     ap.add_argument("--k", type=int, default=40)
     ap.add_argument("--peaks", type=int, default=0)
     args = ap.parse_args()
@@ -23,6 +23,9 @@ def main():
     from tbv_slam_public_amd import api, synth
     if args.data == "scene":
         sc = synth.Scene(0)
+        base = np.stack([sc.render(f, 8) for f in range(8)])
+    elif args.data == "dense":
+        sc = synth.Scene(0, **synth.DENSE_KW)
         base = np.stack([sc.render(f, 8) for f in range(8)])
     else:
         base = synth.uniform_v1(0, batch=8)
@@ -44,7 +47,8 @@ def main():
     for name, (ms, n) in prof.items():
         avg = ms / max(n, 1)
         gbs = args.batch * (400 * 3360) / (avg * 1e-3) / 1e9
-        print("%-18s avg %.4f ms  polar-read %.0f GB/s" % (name, avg, gbs))
+        alg = args.batch * (400 * 3360 + 16 * nf + 4 * 400) / (avg * 1e-3) / 1e9      # R*C + 16 N_f + 4 R
+        print("%-18s avg %.4f ms  polar-read %.0f GB/s  algorithmic %.0f GB/s = %.3f of 8 TB/s" % (name, avg, gbs, alg, alg / 8000.0))
     print("wall %.4f ms per call, %d images, mean points %.0f" % (dt * 1e3, args.batch, nf))
 
 
