@@ -487,7 +487,7 @@ def main(argv=None):
         "roofline": roof,
         "kernel_breakdown": breakdown,
         "mean_cells_per_scan": tot["cells"] / max(tot["frames"], 1),
-        "failed_registrations": bad_total,
+        "failed_registrations": int(bad_total),
         "input_generation_s": t_gen,
     }
     if D.world > 1:
@@ -515,7 +515,7 @@ def main(argv=None):
             dprof = ctx.profile_read(reset=True); ctx.profile_enable(False)
             cand = float((drings[0, :4] >= 60).sum(dim=2).float().mean().item())
             rd = roofline_of(dprof, Bd, dst["points"] / dst["frames"])
-            rd.update({"value": Bd * nfr / td, "unit": "registrations/s (full path on the dense scenes)",
+            rd.update({"full_path_value": Bd * nfr / td, "full_path_unit": "registrations/s (filter -> pose on the dense scenes)",
                        "ms_per_frame_batch": td / nfr * 1e3, "streams": Bd, "frames": nfr,
                        "mean_candidates_per_row": cand, "mean_cells_per_scan": dst["cells"] / dst["frames"],
                        "failed_registrations": dst["bad"],

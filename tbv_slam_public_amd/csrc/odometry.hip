@@ -289,9 +289,13 @@ static int run_filter(cfear_odometry* od, const uint8_t* polar, int buf, const i
     const size_t img_bytes = (size_t)od->in_desc.rows * od->in_desc.stride;
     if (!od->d_polar && !dalloc(&od->d_polar, img_bytes * B)) return cfear_set_error(ctx, CFEAR_ERR_HIP, "staging allocation failed");
     const int64_t bs = B > 1 ? od->in_desc.batch_stride : (int64_t)img_bytes;
-    for (int b = 0; b < B; b++)
-      CFEAR_HIP_CHECK(ctx, hipMemcpyAsync(od->d_polar + (size_t)b * img_bytes, polar + (size_t)b * bs, img_bytes,
-                                          hipMemcpyHostToDevice, ctx->stream));
+    if (bs == (int64_t)img_bytes) {          // a dense batch crosses PCIe as one copy
+      CFEAR_HIP_CHECK(ctx, hipMemcpyAsync(od->d_polar, polar, img_bytes * B, hipMemcpyHostToDevice, ctx->stream));
+    } else {
+      for (int b = 0; b < B; b++)
+        CFEAR_HIP_CHECK(ctx, hipMemcpyAsync(od->d_polar + (size_t)b * img_bytes, polar + (size_t)b * bs, img_bytes,
+                                            hipMemcpyHostToDevice, ctx->stream));
+    }
     d_polar = od->d_polar;
     dd.batch_stride = (int64_t)img_bytes;
   }

@@ -178,3 +178,39 @@ def test_sharded_verification_selects_after_the_gather():
         assert ncalls == (4 if rank == 0 else 3)
         for f in ("t_be", "probability", "accepted", "rank", "coral", "cfear"):
             np.testing.assert_array_equal(out[f], serial[f])
+
+
+def test_bench_launcher_starts_the_ranks_itself():
+    """`python bench.py --gpus 2` must become 2 ranks (torch.distributed.run, one per GPU) without an external launcher;
+    the dry run rendezvous over gloo and reports what an all_gather sees."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-run", "--steps", "7"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 2 and out["rccl_ranks"] == 2 and out["ranks"] == [0.0, 1.0] and out["steps"] == 7
+    assert len(out["per_rank_value"]) == 2
+
+
+def test_bench_refuses_more_gpus_than_visible():
+    """Without 2 GPUs `--gpus 2` must fail loudly instead of measuring one GPU and calling it two."""
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.is_available() and torch.cuda.device_count() >= 2:
+        pytest.skip("this host really has 2 GPUs")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--streams", "64"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode != 0 and "refusing to run" in r.stderr
+    # and a rank count that contradicts --gpus is an error too
+    env2 = dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-run"],
+                       capture_output=True, text=True, timeout=300, env=env2)
+    assert r.returncode != 0 and "rank(s)" in (r.stderr + r.stdout)
