@@ -143,8 +143,10 @@ void cfear_surface_fill_job_rows(void* dst, float* d_xyzi, int32_t* d_n_out, con
 // rows mode needs the polar -> Cartesian constants: call before cfear_surface_launch (per context)
 struct cfear_surface_polar { const double* cos_t = nullptr; const double* sin_t = nullptr; double range_res = 0.0; };
 int cfear_trig_tables(cfear_ctx* ctx, int rows, double** d_cos, double** d_sin);
+// max_cell_cap: the largest cell capacity (ScanView::cap) among the jobs' output slabs
 int cfear_surface_launch(cfear_ctx* ctx, const void* d_jobs, int n_jobs, const cfear_feature_params* par,
-                         char* d_scratch, int32_t* d_status, int32_t* d_ncells_out, const cfear_surface_polar* polar = nullptr);
+                         char* d_scratch, int32_t* d_status, int32_t* d_ncells_out, int max_cell_cap,
+                         const cfear_surface_polar* polar = nullptr);
 size_t cfear_reg_job_bytes();
 int cfear_reg_max_scans();
 void cfear_reg_fill_job(void* dst, const ScanView* views, int n_scans, const double* poses_xyt);

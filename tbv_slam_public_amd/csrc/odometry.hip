@@ -514,7 +514,7 @@ static int process_frame(cfear_odometry* od, const uint8_t* polar, const uint8_t
     if (rc != CFEAR_OK) return fail(rc);
     sp.cos_t = d_cos; sp.sin_t = d_sin; sp.range_res = (double)par.kstrong.range_res;
   }
-  rc = cfear_surface_launch(ctx, od->d_surf_jobs, B, &fp, od->d_surf_scratch, od->d_status, od->d_ncells, rows_mode ? &sp : nullptr);
+  rc = cfear_surface_launch(ctx, od->d_surf_jobs, B, &fp, od->d_surf_scratch, od->d_status, od->d_ncells, od->cell_cap, rows_mode ? &sp : nullptr);
   if (rc != CFEAR_OK) return fail(rc);
   if (n_jobs > 0) {
     OD_CHECK(hipStreamWaitEvent(ctx->stream, od->ev_jobs, 0));

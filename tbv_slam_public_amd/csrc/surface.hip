@@ -68,6 +68,9 @@ struct SurfCommon {
   const double* cos_t;                        // rows mode: [rows] azimuth tables (host-computed doubles) and range_res
   const double* sin_t;
   double range_res;
+  int32_t* fallback;                          // [1 + n_jobs]: count, then the jobs the fast pipeline handed to the single-kernel path
+  int32_t n_jobs;
+  int32_t fast_ok;                            // reach == 1: the fast pipeline applies
 };
 
 struct TmpCell {                              // one candidate cell per voxel (before compaction)
@@ -75,13 +78,45 @@ struct TmpCell {                              // one candidate cell per voxel (b
   int32_t nsamples, valid;
 };
 
+// Per-scan global scratch (one region per job, shared by the fast pipeline and the single-kernel fallback):
+//   [0, 256)            SurfHdr
+//   + 0       float4[N]    sorted points (x, y, weight, -)
+//   + 16 N    u32[N]       fast: voxel keys         | fallback: float2 centroids [N] (8 N bytes)
+//   + 24 N    TmpCell[N]   candidate cell per voxel
+//   + 128 N   int32[N]     validity flags / compaction offsets
+//   + 132 N   u32[N + 4]   fast: voxel starts (V + 1 entries)
+//   + 136 N+16 u16[kFastMaxCells + 4]  fast: cell -> ordinal of the first occupied cell at or after it
+constexpr int kFastMaxCells = 16384;          // grid cells the LDS counting sort can address
+constexpr int kFastThreads = 512;
+constexpr size_t kFastLds = 78 * 1024;        // two workgroups per CU (160 KiB)
+constexpr int kRouteFast = 0, kRouteFallback = 1, kRouteDone = 2;
+
+struct SurfHdr {                              // written by surface_sort_kernel, read by the kernels behind it
+  int32_t route;                              // kRouteFast: sorted, cells pending | kRouteFallback | kRouteDone (finished / failed)
+  int32_t n, V, dbx, dby, pad[3];
+};
+
 __host__ __device__ inline size_t scratch_bytes_per_scan() {
-  size_t b = 0;
-  b += (size_t)kMaxPoints * 16;               // sorted points float4
-  b += (size_t)kMaxPoints * 8;                // centroids
-  b += (size_t)kMaxPoints * sizeof(TmpCell);
-  b += (size_t)kMaxPoints * 4;                // compaction offsets
+  size_t b = 256;
+  b += (size_t)kMaxPoints * 136 + 16;
+  b += (size_t)(kFastMaxCells + 4) * 2;
   return (b + 255) / 256 * 256;
+}
+struct SurfScratch {
+  SurfHdr* hdr; float4* spt; float2* cen; uint32_t* vkey; TmpCell* tmp; int32_t* coff; uint32_t* vs; unsigned short* ord;
+};
+__host__ __device__ inline SurfScratch scratch_of(char* base) {
+  SurfScratch r;
+  r.hdr = (SurfHdr*)base;
+  char* p = base + 256;
+  r.spt = (float4*)p;
+  r.cen = (float2*)(p + (size_t)kMaxPoints * 16);
+  r.vkey = (uint32_t*)(p + (size_t)kMaxPoints * 16);
+  r.tmp = (TmpCell*)(p + (size_t)kMaxPoints * 24);
+  r.coff = (int32_t*)(p + (size_t)kMaxPoints * 128);
+  r.vs = (uint32_t*)(p + (size_t)kMaxPoints * 132);
+  r.ord = (unsigned short*)(p + (size_t)kMaxPoints * 136 + 16);
+  return r;
 }
 
 __device__ __forceinline__ int row16_sum_i32(int v) {
@@ -142,6 +177,56 @@ __device__ __forceinline__ void sym2_eig(double a, double b, double d, double& l
   }
   if (e0 <= e1) { l0 = e0; l1 = e1; v0[0] = c; v0[1] = -s; }
   else { l0 = e1; l1 = e0; v0[0] = s; v0[1] = c; }
+}
+
+// ---- shared by the single-kernel path and surface_cells_kernel: one oriented surface point from its neighbourhood ----
+struct Moments { int cnt; double s0, s1x, s1y, sxx, sxy, syy; };
+
+// ONE pass over the candidates: weighted raw moments about the voxel centroid (|x'| <= radius, so forming mean /
+// covariance from them loses a few ulp at most; the reference's normalise-then-two-pass form, pointnormal.cpp:18-33,
+// is algebraically the same).  q = (x, y, weight max(I - 60, 0)).
+__device__ __forceinline__ void accum_point(Moments& m, const float2 c, const double cx, const double cy, const float qx,
+                                            const float qy, const float qw, const float r2, const bool weight_intensity) {
+  const float dx = __fsub_rn(c.x, qx), dy = __fsub_rn(c.y, qy);
+  const float d2 = __fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy));         // FLANN L2_Simple
+  if (d2 < r2) {                                                             // RadiusResultSet: strict <
+    const double w = weight_intensity ? (double)qw : 1.0;                    // pointnormal.cpp:15
+    const double xr = (double)qx - cx, yr = (double)qy - cy;
+    const double wx = w * xr, wy = w * yr;
+    m.cnt++;
+    m.s0 += w; m.s1x += wx; m.s1y += wy;
+    m.sxx = fma(wx, xr, m.sxx); m.sxy = fma(wx, yr, m.sxy); m.syy = fma(wy, yr, m.syy);   // own one-pass form: fusing is free
+  }
+}
+
+// cell::cell + cell::ComputeNormal (pointnormal.cpp:7-63) from the moments; returns valid_.
+__device__ __forceinline__ int finish_cell(const Moments& m, const double cx, const double cy, const double ox, const double oy,
+                                           TmpCell& tc) {
+  if (m.cnt < 6) return 0;                                                   // pointnormal.cpp:291
+  const double sum_intensity = m.s0;
+  const double mx = m.s1x / sum_intensity, my = m.s1y / sum_intensity;
+  const double u0 = cx + mx, u1 = cy + my;
+  const double c00 = m.sxx / sum_intensity - mx * mx;
+  const double c10 = m.sxy / sum_intensity - mx * my;
+  const double c01 = c10;
+  const double c11 = m.syy / sum_intensity - my * my;
+  double lmin, lmax, vmin[2];
+  sym2_eig(c00, c10, c11, lmin, lmax, vmin);                               // pointnormal.cpp:39-45
+  const double condition_number = fabs(lmax / lmin);                       // :53
+  const double determinant = lmax * lmin;
+  const bool cov_reasonable = (condition_number <= 10000) && (determinant > 0.00001) && lmin > 0 && lmax > 0;   // :56
+  if (!cov_reasonable) return 0;
+  double n0 = vmin[0], n1 = vmin[1];
+  if (n0 * (ox - u0) + n1 * (oy - u1) < 0) { n0 = -n0; n1 = -n1; }         // :59-61
+  tc.mean[0] = u0; tc.mean[1] = u1;
+  tc.normal[0] = n0; tc.normal[1] = n1;
+  tc.cov[0] = c00; tc.cov[1] = c01; tc.cov[2] = c10; tc.cov[3] = c11;
+  tc.scale = log(1.0 + condition_number / 2);                              // :57
+  tc.avg_intensity = sum_intensity / (double)m.cnt;                        // :19
+  tc.lmin = lmin; tc.lmax = lmax;
+  tc.nsamples = m.cnt;
+  tc.valid = 1;
+  return 1;
 }
 
 __device__ __forceinline__ int lower_bound_u32(const uint32_t* a, int lo, int hi, uint32_t key) {
@@ -223,16 +308,23 @@ __global__ __launch_bounds__(kSurfThreads) void scan_sort_kernel(ScanView v) {
   sort_cells_block(v, *v.n_cells, (unsigned long long*)smem);
 }
 
-__global__ __launch_bounds__(kSurfThreads) void surface_points_kernel(const SurfJob* __restrict__ jobs, const SurfCommon cm) {
-  // all LDS is carved from the dynamic region so its base stays 16-byte aligned (64-bit keys)
-  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+// The single-kernel path: one 1024-thread workgroup per scan, everything in 148 KiB of LDS; any grid size, n <= 16384.
+// It serves the scans the fast pipeline (surface_sort / surface_cells / surface_finish below) hands over: voxel grids
+// with more than kFastMaxCells cells, downsample factors != 1, or tables that do not fit the fast path's LDS budget.
+__device__ void surface_points_job(const SurfJob* __restrict__ jobs, const SurfCommon& cm, const int job_id, uint8_t* smem) {
   float (*red_f)[16] = (float (*)[16])(smem + kLdsSmallOff);          // [4][16]
   int* red_i = (int*)(smem + kLdsSmallOff + 256);                     // [16]
   int* sh_misc = (int*)(smem + kLdsSmallOff + 256 + 64);              // [8]
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const SurfJob job = jobs[blockIdx.x];
+  SurfJob job = jobs[job_id];
+  if (cm.fallback) {                                                  // handed over by surface_sort_kernel
+    const SurfHdr h = *scratch_of(cm.scratch + (size_t)job_id * cm.scratch_stride).hdr;
+    if (h.pad[0]) {                                                   // xyzi already holds the compact, compensated cloud
+      job.row_pts = nullptr; job.n_ptr = nullptr; job.n_host = h.n; job.compensate = 0;
+    }
+  }
   int n = job.n_ptr ? *job.n_ptr : job.n_host;
-  int32_t* status = cm.status + blockIdx.x;
+  int32_t* status = cm.status + job_id;
   int32_t* rowoff = (int32_t*)(smem + kLdsRowbegOff);                 // rows mode: [rows + 1] exclusive prefix of the row counts
   if (job.row_pts) {
     int run = 0;
@@ -253,26 +345,20 @@ __global__ __launch_bounds__(kSurfThreads) void surface_points_kernel(const Surf
     __syncthreads();
   }
   if (n <= 0) {
-    if (tid == 0) { *job.out.n_cells = 0; *status = CFEAR_ERR_EMPTY_CLOUD; if (cm.ncells_out) cm.ncells_out[blockIdx.x] = 0; }
+    if (tid == 0) { *job.out.n_cells = 0; *status = CFEAR_ERR_EMPTY_CLOUD; if (cm.ncells_out) cm.ncells_out[job_id] = 0; }
     return;
   }
   if (n > kMaxPoints) {
-    if (tid == 0) { *job.out.n_cells = 0; *status = CFEAR_ERR_CAPACITY; if (cm.ncells_out) cm.ncells_out[blockIdx.x] = 0; }
+    if (tid == 0) { *job.out.n_cells = 0; *status = CFEAR_ERR_CAPACITY; if (cm.ncells_out) cm.ncells_out[job_id] = 0; }
     return;
   }
   float4* pts = job.xyzi;
-  char* scr = cm.scratch + (size_t)blockIdx.x * cm.scratch_stride;
-  float4* spt = (float4*)scr;                 // sorted points (x, y, intensity, -)
-  float2* cen = (float2*)(spt + kMaxPoints);
-  TmpCell* tmp = (TmpCell*)(cen + kMaxPoints);
-  int32_t* coff = (int32_t*)(tmp + kMaxPoints);
-#ifdef CFEAR_SURF_TIMING
-  long long* tstamp = (long long*)(coff + kMaxPoints - 64);   // debug only: tail of the compaction array
-#endif
+  const SurfScratch scr = scratch_of(cm.scratch + (size_t)job_id * cm.scratch_stride);
+  float4* spt = scr.spt;                      // sorted points (x, y, weight, -)
+  float2* cen = scr.cen;
+  TmpCell* tmp = scr.tmp;
+  int32_t* coff = scr.coff;
 
-#ifdef CFEAR_SURF_TIMING
-  if (tid == 0) tstamp[0] = __builtin_readcyclecounter();
-#endif
   // ---- 1. compensation + bounding box -------------------------------------------------------
   float mnx = FLT_MAX, mny = FLT_MAX, mxx = -FLT_MAX, mxy = -FLT_MAX;
   for (int i0 = tid; i0 < n; i0 += 4 * kSurfThreads) {  // four loads in flight per thread
@@ -320,14 +406,11 @@ __global__ __launch_bounds__(kSurfThreads) void surface_points_kernel(const Surf
   const int min_by = (int)floorf(mny * cm.inv_leaf), max_by = (int)floorf(mxy * cm.inv_leaf);
   const long long div_bx = (long long)max_bx - min_bx + 1, div_by = (long long)max_by - min_by + 1;
   if (div_bx * div_by > 0x7fffffffLL || div_by > kMaxGridRows) {
-    if (tid == 0) { *job.out.n_cells = 0; *status = CFEAR_ERR_CAPACITY; if (cm.ncells_out) cm.ncells_out[blockIdx.x] = 0; }
+    if (tid == 0) { *job.out.n_cells = 0; *status = CFEAR_ERR_CAPACITY; if (cm.ncells_out) cm.ncells_out[job_id] = 0; }
     return;
   }
   const int dbx = (int)div_bx, dby = (int)div_by;
 
-#ifdef CFEAR_SURF_TIMING
-  if (tid == 0) tstamp[1] = __builtin_readcyclecounter();
-#endif
   // ---- 2. (voxel, point) keys -> LDS sort: voxels ascending, points of a voxel in input order --
   unsigned long long* keys = (unsigned long long*)smem;
   const int npad = grid_sort_block(smem, n, (long long)dbx * dby, red_i, [&](int i) {
@@ -337,9 +420,6 @@ __global__ __launch_bounds__(kSurfThreads) void surface_points_kernel(const Surf
     return (uint32_t)(ijk0 + ijk1 * dbx);
   });
 
-#ifdef CFEAR_SURF_TIMING
-  if (tid == 0) tstamp[2] = __builtin_readcyclecounter();
-#endif
   // ---- 3. sorted points -> global scratch; voxel table (key, start) -> LDS --------------------
   // each thread owns kPerThread consecutive sorted elements, held in registers across the barrier
   // because the voxel tables overwrite the key region.
@@ -412,9 +492,6 @@ __global__ __launch_bounds__(kSurfThreads) void surface_points_kernel(const Surf
   // rowbeg[y] = first voxel ordinal whose grid row is >= y
   for (int y = tid; y <= dby; y += kSurfThreads)
     rowbeg[y] = lower_bound_u32(vox_key, 0, V, (uint32_t)((long long)y * dbx));
-#ifdef CFEAR_SURF_TIMING
-  if (tid == 0) tstamp[3] = __builtin_readcyclecounter();
-#endif
   // ---- 4a. voxel centroids: sequential float sums in sorted (= input) order -------------------
   __threadfence_block();
   __syncthreads();
@@ -432,9 +509,6 @@ __global__ __launch_bounds__(kSurfThreads) void surface_points_kernel(const Surf
   __threadfence_block();
   __syncthreads();
 
-#ifdef CFEAR_SURF_TIMING
-  if (tid == 0) tstamp[4] = __builtin_readcyclecounter();
-#endif
   // ---- 4b. one LANE per voxel: radius gather + weighted mean / covariance ----------------------
   // Neighbouring voxels (adjacent lanes) share most of their candidate points, so the per-lane
   // 16-byte loads hit L1; every lane keeps its own fp64 moments (no cross-lane reduction) and
@@ -454,23 +528,8 @@ __global__ __launch_bounds__(kSurfThreads) void surface_points_kernel(const Surf
       p1 = vox_start[b];
     };
     const double cx = (double)c.x, cy = (double)c.y;
-    int cnt = 0;
-    double s0 = 0.0, s1x = 0.0, s1y = 0.0, sxx = 0.0, sxy = 0.0, syy = 0.0;
-    // ONE pass over the candidates: weighted raw moments about the voxel centroid (|x'| <= radius, so
-    // forming mean/covariance from them loses a few ulp at most; the reference's normalise-then-two-
-    // pass form, pointnormal.cpp:18-33, is algebraically the same).
-    auto accum = [&](const float4 q) {
-      const float dx = __fsub_rn(c.x, q.x), dy = __fsub_rn(c.y, q.y);
-      const float d2 = __fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy));         // FLANN L2_Simple
-      if (d2 < cm.r2) {                                                          // RadiusResultSet: strict <
-        const double w = cm.weight_intensity ? (double)q.z : 1.0;                 // q.z = max(I - 60, 0), pointnormal.cpp:15
-        const double xr = (double)q.x - cx, yr = (double)q.y - cy;
-        const double wx = w * xr, wy = w * yr;
-        cnt++;
-        s0 += w; s1x += wx; s1y += wy;
-        sxx = fma(wx, xr, sxx); sxy = fma(wx, yr, sxy); syy = fma(wy, yr, syy);   // own one-pass form: fusing is free
-      }
-    };
+    Moments mo{0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    auto accum = [&](const float4 q) { accum_point(mo, c, cx, cy, q.x, q.y, q.z, cm.r2, cm.weight_intensity != 0); };
     auto scan_run = [&](int p0, int p1) {
       if (lds_pts) {                                      // candidates from LDS (no L1/TA traffic)
         int p = p0;
@@ -516,45 +575,14 @@ __global__ __launch_bounds__(kSurfThreads) void surface_points_kernel(const Surf
         scan_run(p0, p1);
       }
     }
-    int valid = 0;
-    if (cnt >= 6) {                                                              // pointnormal.cpp:291
-      const double sum_intensity = s0;
-      const double mx = s1x / sum_intensity, my = s1y / sum_intensity;
-      const double u0 = cx + mx, u1 = cy + my;
-      const double c00 = sxx / sum_intensity - mx * mx;
-      const double c10 = sxy / sum_intensity - mx * my;
-      const double c01 = c10;
-      const double c11 = syy / sum_intensity - my * my;
-      double lmin, lmax, vmin[2];
-      sym2_eig(c00, c10, c11, lmin, lmax, vmin);                               // pointnormal.cpp:39-45
-      const double condition_number = fabs(lmax / lmin);                       // :53
-      const double determinant = lmax * lmin;
-      const bool cov_reasonable = (condition_number <= 10000) && (determinant > 0.00001) &&
-                                  lmin > 0 && lmax > 0;                        // :56
-      double n0 = vmin[0], n1 = vmin[1];
-      if (n0 * (cm.origin[0] - u0) + n1 * (cm.origin[1] - u1) < 0) { n0 = -n0; n1 = -n1; }   // :59-61
-      valid = cov_reasonable ? 1 : 0;
-      if (valid) {
-        TmpCell tc;
-        tc.mean[0] = u0; tc.mean[1] = u1;
-        tc.normal[0] = n0; tc.normal[1] = n1;
-        tc.cov[0] = c00; tc.cov[1] = c01; tc.cov[2] = c10; tc.cov[3] = c11;
-        tc.scale = log(1.0 + condition_number / 2);                            // :57
-        tc.avg_intensity = sum_intensity / (double)cnt;                        // :19
-        tc.lmin = lmin; tc.lmax = lmax;
-        tc.nsamples = cnt;
-        tc.valid = valid;
-        tmp[v] = tc;
-      }
-    }
+    TmpCell tc;
+    const int valid = finish_cell(mo, cx, cy, cm.origin[0], cm.origin[1], tc);
+    if (valid) tmp[v] = tc;
     coff[v] = valid;
   }
   __threadfence_block();
   __syncthreads();
 
-#ifdef CFEAR_SURF_TIMING
-  if (tid == 0) tstamp[5] = __builtin_readcyclecounter();
-#endif
   // ---- 5. compaction in voxel order -----------------------------------------------------------
   if (tid == 0) sh_misc[0] = 0;
   __syncthreads();
@@ -583,21 +611,372 @@ __global__ __launch_bounds__(kSurfThreads) void surface_points_kernel(const Surf
     if (tid == 0) { int tot = 0; for (int wv = 0; wv < 16; wv++) tot += red_i[wv]; sh_misc[0] += tot; }
     __syncthreads();
   }
-#ifdef CFEAR_SURF_TIMING
-  if (tid == 0) tstamp[6] = __builtin_readcyclecounter();
-#endif
   // ---- 6. x-sorted copy of the float means for the matcher's windowed exact 1-NN -----------------
   __threadfence_block();
   __syncthreads();
   sort_cells_block(job.out, min(sh_misc[0], job.out.cap), (unsigned long long*)smem);
-#ifdef CFEAR_SURF_TIMING
-  if (tid == 0) { tstamp[7] = __builtin_readcyclecounter(); tstamp[8] = n; tstamp[9] = sh_misc[0]; }
-#endif
   if (tid == 0) {
     const int total = sh_misc[0];
     *job.out.n_cells = total <= job.out.cap ? total : job.out.cap;
     *status = total <= job.out.cap ? CFEAR_OK : CFEAR_ERR_CAPACITY;
-    if (cm.ncells_out) cm.ncells_out[blockIdx.x] = total <= job.out.cap ? total : job.out.cap;
+    if (cm.ncells_out) cm.ncells_out[job_id] = total <= job.out.cap ? total : job.out.cap;
+  }
+}
+
+__global__ __launch_bounds__(kSurfThreads) void surface_points_kernel(const SurfJob* __restrict__ jobs, const SurfCommon cm) {
+  // all LDS is carved from the dynamic region so its base stays 16-byte aligned (64-bit keys)
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  if (!cm.fallback) { surface_points_job(jobs, cm, blockIdx.x, smem); return; }
+  const int count = cm.fallback[0];           // persistent over the (usually empty) list of handed-over scans
+  for (int w = blockIdx.x; w < count; w += gridDim.x) {
+    surface_points_job(jobs, cm, cm.fallback[1 + w], smem);
+    __syncthreads();
+  }
+}
+
+
+// =================================================================================================================
+// Fast pipeline (reach == 1, voxel grid <= kFastMaxCells cells, n <= 16384): two launches per batch
+//   surface_sort_kernel    one 512-thread workgroup per scan, 78 KiB of LDS -> TWO scans per CU, whose phases overlap:
+//                          row compaction / polar -> Cartesian / motion compensation / bounding box; a counting sort of
+//                          the points by voxel (LDS histogram over the grid as u16 pairs, exclusive scan -> cell ->
+//                          ordinal map and voxel starts, atomic scatter, an in-voxel rank pass that restores input
+//                          order: PCL's centroid sums are sequential in input order) instead of a 4-pass radix sort
+//                          with per-thread digit counters; then the cells, one lane per voxel, from slabs of sorted
+//                          points staged in LDS, with the three neighbour runs found by O(1) look-ups in the cell ->
+//                          ordinal map instead of binary searches.
+//   surface_finish_kernel  per scan: compaction in voxel order + the x-sorted copy for the matcher (small LDS, 8
+//                          wavefronts per SIMD).
+// The first version ran all of this in one 1024-thread workgroup per CU (148 KiB of LDS) at ~3 % of the VALU peak: every
+// phase waited on barriers and dependent LDS chains with 4 wavefronts per SIMD.  (A flat lane-per-voxel kernel over all
+// scans, fed through global scratch, was tried in between: 1.6 - 2.1 ms per 2048 scans -- its dependent global look-ups
+// and the staging barriers at 10 wavefronts per CU cost more than the old gather phase.)  Scans the fast path cannot
+// take are appended to a work list that the single-kernel path (above) drains.
+// =================================================================================================================
+__global__ __launch_bounds__(kFastThreads, 4) void surface_sort_kernel(const SurfJob* __restrict__ jobs, const SurfCommon cm) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  constexpr int NT = kFastThreads, NW = NT / 64;
+  constexpr int kPer = kMaxPoints / NT;                               // <= 32 points per thread
+  float (*red_f)[NW] = (float (*)[NW])(smem + kFastLds - 512);         // [4][NW]
+  int* red_i = (int*)(smem + kFastLds - 512 + 4 * NW * 4);             // [2][NW]
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int job_id = blockIdx.x;
+  const SurfJob job = jobs[job_id];
+  const SurfScratch scr = scratch_of(cm.scratch + (size_t)job_id * cm.scratch_stride);
+  int32_t* status = cm.status + job_id;
+  auto done = [&](int st) {                                            // nothing (more) to do for this scan
+    if (tid == 0) {
+      scr.hdr->route = kRouteDone;
+      *job.out.n_cells = 0; *status = st;
+      if (cm.ncells_out) cm.ncells_out[job_id] = 0;
+    }
+  };
+  auto hand_over = [&](int n, int prepared) {                          // to the single-kernel path
+    if (tid == 0) {
+      scr.hdr->route = kRouteFallback;
+      scr.hdr->n = n;
+      scr.hdr->pad[0] = prepared;                                      // 1: xyzi already holds the compact, compensated cloud
+      const int w = atomicAdd(&cm.fallback[0], 1);
+      cm.fallback[1 + w] = job_id;
+    }
+  };
+  if (!cm.fast_ok) { hand_over(0, 0); return; }
+  // ---- (a) point count; rows mode: exclusive prefix of the row counts ------------------------------------------
+  int n = job.n_ptr ? *job.n_ptr : job.n_host;
+  int32_t* rowoff = (int32_t*)smem;
+  if (job.row_pts) {
+    int run = 0;
+    for (int r0 = 0; r0 < job.rows; r0 += NT) {
+      const int r = r0 + tid;
+      const int v = r < job.rows ? job.row_cnt[2 * r] : 0;
+      const int incl = wave_incl_scan_i32(v);
+      if (lane == 63) red_i[wave] = incl;
+      __syncthreads();
+      int off = run + incl - v;
+      for (int wv = 0; wv < wave; wv++) off += red_i[wv];
+      if (r < job.rows) rowoff[r] = off;
+      for (int wv = 0; wv < NW; wv++) run += red_i[wv];
+      __syncthreads();
+    }
+    n = run;
+    if (tid == 0) { rowoff[job.rows] = n; if (job.n_out) *job.n_out = n; }
+    __syncthreads();
+  }
+  if (n <= 0) { done(CFEAR_ERR_EMPTY_CLOUD); return; }
+  if (n > kMaxPoints) { done(CFEAR_ERR_CAPACITY); return; }
+  float4* pts = job.xyzi;
+  // ---- (b) polar -> Cartesian (rows mode), motion compensation, bounding box ------------------------------------
+  float mnx = FLT_MAX, mny = FLT_MAX, mxx = -FLT_MAX, mxy = -FLT_MAX;
+  for (int i0 = tid; i0 < n; i0 += 4 * NT) {
+    float4 p[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int i = i0 + u * NT;
+      if (i < n) {
+        if (job.row_pts) {                              // row of point i: the last r with rowoff[r] <= i
+          int lo = 0, hi = job.rows;
+          while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (rowoff[mid] <= i) lo = mid; else hi = mid; }
+          const uint32_t key = job.row_pts[(size_t)lo * job.k + (i - rowoff[lo])];
+          const double range_res_half = cm.range_res / 2.0;
+          const double rho = range_res_half + cm.range_res * (double)(int)(key & 0xFFFFFFu);   // radar_filters.cpp:324-330
+          p[u] = make_float4((float)(rho * cm.cos_t[lo]), (float)(rho * cm.sin_t[lo]), 0.f, (float)(key >> 24));
+        } else {
+          p[u] = pts[i];
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int i = i0 + u * NT;
+      if (i < n) {
+        if (job.compensate) p[u] = compensate_point(p[u], job.mot, cm.ccw != 0);
+        if (job.compensate || job.row_pts) pts[i] = p[u];
+        mnx = fminf(mnx, p[u].x); mxx = fmaxf(mxx, p[u].x);
+        mny = fminf(mny, p[u].y); mxy = fmaxf(mxy, p[u].y);
+      }
+    }
+  }
+  for (int o = 32; o > 0; o >>= 1) {
+    mnx = fminf(mnx, __shfl_xor(mnx, o)); mxx = fmaxf(mxx, __shfl_xor(mxx, o));
+    mny = fminf(mny, __shfl_xor(mny, o)); mxy = fmaxf(mxy, __shfl_xor(mxy, o));
+  }
+  if (lane == 0) { red_f[0][wave] = mnx; red_f[1][wave] = mxx; red_f[2][wave] = mny; red_f[3][wave] = mxy; }
+  __threadfence_block();
+  __syncthreads();                                                   // also: pts[] written by this workgroup are visible to it
+  mnx = red_f[0][0]; mxx = red_f[1][0]; mny = red_f[2][0]; mxy = red_f[3][0];
+  for (int wv = 1; wv < NW; wv++) {
+    mnx = fminf(mnx, red_f[0][wv]); mxx = fmaxf(mxx, red_f[1][wv]);
+    mny = fminf(mny, red_f[2][wv]); mxy = fmaxf(mxy, red_f[3][wv]);
+  }
+  // pcl::VoxelGrid::applyFilter: min_b = floor(min * inverse_leaf), div_b = max_b - min_b + 1
+  const int min_bx = (int)floorf(mnx * cm.inv_leaf), max_bx = (int)floorf(mxx * cm.inv_leaf);
+  const int min_by = (int)floorf(mny * cm.inv_leaf), max_by = (int)floorf(mxy * cm.inv_leaf);
+  const long long div_bx = (long long)max_bx - min_bx + 1, div_by = (long long)max_by - min_by + 1;
+  if (div_bx * div_by > 0x7fffffffLL || div_by > kMaxGridRows) { done(CFEAR_ERR_CAPACITY); return; }   // non-finite / absurd points
+  const int dbx = (int)div_bx, dby = (int)div_by;
+  const int ncells = dbx * dby;
+  if (ncells > kFastMaxCells) { hand_over(n, 1); return; }
+  // ---- (c) histogram of the points over the voxel grid: u16 counters, two per LDS word ---------------------------
+  // cnt[c] for c in [0, ncells]; after the scan the same words hold ord[c] = occupied cells before c.
+  const int words = (ncells + 2) >> 1;                                // covers c = ncells
+  uint32_t* cw = (uint32_t*)smem;
+  const size_t ord_bytes = ((size_t)words * 4 + 15) & ~(size_t)15;
+  __syncthreads();                                                   // rowoff is dead
+  for (int w = tid; w < words; w += NT) cw[w] = 0u;
+  __syncthreads();
+  unsigned short mycell[kPer];                                        // the cells of this thread's points (registers)
+#pragma unroll
+  for (int j = 0; j < kPer; j++) {
+    const int i = tid + j * NT;
+    mycell[j] = 0;
+    if (i < n) {
+      const float2 p = *(const float2*)&pts[i];
+      const int ijk0 = (int)(floorf(p.x * cm.inv_leaf) - (float)min_bx);
+      const int ijk1 = (int)(floorf(p.y * cm.inv_leaf) - (float)min_by);
+      const int c = ijk0 + ijk1 * dbx;
+      mycell[j] = (unsigned short)c;
+      atomicAdd(&cw[c >> 1], (c & 1) ? 0x10000u : 1u);
+    }
+  }
+  __syncthreads();
+  // ---- (d) exclusive scan over the cells: points before a cell (voxel starts) and occupied cells before it -------
+  const int per = (words + NT - 1) / NT;                              // consecutive words per thread (<= 17)
+  const int w0 = tid * per, w1 = min(words, w0 + per);
+  int tp = 0, to = 0;
+  for (int w = w0; w < w1; w++) {
+    const uint32_t x = cw[w];
+    const int a = (int)(x & 0xffffu), b = (int)(x >> 16);
+    tp += a + b; to += (a != 0) + (b != 0);
+  }
+  const int packed = (to << 16) | tp;                                 // both totals < 65536: one scan carries both
+  const int incl = wave_incl_scan_i32(packed);
+  if (lane == 63) red_i[wave] = incl;
+  __syncthreads();
+  int excl = incl - packed, tot = 0;
+  for (int wv = 0; wv < NW; wv++) { if (wv < wave) excl += red_i[wv]; tot += red_i[wv]; }
+  const int V = tot >> 16;
+  // LDS budget: ord | voxel cursors u16[V + 2] | order u16[n]
+  const size_t vs_off = ord_bytes, vs_bytes = (((size_t)V + 2) * 2 + 15) & ~(size_t)15;
+  const size_t ord2_off = vs_off + vs_bytes, need = ord2_off + (((size_t)n * 2 + 15) & ~(size_t)15);
+  if (need > kFastLds - 512) { hand_over(n, 1); return; }
+  unsigned short* vs16 = (unsigned short*)(smem + vs_off);
+  uint32_t* vs32 = (uint32_t*)(smem + vs_off);
+  unsigned short* order = (unsigned short*)(smem + ord2_off);
+  {
+    int run_p = excl & 0xffff, run_o = excl >> 16;
+    for (int w = w0; w < w1; w++) {
+      const uint32_t x = cw[w];
+      const int a = (int)(x & 0xffffu), b = (int)(x >> 16);
+      const int oa = run_o;
+      if (a) { vs16[run_o] = (unsigned short)run_p; scr.vkey[run_o] = (uint32_t)(2 * w); run_o++; run_p += a; }
+      const int ob = run_o;
+      if (b) { vs16[run_o] = (unsigned short)run_p; scr.vkey[run_o] = (uint32_t)(2 * w + 1); run_o++; run_p += b; }
+      cw[w] = (uint32_t)oa | ((uint32_t)ob << 16);
+    }
+  }
+  __syncthreads();
+  const unsigned short* ord16 = (const unsigned short*)smem;
+  // ---- (e) scatter: the atomic cursor of a voxel ends at the start of the next one --------------------------------
+#pragma unroll
+  for (int j = 0; j < kPer; j++) {
+    const int i = tid + j * NT;
+    if (i < n) {
+      const int v = ord16[mycell[j]];
+      const uint32_t old = atomicAdd(&vs32[v >> 1], (v & 1) ? 0x10000u : 1u);
+      const int pos = (v & 1) ? (int)(old >> 16) : (int)(old & 0xffffu);
+      order[pos] = (unsigned short)i;
+    }
+  }
+  __syncthreads();
+  // ---- (f) input order inside every voxel: rank of a point among its voxel's points (runs are a few points long) ---
+#pragma unroll
+  for (int j = 0; j < kPer; j++) {
+    const int i = tid + j * NT;
+    if (i < n) {
+      const int v = ord16[mycell[j]];
+      const int s0 = v ? (int)vs16[v - 1] : 0, e0 = (int)vs16[v];
+      int rank = 0;
+      for (int q = s0; q < e0; q++) rank += (int)order[q] < i;
+      mycell[j] = (unsigned short)(s0 + rank);
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < kPer; j++) {
+    const int i = tid + j * NT;
+    if (i < n) order[mycell[j]] = (unsigned short)i;
+  }
+  __syncthreads();
+  // ---- (g) sorted points -> global scratch (L2): the order array is then dead and its LDS becomes the staging area ---
+  for (int pos = tid; pos < n; pos += NT) {
+    const float4 p = pts[order[pos]];
+    // the sorted copies carry the point's WEIGHT max(I - 60, 0) (pointnormal.cpp:15), not its intensity: float(I) - 60
+    // is exact for I >= 60, so the fp64 weight of the reference is just its widening
+    scr.spt[pos] = make_float4(p.x, p.y, fmaxf(__fsub_rn(p.w, 60.0f), 0.0f), 0.f);
+  }
+  __threadfence_block();
+  __syncthreads();
+  // ---- (h) cells: one lane per voxel, slab by slab.  A slab = the voxels of grid rows [ya, yb) whose candidate points
+  //      (rows ya - 1 .. yb, one contiguous range of the sorted array) fit the staging area; a sparse scan needs two
+  //      slabs, a 16 000-point scan five.  Neighbour runs are O(1) look-ups: the points of cells [c0, c1] of one grid
+  //      row are the run [points before c0, points before c1 + 1). ------------------------------------------------
+  auto pbefore = [&](int c) { const int o = ord16[c]; return o ? (int)vs16[o - 1] : 0; };    // points in cells < c
+  float2* lxy = (float2*)(smem + ord2_off);
+  const int cap_pts = (int)((kFastLds - 512 - ord2_off) / 12);
+  float* lw = (float*)(smem + ord2_off + (size_t)cap_pts * 8);
+  const bool wi = cm.weight_intensity != 0;
+  for (int ya = 0; ya < dby;) {                                       // block-uniform
+    const int P0 = pbefore(max(ya - 1, 0) * dbx);
+    int lo = ya + 1, hi = dby;                                        // largest yb in [ya + 1, dby] whose range fits
+    if (pbefore(min(lo + 1, dby) * dbx) - P0 > cap_pts) { hand_over(n, 1); return; }   // three grid rows exceed the staging area
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if (pbefore(min(mid + 1, dby) * dbx) - P0 <= cap_pts) lo = mid; else hi = mid - 1;
+    }
+    const int yb = lo;
+    const int P1 = pbefore(min(yb + 1, dby) * dbx);
+    for (int i = tid; i < P1 - P0; i += NT) {
+      const float4 q = scr.spt[P0 + i];
+      lxy[i] = make_float2(q.x, q.y);
+      lw[i] = q.z;
+    }
+    __syncthreads();
+    const int vbeg = ord16[ya * dbx], vend = ord16[yb * dbx];
+    for (int v = vbeg + tid; v < vend; v += NT) {
+      const uint32_t key = scr.vkey[v];
+      const int s = (v ? (int)vs16[v - 1] : 0) - P0, e = (int)vs16[v] - P0;
+      const int iy = (int)(key / (uint32_t)dbx), ix = (int)(key - (uint32_t)iy * (uint32_t)dbx);
+      const int x0 = max(ix - 1, 0), x1 = min(ix + 1, dbx - 1);
+      int r0[3], r1[3];
+#pragma unroll
+      for (int d = 0; d < 3; d++) {
+        const int yy = iy - 1 + d;
+        r0[d] = r1[d] = 0;
+        if (yy >= 0 && yy < dby) { r0[d] = pbefore(yy * dbx + x0) - P0; r1[d] = pbefore(yy * dbx + x1 + 1) - P0; }
+      }
+      // voxel centroid: sequential float sums in sorted (= input) order, bit-exact with pcl::CentroidPoint
+      float ax = 0.f, ay = 0.f;
+      for (int p = s; p < e; p++) { const float2 q = lxy[p]; ax = __fadd_rn(ax, q.x); ay = __fadd_rn(ay, q.y); }
+      const float cnt = (float)(e - s);
+      const float2 c = make_float2(__fdiv_rn(ax, cnt), __fdiv_rn(ay, cnt));
+      int valid = 0;
+      if ((r1[0] - r0[0]) + (r1[1] - r0[1]) + (r1[2] - r0[2]) >= 6) {    // upper bound on the neighbour count
+        const double cx = (double)c.x, cy = (double)c.y;
+        Moments mo{0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int d = 0; d < 3; d++) {
+          int p = r0[d];
+          for (; p + 3 < r1[d]; p += 4) {                               // four independent LDS reads in flight
+            const float2 qa = lxy[p], qb = lxy[p + 1], qc = lxy[p + 2], qd = lxy[p + 3];
+            float wa = 0.f, wb = 0.f, wc = 0.f, wd = 0.f;
+            if (wi) { wa = lw[p]; wb = lw[p + 1]; wc = lw[p + 2]; wd = lw[p + 3]; }
+            accum_point(mo, c, cx, cy, qa.x, qa.y, wa, cm.r2, wi);
+            accum_point(mo, c, cx, cy, qb.x, qb.y, wb, cm.r2, wi);
+            accum_point(mo, c, cx, cy, qc.x, qc.y, wc, cm.r2, wi);
+            accum_point(mo, c, cx, cy, qd.x, qd.y, wd, cm.r2, wi);
+          }
+          for (; p < r1[d]; p++) { const float2 q = lxy[p]; accum_point(mo, c, cx, cy, q.x, q.y, wi ? lw[p] : 0.f, cm.r2, wi); }
+        }
+        TmpCell tc;
+        valid = finish_cell(mo, cx, cy, cm.origin[0], cm.origin[1], tc);
+        if (valid) scr.tmp[v] = tc;
+      }
+      scr.coff[v] = valid;
+    }
+    __syncthreads();                                                   // the staging area is reused by the next slab
+    ya = yb;
+  }
+  if (tid == 0) {
+    scr.hdr->route = kRouteFast;                                       // cells computed; compaction + x-sort pending
+    scr.hdr->n = n; scr.hdr->V = V; scr.hdr->dbx = dbx; scr.hdr->dby = dby;
+  }
+}
+
+constexpr int kFinishThreads = 256;
+
+__global__ __launch_bounds__(kFinishThreads) void surface_finish_kernel(const SurfJob* __restrict__ jobs, const SurfCommon cm) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];       // sort keys: next_pow2(cell capacity) x 8 bytes
+  __shared__ int red_i[kFinishThreads / 64];
+  __shared__ int total_s;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int job_id = blockIdx.x;
+  const SurfScratch scr = scratch_of(cm.scratch + (size_t)job_id * cm.scratch_stride);
+  if (scr.hdr->route != kRouteFast) return;
+  const SurfJob job = jobs[job_id];
+  const int V = scr.hdr->V;
+  if (tid == 0) total_s = 0;
+  __syncthreads();
+  for (int v0 = 0; v0 < V; v0 += kFinishThreads) {                     // compaction in voxel order (= PCL's output order)
+    const int v = v0 + tid;
+    const int f = v < V ? scr.coff[v] : 0;
+    const int inc = wave_incl_scan_i32(f);
+    if (lane == 63) red_i[wave] = inc;
+    __syncthreads();
+    int off = total_s + inc - f;
+    for (int wv = 0; wv < wave; wv++) off += red_i[wv];
+    if (f && off < job.out.cap) {
+      const TmpCell t = scr.tmp[v];
+      job.out.mean_f[off] = make_float2((float)t.mean[0], (float)t.mean[1]);  // pointnormal.cpp:154-157
+      job.out.mean[off] = make_double2(t.mean[0], t.mean[1]);
+      job.out.normal[off] = make_double2(t.normal[0], t.normal[1]);
+      job.out.cov[off] = make_double4(t.cov[0], t.cov[1], t.cov[2], t.cov[3]);
+      job.out.scale[off] = t.scale;
+      job.out.avg_intensity[off] = t.avg_intensity;
+      job.out.lambda[off] = make_double2(t.lmin, t.lmax);
+      job.out.nsamples[off] = t.nsamples;
+    }
+    __syncthreads();
+    if (tid == 0) { int tot = 0; for (int wv = 0; wv < kFinishThreads / 64; wv++) tot += red_i[wv]; total_s += tot; }
+    __syncthreads();
+  }
+  __threadfence_block();
+  __syncthreads();
+  const int total = total_s;
+  sort_cells_block(job.out, min(total, job.out.cap), (unsigned long long*)smem);
+  if (tid == 0) {
+    *job.out.n_cells = total <= job.out.cap ? total : job.out.cap;
+    cm.status[job_id] = total <= job.out.cap ? CFEAR_OK : CFEAR_ERR_CAPACITY;
+    if (cm.ncells_out) cm.ncells_out[job_id] = total <= job.out.cap ? total : job.out.cap;
   }
 }
 
@@ -665,7 +1044,8 @@ void cfear_surface_fill_job(void* dst, float* d_xyzi, const int32_t* d_n, int32_
 }
 
 int cfear_surface_launch(cfear_ctx* ctx, const void* d_jobs, int n_jobs, const cfear_feature_params* par,
-                         char* d_scratch, int32_t* d_status, int32_t* d_ncells_out, const cfear_surface_polar* polar) {
+                         char* d_scratch, int32_t* d_status, int32_t* d_ncells_out, int max_cell_cap,
+                         const cfear_surface_polar* polar) {
   if (par->radius <= 0.f || !(par->downsample_factor > 0.0))
     return cfear_set_error(ctx, CFEAR_ERR_INVALID_ARGUMENT, "radius / downsample_factor must be > 0");
   SurfCommon cm;
@@ -687,12 +1067,36 @@ int cfear_surface_launch(cfear_ctx* ctx, const void* d_jobs, int n_jobs, const c
   cm.cos_t = polar ? polar->cos_t : nullptr;
   cm.sin_t = polar ? polar->sin_t : nullptr;
   cm.range_res = polar ? polar->range_res : 0.0;
+  cm.n_jobs = n_jobs;
+  cm.fast_ok = cm.reach == 1 ? 1 : 0;
+  // work list of the scans the fast pipeline hands to the single-kernel path: count + job ids
+  cm.fallback = (int32_t*)cfear_workspace(ctx, 11, ((size_t)n_jobs + 16) * 4);
+  if (!cm.fallback) return cfear_set_error(ctx, CFEAR_ERR_HIP, "workspace allocation failed");
+  CFEAR_HIP_CHECK(ctx, hipMemsetAsync(cm.fallback, 0, 4, ctx->stream));
   // per launch: the attribute is per device, and contexts on other threads / devices share this code
   CFEAR_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)surface_points_kernel,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)cfear_surface_lds_bytes()));
-  ProfScope ps(ctx, "surface_points");
-  hipLaunchKernelGGL(surface_points_kernel, dim3(n_jobs), dim3(kSurfThreads), cfear_surface_lds_bytes(), ctx->stream,
-                     (const SurfJob*)d_jobs, cm);
+  CFEAR_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)surface_sort_kernel,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFastLds));
+  int keys_pow2 = 64;
+  while (keys_pow2 < max_cell_cap) keys_pow2 <<= 1;
+  const size_t finish_lds = (size_t)keys_pow2 * 8;
+  if (finish_lds > 64 * 1024)
+    CFEAR_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)surface_finish_kernel,
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)finish_lds));
+  {
+    ProfScope ps(ctx, "surface_sort");
+    hipLaunchKernelGGL(surface_sort_kernel, dim3(n_jobs), dim3(kFastThreads), kFastLds, ctx->stream, (const SurfJob*)d_jobs, cm);
+  }
+  {
+    ProfScope ps(ctx, "surface_points");       // the single-kernel path drains the hand-over list (usually empty)
+    hipLaunchKernelGGL(surface_points_kernel, dim3(std::min(n_jobs, 256)), dim3(kSurfThreads), cfear_surface_lds_bytes(), ctx->stream,
+                       (const SurfJob*)d_jobs, cm);
+  }
+  {
+    ProfScope ps(ctx, "surface_finish");
+    hipLaunchKernelGGL(surface_finish_kernel, dim3(n_jobs), dim3(kFinishThreads), finish_lds, ctx->stream, (const SurfJob*)d_jobs, cm);
+  }
   CFEAR_HIP_CHECK(ctx, hipGetLastError());
   return CFEAR_OK;
 }
@@ -759,7 +1163,7 @@ extern "C" int cfear_scan_create(cfear_ctx* ctx, float* xyzi, int32_t n, const c
   cfear_surface_fill_job(hjob, d, nullptr, n, par->compensate, par->mot, s->view);
   CFEAR_HIP_CHECK(ctx, hipMemcpyAsync(d_job, hjob, sizeof(SurfJob), hipMemcpyHostToDevice, ctx->stream));
   CFEAR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));     // hjob is on the stack
-  rc = cfear_surface_launch(ctx, d_job, 1, par, d_scratch, d_status, nullptr);
+  rc = cfear_surface_launch(ctx, d_job, 1, par, d_scratch, d_status, nullptr, n);
   if (rc != CFEAR_OK) { cfear_scan_destroy(s); return rc; }
   int32_t hst[2] = {0, 0};
   CFEAR_HIP_CHECK(ctx, hipMemcpyAsync(&hst[0], d_status, 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -883,14 +1287,3 @@ extern "C" int cfear_scan_closest_idx(const cfear_scan* scan, const double* quer
   return CFEAR_OK;
 }
 
-#ifdef CFEAR_SURF_TIMING
-// debug only (not in the header): cycle stamps of the last single-scan cfear_scan_create
-extern "C" int cfear_debug_surface_stamps(cfear_ctx* ctx, long long* out16) {
-  char* ws = (char*)ctx->ws[5].p;
-  if (!ws) return -1;
-  const size_t off = 1024 + (size_t)kMaxPoints * 16 + (size_t)kMaxPoints * 8 + (size_t)kMaxPoints * sizeof(TmpCell) +
-                     (size_t)(kMaxPoints - 64) * 4;
-  (void)hipStreamSynchronize(ctx->stream);
-  return hipMemcpy(out16, ws + off, 16 * 8, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -2;
-}
-#endif
