@@ -24,6 +24,7 @@
 // Working set per scan is a few hundred KB and stays in LDS / L2; nothing here is HBM-bound.
 #include <cfloat>
 #include <cmath>
+#include <type_traits>
 
 #include "common.hpp"
 #include "gridsort.hpp"
@@ -134,7 +135,28 @@ __device__ __forceinline__ double get_rel_time_stamp(double x, double y, bool cc
   return ccw ? -(d - 0.5) : (d - 0.5);
 }
 
+// The same for a point whose azimuth row is known (fused filter output): p = fl32(rho (cos th, sin th)) with th =
+// (row + 1) / rows * 2 pi, so atan2(y, x) = th + delta with |delta| ~ 1e-7 from the float rounding of x and y, and
+// delta = atan(t) = t to double precision for t = (y c - x s) / (x c + y s).  One division instead of an fp64 atan2;
+// the result agrees with libm's atan2 to ~1 ulp, the level at which device and host libm differ anyway.
+__device__ __forceinline__ double rel_time_stamp_known_row(double x, double y, double th, double c, double s, bool ccw) {
+  const double a_full = th + (y * c - x * s) / (x * c + y * s);         // in (0, 2 pi]
+  const double a = a_full > M_PI ? a_full - 2 * M_PI : a_full;          // atan2's range
+  const double d = ((a > 0.00001 ? a : (2 * M_PI + a)) / (2 * M_PI));
+  return ccw ? -(d - 0.5) : (d - 0.5);
+}
+
 // utils.cpp:96-107
+__device__ __forceinline__ float4 compensate_point_d(float4 p, const double d, const double mot[3]) {
+  double s_1, c_1;
+  sincos(d * mot[2], &s_1, &c_1);
+  const double tx = d * mot[0], ty = d * mot[1];
+  const double x = (double)p.x, y = (double)p.y;
+  p.x = (float)((c_1 * x + (-s_1) * y) + tx);
+  p.y = (float)((s_1 * x + c_1 * y) + ty);
+  return p;
+}
+
 __device__ __forceinline__ float4 compensate_point(float4 p, const double mot[3], bool ccw) {
   const double d = get_rel_time_stamp((double)p.x, (double)p.y, ccw);
   double s_1, c_1;
@@ -680,6 +702,13 @@ __global__ __launch_bounds__(kFastThreads, 4) void surface_sort_kernel(const Sur
       cm.fallback[1 + w] = job_id;
     }
   };
+#ifdef CFEAR_SURF_TIMING
+  long long* tstamp = (long long*)((char*)scr.hdr + 64);
+#define STAMP(i) do { if (tid == 0) tstamp[i] = __builtin_readcyclecounter(); } while (0)
+#else
+#define STAMP(i) do { } while (0)
+#endif
+  STAMP(0);
   if (!cm.fast_ok) { hand_over(0, 0); return; }
   // ---- (a) point count; rows mode: exclusive prefix of the row counts ------------------------------------------
   int n = job.n_ptr ? *job.n_ptr : job.n_host;
@@ -705,13 +734,16 @@ __global__ __launch_bounds__(kFastThreads, 4) void surface_sort_kernel(const Sur
   if (n <= 0) { done(CFEAR_ERR_EMPTY_CLOUD); return; }
   if (n > kMaxPoints) { done(CFEAR_ERR_CAPACITY); return; }
   float4* pts = job.xyzi;
+  STAMP(1);
   // ---- (b) polar -> Cartesian (rows mode), motion compensation, bounding box ------------------------------------
   float mnx = FLT_MAX, mny = FLT_MAX, mxx = -FLT_MAX, mxy = -FLT_MAX;
   for (int i0 = tid; i0 < n; i0 += 4 * NT) {
     float4 p[4];
+    double dts[4];                                      // rows mode: relative time stamp from the known azimuth
 #pragma unroll
     for (int u = 0; u < 4; u++) {
       const int i = i0 + u * NT;
+      dts[u] = 0.0;
       if (i < n) {
         if (job.row_pts) {                              // row of point i: the last r with rowoff[r] <= i
           int lo = 0, hi = job.rows;
@@ -719,7 +751,12 @@ __global__ __launch_bounds__(kFastThreads, 4) void surface_sort_kernel(const Sur
           const uint32_t key = job.row_pts[(size_t)lo * job.k + (i - rowoff[lo])];
           const double range_res_half = cm.range_res / 2.0;
           const double rho = range_res_half + cm.range_res * (double)(int)(key & 0xFFFFFFu);   // radar_filters.cpp:324-330
-          p[u] = make_float4((float)(rho * cm.cos_t[lo]), (float)(rho * cm.sin_t[lo]), 0.f, (float)(key >> 24));
+          const double ct = cm.cos_t[lo], st = cm.sin_t[lo];
+          p[u] = make_float4((float)(rho * ct), (float)(rho * st), 0.f, (float)(key >> 24));
+          if (job.compensate) {
+            const double th = ((double)(lo + 1) / (double)job.rows) * 2. * M_PI;              // radar_filters.cpp:317
+            dts[u] = rel_time_stamp_known_row((double)p[u].x, (double)p[u].y, th, ct, st, cm.ccw != 0);
+          }
         } else {
           p[u] = pts[i];
         }
@@ -729,7 +766,7 @@ __global__ __launch_bounds__(kFastThreads, 4) void surface_sort_kernel(const Sur
     for (int u = 0; u < 4; u++) {
       const int i = i0 + u * NT;
       if (i < n) {
-        if (job.compensate) p[u] = compensate_point(p[u], job.mot, cm.ccw != 0);
+        if (job.compensate) p[u] = job.row_pts ? compensate_point_d(p[u], dts[u], job.mot) : compensate_point(p[u], job.mot, cm.ccw != 0);
         if (job.compensate || job.row_pts) pts[i] = p[u];
         mnx = fminf(mnx, p[u].x); mxx = fmaxf(mxx, p[u].x);
         mny = fminf(mny, p[u].y); mxy = fmaxf(mxy, p[u].y);
@@ -756,6 +793,7 @@ __global__ __launch_bounds__(kFastThreads, 4) void surface_sort_kernel(const Sur
   const int dbx = (int)div_bx, dby = (int)div_by;
   const int ncells = dbx * dby;
   if (ncells > kFastMaxCells) { hand_over(n, 1); return; }
+  STAMP(2);
   // ---- (c) histogram of the points over the voxel grid: u16 counters, two per LDS word ---------------------------
   // cnt[c] for c in [0, ncells]; after the scan the same words hold ord[c] = occupied cells before c.
   const int words = (ncells + 2) >> 1;                                // covers c = ncells
@@ -779,6 +817,7 @@ __global__ __launch_bounds__(kFastThreads, 4) void surface_sort_kernel(const Sur
     }
   }
   __syncthreads();
+  STAMP(3);
   // ---- (d) exclusive scan over the cells: points before a cell (voxel starts) and occupied cells before it -------
   const int per = (words + NT - 1) / NT;                              // consecutive words per thread (<= 17)
   const int w0 = tid * per, w1 = min(words, w0 + per);
@@ -795,7 +834,7 @@ __global__ __launch_bounds__(kFastThreads, 4) void surface_sort_kernel(const Sur
   int excl = incl - packed, tot = 0;
   for (int wv = 0; wv < NW; wv++) { if (wv < wave) excl += red_i[wv]; tot += red_i[wv]; }
   const int V = tot >> 16;
-  // LDS budget: ord | voxel cursors u16[V + 2] | order u16[n]
+  // LDS budget: ord | voxel cursors u16[V + 2] | order u16[n] (later: staged points)
   const size_t vs_off = ord_bytes, vs_bytes = (((size_t)V + 2) * 2 + 15) & ~(size_t)15;
   const size_t ord2_off = vs_off + vs_bytes, need = ord2_off + (((size_t)n * 2 + 15) & ~(size_t)15);
   if (need > kFastLds - 512) { hand_over(n, 1); return; }
@@ -816,6 +855,7 @@ __global__ __launch_bounds__(kFastThreads, 4) void surface_sort_kernel(const Sur
   }
   __syncthreads();
   const unsigned short* ord16 = (const unsigned short*)smem;
+  STAMP(4);
   // ---- (e) scatter: the atomic cursor of a voxel ends at the start of the next one --------------------------------
 #pragma unroll
   for (int j = 0; j < kPer; j++) {
@@ -828,6 +868,7 @@ __global__ __launch_bounds__(kFastThreads, 4) void surface_sort_kernel(const Sur
     }
   }
   __syncthreads();
+  STAMP(5);
   // ---- (f) input order inside every voxel: rank of a point among its voxel's points (runs are a few points long) ---
 #pragma unroll
   for (int j = 0; j < kPer; j++) {
@@ -835,8 +876,12 @@ __global__ __launch_bounds__(kFastThreads, 4) void surface_sort_kernel(const Sur
     if (i < n) {
       const int v = ord16[mycell[j]];
       const int s0 = v ? (int)vs16[v - 1] : 0, e0 = (int)vs16[v];
-      int rank = 0;
-      for (int q = s0; q < e0; q++) rank += (int)order[q] < i;
+      int rank = 0, q = s0;
+      for (; q + 3 < e0; q += 4) {                                      // four independent LDS reads in flight
+        const int o0 = order[q], o1 = order[q + 1], o2 = order[q + 2], o3 = order[q + 3];
+        rank += (o0 < i) + (o1 < i) + (o2 < i) + (o3 < i);
+      }
+      for (; q < e0; q++) rank += (int)order[q] < i;
       mycell[j] = (unsigned short)(s0 + rank);
     }
   }
@@ -847,28 +892,38 @@ __global__ __launch_bounds__(kFastThreads, 4) void surface_sort_kernel(const Sur
     if (i < n) order[mycell[j]] = (unsigned short)i;
   }
   __syncthreads();
+  STAMP(6);
   // ---- (g) sorted points -> global scratch (L2): the order array is then dead and its LDS becomes the staging area ---
+  bool w_small = true;                                                // every weight an integer in [0, 255]?
   for (int pos = tid; pos < n; pos += NT) {
     const float4 p = pts[order[pos]];
     // the sorted copies carry the point's WEIGHT max(I - 60, 0) (pointnormal.cpp:15), not its intensity: float(I) - 60
     // is exact for I >= 60, so the fp64 weight of the reference is just its widening
-    scr.spt[pos] = make_float4(p.x, p.y, fmaxf(__fsub_rn(p.w, 60.0f), 0.0f), 0.f);
+    const float wgt = fmaxf(__fsub_rn(p.w, 60.0f), 0.0f);
+    w_small = w_small && wgt <= 255.0f && wgt == truncf(wgt);
+    scr.spt[pos] = make_float4(p.x, p.y, wgt, 0.f);
   }
   __threadfence_block();
-  __syncthreads();
+  const bool wbyte = __syncthreads_and(w_small ? 1 : 0) != 0;
+  STAMP(7);
   // ---- (h) cells: one lane per voxel, slab by slab.  A slab = the voxels of grid rows [ya, yb) whose candidate points
   //      (rows ya - 1 .. yb, one contiguous range of the sorted array) fit the staging area; a sparse scan needs two
   //      slabs, a 16 000-point scan five.  Neighbour runs are O(1) look-ups: the points of cells [c0, c1] of one grid
   //      row are the run [points before c0, points before c1 + 1). ------------------------------------------------
   auto pbefore = [&](int c) { const int o = ord16[c]; return o ? (int)vs16[o - 1] : 0; };    // points in cells < c
   float2* lxy = (float2*)(smem + ord2_off);
-  const int cap_pts = (int)((kFastLds - 512 - ord2_off) / 12);
-  float* lw = (float*)(smem + ord2_off + (size_t)cap_pts * 8);
+  // Staged point: (x, y) + weight.  Radar intensities are integers, so max(I - 60, 0) normally fits ONE byte (9 bytes
+  // per point: a sparse scan, n <~ 5500, is then a single slab); clouds with other intensities keep a float weight.
+  auto cells_phase = [&](auto wb_tag) -> bool {                        // compiled for both weight formats
+  constexpr bool WB = decltype(wb_tag)::value;
+  const int cap_pts = (int)((kFastLds - 512 - ord2_off) / (WB ? 9 : 12)) & ~3;
+  uint8_t* lw = (uint8_t*)(smem + ord2_off + (size_t)cap_pts * 8);
+  float* lwf = (float*)lw;
   const bool wi = cm.weight_intensity != 0;
   for (int ya = 0; ya < dby;) {                                       // block-uniform
     const int P0 = pbefore(max(ya - 1, 0) * dbx);
     int lo = ya + 1, hi = dby;                                        // largest yb in [ya + 1, dby] whose range fits
-    if (pbefore(min(lo + 1, dby) * dbx) - P0 > cap_pts) { hand_over(n, 1); return; }   // three grid rows exceed the staging area
+    if (pbefore(min(lo + 1, dby) * dbx) - P0 > cap_pts) { hand_over(n, 1); return false; }   // three grid rows exceed the staging area
     while (lo < hi) {
       const int mid = (lo + hi + 1) >> 1;
       if (pbefore(min(mid + 1, dby) * dbx) - P0 <= cap_pts) lo = mid; else hi = mid - 1;
@@ -878,7 +933,7 @@ __global__ __launch_bounds__(kFastThreads, 4) void surface_sort_kernel(const Sur
     for (int i = tid; i < P1 - P0; i += NT) {
       const float4 q = scr.spt[P0 + i];
       lxy[i] = make_float2(q.x, q.y);
-      lw[i] = q.z;
+      if (WB) lw[i] = (uint8_t)q.z; else lwf[i] = q.z;
     }
     __syncthreads();
     const int vbeg = ord16[ya * dbx], vend = ord16[yb * dbx];
@@ -909,13 +964,16 @@ __global__ __launch_bounds__(kFastThreads, 4) void surface_sort_kernel(const Sur
           for (; p + 3 < r1[d]; p += 4) {                               // four independent LDS reads in flight
             const float2 qa = lxy[p], qb = lxy[p + 1], qc = lxy[p + 2], qd = lxy[p + 3];
             float wa = 0.f, wb = 0.f, wc = 0.f, wd = 0.f;
-            if (wi) { wa = lw[p]; wb = lw[p + 1]; wc = lw[p + 2]; wd = lw[p + 3]; }
+            if (wi) {
+              if (WB) { wa = (float)lw[p]; wb = (float)lw[p + 1]; wc = (float)lw[p + 2]; wd = (float)lw[p + 3]; }
+              else { wa = lwf[p]; wb = lwf[p + 1]; wc = lwf[p + 2]; wd = lwf[p + 3]; }
+            }
             accum_point(mo, c, cx, cy, qa.x, qa.y, wa, cm.r2, wi);
             accum_point(mo, c, cx, cy, qb.x, qb.y, wb, cm.r2, wi);
             accum_point(mo, c, cx, cy, qc.x, qc.y, wc, cm.r2, wi);
             accum_point(mo, c, cx, cy, qd.x, qd.y, wd, cm.r2, wi);
           }
-          for (; p < r1[d]; p++) { const float2 q = lxy[p]; accum_point(mo, c, cx, cy, q.x, q.y, wi ? lw[p] : 0.f, cm.r2, wi); }
+          for (; p < r1[d]; p++) { const float2 q = lxy[p]; accum_point(mo, c, cx, cy, q.x, q.y, wi ? (WB ? (float)lw[p] : lwf[p]) : 0.f, cm.r2, wi); }
         }
         TmpCell tc;
         valid = finish_cell(mo, cx, cy, cm.origin[0], cm.origin[1], tc);
@@ -926,6 +984,10 @@ __global__ __launch_bounds__(kFastThreads, 4) void surface_sort_kernel(const Sur
     __syncthreads();                                                   // the staging area is reused by the next slab
     ya = yb;
   }
+  return true;
+  };
+  if (!(wbyte ? cells_phase(std::true_type{}) : cells_phase(std::false_type{}))) return;
+  STAMP(8);
   if (tid == 0) {
     scr.hdr->route = kRouteFast;                                       // cells computed; compaction + x-sort pending
     scr.hdr->n = n; scr.hdr->V = V; scr.hdr->dbx = dbx; scr.hdr->dby = dby;
@@ -1098,6 +1160,23 @@ int cfear_surface_launch(cfear_ctx* ctx, const void* d_jobs, int n_jobs, const c
     hipLaunchKernelGGL(surface_finish_kernel, dim3(n_jobs), dim3(kFinishThreads), finish_lds, ctx->stream, (const SurfJob*)d_jobs, cm);
   }
   CFEAR_HIP_CHECK(ctx, hipGetLastError());
+#ifdef CFEAR_SURF_TIMING
+  {                                            // debug build only: phase split of surface_sort_kernel, averaged over the jobs
+    static int calls = 0;
+    if (++calls % 40 == 0) {
+      (void)hipStreamSynchronize(ctx->stream);
+      double acc[9] = {0};
+      const int m = std::min(n_jobs, 256);
+      for (int j = 0; j < m; j++) {
+        long long t[9];
+        (void)hipMemcpy(t, d_scratch + (size_t)j * cm.scratch_stride + 64, sizeof(t), hipMemcpyDeviceToHost);
+        for (int q = 1; q < 9; q++) acc[q] += (double)(t[q] - t[q - 1]);
+      }
+      fprintf(stderr, "surface_sort phases (cycles, mean of %d jobs): count %.0f  comp+bbox %.0f  hist %.0f  scan %.0f  scatter %.0f  order %.0f  spt %.0f  cells %.0f\n",
+              m, acc[1] / m, acc[2] / m, acc[3] / m, acc[4] / m, acc[5] / m, acc[6] / m, acc[7] / m, acc[8] / m);
+    }
+  }
+#endif
   return CFEAR_OK;
 }
 
