@@ -131,7 +131,7 @@ int cfear_cacfar_device(cfear_ctx* ctx, const uint8_t* d_polar, const cfear_pola
                         const cfear_cacfar_params* par, float* d_xyzi, int32_t* d_n_points,
                         int32_t cap_points, uint8_t* d_det_mask);
 size_t cfear_surface_lds_bytes();
-size_t cfear_surface_scratch_bytes();
+size_t cfear_surface_scratch_bytes(int cap_points);   // per scan, for clouds of up to cap_points points
 size_t cfear_surface_job_bytes();
 int cfear_surface_max_points();
 void cfear_surface_fill_job(void* dst, float* d_xyzi, const int32_t* d_n, int32_t n_host, int compensate,
@@ -145,7 +145,7 @@ struct cfear_surface_polar { const double* cos_t = nullptr; const double* sin_t 
 int cfear_trig_tables(cfear_ctx* ctx, int rows, double** d_cos, double** d_sin);
 // max_cell_cap: the largest cell capacity (ScanView::cap) among the jobs' output slabs
 int cfear_surface_launch(cfear_ctx* ctx, const void* d_jobs, int n_jobs, const cfear_feature_params* par,
-                         char* d_scratch, int32_t* d_status, int32_t* d_ncells_out, int max_cell_cap,
+                         char* d_scratch, int32_t* d_status, int32_t* d_ncells_out, int max_cell_cap, int cap_points,
                          const cfear_surface_polar* polar = nullptr);
 size_t cfear_reg_job_bytes();
 int cfear_reg_max_scans();

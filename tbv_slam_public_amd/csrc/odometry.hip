@@ -195,8 +195,9 @@ extern "C" int cfear_odometry_create(cfear_ctx* ctx, int32_t n_streams, const cf
     od->desc.batch_stride = (int64_t)od->desc.rows * od->desc.stride;
   }
   const int B = n_streams, rows = od->desc.rows, k = par->kstrong.k_strongest;
-  od->cap_points = par->filter_type == CFEAR_FILTER_CACFAR ? cfear_surface_max_points()
-                                                           : std::min(rows * k, cfear_surface_max_points());
+  // CA-CFAR puts no bound on the detections of a row (cfar.cpp:35-71): room for 65 536 points per sweep (the surface
+  // kernels take clouds beyond 16 384 points through their global-memory path); k-strongest keeps at most rows * k
+  od->cap_points = par->filter_type == CFEAR_FILTER_CACFAR ? std::min(rows * od->desc.cols, 65536) : rows * k;
   od->cell_cap = 2048;
   od->slabs_per_stream = par->submap_scan_size + 2;
   od->slab_bytes = cfear_scan_slab_bytes(od->cell_cap);
@@ -237,7 +238,7 @@ extern "C" int cfear_odometry_create(cfear_ctx* ctx, int32_t n_streams, const cf
   ok = ok && dalloc(&od->d_results, (size_t)B * sizeof(cfear_reg_result));
   ok = ok && dalloc(&od->d_status, (size_t)B * 4);
   ok = ok && dalloc(&od->d_ncells, (size_t)B * 4);
-  ok = ok && dalloc(&od->d_surf_scratch, (size_t)B * cfear_surface_scratch_bytes());
+  ok = ok && dalloc(&od->d_surf_scratch, (size_t)B * cfear_surface_scratch_bytes(od->cap_points));
   ok = ok && dalloc(&od->d_reg_scratch, (size_t)B * cfear_register_scratch_bytes(par->submap_scan_size * od->cell_cap));
   ok = ok && halloc(&od->h_surf_jobs, (size_t)B * cfear_surface_job_bytes());
   ok = ok && halloc(&od->h_reg_jobs, (size_t)B * cfear_reg_job_bytes());
@@ -514,7 +515,7 @@ static int process_frame(cfear_odometry* od, const uint8_t* polar, const uint8_t
     if (rc != CFEAR_OK) return fail(rc);
     sp.cos_t = d_cos; sp.sin_t = d_sin; sp.range_res = (double)par.kstrong.range_res;
   }
-  rc = cfear_surface_launch(ctx, od->d_surf_jobs, B, &fp, od->d_surf_scratch, od->d_status, od->d_ncells, od->cell_cap, rows_mode ? &sp : nullptr);
+  rc = cfear_surface_launch(ctx, od->d_surf_jobs, B, &fp, od->d_surf_scratch, od->d_status, od->d_ncells, od->cell_cap, od->cap_points, rows_mode ? &sp : nullptr);
   if (rc != CFEAR_OK) return fail(rc);
   if (n_jobs > 0) {
     OD_CHECK(hipStreamWaitEvent(ctx->stream, od->ev_jobs, 0));

@@ -72,6 +72,8 @@ struct SurfCommon {
   int32_t* fallback;                          // [1 + n_jobs]: count, then the jobs the fast pipeline handed to the single-kernel path
   int32_t n_jobs;
   int32_t fast_ok;                            // reach == 1: the fast pipeline applies
+  int32_t scratch_cap;                        // points the per-scan scratch is sized for (>= kMaxPoints)
+  int32_t finish_keys;                        // sort keys surface_finish_kernel's LDS holds
 };
 
 struct TmpCell {                              // one candidate cell per voxel (before compaction)
@@ -91,32 +93,41 @@ constexpr int kFastMaxCells = 16384;          // grid cells the LDS counting sor
 constexpr int kFastThreads = 512;
 constexpr size_t kFastLds = 78 * 1024;        // two workgroups per CU (160 KiB)
 constexpr int kRouteFast = 0, kRouteFallback = 1, kRouteDone = 2;
+constexpr int kScanCreateMaxPoints = 1 << 20;  // cfear_scan_create: clouds beyond kMaxPoints take the global-memory path
 
 struct SurfHdr {                              // written by surface_sort_kernel, read by the kernels behind it
   int32_t route;                              // kRouteFast: sorted, cells pending | kRouteFallback | kRouteDone (finished / failed)
   int32_t n, V, dbx, dby, pad[3];
 };
 
-__host__ __device__ inline size_t scratch_bytes_per_scan() {
+// cap = the largest point count a scan of this launch may have (>= kMaxPoints); clouds beyond kMaxPoints take the
+// big-cloud path, which also keeps its 64-bit sort keys here (2 x next_pow2 entries).
+__host__ __device__ inline size_t scratch_bytes_per_scan(int cap) {
   size_t b = 256;
-  b += (size_t)kMaxPoints * 136 + 16;
+  b += (size_t)cap * 136 + 16;
   b += (size_t)(kFastMaxCells + 4) * 2;
+  b = (b + 255) / 256 * 256;
+  if (cap > kMaxPoints) b += (size_t)cap * 2 * 8 + 256;
   return (b + 255) / 256 * 256;
 }
 struct SurfScratch {
   SurfHdr* hdr; float4* spt; float2* cen; uint32_t* vkey; TmpCell* tmp; int32_t* coff; uint32_t* vs; unsigned short* ord;
+  unsigned long long* bigkeys;
 };
-__host__ __device__ inline SurfScratch scratch_of(char* base) {
+__host__ __device__ inline SurfScratch scratch_of(char* base, int cap) {
   SurfScratch r;
   r.hdr = (SurfHdr*)base;
   char* p = base + 256;
   r.spt = (float4*)p;
-  r.cen = (float2*)(p + (size_t)kMaxPoints * 16);
-  r.vkey = (uint32_t*)(p + (size_t)kMaxPoints * 16);
-  r.tmp = (TmpCell*)(p + (size_t)kMaxPoints * 24);
-  r.coff = (int32_t*)(p + (size_t)kMaxPoints * 128);
-  r.vs = (uint32_t*)(p + (size_t)kMaxPoints * 132);
-  r.ord = (unsigned short*)(p + (size_t)kMaxPoints * 136 + 16);
+  r.cen = (float2*)(p + (size_t)cap * 16);
+  r.vkey = (uint32_t*)(p + (size_t)cap * 16);
+  r.tmp = (TmpCell*)(p + (size_t)cap * 24);
+  r.coff = (int32_t*)(p + (size_t)cap * 128);
+  r.vs = (uint32_t*)(p + (size_t)cap * 132);
+  r.ord = (unsigned short*)(p + (size_t)cap * 136 + 16);
+  size_t b = 256 + (size_t)cap * 136 + 16 + (size_t)(kFastMaxCells + 4) * 2;
+  b = (b + 255) / 256 * 256;
+  r.bigkeys = (unsigned long long*)(base + b);
   return r;
 }
 
@@ -330,6 +341,92 @@ __global__ __launch_bounds__(kSurfThreads) void scan_sort_kernel(ScanView v) {
   sort_cells_block(v, *v.n_cells, (unsigned long long*)smem);
 }
 
+// Clouds with more than kMaxPoints points (CA-CFAR sweeps: cfar.cpp:35-71 puts no bound on the detections per row):
+// the tail of the single-kernel path with every array in global scratch -- bitonic sort of 64-bit (voxel, point) keys,
+// voxel table by head flags, one lane per voxel with binary searches for the neighbour runs.  Slow (a few ms per scan)
+// but unbounded by LDS; compaction and the x-sort are left to surface_finish_kernel.
+__device__ void surface_big_tail(const SurfJob& job, const SurfCommon& cm, const int job_id, const int n, const int dbx,
+                                 const int dby, const int min_bx, const int min_by, uint8_t* smem) {
+  int* red_i = (int*)(smem + kLdsSmallOff + 256);
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const SurfScratch scr = scratch_of(cm.scratch + (size_t)job_id * cm.scratch_stride, cm.scratch_cap);
+  const float4* pts = job.xyzi;
+  unsigned long long* keys = scr.bigkeys;
+  int npad = 1024;
+  while (npad < n) npad <<= 1;
+  for (int i = tid; i < npad; i += kSurfThreads) {
+    unsigned long long key = ~0ull;
+    if (i < n) {
+      const float4 p = pts[i];
+      const int ijk0 = (int)(floorf(p.x * cm.inv_leaf) - (float)min_bx);
+      const int ijk1 = (int)(floorf(p.y * cm.inv_leaf) - (float)min_by);
+      key = ((unsigned long long)(uint32_t)(ijk0 + ijk1 * dbx) << 32) | (unsigned)i;
+    }
+    keys[i] = key;
+  }
+  __threadfence_block();
+  __syncthreads();
+  for (int k = 2; k <= npad; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int t = tid; t < (npad >> 1); t += kSurfThreads) {
+        const int lo = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+        const int hi = lo | j;
+        const bool asc = (lo & k) == 0;
+        const unsigned long long a = keys[lo], b = keys[hi];
+        if ((a > b) == asc) { keys[lo] = b; keys[hi] = a; }
+      }
+      __threadfence_block();
+      __syncthreads();
+    }
+  }
+  // voxel table: contiguous chunks per thread, head flags, block scan
+  const int per = (n + kSurfThreads - 1) / kSurfThreads;
+  const int e0 = min(n, tid * per), e1 = min(n, e0 + per);
+  int heads = 0;
+  for (int e = e0; e < e1; e++) heads += (e == 0 || (uint32_t)(keys[e] >> 32) != (uint32_t)(keys[e - 1] >> 32));
+  const int incl = wave_incl_scan_i32(heads);
+  if (lane == 63) red_i[wave] = incl;
+  __syncthreads();
+  int ordv = incl - heads, V = 0;
+  for (int wv = 0; wv < 16; wv++) { if (wv < wave) ordv += red_i[wv]; V += red_i[wv]; }
+  for (int e = e0; e < e1; e++) {
+    const uint32_t vx = (uint32_t)(keys[e] >> 32);
+    if (e == 0 || vx != (uint32_t)(keys[e - 1] >> 32)) { scr.vkey[ordv] = vx; scr.vs[ordv] = (uint32_t)e; ordv++; }
+    const float4 p = pts[(uint32_t)(keys[e] & 0xFFFFFFFFu)];
+    scr.spt[e] = make_float4(p.x, p.y, fmaxf(__fsub_rn(p.w, 60.0f), 0.0f), 0.f);
+  }
+  if (tid == 0) scr.vs[V] = (uint32_t)n;
+  __threadfence_block();
+  __syncthreads();
+  const bool wi = cm.weight_intensity != 0;
+  for (int v = tid; v < V; v += kSurfThreads) {
+    const uint32_t key = scr.vkey[v];
+    const int s = (int)scr.vs[v], e = (int)scr.vs[v + 1];
+    const int iy = (int)(key / (uint32_t)dbx), ix = (int)(key - (uint32_t)iy * (uint32_t)dbx);
+    const int x0 = max(ix - cm.reach, 0), x1 = min(ix + cm.reach, dbx - 1);
+    float ax = 0.f, ay = 0.f;
+    for (int p = s; p < e; p++) { const float4 q = scr.spt[p]; ax = __fadd_rn(ax, q.x); ay = __fadd_rn(ay, q.y); }
+    const float cnt = (float)(e - s);
+    const float2 c = make_float2(__fdiv_rn(ax, cnt), __fdiv_rn(ay, cnt));
+    const double cx = (double)c.x, cy = (double)c.y;
+    Moments mo{0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    for (int yy = max(iy - cm.reach, 0); yy <= min(iy + cm.reach, dby - 1); yy++) {
+      const uint32_t klo = (uint32_t)(yy * dbx + x0), khi = (uint32_t)(yy * dbx + x1);
+      const int a = lower_bound_u32(scr.vkey, 0, V, klo), b = upper_bound_u32(scr.vkey, a, V, khi);
+      const int p0 = (int)scr.vs[a], p1 = (int)scr.vs[b];
+      for (int p = p0; p < p1; p++) { const float4 q = scr.spt[p]; accum_point(mo, c, cx, cy, q.x, q.y, q.z, cm.r2, wi); }
+    }
+    TmpCell tc;
+    const int valid = finish_cell(mo, cx, cy, cm.origin[0], cm.origin[1], tc);
+    if (valid) scr.tmp[v] = tc;
+    scr.coff[v] = valid;
+  }
+  if (tid == 0) {
+    scr.hdr->route = kRouteFast;                        // cells computed; compaction + x-sort pending
+    scr.hdr->n = n; scr.hdr->V = V; scr.hdr->dbx = dbx; scr.hdr->dby = dby;
+  }
+}
+
 // The single-kernel path: one 1024-thread workgroup per scan, everything in 148 KiB of LDS; any grid size, n <= 16384.
 // It serves the scans the fast pipeline (surface_sort / surface_cells / surface_finish below) hands over: voxel grids
 // with more than kFastMaxCells cells, downsample factors != 1, or tables that do not fit the fast path's LDS budget.
@@ -340,7 +437,7 @@ __device__ void surface_points_job(const SurfJob* __restrict__ jobs, const SurfC
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   SurfJob job = jobs[job_id];
   if (cm.fallback) {                                                  // handed over by surface_sort_kernel
-    const SurfHdr h = *scratch_of(cm.scratch + (size_t)job_id * cm.scratch_stride).hdr;
+    const SurfHdr h = *scratch_of(cm.scratch + (size_t)job_id * cm.scratch_stride, cm.scratch_cap).hdr;
     if (h.pad[0]) {                                                   // xyzi already holds the compact, compensated cloud
       job.row_pts = nullptr; job.n_ptr = nullptr; job.n_host = h.n; job.compensate = 0;
     }
@@ -370,12 +467,12 @@ __device__ void surface_points_job(const SurfJob* __restrict__ jobs, const SurfC
     if (tid == 0) { *job.out.n_cells = 0; *status = CFEAR_ERR_EMPTY_CLOUD; if (cm.ncells_out) cm.ncells_out[job_id] = 0; }
     return;
   }
-  if (n > kMaxPoints) {
+  if (n > cm.scratch_cap) {
     if (tid == 0) { *job.out.n_cells = 0; *status = CFEAR_ERR_CAPACITY; if (cm.ncells_out) cm.ncells_out[job_id] = 0; }
     return;
   }
   float4* pts = job.xyzi;
-  const SurfScratch scr = scratch_of(cm.scratch + (size_t)job_id * cm.scratch_stride);
+  const SurfScratch scr = scratch_of(cm.scratch + (size_t)job_id * cm.scratch_stride, cm.scratch_cap);
   float4* spt = scr.spt;                      // sorted points (x, y, weight, -)
   float2* cen = scr.cen;
   TmpCell* tmp = scr.tmp;
@@ -432,6 +529,10 @@ __device__ void surface_points_job(const SurfJob* __restrict__ jobs, const SurfC
     return;
   }
   const int dbx = (int)div_bx, dby = (int)div_by;
+  if (n > kMaxPoints) {                                 // more points than the LDS sort holds (CA-CFAR clouds): global memory
+    surface_big_tail(job, cm, job_id, n, dbx, dby, min_bx, min_by, smem);
+    return;
+  }
 
   // ---- 2. (voxel, point) keys -> LDS sort: voxels ascending, points of a voxel in input order --
   unsigned long long* keys = (unsigned long long*)smem;
@@ -684,7 +785,7 @@ __global__ __launch_bounds__(kFastThreads, 4) void surface_sort_kernel(const Sur
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int job_id = blockIdx.x;
   const SurfJob job = jobs[job_id];
-  const SurfScratch scr = scratch_of(cm.scratch + (size_t)job_id * cm.scratch_stride);
+  const SurfScratch scr = scratch_of(cm.scratch + (size_t)job_id * cm.scratch_stride, cm.scratch_cap);
   int32_t* status = cm.status + job_id;
   auto done = [&](int st) {                                            // nothing (more) to do for this scan
     if (tid == 0) {
@@ -732,7 +833,8 @@ __global__ __launch_bounds__(kFastThreads, 4) void surface_sort_kernel(const Sur
     __syncthreads();
   }
   if (n <= 0) { done(CFEAR_ERR_EMPTY_CLOUD); return; }
-  if (n > kMaxPoints) { done(CFEAR_ERR_CAPACITY); return; }
+  if (n > cm.scratch_cap) { done(CFEAR_ERR_CAPACITY); return; }
+  if (n > kMaxPoints) { hand_over(n, 0); return; }         // big cloud: global-memory path of the single-kernel workgroup
   float4* pts = job.xyzi;
   STAMP(1);
   // ---- (b) polar -> Cartesian (rows mode), motion compensation, bounding box ------------------------------------
@@ -1002,7 +1104,7 @@ __global__ __launch_bounds__(kFinishThreads) void surface_finish_kernel(const Su
   __shared__ int total_s;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int job_id = blockIdx.x;
-  const SurfScratch scr = scratch_of(cm.scratch + (size_t)job_id * cm.scratch_stride);
+  const SurfScratch scr = scratch_of(cm.scratch + (size_t)job_id * cm.scratch_stride, cm.scratch_cap);
   if (scr.hdr->route != kRouteFast) return;
   const SurfJob job = jobs[job_id];
   const int V = scr.hdr->V;
@@ -1034,11 +1136,12 @@ __global__ __launch_bounds__(kFinishThreads) void surface_finish_kernel(const Su
   __threadfence_block();
   __syncthreads();
   const int total = total_s;
-  sort_cells_block(job.out, min(total, job.out.cap), (unsigned long long*)smem);
+  const int cap = min(job.out.cap, cm.finish_keys);
+  sort_cells_block(job.out, min(total, cap), (unsigned long long*)smem);
   if (tid == 0) {
-    *job.out.n_cells = total <= job.out.cap ? total : job.out.cap;
-    cm.status[job_id] = total <= job.out.cap ? CFEAR_OK : CFEAR_ERR_CAPACITY;
-    if (cm.ncells_out) cm.ncells_out[job_id] = total <= job.out.cap ? total : job.out.cap;
+    *job.out.n_cells = total <= cap ? total : cap;
+    cm.status[job_id] = total <= cap ? CFEAR_OK : CFEAR_ERR_CAPACITY;
+    if (cm.ncells_out) cm.ncells_out[job_id] = total <= cap ? total : cap;
   }
 }
 
@@ -1075,7 +1178,7 @@ __global__ void slab_to_cells_kernel(ScanView v, int n, cfear_cell* cells) {
 }  // namespace
 
 size_t cfear_surface_lds_bytes() { return kLdsTotal; }
-size_t cfear_surface_scratch_bytes() { return scratch_bytes_per_scan(); }
+size_t cfear_surface_scratch_bytes(int cap_points) { return scratch_bytes_per_scan(std::max(cap_points, kMaxPoints)); }
 int cfear_surface_max_points() { return kMaxPoints; }
 
 // Launches the surface-point kernel for n_jobs scans.  d_jobs: device array of SurfJob-compatible
@@ -1106,7 +1209,7 @@ void cfear_surface_fill_job(void* dst, float* d_xyzi, const int32_t* d_n, int32_
 }
 
 int cfear_surface_launch(cfear_ctx* ctx, const void* d_jobs, int n_jobs, const cfear_feature_params* par,
-                         char* d_scratch, int32_t* d_status, int32_t* d_ncells_out, int max_cell_cap,
+                         char* d_scratch, int32_t* d_status, int32_t* d_ncells_out, int max_cell_cap, int cap_points,
                          const cfear_surface_polar* polar) {
   if (par->radius <= 0.f || !(par->downsample_factor > 0.0))
     return cfear_set_error(ctx, CFEAR_ERR_INVALID_ARGUMENT, "radius / downsample_factor must be > 0");
@@ -1123,7 +1226,8 @@ int cfear_surface_launch(cfear_ctx* ctx, const void* d_jobs, int n_jobs, const c
   cm.ccw = par->ccw;
   cm.origin[0] = par->origin[0]; cm.origin[1] = par->origin[1];
   cm.scratch = d_scratch;
-  cm.scratch_stride = scratch_bytes_per_scan();
+  cm.scratch_cap = std::max(cap_points, kMaxPoints);
+  cm.scratch_stride = scratch_bytes_per_scan(cm.scratch_cap);
   cm.status = d_status;
   cm.ncells_out = d_ncells_out;
   cm.cos_t = polar ? polar->cos_t : nullptr;
@@ -1141,7 +1245,8 @@ int cfear_surface_launch(cfear_ctx* ctx, const void* d_jobs, int n_jobs, const c
   CFEAR_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)surface_sort_kernel,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFastLds));
   int keys_pow2 = 64;
-  while (keys_pow2 < max_cell_cap) keys_pow2 <<= 1;
+  while (keys_pow2 < max_cell_cap && keys_pow2 < kMaxPoints) keys_pow2 <<= 1;   // the x-sort holds at most 16 384 cells (128 KiB)
+  cm.finish_keys = keys_pow2;
   const size_t finish_lds = (size_t)keys_pow2 * 8;
   if (finish_lds > 64 * 1024)
     CFEAR_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)surface_finish_kernel,
@@ -1221,7 +1326,7 @@ extern "C" int cfear_scan_create(cfear_ctx* ctx, float* xyzi, int32_t n, const c
   if (!par || !out || (!xyzi && n > 0)) return cfear_set_error(ctx, CFEAR_ERR_INVALID_ARGUMENT, "null argument");
   *out = nullptr;
   if (n <= 0) return cfear_set_error(ctx, CFEAR_ERR_EMPTY_CLOUD, "error, cloud empty");   // pointnormal.cpp:72-75
-  if (n > kMaxPoints) return cfear_set_error(ctx, CFEAR_ERR_CAPACITY, "n = %d > %d points", n, kMaxPoints);
+  if (n > kScanCreateMaxPoints) return cfear_set_error(ctx, CFEAR_ERR_CAPACITY, "n = %d > %d points", n, kScanCreateMaxPoints);
   CFEAR_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   const bool dev = cfear_is_device_ptr(xyzi);
   float* d = xyzi;
@@ -1233,7 +1338,7 @@ extern "C" int cfear_scan_create(cfear_ctx* ctx, float* xyzi, int32_t n, const c
   cfear_scan* s = nullptr;
   int rc = cfear_scan_alloc(ctx, n, &s);          // at most one cell per point
   if (rc != CFEAR_OK) return rc;
-  char* ws = (char*)cfear_workspace(ctx, 5, cfear_surface_scratch_bytes() + 1024);
+  char* ws = (char*)cfear_workspace(ctx, 5, cfear_surface_scratch_bytes(n) + 1024);
   if (!ws) { cfear_scan_destroy(s); return cfear_set_error(ctx, CFEAR_ERR_HIP, "workspace allocation failed"); }
   char* d_job = ws;                                // job record + status in front of the scratch
   int32_t* d_status = (int32_t*)(ws + 512);
@@ -1242,7 +1347,7 @@ extern "C" int cfear_scan_create(cfear_ctx* ctx, float* xyzi, int32_t n, const c
   cfear_surface_fill_job(hjob, d, nullptr, n, par->compensate, par->mot, s->view);
   CFEAR_HIP_CHECK(ctx, hipMemcpyAsync(d_job, hjob, sizeof(SurfJob), hipMemcpyHostToDevice, ctx->stream));
   CFEAR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));     // hjob is on the stack
-  rc = cfear_surface_launch(ctx, d_job, 1, par, d_scratch, d_status, nullptr, n);
+  rc = cfear_surface_launch(ctx, d_job, 1, par, d_scratch, d_status, nullptr, n, n);
   if (rc != CFEAR_OK) { cfear_scan_destroy(s); return rc; }
   int32_t hst[2] = {0, 0};
   CFEAR_HIP_CHECK(ctx, hipMemcpyAsync(&hst[0], d_status, 4, hipMemcpyDeviceToHost, ctx->stream));

@@ -80,8 +80,7 @@ def test_cacfar_pipeline_kvarntorp_preset():
     from oracle import pyoracle as O
     from tbv_slam_public_amd import api, synth
     n_frames = 6
-    # fewer, weaker returns so the detection count stays below the 16384-point surface kernel capacity
-    seqs = [synth.scene_v1(sd, n_frames, range_res=0.175, ccw=True, n_walls=25, noise_scale=4.0)[0] for sd in (11, 12)]
+    seqs = [synth.scene_v1(sd, n_frames, range_res=0.175, ccw=True)[0] for sd in (11, 12)]
     par = api.odometry_params(filter_type=1, cacfar_range_res=0.175, cacfar_z_min=20.0, cacfar_nb_guard_cells=10,
                               cacfar_window_size=40, cacfar_false_alarm_rate=0.01, radar_ccw=1, kstrong_range_res=0.175)
     od = api.OdometryKeyframeFuser(2, 400, 3360, par)
@@ -91,7 +90,7 @@ def test_cacfar_pipeline_kvarntorp_preset():
         info = od.process(np.stack([s[f] for s in seqs]))
         for b, s in enumerate(seqs):
             cloud, _ = O.cacfar(s[f], 40, 10, 0.01, 0.175, 20.0, 2.5)
-            assert 500 < cloud.shape[0] <= 16384
+            assert 500 < cloud.shape[0]
             pose, oi = fz[b].process(cloud)
             assert info["n_points"][b] == cloud.shape[0] and info["n_cells"][b] == oi[0]
             d = np.abs(info["pose"][b] - pose)

@@ -111,9 +111,10 @@ def test_surface_points_edge_cases():
     np.testing.assert_array_equal(back.GetCells(), exp)
 
 
-@pytest.mark.parametrize("n", [8192, 8193, 12000, 16384])
+@pytest.mark.parametrize("n", [8192, 8193, 12000, 16384, 16385, 40000])
 def test_surface_points_large_clouds(n):
-    """Clouds beyond the radix-sort capacity (8192) take the 64-bit bitonic path; 16384 is the maximum."""
+    """Clouds up to 16384 points are sorted in LDS (fast path, or the single-kernel path for big grids); beyond that
+    (CA-CFAR sweeps have no bound per row, cfar.cpp:35-71) the global-memory path takes over -- no capacity error."""
     from oracle import pyoracle as O
     from tbv_slam_public_amd import api
     rng = np.random.default_rng(n)
@@ -136,13 +137,24 @@ def test_surface_points_large_clouds(n):
     _cmp_cells(got, exp)
 
 
-def test_surface_points_too_many_points_is_an_error():
-    from tbv_slam_public_amd import api, _lib as L
-    pts = np.zeros((16385, 4), np.float32)
-    pts[:, 0] = np.linspace(0, 100, 16385)
-    with pytest.raises(L.CfearError) as e:
-        api.MapPointNormal(pts, 3.0)
-    assert e.value.status == L.ERR_CAPACITY
+def test_surface_points_small_voxels_and_downsampling_take_the_single_kernel_path():
+    """Voxel grids with more than 16384 cells (radius 1 m over a 250 m scan) and downsample factors != 1 (several voxels
+    per radius) are handed from the fast pipeline to the single-kernel path: same cells as the oracle."""
+    from oracle import pyoracle as O
+    from tbv_slam_public_amd import api, synth
+    imgs, _, _ = synth.scene_v1(8, 1)
+    sr, si, sc = O.kstrongest(imgs[0], 40, 60)
+    cloud = O.kstrongest_cloud(sr, si, sc, 0.0438, 2.5)
+    for radius, factor in ((1.0, 1.0), (3.0, 2.0), (2.0, 1.5)):
+        exp = O.surface_points(cloud, radius, factor, (0, 0), True)
+        old = api.MapPointNormal.downsample_factor
+        api.MapPointNormal.downsample_factor = factor
+        try:
+            got = api.MapPointNormal(cloud, radius, (0, 0), True).GetCells()
+        finally:
+            api.MapPointNormal.downsample_factor = old
+        assert exp.shape[0] > 50
+        _cmp_cells(got, exp)
 
 
 def test_get_closest_idx_matches_oracle():
