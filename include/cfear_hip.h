@@ -510,6 +510,18 @@ enum cfear_preset { CFEAR_PRESET_CFEAR1 = 1, CFEAR_PRESET_CFEAR2 = 2, CFEAR_PRES
 enum cfear_dataset { CFEAR_DATASET_OXFORD = 0, CFEAR_DATASET_MULRAN = 1, CFEAR_DATASET_KVARNTORP = 2, CFEAR_DATASET_VOLVO = 3 };
 int cfear_odometry_params_preset(cfear_odometry_params* p, int preset, int dataset);
 
+/* The two per-frame decisions of OdometryKeyframeFuser as pure host functions (no context, no GPU), used by the batched
+ * pipeline below and callable on their own:
+ *   cfear_keyframe_based_fuse    KeyFrameBasedFuse (odometrykeyframefuser.cpp:62-73): diff = T_keyframe^-1 * Tcurrent as
+ *                                (x, y, theta); 1 = add a keyframe (translation norm > min_keyframe_dist or |rotation| >
+ *                                min_keyframe_rot_deg, both strict; always 1 without use_keyframe)
+ *   cfear_acc_vel_sanity_check   AccelerationVelocitySanityCheck (:76-94): translations of the previous and the current
+ *                                motion; 0 = acceleration > 200 m/s^2 or speed > 200 m/s at 4 Hz -> the caller keeps
+ *                                its guess (:198-199)                                                              */
+int cfear_keyframe_based_fuse(const double diff_xyt[3], int32_t use_keyframe, double min_keyframe_dist,
+                              double min_keyframe_rot_deg);
+int cfear_acc_vel_sanity_check(const double tmot_prev_xy[2], const double tmot_curr_xy[2]);
+
 typedef struct cfear_odometry cfear_odometry;
 typedef struct cfear_frame_info {
   double pose[3];                       /* Tcurrent (x,y,theta) */

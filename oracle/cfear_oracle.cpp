@@ -659,7 +659,7 @@ double evaluate(const std::vector<Assoc>& blocks, const orc_reg_params& par, con
   return cost;
 }
 
-struct IterSummary { double cost; double relative_decrease; bool successful; };
+struct IterSummary { double cost; double relative_decrease; bool successful; double radius = 0.0; };
 struct SolveSummary {
   std::vector<IterSummary> iterations;
   double initial_cost = 0, final_cost = 0;
@@ -728,6 +728,7 @@ void lm_solve(const std::vector<Assoc>& blocks, const orc_reg_params& par, doubl
 
   for (;;) {
     // ---- FinalizeIterationAndCheckIfMinimizerCanContinue
+    it.radius = radius;                         // iteration_summary_.trust_region_radius = strategy_->Radius()
     sum.iterations.push_back(it);
     if (iteration >= max_iter) break;                                       // NO_CONVERGENCE
     if (it.successful && gradient_max_norm <= gradient_tolerance) break;    // CONVERGENCE
@@ -887,6 +888,30 @@ extern "C" int orc_associate(const orc_cell* const* scans, const int32_t* n_cell
     weights[i] = blocks[i].weight;
   }
   return (int)blocks.size();
+}
+
+// Test hook: one ceres::Solve (lm_solve) on the association set built at `poses` with iteration counter `itr`,
+// started from the last pose; returns the per-iteration records (cost, relative_decrease, step_is_successful,
+// trust_region_radius) so that an independent restatement can be compared iterate by iterate.
+extern "C" int orc_lm_trace(const orc_cell* const* scans, const int32_t* n_cells, int n_scans, const double* poses_xyt,
+                            const orc_reg_params* par, int itr, int max_iter, double x_out[3], double* trace, int cap,
+                            double* final_cost, int32_t* usable) {
+  std::vector<Assoc> blocks;
+  build_problem(scans, n_cells, n_scans, poses_xyt, itr, *par, blocks);
+  double x[3] = {poses_xyt[3 * (n_scans - 1)], poses_xyt[3 * (n_scans - 1) + 1], poses_xyt[3 * (n_scans - 1) + 2]};
+  SolveSummary sum;
+  lm_solve(blocks, *par, x, max_iter, sum);
+  x_out[0] = x[0]; x_out[1] = x[1]; x_out[2] = x[2];
+  *final_cost = sum.final_cost;
+  *usable = sum.usable ? 1 : 0;
+  const int n = (int)sum.iterations.size();
+  for (int i = 0; i < n && i < cap; i++) {
+    trace[4 * i] = sum.iterations[i].cost;
+    trace[4 * i + 1] = sum.iterations[i].relative_decrease;
+    trace[4 * i + 2] = sum.iterations[i].successful ? 1.0 : 0.0;
+    trace[4 * i + 3] = sum.iterations[i].radius;
+  }
+  return n;
 }
 
 // n_scan_normal.cpp:186-211 GetCost

@@ -105,6 +105,13 @@ int orc_normal_eq(const orc_cell* const* scans, const int32_t* n_cells, int n_sc
                   const double* poses_xyt, const orc_reg_params* par, int itr, const double x[3],
                   double H[9], double g[3], double* cost, int32_t* n_res);
 
+/* Test hook: one ceres::Solve on the association set built at `poses` (iteration counter `itr`), from the last pose;
+ * trace[i] = {cost, relative_decrease, step_is_successful, trust_region_radius} of summary.iterations[i].  Returns the
+ * number of iterations recorded in the summary.                                                                   */
+int orc_lm_trace(const orc_cell* const* scans, const int32_t* n_cells, int n_scans, const double* poses_xyt,
+                 const orc_reg_params* par, int itr, int max_iter, double x_out[3], double* trace, int cap,
+                 double* final_cost, int32_t* usable);
+
 /* Covariance by cost sampling (odometrykeyframefuser.cpp:261-380, loopclosure.cpp:99-208): n^3
  * GetCost samples around the registered pose, quadratic least-squares fit, 2 H^-1 scaled by
  * GetCovarianceScaler.  par->first_itr = leftover itr_; final_cost / num_residuals from the

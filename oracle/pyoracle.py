@@ -112,6 +112,8 @@ def lib():
         L.orc_associate.argtypes = [pp, i32p, C.c_int, f64p, C.POINTER(OrcRegParams), C.c_int, i32p, f64p, C.c_int]
         L.orc_normal_eq.argtypes = [pp, i32p, C.c_int, f64p, C.POINTER(OrcRegParams), C.c_int, f64p,
                                     f64p, f64p, f64p, i32p]
+        L.orc_lm_trace.argtypes = [pp, i32p, C.c_int, f64p, C.POINTER(OrcRegParams), C.c_int, C.c_int, f64p, f64p, C.c_int,
+                                   f64p, i32p]
         L.orc_fuser_create.argtypes = [C.POINTER(OrcFuserParams)]
         L.orc_fuser_create.restype = C.c_void_p
         L.orc_fuser_destroy.argtypes = [C.c_void_p]
@@ -385,6 +387,20 @@ def associate(scans, poses, par, itr):
                             _p(pairs, C.c_int32), _p(w, C.c_double), cap)
     assert m >= 0
     return pairs[:m].copy(), w[:m].copy()
+
+
+def lm_trace(scans, poses, par, itr, max_iter):
+    """One ceres::Solve of the oracle on the associations built at `poses` -> (x, trace [n, 4] = cost,
+    relative_decrease, successful, radius per summary iteration, final_cost, usable)."""
+    keep, ptrs, ns = _scan_args(scans)
+    poses = np.ascontiguousarray(poses, np.float64)
+    x = np.zeros(3)
+    trace = np.zeros((max_iter + 8, 4))
+    fc = C.c_double()
+    us = C.c_int32()
+    n = lib().orc_lm_trace(ptrs, _p(ns, C.c_int32), len(keep), _p(poses, C.c_double), C.byref(par), int(itr), int(max_iter),
+                           _p(x, C.c_double), _p(trace, C.c_double), trace.shape[0], C.byref(fc), C.byref(us))
+    return x, trace[:n].copy(), fc.value, bool(us.value)
 
 
 def normal_eq(scans, poses, par, itr, x):

@@ -46,6 +46,32 @@ void aff_to_xyt(const Aff2& a, double p[3]) {            // utils.cpp:115-122 Af
   p[0] = a.t[0]; p[1] = a.t[1]; p[2] = std::atan2(a.l[2], a.l[3]);
 }
 
+}  // namespace
+
+// ---- frame policy as pure host functions (no GPU, no context): the two decisions OdometryKeyframeFuser takes per frame ----
+// KeyFrameBasedFuse (odometrykeyframefuser.cpp:62-73): diff = T_keyframe^-1 * Tcurrent as (x, y, theta).  For a planar
+// pose Matrix3d::eulerAngles(0,1,2) is (0, 0, theta), so its norm is |theta|.
+extern "C" int cfear_keyframe_based_fuse(const double diff_xyt[3], int32_t use_keyframe, double min_keyframe_dist,
+                                         double min_keyframe_rot_deg) {
+  if (!use_keyframe) return 1;
+  const double tn = std::sqrt(diff_xyt[0] * diff_xyt[0] + diff_xyt[1] * diff_xyt[1]);
+  const double rot = std::fabs(diff_xyt[2]);
+  return (tn > min_keyframe_dist || rot > (min_keyframe_rot_deg * M_PI / 180.0)) ? 1 : 0;
+}
+// AccelerationVelocitySanityCheck (odometrykeyframefuser.cpp:76-94): 4 Hz, 200 m/s and 200 m/s^2, strict comparisons,
+// acceleration tested first; only the translations of the two motions enter.  1 = sane, 0 = use the guess (:198-199).
+extern "C" int cfear_acc_vel_sanity_check(const double tmot_prev_xy[2], const double tmot_curr_xy[2]) {
+  const double dt = 0.25, vel_limit = 200, acc_limit = 200;
+  const double vel = std::sqrt((tmot_curr_xy[0] / dt) * (tmot_curr_xy[0] / dt) + (tmot_curr_xy[1] / dt) * (tmot_curr_xy[1] / dt));
+  const double ax = (tmot_curr_xy[0] - tmot_prev_xy[0]) / (dt * dt), ay = (tmot_curr_xy[1] - tmot_prev_xy[1]) / (dt * dt);
+  const double acc = std::sqrt(ax * ax + ay * ay);
+  if (acc > acc_limit) return 0;
+  else if (vel > vel_limit) return 0;
+  return 1;
+}
+
+namespace {
+
 struct Keyframe { int slab; Aff2 pose; };
 struct Stream {
   Aff2 T_prev = aff_identity(), Tmot = aff_identity(), Tcurrent = aff_identity();
@@ -621,20 +647,13 @@ static int process_frame(cfear_odometry* od, const uint8_t* polar, const uint8_t
     Aff2 Tcurrent = aff_from_xyt(rr.pose[0], rr.pose[1], rr.pose[2]);
     {                                                             // AccelerationVelocitySanityCheck :76-94
       const Aff2 Tmot_current = aff_mul(aff_inv(st.T_prev), Tcurrent);
-      const double dt = 0.25, vel_limit = 200, acc_limit = 200;
-      const double vel = std::sqrt((Tmot_current.t[0] / dt) * (Tmot_current.t[0] / dt) + (Tmot_current.t[1] / dt) * (Tmot_current.t[1] / dt));
-      const double ax = (Tmot_current.t[0] - st.Tmot.t[0]) / (dt * dt), ay = (Tmot_current.t[1] - st.Tmot.t[1]) / (dt * dt);
-      const double acc = std::sqrt(ax * ax + ay * ay);
-      if (acc > acc_limit || vel > vel_limit) Tcurrent = st.Tguess;           // :198-199
+      if (!cfear_acc_vel_sanity_check(st.Tmot.t, Tmot_current.t)) Tcurrent = st.Tguess;   // :198-199
     }
     st.Tmot = aff_mul(aff_inv(st.T_prev), Tcurrent);              // :200
     const Aff2 Tkeydiff = aff_mul(aff_inv(st.keyframes.back().pose), Tcurrent);
-    bool fuse = true;                                             // KeyFrameBasedFuse :62-73
-    if (par.use_keyframe) {
-      const double tn = std::sqrt(Tkeydiff.t[0] * Tkeydiff.t[0] + Tkeydiff.t[1] * Tkeydiff.t[1]);
-      const double rot = std::fabs(std::atan2(Tkeydiff.l[2], Tkeydiff.l[3]));
-      fuse = tn > par.min_keyframe_dist || rot > (par.min_keyframe_rot_deg * M_PI / 180.0);
-    }
+    double kd[3];
+    aff_to_xyt(Tkeydiff, kd);
+    const bool fuse = cfear_keyframe_based_fuse(kd, par.use_keyframe, par.min_keyframe_dist, par.min_keyframe_rot_deg) != 0;   // :62-73
     if (fuse) {                                                   // :236-250, AddToReference :470-476
       st.keyframes.push_back(Keyframe{st.cur_slab, Tcurrent});
       if ((int)st.keyframes.size() > par.submap_scan_size) {

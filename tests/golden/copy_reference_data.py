@@ -9,6 +9,9 @@
   loop_rows      its 4390 training rows "y,odom-bounds,sc-sim,alignment_quality" (tbv_model_8.txt, SaveData :152-173)
   combined_head  the first 1300 rows (100 keyframe pairs x 13 perturbations) of combined.txt:
                  "y,joint,sep,overlap,cost,#residuals,mean #cells" -- real CorAl / GetCost outputs
+  combined_aligned_quantiles   [1, 5, 25, 50, 75, 95, 99] % quantiles of {cost, #residuals, mean #cells} over ALL aligned
+                 rows (label 1; 4 467 of the 58 071) of combined.txt, and combined_misaligned_quantiles of {cost, #residuals}
+                 over the perturbed rows: the distribution gate of tests/test_oracle_pinning.py
   sha256_*       digest of each source file's bytes (of the first 1300 lines for combined.txt): the tests re-create
                  the text with the mirror's SaveData / SaveCoefficients and compare digests, which pins the two text
                  formats byte for byte without keeping the files
@@ -42,5 +45,11 @@ if __name__ == "__main__":
         # the numbers survive the reference's own text format: "%g" of every value reproduces the file
         again = "".join(",".join("%g" % v for v in row) + "\n" for row in a)
         assert again == text, name
+    full = _rows(open(os.path.join(SRC, "combined.txt")).read())
+    q = [1, 5, 25, 50, 75, 95, 99]
+    al, mis = full[full[:, 0] == 1], full[full[:, 0] == 0]
+    out["combined_aligned_quantiles"] = np.stack([np.percentile(al[:, c], q) for c in (4, 5, 6)])
+    out["combined_misaligned_quantiles"] = np.stack([np.percentile(mis[:, c], q) for c in (4, 5)])
+    out["combined_rows"] = np.array([full.shape[0], al.shape[0]])
     np.savez_compressed(DST, **out)
     print("wrote", DST, {k: getattr(v, "shape", None) for k, v in out.items()})
