@@ -460,7 +460,7 @@ def test_synthetic_quality_triples_look_like_the_real_ones():
     AlignmentQuality.cpp:345-347.  Quantiles [1, 5, 25, 50, 75, 95, 99] of the ALIGNED rows are kept in
     tests/golden/model_parameters.npz.  60 synthetic consecutive frames at the oracle's own odometry poses must look
     alike: cell and correspondence counts inside the real 5-95 % band (medians inside the inter-quartile range), the cost
-    never above the real 95th percentile.  Synthetic walls are cleaner than Oxford's, so the cost sits LOWER than the real
+    never above the real 99th percentile and at most 5 % of it above the 95th.  Synthetic walls are cleaner than Oxford's, so the cost sits LOWER than the real
     one (median 2.6 vs 5.3) -- the gate states that instead of hiding it."""
     from tbv_slam_public_amd import synth
     g = np.load(os.path.join(GOLD, "model_parameters.npz"))
@@ -489,7 +489,7 @@ def test_synthetic_quality_triples_look_like_the_real_ones():
         inside = ((vals >= band[1]) & (vals <= band[5])).mean()
         assert inside >= 0.9, (inside, np.percentile(vals, [5, 50, 95]), band)
         assert band[2] <= np.median(vals) <= band[4]
-    assert (cost <= qs[0][5]).all() and (cost >= 0.5 * qs[0][0]).all()
+    assert (cost <= qs[0][6]).all() and (cost <= qs[0][5]).mean() >= 0.95 and (cost >= 0.5 * qs[0][0]).all()
     assert qs[0][1] <= np.median(cost) <= qs[0][3]                 # between the real 5th percentile and the real median
     # correspondences per cell: the real ratio #residuals / #cells is 0.50-0.71 (5-95 %)
     ratio = nres / ncell
