@@ -128,6 +128,18 @@ typedef struct cfear_kstrong_out {
 int cfear_filter_kstrongest(cfear_ctx* ctx, const uint8_t* polar, const cfear_polar_desc* desc,
                             const cfear_kstrong_params* par, const cfear_kstrong_out* out);
 
+/* Legacy filter: replaces k_strongest_filter / InsertStrongestK (radar_filters.cpp:25-78), which CorAl's standalone
+ * kstrongRadar scan type still calls (coral_alignment_quality/src/alignment_checker/ScanType.cpp:104-114); TBV itself uses
+ * the structured filter above.  Different rule: the first bin >= z_min of a row sets a floor, later bins
+ * <= the running minimum are rejected even while fewer than k are held, ties at the cut keep the SMALLER ranges, points
+ * sit at bin EDGES (range_res * bin) with a float azimuth, and the near cut is x^2 + y^2 > min_distance^2.  z_min,
+ * range_res, min_distance are doubles as in the reference's signature.  xyzi float [batch][cap_points][4] (rows ascending,
+ * within a row descending intensity, ascending range on ties -- the order of a stable sort; libstdc++'s std::sort is stable
+ * up to 16 elements, i.e. k <= 15), n_points int32 [batch]; all three buffers host or all device.               */
+int cfear_filter_kstrongest_legacy(cfear_ctx* ctx, const uint8_t* polar, const cfear_polar_desc* desc, int32_t k_strongest,
+                                   double z_min, double range_res, double min_distance, float* xyzi, int32_t* n_points,
+                                   int32_t cap_points);
+
 typedef struct cfear_cacfar_params {    /* AzimuthCACFAR ctor, cfar.cpp:28-33; radar_driver.cpp:54 */
   int32_t window_size;                  /* cells per side */
   int32_t nb_guard_cells;

@@ -218,6 +218,48 @@ extern "C" int orc_kstrongest_cloud(int rows, int k, const int32_t* sel_range,
 }
 
 // ==========================================================================================
+// F: legacy k_strongest_filter / InsertStrongestK (radar_filters.cpp:25-78), used by CorAl's standalone kstrongRadar
+// (coral_alignment_quality/src/alignment_checker/ScanType.cpp:104-114), not by TBV.  Literal restatement: the sorted
+// vector, the "<= current minimum -> reject, even when not full" rule, sort by intensity only.  std::sort on <= 16
+// elements is libstdc++'s insertion sort, i.e. stable -- equal intensities stay in insertion (= ascending range) order;
+// for k >= 16 libstdc++ switches to introsort and the reference's tie order becomes implementation-defined (the kept
+// intensities are the same); this restatement stays stable for every k.  theta is a FLOAT and cos / sin are the float
+// overloads (ros/duration.h pulls <math.h> into the reference's translation unit): x = float(range_res * i * cosf(theta)).
+// ==========================================================================================
+extern "C" int orc_kstrongest_legacy(const uint8_t* img, int rows, int cols, int stride, int k_strongest, double z_min,
+                                     double range_res, double min_distance, float* xyzi, int cap) {
+  struct P { float x, y, intensity; };
+  const double min_distance_sqrd = min_distance * min_distance;
+  int n = 0;
+  for (int bearing = 0; bearing < rows; bearing++) {
+    const float theta = ((float)(bearing + 1) / rows) * 2 * M_PI;            // :52 (float)
+    std::vector<P> pnts_sorted;
+    for (int i = 0; i < cols; i++) {
+      const uint8_t v = img[(size_t)bearing * stride + i];
+      if (v < z_min) continue;                                               // :58 uchar < double
+      P p;
+      p.x = (float)(range_res * i * std::cos(theta));                        // :62-63, std::cos(float)
+      p.y = (float)(range_res * i * std::sin(theta));
+      p.intensity = (float)v;
+      // InsertStrongestK :25-38
+      if (pnts_sorted.empty()) { pnts_sorted.push_back(p); continue; }
+      if (p.intensity <= pnts_sorted.back().intensity) continue;
+      pnts_sorted.push_back(p);
+      std::stable_sort(pnts_sorted.begin(), pnts_sorted.end(), [](const P& a, const P& b) { return a.intensity > b.intensity; });
+      if ((int)pnts_sorted.size() > k_strongest) pnts_sorted.pop_back();
+    }
+    for (const P& p : pnts_sorted) {
+      if ((double)(p.x * p.x + p.y * p.y) > min_distance_sqrd) {             // :71 float arithmetic, compared as double
+        if (n >= cap) return -1;
+        xyzi[4 * n] = p.x; xyzi[4 * n + 1] = p.y; xyzi[4 * n + 2] = 0.f; xyzi[4 * n + 3] = p.intensity;
+        n++;
+      }
+    }
+  }
+  return n;
+}
+
+// ==========================================================================================
 // F: CA-CFAR  (cfar.cpp:12-83; constructed at radar_driver.cpp:54 with max_distance 400.0)
 // ==========================================================================================
 namespace {

@@ -71,6 +71,10 @@ int orc_peaks(const uint8_t* img, int rows, int cols, int stride, int k,
 int orc_kstrongest_cloud(int rows, int k, const int32_t* sel_range, const uint8_t* sel_intensity,
                          const int32_t* sel_count, const uint8_t* mask, float range_res,
                          float min_distance, float* xyzi);
+/* Legacy k_strongest_filter / InsertStrongestK (radar_filters.cpp:25-78; CorAl's kstrongRadar).  Returns the number
+ * of points written ([n][4]: x, y, 0, intensity; rows ascending, within a row descending intensity), -1 if cap is too small. */
+int orc_kstrongest_legacy(const uint8_t* img, int rows, int cols, int stride, int k_strongest, double z_min,
+                          double range_res, double min_distance, float* xyzi, int cap);
 /* cfar.cpp:12-83 + radar_driver.cpp:52-56.  Returns number of detections; det_rc nullable. */
 int orc_cacfar(const uint8_t* img, int rows, int cols, int stride, int window, int guard,
                float false_alarm_rate, float range_res, float z_min, float min_distance,

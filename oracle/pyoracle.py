@@ -88,6 +88,8 @@ def lib():
         L.orc_kstrongest_cloud.argtypes = [C.c_int, C.c_int, i32p, u8p, i32p, u8p, C.c_float, C.c_float, f32p]
         L.orc_cacfar.argtypes = [u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float,
                                  C.c_float, C.c_float, C.c_double, f32p, i32p, C.c_int]
+        L.orc_kstrongest_legacy.argtypes = [u8p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double,
+                                            f32p, C.c_int]
         L.orc_compensate.argtypes = [f32p, C.c_int, f64p, C.c_int]
         L.orc_compensate.restype = None
         L.orc_surface_points.argtypes = [f32p, C.c_int, C.c_float, C.c_double, f64p, C.c_int,
@@ -157,6 +159,17 @@ def kstrongest_cloud(sel_range, sel_intensity, sel_count, range_res, min_distanc
     n = lib().orc_kstrongest_cloud(rows, k, _p(sel_range, C.c_int32), _p(sel_intensity, C.c_uint8),
                                    _p(sel_count, C.c_int32), m, np.float32(range_res),
                                    np.float32(min_distance), _p(out, C.c_float))
+    return out[:n].copy()
+
+
+def kstrongest_legacy(img, k, z_min, range_res, min_distance):
+    """k_strongest_filter (radar_filters.cpp:40-78) -> float32 [n, 4]."""
+    img = np.ascontiguousarray(img, np.uint8)
+    rows, cols = img.shape
+    out = np.empty((rows * max(k, 1), 4), np.float32)
+    n = lib().orc_kstrongest_legacy(_p(img, C.c_uint8), rows, cols, cols, int(k), float(z_min), float(range_res),
+                                    float(min_distance), _p(out, C.c_float), out.shape[0])
+    assert n >= 0
     return out[:n].copy()
 
 

@@ -205,7 +205,7 @@ EXPORTS = [
     "cfear_odometry_process_prefetch", "cfear_odometry_get_covariance", "cfear_odometry_destroy",
     "cfear_odometry_get_scan", "cfear_odometry_get_cloud", "cfear_odometry_get_peaks", "cfear_odometry_process_clouds",
     "cfear_odometry_process_offsets", "cfear_odometry_discard_prefetch",
-    "cfear_keyframe_based_fuse", "cfear_acc_vel_sanity_check",
+    "cfear_keyframe_based_fuse", "cfear_acc_vel_sanity_check", "cfear_filter_kstrongest_legacy",
 ]
 
 _LIB = None
@@ -309,6 +309,8 @@ def lib():
     L.cfear_odometry_process_prefetch.argtypes = [vp, vp, vp, vp]
     L.cfear_odometry_process_offsets.argtypes = [vp, vp, vp, vp, vp]
     L.cfear_odometry_discard_prefetch.argtypes = [vp]
+    L.cfear_filter_kstrongest_legacy.argtypes = [vp, vp, C.POINTER(PolarDesc), C.c_int32, C.c_double, C.c_double, C.c_double, vp, vp,
+                                                 C.c_int32]
     L.cfear_keyframe_based_fuse.argtypes = [C.POINTER(C.c_double), C.c_int32, C.c_double, C.c_double]
     L.cfear_acc_vel_sanity_check.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_double)]
     L.cfear_odometry_get_covariance.argtypes = [vp, vp, vp]

@@ -202,6 +202,25 @@ def filter_cacfar(img, window_size, nb_guard_cells, false_alarm_rate, range_res,
     return res
 
 
+def k_strongest_filter(img, k_strongest, z_min, range_res, min_distance, ctx=None):
+    """The legacy k_strongest_filter / InsertStrongestK (radar_filters.cpp:25-78; CorAl's kstrongRadar).  img: uint8
+    [rows, cols] or [batch, rows, cols] (NumPy or torch CUDA).  Returns dict(xyzi [batch, rows * k, 4], n_points)."""
+    ctx = ctx or default_context()
+    d, batch, rows, cols = _desc(img)
+    cap = rows * int(k_strongest)
+    if _is_torch(img):
+        import torch
+        xyzi = torch.empty((batch, cap, 4), dtype=torch.float32, device=img.device)
+        npts = torch.empty((batch,), dtype=torch.int32, device=img.device)
+    else:
+        img = np.ascontiguousarray(img, dtype=np.uint8)
+        xyzi = np.empty((batch, cap, 4), np.float32)
+        npts = np.empty((batch,), np.int32)
+    ctx.check(ctx._lib.cfear_filter_kstrongest_legacy(ctx.h, _ptr(img)[0], C.byref(d), int(k_strongest), float(z_min), float(range_res),
+                                                      float(min_distance), _ptr(xyzi)[0], _ptr(npts)[0], cap))
+    return dict(xyzi=xyzi, n_points=npts)
+
+
 class radarDriver:
     """radarDriver (radar_driver.cpp): CallbackOffline(image) -> (cloud, cloud_peaks)."""
 

@@ -788,6 +788,107 @@ __global__ __launch_bounds__(256) void cacfar_cloud_kernel(const CfarCloudArgs a
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Legacy k_strongest_filter / InsertStrongestK (radar_filters.cpp:25-78; CorAl's standalone kstrongRadar,
+// coral_alignment_quality/src/alignment_checker/ScanType.cpp:104-114).  Different rule than StructuredKStrongest
+// (SURVEY App. C): the first bin f with intensity >= z_min sets a floor m0 -- later bins <= the list's minimum are
+// rejected even while the list is not full -- and ties at the cut keep the SMALLER ranges.  In closed form: with D = the
+// bins after f with intensity > m0, the row keeps the k largest of D under (intensity, -range), plus f iff |D| < k,
+// in descending intensity / ascending range order.  "k largest under (intensity, -range)" is StructuredKStrongest on the
+// REVERSED row, so the tuned sweep does the selection: a prepare pass writes the row reversed with everything outside D
+// zeroed, the sweep runs with z_min = 1, and a post pass undoes the reversal, appends f and converts to PointXYZI.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void legacy_prepare_kernel(const uint8_t* __restrict__ polar, int rows, int cols, int stride,
+                                                             long long batch_stride, int u_z, uint8_t* __restrict__ rev,
+                                                             int rev_stride, int32_t* __restrict__ first /*[batch][rows][2]*/) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const long long grow = (long long)blockIdx.x * 4 + wave;
+  const int b = blockIdx.y;
+  if (grow >= rows) return;
+  const int r = (int)grow;
+  const uint8_t* rowp = polar + (long long)b * batch_stride + (long long)r * stride;
+  int fpos = 0x7fffffff;                                   // first bin with intensity >= z_min
+  for (int i0 = 0; i0 < cols && fpos == 0x7fffffff; i0 += 64) {
+    const int i = i0 + lane;
+    const bool c = i < cols && (int)rowp[i] >= u_z;
+    const unsigned long long bal = __ballot(c);
+    if (bal) fpos = i0 + __ffsll((long long)bal) - 1;
+  }
+  const int m0 = fpos < cols ? (int)rowp[fpos] : 255;
+  uint8_t* out = rev + ((long long)b * rows + r) * rev_stride;
+  for (int i = lane; i < cols; i += 64) {
+    const int v = rowp[i];
+    out[cols - 1 - i] = (i > fpos && v > m0) ? (uint8_t)v : (uint8_t)0;
+  }
+  if (lane == 0) { first[((long long)b * rows + r) * 2] = fpos < cols ? fpos : -1; first[((long long)b * rows + r) * 2 + 1] = m0; }
+}
+
+// one workgroup per image: per-row output counts -> offsets -> points
+__global__ __launch_bounds__(256) void legacy_cloud_kernel(const int32_t* __restrict__ sel_range, const uint8_t* __restrict__ sel_int,
+                                                           const int32_t* __restrict__ sel_count, const int32_t* __restrict__ first,
+                                                           const float* __restrict__ cosf_t, const float* __restrict__ sinf_t,
+                                                           int rows, int cols, int k, double range_res, double min_d2,
+                                                           float* __restrict__ xyzi, int32_t* __restrict__ n_points, int cap) {
+  extern __shared__ int32_t row_off[];                    // [rows + 1]
+  __shared__ int32_t wave_tot[4];
+  __shared__ int32_t run_base;
+  const int b = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  auto point = [&](int r, int j, int cnt, float4& p) -> bool {    // j-th entry of row r in the reference's list order
+    int bin, inten;
+    if (j < cnt) {                                         // descending: the sweep's list reversed; undo the row reversal
+      const long long e = ((long long)b * rows + r) * k + (cnt - 1 - j);
+      bin = cols - 1 - sel_range[e];
+      inten = sel_int[e];
+    } else {                                               // f, the floor-setting first bin (only while |D| < k)
+      bin = first[((long long)b * rows + r) * 2];
+      inten = first[((long long)b * rows + r) * 2 + 1];
+    }
+    p.x = (float)(range_res * bin * cosf_t[r]);            // :62-63
+    p.y = (float)(range_res * bin * sinf_t[r]);
+    p.z = 0.f;
+    p.w = (float)inten;
+    return (double)(p.x * p.x + p.y * p.y) > min_d2;       // :71
+  };
+  auto row_entries = [&](int r) {
+    const int cnt = sel_count[(long long)b * rows + r];
+    const bool has_f = first[((long long)b * rows + r) * 2] >= 0 && cnt < k;
+    return cnt + (has_f ? 1 : 0);
+  };
+  if (threadIdx.x == 0) run_base = 0;
+  __syncthreads();
+  for (int r0 = 0; r0 < rows; r0 += 256) {
+    const int r = r0 + threadIdx.x;
+    int v = 0;
+    if (r < rows) {
+      const int cnt = sel_count[(long long)b * rows + r], ne = row_entries(r);
+      float4 p;
+      for (int j = 0; j < ne; j++) v += point(r, j, cnt, p) ? 1 : 0;
+    }
+    const int incl = wave_incl_scan_i32(v);
+    if (lane == 63) wave_tot[wave] = incl;
+    __syncthreads();
+    int off = run_base;
+    for (int wv = 0; wv < wave; wv++) off += wave_tot[wv];
+    if (r < rows) row_off[r] = off + incl - v;
+    __syncthreads();
+    if (threadIdx.x == 0) run_base += wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) n_points[b] = run_base;
+  for (int r = threadIdx.x; r < rows; r += 256) {
+    const int cnt = sel_count[(long long)b * rows + r], ne = row_entries(r);
+    int o = row_off[r];
+    for (int j = 0; j < ne; j++) {
+      float4 p;
+      if (point(r, j, cnt, p)) {
+        if (o < cap) ((float4*)xyzi)[(long long)b * cap + o] = p;
+        o++;
+      }
+    }
+  }
+}
+
 // ---- host helpers --------------------------------------------------------------------------------
 }  // namespace
 // cos / sin of the azimuths (radar_filters.cpp:317), computed on the host in double so that the device's float
@@ -990,6 +1091,85 @@ extern "C" int cfear_filter_kstrongest(cfear_ctx* ctx, const uint8_t* polar, con
     if (d.xyzi_peaks) CFEAR_HIP_CHECK(ctx, back(out->xyzi_peaks, d.xyzi_peaks, nsel * 16));
     if (d.n_peaks) CFEAR_HIP_CHECK(ctx, back(out->n_peaks, d.n_peaks, (size_t)batch * 4));
     CFEAR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  }
+  return CFEAR_OK;
+}
+
+
+extern "C" int cfear_filter_kstrongest_legacy(cfear_ctx* ctx, const uint8_t* polar, const cfear_polar_desc* desc, int32_t k_strongest,
+                                              double z_min, double range_res, double min_distance, float* xyzi, int32_t* n_points,
+                                              int32_t cap_points) {
+  if (!ctx) return CFEAR_ERR_INVALID_ARGUMENT;
+  if (!polar || !xyzi || !n_points || cap_points <= 0) return cfear_set_error(ctx, CFEAR_ERR_INVALID_ARGUMENT, "null argument");
+  int rc = check_desc(ctx, desc);
+  if (rc != CFEAR_OK) return rc;
+  if (k_strongest < 1 || k_strongest > kMaxK) return cfear_set_error(ctx, CFEAR_ERR_INVALID_ARGUMENT, "k_strongest must be in [1,%d]", kMaxK);
+  if (!(range_res > 0.0)) return cfear_set_error(ctx, CFEAR_ERR_INVALID_ARGUMENT, "range_res must be > 0");
+  CFEAR_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  const int rows = desc->rows, cols = desc->cols, batch = desc->batch, k = k_strongest;
+  const bool dev = cfear_is_device_ptr(polar);
+  if (dev != cfear_is_device_ptr(xyzi) || dev != cfear_is_device_ptr(n_points))
+    return cfear_set_error(ctx, CFEAR_ERR_INVALID_ARGUMENT, "polar, xyzi and n_points must all be host or all be device memory");
+  const size_t img_bytes = (size_t)rows * desc->stride;
+  const uint8_t* d_polar = polar;
+  long long bs = batch > 1 ? desc->batch_stride : (long long)img_bytes;
+  if (!dev) {
+    uint8_t* st = (uint8_t*)cfear_workspace(ctx, 0, img_bytes * batch);
+    if (!st) return cfear_set_error(ctx, CFEAR_ERR_HIP, "workspace allocation failed");
+    for (int b = 0; b < batch; b++)
+      CFEAR_HIP_CHECK(ctx, hipMemcpyAsync(st + (size_t)b * img_bytes, polar + (size_t)b * bs, img_bytes, hipMemcpyHostToDevice, ctx->stream));
+    d_polar = st;
+    bs = (long long)img_bytes;
+  }
+  // workspace: reversed masked images | first-bin records | sel arrays | float trig tables | (host mode) cloud
+  const int rev_stride = (cols + 15) / 16 * 16;
+  const size_t nsel = (size_t)batch * rows * k;
+  size_t off = 0;
+  auto carve = [&](size_t bytes) { size_t o = off; off += (bytes + 255) / 256 * 256; return o; };
+  const size_t o_rev = carve((size_t)batch * rows * rev_stride), o_first = carve((size_t)batch * rows * 8);
+  const size_t o_sr = carve(nsel * 4), o_si = carve(nsel), o_sc = carve((size_t)batch * rows * 4), o_trig = carve((size_t)rows * 8);
+  const size_t o_xyz = carve(dev ? 0 : (size_t)batch * cap_points * 16), o_np = carve((size_t)batch * 4);
+  char* ws = (char*)cfear_workspace(ctx, 1, off);
+  if (!ws) return cfear_set_error(ctx, CFEAR_ERR_HIP, "workspace allocation failed (%zu bytes)", off);
+  {
+    std::vector<float> h(2 * (size_t)rows);                // host cosf / sinf of the FLOAT theta: bit-exact with glibc
+    for (int bearing = 0; bearing < rows; bearing++) {
+      const float theta = ((float)(bearing + 1) / rows) * 2 * M_PI;            // radar_filters.cpp:52
+      h[bearing] = std::cos(theta);
+      h[rows + bearing] = std::sin(theta);
+    }
+    CFEAR_HIP_CHECK(ctx, hipMemcpyAsync(ws + o_trig, h.data(), h.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+    CFEAR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  }
+  int u_z = (int)std::ceil(z_min);                         // uchar v < z_min  <=>  v < ceil(z_min)
+  u_z = std::max(0, std::min(256, u_z));
+  {
+    ProfScope ps(ctx, "kstrong_legacy_prepare");
+    hipLaunchKernelGGL(legacy_prepare_kernel, dim3((rows + 3) / 4, batch), dim3(256), 0, ctx->stream, d_polar, rows, cols, desc->stride, bs,
+                       u_z, (uint8_t*)(ws + o_rev), rev_stride, (int32_t*)(ws + o_first));
+  }
+  CFEAR_HIP_CHECK(ctx, hipGetLastError());
+  cfear_polar_desc rd{rows, cols, rev_stride, batch, (int64_t)rows * rev_stride};
+  cfear_kstrong_params kp{k, 1.0f, 1.0f, 0.0f, 0};
+  cfear_kstrong_out o{};
+  o.sel_range = (int32_t*)(ws + o_sr); o.sel_intensity = (uint8_t*)(ws + o_si); o.sel_count = (int32_t*)(ws + o_sc);
+  rc = cfear_kstrong_device(ctx, (const uint8_t*)(ws + o_rev), &rd, &kp, &o);
+  if (rc != CFEAR_OK) return rc;
+  float* d_xyzi = dev ? xyzi : (float*)(ws + o_xyz);
+  int32_t* d_np = dev ? n_points : (int32_t*)(ws + o_np);
+  {
+    ProfScope ps(ctx, "kstrong_legacy_cloud");
+    hipLaunchKernelGGL(legacy_cloud_kernel, dim3(batch), dim3(256), (size_t)(rows + 1) * 4, ctx->stream, o.sel_range, o.sel_intensity,
+                       o.sel_count, (const int32_t*)(ws + o_first), (const float*)(ws + o_trig), (const float*)(ws + o_trig) + rows, rows, cols, k,
+                       range_res, min_distance * min_distance, d_xyzi, d_np, cap_points);
+  }
+  CFEAR_HIP_CHECK(ctx, hipGetLastError());
+  if (!dev) {
+    CFEAR_HIP_CHECK(ctx, hipMemcpyAsync(n_points, d_np, (size_t)batch * 4, hipMemcpyDeviceToHost, ctx->stream));
+    CFEAR_HIP_CHECK(ctx, hipMemcpyAsync(xyzi, d_xyzi, (size_t)batch * cap_points * 16, hipMemcpyDeviceToHost, ctx->stream));
+    CFEAR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    for (int b = 0; b < batch; b++)
+      if (n_points[b] > cap_points) return cfear_set_error(ctx, CFEAR_ERR_CAPACITY, "image %d: %d points > cap_points %d", b, n_points[b], cap_points);
   }
   return CFEAR_OK;
 }

@@ -281,3 +281,37 @@ def test_kstrongest_dense_scene_vs_oracle():
     assert ((imgs >= 60).sum(2) > 40).all()             # every row is cut by the filter
     _check(imgs, 40, 60)
     _check(imgs[0], 12, 60, device=True)
+
+
+def test_legacy_k_strongest_filter_vs_oracle():
+    """a6: k_strongest_filter / InsertStrongestK (radar_filters.cpp:25-78) through cfear_filter_kstrongest_legacy -- the
+    clouds are bit-exact with the oracle's literal restatement (k <= 15: the regime where the reference's std::sort is
+    stable), on scenes, on uniform noise (ties everywhere) and on crafted rows; host and device buffers."""
+    import torch
+    from oracle import pyoracle as O
+    from tbv_slam_public_amd import api, synth
+    imgs, _, _ = synth.scene_v1(31, 2)
+    uni = synth.uniform_v1(5, rows=50, cols=1000)[0]
+    craft = np.zeros((6, 500), np.uint8)
+    craft[0, 100:200] = 90                      # plateau: only the first bin (the floor) survives
+    craft[1, 10] = 70; craft[1, 20:60] = 71     # floor + 40 ties above it
+    craft[2, :] = 255
+    craft[3, 499] = 200                         # a single candidate in the last bin
+    craft[4, 5] = 61; craft[4, 6:30] = np.arange(62, 86)
+    for img, k, z, rr, md in ((imgs, 12, 60.0, 0.0438, 2.5), (imgs[0], 5, 70.0, 0.0595238, 2.5), (uni, 12, 60.0, 0.0438, 2.5),
+                              (uni, 15, 0.0, 0.175, 1.0), (uni, 1, 250.5, 0.0438, 0.0), (craft, 12, 60.0, 0.0438, 0.5),
+                              (craft, 3, 60.0, 0.0438, 0.5)):
+        r = api.k_strongest_filter(img, k, z, rr, md)
+        batch = img if img.ndim == 3 else img[None]
+        for b in range(batch.shape[0]):
+            exp = O.kstrongest_legacy(batch[b], k, z, rr, md)
+            assert r["n_points"][b] == exp.shape[0], (k, z, b, r["n_points"][b], exp.shape)
+            np.testing.assert_array_equal(r["xyzi"][b, :exp.shape[0]], exp)
+    d = api.k_strongest_filter(torch.from_numpy(imgs).cuda(), 12, 60.0, 0.0438, 2.5)
+    torch.cuda.synchronize()
+    api.default_context().synchronize()
+    h = api.k_strongest_filter(imgs, 12, 60.0, 0.0438, 2.5)
+    np.testing.assert_array_equal(d["n_points"].cpu().numpy(), h["n_points"])
+    for b in range(2):
+        n = int(h["n_points"][b])
+        np.testing.assert_array_equal(d["xyzi"][b, :n].cpu().numpy(), h["xyzi"][b, :n])

@@ -158,3 +158,31 @@ def test_cacfar_vs_brute():
     th = (rc[:, 0].astype(np.float64) + 1) / 16 * 2.0 * np.pi
     np.testing.assert_array_equal(cloud[:, 0], (rr * rc[:, 1] * np.cos(th)).astype(np.float32))
     np.testing.assert_array_equal(cloud[:, 3], img[rc[:, 0], rc[:, 1]].astype(np.float32))
+
+
+def test_legacy_filter_closed_form():
+    """The legacy k_strongest_filter (radar_filters.cpp:25-78) restated literally in the oracle equals its closed form: with f
+    the first bin >= z_min (intensity m0) and D the later bins with intensity > m0, the row keeps the k largest of D under
+    (intensity, -range) -- ties at the cut keep the smaller ranges -- plus f iff |D| < k."""
+    rng = np.random.default_rng(3)
+    for trial in range(40):
+        cols = int(rng.integers(30, 400))
+        k = int(rng.integers(1, 16))
+        row = rng.integers(0, 256, cols).astype(np.uint8) if trial % 2 else rng.integers(50, 80, cols).astype(np.uint8)
+        z_min = float(rng.choice([0.0, 60.0, 60.5, 200.0]))
+        got = O.kstrongest_legacy(row[None], k, z_min, 0.0438, 0.0)          # min_distance 0: only bin 0 is dropped
+        cand = np.nonzero(row >= z_min)[0]
+        exp = []
+        if cand.size:
+            f = cand[0]
+            D = [i for i in cand[1:] if row[i] > row[f]]
+            D.sort(key=lambda i: (-int(row[i]), i))
+            exp = D[:k] + ([f] if len(D) < k else [])
+        exp = [i for i in exp if i > 0]
+        theta = np.float32(np.float32(1.0) / np.float32(1)) * 2 * np.pi      # rows = 1: theta = float(2 pi)
+        theta = np.float32(theta)
+        ex = np.array([[np.float32(0.0438 * i * np.cos(theta)), np.float32(0.0438 * i * np.sin(theta)), 0.0, row[i]] for i in exp],
+                      np.float32).reshape(-1, 4)
+        assert got.shape == ex.shape, (trial, got.shape, ex.shape)
+        np.testing.assert_array_equal(got[:, 3], ex[:, 3])
+        np.testing.assert_allclose(got[:, :2], ex[:, :2], rtol=1e-6, atol=1e-6)
