@@ -341,6 +341,7 @@ int cfear_odometry_params_preset(cfear_odometry_params* p, int preset, int datas
   switch (preset) {                       // launch/oxford/eval/params/baseline/oxford_cfear-*:13-26
     case CFEAR_PRESET_CFEAR1:
     case CFEAR_PRESET_CFEAR2:
+      p->reg.regularization = 1.0;        // EVALUATION_regularization="1" (:23); only P2D reads it (n_scan_normal.cpp:288-292)
       p->reg.cost = CFEAR_P2L;
       p->submap_scan_size = preset == CFEAR_PRESET_CFEAR1 ? 1 : 3;
       p->res = 3.5f;
@@ -348,6 +349,7 @@ int cfear_odometry_params_preset(cfear_odometry_params* p, int preset, int datas
       p->weight_intensity = 0;
       break;
     case CFEAR_PRESET_CFEAR3:
+      p->reg.regularization = 1.0;        // oxford_cfear-3:23; the struct default 0.0 is OdometryKeyframeFuser::Parameters' own
       break;
     case CFEAR_PRESET_CFEAR3_S10:
       p->submap_scan_size = 10;

@@ -74,9 +74,9 @@ def test_presets_follow_the_reference_launch_files():
     (cfear_radarodometry/launch/oxford/eval/params/baseline/oxford_cfear-*:13-26) on the four sensor setups
     (tbv_slam/script/*/run_tbv_simple.sh)."""
     from tbv_slam_public_amd import api
-    want = {"CFEAR-1": (L.COST["P2L"], 1, 3.5, 12, L.LOSS["Huber"], 0, 0.0),
-            "CFEAR-2": (L.COST["P2L"], 3, 3.5, 12, L.LOSS["Huber"], 0, 0.0),
-            "CFEAR-3": (L.COST["P2P"], 4, 3.0, 40, L.LOSS["Huber"], 1, 0.0),
+    want = {"CFEAR-1": (L.COST["P2L"], 1, 3.5, 12, L.LOSS["Huber"], 0, 1.0),     # EVALUATION_regularization="1" (:23)
+            "CFEAR-2": (L.COST["P2L"], 3, 3.5, 12, L.LOSS["Huber"], 0, 1.0),
+            "CFEAR-3": (L.COST["P2P"], 4, 3.0, 40, L.LOSS["Huber"], 1, 1.0),
             "CFEAR-3-s10": (L.COST["P2P"], 10, 3.0, 40, L.LOSS["Cauchy"], 1, 0.1)}
     for name, (cost, s, res, k, loss, wi, regu) in want.items():
         p = api.odometry_preset(name)
@@ -87,7 +87,7 @@ def test_presets_follow_the_reference_launch_files():
         p = api.odometry_preset("CFEAR-3", ds)
         assert abs(p.kstrong.range_res - rr) < 1e-7 and p.cacfar.range_res == p.kstrong.range_res
         assert (p.radar_ccw, p.rotate_ccw) == (ccw, rot)
-    same = api.odometry_params()
+    same = api.odometry_params(reg_regularization=1.0)     # the struct default keeps OdometryKeyframeFuser::Parameters' 0.0
     assert bytes(api.odometry_preset("CFEAR-3", "oxford")) == bytes(same)
     assert api.odometry_preset("CFEAR-2", submap_scan_size=2).submap_scan_size == 2
     p = L.OdometryParams()
