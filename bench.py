@@ -208,7 +208,7 @@ def roofline_of(prof, n_scans_per_launch, mean_points):
 # ---------------------------------------------------------------------------------------------------------
 # neighbouring workloads (functions so that the odometry run can report them in its own line)
 # ---------------------------------------------------------------------------------------------------------
-def loopclosure_run(D, n_cand, steps, warmup):
+def loopclosure_run(D, n_cand, steps, warmup, graph=None):
     """BASELINE configs[3]: loop-closure candidate registrations (P2L, Huber 0.1, Uniform, SetParameters(4,10) --
     loopclosure.cpp:56-57) between cached surface-point sets, block-sharded over the ranks, results all_gathered
     (RCCL) in candidate order."""
@@ -216,13 +216,22 @@ def loopclosure_run(D, n_cand, steps, warmup):
     from tbv_slam_public_amd import api, synth
     from tbv_slam_public_amd import dist as cdist
     ctx = api.Context(D.local_rank, stream=torch.cuda.current_stream().cuda_stream)
-    n_frames = 40
-    sc = synth.Scene(3)
-    gt = np.stack([sc.pose_at(f, n_frames) for f in range(n_frames)])
-    scans = []
-    for f in range(n_frames):                      # every rank featurises the scans it may reference
-        r = api.filter_kstrongest(sc.render(f, n_frames), 40, 60, 0.0438, 2.5, ctx=ctx)
-        scans.append(api.MapPointNormal(r["xyzi"][0, :int(r["n_points"][0])], 3.0, (0, 0), True, ctx=ctx))
+    if graph:
+        # a precomputed simple_graph.sgh (tools/make_graph.py, or the reference's SaveGraph): the cached surface points
+        # of every node feed the matcher directly, as loopclosure::Register does (types.h:119-122)
+        nodes = [nd for nd in api.LoadSimpleGraph(graph) if nd["cells"] is not None and len(nd["cells"]) > 0]
+        n_frames = len(nodes)
+        assert n_frames >= 8, "the graph needs at least 8 nodes with surface points"
+        gt = np.stack([nd["T_xyt"] for nd in nodes])
+        scans = [api.MapPointNormal(cells=nd["cells"], ctx=ctx) for nd in nodes]
+    else:
+        n_frames = 40
+        sc = synth.Scene(3)
+        gt = np.stack([sc.pose_at(f, n_frames) for f in range(n_frames)])
+        scans = []
+        for f in range(n_frames):                      # every rank featurises the scans it may reference
+            r = api.filter_kstrongest(sc.render(f, n_frames), 40, 60, 0.0438, 2.5, ctx=ctx)
+            scans.append(api.MapPointNormal(r["xyzi"][0, :int(r["n_points"][0])], 3.0, (0, 0), True, ctx=ctx))
     rng = np.random.Generator(np.random.PCG64(11))
 
     def rel(a, b):
@@ -252,7 +261,7 @@ def loopclosure_run(D, n_cand, steps, warmup):
             "value": n_cand * steps / elapsed, "unit": "registrations/s", "n_gpus": D.world, "steps": steps,
             "warmup": max(warmup, 1), "ms_per_step": elapsed / steps * 1e3, "ms_per_4096": elapsed / steps * 1e3 * 4096.0 / n_cand,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32 search / f64 solve",
-            "data": "synthetic (scene_v1)",
+            "data": ("simple_graph %s (%d nodes)" % (os.path.basename(graph), n_frames)) if graph else "synthetic (scene_v1)",
             "config": {"workload": "configs[3]: %d loop-closure candidates sharded over %d rank(s), all_gather of "
                                    "72-byte result records" % (n_cand, D.world), "candidates": n_cand},
             "ok_fraction": float((out["status"] == 0).mean()), "mean_outer_iters": float(out["outer_iters"].mean()),
@@ -347,6 +356,8 @@ def main(argv=None):
                          "a batch of candidate registrations from cached features, sharded over the ranks "
                          "with one RCCL all_gather of the result records per step")
     ap.add_argument("--candidates", type=int, default=4096)
+    ap.add_argument("--graph", default=None, help="loopclosure: take the nodes' cached surface points from this simple_graph.sgh "
+                                                  "(tools/make_graph.py writes one) instead of featurising synthetic sweeps")
     ap.add_argument("--bins-major", action="store_true",
                     help="feed the images as [range bins][azimuths] (non-Oxford drivers): adds the GPU rotation of "
                          "radarDriver::Callback (radar_driver.cpp:74-90) to every step; not the BASELINE layout")
@@ -363,7 +374,8 @@ def main(argv=None):
     if args.dry_run:
         return dry_run(D, args)
     if args.workload in ("loopclosure", "verify"):
-        out = (loopclosure_run if args.workload == "loopclosure" else verify_run)(D, args.candidates, args.steps, args.warmup)
+        out = (loopclosure_run(D, args.candidates, args.steps, args.warmup, args.graph) if args.workload == "loopclosure"
+               else verify_run(D, args.candidates, args.steps, args.warmup))
         vals = D.gather(out["value"])
         if D.rank == 0:
             out["rccl_ranks"] = len(vals)

@@ -46,6 +46,8 @@ extern "C" {
 #define CFEAR_ERR_SOLVER (-5)           /* !summary_.IsSolutionUsable() (n_scan_normal.cpp:449)*/
 #define CFEAR_ERR_EMPTY_CLOUD (-6)      /* pointnormal.cpp:72-75 ("error, cloud empty")        */
 #define CFEAR_ERR_NO_DEVICE (-7)        /* no HIP device / kernels not loadable                */
+#define CFEAR_ERR_IO (-8)               /* a file could not be opened / read / written         */
+#define CFEAR_ERR_FORMAT (-9)           /* a file is not a simple_graph archive this reader understands */
 
 /* ---- enums (values follow the reference's enums) ------------------------------------------ */
 enum cfear_cost_metric { CFEAR_P2P = 0, CFEAR_P2L = 1, CFEAR_P2D = 2 };          /* registration.h:55 */
@@ -592,6 +594,63 @@ int cfear_odometry_get_scan(cfear_odometry* od, int32_t stream, cfear_scan** out
 int cfear_odometry_get_cloud(cfear_odometry* od, int32_t stream, float* xyzi, int32_t cap, int32_t* n_out);
 int cfear_odometry_get_peaks(cfear_odometry* od, int32_t stream, float* xyzi, int32_t cap, int32_t* n_out);
 int cfear_odometry_destroy(cfear_odometry* od);
+
+/* ---- after the path: pose-graph nodes on disk ------------------------------------------------
+ * simple_graph.sgh = Boost binary archive of std::vector<std::pair<RadarScan, std::vector<Constraint3d>>>
+ * (types.h:46-192, types.cpp:103-130; MapPointNormal::save/load pointnormal.h:206-228; serialization.h): what
+ * OdometryKeyframeFuser::SaveGraph writes and the loop-closure tools read back ("advanced usage", README.md:113-168).
+ * Pure host code, no context.  The archive layout is restated from Boost 1.71's sources; no reference-produced file
+ * exists in the repository to pin it against (csrc/graph.hip says what is assumed).                              */
+typedef struct cfear_pose3d { double p[3]; double q[4]; } cfear_pose3d;      /* Pose3d: translation, quaternion (x, y, z, w) */
+void cfear_pose3d_from_xyt(const double xyt[3], cfear_pose3d* out);          /* PoseEigToCeres of a planar pose (types.cpp:25-32) */
+void cfear_pose3d_to_xyt(const cfear_pose3d* p, double xyt[3]);
+typedef struct cfear_graph_cloud {      /* pcl::PointCloud<PointXYZI>::Ptr: n < 0 = null pointer */
+  const float* xyzi;                    /* [n][4] x, y, z, intensity */
+  int32_t n;
+  uint32_t seq;                         /* header.seq */
+  uint64_t stamp;                       /* header.stamp */
+  const char* frame_id;                 /* header.frame_id (NULL = "") */
+} cfear_graph_cloud;
+typedef struct cfear_graph_constraint { /* Constraint3d, types.h:152-186 */
+  uint64_t id_begin, id_end;
+  cfear_pose3d t_be;
+  double information[36];               /* row-major 6x6 */
+  int32_t type;                         /* ConstraintType: 0 odometry, 1 loop_appearance, 2 mini_loop, 3 candidate */
+  int32_t n_quality;
+  const char* const* quality_keys;      /* std::map<std::string, double> quality, in key order */
+  const double* quality_values;
+  const char* info;
+} cfear_graph_constraint;
+typedef struct cfear_graph_node {       /* RadarScan (types.h:88-142) + the constraints stored with it */
+  cfear_pose3d T, Tgt;
+  int32_t has_Tgt;
+  uint32_t idx;                         /* idx_ */
+  uint64_t stamp;                       /* stamp_ */
+  double motion[16];                    /* motion_: Affine3d::data(), column-major 4x4 */
+  cfear_graph_cloud cloud_peaks, cloud_nopeaks;
+  int32_t has_normal;                   /* cloud_normal_ != NULL */
+  int32_t input_is_nopeaks;             /* cloud_normal_->input_ is the cloud_nopeaks_ object (how the fuser builds nodes): stored once */
+  cfear_graph_cloud normal_input;       /* cloud_normal_->input_ otherwise */
+  const cfear_cell* cells;              /* cloud_normal_->cells */
+  int32_t n_cells;
+  float radius;                         /* radius_ */
+  int32_t weight_intensity, pad;
+  const cfear_graph_constraint* constraints;
+  int32_t n_constraints, pad2;
+} cfear_graph_node;
+typedef struct cfear_graph cfear_graph;
+int cfear_graph_save(const char* path, const cfear_graph_node* nodes, int32_t n_nodes);      /* SaveSimpleGraph */
+int cfear_graph_load(const char* path, cfear_graph** out);                                    /* LoadSimpleGraph */
+int cfear_graph_size(const cfear_graph* g);
+int cfear_graph_node_at(const cfear_graph* g, int32_t i, cfear_graph_node* out);              /* pointers live until destroy */
+int cfear_graph_destroy(cfear_graph* g);
+/* OdometryKeyframeFuser::AddToGraph (odometrykeyframefuser.cpp:428-445) for `stream`: the odometry constraint from the
+ * keyframe added by the LAST processed frame to the keyframe before it -- id_begin / id_end are the stream's keyframe
+ * ordinals (RadarScan::counter), t_be = Tfrom^-1 * Tto, type odometry.  The reference stores information = C.inverse()
+ * of cov_current with its 3x3 block rotated into the from-frame; Register's constant diag(0.01, 0.01, 0, 0, 0, 1e-4) is
+ * singular, so the reference's matrix is not finite -- here information is the inverse on the planar (x, y, yaw)
+ * sub-space and zero elsewhere.  CFEAR_ERR_INVALID_ARGUMENT if the last frame added no keyframe or the first one.   */
+int cfear_odometry_get_constraint(cfear_odometry* od, int32_t stream, cfear_graph_constraint* out);
 
 #ifdef __cplusplus
 }

@@ -15,6 +15,7 @@ SO_PATH = os.path.join(_HERE, "libcfear_hip.so")
 OK = 0
 ERR_INVALID_ARGUMENT, ERR_HIP, ERR_CAPACITY = -1, -2, -3
 ERR_TOO_FEW_RESIDUALS, ERR_SOLVER, ERR_EMPTY_CLOUD, ERR_NO_DEVICE = -4, -5, -6, -7
+ERR_IO, ERR_FORMAT = -8, -9
 
 P2P, P2L, P2D = 0, 1, 2
 LOSS = {"None": 0, "Huber": 1, "Cauchy": 2, "SoftLOne": 3, "Combined": 4, "Tukey": 5}
@@ -206,7 +207,32 @@ EXPORTS = [
     "cfear_odometry_get_scan", "cfear_odometry_get_cloud", "cfear_odometry_get_peaks", "cfear_odometry_process_clouds",
     "cfear_odometry_process_offsets", "cfear_odometry_discard_prefetch",
     "cfear_keyframe_based_fuse", "cfear_acc_vel_sanity_check", "cfear_filter_kstrongest_legacy",
+    "cfear_graph_save", "cfear_graph_load", "cfear_graph_size", "cfear_graph_node_at", "cfear_graph_destroy",
+    "cfear_pose3d_from_xyt", "cfear_pose3d_to_xyt", "cfear_odometry_get_constraint",
 ]
+
+
+class Pose3d(C.Structure):
+    _fields_ = [("p", C.c_double * 3), ("q", C.c_double * 4)]
+
+
+class GraphCloud(C.Structure):
+    _fields_ = [("xyzi", C.c_void_p), ("n", C.c_int32), ("seq", C.c_uint32), ("stamp", C.c_uint64), ("frame_id", C.c_char_p)]
+
+
+class GraphConstraint(C.Structure):
+    _fields_ = [("id_begin", C.c_uint64), ("id_end", C.c_uint64), ("t_be", Pose3d), ("information", C.c_double * 36),
+                ("type", C.c_int32), ("n_quality", C.c_int32), ("quality_keys", C.POINTER(C.c_char_p)),
+                ("quality_values", C.POINTER(C.c_double)), ("info", C.c_char_p)]
+
+
+class GraphNode(C.Structure):
+    _fields_ = [("T", Pose3d), ("Tgt", Pose3d), ("has_Tgt", C.c_int32), ("idx", C.c_uint32), ("stamp", C.c_uint64),
+                ("motion", C.c_double * 16), ("cloud_peaks", GraphCloud), ("cloud_nopeaks", GraphCloud),
+                ("has_normal", C.c_int32), ("input_is_nopeaks", C.c_int32), ("normal_input", GraphCloud),
+                ("cells", C.c_void_p), ("n_cells", C.c_int32), ("radius", C.c_float), ("weight_intensity", C.c_int32),
+                ("pad", C.c_int32), ("constraints", C.POINTER(GraphConstraint)), ("n_constraints", C.c_int32), ("pad2", C.c_int32)]
+
 
 _LIB = None
 
@@ -311,6 +337,16 @@ def lib():
     L.cfear_odometry_discard_prefetch.argtypes = [vp]
     L.cfear_filter_kstrongest_legacy.argtypes = [vp, vp, C.POINTER(PolarDesc), C.c_int32, C.c_double, C.c_double, C.c_double, vp, vp,
                                                  C.c_int32]
+    L.cfear_graph_save.argtypes = [C.c_char_p, C.POINTER(GraphNode), C.c_int32]
+    L.cfear_graph_load.argtypes = [C.c_char_p, C.POINTER(vp)]
+    L.cfear_graph_size.argtypes = [vp]
+    L.cfear_graph_node_at.argtypes = [vp, C.c_int32, C.POINTER(GraphNode)]
+    L.cfear_graph_destroy.argtypes = [vp]
+    L.cfear_pose3d_from_xyt.argtypes = [C.POINTER(C.c_double), C.POINTER(Pose3d)]
+    L.cfear_pose3d_from_xyt.restype = None
+    L.cfear_pose3d_to_xyt.argtypes = [C.POINTER(Pose3d), C.POINTER(C.c_double)]
+    L.cfear_pose3d_to_xyt.restype = None
+    L.cfear_odometry_get_constraint.argtypes = [vp, C.c_int32, C.POINTER(GraphConstraint)]
     L.cfear_keyframe_based_fuse.argtypes = [C.POINTER(C.c_double), C.c_int32, C.c_double, C.c_double]
     L.cfear_acc_vel_sanity_check.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_double)]
     L.cfear_odometry_get_covariance.argtypes = [vp, vp, vp]

@@ -11,6 +11,7 @@ with ROS / PCL / Eigen types replaced by NumPy arrays (host) or torch CUDA tenso
 Everything computes in libcfear_hip.so on the GPU; there is no CPU path in this package.
 """
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -1249,6 +1250,18 @@ class OdometryKeyframeFuser:
             out[name] = buf
         return out
 
+    def constraint(self, stream):
+        """OdometryKeyframeFuser::AddToGraph (odometrykeyframefuser.cpp:428-445): the odometry Constraint3d from the keyframe
+        the last frame added to the keyframe before it -> dict (SaveSimpleGraph layout), or None if the last frame added
+        no keyframe (or the first one)."""
+        c = L.GraphConstraint()
+        rc = self.ctx._lib.cfear_odometry_get_constraint(self._h, int(stream), C.byref(c))
+        if rc == L.ERR_INVALID_ARGUMENT:
+            return None
+        self.ctx.check(rc)
+        return dict(id_begin=int(c.id_begin), id_end=int(c.id_end), t_be=np.array(list(c.t_be.p) + list(c.t_be.q)),
+                    information=np.array(c.information).reshape(6, 6), type=int(c.type), quality={}, info="")
+
     def covariance(self):
         """cov_current of every stream after the last frame -> (cov [n_streams,6,6], sampled [n_streams] bool):
         Register's constant diagonal, Identity after a failed registration, or the sampled covariance when
@@ -1269,3 +1282,135 @@ class OdometryKeyframeFuser:
             self.close()
         except Exception:
             pass
+
+
+# ---- simple_graph.sgh (types.cpp:103-130): host-only, no GPU ---------------------------------------------------
+def pose3d_from_xyt(xyt):
+    """PoseEigToCeres of a planar pose -> (p [3], q [4] = x, y, z, w)."""
+    p = L.Pose3d()
+    L.lib().cfear_pose3d_from_xyt((C.c_double * 3)(*[float(v) for v in xyt]), C.byref(p))
+    return np.array(p.p), np.array(p.q)
+
+
+def _pose3d(v):
+    p = L.Pose3d()
+    if v is None:
+        p.q[3] = 1.0
+    elif len(v) == 3:
+        L.lib().cfear_pose3d_from_xyt((C.c_double * 3)(*[float(x) for x in v]), C.byref(p))
+    else:
+        for i in range(3):
+            p.p[i] = float(v[i])
+        for i in range(4):
+            p.q[i] = float(v[3 + i])
+    return p
+
+
+def _graph_cloud(c, keep):
+    g = L.GraphCloud()
+    if c is None:
+        g.n = -1
+        return g
+    xyzi = c if not isinstance(c, dict) else c["xyzi"]
+    a = np.ascontiguousarray(xyzi, np.float32).reshape(-1, 4)
+    keep.append(a)
+    g.xyzi, g.n = a.ctypes.data, a.shape[0]
+    if isinstance(c, dict):
+        g.seq, g.stamp = int(c.get("seq", 0)), int(c.get("stamp", 0))
+        fid = c.get("frame_id", "").encode()
+        keep.append(fid)
+        g.frame_id = fid
+    return g
+
+
+def SaveSimpleGraph(path, nodes):
+    """SaveSimpleGraph (types.cpp:103-113).  nodes: list of dicts with keys T, Tgt (xyt or p+q 7-vectors), has_Tgt, idx,
+    stamp, motion (4x4), cloud_peaks, cloud_nopeaks (float [n, 4] or dict(xyzi, stamp, seq, frame_id) or None), cells
+    (CELL_DTYPE array or None), radius, weight_intensity, input_is_nopeaks (default True), normal_input, constraints
+    (list of dicts: id_begin, id_end, t_be, information [6, 6], type, quality {str: float}, info)."""
+    keep = []
+    arr = (L.GraphNode * len(nodes))()
+    for i, nd in enumerate(nodes):
+        g = arr[i]
+        g.T, g.Tgt = _pose3d(nd.get("T")), _pose3d(nd.get("Tgt"))
+        g.has_Tgt, g.idx, g.stamp = int(nd.get("has_Tgt", 0)), int(nd.get("idx", i)), int(nd.get("stamp", 0))
+        m = np.asarray(nd.get("motion", np.eye(4)), np.float64).reshape(4, 4)
+        for k, v in enumerate(m.T.reshape(-1)):                       # Affine3d::data() is column-major
+            g.motion[k] = float(v)
+        g.cloud_peaks = _graph_cloud(nd.get("cloud_peaks"), keep)
+        g.cloud_nopeaks = _graph_cloud(nd.get("cloud_nopeaks"), keep)
+        g.normal_input = _graph_cloud(nd.get("normal_input"), keep)
+        cells = nd.get("cells")
+        g.has_normal = int(cells is not None)
+        g.input_is_nopeaks = int(nd.get("input_is_nopeaks", True))
+        if cells is not None:
+            ca = np.ascontiguousarray(cells, L.CELL_DTYPE)
+            keep.append(ca)
+            g.cells, g.n_cells = ca.ctypes.data, ca.shape[0]
+        g.radius, g.weight_intensity = float(nd.get("radius", 0.0)), int(nd.get("weight_intensity", 0))
+        cons = nd.get("constraints", [])
+        carr = (L.GraphConstraint * max(len(cons), 1))()
+        keep.append(carr)
+        for j, c in enumerate(cons):
+            carr[j].id_begin, carr[j].id_end = int(c["id_begin"]), int(c["id_end"])
+            carr[j].t_be = _pose3d(c.get("t_be"))
+            info = np.asarray(c.get("information", np.eye(6)), np.float64).reshape(-1)
+            for k in range(36):
+                carr[j].information[k] = float(info[k])
+            carr[j].type = int(c.get("type", 0))
+            q = c.get("quality", {})
+            keys = sorted(q)                                          # std::map order
+            ka = (C.c_char_p * max(len(keys), 1))(*[k.encode() for k in keys])
+            va = (C.c_double * max(len(keys), 1))(*[float(q[k]) for k in keys])
+            keep += [ka, va]
+            carr[j].n_quality, carr[j].quality_keys, carr[j].quality_values = len(keys), ka, va
+            ib = c.get("info", "").encode()
+            keep.append(ib)
+            carr[j].info = ib
+        g.constraints, g.n_constraints = carr, len(cons)
+    rc = L.lib().cfear_graph_save(os.fsencode(path), arr, len(nodes))
+    if rc != L.OK:
+        raise L.CfearError(rc, "cfear_graph_save(%s)" % path)
+
+
+def LoadSimpleGraph(path):
+    """LoadSimpleGraph (types.cpp:115-130) -> list of node dicts (the SaveSimpleGraph layout; poses as p+q 7-vectors and
+    'T_xyt' as (x, y, theta); 'scan' is NOT built here -- feed node['cells'] to MapPointNormal(cells=...) on a GPU box)."""
+    lib = L.lib()
+    h = C.c_void_p()
+    rc = lib.cfear_graph_load(os.fsencode(path), C.byref(h))
+    if rc != L.OK:
+        raise L.CfearError(rc, "cfear_graph_load(%s)" % path)
+    try:
+        out = []
+        for i in range(lib.cfear_graph_size(h)):
+            g = L.GraphNode()
+            assert lib.cfear_graph_node_at(h, i, C.byref(g)) == L.OK
+
+            def pose(p):
+                return np.array(list(p.p) + list(p.q))
+
+            def cloud(c):
+                if c.n < 0:
+                    return None
+                a = np.ctypeslib.as_array(C.cast(c.xyzi, C.POINTER(C.c_float)), (c.n, 4)).copy() if c.n else np.zeros((0, 4), np.float32)
+                return dict(xyzi=a, stamp=int(c.stamp), seq=int(c.seq), frame_id=(c.frame_id or b"").decode())
+            xyt = (C.c_double * 3)()
+            lib.cfear_pose3d_to_xyt(C.byref(g.T), xyt)
+            nd = dict(T=pose(g.T), T_xyt=np.array(xyt), Tgt=pose(g.Tgt), has_Tgt=bool(g.has_Tgt), idx=int(g.idx), stamp=int(g.stamp),
+                      motion=np.array(g.motion).reshape(4, 4).T.copy(), cloud_peaks=cloud(g.cloud_peaks),
+                      cloud_nopeaks=cloud(g.cloud_nopeaks), normal_input=cloud(g.normal_input), input_is_nopeaks=bool(g.input_is_nopeaks),
+                      cells=None, radius=float(g.radius), weight_intensity=bool(g.weight_intensity), constraints=[])
+            if g.has_normal:
+                nd["cells"] = (np.frombuffer(C.string_at(g.cells, g.n_cells * L.CELL_DTYPE.itemsize), L.CELL_DTYPE).copy()
+                               if g.n_cells else np.zeros(0, L.CELL_DTYPE))
+            for j in range(g.n_constraints):
+                c = g.constraints[j]
+                nd["constraints"].append(dict(
+                    id_begin=int(c.id_begin), id_end=int(c.id_end), t_be=pose(c.t_be), information=np.array(c.information).reshape(6, 6),
+                    type=int(c.type), quality={c.quality_keys[k].decode(): float(c.quality_values[k]) for k in range(c.n_quality)},
+                    info=(c.info or b"").decode()))
+            out.append(nd)
+        return out
+    finally:
+        lib.cfear_graph_destroy(h)

@@ -207,6 +207,8 @@ const char* cfear_status_string(int status) {
     case CFEAR_ERR_SOLVER: return "solver failure";
     case CFEAR_ERR_EMPTY_CLOUD: return "empty cloud";
     case CFEAR_ERR_NO_DEVICE: return "no HIP device";
+    case CFEAR_ERR_IO: return "file i/o failed";
+    case CFEAR_ERR_FORMAT: return "not a simple_graph archive";
     default: return "unknown status";
   }
 }

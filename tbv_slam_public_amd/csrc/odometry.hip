@@ -72,7 +72,7 @@ extern "C" int cfear_acc_vel_sanity_check(const double tmot_prev_xy[2], const do
 
 namespace {
 
-struct Keyframe { int slab; Aff2 pose; };
+struct Keyframe { int slab; Aff2 pose; uint64_t idx = 0; };
 struct Stream {
   Aff2 T_prev = aff_identity(), Tmot = aff_identity(), Tcurrent = aff_identity();
   std::vector<Keyframe> keyframes;
@@ -80,6 +80,11 @@ struct Stream {
   int cur_slab = -1;
   Aff2 Tguess = aff_identity();
   int job = -1;              // index into this call's registration batch, -1 = first frame
+  uint64_t n_keyframes = 0;  // RadarScan::counter of this stream
+  bool has_constraint = false;          // the last frame added a keyframe behind another one (AddToGraph)
+  uint64_t c_from = 0, c_to = 0;
+  Aff2 c_Tdiff = aff_identity();
+  double c_cov[36] = {0};
 };
 
 }  // namespace
@@ -611,8 +616,9 @@ static int process_frame(cfear_odometry* od, const uint8_t* polar, const uint8_t
       aff_to_xyt(st.Tcurrent, fi.pose);
       continue;
     }
+    st.has_constraint = false;
     if (st.job < 0) {                                             // first frame becomes the first keyframe
-      st.keyframes.push_back(Keyframe{st.cur_slab, aff_identity()});
+      st.keyframes.push_back(Keyframe{st.cur_slab, aff_identity(), st.n_keyframes++});
       fi.keyframe_added = 1;
       fi.reg_status = 1;
       aff_to_xyt(st.Tcurrent, fi.pose);
@@ -655,7 +661,22 @@ static int process_frame(cfear_odometry* od, const uint8_t* polar, const uint8_t
     aff_to_xyt(Tkeydiff, kd);
     const bool fuse = cfear_keyframe_based_fuse(kd, par.use_keyframe, par.min_keyframe_dist, par.min_keyframe_rot_deg) != 0;   // :62-73
     if (fuse) {                                                   // :236-250, AddToReference :470-476
-      st.keyframes.push_back(Keyframe{st.cur_slab, Tcurrent});
+      {                                                           // AddToGraph :428-445: constraint to the latest keyframe
+        const Keyframe& to = st.keyframes.back();
+        st.has_constraint = true;
+        st.c_from = st.n_keyframes; st.c_to = to.idx;
+        st.c_Tdiff = aff_mul(aff_inv(Tcurrent), to.pose);         // Tfrom^-1 * Tto
+        const double* cv = od->cov.data() + (size_t)b * 36;
+        memcpy(st.c_cov, cv, sizeof(st.c_cov));
+        // C.block<3,3>(0,0) = Tfrom^-1.rotation() * Cov.block<3,3>(0,0) * Tfrom^-1.rotation()^T
+        const Aff2 Ti = aff_inv(Tcurrent);
+        const double R[9] = {Ti.l[0], Ti.l[1], 0, Ti.l[2], Ti.l[3], 0, 0, 0, 1};
+        double t[9], o[9];
+        for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) { t[r * 3 + c] = 0; for (int k = 0; k < 3; k++) t[r * 3 + c] += R[r * 3 + k] * cv[k * 6 + c]; }
+        for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) { o[r * 3 + c] = 0; for (int k = 0; k < 3; k++) o[r * 3 + c] += t[r * 3 + k] * R[c * 3 + k]; }
+        for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) st.c_cov[r * 6 + c] = o[r * 3 + c];
+      }
+      st.keyframes.push_back(Keyframe{st.cur_slab, Tcurrent, st.n_keyframes++});
       if ((int)st.keyframes.size() > par.submap_scan_size) {
         st.free_slabs.push_back(st.keyframes.front().slab);
         st.keyframes.erase(st.keyframes.begin());
@@ -709,4 +730,28 @@ extern "C" int cfear_odometry_get_peaks(cfear_odometry* od, int32_t stream, floa
   if (!od->par.keep_nodes) return cfear_set_error(od->ctx, CFEAR_ERR_INVALID_ARGUMENT, "peaks clouds are kept only with keep_nodes = 1");
   if (od->last_slab[stream] < 0) return cfear_set_error(od->ctx, CFEAR_ERR_INVALID_ARGUMENT, "stream %d: no frame processed yet", stream);
   return copy_cloud_out(od, od->d_pk + (size_t)stream * od->cap_points * 4, od->h_npk[stream], xyzi, cap, n_out);
+}
+
+extern "C" int cfear_odometry_get_constraint(cfear_odometry* od, int32_t stream, cfear_graph_constraint* out) {
+  if (!od || !out || stream < 0 || stream >= od->n_streams) return CFEAR_ERR_INVALID_ARGUMENT;
+  const Stream& st = od->streams[stream];
+  if (!st.has_constraint) return cfear_set_error(od->ctx, CFEAR_ERR_INVALID_ARGUMENT, "stream %d: the last frame added no keyframe behind another one", stream);
+  memset(out, 0, sizeof(*out));
+  out->id_begin = st.c_from; out->id_end = st.c_to;
+  double xyt[3];
+  aff_to_xyt(st.c_Tdiff, xyt);
+  cfear_pose3d_from_xyt(xyt, &out->t_be);
+  out->type = 0;                                                  // ConstraintType::odometry
+  // information on the planar sub-space (x, y, yaw) = indices 0, 1, 5; the full 6x6 is singular (see cfear_hip.h)
+  const int ix[3] = {0, 1, 5};
+  double M[9], I[9];
+  for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) M[r * 3 + c] = st.c_cov[ix[r] * 6 + ix[c]];
+  const double det = M[0] * (M[4] * M[8] - M[5] * M[7]) - M[1] * (M[3] * M[8] - M[5] * M[6]) + M[2] * (M[3] * M[7] - M[4] * M[6]);
+  if (det != 0.0 && std::isfinite(det)) {
+    I[0] = (M[4] * M[8] - M[5] * M[7]) / det; I[1] = (M[2] * M[7] - M[1] * M[8]) / det; I[2] = (M[1] * M[5] - M[2] * M[4]) / det;
+    I[3] = (M[5] * M[6] - M[3] * M[8]) / det; I[4] = (M[0] * M[8] - M[2] * M[6]) / det; I[5] = (M[2] * M[3] - M[0] * M[5]) / det;
+    I[6] = (M[3] * M[7] - M[4] * M[6]) / det; I[7] = (M[1] * M[6] - M[0] * M[7]) / det; I[8] = (M[0] * M[4] - M[1] * M[3]) / det;
+    for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) out->information[ix[r] * 6 + ix[c]] = I[r * 3 + c];
+  }
+  return CFEAR_OK;
 }

@@ -364,3 +364,53 @@ def test_dense_scene_pipeline_matches_oracle():
         d = np.abs(info["pose"][0] - pose)
         assert d[:2].max() <= 1e-4 and d[2] <= 1e-5, (f, d)
         assert (info["reg_status"][0] == 0) == bool(oi[2]) and info["outer_iters"][0] == oi[3]
+
+
+def test_fuser_graph_goes_to_disk_and_back(tmp_path):
+    """The pose-graph nodes of one stream (keep_nodes) with AddToGraph's odometry constraints -> simple_graph.sgh ->
+    LoadSimpleGraph: the loaded surface points register exactly like the originals, and every constraint is
+    Tfrom^-1 * Tto of the two keyframes it names."""
+    import torch
+    from tbv_slam_public_amd import api, synth
+    imgs, _, _ = synth.scene_v1(61, 8)
+    od = api.OdometryKeyframeFuser(1, 400, 3360, api.odometry_params(keep_nodes=1))
+    nodes, scans = [], []
+    for f in range(8):
+        info = od.process(torch.from_numpy(imgs[f:f + 1]).cuda())
+        if not info["keyframe_added"][0]:
+            continue
+        nd = od.node(0)
+        c = od.constraint(0)
+        assert (c is None) == (len(nodes) == 0)
+        scans.append(nd["scan"])
+        nodes.append(dict(T=info["pose"][0], idx=len(nodes), stamp=1000 + f, cloud_peaks=nd["peaks"], cloud_nopeaks=nd["cloud"],
+                          cells=nd["scan"].GetCells(), radius=3.0, weight_intensity=1, constraints=[c] if c else []))
+    assert len(nodes) >= 6
+    path = str(tmp_path / "simple_graph.sgh")
+    api.SaveSimpleGraph(path, nodes)
+    back = api.LoadSimpleGraph(path)
+    assert len(back) == len(nodes)
+    for i, (a, b) in enumerate(zip(nodes, back)):
+        np.testing.assert_array_equal(b["cells"], a["cells"])
+        np.testing.assert_array_equal(b["cloud_peaks"]["xyzi"], a["cloud_peaks"])
+        np.testing.assert_allclose(b["T_xyt"], a["T"], atol=1e-14)
+        if i:
+            c = b["constraints"][0]
+            assert (c["id_begin"], c["id_end"], c["type"]) == (i, i - 1, 0)
+            pa, pb = nodes[i]["T"], nodes[i - 1]["T"]                       # t_be = Tfrom^-1 * Tto
+            ca, sa = np.cos(pa[2]), np.sin(pa[2])
+            d = pb[:2] - pa[:2]
+            exp = np.array([ca * d[0] + sa * d[1], -sa * d[0] + ca * d[1], pb[2] - pa[2]])
+            xyt = np.array([c["t_be"][0], c["t_be"][1], 2 * np.arctan2(c["t_be"][5], c["t_be"][6])])
+            np.testing.assert_allclose(xyt, exp, atol=1e-12)
+            np.testing.assert_allclose(np.diag(c["information"]), [100.0, 100.0, 0, 0, 0, 1e4], rtol=1e-12)
+    # loop-closure style registration between loaded nodes == between the live ones
+    reg = api.n_scan_normal_reg("P2L")
+    reg.SetParameters(4, 10)
+    live = [scans[0], scans[3]]
+    loaded = [api.MapPointNormal(cells=back[0]["cells"]), api.MapPointNormal(cells=back[3]["cells"])]
+    guess = np.array([back[0]["T_xyt"], back[3]["T_xyt"] + [0.4, -0.3, 0.02]])
+    ok1, T1, _ = reg.Register(live, guess.copy())
+    ok2, T2, _ = reg.Register(loaded, guess.copy())
+    assert ok1 and ok2
+    np.testing.assert_array_equal(T1, T2)
