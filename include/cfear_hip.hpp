@@ -15,7 +15,30 @@
 
 #include "cfear_hip.h"
 
+// Where Eigen, PCL and boost::shared_ptr exist (a ROS Noetic host; they are NOT in this image), the classes below also
+// carry the reference's EXACT signatures -- Eigen::Affine3d poses, pcl::PointCloud<pcl::PointXYZI>::Ptr clouds,
+// MapNormalPtr, Matrix6d covariances (n_scan_normal.h:37-41, pointnormal.h:110-118, odometrykeyframefuser.h:197-249) --
+// forwarding to the POD methods.  tests/test_cpp_shim.py compiles this block against minimal stand-in headers (a syntax
+// check of THIS header only; it proves nothing about Eigen or PCL).
+#if defined(__has_include)
+#if __has_include(<Eigen/Geometry>) && __has_include(<pcl/point_cloud.h>) && __has_include(<pcl/point_types.h>) && __has_include(<boost/shared_ptr.hpp>)
+#define CFEAR_HIP_HAVE_EIGEN_PCL 1
+#include <Eigen/Geometry>
+#include <boost/shared_ptr.hpp>
+#include <pcl/point_cloud.h>
+#include <pcl/point_types.h>
+#endif
+#endif
+
 namespace CFEAR_Radarodometry {
+
+#ifdef CFEAR_HIP_HAVE_EIGEN_PCL
+typedef Eigen::Matrix<double, 6, 6> Matrix6d;                // registration.h
+typedef Eigen::Matrix<double, 6, 6> Covariance;             // types.h
+typedef enum costmetric { P2P, P2L, P2D } cost_metric;                                        // registration.h:55
+typedef enum losstype { None, Huber, Cauchy, SoftLOne, Combined, Tukey } loss_type;           // registration.h:60
+typedef enum weight_options { Uniform = 0, Sim_N = 1, Sim_direciton = 2, Sim_scale = 3, Combined_weights = 4 } weightoption;   // :50
+#endif
 
 struct PointXYZI { float x, y, z, intensity; };            // 16-byte PointXYZI payload
 typedef std::vector<PointXYZI> PointCloud;
@@ -37,9 +60,27 @@ class Context {                                            // one per host threa
   Context& operator=(const Context&) = delete;
   cfear_ctx* get() const { return ctx_; }
   void check(int st) const { if (st != CFEAR_OK) throw CfearError(st, cfear_last_error(ctx_)); }
+  // The context of the calling thread on device 0, for the reference-signature constructors that take none
+  // (the reference's objects are not shared between threads either).
+  static Context& Default() { static thread_local Context c(0); return c; }
  private:
   cfear_ctx* ctx_ = nullptr;
 };
+
+#ifdef CFEAR_HIP_HAVE_EIGEN_PCL
+inline Pose2d Affine3dToPose2d(const Eigen::Affine3d& T) {                                    // utils.cpp:115-122
+  const Eigen::Vector3d eul = T.linear().eulerAngles(0, 1, 2);
+  return Pose2d{T.translation()(0), T.translation()(1), eul(2)};
+}
+inline Eigen::Affine3d Pose2dToAffine3d(const Pose2d& p) {                                    // registration.cpp:128-135
+  return Eigen::Translation3d(p.x, p.y, 0) * Eigen::AngleAxisd(p.theta, Eigen::Vector3d::UnitZ());
+}
+inline PointCloud FromPcl(const pcl::PointCloud<pcl::PointXYZI>& c) {
+  PointCloud out(c.points.size());
+  for (size_t i = 0; i < c.points.size(); i++) out[i] = PointXYZI{c.points[i].x, c.points[i].y, c.points[i].z, c.points[i].intensity};
+  return out;
+}
+#endif
 
 enum filtertype { kstrong, CACFAR };                       // radar_driver.h:25
 
@@ -107,6 +148,38 @@ class MapPointNormal {
   MapPointNormal(Context& ctx, const std::vector<cfear_cell>& cells) : ctx_(ctx) {           // Boost load() path
     ctx_.check(cfear_scan_from_cells(ctx_.get(), cells.data(), (int32_t)cells.size(), &scan_));
   }
+#ifdef CFEAR_HIP_HAVE_EIGEN_PCL
+  // pointnormal.h:116 / pointnormal.cpp:65-90.  raw: one identity cell per point (cell::GetIdentityCell, pointnormal.h:59)
+  MapPointNormal(const pcl::PointCloud<pcl::PointXYZI>::Ptr& cld, float radius, const Eigen::Vector2d& origin = Eigen::Vector2d(0, 0),
+                 const bool weight_intensity = false, const bool raw = false) : ctx_(Context::Default()) {
+    if (raw) {
+      std::vector<cfear_cell> cells(cld->points.size());
+      for (size_t i = 0; i < cells.size(); i++) {
+        cfear_cell c{};
+        c.mean[0] = cld->points[i].x; c.mean[1] = cld->points[i].y;
+        c.normal[0] = 1; c.normal[1] = 0; c.cov[0] = 0.1; c.cov[3] = 0.1;          // cov_ default Identity * 0.1 (pointnormal.h:68)
+        c.scale = 1.0; c.avg_intensity = 1.0; c.lambda_min = 1; c.lambda_max = 1; c.nsamples = 1;
+        cells[i] = c;
+      }
+      ctx_.check(cfear_scan_from_cells(ctx_.get(), cells.data(), (int32_t)cells.size(), &scan_));
+      return;
+    }
+    PointCloud pts = FromPcl(*cld);
+    cfear_feature_params fp{};
+    fp.radius = radius; fp.downsample_factor = downsample_factor(); fp.origin[0] = origin(0); fp.origin[1] = origin(1);
+    fp.weight_intensity = weight_intensity ? 1 : 0;
+    ctx_.check(cfear_scan_create(ctx_.get(), pts.empty() ? nullptr : &pts[0].x, (int32_t)pts.size(), &fp, &scan_));
+  }
+  Eigen::Vector2d GetMean2d(const size_t i) { const cfear_cell& c = cached()[i]; return Eigen::Vector2d(c.mean[0], c.mean[1]); }       // :127
+  Eigen::Vector2d GetNormal2d(const size_t i) { const cfear_cell& c = cached()[i]; return Eigen::Vector2d(c.normal[0], c.normal[1]); } // :131
+  Eigen::Matrix2d GetCov2d(const size_t i) {                                                                                          // :135
+    const cfear_cell& c = cached()[i];
+    Eigen::Matrix2d m;
+    m(0, 0) = c.cov[0]; m(0, 1) = c.cov[1]; m(1, 0) = c.cov[2]; m(1, 1) = c.cov[3];
+    return m;
+  }
+  std::vector<int> GetClosestIdx(const Eigen::Vector2d& p, double d) const { return GetClosestIdx(p(0), p(1), d); }                   // :238
+#endif
   ~MapPointNormal() { cfear_scan_destroy(scan_); }
   MapPointNormal(const MapPointNormal&) = delete;
   MapPointNormal& operator=(const MapPointNormal&) = delete;
@@ -124,9 +197,14 @@ class MapPointNormal {
   }
   const cfear_scan* device() const { return scan_; }
  private:
+  const std::vector<cfear_cell>& cached() { if (cache_.empty()) cache_ = GetCells(); return cache_; }
+  std::vector<cfear_cell> cache_;
   Context& ctx_;
   cfear_scan* scan_ = nullptr;
 };
+#ifdef CFEAR_HIP_HAVE_EIGEN_PCL
+typedef boost::shared_ptr<MapPointNormal> MapNormalPtr;                                       // pointnormal.h:108
+#endif
 
 class n_scan_normal_reg {
  public:
@@ -164,6 +242,39 @@ class n_scan_normal_reg {
     score_ = s;
     return st == CFEAR_OK;
   }
+#ifdef CFEAR_HIP_HAVE_EIGEN_PCL
+  n_scan_normal_reg() : n_scan_normal_reg(Context::Default()) {}                              // n_scan_normal.h:33
+  n_scan_normal_reg(const cost_metric& cost, loss_type loss = Huber, double loss_limit = 0.1,
+                    const weightoption opt = weightoption::Uniform)                           // n_scan_normal.h:35
+      : n_scan_normal_reg(Context::Default(), (int)cost, (int)loss, loss_limit, (int)opt) {}
+  // n_scan_normal.h:37 / n_scan_normal.cpp:82-185: on success EVERY Tsrc[i] is rewritten from its (x, y, theta) parameters
+  // (:176-177) and every reg_cov[i] is the constant diag(0.01, 0.01, 0, 0, 0, 1e-4) (:171-175); soft_constraints is never
+  // set by the shipped callers (offline_odometry.cpp:274) and is not built.
+  bool Register(std::vector<MapNormalPtr>& scans, std::vector<Eigen::Affine3d>& Tsrc, std::vector<Matrix6d>& reg_cov,
+                bool soft_constraints = false) {
+    (void)soft_constraints;
+    std::vector<const MapPointNormal*> h(scans.size());
+    std::vector<Pose2d> poses(scans.size());
+    for (size_t i = 0; i < scans.size(); i++) { h[i] = scans[i].get(); poses[i] = Affine3dToPose2d(Tsrc[i]); }
+    const bool ok = Register(h, poses);
+    if (ok) {
+      Matrix6d m = Matrix6d::Zero();
+      m(0, 0) = 0.1 * 0.1; m(1, 1) = 0.1 * 0.1; m(5, 5) = 0.01 * 0.01;
+      for (size_t i = 0; i < scans.size(); i++) {
+        if (i < reg_cov.size()) reg_cov[i] = m;
+        Tsrc[i] = Pose2dToAffine3d(poses[i]);
+      }
+    }
+    return ok;
+  }
+  bool GetCost(std::vector<MapNormalPtr>& scans, std::vector<Eigen::Affine3d>& Tsrc, double& score,
+               std::vector<double>& residuals) {                                              // n_scan_normal.h:41
+    std::vector<const MapPointNormal*> h(scans.size());
+    std::vector<Pose2d> poses(scans.size());
+    for (size_t i = 0; i < scans.size(); i++) { h[i] = scans[i].get(); poses[i] = Affine3dToPose2d(Tsrc[i]); }
+    return GetCost(h, poses, score, residuals);
+  }
+#endif
   double getScore() const { return score_; }
   bool GetCovarianceScaler(double& cov_scale) const {                                         // n_scan_normal.cpp:433-439
     if (summary_.num_residuals - 3 == 0) return false;
@@ -223,6 +334,61 @@ class OdometryKeyframeFuser {
     ctx_.check(cfear_odometry_process_clouds(od_, c.data(), peaks.empty() ? nullptr : p.data(), info.data()));
     return info;
   }
+#ifdef CFEAR_HIP_HAVE_EIGEN_PCL
+  // The reference's single-sequence object (odometrykeyframefuser.h:72-249): its Parameters by their names, its
+  // constructor, and pointcloudCallback with the reference's argument list (Time: ros::Time or anything else; unused).
+  struct Parameters {
+    std::string cost_type = "P2L", loss_type_ = "Huber";
+    weightoption weight_opt = weightoption::Uniform;
+    int submap_scan_size = 3;
+    bool weight_intensity_ = false, use_guess = true, compensate = true, radar_ccw = false, use_keyframe = true;
+    double res = 3.5, min_keyframe_dist_ = 1.5, min_keyframe_rot_deg_ = 5, loss_limit_ = 0.1, covar_scale_ = 1.0, regularization_ = 0.0;
+    bool estimate_cov_by_sampling = false;
+    double cov_sampling_xy_range = 0.4, cov_sampling_yaw_range = 0.0043625, cov_sampling_covariance_scaler = 4.0;
+    unsigned int cov_sampling_samples_per_axis = 3;
+    int max_points = 400 * 40;                                  // capacity of a filtered cloud (rows * k of the driver)
+  };
+  explicit OdometryKeyframeFuser(const Parameters& pars, bool disable_callback = false) : ctx_(Context::Default()), n_(1) {
+    (void)disable_callback;
+    cfear_odometry_params p;
+    cfear_odometry_params_default(&p);
+    p.reg.cost = pars.cost_type == "P2P" ? CFEAR_P2P : pars.cost_type == "P2D" ? CFEAR_P2D : CFEAR_P2L;        // Str2Cost
+    p.reg.loss = pars.loss_type_ == "Cauchy" ? CFEAR_LOSS_CAUCHY : pars.loss_type_ == "SoftLOne" ? CFEAR_LOSS_SOFTLONE
+               : pars.loss_type_ == "Combined" ? CFEAR_LOSS_COMBINED : pars.loss_type_ == "Tukey" ? CFEAR_LOSS_TUKEY
+               : pars.loss_type_ == "None" ? CFEAR_LOSS_NONE : CFEAR_LOSS_HUBER;                              // Str2loss
+    p.reg.loss_limit = pars.loss_limit_; p.reg.weight_opt = (int)pars.weight_opt;
+    p.reg.cov_scale = pars.covar_scale_; p.reg.regularization = pars.regularization_;
+    p.res = (float)pars.res; p.submap_scan_size = pars.submap_scan_size; p.weight_intensity = pars.weight_intensity_;
+    p.use_guess = pars.use_guess; p.compensate = pars.compensate; p.radar_ccw = pars.radar_ccw; p.use_keyframe = pars.use_keyframe;
+    p.min_keyframe_dist = pars.min_keyframe_dist_; p.min_keyframe_rot_deg = pars.min_keyframe_rot_deg_;
+    p.estimate_cov_by_sampling = pars.estimate_cov_by_sampling;
+    p.cov_sampling.xy_range = pars.cov_sampling_xy_range; p.cov_sampling.yaw_range = pars.cov_sampling_yaw_range;
+    p.cov_sampling.samples_per_axis = (int32_t)pars.cov_sampling_samples_per_axis;
+    p.cov_sampling.covariance_scaler = pars.cov_sampling_covariance_scaler;
+    p.keep_nodes = 1;
+    p.kstrong.k_strongest = 1;                                 // the cloud entry sizes its buffers by rows * k
+    cfear_polar_desc d{pars.max_points, 1, 1, 1, (int64_t)pars.max_points};
+    ctx_.check(cfear_odometry_create(ctx_.get(), 1, &d, &p, &od_));
+  }
+  bool updated = false;                                        // odometrykeyframefuser.h:198
+  template <class Time>
+  void pointcloudCallback(pcl::PointCloud<pcl::PointXYZI>::Ptr& cloud_filtered, pcl::PointCloud<pcl::PointXYZI>::Ptr& cloud_filtered_peaks,
+                          Eigen::Affine3d& Tcurr, const Time& t) {                                            // :223
+    Covariance cov;
+    pointcloudCallback(cloud_filtered, cloud_filtered_peaks, Tcurr, t, cov);
+  }
+  template <class Time>
+  void pointcloudCallback(pcl::PointCloud<pcl::PointXYZI>::Ptr& cloud_filtered, pcl::PointCloud<pcl::PointXYZI>::Ptr& cloud_filtered_peaks,
+                          Eigen::Affine3d& Tcurr, const Time& /*t*/, Covariance& cov_curr) {                  // :225
+    const PointCloud c = FromPcl(*cloud_filtered), pk = FromPcl(*cloud_filtered_peaks);
+    const std::vector<cfear_frame_info> info = pointcloudCallback(std::vector<const PointCloud*>{&c}, std::vector<const PointCloud*>{&pk});
+    Tcurr = Pose2dToAffine3d(Pose2d{info[0].pose[0], info[0].pose[1], info[0].pose[2]});
+    updated = info[0].keyframe_added != 0;
+    double cov[36];
+    ctx_.check(cfear_odometry_get_covariance(od_, cov, nullptr));
+    for (int r = 0; r < 6; r++) for (int q = 0; q < 6; q++) cov_curr(r, q) = cov[r * 6 + q];
+  }
+#endif
   // scan_ of a stream's last frame (odometrykeyframefuser.cpp:172, 244): surface points + the two clouds
   cfear_scan* GetScan(int stream) { cfear_scan* s = nullptr; ctx_.check(cfear_odometry_get_scan(od_, stream, &s)); return s; }
   PointCloud GetCloud(int stream, bool peaks) {
@@ -342,18 +508,3 @@ inline std::vector<cfear_verify_result> VerifyLoopCandidates(CFEAR_Radarodometry
   return res;
 }
 }  // namespace tbv_slam
-
-#if defined(__has_include)
-#if __has_include(<Eigen/Geometry>)
-#include <Eigen/Geometry>
-namespace CFEAR_Radarodometry {
-inline Pose2d Affine3dToPose2d(const Eigen::Affine3d& T) {                                    // utils.cpp:115-122
-  const Eigen::Vector3d eul = T.linear().eulerAngles(0, 1, 2);
-  return Pose2d{T.translation()(0), T.translation()(1), eul(2)};
-}
-inline Eigen::Affine3d Pose2dToAffine3d(const Pose2d& p) {                                    // registration.cpp:128-135
-  return Eigen::Translation3d(p.x, p.y, 0) * Eigen::AngleAxisd(p.theta, Eigen::Vector3d::UnitZ());
-}
-}  // namespace CFEAR_Radarodometry
-#endif
-#endif

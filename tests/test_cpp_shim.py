@@ -95,3 +95,60 @@ def test_cpp_mirror_matches_oracle(tmp_path, layout):
     assert np.abs(gp[:2] - pose[:2]).max() <= 1e-4 and abs(gp[2] - pose[2]) <= 1e-5
     assert int(v[28]) == int(v[29]) == finfo[0]
     assert int(v[30]) == pk[1].shape[0]                     # second frame, first motion estimate is identity
+
+
+def _build_ref_signatures(tmp_path):
+    exe = str(tmp_path / "ref_signatures")
+    so_dir = os.path.join(ROOT, "tbv_slam_public_amd")
+    subprocess.check_call(["g++", "-std=c++14", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"),
+                           "-I", os.path.join(ROOT, "tests", "cpp", "standin"),
+                           os.path.join(ROOT, "tests", "cpp", "ref_signatures.cpp"), "-o", exe, "-L", so_dir, "-lcfear_hip",
+                           "-Wl,-rpath," + so_dir])
+    return exe
+
+
+def test_reference_signatures_compile():
+    """The reference-signature block of cfear_hip.hpp (Register(std::vector<MapNormalPtr>&, std::vector<Eigen::Affine3d>&,
+    std::vector<Matrix6d>&, bool), GetCost, the PCL MapPointNormal constructor, pointcloudCallback) compiles against
+    stand-in Eigen / PCL / boost headers: a syntax check of OUR header, written the way loopclosure::Register and
+    offline_odometry.cpp call these classes."""
+    import tempfile
+    import pathlib
+    with tempfile.TemporaryDirectory() as d:
+        _build_ref_signatures(pathlib.Path(d))
+
+
+@pytest.mark.gpu
+def test_reference_signatures_run(tmp_path):
+    from oracle import pyoracle as O
+    from tbv_slam_public_amd import synth
+    exe = _build_ref_signatures(tmp_path)
+    imgs, gt, _ = synth.scene_v1(31, 2)
+    clouds = []
+    for f in range(2):
+        sr, si, sc = O.kstrongest(imgs[f], 40, 60)
+        clouds.append(O.kstrongest_cloud(sr, si, sc, 0.0438, 2.5))
+    p = tmp_path / "clouds.bin"
+    with open(p, "wb") as fh:
+        fh.write(np.array([c.shape[0] for c in clouds], np.int32).tobytes())
+        for c in clouds:
+            fh.write(np.ascontiguousarray(c, np.float32).tobytes())
+    r = subprocess.run([exe, str(p)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    v = r.stdout.split()
+    cells = [O.surface_points(c, 3.0, 1.0, (0, 0), True) for c in clouds]
+    assert [int(v[0]), int(v[1])] == [c.shape[0] for c in cells]
+    ok, po, ro = O.register(cells, np.array([[0, 0, 0], [2.0, 0.0, 0.0]]), O.reg_params(cost="P2L", max_outer=4, max_inner=10))
+    assert int(v[2]) == int(ok)
+    np.testing.assert_allclose([float(x) for x in v[3:6]], po[1], atol=1e-9)
+    assert float(v[6]) == 0.1 * 0.1 and float(v[7]) == 0.01 * 0.01                 # Register's constant covariance
+    okc, cost, res, score = O.get_cost(cells, po, O.reg_params(cost="P2L", loss_limit=0.3, first_itr=0))
+    assert int(v[8]) == int(okc) and int(v[10]) == len(res)
+    np.testing.assert_allclose(float(v[9]), cost, rtol=1e-9)                        # GetCost returns the cost in `score`
+    # the single-sequence fuser fed with the two filtered clouds == the oracle's fuser
+    reg = O.reg_params(cost="P2P", loss="Huber", loss_limit=0.1, weight_opt=4, regularization=0.0)
+    fz = O.Fuser(reg, res=3.0, submap_scan_size=4, weight_intensity=True)
+    for c in clouds:
+        pose, oi = fz.process(c.copy())
+    np.testing.assert_allclose([float(x) for x in v[11:14]], pose, atol=1e-9)
+    assert int(v[14]) == oi[1]
