@@ -29,6 +29,7 @@
  */
 #ifndef CFEAR_HIP_H
 #define CFEAR_HIP_H
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -485,6 +486,30 @@ int cfear_verify_loop_candidates(cfear_ctx* ctx, const cfear_verify_job* jobs, i
  * 1 when verify_via_odometry is 0.  No context: pure host arithmetic.                                               */
 int cfear_verify_by_odometry(const double* rel_xyt, int32_t n, double odom_sigma_error, int32_t verify_via_odometry,
                              double* similarity);
+
+/* ---- caller: candidate batches sharded over the GPUs of one node, for a C++ host ------------------------------
+ * Loop-closure candidates are independent (loopclosure.cpp:658-721), so a batch shards by contiguous blocks of
+ * ceil(n / world) candidates per rank (one process, context and GPU per rank), with ONE all_gather of the fixed-size
+ * result records at the end -- rank order = candidate order.  The host owns the communicator: the collective is a
+ * callback gather(user, send, recv, bytes) that must place every rank's `bytes` bytes, rank after rank, into recv on
+ * every rank and return 0.  cfear_rccl_allgather is that callback over an ncclComm_t (RCCL over xGMI), user = a
+ * cfear_rccl_comm; librccl.so is resolved at run time.  jobs / n_jobs are the FULL candidate list on every rank and
+ * results receives all n_jobs records on every rank.  world == 1 needs no callback.                              */
+typedef int (*cfear_allgather_fn)(void* user, const void* send, void* recv_all, size_t bytes_per_rank);
+typedef struct cfear_rccl_comm { cfear_ctx* ctx; void* nccl_comm; int32_t world, pad; } cfear_rccl_comm;
+int cfear_rccl_allgather(void* user /* cfear_rccl_comm* */, const void* send, void* recv_all, size_t bytes_per_rank);
+int cfear_shard_range(int32_t n, int32_t world, int32_t rank, int32_t* lo, int32_t* hi, int32_t* per_rank);
+/* the gather step alone: local = this rank's hi - lo records; all = n_total records in candidate order */
+int cfear_gather_records(const void* local, int32_t n_total, int32_t record_bytes, int32_t world, int32_t rank,
+                         cfear_allgather_fn gather, void* user, void* all);
+int cfear_register_batch_sharded(cfear_ctx* ctx, const cfear_reg_job* jobs, int32_t n_jobs, const cfear_reg_params* par,
+                                 int32_t rank, int32_t world, cfear_allgather_fn gather, void* user,
+                                 cfear_reg_result* results);
+/* verification: ApplyConstratins (loopclosure.cpp:261-274) is redone over the gathered list, because the candidates
+ * of one query may sit on two ranks                                                                             */
+int cfear_verify_loop_candidates_sharded(cfear_ctx* ctx, const cfear_verify_job* jobs, int32_t n_jobs,
+                                         const cfear_verify_params* par, int32_t rank, int32_t world,
+                                         cfear_allgather_fn gather, void* user, cfear_verify_result* results);
 
 /* ---- caller: batched radarDriver + OdometryKeyframeFuser --------------------------------------
  * n_streams independent sequences advance one frame per call: filter (F) -> compensate (C) ->

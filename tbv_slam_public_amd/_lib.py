@@ -209,6 +209,8 @@ EXPORTS = [
     "cfear_keyframe_based_fuse", "cfear_acc_vel_sanity_check", "cfear_filter_kstrongest_legacy",
     "cfear_graph_save", "cfear_graph_load", "cfear_graph_size", "cfear_graph_node_at", "cfear_graph_destroy",
     "cfear_pose3d_from_xyt", "cfear_pose3d_to_xyt", "cfear_odometry_get_constraint",
+    "cfear_shard_range", "cfear_gather_records", "cfear_register_batch_sharded", "cfear_verify_loop_candidates_sharded",
+    "cfear_rccl_allgather",
 ]
 
 
@@ -337,6 +339,8 @@ def lib():
     L.cfear_odometry_discard_prefetch.argtypes = [vp]
     L.cfear_filter_kstrongest_legacy.argtypes = [vp, vp, C.POINTER(PolarDesc), C.c_int32, C.c_double, C.c_double, C.c_double, vp, vp,
                                                  C.c_int32]
+    L.cfear_shard_range.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+    L.cfear_gather_records.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, vp, vp, vp]
     L.cfear_graph_save.argtypes = [C.c_char_p, C.POINTER(GraphNode), C.c_int32]
     L.cfear_graph_load.argtypes = [C.c_char_p, C.POINTER(vp)]
     L.cfear_graph_size.argtypes = [vp]

@@ -44,6 +44,19 @@ int main(int argc, char** argv) {
     reg.SetParameters(4, 10);
     std::vector<Pose2d> T = {{0, 0, 0}, {2.0, 0.0, 0.0}};
     const bool ok = reg.Register({&m0, &m1}, T);
+    {
+      // the same candidate through the sharded entry a C++ loop-closure thread would call on each rank (world 1 here):
+      // it must reproduce the registration above
+      const cfear_scan* hs[2] = {m0.device(), m1.device()};
+      const double guess[6] = {0, 0, 0, 2.0, 0.0, 0.0};
+      cfear_reg_job job{hs, 2, 0, guess};
+      cfear_reg_params par;
+      cfear_reg_params_default(&par);
+      par.max_itr_association = 4; par.max_itr_solver = 10;
+      cfear_reg_result rr{};
+      ctx.check(cfear_register_batch_sharded(ctx.get(), &job, 1, &par, 0, 1, nullptr, nullptr, &rr));
+      if (rr.pose[0] != T[1].x || rr.pose[1] != T[1].y || rr.pose[2] != T[1].theta) throw CfearError(-1, "sharded entry disagrees");
+    }
     double cov[36];
     cfear_cov_sampling_params sp;
     cfear_cov_sampling_params_default(&sp);

@@ -214,3 +214,43 @@ def test_bench_refuses_more_gpus_than_visible():
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-run"],
                        capture_output=True, text=True, timeout=300, env=env2)
     assert r.returncode != 0 and "rank(s)" in (r.stderr + r.stdout)
+
+
+def test_c_abi_gather_with_a_mock_two_rank_callback():
+    """cfear_gather_records (the collective step of cfear_register_batch_sharded / cfear_verify_loop_candidates_sharded): a
+    C++ host hands in its own all_gather as a callback.  Here a mock 2-rank callback: each "rank" contributes its padded
+    block; the library must send exactly its block (zero-padded to ceil(n / world) records) and return all n records in
+    candidate order without the padding."""
+    import ctypes as C
+    lib = L.lib()
+    n, world, rec = 7, 2, 72
+    records = np.arange(n * rec, dtype=np.uint8).reshape(n, rec) % 251
+    lo, hi, per = (C.c_int32(), C.c_int32(), C.c_int32())
+    blocks, sent = {}, {}
+    for r in range(world):
+        assert lib.cfear_shard_range(n, world, r, C.byref(lo), C.byref(hi), C.byref(per)) == 0
+        assert (lo.value, hi.value, per.value) == cdist.shard_range(n, world, r)
+        pad = np.zeros((per.value, rec), np.uint8)
+        pad[:hi.value - lo.value] = records[lo.value:hi.value]
+        blocks[r] = pad.tobytes()
+    CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t)
+    for me in range(world):
+        def gather(user, send, recv, nbytes, me=me):
+            sent[me] = C.string_at(send, nbytes)
+            C.memmove(recv, b"".join(sent[me] if r == me else blocks[r] for r in range(world)), nbytes * world)
+            return 0
+        cb = CB(gather)
+        lo_, hi_, _ = cdist.shard_range(n, world, me)
+        local = np.ascontiguousarray(records[lo_:hi_])
+        out = np.zeros((n, rec), np.uint8)
+        rc = lib.cfear_gather_records(local.ctypes.data, n, rec, world, me, C.cast(cb, C.c_void_p), None, out.ctypes.data)
+        assert rc == 0
+        assert sent[me] == blocks[me]                       # the rank's own block, zero-padded
+        np.testing.assert_array_equal(out, records)
+    # world 1 needs no callback; a failing callback is an error status
+    out = np.zeros((n, rec), np.uint8)
+    assert lib.cfear_gather_records(records.ctypes.data, n, rec, 1, 0, None, None, out.ctypes.data) == 0
+    np.testing.assert_array_equal(out, records)
+    bad = CB(lambda user, send, recv, nbytes: 5)
+    assert lib.cfear_gather_records(records[:4].ctypes.data, n, rec, 2, 0, C.cast(bad, C.c_void_p), None, out.ctypes.data) != 0
+    assert lib.cfear_shard_range(5, 2, 2, C.byref(lo), C.byref(hi), None) == L.ERR_INVALID_ARGUMENT

@@ -284,3 +284,46 @@ def test_full_batch_rigid_frame_equivariance():
     np.testing.assert_allclose(b["final_cost"][ok], a["final_cost"][ok], rtol=1e-6, atol=1e-9)
     # the batch is deterministic: the same launch twice gives the same bits
     np.testing.assert_array_equal(reg.RegisterBatch(jobs)["pose"], a["pose"])
+
+
+def test_sharded_c_abi_entry_world_one_and_mock_world_two():
+    """cfear_register_batch_sharded: world 1 equals cfear_register_batch; with world 2 and a mock all_gather that supplies
+    the other rank's block (computed by a plain batch call), both "ranks" return the full, ordered result list."""
+    import ctypes as C
+    from tbv_slam_public_amd import api, _lib as L, synth
+    from oracle import pyoracle as O
+    imgs, gt, _ = synth.scene_v1(17, 4)
+    scans = []
+    for f in range(4):
+        r = api.filter_kstrongest(imgs[f], 40, 60, 0.0438, 2.5)
+        scans.append(api.MapPointNormal(r["xyzi"][0, :int(r["n_points"][0])], 3.0, (0, 0), True))
+    rng = np.random.default_rng(0)
+    jobs = []
+    for q in range(9):
+        i, j = (q % 3), (q % 3) + 1
+        jobs.append(([scans[i], scans[j]], np.array([[0, 0, 0.0], gt[j] - gt[i] + rng.normal(0, 0.2, 3) * [1, 1, 0.05]])))
+    reg = api.n_scan_normal_reg("P2L")
+    reg.SetParameters(4, 10)
+    arr, n, keep = reg.PrepareBatch(jobs)
+    ref = reg.RegisterBatch((arr, n, keep))
+    lib, ctx = api.default_context()._lib, api.default_context()
+    lib.cfear_register_batch_sharded.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p,
+                                                 C.c_void_p, C.c_void_p]
+    out = np.zeros(n, L.RESULT_DTYPE)
+    ctx.check(lib.cfear_register_batch_sharded(ctx.h, arr, n, C.byref(reg.par), 0, 1, None, None, out.ctypes.data))
+    np.testing.assert_array_equal(out, ref)
+    CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t)
+    per = (n + 1) // 2
+    for me in range(2):
+        def gather(user, send, recv, nbytes, me=me):
+            other = 1 - me
+            lo, hi = other * per, min(n, other * per + per)
+            blk = np.zeros(per, L.RESULT_DTYPE)
+            blk[:hi - lo] = ref[lo:hi]
+            parts = [C.string_at(send, nbytes), blk.tobytes()] if me == 0 else [blk.tobytes(), C.string_at(send, nbytes)]
+            C.memmove(recv, b"".join(parts), 2 * nbytes)
+            return 0
+        cb = CB(gather)
+        out = np.zeros(n, L.RESULT_DTYPE)
+        ctx.check(lib.cfear_register_batch_sharded(ctx.h, arr, n, C.byref(reg.par), me, 2, C.cast(cb, C.c_void_p), None, out.ctypes.data))
+        np.testing.assert_array_equal(out, ref)
