@@ -367,6 +367,7 @@ def main(argv=None):
     ap.add_argument("--cov-sampling", action="store_true",
                     help="odometry: also estimate every frame's covariance by cost sampling (27 GetCost per "
                          "registration, odometrykeyframefuser.cpp:203-208; off in the reference's presets)")
+    ap.add_argument("--no-profile", action="store_true", help="experiment: no per-kernel hipEvents inside the timed region")
     ap.add_argument("--dry-run", action="store_true", help="launcher test without GPUs: ranks rendezvous over gloo and exit")
     args = ap.parse_args(argv)
     maybe_self_launch(args, argv)
@@ -432,7 +433,7 @@ def main(argv=None):
     for w in range(W):
         advance(FPS, w * FPS, (poses[w * FPS:], n_cmp))
     D.barrier()
-    ctx.profile_enable(True)
+    ctx.profile_enable(not args.no_profile)
     ctx.profile_read(reset=True)
     t1 = time.perf_counter()
     tot = {"points": 0.0, "cells": 0.0, "bad": 0, "frames": 0}

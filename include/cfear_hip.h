@@ -669,6 +669,32 @@ int cfear_graph_load(const char* path, cfear_graph** out);                      
 int cfear_graph_size(const cfear_graph* g);
 int cfear_graph_node_at(const cfear_graph* g, int32_t i, cfear_graph_node* out);              /* pointers live until destroy */
 int cfear_graph_destroy(cfear_graph* g);
+/* ---- after the path: pose-graph optimisation -----------------------------------------------------
+ * Replaces tbv_slam's CeresLeastSquares::Solve (tbv_slam/src/tbv_slam/ceresoptimizer.cpp:13-113) with its
+ * PoseGraph3dErrorTerm (include/tbv_slam/ceresoptimizer.h:55-112): one 6-residual block per constraint,
+ * sqrt_information = llt(I_scaled).matrixL() with I_scaled = diag(1/odom_vxx, 1/odom_vyy, 1, 1, 1, 1/odom_vtt) (both
+ * types -- the loop_v* values are never read, :79-88) or the constraint's own information, times 1 / loop_scaling for
+ * loop constraints; no loss on odometry, CauchyLoss(0.1) on loop_appearance; mini_loop / candidate constraints are not
+ * optimised; the first node (smallest id) is constant; quaternions move on ceres::EigenQuaternionParameterization;
+ * ceres::Solve with the default trust-region LM and max_num_iterations 200.  Host code (csrc/pgo.hip says why), no
+ * context.  poses [n] in/out, ids [n] strictly ascending (the reference's node map order).                        */
+typedef struct cfear_pgo_params {        /* tbv_slam::OptimizationParamsConfig as CeresLeastSquares::Parameters sets it */
+  double loop_vxx, loop_vyy, loop_vtt, odom_vxx, odom_vyy, odom_vtt, loop_scaling;
+  int32_t replace_cov_by_identity;
+  int32_t max_num_iterations;            /* 200 (ceresoptimizer.cpp:52) */
+  double loop_loss_limit;                /* CauchyLoss(0.1) (:36) */
+} cfear_pgo_params;
+void cfear_pgo_params_default(cfear_pgo_params* p);
+typedef struct cfear_pgo_summary {
+  double initial_cost, final_cost;       /* ceres::Solver::Summary */
+  int32_t iterations;                    /* summary.iterations.size() - 1 */
+  int32_t usable;                        /* IsSolutionUsable() */
+  int32_t num_residual_blocks;
+  int32_t linear_iterations;             /* conjugate-gradient iterations over all steps */
+} cfear_pgo_summary;
+int cfear_pgo_solve(cfear_pose3d* poses, const uint64_t* ids, int32_t n, const cfear_graph_constraint* constraints,
+                    int32_t m, const cfear_pgo_params* par, cfear_pgo_summary* summary);
+
 /* OdometryKeyframeFuser::AddToGraph (odometrykeyframefuser.cpp:428-445) for `stream`: the odometry constraint from the
  * keyframe added by the LAST processed frame to the keyframe before it -- id_begin / id_end are the stream's keyframe
  * ordinals (RadarScan::counter), t_be = Tfrom^-1 * Tto, type odometry.  The reference stores information = C.inverse()

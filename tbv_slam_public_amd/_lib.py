@@ -210,8 +210,20 @@ EXPORTS = [
     "cfear_graph_save", "cfear_graph_load", "cfear_graph_size", "cfear_graph_node_at", "cfear_graph_destroy",
     "cfear_pose3d_from_xyt", "cfear_pose3d_to_xyt", "cfear_odometry_get_constraint",
     "cfear_shard_range", "cfear_gather_records", "cfear_register_batch_sharded", "cfear_verify_loop_candidates_sharded",
-    "cfear_rccl_allgather",
+    "cfear_rccl_allgather", "cfear_pgo_params_default", "cfear_pgo_solve",
 ]
+
+
+class PgoParams(C.Structure):
+    _fields_ = [("loop_vxx", C.c_double), ("loop_vyy", C.c_double), ("loop_vtt", C.c_double), ("odom_vxx", C.c_double),
+                ("odom_vyy", C.c_double), ("odom_vtt", C.c_double), ("loop_scaling", C.c_double),
+                ("replace_cov_by_identity", C.c_int32), ("max_num_iterations", C.c_int32), ("loop_loss_limit", C.c_double)]
+
+
+class PgoSummary(C.Structure):
+    _fields_ = [("initial_cost", C.c_double), ("final_cost", C.c_double), ("iterations", C.c_int32), ("usable", C.c_int32),
+                ("num_residual_blocks", C.c_int32), ("linear_iterations", C.c_int32)]
+
 
 
 class Pose3d(C.Structure):
@@ -339,6 +351,9 @@ def lib():
     L.cfear_odometry_discard_prefetch.argtypes = [vp]
     L.cfear_filter_kstrongest_legacy.argtypes = [vp, vp, C.POINTER(PolarDesc), C.c_int32, C.c_double, C.c_double, C.c_double, vp, vp,
                                                  C.c_int32]
+    L.cfear_pgo_params_default.argtypes = [C.POINTER(PgoParams)]
+    L.cfear_pgo_params_default.restype = None
+    L.cfear_pgo_solve.argtypes = [vp, vp, C.c_int32, vp, C.c_int32, C.POINTER(PgoParams), C.POINTER(PgoSummary)]
     L.cfear_shard_range.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     L.cfear_gather_records.argtypes = [vp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, vp, vp, vp]
     L.cfear_graph_save.argtypes = [C.c_char_p, C.POINTER(GraphNode), C.c_int32]

@@ -1414,3 +1414,36 @@ def LoadSimpleGraph(path):
         return out
     finally:
         lib.cfear_graph_destroy(h)
+
+
+def pose_graph_optimize(poses, ids, constraints, **par):
+    """CeresLeastSquares::Solve (tbv_slam/src/tbv_slam/ceresoptimizer.cpp:13-62) over the nodes `poses` ([n, 7] = p, q(x, y, z, w),
+    or [n, 3] planar (x, y, theta)) with node ids `ids` (ascending) and `constraints` (SaveSimpleGraph's constraint dicts:
+    id_begin, id_end, t_be, information, type).  Keyword overrides: the cfear_pgo_params fields.  Host code, no GPU.
+    Returns (poses [n, 7], summary dict)."""
+    lib = L.lib()
+    poses = np.asarray(poses, np.float64)
+    n = poses.shape[0]
+    arr = (L.Pose3d * n)()
+    for i in range(n):
+        arr[i] = _pose3d(poses[i])
+    ida = np.ascontiguousarray(ids, np.uint64)
+    carr = (L.GraphConstraint * max(len(constraints), 1))()
+    for j, c in enumerate(constraints):
+        carr[j].id_begin, carr[j].id_end = int(c["id_begin"]), int(c["id_end"])
+        carr[j].t_be = _pose3d(c.get("t_be"))
+        info = np.asarray(c.get("information", np.eye(6)), np.float64).reshape(-1)
+        for k in range(36):
+            carr[j].information[k] = float(info[k])
+        carr[j].type = int(c.get("type", 0))
+    p = L.PgoParams()
+    lib.cfear_pgo_params_default(C.byref(p))
+    for k, v in par.items():
+        setattr(p, k, type(getattr(p, k))(v))
+    s = L.PgoSummary()
+    rc = lib.cfear_pgo_solve(arr, ida.ctypes.data, n, carr, len(constraints), C.byref(p), C.byref(s))
+    if rc != L.OK:
+        raise L.CfearError(rc, "cfear_pgo_solve")
+    out = np.array([list(a.p) + list(a.q) for a in arr])
+    return out, dict(initial_cost=s.initial_cost, final_cost=s.final_cost, iterations=s.iterations, usable=bool(s.usable),
+                     num_residual_blocks=s.num_residual_blocks, linear_iterations=s.linear_iterations)

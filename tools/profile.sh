@@ -1,34 +1,52 @@
 #!/bin/bash
 # rocprofv3 passes behind the numbers in bench.py / DESIGN.md.  Run on the GPU box from the repo root:
-#   bash tools/profile.sh r01
-# Writes raw output under gpurun_out/prof_<tag>/ and the judged summaries under gpurun_out/profiles_<tag>/
-# (copy those into profiles/).  Counters are collected in their own passes (no trace domains mixed in).
+#   bash tools/profile.sh r02
+# Raw output goes to /tmp (a kernel trace of torch's input generation is hundreds of MB); the judged summaries land under
+# gpurun_out/profiles_<tag>/ (copy them into profiles/<tag>/).  Counters are collected in their own passes (no trace
+# domains mixed in).
 set -u
-TAG=${1:-r01}
+TAG=${1:-r02}
 ROOT=$(pwd)
-OUT=$ROOT/gpurun_out/prof_$TAG
+OUT=/tmp/prof_$TAG
 SUM=$ROOT/gpurun_out/profiles_$TAG
-mkdir -p "$OUT" "$SUM"
+rm -rf "$OUT" "$SUM"; mkdir -p "$OUT" "$SUM"
 export TMPDIR=/tmp
 make -C oracle -s
-# 1. kernel trace + stats of the bench command
-( cd /tmp && rocprofv3 --output-format csv --kernel-trace --stats -d "$OUT/bench" -o bench -- python "$ROOT/bench.py" --no-cpu-baseline --steps 10 > "$SUM/bench_stdout.json" 2> "$OUT/bench.err" )
-find "$OUT/bench" -name "*kernel_stats.csv" -exec cp {} "$SUM/bench_kernel_stats.csv" \;
-# 1b. the neighbouring workloads: candidate verification (register + coral + cost-only) and the bins-major
-#     input layout (adds rotate_ccw_rows_kernel)
+keep_ours() {   # kernel_stats.csv of a run -> only this library's kernels (torch's input generation dominates the raw file)
+  python - "$1" "$2" <<'PY'
+import csv, glob, sys
+src = glob.glob(sys.argv[1] + "/**/*kernel_stats.csv", recursive=True)
+rows = list(csv.reader(open(src[0]))) if src else []
+ours = ("kstrongest_rows_kernel", "kstrong_cloud_kernel", "cacfar_", "surface_", "register_kernel", "assoc_kernel", "eval_kernel",
+        "coral_kernel", "sc_descriptor", "sc_distance", "rotate_ccw", "compensate", "legacy_", "scan_sort", "cells_to_slab",
+        "slab_to_cells", "closest_idx")
+keep = [rows[0]] + [r for r in rows[1:] if any(k in r[0] for k in ours)] if rows else []
+csv.writer(open(sys.argv[2], "w")).writerows(keep)
+PY
+}
+# 1. kernel trace + stats of the default bench command (headline launches + the extra passes)
+( cd /tmp && rocprofv3 --output-format csv --kernel-trace --stats -d "$OUT/bench" -o bench -- python "$ROOT/bench.py" --no-cpu-baseline --no-extras > "$SUM/bench_stdout.json" 2> "$OUT/bench.err" )
+keep_ours "$OUT/bench" "$SUM/bench_kernel_stats.csv"; rm -rf "$OUT/bench"
+( cd /tmp && rocprofv3 --output-format csv --kernel-trace --stats -d "$OUT/dense" -o d -- python "$ROOT/bench.py" --no-cpu-baseline --no-extras --dense --streams 1024 --sequences 64 --steps 4 --frames-per-step 8 > "$SUM/bench_dense_stdout.json" 2> "$OUT/dense.err" )
+keep_ours "$OUT/dense" "$SUM/bench_dense_kernel_stats.csv"; rm -rf "$OUT/dense"
+# 1b. the neighbouring workloads
 ( cd /tmp && rocprofv3 --output-format csv --kernel-trace --stats -d "$OUT/verify" -o v -- python "$ROOT/bench.py" --workload verify --steps 5 --warmup 2 > "$SUM/verify_stdout.json" 2> "$OUT/verify.err" )
-find "$OUT/verify" -name "*kernel_stats.csv" -exec cp {} "$SUM/verify_kernel_stats.csv" \;
-( cd /tmp && rocprofv3 --output-format csv --kernel-trace --stats -d "$OUT/binsmajor" -o b -- python "$ROOT/bench.py" --no-cpu-baseline --bins-major --steps 5 > "$SUM/bins_major_stdout.json" 2> "$OUT/binsmajor.err" )
-find "$OUT/binsmajor" -name "*kernel_stats.csv" -exec cp {} "$SUM/bins_major_kernel_stats.csv" \;
-# 2. polar sweep alone: kernel trace, then PMC passes (FETCH_SIZE and WRITE_SIZE do not fit one pass)
-for DATA in scene uniform; do
+keep_ours "$OUT/verify" "$SUM/verify_kernel_stats.csv"; rm -rf "$OUT/verify"
+( cd /tmp && rocprofv3 --output-format csv --kernel-trace --stats -d "$OUT/lc" -o v -- python "$ROOT/bench.py" --workload loopclosure --steps 20 --warmup 3 > "$SUM/loopclosure_stdout.json" 2> "$OUT/lc.err" )
+keep_ours "$OUT/lc" "$SUM/loopclosure_kernel_stats.csv"; rm -rf "$OUT/lc"
+( cd /tmp && rocprofv3 --output-format csv --kernel-trace --stats -d "$OUT/binsmajor" -o b -- python "$ROOT/bench.py" --no-cpu-baseline --no-extras --bins-major --steps 3 --frames-per-step 8 > "$SUM/bins_major_stdout.json" 2> "$OUT/binsmajor.err" )
+keep_ours "$OUT/binsmajor" "$SUM/bins_major_kernel_stats.csv"; rm -rf "$OUT/binsmajor"
+# 2. polar sweep alone: kernel trace on the three data sets, then PMC passes (FETCH_SIZE and WRITE_SIZE do not fit one pass)
+for DATA in scene dense uniform; do
   ( cd /tmp && rocprofv3 --output-format csv --kernel-trace --stats -d "$OUT/filter_$DATA" -o f -- python "$ROOT/tools/bench_filter.py" --data $DATA > "$SUM/filter_${DATA}_stdout.txt" 2> "$OUT/filter_$DATA.err" )
-  find "$OUT/filter_$DATA" -name "*kernel_stats.csv" -exec cp {} "$SUM/filter_${DATA}_kernel_stats.csv" \;
+  keep_ours "$OUT/filter_$DATA" "$SUM/filter_${DATA}_kernel_stats.csv"; rm -rf "$OUT/filter_$DATA"
 done
 ( cd /tmp && rocprofv3 --output-format csv --pmc FETCH_SIZE -d "$OUT/pmc_fetch" -o p -- python "$ROOT/tools/bench_filter.py" --iters 5 > /dev/null 2> "$OUT/pmc_fetch.err" )
 ( cd /tmp && rocprofv3 --output-format csv --pmc WRITE_SIZE -d "$OUT/pmc_write" -o p -- python "$ROOT/tools/bench_filter.py" --iters 5 > /dev/null 2> "$OUT/pmc_write.err" )
 ( cd /tmp && rocprofv3 --output-format csv --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU -d "$OUT/pmc_sq" -o p -- python "$ROOT/tools/bench_filter.py" --iters 5 > /dev/null 2> "$OUT/pmc_sq.err" )
+( cd /tmp && rocprofv3 --output-format csv --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU -d "$OUT/pmc_sq_dense" -o p -- python "$ROOT/tools/bench_filter.py" --iters 5 --data dense > /dev/null 2> "$OUT/pmc_sq_dense.err" )
 # whole pipeline under the SQ counters, SMALL run (counter collection serialises every dispatch)
-( cd /tmp && timeout 300 rocprofv3 --output-format csv --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU -d "$OUT/pmc_pipe" -o p -- python "$ROOT/bench.py" --no-cpu-baseline --steps 3 --warmup 2 --streams 256 > /dev/null 2> "$OUT/pmc_pipe.err" )
-python "$ROOT/tools/summarize_pmc.py" "$OUT" > "$SUM/pmc_summary.txt" 2>&1
+( cd /tmp && timeout 600 rocprofv3 --output-format csv --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU -d "$OUT/pmc_pipe" -o p -- python "$ROOT/bench.py" --no-cpu-baseline --no-extras --steps 1 --warmup 1 --frames-per-step 2 --streams 256 --sequences 32 > /dev/null 2> "$OUT/pmc_pipe.err" )
+python "$ROOT/tools/summarize_pmc.py" "$OUT" "$SUM/pmc_traffic.json" > "$SUM/pmc_summary.txt" 2>&1
+rm -rf "$OUT"
 ls -la "$SUM"
