@@ -81,6 +81,11 @@ struct TmpCell {                              // one candidate cell per voxel (b
   int32_t nsamples, valid;
 };
 
+// Fast pipeline: what surface_sort_kernel leaves per voxel in the TmpCell slot (the first 64 of its 104 bytes) -- the raw
+// moments of the neighbourhood; surface_finish_kernel turns them into the cell.
+struct CellMom { double s0, s1x, s1y, sxx, sxy, syy; float cx, cy; int32_t cnt, pad; };
+static_assert(sizeof(CellMom) <= sizeof(TmpCell), "CellMom lives in the TmpCell slot");
+
 // Per-scan global scratch (one region per job, shared by the fast pipeline and the single-kernel fallback):
 //   [0, 256)            SurfHdr
 //   + 0       float4[N]    sorted points (x, y, weight, -)
@@ -139,6 +144,30 @@ __device__ __forceinline__ int row16_sum_i32(int v) {
   return v;
 }
 
+// all-reduce over aligned groups of G lanes (G = 4: quad, G = 16: DPP row); every lane ends with the same sum
+template <int G> __device__ __forceinline__ int group_sum_i32(int v) {
+  v += __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xf, 0xf, false);             // quad_perm [1,0,3,2]
+  v += __builtin_amdgcn_update_dpp(v, v, 0x4E, 0xf, 0xf, false);             // quad_perm [2,3,0,1]
+  if (G == 16) {
+    v += __builtin_amdgcn_update_dpp(v, v, 0x141, 0xf, 0xf, false);          // row_half_mirror
+    v += __builtin_amdgcn_update_dpp(v, v, 0x140, 0xf, 0xf, false);          // row_mirror
+  }
+  return v;
+}
+template <int CTRL> __device__ __forceinline__ double dpp_f64(double v) {
+  const long long b = __double_as_longlong(v);
+  int lo = (int)b, hi = (int)(b >> 32);
+  lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
+  hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
+  return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+}
+template <int G> __device__ __forceinline__ double group_sum_f64(double v) {
+  v += dpp_f64<0xB1>(v);
+  v += dpp_f64<0x4E>(v);
+  if (G == 16) { v += dpp_f64<0x141>(v); v += dpp_f64<0x140>(v); }
+  return v;
+}
+
 // utils.h:28-32
 __device__ __forceinline__ double get_rel_time_stamp(double x, double y, bool ccw) {
   const double a = atan2(y, x);
@@ -151,16 +180,54 @@ __device__ __forceinline__ double get_rel_time_stamp(double x, double y, bool cc
 // delta = atan(t) = t to double precision for t = (y c - x s) / (x c + y s).  One division instead of an fp64 atan2;
 // the result agrees with libm's atan2 to ~1 ulp, the level at which device and host libm differ anyway.
 __device__ __forceinline__ double rel_time_stamp_known_row(double x, double y, double th, double c, double s, bool ccw) {
-  const double a_full = th + (y * c - x * s) / (x * c + y * s);         // in (0, 2 pi]
+  // delta = num / den with den = rho (1 + O(1e-7)) > 0: a float reciprocal refined by one Newton step carries ~1e-14
+  // relative error on a term that is itself ~1e-7 of th -- far below the last bit of th + delta
+  const double den = x * c + y * s;
+  double r = (double)__builtin_amdgcn_rcpf((float)den);
+  r = r * (2.0 - den * r);
+  const double a_full = th + (y * c - x * s) * r;                       // in (0, 2 pi]
   const double a = a_full > M_PI ? a_full - 2 * M_PI : a_full;          // atan2's range
-  const double d = ((a > 0.00001 ? a : (2 * M_PI + a)) / (2 * M_PI));
+  const double d = (a > 0.00001 ? a : (2 * M_PI + a)) * (1.0 / (2 * M_PI));
   return ccw ? -(d - 0.5) : (d - 0.5);
+}
+
+// sin / cos of |a| <= 0.5 without libm's range reduction: Taylor series to x^17 / x^16 (truncation < 1e-22), Horner in
+// fp64 -- within an ulp or two of libm, the level at which device and host libm differ anyway.
+__device__ __forceinline__ void sincos_small(const double a, double* s, double* c) {
+  const double z = a * a;
+  double ps = 2.8114572543455206e-15;                 // 1/17!
+  ps = fma(ps, z, -7.6471637318198164e-13);           // -1/15!
+  ps = fma(ps, z, 1.6059043836821613e-10);            // 1/13!
+  ps = fma(ps, z, -2.5052108385441720e-08);           // -1/11!
+  ps = fma(ps, z, 2.7557319223985893e-06);            // 1/9!
+  ps = fma(ps, z, -1.9841269841269841e-04);           // -1/7!
+  ps = fma(ps, z, 8.3333333333333332e-03);            // 1/5!
+  ps = fma(ps, z, -1.6666666666666666e-01);           // -1/3!
+  *s = fma(a * z, ps, a);
+  double pc = 4.7794773323873853e-14;                 // 1/16!
+  pc = fma(pc, z, -1.1470745597729725e-11);           // -1/14!
+  pc = fma(pc, z, 2.0876756987868100e-09);            // 1/12!
+  pc = fma(pc, z, -2.7557319223985888e-07);           // -1/10!
+  pc = fma(pc, z, 2.4801587301587302e-05);            // 1/8!
+  pc = fma(pc, z, -1.3888888888888889e-03);           // -1/6!
+  pc = fma(pc, z, 4.1666666666666664e-02);            // 1/4!
+  *c = fma(z * z, pc, fma(z, -0.5, 1.0));
 }
 
 // utils.cpp:96-107
 __device__ __forceinline__ float4 compensate_point_d(float4 p, const double d, const double mot[3]) {
   double s_1, c_1;
   sincos(d * mot[2], &s_1, &c_1);
+  const double tx = d * mot[0], ty = d * mot[1];
+  const double x = (double)p.x, y = (double)p.y;
+  p.x = (float)((c_1 * x + (-s_1) * y) + tx);
+  p.y = (float)((s_1 * x + c_1 * y) + ty);
+  return p;
+}
+
+__device__ __forceinline__ float4 compensate_point_small(float4 p, const double d, const double mot[3]) {
+  double s_1, c_1;
+  sincos_small(d * mot[2], &s_1, &c_1);
   const double tx = d * mot[0], ty = d * mot[1];
   const double x = (double)p.x, y = (double)p.y;
   p.x = (float)((c_1 * x + (-s_1) * y) + tx);
@@ -416,13 +483,12 @@ __device__ void surface_big_tail(const SurfJob& job, const SurfCommon& cm, const
       const int p0 = (int)scr.vs[a], p1 = (int)scr.vs[b];
       for (int p = p0; p < p1; p++) { const float4 q = scr.spt[p]; accum_point(mo, c, cx, cy, q.x, q.y, q.z, cm.r2, wi); }
     }
-    TmpCell tc;
-    const int valid = finish_cell(mo, cx, cy, cm.origin[0], cm.origin[1], tc);
-    if (valid) scr.tmp[v] = tc;
-    scr.coff[v] = valid;
+    CellMom* cmo = (CellMom*)&scr.tmp[v];               // surface_finish_kernel turns the moments into the cell
+    cmo->s0 = mo.s0; cmo->s1x = mo.s1x; cmo->s1y = mo.s1y; cmo->sxx = mo.sxx; cmo->sxy = mo.sxy; cmo->syy = mo.syy;
+    cmo->cx = c.x; cmo->cy = c.y; cmo->cnt = mo.cnt;
   }
   if (tid == 0) {
-    scr.hdr->route = kRouteFast;                        // cells computed; compaction + x-sort pending
+    scr.hdr->route = kRouteFast;                        // moments computed; cells + compaction + x-sort pending
     scr.hdr->n = n; scr.hdr->V = V; scr.hdr->dbx = dbx; scr.hdr->dby = dby;
   }
 }
@@ -838,40 +904,45 @@ __global__ __launch_bounds__(kFastThreads, 4) void surface_sort_kernel(const Sur
   float4* pts = job.xyzi;
   STAMP(1);
   // ---- (b) polar -> Cartesian (rows mode), motion compensation, bounding box ------------------------------------
-  float mnx = FLT_MAX, mny = FLT_MAX, mxx = -FLT_MAX, mxy = -FLT_MAX;
-  for (int i0 = tid; i0 < n; i0 += 4 * NT) {
-    float4 p[4];
-    double dts[4];                                      // rows mode: relative time stamp from the known azimuth
-#pragma unroll
-    for (int u = 0; u < 4; u++) {
-      const int i = i0 + u * NT;
-      dts[u] = 0.0;
-      if (i < n) {
-        if (job.row_pts) {                              // row of point i: the last r with rowoff[r] <= i
-          int lo = 0, hi = job.rows;
-          while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (rowoff[mid] <= i) lo = mid; else hi = mid; }
-          const uint32_t key = job.row_pts[(size_t)lo * job.k + (i - rowoff[lo])];
-          const double range_res_half = cm.range_res / 2.0;
-          const double rho = range_res_half + cm.range_res * (double)(int)(key & 0xFFFFFFu);   // radar_filters.cpp:324-330
-          const double ct = cm.cos_t[lo], st = cm.sin_t[lo];
-          p[u] = make_float4((float)(rho * ct), (float)(rho * st), 0.f, (float)(key >> 24));
-          if (job.compensate) {
-            const double th = ((double)(lo + 1) / (double)job.rows) * 2. * M_PI;              // radar_filters.cpp:317
-            dts[u] = rel_time_stamp_known_row((double)p[u].x, (double)p[u].y, th, ct, st, cm.ccw != 0);
-          }
-        } else {
-          p[u] = pts[i];
-        }
-      }
+  // rows mode: the azimuth row of every point as a u16 table behind rowoff (one thread per row fills its <= k slots;
+  // a per-point binary search over rowoff cost nine dependent LDS reads)
+  unsigned short* rid = (unsigned short*)(smem + (((size_t)(job.rows + 1) * 4 + 15) & ~(size_t)15));
+  if (job.row_pts) {
+    for (int r = tid; r < job.rows; r += NT) {
+      const int o = rowoff[r], e = rowoff[r + 1];
+      for (int q = o; q < e; q++) rid[q] = (unsigned short)r;
     }
+    __syncthreads();
+  }
+  float mnx = FLT_MAX, mny = FLT_MAX, mxx = -FLT_MAX, mxy = -FLT_MAX;
+  const double range_res_half = cm.range_res / 2.0;
+  const double th_step = (2. * M_PI) / (double)max(job.rows, 1);
+  // |d| <= 0.5: the rotation angle d * mot[2] stays inside the polynomial's range for every sane motion (job-uniform)
+  const bool small_rot = fabs(job.mot[2]) <= 1.0;
+  for (int i0 = tid; i0 < n; i0 += 4 * NT) {
 #pragma unroll
     for (int u = 0; u < 4; u++) {
       const int i = i0 + u * NT;
       if (i < n) {
-        if (job.compensate) p[u] = job.row_pts ? compensate_point_d(p[u], dts[u], job.mot) : compensate_point(p[u], job.mot, cm.ccw != 0);
-        if (job.compensate || job.row_pts) pts[i] = p[u];
-        mnx = fminf(mnx, p[u].x); mxx = fmaxf(mxx, p[u].x);
-        mny = fminf(mny, p[u].y); mxy = fmaxf(mxy, p[u].y);
+        float4 p;
+        if (job.row_pts) {
+          const int row = rid[i];
+          const uint32_t key = job.row_pts[(size_t)row * job.k + (i - rowoff[row])];
+          const double rho = range_res_half + cm.range_res * (double)(int)(key & 0xFFFFFFu);   // radar_filters.cpp:324-330
+          const double ct = cm.cos_t[row], st = cm.sin_t[row];
+          p = make_float4((float)(rho * ct), (float)(rho * st), 0.f, (float)(key >> 24));
+          if (job.compensate) {
+            const double th = (double)(row + 1) * th_step;                                     // radar_filters.cpp:317
+            const double d = rel_time_stamp_known_row((double)p.x, (double)p.y, th, ct, st, cm.ccw != 0);
+            p = small_rot ? compensate_point_small(p, d, job.mot) : compensate_point_d(p, d, job.mot);
+          }
+          pts[i] = p;
+        } else {
+          p = pts[i];
+          if (job.compensate) { p = compensate_point(p, job.mot, cm.ccw != 0); pts[i] = p; }
+        }
+        mnx = fminf(mnx, p.x); mxx = fmaxf(mxx, p.x);
+        mny = fminf(mny, p.y); mxy = fmaxf(mxy, p.y);
       }
     }
   }
@@ -1008,81 +1079,173 @@ __global__ __launch_bounds__(kFastThreads, 4) void surface_sort_kernel(const Sur
   __threadfence_block();
   const bool wbyte = __syncthreads_and(w_small ? 1 : 0) != 0;
   STAMP(7);
-  // ---- (h) cells: one lane per voxel, slab by slab.  A slab = the voxels of grid rows [ya, yb) whose candidate points
-  //      (rows ya - 1 .. yb, one contiguous range of the sorted array) fit the staging area; a sparse scan needs two
-  //      slabs, a 16 000-point scan five.  Neighbour runs are O(1) look-ups: the points of cells [c0, c1] of one grid
-  //      row are the run [points before c0, points before c1 + 1). ------------------------------------------------
+  // ---- (h) neighbourhood moments of every voxel, slab by slab.  A slab = the voxels of grid rows [ya, yb) whose
+  //      candidate points (rows ya - 1 .. yb, one contiguous range of the sorted array) fit the staging area; a sparse
+  //      scan is one slab, a 16 000-point scan five.  Neighbour runs are O(1) look-ups: the points of cells [c0, c1] of
+  //      one grid row are the run [points before c0, points before c1 + 1).
+  //      Voxel loads are very uneven (walls: a few voxels hold hundreds of points, half of the voxels see < 6
+  //      candidates and cannot become cells), and one lane per voxel in grid order left ~85 % of the lanes idle behind
+  //      the heaviest voxel of each wavefront.  So per slab: classify the voxels by candidate count C into power-of-two
+  //      buckets (LDS counters), list them heaviest first, and give a voxel 16 lanes (C > 64), 4 lanes (16 < C <= 64)
+  //      or one lane; group partial sums are combined with DPP all-reduces.  The fp64 sums of a split voxel are then
+  //      added in a different order than the oracle's sequential loop -- differences of a few ulp, inside the 1e-9
+  //      tolerance the cell tests carry; the float voxel centroid stays a sequential sum (bit-exact).
   auto pbefore = [&](int c) { const int o = ord16[c]; return o ? (int)vs16[o - 1] : 0; };    // points in cells < c
   float2* lxy = (float2*)(smem + ord2_off);
+  int* bucket = red_i;                                                 // [16] counters, then cursors (red_i is free here)
+  constexpr int kSlabVoxels = 4 * NT;                                  // voxels per slab: their (bucket, slot) stay in registers
   // Staged point: (x, y) + weight.  Radar intensities are integers, so max(I - 60, 0) normally fits ONE byte (9 bytes
-  // per point: a sparse scan, n <~ 5500, is then a single slab); clouds with other intensities keep a float weight.
+  // per point); clouds with other intensities keep a float weight.
   auto cells_phase = [&](auto wb_tag) -> bool {                        // compiled for both weight formats
   constexpr bool WB = decltype(wb_tag)::value;
-  const int cap_pts = (int)((kFastLds - 512 - ord2_off) / (WB ? 9 : 12)) & ~3;
-  uint8_t* lw = (uint8_t*)(smem + ord2_off + (size_t)cap_pts * 8);
-  float* lwf = (float*)lw;
+  constexpr int PB = WB ? 9 : 12;
+  const size_t avail = kFastLds - 512 - ord2_off;
   const bool wi = cm.weight_intensity != 0;
   for (int ya = 0; ya < dby;) {                                       // block-uniform
     const int P0 = pbefore(max(ya - 1, 0) * dbx);
-    int lo = ya + 1, hi = dby;                                        // largest yb in [ya + 1, dby] whose range fits
-    if (pbefore(min(lo + 1, dby) * dbx) - P0 > cap_pts) { hand_over(n, 1); return false; }   // three grid rows exceed the staging area
+    const int vbeg = ord16[ya * dbx];
+    // a slab fits when its points (PB bytes each, padded) and its voxel list (2 bytes each) fit the staging area
+    auto fits = [&](int yb) {
+      const int np = pbefore(min(yb + 1, dby) * dbx) - P0, nv = (int)ord16[yb * dbx] - vbeg;
+      return nv <= kSlabVoxels && (size_t)((np + 3) & ~3) * PB + (size_t)nv * 2 + 16 <= avail;
+    };
+    int lo = ya + 1, hi = dby;                                        // largest yb in [ya + 1, dby] that fits
+    if (!fits(lo)) { hand_over(n, 1); return false; }                 // three grid rows exceed the staging area
     while (lo < hi) {
       const int mid = (lo + hi + 1) >> 1;
-      if (pbefore(min(mid + 1, dby) * dbx) - P0 <= cap_pts) lo = mid; else hi = mid - 1;
+      if (fits(mid)) lo = mid; else hi = mid - 1;
     }
     const int yb = lo;
     const int P1 = pbefore(min(yb + 1, dby) * dbx);
+    const int vend = ord16[yb * dbx];
+    const int cap_pts = (P1 - P0 + 3) & ~3;
+    uint8_t* lw = (uint8_t*)(smem + ord2_off + (size_t)cap_pts * 8);
+    float* lwf = (float*)lw;
+    unsigned short* vlist = (unsigned short*)(smem + ord2_off + (((size_t)cap_pts * PB + 15) & ~(size_t)15));
     for (int i = tid; i < P1 - P0; i += NT) {
       const float4 q = scr.spt[P0 + i];
       lxy[i] = make_float2(q.x, q.y);
       if (WB) lw[i] = (uint8_t)q.z; else lwf[i] = q.z;
     }
+    if (tid < 16) bucket[tid] = 0;
     __syncthreads();
-    const int vbeg = ord16[ya * dbx], vend = ord16[yb * dbx];
-    for (int v = vbeg + tid; v < vend; v += NT) {
+    // neighbour runs of voxel v (relative to the staging area) and its own run
+    auto runs_of = [&](int v, int* r0, int* r1, int& s, int& e) {
       const uint32_t key = scr.vkey[v];
-      const int s = (v ? (int)vs16[v - 1] : 0) - P0, e = (int)vs16[v] - P0;
+      s = (v ? (int)vs16[v - 1] : 0) - P0; e = (int)vs16[v] - P0;
       const int iy = (int)(key / (uint32_t)dbx), ix = (int)(key - (uint32_t)iy * (uint32_t)dbx);
       const int x0 = max(ix - 1, 0), x1 = min(ix + 1, dbx - 1);
-      int r0[3], r1[3];
 #pragma unroll
       for (int d = 0; d < 3; d++) {
         const int yy = iy - 1 + d;
         r0[d] = r1[d] = 0;
         if (yy >= 0 && yy < dby) { r0[d] = pbefore(yy * dbx + x0) - P0; r1[d] = pbefore(yy * dbx + x1 + 1) - P0; }
       }
-      // voxel centroid: sequential float sums in sorted (= input) order, bit-exact with pcl::CentroidPoint
+    };
+    // -- classify: bucket b = ceil(log2(C)) in [3, 12] for C >= 6 candidates (an upper bound on the neighbour count)
+    int kb[4], slot[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int v = vbeg + tid + u * NT;
+      kb[u] = 0; slot[u] = 0;
+      if (v < vend) {
+        int r0[3], r1[3], sdum, edum;
+        runs_of(v, r0, r1, sdum, edum);
+        const int C = (r1[0] - r0[0]) + (r1[1] - r0[1]) + (r1[2] - r0[2]);
+        if (C >= 6) {
+          kb[u] = min(12, 32 - __clz(C - 1));
+          slot[u] = atomicAdd(&bucket[kb[u]], 1);
+        } else {
+          ((CellMom*)&scr.tmp[v])->cnt = 0;                               // cannot reach 6 neighbours (pointnormal.cpp:291)
+        }
+      }
+    }
+    __syncthreads();
+    int boff[13];                                                       // list offset of bucket b: heaviest first
+    {
+      int run = 0;
+#pragma unroll
+      for (int b = 12; b >= 3; b--) { boff[b] = run; run += bucket[b]; }
+      boff[2] = run;                                                    // = list length
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      if (kb[u]) {
+        int off = 0;
+#pragma unroll
+        for (int b = 3; b <= 12; b++) off = kb[u] == b ? boff[b] : off;
+        vlist[off + slot[u]] = (unsigned short)(tid + u * NT);
+      }
+    }
+    const int n16 = boff[6], n4 = boff[4], nlist = boff[2];             // C > 64 | 16 < C <= 64 | 6 <= C <= 16
+    __syncthreads();
+    // -- centroids of the split voxels: sequential float sums in sorted (= input) order, bit-exact with
+    //    pcl::CentroidPoint; one lane per voxel, handed to the voxel's lane group through its scratch slot
+    for (int idx = tid; idx < n4; idx += NT) {
+      const int v = vbeg + vlist[idx];
+      const int s = (v ? (int)vs16[v - 1] : 0) - P0, e = (int)vs16[v] - P0;
       float ax = 0.f, ay = 0.f;
       for (int p = s; p < e; p++) { const float2 q = lxy[p]; ax = __fadd_rn(ax, q.x); ay = __fadd_rn(ay, q.y); }
       const float cnt = (float)(e - s);
-      const float2 c = make_float2(__fdiv_rn(ax, cnt), __fdiv_rn(ay, cnt));
-      int valid = 0;
-      if ((r1[0] - r0[0]) + (r1[1] - r0[1]) + (r1[2] - r0[2]) >= 6) {    // upper bound on the neighbour count
+      CellMom* cmo = (CellMom*)&scr.tmp[v];
+      cmo->cx = __fdiv_rn(ax, cnt); cmo->cy = __fdiv_rn(ay, cnt);
+    }
+    __threadfence_block();
+    __syncthreads();
+    // -- moments
+    auto tier = [&](auto g_tag, const int lbeg, const int lend) {
+      constexpr int G = decltype(g_tag)::value;
+      const int sub = tid & (G - 1);
+      for (int idx = lbeg + tid / G; idx < lend; idx += NT / G) {
+        const int v = vbeg + vlist[idx];
+        int r0[3], r1[3], s, e;
+        runs_of(v, r0, r1, s, e);
+        CellMom* cmo = (CellMom*)&scr.tmp[v];
+        float2 c;
+        if (G == 1) {
+          float ax = 0.f, ay = 0.f;
+          for (int p = s; p < e; p++) { const float2 q = lxy[p]; ax = __fadd_rn(ax, q.x); ay = __fadd_rn(ay, q.y); }
+          const float cnt = (float)(e - s);
+          c = make_float2(__fdiv_rn(ax, cnt), __fdiv_rn(ay, cnt));
+        } else {
+          c = make_float2(cmo->cx, cmo->cy);
+        }
         const double cx = (double)c.x, cy = (double)c.y;
         Moments mo{0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
 #pragma unroll
         for (int d = 0; d < 3; d++) {
-          int p = r0[d];
-          for (; p + 3 < r1[d]; p += 4) {                               // four independent LDS reads in flight
-            const float2 qa = lxy[p], qb = lxy[p + 1], qc = lxy[p + 2], qd = lxy[p + 3];
-            float wa = 0.f, wb = 0.f, wc = 0.f, wd = 0.f;
-            if (wi) {
-              if (WB) { wa = (float)lw[p]; wb = (float)lw[p + 1]; wc = (float)lw[p + 2]; wd = (float)lw[p + 3]; }
-              else { wa = lwf[p]; wb = lwf[p + 1]; wc = lwf[p + 2]; wd = lwf[p + 3]; }
+          int p = r0[d] + sub;
+          if (G == 1) {
+            for (; p + 3 < r1[d]; p += 4) {                             // four independent LDS reads in flight
+              const float2 qa = lxy[p], qb = lxy[p + 1], qc = lxy[p + 2], qd = lxy[p + 3];
+              float wa = 0.f, wb = 0.f, wc = 0.f, wd = 0.f;
+              if (wi) {
+                if (WB) { wa = (float)lw[p]; wb = (float)lw[p + 1]; wc = (float)lw[p + 2]; wd = (float)lw[p + 3]; }
+                else { wa = lwf[p]; wb = lwf[p + 1]; wc = lwf[p + 2]; wd = lwf[p + 3]; }
+              }
+              accum_point(mo, c, cx, cy, qa.x, qa.y, wa, cm.r2, wi);
+              accum_point(mo, c, cx, cy, qb.x, qb.y, wb, cm.r2, wi);
+              accum_point(mo, c, cx, cy, qc.x, qc.y, wc, cm.r2, wi);
+              accum_point(mo, c, cx, cy, qd.x, qd.y, wd, cm.r2, wi);
             }
-            accum_point(mo, c, cx, cy, qa.x, qa.y, wa, cm.r2, wi);
-            accum_point(mo, c, cx, cy, qb.x, qb.y, wb, cm.r2, wi);
-            accum_point(mo, c, cx, cy, qc.x, qc.y, wc, cm.r2, wi);
-            accum_point(mo, c, cx, cy, qd.x, qd.y, wd, cm.r2, wi);
           }
-          for (; p < r1[d]; p++) { const float2 q = lxy[p]; accum_point(mo, c, cx, cy, q.x, q.y, wi ? (WB ? (float)lw[p] : lwf[p]) : 0.f, cm.r2, wi); }
+          for (; p < r1[d]; p += G) { const float2 q = lxy[p]; accum_point(mo, c, cx, cy, q.x, q.y, wi ? (WB ? (float)lw[p] : lwf[p]) : 0.f, cm.r2, wi); }
         }
-        TmpCell tc;
-        valid = finish_cell(mo, cx, cy, cm.origin[0], cm.origin[1], tc);
-        if (valid) scr.tmp[v] = tc;
+        if (G > 1) {
+          mo.cnt = group_sum_i32<G>(mo.cnt);
+          mo.s0 = group_sum_f64<G>(mo.s0); mo.s1x = group_sum_f64<G>(mo.s1x); mo.s1y = group_sum_f64<G>(mo.s1y);
+          mo.sxx = group_sum_f64<G>(mo.sxx); mo.sxy = group_sum_f64<G>(mo.sxy); mo.syy = group_sum_f64<G>(mo.syy);
+        }
+        if (sub == 0) {
+          cmo->s0 = mo.s0; cmo->s1x = mo.s1x; cmo->s1y = mo.s1y; cmo->sxx = mo.sxx; cmo->sxy = mo.sxy; cmo->syy = mo.syy;
+          if (G == 1) { cmo->cx = c.x; cmo->cy = c.y; }
+          cmo->cnt = mo.cnt;
+        }
       }
-      scr.coff[v] = valid;
-    }
+    };
+    tier(std::integral_constant<int, 16>{}, 0, n16);
+    tier(std::integral_constant<int, 4>{}, n16, n4);
+    tier(std::integral_constant<int, 1>{}, n4, nlist);
     __syncthreads();                                                   // the staging area is reused by the next slab
     ya = yb;
   }
@@ -1110,16 +1273,23 @@ __global__ __launch_bounds__(kFinishThreads) void surface_finish_kernel(const Su
   const int V = scr.hdr->V;
   if (tid == 0) total_s = 0;
   __syncthreads();
-  for (int v0 = 0; v0 < V; v0 += kFinishThreads) {                     // compaction in voxel order (= PCL's output order)
+  for (int v0 = 0; v0 < V; v0 += kFinishThreads) {                     // cells + compaction in voxel order (= PCL's output order)
     const int v = v0 + tid;
-    const int f = v < V ? scr.coff[v] : 0;
+    TmpCell t;
+    int f = 0;
+    if (v < V) {
+      const CellMom cmo = *(const CellMom*)&scr.tmp[v];
+      if (cmo.cnt >= 6) {
+        const Moments mo{cmo.cnt, cmo.s0, cmo.s1x, cmo.s1y, cmo.sxx, cmo.sxy, cmo.syy};
+        f = finish_cell(mo, (double)cmo.cx, (double)cmo.cy, cm.origin[0], cm.origin[1], t);
+      }
+    }
     const int inc = wave_incl_scan_i32(f);
     if (lane == 63) red_i[wave] = inc;
     __syncthreads();
     int off = total_s + inc - f;
     for (int wv = 0; wv < wave; wv++) off += red_i[wv];
     if (f && off < job.out.cap) {
-      const TmpCell t = scr.tmp[v];
       job.out.mean_f[off] = make_float2((float)t.mean[0], (float)t.mean[1]);  // pointnormal.cpp:154-157
       job.out.mean[off] = make_double2(t.mean[0], t.mean[1]);
       job.out.normal[off] = make_double2(t.normal[0], t.normal[1]);
