@@ -141,7 +141,7 @@ void cfear_surface_fill_job(void* dst, float* d_xyzi, const int32_t* d_n, int32_
 void cfear_surface_fill_job_rows(void* dst, float* d_xyzi, int32_t* d_n_out, const uint32_t* d_row_keys, const int32_t* d_row_cnt,
                                  int rows, int k, int compensate, const double mot[3], const ScanView& out);
 // rows mode needs the polar -> Cartesian constants: call before cfear_surface_launch (per context)
-struct cfear_surface_polar { const double* cos_t = nullptr; const double* sin_t = nullptr; double range_res = 0.0; };
+struct cfear_surface_polar { const double* cos_t = nullptr; const double* sin_t = nullptr; double range_res = 0.0; int rows = 0, k = 0; };
 int cfear_trig_tables(cfear_ctx* ctx, int rows, double** d_cos, double** d_sin);
 // max_cell_cap: the largest cell capacity (ScanView::cap) among the jobs' output slabs
 int cfear_surface_launch(cfear_ctx* ctx, const void* d_jobs, int n_jobs, const cfear_feature_params* par,

@@ -545,6 +545,7 @@ static int process_frame(cfear_odometry* od, const uint8_t* polar, const uint8_t
     rc = cfear_trig_tables(ctx, od->desc.rows, &d_cos, &d_sin);
     if (rc != CFEAR_OK) return fail(rc);
     sp.cos_t = d_cos; sp.sin_t = d_sin; sp.range_res = (double)par.kstrong.range_res;
+    sp.rows = od->desc.rows; sp.k = par.kstrong.k_strongest;
   }
   rc = cfear_surface_launch(ctx, od->d_surf_jobs, B, &fp, od->d_surf_scratch, od->d_status, od->d_ncells, od->cell_cap, od->cap_points, rows_mode ? &sp : nullptr);
   if (rc != CFEAR_OK) return fail(rc);

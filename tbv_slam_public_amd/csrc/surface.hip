@@ -97,7 +97,7 @@ static_assert(sizeof(CellMom) <= sizeof(TmpCell), "CellMom lives in the TmpCell 
 constexpr int kFastMaxCells = 16384;          // grid cells the LDS counting sort can address
 constexpr int kFastThreads = 512;
 constexpr size_t kFastLds = 78 * 1024;        // two workgroups per CU (160 KiB)
-constexpr int kRouteFast = 0, kRouteFallback = 1, kRouteDone = 2;
+constexpr int kRouteFast = 0, kRouteFallback = 1, kRouteDone = 2, kRoutePrepped = 3;
 constexpr int kScanCreateMaxPoints = 1 << 20;  // cfear_scan_create: clouds beyond kMaxPoints take the global-memory path
 
 struct SurfHdr {                              // written by surface_sort_kernel, read by the kernels behind it
@@ -225,9 +225,25 @@ __device__ __forceinline__ float4 compensate_point_d(float4 p, const double d, c
   return p;
 }
 
+// sin / cos for |a| <= 1e5: beyond the polynomial's range, Cody-Waite reduction by pi/2 in three parts (k < 2^17, so
+// k * the 33-bit head is exact) and the same polynomials on |r| <= pi/4 (truncation < 2e-18).
+__device__ __forceinline__ void sincos_reduced(const double a, double* s, double* c) {
+  if (fabs(a) <= 0.5) { sincos_small(a, s, c); return; }
+  const double k = rint(a * 6.36619772367581382433e-01);               // 2 / pi
+  double r = fma(-k, 1.57079632673412561417e+00, a);                   // pi/2: first 33 bits
+  r = fma(-k, 6.07710050630396597660e-11, r);                          //       next 33 bits
+  r = fma(-k, 2.02226624879595063154e-21, r);                          //       the rest
+  double sr, cr;
+  sincos_small(r, &sr, &cr);
+  const int q = (int)k & 3;
+  const double ss = (q & 1) ? cr : sr, cc = (q & 1) ? sr : cr;
+  *s = (q & 2) ? -ss : ss;
+  *c = ((q + 1) & 2) ? -cc : cc;
+}
+
 __device__ __forceinline__ float4 compensate_point_small(float4 p, const double d, const double mot[3]) {
   double s_1, c_1;
-  sincos_small(d * mot[2], &s_1, &c_1);
+  sincos_reduced(d * mot[2], &s_1, &c_1);
   const double tx = d * mot[0], ty = d * mot[1];
   const double x = (double)p.x, y = (double)p.y;
   p.x = (float)((c_1 * x + (-s_1) * y) + tx);
@@ -842,12 +858,12 @@ __global__ __launch_bounds__(kSurfThreads) void surface_points_kernel(const Surf
 // and the staging barriers at 10 wavefronts per CU cost more than the old gather phase.)  Scans the fast path cannot
 // take are appended to a work list that the single-kernel path (above) drains.
 // =================================================================================================================
-__global__ __launch_bounds__(kFastThreads, 4) void surface_sort_kernel(const SurfJob* __restrict__ jobs, const SurfCommon cm) {
+template <bool ROWS>
+__global__ __launch_bounds__(kFastThreads) void surface_prep_kernel(const SurfJob* __restrict__ jobs, const SurfCommon cm) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   constexpr int NT = kFastThreads, NW = NT / 64;
-  constexpr int kPer = kMaxPoints / NT;                               // <= 32 points per thread
-  float (*red_f)[NW] = (float (*)[NW])(smem + kFastLds - 512);         // [4][NW]
-  int* red_i = (int*)(smem + kFastLds - 512 + 4 * NW * 4);             // [2][NW]
+  __shared__ float red_f[4][NW];
+  __shared__ int red_i[NW];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int job_id = blockIdx.x;
   const SurfJob job = jobs[job_id];
@@ -869,18 +885,13 @@ __global__ __launch_bounds__(kFastThreads, 4) void surface_sort_kernel(const Sur
       cm.fallback[1 + w] = job_id;
     }
   };
-#ifdef CFEAR_SURF_TIMING
-  long long* tstamp = (long long*)((char*)scr.hdr + 64);
-#define STAMP(i) do { if (tid == 0) tstamp[i] = __builtin_readcyclecounter(); } while (0)
-#else
-#define STAMP(i) do { } while (0)
-#endif
-  STAMP(0);
-  if (!cm.fast_ok) { hand_over(0, 0); return; }
+  if (!cm.fast_ok || (job.row_pts != nullptr) != ROWS) { hand_over(0, 0); return; }
+  // rotations beyond the reduced sincos' range (never a real motion; also NaN): the single-kernel path uses libm
+  if (job.compensate && !(fabs(job.mot[2]) <= 1e5)) { hand_over(0, 0); return; }
   // ---- (a) point count; rows mode: exclusive prefix of the row counts ------------------------------------------
   int n = job.n_ptr ? *job.n_ptr : job.n_host;
   int32_t* rowoff = (int32_t*)smem;
-  if (job.row_pts) {
+  if (ROWS) {
     int run = 0;
     for (int r0 = 0; r0 < job.rows; r0 += NT) {
       const int r = r0 + tid;
@@ -902,47 +913,62 @@ __global__ __launch_bounds__(kFastThreads, 4) void surface_sort_kernel(const Sur
   if (n > cm.scratch_cap) { done(CFEAR_ERR_CAPACITY); return; }
   if (n > kMaxPoints) { hand_over(n, 0); return; }         // big cloud: global-memory path of the single-kernel workgroup
   float4* pts = job.xyzi;
-  STAMP(1);
   // ---- (b) polar -> Cartesian (rows mode), motion compensation, bounding box ------------------------------------
   // rows mode: the azimuth row of every point as a u16 table behind rowoff (one thread per row fills its <= k slots;
   // a per-point binary search over rowoff cost nine dependent LDS reads)
-  unsigned short* rid = (unsigned short*)(smem + (((size_t)(job.rows + 1) * 4 + 15) & ~(size_t)15));
-  if (job.row_pts) {
+  // and the (cos, sin) table of the azimuths, staged once per scan
+  const size_t rid_off = ((size_t)(job.rows + 1) * 4 + 15) & ~(size_t)15;
+  unsigned short* rid = (unsigned short*)(smem + rid_off);
+  double2* cs = (double2*)(smem + ((rid_off + (size_t)n * 2 + 15) & ~(size_t)15));
+  if (ROWS) {
     for (int r = tid; r < job.rows; r += NT) {
       const int o = rowoff[r], e = rowoff[r + 1];
       for (int q = o; q < e; q++) rid[q] = (unsigned short)r;
+      cs[r] = make_double2(cm.cos_t[r], cm.sin_t[r]);
     }
     __syncthreads();
   }
   float mnx = FLT_MAX, mny = FLT_MAX, mxx = -FLT_MAX, mxy = -FLT_MAX;
   const double range_res_half = cm.range_res / 2.0;
   const double th_step = (2. * M_PI) / (double)max(job.rows, 1);
-  // |d| <= 0.5: the rotation angle d * mot[2] stays inside the polynomial's range for every sane motion (job-uniform)
-  const bool small_rot = fabs(job.mot[2]) <= 1.0;
-  for (int i0 = tid; i0 < n; i0 += 4 * NT) {
+  constexpr int U = 4;
+  for (int i0 = tid; i0 < n; i0 += U * NT) {
+    float4 p[U];
+    int row[U];
+    uint32_t key[U];
 #pragma unroll
-    for (int u = 0; u < 4; u++) {
+    for (int u = 0; u < U; u++) {                         // all global loads of the batch first
+      const int i = i0 + u * NT;
+      row[u] = 0; key[u] = 0;
+      if (i < n) {
+        if (ROWS) {
+          row[u] = rid[i];
+          key[u] = job.row_pts[(size_t)row[u] * job.k + (i - rowoff[row[u]])];
+        } else {
+          p[u] = pts[i];
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; u++) {
       const int i = i0 + u * NT;
       if (i < n) {
-        float4 p;
-        if (job.row_pts) {
-          const int row = rid[i];
-          const uint32_t key = job.row_pts[(size_t)row * job.k + (i - rowoff[row])];
-          const double rho = range_res_half + cm.range_res * (double)(int)(key & 0xFFFFFFu);   // radar_filters.cpp:324-330
-          const double ct = cm.cos_t[row], st = cm.sin_t[row];
-          p = make_float4((float)(rho * ct), (float)(rho * st), 0.f, (float)(key >> 24));
+        if (ROWS) {
+          const double rho = range_res_half + cm.range_res * (double)(int)(key[u] & 0xFFFFFFu);   // radar_filters.cpp:324-330
+          const double2 t = cs[row[u]];
+          p[u] = make_float4((float)(rho * t.x), (float)(rho * t.y), 0.f, (float)(key[u] >> 24));
           if (job.compensate) {
-            const double th = (double)(row + 1) * th_step;                                     // radar_filters.cpp:317
-            const double d = rel_time_stamp_known_row((double)p.x, (double)p.y, th, ct, st, cm.ccw != 0);
-            p = small_rot ? compensate_point_small(p, d, job.mot) : compensate_point_d(p, d, job.mot);
+            const double th = (double)(row[u] + 1) * th_step;                                     // radar_filters.cpp:317
+            const double d = rel_time_stamp_known_row((double)p[u].x, (double)p[u].y, th, t.x, t.y, cm.ccw != 0);
+            p[u] = compensate_point_small(p[u], d, job.mot);
           }
-          pts[i] = p;
-        } else {
-          p = pts[i];
-          if (job.compensate) { p = compensate_point(p, job.mot, cm.ccw != 0); pts[i] = p; }
+          pts[i] = p[u];
+        } else if (job.compensate) {
+          p[u] = compensate_point_small(p[u], get_rel_time_stamp((double)p[u].x, (double)p[u].y, cm.ccw != 0), job.mot);
+          pts[i] = p[u];
         }
-        mnx = fminf(mnx, p.x); mxx = fmaxf(mxx, p.x);
-        mny = fminf(mny, p.y); mxy = fmaxf(mxy, p.y);
+        mnx = fminf(mnx, p[u].x); mxx = fmaxf(mxx, p[u].x);
+        mny = fminf(mny, p[u].y); mxy = fmaxf(mxy, p[u].y);
       }
     }
   }
@@ -966,6 +992,42 @@ __global__ __launch_bounds__(kFastThreads, 4) void surface_sort_kernel(const Sur
   const int dbx = (int)div_bx, dby = (int)div_by;
   const int ncells = dbx * dby;
   if (ncells > kFastMaxCells) { hand_over(n, 1); return; }
+  if (tid == 0) {                                                      // hand-off to surface_sort_kernel
+    scr.hdr->route = kRoutePrepped;
+    scr.hdr->n = n; scr.hdr->dbx = dbx; scr.hdr->dby = dby; scr.hdr->pad[1] = min_bx; scr.hdr->pad[2] = min_by;
+  }
+}
+
+__global__ __launch_bounds__(kFastThreads, 4) void surface_sort_kernel(const SurfJob* __restrict__ jobs, const SurfCommon cm) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  constexpr int NT = kFastThreads, NW = NT / 64;
+  constexpr int kPer = kMaxPoints / NT;                               // <= 32 points per thread
+  int* red_i = (int*)(smem + kFastLds - 512 + 4 * NW * 4);             // [2][NW]
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int job_id = blockIdx.x;
+  const SurfScratch scr = scratch_of(cm.scratch + (size_t)job_id * cm.scratch_stride, cm.scratch_cap);
+  if (scr.hdr->route != kRoutePrepped) return;                         // failed, empty or handed to the single-kernel path
+  const SurfJob job = jobs[job_id];
+  auto hand_over = [&](int n, int prepared) {                          // to the single-kernel path
+    if (tid == 0) {
+      scr.hdr->route = kRouteFallback;
+      scr.hdr->n = n;
+      scr.hdr->pad[0] = prepared;                                      // 1: xyzi already holds the compact, compensated cloud
+      const int w = atomicAdd(&cm.fallback[0], 1);
+      cm.fallback[1 + w] = job_id;
+    }
+  };
+#ifdef CFEAR_SURF_TIMING
+  long long* tstamp = (long long*)((char*)scr.hdr + 64);
+#define STAMP(i) do { if (tid == 0) tstamp[i] = __builtin_readcyclecounter(); } while (0)
+#else
+#define STAMP(i) do { } while (0)
+#endif
+  STAMP(0); STAMP(1);
+  const int n = scr.hdr->n, dbx = scr.hdr->dbx, dby = scr.hdr->dby, min_bx = scr.hdr->pad[1], min_by = scr.hdr->pad[2];
+  const int ncells = dbx * dby;
+  const float4* pts = job.xyzi;
+  __syncthreads();                                                     // every thread has read the header before tid 0 may rewrite it
   STAMP(2);
   // ---- (c) histogram of the points over the voxel grid: u16 counters, two per LDS word ---------------------------
   // cnt[c] for c in [0, ncells]; after the scan the same words hold ord[c] = occupied cells before c.
@@ -1422,6 +1484,20 @@ int cfear_surface_launch(cfear_ctx* ctx, const void* d_jobs, int n_jobs, const c
     CFEAR_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)surface_finish_kernel,
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)finish_lds));
   {
+    // rows mode: rowoff i32[rows + 1] | row of every point u16[n] | (cos, sin) f64[rows]
+    size_t prep_lds = 0;
+    if (polar) {
+      const size_t np = (size_t)std::min<long long>((long long)polar->rows * polar->k, kMaxPoints);
+      prep_lds = (((size_t)(polar->rows + 1) * 4 + 15) & ~(size_t)15) + ((np * 2 + 15) & ~(size_t)15) + (size_t)polar->rows * 16;
+      if (prep_lds > 150 * 1024) return cfear_set_error(ctx, CFEAR_ERR_CAPACITY, "%d azimuths exceed the row tables", polar->rows);
+      if (prep_lds > 64 * 1024)
+        CFEAR_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)surface_prep_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)prep_lds));
+    }
+    ProfScope ps(ctx, "surface_prep");
+    if (polar) hipLaunchKernelGGL(surface_prep_kernel<true>, dim3(n_jobs), dim3(kFastThreads), prep_lds, ctx->stream, (const SurfJob*)d_jobs, cm);
+    else hipLaunchKernelGGL(surface_prep_kernel<false>, dim3(n_jobs), dim3(kFastThreads), 0, ctx->stream, (const SurfJob*)d_jobs, cm);
+  }
+  {
     ProfScope ps(ctx, "surface_sort");
     hipLaunchKernelGGL(surface_sort_kernel, dim3(n_jobs), dim3(kFastThreads), kFastLds, ctx->stream, (const SurfJob*)d_jobs, cm);
   }
@@ -1440,13 +1516,15 @@ int cfear_surface_launch(cfear_ctx* ctx, const void* d_jobs, int n_jobs, const c
     static int calls = 0;
     if (++calls % 40 == 0) {
       (void)hipStreamSynchronize(ctx->stream);
-      double acc[9] = {0};
+      double acc[9] = {0}, sub[2] = {0};
       const int m = std::min(n_jobs, 256);
       for (int j = 0; j < m; j++) {
-        long long t[9];
+        long long t[11];
         (void)hipMemcpy(t, d_scratch + (size_t)j * cm.scratch_stride + 64, sizeof(t), hipMemcpyDeviceToHost);
         for (int q = 1; q < 9; q++) acc[q] += (double)(t[q] - t[q - 1]);
+        sub[0] += (double)(t[9] - t[1]); sub[1] += (double)(t[10] - t[9]);
       }
+      fprintf(stderr, "  comp split: row table %.0f  point loop (tid 0) %.0f\n", sub[0] / m, sub[1] / m);
       fprintf(stderr, "surface_sort phases (cycles, mean of %d jobs): count %.0f  comp+bbox %.0f  hist %.0f  scan %.0f  scatter %.0f  order %.0f  spt %.0f  cells %.0f\n",
               m, acc[1] / m, acc[2] / m, acc[3] / m, acc[4] / m, acc[5] / m, acc[6] / m, acc[7] / m, acc[8] / m);
     }

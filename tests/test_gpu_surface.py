@@ -80,6 +80,25 @@ def test_surface_points_device_input_with_fused_compensation():
     np.testing.assert_array_equal(t.cpu().numpy(), comp)      # compensated in place
 
 
+@pytest.mark.parametrize("w", [0.9, 2.5, -400.0, 3e5])
+def test_fused_compensation_large_rotations(w):
+    """The fast path's own sin / cos (polynomial, Cody-Waite reduction beyond 0.5 rad, hand-over to the libm path beyond
+    1e5 rad) against the oracle's libm: the float cloud may differ by an ulp on a handful of points only."""
+    import torch
+    from oracle import pyoracle as O
+    from tbv_slam_public_amd import api
+    cloud = _cloud(7)
+    mot = (1.5, -0.2, w)
+    exp = O.compensate(cloud, mot, False)
+    t = torch.from_numpy(cloud).cuda()
+    m = api.MapPointNormal(t, 3.0, (0.0, 0.0), True, compensate=mot, ccw=False)
+    got = t.cpu().numpy()
+    d = np.abs(got[:, :2] - exp[:, :2])
+    assert d.max() <= 4e-5
+    assert (d > 0).mean() < (1e-3 if abs(w) < 1e3 else 0.05)     # 3e5 rad x 2^-53 relative already moves float ulps
+    assert m.GetSize() > 0
+
+
 def test_surface_points_edge_cases():
     from oracle import pyoracle as O
     from tbv_slam_public_amd import api, _lib as L
