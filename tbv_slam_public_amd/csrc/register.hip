@@ -598,6 +598,7 @@ __device__ __forceinline__ bool fused_carve(uint8_t* smem, size_t lds_total, int
 template <int NW>
 __device__ void fused_stage(const RegJob& job, const FusedLds& f, float cm_radius) {
   const int tid = threadIdx.x, last = job.n_scans - 1;
+  REG_T0();
   if (tid == 0) {
     int acc = 0;
     for (int i = 0; i < last; i++) { f.koff[i] = acc; acc += *job.scans[i].n_cells; }
@@ -612,6 +613,7 @@ __device__ void fused_stage(const RegJob& job, const FusedLds& f, float cm_radiu
     tp[0] = tv.mean; tp[1] = tv.normal; tp[2] = tv.nsamples; tp[3] = tv.scale; tp[4] = tv.cov;
   }
   __syncthreads();
+  REG_TACC(8);
   // ---- uniform grid per keyframe (replaces the reference's kd-tree): targets grouped by cell -------------
   // The float means cluster along walls, so a window in one coordinate alone can hold a hundred candidates;
   // with cells no smaller than the search radius a query touches the few cells its square overlaps.
@@ -621,6 +623,7 @@ __device__ void fused_stage(const RegJob& job, const FusedLds& f, float cm_radiu
   if (tid < last) { f.gext[tid * 4] = 0xFFFFFFFFu; f.gext[tid * 4 + 1] = 0u; }
   for (int c = tid; c < last * GG; c += NW * 64) f.ccnt[c] = 0;
   __syncthreads();
+  REG_TACC(9);
   auto keyframe_of = [&](int t, int& i, int& j) {        // merged target index -> (keyframe, x-sorted position)
     i = 0;
     while (i + 1 < last && t >= f.koff[i + 1]) i++;
@@ -658,6 +661,7 @@ __device__ void fused_stage(const RegJob& job, const FusedLds& f, float cm_radiu
     atomicMax(&f.gext[i * 4 + 1], u);
   });
   __syncthreads();
+  REG_TACC(10);
   if (tid < last) {
     const ScanView& tar = job.scans[tid];
     const int n = f.koff[tid + 1] - f.koff[tid];
@@ -672,6 +676,7 @@ __device__ void fused_stage(const RegJob& job, const FusedLds& f, float cm_radiu
     f.ggeo[tid] = make_float4(x0, y0, 1.0f / edge, 0.f);
   }
   __syncthreads();
+  REG_TACC(11);
   auto cell_of = [&](const float4 g, float x, float y) {
     const int cx = min(G - 1, max(0, (int)floorf((x - g.x) * g.z)));
     const int cy = min(G - 1, max(0, (int)floorf((y - g.y) * g.z)));
@@ -681,6 +686,7 @@ __device__ void fused_stage(const RegJob& job, const FusedLds& f, float cm_radiu
     atomicAdd(&f.ccnt[i * GG + cell_of(f.ggeo[i], x, y)], 1u);
   });
   __syncthreads();
+  REG_TACC(12);
   {                                                      // exclusive scan over (keyframe, cell): absolute starts
     const int C = last * GG, per = (C + NW * 64 - 1) / (NW * 64);
     const int c0 = tid * per;
@@ -690,6 +696,7 @@ __device__ void fused_stage(const RegJob& job, const FusedLds& f, float cm_radiu
     const int incl = wave_incl_scan_i32(tot);
     if ((tid & 63) == 63) ip[tid >> 6] = incl;
     __syncthreads();
+  REG_TACC(13);
     int run = incl - tot;
     for (int wv = 0; wv < (tid >> 6); wv++) run += ip[wv];
     for (int c = c0; c < min(C, c0 + per); c++) {
@@ -701,6 +708,7 @@ __device__ void fused_stage(const RegJob& job, const FusedLds& f, float cm_radiu
     if (tid == 0) f.cstart[C] = (unsigned short)sum_tar;
   }
   __syncthreads();
+  REG_TACC(14);
   for_targets([&](int i, float x, float y, int idx) {     // scatter (order inside a cell is irrelevant: the NN
     const unsigned pos = atomicAdd(&f.ccnt[i * GG + cell_of(f.ggeo[i], x, y)], 1u);   // tie rule is by cell index)
     f.txyi[pos] = make_float4(x, y, __int_as_float(idx), 0.f);
@@ -711,6 +719,7 @@ __device__ void fused_stage(const RegJob& job, const FusedLds& f, float cm_radiu
     f.smean[s] = src.mean[s];
   }
   __syncthreads();
+  REG_TACC(15);
 }
 
 // One association pass (n_scan_normal.cpp:213-318) at source pose xsrc; fills `dn`; returns #blocks.
@@ -1255,6 +1264,7 @@ __global__ __launch_bounds__(NW * 64) void register_kernel(const RegJob* __restr
       printf("reg cycles: total %lld | stage %lld | Tst %lld nn+gate %lld scan %lld gather %lld | sincos %lld eval %lld reduce %lld | outer %d lm %d n %d\n",
              (long long)res->last_relative_decrease + g_reg_t[6], g_reg_t[6], g_reg_t[0], g_reg_t[1], g_reg_t[2], g_reg_t[3],
              g_reg_t[7], g_reg_t[4], g_reg_t[5], itr, lm_iters, num_residuals);
+      printf("  stage split:"); for (int k = 8; k < 16; k++) printf(" %lld", g_reg_t[k]); printf("\n");
       for (int k = 0; k < 16; k++) g_reg_t[k] = 0;
     }
 #endif
