@@ -589,9 +589,12 @@ static int process_frame(cfear_odometry* od, const uint8_t* polar, const uint8_t
   OD_CHECK(hipEventRecord(od->ev_results, ctx->stream));
   int prefetch_rc = CFEAR_OK;
   if (polar_next) {
-    // (Tried: the sweep on its own stream beside this frame's kernels.  Every kernel of the path fills the chip -- the
-    // sweep holds all vector registers of its SIMDs, the matcher all LDS of its CUs -- so nothing co-resides and the
-    // result was 2.51 ms per frame batch instead of 2.19.)
+    // (Tried twice: the sweep on its own low-priority stream.  Enqueued ahead of this frame's kernels it simply ran first
+    // -- every kernel of the path fills the chip, the sweep holds all vector registers of its SIMDs and the matcher all
+    // LDS of its CUs, so nothing co-resides: 2.51 ms per frame batch instead of 2.19.  Gated to start with the matcher,
+    // to fill the ~0.2 ms in which the last uneven registrations leave CUs idle, its small workgroups took the LDS the
+    // next 80 KB registration needed on every CU that drained: matcher 0.98 -> 1.47 ms, sweep 0.52 -> 1.32 ms, 2.68 ms
+    // per frame batch.)
     // The next frame's filter needs no state of this frame: enqueue it now so the GPU sweeps the next
     // polar batch while the host applies the keyframe policy below.
     // A failed prefetch does not throw this frame away: its kernels already ran and its policy is applied below;
