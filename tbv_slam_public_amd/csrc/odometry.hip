@@ -11,7 +11,10 @@
 // is host code exactly as in the reference; the four stages F, C, N, M are three kernel launches
 // over the whole batch (kstrongest_rows + kstrong_cloud, surface_points, register) and one small
 // read-back (pose, counts) per call.
+#include <algorithm>
+#include <chrono>
 #include <cmath>
+#include <cstdlib>
 
 #include "common.hpp"
 
@@ -149,6 +152,7 @@ struct cfear_odometry {
   std::vector<double> cov;             // [n_streams][36] cov_current
   std::vector<int32_t> cov_sampled;    // [n_streams]
   std::vector<Stream> streams;
+  std::vector<double> cost_est, cost_tmp;   // per stream: work of its last registration (residuals x iterations): orders the next batch
   std::vector<ScanView> views;         // [n_streams * slabs_per_stream]
 };
 
@@ -288,6 +292,7 @@ extern "C" int cfear_odometry_create(cfear_ctx* ctx, int32_t n_streams, const cf
   od->cov_sampled.assign(B, 0);
   if (!ok) { cfear_odometry_destroy(od); return cfear_set_error(ctx, CFEAR_ERR_HIP, "odometry buffers: allocation failed"); }
   od->streams.resize(B);
+  od->cost_est.assign(B, 0.0);
   od->views.resize((size_t)B * od->slabs_per_stream);
   for (int b = 0; b < B; b++) {
     for (int s = 0; s < od->slabs_per_stream; s++) {
@@ -439,8 +444,40 @@ static int load_clouds(cfear_odometry* od, const cfear_sc_cloud* clouds, float* 
   return CFEAR_OK;
 }
 
+namespace {
+struct HostTimeline {          // CFEAR_OD_TIMING=1: where the host spends a frame (printed every 256 calls)
+  bool on = getenv("CFEAR_OD_TIMING") != nullptr;
+  double acc[8] = {0};
+  int calls = 0;
+  std::chrono::steady_clock::time_point last, exit_t;
+  bool have_exit = false;
+  void start() {
+    if (!on) return;
+    last = std::chrono::steady_clock::now();
+    if (have_exit) acc[6] += std::chrono::duration<double, std::micro>(last - exit_t).count();
+  }
+  void mark(int k) {
+    if (!on) return;
+    const auto t = std::chrono::steady_clock::now();
+    acc[k] += std::chrono::duration<double, std::micro>(t - last).count();
+    last = t;
+  }
+  void end() {
+    if (!on) return;
+    exit_t = std::chrono::steady_clock::now(); have_exit = true;
+    if (++calls % 256 == 0) {
+      fprintf(stderr, "host us/frame: surf jobs+launch %.0f | reg jobs %.0f | enqueue rest %.0f | wait results %.0f | policy %.0f | outside the call %.0f\n",
+              acc[0] / 256, acc[1] / 256, acc[2] / 256, acc[3] / 256, acc[4] / 256, acc[6] / 256);
+      for (double& a : acc) a = 0;
+    }
+  }
+};
+HostTimeline g_tl;
+}  // namespace
+
 static int process_frame(cfear_odometry* od, const uint8_t* polar, const uint8_t* polar_next, const cfear_sc_cloud* clouds,
                          const cfear_sc_cloud* peaks, cfear_frame_info* info, const int64_t* offsets, const int64_t* offsets_next) {
+  g_tl.start();
   cfear_ctx* ctx = od->ctx;
   CFEAR_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   const int B = od->n_streams;
@@ -507,31 +544,6 @@ static int process_frame(cfear_odometry* od, const uint8_t* polar, const uint8_t
     if (_e != hipSuccess)                                                                                     \
       return fail(cfear_set_error(ctx, CFEAR_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__)); \
   } while (0)
-  // ---- M: the registration jobs depend on host state only: they are built and uploaded (copy stream) now,
-  //      so the 2.3 KB per stream travel while the surface kernel runs (:164-186) ---------------------------
-  const size_t rjb = cfear_reg_job_stride(par.submap_scan_size + 1);   // records cover the keyframe window + the new scan
-  int n_jobs = 0;
-  std::vector<ScanView> views(cfear_reg_max_scans());
-  std::vector<double> poses(3 * (size_t)cfear_reg_max_scans());
-  for (int b = 0; b < B; b++) {
-    Stream& st = od->streams[b];
-    st.Tguess = par.use_guess ? aff_mul(st.T_prev, st.Tmot) : st.T_prev;      // :164-168
-    st.job = -1;
-    if (st.keyframes.empty()) continue;                                       // :171-177 first frame
-    const int ns = (int)st.keyframes.size() + 1;                              // FormatScans :478-494
-    for (int i = 0; i < ns - 1; i++) {
-      views[i] = od->views[(size_t)b * od->slabs_per_stream + st.keyframes[i].slab];
-      aff_to_xyt(st.keyframes[i].pose, &poses[3 * i]);
-    }
-    views[ns - 1] = od->views[(size_t)b * od->slabs_per_stream + st.cur_slab];
-    aff_to_xyt(st.Tguess, &poses[3 * (ns - 1)]);
-    cfear_reg_fill_job(od->h_reg_jobs + (size_t)n_jobs * rjb, views.data(), ns, poses.data());
-    st.job = n_jobs++;
-  }
-  if (n_jobs > 0) {
-    OD_CHECK(hipMemcpyAsync(od->d_reg_jobs, od->h_reg_jobs, (size_t)n_jobs * rjb, hipMemcpyHostToDevice, od->copy_stream));
-    OD_CHECK(hipEventRecord(od->ev_jobs, od->copy_stream));
-  }
   OD_CHECK(hipMemcpyAsync(od->d_surf_jobs, od->h_surf_jobs, (size_t)B * sjb, hipMemcpyHostToDevice, ctx->stream));
   cfear_feature_params fp{};
   fp.radius = par.res;
@@ -549,6 +561,58 @@ static int process_frame(cfear_odometry* od, const uint8_t* polar, const uint8_t
   }
   rc = cfear_surface_launch(ctx, od->d_surf_jobs, B, &fp, od->d_surf_scratch, od->d_status, od->d_ncells, od->cell_cap, od->cap_points, rows_mode ? &sp : nullptr);
   if (rc != CFEAR_OK) return fail(rc);
+  g_tl.mark(0);
+  // ---- M: the registration jobs depend on host state only: they are built and uploaded (copy stream) while the
+  //      surface kernels, already enqueued above, run -- 2.3 KB per stream, ~0.3 ms of host time for 2048 streams
+  //      that would otherwise sit between the sweep and the surface kernels (:164-186) ------------------------
+  const size_t rjb = cfear_reg_job_stride(par.submap_scan_size + 1);   // records cover the keyframe window + the new scan
+  int n_jobs = 0;
+  std::vector<ScanView> views(cfear_reg_max_scans());
+  std::vector<double> poses(3 * (size_t)cfear_reg_max_scans());
+  // Longest first: registrations differ by ~2x in work (cells, outer and LM iterations), and 2048 of them over the 512
+  // workgroup slots of the chip end with whatever the last-started ones need.  A stream's previous registration is a
+  // good estimate of its next one, so the batch is ordered by it (the job index is only a slot in the batch) -- in
+  // four classes by the quartiles of the estimate, streams in index order inside a class: a full sort walked the
+  // stream records in random order and cost more host time than the kernel saved.
+  std::vector<double>& est = od->cost_est;
+  double cut[3] = {0.0, 0.0, 0.0};
+  {
+    std::vector<double>& tmp = od->cost_tmp;
+    tmp.assign(est.begin(), est.end());
+    if (B >= 8)
+      for (int q = 0; q < 3; q++) {
+        const size_t k = (size_t)B * (3 - q) / 4;                                // descending cuts: 75 %, 50 %, 25 %
+        std::nth_element(tmp.begin(), tmp.begin() + k, tmp.end());
+        cut[q] = tmp[k];
+      }
+  }
+  for (int b = 0; b < B; b++) {
+    Stream& st = od->streams[b];
+    st.Tguess = par.use_guess ? aff_mul(st.T_prev, st.Tmot) : st.T_prev;      // :164-168
+    st.job = -1;
+  }
+  for (int cls = 0; cls < 4; cls++)
+  for (int b = 0; b < B; b++) {
+    const double e = est[b];
+    const int c = e >= cut[0] ? 0 : e >= cut[1] ? 1 : e >= cut[2] ? 2 : 3;
+    if (c != cls) continue;
+    Stream& st = od->streams[b];
+    if (st.keyframes.empty()) continue;                                       // :171-177 first frame: no registration
+    const int ns = (int)st.keyframes.size() + 1;                              // FormatScans :478-494
+    for (int i = 0; i < ns - 1; i++) {
+      views[i] = od->views[(size_t)b * od->slabs_per_stream + st.keyframes[i].slab];
+      aff_to_xyt(st.keyframes[i].pose, &poses[3 * i]);
+    }
+    views[ns - 1] = od->views[(size_t)b * od->slabs_per_stream + st.cur_slab];
+    aff_to_xyt(st.Tguess, &poses[3 * (ns - 1)]);
+    cfear_reg_fill_job(od->h_reg_jobs + (size_t)n_jobs * rjb, views.data(), ns, poses.data());
+    st.job = n_jobs++;
+  }
+  if (n_jobs > 0) {
+    OD_CHECK(hipMemcpyAsync(od->d_reg_jobs, od->h_reg_jobs, (size_t)n_jobs * rjb, hipMemcpyHostToDevice, od->copy_stream));
+    OD_CHECK(hipEventRecord(od->ev_jobs, od->copy_stream));
+  }
+  g_tl.mark(1);
   if (n_jobs > 0) {
     OD_CHECK(hipStreamWaitEvent(ctx->stream, od->ev_jobs, 0));
     rc = cfear_register_launch(ctx, od->d_reg_jobs, n_jobs, &par.reg, par.submap_scan_size * od->cell_cap, od->cell_cap,
@@ -605,7 +669,9 @@ static int process_frame(cfear_odometry* od, const uint8_t* polar, const uint8_t
       if (offsets_next) od->prefetched_offsets.assign(offsets_next, offsets_next + B);
     }
   }
+  g_tl.mark(2);
   OD_CHECK(hipEventSynchronize(od->ev_results));
+  g_tl.mark(3);
   // ---- frame policy (:195-257) ------------------------------------------------------------------
   int first_error = CFEAR_OK;
   for (int b = 0; b < B; b++) {
@@ -633,6 +699,7 @@ static int process_frame(cfear_odometry* od, const uint8_t* polar, const uint8_t
     }
     const cfear_reg_result& rr = od->h_results[st.job];
     fi.reg_status = rr.status; fi.outer_iters = rr.outer_iters; fi.lm_iters = rr.lm_iters; fi.score = rr.score;
+    od->cost_est[b] = (double)rr.num_residuals * (3.0 * rr.outer_iters + rr.lm_iters);   // association ~ 3 LM iterations
     {                                                             // cov_current = cov_vek.back() (:196)
       double* cv = od->cov.data() + (size_t)b * 36;
       for (int k = 0; k < 36; k++) cv[k] = 0.0;
@@ -698,6 +765,8 @@ static int process_frame(cfear_odometry* od, const uint8_t* polar, const uint8_t
   }
   for (int b = 0; b < B; b++) od->streams[b].cur_slab = -1;      // every slab is a keyframe or back on the free list
 #undef OD_CHECK
+  g_tl.mark(4);
+  g_tl.end();
   return first_error != CFEAR_OK ? first_error : prefetch_rc;
 }
 
