@@ -1038,20 +1038,32 @@ __global__ __launch_bounds__(kFastThreads, 4) void surface_sort_kernel(const Sur
   for (int w = tid; w < words; w += NT) cw[w] = 0u;
   __syncthreads();
   unsigned short mycell[kPer];                                        // the cells of this thread's points (registers)
+  bool w_small = true;                                                // every weight max(I - 60, 0) an integer in [0, 255]?
 #pragma unroll
-  for (int j = 0; j < kPer; j++) {
-    const int i = tid + j * NT;
-    mycell[j] = 0;
-    if (i < n) {
-      const float2 p = *(const float2*)&pts[i];
-      const int ijk0 = (int)(floorf(p.x * cm.inv_leaf) - (float)min_bx);
-      const int ijk1 = (int)(floorf(p.y * cm.inv_leaf) - (float)min_by);
-      const int c = ijk0 + ijk1 * dbx;
-      mycell[j] = (unsigned short)c;
-      atomicAdd(&cw[c >> 1], (c & 1) ? 0x10000u : 1u);
+  for (int j0 = 0; j0 < kPer; j0 += 8) {                              // eight loads in flight per thread
+    float4 pp[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      const int i = tid + (j0 + u) * NT;
+      if (i < n) pp[u] = pts[i];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      const int j = j0 + u, i = tid + j * NT;
+      mycell[j] = 0;
+      if (i < n) {
+        const float4 p = pp[u];
+        const int ijk0 = (int)(floorf(p.x * cm.inv_leaf) - (float)min_bx);
+        const int ijk1 = (int)(floorf(p.y * cm.inv_leaf) - (float)min_by);
+        const int c = ijk0 + ijk1 * dbx;
+        mycell[j] = (unsigned short)c;
+        atomicAdd(&cw[c >> 1], (c & 1) ? 0x10000u : 1u);
+        const float wgt = fmaxf(__fsub_rn(p.w, 60.0f), 0.0f);
+        w_small = w_small && wgt <= 255.0f && wgt == truncf(wgt);
+      }
     }
   }
-  __syncthreads();
+  const bool wbyte = __syncthreads_and(w_small ? 1 : 0) != 0;
   STAMP(3);
   // ---- (d) exclusive scan over the cells: points before a cell (voxel starts) and occupied cells before it -------
   const int per = (words + NT - 1) / NT;                              // consecutive words per thread (<= 17)
@@ -1128,18 +1140,50 @@ __global__ __launch_bounds__(kFastThreads, 4) void surface_sort_kernel(const Sur
   }
   __syncthreads();
   STAMP(6);
-  // ---- (g) sorted points -> global scratch (L2): the order array is then dead and its LDS becomes the staging area ---
-  bool w_small = true;                                                // every weight an integer in [0, 255]?
-  for (int pos = tid; pos < n; pos += NT) {
-    const float4 p = pts[order[pos]];
-    // the sorted copies carry the point's WEIGHT max(I - 60, 0) (pointnormal.cpp:15), not its intensity: float(I) - 60
-    // is exact for I >= 60, so the fp64 weight of the reference is just its widening
-    const float wgt = fmaxf(__fsub_rn(p.w, 60.0f), 0.0f);
-    w_small = w_small && wgt <= 255.0f && wgt == truncf(wgt);
-    scr.spt[pos] = make_float4(p.x, p.y, wgt, 0.f);
+  // ---- (g) sorted points.  A scan whose points and voxel list fit the staging area at once (the usual 5 000-point
+  //      scan) gathers them from the cloud straight into LDS: every thread first takes its entries of the order array
+  //      into registers, because the staging area reuses that array's LDS.  Larger scans park the sorted points in
+  //      global scratch (L2) and stage them slab by slab. ------------------------------------------------------------
+  const size_t avail_all = kFastLds - 512 - ord2_off;
+  const int cap_all = (n + 3) & ~3;
+  const bool single = V <= 4 * NT && (size_t)cap_all * (wbyte ? 9 : 12) + (size_t)V * 2 + 16 <= avail_all;
+  if (single) {
+#pragma unroll
+    for (int j = 0; j < kPer; j++) {
+      const int pos = tid + j * NT;
+      if (pos < n) mycell[j] = order[pos];
+    }
+    __syncthreads();                                                   // the order array is dead
+    float2* sxy = (float2*)(smem + ord2_off);
+    uint8_t* sw = (uint8_t*)(smem + ord2_off + (size_t)cap_all * 8);
+    float* swf = (float*)sw;
+#pragma unroll
+    for (int j0 = 0; j0 < kPer; j0 += 8) {                            // eight gathers in flight per thread
+      float4 pp[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++)
+        if (tid + (j0 + u) * NT < n) pp[u] = pts[mycell[j0 + u]];
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        const int pos = tid + (j0 + u) * NT;
+        if (pos < n) {
+          const float4 p = pp[u];
+          // the staged copies carry the point's WEIGHT max(I - 60, 0) (pointnormal.cpp:15), not its intensity: float(I) - 60
+          // is exact for I >= 60, so the fp64 weight of the reference is just its widening
+          const float wgt = fmaxf(__fsub_rn(p.w, 60.0f), 0.0f);
+          sxy[pos] = make_float2(p.x, p.y);
+          if (wbyte) sw[pos] = (uint8_t)wgt; else swf[pos] = wgt;
+        }
+      }
+    }
+  } else {
+    for (int pos = tid; pos < n; pos += NT) {
+      const float4 p = pts[order[pos]];
+      scr.spt[pos] = make_float4(p.x, p.y, fmaxf(__fsub_rn(p.w, 60.0f), 0.0f), 0.f);
+    }
+    __threadfence_block();
   }
-  __threadfence_block();
-  const bool wbyte = __syncthreads_and(w_small ? 1 : 0) != 0;
+  __syncthreads();
   STAMP(7);
   // ---- (h) neighbourhood moments of every voxel, slab by slab.  A slab = the voxels of grid rows [ya, yb) whose
   //      candidate points (rows ya - 1 .. yb, one contiguous range of the sorted array) fit the staging area; a sparse
@@ -1184,13 +1228,15 @@ __global__ __launch_bounds__(kFastThreads, 4) void surface_sort_kernel(const Sur
     uint8_t* lw = (uint8_t*)(smem + ord2_off + (size_t)cap_pts * 8);
     float* lwf = (float*)lw;
     unsigned short* vlist = (unsigned short*)(smem + ord2_off + (((size_t)cap_pts * PB + 15) & ~(size_t)15));
-    for (int i = tid; i < P1 - P0; i += NT) {
-      const float4 q = scr.spt[P0 + i];
-      lxy[i] = make_float2(q.x, q.y);
-      if (WB) lw[i] = (uint8_t)q.z; else lwf[i] = q.z;
-    }
+    if (!single)
+      for (int i = tid; i < P1 - P0; i += NT) {
+        const float4 q = scr.spt[P0 + i];
+        lxy[i] = make_float2(q.x, q.y);
+        if (WB) lw[i] = (uint8_t)q.z; else lwf[i] = q.z;
+      }
     if (tid < 16) bucket[tid] = 0;
     __syncthreads();
+    STAMP(11);
     // neighbour runs of voxel v (relative to the staging area) and its own run
     auto runs_of = [&](int v, int* r0, int* r1, int& s, int& e) {
       const uint32_t key = scr.vkey[v];
@@ -1241,19 +1287,27 @@ __global__ __launch_bounds__(kFastThreads, 4) void surface_sort_kernel(const Sur
     }
     const int n16 = boff[6], n4 = boff[4], nlist = boff[2];             // C > 64 | 16 < C <= 64 | 6 <= C <= 16
     __syncthreads();
+    STAMP(12);
     // -- centroids of the split voxels: sequential float sums in sorted (= input) order, bit-exact with
     //    pcl::CentroidPoint; one lane per voxel, handed to the voxel's lane group through its scratch slot
     for (int idx = tid; idx < n4; idx += NT) {
       const int v = vbeg + vlist[idx];
       const int s = (v ? (int)vs16[v - 1] : 0) - P0, e = (int)vs16[v] - P0;
       float ax = 0.f, ay = 0.f;
-      for (int p = s; p < e; p++) { const float2 q = lxy[p]; ax = __fadd_rn(ax, q.x); ay = __fadd_rn(ay, q.y); }
+      int p = s;
+      for (; p + 3 < e; p += 4) {                                       // four LDS reads in flight; the sums stay sequential
+        const float2 q0 = lxy[p], q1 = lxy[p + 1], q2 = lxy[p + 2], q3 = lxy[p + 3];
+        ax = __fadd_rn(__fadd_rn(__fadd_rn(__fadd_rn(ax, q0.x), q1.x), q2.x), q3.x);
+        ay = __fadd_rn(__fadd_rn(__fadd_rn(__fadd_rn(ay, q0.y), q1.y), q2.y), q3.y);
+      }
+      for (; p < e; p++) { const float2 q = lxy[p]; ax = __fadd_rn(ax, q.x); ay = __fadd_rn(ay, q.y); }
       const float cnt = (float)(e - s);
       CellMom* cmo = (CellMom*)&scr.tmp[v];
       cmo->cx = __fdiv_rn(ax, cnt); cmo->cy = __fdiv_rn(ay, cnt);
     }
     __threadfence_block();
     __syncthreads();
+    STAMP(13);
     // -- moments
     auto tier = [&](auto g_tag, const int lbeg, const int lend) {
       constexpr int G = decltype(g_tag)::value;
@@ -1306,7 +1360,9 @@ __global__ __launch_bounds__(kFastThreads, 4) void surface_sort_kernel(const Sur
       }
     };
     tier(std::integral_constant<int, 16>{}, 0, n16);
+    STAMP(14);
     tier(std::integral_constant<int, 4>{}, n16, n4);
+    STAMP(15);
     tier(std::integral_constant<int, 1>{}, n4, nlist);
     __syncthreads();                                                   // the staging area is reused by the next slab
     ya = yb;
@@ -1516,15 +1572,18 @@ int cfear_surface_launch(cfear_ctx* ctx, const void* d_jobs, int n_jobs, const c
     static int calls = 0;
     if (++calls % 40 == 0) {
       (void)hipStreamSynchronize(ctx->stream);
-      double acc[9] = {0}, sub[2] = {0};
+      double acc[9] = {0}, sub[2] = {0}, cel[6] = {0};
       const int m = std::min(n_jobs, 256);
       for (int j = 0; j < m; j++) {
-        long long t[11];
+        long long t[16];
         (void)hipMemcpy(t, d_scratch + (size_t)j * cm.scratch_stride + 64, sizeof(t), hipMemcpyDeviceToHost);
         for (int q = 1; q < 9; q++) acc[q] += (double)(t[q] - t[q - 1]);
         sub[0] += (double)(t[9] - t[1]); sub[1] += (double)(t[10] - t[9]);
+        cel[0] += (double)(t[11] - t[7]); cel[1] += (double)(t[12] - t[11]); cel[2] += (double)(t[13] - t[12]);
+        cel[3] += (double)(t[14] - t[13]); cel[4] += (double)(t[15] - t[14]); cel[5] += (double)(t[8] - t[15]);
       }
-      fprintf(stderr, "  comp split: row table %.0f  point loop (tid 0) %.0f\n", sub[0] / m, sub[1] / m);
+      fprintf(stderr, "  cells split (last slab, tid 0): stage %.0f  classify+list %.0f  centroids %.0f  16-lane %.0f  4-lane %.0f  1-lane %.0f\n",
+              cel[0] / m, cel[1] / m, cel[2] / m, cel[3] / m, cel[4] / m, cel[5] / m);
       fprintf(stderr, "surface_sort phases (cycles, mean of %d jobs): count %.0f  comp+bbox %.0f  hist %.0f  scan %.0f  scatter %.0f  order %.0f  spt %.0f  cells %.0f\n",
               m, acc[1] / m, acc[2] / m, acc[3] / m, acc[4] / m, acc[5] / m, acc[6] / m, acc[7] / m, acc[8] / m);
     }
