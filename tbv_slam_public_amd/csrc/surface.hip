@@ -74,6 +74,7 @@ struct SurfCommon {
   int32_t fast_ok;                            // reach == 1: the fast pipeline applies
   int32_t scratch_cap;                        // points the per-scan scratch is sized for (>= kMaxPoints)
   int32_t finish_keys;                        // sort keys surface_finish_kernel's LDS holds
+  uint32_t finish_lds;                        // its dynamic LDS bytes
 };
 
 struct TmpCell {                              // one candidate cell per voxel (before compaction)
@@ -356,7 +357,7 @@ __device__ __forceinline__ int upper_bound_u32(const uint32_t* a, int lo, int hi
 
 // Sorts the n float means of a scan by (x, cell index) into v.sorted_{x,y,idx}; block-wide collective.
 // keys: LDS scratch for at least next_pow2(n) 64-bit keys.
-__device__ void sort_cells_block(const ScanView& v, int n, unsigned long long* keys) {
+__device__ void sort_cells_block(const ScanView& v, int n, unsigned long long* keys, const size_t lds_bytes = 0) {
   const int tid = threadIdx.x, nth = blockDim.x;
   int npad = 64;
   while (npad < n) npad <<= 1;
@@ -370,6 +371,61 @@ __device__ void sort_cells_block(const ScanView& v, int n, unsigned long long* k
     keys[i] = key;
   }
   __syncthreads();
+  if (n > 128 && n <= 2048 && lds_bytes >= (size_t)npad * 16 + 1024) {
+    // Bucketed rank sort.  A plain rank sort compares every key with every other (335 cells: 112 k comparisons, half of
+    // surface_finish_kernel's instructions); here the keys are first grouped into 64 buckets by x (a monotone function
+    // of x, so a key's rank = keys in lower buckets + smaller keys of its own bucket -- still the exact (x, index) order)
+    // with an LDS counting sort, and every key only meets the ~n / 64 keys of its bucket.
+    constexpr int B = 64;
+    unsigned long long* keys2 = keys + npad;
+    int* cnt = (int*)(keys2 + npad);                       // [B] counts -> cursors | [B + 1] starts | 32 floats
+    int* start = cnt + B;
+    float* red = (float*)(start + B + 1);
+    auto x_of = [](unsigned long long key) {
+      const unsigned u = (unsigned)(key >> 32);
+      return __uint_as_float((u >> 31) ? (u ^ 0x80000000u) : ~u);
+    };
+    float mn = FLT_MAX, mx = -FLT_MAX;
+    for (int i = tid; i < n; i += nth) { const float x = x_of(keys[i]); mn = fminf(mn, x); mx = fmaxf(mx, x); }
+    for (int o = 32; o > 0; o >>= 1) { mn = fminf(mn, __shfl_xor(mn, o)); mx = fmaxf(mx, __shfl_xor(mx, o)); }
+    if ((tid & 63) == 0) { red[tid >> 6] = mn; red[16 + (tid >> 6)] = mx; }
+    if (tid < B) cnt[tid] = 0;
+    __syncthreads();
+    mn = red[0]; mx = red[16];
+    for (int w = 1; w < (nth >> 6); w++) { mn = fminf(mn, red[w]); mx = fmaxf(mx, red[16 + w]); }
+    const float scale = mx > mn ? (float)B / (mx - mn) : 0.f;
+    auto bucket_of = [&](float x) { return min(B - 1, (int)((x - mn) * scale)); };
+    for (int i = tid; i < n; i += nth) atomicAdd(&cnt[bucket_of(x_of(keys[i]))], 1);
+    __syncthreads();
+    if (tid < 64) {                                        // B == 64: one wavefront scans the buckets
+      const int c = cnt[tid];
+      const int incl = wave_incl_scan_i32(c);
+      start[tid] = incl - c;
+      if (tid == 63) start[B] = incl;
+    }
+    __syncthreads();
+    if (tid < B) cnt[tid] = start[tid];
+    __syncthreads();
+    for (int i = tid; i < n; i += nth) {
+      const unsigned long long key = keys[i];
+      keys2[atomicAdd(&cnt[bucket_of(x_of(key))], 1)] = key;
+    }
+    __syncthreads();
+    for (int j = tid; j < n; j += nth) {
+      const unsigned long long key = keys2[j];
+      const int b = bucket_of(x_of(key));
+      const int bs = start[b], be = start[b + 1];
+      int rank = bs, q = bs;
+      for (; q + 1 < be; q += 2) { const unsigned long long k0 = keys2[q], k1 = keys2[q + 1]; rank += (k0 < key) + (k1 < key); }
+      if (q < be) rank += keys2[q] < key;
+      const int i = (int)(unsigned)(key & 0xFFFFFFFFu);
+      const float2 m = v.mean_f[i];
+      v.sorted_x[rank] = m.x;
+      v.sorted_y[rank] = m.y;
+      v.sorted_idx[rank] = i;
+    }
+    return;
+  }
   if (n <= 2048) {
     // rank sort: keys are unique, so rank = #smaller keys; every lane reads the same LDS address per
     // step (broadcast), no barriers -- far cheaper than ~50 bitonic passes for a few hundred cells.
@@ -419,9 +475,9 @@ __device__ void sort_cells_block(const ScanView& v, int n, unsigned long long* k
   }
 }
 
-__global__ __launch_bounds__(kSurfThreads) void scan_sort_kernel(ScanView v) {
+__global__ __launch_bounds__(kSurfThreads) void scan_sort_kernel(ScanView v, uint32_t lds_bytes) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-  sort_cells_block(v, *v.n_cells, (unsigned long long*)smem);
+  sort_cells_block(v, *v.n_cells, (unsigned long long*)smem, lds_bytes);
 }
 
 // Clouds with more than kMaxPoints points (CA-CFAR sweeps: cfar.cpp:35-71 puts no bound on the detections per row):
@@ -819,7 +875,7 @@ __device__ void surface_points_job(const SurfJob* __restrict__ jobs, const SurfC
   // ---- 6. x-sorted copy of the float means for the matcher's windowed exact 1-NN -----------------
   __threadfence_block();
   __syncthreads();
-  sort_cells_block(job.out, min(sh_misc[0], job.out.cap), (unsigned long long*)smem);
+  sort_cells_block(job.out, min(sh_misc[0], job.out.cap), (unsigned long long*)smem, kLdsRowbegOff);
   if (tid == 0) {
     const int total = sh_misc[0];
     *job.out.n_cells = total <= job.out.cap ? total : job.out.cap;
@@ -1425,7 +1481,7 @@ __global__ __launch_bounds__(kFinishThreads) void surface_finish_kernel(const Su
   __syncthreads();
   const int total = total_s;
   const int cap = min(job.out.cap, cm.finish_keys);
-  sort_cells_block(job.out, min(total, cap), (unsigned long long*)smem);
+  sort_cells_block(job.out, min(total, cap), (unsigned long long*)smem, cm.finish_lds);
   if (tid == 0) {
     *job.out.n_cells = total <= cap ? total : cap;
     cm.status[job_id] = total <= cap ? CFEAR_OK : CFEAR_ERR_CAPACITY;
@@ -1535,7 +1591,8 @@ int cfear_surface_launch(cfear_ctx* ctx, const void* d_jobs, int n_jobs, const c
   int keys_pow2 = 64;
   while (keys_pow2 < max_cell_cap && keys_pow2 < kMaxPoints) keys_pow2 <<= 1;   // the x-sort holds at most 16 384 cells (128 KiB)
   cm.finish_keys = keys_pow2;
-  const size_t finish_lds = (size_t)keys_pow2 * 8;
+  const size_t finish_lds = std::max((size_t)keys_pow2 * 8, (size_t)std::min(keys_pow2, 2048) * 16 + 1024);   // bucketed rank sort: two key arrays
+  cm.finish_lds = (uint32_t)finish_lds;
   if (finish_lds > 64 * 1024)
     CFEAR_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)surface_finish_kernel,
                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)finish_lds));
@@ -1692,7 +1749,8 @@ extern "C" int cfear_scan_from_cells(cfear_ctx* ctx, const cfear_cell* cells, in
       CFEAR_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)scan_sort_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                                (int)((size_t)kMaxPoints * 8)));
     if (npad > kMaxPoints) { cfear_scan_destroy(s); return cfear_set_error(ctx, CFEAR_ERR_CAPACITY, "more than %d cells", kMaxPoints); }
-    hipLaunchKernelGGL(scan_sort_kernel, dim3(1), dim3(kSurfThreads), (size_t)npad * 8, ctx->stream, s->view);
+    const size_t sort_lds = std::max((size_t)npad * 8, (size_t)std::min(npad, 2048) * 16 + 1024);
+    hipLaunchKernelGGL(scan_sort_kernel, dim3(1), dim3(kSurfThreads), sort_lds, ctx->stream, s->view, (uint32_t)sort_lds);
     CFEAR_HIP_CHECK(ctx, hipGetLastError());
   }
   CFEAR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));     // caller's host array may go away
