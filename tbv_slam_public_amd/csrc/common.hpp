@@ -163,7 +163,8 @@ struct RegCostMode {
 int cfear_register_launch(cfear_ctx* ctx, const void* d_jobs, int n_jobs, const cfear_reg_params* par, int slots_cap,
                           int lds_targets, char* d_scratch, cfear_reg_result* d_results, const RegCostMode* mode = nullptr,
                           size_t job_stride = 0,    // 0: full records (cfear_reg_job_bytes)
-                          bool compact = false);    // 2-wavefront / 40 KB geometry: the caller guarantees that every job fits
+                          bool compact = false,     // 2-wavefront / 40 KB geometry: the caller guarantees that every job fits
+                          bool big_pass = false);   // second launch (one workgroup per CU, all of its LDS) for registrations too large for 80 KB
 size_t cfear_reg_job_stride(int max_scans);         // bytes of a record that holds up to max_scans scan views
 void cfear_reg_job_set_itr(void* job, int itr);
 // quadratic fit of the cost samples -> 6x6 covariance (covariance.hip, host)

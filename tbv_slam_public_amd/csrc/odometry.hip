@@ -152,6 +152,7 @@ struct cfear_odometry {
   std::vector<double> cov;             // [n_streams][36] cov_current
   std::vector<int32_t> cov_sampled;    // [n_streams]
   std::vector<Stream> streams;
+  int big_regs = 0;                    // > 0: recent frames held registrations too large for 80 KB of LDS -> keep the second launch on
   std::vector<double> cost_est, cost_tmp;   // per stream: work of its last registration (residuals x iterations): orders the next batch
   std::vector<ScanView> views;         // [n_streams * slabs_per_stream]
 };
@@ -616,7 +617,7 @@ static int process_frame(cfear_odometry* od, const uint8_t* polar, const uint8_t
   if (n_jobs > 0) {
     OD_CHECK(hipStreamWaitEvent(ctx->stream, od->ev_jobs, 0));
     rc = cfear_register_launch(ctx, od->d_reg_jobs, n_jobs, &par.reg, par.submap_scan_size * od->cell_cap, od->cell_cap,
-                               od->d_reg_scratch, od->d_results, nullptr, rjb);
+                               od->d_reg_scratch, od->d_results, nullptr, rjb, false, od->big_regs > 0);
     if (rc != CFEAR_OK) return fail(rc);
     OD_CHECK(hipMemcpyAsync(od->h_results, od->d_results, (size_t)n_jobs * sizeof(cfear_reg_result),
                                         hipMemcpyDeviceToHost, ctx->stream));
@@ -674,6 +675,7 @@ static int process_frame(cfear_odometry* od, const uint8_t* polar, const uint8_t
   g_tl.mark(3);
   // ---- frame policy (:195-257) ------------------------------------------------------------------
   int first_error = CFEAR_OK;
+  bool saw_big = false;
   for (int b = 0; b < B; b++) {
     Stream& st = od->streams[b];
     cfear_frame_info& fi = info[b];
@@ -700,6 +702,7 @@ static int process_frame(cfear_odometry* od, const uint8_t* polar, const uint8_t
     const cfear_reg_result& rr = od->h_results[st.job];
     fi.reg_status = rr.status; fi.outer_iters = rr.outer_iters; fi.lm_iters = rr.lm_iters; fi.score = rr.score;
     od->cost_est[b] = (double)rr.num_residuals * (3.0 * rr.outer_iters + rr.lm_iters);   // association ~ 3 LM iterations
+    if (rr.reserved != 0.0) saw_big = true;
     {                                                             // cov_current = cov_vek.back() (:196)
       double* cv = od->cov.data() + (size_t)b * 36;
       for (int k = 0; k < 36; k++) cv[k] = 0.0;
@@ -765,6 +768,7 @@ static int process_frame(cfear_odometry* od, const uint8_t* polar, const uint8_t
   }
   for (int b = 0; b < B; b++) od->streams[b].cur_slab = -1;      // every slab is a keyframe or back on the free list
 #undef OD_CHECK
+  od->big_regs = saw_big ? 64 : std::max(0, od->big_regs - 1);     // large scans come in runs: keep the second launch for 64 frames
   g_tl.mark(4);
   g_tl.end();
   return first_error != CFEAR_OK ? first_error : prefetch_rc;

@@ -69,6 +69,8 @@ struct RegCommon {
   int32_t cost_only;
   int32_t n_samples;
   int32_t samples_per_axis;
+  int32_t big_mode;                           // 0: single launch | 1: first launch, registrations that only fit lds_big are deferred | 2: the deferred ones
+  uint32_t lds_big;                           // dynamic LDS of the second launch (one workgroup per CU)
   int32_t pad;
   double xy_half, yaw_half;
   const cfear_reg_result* prior;              // cost-only: source pose and itr_ come from these records (device)
@@ -96,6 +98,8 @@ constexpr size_t kRegLdsBudget = REG_LDS_KB * 1024 - 256;    // keeps 2 workgrou
 // Compact geometry for small registrations (a two-scan loop-closure candidate needs ~37 KB): 2 wavefronts and 40 KB per
 // workgroup, so four registrations share a CU instead of two.  The work of one registration is a chain of short
 // dependent phases, so halving its lanes costs little latency while doubling the registrations in flight.
+constexpr int kRegDeferred = 1000;            // internal status between the two launches of a batch with large registrations
+constexpr int kRegNWBig = 8;                  // wavefronts of the second launch's workgroups (one per CU)
 constexpr int kRegNWCompact = 2;
 constexpr size_t kRegLdsBudgetCompact = 40 * 1024 - 256;
 // Measured on MI355X (round 1): with ~190 VGPRs only 2 wavefronts fit a SIMD, so the wave-per-job
@@ -558,7 +562,7 @@ struct FusedLds {
   int G;               // grid cells per axis
   double2* smean;      // [n_src] source means (read by every evaluation); the source normals / scales / sample
                        // counts are read from global memory next to the target attributes (accepted pairs only)
-  int* match;          // [n_pairs]
+  unsigned short* match;   // [n_pairs] matched target (index inside its keyframe, < kMaxTargetsLds), 0xFFFF = none
   double* dense;       // rest
   int dense_cap;
 };
@@ -586,7 +590,7 @@ __device__ __forceinline__ bool fused_carve(uint8_t* smem, size_t lds_total, int
   f.txyi = (float4*)(smem + off); off += (size_t)sum_tar * 16;
   const size_t ns = ((size_t)n_src + 1) & ~(size_t)1;
   f.smean = (double2*)(smem + off); off += ns * 16;
-  f.match = (int*)(smem + off); off += (((size_t)n_pairs + 3) & ~(size_t)3) * 4;
+  f.match = (unsigned short*)(smem + off); off += (((size_t)n_pairs + 7) & ~(size_t)7) * 2;
   off = (off + 15) & ~(size_t)15;
   if (sum_tar > 65535 || off + n_cells * 4 + 1024 > lds_total) return false;   // cell table is u16; counters alias dense
   f.dense = (double*)(smem + off);
@@ -800,7 +804,7 @@ __device__ int associate_fused(const RegJob& job, const RegCommon& cm, const dou
         const double nsx = T[0] * ns.x + T[1] * ns.y, nsy = T[2] * ns.x + T[3] * ns.y;
         if (fmax(nsx * nt.x + nsy * nt.y, 0.0) > cm.angle_outlier) m = best;    // :244-245
       }
-      f.match[p] = m;
+      f.match[p] = (unsigned short)m;                                           // -1 -> 0xFFFF
       accepted += (m >= 0);
       s += NW * 64;
       while (s >= n_src && i < last) { s -= n_src; i++; }
@@ -841,7 +845,8 @@ __device__ int associate_fused(const RegJob& job, const RegCommon& cm, const dou
     const ScanView& srcv = job.scans[last];
     auto gather = [&](int p, int i, int s) {
       Gathered g;
-      g.best = p < n_pairs ? f.match[p] : -1;
+      g.best = p < n_pairs ? (int)f.match[p] : 0xFFFF;
+      if (g.best == 0xFFFF) g.best = -1;
       g.i = i; g.s = s;
       if (g.best >= 0) {
         const void* const* tp = f.tptr + i * 5;           // matched target's attribute arrays
@@ -1106,6 +1111,7 @@ __global__ __launch_bounds__(NW * 64) void register_kernel(const RegJob* __restr
   double* lds_dense = (double*)(smem + kRegFixedLds + reg_lds_targets_bytes(cm.lds_targets));
   const RegJob& job = *(const RegJob*)((const char*)jobs + (size_t)blockIdx.x * cm.job_stride);
   cfear_reg_result* res = cm.results + blockIdx.x;
+  if (cm.big_mode == 2 && res->status != kRegDeferred) return;       // second launch: only what the first one deferred
   const int last = job.n_scans - 1;
   const int n_src = *job.scans[last].n_cells;
   int max_tar = 0;
@@ -1139,6 +1145,15 @@ __global__ __launch_bounds__(NW * 64) void register_kernel(const RegJob* __restr
   for (int i = 0; i < last; i++) sum_tar += *job.scans[i].n_cells;
   FusedLds fl;
   const bool fused = fused_carve(smem, cm.lds_total, last, sum_tar, n_src, n_slots, cm.dense_fields, fl);
+  if (!fused && cm.big_mode == 1) {
+    // Too large for the association in 80 KB of LDS, but not for a workgroup that owns the CU's LDS: leave it to the second
+    // launch instead of the x-window path below (13 x slower per registration on 1 400-cell scans).
+    FusedLds probe;
+    if (fused_carve(smem, cm.lds_big, last, sum_tar, n_src, n_slots, cm.dense_fields, probe)) {
+      if (threadIdx.x == 0) { res->status = kRegDeferred; res->reserved = 1.0; }
+      return;
+    }
+  }
   REG_T0();
   if (fused) fused_stage<NW>(job, fl, (float)cm.par.radius);
   REG_TACC(6);
@@ -1256,7 +1271,7 @@ __global__ __launch_bounds__(NW * 64) void register_kernel(const RegJob* __restr
     res->outer_iters = itr;
     res->lm_iters = lm_iters;
     res->last_relative_decrease = summary.last_relative_decrease;
-    res->reserved = 0;
+    res->reserved = (cm.big_mode == 2 || !fused) ? 1.0 : 0.0;     // a large registration: tells the caller to keep the second launch on
 #ifdef CFEAR_REG_TIMING
     res->reserved = (double)t_assoc;
     res->last_relative_decrease = (double)(__builtin_readcyclecounter() - t_total0);
@@ -1394,14 +1409,14 @@ size_t cfear_reg_fused_lds_need(int n_scans, int sum_targets, int n_src, int cos
   const size_t n_pairs = (size_t)last * n_src, fields = (size_t)reg_dense_fields(cost);
   size_t b = kRegFixedLds + 16 * 12 * 8 + 80 + 16 * 5 * 8 + 16 * 16 + 16 * 4 * 4;
   b += (((size_t)last * G * G + 1) * 2 + 15) & ~(size_t)15;
-  b += (size_t)sum_targets * 16 + (((size_t)n_src + 1) & ~(size_t)1) * 16 + ((n_pairs + 3) & ~(size_t)3) * 4 + 64;
+  b += (size_t)sum_targets * 16 + (((size_t)n_src + 1) & ~(size_t)1) * 16 + ((n_pairs + 7) & ~(size_t)7) * 2 + 64;
   b += n_pairs * (fields * 8 + 4) + 64;                 // every pair matched: upper bound of the dense arrays
   return b;
 }
 
 int cfear_register_launch(cfear_ctx* ctx, const void* d_jobs, int n_jobs, const cfear_reg_params* par, int slots_cap,
                           int lds_targets, char* d_scratch, cfear_reg_result* d_results, const RegCostMode* mode,
-                          size_t job_stride, bool compact) {
+                          size_t job_stride, bool compact, bool big_pass) {
   if (lds_targets > kMaxTargetsLds)
     return cfear_set_error(ctx, CFEAR_ERR_CAPACITY, "target scan with more than %d cells", kMaxTargetsLds);
   if (lds_targets < 1) lds_targets = 1;
@@ -1449,10 +1464,31 @@ int cfear_register_launch(cfear_ctx* ctx, const void* d_jobs, int n_jobs, const 
     }
   }
   CFEAR_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-  ProfScope ps(ctx, mode ? "get_cost" : "register");
-  hipLaunchKernelGGL(fn, dim3(n_jobs, mode ? std::max(mode->blocks_per_job, 1) : 1), dim3((compact ? kRegNWCompact : kRegNW) * 64), lds, ctx->stream,
-                     (const RegJob*)d_jobs, cm);
+  const bool two = big_pass && !mode && !compact;
+  cm.big_mode = two ? 1 : 0;
+  cm.lds_big = 160 * 1024 - 256;
+  {
+    ProfScope ps(ctx, mode ? "get_cost" : "register");
+    hipLaunchKernelGGL(fn, dim3(n_jobs, mode ? std::max(mode->blocks_per_job, 1) : 1), dim3((compact ? kRegNWCompact : kRegNW) * 64), lds, ctx->stream,
+                       (const RegJob*)d_jobs, cm);
+  }
   CFEAR_HIP_CHECK(ctx, hipGetLastError());
+  if (two) {
+    // Registrations the first launch deferred: 8 wavefronts and the whole LDS of a CU each.  Everything else returns at
+    // once (a batch without large scans pays a few microseconds; the caller switches this launch off when none show up).
+    KernelFn fb;
+    switch (par->cost) {
+      case CFEAR_P2P: fb = huber ? register_kernel<kRegNWBig, CFEAR_P2P, CFEAR_LOSS_HUBER> : register_kernel<kRegNWBig, CFEAR_P2P, -1>; break;
+      case CFEAR_P2L: fb = huber ? register_kernel<kRegNWBig, CFEAR_P2L, CFEAR_LOSS_HUBER> : register_kernel<kRegNWBig, CFEAR_P2L, -1>; break;
+      default: fb = huber ? register_kernel<kRegNWBig, CFEAR_P2D, CFEAR_LOSS_HUBER> : register_kernel<kRegNWBig, CFEAR_P2D, -1>; break;
+    }
+    CFEAR_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)fb, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    cm.big_mode = 2;
+    cm.lds_total = cm.lds_big;
+    ProfScope ps(ctx, "register_large");
+    hipLaunchKernelGGL(fb, dim3(n_jobs, 1), dim3(kRegNWBig * 64), (size_t)cm.lds_big, ctx->stream, (const RegJob*)d_jobs, cm);
+    CFEAR_HIP_CHECK(ctx, hipGetLastError());
+  }
   return CFEAR_OK;
 }
 size_t cfear_register_scratch_bytes(int slots_cap) { return reg_scratch_bytes(slots_cap); }
