@@ -315,6 +315,38 @@ def test_long_closed_trajectory_keeps_per_frame_parity():
     assert worst[:2].max() < 1e-9                             # in fact nowhere near the tolerance
 
 
+def test_oxford_sequence_length_run():
+    """configs[1] is quoted on 8 617 sweeps (Oxford 10-12-32): four sequences advance that many frames around 64-frame
+    closed rings (134 laps each).  No registration may fail, the scan slabs must keep recycling, and a lap later the
+    estimate must be back where it was -- the odometry drift per 157 m lap stays in the decimetres and does not grow."""
+    import torch
+    from tbv_slam_public_amd import api, synth
+    B, F, N = 4, 64, 8617
+    rings = torch.empty((B, F, 400, 3360), dtype=torch.uint8, device="cuda")
+    for b in range(B):
+        rings[b] = synth.render_frames_torch(synth.Scene(300 + b, circle_frames=F), list(range(F)), "cuda")
+    od = api.OdometryKeyframeFuser(B, 400, 3360)
+    img = 400 * 3360
+    base = np.arange(B, dtype=np.int64) * F * img
+    poses = np.zeros((N, B, 3))
+    fails = keyframes = 0
+    for t in range(N):
+        info = od.process_offsets(rings, base + (t % F) * img, base + ((t + 1) % F) * img)
+        poses[t] = info["pose"]
+        if t > 0:
+            fails += int((info["reg_status"] != 0).sum())
+        keyframes += int(info["keyframe_added"].sum())
+        assert (info["n_cells"] > 100).all(), t
+    assert fails == 0
+    assert B * N // 8 < keyframes <= B * N
+    lap = poses[2 * F:] - poses[F:-F]                              # the same place one lap later, from the second lap on:
+    lap[..., 2] = (lap[..., 2] + np.pi) % (2 * np.pi) - np.pi      # the first registrations start without a motion prior
+    worst_xy, worst_th = np.abs(lap[..., :2]).max(), np.abs(lap[..., 2]).max()
+    assert worst_xy < 0.6 and worst_th < 0.02, (worst_xy, worst_th)   # < 0.4 % of the 157 m lap, and it does not grow:
+    early, late = np.abs(lap[:20 * F, :, :2]).max(), np.abs(lap[-20 * F:, :, :2]).max()
+    assert late < 2.0 * early + 0.05, (early, late)
+
+
 def test_image_offsets_entry_equals_the_strided_batch():
     """cfear_odometry_process_offsets: streams whose sweeps sit anywhere in one device buffer (a ring of frames, here
     in shuffled order with gaps) advance exactly like the same sweeps handed over as a strided batch."""
