@@ -241,7 +241,8 @@ typedef struct cfear_reg_result {
   int32_t lm_iters;                     /* total LM iterations */
   int32_t status;                       /* CFEAR_OK / CFEAR_ERR_TOO_FEW_RESIDUALS / CFEAR_ERR_SOLVER */
   double last_relative_decrease;        /* summary_.iterations.back().relative_decrease */
-  double reserved;
+  double reserved;                      /* diagnostic: 1.0 when the registration was too large for the 80 KB association
+                                         * geometry (second launch / global-scratch path); 0.0 otherwise */
 } cfear_reg_result;                     /* 72 bytes */
 
 /* Replaces n_scan_normal_reg::Register (n_scan_normal.cpp:82-185).  poses_xyt [n_scans][3]

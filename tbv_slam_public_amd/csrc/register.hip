@@ -1413,6 +1413,11 @@ size_t cfear_reg_fused_lds_need(int n_scans, int sum_targets, int n_src, int cos
   b += n_pairs * (fields * 8 + 4) + 64;                 // every pair matched: upper bound of the dense arrays
   return b;
 }
+// The same without the dense arrays (they may live in global scratch): what fused_carve needs to accept a registration.
+static size_t reg_fused_lds_core(int n_scans, int sum_targets, int n_src, int cost) {
+  const size_t n_pairs = (size_t)(n_scans - 1) * n_src, fields = (size_t)reg_dense_fields(cost);
+  return cfear_reg_fused_lds_need(n_scans, sum_targets, n_src, cost) - (n_pairs * (fields * 8 + 4) + 64) + 1024;
+}
 
 int cfear_register_launch(cfear_ctx* ctx, const void* d_jobs, int n_jobs, const cfear_reg_params* par, int slots_cap,
                           int lds_targets, char* d_scratch, cfear_reg_result* d_results, const RegCostMode* mode,
@@ -1508,7 +1513,7 @@ size_t cfear_register_scratch_bytes(int slots_cap) { return reg_scratch_bytes(sl
 // ---- host-facing wrappers ----------------------------------------------------------------------
 namespace {
 
-struct JobSizes { int slots_cap = 1; int lds_targets = 1; size_t fused_need = 0; int cost = CFEAR_P2L; };
+struct JobSizes { int slots_cap = 1; int lds_targets = 1; size_t fused_need = 0, fused_core = 0; int cost = CFEAR_P2L; };
 
 int gather_job(cfear_ctx* ctx, const cfear_scan* const* scans, int n_scans, const double* poses, unsigned char* dst,
                JobSizes& sz) {
@@ -1526,6 +1531,7 @@ int gather_job(cfear_ctx* ctx, const cfear_scan* const* scans, int n_scans, cons
     else { sz.slots_cap = std::max(sz.slots_cap, (n_scans - 1) * std::max(nc, 1)); n_src = nc; }
   }
   sz.fused_need = std::max(sz.fused_need, cfear_reg_fused_lds_need(n_scans, sum_tar, n_src, sz.cost));
+  sz.fused_core = std::max(sz.fused_core, reg_fused_lds_core(n_scans, sum_tar, n_src, sz.cost));
   cfear_reg_fill_job(dst, views, n_scans, poses);
   return CFEAR_OK;
 }
@@ -1563,7 +1569,9 @@ extern "C" int cfear_register_batch(cfear_ctx* ctx, const cfear_reg_job* jobs, i
   char* d_jobs = ws;
   cfear_reg_result* d_res = (cfear_reg_result*)(ws + (jb + 255) / 256 * 256);
   CFEAR_HIP_CHECK(ctx, hipMemcpyAsync(d_jobs, hjobs, jb, hipMemcpyHostToDevice, ctx->stream));
-  rc = cfear_register_launch(ctx, d_jobs, n_jobs, par, sz.slots_cap, sz.lds_targets, scr, d_res, nullptr, stride, compact);
+  // a registration whose keyframes do not fit the 80 KB association: second launch with a CU's whole LDS per workgroup
+  const bool big = sz.fused_core > kRegLdsBudget;
+  rc = cfear_register_launch(ctx, d_jobs, n_jobs, par, sz.slots_cap, sz.lds_targets, scr, d_res, nullptr, stride, compact, big);
   if (rc != CFEAR_OK) { (void)hipStreamSynchronize(ctx->stream); return rc; }
   CFEAR_HIP_CHECK(ctx, hipMemcpyAsync(results, d_res, rb, hipMemcpyDeviceToHost, ctx->stream));
   CFEAR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));

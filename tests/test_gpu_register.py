@@ -96,6 +96,44 @@ def test_many_to_one_window():
     _compare_register(reg2, cells[1:], poses[1:])
 
 
+def _dense_cells(seed, frames):
+    from oracle import pyoracle as O
+    from tbv_slam_public_amd import synth
+    imgs, gt, _ = synth.scene_dense(seed, max(frames) + 1)
+    out = []
+    for f in frames:
+        sr, si, sc = O.kstrongest(imgs[f], 40, 60)
+        out.append(O.surface_points(O.kstrongest_cloud(sr, si, sc, 0.0438, 2.5), 3.0, 1.0, (0, 0), True))
+    return out, gt
+
+
+def test_large_scans_take_the_second_launch():
+    """Scans of ~1 400 cells: four keyframes do not fit the 80 KB association, so the batch entry adds the second launch
+    (one workgroup per CU with all of its LDS); a five-scan window still fits it, and the result is the oracle's either
+    way.  Mixed with an ordinary job in the same batch: that one must come out exactly as it does alone."""
+    from tbv_slam_public_amd import api
+    frames = [0, 1, 2, 3, 4]
+    cells, gt = _dense_cells(7, frames)
+    assert min(len(c) for c in cells) > 1000
+    poses = np.array([_rel(gt[0], gt[f]) for f in frames])
+    poses[-1] += [0.3, -0.2, 0.008]
+    reg = api.n_scan_normal_reg("P2P", "Huber", 0.1, 4)
+    _compare_register(reg, cells, poses)                              # 4 x ~1400 targets: second launch
+    _compare_register(reg, cells[2:], poses[2:])                      # 2 x ~1400: still the ordinary geometry
+    small, gts = _cells(3, frames)
+    sp = np.array([_rel(gts[0], gts[f]) for f in frames])
+    sp[-1] += [0.4, -0.2, 0.01]
+    alone = reg.Register([api.MapPointNormal(cells=c) for c in small], sp)[1]
+    jobs = [([api.MapPointNormal(cells=c) for c in cells], poses), ([api.MapPointNormal(cells=c) for c in small], sp)]
+    both = reg.RegisterBatch(jobs)
+    np.testing.assert_array_equal(both[1]["pose"], alone[-1])
+    assert both[0]["reserved"] == 1.0 and both[1]["reserved"] == 0.0     # which geometry served the registration
+    from oracle import pyoracle as O
+    _, po, ro = O.register(cells, poses, _oracle_par(reg))
+    assert np.abs(both[0]["pose"][:2] - po[-1, :2]).max() <= POS_TOL and abs(both[0]["pose"][2] - po[-1, 2]) <= ROT_TOL
+    assert both[0]["outer_iters"] == ro.outer_iters and both[0]["num_residuals"] == ro.num_residuals
+
+
 def test_failure_too_few_residuals():
     from oracle import pyoracle as O
     from tbv_slam_public_amd import api, _lib as L
