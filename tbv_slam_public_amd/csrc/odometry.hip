@@ -133,6 +133,12 @@ struct cfear_odometry {
   char* d_slabs = nullptr;
   char* d_surf_jobs = nullptr;
   char* d_reg_jobs = nullptr;
+  // what a frame returns to the host lives in ONE device block (and one pinned block): results | status | n_cells |
+  // n_points -- one read-back per frame instead of four small copies queued between the matcher and the next sweep
+  char* d_out = nullptr;
+  char* h_out = nullptr;
+  size_t out_bytes = 0;
+  int32_t* d_npts_out = nullptr;       // n_points slot of the block (rows mode: written by surface_prep_kernel)
   cfear_reg_result* d_results = nullptr;
   int32_t* d_status = nullptr;
   int32_t* d_ncells = nullptr;         // gathered n_cells of the current scans
@@ -183,9 +189,9 @@ extern "C" int cfear_odometry_destroy(cfear_odometry* od) {
   for (void* p : dev2) if (p) (void)hipFree(p);
   if (od->h_offsets) (void)hipHostFree(od->h_offsets);
   void* dev[] = {od->d_pk2[0], od->d_pk2[1], od->d_npk2[0], od->d_npk2[1], od->d_mot, od->d_polar, od->d_rot, od->d_sel, od->d_xyzi2[0], od->d_xyzi2[1], od->d_npts2[0], od->d_npts2[1], od->d_slabs, od->d_surf_jobs, od->d_reg_jobs,
-                 od->d_results, od->d_status, od->d_ncells, od->d_surf_scratch, od->d_reg_scratch, od->d_samples};
+                 od->d_out, od->d_surf_scratch, od->d_reg_scratch, od->d_samples};
   for (void* p : dev) if (p) (void)hipFree(p);
-  void* host[] = {od->h_mot, od->h_npk, od->h_surf_jobs, od->h_reg_jobs, od->h_results, od->h_status, od->h_npts, od->h_ncells, od->h_samples};
+  void* host[] = {od->h_mot, od->h_npk, od->h_surf_jobs, od->h_reg_jobs, od->h_out, od->h_samples};
   for (void* p : host) if (p) (void)hipHostFree(p);
   delete od;
   return CFEAR_OK;
@@ -271,17 +277,25 @@ extern "C" int cfear_odometry_create(cfear_ctx* ctx, int32_t n_streams, const cf
   ok = ok && dalloc(&od->d_slabs, (size_t)B * od->slabs_per_stream * od->slab_bytes);
   ok = ok && dalloc(&od->d_surf_jobs, (size_t)B * cfear_surface_job_bytes());
   ok = ok && dalloc(&od->d_reg_jobs, (size_t)B * cfear_reg_job_bytes());
-  ok = ok && dalloc(&od->d_results, (size_t)B * sizeof(cfear_reg_result));
-  ok = ok && dalloc(&od->d_status, (size_t)B * 4);
-  ok = ok && dalloc(&od->d_ncells, (size_t)B * 4);
+  od->out_bytes = (size_t)B * (sizeof(cfear_reg_result) + 12);
+  ok = ok && dalloc(&od->d_out, od->out_bytes);
+  ok = ok && halloc(&od->h_out, od->out_bytes);
+  if (ok) {
+    auto carve = [&](char* base) {
+      struct P { cfear_reg_result* r; int32_t *st, *nc, *np; } q;
+      q.r = (cfear_reg_result*)base;
+      q.st = (int32_t*)(base + (size_t)B * sizeof(cfear_reg_result));
+      q.nc = q.st + B; q.np = q.nc + B;
+      return q;
+    };
+    const auto d = carve(od->d_out), h = carve(od->h_out);
+    od->d_results = d.r; od->d_status = d.st; od->d_ncells = d.nc; od->d_npts_out = d.np;
+    od->h_results = h.r; od->h_status = h.st; od->h_ncells = h.nc; od->h_npts = h.np;
+  }
   ok = ok && dalloc(&od->d_surf_scratch, (size_t)B * cfear_surface_scratch_bytes(od->cap_points));
   ok = ok && dalloc(&od->d_reg_scratch, (size_t)B * cfear_register_scratch_bytes(par->submap_scan_size * od->cell_cap));
   ok = ok && halloc(&od->h_surf_jobs, (size_t)B * cfear_surface_job_bytes());
   ok = ok && halloc(&od->h_reg_jobs, (size_t)B * cfear_reg_job_bytes());
-  ok = ok && halloc(&od->h_results, (size_t)B * sizeof(cfear_reg_result));
-  ok = ok && halloc(&od->h_status, (size_t)B * 4);
-  ok = ok && halloc(&od->h_npts, (size_t)B * 4);
-  ok = ok && halloc(&od->h_ncells, (size_t)B * 4);
   if (par->estimate_cov_by_sampling) {
     od->fit.prepare(par->cov_sampling.samples_per_axis, par->cov_sampling.xy_range * 0.5, par->cov_sampling.yaw_range * 0.5);
     ok = ok && dalloc(&od->d_samples, (size_t)B * od->fit.m * sizeof(cfear_reg_result));
@@ -521,7 +535,7 @@ static int process_frame(cfear_odometry* od, const uint8_t* polar, const uint8_t
     od->last_slab[b] = st.cur_slab;
     if (par.keep_nodes) { od->h_mot[3 * b] = mot[0]; od->h_mot[3 * b + 1] = mot[1]; od->h_mot[3 * b + 2] = mot[2]; }
     if (rows_mode)
-      cfear_surface_fill_job_rows(od->h_surf_jobs + (size_t)b * sjb, od->d_xyzi + (size_t)b * od->cap_points * 4, od->d_npts + b,
+      cfear_surface_fill_job_rows(od->h_surf_jobs + (size_t)b * sjb, od->d_xyzi + (size_t)b * od->cap_points * 4, od->d_npts_out + b,
                                   od->d_rowpts2[od->cur_buf] + (size_t)b * od->desc.rows * par.kstrong.k_strongest,
                                   od->d_rowcnt2[od->cur_buf] + (size_t)b * od->desc.rows * 2, od->desc.rows,
                                   par.kstrong.k_strongest, par.compensate, mot,
@@ -619,8 +633,6 @@ static int process_frame(cfear_odometry* od, const uint8_t* polar, const uint8_t
     rc = cfear_register_launch(ctx, od->d_reg_jobs, n_jobs, &par.reg, par.submap_scan_size * od->cell_cap, od->cell_cap,
                                od->d_reg_scratch, od->d_results, nullptr, rjb, false, od->big_regs > 0);
     if (rc != CFEAR_OK) return fail(rc);
-    OD_CHECK(hipMemcpyAsync(od->h_results, od->d_results, (size_t)n_jobs * sizeof(cfear_reg_result),
-                                        hipMemcpyDeviceToHost, ctx->stream));
     if (par.estimate_cov_by_sampling) {
       // approximateCovarianceBySampling (:203-208, 261-316): n^3 GetCost evaluations around the pose the
       // registration just produced; pose and leftover itr_ are read from d_results on the device, so no host
@@ -648,9 +660,9 @@ static int process_frame(cfear_odometry* od, const uint8_t* polar, const uint8_t
     }
     OD_CHECK(hipMemcpyAsync(od->h_npk, od->d_npk, (size_t)B * 4, hipMemcpyDeviceToHost, ctx->stream));
   }
-  OD_CHECK(hipMemcpyAsync(od->h_status, od->d_status, (size_t)B * 4, hipMemcpyDeviceToHost, ctx->stream));
-  OD_CHECK(hipMemcpyAsync(od->h_npts, od->d_npts, (size_t)B * 4, hipMemcpyDeviceToHost, ctx->stream));
-  OD_CHECK(hipMemcpyAsync(od->h_ncells, od->d_ncells, (size_t)B * 4, hipMemcpyDeviceToHost, ctx->stream));
+  if (!rows_mode)     // the point counts came from the filter / the caller: bring them into the block first
+    OD_CHECK(hipMemcpyAsync(od->d_npts_out, od->d_npts, (size_t)B * 4, hipMemcpyDeviceToDevice, ctx->stream));
+  OD_CHECK(hipMemcpyAsync(od->h_out, od->d_out, od->out_bytes, hipMemcpyDeviceToHost, ctx->stream));
   OD_CHECK(hipEventRecord(od->ev_results, ctx->stream));
   int prefetch_rc = CFEAR_OK;
   if (polar_next) {

@@ -1442,6 +1442,7 @@ __global__ __launch_bounds__(kFinishThreads) void surface_finish_kernel(const Su
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int job_id = blockIdx.x;
   const SurfScratch scr = scratch_of(cm.scratch + (size_t)job_id * cm.scratch_stride, cm.scratch_cap);
+  if (job_id == 0 && tid == 0) cm.fallback[0] = 0;                     // the hand-over list has been drained: ready for the next launch
   if (scr.hdr->route != kRouteFast) return;
   const SurfJob job = jobs[job_id];
   const int V = scr.hdr->V;
@@ -1580,9 +1581,11 @@ int cfear_surface_launch(cfear_ctx* ctx, const void* d_jobs, int n_jobs, const c
   cm.n_jobs = n_jobs;
   cm.fast_ok = cm.reach == 1 ? 1 : 0;
   // work list of the scans the fast pipeline hands to the single-kernel path: count + job ids
+  // (its counter is zeroed by surface_finish_kernel for the next launch; a fresh allocation is zeroed here)
+  const void* ws_before = ctx->ws[11].p;
   cm.fallback = (int32_t*)cfear_workspace(ctx, 11, ((size_t)n_jobs + 16) * 4);
   if (!cm.fallback) return cfear_set_error(ctx, CFEAR_ERR_HIP, "workspace allocation failed");
-  CFEAR_HIP_CHECK(ctx, hipMemsetAsync(cm.fallback, 0, 4, ctx->stream));
+  if (cm.fallback != ws_before) CFEAR_HIP_CHECK(ctx, hipMemsetAsync(cm.fallback, 0, 4, ctx->stream));
   // per launch: the attribute is per device, and contexts on other threads / devices share this code
   CFEAR_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)surface_points_kernel,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)cfear_surface_lds_bytes()));
