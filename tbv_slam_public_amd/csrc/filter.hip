@@ -671,8 +671,13 @@ struct CfarArgs {
   unsigned long long* det_bits;   // [batch][rows][words]  (words = ceil(cols/64))
   int32_t* det_count;             // [batch][rows]
   int words;
+  int raw_in_lds;                 // the row's bytes are kept in LDS next to the prefix sums (rows up to 7168 bins)
 };
 
+// One wavefront per azimuth row.  The row is read once in 16-byte pieces (lane-interleaved, coalesced) into LDS together
+// with the exact uint32 prefix sums of its squares: 16 bins are summed inside a lane and ONE wave scan per 1024 bins
+// places the lanes (the first version scanned every 64 bins with single-byte loads: 53 dependent DPP ladders per row).
+// The threshold test then runs from LDS.
 __global__ __launch_bounds__(256) void cacfar_rows_kernel(const CfarArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -680,16 +685,44 @@ __global__ __launch_bounds__(256) void cacfar_rows_kernel(const CfarArgs a) {
   if (grow >= (long long)a.batch * a.rows) return;
   const int b = (int)(grow / a.rows), r = (int)(grow - (long long)b * a.rows);
   const uint8_t* rowp = a.polar + (long long)b * a.batch_stride + (long long)r * a.stride;
-  const int colsp = (a.cols + 64) & ~63;
-  uint32_t* P = (uint32_t*)(smem + (size_t)wave * ((size_t)colsp * 4 + 256));   // P[i] = sum_{q<i} I_q^2, exact in uint32
-  // prefix sums of squares, 64 bins per step (coalesced byte loads, conflict-free LDS writes)
+  const int colsp = (a.cols + 1023) & ~1023;                               // whole 1024-bin chunks
+  uint8_t* wbase = smem + (size_t)wave * ((size_t)colsp * (a.raw_in_lds ? 5 : 4) + 256);
+  // A[4 + i] = sum_{q<=i} I_q^2, exact in uint32; P[i] = sum_{q<i} = A[3 + i] with A[3] = 0 (16-byte aligned writes)
+  uint32_t* A = (uint32_t*)wbase;
+  const uint32_t* P = A + 3;
+  uint8_t* raw = wbase + (size_t)(colsp + 16) * 4;                         // the row itself (when it fits)
+  const bool vec = (((uintptr_t)rowp) & 15) == 0;
   uint32_t run = 0;
-  if (lane == 0) P[0] = 0;
-  for (int i0 = 0; i0 < a.cols; i0 += 64) {
-    const int i = i0 + lane;
-    const uint32_t v = i < a.cols ? (uint32_t)rowp[i] : 0u;
-    const int incl = wave_incl_scan_i32((int)(v * v));
-    if (i < a.cols) P[i + 1] = run + (uint32_t)incl;
+  if (lane == 0) A[3] = 0;
+  for (int c0 = 0; c0 < a.cols; c0 += 1024) {
+    const int pos = c0 + lane * 16;
+    uint32_t w[4] = {0u, 0u, 0u, 0u};
+    if (vec && pos + 16 <= a.cols) {
+      const u32x4 v = __builtin_nontemporal_load((const u32x4*)(rowp + pos));
+      w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
+    } else if (pos < a.cols) {
+#pragma unroll
+      for (int d = 0; d < 4; d++)
+#pragma unroll
+        for (int by = 0; by < 4; by++) {
+          const int q = pos + d * 4 + by;
+          if (q < a.cols) w[d] |= (uint32_t)rowp[q] << (8 * by);
+        }
+    }
+    if (a.raw_in_lds) *(uint4*)(raw + pos) = make_uint4(w[0], w[1], w[2], w[3]);
+    uint32_t loc[16];                                                      // inclusive sums of squares inside the lane
+    uint32_t acc = 0;
+#pragma unroll
+    for (int j = 0; j < 16; j++) {
+      const uint32_t v = (w[j >> 2] >> (8 * (j & 3))) & 0xffu;
+      acc += v * v;
+      loc[j] = acc;
+    }
+    const int incl = wave_incl_scan_i32((int)acc);
+    const uint32_t base = run + (uint32_t)incl - acc;
+#pragma unroll
+    for (int j = 0; j < 16; j += 4)
+      *(uint4*)(A + 4 + pos + j) = make_uint4(base + loc[j], base + loc[j + 1], base + loc[j + 2], base + loc[j + 3]);
     run += (uint32_t)__builtin_amdgcn_readlane(incl, 63);
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -701,8 +734,9 @@ __global__ __launch_bounds__(256) void cacfar_rows_kernel(const CfarArgs a) {
     bool det = false;
     if (bin < a.cols) {
       const double range = a.range_res * (double)bin;                         // cfar.cpp:43
-      const uint32_t sq = P[bin + 1] - P[bin];
-      const double intensity = (double)rowp[bin];
+      const uint32_t v = a.raw_in_lds ? raw[bin] : rowp[bin];
+      const uint32_t sq = v * v;
+      const double intensity = (double)v;
       if (range > a.min_distance && range < a.max_distance && intensity > a.static_threshold) {   // :45
         const int t0 = max(0, bin - a.guard - a.window), t1 = bin - a.guard;  // :48-49
         const int f0 = bin + a.guard, f1 = min(a.cols, bin + a.guard + a.window);   // :52-53
@@ -739,6 +773,10 @@ struct CfarCloudArgs {
   uint8_t* det_mask;
 };
 
+// Compaction in (row, bin) order.  grid = (image, kCloudSplit row slices): every workgroup scans all row counts (cheap)
+// and emits the rows of its slice, one wavefront per row: lane w takes word w of the row's detection bitmap, a wave
+// scan of the popcounts places the words, and each lane walks the set bits of its own word.  (The first version gave one
+// workgroup a whole image and walked every 64-bin word of every row in turn: 1.5 ms per batch whatever its size.)
 __global__ __launch_bounds__(256) void cacfar_cloud_kernel(const CfarCloudArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   int32_t* row_off = (int32_t*)smem;
@@ -761,19 +799,27 @@ __global__ __launch_bounds__(256) void cacfar_cloud_kernel(const CfarCloudArgs a
     if (threadIdx.x == 0) run_base += wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
     __syncthreads();
   }
-  if (threadIdx.x == 0) a.n_points[b] = run_base;
+  if (threadIdx.x == 0 && blockIdx.y == 0) a.n_points[b] = run_base;
   const uint8_t* img = a.polar + (long long)b * a.batch_stride;
-  for (int r = wave; r < a.rows; r += 4) {
-    int base = row_off[r];
+  const int rows_per = (a.rows + (int)gridDim.y - 1) / (int)gridDim.y;
+  const int rbeg = blockIdx.y * rows_per, rend = min(a.rows, rbeg + rows_per);
+  for (int r = rbeg + wave; r < rend; r += 4) {
     const double cos_t = a.cos_t[r], sin_t = a.sin_t[r];
-    for (int wd = 0; wd < a.words; wd++) {
-      const unsigned long long bits = a.det_bits[((long long)b * a.rows + r) * a.words + wd];
-      const int bin = wd * 64 + lane;
-      const bool det = (bits >> lane) & 1ull;
-      if (a.det_mask && bin < a.cols) a.det_mask[((long long)b * a.rows + r) * a.cols + bin] = det ? 1 : 0;
-      if (det) {
-        const int idx = base + __popcll(bits & ((1ull << lane) - 1ull));
+    int base = row_off[r];
+    for (int w0 = 0; w0 < a.words; w0 += 64) {                              // cols <= 8192: at most two rounds
+      const int wd = w0 + lane;
+      unsigned long long bits = wd < a.words ? a.det_bits[((long long)b * a.rows + r) * a.words + wd] : 0ull;
+      if (a.det_mask && wd < a.words)
+        for (int j = 0; j < 64 && wd * 64 + j < a.cols; j++)
+          a.det_mask[((long long)b * a.rows + r) * a.cols + wd * 64 + j] = (uint8_t)((bits >> j) & 1ull);
+      const int pc = __popcll(bits);
+      const int incl = wave_incl_scan_i32(pc);
+      int idx = base + incl - pc;
+      while (bits) {
+        const int t = __ffsll((long long)bits) - 1;
+        bits &= bits - 1;
         if (idx < a.cap_points) {
+          const int bin = wd * 64 + t;
           const double range = a.range_res * (double)bin;
           float4 p;
           p.x = (float)(range * cos_t);                                       // cfar.cpp:63-65
@@ -782,8 +828,9 @@ __global__ __launch_bounds__(256) void cacfar_cloud_kernel(const CfarCloudArgs a
           p.w = (float)img[(long long)r * a.stride + bin];
           ((float4*)a.xyzi)[(long long)b * a.cap_points + idx] = p;
         }
+        idx++;
       }
-      base += __popcll(bits);
+      base += __builtin_amdgcn_readlane(incl, 63);
     }
   }
 }
@@ -1198,11 +1245,15 @@ int cfear_cacfar_device(cfear_ctx* ctx, const uint8_t* d_polar, const cfear_pola
   a.det_count = (int32_t*)(ws + (bits_bytes + 255) / 256 * 256);
   a.words = words;
   const long long nrows = (long long)batch * rows;
-  const int colsp = (cols + 64) & ~63;
+  const int colsp = (cols + 1023) & ~1023;
   {
+    // per wavefront: prefix sums u32[colsp + 16] | the row u8[colsp]
+    a.raw_in_lds = (size_t)kRowsPerBlock * ((size_t)colsp * 5 + 256) <= 150 * 1024 ? 1 : 0;
+    const size_t rows_lds = (size_t)kRowsPerBlock * ((size_t)colsp * (a.raw_in_lds ? 5 : 4) + 256);
+    if (rows_lds > 64 * 1024)
+      CFEAR_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)cacfar_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rows_lds));
     ProfScope ps(ctx, "cacfar_rows");
-    hipLaunchKernelGGL(cacfar_rows_kernel, dim3((unsigned)((nrows + kRowsPerBlock - 1) / kRowsPerBlock)), dim3(256),
-                       (size_t)kRowsPerBlock * ((size_t)colsp * 4 + 256), ctx->stream, a);
+    hipLaunchKernelGGL(cacfar_rows_kernel, dim3((unsigned)((nrows + kRowsPerBlock - 1) / kRowsPerBlock)), dim3(256), rows_lds, ctx->stream, a);
   }
   CFEAR_HIP_CHECK(ctx, hipGetLastError());
   double *d_cos = nullptr, *d_sin = nullptr;
@@ -1215,7 +1266,7 @@ int cfear_cacfar_device(cfear_ctx* ctx, const uint8_t* d_polar, const cfear_pola
   c.xyzi = d_xyzi; c.n_points = d_n_points; c.cap_points = cap_points; c.det_mask = d_det_mask;
   {
     ProfScope ps(ctx, "cacfar_cloud");
-    hipLaunchKernelGGL(cacfar_cloud_kernel, dim3(batch), dim3(256), (size_t)(rows + 1) * 4, ctx->stream, c);
+    hipLaunchKernelGGL(cacfar_cloud_kernel, dim3(batch, kCloudSplit), dim3(256), (size_t)(rows + 1) * 4, ctx->stream, c);
   }
   CFEAR_HIP_CHECK(ctx, hipGetLastError());
   return CFEAR_OK;
