@@ -95,7 +95,7 @@ static_assert(sizeof(CellMom) <= sizeof(TmpCell), "CellMom lives in the TmpCell 
 //   + 128 N   int32[N]     validity flags / compaction offsets
 //   + 132 N   u32[N + 4]   fast: voxel starts (V + 1 entries)
 //   + 136 N+16 u16[kFastMaxCells + 4]  fast: cell -> ordinal of the first occupied cell at or after it
-constexpr int kFastMaxCells = 16384;          // grid cells the LDS counting sort can address
+constexpr int kFastMaxCells = 32768;          // grid cells the LDS counting sort can address (u16 pair counters; the LDS check below decides)
 constexpr int kFastThreads = 512;
 constexpr size_t kFastLds = 78 * 1024;        // two workgroups per CU (160 KiB); three (52 KiB, 80 VGPRs) measured no faster: the kernel is issue-bound
 constexpr int kRouteFast = 0, kRouteFallback = 1, kRouteDone = 2, kRoutePrepped = 3;
