@@ -574,6 +574,47 @@ def main(argv=None):
                                      "(PCIe-bound; never `value`); a ring of %d frame batches cycles" % Gh}
         hod.close()
         del host
+        # ---- the other sensor setups of BASELINE.json, each on its own synthetic worlds ----------------------------
+        # configs[2]: MulRan (sweeps arrive [range bins][azimuths], 0.0595 m bins, counter-clockwise, 5-keyframe window);
+        # configs[4]: CA-CFAR on the Kvarntorp setup (0.175 m bins: 588 m range, ~15 000 detections per sweep)
+        def side_config(params, seed0, range_res, bins_major, Bs, Ss, nfr):
+            from tbv_slam_public_amd import synth
+            Fs = 16
+            sr = torch.empty((Ss, Fs, ROWS, COLS), dtype=torch.uint8, device=dev)
+            for q in range(Ss):
+                scn = synth.Scene(seed0 + q, circle_frames=F, range_res=range_res, ccw=True)
+                sr[q] = synth.render_frames_torch(scn, list(range(Fs)), dev)
+            sod = api.OdometryKeyframeFuser(Bs, COLS if bins_major else ROWS, ROWS if bins_major else COLS, params, ctx=ctx)
+            seq = torch.arange(Bs, device=dev) % Ss
+
+            def frame(t):                                        # stream b = world b % Ss at frame t (worlds shared, poses not)
+                x = sr[:, t % Fs].index_select(0, seq)
+                return torch.rot90(x, -1, dims=(1, 2)).contiguous() if bins_major else x
+            batches = [frame(t) for t in range(4)]                # the ring's first frames, cycled as gathered batches
+            bad = 0
+            for t in range(4):
+                sod.process(batches[t % 4], batches[(t + 1) % 4])
+            D.barrier()
+            ctx.profile_enable(True); ctx.profile_read(reset=True)
+            t0s = time.perf_counter()
+            pts = cells = 0.0
+            for t in range(nfr):
+                info = sod.process(batches[t % 4], batches[(t + 1) % 4])
+                bad += int((info["reg_status"] < 0).sum())
+                pts += float(info["n_points"].mean()); cells += float(info["n_cells"].mean())
+            D.barrier()
+            dts = time.perf_counter() - t0s
+            sp = ctx.profile_read(reset=True); ctx.profile_enable(False)
+            sod.close()
+            return {"value": Bs * nfr / dts, "unit": "registrations/s", "ms_per_frame_batch": dts / nfr * 1e3, "streams": Bs,
+                    "frames": nfr, "mean_points_per_scan": pts / nfr, "mean_cells_per_scan": cells / nfr,
+                    "failed_registrations": bad, "kernel_breakdown": {k: v[0] / max(v[1], 1) for k, v in sp.items()},
+                    "note": "4 gathered frame batches cycle (not a continuous trajectory)"}
+        out["config2_mulran"] = side_config(api.odometry_preset("CFEAR-3", "mulran", submap_scan_size=5), 70000, 0.0595238, True, 1024, 32, 12)
+        out["config4_cacfar_kvarntorp"] = side_config(
+            api.odometry_params(filter_type=1, cacfar_range_res=0.175, cacfar_z_min=20.0, cacfar_nb_guard_cells=10,
+                                cacfar_window_size=40, cacfar_false_alarm_rate=0.01, radar_ccw=1, kstrong_range_res=0.175),
+            80000, 0.175, False, 512, 32, 8)
         # ---- loop-closure candidates from cached features (configs[3]) ---------------------------------------
         lc = loopclosure_run(D, args.candidates, 20, 3)
         out["loopclosure"] = {k: lc[k] for k in ("value", "unit", "ms_per_step", "ms_per_4096", "ok_fraction", "mean_outer_iters")}

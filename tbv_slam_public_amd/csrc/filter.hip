@@ -672,12 +672,19 @@ struct CfarArgs {
   int32_t* det_count;             // [batch][rows]
   int words;
   int raw_in_lds;                 // the row's bytes are kept in LDS next to the prefix sums (rows up to 7168 bins)
+  int thr_i, bin_lo, bin_hi;      // candidate pre-test in integers: intensity >= thr_i, bin_lo <= bin < bin_hi
 };
 
 // One wavefront per azimuth row.  The row is read once in 16-byte pieces (lane-interleaved, coalesced) into LDS together
 // with the exact uint32 prefix sums of its squares: 16 bins are summed inside a lane and ONE wave scan per 1024 bins
 // places the lanes (the first version scanned every 64 bins with single-byte loads: 53 dependent DPP ladders per row).
-// The threshold test then runs from LDS.
+// Only bins above the static threshold inside the range window reach the threshold arithmetic (two fp64 divisions
+// each); typically a quarter of the row.  They are marked in a bitmap while the row is in registers and then handed out
+// one per lane, so the fp64 part runs ~C / 64 times per row instead of once per 64 bins.
+__device__ __forceinline__ size_t cfar_wave_lds(int colsp, bool raw_in_lds) {
+  // A u32[colsp + 16] | raw u8[colsp] (optional) | cand u16[colsp / 16] | det u32[colsp / 32] | pref i32[colsp / 64 + 4]
+  return (size_t)(colsp + 16) * 4 + (raw_in_lds ? (size_t)colsp : 0) + (size_t)colsp / 8 + (size_t)colsp / 8 + ((size_t)colsp / 64 + 4) * 4 + 64;
+}
 __global__ __launch_bounds__(256) void cacfar_rows_kernel(const CfarArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -686,11 +693,17 @@ __global__ __launch_bounds__(256) void cacfar_rows_kernel(const CfarArgs a) {
   const int b = (int)(grow / a.rows), r = (int)(grow - (long long)b * a.rows);
   const uint8_t* rowp = a.polar + (long long)b * a.batch_stride + (long long)r * a.stride;
   const int colsp = (a.cols + 1023) & ~1023;                               // whole 1024-bin chunks
-  uint8_t* wbase = smem + (size_t)wave * ((size_t)colsp * (a.raw_in_lds ? 5 : 4) + 256);
+  const size_t per_wave = (cfar_wave_lds(colsp, a.raw_in_lds != 0) + 15) & ~(size_t)15;
+  uint8_t* wbase = smem + (size_t)wave * per_wave;
   // A[4 + i] = sum_{q<=i} I_q^2, exact in uint32; P[i] = sum_{q<i} = A[3 + i] with A[3] = 0 (16-byte aligned writes)
   uint32_t* A = (uint32_t*)wbase;
   const uint32_t* P = A + 3;
   uint8_t* raw = wbase + (size_t)(colsp + 16) * 4;                         // the row itself (when it fits)
+  uint8_t* q0 = raw + (a.raw_in_lds ? colsp : 0);
+  unsigned short* cand16 = (unsigned short*)q0;                            // bit j of cand16[h]: bin 16 h + j is a candidate
+  uint32_t* det32 = (uint32_t*)(q0 + colsp / 8);                           // detections, bit per bin
+  int* pref = (int*)(q0 + colsp / 4);                                      // [G + 1] candidates before each 64-bin word
+  const int G = colsp >> 6;
   const bool vec = (((uintptr_t)rowp) & 15) == 0;
   uint32_t run = 0;
   if (lane == 0) A[3] = 0;
@@ -711,13 +724,17 @@ __global__ __launch_bounds__(256) void cacfar_rows_kernel(const CfarArgs a) {
     }
     if (a.raw_in_lds) *(uint4*)(raw + pos) = make_uint4(w[0], w[1], w[2], w[3]);
     uint32_t loc[16];                                                      // inclusive sums of squares inside the lane
-    uint32_t acc = 0;
+    uint32_t acc = 0, cmask = 0;
 #pragma unroll
     for (int j = 0; j < 16; j++) {
       const uint32_t v = (w[j >> 2] >> (8 * (j & 3))) & 0xffu;
       acc += v * v;
       loc[j] = acc;
+      // candidate: intensity > static_threshold (an integer test: a.thr_i = the smallest passing value) inside the
+      // bins whose range passes min / max distance (a.bin_lo <= bin < a.bin_hi, found on the host with the exact test)
+      cmask |= (uint32_t)((int)v >= a.thr_i && pos + j >= a.bin_lo && pos + j < a.bin_hi) << j;
     }
+    cand16[(c0 >> 4) + lane] = (unsigned short)cmask;
     const int incl = wave_incl_scan_i32((int)acc);
     const uint32_t base = run + (uint32_t)incl - acc;
 #pragma unroll
@@ -725,35 +742,65 @@ __global__ __launch_bounds__(256) void cacfar_rows_kernel(const CfarArgs a) {
       *(uint4*)(A + 4 + pos + j) = make_uint4(base + loc[j], base + loc[j + 1], base + loc[j + 2], base + loc[j + 3]);
     run += (uint32_t)__builtin_amdgcn_readlane(incl, 63);
   }
+  for (int i = lane; i < colsp / 32; i += 64) det32[i] = 0u;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  // candidates before every 64-bin word
+  const unsigned long long* cand64 = (const unsigned long long*)cand16;
+  int C = 0;
+  for (int g0 = 0; g0 < G; g0 += 64) {
+    const int g = g0 + lane;
+    const int pc = g < G ? __popcll(cand64[g]) : 0;
+    const int incl = wave_incl_scan_i32(pc);
+    if (g < G) pref[g] = C + incl - pc;
+    C += __builtin_amdgcn_readlane(incl, 63);
+  }
+  if (lane == 0) pref[G] = C;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  for (int k0 = 0; k0 < C; k0 += 64) {
+    const int k = k0 + lane;
+    if (k < C) {
+      int lo = 0, hi = G;                                                   // the word of candidate k: last g with pref[g] <= k
+      while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (pref[mid] <= k) lo = mid; else hi = mid; }
+      int rnk = k - pref[lo];
+      unsigned long long wq = cand64[lo];
+      int pos = 0;                                                          // position of set bit number rnk
+#pragma unroll
+      for (int sh = 32; sh >= 1; sh >>= 1) {
+        const int c = __popcll(wq & ((1ull << sh) - 1ull));
+        if (rnk >= c) { rnk -= c; wq >>= sh; pos += sh; }
+      }
+      const int bin = lo * 64 + pos;
+      const uint32_t v = a.raw_in_lds ? raw[bin] : rowp[bin];
+      const uint32_t sq = v * v;
+      const int t0 = max(0, bin - a.guard - a.window), t1 = bin - a.guard;  // cfar.cpp:48-49
+      const int f0 = bin + a.guard, f1 = min(a.cols, bin + a.guard + a.window);   // :52-53
+      // getMean: sequential sum of exact integer-valued doubles / count; an empty window is 0/0
+      if (t1 > t0 && f1 > f0) {
+        const double trailing_mean = (double)(P[t1] - P[t0]) / (double)(t1 - t0);
+        const double forwarding_mean = (double)(P[f1] - P[f0]) / (double)(f1 - f0);
+        const double mean = (trailing_mean + forwarding_mean) / 2.0;        // :56
+        const double threshold = a.scaling * mean;                          // :58
+        if ((double)sq > threshold) atomicOr(&det32[bin >> 5], 1u << (bin & 31));   // :59-60
+      }
+    }
+  }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   int total = 0;
-  for (int i0 = 0; i0 < a.cols; i0 += 64) {
-    const int bin = i0 + lane;
-    bool det = false;
-    if (bin < a.cols) {
-      const double range = a.range_res * (double)bin;                         // cfar.cpp:43
-      const uint32_t v = a.raw_in_lds ? raw[bin] : rowp[bin];
-      const uint32_t sq = v * v;
-      const double intensity = (double)v;
-      if (range > a.min_distance && range < a.max_distance && intensity > a.static_threshold) {   // :45
-        const int t0 = max(0, bin - a.guard - a.window), t1 = bin - a.guard;  // :48-49
-        const int f0 = bin + a.guard, f1 = min(a.cols, bin + a.guard + a.window);   // :52-53
-        // getMean: sequential sum of exact integer-valued doubles / count; an empty window is 0/0
-        if (t1 > t0 && f1 > f0) {
-          const double trailing_mean = (double)(P[t1] - P[t0]) / (double)(t1 - t0);
-          const double forwarding_mean = (double)(P[f1] - P[f0]) / (double)(f1 - f0);
-          const double mean = (trailing_mean + forwarding_mean) / 2.0;        // :56
-          const double threshold = a.scaling * mean;                          // :58
-          det = (double)sq > threshold;                                       // :59-60
-        }
-      }
+  for (int w0 = 0; w0 < a.words; w0 += 64) {
+    const int wd = w0 + lane;
+    if (wd < a.words) {
+      const unsigned long long bits = (unsigned long long)det32[2 * wd] | ((unsigned long long)det32[2 * wd + 1] << 32);
+      a.det_bits[((long long)b * a.rows + r) * a.words + wd] = bits;
+      total += __popcll(bits);
     }
-    const unsigned long long bal = __ballot(det);
-    if (lane == 0) a.det_bits[((long long)b * a.rows + r) * a.words + (i0 >> 6)] = bal;
-    total += __popcll(bal);
   }
+  total = wave_sum_i32(total);
   if (lane == 0) a.det_count[(long long)b * a.rows + r] = total;
 }
 
@@ -1248,8 +1295,22 @@ int cfear_cacfar_device(cfear_ctx* ctx, const uint8_t* d_polar, const cfear_pola
   const int colsp = (cols + 1023) & ~1023;
   {
     // per wavefront: prefix sums u32[colsp + 16] | the row u8[colsp]
-    a.raw_in_lds = (size_t)kRowsPerBlock * ((size_t)colsp * 5 + 256) <= 150 * 1024 ? 1 : 0;
-    const size_t rows_lds = (size_t)kRowsPerBlock * ((size_t)colsp * (a.raw_in_lds ? 5 : 4) + 256);
+    auto wave_lds = [&](bool raw) {
+      return (((size_t)(colsp + 16) * 4 + (raw ? (size_t)colsp : 0) + (size_t)colsp / 8 + (size_t)colsp / 8 + ((size_t)colsp / 64 + 4) * 4 + 64) + 15) & ~(size_t)15;
+    };
+    a.raw_in_lds = (size_t)kRowsPerBlock * wave_lds(true) <= 150 * 1024 ? 1 : 0;
+    const size_t rows_lds = (size_t)kRowsPerBlock * wave_lds(a.raw_in_lds != 0);
+    // the candidate pre-test in integers.  intensity > static_threshold for integer intensities: the smallest passing value;
+    // range > min_distance && range < max_distance (cfar.cpp:43-45, range = range_res * bin in double): the bin interval,
+    // found with the reference's own expression
+    {
+      const double st = a.static_threshold;
+      a.thr_i = st < 0.0 ? 0 : (st >= 255.0 ? 256 : (int)std::floor(st) + 1);
+      int lo = 0, hi = cols;
+      while (lo < cols && !(a.range_res * (double)lo > a.min_distance)) lo++;
+      while (hi > 0 && !(a.range_res * (double)(hi - 1) < a.max_distance)) hi--;
+      a.bin_lo = lo; a.bin_hi = hi;
+    }
     if (rows_lds > 64 * 1024)
       CFEAR_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)cacfar_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rows_lds));
     ProfScope ps(ctx, "cacfar_rows");
