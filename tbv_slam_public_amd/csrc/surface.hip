@@ -94,8 +94,7 @@ static_assert(sizeof(CellMom) <= sizeof(TmpCell), "CellMom lives in the TmpCell 
 //   + 24 N    TmpCell[N]   candidate cell per voxel
 //   + 128 N   int32[N]     validity flags / compaction offsets
 //   + 132 N   u32[N + 4]   fast: voxel starts (V + 1 entries)
-//   + 136 N+16 u16[kFastMaxCells + 4]  fast: cell -> ordinal of the first occupied cell at or after it
-constexpr int kFastMaxCells = 32768;          // grid cells the LDS counting sort can address (u16 pair counters; the LDS check below decides)
+constexpr int kFastMaxCells = 1 << 18;        // grid cells of the fast pipeline (one occupancy bit + 1/16 u16 per cell in LDS; the LDS check decides)
 constexpr int kFastThreads = 512;
 constexpr size_t kFastLds = 78 * 1024;        // two workgroups per CU (160 KiB); three (52 KiB, 80 VGPRs) measured no faster: the kernel is issue-bound
 constexpr int kRouteFast = 0, kRouteFallback = 1, kRouteDone = 2, kRoutePrepped = 3;
@@ -111,7 +110,6 @@ struct SurfHdr {                              // written by surface_sort_kernel,
 __host__ __device__ inline size_t scratch_bytes_per_scan(int cap) {
   size_t b = 256;
   b += (size_t)cap * 136 + 16;
-  b += (size_t)(kFastMaxCells + 4) * 2;
   b = (b + 255) / 256 * 256;
   if (cap > kMaxPoints) b += (size_t)cap * 2 * 8 + 256;
   return (b + 255) / 256 * 256;
@@ -131,7 +129,7 @@ __host__ __device__ inline SurfScratch scratch_of(char* base, int cap) {
   r.coff = (int32_t*)(p + (size_t)cap * 128);
   r.vs = (uint32_t*)(p + (size_t)cap * 132);
   r.ord = (unsigned short*)(p + (size_t)cap * 136 + 16);
-  size_t b = 256 + (size_t)cap * 136 + 16 + (size_t)(kFastMaxCells + 4) * 2;
+  size_t b = 256 + (size_t)cap * 136 + 16;
   b = (b + 255) / 256 * 256;
   r.bigkeys = (unsigned long long*)(base + b);
   return r;
@@ -1085,15 +1083,18 @@ __global__ __launch_bounds__(kFastThreads, 4) void surface_sort_kernel(const Sur
   const float4* pts = job.xyzi;
   __syncthreads();                                                     // every thread has read the header before tid 0 may rewrite it
   STAMP(2);
-  // ---- (c) histogram of the points over the voxel grid: u16 counters, two per LDS word ---------------------------
-  // cnt[c] for c in [0, ncells]; after the scan the same words hold ord[c] = occupied cells before c.
-  const int words = (ncells + 2) >> 1;                                // covers c = ncells
-  uint32_t* cw = (uint32_t*)smem;
-  const size_t ord_bytes = ((size_t)words * 4 + 15) & ~(size_t)15;
+  // ---- (c) occupancy of the voxel grid: ONE BIT per cell + the occupied cells before every 32-cell word.  ord(c) = the
+  //      number of occupied cells before cell c is then two LDS reads and a popcount, for any cell, at 0.19 bytes of LDS
+  //      per cell (dense u16 counters took 2 bytes: MulRan's 134 x 134 and Kvarntorp's 392 x 392 voxels did not fit). ----
+  const int nw32 = (ncells >> 5) + 1;                                 // covers c = ncells
+  uint32_t* occ = (uint32_t*)smem;
+  unsigned short* wpref = (unsigned short*)(smem + (size_t)nw32 * 4);
+  const size_t ord_bytes = ((size_t)nw32 * 6 + 15) & ~(size_t)15;
+  if (ord_bytes + 8192 > kFastLds - 512) { hand_over(n, 1); return; }
   __syncthreads();                                                   // rowoff is dead
-  for (int w = tid; w < words; w += NT) cw[w] = 0u;
+  for (int w = tid; w < nw32; w += NT) occ[w] = 0u;
   __syncthreads();
-  unsigned short mycell[kPer];                                        // the cells of this thread's points (registers)
+  unsigned short mycell[kPer];                                        // the cells of this thread's points (registers); later their voxels
   bool w_small = true;                                                // every weight max(I - 60, 0) an integer in [0, 255]?
 #pragma unroll
   for (int j0 = 0; j0 < kPer; j0 += 8) {                              // eight loads in flight per thread
@@ -1112,8 +1113,8 @@ __global__ __launch_bounds__(kFastThreads, 4) void surface_sort_kernel(const Sur
         const int ijk0 = (int)(floorf(p.x * cm.inv_leaf) - (float)min_bx);
         const int ijk1 = (int)(floorf(p.y * cm.inv_leaf) - (float)min_by);
         const int c = ijk0 + ijk1 * dbx;
-        mycell[j] = (unsigned short)c;
-        atomicAdd(&cw[c >> 1], (c & 1) ? 0x10000u : 1u);
+        mycell[j] = (unsigned short)c;                                  // complete for grids up to 65 536 cells
+        atomicOr(&occ[c >> 5], 1u << (c & 31));
         const float wgt = fmaxf(__fsub_rn(p.w, 60.0f), 0.0f);
         w_small = w_small && wgt <= 255.0f && wgt == truncf(wgt);
       }
@@ -1121,23 +1122,17 @@ __global__ __launch_bounds__(kFastThreads, 4) void surface_sort_kernel(const Sur
   }
   const bool wbyte = __syncthreads_and(w_small ? 1 : 0) != 0;
   STAMP(3);
-  // ---- (d) exclusive scan over the cells: points before a cell (voxel starts) and occupied cells before it -------
-  const int per = (words + NT - 1) / NT;                              // consecutive words per thread (<= 17)
-  const int w0 = tid * per, w1 = min(words, w0 + per);
-  int tp = 0, to = 0;
-  for (int w = w0; w < w1; w++) {
-    const uint32_t x = cw[w];
-    const int a = (int)(x & 0xffffu), b = (int)(x >> 16);
-    tp += a + b; to += (a != 0) + (b != 0);
-  }
-  const int packed = (to << 16) | tp;                                 // both totals < 65536: one scan carries both
-  const int incl = wave_incl_scan_i32(packed);
+  // ---- (d) occupied cells before every word (exclusive scan of the popcounts); the voxel keys in cell order --------
+  const int per = (nw32 + NT - 1) / NT;                               // consecutive words per thread
+  const int w0 = min(nw32, tid * per), w1 = min(nw32, w0 + per);
+  int to = 0;
+  for (int w = w0; w < w1; w++) to += __popc(occ[w]);
+  int incl = wave_incl_scan_i32(to);
   if (lane == 63) red_i[wave] = incl;
   __syncthreads();
-  int excl = incl - packed, tot = 0;
-  for (int wv = 0; wv < NW; wv++) { if (wv < wave) excl += red_i[wv]; tot += red_i[wv]; }
-  const int V = tot >> 16;
-  // LDS budget: ord | voxel cursors u16[V + 2] | order u16[n] (later: staged points)
+  int excl = incl - to, V = 0;
+  for (int wv = 0; wv < NW; wv++) { if (wv < wave) excl += red_i[wv]; V += red_i[wv]; }
+  // LDS budget: occupancy | voxel cursors u16[V + 2] | order u16[n] (later: staged points)
   const size_t vs_off = ord_bytes, vs_bytes = (((size_t)V + 2) * 2 + 15) & ~(size_t)15;
   const size_t ord2_off = vs_off + vs_bytes, need = ord2_off + (((size_t)n * 2 + 15) & ~(size_t)15);
   if (need > kFastLds - 512) { hand_over(n, 1); return; }
@@ -1145,26 +1140,71 @@ __global__ __launch_bounds__(kFastThreads, 4) void surface_sort_kernel(const Sur
   uint32_t* vs32 = (uint32_t*)(smem + vs_off);
   unsigned short* order = (unsigned short*)(smem + ord2_off);
   {
-    int run_p = excl & 0xffff, run_o = excl >> 16;
+    int run_o = excl;
     for (int w = w0; w < w1; w++) {
-      const uint32_t x = cw[w];
-      const int a = (int)(x & 0xffffu), b = (int)(x >> 16);
-      const int oa = run_o;
-      if (a) { vs16[run_o] = (unsigned short)run_p; scr.vkey[run_o] = (uint32_t)(2 * w); run_o++; run_p += a; }
-      const int ob = run_o;
-      if (b) { vs16[run_o] = (unsigned short)run_p; scr.vkey[run_o] = (uint32_t)(2 * w + 1); run_o++; run_p += b; }
-      cw[w] = (uint32_t)oa | ((uint32_t)ob << 16);
+      wpref[w] = (unsigned short)run_o;
+      uint32_t bits = occ[w];
+      while (bits) { const int t = __ffs(bits) - 1; bits &= bits - 1; scr.vkey[run_o++] = (uint32_t)(32 * w + t); }
+    }
+  }
+  for (int k = tid; k < (V + 3) / 2; k += NT) vs32[k] = 0u;           // per-voxel point counters
+  __syncthreads();
+  auto ord = [&](int c) { const int w = c >> 5; return (int)wpref[w] + __popc(occ[w] & ((1u << (c & 31)) - 1u)); };
+  // points per voxel; mycell[] holds the VOXEL (ordinal) of each point from here on.  Grids beyond 65 536 cells (long-range
+  // sensors) read the points a second time (L2): their cell needs 18 bits, and 32 more registers spilled the kernel.
+  if (ncells <= 65536) {
+#pragma unroll
+    for (int j = 0; j < kPer; j++) {
+      const int i = tid + j * NT;
+      if (i < n) {
+        const int v = ord((int)mycell[j]);
+        mycell[j] = (unsigned short)v;
+        atomicAdd(&vs32[v >> 1], (v & 1) ? 0x10000u : 1u);
+      }
+    }
+  } else {
+#pragma unroll
+    for (int j0 = 0; j0 < kPer; j0 += 8) {
+      float2 pq[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        const int i = tid + (j0 + u) * NT;
+        if (i < n) pq[u] = *(const float2*)&pts[i];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        const int j = j0 + u, i = tid + j * NT;
+        if (i < n) {
+          const int ijk0 = (int)(floorf(pq[u].x * cm.inv_leaf) - (float)min_bx);
+          const int ijk1 = (int)(floorf(pq[u].y * cm.inv_leaf) - (float)min_by);
+          const int v = ord(ijk0 + ijk1 * dbx);
+          mycell[j] = (unsigned short)v;
+          atomicAdd(&vs32[v >> 1], (v & 1) ? 0x10000u : 1u);
+        }
+      }
     }
   }
   __syncthreads();
-  const unsigned short* ord16 = (const unsigned short*)smem;
+  {                                                                  // counts -> voxel starts (exclusive scan over the voxels)
+    const int perv = (V + NT - 1) / NT;
+    const int o0 = min(V, tid * perv), o1 = min(V, o0 + perv);
+    int tp = 0;
+    for (int o = o0; o < o1; o++) tp += (int)vs16[o];
+    incl = wave_incl_scan_i32(tp);
+    if (lane == 63) red_i[NW + wave] = incl;
+    __syncthreads();
+    int run_p = incl - tp;
+    for (int wv = 0; wv < wave; wv++) run_p += red_i[NW + wv];
+    for (int o = o0; o < o1; o++) { const int cnt = (int)vs16[o]; vs16[o] = (unsigned short)run_p; run_p += cnt; }
+  }
+  __syncthreads();
   STAMP(4);
   // ---- (e) scatter: the atomic cursor of a voxel ends at the start of the next one --------------------------------
 #pragma unroll
   for (int j = 0; j < kPer; j++) {
     const int i = tid + j * NT;
     if (i < n) {
-      const int v = ord16[mycell[j]];
+      const int v = (int)mycell[j];
       const uint32_t old = atomicAdd(&vs32[v >> 1], (v & 1) ? 0x10000u : 1u);
       const int pos = (v & 1) ? (int)(old >> 16) : (int)(old & 0xffffu);
       order[pos] = (unsigned short)i;
@@ -1177,7 +1217,7 @@ __global__ __launch_bounds__(kFastThreads, 4) void surface_sort_kernel(const Sur
   for (int j = 0; j < kPer; j++) {
     const int i = tid + j * NT;
     if (i < n) {
-      const int v = ord16[mycell[j]];
+      const int v = (int)mycell[j];
       const int s0 = v ? (int)vs16[v - 1] : 0, e0 = (int)vs16[v];
       int rank = 0, q = s0;
       for (; q + 3 < e0; q += 4) {                                      // four independent LDS reads in flight
@@ -1252,7 +1292,7 @@ __global__ __launch_bounds__(kFastThreads, 4) void surface_sort_kernel(const Sur
   //      or one lane; group partial sums are combined with DPP all-reduces.  The fp64 sums of a split voxel are then
   //      added in a different order than the oracle's sequential loop -- differences of a few ulp, inside the 1e-9
   //      tolerance the cell tests carry; the float voxel centroid stays a sequential sum (bit-exact).
-  auto pbefore = [&](int c) { const int o = ord16[c]; return o ? (int)vs16[o - 1] : 0; };    // points in cells < c
+  auto pbefore = [&](int c) { const int o = ord(c); return o ? (int)vs16[o - 1] : 0; };      // points in cells < c
   float2* lxy = (float2*)(smem + ord2_off);
   int* bucket = red_i;                                                 // [16] counters, then cursors (red_i is free here)
   constexpr int kSlabVoxels = 4 * NT;                                  // voxels per slab: their (bucket, slot) stay in registers
@@ -1265,10 +1305,10 @@ __global__ __launch_bounds__(kFastThreads, 4) void surface_sort_kernel(const Sur
   const bool wi = cm.weight_intensity != 0;
   for (int ya = 0; ya < dby;) {                                       // block-uniform
     const int P0 = pbefore(max(ya - 1, 0) * dbx);
-    const int vbeg = ord16[ya * dbx];
+    const int vbeg = ord(ya * dbx);
     // a slab fits when its points (PB bytes each, padded) and its voxel list (2 bytes each) fit the staging area
     auto fits = [&](int yb) {
-      const int np = pbefore(min(yb + 1, dby) * dbx) - P0, nv = (int)ord16[yb * dbx] - vbeg;
+      const int np = pbefore(min(yb + 1, dby) * dbx) - P0, nv = ord(yb * dbx) - vbeg;
       return nv <= kSlabVoxels && (size_t)((np + 3) & ~3) * PB + (size_t)nv * 2 + 16 <= avail;
     };
     int lo = ya + 1, hi = dby;                                        // largest yb in [ya + 1, dby] that fits
@@ -1279,7 +1319,7 @@ __global__ __launch_bounds__(kFastThreads, 4) void surface_sort_kernel(const Sur
     }
     const int yb = lo;
     const int P1 = pbefore(min(yb + 1, dby) * dbx);
-    const int vend = ord16[yb * dbx];
+    const int vend = ord(yb * dbx);
     const int cap_pts = (P1 - P0 + 3) & ~3;
     uint8_t* lw = (uint8_t*)(smem + ord2_off + (size_t)cap_pts * 8);
     float* lwf = (float*)lw;
@@ -1632,6 +1672,18 @@ int cfear_surface_launch(cfear_ctx* ctx, const void* d_jobs, int n_jobs, const c
     static int calls = 0;
     if (++calls % 40 == 0) {
       (void)hipStreamSynchronize(ctx->stream);
+      {
+        int32_t nfb = -1;
+        (void)hipMemcpy(&nfb, cm.fallback, 4, hipMemcpyDeviceToHost);   // (already reset by the finish kernel: read the routes instead)
+        int routes[4] = {0, 0, 0, 0}, prepared = 0;
+        for (int j = 0; j < n_jobs; j++) {
+          SurfHdr h;
+          (void)hipMemcpy(&h, d_scratch + (size_t)j * cm.scratch_stride, sizeof(h), hipMemcpyDeviceToHost);
+          if (h.route >= 0 && h.route < 4) routes[h.route]++;
+          if (h.route == kRouteFallback) prepared += h.pad[0];
+        }
+        fprintf(stderr, "surface routes of %d jobs: fast %d  fallback %d (prepared %d)  done %d  prepped %d\n", n_jobs, routes[0], routes[1], prepared, routes[2], routes[3]);
+      }
       double acc[9] = {0}, sub[2] = {0}, cel[6] = {0};
       const int m = std::min(n_jobs, 256);
       for (int j = 0; j < m; j++) {
