@@ -671,7 +671,6 @@ struct CfarArgs {
   unsigned long long* det_bits;   // [batch][rows][words]  (words = ceil(cols/64))
   int32_t* det_count;             // [batch][rows]
   int words;
-  int raw_in_lds;                 // the row's bytes are kept in LDS next to the prefix sums (rows up to 7168 bins)
   int thr_i, bin_lo, bin_hi;      // candidate pre-test in integers: intensity >= thr_i, bin_lo <= bin < bin_hi
 };
 
@@ -681,9 +680,9 @@ struct CfarArgs {
 // Only bins above the static threshold inside the range window reach the threshold arithmetic (two fp64 divisions
 // each); typically a quarter of the row.  They are marked in a bitmap while the row is in registers and then handed out
 // one per lane, so the fp64 part runs ~C / 64 times per row instead of once per 64 bins.
-__device__ __forceinline__ size_t cfar_wave_lds(int colsp, bool raw_in_lds) {
-  // A u32[colsp + 16] | raw u8[colsp] (optional) | cand u16[colsp / 16] | det u32[colsp / 32] | pref i32[colsp / 64 + 4]
-  return (size_t)(colsp + 16) * 4 + (raw_in_lds ? (size_t)colsp : 0) + (size_t)colsp / 8 + (size_t)colsp / 8 + ((size_t)colsp / 64 + 4) * 4 + 64;
+__host__ __device__ inline size_t cfar_wave_lds(int colsp) {
+  // P4 u32[colsp / 4 + 4] | raw u8[colsp] | cand u16[colsp / 16] | det u32[colsp / 32] | pref i32[colsp / 64 + 4]
+  return (((size_t)(colsp / 4 + 4) * 4 + (size_t)colsp + (size_t)colsp / 8 + (size_t)colsp / 8 + ((size_t)colsp / 64 + 4) * 4) + 15) & ~(size_t)15;
 }
 __global__ __launch_bounds__(256) void cacfar_rows_kernel(const CfarArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -693,20 +692,18 @@ __global__ __launch_bounds__(256) void cacfar_rows_kernel(const CfarArgs a) {
   const int b = (int)(grow / a.rows), r = (int)(grow - (long long)b * a.rows);
   const uint8_t* rowp = a.polar + (long long)b * a.batch_stride + (long long)r * a.stride;
   const int colsp = (a.cols + 1023) & ~1023;                               // whole 1024-bin chunks
-  const size_t per_wave = (cfar_wave_lds(colsp, a.raw_in_lds != 0) + 15) & ~(size_t)15;
-  uint8_t* wbase = smem + (size_t)wave * per_wave;
-  // A[4 + i] = sum_{q<=i} I_q^2, exact in uint32; P[i] = sum_{q<i} = A[3 + i] with A[3] = 0 (16-byte aligned writes)
-  uint32_t* A = (uint32_t*)wbase;
-  const uint32_t* P = A + 3;
-  uint8_t* raw = wbase + (size_t)(colsp + 16) * 4;                         // the row itself (when it fits)
-  uint8_t* q0 = raw + (a.raw_in_lds ? colsp : 0);
-  unsigned short* cand16 = (unsigned short*)q0;                            // bit j of cand16[h]: bin 16 h + j is a candidate
-  uint32_t* det32 = (uint32_t*)(q0 + colsp / 8);                           // detections, bit per bin
-  int* pref = (int*)(q0 + colsp / 4);                                      // [G + 1] candidates before each 64-bin word
+  uint8_t* wbase = smem + (size_t)wave * cfar_wave_lds(colsp);
+  // Prefix sums of squares, exact in uint32, kept for every FOURTH bin only (P4[i] = sum_{q < 4 i} I_q^2) next to the row's
+  // bytes: P(x) = P4[x / 4] + the squares of up to three bytes of one LDS word.  A quarter of the LDS of a full table,
+  // i.e. 16 instead of 8 wavefronts per CU -- the kernel is bound by the latency of its dependent LDS reads.
+  uint32_t* P4 = (uint32_t*)wbase;
+  uint8_t* raw = wbase + (size_t)(colsp / 4 + 4) * 4;                      // the row itself
+  unsigned short* cand16 = (unsigned short*)(raw + colsp);                 // bit j of cand16[h]: bin 16 h + j is a candidate
+  uint32_t* det32 = (uint32_t*)(raw + colsp + colsp / 8);                  // detections, bit per bin
+  int* pref = (int*)(raw + colsp + colsp / 4);                             // [G + 1] candidates before each 64-bin word
   const int G = colsp >> 6;
   const bool vec = (((uintptr_t)rowp) & 15) == 0;
   uint32_t run = 0;
-  if (lane == 0) A[3] = 0;
   for (int c0 = 0; c0 < a.cols; c0 += 1024) {
     const int pos = c0 + lane * 16;
     uint32_t w[4] = {0u, 0u, 0u, 0u};
@@ -722,30 +719,45 @@ __global__ __launch_bounds__(256) void cacfar_rows_kernel(const CfarArgs a) {
           if (q < a.cols) w[d] |= (uint32_t)rowp[q] << (8 * by);
         }
     }
-    if (a.raw_in_lds) *(uint4*)(raw + pos) = make_uint4(w[0], w[1], w[2], w[3]);
-    uint32_t loc[16];                                                      // inclusive sums of squares inside the lane
-    uint32_t acc = 0, cmask = 0;
+    *(uint4*)(raw + pos) = make_uint4(w[0], w[1], w[2], w[3]);
+    uint32_t q4[4];                                                        // sums of squares of the lane's four 4-bin groups
+    uint32_t cmask = 0;
 #pragma unroll
-    for (int j = 0; j < 16; j++) {
-      const uint32_t v = (w[j >> 2] >> (8 * (j & 3))) & 0xffu;
-      acc += v * v;
-      loc[j] = acc;
-      // candidate: intensity > static_threshold (an integer test: a.thr_i = the smallest passing value) inside the
-      // bins whose range passes min / max distance (a.bin_lo <= bin < a.bin_hi, found on the host with the exact test)
-      cmask |= (uint32_t)((int)v >= a.thr_i && pos + j >= a.bin_lo && pos + j < a.bin_hi) << j;
+    for (int d = 0; d < 4; d++) {
+      uint32_t g4 = 0;
+#pragma unroll
+      for (int by = 0; by < 4; by++) {
+        const int j = d * 4 + by;
+        const uint32_t v = (w[d] >> (8 * by)) & 0xffu;
+        g4 += v * v;
+        // candidate: intensity > static_threshold (an integer test: a.thr_i = the smallest passing value) inside the
+        // bins whose range passes min / max distance (a.bin_lo <= bin < a.bin_hi, found on the host with the exact test)
+        cmask |= (uint32_t)((int)v >= a.thr_i && pos + j >= a.bin_lo && pos + j < a.bin_hi) << j;
+      }
+      q4[d] = g4;
     }
     cand16[(c0 >> 4) + lane] = (unsigned short)cmask;
+    const uint32_t acc = q4[0] + q4[1] + q4[2] + q4[3];
     const int incl = wave_incl_scan_i32((int)acc);
-    const uint32_t base = run + (uint32_t)incl - acc;
-#pragma unroll
-    for (int j = 0; j < 16; j += 4)
-      *(uint4*)(A + 4 + pos + j) = make_uint4(base + loc[j], base + loc[j + 1], base + loc[j + 2], base + loc[j + 3]);
+    const uint32_t base = run + (uint32_t)incl - acc;                       // sum before this lane's first bin
+    *(uint4*)(P4 + (pos >> 2)) = make_uint4(base, base + q4[0], base + q4[0] + q4[1], base + q4[0] + q4[1] + q4[2]);
     run += (uint32_t)__builtin_amdgcn_readlane(incl, 63);
   }
+  if (lane == 0) P4[colsp >> 2] = run;                                      // P(colsp)
   for (int i = lane; i < colsp / 32; i += 64) det32[i] = 0u;
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  auto P = [&](int x) -> uint32_t {                                         // sum_{q < x} I_q^2, 0 <= x <= cols
+    const int q = x >> 2, rr = x & 3;
+    uint32_t p = P4[q];
+    if (rr) {
+      const uint32_t wd = *(const uint32_t*)(raw + 4 * q);
+      const uint32_t v0 = wd & 0xffu, v1 = (wd >> 8) & 0xffu, v2 = (wd >> 16) & 0xffu;
+      p += v0 * v0 + (rr > 1 ? v1 * v1 : 0u) + (rr > 2 ? v2 * v2 : 0u);
+    }
+    return p;
+  };
   // candidates before every 64-bin word
   const unsigned long long* cand64 = (const unsigned long long*)cand16;
   int C = 0;
@@ -774,14 +786,14 @@ __global__ __launch_bounds__(256) void cacfar_rows_kernel(const CfarArgs a) {
         if (rnk >= c) { rnk -= c; wq >>= sh; pos += sh; }
       }
       const int bin = lo * 64 + pos;
-      const uint32_t v = a.raw_in_lds ? raw[bin] : rowp[bin];
+      const uint32_t v = raw[bin];
       const uint32_t sq = v * v;
       const int t0 = max(0, bin - a.guard - a.window), t1 = bin - a.guard;  // cfar.cpp:48-49
       const int f0 = bin + a.guard, f1 = min(a.cols, bin + a.guard + a.window);   // :52-53
       // getMean: sequential sum of exact integer-valued doubles / count; an empty window is 0/0
       if (t1 > t0 && f1 > f0) {
-        const double trailing_mean = (double)(P[t1] - P[t0]) / (double)(t1 - t0);
-        const double forwarding_mean = (double)(P[f1] - P[f0]) / (double)(f1 - f0);
+        const double trailing_mean = (double)(P(t1) - P(t0)) / (double)(t1 - t0);
+        const double forwarding_mean = (double)(P(f1) - P(f0)) / (double)(f1 - f0);
         const double mean = (trailing_mean + forwarding_mean) / 2.0;        // :56
         const double threshold = a.scaling * mean;                          // :58
         if ((double)sq > threshold) atomicOr(&det32[bin >> 5], 1u << (bin & 31));   // :59-60
@@ -1295,11 +1307,7 @@ int cfear_cacfar_device(cfear_ctx* ctx, const uint8_t* d_polar, const cfear_pola
   const int colsp = (cols + 1023) & ~1023;
   {
     // per wavefront: prefix sums u32[colsp + 16] | the row u8[colsp]
-    auto wave_lds = [&](bool raw) {
-      return (((size_t)(colsp + 16) * 4 + (raw ? (size_t)colsp : 0) + (size_t)colsp / 8 + (size_t)colsp / 8 + ((size_t)colsp / 64 + 4) * 4 + 64) + 15) & ~(size_t)15;
-    };
-    a.raw_in_lds = (size_t)kRowsPerBlock * wave_lds(true) <= 150 * 1024 ? 1 : 0;
-    const size_t rows_lds = (size_t)kRowsPerBlock * wave_lds(a.raw_in_lds != 0);
+    const size_t rows_lds = (size_t)kRowsPerBlock * cfar_wave_lds(colsp);
     // the candidate pre-test in integers.  intensity > static_threshold for integer intensities: the smallest passing value;
     // range > min_distance && range < max_distance (cfar.cpp:43-45, range = range_res * bin in double): the bin interval,
     // found with the reference's own expression
