@@ -1397,7 +1397,7 @@ struct RotArgs {
   const uint8_t* src; uint8_t* dst;
   int rows_in, cols_in, stride_in, stride_out;
   long long bs_in, bs_out;
-  int batch0, vec_in, vec_out;
+  int batch0, vec_in, vec_out, vec16_out;
 };
 
 // General kernel: one 64 x 64 byte tile per workgroup.  Load: 16-byte pieces along the source rows -> LDS.  Each thread then owns
@@ -1492,6 +1492,30 @@ __global__ __launch_bounds__(256) void rotate_ccw_rows_kernel(const RotArgs a) {
   }
   __syncthreads();
   const int nbc = (a.cols_in + 3) >> 2;          // 4 x 4 blocks along the source columns
+  if (a.vec16_out && rows_here == kRotRows) {
+    // full tile, 16-byte aligned destination: a thread transposes 16 source rows x 4 source columns and writes four
+    // 16-byte pieces (8 lanes fill a 128-byte line of a destination row) -- a quarter of the store instructions
+    for (int blk = t; blk < (kRotRows / 16) * nbc; blk += 256) {
+      const int br = blk & (kRotRows / 16 - 1), bc = blk / (kRotRows / 16);
+      const uint32_t* c0 = rtile + (size_t)(16 * br) * pitch + bc;
+      uint32_t colw[4][4];                       // [row group][source column]
+#pragma unroll
+      for (int g = 0; g < 4; g++) {
+        const uint32_t w0 = c0[(4 * g) * pitch], w1 = c0[(4 * g + 1) * pitch], w2 = c0[(4 * g + 2) * pitch], w3 = c0[(4 * g + 3) * pitch];
+        const uint32_t t0 = __builtin_amdgcn_perm(w1, w0, 0x05010400u), t1 = __builtin_amdgcn_perm(w1, w0, 0x07030602u);
+        const uint32_t t2 = __builtin_amdgcn_perm(w3, w2, 0x05010400u), t3 = __builtin_amdgcn_perm(w3, w2, 0x07030602u);
+        colw[g][0] = __builtin_amdgcn_perm(t2, t0, 0x05040100u); colw[g][1] = __builtin_amdgcn_perm(t2, t0, 0x07060302u);
+        colw[g][2] = __builtin_amdgcn_perm(t3, t1, 0x05040100u); colw[g][3] = __builtin_amdgcn_perm(t3, t1, 0x07060302u);
+      }
+#pragma unroll
+      for (int b = 0; b < 4; b++) {
+        const int c = 4 * bc + b;
+        if (c < a.cols_in)
+          *(uint4*)(dst + (size_t)(a.cols_in - 1 - c) * a.stride_out + R0 + 16 * br) = make_uint4(colw[0][b], colw[1][b], colw[2][b], colw[3][b]);
+      }
+    }
+    return;
+  }
   for (int blk = t; blk < (kRotRows / 4) * nbc; blk += 256) {
     const int br = blk & (kRotRows / 4 - 1), bc = blk / (kRotRows / 4);
     const int j0 = R0 + 4 * br;
@@ -1532,6 +1556,7 @@ int cfear_rotate_ccw_device(cfear_ctx* ctx, const uint8_t* d_src, const cfear_po
   a.bs_in = sd->batch > 1 ? sd->batch_stride : 0; a.bs_out = sd->batch > 1 ? dst_batch_stride : 0;
   a.vec_in = ((uintptr_t)d_src % 16 == 0) && (sd->stride % 16 == 0) && (a.bs_in % 16 == 0);
   a.vec_out = ((uintptr_t)d_dst % 4 == 0) && (dst_stride % 4 == 0) && (a.bs_out % 4 == 0);
+  a.vec16_out = ((uintptr_t)d_dst % 16 == 0) && (dst_stride % 16 == 0) && (a.bs_out % 16 == 0);
   ProfScope ps(ctx, "rotate_ccw");
   if (sd->cols <= kRotMaxCols) {
     const int ppr = (sd->cols + 15) >> 4;
