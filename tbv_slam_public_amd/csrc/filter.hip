@@ -1479,7 +1479,7 @@ __global__ __launch_bounds__(256) void rotate_ccw_rows_kernel(const RotArgs a) {
     const uint8_t* p = src + (size_t)(R0 + r) * a.stride_in + col;
     uint4 v;
     if (a.vec_in && col + 16 <= a.cols_in) {
-      v = *(const uint4*)p;
+      { const u32x4 nv = __builtin_nontemporal_load((const u32x4*)p); v = make_uint4(nv.x, nv.y, nv.z, nv.w); }
     } else {
       uint32_t w[4] = {0, 0, 0, 0};
 #pragma unroll
@@ -1511,7 +1511,10 @@ __global__ __launch_bounds__(256) void rotate_ccw_rows_kernel(const RotArgs a) {
       for (int b = 0; b < 4; b++) {
         const int c = 4 * bc + b;
         if (c < a.cols_in)
-          *(uint4*)(dst + (size_t)(a.cols_in - 1 - c) * a.stride_out + R0 + 16 * br) = make_uint4(colw[0][b], colw[1][b], colw[2][b], colw[3][b]);
+        {
+          u32x4 ov; ov.x = colw[0][b]; ov.y = colw[1][b]; ov.z = colw[2][b]; ov.w = colw[3][b];
+          __builtin_nontemporal_store(ov, (u32x4*)(dst + (size_t)(a.cols_in - 1 - c) * a.stride_out + R0 + 16 * br));
+        }
       }
     }
     return;
