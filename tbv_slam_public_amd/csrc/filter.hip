@@ -722,19 +722,26 @@ __global__ __launch_bounds__(256) void cacfar_rows_kernel(const CfarArgs a) {
     *(uint4*)(raw + pos) = make_uint4(w[0], w[1], w[2], w[3]);
     uint32_t q4[4];                                                        // sums of squares of the lane's four 4-bin groups
     uint32_t cmask = 0;
+    // candidate: intensity > static_threshold (an integer test: a.thr_i = the smallest passing value) inside the bins
+    // whose range passes min / max distance (a.bin_lo <= bin < a.bin_hi, found on the host with the exact test).
+    // Four bins per word: v_dot4 squares and sums them in one instruction, the byte compare is the sweep's SWAR test.
 #pragma unroll
     for (int d = 0; d < 4; d++) {
-      uint32_t g4 = 0;
-#pragma unroll
-      for (int by = 0; by < 4; by++) {
-        const int j = d * 4 + by;
-        const uint32_t v = (w[d] >> (8 * by)) & 0xffu;
-        g4 += v * v;
-        // candidate: intensity > static_threshold (an integer test: a.thr_i = the smallest passing value) inside the
-        // bins whose range passes min / max distance (a.bin_lo <= bin < a.bin_hi, found on the host with the exact test)
-        cmask |= (uint32_t)((int)v >= a.thr_i && pos + j >= a.bin_lo && pos + j < a.bin_hi) << j;
-      }
-      q4[d] = g4;
+      const uint32_t x = w[d];
+      q4[d] = __builtin_amdgcn_udot4(x, x, 0u, false);
+      uint32_t ge;                                                         // bit 7 of every byte: byte >= thr_i
+      if (a.thr_i >= 256) ge = 0u;
+      else if (a.thr_i & 0x80) ge = (((x & 0x7f7f7f7fu) | 0x80808080u) - (uint32_t)(a.thr_i & 0x7f) * 0x01010101u) & x;
+      else ge = (((x & 0x7f7f7f7fu) | 0x80808080u) - (uint32_t)a.thr_i * 0x01010101u) | x;
+      ge &= 0x80808080u;
+      // gather the four verdict bits (bit 7, 15, 23, 31) into bits 0..3
+      const uint32_t nib = ((ge >> 7) & 1u) | ((ge >> 14) & 2u) | ((ge >> 21) & 4u) | ((ge >> 28) & 8u);
+      cmask |= nib << (4 * d);
+    }
+    {                                                                      // range window: bins [bin_lo, bin_hi) of this lane's 16
+      const int lo = min(16, max(0, a.bin_lo - pos)), hi = min(16, max(0, a.bin_hi - pos));
+      const uint32_t win = hi > lo ? ((hi >= 16 ? 0xffffu : ((1u << hi) - 1u)) & ~((1u << lo) - 1u)) : 0u;
+      cmask &= win;
     }
     cand16[(c0 >> 4) + lane] = (unsigned short)cmask;
     const uint32_t acc = q4[0] + q4[1] + q4[2] + q4[3];
@@ -752,9 +759,8 @@ __global__ __launch_bounds__(256) void cacfar_rows_kernel(const CfarArgs a) {
     const int q = x >> 2, rr = x & 3;
     uint32_t p = P4[q];
     if (rr) {
-      const uint32_t wd = *(const uint32_t*)(raw + 4 * q);
-      const uint32_t v0 = wd & 0xffu, v1 = (wd >> 8) & 0xffu, v2 = (wd >> 16) & 0xffu;
-      p += v0 * v0 + (rr > 1 ? v1 * v1 : 0u) + (rr > 2 ? v2 * v2 : 0u);
+      const uint32_t wd = *(const uint32_t*)(raw + 4 * q) & ((1u << (8 * rr)) - 1u);   // the first rr bytes of the word
+      p = __builtin_amdgcn_udot4(wd, wd, p, false);
     }
     return p;
   };
