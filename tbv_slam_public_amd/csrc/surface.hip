@@ -1477,8 +1477,7 @@ constexpr int kFinishThreads = 256;
 
 __global__ __launch_bounds__(kFinishThreads) void surface_finish_kernel(const SurfJob* __restrict__ jobs, const SurfCommon cm) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];       // sort keys: next_pow2(cell capacity) x 8 bytes
-  __shared__ int red_i[kFinishThreads / 64];
-  __shared__ int total_s;
+  __shared__ int red_i2[2][kFinishThreads / 64];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int job_id = blockIdx.x;
   const SurfScratch scr = scratch_of(cm.scratch + (size_t)job_id * cm.scratch_stride, cm.scratch_cap);
@@ -1486,9 +1485,8 @@ __global__ __launch_bounds__(kFinishThreads) void surface_finish_kernel(const Su
   if (scr.hdr->route != kRouteFast) return;
   const SurfJob job = jobs[job_id];
   const int V = scr.hdr->V;
-  if (tid == 0) total_s = 0;
-  __syncthreads();
-  for (int v0 = 0; v0 < V; v0 += kFinishThreads) {                     // cells + compaction in voxel order (= PCL's output order)
+  int run = 0;                                                         // valid cells so far: every thread keeps the total
+  for (int v0 = 0, rnd = 0; v0 < V; v0 += kFinishThreads, rnd ^= 1) { // cells + compaction in voxel order (= PCL's output order)
     const int v = v0 + tid;
     TmpCell t;
     int f = 0;
@@ -1500,10 +1498,10 @@ __global__ __launch_bounds__(kFinishThreads) void surface_finish_kernel(const Su
       }
     }
     const int inc = wave_incl_scan_i32(f);
-    if (lane == 63) red_i[wave] = inc;
+    if (lane == 63) red_i2[rnd][wave] = inc;                           // double-buffered: ONE barrier per round
     __syncthreads();
-    int off = total_s + inc - f;
-    for (int wv = 0; wv < wave; wv++) off += red_i[wv];
+    int off = run + inc - f;
+    for (int wv = 0; wv < kFinishThreads / 64; wv++) { if (wv < wave) off += red_i2[rnd][wv]; run += red_i2[rnd][wv]; }
     if (f && off < job.out.cap) {
       job.out.mean_f[off] = make_float2((float)t.mean[0], (float)t.mean[1]);  // pointnormal.cpp:154-157
       job.out.mean[off] = make_double2(t.mean[0], t.mean[1]);
@@ -1514,13 +1512,10 @@ __global__ __launch_bounds__(kFinishThreads) void surface_finish_kernel(const Su
       job.out.lambda[off] = make_double2(t.lmin, t.lmax);
       job.out.nsamples[off] = t.nsamples;
     }
-    __syncthreads();
-    if (tid == 0) { int tot = 0; for (int wv = 0; wv < kFinishThreads / 64; wv++) tot += red_i[wv]; total_s += tot; }
-    __syncthreads();
   }
   __threadfence_block();
   __syncthreads();
-  const int total = total_s;
+  const int total = run;
   const int cap = min(job.out.cap, cm.finish_keys);
   sort_cells_block(job.out, min(total, cap), (unsigned long long*)smem, cm.finish_lds);
   if (tid == 0) {
