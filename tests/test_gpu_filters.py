@@ -113,6 +113,17 @@ def test_cacfar_vs_oracle():
     r = api.filter_cacfar(img, 40, 10, 0.01, 0.175, 20, 2.5)
     cloud, _ = O.cacfar(img, 40, 10, 0.01, 0.175, 20, 2.5)
     np.testing.assert_array_equal(r["xyzi"][0, :r["n_points"][0]], cloud)
+    # static thresholds on either side of 128 (the byte test has two forms), at 0 and above every intensity; a range
+    # window that cuts both ends of the row.  (min_distance keeps the first bins out: with range_bin < nb_guard_cells the
+    # reference's getMean compares a size_t index with a negative end, cfar.cpp:77 -- undefined there, not a case.)
+    img2 = rng.integers(0, 256, size=(12, 1100)).astype(np.uint8)
+    for args, maxd in [((12, 4, 0.05, 0.0438, 200, 2.5), 400.0), ((12, 4, 0.05, 0.0438, 254.5, 0.5), 400.0),
+                       ((8, 2, 0.1, 0.0438, 0, 2.5), 30.0), ((8, 2, 0.1, 0.0438, 127, 10.0), 40.0), ((8, 2, 0.1, 0.0438, 128, 0.5), 400.0),
+                       ((8, 2, 0.1, 0.0438, 255, 0.5), 400.0)]:
+        r = api.filter_cacfar(img2, *args, max_distance=maxd)
+        cloud, _ = O.cacfar(img2, *args, max_distance=maxd)
+        assert r["n_points"][0] == cloud.shape[0], (args, r["n_points"][0], cloud.shape[0])
+        np.testing.assert_array_equal(r["xyzi"][0, :cloud.shape[0]], cloud)
 
 
 def test_radar_driver_mirror():
