@@ -10,6 +10,7 @@
 #include <cstdint>
 #include <algorithm>
 #include <stdexcept>
+#include <sstream>
 #include <string>
 #include <vector>
 
@@ -83,6 +84,8 @@ inline PointCloud FromPcl(const pcl::PointCloud<pcl::PointXYZI>& c) {
 #endif
 
 enum filtertype { kstrong, CACFAR };                       // radar_driver.h:25
+inline filtertype Str2filter(const std::string& str) { return str == "CA-CFAR" ? CACFAR : kstrong; }       // radar_driver.cpp:7-13
+inline std::string Filter2str(const filtertype& filter) { return filter == CACFAR ? "CA-CFAR" : "kstrong"; }   // :15-21
 
 class radarDriver {
  public:
@@ -91,6 +94,17 @@ class radarDriver {
     int nb_guard_cells = 20, window_size = 10; float false_alarm_rate = 0.01f;
     float min_distance = 2.5f, max_distance = 200; filtertype filter_type_ = kstrong;
     std::string dataset = "oxford";                        // anything else: images arrive as [range bins][azimuths]
+    std::string topic_filtered = "/Navtech/Filtered", radar_frameid = "sensor_est";
+    std::string ToString() const {                         // radar_driver.h:65-82 (what the evaluation scripts log)
+      std::ostringstream ss;
+      ss << "range res, " << range_res << std::endl << "z min, " << z_min << std::endl << "min distance, " << min_distance << std::endl
+         << "max distance, " << max_distance << std::endl << "k strongest, " << k_strongest << std::endl
+         << "topic_filtered, " << topic_filtered << std::endl << "radar_frameid, " << radar_frameid << std::endl
+         << "dataset, " << dataset << std::endl << "filter type, " << Filter2str(filter_type_) << std::endl
+         << "nb guard cells, " << nb_guard_cells << std::endl << "window size, " << window_size << std::endl
+         << "false alarm rate, " << false_alarm_rate << std::endl;
+      return ss.str();
+    }
   };
   radarDriver(Context& ctx, const Parameters& pars) : ctx_(ctx), par(pars) {}
   // image: row-major uint8; rows = azimuth for dataset "oxford" (CallbackOxford, radar_driver.cpp:99-111), otherwise

@@ -17,6 +17,16 @@
 using namespace CFEAR_Radarodometry;
 
 int main(int argc, char** argv) {
+  {  // the small boundary symbols external packages use (radar_driver.h:24-28, 65-82)
+    using namespace CFEAR_Radarodometry;
+    if (Str2filter("CA-CFAR") != CACFAR || Str2filter("kstrong") != kstrong || Str2filter("anything") != kstrong) return 91;
+    if (Filter2str(CACFAR) != "CA-CFAR" || Filter2str(kstrong) != "kstrong") return 92;
+    radarDriver::Parameters rp;
+    rp.filter_type_ = Str2filter("CA-CFAR");
+    const std::string txt = rp.ToString();
+    if (txt.find("filter type, CA-CFAR\n") == std::string::npos || txt.find("range res, 0.0438\n") != 0) return 93;
+  }
+
   if (argc < 4) return 2;
   const int rows = atoi(argv[2]), cols = atoi(argv[3]);
   std::vector<uint8_t> img((size_t)2 * rows * cols);
