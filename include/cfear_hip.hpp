@@ -403,6 +403,57 @@ class OdometryKeyframeFuser {
     for (int r = 0; r < 6; r++) for (int q = 0; q < 6; q++) cov_curr(r, q) = cov[r * 6 + q];
   }
 #endif
+  // graph_ of a stream (odometrykeyframefuser.h:197-249: AddToGraph :428-445, SaveGraph, GetLastNode): call AddToGraph
+  // after a frame whose info.keyframe_added is set (the odometry must have been created with par.keep_nodes); the node
+  // keeps the pose, the compensated clouds, the surface points and the odometry constraint to the keyframe before it.
+  struct GraphNode {
+    Pose2d T;
+    unsigned idx = 0;
+    uint64_t stamp = 0;
+    PointCloud cloud_peaks, cloud_nopeaks;
+    std::vector<cfear_cell> cells;
+    bool has_constraint = false;
+    cfear_graph_constraint constraint{};
+  };
+  void AddToGraph(int stream, const cfear_frame_info& info, uint64_t stamp = 0) {
+    if ((int)graph_.size() < n_) graph_.resize((size_t)n_);
+    GraphNode nd;
+    nd.T = Pose2d{info.pose[0], info.pose[1], info.pose[2]};
+    nd.idx = (unsigned)graph_[stream].size();
+    nd.stamp = stamp;
+    nd.cloud_nopeaks = GetCloud(stream, false);
+    nd.cloud_peaks = GetCloud(stream, true);
+    cfear_scan* s = GetScan(stream);
+    nd.cells.resize((size_t)std::max(cfear_scan_size(s), 0));
+    const int got = nd.cells.empty() ? 0 : cfear_scan_get_cells(s, nd.cells.data(), (int32_t)nd.cells.size());   // returns the count
+    cfear_scan_destroy(s);
+    if (got < 0) ctx_.check(got);
+    nd.has_constraint = cfear_odometry_get_constraint(od_, stream, &nd.constraint) == CFEAR_OK;   // none for the first keyframe
+    graph_[stream].push_back(std::move(nd));
+  }
+  const GraphNode& GetLastNode(int stream = 0) const { return graph_.at((size_t)stream).back(); }
+  size_t GraphSize(int stream = 0) const { return (size_t)stream < graph_.size() ? graph_[stream].size() : 0; }
+  void SaveGraph(const std::string& path, int stream = 0, float radius = 3.0f, bool weight_intensity = true) const {  // SaveSimpleGraph, types.cpp:103-113
+    const std::vector<GraphNode>& g = graph_.at((size_t)stream);
+    std::vector<cfear_graph_node> nodes(g.size());
+    for (size_t i = 0; i < g.size(); i++) {
+      cfear_graph_node& n = nodes[i];
+      n = cfear_graph_node{};
+      const double xyt[3] = {g[i].T.x, g[i].T.y, g[i].T.theta};
+      cfear_pose3d_from_xyt(xyt, &n.T);
+      n.idx = g[i].idx; n.stamp = g[i].stamp;
+      for (int k = 0; k < 16; k++) n.motion[k] = (k % 5 == 0) ? 1.0 : 0.0;            // motion_ = Identity
+      n.cloud_peaks = cfear_graph_cloud{g[i].cloud_peaks.empty() ? nullptr : &g[i].cloud_peaks[0].x, (int32_t)g[i].cloud_peaks.size(), 0, g[i].stamp, nullptr};
+      n.cloud_nopeaks = cfear_graph_cloud{g[i].cloud_nopeaks.empty() ? nullptr : &g[i].cloud_nopeaks[0].x, (int32_t)g[i].cloud_nopeaks.size(), 0, g[i].stamp, nullptr};
+      n.has_normal = 1; n.input_is_nopeaks = 1;
+      n.cells = g[i].cells.data(); n.n_cells = (int32_t)g[i].cells.size();
+      n.radius = radius; n.weight_intensity = weight_intensity ? 1 : 0;
+      n.constraints = g[i].has_constraint ? &g[i].constraint : nullptr;
+      n.n_constraints = g[i].has_constraint ? 1 : 0;
+    }
+    const int rc = cfear_graph_save(path.c_str(), nodes.data(), (int32_t)nodes.size());
+    if (rc != CFEAR_OK) throw CfearError(rc, cfear_status_string(rc));
+  }
   // scan_ of a stream's last frame (odometrykeyframefuser.cpp:172, 244): surface points + the two clouds
   cfear_scan* GetScan(int stream) { cfear_scan* s = nullptr; ctx_.check(cfear_odometry_get_scan(od_, stream, &s)); return s; }
   PointCloud GetCloud(int stream, bool peaks) {
@@ -416,6 +467,7 @@ class OdometryKeyframeFuser {
   Context& ctx_;
   cfear_odometry* od_ = nullptr;
   int n_;
+  std::vector<std::vector<GraphNode>> graph_;
 };
 
 }  // namespace CFEAR_Radarodometry

@@ -90,13 +90,27 @@ int main(int argc, char** argv) {
     op.keep_nodes = 1;
     op.rotate_ccw = bins_major ? 1 : 0;
     OdometryKeyframeFuser fuser(ctx, 1, bins_major ? cols : rows, bins_major ? rows : cols, &op);
-    fuser.processFrame(img.data());
+    const std::vector<cfear_frame_info> fi0 = fuser.processFrame(img.data());
+    if (fi0[0].keyframe_added) fuser.AddToGraph(0, fi0[0], 1000);
     const std::vector<cfear_frame_info> fi = fuser.processFrame(img.data() + (size_t)rows * cols);
+    if (fi[0].keyframe_added) fuser.AddToGraph(0, fi[0], 2000);
     const PointCloud node_peaks = fuser.GetCloud(0, true);
     cfear_scan* node_scan = fuser.GetScan(0);
-    printf(" %.12g %.12g %.12g %d %d %zu\n", fi[0].pose[0], fi[0].pose[1], fi[0].pose[2], fi[0].n_cells,
+    printf(" %.12g %.12g %.12g %d %d %zu", fi[0].pose[0], fi[0].pose[1], fi[0].pose[2], fi[0].n_cells,
            cfear_scan_size(node_scan), node_peaks.size());
     cfear_scan_destroy(node_scan);
+    // graph_ of the stream written as simple_graph.sgh and read back (SaveGraph / LoadSimpleGraph)
+    const std::string sgh = std::string(argv[1]) + ".sgh";
+    fuser.SaveGraph(sgh);
+    cfear_graph* g = nullptr;
+    ctx.check(cfear_graph_load(sgh.c_str(), &g));
+    cfear_graph_node last;
+    ctx.check(cfear_graph_node_at(g, cfear_graph_size(g) - 1, &last));
+    double lxyt[3];
+    cfear_pose3d_to_xyt(&last.T, lxyt);
+    printf(" %zu %d %d %d %d %.12g %.12g %.12g %llu\n", fuser.GraphSize(), cfear_graph_size(g), last.n_cells, last.cloud_peaks.n,
+           last.n_constraints, lxyt[0], lxyt[1], lxyt[2], (unsigned long long)fuser.GetLastNode().stamp);
+    cfear_graph_destroy(g);
   } catch (const CfearError& e) {
     fprintf(stderr, "cfear error %d: %s\n", e.status, e.what());
     return 1;

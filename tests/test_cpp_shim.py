@@ -95,6 +95,11 @@ def test_cpp_mirror_matches_oracle(tmp_path, layout):
     assert np.abs(gp[:2] - pose[:2]).max() <= 1e-4 and abs(gp[2] - pose[2]) <= 1e-5
     assert int(v[28]) == int(v[29]) == finfo[0]
     assert int(v[30]) == pk[1].shape[0]                     # second frame, first motion estimate is identity
+    # graph_ collected with AddToGraph, written by SaveGraph and read back: both frames are keyframes (2 m apart)
+    assert int(v[31]) == int(v[32]) == 2
+    assert int(v[33]) == finfo[0] and int(v[34]) == pk[1].shape[0] and int(v[35]) == 1
+    np.testing.assert_allclose([float(x) for x in v[36:39]], gp, rtol=0, atol=1e-12)
+    assert int(v[39]) == 2000
 
 
 def _build_ref_signatures(tmp_path):
