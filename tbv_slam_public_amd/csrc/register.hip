@@ -22,11 +22,12 @@
 #include <cmath>
 
 #include "common.hpp"
+#include "fastmath.hpp"
 
 namespace {
 
 #ifdef CFEAR_REG_TIMING   // debug build only: cycle split of workgroup 0, printed at kernel end
-__device__ long long g_reg_t[16];
+__device__ long long g_reg_t[32];
 #define REG_T0() long long _t0 = __builtin_readcyclecounter()
 #define REG_TACC(k) do { const long long _t1 = __builtin_readcyclecounter(); \
     if (threadIdx.x == 0 && blockIdx.x == 0) g_reg_t[k] += _t1 - _t0; _t0 = _t1; } while (0)
@@ -906,21 +907,22 @@ __device__ int associate_fused(const RegJob& job, const RegCommon& cm, const dou
   return total;
 }
 
-// Solves the SPD system A y = b (3x3, A = J^T J + D^2) by LDL^T: three divisions, no square roots.
+// Solves the SPD system A y = b (3x3, A = J^T J + D^2) by LDL^T: three reciprocals (rcp_newton: this chain of dependent
+// fp64 instructions is the longest serial piece of an LM iteration), no square roots.
 // Ceres factorises the same matrix with a sparse Cholesky; the solutions agree to rounding.
 __device__ __forceinline__ bool chol3_solve(const double A[9], const double b[3], double y[3]) {
   const double d0 = A[0];
   if (!(d0 > 0.0)) return false;
-  const double i0 = 1.0 / d0;
+  const double i0 = rcp_newton(d0);
   const double l10 = A[3] * i0, l20 = A[6] * i0;
   const double d1 = A[4] - l10 * A[3];
   if (!(d1 > 0.0)) return false;
-  const double i1 = 1.0 / d1;
+  const double i1 = rcp_newton(d1);
   const double t21 = A[7] - l20 * A[3];
   const double l21 = t21 * i1;
   const double d2 = A[8] - l20 * A[6] - l21 * t21;
   if (!(d2 > 0.0)) return false;
-  const double i2 = 1.0 / d2;
+  const double i2 = rcp_newton(d2);
   const double z0 = b[0];
   const double z1 = b[1] - l10 * z0;
   const double z2 = b[2] - l20 * z0 - l21 * z1;
@@ -928,6 +930,13 @@ __device__ __forceinline__ bool chol3_solve(const double A[9], const double b[3]
   y[1] = z1 * i1 - l21 * y[2];
   y[0] = z0 * i0 - l10 * y[1] - l20 * y[2];
   return isfinite(y[0]) && isfinite(y[1]) && isfinite(y[2]);
+}
+
+// Rotation of an evaluation point: Cody-Waite reduction + Taylor polynomials (fastmath.hpp, an ulp or two from libm) --
+// a fifth of libm's instruction chain; headings beyond the reduction's range go to libm.
+__device__ __forceinline__ void sincos_pose(const double a, double* s, double* c) {
+  if (fabs(a) <= 1e5) sincos_reduced(a, s, c);
+  else sincos(a, s, c);
 }
 
 struct LmSummary {
@@ -958,7 +967,7 @@ __device__ void lm_solve(const RegCommon& cm, const Dense& dn, double x[3], int 
   double cur[10];                                        // cost, g, H at the accepted x
   {
     double s0, c0;
-    sincos(x[2], &s0, &c0);
+    sincos_pose(x[2], &s0, &c0);
     eval_all<NW, COST, LOSS>(cm, dn, x, c0, s0, cur, part, phase);
   }
   double x_cost = cur[0];
@@ -976,34 +985,36 @@ __device__ void lm_solve(const RegCommon& cm, const Dense& dn, double x[3], int 
     scale[1] = 1.0 / (1.0 + sqrt(cur[7]));
     scale[2] = 1.0 / (1.0 + sqrt(cur[9]));
     gradient_max_norm = fmax(fabs(cur[1]), fmax(fabs(cur[2]), fabs(cur[3])));
-    x_norm = sqrt(x[0] * x[0] + x[1] * x[1] + x[2] * x[2]);
+    x_norm = sqrt_newton(x[0] * x[0] + x[1] * x[1] + x[2] * x[2]);
   }
   double cand[3] = {x[0], x[1], x[2]};
   double cnd[10];                                        // cost (and, speculatively, g and H) at cand
   bool have_cnd = false;
   for (;;) {
     int done = 0;
+    REG_T0();
     if (w0) {
       bool proceed = true;
       if (have_cnd) {                                    // the candidate of the previous round was evaluated
         const double cand_cost = cnd[0];
-        const double step_norm = sqrt((x[0] - cand[0]) * (x[0] - cand[0]) + (x[1] - cand[1]) * (x[1] - cand[1]) +
-                                      (x[2] - cand[2]) * (x[2] - cand[2]));
+        const double step_norm2 = (x[0] - cand[0]) * (x[0] - cand[0]) + (x[1] - cand[1]) * (x[1] - cand[1]) +
+                                  (x[2] - cand[2]) * (x[2] - cand[2]);
         const double cost_change = x_cost - cand_cost;
-        if (step_norm <= parameter_tolerance * (x_norm + parameter_tolerance)) { done = 1; proceed = false; }
+        const double step_bound = parameter_tolerance * (x_norm + parameter_tolerance);
+        if (step_norm2 <= step_bound * step_bound) { done = 1; proceed = false; }      // ||step|| <= tolerance (||x|| + tolerance)
         else if (fabs(cost_change) <= function_tolerance * x_cost) { done = 1; proceed = false; }
         else {
           it_rel = cost_change / model_cost_change;
           if (it_rel > min_relative_decrease) {
             x[0] = cand[0]; x[1] = cand[1]; x[2] = cand[2];
-            x_norm = sqrt(x[0] * x[0] + x[1] * x[1] + x[2] * x[2]);
+            x_norm = sqrt_newton(x[0] * x[0] + x[1] * x[1] + x[2] * x[2]);
 #pragma unroll
             for (int k = 0; k < 10; k++) cur[k] = cnd[k];
             x_cost = cand_cost;
             gradient_max_norm = fmax(fabs(cur[1]), fmax(fabs(cur[2]), fabs(cur[3])));
             it_cost = x_cost; it_success = true;
             const double q = 2.0 * it_rel - 1.0;
-            radius = radius / fmax(1.0 / 3.0, 1.0 - q * q * q);
+            radius = radius * rcp_newton(fmax(1.0 / 3.0, 1.0 - q * q * q));
             radius = fmin(max_radius, radius);
             decrease_factor = 2.0; reuse_diagonal = false;
           } else {
@@ -1012,6 +1023,7 @@ __device__ void lm_solve(const RegCommon& cm, const Dense& dn, double x[3], int 
           }
         }
       }
+      REG_TACC(16);
       while (proceed) {
         // FinalizeIterationAndCheckIfMinimizerCanContinue
         sum.n_pushed++;
@@ -1037,10 +1049,13 @@ __device__ void lm_solve(const RegCommon& cm, const Dense& dn, double x[3], int 
         double A[9];
 #pragma unroll
         for (int k = 0; k < 9; k++) A[k] = Hs[k];
+        const double inv_radius = rcp_newton(radius);                          // radius in [1e-32, 1e16]
 #pragma unroll
-        for (int k = 0; k < 3; k++) A[k * 3 + k] += diagonal[k] / radius;    // D^2 = diag / radius
+        for (int k = 0; k < 3; k++) A[k * 3 + k] += diagonal[k] * inv_radius;  // D^2 = diag / radius
         double y[3], step[3] = {0, 0, 0};
+        REG_TACC(17);
         const bool solved = chol3_solve(A, gs, y);
+        REG_TACC(18);
         reuse_diagonal = true;
         bool step_is_valid = false;
         model_cost_change = 0.0;
@@ -1065,20 +1080,23 @@ __device__ void lm_solve(const RegCommon& cm, const Dense& dn, double x[3], int 
         for (int k = 0; k < 3; k++) cand[k] = x[k] + step[k] * scale[k];
         break;
       }
+      REG_TACC(19);
       if (!done) {                                       // the rotation of the next evaluation point, once per
         double sn, cs;                                   // workgroup instead of once per wavefront
-        sincos(cand[2], &sn, &cs);
+        sincos_pose(cand[2], &sn, &cs);
         if (writer) { ctrl[10] = cs; ctrl[11] = sn; }
       }
       if (writer) {
         ctrl[0] = cand[0]; ctrl[1] = cand[1]; ctrl[2] = cand[2];
         ((int*)(ctrl + 3))[0] = done;
       }
+      REG_TACC(20);
     }
     __syncthreads();
     done = __builtin_amdgcn_readfirstlane(((const int*)(ctrl + 3))[0]);
     if (done) break;
     cand[0] = ctrl[0]; cand[1] = ctrl[1]; cand[2] = ctrl[2];
+    REG_TACC(21);
     eval_all<NW, COST, LOSS>(cm, dn, cand, ctrl[10], ctrl[11], cnd, part, phase);   // its barrier also protects ctrl
     have_cnd = true;
   }
@@ -1280,7 +1298,9 @@ __global__ __launch_bounds__(NW * 64) void register_kernel(const RegJob* __restr
              (long long)res->last_relative_decrease + g_reg_t[6], g_reg_t[6], g_reg_t[0], g_reg_t[1], g_reg_t[2], g_reg_t[3],
              g_reg_t[7], g_reg_t[4], g_reg_t[5], itr, lm_iters, num_residuals);
       printf("  stage split:"); for (int k = 8; k < 16; k++) printf(" %lld", g_reg_t[k]); printf("\n");
-      for (int k = 0; k < 16; k++) g_reg_t[k] = 0;
+      printf("  lm bookkeeping: decide %lld | scale+diag %lld | chol %lld | model+cand %lld | sincos+ctrl %lld | barrier+read %lld\n",
+             g_reg_t[16], g_reg_t[17], g_reg_t[18], g_reg_t[19], g_reg_t[20], g_reg_t[21]);
+      for (int k = 0; k < 32; k++) g_reg_t[k] = 0;
     }
 #endif
     if (success) { res->score = summary.final_cost / (double)num_residuals; res->status = CFEAR_OK; }   // :162
