@@ -672,17 +672,22 @@ struct CfarArgs {
   int32_t* det_count;             // [batch][rows]
   int words;
   int thr_i, bin_lo, bin_hi;      // candidate pre-test in integers: intensity >= thr_i, bin_lo <= bin < bin_hi
+  double thr_scale;               // scaling / (2 window): threshold per unit of (trailing + forwarding) sum when both windows are full
 };
 
 // One wavefront per azimuth row.  The row is read once in 16-byte pieces (lane-interleaved, coalesced) into LDS together
 // with the exact uint32 prefix sums of its squares: 16 bins are summed inside a lane and ONE wave scan per 1024 bins
 // places the lanes (the first version scanned every 64 bins with single-byte loads: 53 dependent DPP ladders per row).
-// Only bins above the static threshold inside the range window reach the threshold arithmetic (two fp64 divisions
-// each); typically a quarter of the row.  They are marked in a bitmap while the row is in registers and then handed out
-// one per lane, so the fp64 part runs ~C / 64 times per row instead of once per 64 bins.
+// Only bins above the static threshold inside the range window reach the threshold arithmetic; typically a quarter of
+// the row.  Each lane keeps the 16-bit candidate mask of its 16 bins per chunk in registers; per piece of 2048 bins the
+// lanes write their candidates' bin numbers into a list in LDS (one wave scan of the popcounts places them), and the
+// list is then evaluated one candidate per lane -- C / 64 rounds per row whatever the clustering.  (The version before
+// kept the masks in LDS and found candidate k's word by a binary search over per-word counts: six dependent LDS reads
+// and a rank-select per candidate, 0.91 ms per 512 Kvarntorp sweeps.)
+constexpr int kCfarList = 2048;            // candidates of one piece (two 1024-bin chunks)
 __host__ __device__ inline size_t cfar_wave_lds(int colsp) {
-  // P4 u32[colsp / 4 + 4] | raw u8[colsp] | cand u16[colsp / 16] | det u32[colsp / 32] | pref i32[colsp / 64 + 4]
-  return (((size_t)(colsp / 4 + 4) * 4 + (size_t)colsp + (size_t)colsp / 8 + (size_t)colsp / 8 + ((size_t)colsp / 64 + 4) * 4) + 15) & ~(size_t)15;
+  // P4 u32[colsp / 4 + 4] | raw u8[colsp] | det u32[colsp / 32] | list u16[kCfarList]
+  return (((size_t)(colsp / 4 + 4) * 4 + (size_t)colsp + (size_t)colsp / 8 + (size_t)kCfarList * 2) + 15) & ~(size_t)15;
 }
 __global__ __launch_bounds__(256) void cacfar_rows_kernel(const CfarArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -691,34 +696,57 @@ __global__ __launch_bounds__(256) void cacfar_rows_kernel(const CfarArgs a) {
   if (grow >= (long long)a.batch * a.rows) return;
   const int b = (int)(grow / a.rows), r = (int)(grow - (long long)b * a.rows);
   const uint8_t* rowp = a.polar + (long long)b * a.batch_stride + (long long)r * a.stride;
-  const int colsp = (a.cols + 1023) & ~1023;                               // whole 1024-bin chunks
+  const int colsp = (a.cols + 1023) & ~1023;                               // whole 1024-bin chunks (at most 8)
   uint8_t* wbase = smem + (size_t)wave * cfar_wave_lds(colsp);
   // Prefix sums of squares, exact in uint32, kept for every FOURTH bin only (P4[i] = sum_{q < 4 i} I_q^2) next to the row's
-  // bytes: P(x) = P4[x / 4] + the squares of up to three bytes of one LDS word.  A quarter of the LDS of a full table,
-  // i.e. 16 instead of 8 wavefronts per CU -- the kernel is bound by the latency of its dependent LDS reads.
+  // bytes: P(x) = P4[x / 4] + the squares of up to three bytes of one LDS word.
   uint32_t* P4 = (uint32_t*)wbase;
   uint8_t* raw = wbase + (size_t)(colsp / 4 + 4) * 4;                      // the row itself
-  unsigned short* cand16 = (unsigned short*)(raw + colsp);                 // bit j of cand16[h]: bin 16 h + j is a candidate
-  uint32_t* det32 = (uint32_t*)(raw + colsp + colsp / 8);                  // detections, bit per bin
-  int* pref = (int*)(raw + colsp + colsp / 4);                             // [G + 1] candidates before each 64-bin word
-  const int G = colsp >> 6;
+  uint32_t* det32 = (uint32_t*)(raw + colsp);                              // detections, bit per bin
+  unsigned short* list = (unsigned short*)(raw + colsp + colsp / 8);       // candidate bins of the current piece
   const bool vec = (((uintptr_t)rowp) & 15) == 0;
+#ifdef CFEAR_CFAR_TIMING
+  long long tq[6]; int ctot = 0; tq[0] = __builtin_readcyclecounter();
+#define CFAR_T(k) tq[k] = __builtin_readcyclecounter()
+#else
+#define CFAR_T(k)
+#endif
   uint32_t run = 0;
-  for (int c0 = 0; c0 < a.cols; c0 += 1024) {
-    const int pos = c0 + lane * 16;
-    uint32_t w[4] = {0u, 0u, 0u, 0u};
-    if (vec && pos + 16 <= a.cols) {
-      const u32x4 v = __builtin_nontemporal_load((const u32x4*)(rowp + pos));
-      w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
-    } else if (pos < a.cols) {
-#pragma unroll
-      for (int d = 0; d < 4; d++)
-#pragma unroll
-        for (int by = 0; by < 4; by++) {
-          const int q = pos + d * 4 + by;
-          if (q < a.cols) w[d] |= (uint32_t)rowp[q] << (8 * by);
-        }
+  unsigned long long cmw0 = 0ull, cmw1 = 0ull;                             // the lane's 16-bit candidate masks, chunk c at bits 16 (c & 3) of word c >> 2
+  // All of a row's 16-byte loads (four chunks at a time) are issued before the first is used: one memory round trip per
+  // row instead of one per chunk -- with 12 rows per CU in flight, the chunk-by-chunk form kept 12 KB per CU on the wire.
+  // Rows that cannot be read in aligned 16-byte pieces (odd strides, cols not a multiple of 16) are first copied into LDS
+  // byte by byte, zero-padded, and the common path below then takes its pieces from there.
+  const bool direct = vec && (a.cols & 15) == 0;
+  if (!direct) {
+    for (int pos = lane * 16; pos < colsp; pos += 1024) {
+      uint32_t w[4] = {0u, 0u, 0u, 0u};
+      for (int q = pos; q < min(pos + 16, a.cols); q++) w[(q - pos) >> 2] |= (uint32_t)rowp[q] << (8 * (q & 3));
+      *(uint4*)(raw + pos) = make_uint4(w[0], w[1], w[2], w[3]);
     }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
+  // candidate test "byte >= thr_i" for four bytes at once: with tl = thr_i & 127 and y = ((x & 0x7f..) | 0x80..) - tl * 0x0101..,
+  // bit 7 of a byte of y says (x & 127) >= tl; the verdict is y & x for thr_i >= 128 and y | x below.
+  const uint32_t thr_lo4 = (uint32_t)(a.thr_i & 0x7f) * 0x01010101u;
+  const uint32_t thr_hi = (a.thr_i & 0x80) ? 0xffffffffu : 0u;
+  for (int cb = 0; cb < a.cols; cb += 4096) {
+  u32x4 pre[4];
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const int pos = cb + j * 1024 + lane * 16;
+    pre[j] = u32x4{0u, 0u, 0u, 0u};
+    if (direct) { if (pos < a.cols) pre[j] = __builtin_nontemporal_load((const u32x4*)(rowp + pos)); }
+    else if (pos < colsp) pre[j] = *(const u32x4*)(raw + pos);
+  }
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const int c0 = cb + j * 1024;
+    if (c0 >= a.cols) break;
+    const int pos = c0 + lane * 16;
+    const uint32_t w[4] = {pre[j].x, pre[j].y, pre[j].z, pre[j].w};
     *(uint4*)(raw + pos) = make_uint4(w[0], w[1], w[2], w[3]);
     uint32_t q4[4];                                                        // sums of squares of the lane's four 4-bin groups
     uint32_t cmask = 0;
@@ -729,13 +757,11 @@ __global__ __launch_bounds__(256) void cacfar_rows_kernel(const CfarArgs a) {
     for (int d = 0; d < 4; d++) {
       const uint32_t x = w[d];
       q4[d] = __builtin_amdgcn_udot4(x, x, 0u, false);
-      uint32_t ge;                                                         // bit 7 of every byte: byte >= thr_i
-      if (a.thr_i >= 256) ge = 0u;
-      else if (a.thr_i & 0x80) ge = (((x & 0x7f7f7f7fu) | 0x80808080u) - (uint32_t)(a.thr_i & 0x7f) * 0x01010101u) & x;
-      else ge = (((x & 0x7f7f7f7fu) | 0x80808080u) - (uint32_t)a.thr_i * 0x01010101u) | x;
-      ge &= 0x80808080u;
-      // gather the four verdict bits (bit 7, 15, 23, 31) into bits 0..3
-      const uint32_t nib = ((ge >> 7) & 1u) | ((ge >> 14) & 2u) | ((ge >> 21) & 4u) | ((ge >> 28) & 8u);
+      const uint32_t y = ((x & 0x7f7f7f7fu) | 0x80808080u) - thr_lo4;
+      const uint32_t ge = (y & x) | ((y | x) & ~thr_hi);                   // bit 7 of every byte: byte >= thr_i
+      // gather the four verdict bits (bit 7, 15, 23, 31) into bits 0..3: with y = bits 0, 8, 16, 24, the product
+      // y * 0x01020408 puts bit 8 i at 24 + i (the partial products do not collide), so the top nibble-pair's low 4 bits are the answer
+      const uint32_t nib = ((((ge >> 7) & 0x01010101u) * 0x01020408u) >> 24) & 0xfu;
       cmask |= nib << (4 * d);
     }
     {                                                                      // range window: bins [bin_lo, bin_hi) of this lane's 16
@@ -743,72 +769,94 @@ __global__ __launch_bounds__(256) void cacfar_rows_kernel(const CfarArgs a) {
       const uint32_t win = hi > lo ? ((hi >= 16 ? 0xffffu : ((1u << hi) - 1u)) & ~((1u << lo) - 1u)) : 0u;
       cmask &= win;
     }
-    cand16[(c0 >> 4) + lane] = (unsigned short)cmask;
+    {
+      const int c = c0 >> 10;
+      const unsigned long long m = (unsigned long long)cmask << (16 * (c & 3));
+      if (c < 4) cmw0 |= m; else cmw1 |= m;
+    }
     const uint32_t acc = q4[0] + q4[1] + q4[2] + q4[3];
     const int incl = wave_incl_scan_i32((int)acc);
     const uint32_t base = run + (uint32_t)incl - acc;                       // sum before this lane's first bin
     *(uint4*)(P4 + (pos >> 2)) = make_uint4(base, base + q4[0], base + q4[0] + q4[1], base + q4[0] + q4[1] + q4[2]);
     run += (uint32_t)__builtin_amdgcn_readlane(incl, 63);
   }
+  }
   if (lane == 0) P4[colsp >> 2] = run;                                      // P(colsp)
   for (int i = lane; i < colsp / 32; i += 64) det32[i] = 0u;
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   auto P = [&](int x) -> uint32_t {                                         // sum_{q < x} I_q^2, 0 <= x <= cols
     const int q = x >> 2, rr = x & 3;
-    uint32_t p = P4[q];
-    if (rr) {
-      const uint32_t wd = *(const uint32_t*)(raw + 4 * q) & ((1u << (8 * rr)) - 1u);   // the first rr bytes of the word
-      p = __builtin_amdgcn_udot4(wd, wd, p, false);
-    }
-    return p;
+    // the first rr bytes of the word (none for rr = 0; the word of x = colsp lies in det32 and is masked away): no branch
+    const uint32_t wd = *(const uint32_t*)(raw + 4 * q) & ((1u << (8 * rr)) - 1u);
+    return __builtin_amdgcn_udot4(wd, wd, P4[q], false);
   };
-  // candidates before every 64-bin word
-  const unsigned long long* cand64 = (const unsigned long long*)cand16;
-  int C = 0;
-  for (int g0 = 0; g0 < G; g0 += 64) {
-    const int g = g0 + lane;
-    const int pc = g < G ? __popcll(cand64[g]) : 0;
-    const int incl = wave_incl_scan_i32(pc);
-    if (g < G) pref[g] = C + incl - pc;
-    C += __builtin_amdgcn_readlane(incl, 63);
-  }
-  if (lane == 0) pref[G] = C;
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-  for (int k0 = 0; k0 < C; k0 += 64) {
-    const int k = k0 + lane;
-    if (k < C) {
-      int lo = 0, hi = G;                                                   // the word of candidate k: last g with pref[g] <= k
-      while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (pref[mid] <= k) lo = mid; else hi = mid; }
-      int rnk = k - pref[lo];
-      unsigned long long wq = cand64[lo];
-      int pos = 0;                                                          // position of set bit number rnk
-#pragma unroll
-      for (int sh = 32; sh >= 1; sh >>= 1) {
-        const int c = __popcll(wq & ((1ull << sh) - 1ull));
-        if (rnk >= c) { rnk -= c; wq >>= sh; pos += sh; }
+  const int nchunks = colsp >> 10;
+  CFAR_T(1);
+#ifdef CFEAR_CFAR_TIMING
+  long long t_scatter = 0, t_rounds = 0;
+#endif
+  for (int c2 = 0; c2 < nchunks; c2 += 2) {
+#ifdef CFEAR_CFAR_TIMING
+    const long long ta = __builtin_readcyclecounter();
+#endif
+    // the piece's candidates -> list (in bin order: chunk, lane, bit)
+    int C = 0;
+    for (int c = c2; c < min(c2 + 2, nchunks); c++) {
+      uint32_t m = (uint32_t)((c < 4 ? cmw0 : cmw1) >> (16 * (c & 3))) & 0xffffu;
+      const int pc = __popc(m);
+      const int incl = wave_incl_scan_i32(pc);
+      int off = C + incl - pc;
+      const int binbase = (c << 10) + lane * 16;
+      while (m) {
+        list[off++] = (unsigned short)(binbase + __ffs((int)m) - 1);
+        m &= m - 1u;
       }
-      const int bin = lo * 64 + pos;
-      const uint32_t v = raw[bin];
-      const uint32_t sq = v * v;
-      const int t0 = max(0, bin - a.guard - a.window), t1 = bin - a.guard;  // cfar.cpp:48-49
-      const int f0 = bin + a.guard, f1 = min(a.cols, bin + a.guard + a.window);   // :52-53
-      // getMean: sequential sum of exact integer-valued doubles / count; an empty window is 0/0
-      if (t1 > t0 && f1 > f0) {
-        const double trailing_mean = (double)(P(t1) - P(t0)) / (double)(t1 - t0);
-        const double forwarding_mean = (double)(P(f1) - P(f0)) / (double)(f1 - f0);
-        const double mean = (trailing_mean + forwarding_mean) / 2.0;        // :56
-        const double threshold = a.scaling * mean;                          // :58
-        if ((double)sq > threshold) atomicOr(&det32[bin >> 5], 1u << (bin & 31));   // :59-60
+      C += __builtin_amdgcn_readlane(incl, 63);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#ifdef CFEAR_CFAR_TIMING
+    const long long tb = __builtin_readcyclecounter(); t_scatter += tb - ta; ctot += C;
+#endif
+    for (int k0 = 0; k0 < C; k0 += 64) {
+      const int k = k0 + lane;
+      if (k < C) {
+        const int bin = list[k];
+        const uint32_t v = raw[bin];
+        const uint32_t sq = v * v;
+        const int t0 = max(0, bin - a.guard - a.window), t1 = bin - a.guard;  // cfar.cpp:48-49
+        const int f0 = bin + a.guard, f1 = min(a.cols, bin + a.guard + a.window);   // :52-53
+        // getMean: sequential sum of exact integer-valued doubles / count; an empty window is 0/0
+        if (t1 > t0 && f1 > f0) {
+          const uint32_t st = P(t1) - P(t0), sf = P(f1) - P(f0);
+          bool det, decided = false;
+          if (t1 - t0 == a.window && f1 - f0 == a.window) {
+            // Both windows full (every bin but the row's ends): scaling (st / w + sf / w) / 2 = (st + sf) scaling / (2 w) up to
+            // seven roundings of 2^-53 between the two forms; a candidate whose square is not within 1e-12 of that
+            // threshold compares the same way in both, and the two fp64 divisions are skipped.
+            const double thr = (double)(st + sf) * a.thr_scale;
+            const double d = (double)sq - thr;
+            if (fabs(d) > fabs(thr) * 1e-12) { det = d > 0.0; decided = true; }
+          }
+          if (!decided) {
+            const double trailing_mean = (double)st / (double)(t1 - t0);
+            const double forwarding_mean = (double)sf / (double)(f1 - f0);
+            const double mean = (trailing_mean + forwarding_mean) / 2.0;        // :56
+            const double threshold = a.scaling * mean;                          // :58
+            det = (double)sq > threshold;                                       // :59-60
+          }
+          if (det) atomicOr(&det32[bin >> 5], 1u << (bin & 31));
+        }
       }
     }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#ifdef CFEAR_CFAR_TIMING
+    t_rounds += __builtin_readcyclecounter() - tb;
+#endif
   }
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  CFAR_T(2);
   int total = 0;
   for (int w0 = 0; w0 < a.words; w0 += 64) {
     const int wd = w0 + lane;
@@ -820,6 +868,12 @@ __global__ __launch_bounds__(256) void cacfar_rows_kernel(const CfarArgs a) {
   }
   total = wave_sum_i32(total);
   if (lane == 0) a.det_count[(long long)b * a.rows + r] = total;
+#ifdef CFEAR_CFAR_TIMING
+  CFAR_T(3);
+  if (lane == 0 && (grow % 20011) == 0)
+    printf("cfar row %lld: load+prefix %lld | scatter %lld rounds %lld (C %d) | write %lld | total %lld\n", grow, tq[1] - tq[0],
+           t_scatter, t_rounds, ctot, tq[3] - tq[2], tq[3] - tq[0]);
+#endif
 }
 
 struct CfarCloudArgs {
@@ -1302,6 +1356,7 @@ int cfear_cacfar_device(cfear_ctx* ctx, const uint8_t* d_polar, const cfear_pola
   const double false_alarm_rate_ = (double)par->false_alarm_rate;
   const double N = par->window_size * 2;                                     // cfar.cpp:32
   a.scaling = N * (std::pow(false_alarm_rate_, -1. / N) - 1.);               // cfar.cpp:12-16
+  a.thr_scale = a.scaling / (2.0 * (double)par->window_size);
   a.range_res = (double)par->range_res;
   a.static_threshold = (double)par->z_min;
   a.min_distance = (double)par->min_distance;
@@ -1312,7 +1367,6 @@ int cfear_cacfar_device(cfear_ctx* ctx, const uint8_t* d_polar, const cfear_pola
   const long long nrows = (long long)batch * rows;
   const int colsp = (cols + 1023) & ~1023;
   {
-    // per wavefront: prefix sums u32[colsp + 16] | the row u8[colsp]
     const size_t rows_lds = (size_t)kRowsPerBlock * cfar_wave_lds(colsp);
     // the candidate pre-test in integers.  intensity > static_threshold for integer intensities: the smallest passing value;
     // range > min_distance && range < max_distance (cfar.cpp:43-45, range = range_res * bin in double): the bin interval,
@@ -1324,6 +1378,7 @@ int cfear_cacfar_device(cfear_ctx* ctx, const uint8_t* d_polar, const cfear_pola
       while (lo < cols && !(a.range_res * (double)lo > a.min_distance)) lo++;
       while (hi > 0 && !(a.range_res * (double)(hi - 1) < a.max_distance)) hi--;
       a.bin_lo = lo; a.bin_hi = hi;
+      if (a.thr_i >= 256) a.bin_hi = a.bin_lo = 0;                            // nothing passes the static threshold
     }
     if (rows_lds > 64 * 1024)
       CFEAR_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)cacfar_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rows_lds));

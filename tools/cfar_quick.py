@@ -1,10 +1,11 @@
 import sys, time, numpy as np, torch
 sys.path.insert(0, '/root/repo')
 from tbv_slam_public_amd import api, synth
-B, F = 64, 8
+B, F = (int(sys.argv[1]) if len(sys.argv) > 1 else 64), 8
 dev = "cuda"
 rings = torch.empty((B, F, 400, 3360), dtype=torch.uint8, device=dev)
-for b in range(B):
+for b in range(B):  # distinct scenes up to 64, then repeats
+    if b >= 64: rings[b] = rings[b % 64]; continue
     sc = synth.Scene(500 + b, circle_frames=64, range_res=0.175, ccw=True)
     rings[b] = synth.render_frames_torch(sc, list(range(F)), dev)
 par = api.odometry_params(filter_type=1, cacfar_range_res=0.175, cacfar_z_min=20.0, cacfar_nb_guard_cells=10,
