@@ -205,6 +205,17 @@ def roofline_of(prof, n_scans_per_launch, mean_points):
             "polar_read_only_GBs": read_only, "scans_per_launch": n_scans_per_launch}
 
 
+def whole_path_of(mean_points, mean_cells, keyframes, registrations_per_s_per_gpu):
+    """SURVEY.md 8(d), "scan registration from raw polar": R*C + 32*N_f + 96*N_s + 48*sum_j N_t,j algorithmic bytes per
+    registration (image read; points written then read; cells written then read; the keyframes' cells read once) against
+    the HBM spec -- the honest figure for the whole path: only the polar sweep is HBM-bound, the surface-point and matcher
+    kernels work on KB-scale sets in LDS / L2 and are issue- and latency-bound."""
+    b = IMG + 32.0 * mean_points + 96.0 * mean_cells + 48.0 * keyframes * mean_cells
+    gbs = b * registrations_per_s_per_gpu / 1e9
+    return {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+            "algorithmic_bytes_per_registration": b}
+
+
 # ---------------------------------------------------------------------------------------------------------
 # neighbouring workloads (functions so that the odometry run can report them in its own line)
 # ---------------------------------------------------------------------------------------------------------
@@ -498,6 +509,7 @@ def main(argv=None):
         "rccl_ranks": len(per_rank),
         "per_rank_value": per_rank,
         "roofline": roof,
+        "roofline_whole_path": whole_path_of(nf, tot["cells"] / max(tot["frames"], 1), 4, value / D.world),
         "kernel_breakdown": breakdown,
         "mean_cells_per_scan": tot["cells"] / max(tot["frames"], 1),
         "failed_registrations": int(bad_total),
