@@ -205,6 +205,14 @@ def roofline_of(prof, n_scans_per_launch, mean_points):
             "polar_read_only_GBs": read_only, "scans_per_launch": n_scans_per_launch}
 
 
+def pingpong(t, n):
+    """0, 1, .., n-1, n-2, .., 1, 0, 1, ..: a finite run of frames walked forth and back."""
+    if n < 2:
+        return 0
+    q = t % (2 * n - 2)
+    return q if q < n else 2 * n - 2 - q
+
+
 def whole_path_of(mean_points, mean_cells, keyframes, registrations_per_s_per_gpu):
     """SURVEY.md 8(d), "scan registration from raw polar": R*C + 32*N_f + 96*N_s + 48*sum_j N_t,j algorithmic bytes per
     registration (image read; points written then read; cells written then read; the keyframes' cells read once) against
@@ -422,15 +430,17 @@ def main(argv=None):
             idx = torch.from_numpy(ss.seq * F + (ss.start + t) % F).to(dev)
             x = rings.view(S * F, ROWS, COLS).index_select(0, idx)
             return torch.rot90(x, -1, dims=(1, 2)).contiguous() if args.bins_major else x
-        G = min(F, 4)                      # a few gathered batches cycle (each is B images: 2.75 GB)
+        G = min(F, 16)                     # gathered batches (each is B images: 2.75 GB), walked forth and back
         cache = [batch_of(t) for t in range(G)]
+        torch.cuda.synchronize()           # the library's stream is not torch's: the batches must exist before the first frame
         if G < F:
-            sys.stderr.write("bench.py: --bins-major/--keep-nodes cycle %d gathered frames (not a continuous trajectory)\n" % G)
+            sys.stderr.write("bench.py: --bins-major/--keep-nodes walk %d gathered frames forth and back (the motion reverses "
+                             "at both ends)\n" % G)
 
         def advance(n, t_first, record=None):
             st = {"points": 0.0, "cells": 0.0, "bad": 0, "frames": 0}
             for t in range(t_first, t_first + n):
-                info = od.process(cache[t % G], cache[(t + 1) % G])
+                info = od.process(cache[pingpong(t, G)], cache[pingpong(t + 1, G)])
                 st["points"] += float(info["n_points"].mean()); st["cells"] += float(info["n_cells"].mean())
                 st["bad"] += int((info["reg_status"] != 0).sum()); st["frames"] += 1
             return st
@@ -602,16 +612,17 @@ def main(argv=None):
             def frame(t):                                        # stream b = world b % Ss at frame t (worlds shared, poses not)
                 x = sr[:, t % Fs].index_select(0, seq)
                 return torch.rot90(x, -1, dims=(1, 2)).contiguous() if bins_major else x
-            batches = [frame(t) for t in range(4)]                # the ring's first frames, cycled as gathered batches
+            batches = [frame(t) for t in range(Fs)]               # the ring's first frames as gathered batches, walked forth and back
             bad = 0
+            torch.cuda.synchronize()                             # the library's stream is not torch's: the batches must exist
             for t in range(4):
-                sod.process(batches[t % 4], batches[(t + 1) % 4])
+                sod.process(batches[pingpong(t, Fs)], batches[pingpong(t + 1, Fs)])
             D.barrier()
             ctx.profile_enable(True); ctx.profile_read(reset=True)
             t0s = time.perf_counter()
             pts = cells = 0.0
-            for t in range(nfr):
-                info = sod.process(batches[t % 4], batches[(t + 1) % 4])
+            for t in range(4, 4 + nfr):
+                info = sod.process(batches[pingpong(t, Fs)], batches[pingpong(t + 1, Fs)])
                 bad += int((info["reg_status"] < 0).sum())
                 pts += float(info["n_points"].mean()); cells += float(info["n_cells"].mean())
             D.barrier()
@@ -621,7 +632,7 @@ def main(argv=None):
             return {"value": Bs * nfr / dts, "unit": "registrations/s", "ms_per_frame_batch": dts / nfr * 1e3, "streams": Bs,
                     "frames": nfr, "mean_points_per_scan": pts / nfr, "mean_cells_per_scan": cells / nfr,
                     "failed_registrations": bad, "kernel_breakdown": {k: v[0] / max(v[1], 1) for k, v in sp.items()},
-                    "note": "4 gathered frame batches cycle (not a continuous trajectory)"}
+                    "note": "%d gathered frame batches walked forth and back (the motion reverses at both ends)" % Fs}
         out["config2_mulran"] = side_config(api.odometry_preset("CFEAR-3", "mulran", submap_scan_size=5), 70000, 0.0595238, True, 1024, 32, 12)
         out["config4_cacfar_kvarntorp"] = side_config(
             api.odometry_params(filter_type=1, cacfar_range_res=0.175, cacfar_z_min=20.0, cacfar_nb_guard_cells=10,
