@@ -34,7 +34,10 @@ def _ptr(x):
 
 
 class Context:
-    """cfear_ctx: one per host thread / HIP stream."""
+    """cfear_ctx: one per host thread / HIP stream.  `stream` = a hipStream_t handle to enqueue on; None or 0 (which is
+    also what torch reports for its default stream) gives the context a PRIVATE non-blocking stream: work torch has queued
+    that produces this context's inputs must then be synchronised by the caller (default_context() passes hipStreamLegacy
+    for torch's default stream instead, which orders the two)."""
 
     def __init__(self, device=0, stream=None):
         self._lib = L.lib()
