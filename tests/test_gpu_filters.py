@@ -124,6 +124,18 @@ def test_cacfar_vs_oracle():
         cloud, _ = O.cacfar(img2, *args, max_distance=maxd)
         assert r["n_points"][0] == cloud.shape[0], (args, r["n_points"][0], cloud.shape[0])
         np.testing.assert_array_equal(r["xyzi"][0, :cloud.shape[0]], cloud)
+    # rows beyond 4096 bins: the second block of 16-byte loads, candidate masks of chunks 4..7, four list pieces; the
+    # widest row the library takes (8192), one that is no multiple of 16, and a dense one (every bin a candidate)
+    for cols, thr in [(5000, 40), (8192, 60), (6001, 30), (4100, 0)]:
+        img3 = (8 + rng.exponential(20, size=(5, cols))).clip(0, 255).astype(np.uint8)
+        img3[2, cols - 30:] = 250
+        r = api.filter_cacfar(img3, 20, 6, 0.02, 0.0438, thr, 2.5, max_distance=1000.0, want_mask=True)
+        cloud, rc = O.cacfar(img3, 20, 6, 0.02, 0.0438, thr, 2.5, max_distance=1000.0)
+        assert r["n_points"][0] == cloud.shape[0], (cols, r["n_points"][0], cloud.shape[0])
+        np.testing.assert_array_equal(r["xyzi"][0, :cloud.shape[0]], cloud)
+        mask = np.zeros(img3.shape, np.uint8)
+        mask[rc[:, 0], rc[:, 1]] = 1
+        np.testing.assert_array_equal(r["det_mask"][0], mask)
 
 
 def test_radar_driver_mirror():
