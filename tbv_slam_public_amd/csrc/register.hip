@@ -555,6 +555,8 @@ struct FusedLds {
   double* kf;          // [16][12]: Ttar (l0..l3,t0,t1), Tst (l0..l3,t0,t1)
   int* koff;           // [17] prefix of target counts
   float4* txyi;        // [sum targets] (x, y, index-as-int-bits, -) grouped by (keyframe, grid cell): one 16-byte LDS read per candidate
+  float2* txy;         // packed form (the 8-wavefront kernel: large registrations): (x, y) here and the index as u16 in tix --
+  unsigned short* tix; // 10 bytes per target instead of 16, so 1.6 x the cells fit the CU's LDS
   const void** tptr;   // [16][5] per keyframe: mean, normal, nsamples, scale, cov arrays (global pointers)
   float4* ggeo;        // [16] per keyframe grid: (x0, y0, cells per metre, -)
   unsigned* gext;      // [16][4] order-preserving uint images of the y extent (min, max) while the grid is built
@@ -577,7 +579,7 @@ __host__ __device__ inline int reg_grid_dim(int keyframes) {
 // Carves the workgroup's dynamic LDS (bytes `lds_total`) for the actual sizes; returns false when the
 // fixed parts leave no room (the caller then uses the slot-array path).
 __device__ __forceinline__ bool fused_carve(uint8_t* smem, size_t lds_total, int last, int sum_tar, int n_src, int n_pairs,
-                                            int fields, FusedLds& f) {
+                                            int fields, FusedLds& f, bool packed) {
   size_t off = kRegFixedLds;
   f.kf = (double*)(smem + off); off += 16 * 12 * 8;
   f.koff = (int*)(smem + off); off += 80;
@@ -588,7 +590,13 @@ __device__ __forceinline__ bool fused_carve(uint8_t* smem, size_t lds_total, int
   const size_t n_cells = (size_t)last * f.G * f.G;
   f.cstart = (unsigned short*)(smem + off); off += ((n_cells + 1) * 2 + 15) & ~(size_t)15;
   off = (off + 15) & ~(size_t)15;
-  f.txyi = (float4*)(smem + off); off += (size_t)sum_tar * 16;
+  f.txyi = (float4*)(smem + off); f.txy = (float2*)(smem + off);
+  if (packed) {
+    off += (size_t)sum_tar * 8;
+    f.tix = (unsigned short*)(smem + off); off += (((size_t)sum_tar * 2 + 15) & ~(size_t)15);
+  } else {
+    f.tix = nullptr; off += (size_t)sum_tar * 16;
+  }
   const size_t ns = ((size_t)n_src + 1) & ~(size_t)1;
   f.smean = (double2*)(smem + off); off += ns * 16;
   f.match = (unsigned short*)(smem + off); off += (((size_t)n_pairs + 7) & ~(size_t)7) * 2;
@@ -716,7 +724,8 @@ __device__ void fused_stage(const RegJob& job, const FusedLds& f, float cm_radiu
   REG_TACC(14);
   for_targets([&](int i, float x, float y, int idx) {     // scatter (order inside a cell is irrelevant: the NN
     const unsigned pos = atomicAdd(&f.ccnt[i * GG + cell_of(f.ggeo[i], x, y)], 1u);   // tie rule is by cell index)
-    f.txyi[pos] = make_float4(x, y, __int_as_float(idx), 0.f);
+    if (NW == kRegNWBig) { f.txy[pos] = make_float2(x, y); f.tix[pos] = (unsigned short)idx; }
+    else f.txyi[pos] = make_float4(x, y, __int_as_float(idx), 0.f);
   });
   const ScanView& src = job.scans[last];
   const int n_src = *src.n_cells;
@@ -775,6 +784,10 @@ __device__ int associate_fused(const RegJob& job, const RegCommon& cm, const dou
         const unsigned long long key = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)__float_as_int(c.z);
         bestkey = key < bestkey ? key : bestkey;
       };
+      auto fetch = [&](int q) -> float4 {           // a candidate record in either layout
+        if (NW == kRegNWBig) { const float2 v = f.txy[q]; return make_float4(v.x, v.y, __int_as_float((int)f.tix[q]), 0.f); }
+        return f.txyi[q];
+      };
       const unsigned short* cs = f.cstart + i * G * G;
       // cells of a grid row are contiguous in txyi.  The bounds of the (at most three, unless the radius
       // exceeds the cell edge) rows are fetched together; candidates are visited four per step with the
@@ -782,7 +795,7 @@ __device__ int associate_fused(const RegJob& job, const RegCommon& cm, const dou
       auto scan_run = [&](int qb, int qe) {
         for (int q = qb; q < qe; q += 4) {
           const int l = qe - 1;
-          const float4 ca = f.txyi[q], cb = f.txyi[min(q + 1, l)], cc = f.txyi[min(q + 2, l)], cd = f.txyi[min(q + 3, l)];
+          const float4 ca = fetch(q), cb = fetch(min(q + 1, l)), cc = fetch(min(q + 2, l)), cd = fetch(min(q + 3, l));
           visit(ca); visit(cb); visit(cc); visit(cd);
         }
       };
@@ -1162,12 +1175,12 @@ __global__ __launch_bounds__(NW * 64) void register_kernel(const RegJob* __restr
   int sum_tar = 0;
   for (int i = 0; i < last; i++) sum_tar += *job.scans[i].n_cells;
   FusedLds fl;
-  const bool fused = fused_carve(smem, cm.lds_total, last, sum_tar, n_src, n_slots, cm.dense_fields, fl);
+  const bool fused = fused_carve(smem, cm.lds_total, last, sum_tar, n_src, n_slots, cm.dense_fields, fl, NW == kRegNWBig);
   if (!fused && cm.big_mode == 1) {
     // Too large for the association in 80 KB of LDS, but not for a workgroup that owns the CU's LDS: leave it to the second
     // launch instead of the x-window path below (13 x slower per registration on 1 400-cell scans).
     FusedLds probe;
-    if (fused_carve(smem, cm.lds_big, last, sum_tar, n_src, n_slots, cm.dense_fields, probe)) {
+    if (fused_carve(smem, cm.lds_big, last, sum_tar, n_src, n_slots, cm.dense_fields, probe, true)) {   // the second launch packs its targets
       if (threadIdx.x == 0) { res->status = kRegDeferred; res->reserved = 1.0; }
       return;
     }
