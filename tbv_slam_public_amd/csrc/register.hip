@@ -1185,6 +1185,10 @@ __global__ __launch_bounds__(NW * 64) void register_kernel(const RegJob* __restr
       return;
     }
   }
+  // Code placement (MI355X_MICROARCH.md, code-placement sensitivity): without these 32 bytes the loops of this build of the
+  // 4-wavefront kernel land where they run 1.3 % slower (0.930 against 0.917 ms per 2048 registrations; 16, 32 or 48 bytes
+  // all restore it).  Executed once per registration.  Re-check with tools/ab.sh when the kernel changes.
+  if (NW == kRegNW) asm volatile("s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0");
   REG_T0();
   if (fused) fused_stage<NW>(job, fl, (float)cm.par.radius);
   REG_TACC(6);
