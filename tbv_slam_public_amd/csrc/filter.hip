@@ -282,14 +282,14 @@ __global__ __launch_bounds__(256, 7) void kstrongest_rows_kernel(const KStrongAr
     n_eq = __builtin_amdgcn_readlane(el, lc);
   };
 
-  if (n_ge <= k || n_ge <= 64) {
+  if (__builtin_expect(n_ge <= k || n_ge <= 64, 1)) {
     // ---- at most k candidates, or at most 64: all of them become keys (any order); the ranking below
     //      restores the reference's ascending (intensity, range) order and, when there are more than k,
     //      keeps the k largest keys -- the lexicographic (intensity, range) cut of the reference, ties at
     //      the cut intensity resolved toward the larger range, without building the histogram --------------
     n_sel = min(n_ge, k);
     n_all = n_ge;
-    if (n_ge <= 64) {
+    if (__builtin_expect(n_ge <= 64, 1)) {
       scatter_to_lanes(bm, c_lane, c_incl, n_ge);
     } else {
       int slot = c_incl - c_lane;
@@ -449,7 +449,7 @@ __global__ __launch_bounds__(256, 7) void kstrongest_rows_kernel(const KStrongAr
       if (m >= a.cols - 16) atomicOr(&hist[1], 1u << (m - (a.cols - 16)));
     }
   };
-  if (do_peaks) {
+  if (__builtin_expect(do_peaks, 0)) {
     if (halo_pos != 0) rowbuf[halo_pos] = halo;    // after the row staging: the tail chunk's zero padding lies there
     if (lane < 2) hist[lane] = 0;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -523,7 +523,7 @@ __global__ __launch_bounds__(256, 7) void kstrongest_rows_kernel(const KStrongAr
         beyond_pk = beyond && pk;
       }
     }
-    if (a.row_keys) {
+    if (__builtin_expect(a.row_keys != nullptr, 1)) {
       // fused getPeaksFilteredPointCloud(cloud, false) (radar_filters.cpp:309-337): the row's kept bins in rank order;
       // a bin's slot = number of kept bins beyond min_range_bin with a lower rank (k <= 64: one pass)
       if (beyond) atomicOr(&hist[2 + (rank >> 5)], 1u << (rank & 31));
