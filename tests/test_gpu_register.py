@@ -107,6 +107,38 @@ def _dense_cells(seed, frames):
     return out, gt
 
 
+def test_second_launch_capacity_with_packed_targets():
+    """1 900 cells per scan (cells of two dense scenes side by side, 600 m apart): four keyframes exceed what the second
+    launch held with 16-byte target records (1 650 cells per scan) and fit with the packed 10-byte ones (~2 070); ~2 800
+    cells per scan exceed that too and take the x-window path.  Both must give the oracle's result."""
+    from oracle import pyoracle as O
+    from tbv_slam_public_amd import api, synth
+    frames = [0, 1, 2, 3, 4]
+    worlds = [synth.scene_dense(seed, 5) for seed in (9, 10)]
+    gt = worlds[0][1]
+    poses = np.array([_rel(gt[0], gt[f]) for f in frames])
+    poses[-1] += [0.25, -0.15, 0.006]
+    reg = api.n_scan_normal_reg("P2P", "Huber", 0.1, 4)
+    for radius, keep, lo, hi, second in ((2.5, 950, 1700, 2000, 1.0), (3.0, 100000, 2100, 8000, None)):
+        cells = []
+        for f in frames:
+            parts = []
+            for w, (imgs, _, _) in enumerate(worlds):
+                sr, si, sc = O.kstrongest(imgs[f], 40, 60)
+                c = O.surface_points(O.kstrongest_cloud(sr, si, sc, 0.0438, 2.5), radius, 1.0, (0, 0), True).copy()
+                c["mean"][:, 0] += 600.0 * w
+                parts.append(c[:keep])
+            cells.append(np.concatenate(parts))
+        assert lo < min(len(c) for c in cells) and max(len(c) for c in cells) < hi, [len(c) for c in cells]
+        out = reg.RegisterBatch([([api.MapPointNormal(cells=c) for c in cells], poses)])[0]
+        ok_o, po, ro = O.register(cells, poses, _oracle_par(reg))
+        assert (out["status"] == 0) == ok_o
+        assert (out["outer_iters"], out["lm_iters"], out["num_residuals"]) == (ro.outer_iters, ro.lm_iters, ro.num_residuals)
+        assert np.abs(out["pose"][:2] - po[-1, :2]).max() <= POS_TOL and abs(out["pose"][2] - po[-1, 2]) <= ROT_TOL
+        if second is not None:
+            assert out["reserved"] == second
+
+
 def test_large_scans_take_the_second_launch():
     """Scans of ~1 400 cells: four keyframes do not fit the 80 KB association, so the batch entry adds the second launch
     (one workgroup per CU with all of its LDS); a five-scan window still fits it, and the result is the oracle's either
