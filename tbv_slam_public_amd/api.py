@@ -58,6 +58,7 @@ class Context:
         self.check(self._lib.cfear_ctx_synchronize(self.h))
 
     def profile_enable(self, on=True):
+        """True / 1: every kernel family; 2: only the polar filter's row kernels; False / 0: off."""
         self.check(self._lib.cfear_ctx_profile_enable(self.h, int(on)))
 
     def profile_read(self, reset=True):

@@ -27,7 +27,7 @@ struct cfear_ctx {
   hipStream_t stream = nullptr;
   bool own_stream = false;
   std::string last_error;
-  bool profile = false;
+  int profile = 0;            // 0 off, 1 every kernel family, 2 the polar filter's row kernels only (the HBM-bound launch)
   std::vector<ProfRow> prof;
   std::vector<hipEvent_t> event_pool;
   // grow-only device workspaces (indexed by purpose so stages of one pipeline do not alias)
@@ -68,7 +68,10 @@ struct ProfScope {
   cfear_ctx* ctx;
   int row;
   ProfScope(cfear_ctx* c, const char* name) : ctx(c), row(-1) {
-    if (ctx->profile) { row = cfear_prof_row(ctx, name); cfear_prof_begin(ctx, row); }
+    if (ctx->profile == 1 || (ctx->profile == 2 && (!strcmp(name, "kstrongest_rows") || !strcmp(name, "cacfar_rows")))) {
+      row = cfear_prof_row(ctx, name);
+      cfear_prof_begin(ctx, row);
+    }
   }
   ~ProfScope() { if (row >= 0) cfear_prof_end(ctx, row); }
 };

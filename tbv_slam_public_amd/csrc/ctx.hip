@@ -263,7 +263,7 @@ const char* cfear_last_error(const cfear_ctx* ctx) { return ctx ? ctx->last_erro
 
 int cfear_ctx_profile_enable(cfear_ctx* ctx, int enable) {
   if (!ctx) return CFEAR_ERR_INVALID_ARGUMENT;
-  ctx->profile = enable != 0;
+  ctx->profile = enable == 2 ? 2 : (enable != 0 ? 1 : 0);
   return CFEAR_OK;
 }
 
