@@ -137,6 +137,12 @@ __global__ __launch_bounds__(kCoralThreads) void coral_kernel(const CoralJob* __
   int32_t* vres = (int32_t*)(wres + cm.cap);
   int32_t* work = vres + cm.cap;                               // sorted positions of the points that overlap the other cloud
 
+#ifdef CFEAR_CORAL_TIMING
+  long long tq[8]; tq[0] = __builtin_readcyclecounter();
+#define CORAL_T(k) tq[k] = __builtin_readcyclecounter()
+#else
+#define CORAL_T(k)
+#endif
   const Aff2d Tref = aff_xyt(job.ref_pose);
   const Aff2d Tsrc = aff_compose(aff_xyt(job.src_pose), aff_xyt(job.offset));            // src->GetAffine() * Toffset (:101)
   auto point = [&](int i) -> float2 {                          // merged index: source points first (:132, :155)
@@ -172,6 +178,7 @@ __global__ __launch_bounds__(kCoralThreads) void coral_kernel(const CoralJob* __
     ix = (int)(floorf(p.x * cm.inv_cell) - (float)min_bx);
     iy = (int)(floorf(p.y * cm.inv_cell) - (float)min_by);
   };
+  CORAL_T(1);
   // ---- 2. sort by (cell, index) ------------------------------------------------------------------
   unsigned long long* keys = (unsigned long long*)smem;
   int npad = grid_sort_rows_block(smem, n, dbx, dby, (uint32_t*)(smem + kCoralRowbegOff), red_i, red_c, 512,
@@ -182,6 +189,7 @@ __global__ __launch_bounds__(kCoralThreads) void coral_kernel(const CoralJob* __
       cell_xy(point(i), ix, iy);
       return (uint32_t)(ix + iy * dbx);
     });
+  CORAL_T(2);
   // ---- 3. sorted points -> scratch; cell table (key, start) -> LDS ---------------------------------
   const int per = npad / kCoralThreads;                 // 1..16 consecutive sorted elements per thread
   unsigned long long mine[kCoralPerThread];
@@ -250,6 +258,7 @@ __global__ __launch_bounds__(kCoralThreads) void coral_kernel(const CoralJob* __
   // (overlap_req_ = 1, :138, :160)?  Float distance tests only, first hit ends the search.  Points without one are
   // final (100, 100, invalid); the others go to a work list.  Pass B (expensive, work list only): fp64 moments and
   // entropies -- typically a quarter to a half of the points, spread evenly over the workgroup.
+  CORAL_T(3);
   int* n_work = red_i;                                          // LDS counter (red_i is free after the sort)
   if (tid == 0) *n_work = 0;
   __syncthreads();
@@ -295,6 +304,7 @@ __global__ __launch_bounds__(kCoralThreads) void coral_kernel(const CoralJob* __
   __threadfence_block();
   __syncthreads();
   const int W = *n_work;
+  CORAL_T(4);
   auto sweep = [&](auto* SP) {
     for (int k = tid; k < W; k += kCoralThreads) {
       const int e = work[k];
@@ -358,6 +368,7 @@ __global__ __launch_bounds__(kCoralThreads) void coral_kernel(const CoralJob* __
   else sweep((const v4f*)spt);
   __threadfence_block();
   __syncthreads();
+  CORAL_T(5);
   // ---- 5. aggregation in index order (:178-204): contiguous chunk per thread, then a fixed tree ------
   {
     const int chunk = (n + kCoralThreads - 1) / kCoralThreads;
@@ -381,6 +392,12 @@ __global__ __launch_bounds__(kCoralThreads) void coral_kernel(const CoralJob* __
       r.count_valid = count_valid; r.status = CFEAR_OK; r.pad = 0;
     }
   }
+#ifdef CFEAR_CORAL_TIMING
+  CORAL_T(6);
+  if (tid == 0 && (blockIdx.x % 997) == 0)
+    printf("coral job %d n %d W %d: bbox %lld | sort %lld | table %lld | overlap %lld | sweep %lld | reduce %lld | total %lld\n", blockIdx.x, n, W,
+           tq[1] - tq[0], tq[2] - tq[1], tq[3] - tq[2], tq[4] - tq[3], tq[5] - tq[4], tq[6] - tq[5], tq[6] - tq[0]);
+#endif
   if (cm.per_point) {
     double* pp = cm.per_point + (size_t)blockIdx.x * cm.cap * 3;
     for (int i = tid; i < n; i += kCoralThreads) { pp[3 * i] = jres[i]; pp[3 * i + 1] = sres[i]; pp[3 * i + 2] = (double)vres[i]; }
