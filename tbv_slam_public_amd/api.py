@@ -1002,14 +1002,44 @@ class RSCManager:
         cands.sort()                                  # lower_bound insertion == sort by (distance, index)
         return [i for _, i in cands[:self.NUM_CANDIDATES_FROM_TREE]]
 
-    def _vanilla_nn_search(self, curr_key):                                 # RadarScancontext.cpp:225-248 (exact KNN)
-        n = len(self.polarcontext_invkeys_mat_) - self.NUM_EXCLUDE_RECENT
-        if n <= 0:
-            return []
-        K = np.asarray(self.polarcontext_invkeys_mat_[:n], np.float32)
-        d = ((K - curr_key.astype(np.float32)[None]) ** 2).sum(1)
-        order = np.argsort(d, kind="stable")[:self.NUM_CANDIDATES_FROM_TREE]
-        return [int(i) for i in order]
+    TREE_MAKING_PERIOD_ = 50                          # Scancontext.h:116
+
+    @staticmethod
+    def _l2_adaptor(K, q):
+        """nanoflann::L2_Adaptor::evalMetric (the reference's vendored nanoflann.hpp:383-408) in float: groups of four
+        squared differences are added among themselves first, then to the running sum; the tail one by one."""
+        K = np.asarray(K, np.float32)
+        e = K - np.asarray(q, np.float32)[None]
+        e2 = e * e
+        d = np.zeros(K.shape[0], np.float32)
+        g4 = (K.shape[1] // 4) * 4
+        for c in range(0, g4, 4):
+            d = d + (((e2[:, c] + e2[:, c + 1]) + e2[:, c + 2]) + e2[:, c + 3])
+        for c in range(g4, K.shape[1]):
+            d = d + e2[:, c]
+        return d
+
+    def _vanilla_nn_search(self, curr_key):                                 # RadarScancontext.cpp:225-248
+        """The ring-key kd-tree retrieval with the reference's bookkeeping: the tree is rebuilt only on every
+        TREE_MAKING_PERIOD_-th CALL (one call per augmentation of every node) from the keys older than the recent-node
+        exclusion AT THAT MOMENT, and a tree with fewer points than NUM_CANDIDATES_FROM_TREE leaves the rest of the
+        zero-initialised index vector in place (node 0 is then proposed again).  The search itself is exact (nanoflann,
+        eps = 0), so a linear scan with the tree's own metric arithmetic returns the same neighbours; equal distances
+        come back in index order here, in tree-visiting order there (tests/test_ref_nanoflann.py)."""
+        if getattr(self, "_tree_counter", None) is None:
+            self._tree_counter, self._tree_keys = 0, np.zeros((0, 0), np.float32)
+        if self._tree_counter % self.TREE_MAKING_PERIOD_ == 0:
+            n = len(self.polarcontext_invkeys_mat_) - self.NUM_EXCLUDE_RECENT
+            self._tree_keys = np.asarray(self.polarcontext_invkeys_mat_[:max(n, 0)], np.float32).copy()
+        self._tree_counter += 1
+        K = self._tree_keys
+        out = [0] * self.NUM_CANDIDATES_FROM_TREE
+        if K.shape[0] > 0:
+            d = self._l2_adaptor(K, curr_key)
+            order = np.argsort(d, kind="stable")[:self.NUM_CANDIDATES_FROM_TREE]
+            for j, i in enumerate(order):
+                out[j] = int(i)
+        return out
 
     def detectLoopClosureID(self):
         """RadarScancontext.cpp:286-345 -> list of candidates dict(min_dist, min_dist_sc, min_dist_odom,

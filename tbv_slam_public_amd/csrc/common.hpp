@@ -130,9 +130,17 @@ int cfear_compensate_batch_device(cfear_ctx* ctx, float* d_xyzi, size_t cloud_st
                                   const double* d_mot, int n_clouds, int max_points, int ccw);
 int cfear_rotate_ccw_device(cfear_ctx* ctx, const uint8_t* d_src, const cfear_polar_desc* src_desc, uint8_t* d_dst,
                             int dst_stride, int64_t dst_batch_stride);
+// CA-CFAR for the batched odometry: per-row key lists (intensity << 24 | range bin, ascending bins; row_cnt[2 row] = the
+// row's detections, which may exceed kcap -- the keys beyond are dropped and surface_prep_kernel reports the scan) in the
+// layout of cfear_kstrong_fused, so surface_prep_kernel compacts and converts them (rho = range_res * bin, cfar.cpp:43).
+struct cfear_cacfar_fused {
+  uint32_t* row_keys = nullptr;
+  int32_t* row_cnt = nullptr;
+  int kcap = 0;
+};
 int cfear_cacfar_device(cfear_ctx* ctx, const uint8_t* d_polar, const cfear_polar_desc* desc,
                         const cfear_cacfar_params* par, float* d_xyzi, int32_t* d_n_points,
-                        int32_t cap_points, uint8_t* d_det_mask);
+                        int32_t cap_points, uint8_t* d_det_mask, const cfear_cacfar_fused* fused = nullptr);
 size_t cfear_surface_lds_bytes();
 size_t cfear_surface_scratch_bytes(int cap_points);   // per scan, for clouds of up to cap_points points
 size_t cfear_surface_job_bytes();
@@ -144,7 +152,8 @@ void cfear_surface_fill_job(void* dst, float* d_xyzi, const int32_t* d_n, int32_
 void cfear_surface_fill_job_rows(void* dst, float* d_xyzi, int32_t* d_n_out, const uint32_t* d_row_keys, const int32_t* d_row_cnt,
                                  int rows, int k, int compensate, const double mot[3], const ScanView& out);
 // rows mode needs the polar -> Cartesian constants: call before cfear_surface_launch (per context)
-struct cfear_surface_polar { const double* cos_t = nullptr; const double* sin_t = nullptr; double range_res = 0.0; int rows = 0, k = 0; };
+// rho = range_off + range_res * bin: range_off = range_res / 2 for the k-strongest filter (radar_filters.cpp:324), 0 for CA-CFAR
+struct cfear_surface_polar { const double* cos_t = nullptr; const double* sin_t = nullptr; double range_res = 0.0, range_off = 0.0; int rows = 0, k = 0; };
 int cfear_trig_tables(cfear_ctx* ctx, int rows, double** d_cos, double** d_sin);
 // max_cell_cap: the largest cell capacity (ScanView::cap) among the jobs' output slabs
 int cfear_surface_launch(cfear_ctx* ctx, const void* d_jobs, int n_jobs, const cfear_feature_params* par,

@@ -667,214 +667,332 @@ struct CfarArgs {
   const uint8_t* polar;
   int rows, cols, stride, batch;
   long long batch_stride;
+  long long total_rows;
   int window, guard;
   double scaling, range_res, static_threshold, min_distance, max_distance;
+  // bitmap output (standalone filter; cacfar_cloud_kernel compacts it)
   unsigned long long* det_bits;   // [batch][rows][words]  (words = ceil(cols/64))
   int32_t* det_count;             // [batch][rows]
   int words;
+  // key output (batched odometry): row r of image b leaves its detections as (intensity << 24 | bin), ascending bins, at
+  // row_keys[(b rows + r) kcap ...] and their number in row_cnt[2 (b rows + r)] -- the layout surface_prep_kernel
+  // already takes from the k-strongest sweep, so no cloud kernel runs in between
+  uint32_t* row_keys;
+  int32_t* row_cnt;
+  int kcap;
   int thr_i, bin_lo, bin_hi;      // candidate pre-test in integers: intensity >= thr_i, bin_lo <= bin < bin_hi
-  double thr_scale;               // scaling / (2 window): threshold per unit of (trailing + forwarding) sum when both windows are full
+  int need_cols;                  // bins a row's arithmetic can touch: min(cols, bin_hi - 1 + guard + window), in 16s
+  int colsp;                      // need_cols in whole 1024-bin chunks: the row's length in LDS
+  int lut_ok;                     // lut[] decides a candidate with two full windows in integers
+  int pre_on;                     // lower-bound pre-filter on (pa*, pb*, kappa_lb valid)
+  int pa0, pa1, pb0, pb1;         // quads [2H + pa0, 2H + pa1) / [2H + pb0, 2H + pb1) lie in the trailing / forwarding
+                                  // window of EVERY bin of the 8-bin block H
+  int pad_lo, pad_hi;             // guard entries of the prefix table below bin 0 / beyond the row
+  float kappa_lb;                 // scaling / (2 window), rounded down a little
+  uint32_t lut[256];              // see cfar_build_lut
 };
 
-// One wavefront per azimuth row.  The row is read once in 16-byte pieces (lane-interleaved, coalesced) into LDS together
-// with the exact uint32 prefix sums of its squares: 16 bins are summed inside a lane and ONE wave scan per 1024 bins
-// places the lanes (the first version scanned every 64 bins with single-byte loads: 53 dependent DPP ladders per row).
-// Only bins above the static threshold inside the range window reach the threshold arithmetic; typically a quarter of
-// the row.  Each lane keeps the 16-bit candidate mask of its 16 bins per chunk in registers; per piece of 2048 bins the
-// lanes write their candidates' bin numbers into a list in LDS (one wave scan of the popcounts places them), and the
-// list is then evaluated one candidate per lane -- C / 64 rounds per row whatever the clustering.  (The version before
-// kept the masks in LDS and found candidate k's word by a binary search over per-word counts: six dependent LDS reads
-// and a rank-select per candidate, 0.91 ms per 512 Kvarntorp sweeps.)
-constexpr int kCfarList = 2048;            // candidates of one piece (two 1024-bin chunks)
-__host__ __device__ inline size_t cfar_wave_lds(int colsp) {
-  // P4 u32[colsp / 4 + 4] | raw u8[colsp] | det u32[colsp / 32] | list u16[kCfarList]
-  return (((size_t)(colsp / 4 + 4) * 4 + (size_t)colsp + (size_t)colsp / 8 + (size_t)kCfarList * 2) + 15) & ~(size_t)15;
+// One wavefront per azimuth row, persistent: a wavefront walks rows g, g + W, g + 2 W, ... and requests the NEXT row's
+// 16-byte pieces before it works on the current one, so the HBM round trip hides behind its own arithmetic (the version
+// before ran one row per wavefront and 12 wavefronts per CU: a third of a row's residence was the wait for its loads).
+//
+// Per row:
+//  A. the row's bytes and the exact uint32 prefix sums of their squares go to LDS: 16 bins are summed inside a lane
+//     (v_dot4), ONE wave scan per 1024 bins places the lanes, the table keeps every fourth prefix (P(x) = P4[x / 4] + the
+//     squares of up to three bytes of one LDS word).  Only the bins the arithmetic can reach are read at all: with
+//     radar_driver.cpp:54's 400 m cap a Kvarntorp row ends at bin 2286 + guard + window.
+//  B. candidates.  cfar.cpp:45 lets a bin through when intensity > static_threshold inside the range window; here a bin
+//     must ALSO beat a lower bound of its own CFAR threshold: the aligned 4-bin groups that lie inside the trailing /
+//     forwarding window of every bin of an 8-bin block (56 of 80 bins for guard 10, window 40) give S_lb <= S_t + S_f from
+//     four prefix reads per block, and I^2 > scaling (S_t / n_t + S_f / n_f) / 2 >= scaling S_lb / (2 w) is necessary for
+//     a detection (n_t, n_f <= w).  So each block compares its bytes (SWAR) against max(thr_i, floor(sqrt(kappa S_lb)))
+//     instead of thr_i alone: a quarter of the candidates survive on the synthetic Kvarntorp rows, and nothing that can
+//     fire is lost.  Survivors are listed in LDS in bin order (a wave scan of the popcounts places the lanes).
+//  C. the list is evaluated one candidate per lane, 64 at a time, carrying the remainder from chunk to chunk so that
+//     every round but the last is full.  With both windows full the decision is an integer compare: with S = S_t + S_f
+//     the reference computes  I^2 > scaling ((S_t / w + S_f / w) / 2)  in fp64, which differs from the exact
+//     I^2 > S scaling / (2 w) by at most 5 roundings of 2^-53 -- so with B = I^2 2 w / scaling it fires for S <= B - 1e-3
+//     and does not for S >= B + 1e-3, and lut[I] = (T << 1 | amb) with T = ceil(B - 1e-3), amb = an integer lies within
+//     1e-3 of B:  fires <=> 2 S + 1 < lut[I];  2 S + 1 == lut[I] (practically never) and bins whose windows the row's ends
+//     cut take cfar.cpp:45-60 literally in fp64.
+//  D. detections leave in list (= bin) order: as keys for surface_prep_kernel (batched odometry) or as a bit per bin.
+constexpr int kCfarList = 1024 + 64 + 64;  // one chunk's candidates + the carried remainder
+__host__ __device__ inline size_t cfar_wave_lds(int colsp, int pad_lo, int pad_hi, bool keys) {
+  // P4 u32[pad_lo + colsp / 4 + 1 + pad_hi] | raw u8[colsp + 16] | det u32[colsp / 32] (bitmap output) | list u16[kCfarList]
+  size_t b = ((size_t)(pad_lo + colsp / 4 + 1 + pad_hi) * 4 + 15) & ~(size_t)15;
+  b += (size_t)colsp + 16;
+  if (!keys) b += (size_t)colsp / 8;
+  b += (size_t)kCfarList * 2;
+  return (b + 15) & ~(size_t)15;
 }
+template <int NCH, bool KEYS>
 __global__ __launch_bounds__(256) void cacfar_rows_kernel(const CfarArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const long long grow = (long long)blockIdx.x * kRowsPerBlock + wave;
-  if (grow >= (long long)a.batch * a.rows) return;
-  const int b = (int)(grow / a.rows), r = (int)(grow - (long long)b * a.rows);
-  const uint8_t* rowp = a.polar + (long long)b * a.batch_stride + (long long)r * a.stride;
-  const int colsp = (a.cols + 1023) & ~1023;                               // whole 1024-bin chunks (at most 8)
-  uint8_t* wbase = smem + (size_t)wave * cfar_wave_lds(colsp);
-  // Prefix sums of squares, exact in uint32, kept for every FOURTH bin only (P4[i] = sum_{q < 4 i} I_q^2) next to the row's
-  // bytes: P(x) = P4[x / 4] + the squares of up to three bytes of one LDS word.
-  uint32_t* P4 = (uint32_t*)wbase;
-  uint8_t* raw = wbase + (size_t)(colsp / 4 + 4) * 4;                      // the row itself
-  uint32_t* det32 = (uint32_t*)(raw + colsp);                              // detections, bit per bin
-  unsigned short* list = (unsigned short*)(raw + colsp + colsp / 8);       // candidate bins of the current piece
-  const bool vec = (((uintptr_t)rowp) & 15) == 0;
-#ifdef CFEAR_CFAR_TIMING
-  long long tq[6]; int ctot = 0; tq[0] = __builtin_readcyclecounter();
-#define CFAR_T(k) tq[k] = __builtin_readcyclecounter()
-#else
-#define CFAR_T(k)
-#endif
-  uint32_t run = 0;
-  unsigned long long cmw0 = 0ull, cmw1 = 0ull;                             // the lane's 16-bit candidate masks, chunk c at bits 16 (c & 3) of word c >> 2
-  // All of a row's 16-byte loads (four chunks at a time) are issued before the first is used: one memory round trip per
-  // row instead of one per chunk -- with 12 rows per CU in flight, the chunk-by-chunk form kept 12 KB per CU on the wire.
-  // Rows that cannot be read in aligned 16-byte pieces (odd strides, cols not a multiple of 16) are first copied into LDS
-  // byte by byte, zero-padded, and the common path below then takes its pieces from there.
-  const bool direct = vec && (a.cols & 15) == 0;
-  if (!direct) {
-    for (int pos = lane * 16; pos < colsp; pos += 1024) {
-      uint32_t w[4] = {0u, 0u, 0u, 0u};
-      for (int q = pos; q < min(pos + 16, a.cols); q++) w[(q - pos) >> 2] |= (uint32_t)rowp[q] << (8 * (q & 3));
-      *(uint4*)(raw + pos) = make_uint4(w[0], w[1], w[2], w[3]);
+  uint32_t* lut = (uint32_t*)smem;
+  lut[threadIdx.x] = a.lut[threadIdx.x];
+  __syncthreads();
+  const int colsp = a.colsp;
+  uint8_t* wbase = smem + 1024 + (size_t)wave * cfar_wave_lds(colsp, a.pad_lo, a.pad_hi, KEYS);
+  uint32_t* P4 = (uint32_t*)wbase + a.pad_lo;                                // P4[i] = sum_{q < 4 i} I_q^2, i in [-pad_lo, colsp / 4 + pad_hi]
+  uint8_t* raw = wbase + (((size_t)(a.pad_lo + colsp / 4 + 1 + a.pad_hi) * 4 + 15) & ~(size_t)15);   // the row itself
+  uint32_t* det32 = (uint32_t*)(raw + colsp + 16);                           // detections, bit per bin (bitmap output)
+  unsigned short* list = (unsigned short*)(raw + colsp + 16 + (KEYS ? 0 : colsp / 8));
+  for (int i = lane; i < a.pad_lo; i += 64) P4[-1 - i] = 0u;
+  const int nch = colsp >> 10;
+  const long long step = (long long)gridDim.x * kRowsPerBlock;
+  long long grow = (long long)blockIdx.x * kRowsPerBlock + wave;
+  // (image, row) of the current and of the next row walk along with grow: no 64-bit division per row
+  const int step_b = (int)(step / a.rows), step_r = (int)(step - (long long)step_b * a.rows);
+  int cb = (int)(grow / a.rows), cr = (int)(grow - (long long)cb * a.rows);
+  auto row_ptr = [&](int b, int r) -> const uint8_t* { return a.polar + (long long)b * a.batch_stride + (long long)r * a.stride; };
+  // rows that cannot be read in aligned 16-byte pieces (odd strides, cols not a multiple of 16) are copied into LDS byte by
+  // byte first, zero-padded, and take their pieces from there (no prefetch)
+  auto is_direct = [&](const uint8_t* p) -> bool { return (((uintptr_t)p) & 15) == 0 && (a.cols & 15) == 0; };
+  auto issue = [&](const uint8_t* p, u32x4 (&dst)[NCH]) {
+#pragma unroll
+    for (int j = 0; j < NCH; j++) {
+      const int pos = j * 1024 + lane * 16;
+      dst[j] = u32x4{0u, 0u, 0u, 0u};
+      if (pos < a.need_cols) dst[j] = __builtin_nontemporal_load((const u32x4*)(p + pos));
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  };
+  // LDS hand-over between the lanes of this wavefront.  The fences name the LDS address space only: a plain wavefront
+  // fence makes the compiler wait for vmcnt(0) too, i.e. for the NEXT row's loads that were just requested.
+  auto wave_sync = [&]() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
     __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-  }
-  // candidate test "byte >= thr_i" for four bytes at once: with tl = thr_i & 127 and y = ((x & 0x7f..) | 0x80..) - tl * 0x0101..,
-  // bit 7 of a byte of y says (x & 127) >= tl; the verdict is y & x for thr_i >= 128 and y | x below.
-  const uint32_t thr_lo4 = (uint32_t)(a.thr_i & 0x7f) * 0x01010101u;
-  const uint32_t thr_hi = (a.thr_i & 0x80) ? 0xffffffffu : 0u;
-  for (int cb = 0; cb < a.cols; cb += 4096) {
-  u32x4 pre[4];
-#pragma unroll
-  for (int j = 0; j < 4; j++) {
-    const int pos = cb + j * 1024 + lane * 16;
-    pre[j] = u32x4{0u, 0u, 0u, 0u};
-    if (direct) { if (pos < a.cols) pre[j] = __builtin_nontemporal_load((const u32x4*)(rowp + pos)); }
-    else if (pos < colsp) pre[j] = *(const u32x4*)(raw + pos);
-  }
-#pragma unroll
-  for (int j = 0; j < 4; j++) {
-    const int c0 = cb + j * 1024;
-    if (c0 >= a.cols) break;
-    const int pos = c0 + lane * 16;
-    const uint32_t w[4] = {pre[j].x, pre[j].y, pre[j].z, pre[j].w};
-    *(uint4*)(raw + pos) = make_uint4(w[0], w[1], w[2], w[3]);
-    uint32_t q4[4];                                                        // sums of squares of the lane's four 4-bin groups
-    uint32_t cmask = 0;
-    // candidate: intensity > static_threshold (an integer test: a.thr_i = the smallest passing value) inside the bins
-    // whose range passes min / max distance (a.bin_lo <= bin < a.bin_hi, found on the host with the exact test).
-    // Four bins per word: v_dot4 squares and sums them in one instruction, the byte compare is the sweep's SWAR test.
-#pragma unroll
-    for (int d = 0; d < 4; d++) {
-      const uint32_t x = w[d];
-      q4[d] = __builtin_amdgcn_udot4(x, x, 0u, false);
-      const uint32_t y = ((x & 0x7f7f7f7fu) | 0x80808080u) - thr_lo4;
-      const uint32_t ge = (y & x) | ((y | x) & ~thr_hi);                   // bit 7 of every byte: byte >= thr_i
-      // gather the four verdict bits (bit 7, 15, 23, 31) into bits 0..3: with y = bits 0, 8, 16, 24, the product
-      // y * 0x01020408 puts bit 8 i at 24 + i (the partial products do not collide), so the top nibble-pair's low 4 bits are the answer
-      const uint32_t nib = ((((ge >> 7) & 0x01010101u) * 0x01020408u) >> 24) & 0xfu;
-      cmask |= nib << (4 * d);
-    }
-    {                                                                      // range window: bins [bin_lo, bin_hi) of this lane's 16
-      const int lo = min(16, max(0, a.bin_lo - pos)), hi = min(16, max(0, a.bin_hi - pos));
-      const uint32_t win = hi > lo ? ((hi >= 16 ? 0xffffu : ((1u << hi) - 1u)) & ~((1u << lo) - 1u)) : 0u;
-      cmask &= win;
-    }
-    {
-      const int c = c0 >> 10;
-      const unsigned long long m = (unsigned long long)cmask << (16 * (c & 3));
-      if (c < 4) cmw0 |= m; else cmw1 |= m;
-    }
-    const uint32_t acc = q4[0] + q4[1] + q4[2] + q4[3];
-    const int incl = wave_incl_scan_i32((int)acc);
-    const uint32_t base = run + (uint32_t)incl - acc;                       // sum before this lane's first bin
-    *(uint4*)(P4 + (pos >> 2)) = make_uint4(base, base + q4[0], base + q4[0] + q4[1], base + q4[0] + q4[1] + q4[2]);
-    run += (uint32_t)__builtin_amdgcn_readlane(incl, 63);
-  }
-  }
-  if (lane == 0) P4[colsp >> 2] = run;                                      // P(colsp)
-  for (int i = lane; i < colsp / 32; i += 64) det32[i] = 0u;
-  auto P = [&](int x) -> uint32_t {                                         // sum_{q < x} I_q^2, 0 <= x <= cols
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
+  };
+  auto P = [&](int x) -> uint32_t {                                         // sum_{q < x} I_q^2, 0 <= x <= colsp
     const int q = x >> 2, rr = x & 3;
-    // the first rr bytes of the word (none for rr = 0; the word of x = colsp lies in det32 and is masked away): no branch
+    // the first rr bytes of the word (none for rr = 0; the word of x = colsp is the 16 bytes of padding): no branch
     const uint32_t wd = *(const uint32_t*)(raw + 4 * q) & ((1u << (8 * rr)) - 1u);
     return __builtin_amdgcn_udot4(wd, wd, P4[q], false);
   };
-  const int nchunks = colsp >> 10;
-  CFAR_T(1);
 #ifdef CFEAR_CFAR_TIMING
-  long long t_scatter = 0, t_rounds = 0;
+  long long tq[6] = {0, 0, 0, 0, 0, 0}; int ctot = 0, nrounds = 0;
+#define CFAR_T0() long long t_ = __builtin_readcyclecounter()
+#define CFAR_T(k) { const long long n_ = __builtin_readcyclecounter(); tq[k] += n_ - t_; t_ = n_; }
+#else
+#define CFAR_T0()
+#define CFAR_T(k)
 #endif
-  for (int c2 = 0; c2 < nchunks; c2 += 2) {
-#ifdef CFEAR_CFAR_TIMING
-    const long long ta = __builtin_readcyclecounter();
-#endif
-    // the piece's candidates -> list (in bin order: chunk, lane, bit)
-    int C = 0;
-    for (int c = c2; c < min(c2 + 2, nchunks); c++) {
-      uint32_t m = (uint32_t)((c < 4 ? cmw0 : cmw1) >> (16 * (c & 3))) & 0xffffu;
-      const int pc = __popc(m);
-      const int incl = wave_incl_scan_i32(pc);
-      int off = C + incl - pc;
-      const int binbase = (c << 10) + lane * 16;
-      while (m) {
-        list[off++] = (unsigned short)(binbase + __ffs((int)m) - 1);
-        m &= m - 1u;
+  u32x4 cur[NCH], nxt[NCH];
+  if (grow < a.total_rows) { const uint8_t* p0 = row_ptr(cb, cr); if (is_direct(p0)) issue(p0, cur); }
+  // the first row's pieces are waited for HERE, so that inside the loop `cur` only ever comes from register copies: the
+  // compiler cannot count conditional loads and would otherwise wait for vmcnt(0) -- the NEXT row's requests -- at the
+  // first use of `cur` in every iteration
+  __builtin_amdgcn_s_waitcnt(0);
+  for (; grow < a.total_rows; grow += step) {
+    CFAR_T0();
+    const uint8_t* rowp = row_ptr(cb, cr);
+    cb += step_b; cr += step_r;
+    if (cr >= a.rows) { cr -= a.rows; cb++; }
+    if (!is_direct(rowp)) {
+      for (int pos = lane * 16; pos < colsp; pos += 1024) {
+        uint32_t w[4] = {0u, 0u, 0u, 0u};
+        for (int q = pos; q < min(pos + 16, a.cols); q++) w[(q - pos) >> 2] |= (uint32_t)rowp[q] << (8 * (q & 3));
+        *(uint4*)(raw + pos) = make_uint4(w[0], w[1], w[2], w[3]);
       }
-      C += __builtin_amdgcn_readlane(incl, 63);
+      wave_sync();
+#pragma unroll
+      for (int j = 0; j < NCH; j++) {
+        const int pos = j * 1024 + lane * 16;
+        cur[j] = u32x4{0u, 0u, 0u, 0u};
+        if (pos < colsp) cur[j] = *(const u32x4*)(raw + pos);
+      }
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#ifdef CFEAR_CFAR_TIMING
-    const long long tb = __builtin_readcyclecounter(); t_scatter += tb - ta; ctot += C;
-#endif
-    for (int k0 = 0; k0 < C; k0 += 64) {
-      const int k = k0 + lane;
-      if (k < C) {
-        const int bin = list[k];
-        const uint32_t v = raw[bin];
-        const uint32_t sq = v * v;
-        const int t0 = max(0, bin - a.guard - a.window), t1 = bin - a.guard;  // cfar.cpp:48-49
-        const int f0 = bin + a.guard, f1 = min(a.cols, bin + a.guard + a.window);   // :52-53
-        // getMean: sequential sum of exact integer-valued doubles / count; an empty window is 0/0
-        if (t1 > t0 && f1 > f0) {
-          const uint32_t st = P(t1) - P(t0), sf = P(f1) - P(f0);
-          bool det, decided = false;
-          if (t1 - t0 == a.window && f1 - f0 == a.window) {
-            // Both windows full (every bin but the row's ends): scaling (st / w + sf / w) / 2 = (st + sf) scaling / (2 w) up to
-            // seven roundings of 2^-53 between the two forms; a candidate whose square is not within 1e-12 of that
-            // threshold compares the same way in both, and the two fp64 divisions are skipped.
-            const double thr = (double)(st + sf) * a.thr_scale;
-            const double d = (double)sq - thr;
-            if (fabs(d) > fabs(thr) * 1e-12) { det = d > 0.0; decided = true; }
+    const bool have_next = grow + step < a.total_rows;
+    const uint8_t* nextp = have_next ? row_ptr(cb, cr) : rowp;
+    const bool next_direct = have_next && is_direct(nextp);
+    if (next_direct) issue(nextp, nxt);
+    // ---- A: bytes + prefix sums of squares -> LDS ---------------------------------------------------------------
+    uint32_t run = 0;
+#pragma unroll
+    for (int j = 0; j < NCH; j++) {
+      if (j >= nch) break;
+      const int pos = j * 1024 + lane * 16;
+      *(uint4*)(raw + pos) = make_uint4(cur[j].x, cur[j].y, cur[j].z, cur[j].w);
+      const uint32_t q0 = __builtin_amdgcn_udot4(cur[j].x, cur[j].x, 0u, false), q1 = __builtin_amdgcn_udot4(cur[j].y, cur[j].y, 0u, false);
+      const uint32_t q2 = __builtin_amdgcn_udot4(cur[j].z, cur[j].z, 0u, false), q3 = __builtin_amdgcn_udot4(cur[j].w, cur[j].w, 0u, false);
+      const uint32_t acc = q0 + q1 + q2 + q3;
+      const int incl = wave_incl_scan_i32((int)acc);
+      const uint32_t base = run + (uint32_t)incl - acc;                     // sum before this lane's first bin
+      *(uint4*)(P4 + (pos >> 2)) = make_uint4(base, base + q0, base + q0 + q1, base + q0 + q1 + q2);
+      run += (uint32_t)__builtin_amdgcn_readlane(incl, 63);
+    }
+    if (lane == 0) P4[colsp >> 2] = run;                                    // P(colsp)
+    for (int i = lane; i < a.pad_hi; i += 64) P4[(colsp >> 2) + 1 + i] = run;
+    if (!KEYS) for (int i = lane; i < colsp / 32; i += 64) det32[i] = 0u;
+    wave_sync();
+    CFAR_T(0);
+    // ---- B + C -------------------------------------------------------------------------------------------------
+    int C = 0, ndet = 0;
+    const long long key_base = grow * (long long)a.kcap;
+    auto round = [&](int k0, int cnt) {
+      const bool act = lane < cnt;
+      int bin = 0; uint32_t v = 0;
+      if (act) { bin = list[k0 + lane]; v = raw[bin]; }
+      const int t1 = bin - a.guard, t0 = t1 - a.window, f0 = bin + a.guard, f1 = f0 + a.window;   // cfar.cpp:48-53
+      const bool full = t0 >= 0 && f1 <= a.cols;
+      // both windows full (every bin but the row's ends): the integer decision; lanes outside compute on clamped indices
+      const uint32_t S = (P(t1 < 0 ? 0 : t1) - P(t0 < 0 ? 0 : t0)) + (P(min(f1, colsp)) - P(min(f0, colsp)));
+      const uint32_t X = 2u * S + 1u, L = lut[v];
+      bool det = act && full && a.lut_ok && X < L;
+      const bool slow = act && (!full || !a.lut_ok || X == L);
+      if (__ballot(slow)) {
+        if (slow) {                                                         // cfar.cpp:45-60, literally
+          const int lt0 = max(0, t0), lf1 = min(a.cols, f1);
+          // getMean: sequential sum of exact integer-valued doubles / count; an empty window is 0 / 0 = NaN: no detection
+          if (t1 > lt0 && lf1 > f0) {
+            const uint32_t st = P(t1) - P(lt0), sf = P(lf1) - P(f0);
+            const double trailing_mean = (double)st / (double)(t1 - lt0);
+            const double forwarding_mean = (double)sf / (double)(lf1 - f0);
+            const double mean = (trailing_mean + forwarding_mean) / 2.0;      // :56
+            const double threshold = a.scaling * mean;                        // :58
+            det = (double)(v * v) > threshold;                                // :59-60
           }
-          if (!decided) {
-            const double trailing_mean = (double)st / (double)(t1 - t0);
-            const double forwarding_mean = (double)sf / (double)(f1 - f0);
-            const double mean = (trailing_mean + forwarding_mean) / 2.0;        // :56
-            const double threshold = a.scaling * mean;                          // :58
-            det = (double)sq > threshold;                                       // :59-60
-          }
-          if (det) atomicOr(&det32[bin >> 5], 1u << (bin & 31));
         }
       }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      if (KEYS) {
+        const unsigned long long dm = __ballot(det);
+        const int at = ndet + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(dm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)dm, 0u));
+        if (det && at < a.kcap) a.row_keys[key_base + at] = (v << 24) | (uint32_t)bin;
+        ndet += __popcll(dm);
+      } else {
+        if (det) atomicOr(&det32[bin >> 5], 1u << (bin & 31));
+      }
 #ifdef CFEAR_CFAR_TIMING
-    t_rounds += __builtin_readcyclecounter() - tb;
+      nrounds++;
 #endif
-  }
-  CFAR_T(2);
-  int total = 0;
-  for (int w0 = 0; w0 < a.words; w0 += 64) {
-    const int wd = w0 + lane;
-    if (wd < a.words) {
-      const unsigned long long bits = (unsigned long long)det32[2 * wd] | ((unsigned long long)det32[2 * wd + 1] << 32);
-      a.det_bits[((long long)b * a.rows + r) * a.words + wd] = bits;
-      total += __popcll(bits);
+    };
+    // candidate test "byte >= t" for four bytes at once: with tl = t & 127 and y = ((x & 0x7f..) | 0x80..) - tl * 0x0101..,
+    // bit 7 of a byte of y says (x & 127) >= tl; the verdict is y & x for t >= 128 and y | x below.
+    const int cj_lo = a.bin_lo >> 10, cj_hi = (a.bin_hi + 1023) >> 10;      // chunks that hold bins of the range window
+#pragma unroll
+    for (int j = 0; j < NCH; j++) {
+      if (j >= cj_hi) break;
+      if (j < cj_lo) continue;
+      const int pos = j * 1024 + lane * 16;
+      const uint32_t w[4] = {cur[j].x, cur[j].y, cur[j].z, cur[j].w};
+      uint32_t cmask = 0;
+#pragma unroll
+      for (int h = 0; h < 2; h++) {
+        int t = a.thr_i;
+        if (a.pre_on) {
+          const uint32_t* pq = P4 + (pos >> 2) + 2 * h;                     // quad 2 H of this 8-bin block
+          const uint32_t slb = (pq[a.pa1] - pq[a.pa0]) + (pq[a.pb1] - pq[a.pb0]);
+          const float f = __builtin_amdgcn_sqrtf((float)slb * a.kappa_lb);  // <= sqrt(kappa S_lb): kappa_lb carries the slack
+          t = max(t, (int)f);
+        }
+        const uint32_t tl = (uint32_t)(t & 0x7f);
+        const uint32_t lo4 = __builtin_amdgcn_perm(tl, tl, 0u);               // the byte in all four places
+        const uint32_t nhi = (t & 0x80) ? 0u : 0xffffffffu;
+        uint32_t m8 = 0;
+#pragma unroll
+        for (int d = 0; d < 2; d++) {
+          const uint32_t x = w[2 * h + d];
+          const uint32_t y = ((x & 0x7f7f7f7fu) | 0x80808080u) - lo4;
+          const uint32_t ge = (y & x) | ((y | x) & nhi);                    // bit 7 of every byte: byte >= t
+          // gather the four verdict bits (bit 7, 15, 23, 31) into bits 0..3: with z = bits 0, 8, 16, 24, the product
+          // z * 0x01020408 puts bit 8 i at 24 + i (the partial products do not collide)
+          const uint32_t nib = ((((ge >> 7) & 0x01010101u) * 0x01020408u) >> 24) & 0xfu;
+          m8 |= nib << (4 * d);
+        }
+        if (t > 255) m8 = 0u;
+        cmask |= m8 << (8 * h);
+      }
+      {                                                                     // range window: bins [bin_lo, bin_hi) of this lane's 16
+        const int lo = min(16, max(0, a.bin_lo - pos)), hi = min(16, max(0, a.bin_hi - pos));
+        const uint32_t win = hi > lo ? ((hi >= 16 ? 0xffffu : ((1u << hi) - 1u)) & ~((1u << lo) - 1u)) : 0u;
+        cmask &= win;
+      }
+      CFAR_T(1);
+      // the chunk's candidates -> list, behind the carried remainder, in bin order (lane, bit)
+      {
+        uint32_t m = cmask;
+        const int pc = __popc(m);
+        const int incl = wave_incl_scan_i32(pc);
+        int off = C + incl - pc;
+        while (m) {
+          list[off++] = (unsigned short)(pos + __ffs((int)m) - 1);
+          m &= m - 1u;
+        }
+        C += __builtin_amdgcn_readlane(incl, 63);
+      }
+      wave_sync();
+      CFAR_T(2);
+#ifdef CFEAR_CFAR_TIMING
+      ctot += C;
+#endif
+      int k0 = 0;
+      for (; k0 + 64 <= C; k0 += 64) round(k0, 64);
+      if (k0 > 0) {                                                         // carry the remainder (< 64) to the front
+        const int rem = C - k0;
+        wave_sync();
+        const unsigned short tmp = lane < rem ? list[k0 + lane] : (unsigned short)0;
+        wave_sync();
+        if (lane < rem) list[lane] = tmp;
+        C = rem;
+        wave_sync();
+      }
+#ifdef CFEAR_CFAR_TIMING
+      ctot -= C;
+#endif
+      CFAR_T(3);
+    }
+    if (C > 0) round(0, C);
+    CFAR_T(3);
+    // ---- D ------------------------------------------------------------------------------------------------------
+    if (KEYS) {
+      if (lane == 0) { a.row_cnt[2 * grow] = ndet; a.row_cnt[2 * grow + 1] = 0; }
+    } else {
+      wave_sync();
+      int total = 0;
+      for (int w0 = 0; w0 < a.words; w0 += 64) {
+        const int wd = w0 + lane;
+        if (wd < a.words) {
+          unsigned long long bits = 0ull;
+          if (2 * wd < colsp / 32) bits = (unsigned long long)det32[2 * wd];
+          if (2 * wd + 1 < colsp / 32) bits |= (unsigned long long)det32[2 * wd + 1] << 32;
+          a.det_bits[grow * a.words + wd] = bits;
+          total += __popcll(bits);
+        }
+      }
+      total = wave_sum_i32(total);
+      if (lane == 0) a.det_count[grow] = total;
+    }
+    wave_sync();                                                            // the next row's writes stay behind this row's reads
+    CFAR_T(4);
+#ifdef CFEAR_CFAR_TIMING
+    if (lane == 0 && (grow % 20011) == 0)
+      printf("cfar row %lld: prefix %lld | thresholds+swar %lld | list %lld | rounds %lld (%d rounds, %d candidates) | write %lld\n", grow,
+             tq[0], tq[1], tq[2], tq[3], nrounds, ctot, tq[4]);
+    for (int k = 0; k < 6; k++) tq[k] = 0;
+    ctot = 0; nrounds = 0;
+#endif
+    if (next_direct) {
+#pragma unroll
+      for (int j = 0; j < NCH; j++) cur[j] = nxt[j];
     }
   }
-  total = wave_sum_i32(total);
-  if (lane == 0) a.det_count[(long long)b * a.rows + r] = total;
-#ifdef CFEAR_CFAR_TIMING
-  CFAR_T(3);
-  if (lane == 0 && (grow % 20011) == 0)
-    printf("cfar row %lld: load+prefix %lld | scatter %lld rounds %lld (C %d) | write %lld | total %lld\n", grow, tq[1] - tq[0],
-           t_scatter, t_rounds, ctot, tq[3] - tq[2], tq[3] - tq[0]);
-#endif
+}
+
+// lut[I] for cacfar_rows_kernel (step C of its comment): 0 when I does not pass the static threshold.
+static bool cfar_build_lut(const CfarArgs& a, uint32_t* lut) {
+  for (int i = 0; i < 256; i++) lut[i] = 0u;
+  if (!(a.scaling > 0.0) || !std::isfinite(a.scaling) || a.window > 8192) return false;
+  const double c = 2.0 * (double)a.window / a.scaling;
+  for (int i = 0; i < 256; i++) {
+    if (!((double)i > a.static_threshold)) continue;                        // cfar.cpp:45
+    const double B = (double)(i * i) * c;
+    if (!(B < 1.0e9)) return false;                                         // tiny scalings: the table would not fit 31 bits
+    const double T = std::ceil(B - 1e-3), Tn = std::ceil(B + 1e-3);
+    const uint32_t t = T < 0.0 ? 0u : (uint32_t)T;
+    lut[i] = (t << 1) | (Tn > T ? 1u : 0u);
+  }
+  return true;
 }
 
 struct CfarCloudArgs {
@@ -1361,52 +1479,90 @@ extern "C" int cfear_filter_kstrongest_legacy(cfear_ctx* ctx, const uint8_t* pol
   return CFEAR_OK;
 }
 
-// Device-side CA-CFAR entry (also used by the odometry pipeline).
+// Device-side CA-CFAR entry (also used by the odometry pipeline).  With `fused` the rows kernel leaves per-row key lists for
+// surface_prep_kernel (cfear_cacfar_fused, common.hpp) and no cloud is built here.
 int cfear_cacfar_device(cfear_ctx* ctx, const uint8_t* d_polar, const cfear_polar_desc* desc,
                         const cfear_cacfar_params* par, float* d_xyzi, int32_t* d_n_points,
-                        int32_t cap_points, uint8_t* d_det_mask) {
+                        int32_t cap_points, uint8_t* d_det_mask, const cfear_cacfar_fused* fused) {
   const int rows = desc->rows, cols = desc->cols, batch = desc->batch;
   const int words = (cols + 63) / 64;
-  size_t bits_bytes = (size_t)batch * rows * words * 8, cnt_bytes = (size_t)batch * rows * 4;
-  char* ws = (char*)cfear_workspace(ctx, 3, bits_bytes + cnt_bytes + 256);
-  if (!ws) return cfear_set_error(ctx, CFEAR_ERR_HIP, "workspace allocation failed");
+  const bool keys = fused && fused->row_keys;
   CfarArgs a;
+  memset(&a, 0, sizeof(a));
   a.polar = d_polar; a.rows = rows; a.cols = cols; a.stride = desc->stride; a.batch = batch;
   a.batch_stride = batch > 1 ? desc->batch_stride : (int64_t)rows * desc->stride;
+  a.total_rows = (long long)batch * rows;
   a.window = par->window_size; a.guard = par->nb_guard_cells;
   const double false_alarm_rate_ = (double)par->false_alarm_rate;
   const double N = par->window_size * 2;                                     // cfar.cpp:32
   a.scaling = N * (std::pow(false_alarm_rate_, -1. / N) - 1.);               // cfar.cpp:12-16
-  a.thr_scale = a.scaling / (2.0 * (double)par->window_size);
   a.range_res = (double)par->range_res;
   a.static_threshold = (double)par->z_min;
   a.min_distance = (double)par->min_distance;
   a.max_distance = par->max_distance;
-  a.det_bits = (unsigned long long*)ws;
-  a.det_count = (int32_t*)(ws + (bits_bytes + 255) / 256 * 256);
   a.words = words;
-  const long long nrows = (long long)batch * rows;
-  const int colsp = (cols + 1023) & ~1023;
+  if (keys) {
+    a.row_keys = fused->row_keys; a.row_cnt = fused->row_cnt; a.kcap = fused->kcap;
+  } else {
+    size_t bits_bytes = (size_t)batch * rows * words * 8, cnt_bytes = (size_t)batch * rows * 4;
+    char* ws = (char*)cfear_workspace(ctx, 3, bits_bytes + cnt_bytes + 256);
+    if (!ws) return cfear_set_error(ctx, CFEAR_ERR_HIP, "workspace allocation failed");
+    a.det_bits = (unsigned long long*)ws;
+    a.det_count = (int32_t*)(ws + (bits_bytes + 255) / 256 * 256);
+  }
   {
-    const size_t rows_lds = (size_t)kRowsPerBlock * cfar_wave_lds(colsp);
     // the candidate pre-test in integers.  intensity > static_threshold for integer intensities: the smallest passing value;
     // range > min_distance && range < max_distance (cfar.cpp:43-45, range = range_res * bin in double): the bin interval,
     // found with the reference's own expression
-    {
-      const double st = a.static_threshold;
-      a.thr_i = st < 0.0 ? 0 : (st >= 255.0 ? 256 : (int)std::floor(st) + 1);
-      int lo = 0, hi = cols;
-      while (lo < cols && !(a.range_res * (double)lo > a.min_distance)) lo++;
-      while (hi > 0 && !(a.range_res * (double)(hi - 1) < a.max_distance)) hi--;
-      a.bin_lo = lo; a.bin_hi = hi;
-      if (a.thr_i >= 256) a.bin_hi = a.bin_lo = 0;                            // nothing passes the static threshold
-    }
+    const double st = a.static_threshold;
+    a.thr_i = st < 0.0 ? 0 : (st >= 255.0 ? 256 : (int)std::floor(st) + 1);
+    int lo = 0, hi = cols;
+    while (lo < cols && !(a.range_res * (double)lo > a.min_distance)) lo++;
+    while (hi > 0 && !(a.range_res * (double)(hi - 1) < a.max_distance)) hi--;
+    a.bin_lo = lo; a.bin_hi = hi;
+    if (a.thr_i >= 256 || hi <= lo) a.bin_hi = a.bin_lo = 0;                  // nothing passes the static threshold / the range window
+    // bins the arithmetic of the bins in [bin_lo, bin_hi) can reach
+    const long long reach = a.bin_hi > 0 ? std::min<long long>(cols, (long long)a.bin_hi - 1 + a.guard + a.window) : 0;
+    a.need_cols = (int)((reach + 15) / 16 * 16);
+    a.colsp = std::max(1024, (a.need_cols + 1023) & ~1023);
+    a.lut_ok = cfar_build_lut(a, a.lut) ? 1 : 0;
+    // lower-bound pre-filter: the aligned quads inside the windows of every bin of an 8-bin block
+    auto floor_div = [](int x, int y) { return x >= 0 ? x / y : -((-x + y - 1) / y); };
+    auto ceil_div = [&](int x, int y) { return -floor_div(-x, y); };
+    a.pa0 = ceil_div(7 - a.guard - a.window, 4); a.pa1 = floor_div(-a.guard, 4);
+    a.pb0 = ceil_div(7 + a.guard, 4); a.pb1 = floor_div(a.guard + a.window, 4);
+    if (a.pa1 < a.pa0) a.pa1 = a.pa0;
+    if (a.pb1 < a.pb0) a.pb1 = a.pb0;
+    a.pre_on = a.lut_ok && a.guard + a.window <= 1024 && (a.pa1 > a.pa0 || a.pb1 > a.pb0);
+    if (!a.pre_on) a.pa0 = a.pa1 = a.pb0 = a.pb1 = 0;
+    a.pad_lo = a.pre_on ? (std::max(0, -a.pa0) + 3) / 4 * 4 : 0;
+    a.pad_hi = a.pre_on ? std::max(0, a.pb1) + 2 : 0;
+    a.kappa_lb = (float)(a.scaling / (2.0 * (double)a.window) * (1.0 - 3e-5));
+  }
+  {
+    const size_t rows_lds = 1024 + (size_t)kRowsPerBlock * cfar_wave_lds(a.colsp, a.pad_lo, a.pad_hi, keys);
+    const bool wide = a.colsp > 4096;
+    const void* fn = wide ? (keys ? (const void*)cacfar_rows_kernel<8, true> : (const void*)cacfar_rows_kernel<8, false>)
+                          : (keys ? (const void*)cacfar_rows_kernel<4, true> : (const void*)cacfar_rows_kernel<4, false>);
     if (rows_lds > 64 * 1024)
-      CFEAR_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)cacfar_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rows_lds));
+      CFEAR_HIP_CHECK(ctx, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rows_lds));
+    // persistent wavefronts: as many workgroups as the chip holds at this LDS footprint (160 KiB per CU)
+    int n_cu = 256;
+    (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, ctx->device);
+    const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(8, (size_t)(160 * 1024) / rows_lds));
+    const long long want = (a.total_rows + kRowsPerBlock - 1) / kRowsPerBlock;
+    const unsigned grid = (unsigned)std::max<long long>(1, std::min<long long>(want, (long long)n_cu * per_cu));
     ProfScope ps(ctx, "cacfar_rows");
-    hipLaunchKernelGGL(cacfar_rows_kernel, dim3((unsigned)((nrows + kRowsPerBlock - 1) / kRowsPerBlock)), dim3(256), rows_lds, ctx->stream, a);
+    if (wide) {
+      if (keys) hipLaunchKernelGGL((cacfar_rows_kernel<8, true>), dim3(grid), dim3(256), rows_lds, ctx->stream, a);
+      else hipLaunchKernelGGL((cacfar_rows_kernel<8, false>), dim3(grid), dim3(256), rows_lds, ctx->stream, a);
+    } else {
+      if (keys) hipLaunchKernelGGL((cacfar_rows_kernel<4, true>), dim3(grid), dim3(256), rows_lds, ctx->stream, a);
+      else hipLaunchKernelGGL((cacfar_rows_kernel<4, false>), dim3(grid), dim3(256), rows_lds, ctx->stream, a);
+    }
   }
   CFEAR_HIP_CHECK(ctx, hipGetLastError());
+  if (keys) return CFEAR_OK;
   double *d_cos = nullptr, *d_sin = nullptr;
   int rc = upload_trig(ctx, rows, &d_cos, &d_sin);
   if (rc != CFEAR_OK) return rc;

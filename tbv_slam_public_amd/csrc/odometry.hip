@@ -111,6 +111,9 @@ struct cfear_odometry {
   // fused filter output (k-strongest without keep_nodes, k <= 64): per-row points + counts written by the polar sweep
   // itself; the surface-point kernel compacts them, so neither sel_* arrays nor a cloud kernel exist in this mode
   bool fused = false;
+  // the same hand-over for CA-CFAR (no keep_nodes): cacfar_rows_kernel leaves per-row keys with a row capacity row_k
+  bool fused_cfar = false;
+  int row_k = 0;                                 // keys per row in d_rowpts2: k (k-strongest) or the CA-CFAR row capacity
   uint32_t* d_rowpts2[2] = {nullptr, nullptr};   // [B][rows][k] packed keys (intensity << 24 | range bin)
   int32_t* d_rowcnt2[2] = {nullptr, nullptr};   // [B][rows][2]
   int64_t* d_offsets2[2] = {nullptr, nullptr};  // [B] image offsets of the sweep in each filter buffer (process_offsets)
@@ -247,6 +250,17 @@ extern "C" int cfear_odometry_create(cfear_ctx* ctx, int32_t n_streams, const cf
   bool ok = true;
   od->fused = par->filter_type == CFEAR_FILTER_KSTRONG && !par->keep_nodes && k <= 64 && rows <= 4096 &&
               rows * k <= cfear_surface_max_points();
+  od->row_k = k;
+  // CA-CFAR puts no bound on a row's detections either: 1024 keys per row (a row beyond that marks its scan
+  // CFEAR_ERR_CAPACITY, like a sweep beyond cap_points)
+  od->fused_cfar = par->filter_type == CFEAR_FILTER_CACFAR && !par->keep_nodes && rows <= 4096;
+  if (od->fused_cfar) {
+    od->row_k = std::min((od->desc.cols + 3) / 4 * 4, 1024);
+    for (int i = 0; i < 2; i++) {
+      ok = ok && dalloc(&od->d_rowpts2[i], (size_t)B * rows * od->row_k * 4);
+      ok = ok && dalloc(&od->d_rowcnt2[i], (size_t)B * rows * 8);
+    }
+  }
   if (od->fused) {
     for (int i = 0; i < 2; i++) {
       ok = ok && dalloc(&od->d_rowpts2[i], nsel * 4);
@@ -363,6 +377,11 @@ static int run_filter(cfear_odometry* od, const uint8_t* polar, int buf, const i
     cfear_cacfar_params cp = par.cacfar;
     if (par.keep_nodes)    // CA-CFAR produces no peaks cloud (radar_driver.cpp:52-56)
       CFEAR_HIP_CHECK(ctx, hipMemsetAsync(od->d_npk2[buf], 0, (size_t)B * 4, ctx->stream));
+    if (od->fused_cfar) {
+      cfear_cacfar_fused fz;
+      fz.row_keys = od->d_rowpts2[buf]; fz.row_cnt = od->d_rowcnt2[buf]; fz.kcap = od->row_k;
+      return cfear_cacfar_device(ctx, d_polar, &dd, &cp, nullptr, nullptr, od->cap_points, nullptr, &fz);
+    }
     return cfear_cacfar_device(ctx, d_polar, &dd, &cp, od->d_xyzi2[buf], od->d_npts2[buf], od->cap_points, nullptr);
   }
   const size_t nsel = (size_t)B * rows * k;
@@ -521,7 +540,7 @@ static int process_frame(cfear_odometry* od, const uint8_t* polar, const uint8_t
   od->d_npts = od->d_npts2[od->cur_buf];
   od->d_pk = od->d_pk2[od->cur_buf];
   od->d_npk = od->d_npk2[od->cur_buf];
-  const bool rows_mode = od->fused && !clouds;     // the filter left per-row points: the surface kernel compacts them
+  const bool rows_mode = (od->fused || od->fused_cfar) && !clouds;     // the filter left per-row points: the surface kernel compacts them
   // ---- C + N: compensate with the previous motion, surface points (odometrykeyframefuser.cpp:146-161)
   const size_t sjb = cfear_surface_job_bytes();
   for (int b = 0; b < B; b++)
@@ -536,9 +555,9 @@ static int process_frame(cfear_odometry* od, const uint8_t* polar, const uint8_t
     if (par.keep_nodes) { od->h_mot[3 * b] = mot[0]; od->h_mot[3 * b + 1] = mot[1]; od->h_mot[3 * b + 2] = mot[2]; }
     if (rows_mode)
       cfear_surface_fill_job_rows(od->h_surf_jobs + (size_t)b * sjb, od->d_xyzi + (size_t)b * od->cap_points * 4, od->d_npts_out + b,
-                                  od->d_rowpts2[od->cur_buf] + (size_t)b * od->desc.rows * par.kstrong.k_strongest,
+                                  od->d_rowpts2[od->cur_buf] + (size_t)b * od->desc.rows * od->row_k,
                                   od->d_rowcnt2[od->cur_buf] + (size_t)b * od->desc.rows * 2, od->desc.rows,
-                                  par.kstrong.k_strongest, par.compensate, mot,
+                                  od->row_k, par.compensate, mot,
                                   od->views[(size_t)b * od->slabs_per_stream + st.cur_slab]);
     else
       cfear_surface_fill_job(od->h_surf_jobs + (size_t)b * sjb, od->d_xyzi + (size_t)b * od->cap_points * 4,
@@ -571,8 +590,13 @@ static int process_frame(cfear_odometry* od, const uint8_t* polar, const uint8_t
     double *d_cos = nullptr, *d_sin = nullptr;
     rc = cfear_trig_tables(ctx, od->desc.rows, &d_cos, &d_sin);
     if (rc != CFEAR_OK) return fail(rc);
-    sp.cos_t = d_cos; sp.sin_t = d_sin; sp.range_res = (double)par.kstrong.range_res;
-    sp.rows = od->desc.rows; sp.k = par.kstrong.k_strongest;
+    sp.cos_t = d_cos; sp.sin_t = d_sin;
+    sp.rows = od->desc.rows; sp.k = od->row_k;
+    if (od->fused_cfar) {                 // cfar.cpp:43: range = range_resolution_ * double(range_bin)
+      sp.range_res = (double)par.cacfar.range_res; sp.range_off = 0.0;
+    } else {                              // radar_filters.cpp:324: range_res / 2 + range_res * bin
+      sp.range_res = (double)par.kstrong.range_res; sp.range_off = sp.range_res / 2.0;
+    }
   }
   rc = cfear_surface_launch(ctx, od->d_surf_jobs, B, &fp, od->d_surf_scratch, od->d_status, od->d_ncells, od->cell_cap, od->cap_points, rows_mode ? &sp : nullptr);
   if (rc != CFEAR_OK) return fail(rc);

@@ -362,6 +362,10 @@ struct cfear_sc_manager {
   std::vector<double> poses;                         // odom_poses_ (x, y, theta)
   std::vector<double> odom_similarity;
   int num_exclude_recent = 0;
+  // VanillaKDNNSearch's tree bookkeeping (RadarScancontext.cpp:227-238; Scancontext.h:116-117): rebuilt on every 50th CALL
+  // from the keys older than the recent-node exclusion at that moment
+  int tree_making_period_counter = 0;
+  int tree_n = 0;                                    // polarcontext_invkeys_to_search_ = ringkeys[0 .. tree_n)
 };
 
 extern "C" void cfear_sc_manager_params_default(cfear_sc_manager_params* p) {
@@ -493,13 +497,31 @@ extern "C" int cfear_sc_manager_detect(cfear_sc_manager* m, cfear_sc_candidate* 
         }
         cands.emplace_back(l2, idx);
       }
-    } else {                                                                  // ring-key KNN (:225-248), exact
-      const int nn = m->n - m->num_exclude_recent;
-      for (int idx = 0; idx < nn; idx++) {
+    } else {                                                                  // VanillaKDNNSearch (:225-248)
+      // The reference asks a nanoflann kd-tree (exact search, eps = 0) that it rebuilds on every TREE_MAKING_PERIOD_-th
+      // call only, and copies the whole zero-initialised index vector: a tree with fewer points than requested proposes
+      // node 0 for the missing places.  A linear scan with the tree's metric arithmetic (L2_Adaptor::evalMetric: four
+      // squared differences are added among themselves, then to the running sum) finds the same neighbours; equal
+      // distances come back in index order here, in tree-visiting order there (tests/test_ref_nanoflann.py).
+      if (m->tree_making_period_counter % 50 == 0) m->tree_n = std::max(m->n - m->num_exclude_recent, 0);
+      m->tree_making_period_counter++;
+      for (int idx = 0; idx < m->tree_n; idx++) {
+        const float* kk = m->ringkeys[idx].data();
         float d = 0.f;
-        for (int r = 0; r < R; r++) { const float e = m->ringkeys[idx][r] - key[r]; d += e * e; }
+        int r = 0;
+        for (; r + 3 < R; r += 4) {
+          const float e0 = key[r] - kk[r], e1 = key[r + 1] - kk[r + 1], e2 = key[r + 2] - kk[r + 2], e3 = key[r + 3] - kk[r + 3];
+          d += e0 * e0 + e1 * e1 + e2 * e2 + e3 * e3;
+        }
+        for (; r < R; r++) { const float e = key[r] - kk[r]; d += e * e; }
         cands.emplace_back(d, idx);
       }
+      std::stable_sort(cands.begin(), cands.end());
+      for (int c = 0; c < m->par.num_candidates_from_tree; c++) {
+        pairs.push_back(k);
+        pairs.push_back(c < (int)cands.size() ? cands[c].second : 0);
+      }
+      continue;
     }
     std::stable_sort(cands.begin(), cands.end());
     for (int c = 0; c < (int)cands.size() && c < m->par.num_candidates_from_tree; c++) {

@@ -69,7 +69,7 @@ struct SurfCommon {
   int32_t* ncells_out;                        // [n_jobs] dense copy of the cell counts (nullable)
   const double* cos_t;                        // rows mode: [rows] azimuth tables (host-computed doubles) and range_res
   const double* sin_t;
-  double range_res;
+  double range_res, range_off;                // rho = range_off + range_res * bin
   int32_t* fallback;                          // [1 + n_jobs]: count, then the jobs the fast pipeline handed to the single-kernel path
   int32_t n_jobs;
   int32_t fast_ok;                            // reach == 1: the fast pipeline applies
@@ -544,10 +544,11 @@ __device__ void surface_points_job(const SurfJob* __restrict__ jobs, const SurfC
   int32_t* status = cm.status + job_id;
   int32_t* rowoff = (int32_t*)(smem + kLdsRowbegOff);                 // rows mode: [rows + 1] exclusive prefix of the row counts
   if (job.row_pts) {
-    int run = 0;
+    int run = 0, over = 0;
     for (int r0 = 0; r0 < job.rows; r0 += kSurfThreads) {
       const int r = r0 + tid;
       const int v = r < job.rows ? job.row_cnt[2 * r] : 0;
+      over |= v > job.k;
       const int incl = wave_incl_scan_i32(v);
       if (lane == 63) red_i[wave] = incl;
       __syncthreads();
@@ -556,6 +557,10 @@ __device__ void surface_points_job(const SurfJob* __restrict__ jobs, const SurfC
       if (r < job.rows) rowoff[r] = off;
       for (int wv = 0; wv < 16; wv++) run += red_i[wv];
       __syncthreads();
+    }
+    if (__syncthreads_or(over)) {
+      if (tid == 0) { *job.out.n_cells = 0; *status = CFEAR_ERR_CAPACITY; if (cm.ncells_out) cm.ncells_out[job_id] = 0; }
+      return;
     }
     n = run;
     if (tid == 0) { rowoff[job.rows] = n; if (job.n_out) *job.n_out = n; }
@@ -588,8 +593,7 @@ __device__ void surface_points_job(const SurfJob* __restrict__ jobs, const SurfC
           int lo = 0, hi = job.rows;
           while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (rowoff[mid] <= i) lo = mid; else hi = mid; }
           const uint32_t key = job.row_pts[(size_t)lo * job.k + (i - rowoff[lo])];
-          const double range_res_half = cm.range_res / 2.0;
-          const double rho = range_res_half + cm.range_res * (double)(int)(key & 0xFFFFFFu);   // radar_filters.cpp:324-330
+          const double rho = cm.range_off + cm.range_res * (double)(int)(key & 0xFFFFFFu);     // radar_filters.cpp:324-330 / cfar.cpp:43
           p[u] = make_float4((float)(rho * cm.cos_t[lo]), (float)(rho * cm.sin_t[lo]), 0.f, (float)(key >> 24));
         } else {
           p[u] = pts[i];
@@ -908,10 +912,11 @@ __global__ __launch_bounds__(kFastThreads) void surface_prep_kernel(const SurfJo
   int n = job.n_ptr ? *job.n_ptr : job.n_host;
   int32_t* rowoff = (int32_t*)smem;
   if (ROWS) {
-    int run = 0;
+    int run = 0, over = 0;
     for (int r0 = 0; r0 < job.rows; r0 += NT) {
       const int r = r0 + tid;
       const int v = r < job.rows ? job.row_cnt[2 * r] : 0;
+      over |= v > job.k;                                   // a CA-CFAR row beyond its key capacity (keys were dropped)
       const int incl = wave_incl_scan_i32(v);
       if (lane == 63) red_i[wave] = incl;
       __syncthreads();
@@ -921,6 +926,7 @@ __global__ __launch_bounds__(kFastThreads) void surface_prep_kernel(const SurfJo
       for (int wv = 0; wv < NW; wv++) run += red_i[wv];
       __syncthreads();
     }
+    if (__syncthreads_or(over)) { done(CFEAR_ERR_CAPACITY); return; }
     n = run;
     if (tid == 0) { rowoff[job.rows] = n; if (job.n_out) *job.n_out = n; }
     __syncthreads();
@@ -945,7 +951,7 @@ __global__ __launch_bounds__(kFastThreads) void surface_prep_kernel(const SurfJo
     __syncthreads();
   }
   float mnx = FLT_MAX, mny = FLT_MAX, mxx = -FLT_MAX, mxy = -FLT_MAX;
-  const double range_res_half = cm.range_res / 2.0;
+  const double range_res_half = cm.range_off;
   const double th_step = (2. * M_PI) / (double)max(job.rows, 1);
   constexpr int U = 4;
   for (int i0 = tid; i0 < n; i0 += U * NT) {
@@ -1575,6 +1581,7 @@ int cfear_surface_launch(cfear_ctx* ctx, const void* d_jobs, int n_jobs, const c
   cm.cos_t = polar ? polar->cos_t : nullptr;
   cm.sin_t = polar ? polar->sin_t : nullptr;
   cm.range_res = polar ? polar->range_res : 0.0;
+  cm.range_off = polar ? polar->range_off : 0.0;
   cm.n_jobs = n_jobs;
   cm.fast_ok = cm.reach == 1 ? 1 : 0;
   // work list of the scans the fast pipeline hands to the single-kernel path: count + job ids
@@ -1627,7 +1634,7 @@ int cfear_surface_launch(cfear_ctx* ctx, const void* d_jobs, int n_jobs, const c
 #ifdef CFEAR_SURF_TIMING
   {                                            // debug build only: phase split of surface_sort_kernel, averaged over the jobs
     static int calls = 0;
-    if (++calls % 40 == 0) {
+    if (++calls % 40 == 0 || getenv("CFEAR_SURF_ROUTES")) {
       (void)hipStreamSynchronize(ctx->stream);
       {
         int32_t nfb = -1;

@@ -95,6 +95,9 @@ def test_cacfar_pipeline_kvarntorp_preset():
             assert info["n_points"][b] == cloud.shape[0] and info["n_cells"][b] == oi[0]
             d = np.abs(info["pose"][b] - pose)
             assert d[:2].max() <= POS_TOL and d[2] <= ROT_TOL, (f, b, d)
+            if f > 0:      # Register's verdict (n_scan_normal.cpp:82-185) and its outer iterations, stream by stream
+                assert (info["reg_status"][b] == 0) == (oi[2] == 1), (f, b, info["reg_status"][b], oi[2])
+                assert info["outer_iters"][b] == oi[3], (f, b)
 
 
 @pytest.mark.parametrize("device_input", [False, True])
