@@ -725,7 +725,7 @@ __host__ __device__ inline size_t cfar_wave_lds(int colsp, int pad_lo, int pad_h
   b += (size_t)kCfarList * 2;
   return (b + 15) & ~(size_t)15;
 }
-template <int NCH, bool KEYS>
+template <int NCH, bool KEYS, bool PRE>
 __global__ __launch_bounds__(256) void cacfar_rows_kernel(const CfarArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -835,24 +835,40 @@ __global__ __launch_bounds__(256) void cacfar_rows_kernel(const CfarArgs a) {
       int bin = 0; uint32_t v = 0;
       if (act) { bin = list[k0 + lane]; v = raw[bin]; }
       const int t1 = bin - a.guard, t0 = t1 - a.window, f0 = bin + a.guard, f1 = f0 + a.window;   // cfar.cpp:48-53
-      const bool full = t0 >= 0 && f1 <= a.cols;
-      // both windows full (every bin but the row's ends): the integer decision; lanes outside compute on clamped indices
-      const uint32_t S = (P(t1 < 0 ? 0 : t1) - P(t0 < 0 ? 0 : t0)) + (P(min(f1, colsp)) - P(min(f0, colsp)));
-      const uint32_t X = 2u * S + 1u, L = lut[v];
-      bool det = act && full && a.lut_ok && X < L;
-      const bool slow = act && (!full || !a.lut_ok || X == L);
+      const int lt0 = max(t0, 0), lf1 = min(f1, a.cols);                     // the windows as the row's ends cut them
+      const int nt = t1 - lt0, nf = lf1 - f0;
+      // getMean over an empty window is 0 / 0 = NaN: no detection (a window "ending" before bin 0 compares a size_t index
+      // with a negative end in the reference -- undefined there, no detection here)
+      const bool valid = act && nt > 0 && nf > 0;
+      const uint32_t st = P(max(t1, 0)) - P(lt0), sf = P(lf1) - P(min(f0, colsp));
+      const bool full = nt == a.window && nf == a.window;
+      bool det = false, slow = false;
+      if (PRE) {
+        // both windows full (every bin but the row's ends): the integer decision of step C
+        const uint32_t X = 2u * (st + sf) + 1u, L = lut[v];
+        det = valid && full && X < L;
+        slow = valid && full && X == L;
+        const bool edge = valid && !full;
+        if (__ballot(edge)) {
+          // a cut window: I^2 > scaling (S_t / n_t + S_f / n_f) / 2  <=>  I^2 2 n_t n_f > scaling (S_t n_f + S_f n_t) up to
+          // six roundings of 2^-53; the integers on both sides are exact in fp64, so unless the two sides agree to 1e-12
+          // the comparison is decided without the reference's divisions
+          const double lhs = (double)(v * v) * (double)(2 * nt * nf);
+          const double rhs = a.scaling * ((double)st * (double)nf + (double)sf * (double)nt);
+          const double d = lhs - rhs;
+          const bool sure = fabs(d) > fabs(rhs) * 1e-12;
+          if (edge) { det = sure && d > 0.0; slow = !sure; }
+        }
+      } else {
+        slow = valid;
+      }
       if (__ballot(slow)) {
-        if (slow) {                                                         // cfar.cpp:45-60, literally
-          const int lt0 = max(0, t0), lf1 = min(a.cols, f1);
-          // getMean: sequential sum of exact integer-valued doubles / count; an empty window is 0 / 0 = NaN: no detection
-          if (t1 > lt0 && lf1 > f0) {
-            const uint32_t st = P(t1) - P(lt0), sf = P(lf1) - P(f0);
-            const double trailing_mean = (double)st / (double)(t1 - lt0);
-            const double forwarding_mean = (double)sf / (double)(lf1 - f0);
-            const double mean = (trailing_mean + forwarding_mean) / 2.0;      // :56
-            const double threshold = a.scaling * mean;                        // :58
-            det = (double)(v * v) > threshold;                                // :59-60
-          }
+        if (slow) {                                                         // cfar.cpp:55-60, literally
+          const double trailing_mean = (double)st / (double)nt;
+          const double forwarding_mean = (double)sf / (double)nf;
+          const double mean = (trailing_mean + forwarding_mean) / 2.0;        // :56
+          const double threshold = a.scaling * mean;                          // :58
+          det = (double)(v * v) > threshold;                                  // :59-60
         }
       }
       if (KEYS) {
@@ -880,7 +896,7 @@ __global__ __launch_bounds__(256) void cacfar_rows_kernel(const CfarArgs a) {
 #pragma unroll
       for (int h = 0; h < 2; h++) {
         int t = a.thr_i;
-        if (a.pre_on) {
+        if (PRE) {
           const uint32_t* pq = P4 + (pos >> 2) + 2 * h;                     // quad 2 H of this 8-bin block
           const uint32_t slb = (pq[a.pa1] - pq[a.pa0]) + (pq[a.pb1] - pq[a.pb0]);
           const float f = __builtin_amdgcn_sqrtf((float)slb * a.kappa_lb);  // <= sqrt(kappa S_lb): kappa_lb carries the slack
@@ -889,17 +905,14 @@ __global__ __launch_bounds__(256) void cacfar_rows_kernel(const CfarArgs a) {
         const uint32_t tl = (uint32_t)(t & 0x7f);
         const uint32_t lo4 = __builtin_amdgcn_perm(tl, tl, 0u);               // the byte in all four places
         const uint32_t nhi = (t & 0x80) ? 0u : 0xffffffffu;
-        uint32_t m8 = 0;
-#pragma unroll
-        for (int d = 0; d < 2; d++) {
-          const uint32_t x = w[2 * h + d];
-          const uint32_t y = ((x & 0x7f7f7f7fu) | 0x80808080u) - lo4;
-          const uint32_t ge = (y & x) | ((y | x) & nhi);                    // bit 7 of every byte: byte >= t
-          // gather the four verdict bits (bit 7, 15, 23, 31) into bits 0..3: with z = bits 0, 8, 16, 24, the product
-          // z * 0x01020408 puts bit 8 i at 24 + i (the partial products do not collide)
-          const uint32_t nib = ((((ge >> 7) & 0x01010101u) * 0x01020408u) >> 24) & 0xfu;
-          m8 |= nib << (4 * d);
-        }
+        const uint32_t x0 = w[2 * h], x1 = w[2 * h + 1];
+        const uint32_t y0 = (x0 | 0x80808080u) - lo4, y1 = (x1 | 0x80808080u) - lo4;
+        const uint32_t ge0 = (y0 & x0) | ((y0 | x0) & nhi);                  // bit 7 of every byte: byte >= t
+        const uint32_t ge1 = (y1 & x1) | ((y1 | x1) & nhi);
+        // gather the eight verdict bits: byte k of z holds dword 0's verdict at bit 0 and dword 1's at bit 4; the product
+        // z * 0x01020408 puts bit 8 k + j at 24 + k + j (j = 0, 4; no two partial products meet), so its top byte is the mask
+        const uint32_t z = ((ge0 >> 7) & 0x01010101u) | ((ge1 >> 3) & 0x10101010u);
+        uint32_t m8 = (z * 0x01020408u) >> 24;
         if (t > 255) m8 = 0u;
         cmask |= m8 << (8 * h);
       }
@@ -1541,11 +1554,15 @@ int cfear_cacfar_device(cfear_ctx* ctx, const uint8_t* d_polar, const cfear_pola
   }
   {
     const size_t rows_lds = 1024 + (size_t)kRowsPerBlock * cfar_wave_lds(a.colsp, a.pad_lo, a.pad_hi, keys);
-    const bool wide = a.colsp > 4096;
-    const void* fn = wide ? (keys ? (const void*)cacfar_rows_kernel<8, true> : (const void*)cacfar_rows_kernel<8, false>)
-                          : (keys ? (const void*)cacfar_rows_kernel<4, true> : (const void*)cacfar_rows_kernel<4, false>);
+    const bool wide = a.colsp > 4096, pre = a.pre_on != 0;
+    using KernelFn = void (*)(const CfarArgs);
+    // [wide][keys][pre]
+    static const KernelFn fns[2][2][2] = {
+        {{cacfar_rows_kernel<4, false, false>, cacfar_rows_kernel<4, false, true>}, {cacfar_rows_kernel<4, true, false>, cacfar_rows_kernel<4, true, true>}},
+        {{cacfar_rows_kernel<8, false, false>, cacfar_rows_kernel<8, false, true>}, {cacfar_rows_kernel<8, true, false>, cacfar_rows_kernel<8, true, true>}}};
+    const KernelFn fn = fns[wide ? 1 : 0][keys ? 1 : 0][pre ? 1 : 0];
     if (rows_lds > 64 * 1024)
-      CFEAR_HIP_CHECK(ctx, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rows_lds));
+      CFEAR_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rows_lds));
     // persistent wavefronts: as many workgroups as the chip holds at this LDS footprint (160 KiB per CU)
     int n_cu = 256;
     (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, ctx->device);
@@ -1553,13 +1570,7 @@ int cfear_cacfar_device(cfear_ctx* ctx, const uint8_t* d_polar, const cfear_pola
     const long long want = (a.total_rows + kRowsPerBlock - 1) / kRowsPerBlock;
     const unsigned grid = (unsigned)std::max<long long>(1, std::min<long long>(want, (long long)n_cu * per_cu));
     ProfScope ps(ctx, "cacfar_rows");
-    if (wide) {
-      if (keys) hipLaunchKernelGGL((cacfar_rows_kernel<8, true>), dim3(grid), dim3(256), rows_lds, ctx->stream, a);
-      else hipLaunchKernelGGL((cacfar_rows_kernel<8, false>), dim3(grid), dim3(256), rows_lds, ctx->stream, a);
-    } else {
-      if (keys) hipLaunchKernelGGL((cacfar_rows_kernel<4, true>), dim3(grid), dim3(256), rows_lds, ctx->stream, a);
-      else hipLaunchKernelGGL((cacfar_rows_kernel<4, false>), dim3(grid), dim3(256), rows_lds, ctx->stream, a);
-    }
+    hipLaunchKernelGGL(fn, dim3(grid), dim3(256), rows_lds, ctx->stream, a);
   }
   CFEAR_HIP_CHECK(ctx, hipGetLastError());
   if (keys) return CFEAR_OK;
