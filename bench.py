@@ -91,6 +91,21 @@ def maybe_self_launch(args, argv):
     os.execvpe(cmd[0], cmd, env)
 
 
+def emit(D, out):
+    """The ONE JSON line, as the LAST thing on stdout: the process group is torn down first and C stdio is flushed (RCCL
+    prints its version banner through buffered C stdio, which would otherwise land behind the line at exit)."""
+    rank = D.rank
+    D.close()
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    sys.stdout.flush()
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+
+
 class Dist:
     """torch.distributed plumbing of one rank: RCCL ("nccl") on GPUs, gloo for the launcher dry run."""
 
@@ -110,14 +125,27 @@ class Dist:
             torch.cuda.set_device(self.local_rank)              # rank i <-> GPU i
         self.dev = torch.device("cpu") if self.dry else torch.device("cuda", self.local_rank)
         self.dist = None
-        if self.world > 1:
+        # the sharded workloads bring the process group up at ONE rank too, so that the driver's N = 1 run executes the
+        # same collective (a 1-rank RCCL all_gather) as N = 8
+        if self.world > 1 or not self.dry:
             import torch.distributed as dist
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            if self.dry:
-                dist.init_process_group("gloo")
-            else:
-                dist.init_process_group("nccl", device_id=self.dev)
-            self.dist = dist
+            if self.world == 1:
+                import socket
+                with socket.socket() as sk:                       # a free port: nothing else joins this group
+                    sk.bind(("127.0.0.1", 0))
+                    os.environ.setdefault("MASTER_PORT", str(sk.getsockname()[1]))
+                os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
+            try:
+                if self.dry:
+                    dist.init_process_group("gloo")
+                else:
+                    dist.init_process_group("nccl", device_id=self.dev)
+                self.dist = dist
+            except Exception as e:                                # a lone rank can do without the group; N ranks cannot
+                if self.world > 1:
+                    raise
+                print("bench.py: no 1-rank process group (%s): collectives are skipped" % e, file=sys.stderr)
 
     def barrier(self):
         if not self.dry:
@@ -244,13 +272,23 @@ def loopclosure_run(D, n_cand, steps, warmup, graph=None):
         gt = np.stack([nd["T_xyt"] for nd in nodes])
         scans = [api.MapPointNormal(cells=nd["cells"], ctx=ctx) for nd in nodes]
     else:
-        n_frames = 40
-        sc = synth.Scene(3)
-        gt = np.stack([sc.pose_at(f, n_frames) for f in range(n_frames)])
-        scans = []
-        for f in range(n_frames):                      # every rank featurises the scans it may reference
-            r = api.filter_kstrongest(sc.render(f, n_frames), 40, 60, 0.0438, 2.5, ctx=ctx)
-            scans.append(api.MapPointNormal(r["xyzi"][0, :int(r["n_points"][0])], 3.0, (0, 0), True, ctx=ctx))
+        # 1024 DISTINCT scans: 16 synthetic worlds x a closed lap of 64 sweeps each (rendered and filtered on the GPU);
+        # a 10 k-frame Oxford sequence holds ~3 000 keyframes, so a candidate batch must not revisit 40 scans
+        n_worlds, lap = 16, 64
+        n_frames = n_worlds * lap
+        gt_list, scans = [], []
+        for wd in range(n_worlds):                     # every rank featurises the scans it may reference
+            sc = synth.Scene(3000 + wd, circle_frames=lap)
+            imgs = synth.render_frames_torch(sc, list(range(lap)), D.dev)
+            torch.cuda.synchronize()                   # the library's stream is not torch's
+            r = api.filter_kstrongest(imgs, 40, 60, 0.0438, 2.5, ctx=ctx)
+            ctx.synchronize()
+            xyzi, npts = r["xyzi"].cpu().numpy(), r["n_points"].cpu().numpy()
+            for f in range(lap):
+                gt_list.append(sc.pose_at(f, lap))
+                scans.append(api.MapPointNormal(xyzi[f, :int(npts[f])], 3.0, (0, 0), True, ctx=ctx))
+            del imgs, r
+        gt = np.stack(gt_list)
     rng = np.random.Generator(np.random.PCG64(11))
 
     def rel(a, b):
@@ -258,8 +296,10 @@ def loopclosure_run(D, n_cand, steps, warmup, graph=None):
         d = b[:2] - a[:2]
         return np.array([c * d[0] + s * d[1], -s * d[0] + c * d[1], b[2] - a[2]])
     jobs = []
+    lap_len = n_frames if graph else 64
     for _ in range(n_cand):                        # pairs 2..6 frames (5-15 m) apart, guess error N(0, 1 m), N(0, 3 deg)
-        i = int(rng.integers(0, n_frames - 7))
+        base = int(rng.integers(0, n_frames // lap_len)) * lap_len
+        i = base + int(rng.integers(0, lap_len - 7))
         j = i + int(rng.integers(2, 7))
         guess = rel(gt[i], gt[j]) + np.concatenate([rng.normal(0, 1.0, 2), rng.normal(0, np.deg2rad(3.0), 1)])
         jobs.append(([scans[i], scans[j]], np.array([[0.0, 0.0, 0.0], guess])))
@@ -268,15 +308,37 @@ def loopclosure_run(D, n_cand, steps, warmup, graph=None):
     lo, hi, _per = cdist.shard_range(n_cand, D.world, D.rank)
     prepared = reg.PrepareBatch(jobs[lo:hi])
     fn = lambda _local: reg.RegisterBatch(prepared)
+    fn.into = lambda _local, ptr: reg.RegisterBatchInto(prepared, ptr)     # records stay on the GPU until the gather
+    fn.ctx = ctx
     for _ in range(max(warmup, 1)):
         out = cdist.register_candidates_sharded(jobs, fn)
     D.barrier()
+    ctx.profile_enable(True); ctx.profile_read(reset=True)
     t1 = time.perf_counter()
     for _ in range(steps):
         out = cdist.register_candidates_sharded(jobs, fn)
     D.barrier()
     elapsed = D.max_over_ranks(time.perf_counter() - t1)
-    return {"metric": "loop-closure candidate registrations/sec (cached features, P2L 4x10)",
+    prof = ctx.profile_read(reset=True); ctx.profile_enable(False)
+    kernel_ms = D.max_over_ranks(sum(v[0] for v in prof.values()) / max(steps, 1))
+    # what a step costs whatever the batch: ONE candidate per rank through the same code (job upload, launch, the
+    # collective, read-back) -- at 8 ranks a 4096-candidate step is 512 candidates = one wave of workgroups per rank, so a
+    # strong-scaling curve is read as  step(N) ~ fixed_cost_ms + kernel_ms(1) / N
+    tiny_jobs = [jobs[cdist.shard_range(n_cand, D.world, r)[0]] for r in range(D.world)]
+    tiny_prep = reg.PrepareBatch(tiny_jobs[D.rank:D.rank + 1])
+    tfn = lambda _local: reg.RegisterBatch(tiny_prep)
+    tfn.into = lambda _local, ptr: reg.RegisterBatchInto(tiny_prep, ptr)
+    tfn.ctx = ctx
+    for _ in range(3):
+        cdist.register_candidates_sharded(tiny_jobs, tfn)
+    D.barrier()
+    t2 = time.perf_counter()
+    for _ in range(steps):
+        cdist.register_candidates_sharded(tiny_jobs, tfn)
+    D.barrier()
+    fixed_ms = D.max_over_ranks(time.perf_counter() - t2) / steps * 1e3
+    return {"fixed_cost_ms": fixed_ms, "kernel_ms": kernel_ms, "collective": "rccl all_gather" if D.dist else "none (no process group)",
+            "distinct_scans": n_frames,"metric": "loop-closure candidate registrations/sec (cached features, P2L 4x10)",
             "value": n_cand * steps / elapsed, "unit": "registrations/s", "n_gpus": D.world, "steps": steps,
             "warmup": max(warmup, 1), "ms_per_step": elapsed / steps * 1e3, "ms_per_4096": elapsed / steps * 1e3 * 4096.0 / n_cand,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32 search / f64 solve",
@@ -399,8 +461,7 @@ def main(argv=None):
         vals = D.gather(out["value"])
         if D.rank == 0:
             out["rccl_ranks"] = len(vals)
-            print(json.dumps(out))
-        return D.close()
+        return emit(D, out)
 
     import torch
     from tbv_slam_public_amd import api
@@ -537,8 +598,7 @@ def main(argv=None):
         "input_generation_s": t_gen,
     }
     if D.world > 1:
-        print(json.dumps(out))
-        return D.close()
+        return emit(D, out)
 
     # =====================================================================================================
     # 1 GPU only, after the timed region: extra passes and the CPU baseline
@@ -697,8 +757,7 @@ def main(argv=None):
             "value": done_mt / tm, "unit": "registrations/s", "cores": T, "kind": "port",
             "sample": "%d sequences x %d frames on %d threads (cgroup quota / affinity of this host: %d of %d CPUs), %.1f s"
                       % (n_tasks, nseq_mt, T, T, os.cpu_count() or 0, tm)}
-    print(json.dumps(out))
-    D.close()
+    emit(D, out)
 
 
 if __name__ == "__main__":

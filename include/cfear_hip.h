@@ -255,7 +255,10 @@ int cfear_register(cfear_ctx* ctx, const cfear_scan* const* scans, int32_t n_sca
                    double* poses_xyt, const cfear_reg_params* par, cfear_reg_result* result);
 
 /* One launch, many independent registrations (loop-closure candidate batches,
- * loopclosure.cpp:35-97 called per candidate from :658-721).                                  */
+ * loopclosure.cpp:35-97 called per candidate from :658-721).  results: host memory (the call
+ * returns after the read-back) or DEVICE memory (the records stay on the GPU; the launch is
+ * enqueued on the context's stream and not synchronised -- what a collective over the records
+ * wants, cfear_register_batch_sharded).                                                        */
 typedef struct cfear_reg_job {
   const cfear_scan* const* scans;       /* n_scans handles */
   int32_t n_scans;
@@ -497,10 +500,16 @@ int cfear_verify_by_odometry(const double* rel_xyt, int32_t n, double odom_sigma
  * callback gather(user, send, recv, bytes) that must place every rank's `bytes` bytes, rank after rank, into recv on
  * every rank and return 0.  cfear_rccl_allgather is that callback over an ncclComm_t (RCCL over xGMI), user = a
  * cfear_rccl_comm; librccl.so is resolved at run time.  jobs / n_jobs are the FULL candidate list on every rank and
- * results receives all n_jobs records on every rank.  world == 1 needs no callback.                              */
+ * results receives all n_jobs records on every rank.  world == 1 needs no callback (NULL); a callback that is given is
+ * called at every world size, 1 included.  A rank whose own block fails still takes part in the exchange (its status rides
+ * in an 8-byte trailer behind its block) and EVERY rank returns the first failed rank's status.  With cfear_rccl_allgather
+ * as the callback cfear_register_batch_sharded keeps the records on the device: the kernel writes into the send buffer,
+ * ncclAllGather moves them, one device-to-host copy returns all of them.                                                */
 typedef int (*cfear_allgather_fn)(void* user, const void* send, void* recv_all, size_t bytes_per_rank);
 typedef struct cfear_rccl_comm { cfear_ctx* ctx; void* nccl_comm; int32_t world, pad; } cfear_rccl_comm;
 int cfear_rccl_allgather(void* user /* cfear_rccl_comm* */, const void* send, void* recv_all, size_t bytes_per_rank);
+/* the same collective on DEVICE buffers: enqueued on the communicator's context stream, not synchronised */
+int cfear_rccl_allgather_device(void* user /* cfear_rccl_comm* */, const void* d_send, void* d_recv_all, size_t bytes_per_rank);
 int cfear_shard_range(int32_t n, int32_t world, int32_t rank, int32_t* lo, int32_t* hi, int32_t* per_rank);
 /* the gather step alone: local = this rank's hi - lo records; all = n_total records in candidate order */
 int cfear_gather_records(const void* local, int32_t n_total, int32_t record_bytes, int32_t world, int32_t rank,

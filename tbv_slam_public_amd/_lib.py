@@ -210,7 +210,7 @@ EXPORTS = [
     "cfear_graph_save", "cfear_graph_load", "cfear_graph_size", "cfear_graph_node_at", "cfear_graph_destroy",
     "cfear_pose3d_from_xyt", "cfear_pose3d_to_xyt", "cfear_odometry_get_constraint",
     "cfear_shard_range", "cfear_gather_records", "cfear_register_batch_sharded", "cfear_verify_loop_candidates_sharded",
-    "cfear_rccl_allgather", "cfear_pgo_params_default", "cfear_pgo_solve",
+    "cfear_rccl_allgather", "cfear_rccl_allgather_device", "cfear_pgo_params_default", "cfear_pgo_solve",
 ]
 
 

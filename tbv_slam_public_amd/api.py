@@ -410,6 +410,15 @@ class n_scan_normal_reg:
             self.ctx.check(self.ctx._lib.cfear_register_batch(self.ctx.h, arr, n, C.byref(self.par), out.ctypes.data))
         return out
 
+    def RegisterBatchInto(self, jobs, device_ptr):
+        """As RegisterBatch, but the records stay on the GPU: device_ptr = a device buffer of n * 72 bytes; the launch is
+        enqueued on the context's stream and NOT synchronised (cfear_register_batch with a device pointer for results).
+        Returns n."""
+        arr, n, _keep = jobs if isinstance(jobs, tuple) else self.PrepareBatch(jobs)
+        if n:
+            self.ctx.check(self.ctx._lib.cfear_register_batch(self.ctx.h, arr, n, C.byref(self.par), C.c_void_p(int(device_ptr))))
+        return n
+
     def GetCost(self, scans, Tsrc):
         """GetCost (n_scan_normal.cpp:186-211) -> (success, score(cost), residuals)."""
         p = np.ascontiguousarray(Tsrc, dtype=np.float64)

@@ -159,6 +159,8 @@ int cfear_trig_tables(cfear_ctx* ctx, int rows, double** d_cos, double** d_sin);
 int cfear_surface_launch(cfear_ctx* ctx, const void* d_jobs, int n_jobs, const cfear_feature_params* par,
                          char* d_scratch, int32_t* d_status, int32_t* d_ncells_out, int max_cell_cap, int cap_points,
                          const cfear_surface_polar* polar = nullptr);
+int cfear_register_batch_device(cfear_ctx* ctx, const cfear_reg_job* jobs, int32_t n_jobs, const cfear_reg_params* par,
+                                cfear_reg_result* d_out, cfear_reg_result** d_used);
 size_t cfear_reg_job_bytes();
 int cfear_reg_max_scans();
 void cfear_reg_fill_job(void* dst, const ScanView* views, int n_scans, const double* poses_xyt);

@@ -11,7 +11,8 @@
 //     typedef std::vector<std::pair<RadarScan, std::vector<Constraint3d>>> simple_graph;
 // Boost itself is not in this image, so the archive's byte layout is restated here from the library's published
 // sources (basic_binary_oarchive.hpp, basic_oarchive.cpp, oserializer.hpp, collections_save_imp.hpp, shared_ptr.hpp):
-//   * header: the string "serialization::archive" (u64 length + bytes) and the library version as u16;
+//   * header: the string "serialization::archive" (u64 length + bytes), the library version as u16, then the native sizes
+//     of int / long / float / double as bytes (4 8 4 8) and int32 1 (basic_binary_oprimitive::init);
 //   * strings: u64 length + bytes; bool: 1 byte; enums: int32; collection sizes: u64; item_version: u32;
 //   * every CLASS type (anything that is not a primitive) writes, the first time an object of it is saved,
 //     tracking_type (1 byte) + version_type (u32); types serialized through a pointer are "tracked": the first
@@ -291,6 +292,14 @@ bool io_graph(Archive& a, std::vector<NodeRec>& g) {
   if (!a.saving && sig != "serialization::archive") return false;
   uint16_t ver = 17;                                    // BOOST_ARCHIVE_VERSION of Boost 1.71
   a.prim(ver);
+  // binary_oarchive_impl::init() then calls basic_binary_oprimitive::init() (boost/archive/impl/basic_binary_oprimitive.ipp):
+  // the native sizes of int, long, float, double as single bytes and int(1) as the endianness marker; basic_binary_iprimitive::
+  // init() throws incompatible_native_format on any mismatch, so a reader must find exactly these 8 bytes (x86-64 Linux)
+  uint8_t native[4] = {4, 8, 4, 8};
+  for (int k = 0; k < 4; k++) a.prim(native[k]);
+  int32_t endian = 1;
+  a.prim(endian);
+  if (!a.saving && (native[0] != 4 || native[1] != 8 || native[2] != 4 || native[3] != 8 || endian != 1)) return false;
   a.object_preamble(K_GRAPH);
   uint64_t n = g.size();
   io_count(a, n, K_PAIR);

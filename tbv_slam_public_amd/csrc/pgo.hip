@@ -21,6 +21,7 @@
 // a direct solve to rounding.
 #include <algorithm>
 #include <cmath>
+#include <limits>
 #include <cstring>
 #include <vector>
 

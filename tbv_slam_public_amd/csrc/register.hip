@@ -1575,12 +1575,16 @@ int gather_job(cfear_ctx* ctx, const cfear_scan* const* scans, int n_scans, cons
 
 }  // namespace
 
-extern "C" int cfear_register_batch(cfear_ctx* ctx, const cfear_reg_job* jobs, int32_t n_jobs,
-                                    const cfear_reg_params* par, cfear_reg_result* results) {
+// The batch with its results left ON THE DEVICE (enqueued on the context's stream, not synchronised): d_out when given,
+// otherwise the context's workspace; *d_used receives the pointer.  cfear_register_batch reads them back; the sharded
+// entry hands them straight to the collective (shard.hip).
+int cfear_register_batch_device(cfear_ctx* ctx, const cfear_reg_job* jobs, int32_t n_jobs, const cfear_reg_params* par,
+                                cfear_reg_result* d_out, cfear_reg_result** d_used) {
   if (!ctx) return CFEAR_ERR_INVALID_ARGUMENT;
-  if (!jobs || !results || n_jobs < 0) return cfear_set_error(ctx, CFEAR_ERR_INVALID_ARGUMENT, "null argument");
+  if (!jobs || n_jobs < 0) return cfear_set_error(ctx, CFEAR_ERR_INVALID_ARGUMENT, "null argument");
   int rc = check_params(ctx, par);
   if (rc != CFEAR_OK) return rc;
+  if (d_used) *d_used = d_out;
   if (n_jobs == 0) return CFEAR_OK;
   CFEAR_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   // job records are built in pinned memory: 2.3 KB each, so a 4096-candidate batch is a 9 MB upload that a pageable
@@ -1604,13 +1608,26 @@ extern "C" int cfear_register_batch(cfear_ctx* ctx, const cfear_reg_job* jobs, i
   char* scr = (char*)cfear_workspace(ctx, 7, sb);
   if (!ws || !scr) return cfear_set_error(ctx, CFEAR_ERR_HIP, "workspace allocation failed");
   char* d_jobs = ws;
-  cfear_reg_result* d_res = (cfear_reg_result*)(ws + (jb + 255) / 256 * 256);
+  cfear_reg_result* d_res = d_out ? d_out : (cfear_reg_result*)(ws + (jb + 255) / 256 * 256);
+  if (d_used) *d_used = d_res;
   CFEAR_HIP_CHECK(ctx, hipMemcpyAsync(d_jobs, hjobs, jb, hipMemcpyHostToDevice, ctx->stream));
   // a registration whose keyframes do not fit the 80 KB association: second launch with a CU's whole LDS per workgroup
   const bool big = sz.fused_core > kRegLdsBudget;
   rc = cfear_register_launch(ctx, d_jobs, n_jobs, par, sz.slots_cap, sz.lds_targets, scr, d_res, nullptr, stride, compact, big);
   if (rc != CFEAR_OK) { (void)hipStreamSynchronize(ctx->stream); return rc; }
-  CFEAR_HIP_CHECK(ctx, hipMemcpyAsync(results, d_res, rb, hipMemcpyDeviceToHost, ctx->stream));
+  return CFEAR_OK;
+}
+
+extern "C" int cfear_register_batch(cfear_ctx* ctx, const cfear_reg_job* jobs, int32_t n_jobs,
+                                    const cfear_reg_params* par, cfear_reg_result* results) {
+  if (!ctx) return CFEAR_ERR_INVALID_ARGUMENT;
+  if (!jobs || !results || n_jobs < 0) return cfear_set_error(ctx, CFEAR_ERR_INVALID_ARGUMENT, "null argument");
+  // results on the device: the records stay there, the launch is stream-ordered and not synchronised
+  if (cfear_is_device_ptr(results)) return cfear_register_batch_device(ctx, jobs, n_jobs, par, results, nullptr);
+  cfear_reg_result* d_res = nullptr;
+  const int rc = cfear_register_batch_device(ctx, jobs, n_jobs, par, nullptr, &d_res);
+  if (rc != CFEAR_OK || n_jobs == 0) return rc;
+  CFEAR_HIP_CHECK(ctx, hipMemcpyAsync(results, d_res, (size_t)n_jobs * sizeof(cfear_reg_result), hipMemcpyDeviceToHost, ctx->stream));
   CFEAR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   return CFEAR_OK;
 }

@@ -31,7 +31,17 @@ def shard_range(n, world, rank):
 def default_register_fn(reg):
     def fn(jobs):
         return reg.RegisterBatch(jobs) if jobs else np.zeros(0, L.RESULT_DTYPE)
+
+    def into(jobs, device_ptr):                          # records stay on the GPU (stream-ordered, not synchronised)
+        return reg.RegisterBatchInto(jobs, device_ptr) if jobs else 0
+    fn.into, fn.ctx = into, reg.ctx
     return fn
+
+
+def _unpad(allr, n, world):
+    out = np.concatenate([allr[r, :shard_range(n, world, r)[1] - shard_range(n, world, r)[0]] for r in range(world)])
+    assert out.shape[0] == n
+    return out
 
 
 def _gather_records(local, n, group):
@@ -49,23 +59,35 @@ def _gather_records(local, n, group):
     send = torch.from_numpy(padded.view(np.uint8).reshape(-1).copy()).to(dev)
     recv = torch.empty(world * send.numel(), dtype=torch.uint8, device=dev)
     dist.all_gather_into_tensor(recv, send, group=group)
-    allr = recv.cpu().numpy().view(local.dtype).reshape(world, per)
-    out = np.concatenate([allr[r, :shard_range(n, world, r)[1] - shard_range(n, world, r)[0]] for r in range(world)])
-    assert out.shape[0] == n
-    return out
+    return _unpad(recv.cpu().numpy().view(local.dtype).reshape(world, per), n, world)
 
 
 def register_candidates_sharded(jobs, register_fn, group=None):
     """jobs: the FULL candidate list (same on every rank).  Returns the results of all candidates, in
-    candidate order, on every rank."""
+    candidate order, on every rank.  With the RCCL backend and a register_fn that can leave its records on the GPU
+    (default_register_fn: .into / .ctx) the block never visits the host: the kernel writes into the send tensor,
+    all_gather_into_tensor moves it over xGMI, ONE device-to-host copy returns all n records.  A process group of ONE
+    rank still runs the collective (the driver's N = 1 run exercises the same code as N = 8)."""
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()):
         return register_fn(jobs)
     world, rank = dist.get_world_size(group), dist.get_rank(group)
-    lo, hi, _per = shard_range(len(jobs), world, rank)
+    n = len(jobs)
+    lo, hi, per = shard_range(n, world, rank)
+    if dist.get_backend(group) == "nccl" and hasattr(register_fn, "into"):
+        import torch
+        rec = L.RESULT_DTYPE.itemsize
+        dev = torch.device("cuda", torch.cuda.current_device())
+        send = torch.zeros(per * rec, dtype=torch.uint8, device=dev)
+        got = register_fn.into(jobs[lo:hi], send.data_ptr())
+        assert got == hi - lo
+        register_fn.ctx.synchronize()                    # the library runs on its own stream: torch must see the records
+        recv = torch.empty(world * per * rec, dtype=torch.uint8, device=dev)
+        dist.all_gather_into_tensor(recv, send, group=group)
+        return _unpad(recv.cpu().numpy().view(L.RESULT_DTYPE).reshape(world, per), n, world)
     local = register_fn(jobs[lo:hi])
     assert local.dtype == L.RESULT_DTYPE
-    return _gather_records(local, len(jobs), group)
+    return _gather_records(local, n, group)
 
 
 def apply_constraints(results, groups, model_threshold=0.8, all_candidates=True):

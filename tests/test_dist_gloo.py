@@ -227,12 +227,13 @@ def test_c_abi_gather_with_a_mock_two_rank_callback():
     records = np.arange(n * rec, dtype=np.uint8).reshape(n, rec) % 251
     lo, hi, per = (C.c_int32(), C.c_int32(), C.c_int32())
     blocks, sent = {}, {}
+    import struct
     for r in range(world):
         assert lib.cfear_shard_range(n, world, r, C.byref(lo), C.byref(hi), C.byref(per)) == 0
         assert (lo.value, hi.value, per.value) == cdist.shard_range(n, world, r)
         pad = np.zeros((per.value, rec), np.uint8)
         pad[:hi.value - lo.value] = records[lo.value:hi.value]
-        blocks[r] = pad.tobytes()
+        blocks[r] = pad.tobytes() + struct.pack("<ii", 0, hi.value - lo.value)   # + the trailer {rank status, records}
     CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t)
     for me in range(world):
         def gather(user, send, recv, nbytes, me=me):
@@ -245,8 +246,31 @@ def test_c_abi_gather_with_a_mock_two_rank_callback():
         out = np.zeros((n, rec), np.uint8)
         rc = lib.cfear_gather_records(local.ctypes.data, n, rec, world, me, C.cast(cb, C.c_void_p), None, out.ctypes.data)
         assert rc == 0
-        assert sent[me] == blocks[me]                       # the rank's own block, zero-padded
+        assert sent[me] == blocks[me]                       # the rank's own block, zero-padded, + its trailer
         np.testing.assert_array_equal(out, records)
+    # a peer whose own work failed still takes part; every rank then returns THAT rank's status (nobody hangs, one verdict)
+    def gather_peer_failed(user, send, recv, nbytes):
+        mine = C.string_at(send, nbytes)
+        peer = bytes(nbytes - 8) + struct.pack("<ii", L.ERR_CAPACITY, per.value)
+        C.memmove(recv, mine + peer, 2 * nbytes)
+        return 0
+    cbf = CB(gather_peer_failed)
+    out = np.zeros((n, rec), np.uint8)
+    lo_, hi_, _ = cdist.shard_range(n, world, 0)
+    rc = lib.cfear_gather_records(np.ascontiguousarray(records[lo_:hi_]).ctypes.data, n, rec, world, 0, C.cast(cbf, C.c_void_p), None, out.ctypes.data)
+    assert rc == L.ERR_CAPACITY
+    np.testing.assert_array_equal(out[lo_:hi_], records[lo_:hi_])   # this rank's own records still arrive
+    # a callback given at world 1 is called (a 1-rank communicator runs the same collective as 8)
+    calls = []
+    def gather_one(user, send, recv, nbytes):
+        calls.append(nbytes)
+        C.memmove(recv, send, nbytes)
+        return 0
+    cb1 = CB(gather_one)
+    out = np.zeros((n, rec), np.uint8)
+    assert lib.cfear_gather_records(records.ctypes.data, n, rec, 1, 0, C.cast(cb1, C.c_void_p), None, out.ctypes.data) == 0
+    assert calls == [n * rec + 8]
+    np.testing.assert_array_equal(out, records)
     # world 1 needs no callback; a failing callback is an error status
     out = np.zeros((n, rec), np.uint8)
     assert lib.cfear_gather_records(records.ctypes.data, n, rec, 1, 0, None, None, out.ctypes.data) == 0

@@ -3,6 +3,8 @@
 Tolerance (BASELINE.json north_star): registered SE(2) pose within 1e-4 m / 1e-5 rad of the CPU
 path.  Integer outcomes (association pairs, iteration counts, residual counts) must be identical.
 """
+import struct
+
 import numpy as np
 import pytest
 
@@ -422,10 +424,125 @@ def test_sharded_c_abi_entry_world_one_and_mock_world_two():
             lo, hi = other * per, min(n, other * per + per)
             blk = np.zeros(per, L.RESULT_DTYPE)
             blk[:hi - lo] = ref[lo:hi]
-            parts = [C.string_at(send, nbytes), blk.tobytes()] if me == 0 else [blk.tobytes(), C.string_at(send, nbytes)]
+            peer = blk.tobytes() + struct.pack("<ii", 0, hi - lo)          # the block + its trailer {rank status, records}
+            assert nbytes == len(peer)
+            parts = [C.string_at(send, nbytes), peer] if me == 0 else [peer, C.string_at(send, nbytes)]
             C.memmove(recv, b"".join(parts), 2 * nbytes)
             return 0
         cb = CB(gather)
         out = np.zeros(n, L.RESULT_DTYPE)
         ctx.check(lib.cfear_register_batch_sharded(ctx.h, arr, n, C.byref(reg.par), me, 2, C.cast(cb, C.c_void_p), None, out.ctypes.data))
         np.testing.assert_array_equal(out, ref)
+    # a rank whose own block fails (here: an invalid job) still enters the collective and reports its status there
+    entered = []
+    def gather_fail(user, send, recv, nbytes):
+        entered.append(struct.unpack_from("<ii", C.string_at(send, nbytes), nbytes - 8))
+        C.memmove(recv, C.string_at(send, nbytes) * 2, 2 * nbytes)
+        return 0
+    cbf = CB(gather_fail)
+    bad = (L.RegJob * n)()
+    C.memmove(bad, arr, C.sizeof(bad))
+    bad[0].n_scans = 1                                                      # n_scans must be >= 2: this rank's block fails
+    rc = lib.cfear_register_batch_sharded(ctx.h, bad, n, C.byref(reg.par), 0, 2, C.cast(cbf, C.c_void_p), None, out.ctypes.data)
+    assert rc != 0 and len(entered) == 1 and entered[0][0] == rc
+
+
+def _rccl():
+    """librccl through ctypes: a ONE-rank communicator (ncclGetUniqueId + ncclCommInitRank), as a C++ host would own it."""
+    import ctypes as C
+    for name in ("librccl.so.1", "librccl.so"):
+        try:
+            return C.CDLL(name, mode=C.RTLD_GLOBAL)
+        except OSError:
+            continue
+    pytest.skip("librccl.so not found")
+
+
+def test_sharded_c_abi_entry_over_a_real_one_rank_rccl_communicator():
+    """The north-star collective really runs: cfear_register_batch_sharded(..., cfear_rccl_allgather, &comm) with an
+    ncclComm_t of one rank (the single-GPU box) -- kernel output written straight into the send buffer, ncclAllGather on
+    the context's stream, one read-back -- equals cfear_register_batch; so does the host-buffer callback route
+    (cfear_gather_records) and the sharded verification entry."""
+    import ctypes as C
+    from tbv_slam_public_amd import api, _lib as L, synth
+    rccl = _rccl()
+    imgs, gt, _ = synth.scene_v1(21, 4)
+    scans = []
+    for f in range(4):
+        r = api.filter_kstrongest(imgs[f], 40, 60, 0.0438, 2.5)
+        scans.append(api.MapPointNormal(r["xyzi"][0, :int(r["n_points"][0])], 3.0, (0, 0), True))
+    rng = np.random.default_rng(1)
+    jobs = []
+    for q in range(37):
+        i, j = (q % 3), (q % 3) + 1
+        jobs.append(([scans[i], scans[j]], np.array([[0, 0, 0.0], gt[j] - gt[i] + rng.normal(0, 0.2, 3) * [1, 1, 0.05]])))
+    reg = api.n_scan_normal_reg("P2L")
+    reg.SetParameters(4, 10)
+    arr, n, keep = reg.PrepareBatch(jobs)
+    ref = reg.RegisterBatch((arr, n, keep))
+    ctx = api.default_context()
+    lib = ctx._lib
+
+    class UniqueId(C.Structure):
+        _fields_ = [("internal", C.c_char * 128)]
+    uid = UniqueId()
+    assert rccl.ncclGetUniqueId(C.byref(uid)) == 0
+    comm = C.c_void_p()
+    rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
+    assert rccl.ncclCommInitRank(C.byref(comm), 1, uid, 0) == 0
+    try:
+        class RcclComm(C.Structure):
+            _fields_ = [("ctx", C.c_void_p), ("nccl_comm", C.c_void_p), ("world", C.c_int32), ("pad", C.c_int32)]
+        cc = RcclComm(ctx.h, comm, 1, 0)
+        lib.cfear_register_batch_sharded.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p,
+                                                     C.c_void_p, C.c_void_p]
+        fn = C.cast(lib.cfear_rccl_allgather, C.c_void_p)
+        out = np.zeros(n, L.RESULT_DTYPE)
+        ctx.check(lib.cfear_register_batch_sharded(ctx.h, arr, n, C.byref(reg.par), 0, 1, fn, C.byref(cc), out.ctypes.data))
+        np.testing.assert_array_equal(out, ref)
+        # the generic (host-buffer) route through the same communicator
+        lib.cfear_gather_records.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
+        out2 = np.zeros(n, L.RESULT_DTYPE)
+        ctx.check(lib.cfear_gather_records(ref.ctypes.data, n, L.RESULT_DTYPE.itemsize, 1, 0, fn, C.byref(cc), out2.ctypes.data))
+        np.testing.assert_array_equal(out2, ref)
+        # results may live on the device: cfear_register_batch with a device pointer leaves them there
+        import torch
+        d_out = torch.zeros(n * L.RESULT_DTYPE.itemsize, dtype=torch.uint8, device="cuda")
+        assert reg.RegisterBatchInto((arr, n, keep), d_out.data_ptr()) == n
+        ctx.synchronize()
+        np.testing.assert_array_equal(d_out.cpu().numpy().view(L.RESULT_DTYPE), ref)
+    finally:
+        rccl.ncclCommDestroy.argtypes = [C.c_void_p]
+        rccl.ncclCommDestroy(comm)
+
+
+def test_python_sharded_path_runs_the_collective_at_world_one():
+    """dist.register_candidates_sharded inside a ONE-rank nccl process group: records written into the send tensor on the
+    GPU, all_gather_into_tensor, one copy back -- equal to the plain batch."""
+    import os
+    import socket
+    import torch
+    import torch.distributed as dist
+    from tbv_slam_public_amd import api, synth
+    from tbv_slam_public_amd import dist as cdist
+    imgs, gt, _ = synth.scene_v1(22, 3)
+    scans = []
+    for f in range(3):
+        r = api.filter_kstrongest(imgs[f], 40, 60, 0.0438, 2.5)
+        scans.append(api.MapPointNormal(r["xyzi"][0, :int(r["n_points"][0])], 3.0, (0, 0), True))
+    rng = np.random.default_rng(2)
+    jobs = [([scans[q % 2], scans[q % 2 + 1]], np.array([[0, 0, 0.0], gt[q % 2 + 1] - gt[q % 2] + rng.normal(0, 0.2, 3) * [1, 1, 0.05]]))
+            for q in range(11)]
+    reg = api.n_scan_normal_reg("P2L")
+    reg.SetParameters(4, 10)
+    ref = reg.RegisterBatch(jobs)
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1")
+    dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
+    try:
+        out = cdist.register_candidates_sharded(jobs, cdist.default_register_fn(reg))
+    finally:
+        dist.destroy_process_group()
+    np.testing.assert_array_equal(out, ref)

@@ -76,10 +76,24 @@ def test_distance_batch_bit_identical_to_oracle():
     assert shift[pairs.index((3, 7))] == 101
 
 
+def _ref_key_tree():
+    """The reference's nanoflann ring-key tree (tests/test_ref_nanoflann.py), or None when oracle/_ref was not built."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import test_ref_nanoflann as T
+    if not os.path.exists(T.SO):
+        return None
+    L = T._ref()
+    return lambda keys: T.RefKeyTree(L, keys)
+
+
 def _reference_manager_run(clouds, poses, odom_coupled, augment):
     """RSCManager restated on top of the oracle (RadarScancontext.cpp:133-345), written independently of api.py."""
     from oracle import pyoracle as O
     descs, keys, P, out = [], [], [], []
+    tree = {"counter": 0, "keys": np.zeros((0, 0), np.float32), "ref": None}
+    _RefTree = _ref_key_tree()
     for cloud, T in zip(clouds, poses):
         shifts = [0.0] + ([-2.0, 2.0, -4.0, 4.0] if augment else [])
         cur = [O.sc_descriptor(cloud, shift_y=dy) for dy in shifts]
@@ -116,9 +130,27 @@ def _reference_manager_run(clouds, poses, odom_coupled, augment):
                     lst.append((float(l2), idx))
                 idxs = [i for _, i in sorted(lst)[:10]]
             else:
-                n = len(keys) - n_ex
-                K = np.asarray(keys[:n], np.float32)
-                idxs = [int(i) for i in np.argsort(((K - qk[None]) ** 2).sum(1), kind="stable")[:10]] if n > 0 else []
+                # VanillaKDNNSearch (:225-248): the tree is rebuilt on every 50th CALL only, from the keys older than the
+                # recent-node exclusion at that moment; the zero-initialised index vector is copied whole.  The search
+                # is the REFERENCE's own nanoflann tree (oracle/_ref, built from the reference's vendored header) when that
+                # library is there, a linear scan with the tree's metric arithmetic otherwise.
+                if tree["counter"] % 50 == 0:
+                    tree["keys"] = np.asarray(keys[:max(len(keys) - n_ex, 0)], np.float32).copy()
+                    tree["ref"] = _RefTree(tree["keys"]) if (_RefTree is not None and tree["keys"].shape[0] > 0) else None
+                tree["counter"] += 1
+                idxs = [0] * 10
+                if tree["ref"] is not None:
+                    nfound, ridx, _ = tree["ref"].knn(qk, 10)
+                    idxs[:nfound] = [int(i) for i in ridx[:nfound]]
+                elif tree["keys"].shape[0] > 0:
+                    e2 = (tree["keys"] - qk[None]) ** 2
+                    dd = np.zeros(e2.shape[0], np.float32)
+                    for c in range(0, e2.shape[1] - 3, 4):
+                        dd = dd + (((e2[:, c] + e2[:, c + 1]) + e2[:, c + 2]) + e2[:, c + 3])
+                    for c in range(e2.shape[1] // 4 * 4, e2.shape[1]):
+                        dd = dd + e2[:, c]
+                    order = np.argsort(dd, kind="stable")[:10]
+                    idxs[:len(order)] = [int(i) for i in order]
             for i in idxs:
                 dsc, sh = O.sc_distance(d, descs[i])
                 dod = sim[i] if odom_coupled else 0.0

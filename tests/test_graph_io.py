@@ -77,7 +77,8 @@ def test_round_trip_is_lossless(tmp_path):
 
 
 def test_archive_header_and_first_records_follow_boost_layout(tmp_path):
-    """Hand-checked bytes: header = u64 22 + "serialization::archive" + u16 17; the vector's class info (tracking 0,
+    """Hand-checked bytes: header = u64 22 + "serialization::archive" + u16 17 + the native type sizes 04 08 04 08 and
+    int32 1 (basic_binary_oprimitive::init, which binary_oarchive_impl::init calls after the signature); the vector's class info (tracking 0,
     version 0), count u64, item_version u32; the pair's and RadarScan's class info; Pose3d + Vector3d class info, then
     three doubles."""
     path = str(tmp_path / "one.sgh")
@@ -88,6 +89,8 @@ def test_archive_header_and_first_records_follow_boost_layout(tmp_path):
     o = 30
     assert struct.unpack_from("<H", b, o)[0] == 17
     o += 2
+    assert b[o:o + 4] == bytes([4, 8, 4, 8]) and struct.unpack_from("<i", b, o + 4)[0] == 1   # sizeof int/long/float/double, endian marker
+    o += 8
     for _ in range(1):                                            # simple_graph (vector): tracking, version
         assert b[o] == 0 and struct.unpack_from("<I", b, o + 1)[0] == 0
         o += 5
