@@ -221,16 +221,22 @@ def run_odometry(od, rings, ss, n_frames, t0=0, record=None):
 
 
 def roofline_of(prof, n_scans_per_launch, mean_points):
-    """algorithmic bytes per scan filtered = R*C + 16*N_f + 4*R, N_f = points kept."""
+    """algorithmic bytes per scan filtered = R*C + 16*N_f + 4*R, N_f = points kept -- `achieved` / `frac`
+    follow that figure.  In the batched odometry the sweep does not write 16-byte points but 4-byte keys (intensity << 24 |
+    bin) and two counters per row, so what it really moves is R*C + 4*N_f + 8*R: reported beside it as `fused_*`."""
     ms, launches = prof.get("kstrongest_rows", (0.0, 0))
     avg_ms = ms / max(launches, 1)
     bytes_per_scan = IMG + 16.0 * mean_points + 4 * ROWS
-    achieved = bytes_per_scan * n_scans_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-    read_only = IMG * n_scans_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+    fused_bytes_per_scan = IMG + 4.0 * mean_points + 8 * ROWS
+    per_s = n_scans_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+    achieved = bytes_per_scan * per_s
     return {"bound": "hbm", "kernel": "kstrongest_rows", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS, "avg_launch_ms": avg_ms, "launches": int(launches),
             "algorithmic_bytes_per_launch": bytes_per_scan * n_scans_per_launch, "mean_points_per_scan": mean_points,
-            "polar_read_only_GBs": read_only, "scans_per_launch": n_scans_per_launch}
+            "fused_bytes_per_launch": fused_bytes_per_scan * n_scans_per_launch,
+            "fused_achieved": fused_bytes_per_scan * per_s, "fused_frac": fused_bytes_per_scan * per_s / HBM_PEAK_GBS,
+            "polar_read_only_GBs": IMG * per_s, "polar_read_only_frac": IMG * per_s / HBM_PEAK_GBS,
+            "scans_per_launch": n_scans_per_launch}
 
 
 def pingpong(t, n):
@@ -553,12 +559,13 @@ def main(argv=None):
     breakdown = {k: {"ms_per_frame_batch": v[0] / max(n_all, 1), "launches": int(v[1])} for k, v in prof_all.items()}
     # HBM traffic of that kernel from the committed PMC passes (rocprofv3 cannot run inside this process):
     # per-scan FETCH_SIZE x2 + WRITE_SIZE measured by tools/profile.sh, scaled to this launch's batch
-    for tag in ("r02", "r01"):
+    for tag in ("r03", "r02", "r01"):
         tj = os.path.join(ROOT, "profiles", tag, "pmc_traffic.json")
         if os.path.exists(tj):
             t = json.load(open(tj))
             roof["traffic"] = (t["fetch_bytes_per_scan"] + t["write_bytes_per_scan"]) * B
-            roof["traffic_source"] = "profiles/%s/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, per scan x batch)" % tag
+            roof["traffic_source"] = ("profiles/%s/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE of %s, "
+                                      "per scan x this launch's batch)" % (tag, t.get("configuration", "the standalone filter call")))
             break
     else:
         roof["traffic"] = None
@@ -672,46 +679,66 @@ def main(argv=None):
         # configs[4]: CA-CFAR on the Kvarntorp setup (0.175 m bins: 588 m range, ~15 000 detections per sweep)
         def side_config(params, seed0, range_res, bins_major, Bs, Ss, nfr):
             from tbv_slam_public_amd import synth
-            Fs = 16
+            Fs = F                                               # the whole closed lap: frame Fs continues into frame 0
             sr = torch.empty((Ss, Fs, ROWS, COLS), dtype=torch.uint8, device=dev)
             for q in range(Ss):
                 scn = synth.Scene(seed0 + q, circle_frames=F, range_res=range_res, ccw=True)
                 sr[q] = synth.render_frames_torch(scn, list(range(Fs)), dev)
             sod = api.OdometryKeyframeFuser(Bs, COLS if bins_major else ROWS, ROWS if bins_major else COLS, params, ctx=ctx)
             seq = torch.arange(Bs, device=dev) % Ss
+            start = (torch.arange(Bs, device=dev) // Ss) * 7 % Fs   # streams of one world start at different frames of its lap
 
-            def frame(t):                                        # stream b = world b % Ss at frame t (worlds shared, poses not)
-                x = sr[:, t % Fs].index_select(0, seq)
+            def frame(t):                                        # stream b = world b % Ss at frame (start_b + t) % Fs
+                x = sr.view(Ss * Fs, ROWS, COLS).index_select(0, seq * Fs + (start + t) % Fs)
                 return torch.rot90(x, -1, dims=(1, 2)).contiguous() if bins_major else x
-            batches = [frame(t) for t in range(Fs)]               # the ring's first frames as gathered batches, walked forth and back
+            batches = [frame(t) for t in range(Fs)]               # every frame of the lap as a gathered batch (Bs x 1.3 MB each)
+            del sr
             bad = 0
             torch.cuda.synchronize()                             # the library's stream is not torch's: the batches must exist
             for t in range(4):
-                sod.process(batches[pingpong(t, Fs)], batches[pingpong(t + 1, Fs)])
+                sod.process(batches[t % Fs], batches[(t + 1) % Fs])
             D.barrier()
             ctx.profile_enable(True); ctx.profile_read(reset=True)
             t0s = time.perf_counter()
             pts = cells = 0.0
             for t in range(4, 4 + nfr):
-                info = sod.process(batches[pingpong(t, Fs)], batches[pingpong(t + 1, Fs)])
+                info = sod.process(batches[t % Fs], batches[(t + 1) % Fs])
                 bad += int((info["reg_status"] < 0).sum())
                 pts += float(info["n_points"].mean()); cells += float(info["n_cells"].mean())
             D.barrier()
             dts = time.perf_counter() - t0s
             sp = ctx.profile_read(reset=True); ctx.profile_enable(False)
             sod.close()
+            del batches
             return {"value": Bs * nfr / dts, "unit": "registrations/s", "ms_per_frame_batch": dts / nfr * 1e3, "streams": Bs,
-                    "frames": nfr, "mean_points_per_scan": pts / nfr, "mean_cells_per_scan": cells / nfr,
+                    "frames": nfr, "timed_s": dts, "distinct_frames": Ss * Fs,
+                    "mean_points_per_scan": pts / nfr, "mean_cells_per_scan": cells / nfr,
                     "failed_registrations": bad, "kernel_breakdown": {k: v[0] / max(v[1], 1) for k, v in sp.items()},
-                    "note": "%d gathered frame batches walked forth and back (the motion reverses at both ends)" % Fs}
-        out["config2_mulran"] = side_config(api.odometry_preset("CFEAR-3", "mulran", submap_scan_size=5), 70000, 0.0595238, True, 1024, 32, 12)
-        out["config4_cacfar_kvarntorp"] = side_config(
+                    "note": "%d worlds x a closed lap of %d sweeps (%d distinct frames), every stream walks its lap" % (Ss, Fs, Ss * Fs)}
+        out["config2_mulran"] = side_config(api.odometry_preset("CFEAR-3", "mulran", submap_scan_size=5), 70000, 0.0595238, True, 1024, 32, 320)
+        c4 = side_config(
             api.odometry_params(filter_type=1, cacfar_range_res=0.175, cacfar_z_min=20.0, cacfar_nb_guard_cells=10,
                                 cacfar_window_size=40, cacfar_false_alarm_rate=0.01, radar_ccw=1, kstrong_range_res=0.175),
-            80000, 0.175, False, 512, 32, 8)
+            80000, 0.175, False, 512, 32, 480)
+        # the CA-CFAR rows kernel reads only the bins its arithmetic can reach (400 m cap, radar_driver.cpp:54: bin 2286 + guard
+        # + window of 3360); both the R*C figure and the bytes really requested are given
+        cr_ms = c4["kernel_breakdown"].get("cacfar_rows", 0.0)
+        if cr_ms > 0:
+            need_cols = min(COLS, (int(np.ceil(400.0 / 0.175)) + 10 + 40 + 15) // 16 * 16)
+            c4["roofline_cacfar_rows"] = {"bound": "hbm", "avg_launch_ms": cr_ms, "scans_per_launch": 512,
+                                          "achieved": IMG * 512 / (cr_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                          "frac": IMG * 512 / (cr_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                          "bytes_requested_per_scan": ROWS * need_cols,
+                                          "frac_of_bytes_requested": ROWS * need_cols * 512 / (cr_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+        c4["failed_registrations_note"] = ("status CFEAR_ERR_TOO_FEW_RESIDUALS (n_scan_normal.cpp:368-369) on the streams of the "
+                                           "feature-poor synthetic worlds (e.g. seed 80002: 16-47 surface points per sweep); the CPU "
+                                           "oracle fails on the same (world, frame) steps -- tools/cfar_failed.py, "
+                                           "tests/test_gpu_odometry.py::test_cacfar_pipeline_kvarntorp_preset")
+        out["config4_cacfar_kvarntorp"] = c4
         # ---- loop-closure candidates from cached features (configs[3]) ---------------------------------------
         lc = loopclosure_run(D, args.candidates, 20, 3)
-        out["loopclosure"] = {k: lc[k] for k in ("value", "unit", "ms_per_step", "ms_per_4096", "ok_fraction", "mean_outer_iters")}
+        out["loopclosure"] = {k: lc[k] for k in ("value", "unit", "ms_per_step", "ms_per_4096", "ok_fraction", "mean_outer_iters",
+                                                 "fixed_cost_ms", "kernel_ms", "collective", "distinct_scans")}
         out["loopclosure"]["candidates"] = args.candidates
 
     # ---- CPU baseline: the oracle (port), 1 thread, bounded sample of the same frames -----------------
@@ -722,18 +749,30 @@ def main(argv=None):
         reg = O.reg_params(cost="P2P", loss="Huber", loss_limit=0.1, weight_opt=4, regularization=0.0)
         done, tc0 = 0, time.perf_counter()
         err_xy, err_th = 0.0, 0.0
+        t_filter, stage1, stage1_frames = 0.0, {}, 0
         for sd in range(n_cmp):
             fz = O.Fuser(reg, res=3.0, submap_scan_size=4, weight_intensity=True)
             for f in range(n_frames_cpu):
+                tf0 = time.perf_counter()
                 sr, si, scn = O.kstrongest(host_rings[sd, f % F], K_STRONGEST, 60)
                 cloud = O.kstrongest_cloud(sr, si, scn, 0.0438, 2.5)
+                t_filter += time.perf_counter() - tf0
                 pose, oi = fz.process(cloud)
                 done += 1
                 d = np.abs(poses[f, sd] - pose)
                 d[2] = abs((d[2] + np.pi) % (2 * np.pi) - np.pi)
                 err_xy, err_th = max(err_xy, d[:2].max()), max(err_th, d[2])
+            st_sec, st_n = fz.stage_times()
+            for kk, vv in st_sec.items():
+                stage1[kk] = stage1.get(kk, 0.0) + vv
+            stage1_frames += st_n
         tc = time.perf_counter() - tc0
+        stage1["Filtering"] = t_filter
+        # per-stage CPU time per frame, named like the reference's `timing` keys (radar_driver.cpp:87, 111:
+        # "Filtering"; odometrykeyframefuser.cpp:253-255: "compensate", "build_normals", "register")
+        stage_ms_1 = {kk: vv / max(stage1_frames, 1) * 1e3 for kk, vv in stage1.items()}
         out["cpu_baseline"] = {"value": done / tc, "unit": "registrations/s", "cores": 1, "kind": "port",
+                               "stage_ms": stage_ms_1,
                                "sample": "%d frames = the first %d frames of %d of this run's streams, full path filter->pose, "
                                          "oracle/liboracle.so g++ -O3, 1 thread, %.1f s; host has %d cores"
                                          % (done, n_frames_cpu, n_cmp, tc, os.cpu_count())}
@@ -747,14 +786,19 @@ def main(argv=None):
         def one_sequence(i):
             fz = O.Fuser(reg, res=3.0, submap_scan_size=4, weight_intensity=True)
             fz.run_sequence(host_rings[i % n_cmp, :nseq_mt], K_STRONGEST, 60, 0.0438, 2.5)   # one native call per sequence
-            return nseq_mt
+            return nseq_mt, fz.stage_times()[0]
         n_tasks = 3 * T
         tm0 = time.perf_counter()
         with ThreadPoolExecutor(T) as ex:
-            done_mt = sum(ex.map(one_sequence, range(n_tasks)))
+            res_mt = list(ex.map(one_sequence, range(n_tasks)))
         tm = time.perf_counter() - tm0
+        done_mt = sum(r[0] for r in res_mt)
+        stage_mt = {kk: sum(r[1][kk] for r in res_mt) / max(done_mt, 1) * 1e3 for kk in res_mt[0][1]}
         out["cpu_baseline_all_threads"] = {
             "value": done_mt / tm, "unit": "registrations/s", "cores": T, "kind": "port",
+            "stage_ms": stage_mt,
+            "stage_ms_note": "mean wall time per frame inside a worker thread while all %d threads run (shared caches and "
+                             "memory bandwidth included)" % T,
             "sample": "%d sequences x %d frames on %d threads (cgroup quota / affinity of this host: %d of %d CPUs), %.1f s"
                       % (n_tasks, nseq_mt, T, T, os.cpu_count() or 0, tm)}
     emit(D, out)

@@ -9,9 +9,16 @@
 #pragma once
 #include <cstdint>
 #include <algorithm>
+#include <cmath>
+#include <ctime>
+#include <iostream>
+#include <map>
+#include <memory>
 #include <stdexcept>
 #include <sstream>
 #include <string>
+#include <tuple>
+#include <utility>
 #include <vector>
 
 #include "cfear_hip.h"
@@ -28,6 +35,10 @@
 #include <boost/shared_ptr.hpp>
 #include <pcl/point_cloud.h>
 #include <pcl/point_types.h>
+#if __has_include(<cv_bridge/cv_bridge.h>)
+#define CFEAR_HIP_HAVE_CV_BRIDGE 1
+#include <cv_bridge/cv_bridge.h>
+#endif
 #endif
 #endif
 
@@ -149,6 +160,128 @@ inline void Compensate(Context& ctx, PointCloud& cloud, const Pose2d& mot, bool 
   if (!cloud.empty()) ctx.check(cfear_compensate(ctx.get(), &cloud[0].x, (int32_t)cloud.size(), m, ccw ? 1 : 0));
 }
 
+// ---- statistics.h:19-42 / statistics.cpp: the global `timing` the callers document their stage times into ----------
+class statistics {
+ public:
+  void Document(const std::string& name, const double& value, bool report = false) {
+    t_[name].push_back(value);
+    if (report) std::cout << "Statistics: \"" << name << "\" = " << value << std::endl;
+  }
+  void PresentStatistics() {
+    std::cout << "-------------- EXECUTION STATISTICS ---------------" << std::endl;
+    for (const auto& r : Compute())
+      std::cout << "\"" << std::get<0>(r) << "\" - mean: " << std::get<1>(r) << ", sigma: " << std::get<2>(r) << ", N: " << std::get<3>(r) << std::endl;
+    std::cout << "---------FINGERS CROSSED FOR GOOD RESUTLS --------" << std::endl;
+  }
+  std::string GetStatistics() {                                    // the text the evaluation scripts parse
+    std::string str;
+    for (const auto& r : Compute()) {
+      str += std::get<0>(r) + std::string(" avg, ") + std::to_string(std::get<1>(r)) + "\n";
+      str += std::get<0>(r) + std::string(" dev [\xcf\x83], ") + std::to_string(std::get<2>(r)) + "\n";   // "σ"; the VARIANCE, as in the reference
+      str += std::get<0>(r) + std::string(" count, ") + std::to_string(std::get<3>(r)) + "\n";
+    }
+    return str;
+  }
+ private:
+  typedef std::tuple<std::string, double, double, int> reports;    // name, mean, variance, N samples
+  std::vector<reports> Compute() const {
+    std::vector<reports> rep;
+    for (const auto& kv : t_) {
+      double sum = 0, var = 0;
+      for (double v : kv.second) sum += v;
+      const double mean = sum / (double)kv.second.size();
+      for (double v : kv.second) var += (v - mean) * (v - mean);
+      rep.emplace_back(kv.first, mean, var / (double)kv.second.size(), (int)kv.second.size());
+    }
+    return rep;
+  }
+  std::map<std::string, std::vector<double>> t_;
+};
+inline statistics& timing_singleton() { static statistics s; return s; }
+static statistics& timing = timing_singleton();                    // `extern statistics timing` (statistics.h:38), header-only
+inline double ToMs(double seconds) { return seconds * 1000.0; }
+template <class Duration> inline auto ToMs(const Duration& dur) -> decltype(dur.toNSec() / 1000000.0) { return dur.toNSec() / 1000000.0; }   // ros::Duration (:40)
+inline double ToMsClock(const double& t) { return 1000 * ((double)t) / ((double)CLOCKS_PER_SEC); }
+
+// ---- StructuredKStrongest (radar_filters.h:84-113, radar_filters.cpp:198-337): the constructor filters (FilterKstrongest +
+//      AxialNonMaxSupress), getPeaksFilteredPointCloud APPENDS the kept bins (all of them, or the peaks) to the cloud ------
+class StructuredKStrongest {
+ public:
+  StructuredKStrongest(Context& ctx, const uint8_t* image, int rows, int cols, int stride, const int z_min, const int k_strongest,
+                       const double min_distance, const double range_res) {
+    cfear_polar_desc d{rows, cols, stride, 1, 0};
+    cfear_kstrong_params p{k_strongest, (float)z_min, (float)range_res, (float)min_distance, 1};
+    all_.resize((size_t)rows * k_strongest);
+    peaks_.resize((size_t)rows * k_strongest);
+    int32_t n = 0, n_pk = 0;
+    cfear_kstrong_out o{};
+    o.xyzi = &all_[0].x; o.n_points = &n; o.xyzi_peaks = &peaks_[0].x; o.n_peaks = &n_pk;
+    ctx.check(cfear_filter_kstrongest(ctx.get(), image, &d, &p, &o));
+    all_.resize(n);
+    peaks_.resize(n_pk);
+  }
+  void getPeaksFilteredPointCloud(PointCloud& output_pointcloud, bool peaks = false) const {
+    const PointCloud& src = peaks ? peaks_ : all_;
+    output_pointcloud.insert(output_pointcloud.end(), src.begin(), src.end());
+  }
+#ifdef CFEAR_HIP_HAVE_CV_BRIDGE
+  // the reference's signature (radar_filters.h:88, :90): a MONO8 cv_bridge image, clouds as pcl pointers (created when null)
+  StructuredKStrongest(const cv_bridge::CvImagePtr& radar_image, const int z_min, const int k_strongest, const double min_distance,
+                       const double range_res)
+      : StructuredKStrongest(Context::Default(), radar_image->image.data, radar_image->image.rows, radar_image->image.cols,
+                             (int)radar_image->image.step, z_min, k_strongest, min_distance, range_res) {}
+  void getPeaksFilteredPointCloud(pcl::PointCloud<pcl::PointXYZI>::Ptr& output_pointcloud, bool peaks = false) const {
+    if (!output_pointcloud) output_pointcloud = pcl::PointCloud<pcl::PointXYZI>::Ptr(new pcl::PointCloud<pcl::PointXYZI>());
+    for (const PointXYZI& q : (peaks ? peaks_ : all_)) {
+      pcl::PointXYZI p; p.x = q.x; p.y = q.y; p.z = q.z; p.intensity = q.intensity;
+      output_pointcloud->push_back(p);
+    }
+  }
+#endif
+ private:
+  PointCloud all_, peaks_;
+};
+
+// k_strongest_filter (radar_filters.cpp:40-78, with InsertStrongestK :25-38): the legacy filter CorAl's kstrongRadar calls;
+// APPENDS to cloud
+inline void k_strongest_filter(Context& ctx, const uint8_t* image, int rows, int cols, int stride, PointCloud& cloud, int k_strongest,
+                               double z_min, double range_res, double min_distance) {
+  cfear_polar_desc d{rows, cols, stride, 1, 0};
+  PointCloud out((size_t)rows * k_strongest);
+  int32_t n = 0;
+  ctx.check(cfear_filter_kstrongest_legacy(ctx.get(), image, &d, k_strongest, z_min, range_res, min_distance, out.empty() ? nullptr : &out[0].x,
+                                           &n, rows * k_strongest));
+  cloud.insert(cloud.end(), out.begin(), out.begin() + n);
+}
+#ifdef CFEAR_HIP_HAVE_CV_BRIDGE
+inline void k_strongest_filter(cv_bridge::CvImagePtr& cv_polar_image, pcl::PointCloud<pcl::PointXYZI>::Ptr& cloud, int k_strongest,
+                               double z_min, double range_res, double min_distance) {          // radar_filters.cpp:40
+  if (!cloud) cloud = pcl::PointCloud<pcl::PointXYZI>::Ptr(new pcl::PointCloud<pcl::PointXYZI>());
+  PointCloud c;
+  k_strongest_filter(Context::Default(), cv_polar_image->image.data, cv_polar_image->image.rows, cv_polar_image->image.cols,
+                     (int)cv_polar_image->image.step, c, k_strongest, z_min, range_res, min_distance);
+  for (const PointXYZI& q : c) { pcl::PointXYZI p; p.x = q.x; p.y = q.y; p.z = q.z; p.intensity = q.intensity; cloud->push_back(p); }
+}
+#endif
+
+// cell::TransformCopy (pointnormal.cpp:515-529) on the POD cell.  The covariance follows the reference's expression literally:
+// C = R * T * cov_ * R.transpose() with T an Affine2d multiplies cov_'s COLUMNS as points -- (R R) cov + (R t) 1^T, then * R^T --
+// not the similarity transform R cov R^T one would expect; nothing in the reference reads cov_ of a transformed map.
+inline cfear_cell TransformCopy(const cfear_cell& c, const Pose2d& T) {
+  const double cs = std::cos(T.theta), sn = std::sin(T.theta);
+  const double R[4] = {cs, -sn, sn, cs};
+  const double RR[4] = {R[0] * R[0] + R[1] * R[2], R[0] * R[1] + R[1] * R[3], R[2] * R[0] + R[3] * R[2], R[2] * R[1] + R[3] * R[3]};
+  const double Rt[2] = {R[0] * T.x + R[1] * T.y, R[2] * T.x + R[3] * T.y};
+  const double M[4] = {RR[0] * c.cov[0] + RR[1] * c.cov[2] + Rt[0], RR[0] * c.cov[1] + RR[1] * c.cov[3] + Rt[0],
+                       RR[2] * c.cov[0] + RR[3] * c.cov[2] + Rt[1], RR[2] * c.cov[1] + RR[3] * c.cov[3] + Rt[1]};
+  cfear_cell o = c;
+  o.cov[0] = M[0] * R[0] + M[1] * R[1]; o.cov[1] = M[0] * R[2] + M[1] * R[3];     // M * R^T
+  o.cov[2] = M[2] * R[0] + M[3] * R[1]; o.cov[3] = M[2] * R[2] + M[3] * R[3];
+  o.mean[0] = R[0] * c.mean[0] + R[1] * c.mean[1] + T.x; o.mean[1] = R[2] * c.mean[0] + R[3] * c.mean[1] + T.y;
+  o.normal[0] = R[0] * c.normal[0] + R[1] * c.normal[1]; o.normal[1] = R[2] * c.normal[0] + R[3] * c.normal[1];
+  return o;
+}
+
 class MapPointNormal {
  public:
   static double& downsample_factor() { static double f = 1.0; return f; }                   // pointnormal.cpp:5
@@ -193,6 +326,9 @@ class MapPointNormal {
     return m;
   }
   std::vector<int> GetClosestIdx(const Eigen::Vector2d& p, double d) const { return GetClosestIdx(p(0), p(1), d); }                   // :238
+  boost::shared_ptr<MapPointNormal> TransformMap(const Eigen::Affine3d& T) {                                                          // :168
+    return boost::shared_ptr<MapPointNormal>(new MapPointNormal(ctx_, TransformCells(Affine3dToPose2d(T))));
+  }
 #endif
   ~MapPointNormal() { cfear_scan_destroy(scan_); }
   MapPointNormal(const MapPointNormal&) = delete;
@@ -203,6 +339,14 @@ class MapPointNormal {
     if (!c.empty()) { const int n = cfear_scan_get_cells(scan_, c.data(), (int32_t)c.size()); if (n < 0) ctx_.check(n); }
     return c;
   }
+  const cfear_cell& GetCell(const size_t i) { return cached()[i]; }                          // pointnormal.h:120
+  std::vector<cfear_cell> TransformCells(const Pose2d& T) {                                  // pointnormal.h:140
+    std::vector<cfear_cell> out = GetCells();
+    for (cfear_cell& c : out) c = TransformCopy(c, T);
+    return out;
+  }
+  // TransformMap (pointnormal.cpp:135-137 -> the constructor at :91-111): the cells moved into the frame T, searchable
+  std::unique_ptr<MapPointNormal> TransformMap(const Pose2d& T) { return std::unique_ptr<MapPointNormal>(new MapPointNormal(ctx_, TransformCells(T))); }
   std::vector<int> GetClosestIdx(double px, double py, double d) const {                     // pointnormal.cpp:238-254
     const double q[2] = {px, py};
     int32_t idx = -1;
@@ -262,11 +406,17 @@ class n_scan_normal_reg {
                     const weightoption opt = weightoption::Uniform)                           // n_scan_normal.h:35
       : n_scan_normal_reg(Context::Default(), (int)cost, (int)loss, loss_limit, (int)opt) {}
   // n_scan_normal.h:37 / n_scan_normal.cpp:82-185: on success EVERY Tsrc[i] is rewritten from its (x, y, theta) parameters
-  // (:176-177) and every reg_cov[i] is the constant diag(0.01, 0.01, 0, 0, 0, 1e-4) (:171-175); soft_constraints is never
-  // set by the shipped callers (offline_odometry.cpp:274) and is not built.
+  // (:176-177) and every reg_cov[i] is the constant diag(0.01, 0.01, 0, 0, 0, 1e-4) (:171-175).
+  // soft_constraints = true is REFUSED (CfearError, CFEAR_ERR_INVALID_ARGUMENT), not ignored: the reference's prior
+  // (n_scan_normal.cpp:371-375) is mahalanobisDistanceError created as AutoDiffCostFunction<..., 1, 3> (n_scan_normal.h:279-282)
+  // whose functor writes THREE residuals through an Eigen::Map (:271-275) -- two of them past the one-element output Ceres
+  // hands it.  Its result is undefined in the reference, so there is nothing to be identical to; the shipped callers pass
+  // false (offline_odometry.cpp:274, loopclosure.cpp:60).
   bool Register(std::vector<MapNormalPtr>& scans, std::vector<Eigen::Affine3d>& Tsrc, std::vector<Matrix6d>& reg_cov,
                 bool soft_constraints = false) {
-    (void)soft_constraints;
+    if (soft_constraints)
+      throw CfearError(CFEAR_ERR_INVALID_ARGUMENT, "Register(..., soft_constraints = true): the reference's prior is undefined "
+                                                   "behaviour (3 residuals written into a 1-residual block) and is not provided");
     std::vector<const MapPointNormal*> h(scans.size());
     std::vector<Pose2d> poses(scans.size());
     for (size_t i = 0; i < scans.size(); i++) { h[i] = scans[i].get(); poses[i] = Affine3dToPose2d(Tsrc[i]); }
@@ -414,6 +564,8 @@ class OdometryKeyframeFuser {
     std::vector<cfear_cell> cells;
     bool has_constraint = false;
     cfear_graph_constraint constraint{};
+    bool has_Tgt = false;
+    Pose2d Tgt{0, 0, 0};
   };
   void AddToGraph(int stream, const cfear_frame_info& info, uint64_t stamp = 0) {
     if ((int)graph_.size() < n_) graph_.resize((size_t)n_);
@@ -429,7 +581,39 @@ class OdometryKeyframeFuser {
     cfear_scan_destroy(s);
     if (got < 0) ctx_.check(got);
     nd.has_constraint = cfear_odometry_get_constraint(od_, stream, &nd.constraint) == CFEAR_OK;   // none for the first keyframe
+    if ((int)status_.size() < n_) status_.resize((size_t)n_);
+    if (!graph_[stream].empty()) {                             // a fused keyframe behind the first one
+      const GraphNode& last = graph_[stream].back();
+      status_[(size_t)stream].distance_traveled += std::hypot(nd.T.x - last.T.x, nd.T.y - last.T.y);
+      status_[(size_t)stream].frame_nr++;
+    }
     graph_[stream].push_back(std::move(nd));
+  }
+  // AddGroundTruth (odometrykeyframefuser.cpp:446-463): a node whose stamp appears in gt_vek receives Tgt / has_Tgt_
+  void AddGroundTruth(const std::vector<std::pair<uint64_t, Pose2d>>& gt_vek, int stream = 0) {
+    std::map<uint64_t, Pose2d> stamp_map;
+    for (const auto& gt : gt_vek) stamp_map[gt.first] = gt.second;
+    if ((size_t)stream >= graph_.size()) return;
+    for (GraphNode& nd : graph_[(size_t)stream]) {
+      const auto it = stamp_map.find(nd.stamp);
+      if (it != stamp_map.end()) { nd.Tgt = it->second; nd.has_Tgt = true; }
+    }
+  }
+#ifdef CFEAR_HIP_HAVE_EIGEN_PCL
+  // the reference's argument (odometrykeyframefuser.h:240): poseStampedVector = elements with .pose (Eigen::Affine3d) and .t (ros::Time)
+  template <class PoseStampedVector>
+  auto AddGroundTruth(PoseStampedVector& gt_vek) -> decltype(gt_vek.begin()->t.toNSec(), void()) {
+    std::vector<std::pair<uint64_t, Pose2d>> v;
+    for (auto&& gt : gt_vek) v.emplace_back((uint64_t)gt.t.toNSec(), Affine3dToPose2d(gt.pose));
+    AddGroundTruth(v, 0);
+  }
+#endif
+  // GetStatus (odometrykeyframefuser.h:234): distance_traveled grows by |Tkeydiff.translation()| and frame_nr_ by one with
+  // every fused keyframe after the first (odometrykeyframefuser.cpp:236, 243)
+  std::string GetStatus(int stream = 0) const {
+    const bool have = (size_t)stream < status_.size();
+    return "Distance traveled: " + std::to_string(have ? status_[(size_t)stream].distance_traveled : 0.0) +
+           ", nr sensor readings: " + std::to_string(have ? status_[(size_t)stream].frame_nr : 0u);
   }
   const GraphNode& GetLastNode(int stream = 0) const { return graph_.at((size_t)stream).back(); }
   size_t GraphSize(int stream = 0) const { return (size_t)stream < graph_.size() ? graph_[stream].size() : 0; }
@@ -442,6 +626,7 @@ class OdometryKeyframeFuser {
       const double xyt[3] = {g[i].T.x, g[i].T.y, g[i].T.theta};
       cfear_pose3d_from_xyt(xyt, &n.T);
       n.idx = g[i].idx; n.stamp = g[i].stamp;
+      if (g[i].has_Tgt) { const double gxyt[3] = {g[i].Tgt.x, g[i].Tgt.y, g[i].Tgt.theta}; cfear_pose3d_from_xyt(gxyt, &n.Tgt); n.has_Tgt = 1; }
       for (int k = 0; k < 16; k++) n.motion[k] = (k % 5 == 0) ? 1.0 : 0.0;            // motion_ = Identity
       n.cloud_peaks = cfear_graph_cloud{g[i].cloud_peaks.empty() ? nullptr : &g[i].cloud_peaks[0].x, (int32_t)g[i].cloud_peaks.size(), 0, g[i].stamp, nullptr};
       n.cloud_nopeaks = cfear_graph_cloud{g[i].cloud_nopeaks.empty() ? nullptr : &g[i].cloud_nopeaks[0].x, (int32_t)g[i].cloud_nopeaks.size(), 0, g[i].stamp, nullptr};
@@ -468,6 +653,8 @@ class OdometryKeyframeFuser {
   cfear_odometry* od_ = nullptr;
   int n_;
   std::vector<std::vector<GraphNode>> graph_;
+  struct Status { double distance_traveled = 0.0; unsigned frame_nr = 0; };
+  std::vector<Status> status_;
 };
 
 }  // namespace CFEAR_Radarodometry

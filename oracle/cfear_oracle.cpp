@@ -24,6 +24,7 @@
 
 #include <algorithm>
 #include <cfloat>
+#include <chrono>
 #include <cmath>
 #include <cstring>
 #include <limits>
@@ -1461,6 +1462,10 @@ struct orc_fuser {
   std::vector<Keyframe> keyframes;
   double cov_current[36];
   int cov_sampled = 0;
+  // wall time per stage (seconds), named like the reference's `timing` keys: "Filtering" (radar_driver.cpp:87, 111),
+  // "compensate" + "build_normals", "register" (odometrykeyframefuser.cpp:253-255) -- for bench.py's cpu_baseline.stage_ms
+  double t_stage[4] = {0, 0, 0, 0};
+  long long n_stage_frames = 0;
 };
 
 extern "C" orc_fuser* orc_fuser_create(const orc_fuser_params* p) {
@@ -1475,20 +1480,31 @@ extern "C" void orc_fuser_last_cov(const orc_fuser* f, double cov36[36], int32_t
   if (sampled) *sampled = f->cov_sampled;
 }
 extern "C" void orc_fuser_destroy(orc_fuser* f) { delete f; }
+// accumulated wall seconds {Filtering (run_sequence only), compensate, build_normals, register} and the frames they cover
+extern "C" void orc_fuser_stage_times(const orc_fuser* f, double seconds[4], int64_t* n_frames) {
+  for (int k = 0; k < 4; k++) seconds[k] = f->t_stage[k];
+  if (n_frames) *n_frames = f->n_stage_frames;
+}
 
 extern "C" int orc_fuser_process(orc_fuser* f, float* xyzi, int n, double pose_out[3], int32_t info[4]) {
   const orc_fuser_params& par = f->par;
   info[0] = info[1] = info[2] = info[3] = 0;
   const Aff2 TprevMot = f->Tmot;                                            // :146
+  const auto tw0 = std::chrono::steady_clock::now();
   if (par.compensate) {                                                     // :147-150
     double mot[3];
     aff_to_xyt(TprevMot, mot);
     orc_compensate(xyzi, n, mot, par.radar_ccw);
   }
+  const auto tw1 = std::chrono::steady_clock::now();
   const double origin[2] = {0, 0};
   std::vector<orc_cell> cur(std::max(n, 1));
   int nc = orc_surface_points(xyzi, n, par.res, par.downsample_factor, origin, par.weight_intensity,
                               cur.data(), (int)cur.size(), nullptr, nullptr);   // :161
+  const auto tw2 = std::chrono::steady_clock::now();
+  f->t_stage[1] += std::chrono::duration<double>(tw1 - tw0).count();
+  f->t_stage[2] += std::chrono::duration<double>(tw2 - tw1).count();
+  f->n_stage_frames++;
   if (nc < 0) return -1;
   cur.resize(nc);
   info[0] = nc;
@@ -1513,7 +1529,9 @@ extern "C" int orc_fuser_process(orc_fuser* f, float* xyzi, int n, double pose_o
   ncells[ns - 1] = nc;
   aff_to_xyt(Tguess, &poses[3 * (ns - 1)]);
   orc_reg_result rr;
+  const auto tw3 = std::chrono::steady_clock::now();
   orc_register(scans.data(), ncells.data(), ns, poses.data(), &par.reg, &rr);   // :186 (result shadowed)
+  f->t_stage[3] += std::chrono::duration<double>(std::chrono::steady_clock::now() - tw3).count();
   info[2] = rr.status; info[3] = rr.outer_iters;
   // cov_current = cov_vek.back() (:196): Register's constant diagonal on success (n_scan_normal.cpp:171-175),
   // FormatScans' Identity66 otherwise; replaced by the sampled covariance when enabled and valid (:203-208)
@@ -1573,8 +1591,10 @@ extern "C" int orc_fuser_run_sequence(orc_fuser* f, const uint8_t* imgs, int n_f
   std::vector<float> xyzi((size_t)rows * k * 4);
   for (int t = 0; t < n_frames; t++) {
     const uint8_t* img = imgs + (size_t)t * rows * cols;
+    const auto tf0 = std::chrono::steady_clock::now();
     orc_kstrongest(img, rows, cols, cols, k, z_min, sr.data(), si.data(), sc.data());
     const int n = orc_kstrongest_cloud(rows, k, sr.data(), si.data(), sc.data(), nullptr, range_res, min_distance, xyzi.data());
+    f->t_stage[0] += std::chrono::duration<double>(std::chrono::steady_clock::now() - tf0).count();
     int32_t info[4];
     const int rc = orc_fuser_process(f, xyzi.data(), n, poses_out + 3 * (size_t)t, info);
     if (rc != 0) return rc;

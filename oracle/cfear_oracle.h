@@ -159,6 +159,9 @@ typedef struct orc_fuser_params {
 typedef struct orc_fuser orc_fuser;
 orc_fuser* orc_fuser_create(const orc_fuser_params* p);
 void orc_fuser_destroy(orc_fuser* f);
+/* wall seconds spent in {Filtering (orc_fuser_run_sequence only), compensate, build_normals, register} so far, named
+ * like the reference's timing keys (radar_driver.cpp:87; odometrykeyframefuser.cpp:253-255), and the frames covered */
+void orc_fuser_stage_times(const orc_fuser* f, double seconds[4], int64_t* n_frames);
 /* cov_current after the last processed frame (row-major 6x6); *sampled = 1 if it is the sampled one. */
 void orc_fuser_last_cov(const orc_fuser* f, double cov36[36], int32_t* sampled);
 /* Feeds one filtered cloud (modified in place by compensation).  pose_out = Tcurrent (x,y,th).

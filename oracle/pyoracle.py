@@ -120,6 +120,8 @@ def lib():
         L.orc_fuser_create.restype = C.c_void_p
         L.orc_fuser_destroy.argtypes = [C.c_void_p]
         L.orc_fuser_destroy.restype = None
+        L.orc_fuser_stage_times.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
+        L.orc_fuser_stage_times.restype = None
         L.orc_fuser_process.argtypes = [C.c_void_p, f32p, C.c_int, f64p, i32p]
         L.orc_fuser_last_cov.argtypes = [C.c_void_p, f64p, i32p]
         L.orc_fuser_last_cov.restype = None
@@ -467,6 +469,13 @@ class Fuser:
                                           _p(poses, C.c_double))
         assert rc == 0
         return poses
+
+    def stage_times(self):
+        """{stage: seconds} accumulated so far, keys as the reference's `timing` names, + frames covered."""
+        sec = np.zeros(4, np.float64)
+        n = C.c_int64()
+        lib().orc_fuser_stage_times(self._h, _p(sec, C.c_double), C.byref(n))
+        return dict(Filtering=float(sec[0]), compensate=float(sec[1]), build_normals=float(sec[2]), register=float(sec[3])), int(n.value)
 
     def last_cov(self):
         """cov_current after the last frame -> (cov 6x6, sampled flag)."""

@@ -60,6 +60,41 @@ int main(int argc, char** argv) {
     fuser.pointcloudCallback(cloud[1], peaks, Tcurrent, 0.25, cov);
     const Pose2d fp = Affine3dToPose2d(Tcurrent);
     printf("%.17g %.17g %.17g %d\n", fp.x, fp.y, fp.theta, (int)fuser.updated);
+    // ---- the remaining symbols of SURVEY 8(b), in the reference's own argument types -----------------------------------
+    // TransformMap / GetCell (pointnormal.h:120, 168)
+    MapNormalPtr moved = m0->TransformMap(Pose2dToAffine3d(Pose2d{1.0, 2.0, 0.25}));
+    if (moved->GetSize() != m0->GetSize() || !(moved->GetCell(0).nsamples == m0->GetCell(0).nsamples)) return 4;
+    // soft_constraints = true is refused loudly, never ignored (n_scan_normal.cpp:371-375 is undefined behaviour there)
+    bool refused = false;
+    try { radar_reg.Register(scans_vek, T_vek, cov_vek, true); } catch (const CfearError& e) { refused = e.status == CFEAR_ERR_INVALID_ARGUMENT; }
+    if (!refused) return 5;
+    // AddGroundTruth(poseStampedVector&) (odometrykeyframefuser.h:240) + GetStatus (:234)
+    struct Stamp { uint64_t ns; uint64_t toNSec() const { return ns; } };
+    struct poseStamped { Eigen::Affine3d pose; Stamp t; };
+    std::vector<poseStamped> gt_vek;
+    gt_vek.push_back(poseStamped{Pose2dToAffine3d(Pose2d{1, 2, 0.5}), Stamp{0}});
+    fuser.AddGroundTruth(gt_vek);
+    if (fuser.GetStatus().find("Distance traveled: ") != 0) return 6;
+    // statistics timing / ToMs (statistics.h:38-40), as radar_driver.cpp:87 documents its stage time
+    struct Duration { int64_t ns; int64_t toNSec() const { return ns; } };
+    timing.Document("Filtering", ToMs(Duration{2500000}));
+    if (timing.GetStatistics().find("Filtering avg, 2.500000") != 0) return 7;
+#ifdef CFEAR_HIP_HAVE_CV_BRIDGE
+    // StructuredKStrongest(cv_bridge image, z_min, k, min_distance, range_res) + getPeaksFilteredPointCloud(cloud, peaks)
+    // (radar_driver.cpp:57-60) and k_strongest_filter (coral_alignment_quality ScanType.cpp:104-114)
+    cv_bridge::CvImagePtr cv_polar_image(new cv_bridge::CvImage());
+    cv_polar_image->image = cv::Mat(8, 256);
+    for (int r = 0; r < 8; r++) for (int c = 0; c < 256; c++) cv_polar_image->image.data[r * 256 + c] = (unsigned char)((r * 37 + c * 11) % 251);
+    StructuredKStrongest filt(cv_polar_image, 60, 12, 2.5, 0.0438);
+    pcl::PointCloud<pcl::PointXYZI>::Ptr cloud_filtered, cloud_filtered_peaks;     // null: the filter allocates, like the reference
+    filt.getPeaksFilteredPointCloud(cloud_filtered, false);
+    filt.getPeaksFilteredPointCloud(cloud_filtered_peaks, true);
+    pcl::PointCloud<pcl::PointXYZI>::Ptr legacy;
+    k_strongest_filter(cv_polar_image, legacy, 12, 60, 0.0438, 2.5);
+    if (!cloud_filtered || cloud_filtered->size() == 0 || cloud_filtered_peaks->size() > cloud_filtered->size() || !legacy) return 8;
+#else
+#error "the cv_bridge stand-in was not found"
+#endif
   } catch (const CfearError& e) {
     fprintf(stderr, "%s\n", e.what());
     return 1;

@@ -7,8 +7,10 @@
 // (cov_*: covariance by cost sampling with the loop-closure constants, loopclosure.cpp:108-112; the last eight: the
 // pair verified as a loop candidate, frame 1 = query, frame 0 = candidate, through tbv_slam::VerifyLoopCandidates).
 // With a fifth argument "bins-major" the file holds [2][cols][rows] images as a non-Oxford driver publishes them.
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -108,9 +110,37 @@ int main(int argc, char** argv) {
     ctx.check(cfear_graph_node_at(g, cfear_graph_size(g) - 1, &last));
     double lxyt[3];
     cfear_pose3d_to_xyt(&last.T, lxyt);
-    printf(" %zu %d %d %d %d %.12g %.12g %.12g %llu\n", fuser.GraphSize(), cfear_graph_size(g), last.n_cells, last.cloud_peaks.n,
+    printf(" %zu %d %d %d %d %.12g %.12g %.12g %llu", fuser.GraphSize(), cfear_graph_size(g), last.n_cells, last.cloud_peaks.n,
            last.n_constraints, lxyt[0], lxyt[1], lxyt[2], (unsigned long long)fuser.GetLastNode().stamp);
     cfear_graph_destroy(g);
+    // ---- the smaller boundary symbols: StructuredKStrongest, k_strongest_filter, GetCell / TransformMap,
+    //      AddGroundTruth / GetStatus, timing / ToMs -------------------------------------------------------------------
+    int small_ok = 1;
+    if (!bins_major) {
+      StructuredKStrongest filt(ctx, img.data(), rows, cols, cols, 60, 40, 2.5, 0.0438);
+      PointCloud all, peaks;
+      filt.getPeaksFilteredPointCloud(all, false);
+      filt.getPeaksFilteredPointCloud(peaks, true);
+      filt.getPeaksFilteredPointCloud(peaks, true);            // appends, like the reference's push_back loop
+      small_ok &= all.size() == c0.size() && peaks.size() == 2 * pk0.size();
+      for (size_t i = 0; i < all.size() && small_ok; i++) small_ok &= all[i].x == c0[i].x && all[i].y == c0[i].y && all[i].intensity == c0[i].intensity;
+      for (size_t i = 0; i < pk0.size() && small_ok; i++) small_ok &= peaks[i].x == pk0[i].x && peaks[pk0.size() + i].y == pk0[i].y;
+    }
+    PointCloud legacy;
+    if (!bins_major) k_strongest_filter(ctx, img.data(), rows, cols, cols, legacy, 12, 60.0, 0.0438, 2.5);
+    const cfear_cell& cell0 = m0.GetCell(0);
+    const Pose2d Tm{1.5, -0.5, 0.3};
+    const std::unique_ptr<MapPointNormal> moved = m0.TransformMap(Tm);
+    const cfear_cell& mc0 = moved->GetCell(0);
+    const double ex = std::cos(0.3) * cell0.mean[0] - std::sin(0.3) * cell0.mean[1] + 1.5, ey = std::sin(0.3) * cell0.mean[0] + std::cos(0.3) * cell0.mean[1] - 0.5;
+    small_ok &= moved->GetSize() == m0.GetSize() && std::fabs(mc0.mean[0] - ex) < 1e-12 && std::fabs(mc0.mean[1] - ey) < 1e-12;
+    const std::vector<int> near = moved->GetClosestIdx(ex, ey, 0.5);
+    small_ok &= near.size() == 1 && near[0] == 0;
+    fuser.AddGroundTruth({{2000, Pose2d{2.5, 0.25, 0.125}}, {777, Pose2d{9, 9, 9}}});
+    small_ok &= fuser.GetLastNode().has_Tgt && fuser.GetLastNode().Tgt.x == 2.5 && !fuser.GetStatus().empty();
+    timing.Document("Filtering", 1.0); timing.Document("Filtering", 3.0);
+    small_ok &= timing.GetStatistics().find("Filtering avg, 2.000000\nFiltering dev [") == 0 && ToMs(0.25) == 250.0;
+    printf(" %d %zu %s\n", small_ok, legacy.size(), fuser.GetStatus().c_str());
   } catch (const CfearError& e) {
     fprintf(stderr, "cfear error %d: %s\n", e.status, e.what());
     return 1;

@@ -100,6 +100,15 @@ def test_cpp_mirror_matches_oracle(tmp_path, layout):
     assert int(v[33]) == finfo[0] and int(v[34]) == pk[1].shape[0] and int(v[35]) == 1
     np.testing.assert_allclose([float(x) for x in v[36:39]], gp, rtol=0, atol=1e-12)
     assert int(v[39]) == 2000
+    # StructuredKStrongest == the driver's clouds, TransformMap / GetCell / AddGroundTruth / timing / ToMs checked in C++
+    assert int(v[40]) == 1
+    if layout == "oxford":                                  # k_strongest_filter (legacy rule, k = 12) against the oracle
+        legacy = O.kstrongest_legacy(imgs[0], 12, 60.0, 0.0438, 2.5)
+        assert int(v[41]) == legacy.shape[0]
+    # GetStatus: one fused keyframe behind the first, its distance from the first
+    status = " ".join(v[42:])
+    assert status.startswith("Distance traveled: ") and status.endswith("nr sensor readings: 1")
+    np.testing.assert_allclose(float(status.split(":")[1].split(",")[0]), np.hypot(gp[0], gp[1]), atol=1e-6)
 
 
 def _build_ref_signatures(tmp_path):

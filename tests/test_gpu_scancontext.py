@@ -185,6 +185,13 @@ def test_rsc_manager_finds_the_revisit(odom_coupled, augment):
         assert [c["nn_idx"] for c in g] == [c[2] for c in e]
         np.testing.assert_allclose([c["min_dist"] for c in g], [c[0] for c in e], rtol=1e-12, atol=1e-15)
         assert [c["argmin_shift"] for c in g] == [c[3] for c in e]
+    if not odom_coupled:
+        # VanillaKDNNSearch asks a kd-tree that is rebuilt on every 50th call only (RadarScancontext.cpp:227): over these 18
+        # calls it is the tree of the first searchable moment -- node 0 alone -- so every proposal is node 0 (the rest of the
+        # zero-initialised index vector).  That IS the reference's behaviour on a short run; equality with the restatement
+        # (which runs the reference's own nanoflann tree when oracle/_ref is built) is the assertion above.
+        assert all(c["nn_idx"] == 0 for g in got for c in g)
+        return
     for j in range(4):                                   # the revisits are found, with the 90 degree column shift
         best = got[14 + j][0]
         assert best["nn_idx"] == j and best["min_dist_sc"] < 0.15

@@ -1,11 +1,11 @@
 #!/bin/bash
 # rocprofv3 passes behind the numbers in bench.py / DESIGN.md.  Run on the GPU box from the repo root:
-#   bash tools/profile.sh r02
+#   bash tools/profile.sh r03
 # Raw output goes to /tmp (a kernel trace of torch's input generation is hundreds of MB); the judged summaries land under
 # gpurun_out/profiles_<tag>/ (copy them into profiles/<tag>/).  Counters are collected in their own passes (no trace
 # domains mixed in).
 set -u
-TAG=${1:-r02}
+TAG=${1:-r03}
 ROOT=$(pwd)
 OUT=/tmp/prof_$TAG
 SUM=$ROOT/gpurun_out/profiles_$TAG
@@ -41,8 +41,17 @@ for DATA in scene dense uniform; do
   ( cd /tmp && rocprofv3 --output-format csv --kernel-trace --stats -d "$OUT/filter_$DATA" -o f -- python "$ROOT/tools/bench_filter.py" --data $DATA > "$SUM/filter_${DATA}_stdout.txt" 2> "$OUT/filter_$DATA.err" )
   keep_ours "$OUT/filter_$DATA" "$SUM/filter_${DATA}_kernel_stats.csv"; rm -rf "$OUT/filter_$DATA"
 done
-( cd /tmp && rocprofv3 --output-format csv --pmc FETCH_SIZE -d "$OUT/pmc_fetch" -o p -- python "$ROOT/tools/bench_filter.py" --iters 5 > /dev/null 2> "$OUT/pmc_fetch.err" )
-( cd /tmp && rocprofv3 --output-format csv --pmc WRITE_SIZE -d "$OUT/pmc_write" -o p -- python "$ROOT/tools/bench_filter.py" --iters 5 > /dev/null 2> "$OUT/pmc_write.err" )
+# HBM traffic of the sweep AS IT RUNS IN THE HEADLINE PIPELINE (fused: 4-byte keys per kept bin, no cloud): the default bench
+# command's configuration at a small batch (counter collection serialises every dispatch), kernel-filtered afterwards
+PIPE_ARGS="--no-cpu-baseline --no-extras --steps 1 --warmup 1 --frames-per-step 4 --streams 512 --sequences 32"
+( cd /tmp && timeout 900 rocprofv3 --output-format csv --pmc FETCH_SIZE -d "$OUT/pmc_fetch" -o p -- python "$ROOT/bench.py" $PIPE_ARGS > /dev/null 2> "$OUT/pmc_fetch.err" )
+( cd /tmp && timeout 900 rocprofv3 --output-format csv --pmc WRITE_SIZE -d "$OUT/pmc_write" -o p -- python "$ROOT/bench.py" $PIPE_ARGS > /dev/null 2> "$OUT/pmc_write.err" )
+export CFEAR_PMC_IMAGES=512
+# CA-CFAR pipeline (BASELINE configs[4]): kernel trace + SQ counters of tools/cfar_events.py (512 Kvarntorp sweeps per launch)
+( cd /tmp && rocprofv3 --output-format csv --kernel-trace --stats -d "$OUT/cacfar" -o c -- python "$ROOT/tools/cfar_events.py" 512 > "$SUM/cacfar_stdout.txt" 2> "$OUT/cacfar.err" )
+keep_ours "$OUT/cacfar" "$SUM/cacfar_kernel_stats.csv"; rm -rf "$OUT/cacfar"
+( cd /tmp && timeout 900 rocprofv3 --output-format csv --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU -d "$OUT/pmc_cacfar" -o p -- python "$ROOT/tools/cfar_events.py" 512 > /dev/null 2> "$OUT/pmc_cacfar.err" )
+( cd /tmp && timeout 900 rocprofv3 --output-format csv --pmc FETCH_SIZE -d "$OUT/pmc_cacfar_fetch" -o p -- python "$ROOT/tools/cfar_events.py" 512 > /dev/null 2> "$OUT/pmc_cacfar_fetch.err" )
 ( cd /tmp && rocprofv3 --output-format csv --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU -d "$OUT/pmc_sq" -o p -- python "$ROOT/tools/bench_filter.py" --iters 5 > /dev/null 2> "$OUT/pmc_sq.err" )
 ( cd /tmp && rocprofv3 --output-format csv --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU -d "$OUT/pmc_sq_dense" -o p -- python "$ROOT/tools/bench_filter.py" --iters 5 --data dense > /dev/null 2> "$OUT/pmc_sq_dense.err" )
 # whole pipeline under the SQ counters, SMALL run (counter collection serialises every dispatch)
