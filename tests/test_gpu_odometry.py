@@ -100,6 +100,65 @@ def test_cacfar_pipeline_kvarntorp_preset():
                 assert info["outer_iters"][b] == oi[3], (f, b)
 
 
+def test_cacfar_pipeline_fused_keys_special_rows():
+    """The fused CA-CFAR hand-over (cacfar_rows_kernel -> per-row keys -> surface_prep_kernel) away from the preset:
+    (a) more than 16 384 detections per sweep (false-alarm rate 0.05: ~41 000): the scan leaves the fast pipeline and the single-kernel
+        path converts the row keys itself;
+    (b) images whose rows cannot be read in 16-byte pieces (3350 columns): the byte-copy path of the rows kernel;
+    (c) a range window that cuts the row at both ends (min / max distance) with a window that the first bins cut.
+    Point counts, cell counts and poses equal the oracle's, frame by frame."""
+    from oracle import pyoracle as O
+    from tbv_slam_public_amd import api, synth
+    n_frames = 3
+    base = synth.scene_v1(13, n_frames, range_res=0.175, ccw=True)[0]
+    reg = O.reg_params(cost="P2P", loss="Huber", loss_limit=0.1, weight_opt=4, regularization=0.0)
+    cases = [dict(cols=3360, pfa=0.05, z=20.0, win=40, guard=10, mind=2.5, min_pts=16385),
+             dict(cols=3350, pfa=0.01, z=20.0, win=40, guard=10, mind=2.5, min_pts=500),
+             dict(cols=3360, pfa=0.02, z=30.0, win=24, guard=4, mind=1.0, min_pts=500)]
+    for c in cases:
+        seq = np.ascontiguousarray(base[:, :, :c["cols"]])
+        par = api.odometry_params(filter_type=1, cacfar_range_res=0.175, cacfar_z_min=c["z"], cacfar_nb_guard_cells=c["guard"],
+                                  cacfar_window_size=c["win"], cacfar_false_alarm_rate=c["pfa"], cacfar_min_distance=c["mind"],
+                                  radar_ccw=1, kstrong_range_res=0.175)
+        od = api.OdometryKeyframeFuser(1, 400, c["cols"], par)
+        fz = O.Fuser(reg, res=3.0, submap_scan_size=4, weight_intensity=True, radar_ccw=True)
+        for f in range(n_frames):
+            info = od.process(seq[f:f + 1])
+            cloud, _ = O.cacfar(seq[f], c["win"], c["guard"], c["pfa"], 0.175, c["z"], c["mind"])
+            assert cloud.shape[0] >= c["min_pts"], (c, cloud.shape[0])
+            pose, oi = fz.process(cloud)
+            assert info["n_points"][0] == cloud.shape[0], (c, f)
+            assert info["n_cells"][0] == oi[0], (c, f, info["n_cells"][0], oi[0])
+            d = np.abs(info["pose"][0] - pose)
+            assert d[:2].max() <= POS_TOL and d[2] <= ROT_TOL, (c, f, d)
+        od.close()
+
+
+def test_cacfar_pipeline_row_beyond_key_capacity_is_reported():
+    """A row with more detections than the 1024 keys the fused hand-over keeps per row marks its scan CFEAR_ERR_CAPACITY
+    (like a sweep beyond cap_points) instead of dropping detections silently; the other stream of the batch is unaffected."""
+    from tbv_slam_public_amd import api, _lib as L, synth
+    imgs = synth.scene_v1(14, 1, range_res=0.175, ccw=True)[0]
+    bad = imgs[0].copy()
+    rng = np.random.default_rng(0)
+    # every other bin of one row far above its neighbours: ~1100 detections in that row
+    bad[7, 60:2260:2] = 250
+    bad[7, 61:2261:2] = rng.integers(0, 8, 1100)
+    # (with the presets' false-alarm rate 0.01 the CFAR scaling is >= 4.6: fewer than a quarter of a row's bins can fire, so
+    # the 1024 keys cannot overflow on a 3360-bin row; it takes a rate like 0.2 and a short window)
+    par = api.odometry_params(filter_type=1, cacfar_range_res=0.175, cacfar_z_min=60.0, cacfar_nb_guard_cells=2,
+                              cacfar_window_size=8, cacfar_false_alarm_rate=0.2, radar_ccw=1, kstrong_range_res=0.175)
+    od = api.OdometryKeyframeFuser(2, 400, 3360, par)
+    try:
+        info = od.process(np.stack([bad, imgs[0]]))
+    except L.CfearError as e:                              # the call reports the first per-stream status; info is filled
+        assert e.status == L.ERR_CAPACITY
+        info = od._info
+    assert info["reg_status"][0] == L.ERR_CAPACITY or info["n_cells"][0] == 0
+    assert info["n_cells"][1] > 50
+    od.close()
+
+
 @pytest.mark.parametrize("device_input", [False, True])
 def test_rotated_input_layout_equals_prerotated(device_input):
     """par.rotate_ccw: images arrive as [range bins][azimuths] (non-Oxford drivers, radar_driver.cpp:74-90); the
