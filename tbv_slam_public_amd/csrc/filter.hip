@@ -716,7 +716,9 @@ struct CfarArgs {
 //     1e-3 of B:  fires <=> 2 S + 1 < lut[I];  2 S + 1 == lut[I] (practically never) and bins whose windows the row's ends
 //     cut take cfar.cpp:45-60 literally in fp64.
 //  D. detections leave in list (= bin) order: as keys for surface_prep_kernel (batched odometry) or as a bit per bin.
-constexpr int kCfarList = 1024 + 64 + 64;  // one chunk's candidates + the carried remainder
+constexpr int kCfarList = 1024 + 64 + 64;  // one chunk's candidates + the carried remainder (a 576-entry list with windowed
+                                           // appends admits a fifth workgroup per CU and measured 4 % SLOWER: the kernel is
+                                           // bound by VALU issue, not by latency)
 __host__ __device__ inline size_t cfar_wave_lds(int colsp, int pad_lo, int pad_hi, bool keys) {
   // P4 u32[pad_lo + colsp / 4 + 1 + pad_hi] | raw u8[colsp + 16] | det u32[colsp / 32] (bitmap output) | list u16[kCfarList]
   size_t b = ((size_t)(pad_lo + colsp / 4 + 1 + pad_hi) * 4 + 15) & ~(size_t)15;
@@ -902,6 +904,8 @@ __global__ __launch_bounds__(256) void cacfar_rows_kernel(const CfarArgs a) {
           const float f = __builtin_amdgcn_sqrtf((float)slb * a.kappa_lb);  // <= sqrt(kappa S_lb): kappa_lb carries the slack
           t = max(t, (int)f);
         }
+        t = min(t, 255);                                                     // (a threshold above 255 lets 255 through: harmless, the
+                                                                             //  list is decided exactly; thr_i = 256 empties the window on the host)
         const uint32_t tl = (uint32_t)(t & 0x7f);
         const uint32_t lo4 = __builtin_amdgcn_perm(tl, tl, 0u);               // the byte in all four places
         const uint32_t nhi = (t & 0x80) ? 0u : 0xffffffffu;
@@ -909,15 +913,14 @@ __global__ __launch_bounds__(256) void cacfar_rows_kernel(const CfarArgs a) {
         const uint32_t y0 = (x0 | 0x80808080u) - lo4, y1 = (x1 | 0x80808080u) - lo4;
         const uint32_t ge0 = (y0 & x0) | ((y0 | x0) & nhi);                  // bit 7 of every byte: byte >= t
         const uint32_t ge1 = (y1 & x1) | ((y1 | x1) & nhi);
-        // gather the eight verdict bits: byte k of z holds dword 0's verdict at bit 0 and dword 1's at bit 4; the product
-        // z * 0x01020408 puts bit 8 k + j at 24 + k + j (j = 0, 4; no two partial products meet), so its top byte is the mask
+        // gather the eight verdict bits: byte k of z holds dword 0's verdict at bit 0 and dword 1's at bit 4, and the dot
+        // product of z's bytes with (1, 2, 4, 8) is the mask (one full-rate v_dot4 instead of a 32-bit multiply)
         const uint32_t z = ((ge0 >> 7) & 0x01010101u) | ((ge1 >> 3) & 0x10101010u);
-        uint32_t m8 = (z * 0x01020408u) >> 24;
-        if (t > 255) m8 = 0u;
+        const uint32_t m8 = __builtin_amdgcn_udot4(z, 0x08040201u, 0u, false);
         cmask |= m8 << (8 * h);
       }
-      {                                                                     // range window: bins [bin_lo, bin_hi) of this lane's 16
-        const int lo = min(16, max(0, a.bin_lo - pos)), hi = min(16, max(0, a.bin_hi - pos));
+      if (a.bin_lo > j * 1024 || a.bin_hi < j * 1024 + 1024) {              // range window: bins [bin_lo, bin_hi) of this lane's 16
+        const int lo = min(16, max(0, a.bin_lo - pos)), hi = min(16, max(0, a.bin_hi - pos));   // (chunks inside the window skip this)
         const uint32_t win = hi > lo ? ((hi >= 16 ? 0xffffu : ((1u << hi) - 1u)) & ~((1u << lo) - 1u)) : 0u;
         cmask &= win;
       }
