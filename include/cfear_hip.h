@@ -258,7 +258,13 @@ int cfear_register(cfear_ctx* ctx, const cfear_scan* const* scans, int32_t n_sca
  * loopclosure.cpp:35-97 called per candidate from :658-721).  results: host memory (the call
  * returns after the read-back) or DEVICE memory (the records stay on the GPU; the launch is
  * enqueued on the context's stream and not synchronised -- what a collective over the records
- * wants, cfear_register_batch_sharded).                                                        */
+ * wants, cfear_register_batch_sharded).
+ * Batches of up to 64 jobs run with 8 wavefronts per registration (latency), larger ones with 4
+ * (throughput); the two geometries add the fp64 sums in different orders, so the SAME job may
+ * differ by a few ulp of cost / pose between a small and a large batch -- e.g. between world 1 and
+ * a sharded run whose per-rank block falls below 65.  Iteration counts and the accept / reject
+ * decisions are the same in every test of this repository (tests/test_gpu_register.py), the poses
+ * agree to 1e-12.                                                                              */
 typedef struct cfear_reg_job {
   const cfear_scan* const* scans;       /* n_scans handles */
   int32_t n_scans;

@@ -41,6 +41,7 @@ struct cfear_ctx {
   std::vector<Slab> free_slabs;
   int64_t live_scans = 0;
   int trig_rows = 0;       // rows the cos/sin tables in ws[2] were built for
+  bool surf_list_dirty = true;   // the surface pipeline's hand-over counter may be non-zero (see cfear_surface_launch)
 };
 
 int cfear_set_error(cfear_ctx* ctx, int status, const char* fmt, ...);

@@ -852,7 +852,7 @@ __global__ __launch_bounds__(kSurfThreads) void surface_points_kernel(const Surf
   // all LDS is carved from the dynamic region so its base stays 16-byte aligned (64-bit keys)
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   if (!cm.fallback) { surface_points_job(jobs, cm, blockIdx.x, smem); return; }
-  const int count = cm.fallback[0];           // persistent over the (usually empty) list of handed-over scans
+  const int count = min(cm.fallback[0], cm.n_jobs);   // persistent over the (usually empty) list of handed-over scans
   for (int w = blockIdx.x; w < count; w += gridDim.x) {
     surface_points_job(jobs, cm, cm.fallback[1 + w], smem);
     __syncthreads();
@@ -902,7 +902,7 @@ __global__ __launch_bounds__(kFastThreads) void surface_prep_kernel(const SurfJo
       scr.hdr->n = n;
       scr.hdr->pad[0] = prepared;                                      // 1: xyzi already holds the compact, compensated cloud
       const int w = atomicAdd(&cm.fallback[0], 1);
-      cm.fallback[1 + w] = job_id;
+      if (w < cm.n_jobs) cm.fallback[1 + w] = job_id;         // (a stale count can never index past the list)
     }
   };
   if (!cm.fast_ok || (job.row_pts != nullptr) != ROWS) { hand_over(0, 0); return; }
@@ -1036,7 +1036,7 @@ __global__ __launch_bounds__(kFastThreads, 4) void surface_sort_kernel(const Sur
       scr.hdr->n = n;
       scr.hdr->pad[0] = prepared;                                      // 1: xyzi already holds the compact, compensated cloud
       const int w = atomicAdd(&cm.fallback[0], 1);
-      cm.fallback[1 + w] = job_id;
+      if (w < cm.n_jobs) cm.fallback[1 + w] = job_id;         // (a stale count can never index past the list)
     }
   };
 #ifdef CFEAR_SURF_TIMING
@@ -1586,10 +1586,15 @@ int cfear_surface_launch(cfear_ctx* ctx, const void* d_jobs, int n_jobs, const c
   cm.fast_ok = cm.reach == 1 ? 1 : 0;
   // work list of the scans the fast pipeline hands to the single-kernel path: count + job ids
   // (its counter is zeroed by surface_finish_kernel for the next launch; a fresh allocation is zeroed here)
-  const void* ws_before = ctx->ws[11].p;
+  // (the counter is zeroed by surface_finish_kernel for the next launch; it is zeroed HERE when the workspace was (re)allocated
+  // -- hipFree + hipMalloc may hand back the same address -- or when the previous launch sequence did not reach its finish
+  // kernel: ctx->surf_list_dirty stays set from before the first launch until after the last one was enqueued without error)
+  const size_t ws_bytes_before = ctx->ws[11].bytes;
   cm.fallback = (int32_t*)cfear_workspace(ctx, 11, ((size_t)n_jobs + 16) * 4);
   if (!cm.fallback) return cfear_set_error(ctx, CFEAR_ERR_HIP, "workspace allocation failed");
-  if (cm.fallback != ws_before) CFEAR_HIP_CHECK(ctx, hipMemsetAsync(cm.fallback, 0, 4, ctx->stream));
+  if (ctx->ws[11].bytes != ws_bytes_before || ctx->surf_list_dirty)
+    CFEAR_HIP_CHECK(ctx, hipMemsetAsync(cm.fallback, 0, 4, ctx->stream));
+  ctx->surf_list_dirty = true;
   // per launch: the attribute is per device, and contexts on other threads / devices share this code
   CFEAR_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)surface_points_kernel,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)cfear_surface_lds_bytes()));
@@ -1631,6 +1636,7 @@ int cfear_surface_launch(cfear_ctx* ctx, const void* d_jobs, int n_jobs, const c
     hipLaunchKernelGGL(surface_finish_kernel, dim3(n_jobs), dim3(kFinishThreads), finish_lds, ctx->stream, (const SurfJob*)d_jobs, cm);
   }
   CFEAR_HIP_CHECK(ctx, hipGetLastError());
+  ctx->surf_list_dirty = false;                              // the finish kernel is enqueued: it leaves the counter at zero
 #ifdef CFEAR_SURF_TIMING
   {                                            // debug build only: phase split of surface_sort_kernel, averaged over the jobs
     static int calls = 0;

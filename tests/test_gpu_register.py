@@ -447,6 +447,34 @@ def test_sharded_c_abi_entry_world_one_and_mock_world_two():
     assert rc != 0 and len(entered) == 1 and entered[0][0] == rc
 
 
+def test_small_and_large_batches_agree():
+    """Batches of <= 64 jobs run on the 8-wavefront kernel, larger ones on the 4-wavefront kernel (different summation
+    order): the same nine registrations alone and inside a batch of 108 agree in every integer outcome and to 1e-12 in the
+    pose -- what a sharded run relies on when its per-rank block falls below 65 jobs."""
+    from tbv_slam_public_amd import api, synth
+    imgs, gt, _ = synth.scene_v1(17, 4)
+    scans = []
+    for f in range(4):
+        r = api.filter_kstrongest(imgs[f], 40, 60, 0.0438, 2.5)
+        scans.append(api.MapPointNormal(r["xyzi"][0, :int(r["n_points"][0])], 3.0, (0, 0), True))
+    rng = np.random.default_rng(3)
+    jobs = []
+    for q in range(9):
+        i, j = (q % 3), (q % 3) + 1
+        jobs.append(([scans[i], scans[j]], np.array([[0, 0, 0.0], gt[j] - gt[i] + rng.normal(0, 0.2, 3) * [1, 1, 0.05]])))
+    reg = api.n_scan_normal_reg("P2L")
+    reg.SetParameters(4, 10)
+    small = reg.RegisterBatch(jobs)
+    large = reg.RegisterBatch(jobs * 12)
+    for q in range(9):
+        for rep in range(12):
+            b = large[rep * 9 + q]
+            assert b["status"] == small[q]["status"] and b["outer_iters"] == small[q]["outer_iters"]
+            assert b["lm_iters"] == small[q]["lm_iters"] and b["num_residuals"] == small[q]["num_residuals"]
+            np.testing.assert_allclose(b["pose"], small[q]["pose"], rtol=0, atol=1e-12)
+            np.testing.assert_allclose(b["final_cost"], small[q]["final_cost"], rtol=1e-11)
+
+
 def _rccl():
     """librccl through ctypes: a ONE-rank communicator (ncclGetUniqueId + ncclCommInitRank), as a C++ host would own it."""
     import ctypes as C
