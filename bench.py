@@ -429,7 +429,9 @@ def main(argv=None):
     ap.add_argument("--frames-per-step", type=int, default=32,
                     help="consecutive frames every stream advances per step (a step = one pass of the hot path over "
                          "streams x frames_per_step sweeps)")
-    ap.add_argument("--streams", type=int, default=2048, help="independent sequences per GPU")
+    ap.add_argument("--streams", type=int, default=4096,
+                    help="independent sequences per GPU, one frame each per frame batch (2048 fills the chip once; 4096 halves the "
+                         "share of the uneven last registrations of a batch: +6 %% registrations/s at twice the batch latency)")
     ap.add_argument("--sequences", type=int, default=256, help="distinct synthetic worlds per GPU (streams = worlds x start frames)")
     ap.add_argument("--ring", type=int, default=64, help="frames of the closed circle every world is rendered along")
     ap.add_argument("--cpu-frames", type=int, default=0, help="frames of CPU baseline (0 = auto, ~10-30 s)")

@@ -716,32 +716,39 @@ struct CfarArgs {
 //     1e-3 of B:  fires <=> 2 S + 1 < lut[I];  2 S + 1 == lut[I] (practically never) and bins whose windows the row's ends
 //     cut take cfar.cpp:45-60 literally in fp64.
 //  D. detections leave in list (= bin) order: as keys for surface_prep_kernel (batched odometry) or as a bit per bin.
-constexpr int kCfarList = 1024 + 64 + 64;  // one chunk's candidates + the carried remainder (a 576-entry list with windowed
+constexpr int kCfarListSlack = 64 + 64;     // list entries = one chunk's bins + the carried remainder (a 576-entry list with windowed
                                            // appends admits a fifth workgroup per CU and measured 4 % SLOWER: the kernel is
                                            // bound by VALU issue, not by latency)
-__host__ __device__ inline size_t cfar_wave_lds(int colsp, int pad_lo, int pad_hi, bool keys) {
-  // P4 u32[pad_lo + colsp / 4 + 1 + pad_hi] | raw u8[colsp + 16] | det u32[colsp / 32] (bitmap output) | list u16[kCfarList]
+__host__ __device__ inline size_t cfar_wave_lds(int colsp, int pad_lo, int pad_hi, bool keys, int chunk_bins) {
+  // P4 u32[pad_lo + colsp / 4 + 1 + pad_hi] | raw u8[colsp + 16] | det u32[colsp / 32] (bitmap output) | list u16[chunk + slack]
   size_t b = ((size_t)(pad_lo + colsp / 4 + 1 + pad_hi) * 4 + 15) & ~(size_t)15;
   b += (size_t)colsp + 16;
   if (!keys) b += (size_t)colsp / 8;
-  b += (size_t)kCfarList * 2;
+  b += (size_t)(chunk_bins + kCfarListSlack) * 2;
   return (b + 15) & ~(size_t)15;
 }
-template <int NCH, bool KEYS, bool PRE>
+// D = dwords a lane owns per chunk (4, 6 or 8: a chunk is 256 D bins), NCH = chunks the registers hold.  The per-chunk
+// overhead (two wave scans, the list loop, the round bookkeeping) is paid per CHUNK, so the host picks the D that covers
+// the reachable bins with the fewest chunks: 2336 bins of a Kvarntorp row are 2 chunks of 1536 (D = 6) instead of 3 of
+// 1024, of which the third held 18 busy lanes and cost 18 % of the kernel.
+template <int D, int NCH, bool KEYS, bool PRE>
 __global__ __launch_bounds__(256) void cacfar_rows_kernel(const CfarArgs a) {
+  constexpr int CB = 256 * D;                                                // bins per chunk
+  constexpr int LB = 4 * D;                                                  // bytes (bins) per lane and chunk
+  typedef uint32_t u32x2 __attribute__((ext_vector_type(2), aligned(4)));
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   uint32_t* lut = (uint32_t*)smem;
   lut[threadIdx.x] = a.lut[threadIdx.x];
   __syncthreads();
   const int colsp = a.colsp;
-  uint8_t* wbase = smem + 1024 + (size_t)wave * cfar_wave_lds(colsp, a.pad_lo, a.pad_hi, KEYS);
+  uint8_t* wbase = smem + 1024 + (size_t)wave * cfar_wave_lds(colsp, a.pad_lo, a.pad_hi, KEYS, CB);
   uint32_t* P4 = (uint32_t*)wbase + a.pad_lo;                                // P4[i] = sum_{q < 4 i} I_q^2, i in [-pad_lo, colsp / 4 + pad_hi]
   uint8_t* raw = wbase + (((size_t)(a.pad_lo + colsp / 4 + 1 + a.pad_hi) * 4 + 15) & ~(size_t)15);   // the row itself
   uint32_t* det32 = (uint32_t*)(raw + colsp + 16);                           // detections, bit per bin (bitmap output)
   unsigned short* list = (unsigned short*)(raw + colsp + 16 + (KEYS ? 0 : colsp / 8));
   for (int i = lane; i < a.pad_lo; i += 64) P4[-1 - i] = 0u;
-  const int nch = colsp >> 10;
+  const int nch = colsp / CB;
   const long long step = (long long)gridDim.x * kRowsPerBlock;
   long long grow = (long long)blockIdx.x * kRowsPerBlock + wave;
   // (image, row) of the current and of the next row walk along with grow: no 64-bit division per row
@@ -751,12 +758,38 @@ __global__ __launch_bounds__(256) void cacfar_rows_kernel(const CfarArgs a) {
   // rows that cannot be read in aligned 16-byte pieces (odd strides, cols not a multiple of 16) are copied into LDS byte by
   // byte first, zero-padded, and take their pieces from there (no prefetch)
   auto is_direct = [&](const uint8_t* p) -> bool { return (((uintptr_t)p) & 15) == 0 && (a.cols & 15) == 0; };
-  auto issue = [&](const uint8_t* p, u32x4 (&dst)[NCH]) {
+  // a lane's LB bytes of a chunk: 16-byte pieces where LB is a multiple of 16 (D = 4, 8), 8-byte pieces otherwise (D = 6:
+  // 24 lane is only 8-byte aligned, and ds_write_b128 wants 16)
+  auto issue = [&](const uint8_t* p, uint32_t (&dst)[NCH][D]) {
 #pragma unroll
     for (int j = 0; j < NCH; j++) {
-      const int pos = j * 1024 + lane * 16;
-      dst[j] = u32x4{0u, 0u, 0u, 0u};
-      if (pos < a.need_cols) dst[j] = __builtin_nontemporal_load((const u32x4*)(p + pos));
+      const int pos = j * CB + lane * LB;
+#pragma unroll
+      for (int d = 0; d < D; d++) dst[j][d] = 0u;
+      if (D % 4 == 0) {
+#pragma unroll
+        for (int k = 0; k < D / 4; k++)
+          if (pos + 16 * k < a.need_cols) {
+            const u32x4 v = __builtin_nontemporal_load((const u32x4*)(p + pos + 16 * k));
+            dst[j][4 * k] = v.x; dst[j][4 * k + 1] = v.y; dst[j][4 * k + 2] = v.z; dst[j][4 * k + 3] = v.w;
+          }
+      } else {
+#pragma unroll
+        for (int k = 0; k < D / 2; k++)
+          if (pos + 8 * k < a.need_cols) {
+            const u32x2 v = __builtin_nontemporal_load((const u32x2*)(p + pos + 8 * k));
+            dst[j][2 * k] = v.x; dst[j][2 * k + 1] = v.y;
+          }
+      }
+    }
+  };
+  auto lds_put = [&](void* at, const uint32_t (&v)[D]) {
+    if (D % 4 == 0) {
+#pragma unroll
+      for (int k = 0; k < D / 4; k++) ((uint4*)at)[k] = make_uint4(v[4 * k], v[4 * k + 1], v[4 * k + 2], v[4 * k + 3]);
+    } else {
+#pragma unroll
+      for (int k = 0; k < D / 2; k++) ((uint2*)at)[k] = make_uint2(v[2 * k], v[2 * k + 1]);
     }
   };
   // LDS hand-over between the lanes of this wavefront.  The fences name the LDS address space only: a plain wavefront
@@ -780,7 +813,7 @@ __global__ __launch_bounds__(256) void cacfar_rows_kernel(const CfarArgs a) {
 #define CFAR_T0()
 #define CFAR_T(k)
 #endif
-  u32x4 cur[NCH], nxt[NCH];
+  uint32_t cur[NCH][D], nxt[NCH][D];
   if (grow < a.total_rows) { const uint8_t* p0 = row_ptr(cb, cr); if (is_direct(p0)) issue(p0, cur); }
   // the first row's pieces are waited for HERE, so that inside the loop `cur` only ever comes from register copies: the
   // compiler cannot count conditional loads and would otherwise wait for vmcnt(0) -- the NEXT row's requests -- at the
@@ -800,9 +833,9 @@ __global__ __launch_bounds__(256) void cacfar_rows_kernel(const CfarArgs a) {
       wave_sync();
 #pragma unroll
       for (int j = 0; j < NCH; j++) {
-        const int pos = j * 1024 + lane * 16;
-        cur[j] = u32x4{0u, 0u, 0u, 0u};
-        if (pos < colsp) cur[j] = *(const u32x4*)(raw + pos);
+        const int pos = j * CB + lane * LB;
+#pragma unroll
+        for (int d = 0; d < D; d++) cur[j][d] = pos < colsp ? *(const uint32_t*)(raw + pos + 4 * d) : 0u;
       }
     }
     const bool have_next = grow + step < a.total_rows;
@@ -814,14 +847,17 @@ __global__ __launch_bounds__(256) void cacfar_rows_kernel(const CfarArgs a) {
 #pragma unroll
     for (int j = 0; j < NCH; j++) {
       if (j >= nch) break;
-      const int pos = j * 1024 + lane * 16;
-      *(uint4*)(raw + pos) = make_uint4(cur[j].x, cur[j].y, cur[j].z, cur[j].w);
-      const uint32_t q0 = __builtin_amdgcn_udot4(cur[j].x, cur[j].x, 0u, false), q1 = __builtin_amdgcn_udot4(cur[j].y, cur[j].y, 0u, false);
-      const uint32_t q2 = __builtin_amdgcn_udot4(cur[j].z, cur[j].z, 0u, false), q3 = __builtin_amdgcn_udot4(cur[j].w, cur[j].w, 0u, false);
-      const uint32_t acc = q0 + q1 + q2 + q3;
+      const int pos = j * CB + lane * LB;
+      lds_put(raw + pos, cur[j]);
+      uint32_t pre[D];                                                      // sums of squares before each of the lane's quads
+      uint32_t acc = 0;
+#pragma unroll
+      for (int d = 0; d < D; d++) { pre[d] = acc; acc += __builtin_amdgcn_udot4(cur[j][d], cur[j][d], 0u, false); }
       const int incl = wave_incl_scan_i32((int)acc);
       const uint32_t base = run + (uint32_t)incl - acc;                     // sum before this lane's first bin
-      *(uint4*)(P4 + (pos >> 2)) = make_uint4(base, base + q0, base + q0 + q1, base + q0 + q1 + q2);
+#pragma unroll
+      for (int d = 0; d < D; d++) pre[d] += base;
+      lds_put(P4 + (pos >> 2), pre);
       run += (uint32_t)__builtin_amdgcn_readlane(incl, 63);
     }
     if (lane == 0) P4[colsp >> 2] = run;                                    // P(colsp)
@@ -887,16 +923,15 @@ __global__ __launch_bounds__(256) void cacfar_rows_kernel(const CfarArgs a) {
     };
     // candidate test "byte >= t" for four bytes at once: with tl = t & 127 and y = ((x & 0x7f..) | 0x80..) - tl * 0x0101..,
     // bit 7 of a byte of y says (x & 127) >= tl; the verdict is y & x for t >= 128 and y | x below.
-    const int cj_lo = a.bin_lo >> 10, cj_hi = (a.bin_hi + 1023) >> 10;      // chunks that hold bins of the range window
+    const int cj_lo = a.bin_lo / CB, cj_hi = (a.bin_hi + CB - 1) / CB;      // chunks that hold bins of the range window
 #pragma unroll
     for (int j = 0; j < NCH; j++) {
       if (j >= cj_hi) break;
       if (j < cj_lo) continue;
-      const int pos = j * 1024 + lane * 16;
-      const uint32_t w[4] = {cur[j].x, cur[j].y, cur[j].z, cur[j].w};
-      uint32_t cmask = 0;
+      const int pos = j * CB + lane * LB;
+      uint32_t cmask = 0;                                                   // bit per bin of the lane (LB <= 32)
 #pragma unroll
-      for (int h = 0; h < 2; h++) {
+      for (int h = 0; h < D / 2; h++) {
         int t = a.thr_i;
         if (PRE) {
           const uint32_t* pq = P4 + (pos >> 2) + 2 * h;                     // quad 2 H of this 8-bin block
@@ -909,7 +944,7 @@ __global__ __launch_bounds__(256) void cacfar_rows_kernel(const CfarArgs a) {
         const uint32_t tl = (uint32_t)(t & 0x7f);
         const uint32_t lo4 = __builtin_amdgcn_perm(tl, tl, 0u);               // the byte in all four places
         const uint32_t nhi = (t & 0x80) ? 0u : 0xffffffffu;
-        const uint32_t x0 = w[2 * h], x1 = w[2 * h + 1];
+        const uint32_t x0 = cur[j][2 * h], x1 = cur[j][2 * h + 1];
         const uint32_t y0 = (x0 | 0x80808080u) - lo4, y1 = (x1 | 0x80808080u) - lo4;
         const uint32_t ge0 = (y0 & x0) | ((y0 | x0) & nhi);                  // bit 7 of every byte: byte >= t
         const uint32_t ge1 = (y1 & x1) | ((y1 | x1) & nhi);
@@ -919,9 +954,9 @@ __global__ __launch_bounds__(256) void cacfar_rows_kernel(const CfarArgs a) {
         const uint32_t m8 = __builtin_amdgcn_udot4(z, 0x08040201u, 0u, false);
         cmask |= m8 << (8 * h);
       }
-      if (a.bin_lo > j * 1024 || a.bin_hi < j * 1024 + 1024) {              // range window: bins [bin_lo, bin_hi) of this lane's 16
-        const int lo = min(16, max(0, a.bin_lo - pos)), hi = min(16, max(0, a.bin_hi - pos));   // (chunks inside the window skip this)
-        const uint32_t win = hi > lo ? ((hi >= 16 ? 0xffffu : ((1u << hi) - 1u)) & ~((1u << lo) - 1u)) : 0u;
+      if (a.bin_lo > j * CB || a.bin_hi < j * CB + CB) {                    // range window: bins [bin_lo, bin_hi) of this lane's LB
+        const int lo = min(LB, max(0, a.bin_lo - pos)), hi = min(LB, max(0, a.bin_hi - pos));   // (chunks inside the window skip this)
+        const uint32_t win = hi > lo ? ((hi >= 32 ? 0xffffffffu : ((1u << hi) - 1u)) & ~((1u << lo) - 1u)) : 0u;
         cmask &= win;
       }
       CFAR_T(1);
@@ -990,7 +1025,9 @@ __global__ __launch_bounds__(256) void cacfar_rows_kernel(const CfarArgs a) {
 #endif
     if (next_direct) {
 #pragma unroll
-      for (int j = 0; j < NCH; j++) cur[j] = nxt[j];
+      for (int j = 0; j < NCH; j++)
+#pragma unroll
+        for (int d = 0; d < D; d++) cur[j][d] = nxt[j][d];
     }
   }
 }
@@ -1540,7 +1577,6 @@ int cfear_cacfar_device(cfear_ctx* ctx, const uint8_t* d_polar, const cfear_pola
     // bins the arithmetic of the bins in [bin_lo, bin_hi) can reach
     const long long reach = a.bin_hi > 0 ? std::min<long long>(cols, (long long)a.bin_hi - 1 + a.guard + a.window) : 0;
     a.need_cols = (int)((reach + 15) / 16 * 16);
-    a.colsp = std::max(1024, (a.need_cols + 1023) & ~1023);
     a.lut_ok = cfar_build_lut(a, a.lut) ? 1 : 0;
     // lower-bound pre-filter: the aligned quads inside the windows of every bin of an 8-bin block
     auto floor_div = [](int x, int y) { return x >= 0 ? x / y : -((-x + y - 1) / y); };
@@ -1556,14 +1592,37 @@ int cfear_cacfar_device(cfear_ctx* ctx, const uint8_t* d_polar, const cfear_pola
     a.kappa_lb = (float)(a.scaling / (2.0 * (double)a.window) * (1.0 - 3e-5));
   }
   {
-    const size_t rows_lds = 1024 + (size_t)kRowsPerBlock * cfar_wave_lds(a.colsp, a.pad_lo, a.pad_hi, keys);
-    const bool wide = a.colsp > 4096, pre = a.pre_on != 0;
+    // chunk geometry: D dwords per lane and chunk.  Per-chunk overhead ~ 60 wave instructions, per dword of a lane ~ 25:
+    // the D in {4, 6, 8} with the cheapest cover of the reachable bins (without the pre-filter only D = 4 is built)
+    const bool pre = a.pre_on != 0;
+    int D = 4, nch = std::max(1, (a.need_cols + 1023) / 1024);
+    if (pre) {
+      long long best = (long long)nch * (60 + 25 * 4);
+      for (int d : {6, 8}) {
+        const int n = std::max(1, (a.need_cols + 256 * d - 1) / (256 * d));
+        const long long c = (long long)n * (60 + 25 * d);
+        if (c < best) { best = c; D = d; nch = n; }
+      }
+    }
+    a.colsp = nch * 256 * D;
     using KernelFn = void (*)(const CfarArgs);
-    // [wide][keys][pre]
-    static const KernelFn fns[2][2][2] = {
-        {{cacfar_rows_kernel<4, false, false>, cacfar_rows_kernel<4, false, true>}, {cacfar_rows_kernel<4, true, false>, cacfar_rows_kernel<4, true, true>}},
-        {{cacfar_rows_kernel<8, false, false>, cacfar_rows_kernel<8, false, true>}, {cacfar_rows_kernel<8, true, false>, cacfar_rows_kernel<8, true, true>}}};
-    const KernelFn fn = fns[wide ? 1 : 0][keys ? 1 : 0][pre ? 1 : 0];
+    KernelFn fn = nullptr;
+    if (D == 4) {
+      const bool wide = nch > 4;
+      static const KernelFn f4[2][2][2] = {   // [wide][keys][pre]
+          {{cacfar_rows_kernel<4, 4, false, false>, cacfar_rows_kernel<4, 4, false, true>}, {cacfar_rows_kernel<4, 4, true, false>, cacfar_rows_kernel<4, 4, true, true>}},
+          {{cacfar_rows_kernel<4, 8, false, false>, cacfar_rows_kernel<4, 8, false, true>}, {cacfar_rows_kernel<4, 8, true, false>, cacfar_rows_kernel<4, 8, true, true>}}};
+      fn = f4[wide ? 1 : 0][keys ? 1 : 0][pre ? 1 : 0];
+    } else if (D == 6) {
+      static const KernelFn f6[2][2] = {{cacfar_rows_kernel<6, 2, false, true>, cacfar_rows_kernel<6, 2, true, true>},
+                                        {cacfar_rows_kernel<6, 6, false, true>, cacfar_rows_kernel<6, 6, true, true>}};
+      fn = f6[nch > 2 ? 1 : 0][keys ? 1 : 0];
+    } else {
+      static const KernelFn f8[2][2] = {{cacfar_rows_kernel<8, 2, false, true>, cacfar_rows_kernel<8, 2, true, true>},
+                                        {cacfar_rows_kernel<8, 4, false, true>, cacfar_rows_kernel<8, 4, true, true>}};
+      fn = f8[nch > 2 ? 1 : 0][keys ? 1 : 0];
+    }
+    const size_t rows_lds = 1024 + (size_t)kRowsPerBlock * cfar_wave_lds(a.colsp, a.pad_lo, a.pad_hi, keys, 256 * D);
     if (rows_lds > 64 * 1024)
       CFEAR_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rows_lds));
     // persistent wavefronts: as many workgroups as the chip holds at this LDS footprint (160 KiB per CU)

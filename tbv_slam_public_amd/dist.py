@@ -44,6 +44,28 @@ def _unpad(allr, n, world):
     return out
 
 
+_BUFFERS = {}
+
+
+def _buffers(nbytes, world, dev):
+    """Send / receive tensors (+ pinned host mirrors on the GPU path) reused from step to step: a loop-closure thread gathers
+    the same few hundred KiB every time."""
+    import torch
+    key = (nbytes, world, str(dev))
+    b = _BUFFERS.get(key)
+    if b is None:
+        pin = dev.type == "cuda"
+        b = dict(send_h=torch.zeros(nbytes, dtype=torch.uint8, pin_memory=pin),
+                 recv_h=torch.zeros(world * nbytes, dtype=torch.uint8, pin_memory=pin))
+        if pin:
+            b["send_d"] = torch.zeros(nbytes, dtype=torch.uint8, device=dev)
+            b["recv_d"] = torch.zeros(world * nbytes, dtype=torch.uint8, device=dev)
+        if len(_BUFFERS) > 8:
+            _BUFFERS.clear()
+        _BUFFERS[key] = b
+    return b
+
+
 def _gather_records(local, n, group):
     """all_gather of one fixed-size record per candidate: every rank contributes ceil(n / world) records (its block,
     zero-padded), rank order = candidate order; returns the n real records on every rank."""
@@ -52,14 +74,24 @@ def _gather_records(local, n, group):
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     lo, hi, per = shard_range(n, world, rank)
     assert local.shape[0] == hi - lo
-    padded = np.zeros(per, local.dtype)                 # padding slots are never returned
-    padded[:hi - lo] = local
     backend = dist.get_backend(group)
     dev = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
-    send = torch.from_numpy(padded.view(np.uint8).reshape(-1).copy()).to(dev)
-    recv = torch.empty(world * send.numel(), dtype=torch.uint8, device=dev)
-    dist.all_gather_into_tensor(recv, send, group=group)
-    return _unpad(recv.cpu().numpy().view(local.dtype).reshape(world, per), n, world)
+    rec = local.dtype.itemsize
+    b = _buffers(per * rec, world, dev)
+    sh = b["send_h"].numpy()
+    sh[:(hi - lo) * rec] = local.view(np.uint8).reshape(-1)
+    sh[(hi - lo) * rec:] = 0                            # padding slots are never returned
+    if dev.type == "cuda":
+        b["send_d"].copy_(b["send_h"], non_blocking=True)
+        dist.all_gather_into_tensor(b["recv_d"], b["send_d"], group=group)
+        b["recv_h"].copy_(b["recv_d"], non_blocking=True)
+        torch.cuda.current_stream().synchronize()
+    else:
+        dist.all_gather_into_tensor(b["recv_h"], b["send_h"], group=group)
+    allr = b["recv_h"].numpy().view(local.dtype).reshape(world, per)
+    if world == 1:
+        return allr[0, :n].copy()
+    return _unpad(allr, n, world)
 
 
 def register_candidates_sharded(jobs, register_fn, group=None):
@@ -78,13 +110,19 @@ def register_candidates_sharded(jobs, register_fn, group=None):
         import torch
         rec = L.RESULT_DTYPE.itemsize
         dev = torch.device("cuda", torch.cuda.current_device())
-        send = torch.zeros(per * rec, dtype=torch.uint8, device=dev)
+        b = _buffers(per * rec, world, dev)
+        send = b["send_d"]
+        if hi - lo < per:
+            send[(hi - lo) * rec:].zero_()               # padding slots are never returned
+            torch.cuda.current_stream().synchronize()    # (the library writes on its own stream)
         got = register_fn.into(jobs[lo:hi], send.data_ptr())
         assert got == hi - lo
         register_fn.ctx.synchronize()                    # the library runs on its own stream: torch must see the records
-        recv = torch.empty(world * per * rec, dtype=torch.uint8, device=dev)
-        dist.all_gather_into_tensor(recv, send, group=group)
-        return _unpad(recv.cpu().numpy().view(L.RESULT_DTYPE).reshape(world, per), n, world)
+        dist.all_gather_into_tensor(b["recv_d"], send, group=group)
+        b["recv_h"].copy_(b["recv_d"], non_blocking=True)
+        torch.cuda.current_stream().synchronize()
+        allr = b["recv_h"].numpy().view(L.RESULT_DTYPE).reshape(world, per)
+        return allr[0, :n].copy() if world == 1 else _unpad(allr, n, world)
     local = register_fn(jobs[lo:hi])
     assert local.dtype == L.RESULT_DTYPE
     return _gather_records(local, n, group)
@@ -127,4 +165,6 @@ def verify_candidates_sharded(cands, verify_fn, model_threshold=0.8, all_candida
     local = verify_fn(cands[lo:hi])
     assert local.dtype == L.VERIFY_RESULT_DTYPE
     out = _gather_records(local, len(cands), group)
+    if world == 1 and fn_selects:                             # one rank saw every candidate of every query and has selected
+        return out
     return apply_constraints(out, groups, model_threshold, all_candidates)
