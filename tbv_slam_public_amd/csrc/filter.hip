@@ -731,10 +731,12 @@ __host__ __device__ inline size_t cfar_wave_lds(int colsp, int pad_lo, int pad_h
 // overhead (two wave scans, the list loop, the round bookkeeping) is paid per CHUNK, so the host picks the D that covers
 // the reachable bins with the fewest chunks: 2336 bins of a Kvarntorp row are 2 chunks of 1536 (D = 6) instead of 3 of
 // 1024, of which the third held 18 busy lanes and cost 18 % of the kernel.
-template <int D, int NCH, bool KEYS, bool PRE>
+// DL = dwords per lane of the LAST chunk (DL <= D; DL < D only with exactly NCH chunks): 2336 reachable bins are a chunk
+// of 1536 (D = 6) and one of 1024 (DL = 4) -- ten dwords per lane and row instead of twelve.
+template <int D, int NCH, int DL, bool KEYS, bool PRE>
 __global__ __launch_bounds__(256) void cacfar_rows_kernel(const CfarArgs a) {
-  constexpr int CB = 256 * D;                                                // bins per chunk
-  constexpr int LB = 4 * D;                                                  // bytes (bins) per lane and chunk
+  constexpr int CB = 256 * D;                                                // bins per chunk (all but a shorter last one)
+  auto DJ = [](int j) { return (DL != D && j == NCH - 1) ? DL : D; };        // dwords per lane of chunk j (folds after unrolling)
   typedef uint32_t u32x2 __attribute__((ext_vector_type(2), aligned(4)));
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -742,13 +744,13 @@ __global__ __launch_bounds__(256) void cacfar_rows_kernel(const CfarArgs a) {
   lut[threadIdx.x] = a.lut[threadIdx.x];
   __syncthreads();
   const int colsp = a.colsp;
-  uint8_t* wbase = smem + 1024 + (size_t)wave * cfar_wave_lds(colsp, a.pad_lo, a.pad_hi, KEYS, CB);
+  uint8_t* wbase = smem + 1024 + (size_t)wave * cfar_wave_lds(colsp, a.pad_lo, a.pad_hi, KEYS, CB);   // (the list holds a full chunk)
   uint32_t* P4 = (uint32_t*)wbase + a.pad_lo;                                // P4[i] = sum_{q < 4 i} I_q^2, i in [-pad_lo, colsp / 4 + pad_hi]
   uint8_t* raw = wbase + (((size_t)(a.pad_lo + colsp / 4 + 1 + a.pad_hi) * 4 + 15) & ~(size_t)15);   // the row itself
   uint32_t* det32 = (uint32_t*)(raw + colsp + 16);                           // detections, bit per bin (bitmap output)
   unsigned short* list = (unsigned short*)(raw + colsp + 16 + (KEYS ? 0 : colsp / 8));
   for (int i = lane; i < a.pad_lo; i += 64) P4[-1 - i] = 0u;
-  const int nch = colsp / CB;
+  const int nch = DL != D ? NCH : colsp / CB;
   const long long step = (long long)gridDim.x * kRowsPerBlock;
   long long grow = (long long)blockIdx.x * kRowsPerBlock + wave;
   // (image, row) of the current and of the next row walk along with grow: no 64-bit division per row
@@ -763,33 +765,34 @@ __global__ __launch_bounds__(256) void cacfar_rows_kernel(const CfarArgs a) {
   auto issue = [&](const uint8_t* p, uint32_t (&dst)[NCH][D]) {
 #pragma unroll
     for (int j = 0; j < NCH; j++) {
-      const int pos = j * CB + lane * LB;
+      const int dj = DJ(j);
+      const int pos = j * CB + lane * 4 * dj;
 #pragma unroll
       for (int d = 0; d < D; d++) dst[j][d] = 0u;
-      if (D % 4 == 0) {
+      if (dj % 4 == 0) {
 #pragma unroll
         for (int k = 0; k < D / 4; k++)
-          if (pos + 16 * k < a.need_cols) {
+          if (4 * k < dj && pos + 16 * k < a.need_cols) {
             const u32x4 v = __builtin_nontemporal_load((const u32x4*)(p + pos + 16 * k));
             dst[j][4 * k] = v.x; dst[j][4 * k + 1] = v.y; dst[j][4 * k + 2] = v.z; dst[j][4 * k + 3] = v.w;
           }
       } else {
 #pragma unroll
         for (int k = 0; k < D / 2; k++)
-          if (pos + 8 * k < a.need_cols) {
+          if (2 * k < dj && pos + 8 * k < a.need_cols) {
             const u32x2 v = __builtin_nontemporal_load((const u32x2*)(p + pos + 8 * k));
             dst[j][2 * k] = v.x; dst[j][2 * k + 1] = v.y;
           }
       }
     }
   };
-  auto lds_put = [&](void* at, const uint32_t (&v)[D]) {
-    if (D % 4 == 0) {
+  auto lds_put = [&](void* at, const uint32_t (&v)[D], int dj) {               // the first dj dwords of v
+    if (dj % 4 == 0) {
 #pragma unroll
-      for (int k = 0; k < D / 4; k++) ((uint4*)at)[k] = make_uint4(v[4 * k], v[4 * k + 1], v[4 * k + 2], v[4 * k + 3]);
+      for (int k = 0; k < D / 4; k++) if (4 * k < dj) ((uint4*)at)[k] = make_uint4(v[4 * k], v[4 * k + 1], v[4 * k + 2], v[4 * k + 3]);
     } else {
 #pragma unroll
-      for (int k = 0; k < D / 2; k++) ((uint2*)at)[k] = make_uint2(v[2 * k], v[2 * k + 1]);
+      for (int k = 0; k < D / 2; k++) if (2 * k < dj) ((uint2*)at)[k] = make_uint2(v[2 * k], v[2 * k + 1]);
     }
   };
   // LDS hand-over between the lanes of this wavefront.  The fences name the LDS address space only: a plain wavefront
@@ -833,9 +836,10 @@ __global__ __launch_bounds__(256) void cacfar_rows_kernel(const CfarArgs a) {
       wave_sync();
 #pragma unroll
       for (int j = 0; j < NCH; j++) {
-        const int pos = j * CB + lane * LB;
+        const int dj = DJ(j);
+        const int pos = j * CB + lane * 4 * dj;
 #pragma unroll
-        for (int d = 0; d < D; d++) cur[j][d] = pos < colsp ? *(const uint32_t*)(raw + pos + 4 * d) : 0u;
+        for (int d = 0; d < D; d++) cur[j][d] = (d < dj && pos < colsp) ? *(const uint32_t*)(raw + pos + 4 * d) : 0u;
       }
     }
     const bool have_next = grow + step < a.total_rows;
@@ -847,17 +851,18 @@ __global__ __launch_bounds__(256) void cacfar_rows_kernel(const CfarArgs a) {
 #pragma unroll
     for (int j = 0; j < NCH; j++) {
       if (j >= nch) break;
-      const int pos = j * CB + lane * LB;
-      lds_put(raw + pos, cur[j]);
+      const int dj = DJ(j);
+      const int pos = j * CB + lane * 4 * dj;
+      lds_put(raw + pos, cur[j], dj);
       uint32_t pre[D];                                                      // sums of squares before each of the lane's quads
       uint32_t acc = 0;
 #pragma unroll
-      for (int d = 0; d < D; d++) { pre[d] = acc; acc += __builtin_amdgcn_udot4(cur[j][d], cur[j][d], 0u, false); }
+      for (int d = 0; d < D; d++) if (d < dj) { pre[d] = acc; acc += __builtin_amdgcn_udot4(cur[j][d], cur[j][d], 0u, false); }
       const int incl = wave_incl_scan_i32((int)acc);
       const uint32_t base = run + (uint32_t)incl - acc;                     // sum before this lane's first bin
 #pragma unroll
-      for (int d = 0; d < D; d++) pre[d] += base;
-      lds_put(P4 + (pos >> 2), pre);
+      for (int d = 0; d < D; d++) if (d < dj) pre[d] += base;
+      lds_put(P4 + (pos >> 2), pre, dj);
       run += (uint32_t)__builtin_amdgcn_readlane(incl, 63);
     }
     if (lane == 0) P4[colsp >> 2] = run;                                    // P(colsp)
@@ -928,10 +933,12 @@ __global__ __launch_bounds__(256) void cacfar_rows_kernel(const CfarArgs a) {
     for (int j = 0; j < NCH; j++) {
       if (j >= cj_hi) break;
       if (j < cj_lo) continue;
+      const int dj = DJ(j), LB = 4 * dj;                                    // bytes (bins) of the lane in this chunk
       const int pos = j * CB + lane * LB;
       uint32_t cmask = 0;                                                   // bit per bin of the lane (LB <= 32)
 #pragma unroll
       for (int h = 0; h < D / 2; h++) {
+        if (2 * h >= dj) break;
         int t = a.thr_i;
         if (PRE) {
           const uint32_t* pq = P4 + (pos >> 2) + 2 * h;                     // quad 2 H of this 8-bin block
@@ -954,7 +961,7 @@ __global__ __launch_bounds__(256) void cacfar_rows_kernel(const CfarArgs a) {
         const uint32_t m8 = __builtin_amdgcn_udot4(z, 0x08040201u, 0u, false);
         cmask |= m8 << (8 * h);
       }
-      if (a.bin_lo > j * CB || a.bin_hi < j * CB + CB) {                    // range window: bins [bin_lo, bin_hi) of this lane's LB
+      if (a.bin_lo > j * CB || a.bin_hi < j * CB + 64 * LB) {               // range window: bins [bin_lo, bin_hi) of this lane's LB
         const int lo = min(LB, max(0, a.bin_lo - pos)), hi = min(LB, max(0, a.bin_hi - pos));   // (chunks inside the window skip this)
         const uint32_t win = hi > lo ? ((hi >= 32 ? 0xffffffffu : ((1u << hi) - 1u)) & ~((1u << lo) - 1u)) : 0u;
         cmask &= win;
@@ -1595,32 +1602,41 @@ int cfear_cacfar_device(cfear_ctx* ctx, const uint8_t* d_polar, const cfear_pola
     // chunk geometry: D dwords per lane and chunk.  Per-chunk overhead ~ 60 wave instructions, per dword of a lane ~ 25:
     // the D in {4, 6, 8} with the cheapest cover of the reachable bins (without the pre-filter only D = 4 is built)
     const bool pre = a.pre_on != 0;
-    int D = 4, nch = std::max(1, (a.need_cols + 1023) / 1024);
+    int D = 4, DL = 4, nch = std::max(1, (a.need_cols + 1023) / 1024);
     if (pre) {
-      long long best = (long long)nch * (60 + 25 * 4);
+      // measured on the Kvarntorp rows: ~10 us per chunk and ~9 us per dword of a lane (per 204 800 rows)
+      auto cost = [](int n, int d, int dl) { return (long long)n * 10 + (long long)((n - 1) * d + dl) * 9; };
+      long long best = cost(nch, 4, 4);
       for (int d : {6, 8}) {
         const int n = std::max(1, (a.need_cols + 256 * d - 1) / (256 * d));
-        const long long c = (long long)n * (60 + 25 * d);
-        if (c < best) { best = c; D = d; nch = n; }
+        if (cost(n, d, d) < best) { best = cost(n, d, d); D = d; DL = d; nch = n; }
+        if (n == 2)                                          // two chunks: the second may be shorter
+          for (int dl = 2; dl < d; dl += 2)
+            if (256 * d + 256 * dl >= a.need_cols && cost(2, d, dl) < best) { best = cost(2, d, dl); D = d; DL = dl; nch = 2; }
       }
     }
-    a.colsp = nch * 256 * D;
+    a.colsp = (nch - 1) * 256 * D + 256 * DL;
     using KernelFn = void (*)(const CfarArgs);
     KernelFn fn = nullptr;
     if (D == 4) {
       const bool wide = nch > 4;
       static const KernelFn f4[2][2][2] = {   // [wide][keys][pre]
-          {{cacfar_rows_kernel<4, 4, false, false>, cacfar_rows_kernel<4, 4, false, true>}, {cacfar_rows_kernel<4, 4, true, false>, cacfar_rows_kernel<4, 4, true, true>}},
-          {{cacfar_rows_kernel<4, 8, false, false>, cacfar_rows_kernel<4, 8, false, true>}, {cacfar_rows_kernel<4, 8, true, false>, cacfar_rows_kernel<4, 8, true, true>}}};
+          {{cacfar_rows_kernel<4, 4, 4, false, false>, cacfar_rows_kernel<4, 4, 4, false, true>}, {cacfar_rows_kernel<4, 4, 4, true, false>, cacfar_rows_kernel<4, 4, 4, true, true>}},
+          {{cacfar_rows_kernel<4, 8, 4, false, false>, cacfar_rows_kernel<4, 8, 4, false, true>}, {cacfar_rows_kernel<4, 8, 4, true, false>, cacfar_rows_kernel<4, 8, 4, true, true>}}};
       fn = f4[wide ? 1 : 0][keys ? 1 : 0][pre ? 1 : 0];
     } else if (D == 6) {
-      static const KernelFn f6[2][2] = {{cacfar_rows_kernel<6, 2, false, true>, cacfar_rows_kernel<6, 2, true, true>},
-                                        {cacfar_rows_kernel<6, 6, false, true>, cacfar_rows_kernel<6, 6, true, true>}};
-      fn = f6[nch > 2 ? 1 : 0][keys ? 1 : 0];
+      static const KernelFn f6[2][2] = {{cacfar_rows_kernel<6, 2, 6, false, true>, cacfar_rows_kernel<6, 2, 6, true, true>},
+                                        {cacfar_rows_kernel<6, 6, 6, false, true>, cacfar_rows_kernel<6, 6, 6, true, true>}};
+      static const KernelFn f6s[2][2] = {{cacfar_rows_kernel<6, 2, 2, false, true>, cacfar_rows_kernel<6, 2, 2, true, true>},
+                                         {cacfar_rows_kernel<6, 2, 4, false, true>, cacfar_rows_kernel<6, 2, 4, true, true>}};
+      fn = DL != D ? f6s[DL / 2 - 1][keys ? 1 : 0] : f6[nch > 2 ? 1 : 0][keys ? 1 : 0];
     } else {
-      static const KernelFn f8[2][2] = {{cacfar_rows_kernel<8, 2, false, true>, cacfar_rows_kernel<8, 2, true, true>},
-                                        {cacfar_rows_kernel<8, 4, false, true>, cacfar_rows_kernel<8, 4, true, true>}};
-      fn = f8[nch > 2 ? 1 : 0][keys ? 1 : 0];
+      static const KernelFn f8[2][2] = {{cacfar_rows_kernel<8, 2, 8, false, true>, cacfar_rows_kernel<8, 2, 8, true, true>},
+                                        {cacfar_rows_kernel<8, 4, 8, false, true>, cacfar_rows_kernel<8, 4, 8, true, true>}};
+      static const KernelFn f8s[3][2] = {{cacfar_rows_kernel<8, 2, 2, false, true>, cacfar_rows_kernel<8, 2, 2, true, true>},
+                                         {cacfar_rows_kernel<8, 2, 4, false, true>, cacfar_rows_kernel<8, 2, 4, true, true>},
+                                         {cacfar_rows_kernel<8, 2, 6, false, true>, cacfar_rows_kernel<8, 2, 6, true, true>}};
+      fn = DL != D ? f8s[DL / 2 - 1][keys ? 1 : 0] : f8[nch > 2 ? 1 : 0][keys ? 1 : 0];
     }
     const size_t rows_lds = 1024 + (size_t)kRowsPerBlock * cfar_wave_lds(a.colsp, a.pad_lo, a.pad_hi, keys, 256 * D);
     if (rows_lds > 64 * 1024)
