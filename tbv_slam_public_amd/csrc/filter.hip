@@ -767,8 +767,8 @@ __global__ __launch_bounds__(256) void cacfar_rows_kernel(const CfarArgs a) {
     for (int j = 0; j < NCH; j++) {
       const int dj = DJ(j);
       const int pos = j * CB + lane * 4 * dj;
-#pragma unroll
-      for (int d = 0; d < D; d++) dst[j][d] = 0u;
+      // (no zeroing here: the registers of the lanes beyond need_cols are zeroed ONCE before the row loop; the masked loads
+      //  never write them, and the copies below move zeros)
       if (dj % 4 == 0) {
 #pragma unroll
         for (int k = 0; k < D / 4; k++)
@@ -817,14 +817,20 @@ __global__ __launch_bounds__(256) void cacfar_rows_kernel(const CfarArgs a) {
 #define CFAR_T(k)
 #endif
   uint32_t cur[NCH][D], nxt[NCH][D];
+#pragma unroll
+  for (int j = 0; j < NCH; j++)
+#pragma unroll
+    for (int d = 0; d < D; d++) { cur[j][d] = 0u; nxt[j][d] = 0u; }
   if (grow < a.total_rows) { const uint8_t* p0 = row_ptr(cb, cr); if (is_direct(p0)) issue(p0, cur); }
   // the first row's pieces are waited for HERE, so that inside the loop `cur` only ever comes from register copies: the
   // compiler cannot count conditional loads and would otherwise wait for vmcnt(0) -- the NEXT row's requests -- at the
   // first use of `cur` in every iteration
   __builtin_amdgcn_s_waitcnt(0);
-  for (; grow < a.total_rows; grow += step) {
+  const uint8_t* rowp = row_ptr(cb, cr);
+  long long key_base = grow * (long long)a.kcap;
+  const long long key_step = step * (long long)a.kcap;
+  for (; grow < a.total_rows; grow += step, key_base += key_step) {
     CFAR_T0();
-    const uint8_t* rowp = row_ptr(cb, cr);
     cb += step_b; cr += step_r;
     if (cr >= a.rows) { cr -= a.rows; cb++; }
     if (!is_direct(rowp)) {
@@ -846,6 +852,7 @@ __global__ __launch_bounds__(256) void cacfar_rows_kernel(const CfarArgs a) {
     const uint8_t* nextp = have_next ? row_ptr(cb, cr) : rowp;
     const bool next_direct = have_next && is_direct(nextp);
     if (next_direct) issue(nextp, nxt);
+    rowp = nextp;                                                           // (this row is in registers / LDS from here on)
     // ---- A: bytes + prefix sums of squares -> LDS ---------------------------------------------------------------
     uint32_t run = 0;
 #pragma unroll
@@ -872,7 +879,6 @@ __global__ __launch_bounds__(256) void cacfar_rows_kernel(const CfarArgs a) {
     CFAR_T(0);
     // ---- B + C -------------------------------------------------------------------------------------------------
     int C = 0, ndet = 0;
-    const long long key_base = grow * (long long)a.kcap;
     auto round = [&](int k0, int cnt) {
       const bool act = lane < cnt;
       int bin = 0; uint32_t v = 0;
@@ -929,8 +935,10 @@ __global__ __launch_bounds__(256) void cacfar_rows_kernel(const CfarArgs a) {
     // candidate test "byte >= t" for four bytes at once: with tl = t & 127 and y = ((x & 0x7f..) | 0x80..) - tl * 0x0101..,
     // bit 7 of a byte of y says (x & 127) >= tl; the verdict is y & x for t >= 128 and y | x below.
     const int cj_lo = a.bin_lo / CB, cj_hi = (a.bin_hi + CB - 1) / CB;      // chunks that hold bins of the range window
+    uint32_t cm[NCH];                                                       // candidate bits of the lane, chunk by chunk
 #pragma unroll
     for (int j = 0; j < NCH; j++) {
+      cm[j] = 0u;
       if (j >= cj_hi) break;
       if (j < cj_lo) continue;
       const int dj = DJ(j), LB = 4 * dj;                                    // bytes (bins) of the lane in this chunk
@@ -966,10 +974,26 @@ __global__ __launch_bounds__(256) void cacfar_rows_kernel(const CfarArgs a) {
         const uint32_t win = hi > lo ? ((hi >= 32 ? 0xffffffffu : ((1u << hi) - 1u)) & ~((1u << lo) - 1u)) : 0u;
         cmask &= win;
       }
-      CFAR_T(1);
+      cm[j] = cmask;
+    }
+    CFAR_T(1);
+    // The row's bytes are dead from here on (the rounds work from LDS): the NEXT row's pieces move into `cur` now, so that
+    // the wait for them does not sit behind this row's key stores (vmcnt counts stores too: at the end of the row the copy
+    // waited for the stores of the last round every time).
+    if (next_direct) {
+#pragma unroll
+      for (int j = 0; j < NCH; j++)
+#pragma unroll
+        for (int d = 0; d < D; d++) cur[j][d] = nxt[j][d];
+    }
+#pragma unroll
+    for (int j = 0; j < NCH; j++) {
+      if (j >= cj_hi) break;
+      if (j < cj_lo) continue;
+      const int pos = j * CB + lane * 4 * DJ(j);
       // the chunk's candidates -> list, behind the carried remainder, in bin order (lane, bit)
       {
-        uint32_t m = cmask;
+        uint32_t m = cm[j];
         const int pc = __popc(m);
         const int incl = wave_incl_scan_i32(pc);
         int off = C + incl - pc;
@@ -1030,12 +1054,6 @@ __global__ __launch_bounds__(256) void cacfar_rows_kernel(const CfarArgs a) {
     for (int k = 0; k < 6; k++) tq[k] = 0;
     ctot = 0; nrounds = 0;
 #endif
-    if (next_direct) {
-#pragma unroll
-      for (int j = 0; j < NCH; j++)
-#pragma unroll
-        for (int d = 0; d < D; d++) cur[j][d] = nxt[j][d];
-    }
   }
 }
 
