@@ -138,6 +138,48 @@ def test_cacfar_vs_oracle():
         np.testing.assert_array_equal(r["det_mask"][0], mask)
 
 
+def test_cacfar_fuzz_shapes_and_parameters():
+    """Random small images and parameter sets through every geometry the rows kernel picks (chunk widths, shorter last
+    chunk, pre-filter on / off, rows that cannot be read in 16-byte pieces, empty range windows, batches smaller than the
+    persistent grid): clouds and masks equal the oracle's bit for bit."""
+    from oracle import pyoracle as O
+    from tbv_slam_public_amd import api
+    rng = np.random.default_rng(2024)
+    n_cases = 0
+    for case in range(60):
+        rows = int(rng.integers(1, 23))
+        cols = int(rng.choice([rng.integers(20, 200), rng.integers(200, 1500), rng.integers(1500, 3600), 16 * rng.integers(4, 220)]))
+        window = int(rng.choice([1, 2, 3, 5, 8, 12, 20, 40, 64, 120]))
+        guard = int(rng.integers(0, 24))
+        pfa = float(rng.choice([1e-4, 1e-3, 0.01, 0.05, 0.2, 0.6]))
+        z = float(rng.choice([-1.0, 0.0, 7.5, 20.0, 60.0, 127.0, 128.0, 200.0, 254.0, 255.0]))
+        res = float(rng.choice([0.0438, 0.0595238, 0.175]))
+        mind = float(rng.choice([0.0, 0.5, 2.5, 10.0]))
+        maxd = float(rng.choice([400.0, res * cols * rng.uniform(0.2, 0.9), res * 5, 1e6]))
+        kind = case % 3
+        if kind == 0:
+            img = (6 + rng.exponential(rng.uniform(4, 40), size=(rows, cols))).clip(0, 255).astype(np.uint8)
+        elif kind == 1:
+            img = rng.integers(0, 256, size=(rows, cols)).astype(np.uint8)
+        else:
+            img = np.full((rows, cols), int(rng.integers(0, 40)), np.uint8)
+            for _ in range(int(rng.integers(1, 30))):
+                r0, c0 = int(rng.integers(0, rows)), int(rng.integers(0, cols))
+                img[r0, c0:c0 + int(rng.integers(1, 6))] = int(rng.integers(100, 256))
+        if guard > 0 and mind < res * (guard + 1):     # bins below nb_guard_cells that pass min_distance: undefined in the reference (cfar.cpp:77)
+            mind = float(res * (guard + 1))
+        r = api.filter_cacfar(img, window, guard, pfa, res, z, mind, max_distance=maxd, want_mask=True)
+        cloud, rc = O.cacfar(img, window, guard, pfa, res, z, mind, max_distance=maxd)
+        args = (case, rows, cols, window, guard, pfa, z, res, mind, maxd)
+        assert r["n_points"][0] == cloud.shape[0], (args, r["n_points"][0], cloud.shape[0])
+        np.testing.assert_array_equal(r["xyzi"][0, :cloud.shape[0]], cloud, err_msg=str(args))
+        mask = np.zeros(img.shape, np.uint8)
+        mask[rc[:, 0], rc[:, 1]] = 1
+        np.testing.assert_array_equal(r["det_mask"][0], mask, err_msg=str(args))
+        n_cases += cloud.shape[0] > 0
+    assert n_cases > 20
+
+
 def test_radar_driver_mirror():
     from oracle import pyoracle as O
     from tbv_slam_public_amd import api, synth
