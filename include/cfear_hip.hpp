@@ -299,6 +299,7 @@ class MapPointNormal {
   // pointnormal.h:116 / pointnormal.cpp:65-90.  raw: one identity cell per point (cell::GetIdentityCell, pointnormal.h:59)
   MapPointNormal(const pcl::PointCloud<pcl::PointXYZI>::Ptr& cld, float radius, const Eigen::Vector2d& origin = Eigen::Vector2d(0, 0),
                  const bool weight_intensity = false, const bool raw = false) : ctx_(Context::Default()) {
+    input_ = cld;                                                                  // pointnormal.cpp:78 (GetScan hands it back)
     if (raw) {
       std::vector<cfear_cell> cells(cld->points.size());
       for (size_t i = 0; i < cells.size(); i++) {
@@ -326,6 +327,11 @@ class MapPointNormal {
     return m;
   }
   std::vector<int> GetClosestIdx(const Eigen::Vector2d& p, double d) const { return GetClosestIdx(p(0), p(1), d); }                   // :238
+  pcl::PointCloud<pcl::PointXYZI>::Ptr GetScan() { return input_; }                                                                 // :170
+  // PublishMap (pointnormal.h:235) draws RViz markers through a static ros::Publisher map: visualisation, out of scope --
+  // kept as a no-op so that callers (odometrykeyframefuser.cpp:209-216) compile unchanged
+  template <class MapPtr, class Affine>
+  static void PublishMap(const std::string&, MapPtr, const Affine&, const std::string&, const int = 0, float = 1.0f) {}
   boost::shared_ptr<MapPointNormal> TransformMap(const Eigen::Affine3d& T) {                                                          // :168
     return boost::shared_ptr<MapPointNormal>(new MapPointNormal(ctx_, TransformCells(Affine3dToPose2d(T))));
   }
@@ -359,6 +365,9 @@ class MapPointNormal {
   std::vector<cfear_cell> cache_;
   Context& ctx_;
   cfear_scan* scan_ = nullptr;
+#ifdef CFEAR_HIP_HAVE_EIGEN_PCL
+  pcl::PointCloud<pcl::PointXYZI>::Ptr input_;
+#endif
 };
 #ifdef CFEAR_HIP_HAVE_EIGEN_PCL
 typedef boost::shared_ptr<MapPointNormal> MapNormalPtr;                                       // pointnormal.h:108

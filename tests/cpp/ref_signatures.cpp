@@ -64,6 +64,8 @@ int main(int argc, char** argv) {
     // TransformMap / GetCell (pointnormal.h:120, 168)
     MapNormalPtr moved = m0->TransformMap(Pose2dToAffine3d(Pose2d{1.0, 2.0, 0.25}));
     if (moved->GetSize() != m0->GetSize() || !(moved->GetCell(0).nsamples == m0->GetCell(0).nsamples)) return 4;
+    if (m0->GetScan() != cloud[0]) return 4;                                   // GetScan (pointnormal.h:170)
+    MapPointNormal::PublishMap("/current_normals", m1, T_vek.back(), "world", 1);   // a no-op here (RViz markers)
     // soft_constraints = true is refused loudly, never ignored (n_scan_normal.cpp:371-375 is undefined behaviour there)
     bool refused = false;
     try { radar_reg.Register(scans_vek, T_vek, cov_vek, true); } catch (const CfearError& e) { refused = e.status == CFEAR_ERR_INVALID_ARGUMENT; }
