@@ -224,13 +224,14 @@ def roofline_of(prof, n_scans_per_launch, mean_points):
     """algorithmic bytes per scan filtered = R*C + 16*N_f + 4*R, N_f = points kept -- `achieved` / `frac`
     follow that figure.  In the batched odometry the sweep does not write 16-byte points but 4-byte keys (intensity << 24 |
     bin) and two counters per row, so what it really moves is R*C + 4*N_f + 8*R: reported beside it as `fused_*`."""
-    ms, launches = prof.get("kstrongest_rows", (0.0, 0))
+    kernel = "kstrongest_rows" if "kstrongest_rows" in prof or "kstrong_image" not in prof else "kstrong_image"   # ([bins][azimuths] sources: the fused decode + sweep)
+    ms, launches = prof.get(kernel, (0.0, 0))
     avg_ms = ms / max(launches, 1)
     bytes_per_scan = IMG + 16.0 * mean_points + 4 * ROWS
     fused_bytes_per_scan = IMG + 4.0 * mean_points + 8 * ROWS
     per_s = n_scans_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
     achieved = bytes_per_scan * per_s
-    return {"bound": "hbm", "kernel": "kstrongest_rows", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+    return {"bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS, "avg_launch_ms": avg_ms, "launches": int(launches),
             "algorithmic_bytes_per_launch": bytes_per_scan * n_scans_per_launch, "mean_points_per_scan": mean_points,
             "fused_bytes_per_launch": fused_bytes_per_scan * n_scans_per_launch,

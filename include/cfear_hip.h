@@ -133,6 +133,28 @@ typedef struct cfear_kstrong_out {
 int cfear_filter_kstrongest(cfear_ctx* ctx, const uint8_t* polar, const cfear_polar_desc* desc,
                             const cfear_kstrong_params* par, const cfear_kstrong_out* out);
 
+/* The filter stage of the batched odometry on its own (device memory only): radarDriver::Callback's decode
+ * (radar_driver.cpp:74-90), FilterKstrongest (radar_filters.cpp:209-237) and the selection of
+ * getPeaksFilteredPointCloud(cloud, false) (radar_filters.cpp:309-337) in ONE pass over the sweep.  Per azimuth row the kept
+ * bins beyond ceil(min_distance / range_res) as packed keys (intensity << 24 | range bin), in the reference's cloud order
+ * (ascending (intensity, range)):
+ *   row_keys   uint32 [batch][azimuths][k]     (k = k_strongest <= 64; entries beyond the row's count are unspecified)
+ *   row_counts int32  [batch][azimuths][2]     {kept bins of the row, 0}
+ * flags: CFEAR_ROWKEYS_BINS_MAJOR -- the images are [range bins][azimuths] (desc->rows = bins, desc->cols = azimuths) and
+ * row r of the result is source column cols - 1 - r (cv::ROTATE_90_COUNTERCLOCKWISE).  The rotated image is never built:
+ * one streaming pass lists, per azimuth, the bins >= uchar(z_min) (the only ones the filter can keep), a second picks the
+ * k strongest of each list; azimuths with more than 256 such bins have their 16-column tile transposed in LDS and swept
+ * there (CFEAR_ROWKEYS_TILE_SWEEP: every tile takes that route).  Needs 16-byte aligned images, cols % 16 == 0, rows % 4 == 0
+ * and <= 4096 bins; any other geometry, or CFEAR_ROWKEYS_TWO_PASS, takes cfear_polar_rotate_ccw's kernel into a workspace
+ * first -- same result.  want_peaks is ignored.                                                                        */
+#define CFEAR_ROWKEYS_BINS_MAJOR 1
+#define CFEAR_ROWKEYS_TWO_PASS 2
+#define CFEAR_ROWKEYS_TILE_SWEEP 4
+#define CFEAR_ROWKEYS_ROUTE_LISTS 16   /* candidate lists in global memory whatever the batch size (default: small batches) */
+#define CFEAR_ROWKEYS_ROUTE_IMAGE 32   /* one workgroup per image, lists in LDS (default: batches that fill the chip) */
+int cfear_filter_kstrongest_rowkeys(cfear_ctx* ctx, const uint8_t* polar, const cfear_polar_desc* desc,
+                                    const cfear_kstrong_params* par, int32_t flags, uint32_t* row_keys, int32_t* row_counts);
+
 /* Legacy filter: replaces k_strongest_filter / InsertStrongestK (radar_filters.cpp:25-78), which CorAl's standalone
  * kstrongRadar scan type still calls (coral_alignment_quality/src/alignment_checker/ScanType.cpp:104-114); TBV itself uses
  * the structured filter above.  Different rule: the first bin >= z_min of a row sets a floor, later bins

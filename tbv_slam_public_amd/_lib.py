@@ -206,7 +206,7 @@ EXPORTS = [
     "cfear_odometry_process_prefetch", "cfear_odometry_get_covariance", "cfear_odometry_destroy",
     "cfear_odometry_get_scan", "cfear_odometry_get_cloud", "cfear_odometry_get_peaks", "cfear_odometry_process_clouds",
     "cfear_odometry_process_offsets", "cfear_odometry_discard_prefetch",
-    "cfear_keyframe_based_fuse", "cfear_acc_vel_sanity_check", "cfear_filter_kstrongest_legacy",
+    "cfear_keyframe_based_fuse", "cfear_acc_vel_sanity_check", "cfear_filter_kstrongest_legacy", "cfear_filter_kstrongest_rowkeys",
     "cfear_graph_save", "cfear_graph_load", "cfear_graph_size", "cfear_graph_node_at", "cfear_graph_destroy",
     "cfear_pose3d_from_xyt", "cfear_pose3d_to_xyt", "cfear_odometry_get_constraint",
     "cfear_shard_range", "cfear_gather_records", "cfear_register_batch_sharded", "cfear_verify_loop_candidates_sharded",
@@ -351,6 +351,7 @@ def lib():
     L.cfear_odometry_discard_prefetch.argtypes = [vp]
     L.cfear_filter_kstrongest_legacy.argtypes = [vp, vp, C.POINTER(PolarDesc), C.c_int32, C.c_double, C.c_double, C.c_double, vp, vp,
                                                  C.c_int32]
+    L.cfear_filter_kstrongest_rowkeys.argtypes = [vp, vp, C.POINTER(PolarDesc), C.POINTER(KStrongParams), C.c_int32, vp, vp]
     L.cfear_pgo_params_default.argtypes = [C.POINTER(PgoParams)]
     L.cfear_pgo_params_default.restype = None
     L.cfear_pgo_solve.argtypes = [vp, vp, C.c_int32, vp, C.c_int32, C.POINTER(PgoParams), C.POINTER(PgoSummary)]

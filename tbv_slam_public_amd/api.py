@@ -181,6 +181,29 @@ def filter_kstrongest(img, k, z_min, range_res, min_distance, want_peaks=False, 
     return res
 
 
+def filter_kstrongest_rowkeys(img, k, z_min, range_res, min_distance, bins_major=False, two_pass=False, tile_sweep=False, route=0, ctx=None):
+    """cfear_filter_kstrongest_rowkeys: the batched odometry's filter stage on its own, for a torch CUDA uint8 image
+    [rows, cols] or batch [b, rows, cols]; bins_major: the images are [range bins][azimuths] and are decoded (rotated
+    counter-clockwise, radar_driver.cpp:74-90) by the sweep itself (two_pass: by the rotation kernel first; tile_sweep:
+    every 16-column tile through the LDS transposition instead of the candidate lists; route 1 / 2: the lists in global
+    memory / one workgroup per image whatever the batch size).
+    Returns (row_keys uint32-as-int32 [b, azimuths, k], row_counts int32 [b, azimuths, 2]) as CUDA tensors."""
+    import torch
+    ctx = ctx or default_context()
+    d, batch, rows, cols = _desc(img)
+    assert img.dtype == torch.uint8 and img.stride(-1) == 1      # a view with a row pitch / batch stride is fine
+    d.stride = img.stride(-2)
+    d.batch_stride = img.stride(0) if img.ndim == 3 else rows * d.stride
+    az = cols if bins_major else rows
+    par = L.KStrongParams(int(k), float(z_min), float(range_res), float(min_distance), 0)
+    keys = torch.zeros((batch, az, k), dtype=torch.int32, device=img.device)
+    cnt = torch.zeros((batch, az, 2), dtype=torch.int32, device=img.device)
+    p = img.data_ptr()
+    flags = (1 if bins_major else 0) | (2 if two_pass else 0) | (4 if tile_sweep else 0) | (int(route) << 4)
+    ctx.check(ctx._lib.cfear_filter_kstrongest_rowkeys(ctx.h, p, C.byref(d), C.byref(par), flags, _ptr(keys)[0], _ptr(cnt)[0]))
+    return keys, cnt
+
+
 def filter_cacfar(img, window_size, nb_guard_cells, false_alarm_rate, range_res, z_min, min_distance,
                   max_distance=400.0, cap_points=None, want_mask=False, ctx=None):
     """AzimuthCACFAR::getFilteredPointCloud (cfar.cpp:35-71).  Returns dict(xyzi, n_points[, det_mask])."""

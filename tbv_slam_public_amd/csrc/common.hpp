@@ -32,7 +32,7 @@ struct cfear_ctx {
   std::vector<hipEvent_t> event_pool;
   // grow-only device workspaces (indexed by purpose so stages of one pipeline do not alias)
   struct Ws { void* p = nullptr; size_t bytes = 0; };
-  Ws ws[12];
+  Ws ws[13];
   // pinned host staging for small read-backs
   void* pinned = nullptr;
   size_t pinned_bytes = 0;
@@ -69,7 +69,7 @@ struct ProfScope {
   cfear_ctx* ctx;
   int row;
   ProfScope(cfear_ctx* c, const char* name) : ctx(c), row(-1) {
-    if (ctx->profile == 1 || (ctx->profile == 2 && (!strcmp(name, "kstrongest_rows") || !strcmp(name, "cacfar_rows")))) {
+    if (ctx->profile == 1 || (ctx->profile == 2 && (!strcmp(name, "kstrongest_rows") || !strcmp(name, "cacfar_rows") || !strcmp(name, "kstrong_image")))) {
       row = cfear_prof_row(ctx, name);
       cfear_prof_begin(ctx, row);
     }
@@ -127,6 +127,10 @@ struct cfear_kstrong_fused {
 int cfear_kstrong_device(cfear_ctx* ctx, const uint8_t* d_polar, const cfear_polar_desc* desc,
                          const cfear_kstrong_params* par, const cfear_kstrong_out* o, bool dense_halo = false,
                          const cfear_kstrong_fused* fused = nullptr);
+// fused decode + sweep for [range bins][azimuths] sources (sd = the SOURCE images); key output only
+bool cfear_kstrong_cols_supported(const uint8_t* d_src, const cfear_polar_desc* sd, const cfear_kstrong_params* par);
+int cfear_kstrong_cols_device(cfear_ctx* ctx, const uint8_t* d_src, const cfear_polar_desc* sd, const cfear_kstrong_params* par,
+                              const cfear_kstrong_fused* fused, int route = 0);
 int cfear_compensate_batch_device(cfear_ctx* ctx, float* d_xyzi, size_t cloud_stride_points, const int32_t* d_n,
                                   const double* d_mot, int n_clouds, int max_points, int ccw);
 int cfear_rotate_ccw_device(cfear_ctx* ctx, const uint8_t* d_src, const cfear_polar_desc* src_desc, uint8_t* d_dst,

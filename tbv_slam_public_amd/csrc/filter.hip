@@ -129,29 +129,22 @@ __device__ __forceinline__ void for_each_candidate(const uint32_t (&bm)[NCHUNK],
   }
 }
 
-template <int NCHUNK, bool VEC, bool MASK>
-__global__ __launch_bounds__(256, 7) void kstrongest_rows_kernel(const KStrongArgs a) {
-  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-  const int r = blockIdx.x * kRowsPerBlock + wave;          // grid = (row quads, images): no division
-  if (r >= a.rows) return;                                  // no workgroup barrier below
-  const int b = a.batch0 + blockIdx.y;
-  const uint8_t* img = a.polar + (a.image_offsets ? a.image_offsets[b] : (long long)b * a.batch_stride);
+// One azimuth row on one wavefront.  STAGED = false: the row is read from `rowp` (global memory) and staged in `rowbuf`;
+// STAGED = true: the caller has already placed the row's bytes in `rowbuf` (LDS, 16-byte aligned, readable up to the next
+// multiple of 16 bins; kstrongest_cols_kernel transposes them there) -- no peaks in that mode (no halo bytes).
+// hist: [kScratch / 4] dwords of scratch, list: [kpad] packed keys; nothing below crosses a workgroup barrier.
+template <int NCHUNK, bool VEC, bool MASK, bool STAGED>
+__device__ __forceinline__ void kstrong_row(const KStrongArgs& a, const int r, const int b, const uint8_t* img, uint8_t* rowbuf,
+                                            uint32_t* hist, uint32_t* list, const int lane) {
   const long long row_lin = (long long)r * a.stride;
   const uint8_t* rowp = img + row_lin;
   const int k = a.k;
-  const int kpad = max((k + 3) & ~3, 64);          // list capacity: k survivors, or up to 64 candidates to rank
   constexpr int NP = (NCHUNK + 1) / 2;             // bitmap words per lane (two chunks per word)
-  constexpr int kScratch = (NP + 2) * 256 > 1024 ? (NP + 2) * 256 : 1024;    // marker u8[256] | sexcl[64] | spw[NP][64], or hist[256]
-  const int per_wave = NCHUNK * 1024 + 32 + kScratch + kpad * 4;
-  uint8_t* rowbuf = smem + wave * per_wave + 16;                                  // the raw row, 16-byte halo either side
-  uint32_t* hist = (uint32_t*)(smem + wave * per_wave + NCHUNK * 1024 + 32);      // [256] histogram / scatter scratch
-  uint32_t* list = (uint32_t*)(smem + wave * per_wave + NCHUNK * 1024 + 32 + kScratch);   // [kpad] survivors (packed keys)
 
   // Peaks only: the six bytes before and after the row (AxialNonMaxSupress reads them through unchecked cv::Mat::at,
   // radar_filters.cpp:238-298).  Their loads are issued here, together with the row's, so that they cost no extra
   // memory round trip later.
-  const bool do_peaks = a.want_peaks && a.is_peak;
+  const bool do_peaks = !STAGED && a.want_peaks && a.is_peak;
   uint8_t halo = 0;
   int halo_pos = 0;                                // rowbuf offset this lane's halo byte belongs to (0 = none)
   if (do_peaks && (lane < 6 || (lane >= 8 && lane < 14))) {
@@ -168,18 +161,29 @@ __global__ __launch_bounds__(256, 7) void kstrongest_rows_kernel(const KStrongAr
     }
     if (lin >= 0 && lin < total) halo = img[lin];
   }
+  const int cols16 = (a.cols + 15) & ~15;          // STAGED: the bytes of rowbuf that may be read
   uint32_t w[NCHUNK * 4];
-  load_row<NCHUNK, VEC>(rowp, a.cols, lane, w);
+  if (STAGED) {
 #pragma unroll
-  for (int c = 0; c < NCHUNK; c++)                 // stage the row: candidate bytes are fetched by position
-    *(uint4*)(rowbuf + (c * 64 + lane) * 16) = make_uint4(w[c * 4], w[c * 4 + 1], w[c * 4 + 2], w[c * 4 + 3]);
+    for (int c = 0; c < NCHUNK; c++) {
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if ((c * 64 + lane) * 16 < cols16) v = *(const uint4*)(rowbuf + (c * 64 + lane) * 16);
+      w[c * 4] = v.x; w[c * 4 + 1] = v.y; w[c * 4 + 2] = v.z; w[c * 4 + 3] = v.w;
+    }
+  } else {
+    load_row<NCHUNK, VEC>(rowp, a.cols, lane, w);
+#pragma unroll
+    for (int c = 0; c < NCHUNK; c++)                 // stage the row: candidate bytes are fetched by position
+      *(uint4*)(rowbuf + (c * 64 + lane) * 16) = make_uint4(w[c * 4], w[c * 4 + 1], w[c * 4 + 2], w[c * 4 + 3]);
+  }
 
   // The row lives on in LDS: the (rare) later passes over it re-read it from there instead of keeping 4 NCHUNK
   // registers alive across the whole kernel (occupancy: 8 wavefronts per SIMD need <= 64 VGPRs).
   auto reload_row = [&](uint32_t (&x)[NCHUNK * 4]) {
 #pragma unroll
     for (int c = 0; c < NCHUNK; c++) {
-      const uint4 v = *(const uint4*)(rowbuf + (c * 64 + lane) * 16);
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (!STAGED || (c * 64 + lane) * 16 < cols16) v = *(const uint4*)(rowbuf + (c * 64 + lane) * 16);
       x[c * 4] = v.x; x[c * 4 + 1] = v.y; x[c * 4 + 2] = v.z; x[c * 4 + 3] = v.w;
     }
   };
@@ -549,6 +553,328 @@ __global__ __launch_bounds__(256, 7) void kstrongest_rows_kernel(const KStrongAr
       a.row_valid[((long long)b * a.rows + r) * 2 + 1] = nvalid_pk;
     }
     if (a.sel_count) a.sel_count[(long long)b * a.rows + r] = n_sel;
+  }
+}
+
+// per-wavefront LDS of a row: [raw row + 16-byte halos] (not STAGED) | scratch | list
+__host__ __device__ constexpr int kstrong_scratch_bytes(int nchunk) { return ((nchunk + 1) / 2 + 2) * 256 > 1024 ? ((nchunk + 1) / 2 + 2) * 256 : 1024; }
+
+template <int NCHUNK, bool VEC, bool MASK>
+__global__ __launch_bounds__(256, 7) void kstrongest_rows_kernel(const KStrongArgs a) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int r = blockIdx.x * kRowsPerBlock + wave;          // grid = (row quads, images): no division
+  if (r >= a.rows) return;                                  // no workgroup barrier below
+  const int b = a.batch0 + blockIdx.y;
+  const uint8_t* img = a.polar + (a.image_offsets ? a.image_offsets[b] : (long long)b * a.batch_stride);
+  const int kpad = max((a.k + 3) & ~3, 64);        // list capacity: k survivors, or up to 64 candidates to rank
+  constexpr int kScratch = kstrong_scratch_bytes(NCHUNK);   // marker u8[256] | sexcl[64] | spw[NP][64], or hist[256]
+  const int per_wave = NCHUNK * 1024 + 32 + kScratch + kpad * 4;
+  uint8_t* rowbuf = smem + wave * per_wave + 16;                                  // the raw row, 16-byte halo either side
+  uint32_t* hist = (uint32_t*)(smem + wave * per_wave + NCHUNK * 1024 + 32);      // [256] histogram / scatter scratch
+  uint32_t* list = (uint32_t*)(smem + wave * per_wave + NCHUNK * 1024 + 32 + kScratch);   // [kpad] survivors (packed keys)
+  kstrong_row<NCHUNK, VEC, MASK, false>(a, r, b, img, rowbuf, hist, list, lane);
+}
+
+// ---- [range bins][azimuths] sources: the driver's decode fused into the sweep ---------------------------------------
+// radarDriver::Callback (radar_driver.cpp:74-90) rotates such a sweep 90 degrees counter-clockwise before Process();
+// rotate_ccw_rows_kernel + kstrongest_rows_kernel move the image through HBM three times (read, write, read).  The fused
+// route reads it ONCE, along its own rows, and never builds the rotated image:
+//   1. kstrong_extract_kernel   streams the source in 16-byte pieces (16 azimuths of one bin), a SWAR compare finds the
+//      bytes >= uchar(z_min) -- the only bins FilterKstrongest can keep (radar_filters.cpp:217) -- and appends each as a
+//      key (intensity << 24 | bin) to the list of ITS azimuth (a global atomic per candidate; a radar sweep holds a few
+//      dozen per azimuth).  No LDS, a dozen registers: the kernel runs at the speed of the read.
+//   2. kstrong_select_kernel    one wavefront per azimuth: the k largest keys of the list ARE the reference's selection
+//      (lexicographic (intensity, range) cut, ties toward the larger range), ranked into its ascending order.
+//   3. kstrongest_cols_kernel   azimuths with more than kCandCap candidates (dense returns; z_min = 0) need the raw row:
+//      pass 2 puts their 16-column tile on a work list, and this kernel transposes those tiles into LDS (v_perm_b32 on
+//      4 x 4 byte blocks) and runs the complete row algorithm on them.  Without a list it takes every tile.
+// a.rows / a.cols are the ROTATED image's (azimuths, bins); a.stride / a.batch_stride are the SOURCE's (bytes per bin
+// row, per image).  Output row r holds source column a.rows - 1 - r (cv::ROTATE_90_COUNTERCLOCKWISE).
+constexpr int kColsTile = 16;
+constexpr int kColsWaves = 8;
+constexpr int kXcds = 8;
+constexpr int kCandCap = 256;                 // candidate keys kept per azimuth (1 KiB)
+constexpr int kExtractPieces = 8;             // 16-byte pieces per thread and step (the select tree below is written for 8)
+
+// The candidates among kExtractPieces 16-byte pieces held in registers (w[u] = piece p0 + step * u of the image, pieces
+// numbered along the source rows: piece p = bin p / segs, source columns 16 (p % segs) ..): emit(r, key) once per byte
+// >= uchar(z_min), r = the azimuth row of the ROTATED image.  One candidate per lane and turn, whichever piece it sits in
+// (a wall fills adjacent azimuths of ONE piece): a wavefront takes as many turns as its busiest lane holds candidates.
+template <typename Emit>
+__device__ __forceinline__ void extract_candidates(const KStrongArgs& a, const uint32_t (&w)[kExtractPieces][4], const uint32_t p0,
+                                                   const uint32_t step, const uint32_t n_pieces, const uint32_t seg_magic,
+                                                   const int segs, Emit&& emit) {
+  const uint32_t tz4 = (uint32_t)(a.u_zmin & 0x7f) * 0x01010101u;
+  const bool thi = (a.u_zmin & 0x80) != 0;
+  uint32_t cm[kExtractPieces / 2];                           // bit 16 (u & 1) + 4 d + byte of word u / 2
+#pragma unroll
+  for (int h = 0; h < kExtractPieces / 2; h++) cm[h] = 0;
+#pragma unroll
+  for (int u = 0; u < kExtractPieces; u++) {
+    uint32_t pm = 0;
+#pragma unroll
+    for (int d = 0; d < 4; d++)                              // bit 7 of every byte -> one nibble (v_dot4_u32_u8)
+      pm |= __builtin_amdgcn_udot4((swar_ge(w[u][d], tz4, thi) >> 7) & 0x01010101u, 0x08040201u, 0u, false) << (4 * d);
+    if (p0 + step * u >= n_pieces) pm = 0;
+    cm[u >> 1] |= pm << (16 * (u & 1));
+  }
+  for (;;) {
+    int t = -1;
+#pragma unroll
+    for (int h = kExtractPieces / 2 - 1; h >= 0; h--)
+      if (cm[h]) t = 32 * h + __ffs(cm[h]) - 1;
+    if (t < 0) break;
+#pragma unroll
+    for (int h = 0; h < kExtractPieces / 2; h++)
+      if ((t >> 5) == h) cm[h] &= cm[h] - 1;
+    const int u = t >> 4, e = t & 15;
+    uint32_t word = 0;                                       // w[u][e >> 2]: registers cannot be indexed by a lane
+#pragma unroll
+    for (int i = 0; i < kExtractPieces * 4; i++)
+      if (i == (u << 2 | e >> 2)) word = w[i >> 2][i & 3];
+    const uint32_t p = p0 + step * (uint32_t)u;
+    const uint32_t j = segs == 1 ? p : __umulhi(p, seg_magic), sg = p - j * (uint32_t)segs;
+    emit(a.rows - 1 - (int)(16u * sg + e), (((word >> (8 * (e & 3))) & 0xffu) << 24) | j);
+  }
+}
+
+__device__ __forceinline__ void load_pieces(const KStrongArgs& a, const uint8_t* img, const uint32_t p0, const uint32_t step,
+                                            const uint32_t n_pieces, const uint32_t seg_magic, const int segs,
+                                            uint32_t (&w)[kExtractPieces][4]) {
+#pragma unroll
+  for (int u = 0; u < kExtractPieces; u++) {
+    const uint32_t p = min(p0 + step * u, n_pieces - 1u);
+    const uint32_t j = segs == 1 ? p : __umulhi(p, seg_magic), sg = p - j * (uint32_t)segs;
+    const u32x4 v = __builtin_nontemporal_load((const u32x4*)(img + (size_t)j * a.stride + 16u * sg));
+    w[u][0] = v.x; w[u][1] = v.y; w[u][2] = v.z; w[u][3] = v.w;
+  }
+}
+
+// The k strongest of one azimuth's n <= kCandCap candidate keys (fetch(j), j < n, any order) -> row_keys / row_valid.
+// list: [kCandCap + 8] dwords of this wavefront's LDS.  Survivors = the min(n, k) largest keys -- the lexicographic
+// (intensity, range) cut of FilterKstrongest (radar_filters.cpp:214-229), ties toward the larger range; the slot of a
+// survivor = its rank among the survivors beyond min_range_bin (getPeaksFilteredPointCloud(cloud, false), :309-337).
+template <typename Fetch>
+__device__ __forceinline__ void select_row(const KStrongArgs& a, const long long row, const int n, uint32_t* list, const int lane,
+                                           Fetch&& fetch) {
+  uint32_t* bits = list + kCandCap + 4;
+  constexpr int NR = kCandCap / 64;
+  uint32_t key[NR];
+#pragma unroll
+  for (int i = 0; i < NR; i++) {
+    const int j = i * 64 + lane;
+    key[i] = 0xFFFFFFFFu;                                    // the padding ranks above every key
+    if (i * 64 < n) {
+      if (j < n) key[i] = fetch(j);
+      list[j] = key[i];
+    }
+  }
+  if (lane < 2) bits[lane] = 0;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  const int k = a.k, drop = n - min(n, k), nq = (n + 3) & ~3;
+  int rank[NR];
+  bool beyond[NR];
+#pragma unroll
+  for (int i = 0; i < NR; i++) {
+    rank[i] = -1;
+    beyond[i] = false;
+    if (i * 64 < n) {                                        // wave-uniform
+      if (i * 64 + lane < n) {
+        int c = 0;
+        for (int q = 0; q < nq; q += 4) {
+          const uint4 x = *(const uint4*)(list + q);         // same address in every lane: LDS broadcast
+          c += (x.x < key[i]) + (x.y < key[i]) + (x.z < key[i]) + (x.w < key[i]);
+        }
+        rank[i] = c - drop;
+      }
+      beyond[i] = rank[i] >= 0 && (int)(key[i] & 0xFFFFFFu) > a.min_range_bin;
+      if (beyond[i]) atomicOr(&bits[rank[i] >> 5], 1u << (rank[i] & 31));      // (the survivors' ranks are < k <= 64)
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  const uint32_t m0 = bits[0], m1 = bits[1];
+#pragma unroll
+  for (int i = 0; i < NR; i++) {
+    if (beyond[i]) {
+      const int rk = rank[i];
+      const int idx = rk < 32 ? __popc(m0 & ((1u << rk) - 1u)) : __popc(m0) + __popc(m1 & ((1u << (rk - 32)) - 1u));
+      a.row_keys[row * k + idx] = key[i];
+    }
+  }
+  if (lane == 0) {
+    a.row_valid[row * 2] = __popc(m0) + __popc(m1);
+    a.row_valid[row * 2 + 1] = 0;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // the list is reused by the wavefront's next row
+  __builtin_amdgcn_wave_barrier();
+}
+
+// a row whose list overflowed: its 16-column tile goes to kstrongest_cols_kernel (once)
+__device__ __forceinline__ void flag_tile(const KStrongArgs& a, const int b, const int r, const int tiles, uint32_t* tile_flag,
+                                          int32_t* work_n, uint32_t* work) {
+  const uint32_t id = (uint32_t)b * (uint32_t)tiles + (uint32_t)((a.rows - 1 - r) / kColsTile);
+  if (atomicExch(&tile_flag[id], 1u) == 0u) work[atomicAdd(work_n, 1)] = id;
+}
+
+// ---- small batches: many workgroups per image, the lists in global memory (one atomic per candidate) ---------------
+__global__ __launch_bounds__(256) void kstrong_extract_kernel(const KStrongArgs a, const uint32_t seg_magic, const int segs,
+                                                              int32_t* __restrict__ cand_cnt, uint32_t* __restrict__ cand) {
+  const int b = a.batch0 + blockIdx.y;
+  const uint8_t* img = a.polar + (long long)b * a.batch_stride;
+  const uint32_t n_pieces = (uint32_t)a.cols * (uint32_t)segs;
+  const uint32_t p0 = blockIdx.x * (256u * kExtractPieces) + threadIdx.x;
+  uint32_t w[kExtractPieces][4];
+  load_pieces(a, img, p0, 256u, n_pieces, seg_magic, segs, w);
+  extract_candidates(a, w, p0, 256u, n_pieces, seg_magic, segs, [&](const int r, const uint32_t key) {
+    const long long row = (long long)b * a.rows + r;
+    const int slot = atomicAdd(&cand_cnt[row], 1);
+    if (slot < kCandCap) cand[row * kCandCap + slot] = key;
+  });
+}
+
+__global__ __launch_bounds__(256) void kstrong_select_kernel(const KStrongArgs a, const int tiles, const int32_t* __restrict__ cand_cnt,
+                                                             const uint32_t* __restrict__ cand, uint32_t* tile_flag,
+                                                             int32_t* work_n, uint32_t* work) {
+  __shared__ __attribute__((aligned(16))) uint32_t lists[kRowsPerBlock][kCandCap + 8];   // keys | 2 bitmap words
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int r = blockIdx.x * kRowsPerBlock + wave;
+  if (r >= a.rows) return;                                   // no workgroup barrier below
+  const int b = a.batch0 + blockIdx.y;
+  const long long row = (long long)b * a.rows + r;
+  const int n = __builtin_amdgcn_readfirstlane(cand_cnt[row]);
+  if (n > kCandCap) {                                        // the list is incomplete: the row needs its raw bytes
+    if (lane == 0) flag_tile(a, b, r, tiles, tile_flag, work_n, work);
+    return;
+  }
+  select_row(a, row, n, lists[wave], lane, [&](const int j) { return cand[row * kCandCap + j]; });
+}
+
+// ---- large batches: ONE workgroup streams a whole image; the lists of all its azimuths sit in LDS (the first lds_cap
+// keys of each; the rest, up to kCandCap, in global memory), so a candidate costs an LDS atomic, and the same workgroup
+// then picks the k strongest of every list: one kernel, nothing but the keys written.  Two workgroups per CU: one streams
+// while the other selects.
+constexpr int kImgWaves = 8;
+
+__global__ __launch_bounds__(64 * kImgWaves, 4) void kstrong_image_kernel(const KStrongArgs a, const uint32_t seg_magic, const int segs,
+                                                                           const int tiles, const int lds_cap,
+                                                                           uint32_t* __restrict__ cand, uint32_t* tile_flag,
+                                                                           int32_t* work_n, uint32_t* work) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int rows4 = (a.rows + 3) & ~3;
+  uint32_t* cnt = (uint32_t*)smem;                           // [rows]
+  uint32_t* lists = cnt + rows4;                             // [rows][lds_cap]
+  uint32_t* mine = lists + (size_t)a.rows * lds_cap + wave * (kCandCap + 8);
+  const uint32_t n_pieces = (uint32_t)a.cols * (uint32_t)segs;
+  constexpr uint32_t kThreads = 64 * kImgWaves;
+  for (int b = blockIdx.x; b < a.batch; b += gridDim.x) {
+    const uint8_t* img = a.polar + (long long)b * a.batch_stride;
+    for (int i = threadIdx.x; i < a.rows; i += kThreads) cnt[i] = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < n_pieces; base += kThreads * kExtractPieces) {
+      uint32_t w[kExtractPieces][4];
+      load_pieces(a, img, base + threadIdx.x, kThreads, n_pieces, seg_magic, segs, w);
+      extract_candidates(a, w, base + threadIdx.x, kThreads, n_pieces, seg_magic, segs, [&](const int r, const uint32_t key) {
+        const int slot = (int)atomicAdd(&cnt[r], 1u);
+        if (slot < lds_cap) lists[r * lds_cap + slot] = key;
+        else if (slot < kCandCap) cand[((long long)b * a.rows + r) * kCandCap + slot] = key;
+      });
+    }
+    __syncthreads();                                         // (also orders the overflow stores before the loads below)
+    for (int r = wave; r < a.rows; r += kImgWaves) {
+      const long long row = (long long)b * a.rows + r;
+      const int n = (int)cnt[r];
+      if (n > kCandCap) {
+        if (lane == 0) flag_tile(a, b, r, tiles, tile_flag, work_n, work);
+        continue;
+      }
+      select_row(a, row, n, mine, lane, [&](const int j) { return j < lds_cap ? lists[r * lds_cap + j] : cand[row * kCandCap + j]; });
+    }
+    __syncthreads();                                         // the counters are cleared for the next image
+  }
+}
+
+// Persistent workgroups, two per CU.  With a work list: tile ids (image * tiles + tile), taken round robin.  Without:
+// every tile of every image -- workgroup n lives on XCD n % 8 and is that XCD's slot n / 8; XCD x takes the images
+// b = x (mod 8), tile after tile, its slots striding through that sequence together, so the (up to) eight tiles that
+// share a 128-byte line are read by neighbouring slots of one XCD at about the same time.  While a workgroup runs the
+// row algorithm on the tile in LDS, the 16-byte pieces of its NEXT tile are already in flight into registers.
+template <int NCHUNK, bool MASK>
+__global__ __launch_bounds__(64 * kColsWaves, 4) void kstrongest_cols_kernel(const KStrongArgs a, const int tiles,
+                                                                              const uint32_t* __restrict__ work,
+                                                                              const int32_t* __restrict__ work_n) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int xcd = blockIdx.x % kXcds, slot = blockIdx.x / kXcds, slots = gridDim.x / kXcds;
+  const int nq = work ? *work_n : ((a.batch - xcd + kXcds - 1) / kXcds) * tiles;       // items of this workgroup's sequence
+  const int q0 = work ? (int)blockIdx.x : slot, dq = work ? (int)gridDim.x : slots;
+  auto locate = [&](const int q, int& b, int& tile) {
+    if (work) { const uint32_t id = work[q]; b = (int)(id / (uint32_t)tiles); tile = (int)(id - (uint32_t)b * (uint32_t)tiles); }
+    else { const int im = q / tiles; b = im * kXcds + xcd; tile = q - im * tiles; }
+  };
+  const int bins = a.cols, cols16 = (bins + 15) & ~15;
+  const int kpad = max((a.k + 3) & ~3, 64);
+  constexpr int kScratch = kstrong_scratch_bytes(NCHUNK);
+  uint8_t* tbase = smem;                                     // [kColsTile][cols16]: row lr = source column c0 + 15 - lr
+  uint32_t* hist = (uint32_t*)(smem + kColsTile * cols16 + wave * (kScratch + kpad * 4));
+  uint32_t* list = hist + kScratch / 4;
+  constexpr int GP = (NCHUNK * 256 + 64 * kColsWaves - 1) / (64 * kColsWaves);   // groups of 4 bins per thread
+  uint32_t rw[GP][4][4];
+  // one 32-bit byte offset per group and thread (groups past the last bin re-read the last one; their tile bytes are
+  // zeroed below), the bin row i and the tile folded into the wave-uniform base: SGPR base + VGPR offset addressing
+  uint32_t goff[GP];
+#pragma unroll
+  for (int p = 0; p < GP; p++)
+    goff[p] = (uint32_t)min((int)threadIdx.x + p * 64 * kColsWaves, (bins >> 2) - 1) * 4u * (uint32_t)a.stride;
+  auto issue = [&](const int q) {                            // the pieces of item q: bins 4 g .. 4 g + 3, 16 source columns
+    int b, tile;
+    locate(q, b, tile);
+    const uint8_t* src = a.polar + (long long)b * a.batch_stride + tile * kColsTile;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const uint8_t* bi = src + (long long)i * a.stride;
+#pragma unroll
+      for (int p = 0; p < GP; p++) {
+        const u32x4 v = *(const u32x4*)(bi + (size_t)goff[p]);
+        rw[p][i][0] = v.x; rw[p][i][1] = v.y; rw[p][i][2] = v.z; rw[p][i][3] = v.w;
+      }
+    }
+  };
+  int q = q0;
+  if (q < nq) issue(q);
+  while (q < nq) {
+#pragma unroll
+    for (int p = 0; p < GP; p++) {
+      const int g = threadIdx.x + p * 64 * kColsWaves;
+      if (4 * g < cols16) {
+#pragma unroll
+        for (int d = 0; d < 4; d++) {                        // source columns c0 + 4 d .. + 3 of bins 4 g .. 4 g + 3
+          const uint32_t w0 = rw[p][0][d], w1 = rw[p][1][d], w2 = rw[p][2][d], w3 = rw[p][3][d];
+          const uint32_t t0 = __builtin_amdgcn_perm(w1, w0, 0x05010400u), t1 = __builtin_amdgcn_perm(w1, w0, 0x07030602u);
+          const uint32_t t2 = __builtin_amdgcn_perm(w3, w2, 0x05010400u), t3 = __builtin_amdgcn_perm(w3, w2, 0x07030602u);
+          uint32_t colw[4];                                  // colw[e] = column c0 + 4 d + e as {bin 4g, +1, +2, +3}
+          colw[0] = __builtin_amdgcn_perm(t2, t0, 0x05040100u); colw[1] = __builtin_amdgcn_perm(t2, t0, 0x07060302u);
+          colw[2] = __builtin_amdgcn_perm(t3, t1, 0x05040100u); colw[3] = __builtin_amdgcn_perm(t3, t1, 0x07060302u);
+#pragma unroll
+          for (int e = 0; e < 4; e++)
+            *(uint32_t*)(tbase + (kColsTile - 1 - (4 * d + e)) * cols16 + 4 * g) = 4 * g < bins ? colw[e] : 0u;
+        }
+      }
+    }
+    __syncthreads();
+    int b, tile;
+    locate(q, b, tile);
+    const int qn = q + dq;
+    if (qn < nq) issue(qn);
+    const int r0 = a.rows - kColsTile - tile * kColsTile;    // output row of tile row 0
+    for (int lr = wave; lr < kColsTile; lr += kColsWaves)
+      kstrong_row<NCHUNK, true, MASK, true>(a, r0 + lr, b, a.polar, tbase + lr * cols16, hist, list, lane);
+    __syncthreads();                                         // every row of the tile has been consumed
+    q = qn;
   }
 }
 
@@ -1398,6 +1724,137 @@ int cfear_kstrong_device(cfear_ctx* ctx, const uint8_t* d_polar, const cfear_pol
     CFEAR_HIP_CHECK(ctx, hipGetLastError());
   }
   return CFEAR_OK;
+}
+
+// [range bins][azimuths] sources, fused decode + sweep (kstrongest_cols_kernel): `sd` describes the SOURCE images (rows =
+// range bins, cols = azimuths).  Only the batched odometry's key output; whatever this path does not take (peaks, k > 64,
+// unaligned or ragged images, more than 4096 bins) goes through cfear_rotate_ccw_device + cfear_kstrong_device.
+bool cfear_kstrong_cols_supported(const uint8_t* d_src, const cfear_polar_desc* sd, const cfear_kstrong_params* par) {
+  return par->k_strongest <= 64 && sd->rows <= 4096 && sd->rows % 4 == 0 && sd->cols % kColsTile == 0 && sd->stride % 16 == 0 &&
+         (uintptr_t)d_src % 16 == 0 && (sd->batch <= 1 || sd->batch_stride % 16 == 0) &&
+         (int64_t)sd->rows * sd->stride < ((int64_t)1 << 31);
+}
+
+// route: 0 = by batch size, 1 = lists in global memory (small batches), 2 = one workgroup per image, 3 = every tile
+// through the LDS transposition
+int cfear_kstrong_cols_device(cfear_ctx* ctx, const uint8_t* d_src, const cfear_polar_desc* sd, const cfear_kstrong_params* par,
+                              const cfear_kstrong_fused* fused, int route) {
+  bool all_tiles = route == 3;
+  if (!fused || !fused->row_keys || !fused->row_valid || !cfear_kstrong_cols_supported(d_src, sd, par))
+    return cfear_set_error(ctx, CFEAR_ERR_INVALID_ARGUMENT, "fused decode: unsupported image geometry or outputs");
+  KStrongArgs a{};
+  a.polar = d_src;
+  a.rows = sd->cols; a.cols = sd->rows; a.stride = sd->stride; a.batch = sd->batch;
+  a.batch_stride = sd->batch > 1 ? sd->batch_stride : (int64_t)sd->rows * sd->stride;
+  a.k = par->k_strongest;
+  a.u_zmin = (int)(uint8_t)(int)par->z_min;                    // radar_driver.cpp:58, radar_filters.cpp:212
+  a.row_keys = fused->row_keys;
+  a.row_valid = fused->row_valid;
+  a.min_range_bin = (int)std::ceil((double)par->min_distance / (double)par->range_res);   // radar_filters.cpp:315
+  const bool mask = (a.cols % 16 != 0) || a.u_zmin == 0;
+  const int nchunk = (a.cols + 1023) / 1024, tiles = a.rows / kColsTile;
+  if (a.u_zmin == 0) all_tiles = true;                       // every bin is a candidate: the lists would only overflow
+  // scratch: candidate counts | tile flags | work count | work list | candidate keys
+  const size_t n_rows = (size_t)a.batch * a.rows, n_tiles = (size_t)a.batch * tiles;
+  const size_t o_flag = n_rows * 4, o_wn = o_flag + n_tiles * 4, o_work = o_wn + 256, o_cand = (o_work + n_tiles * 4 + 255) / 256 * 256;
+  uint32_t* work = nullptr;
+  int32_t* work_n = nullptr;
+  int n_cu = 256;
+  (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, ctx->device);
+  if (!all_tiles) {
+    char* ws = (char*)cfear_workspace(ctx, 12, o_cand + n_rows * kCandCap * 4);
+    if (!ws) return cfear_set_error(ctx, CFEAR_ERR_HIP, "workspace allocation failed");
+    int32_t* cand_cnt = (int32_t*)ws;
+    uint32_t* tile_flag = (uint32_t*)(ws + o_flag);
+    uint32_t* cand = (uint32_t*)(ws + o_cand);
+    work_n = (int32_t*)(ws + o_wn);
+    work = (uint32_t*)(ws + o_work);
+    const int segs = a.rows / 16;
+    const uint32_t magic = (uint32_t)(((uint64_t)1 << 32) / (uint32_t)segs) + 1u;   // p / segs = umulhi(p, magic) while p * segs < 2^32; segs = 1 is taken apart in the kernel
+    const uint32_t n_pieces = (uint32_t)a.cols * (uint32_t)segs;
+    // image-per-workgroup route: worth it once the batch fills the chip; its LDS holds rows * (1 + lds_cap) dwords
+    const size_t img_fixed = (size_t)((a.rows + 3) & ~3) * 4 + (size_t)kImgWaves * (kCandCap + 8) * 4;
+    const int lds_cap = (int)std::min<size_t>(40, (80 * 1024 - 512 - img_fixed) / ((size_t)a.rows * 4));
+    const bool per_image = route == 2 || (route == 0 && a.batch >= n_cu && lds_cap >= 16);
+    if (per_image && lds_cap < 1) return cfear_set_error(ctx, CFEAR_ERR_INVALID_ARGUMENT, "fused decode: too many azimuths for the image route");
+    if (per_image) {
+      CFEAR_HIP_CHECK(ctx, hipMemsetAsync(ws + o_flag, 0, o_work - o_flag, ctx->stream));
+      const size_t lds = img_fixed + (size_t)a.rows * lds_cap * 4;
+      CFEAR_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)kstrong_image_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      ProfScope ps(ctx, "kstrong_image");
+      hipLaunchKernelGGL(kstrong_image_kernel, dim3((unsigned)std::min(a.batch, 2 * n_cu)), dim3(64 * kImgWaves), lds, ctx->stream, a,
+                         magic, segs, tiles, lds_cap, cand, tile_flag, work_n, work);
+    } else {
+      CFEAR_HIP_CHECK(ctx, hipMemsetAsync(ws, 0, o_work, ctx->stream));
+      for (int b0 = 0; b0 < a.batch; b0 += 65535) {             // gridDim.y limit
+        a.batch0 = b0;
+        const unsigned by = (unsigned)std::min(65535, a.batch - b0);
+        {
+          ProfScope ps(ctx, "kstrong_extract");
+          hipLaunchKernelGGL(kstrong_extract_kernel, dim3((n_pieces + 256 * kExtractPieces - 1) / (256 * kExtractPieces), by), dim3(256), 0,
+                             ctx->stream, a, magic, segs, cand_cnt, cand);
+        }
+        {
+          ProfScope ps(ctx, "kstrong_select");
+          hipLaunchKernelGGL(kstrong_select_kernel, dim3((a.rows + kRowsPerBlock - 1) / kRowsPerBlock, by), dim3(256), 0, ctx->stream, a,
+                             tiles, cand_cnt, cand, tile_flag, work_n, work);
+        }
+      }
+      a.batch0 = 0;
+    }
+  }
+  const int kpad = std::max((a.k + 3) & ~3, 64);
+  const size_t lds = (size_t)kColsTile * ((a.cols + 15) & ~15) +
+                     (size_t)kColsWaves * (kstrong_scratch_bytes(nchunk <= 1 ? 1 : (nchunk <= 2 ? 2 : 4)) + kpad * 4);
+  // persistent: two workgroups per CU (LDS), a multiple of the XCD count; fewer when the batch is small
+  const long long per_xcd = (long long)tiles * ((a.batch + kXcds - 1) / kXcds);
+  const int slots = (int)std::max<long long>(1, std::min<long long>(per_xcd, std::max(1, n_cu * 2 / kXcds)));
+  const dim3 grid((unsigned)(slots * kXcds));
+  ProfScope ps(ctx, "kstrongest_cols");
+  auto launch = [&](auto fn) {
+    (void)hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipLaunchKernelGGL(fn, grid, dim3(64 * kColsWaves), lds, ctx->stream, a, tiles, (const uint32_t*)work, (const int32_t*)work_n);
+  };
+  if (nchunk <= 1) { if (mask) launch(kstrongest_cols_kernel<1, true>); else launch(kstrongest_cols_kernel<1, false>); }
+  else if (nchunk <= 2) { if (mask) launch(kstrongest_cols_kernel<2, true>); else launch(kstrongest_cols_kernel<2, false>); }
+  else { if (mask) launch(kstrongest_cols_kernel<4, true>); else launch(kstrongest_cols_kernel<4, false>); }
+  CFEAR_HIP_CHECK(ctx, hipGetLastError());
+  return CFEAR_OK;
+}
+
+extern "C" int cfear_filter_kstrongest_rowkeys(cfear_ctx* ctx, const uint8_t* polar, const cfear_polar_desc* desc,
+                                               const cfear_kstrong_params* par, int32_t flags, uint32_t* row_keys,
+                                               int32_t* row_counts) {
+  if (!ctx) return CFEAR_ERR_INVALID_ARGUMENT;
+  if (!polar || !par || !row_keys || !row_counts) return cfear_set_error(ctx, CFEAR_ERR_INVALID_ARGUMENT, "null argument");
+  const bool bins_major = (flags & CFEAR_ROWKEYS_BINS_MAJOR) != 0;
+  if (!desc || desc->rows <= 0 || desc->cols <= 0 || desc->stride < desc->cols || desc->batch <= 0 ||
+      (desc->batch > 1 && desc->batch_stride < (int64_t)desc->rows * desc->stride) ||
+      (bins_major ? desc->rows : desc->cols) > kMaxCols)
+    return cfear_set_error(ctx, CFEAR_ERR_INVALID_ARGUMENT, "bad polar descriptor");
+  if (par->k_strongest < 1 || par->k_strongest > 64)
+    return cfear_set_error(ctx, CFEAR_ERR_INVALID_ARGUMENT, "row keys need k_strongest in [1,64]");
+  if (!(par->range_res > 0.f)) return cfear_set_error(ctx, CFEAR_ERR_INVALID_ARGUMENT, "range_res must be > 0");
+  if (!cfear_is_device_ptr(polar) || !cfear_is_device_ptr(row_keys) || !cfear_is_device_ptr(row_counts))
+    return cfear_set_error(ctx, CFEAR_ERR_INVALID_ARGUMENT, "images and outputs must be device memory");
+  CFEAR_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  cfear_kstrong_params kp = *par;
+  kp.want_peaks = 0;
+  cfear_kstrong_fused fz;
+  fz.row_keys = row_keys;
+  fz.row_valid = row_counts;
+  cfear_kstrong_out none{};
+  if (!bins_major) return cfear_kstrong_device(ctx, polar, desc, &kp, &none, false, &fz);
+  if (!(flags & CFEAR_ROWKEYS_TWO_PASS) && cfear_kstrong_cols_supported(polar, desc, &kp))
+    return cfear_kstrong_cols_device(ctx, polar, desc, &kp, &fz, (flags & CFEAR_ROWKEYS_TILE_SWEEP) ? 3 : ((flags >> 4) & 3));
+  cfear_polar_desc rd{};                                      // the rotated images: rows = azimuths
+  rd.rows = desc->cols; rd.cols = desc->rows; rd.stride = (desc->rows + 15) & ~15; rd.batch = desc->batch;
+  rd.batch_stride = (int64_t)rd.rows * rd.stride;
+  uint8_t* rot = (uint8_t*)cfear_workspace(ctx, 0, (size_t)rd.batch_stride * rd.batch);
+  if (!rot) return cfear_set_error(ctx, CFEAR_ERR_HIP, "workspace allocation failed");
+  const int rc = cfear_rotate_ccw_device(ctx, polar, desc, rot, rd.stride, rd.batch_stride);
+  if (rc != CFEAR_OK) return rc;
+  return cfear_kstrong_device(ctx, rot, &rd, &kp, &none, true, &fz);
 }
 
 extern "C" int cfear_filter_kstrongest(cfear_ctx* ctx, const uint8_t* polar, const cfear_polar_desc* desc,

@@ -103,6 +103,7 @@ struct cfear_odometry {
   // device memory (one allocation each)
   uint8_t* d_polar = nullptr;          // staging when the caller passes host images
   uint8_t* d_rot = nullptr;            // rotated images (par.rotate_ccw)
+  bool fused_decode = false;           // par.rotate_ccw: the sweep transposes the source itself where it can (no d_rot)
   char* d_sel = nullptr;               // sel_range | sel_intensity | sel_count
   float* d_xyzi2[2] = {nullptr, nullptr};    // filter outputs are double-buffered: the next frame's filter
   int32_t* d_npts2[2] = {nullptr, nullptr};  //   may run while the host applies this frame's policy
@@ -251,6 +252,9 @@ extern "C" int cfear_odometry_create(cfear_ctx* ctx, int32_t n_streams, const cf
   od->fused = par->filter_type == CFEAR_FILTER_KSTRONG && !par->keep_nodes && k <= 64 && rows <= 4096 &&
               rows * k <= cfear_surface_max_points();
   od->row_k = k;
+  // [range bins][azimuths] sources: decode fused into the sweep (CFEAR_NO_FUSED_DECODE keeps the two-kernel route, for
+  // A/B runs and the tests that compare the two)
+  od->fused_decode = od->fused && par->rotate_ccw && !getenv("CFEAR_NO_FUSED_DECODE");
   // CA-CFAR puts no bound on a row's detections either: 1024 keys per row (a row beyond that marks its scan
   // CFEAR_ERR_CAPACITY, like a sweep beyond cap_points)
   od->fused_cfar = par->filter_type == CFEAR_FILTER_CACFAR && !par->keep_nodes && rows <= 4096;
@@ -364,6 +368,14 @@ static int run_filter(cfear_odometry* od, const uint8_t* polar, int buf, const i
     }
     d_polar = od->d_polar;
     dd.batch_stride = (int64_t)img_bytes;
+  }
+  if (od->fused_decode && cfear_kstrong_cols_supported(d_polar, &dd, &par.kstrong)) {
+    cfear_kstrong_params kp = par.kstrong;
+    kp.want_peaks = 0;
+    cfear_kstrong_fused fz;
+    fz.row_keys = od->d_rowpts2[buf];
+    fz.row_valid = od->d_rowcnt2[buf];
+    return cfear_kstrong_cols_device(ctx, d_polar, &dd, &kp, &fz);
   }
   if (par.rotate_ccw) {
     const size_t rot_bytes = (size_t)od->desc.rows * od->desc.stride;

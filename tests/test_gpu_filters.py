@@ -380,3 +380,92 @@ def test_legacy_k_strongest_filter_vs_oracle():
     for b in range(2):
         n = int(h["n_points"][b])
         np.testing.assert_array_equal(d["xyzi"][b, :n].cpu().numpy(), h["xyzi"][b, :n])
+
+
+def _rowkeys_expected(img, k, z_min, range_res, min_distance):
+    """[azimuths][<= k] packed keys (intensity << 24 | bin) of the kept bins beyond ceil(min_distance / range_res), in the
+    oracle's (intensity, range) order (radar_filters.cpp:209-237, 309-337)."""
+    from oracle import pyoracle as O
+    sr, si, sc = O.kstrongest(img, k, z_min)
+    min_bin = int(np.ceil(np.float64(np.float32(min_distance)) / np.float64(np.float32(range_res))))
+    rows = []
+    for r in range(img.shape[0]):
+        rng, inten = sr[r, :sc[r]].astype(np.int64), si[r, :sc[r]].astype(np.int64)
+        keep = rng > min_bin
+        rows.append(((inten[keep] << 24) | rng[keep]).astype(np.uint32))
+    return rows
+
+
+def _rowkeys_check(keys, cnt, img_rows_major, k, z_min, range_res, min_distance):
+    keys, cnt = keys.cpu().numpy().view(np.uint32), cnt.cpu().numpy()
+    for b in range(img_rows_major.shape[0]):
+        exp = _rowkeys_expected(img_rows_major[b], k, z_min, range_res, min_distance)
+        np.testing.assert_array_equal(cnt[b, :, 0], [len(e) for e in exp])
+        for r, e in enumerate(exp):
+            np.testing.assert_array_equal(keys[b, r, :len(e)], e, err_msg="image %d row %d" % (b, r))
+
+
+@pytest.mark.parametrize("bins,az,k,z_min,data", [
+    (3360, 400, 12, 60, "scene"), (3360, 400, 40, 60, "dense"), (3360, 48, 40, 60, "uniform"), (1000, 64, 12, 100, "uniform"),
+    (2000, 32, 7, 0, "uniform"), (1501, 16, 40, 200, "uniform"), (4096, 16, 64, 250, "uniform"), (37, 16, 5, 10, "uniform"),
+    (3360, 40, 12, 60, "uniform"), (5000, 16, 12, 100, "uniform")])
+def test_rowkeys_fused_decode_matches_oracle_and_two_pass(bins, az, k, z_min, data):
+    """[range bins][azimuths] sweeps (every sensor but Oxford's, radar_driver.cpp:74-90): the fused decode lists the bins
+    >= z_min per azimuth in one streaming pass, picks the k strongest of each list, and sweeps the 16-column tiles of
+    azimuths with more than 256 candidates through an LDS transposition.  The per-row keys must equal the oracle's
+    selection on the rotated image on every route: lists in global memory and lists in LDS (one workgroup per image)
+    for sparse scenes, lists + tiles (dense scenes: some rows
+    overflow), tiles only (uniform images: every row overflows; z_min = 0; the forced tile sweep), the two-kernel route
+    (rotation kernel, then the row sweep), the row sweep on a pre-rotated image -- and on geometries the fused route does
+    not take (az % 16 != 0, bins % 4 != 0, > 4096 bins: fall back)."""
+    import torch
+    from tbv_slam_public_amd import api, synth
+    if data == "scene":
+        rot = np.stack([synth.scene_v1(3, 1)[0][0], synth.scene_v1(4, 1)[0][0]])[:, :az, :bins]
+    elif data == "dense":
+        rot = synth.scene_dense(5, 2)[0][:, :az, :bins]
+    else:
+        rot = synth.uniform_v1(bins + az, rows=az, cols=bins, batch=3)
+        rot[0, 1, :] = 0                      # an empty azimuth
+        rot[0, 2, :] = 255                    # a saturated one: every bin ties at the cut
+        rot[1, :, -5:] = 254                  # strong returns in the last bins (beyond a multiple of 16 when bins % 16)
+    rot = np.ascontiguousarray(rot)
+    src = np.ascontiguousarray(np.rot90(rot, -1, axes=(1, 2)))       # what the sensor publishes: [bins][azimuths]
+    assert src.shape[1:] == (bins, az)
+    rr, md = 0.0595238, 2.5
+    d_src = torch.from_numpy(src).cuda()
+    fused = api.filter_kstrongest_rowkeys(d_src, k, z_min, rr, md, bins_major=True)
+    two = api.filter_kstrongest_rowkeys(d_src, k, z_min, rr, md, bins_major=True, two_pass=True)
+    tile = api.filter_kstrongest_rowkeys(d_src, k, z_min, rr, md, bins_major=True, tile_sweep=True)
+    img_wg = api.filter_kstrongest_rowkeys(d_src, k, z_min, rr, md, bins_major=True, route=2)
+    lists = api.filter_kstrongest_rowkeys(d_src, k, z_min, rr, md, bins_major=True, route=1)
+    pre = api.filter_kstrongest_rowkeys(torch.from_numpy(rot).cuda(), k, z_min, rr, md)
+    api.default_context().synchronize()
+    _rowkeys_check(*fused, rot, k, z_min, rr, md)
+    _rowkeys_check(*two, rot, k, z_min, rr, md)
+    _rowkeys_check(*tile, rot, k, z_min, rr, md)
+    _rowkeys_check(*img_wg, rot, k, z_min, rr, md)
+    _rowkeys_check(*lists, rot, k, z_min, rr, md)
+    _rowkeys_check(*pre, rot, k, z_min, rr, md)
+
+
+def test_rowkeys_fused_decode_strided_batch_and_errors():
+    """Source images with a row pitch (stride > azimuths) and a batch stride, as views of a larger device buffer; an
+    unaligned view (offset 4) takes the two-pass route with the same result; host pointers are refused."""
+    import torch
+    from tbv_slam_public_amd import api, synth, _lib as L
+    bins, az, k = 1200, 32, 12
+    rot = synth.uniform_v1(77, rows=az, cols=bins, batch=2)
+    src = np.rot90(rot, -1, axes=(1, 2))
+    big = torch.zeros((2, bins + 3, az + 32), dtype=torch.uint8).cuda()
+    big[:, :bins, 16:16 + az] = torch.from_numpy(np.ascontiguousarray(src)).cuda()
+    view = big[:, :bins, 16:16 + az]
+    a = api.filter_kstrongest_rowkeys(view, k, 100, 0.0438, 2.5, bins_major=True)
+    big2 = torch.zeros((2, bins + 3, az + 32), dtype=torch.uint8).cuda()
+    big2[:, :bins, 4:4 + az] = torch.from_numpy(np.ascontiguousarray(src)).cuda()
+    b = api.filter_kstrongest_rowkeys(big2[:, :bins, 4:4 + az], k, 100, 0.0438, 2.5, bins_major=True)
+    api.default_context().synchronize()
+    _rowkeys_check(*a, rot, k, 100, 0.0438, 2.5)
+    _rowkeys_check(*b, rot, k, 100, 0.0438, 2.5)
+    with pytest.raises(L.CfearError):
+        api.filter_kstrongest_rowkeys(view, 65, 100, 0.0438, 2.5, bins_major=True)      # row keys need k <= 64
