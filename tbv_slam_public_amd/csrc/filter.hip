@@ -612,10 +612,13 @@ __device__ __forceinline__ void extract_candidates(const KStrongArgs& a, const u
   for (int h = 0; h < kExtractPieces / 2; h++) cm[h] = 0;
 #pragma unroll
   for (int u = 0; u < kExtractPieces; u++) {
-    uint32_t pm = 0;
-#pragma unroll
-    for (int d = 0; d < 4; d++)                              // bit 7 of every byte -> one nibble (v_dot4_u32_u8)
-      pm |= __builtin_amdgcn_udot4((swar_ge(w[u][d], tz4, thi) >> 7) & 0x01010101u, 0x08040201u, 0u, false) << (4 * d);
+    // the SWAR verdicts sit in bit 7 of every byte; v_dot4_u32_u8 with the weights 1, 2, 4, .., 128 sums them into
+    // 128 * (one bit per byte) -- two dwords per accumulator
+    const uint32_t lo = __builtin_amdgcn_udot4(swar_ge(w[u][1], tz4, thi), 0x80402010u,
+                                               __builtin_amdgcn_udot4(swar_ge(w[u][0], tz4, thi), 0x08040201u, 0u, false), false);
+    const uint32_t hi = __builtin_amdgcn_udot4(swar_ge(w[u][3], tz4, thi), 0x80402010u,
+                                               __builtin_amdgcn_udot4(swar_ge(w[u][2], tz4, thi), 0x08040201u, 0u, false), false);
+    uint32_t pm = (lo >> 7) | ((hi >> 7) << 8);
     if (p0 + step * u >= n_pieces) pm = 0;
     cm[u >> 1] |= pm << (16 * (u & 1));
   }
@@ -629,10 +632,14 @@ __device__ __forceinline__ void extract_candidates(const KStrongArgs& a, const u
     for (int h = 0; h < kExtractPieces / 2; h++)
       if ((t >> 5) == h) cm[h] &= cm[h] - 1;
     const int u = t >> 4, e = t & 15;
-    uint32_t word = 0;                                       // w[u][e >> 2]: registers cannot be indexed by a lane
+    // w[u][e >> 2]: registers cannot be indexed by a lane -- the piece by a chain of selects, then the dword
+    uint32_t x0 = 0, x1 = 0, x2 = 0, x3 = 0;
 #pragma unroll
-    for (int i = 0; i < kExtractPieces * 4; i++)
-      if (i == (u << 2 | e >> 2)) word = w[i >> 2][i & 3];
+    for (int uu = 0; uu < kExtractPieces; uu++) {
+      const bool is = u == uu;
+      x0 = is ? w[uu][0] : x0; x1 = is ? w[uu][1] : x1; x2 = is ? w[uu][2] : x2; x3 = is ? w[uu][3] : x3;
+    }
+    const uint32_t word = (e & 8) ? ((e & 4) ? x3 : x2) : ((e & 4) ? x1 : x0);
     const uint32_t p = p0 + step * (uint32_t)u;
     const uint32_t j = segs == 1 ? p : __umulhi(p, seg_magic), sg = p - j * (uint32_t)segs;
     emit(a.rows - 1 - (int)(16u * sg + e), (((word >> (8 * (e & 3))) & 0xffu) << 24) | j);
@@ -642,6 +649,15 @@ __device__ __forceinline__ void extract_candidates(const KStrongArgs& a, const u
 __device__ __forceinline__ void load_pieces(const KStrongArgs& a, const uint8_t* img, const uint32_t p0, const uint32_t step,
                                             const uint32_t n_pieces, const uint32_t seg_magic, const int segs,
                                             uint32_t (&w)[kExtractPieces][4]) {
+  if (a.stride == 16 * segs) {                               // no row pitch: piece p is bytes 16 p .. of the image
+#pragma unroll
+    for (int u = 0; u < kExtractPieces; u++) {
+      const uint32_t p = min(p0 + step * u, n_pieces - 1u);
+      const u32x4 v = __builtin_nontemporal_load((const u32x4*)(img + (size_t)p * 16u));
+      w[u][0] = v.x; w[u][1] = v.y; w[u][2] = v.z; w[u][3] = v.w;
+    }
+    return;
+  }
 #pragma unroll
   for (int u = 0; u < kExtractPieces; u++) {
     const uint32_t p = min(p0 + step * u, n_pieces - 1u);
@@ -710,6 +726,45 @@ __device__ __forceinline__ void select_row(const KStrongArgs& a, const long long
     a.row_valid[row * 2 + 1] = 0;
   }
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // the list is reused by the wavefront's next row
+  __builtin_amdgcn_wave_barrier();
+}
+
+// Two azimuths with at most 32 candidates each on one wavefront: lanes 0-31 take row[0], lanes 32-63 row[1] (the typical
+// radar azimuth holds two or three dozen bins >= z_min, so select_row leaves half of its lanes idle).  fetch(h, j) = key j
+// of the half's row; list: [64] keys + [2] bitmap words.
+template <typename Fetch>
+__device__ __forceinline__ void select_pair(const KStrongArgs& a, const long long row0, const long long row1, const int n0,
+                                            const int n1, uint32_t* list, const int lane, Fetch&& fetch) {
+  const int half = lane >> 5, h = lane & 31;
+  const int n = half ? n1 : n0;
+  const long long row = half ? row1 : row0;
+  uint32_t* bits = list + 64;
+  const uint32_t key = h < n ? fetch(half, h) : 0xFFFFFFFFu;
+  list[lane] = key;
+  if (h == 0) bits[half] = 0;
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  const int k = a.k, drop = n - min(n, k);
+  const int nq = (max(n0, n1) + 3) & ~3;                     // wave-uniform
+  const uint32_t* mine = list + 32 * half;
+  int c = 0;
+  for (int q = 0; q < nq; q += 4) {
+    const uint4 x = *(const uint4*)(mine + q);               // two addresses per instruction
+    c += (x.x < key) + (x.y < key) + (x.z < key) + (x.w < key);
+  }
+  const int rank = h < n ? c - drop : -1;
+  const bool beyond = rank >= 0 && (int)(key & 0xFFFFFFu) > a.min_range_bin;
+  if (beyond) atomicOr(&bits[half], 1u << rank);             // (survivors' ranks are < min(n, k) <= 32)
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  const uint32_t m = bits[half];
+  if (beyond) a.row_keys[row * k + __popc(m & ((1u << rank) - 1u))] = key;
+  if (h == 0) {
+    a.row_valid[row * 2] = __popc(m);
+    a.row_valid[row * 2 + 1] = 0;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   __builtin_amdgcn_wave_barrier();
 }
 
@@ -785,14 +840,25 @@ __global__ __launch_bounds__(64 * kImgWaves, 4) void kstrong_image_kernel(const 
       });
     }
     __syncthreads();                                         // (also orders the overflow stores before the loads below)
-    for (int r = wave; r < a.rows; r += kImgWaves) {
-      const long long row = (long long)b * a.rows + r;
-      const int n = (int)cnt[r];
-      if (n > kCandCap) {
-        if (lane == 0) flag_tile(a, b, r, tiles, tile_flag, work_n, work);
+    const int pair_cap = min(32, lds_cap);                   // (a pair's keys all come from LDS)
+    for (int r = wave; r < a.rows; r += 2 * kImgWaves) {
+      const int r1 = r + kImgWaves;
+      const int n0 = (int)cnt[r], n1 = r1 < a.rows ? (int)cnt[r1] : 0;
+      if (r1 < a.rows && n0 <= pair_cap && n1 <= pair_cap) {
+        select_pair(a, (long long)b * a.rows + r, (long long)b * a.rows + r1, n0, n1, mine, lane,
+                    [&](const int half, const int j) { return lists[(half ? r1 : r) * lds_cap + j]; });
         continue;
       }
-      select_row(a, row, n, mine, lane, [&](const int j) { return j < lds_cap ? lists[r * lds_cap + j] : cand[row * kCandCap + j]; });
+      for (int i = 0; i < 2; i++) {
+        const int rr = i ? r1 : r, n = i ? n1 : n0;
+        if (rr >= a.rows) break;
+        const long long row = (long long)b * a.rows + rr;
+        if (n > kCandCap) {
+          if (lane == 0) flag_tile(a, b, rr, tiles, tile_flag, work_n, work);
+          continue;
+        }
+        select_row(a, row, n, mine, lane, [&](const int j) { return j < lds_cap ? lists[rr * lds_cap + j] : cand[row * kCandCap + j]; });
+      }
     }
     __syncthreads();                                         // the counters are cleared for the next image
   }

@@ -1,6 +1,6 @@
 #!/bin/bash
 # the fused decode in the pipeline: parity tests, then A/B of the bins-major bench (CFEAR_NO_FUSED_DECODE=1 = rotation kernel + row sweep)
-python -m pytest tests/test_gpu_filters.py tests/test_gpu_odometry.py -x -q -m gpu 2>&1 | tail -3
+python -m pytest tests -x -q -m gpu 2>&1 | tail -3
 for v in 1 0; do
   if [ $v = 1 ]; then export CFEAR_NO_FUSED_DECODE=1; else unset CFEAR_NO_FUSED_DECODE; fi
   python bench.py --no-cpu-baseline --no-extras --bins-major --streams 2048 --steps 3 --frames-per-step 8 2>/dev/null | tail -1 | python -c "
