@@ -17,7 +17,7 @@ keep_ours() {   # kernel_stats.csv of a run -> only this library's kernels (torc
 import csv, glob, sys
 src = glob.glob(sys.argv[1] + "/**/*kernel_stats.csv", recursive=True)
 rows = list(csv.reader(open(src[0]))) if src else []
-ours = ("kstrongest_rows_kernel", "kstrong_cloud_kernel", "cacfar_", "surface_", "register_kernel", "assoc_kernel", "eval_kernel",
+ours = ("kstrongest_rows_kernel", "kstrong_cloud_kernel", "kstrong_image", "kstrong_extract", "kstrong_select", "kstrongest_cols", "cacfar_", "surface_", "register_kernel", "assoc_kernel", "eval_kernel",
         "coral_kernel", "sc_descriptor", "sc_distance", "rotate_ccw", "compensate", "legacy_", "scan_sort", "cells_to_slab",
         "slab_to_cells", "closest_idx")
 keep = [rows[0]] + [r for r in rows[1:] if any(k in r[0] for k in ours)] if rows else []
@@ -36,6 +36,14 @@ keep_ours "$OUT/verify" "$SUM/verify_kernel_stats.csv"; rm -rf "$OUT/verify"
 keep_ours "$OUT/lc" "$SUM/loopclosure_kernel_stats.csv"; rm -rf "$OUT/lc"
 ( cd /tmp && rocprofv3 --output-format csv --kernel-trace --stats -d "$OUT/binsmajor" -o b -- python "$ROOT/bench.py" --no-cpu-baseline --no-extras --bins-major --steps 3 --frames-per-step 8 > "$SUM/bins_major_stdout.json" 2> "$OUT/binsmajor.err" )
 keep_ours "$OUT/binsmajor" "$SUM/bins_major_kernel_stats.csv"; rm -rf "$OUT/binsmajor"
+# 1c. [bins][azimuths] sweeps: the fused decode (kstrong_image), its fall-backs and the two-kernel route on 2048 images
+for MODE in fused two-pass tile lists; do
+  FLAG=""; [ $MODE != fused ] && FLAG="--$MODE"
+  ( cd /tmp && rocprofv3 --output-format csv --kernel-trace --stats -d "$OUT/decode_$MODE" -o d -- python "$ROOT/tools/decode_bench.py" 2048 $FLAG >> "$SUM/decode_stdout.txt" 2> "$OUT/decode_$MODE.err" )
+  keep_ours "$OUT/decode_$MODE" "$SUM/decode_${MODE}_kernel_stats.csv"; rm -rf "$OUT/decode_$MODE"
+done
+( cd /tmp && timeout 900 rocprofv3 --output-format csv --pmc FETCH_SIZE -d "$OUT/pmc_decode_fetch" -o p -- python "$ROOT/tools/decode_bench.py" 512 --iters 2 > /dev/null 2> "$OUT/pmc_decode_fetch.err" )
+( cd /tmp && timeout 900 rocprofv3 --output-format csv --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU -d "$OUT/pmc_decode_sq" -o p -- python "$ROOT/tools/decode_bench.py" 512 --iters 2 > /dev/null 2> "$OUT/pmc_decode_sq.err" )
 # 2. polar sweep alone: kernel trace on the three data sets, then PMC passes (FETCH_SIZE and WRITE_SIZE do not fit one pass)
 for DATA in scene dense uniform; do
   ( cd /tmp && rocprofv3 --output-format csv --kernel-trace --stats -d "$OUT/filter_$DATA" -o f -- python "$ROOT/tools/bench_filter.py" --data $DATA > "$SUM/filter_${DATA}_stdout.txt" 2> "$OUT/filter_$DATA.err" )

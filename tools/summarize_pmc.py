@@ -15,7 +15,7 @@ for d in sorted(glob.glob(os.path.join(root, "pmc_*"))):
     for f in files:
         for row in csv.DictReader(open(f)):
             k = row.get("Kernel_Name", "?")
-            for name in ("kstrongest_rows_kernel", "kstrong_cloud_kernel", "cacfar_rows_kernel", "cacfar_cloud_kernel",
+            for name in ("kstrongest_rows_kernel", "kstrong_image_kernel", "kstrongest_cols_kernel", "kstrong_cloud_kernel", "cacfar_rows_kernel", "cacfar_cloud_kernel",
                          "surface_points_kernel", "surface_prep_kernel", "surface_sort_kernel", "surface_finish_kernel", "legacy_prepare_kernel", "legacy_cloud_kernel", "register_kernel", "assoc_kernel", "eval_kernel", "compensate_kernel"):
                 if name in k:
                     k = name
@@ -57,6 +57,9 @@ if fetch and write:
     cf = _avg("pmc_cacfar_fetch", "cacfar_rows_kernel", "FETCH_SIZE")
     if cf:
         out["cacfar_rows_fetch_bytes_per_scan"] = cf * 1024.0 * 2.0 / 512
+    df = _avg("pmc_decode_fetch", "kstrong_image_kernel", "FETCH_SIZE")
+    if df:
+        out["kstrong_image_fetch_bytes_per_scan"] = df * 1024.0 * 2.0 / 512     # tools/decode_bench.py 512: [bins][azimuths] sweeps
     print("== traffic", json.dumps(out))
     if len(sys.argv) > 2:
         json.dump(out, open(sys.argv[2], "w"), indent=1)
