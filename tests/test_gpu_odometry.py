@@ -178,12 +178,18 @@ def test_cacfar_pipeline_row_beyond_key_capacity_is_reported():
     od.close()
 
 
-@pytest.mark.parametrize("device_input", [False, True])
-def test_rotated_input_layout_equals_prerotated(device_input):
+@pytest.mark.parametrize("device_input,two_kernel", [(False, False), (True, False), (True, True)])
+def test_rotated_input_layout_equals_prerotated(device_input, two_kernel, monkeypatch):
     """par.rotate_ccw: images arrive as [range bins][azimuths] (non-Oxford drivers, radar_driver.cpp:74-90); the
-    pipeline rotates on the GPU and must then behave exactly like the same frames fed in the Oxford layout."""
+    pipeline decodes them on the GPU -- fused into the filter stage (candidate lists, no rotated copy), or, with
+    CFEAR_NO_FUSED_DECODE (and for image geometries the fused stage does not take), by the rotation kernel -- and must then
+    behave exactly like the same frames fed in the Oxford layout."""
     import torch
     from tbv_slam_public_amd import api, synth
+    if two_kernel:
+        monkeypatch.setenv("CFEAR_NO_FUSED_DECODE", "1")          # read when the odometry object is created
+    else:
+        monkeypatch.delenv("CFEAR_NO_FUSED_DECODE", raising=False)
     n_frames = 5
     seqs = [synth.scene_v1(sd, n_frames, range_res=0.0595238, ccw=True)[0] for sd in (4, 6)]
     kw = dict(kstrong_range_res=0.0595238, radar_ccw=1, submap_scan_size=5)
@@ -194,6 +200,26 @@ def test_rotated_input_layout_equals_prerotated(device_input):
         sent = np.ascontiguousarray(np.rot90(batch, -1, axes=(1, 2)))
         a = ref.process(batch)
         b = rot.process(torch.from_numpy(sent).cuda() if device_input else sent)
+        for name in a.dtype.names:
+            np.testing.assert_array_equal(a[name], b[name], err_msg=name)
+    assert (a["reg_status"] == 0).all() and a["n_cells"].min() > 100
+
+
+def test_rotated_input_batch_that_fills_the_chip():
+    """256 streams of [range bins][azimuths] sweeps: at one image per CU the fused decode switches from global candidate
+    lists to one workgroup per image with the lists in LDS (kstrong_image_kernel); frames, poses and counts must equal the
+    Oxford-layout run of the same sweeps, stream by stream."""
+    import torch
+    from tbv_slam_public_amd import api, synth
+    n_frames, reps = 3, 64
+    seqs = [synth.scene_v1(sd, n_frames, range_res=0.0595238, ccw=True)[0] for sd in (4, 6, 7, 9)]
+    kw = dict(kstrong_range_res=0.0595238, radar_ccw=1, submap_scan_size=5)
+    ref = api.OdometryKeyframeFuser(4 * reps, 400, 3360, api.odometry_params(**kw))
+    rot = api.OdometryKeyframeFuser(4 * reps, 3360, 400, api.odometry_params(rotate_ccw=1, **kw))
+    for f in range(n_frames):
+        batch = torch.from_numpy(np.stack([seqs[i % 4][f] for i in range(4 * reps)])).cuda()
+        a = ref.process(batch)
+        b = rot.process(torch.rot90(batch, -1, dims=(1, 2)).contiguous())
         for name in a.dtype.names:
             np.testing.assert_array_equal(a[name], b[name], err_msg=name)
     assert (a["reg_status"] == 0).all() and a["n_cells"].min() > 100
