@@ -704,7 +704,11 @@ typedef struct cfear_graph_node {       /* RadarScan (types.h:88-142) + the cons
   int32_t n_constraints, pad2;
 } cfear_graph_node;
 typedef struct cfear_graph cfear_graph;
-int cfear_graph_save(const char* path, const cfear_graph_node* nodes, int32_t n_nodes);      /* SaveSimpleGraph */
+/* SaveSimpleGraph.  Boost stores an object reached through several shared_ptrs once: here the buffer is the identity -- a
+ * cloud whose `xyzi` pointer (and size) equals that of a cloud written earlier, in any slot of any node, is written as a
+ * reference to it.  cfear_graph_load resolves such references (its nodes then hold equal copies) and rejects files whose
+ * counts exceed what is left of the file (CFEAR_ERR_FORMAT) before allocating anything.                              */
+int cfear_graph_save(const char* path, const cfear_graph_node* nodes, int32_t n_nodes);
 int cfear_graph_load(const char* path, cfear_graph** out);                                    /* LoadSimpleGraph */
 int cfear_graph_size(const cfear_graph* g);
 int cfear_graph_node_at(const cfear_graph* g, int32_t i, cfear_graph_node* out);              /* pointers live until destroy */

@@ -43,6 +43,7 @@ struct Cloud {
   uint64_t stamp = 0;
   uint32_t seq = 0;
   std::string frame_id;
+  const float* src = nullptr;        // saving: the caller's buffer -- the same buffer in two slots is ONE shared cloud
 };
 struct ConstraintRec {
   uint64_t id_begin = 0, id_end = 0;
@@ -90,6 +91,15 @@ struct Archive {
   bool initialized[K_COUNT];
   int n_classes = 0;
   uint32_t n_objects = 0;
+  // loading: what is left of the file bounds every size the file dictates; clouds by object id, so that a pointer that
+  // refers back to a cloud stored earlier (boost tracks shared_ptr targets) comes back as that cloud
+  uint64_t file_bytes = 0;
+  std::vector<std::pair<uint32_t, const struct Cloud*>> clouds;   // (saving: the clouds written so far)
+  bool fits(uint64_t count, uint64_t min_bytes_each) {
+    const long at = ftell(f);
+    if (at < 0 || (uint64_t)at > file_bytes || count > (file_bytes - (uint64_t)at) / (min_bytes_each ? min_bytes_each : 1)) { ok = false; return false; }
+    return true;
+  }
   Archive() { for (int i = 0; i < K_COUNT; i++) { class_id[i] = -1; initialized[i] = false; } }
   void raw(void* p, size_t n) {
     if (!ok || n == 0) return;
@@ -164,7 +174,12 @@ void io_cloud_xyzi_data(Archive& a, Cloud& c) {
   a.prim(c.stamp); a.prim(c.seq); a.str(c.frame_id);
   uint32_t n = (uint32_t)(c.xyzi.size() / 4), height = 1, width = n;
   a.prim(height); a.prim(width);
-  if (!a.saving) { n = height * width; if (n > (1u << 26)) { a.ok = false; return; } c.xyzi.assign((size_t)n * 4, 0.f); }
+  if (!a.saving) {
+    const uint64_t n64 = (uint64_t)height * width;
+    if (n64 > (1u << 26) || !a.fits(n64, 28)) { a.ok = false; return; }    // a point: count (8) + data[4] (16) + intensity (4)
+    n = (uint32_t)n64;
+    c.xyzi.assign((size_t)n * 4, 0.f);
+  }
   for (uint32_t i = 0; i < n && a.ok; i++) {
     a.object_preamble(K_PXYZI);
     uint64_t cnt = 4;                                   // float data[4]: C array = count + raw elements
@@ -181,8 +196,19 @@ void io_cloud_xyzi_data(Archive& a, Cloud& c) {
 int io_cloud_ptr(Archive& a, Cloud& c, const Cloud* same_as, uint32_t same_oid, bool has_same, uint32_t* oid_out) {
   a.object_preamble(K_SP_CLOUDI);
   uint32_t oid = 0;
+  if (a.saving && !has_same && c.present && c.src) {        // boost writes a tracked object once: the caller's buffer is the identity
+    for (const auto& oc : a.clouds)
+      if (oc.second->src == c.src && oc.second->xyzi.size() == c.xyzi.size()) { same_as = oc.second; same_oid = oc.first; has_same = true; break; }
+  }
   const int st = a.pointer_preamble(K_CLOUDI, !c.present && !(has_same && same_as), same_oid, has_same, &oid);
-  if (st == 1) { c.present = true; io_cloud_xyzi_data(a, c); }
+  if (st == 1) {
+    c.present = true;
+    io_cloud_xyzi_data(a, c);
+    a.clouds.push_back({oid, &c});                         // (the node records do not move while the file is read / written)
+  } else if (st == 2 && !a.saving) {                         // the same cloud object as one stored earlier
+    for (const auto& oc : a.clouds)
+      if (oc.first == oid && oc.second != &c) { c = *oc.second; break; }
+  }
   if (oid_out) *oid_out = oid;
   return st;
 }
@@ -210,7 +236,7 @@ void io_node(Archive& a, NodeRec& n) {
     a.object_preamble(K_VCELL);
     uint64_t nc = n.cells.size();
     io_count(a, nc, K_CELL);
-    if (!a.saving) { if (nc > (1u << 24)) { a.ok = false; return; } n.cells.assign((size_t)nc, cfear_cell{}); }
+    if (!a.saving) { if (nc > (1u << 24) || !a.fits(nc, 121)) { a.ok = false; return; } n.cells.assign((size_t)nc, cfear_cell{}); }   // a cell: 15 doubles + 1 byte
     for (uint64_t i = 0; i < nc && a.ok; i++) {
       cfear_cell& c = n.cells[(size_t)i];
       a.object_preamble(K_CELL);
@@ -277,7 +303,7 @@ void io_constraint(Archive& a, ConstraintRec& c) {
   a.object_preamble(K_QMAP);
   uint64_t nq = c.qkeys.size();
   io_count(a, nq, K_QPAIR);
-  if (!a.saving) { if (nq > (1u << 20)) { a.ok = false; return; } c.qkeys.assign((size_t)nq, std::string()); c.qvals.assign((size_t)nq, 0.0); }
+  if (!a.saving) { if (nq > (1u << 20) || !a.fits(nq, 16)) { a.ok = false; return; } c.qkeys.assign((size_t)nq, std::string()); c.qvals.assign((size_t)nq, 0.0); }
   for (uint64_t i = 0; i < nq && a.ok; i++) {
     a.object_preamble(K_QPAIR);
     a.str(c.qkeys[(size_t)i]);
@@ -303,14 +329,14 @@ bool io_graph(Archive& a, std::vector<NodeRec>& g) {
   a.object_preamble(K_GRAPH);
   uint64_t n = g.size();
   io_count(a, n, K_PAIR);
-  if (!a.saving) { if (n > (1u << 24)) return false; g.assign((size_t)n, NodeRec()); }
+  if (!a.saving) { if (n > (1u << 24) || !a.fits(n, 400)) return false; g.assign((size_t)n, NodeRec()); }   // a node: two poses + motion alone are > 400 bytes
   for (uint64_t i = 0; i < n && a.ok; i++) {
     a.object_preamble(K_PAIR);
     io_node(a, g[(size_t)i]);
     a.object_preamble(K_VCONS);
     uint64_t nc = g[(size_t)i].constraints.size();
     io_count(a, nc, K_CONS);
-    if (!a.saving) { if (nc > (1u << 20)) return false; g[(size_t)i].constraints.assign((size_t)nc, ConstraintRec()); }
+    if (!a.saving) { if (nc > (1u << 20) || !a.fits(nc, 300)) return false; g[(size_t)i].constraints.assign((size_t)nc, ConstraintRec()); }
     for (uint64_t j = 0; j < nc && a.ok; j++) io_constraint(a, g[(size_t)i].constraints[(size_t)j]);
   }
   return a.ok;
@@ -318,6 +344,7 @@ bool io_graph(Archive& a, std::vector<NodeRec>& g) {
 
 void cloud_in(Cloud& c, const cfear_graph_cloud& v) {
   c.present = v.n >= 0;
+  c.src = v.n > 0 ? v.xyzi : nullptr;
   if (v.n > 0) c.xyzi.assign(v.xyzi, v.xyzi + (size_t)v.n * 4);
   c.stamp = v.stamp; c.seq = v.seq; c.frame_id = v.frame_id ? v.frame_id : "";
 }
@@ -369,6 +396,8 @@ extern "C" int cfear_graph_load(const char* path, cfear_graph** out) {
   a.saving = false;
   a.f = fopen(path, "rb");
   if (!a.f) return CFEAR_ERR_IO;
+  if (fseek(a.f, 0, SEEK_END) == 0) { const long sz = ftell(a.f); a.file_bytes = sz > 0 ? (uint64_t)sz : 0; }
+  rewind(a.f);
   std::unique_ptr<cfear_graph> g(new cfear_graph());
   const bool ok = io_graph(a, g->nodes);
   fclose(a.f);

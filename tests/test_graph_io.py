@@ -130,12 +130,56 @@ def test_shared_cloud_is_stored_once(tmp_path):
     nd = _node(0, rng, n_pts=1000)
     shared = str(tmp_path / "a.sgh")
     api.SaveSimpleGraph(shared, [nd])
-    nd2 = dict(nd, input_is_nopeaks=False, normal_input=nd["cloud_nopeaks"])
+    nd2 = dict(nd, input_is_nopeaks=False, normal_input=np.array(nd["cloud_nopeaks"]["xyzi"]))    # equal content, another object
     twice = str(tmp_path / "b.sgh")
     api.SaveSimpleGraph(twice, [nd2])
     per_point = 5 * 0 + 8 + 16 + 4                                # count + float[4] + intensity
     assert os.path.getsize(twice) - os.path.getsize(shared) >= 1000 * per_point
     assert api.LoadSimpleGraph(shared)[0]["input_is_nopeaks"] and not api.LoadSimpleGraph(twice)[0]["input_is_nopeaks"]
+
+
+def test_one_buffer_in_several_slots_is_one_tracked_object(tmp_path):
+    """Boost writes an object reached through several shared_ptrs once and refers back to it by object id
+    (basic_oarchive tracking).  The caller's buffer is the identity here: one array as cloud_peaks_ AND cloud_nopeaks_ of a
+    node, and again as the peaks cloud of the NEXT node, is stored once; the loader resolves every back-reference --
+    across slots and across nodes -- to the stored cloud."""
+    rng = np.random.default_rng(3)
+    a, b = _node(0, rng, n_pts=700), _node(1, rng, n_pts=300)
+    one = a["cloud_nopeaks"]                                    # dict(xyzi = ONE array, ...)
+    copy = lambda: dict(one, xyzi=np.array(one["xyzi"]))
+    sep = str(tmp_path / "separate.sgh")
+    api.SaveSimpleGraph(sep, [dict(a, cloud_peaks=copy()), dict(b, cloud_peaks=copy())])
+    shr = str(tmp_path / "shared.sgh")
+    api.SaveSimpleGraph(shr, [dict(a, cloud_peaks=one), dict(b, cloud_peaks=one)])   # peaks = nopeaks of node 0 = peaks of node 1
+    per_point = 8 + 16 + 4
+    assert os.path.getsize(sep) - os.path.getsize(shr) >= 2 * 700 * per_point
+    for path in (sep, shr):
+        g = api.LoadSimpleGraph(path)
+        for nd in g:
+            np.testing.assert_array_equal(nd["cloud_peaks"]["xyzi"], one["xyzi"])
+        np.testing.assert_array_equal(g[0]["cloud_nopeaks"]["xyzi"], one["xyzi"])
+        np.testing.assert_array_equal(g[1]["cloud_nopeaks"]["xyzi"], b["cloud_nopeaks"]["xyzi"])
+        assert g[0]["input_is_nopeaks"] and g[1]["input_is_nopeaks"]
+
+
+def test_sizes_in_the_file_are_bounded_by_the_file(tmp_path):
+    """Every count the archive dictates (nodes, points, cells, constraints) is checked against what is left of the file
+    before anything is allocated: a 70-byte file that announces 16 million nodes is a format error, not a multi-GB
+    allocation."""
+    import struct
+    rng = np.random.default_rng(4)
+    good = str(tmp_path / "g.sgh")
+    api.SaveSimpleGraph(good, [_node(0, rng)])
+    data = bytearray(open(good, "rb").read())
+    sig = 8 + len("serialization::archive") + 2 + 8           # string, version, native sizes + endianness marker
+    off = sig + 5                                                # class info of the vector (tracking byte + version)
+    assert struct.unpack_from("<Q", data, off)[0] == 1          # the node count
+    struct.pack_into("<Q", data, off, (1 << 24) - 1)
+    bad = tmp_path / "huge_count.sgh"
+    bad.write_bytes(bytes(data[:off + 12 + 40]))
+    with pytest.raises(L.CfearError) as e:
+        api.LoadSimpleGraph(str(bad))
+    assert e.value.status == L.ERR_FORMAT
 
 
 def test_bad_files_are_status_codes(tmp_path):
