@@ -469,3 +469,43 @@ def test_rowkeys_fused_decode_strided_batch_and_errors():
     _rowkeys_check(*b, rot, k, 100, 0.0438, 2.5)
     with pytest.raises(L.CfearError):
         api.filter_kstrongest_rowkeys(view, 65, 100, 0.0438, 2.5, bins_major=True)      # row keys need k <= 64
+
+
+def test_rowkeys_fuzz_geometries_parameters_and_routes():
+    """40 random cases: bins (multiples of 4 up to 4096), azimuths (multiples of 16), k, z_min, min_distance and images that
+    mix empty, sparse, wall-like (one bin across many azimuths), dense and saturated azimuths -- every route of the fused
+    decode against the oracle's selection on the rotated image."""
+    import torch
+    from tbv_slam_public_amd import api
+    rng = np.random.default_rng(20260929)
+    for case in range(40):
+        bins = int(rng.integers(1, 1025)) * 4
+        az = int(rng.integers(1, 9)) * 16
+        k = int(rng.integers(1, 65))
+        z_min = int(rng.choice([1, 20, 60, 100, 200, 255]))
+        md = float(rng.choice([0.0, 2.5, 10.0]))
+        batch = int(rng.integers(1, 4))
+        rot = rng.integers(0, max(2, z_min), size=(batch, az, bins), dtype=np.int64)          # background below z_min
+        for b in range(batch):
+            for r in range(az):
+                kind = rng.integers(0, 6)
+                if kind == 1:                                   # a few returns
+                    idx = rng.integers(0, bins, size=int(rng.integers(1, 30)))
+                    rot[b, r, idx] = rng.integers(z_min, 256, size=idx.size)
+                elif kind == 2:                                 # many returns (more than k, fewer than 256 mostly)
+                    idx = rng.integers(0, bins, size=int(rng.integers(30, 300)))
+                    rot[b, r, idx] = rng.integers(z_min, 256, size=idx.size)
+                elif kind == 3:                                 # dense: most bins above z_min -> the tile route
+                    rot[b, r] = rng.integers(z_min // 2, 256, size=bins)
+                elif kind == 4:                                 # a plateau: equal intensities, ties at the cut
+                    lo = int(rng.integers(0, bins)); hi = min(bins, lo + int(rng.integers(1, 400)))
+                    rot[b, r, lo:hi] = min(255, z_min + int(rng.integers(0, 3)))
+            wall = int(rng.integers(0, bins))                   # one bin across all azimuths: 16 candidates in one 16-byte piece
+            rot[b, :, wall] = 250
+        rot = np.ascontiguousarray(np.clip(rot, 0, 255).astype(np.uint8))
+        src = torch.from_numpy(np.ascontiguousarray(np.rot90(rot, -1, axes=(1, 2)))).cuda()
+        outs = [api.filter_kstrongest_rowkeys(src, k, z_min, 0.0438, md, bins_major=True, **kw)
+                for kw in (dict(), dict(route=1), dict(route=2), dict(tile_sweep=True), dict(two_pass=True))]
+        api.default_context().synchronize()
+        for o in outs:
+            _rowkeys_check(*o, rot, k, z_min, 0.0438, md)
