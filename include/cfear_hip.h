@@ -565,8 +565,10 @@ typedef struct cfear_odometry_params {
   float res;                            /* par.res */
   int32_t submap_scan_size;
   int32_t weight_intensity, use_guess, compensate, radar_ccw, use_keyframe;
-  int32_t rotate_ccw;                   /* 1: the incoming images are [range bins][azimuths] (dataset != oxford) and are
-                                           rotated first, radar_driver.cpp:74-90; desc then describes that source layout */
+  int32_t rotate_ccw;                   /* 1: the incoming images are [range bins][azimuths] (dataset != oxford), to be
+                                           rotated first, radar_driver.cpp:74-90; desc then describes that source layout.
+                                           (The k-strongest stage reads such images directly where their geometry allows --
+                                           see cfear_filter_kstrongest_rowkeys -- and rotates them otherwise.)          */
   double min_keyframe_dist, min_keyframe_rot_deg, downsample_factor;
   int32_t estimate_cov_by_sampling;     /* par.estimate_cov_by_sampling (false), odometrykeyframefuser.h:104 */
   int32_t keep_nodes;                   /* 1: also build what RadarScan needs (types.h:119-122): the peaks cloud of every
