@@ -580,12 +580,14 @@ __global__ __launch_bounds__(256, 7) void kstrongest_rows_kernel(const KStrongAr
 // radarDriver::Callback (radar_driver.cpp:74-90) rotates such a sweep 90 degrees counter-clockwise before Process();
 // rotate_ccw_rows_kernel + kstrongest_rows_kernel move the image through HBM three times (read, write, read).  The fused
 // route reads it ONCE, along its own rows, and never builds the rotated image:
-//   1. kstrong_extract_kernel   streams the source in 16-byte pieces (16 azimuths of one bin), a SWAR compare finds the
-//      bytes >= uchar(z_min) -- the only bins FilterKstrongest can keep (radar_filters.cpp:217) -- and appends each as a
-//      key (intensity << 24 | bin) to the list of ITS azimuth (a global atomic per candidate; a radar sweep holds a few
-//      dozen per azimuth).  No LDS, a dozen registers: the kernel runs at the speed of the read.
-//   2. kstrong_select_kernel    one wavefront per azimuth: the k largest keys of the list ARE the reference's selection
-//      (lexicographic (intensity, range) cut, ties toward the larger range), ranked into its ascending order.
+//   1. extraction   the source is streamed in 16-byte pieces (16 azimuths of one bin); a SWAR compare finds the bytes >=
+//      uchar(z_min) -- the only bins FilterKstrongest can keep (radar_filters.cpp:217) -- and each is appended as a key
+//      (intensity << 24 | bin) to the list of ITS azimuth (a radar sweep holds a few dozen per azimuth).
+//   2. selection    one wavefront per azimuth (two when both lists are short): the k largest keys of the list ARE the
+//      reference's selection (lexicographic (intensity, range) cut, ties toward the larger range), ranked into its order.
+//      Batches that fill the chip run 1 + 2 in ONE kernel, a workgroup per image with the lists in LDS
+//      (kstrong_image_kernel); smaller ones spread an image over many workgroups and keep the lists in global memory
+//      (kstrong_extract_kernel: one returning atomic per candidate; kstrong_select_kernel).
 //   3. kstrongest_cols_kernel   azimuths with more than kCandCap candidates (dense returns; z_min = 0) need the raw row:
 //      pass 2 puts their 16-column tile on a work list, and this kernel transposes those tiles into LDS (v_perm_b32 on
 //      4 x 4 byte blocks) and runs the complete row algorithm on them.  Without a list it takes every tile.
@@ -595,7 +597,7 @@ constexpr int kColsTile = 16;
 constexpr int kColsWaves = 8;
 constexpr int kXcds = 8;
 constexpr int kCandCap = 256;                 // candidate keys kept per azimuth (1 KiB)
-constexpr int kExtractPieces = 8;             // 16-byte pieces per thread and step (the select tree below is written for 8)
+constexpr int kExtractPieces = 8;             // 16-byte pieces in flight per thread and step
 
 // The candidates among kExtractPieces 16-byte pieces held in registers (w[u] = piece p0 + step * u of the image, pieces
 // numbered along the source rows: piece p = bin p / segs, source columns 16 (p % segs) ..): emit(r, key) once per byte
