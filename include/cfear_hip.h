@@ -145,8 +145,8 @@ int cfear_filter_kstrongest(cfear_ctx* ctx, const uint8_t* polar, const cfear_po
  * one streaming pass lists, per azimuth, the bins >= uchar(z_min) (the only ones the filter can keep), a second picks the
  * k strongest of each list; azimuths with more than 256 such bins have their 16-column tile transposed in LDS and swept
  * there (CFEAR_ROWKEYS_TILE_SWEEP: every tile takes that route).  Needs 16-byte aligned images, cols % 16 == 0, rows % 4 == 0
- * and <= 4096 bins; any other geometry, or CFEAR_ROWKEYS_TWO_PASS, takes cfear_polar_rotate_ccw's kernel into a workspace
- * first -- same result.  want_peaks is ignored.                                                                        */
+ * and <= 4096 bins; any other geometry, a batch of fewer than 96 images (unless a route flag asks for the lists), or
+ * CFEAR_ROWKEYS_TWO_PASS, takes cfear_polar_rotate_ccw's kernel into a workspace first -- same result.  want_peaks is ignored.                                                                        */
 #define CFEAR_ROWKEYS_BINS_MAJOR 1
 #define CFEAR_ROWKEYS_TWO_PASS 2
 #define CFEAR_ROWKEYS_TILE_SWEEP 4

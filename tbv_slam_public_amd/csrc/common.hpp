@@ -129,6 +129,7 @@ int cfear_kstrong_device(cfear_ctx* ctx, const uint8_t* d_polar, const cfear_pol
                          const cfear_kstrong_fused* fused = nullptr);
 // fused decode + sweep for [range bins][azimuths] sources (sd = the SOURCE images); key output only
 bool cfear_kstrong_cols_supported(const uint8_t* d_src, const cfear_polar_desc* sd, const cfear_kstrong_params* par);
+bool cfear_kstrong_cols_preferred(const uint8_t* d_src, const cfear_polar_desc* sd, const cfear_kstrong_params* par);   // ... and the batch is large enough to pay
 int cfear_kstrong_cols_device(cfear_ctx* ctx, const uint8_t* d_src, const cfear_polar_desc* sd, const cfear_kstrong_params* par,
                               const cfear_kstrong_fused* fused, int route = 0);
 int cfear_compensate_batch_device(cfear_ctx* ctx, float* d_xyzi, size_t cloud_stride_points, const int32_t* d_n,

@@ -1805,6 +1805,13 @@ bool cfear_kstrong_cols_supported(const uint8_t* d_src, const cfear_polar_desc* 
 
 // route: 0 = by batch size, 1 = lists in global memory (small batches), 2 = one workgroup per image, 3 = every tile
 // through the LDS transposition
+// ... and pays: a handful of sweeps (one radar alone) are done sooner by the rotation kernel + the row sweep (20 us against
+// 37 us for one image: three launches and a chain of global atomics); from about a hundred images on the lists win
+// (tools/single_stream_bins_major.py, tools/decode_bench.py).
+bool cfear_kstrong_cols_preferred(const uint8_t* d_src, const cfear_polar_desc* sd, const cfear_kstrong_params* par) {
+  return sd->batch >= 96 && cfear_kstrong_cols_supported(d_src, sd, par);
+}
+
 int cfear_kstrong_cols_device(cfear_ctx* ctx, const uint8_t* d_src, const cfear_polar_desc* sd, const cfear_kstrong_params* par,
                               const cfear_kstrong_fused* fused, int route) {
   bool all_tiles = route == 3;
@@ -1913,7 +1920,9 @@ extern "C" int cfear_filter_kstrongest_rowkeys(cfear_ctx* ctx, const uint8_t* po
   fz.row_valid = row_counts;
   cfear_kstrong_out none{};
   if (!bins_major) return cfear_kstrong_device(ctx, polar, desc, &kp, &none, false, &fz);
-  if (!(flags & CFEAR_ROWKEYS_TWO_PASS) && cfear_kstrong_cols_supported(polar, desc, &kp))
+  const bool routed = (flags & (CFEAR_ROWKEYS_TILE_SWEEP | CFEAR_ROWKEYS_ROUTE_LISTS | CFEAR_ROWKEYS_ROUTE_IMAGE)) != 0;
+  if (!(flags & CFEAR_ROWKEYS_TWO_PASS) &&
+      (routed ? cfear_kstrong_cols_supported(polar, desc, &kp) : cfear_kstrong_cols_preferred(polar, desc, &kp)))
     return cfear_kstrong_cols_device(ctx, polar, desc, &kp, &fz, (flags & CFEAR_ROWKEYS_TILE_SWEEP) ? 3 : ((flags >> 4) & 3));
   cfear_polar_desc rd{};                                      // the rotated images: rows = azimuths
   rd.rows = desc->cols; rd.cols = desc->rows; rd.stride = (desc->rows + 15) & ~15; rd.batch = desc->batch;

@@ -369,7 +369,7 @@ static int run_filter(cfear_odometry* od, const uint8_t* polar, int buf, const i
     d_polar = od->d_polar;
     dd.batch_stride = (int64_t)img_bytes;
   }
-  if (od->fused_decode && cfear_kstrong_cols_supported(d_polar, &dd, &par.kstrong)) {
+  if (od->fused_decode && cfear_kstrong_cols_preferred(d_polar, &dd, &par.kstrong)) {
     cfear_kstrong_params kp = par.kstrong;
     kp.want_peaks = 0;
     cfear_kstrong_fused fz;

@@ -205,13 +205,15 @@ def test_rotated_input_layout_equals_prerotated(device_input, two_kernel, monkey
     assert (a["reg_status"] == 0).all() and a["n_cells"].min() > 100
 
 
-def test_rotated_input_batch_that_fills_the_chip():
-    """256 streams of [range bins][azimuths] sweeps: at one image per CU the fused decode switches from global candidate
-    lists to one workgroup per image with the lists in LDS (kstrong_image_kernel); frames, poses and counts must equal the
-    Oxford-layout run of the same sweeps, stream by stream."""
+@pytest.mark.parametrize("reps", [32, 64])
+def test_rotated_input_batches_that_take_the_fused_decode(reps):
+    """128 / 256 streams of [range bins][azimuths] sweeps: from 96 images on the filter stage decodes them itself (below, the
+    rotation kernel is quicker) -- candidate lists in global memory, and from one image per CU on one workgroup per image with
+    the lists in LDS (kstrong_image_kernel); frames, poses and counts must equal the Oxford-layout run of the same sweeps,
+    stream by stream."""
     import torch
     from tbv_slam_public_amd import api, synth
-    n_frames, reps = 3, 64
+    n_frames = 3
     seqs = [synth.scene_v1(sd, n_frames, range_res=0.0595238, ccw=True)[0] for sd in (4, 6, 7, 9)]
     kw = dict(kstrong_range_res=0.0595238, radar_ccw=1, submap_scan_size=5)
     ref = api.OdometryKeyframeFuser(4 * reps, 400, 3360, api.odometry_params(**kw))
