@@ -449,8 +449,9 @@ def main(argv=None):
     ap.add_argument("--graph", default=None, help="loopclosure: take the nodes' cached surface points from this simple_graph.sgh "
                                                   "(tools/make_graph.py writes one) instead of featurising synthetic sweeps")
     ap.add_argument("--bins-major", action="store_true",
-                    help="feed the images as [range bins][azimuths] (non-Oxford drivers): adds the GPU rotation of "
-                         "radarDriver::Callback (radar_driver.cpp:74-90) to every step; not the BASELINE layout")
+                    help="feed the images as [range bins][azimuths] (non-Oxford drivers): the decode of radarDriver::Callback "
+                         "(radar_driver.cpp:74-90) becomes part of every step -- fused into the filter stage (kstrong_image), or "
+                         "with CFEAR_NO_FUSED_DECODE=1 the rotation kernel + the row sweep; not the BASELINE layout")
     ap.add_argument("--keep-nodes", action="store_true",
                     help="also keep every frame's compensated peaks cloud (pose-graph nodes, cfear_odometry_get_*); "
                          "off in the BASELINE configuration")
