@@ -1187,12 +1187,23 @@ __global__ __launch_bounds__(kFastThreads, 4) void surface_sort_kernel(const Sur
     if (i < n) {
       const int v = (int)mycell[j];
       const int s0 = v ? (int)vs16[v - 1] : 0, e0 = (int)vs16[v];
-      int rank = 0, q = s0;
-      for (; q + 3 < e0; q += 4) {                                      // four independent LDS reads in flight
-        const int o0 = order[q], o1 = order[q + 1], o2 = order[q + 2], o3 = order[q + 3];
-        rank += (o0 < i) + (o1 < i) + (o2 < i) + (o3 < i);
+      // The loop is a chain of dependent LDS round trips, not arithmetic: sixteen indices per trip (two aligned 16-byte
+      // reads in flight) from the 16-byte boundary below the run on; positions outside the run are masked out, so there
+      // are no head or tail loops.  (Reads stay inside the order array's padded allocation.)
+      int rank = 0;
+      auto below = [&](const uint4 o, const int q) {                    // indices < i among positions q .. q + 7 inside [s0, e0)
+        uint32_t bits = 0;
+        bits |= ((int)(o.x & 0xffffu) < i) ? 1u : 0u;   bits |= ((int)(o.x >> 16) < i) ? 2u : 0u;
+        bits |= ((int)(o.y & 0xffffu) < i) ? 4u : 0u;   bits |= ((int)(o.y >> 16) < i) ? 8u : 0u;
+        bits |= ((int)(o.z & 0xffffu) < i) ? 16u : 0u;  bits |= ((int)(o.z >> 16) < i) ? 32u : 0u;
+        bits |= ((int)(o.w & 0xffffu) < i) ? 64u : 0u;  bits |= ((int)(o.w >> 16) < i) ? 128u : 0u;
+        const int lo = min(max(s0 - q, 0), 8), hi = min(max(e0 - q, 0), 8);
+        return __popc(bits & ((1u << hi) - 1u) & ~((1u << lo) - 1u));
+      };
+      for (int q = s0 & ~7; q < e0; q += 16) {
+        const uint4 oa = *(const uint4*)(order + q), ob = *(const uint4*)(order + q + 8);
+        rank += below(oa, q) + below(ob, q + 8);
       }
-      for (; q < e0; q++) rank += (int)order[q] < i;
       mycell[j] = (unsigned short)(s0 + rank);
     }
   }
