@@ -123,6 +123,7 @@ struct cfear_kstrong_fused {
   uint32_t* row_keys = nullptr;
   int32_t* row_valid = nullptr;
   const int64_t* image_offsets = nullptr;
+  uint32_t* cand_stats = nullptr;     // fused decode only: device [64] counters, += the candidates (bins >= z_min) of the batch
 };
 int cfear_kstrong_device(cfear_ctx* ctx, const uint8_t* d_polar, const cfear_polar_desc* desc,
                          const cfear_kstrong_params* par, const cfear_kstrong_out* o, bool dense_halo = false,

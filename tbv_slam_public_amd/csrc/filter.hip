@@ -795,7 +795,7 @@ __global__ __launch_bounds__(256) void kstrong_extract_kernel(const KStrongArgs 
 
 __global__ __launch_bounds__(256) void kstrong_select_kernel(const KStrongArgs a, const int tiles, const int32_t* __restrict__ cand_cnt,
                                                              const uint32_t* __restrict__ cand, uint32_t* tile_flag,
-                                                             int32_t* work_n, uint32_t* work) {
+                                                             int32_t* work_n, uint32_t* work, uint32_t* stats) {
   __shared__ __attribute__((aligned(16))) uint32_t lists[kRowsPerBlock][kCandCap + 8];   // keys | 2 bitmap words
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int r = blockIdx.x * kRowsPerBlock + wave;
@@ -803,6 +803,7 @@ __global__ __launch_bounds__(256) void kstrong_select_kernel(const KStrongArgs a
   const int b = a.batch0 + blockIdx.y;
   const long long row = (long long)b * a.rows + r;
   const int n = __builtin_amdgcn_readfirstlane(cand_cnt[row]);
+  if (stats && lane == 0) atomicAdd(&stats[(blockIdx.x + blockIdx.y) & 63], (uint32_t)n);   // how dense the batch is (64 counters: no hot address)
   if (n > kCandCap) {                                        // the list is incomplete: the row needs its raw bytes
     if (lane == 0) flag_tile(a, b, r, tiles, tile_flag, work_n, work);
     return;
@@ -819,7 +820,7 @@ constexpr int kImgWaves = 8;
 __global__ __launch_bounds__(64 * kImgWaves, 4) void kstrong_image_kernel(const KStrongArgs a, const uint32_t seg_magic, const int segs,
                                                                            const int tiles, const int lds_cap,
                                                                            uint32_t* __restrict__ cand, uint32_t* tile_flag,
-                                                                           int32_t* work_n, uint32_t* work) {
+                                                                           int32_t* work_n, uint32_t* work, uint32_t* stats) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int rows4 = (a.rows + 3) & ~3;
@@ -842,6 +843,12 @@ __global__ __launch_bounds__(64 * kImgWaves, 4) void kstrong_image_kernel(const 
       });
     }
     __syncthreads();                                         // (also orders the overflow stores before the loads below)
+    if (stats) {                                             // how dense the batch is: the image's candidates, 64 counters (no hot address)
+      int local = 0;
+      for (int i = threadIdx.x; i < a.rows; i += kThreads) local += (int)cnt[i];
+      const int incl = wave_incl_scan_i32(local);
+      if (lane == 63) atomicAdd(&stats[(b * kImgWaves + wave) & 63], (uint32_t)incl);
+    }
     const int pair_cap = min(32, lds_cap);                   // (a pair's keys all come from LDS)
     for (int r = wave; r < a.rows; r += 2 * kImgWaves) {
       const int r1 = r + kImgWaves;
@@ -1836,6 +1843,7 @@ int cfear_kstrong_cols_device(cfear_ctx* ctx, const uint8_t* d_src, const cfear_
   int32_t* work_n = nullptr;
   int n_cu = 256;
   (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, ctx->device);
+  if (fused->cand_stats) CFEAR_HIP_CHECK(ctx, hipMemsetAsync(fused->cand_stats, 0, 64 * 4, ctx->stream));
   if (!all_tiles) {
     char* ws = (char*)cfear_workspace(ctx, 12, o_cand + n_rows * kCandCap * 4);
     if (!ws) return cfear_set_error(ctx, CFEAR_ERR_HIP, "workspace allocation failed");
@@ -1858,7 +1866,7 @@ int cfear_kstrong_cols_device(cfear_ctx* ctx, const uint8_t* d_src, const cfear_
       CFEAR_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)kstrong_image_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
       ProfScope ps(ctx, "kstrong_image");
       hipLaunchKernelGGL(kstrong_image_kernel, dim3((unsigned)std::min(a.batch, 2 * n_cu)), dim3(64 * kImgWaves), lds, ctx->stream, a,
-                         magic, segs, tiles, lds_cap, cand, tile_flag, work_n, work);
+                         magic, segs, tiles, lds_cap, cand, tile_flag, work_n, work, fused->cand_stats);
     } else {
       CFEAR_HIP_CHECK(ctx, hipMemsetAsync(ws, 0, o_work, ctx->stream));
       for (int b0 = 0; b0 < a.batch; b0 += 65535) {             // gridDim.y limit
@@ -1872,7 +1880,7 @@ int cfear_kstrong_cols_device(cfear_ctx* ctx, const uint8_t* d_src, const cfear_
         {
           ProfScope ps(ctx, "kstrong_select");
           hipLaunchKernelGGL(kstrong_select_kernel, dim3((a.rows + kRowsPerBlock - 1) / kRowsPerBlock, by), dim3(256), 0, ctx->stream, a,
-                             tiles, cand_cnt, cand, tile_flag, work_n, work);
+                             tiles, cand_cnt, cand, tile_flag, work_n, work, fused->cand_stats);
         }
       }
       a.batch0 = 0;

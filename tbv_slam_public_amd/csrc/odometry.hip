@@ -92,6 +92,12 @@ struct Stream {
 
 }  // namespace
 
+// Fused decode of [range bins][azimuths] sweeps: candidates per azimuth beyond which the rotation kernel + row sweep are the
+// quicker route (the lists cost ~17 ns of a 2048-sweep pass per candidate and azimuth: equal at ~84, tools/decode_bench.py
+// [--dense]), and for how many frames that verdict stands before one frame measures again.
+constexpr double kDecodeDense = 80.0;
+constexpr int kDecodeHold = 32;
+
 struct cfear_odometry {
   cfear_ctx* ctx = nullptr;
   int n_streams = 0;
@@ -103,7 +109,14 @@ struct cfear_odometry {
   // device memory (one allocation each)
   uint8_t* d_polar = nullptr;          // staging when the caller passes host images
   uint8_t* d_rot = nullptr;            // rotated images (par.rotate_ccw)
-  bool fused_decode = false;           // par.rotate_ccw: the sweep transposes the source itself where it can (no d_rot)
+  bool fused_decode = false;           // par.rotate_ccw: the filter stage decodes the source itself where it pays (no d_rot)
+  // ... which it does on radar-like sweeps (a few dozen bins >= z_min per azimuth): the candidate lists cost time per
+  // candidate, the rotation kernel + row sweep do not.  The decode reports the batch's candidates; beyond kDecodeDense per
+  // azimuth the next kDecodeHold frames take the two-kernel route, then one frame probes again.
+  uint32_t* d_decode_stats = nullptr;  // [2 buffers][64]
+  uint32_t* h_decode_stats = nullptr;  // pinned copy
+  bool decode_measured[2] = {false, false};
+  int decode_hold = 0;
   char* d_sel = nullptr;               // sel_range | sel_intensity | sel_count
   float* d_xyzi2[2] = {nullptr, nullptr};    // filter outputs are double-buffered: the next frame's filter
   int32_t* d_npts2[2] = {nullptr, nullptr};  //   may run while the host applies this frame's policy
@@ -192,10 +205,10 @@ extern "C" int cfear_odometry_destroy(cfear_odometry* od) {
   void* dev2[] = {od->d_rowpts2[0], od->d_rowpts2[1], od->d_rowcnt2[0], od->d_rowcnt2[1], od->d_offsets2[0], od->d_offsets2[1]};
   for (void* p : dev2) if (p) (void)hipFree(p);
   if (od->h_offsets) (void)hipHostFree(od->h_offsets);
-  void* dev[] = {od->d_pk2[0], od->d_pk2[1], od->d_npk2[0], od->d_npk2[1], od->d_mot, od->d_polar, od->d_rot, od->d_sel, od->d_xyzi2[0], od->d_xyzi2[1], od->d_npts2[0], od->d_npts2[1], od->d_slabs, od->d_surf_jobs, od->d_reg_jobs,
+  void* dev[] = {od->d_decode_stats, od->d_pk2[0], od->d_pk2[1], od->d_npk2[0], od->d_npk2[1], od->d_mot, od->d_polar, od->d_rot, od->d_sel, od->d_xyzi2[0], od->d_xyzi2[1], od->d_npts2[0], od->d_npts2[1], od->d_slabs, od->d_surf_jobs, od->d_reg_jobs,
                  od->d_out, od->d_surf_scratch, od->d_reg_scratch, od->d_samples};
   for (void* p : dev) if (p) (void)hipFree(p);
-  void* host[] = {od->h_mot, od->h_npk, od->h_surf_jobs, od->h_reg_jobs, od->h_out, od->h_samples};
+  void* host[] = {od->h_mot, od->h_npk, od->h_surf_jobs, od->h_reg_jobs, od->h_out, od->h_samples, od->h_decode_stats};
   for (void* p : host) if (p) (void)hipHostFree(p);
   delete od;
   return CFEAR_OK;
@@ -255,6 +268,10 @@ extern "C" int cfear_odometry_create(cfear_ctx* ctx, int32_t n_streams, const cf
   // [range bins][azimuths] sources: decode fused into the sweep (CFEAR_NO_FUSED_DECODE keeps the two-kernel route, for
   // A/B runs and the tests that compare the two)
   od->fused_decode = od->fused && par->rotate_ccw && !getenv("CFEAR_NO_FUSED_DECODE");
+  if (od->fused_decode) {
+    ok = ok && dalloc(&od->d_decode_stats, 2 * 64 * 4);
+    ok = ok && halloc(&od->h_decode_stats, 2 * 64 * 4);
+  }
   // CA-CFAR puts no bound on a row's detections either: 1024 keys per row (a row beyond that marks its scan
   // CFEAR_ERR_CAPACITY, like a sweep beyond cap_points)
   od->fused_cfar = par->filter_type == CFEAR_FILTER_CACFAR && !par->keep_nodes && rows <= 4096;
@@ -369,13 +386,20 @@ static int run_filter(cfear_odometry* od, const uint8_t* polar, int buf, const i
     d_polar = od->d_polar;
     dd.batch_stride = (int64_t)img_bytes;
   }
-  if (od->fused_decode && cfear_kstrong_cols_preferred(d_polar, &dd, &par.kstrong)) {
+  od->decode_measured[buf] = false;
+  if (od->fused_decode && od->decode_hold > 0) od->decode_hold--;
+  else if (od->fused_decode && cfear_kstrong_cols_preferred(d_polar, &dd, &par.kstrong)) {
     cfear_kstrong_params kp = par.kstrong;
     kp.want_peaks = 0;
     cfear_kstrong_fused fz;
     fz.row_keys = od->d_rowpts2[buf];
     fz.row_valid = od->d_rowcnt2[buf];
-    return cfear_kstrong_cols_device(ctx, d_polar, &dd, &kp, &fz);
+    fz.cand_stats = od->d_decode_stats + 64 * buf;
+    const int rc = cfear_kstrong_cols_device(ctx, d_polar, &dd, &kp, &fz);
+    if (rc != CFEAR_OK) return rc;
+    CFEAR_HIP_CHECK(ctx, hipMemcpyAsync(od->h_decode_stats + 64 * buf, fz.cand_stats, 64 * 4, hipMemcpyDeviceToHost, ctx->stream));
+    od->decode_measured[buf] = true;                         // read once this buffer's frame has been synchronised
+    return CFEAR_OK;
   }
   if (par.rotate_ccw) {
     const size_t rot_bytes = (size_t)od->desc.rows * od->desc.stride;
@@ -721,6 +745,12 @@ static int process_frame(cfear_odometry* od, const uint8_t* polar, const uint8_t
   g_tl.mark(2);
   OD_CHECK(hipEventSynchronize(od->ev_results));
   g_tl.mark(3);
+  if (od->decode_measured[od->cur_buf]) {                  // this frame's sweeps went through the fused decode: how dense were they?
+    od->decode_measured[od->cur_buf] = false;
+    uint64_t cands = 0;
+    for (int k = 0; k < 64; k++) cands += od->h_decode_stats[64 * od->cur_buf + k];
+    if ((double)cands > kDecodeDense * (double)B * (double)od->desc.rows) od->decode_hold = kDecodeHold;
+  }
   // ---- frame policy (:195-257) ------------------------------------------------------------------
   int first_error = CFEAR_OK;
   bool saw_big = false;

@@ -1,6 +1,6 @@
 """[range bins][azimuths] sweeps: the fused decode + sweep (kstrongest_cols_kernel) against the two-kernel route
 (rotate_ccw_rows_kernel, then kstrongest_rows_kernel) on N distinct MulRan-shaped images resident in HBM.
-    python tools/decode_bench.py [N] [--two-pass | --tile | --lists] [--iters K] [--zmin Z]
+    python tools/decode_bench.py [N] [--two-pass | --tile | --lists] [--iters K] [--zmin Z] [--dense]
 Prints the average time of one pass (hipEvents on the context's stream).  Under rocprofv3 (--kernel-trace --stats, or
 --pmc FETCH_SIZE) it is the workload behind profiles/r03/decode_*.
 """
@@ -21,7 +21,8 @@ def main():
     route = 1 if "--lists" in sys.argv else 0        # candidate lists in global memory whatever the batch size
     iters = int(sys.argv[sys.argv.index("--iters") + 1]) if "--iters" in sys.argv else 10
     zmin = int(sys.argv[sys.argv.index("--zmin") + 1]) if "--zmin" in sys.argv else 60
-    base = np.concatenate([synth.scene_v1(sd, 8, range_res=0.0595238, ccw=True)[0] for sd in range(8)])      # 64 x [400][3360]
+    gen = synth.scene_dense if "--dense" in sys.argv else synth.scene_v1       # --dense: every azimuth holds >= 40 bins >= z_min
+    base = np.concatenate([gen(sd, 8, range_res=0.0595238, ccw=True)[0] for sd in range(8)])      # 64 x [400][3360]
     src = torch.from_numpy(np.ascontiguousarray(np.rot90(base, -1, axes=(1, 2)))).cuda()                  # [64][3360][400]
     imgs = src.repeat((n + 63) // 64, 1, 1)[:n].contiguous()
     noise = torch.randint(0, 8, imgs.shape, dtype=torch.uint8, device="cuda", generator=torch.Generator(device="cuda").manual_seed(1))                             # distinct copies
