@@ -146,7 +146,9 @@ int cfear_filter_kstrongest(cfear_ctx* ctx, const uint8_t* polar, const cfear_po
  * k strongest of each list; azimuths with more than 256 such bins have their 16-column tile transposed in LDS and swept
  * there (CFEAR_ROWKEYS_TILE_SWEEP: every tile takes that route).  Needs 16-byte aligned images, cols % 16 == 0, rows % 4 == 0
  * and <= 4096 bins; any other geometry, a batch of fewer than 96 images (unless a route flag asks for the lists), or
- * CFEAR_ROWKEYS_TWO_PASS, takes cfear_polar_rotate_ccw's kernel into a workspace first -- same result.  want_peaks is ignored.                                                                        */
+ * CFEAR_ROWKEYS_TWO_PASS, takes cfear_polar_rotate_ccw's kernel into a workspace first -- same result.  The lists cost time
+ * per bin >= z_min: beyond ~80 of them per azimuth CFEAR_ROWKEYS_TWO_PASS is the quicker route (the batched odometry measures
+ * this and switches by itself).  want_peaks is ignored.                                                                        */
 #define CFEAR_ROWKEYS_BINS_MAJOR 1
 #define CFEAR_ROWKEYS_TWO_PASS 2
 #define CFEAR_ROWKEYS_TILE_SWEEP 4
