@@ -145,15 +145,15 @@ int cfear_filter_kstrongest(cfear_ctx* ctx, const uint8_t* polar, const cfear_po
  * one streaming pass lists, per azimuth, the bins >= uchar(z_min) (the only ones the filter can keep), a second picks the
  * k strongest of each list; azimuths with more than 256 such bins have their 16-column tile transposed in LDS and swept
  * there (CFEAR_ROWKEYS_TILE_SWEEP: every tile takes that route).  Needs 16-byte aligned images, cols % 16 == 0, rows % 4 == 0
- * and <= 4096 bins; any other geometry, a batch of fewer than 96 images (unless a route flag asks for the lists), or
+ * and <= 4096 bins; any other geometry, a batch of fewer than 128 images (unless a route flag asks otherwise), or
  * CFEAR_ROWKEYS_TWO_PASS, takes cfear_polar_rotate_ccw's kernel into a workspace first -- same result.  The lists cost time
  * per bin >= z_min: beyond ~80 of them per azimuth CFEAR_ROWKEYS_TWO_PASS is the quicker route (the batched odometry measures
  * this and switches by itself).  want_peaks is ignored.                                                                        */
 #define CFEAR_ROWKEYS_BINS_MAJOR 1
 #define CFEAR_ROWKEYS_TWO_PASS 2
 #define CFEAR_ROWKEYS_TILE_SWEEP 4
-#define CFEAR_ROWKEYS_ROUTE_LISTS 16   /* candidate lists in global memory whatever the batch size (default: small batches) */
-#define CFEAR_ROWKEYS_ROUTE_IMAGE 32   /* one workgroup per image, lists in LDS (default: batches that fill the chip) */
+#define CFEAR_ROWKEYS_ROUTE_LISTS 16   /* candidate lists in global memory (default only when an image's lists do not fit the LDS) */
+#define CFEAR_ROWKEYS_ROUTE_IMAGE 32   /* one workgroup per image, lists in LDS (the default route), whatever the batch size */
 int cfear_filter_kstrongest_rowkeys(cfear_ctx* ctx, const uint8_t* polar, const cfear_polar_desc* desc,
                                     const cfear_kstrong_params* par, int32_t flags, uint32_t* row_keys, int32_t* row_counts);
 

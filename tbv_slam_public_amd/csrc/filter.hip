@@ -1815,10 +1815,11 @@ bool cfear_kstrong_cols_supported(const uint8_t* d_src, const cfear_polar_desc* 
 // route: 0 = by batch size, 1 = lists in global memory (small batches), 2 = one workgroup per image, 3 = every tile
 // through the LDS transposition
 // ... and pays: a handful of sweeps (one radar alone) are done sooner by the rotation kernel + the row sweep (20 us against
-// 37 us for one image: three launches and a chain of global atomics); from about a hundred images on the lists win
-// (tools/single_stream_bins_major.py, tools/decode_bench.py).
+// 37 us for one image through the global lists; a workgroup alone streams its image in ~100 us whatever the batch).  From
+// 128 images on the image-per-workgroup kernel wins (128: 0.11 ms against ~0.10 for the two kernels in the pipeline and 0.11
+// for the global lists; 192: 0.11 / 0.15 / 0.14; tools/decode_bench.py N --image | --lists | --two-pass).
 bool cfear_kstrong_cols_preferred(const uint8_t* d_src, const cfear_polar_desc* sd, const cfear_kstrong_params* par) {
-  return sd->batch >= 96 && cfear_kstrong_cols_supported(d_src, sd, par);
+  return sd->batch >= 128 && cfear_kstrong_cols_supported(d_src, sd, par);
 }
 
 int cfear_kstrong_cols_device(cfear_ctx* ctx, const uint8_t* d_src, const cfear_polar_desc* sd, const cfear_kstrong_params* par,
@@ -1857,10 +1858,10 @@ int cfear_kstrong_cols_device(cfear_ctx* ctx, const uint8_t* d_src, const cfear_
     const int segs = a.rows / 16;
     const uint32_t magic = (uint32_t)(((uint64_t)1 << 32) / (uint32_t)segs) + 1u;   // p / segs = umulhi(p, magic) while p * segs < 2^32; segs = 1 is taken apart in the kernel
     const uint32_t n_pieces = (uint32_t)a.cols * (uint32_t)segs;
-    // image-per-workgroup route: worth it once the batch fills the chip; its LDS holds rows * (1 + lds_cap) dwords
+    // image-per-workgroup route: its LDS holds rows * (1 + lds_cap) dwords
     const size_t img_fixed = (size_t)((a.rows + 3) & ~3) * 4 + (size_t)kImgWaves * (kCandCap + 8) * 4;
     const int lds_cap = (int)std::min<size_t>(40, (80 * 1024 - 512 - img_fixed) / ((size_t)a.rows * 4));
-    const bool per_image = route == 2 || (route == 0 && a.batch >= n_cu && lds_cap >= 16);
+    const bool per_image = route == 2 || (route == 0 && lds_cap >= 16);   // (the global lists: azimuth counts whose lists do not fit the LDS)
     if (per_image && lds_cap < 1) return cfear_set_error(ctx, CFEAR_ERR_INVALID_ARGUMENT, "fused decode: too many azimuths for the image route");
     if (per_image) {
       CFEAR_HIP_CHECK(ctx, hipMemsetAsync(ws + o_flag, 0, o_work - o_flag, ctx->stream));

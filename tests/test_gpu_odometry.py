@@ -207,10 +207,9 @@ def test_rotated_input_layout_equals_prerotated(device_input, two_kernel, monkey
 
 @pytest.mark.parametrize("reps", [32, 64])
 def test_rotated_input_batches_that_take_the_fused_decode(reps):
-    """128 / 256 streams of [range bins][azimuths] sweeps: from 96 images on the filter stage decodes them itself (below, the
-    rotation kernel is quicker) -- candidate lists in global memory, and from one image per CU on one workgroup per image with
-    the lists in LDS (kstrong_image_kernel); frames, poses and counts must equal the Oxford-layout run of the same sweeps,
-    stream by stream."""
+    """128 / 256 streams of [range bins][azimuths] sweeps: from 128 images on the filter stage decodes them itself (below, the
+    rotation kernel is quicker) -- one workgroup per image with the candidate lists in LDS (kstrong_image_kernel); frames,
+    poses and counts must equal the Oxford-layout run of the same sweeps, stream by stream."""
     import torch
     from tbv_slam_public_amd import api, synth
     n_frames = 3

@@ -1,6 +1,6 @@
 """[range bins][azimuths] sweeps: the fused decode + sweep (kstrongest_cols_kernel) against the two-kernel route
 (rotate_ccw_rows_kernel, then kstrongest_rows_kernel) on N distinct MulRan-shaped images resident in HBM.
-    python tools/decode_bench.py [N] [--two-pass | --tile | --lists] [--iters K] [--zmin Z] [--dense]
+    python tools/decode_bench.py [N] [--two-pass | --tile | --lists | --image] [--iters K] [--zmin Z] [--dense]
 Prints the average time of one pass (hipEvents on the context's stream).  Under rocprofv3 (--kernel-trace --stats, or
 --pmc FETCH_SIZE) it is the workload behind profiles/r03/decode_*.
 """
@@ -18,7 +18,7 @@ def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 and not sys.argv[1].startswith("--") else 512
     two = "--two-pass" in sys.argv
     tile = "--tile" in sys.argv                      # every tile through the LDS transposition (kstrongest_cols_kernel)
-    route = 1 if "--lists" in sys.argv else 0        # candidate lists in global memory whatever the batch size
+    route = 1 if "--lists" in sys.argv else (2 if "--image" in sys.argv else 0)   # lists in global memory / one workgroup per image, whatever the batch size
     iters = int(sys.argv[sys.argv.index("--iters") + 1]) if "--iters" in sys.argv else 10
     zmin = int(sys.argv[sys.argv.index("--zmin") + 1]) if "--zmin" in sys.argv else 60
     gen = synth.scene_dense if "--dense" in sys.argv else synth.scene_v1       # --dense: every azimuth holds >= 40 bins >= z_min
@@ -42,7 +42,7 @@ def main():
     ms = t0.elapsed_time(t1) / iters
     gb = n * 3360 * 400 / 1e9
     print("%s: %d images, %.3f ms per pass, %.2f TB/s of image bytes, %d points kept" %
-          ("two-pass" if two else "tile sweep" if tile else "global lists" if route else "fused", n, ms, gb / ms, int(cnt[:, :, 0].sum())))
+          ("two-pass" if two else "tile sweep" if tile else "global lists" if route == 1 else "image per workgroup" if route == 2 else "fused", n, ms, gb / ms, int(cnt[:, :, 0].sum())))
 
 
 if __name__ == "__main__":
