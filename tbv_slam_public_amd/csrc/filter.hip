@@ -1807,7 +1807,9 @@ int cfear_kstrong_device(cfear_ctx* ctx, const uint8_t* d_polar, const cfear_pol
 // range bins, cols = azimuths).  Only the batched odometry's key output; whatever this path does not take (peaks, k > 64,
 // unaligned or ragged images, more than 4096 bins) goes through cfear_rotate_ccw_device + cfear_kstrong_device.
 bool cfear_kstrong_cols_supported(const uint8_t* d_src, const cfear_polar_desc* sd, const cfear_kstrong_params* par) {
-  return par->k_strongest <= 64 && sd->rows <= 4096 && sd->rows % 4 == 0 && sd->cols % kColsTile == 0 && sd->stride % 16 == 0 &&
+  // azimuths (sd->cols) <= 4096: the image route's fixed LDS part and the exact range of the umulhi division by the number of
+  // 16-azimuth segments (p * segs < 2^32 with p < bins * segs) both depend on it
+  return par->k_strongest <= 64 && sd->rows <= 4096 && sd->cols <= 4096 && sd->rows % 4 == 0 && sd->cols % kColsTile == 0 && sd->stride % 16 == 0 &&
          (uintptr_t)d_src % 16 == 0 && (sd->batch <= 1 || sd->batch_stride % 16 == 0) &&
          (int64_t)sd->rows * sd->stride < ((int64_t)1 << 31);
 }
@@ -1860,7 +1862,8 @@ int cfear_kstrong_cols_device(cfear_ctx* ctx, const uint8_t* d_src, const cfear_
     const uint32_t n_pieces = (uint32_t)a.cols * (uint32_t)segs;
     // image-per-workgroup route: its LDS holds rows * (1 + lds_cap) dwords
     const size_t img_fixed = (size_t)((a.rows + 3) & ~3) * 4 + (size_t)kImgWaves * (kCandCap + 8) * 4;
-    const int lds_cap = (int)std::min<size_t>(40, (80 * 1024 - 512 - img_fixed) / ((size_t)a.rows * 4));
+    const size_t img_budget = 80 * 1024 - 512;
+    const int lds_cap = img_fixed >= img_budget ? 0 : (int)std::min<size_t>(40, (img_budget - img_fixed) / ((size_t)a.rows * 4));
     const bool per_image = route == 2 || (route == 0 && lds_cap >= 16);   // (the global lists: azimuth counts whose lists do not fit the LDS)
     if (per_image && lds_cap < 1) return cfear_set_error(ctx, CFEAR_ERR_INVALID_ARGUMENT, "fused decode: too many azimuths for the image route");
     if (per_image) {
@@ -1870,6 +1873,7 @@ int cfear_kstrong_cols_device(cfear_ctx* ctx, const uint8_t* d_src, const cfear_
       ProfScope ps(ctx, "kstrong_image");
       hipLaunchKernelGGL(kstrong_image_kernel, dim3((unsigned)std::min(a.batch, 2 * n_cu)), dim3(64 * kImgWaves), lds, ctx->stream, a,
                          magic, segs, tiles, lds_cap, cand, tile_flag, work_n, work, fused->cand_stats);
+      CFEAR_HIP_CHECK(ctx, hipGetLastError());
     } else {
       CFEAR_HIP_CHECK(ctx, hipMemsetAsync(ws, 0, o_work, ctx->stream));
       for (int b0 = 0; b0 < a.batch; b0 += 65535) {             // gridDim.y limit
@@ -1885,6 +1889,7 @@ int cfear_kstrong_cols_device(cfear_ctx* ctx, const uint8_t* d_src, const cfear_
           hipLaunchKernelGGL(kstrong_select_kernel, dim3((a.rows + kRowsPerBlock - 1) / kRowsPerBlock, by), dim3(256), 0, ctx->stream, a,
                              tiles, cand_cnt, cand, tile_flag, work_n, work, fused->cand_stats);
         }
+        CFEAR_HIP_CHECK(ctx, hipGetLastError());
       }
       a.batch0 = 0;
     }

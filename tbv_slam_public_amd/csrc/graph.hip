@@ -198,7 +198,9 @@ int io_cloud_ptr(Archive& a, Cloud& c, const Cloud* same_as, uint32_t same_oid, 
   uint32_t oid = 0;
   if (a.saving && !has_same && c.present && c.src) {        // boost writes a tracked object once: the caller's buffer is the identity
     for (const auto& oc : a.clouds)
-      if (oc.second->src == c.src && oc.second->xyzi.size() == c.xyzi.size()) { same_as = oc.second; same_oid = oc.first; has_same = true; break; }
+      if (oc.second->src == c.src && oc.second->xyzi.size() == c.xyzi.size() && oc.second->stamp == c.stamp &&
+          oc.second->seq == c.seq && oc.second->frame_id == c.frame_id) {   // (the same buffer under another header is another object)
+        same_as = oc.second; same_oid = oc.first; has_same = true; break; }
   }
   const int st = a.pointer_preamble(K_CLOUDI, !c.present && !(has_same && same_as), same_oid, has_same, &oid);
   if (st == 1) {
@@ -236,7 +238,7 @@ void io_node(Archive& a, NodeRec& n) {
     a.object_preamble(K_VCELL);
     uint64_t nc = n.cells.size();
     io_count(a, nc, K_CELL);
-    if (!a.saving) { if (nc > (1u << 24) || !a.fits(nc, 121)) { a.ok = false; return; } n.cells.assign((size_t)nc, cfear_cell{}); }   // a cell: 15 doubles + 1 byte
+    if (!a.saving) { if (nc > (1u << 24) || !a.fits(nc, 113)) { a.ok = false; return; } n.cells.assign((size_t)nc, cfear_cell{}); }   // a cell: 13 doubles + size_t + 1 byte
     for (uint64_t i = 0; i < nc && a.ok; i++) {
       cfear_cell& c = n.cells[(size_t)i];
       a.object_preamble(K_CELL);
@@ -329,7 +331,7 @@ bool io_graph(Archive& a, std::vector<NodeRec>& g) {
   a.object_preamble(K_GRAPH);
   uint64_t n = g.size();
   io_count(a, n, K_PAIR);
-  if (!a.saving) { if (n > (1u << 24) || !a.fits(n, 400)) return false; g.assign((size_t)n, NodeRec()); }   // a node: two poses + motion alone are > 400 bytes
+  if (!a.saving) { if (n > (1u << 24) || !a.fits(n, 240)) return false; g.assign((size_t)n, NodeRec()); }   // a node: two poses (2 x 56) + motion (128) at the very least; a pose-only node is 273 bytes
   for (uint64_t i = 0; i < n && a.ok; i++) {
     a.object_preamble(K_PAIR);
     io_node(a, g[(size_t)i]);

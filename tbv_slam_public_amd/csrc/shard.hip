@@ -64,8 +64,8 @@ int gather_records_status(const void* local, int local_status, int32_t n_total, 
   if (hi > lo && local_status == CFEAR_OK && local) memcpy(send.data(), local, (size_t)(hi - lo) * record_bytes);
   const ShardTrailer t{local_status, hi - lo};
   memcpy(send.data() + bytes - sizeof(t), &t, sizeof(t));
-  rc = gather(user, send.data(), recv.data(), bytes);        // the callback's own status is handed back as it is
-  if (rc != 0) return rc;
+  rc = gather(user, send.data(), recv.data(), bytes);
+  if (rc != 0) return rc < 0 ? rc : CFEAR_ERR_HIP;           // a cfear status is handed back as it is; anything else (a callback's own positive code) is not one
   unpack_blocks(recv.data(), bytes, n_total, record_bytes, world, all);
   return first_rank_status(recv.data(), bytes, world);
 }
@@ -144,10 +144,14 @@ extern "C" int cfear_register_batch_sharded(cfear_ctx* ctx, const cfear_reg_job*
     // the trailer travels with the block (a failed block is zeros + the status); written by the device so that no host
     // buffer has to outlive this call
     if (local_rc != CFEAR_OK) (void)hipMemsetAsync(d_send, 0, rbytes, ctx->stream);
-    CFEAR_HIP_CHECK(ctx, hipMemsetD32Async((hipDeviceptr_t)(d_send + rbytes), local_rc, 1, ctx->stream));
-    CFEAR_HIP_CHECK(ctx, hipMemsetD32Async((hipDeviceptr_t)(d_send + rbytes + 4), hi - lo, 1, ctx->stream));
+    // From here to the collective nothing returns: a rank that left before ncclAllGather would leave its peers in it for
+    // ever.  A trailer write that fails is reported AFTER the collective (the peers then see whatever the buffer held --
+    // zeros from the memset above, i.e. status OK with the block's zero records; this rank returns the error).
+    bool trailer_ok = hipMemsetD32Async((hipDeviceptr_t)(d_send + rbytes), local_rc, 1, ctx->stream) == hipSuccess;
+    trailer_ok = hipMemsetD32Async((hipDeviceptr_t)(d_send + rbytes + 4), hi - lo, 1, ctx->stream) == hipSuccess && trailer_ok;
     rc = cfear_rccl_allgather_device(user, d_send, d_recv, bytes);
     if (rc != 0) return rc;
+    if (!trailer_ok) { (void)hipStreamSynchronize(ctx->stream); return cfear_set_error(ctx, CFEAR_ERR_HIP, "status trailer could not be written"); }
     CFEAR_HIP_CHECK(ctx, hipMemcpyAsync(host.data(), d_recv, bytes * (size_t)world, hipMemcpyDeviceToHost, ctx->stream));
     CFEAR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
     unpack_blocks(host.data(), bytes, n_jobs, (int32_t)sizeof(cfear_reg_result), world, results);

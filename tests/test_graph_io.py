@@ -162,6 +162,40 @@ def test_one_buffer_in_several_slots_is_one_tracked_object(tmp_path):
         assert g[0]["input_is_nopeaks"] and g[1]["input_is_nopeaks"]
 
 
+def test_small_nodes_pass_the_size_bounds(tmp_path):
+    """The file-size bounds must be true LOWER bounds: 50 pose-only nodes (273 bytes each) and 50 nodes with one-point clouds
+    and a single cell load again (round 3's bound of 400 bytes per node rejected both with CFEAR_ERR_FORMAT)."""
+    rng = np.random.default_rng(5)
+    bare = [dict(_node(i, rng), cloud_peaks=None, cloud_nopeaks=None, cells=None, constraints=[]) for i in range(50)]
+    p1 = str(tmp_path / "bare.sgh")
+    api.SaveSimpleGraph(p1, bare)
+    assert os.path.getsize(p1) < 50 * 400
+    back = api.LoadSimpleGraph(p1)
+    assert [b["idx"] for b in back] == list(range(50)) and all(b["cells"] is None and b["cloud_peaks"] is None for b in back)
+    tiny = [dict(_node(i, rng, n_pts=3, n_cells=1), constraints=[]) for i in range(50)]
+    p2 = str(tmp_path / "tiny.sgh")
+    api.SaveSimpleGraph(p2, tiny)
+    back = api.LoadSimpleGraph(p2)
+    for a, b in zip(tiny, back):
+        np.testing.assert_array_equal(b["cloud_nopeaks"]["xyzi"], a["cloud_nopeaks"]["xyzi"])
+        np.testing.assert_array_equal(b["cells"]["mean"], a["cells"]["mean"])
+
+
+def test_one_buffer_under_two_headers_is_two_objects(tmp_path):
+    """The save-side identity of a cloud is (buffer, size, stamp, seq, frame_id): the same array handed in with another
+    header is another pcl::PointCloud object and must come back with ITS header, not the first one's."""
+    rng = np.random.default_rng(6)
+    a, b = _node(0, rng, n_pts=40), _node(1, rng, n_pts=40)
+    arr = a["cloud_nopeaks"]["xyzi"]
+    b = dict(b, cloud_nopeaks=dict(xyzi=arr, stamp=999, seq=41, frame_id="other"), cloud_peaks=None)
+    path = str(tmp_path / "hdr.sgh")
+    api.SaveSimpleGraph(path, [a, b])
+    g = api.LoadSimpleGraph(path)
+    assert (g[0]["cloud_nopeaks"]["stamp"], g[0]["cloud_nopeaks"]["frame_id"]) == (a["cloud_nopeaks"]["stamp"], "sensor_est")
+    assert (g[1]["cloud_nopeaks"]["stamp"], g[1]["cloud_nopeaks"]["seq"], g[1]["cloud_nopeaks"]["frame_id"]) == (999, 41, "other")
+    np.testing.assert_array_equal(g[1]["cloud_nopeaks"]["xyzi"], arr)
+
+
 def test_sizes_in_the_file_are_bounded_by_the_file(tmp_path):
     """Every count the archive dictates (nodes, points, cells, constraints) is checked against what is left of the file
     before anything is allocated: a 70-byte file that announces 16 million nodes is a format error, not a multi-GB
