@@ -93,9 +93,19 @@ struct ScanView {          // plain pointers into one slab; passed to kernels by
   double2* lambda;         // (lambda_min, lambda_max)
   int32_t* nsamples;
   int32_t* n_cells;        // device counter (written by the surface kernel)
+  // The matcher's search structure, prebuilt once per scan (sort_cells_block): the float means bucketed into a uniform
+  // kScanGrid x kScanGrid grid over the scan's own extent -- what the reference keeps as a kd-tree per MapPointNormal
+  // (pointnormal.cpp:151-162).  A registration copies these tables into LDS instead of rebuilding them.
+  float4* grid_txyi;       // [n] (x, y, cell index as int bits, 0) grouped by grid cell
+  unsigned short* grid_cstart;   // [kScanGridStartPad] first record of every grid cell (row-major), entries past the last cell = n
+  float4* grid_geo;        // (x0, y0, cells per metre, 1 = tables valid | 0 = more cells than the 16-bit table can address)
   int32_t cap;
   int32_t pad;
 };
+constexpr int kScanGrid = 32;                                  // grid cells per axis
+constexpr int kScanGridCells = kScanGrid * kScanGrid;
+constexpr int kScanGridStartPad = kScanGridCells + 8;          // u16 entries per scan: a multiple of 16 bytes
+constexpr float kScanGridMinEdge = 2.0f;                       // cell edge floor [m]: the matcher's radius (registration.h:131)
 
 struct cfear_scan {
   cfear_ctx* ctx;

@@ -117,6 +117,7 @@ size_t cfear_scan_slab_bytes(int cap) {
   b += align_up(c * sizeof(double4), 256);
   b += align_up(c * sizeof(double), 256) * 2;      // scale, avg_intensity
   b += align_up(c * sizeof(int32_t), 256);
+  b += align_up(c * sizeof(float4), 256) + align_up(kScanGridStartPad * 2, 256);   // prebuilt matcher grid
   return b;
 }
 
@@ -135,7 +136,10 @@ ScanView cfear_scan_view(void* slab, int cap) {
   v.cov = (double4*)p; p += align_up(c * sizeof(double4), 256);
   v.scale = (double*)p; p += align_up(c * sizeof(double), 256);
   v.avg_intensity = (double*)p; p += align_up(c * sizeof(double), 256);
-  v.nsamples = (int32_t*)p;
+  v.nsamples = (int32_t*)p; p += align_up(c * sizeof(int32_t), 256);
+  v.grid_txyi = (float4*)p; p += align_up(c * sizeof(float4), 256);
+  v.grid_cstart = (unsigned short*)p;
+  v.grid_geo = (float4*)((char*)slab + 16);        // inside the 256-byte header, behind the counter
   v.cap = cap;
   v.pad = 0;
   return v;
@@ -186,6 +190,9 @@ int cfear_scan_clone_view(cfear_ctx* ctx, const ScanView& src, int n, cfear_scan
   if (e == hipSuccess) e = cp(d.scale, src.scale, c * 8);
   if (e == hipSuccess) e = cp(d.avg_intensity, src.avg_intensity, c * 8);
   if (e == hipSuccess) e = cp(d.nsamples, src.nsamples, c * 4);
+  if (e == hipSuccess) e = cp(d.grid_txyi, src.grid_txyi, c * sizeof(float4));
+  if (e == hipSuccess) e = cp(d.grid_cstart, src.grid_cstart, (size_t)kScanGridStartPad * 2);
+  if (e == hipSuccess) e = cp(d.grid_geo, src.grid_geo, sizeof(float4));
   if (e != hipSuccess) { cfear_scan_destroy(s); return cfear_set_error(ctx, CFEAR_ERR_HIP, "scan copy failed: %s", hipGetErrorString(e)); }
   s->n_cells_host = n;
   *out = s;

@@ -4,39 +4,52 @@
 
 namespace {
 
+// A 64-bit literal pinned to a scalar register pair AT ITS USE.  gfx950's VOP3 encodings take no 64-bit literals, so the
+// compiler materialises every fp64 constant in registers and hoists it out of the enclosing loops -- the polynomial
+// coefficients below, inlined at a few sites of a long-running kernel, then hold ~30 VGPRs for the kernel's whole life
+// (register3_kernel: the difference between two and three wavefronts per SIMD).  The empty volatile asm keeps the two
+// s_mov_b32 where they are written; the scalar unit is idle there anyway, and v_fma_f64 takes the pair as an operand.
+template <bool PIN>
+__device__ __forceinline__ double kc(double c) {
+  if (PIN) asm volatile("" : "+s"(c));
+  return c;
+}
+
 // sin / cos of |a| <= 0.5 without libm's range reduction: Taylor series to x^17 / x^16 (truncation < 1e-22), Horner in
 // fp64 -- within an ulp or two of libm, the level at which device and host libm differ anyway.
+template <bool PIN = false>
 __device__ __forceinline__ void sincos_small(const double a, double* s, double* c) {
   const double z = a * a;
-  double ps = 2.8114572543455206e-15;                 // 1/17!
-  ps = fma(ps, z, -7.6471637318198164e-13);           // -1/15!
-  ps = fma(ps, z, 1.6059043836821613e-10);            // 1/13!
-  ps = fma(ps, z, -2.5052108385441720e-08);           // -1/11!
-  ps = fma(ps, z, 2.7557319223985893e-06);            // 1/9!
-  ps = fma(ps, z, -1.9841269841269841e-04);           // -1/7!
-  ps = fma(ps, z, 8.3333333333333332e-03);            // 1/5!
-  ps = fma(ps, z, -1.6666666666666666e-01);           // -1/3!
+  double ps = kc<PIN>(2.8114572543455206e-15);                 // 1/17!
+  ps = fma(ps, z, kc<PIN>(-7.6471637318198164e-13));           // -1/15!
+  ps = fma(ps, z, kc<PIN>(1.6059043836821613e-10));            // 1/13!
+  ps = fma(ps, z, kc<PIN>(-2.5052108385441720e-08));           // -1/11!
+  ps = fma(ps, z, kc<PIN>(2.7557319223985893e-06));            // 1/9!
+  ps = fma(ps, z, kc<PIN>(-1.9841269841269841e-04));           // -1/7!
+  ps = fma(ps, z, kc<PIN>(8.3333333333333332e-03));            // 1/5!
+  ps = fma(ps, z, kc<PIN>(-1.6666666666666666e-01));           // -1/3!
   *s = fma(a * z, ps, a);
-  double pc = 4.7794773323873853e-14;                 // 1/16!
-  pc = fma(pc, z, -1.1470745597729725e-11);           // -1/14!
-  pc = fma(pc, z, 2.0876756987868100e-09);            // 1/12!
-  pc = fma(pc, z, -2.7557319223985888e-07);           // -1/10!
-  pc = fma(pc, z, 2.4801587301587302e-05);            // 1/8!
-  pc = fma(pc, z, -1.3888888888888889e-03);           // -1/6!
-  pc = fma(pc, z, 4.1666666666666664e-02);            // 1/4!
+  double pc = kc<PIN>(4.7794773323873853e-14);                 // 1/16!
+  pc = fma(pc, z, kc<PIN>(-1.1470745597729725e-11));           // -1/14!
+  pc = fma(pc, z, kc<PIN>(2.0876756987868100e-09));            // 1/12!
+  pc = fma(pc, z, kc<PIN>(-2.7557319223985888e-07));           // -1/10!
+  pc = fma(pc, z, kc<PIN>(2.4801587301587302e-05));            // 1/8!
+  pc = fma(pc, z, kc<PIN>(-1.3888888888888889e-03));           // -1/6!
+  pc = fma(pc, z, kc<PIN>(4.1666666666666664e-02));            // 1/4!
   *c = fma(z * z, pc, fma(z, -0.5, 1.0));
 }
 
 // sin / cos for |a| <= 1e5: beyond the polynomial's range, Cody-Waite reduction by pi/2 in three parts (k < 2^17, so
 // k * the 33-bit head is exact) and the same polynomials on |r| <= pi/4 (truncation < 2e-18).
+template <bool PIN = false>
 __device__ __forceinline__ void sincos_reduced(const double a, double* s, double* c) {
-  if (fabs(a) <= 0.5) { sincos_small(a, s, c); return; }
-  const double k = rint(a * 6.36619772367581382433e-01);               // 2 / pi
-  double r = fma(-k, 1.57079632673412561417e+00, a);                   // pi/2: first 33 bits
-  r = fma(-k, 6.07710050630396597660e-11, r);                          //       next 33 bits
-  r = fma(-k, 2.02226624879595063154e-21, r);                          //       the rest
+  if (fabs(a) <= 0.5) { sincos_small<PIN>(a, s, c); return; }
+  const double k = rint(a * kc<PIN>(6.36619772367581382433e-01));               // 2 / pi
+  double r = fma(-k, kc<PIN>(1.57079632673412561417e+00), a);                   // pi/2: first 33 bits
+  r = fma(-k, kc<PIN>(6.07710050630396597660e-11), r);                          //       next 33 bits
+  r = fma(-k, kc<PIN>(2.02226624879595063154e-21), r);                          //       the rest
   double sr, cr;
-  sincos_small(r, &sr, &cr);
+  sincos_small<PIN>(r, &sr, &cr);
   const int q = (int)k & 3;
   const double ss = (q & 1) ? cr : sr, cc = (q & 1) ? sr : cr;
   *s = (q & 2) ? -ss : ss;

@@ -72,7 +72,7 @@ struct RegCommon {
   int32_t samples_per_axis;
   int32_t big_mode;                           // 0: single launch | 1: first launch, registrations that only fit lds_big are deferred | 2: the deferred ones
   uint32_t lds_big;                           // dynamic LDS of the second launch (one workgroup per CU)
-  int32_t pad;
+  int32_t only_deferred;                      // launched behind register3_kernel: only the registrations it marked kRegDeferred
   double xy_half, yaw_half;
   const cfear_reg_result* prior;              // cost-only: source pose and itr_ come from these records (device)
 };
@@ -947,8 +947,9 @@ __device__ __forceinline__ bool chol3_solve(const double A[9], const double b[3]
 
 // Rotation of an evaluation point: Cody-Waite reduction + Taylor polynomials (fastmath.hpp, an ulp or two from libm) --
 // a fifth of libm's instruction chain; headings beyond the reduction's range go to libm.
+template <bool PIN = false>
 __device__ __forceinline__ void sincos_pose(const double a, double* s, double* c) {
-  if (fabs(a) <= 1e5) sincos_reduced(a, s, c);
+  if (fabs(a) <= 1e5) sincos_reduced<PIN>(a, s, c);
   else sincos(a, s, c);
 }
 
@@ -1142,7 +1143,7 @@ __global__ __launch_bounds__(NW * 64) void register_kernel(const RegJob* __restr
   double* lds_dense = (double*)(smem + kRegFixedLds + reg_lds_targets_bytes(cm.lds_targets));
   const RegJob& job = *(const RegJob*)((const char*)jobs + (size_t)blockIdx.x * cm.job_stride);
   cfear_reg_result* res = cm.results + blockIdx.x;
-  if (cm.big_mode == 2 && res->status != kRegDeferred) return;       // second launch: only what the first one deferred
+  if ((cm.big_mode == 2 || cm.only_deferred) && res->status != kRegDeferred) return;   // only what the launch before deferred
   const int last = job.n_scans - 1;
   const int n_src = *job.scans[last].n_cells;
   int max_tar = 0;
@@ -1325,6 +1326,563 @@ __global__ __launch_bounds__(NW * 64) void register_kernel(const RegJob* __restr
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------
+// register3_kernel: the regular registration at THREE workgroups per CU (round 4).
+//
+// register_kernel holds 75 KB of LDS and 231 VGPRs per workgroup -- two registrations per CU -- and idles three of its four
+// wavefronts while wavefront 0 walks the trust-region chain.  The serial chain can only be hidden by more co-resident
+// registrations, so this form fits 52 KB and 168 VGPRs:
+//   * the keyframes' grids come PREBUILT from the scans (ScanView::grid_*, built once per scan by sort_cells_block): staging
+//     an association is a copy of ~30 KB from L2 into LDS, not a counting sort;
+//   * with restaging that cheap, the association's tables (cell starts + target records) and the LM phase's dense
+//     correspondence arrays ALIAS: the tables are copied in again at the start of every outer iteration;
+//   * the outer loop's state lives in LDS across the two phases (r3 state block), so neither phase carries the other's
+//     registers.
+// Same arithmetic as register_kernel's fused path, statement for statement (n_scan_normal.cpp:82-185, 213-318): the
+// results are bit-identical.  A registration that does not fit (keyframe tables + source cells beyond the LDS, a scan
+// without grid tables) is marked kRegDeferred and left to register_kernel, launched behind this kernel.
+// ---------------------------------------------------------------------------------------------------
+// LDS-resident solver state of register3_kernel (doubles; the int fields share the last slots).  Nothing of the
+// trust-region bookkeeping is held in registers across an evaluation: wavefront 0 loads the block, walks one round of the
+// chain and stores it back, so the evaluation's registers and the bookkeeping's never coexist (lm_solve keeps ~70 VGPRs
+// of wave-uniform state live across eval_all, which is what holds register_kernel at two wavefronts per SIMD).
+enum {
+  S_X = 0, S_XCOST = 3, S_CUR = 4 /* g[3], H[6] */, S_SCALE = 13, S_DIAG = 16, S_XNORM = 19, S_GMAX = 20, S_RADIUS = 21,
+  S_DEC = 22, S_MINCOST = 23, S_MODEL = 24, S_CAND = 25, S_COS = 28, S_SIN = 29, S_ITCOST = 30, S_ITREL = 31, S_INIT = 32,
+  S_LASTREL = 33, S_FINAL = 34, S_INTS = 35 /* 8 ints */, S_OUTER = 39 /* x[3] prev_par[3] prev_score */, S_COUNT = 48
+};
+enum { SI_ITER = 0, SI_REUSE = 1, SI_INVALID = 2, SI_PUSHED = 3, SI_USABLE = 4, SI_DONE = 5, SI_ITSUCC = 6 };
+constexpr size_t kR3StateOff = kRegFixedLds;                // behind register_kernel's fixed block
+constexpr size_t kR3FixedLds = kRegFixedLds + S_COUNT * 8;
+
+constexpr int kReg3Threads = 256;
+constexpr size_t kReg3Lds = 52 * 1024;          // x 3 = 156 KB of the CU's 160 KB
+
+struct R3Lds {
+  double* kf;              // [last][12]: Ttar (l0..l3, t0, t1), Tsrctotar (l0..l3, t0, t1)
+  int* koff;               // [last + 1] prefix of the keyframes' cell counts
+  int* poff;               // [last + 1] prefix of their 16-byte pieces (cell-start table + records)
+  const void** tptr;       // [last][7]: mean, normal, nsamples, scale, cov, grid_cstart, grid_txyi (global pointers)
+  float4* ggeo;            // [last] grid geometry (x0, y0, cells per metre, -)
+  double2* smean;          // [n_src]
+  unsigned short* match;   // [n_pairs] matched target (index inside its keyframe), 0xFFFF = none
+  unsigned short* cstart;  // [last][kScanGridStartPad] absolute first record of every grid cell   } association phase; the dense
+  float4* txyi;            // [sum_tar] (x, y, index bits, -) grouped by (keyframe, cell)            } arrays alias both
+  double* dense;           // = cstart
+  int dense_cap;
+};
+constexpr int kR3Ptrs = 7;
+
+__device__ __forceinline__ bool r3_carve(uint8_t* smem, size_t lds_total, int last, int sum_tar, int n_src, int n_pairs, int fields,
+                                         R3Lds& f) {
+  size_t off = kR3FixedLds;
+  f.kf = (double*)(smem + off); off += (size_t)last * 12 * 8;
+  f.tptr = (const void**)(smem + off); off += (size_t)last * kR3Ptrs * 8;
+  f.ggeo = (float4*)(smem + off); off += (size_t)last * 16;
+  f.koff = (int*)(smem + off); off += (((size_t)last + 1) * 4 + 15) & ~(size_t)15;
+  f.poff = (int*)(smem + off); off += (((size_t)last + 1) * 4 + 15) & ~(size_t)15;
+  f.smean = (double2*)(smem + off); off += (size_t)n_src * 16;
+  f.match = (unsigned short*)(smem + off); off += (((size_t)n_pairs + 7) & ~(size_t)7) * 2;
+  off = (off + 15) & ~(size_t)15;
+  const size_t assoc = (size_t)last * kScanGridStartPad * 2 + (size_t)sum_tar * 16;
+  if (sum_tar > 65535 || off + assoc > lds_total) return false;
+  f.cstart = (unsigned short*)(smem + off);
+  f.txyi = (float4*)(smem + off + (size_t)last * kScanGridStartPad * 2);
+  f.dense = (double*)(smem + off);
+  f.dense_cap = (int)((lds_total - off) / ((size_t)fields * 8 + 4)) & ~1;
+  return true;
+}
+
+// once per registration: keyframe transforms and attribute pointers, piece prefix, source means
+__device__ bool r3_stage_once(const RegJob& job, const R3Lds& f, int* flag /* LDS */) {
+  const int tid = threadIdx.x, last = job.n_scans - 1;
+  if (tid == 0) {
+    int acc = 0, pacc = 0, ok = 1;
+    for (int i = 0; i < last; i++) {
+      const int n = *job.scans[i].n_cells;
+      f.koff[i] = acc; f.poff[i] = pacc;
+      acc += n; pacc += kScanGridStartPad / 8 + n;
+      const float4 g = *job.scans[i].grid_geo;
+      f.ggeo[i] = g;
+      ok &= (g.w == 1.f);
+    }
+    f.koff[last] = acc; f.poff[last] = pacc;
+    *flag = ok;
+  }
+  if (tid >= 64 && tid < 64 + last) {
+    const int i = tid - 64;
+    const Aff2 T = aff_from_xyt(job.poses[i]);
+    double* k = f.kf + i * 12;
+    k[0] = T.l0; k[1] = T.l1; k[2] = T.l2; k[3] = T.l3; k[4] = T.t0; k[5] = T.t1;
+    const ScanView& tv = job.scans[i];
+    const void** tp = f.tptr + i * kR3Ptrs;
+    tp[0] = tv.mean; tp[1] = tv.normal; tp[2] = tv.nsamples; tp[3] = tv.scale; tp[4] = tv.cov; tp[5] = tv.grid_cstart; tp[6] = tv.grid_txyi;
+  }
+  const ScanView& src = job.scans[last];
+  const int n_src = *src.n_cells;
+  for (int s = tid; s < n_src; s += kReg3Threads) f.smean[s] = src.mean[s];
+  __syncthreads();
+  return *flag != 0;
+}
+
+// every outer iteration: the keyframes' grid tables from global memory (L2) into the aliased LDS region, and the
+// source-to-keyframe transforms at the current pose (n_scan_normal.cpp:222)
+__device__ __forceinline__ void r3_restage(const R3Lds& f, int last, const double* xsrc) {
+  const int tid = threadIdx.x;
+  const int P = f.poff[last];
+  constexpr int kPieces = 8;                              // pieces a thread keeps in flight (8 x 256 x 16 B = 32 KB per round)
+  constexpr int kCs = kScanGridStartPad / 8;              // pieces of one cell-start table
+  for (int p0 = 0; p0 < P; p0 += kPieces * kReg3Threads) {
+    uint4 v[kPieces];
+    int dst[kPieces];                                     // LDS destination (in 16-byte units from cstart), -1 = none
+#pragma unroll
+    for (int k = 0; k < kPieces; k++) {
+      const int p = p0 + tid + k * kReg3Threads;
+      dst[k] = -1;
+      if (p < P) {
+        int i = 0;
+        while (i + 1 < last && p >= f.poff[i + 1]) i++;
+        const int j = p - f.poff[i];
+        const void* const* tp = f.tptr + i * kR3Ptrs;
+        if (j < kCs) {
+          v[k] = ((const uint4*)tp[5])[j];
+          const unsigned add = (unsigned)f.koff[i] * 0x10001u;       // u16 pairs: no carry, the sums stay below 65536
+          v[k].x += add; v[k].y += add; v[k].z += add; v[k].w += add;
+          dst[k] = i * kCs + j;
+        } else {
+          v[k] = ((const uint4*)tp[6])[j - kCs];
+          dst[k] = last * kCs + f.koff[i] + (j - kCs);
+        }
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < kPieces; k++)
+      if (dst[k] >= 0) ((uint4*)f.cstart)[dst[k]] = v[k];
+  }
+  if (tid < last) {                                        // Tsrctotar_i = Ttar_i^-1 * Tsrc
+    const double* k = f.kf + tid * 12;
+    const Aff2 Ttar{k[0], k[1], k[2], k[3], k[4], k[5]};
+    const Aff2 Tst = aff_mul(aff_inv(Ttar), aff_from_xyt(xsrc));
+    double* o = f.kf + tid * 12 + 6;
+    o[0] = Tst.l0; o[1] = Tst.l1; o[2] = Tst.l2; o[3] = Tst.l3; o[4] = Tst.t0; o[5] = Tst.t1;
+  }
+  __syncthreads();
+}
+
+// One association pass (n_scan_normal.cpp:213-318) over the staged tables; fills `dn` (which overwrites the tables);
+// returns the number of blocks.  associate_fused's two passes with the grid edge fixed at kScanGrid.
+__device__ int r3_associate(const RegJob& job, const RegCommon& cm, int itr, const R3Lds& f, Dense& dn, int* ipart, int& iphase) {
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int last = job.n_scans - 1;
+  const int n_src = *job.scans[last].n_cells;
+  const int n_pairs = last * n_src;
+  const double curr_radius = (itr == 1) ? 2 * cm.par.radius : cm.par.radius;    // :220
+  const double r2 = curr_radius * curr_radius;
+  const float rwin = (float)curr_radius + 1e-3f;
+  constexpr int G = kScanGrid;
+  int accepted = 0;
+  {
+    int i = 0, s = tid;
+    while (s >= n_src && i < last) { s -= n_src; i++; }
+    for (int p = tid; p < n_pairs; p += kReg3Threads) {
+      const double* T = f.kf + i * 12 + 6;
+      const double2 u = f.smean[s];
+      const double px = T[0] * u.x + T[1] * u.y + T[4];
+      const double py = T[2] * u.x + T[3] * u.y + T[5];
+      const float qx = (float)px, qy = (float)py;                               // pointnormal.cpp:240-242
+      const float4 gg = f.ggeo[i];
+      const int cx0 = min(G - 1, max(0, (int)floorf((qx - rwin - gg.x) * gg.z))), cx1 = min(G - 1, max(0, (int)floorf((qx + rwin - gg.x) * gg.z)));
+      const int cy0 = min(G - 1, max(0, (int)floorf((qy - rwin - gg.y) * gg.z))), cy1 = min(G - 1, max(0, (int)floorf((qy + rwin - gg.y) * gg.z)));
+      // exact 1-NN (FLANN L2_Simple float distance, lowest index on ties): one unsigned minimum over (bits(d^2) << 32 | index)
+      unsigned long long bestkey = ~0ull;
+      auto visit = [&](const float4 c) {
+        const float dx = __fsub_rn(qx, c.x), dy = __fsub_rn(qy, c.y);
+        const float d = __fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy));
+        const unsigned long long key = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)__float_as_int(c.z);
+        bestkey = key < bestkey ? key : bestkey;
+      };
+      const unsigned short* cs = f.cstart + i * kScanGridStartPad;
+      auto scan_run = [&](int qb, int qe) {
+        for (int q = qb; q < qe; q += 4) {
+          const int l = qe - 1;
+          const float4 ca = f.txyi[q], cb = f.txyi[min(q + 1, l)], cc = f.txyi[min(q + 2, l)], cd = f.txyi[min(q + 3, l)];
+          visit(ca); visit(cb); visit(cc); visit(cd);
+        }
+      };
+      {
+        const int r1 = min(cy0 + 1, cy1), r2c = min(cy0 + 2, cy1);
+        const int b0 = cs[cy0 * G + cx0], e0 = cs[cy0 * G + cx1 + 1];
+        const int b1 = cs[r1 * G + cx0], e1 = cs[r1 * G + cx1 + 1];
+        const int b2 = cs[r2c * G + cx0], e2 = cs[r2c * G + cx1 + 1];
+        scan_run(b0, e0);
+        if (cy1 > cy0) scan_run(b1, e1);
+        if (cy1 > cy0 + 1) scan_run(b2, e2);
+        for (int cy = cy0 + 3; cy <= cy1; cy++) scan_run((int)cs[cy * G + cx0], (int)cs[cy * G + cx1 + 1]);
+      }
+      const int best = bestkey == ~0ull ? -1 : (int)(unsigned)(bestkey & 0xFFFFFFFFu);
+      const float bestd = __uint_as_float((unsigned)(bestkey >> 32));
+      int m = -1;
+      if (best >= 0 && (double)bestd < r2) {                                    // pointnormal.cpp:250
+        const double2 ns = job.scans[last].normal[s];
+        const double2 nt = ((const double2*)f.tptr[i * kR3Ptrs + 1])[best];
+        const double nsx = T[0] * ns.x + T[1] * ns.y, nsy = T[2] * ns.x + T[3] * ns.y;
+        if (fmax(nsx * nt.x + nsy * nt.y, 0.0) > cm.angle_outlier) m = best;    // :244-245
+      }
+      f.match[p] = (unsigned short)m;
+      accepted += (m >= 0);
+      s += kReg3Threads;
+      while (s >= n_src && i < last) { s -= n_src; i++; }
+    }
+  }
+  const int incl = wave_incl_scan_i32(accepted);
+  int base = incl - accepted, total;
+  {
+    int* buf = ipart + iphase * kRegMaxNW;
+    if (lane == 63) buf[wave] = incl;
+    __syncthreads();                                       // also: every reader of the tables is done -- the dense arrays may overwrite them
+    for (int wv = 0; wv < wave; wv++) base += buf[wv];
+    int tt = buf[0];
+#pragma unroll
+    for (int wv = 1; wv < 4; wv++) tt += buf[wv];
+    total = __builtin_amdgcn_readfirstlane(tt);
+    iphase ^= 1;
+  }
+  if (total > f.dense_cap) return -1;                      // more correspondences than the LDS arrays hold: register_kernel's job
+  dense_bind(dn, f.dense, f.dense_cap, cm.dense_fields, f.smean);   // LDS only: every access below is a ds_ instruction
+  dn.n = total;
+  const size_t cap = (size_t)dn.cap;
+  {
+    struct Gathered {
+      int best, i, s, tns, sns;
+      double2 nt, tm, ns;
+      double tsc, ssc;
+      double4 S;
+    };
+    const ScanView& srcv = job.scans[last];
+    auto gather = [&](int p, int i, int s) {
+      Gathered g;
+      g.best = p < n_pairs ? (int)f.match[p] : 0xFFFF;
+      if (g.best == 0xFFFF) g.best = -1;
+      g.i = i; g.s = s;
+      if (g.best >= 0) {
+        const void* const* tp = f.tptr + i * kR3Ptrs;
+        g.nt = ((const double2*)tp[1])[g.best];
+        g.tm = ((const double2*)tp[0])[g.best];
+        g.tns = ((const int32_t*)tp[2])[g.best];
+        g.tsc = ((const double*)tp[3])[g.best];
+        g.ns = srcv.normal[s];
+        g.sns = srcv.nsamples[s];
+        g.ssc = srcv.scale[s];
+        if (cm.par.cost == CFEAR_P2D) g.S = ((const double4*)tp[4])[g.best];
+      }
+      return g;
+    };
+    int c = base, i = 0, s = tid;
+    while (s >= n_src && i < last) { s -= n_src; i++; }
+    Gathered cur = gather(tid, i, s);
+    for (int p = tid; p < n_pairs; p += kReg3Threads) {
+      s += kReg3Threads;
+      while (s >= n_src && i < last) { s -= n_src; i++; }
+      const Gathered nxt = gather(p + kReg3Threads, i, s);
+      if (cur.best >= 0) {
+        const double* K = f.kf + cur.i * 12;              // Ttar
+        const double* T = K + 6;                          // Tsrctotar
+        const double2 nt = cur.nt, tm = cur.tm, ns = cur.ns;
+        const double nsx = T[0] * ns.x + T[1] * ns.y, nsy = T[2] * ns.x + T[3] * ns.y;
+        const double direction_similarity = fmax(nsx * nt.x + nsy * nt.y, 0.0);   // :244
+        const double w = get_weight(cm.par.weight_opt, (double)cur.sns, (double)cur.tns,
+                                    direction_similarity, cur.ssc, cur.tsc);       // :247-253, :273
+        dn.sidx[c] = cur.s;
+        dn.p[c] = K[0] * tm.x + K[1] * tm.y + K[4];                               // Ttar * tar_mean
+        dn.p[cap + c] = K[2] * tm.x + K[3] * tm.y + K[5];
+        dn.p[2 * cap + c] = w;
+        if (cm.par.cost == CFEAR_P2D) {                                           // :288-297
+          const double4 S = cur.S;
+          const double a00 = K[0] * S.x + K[1] * S.z, a01 = K[0] * S.y + K[1] * S.w;
+          const double a10 = K[2] * S.x + K[3] * S.z, a11 = K[2] * S.y + K[3] * S.w;
+          const double c00 = (cm.par.regularization + (a00 * K[0] + a01 * K[1])) * cm.par.cov_scale;
+          const double c01 = (0.0 + (a00 * K[2] + a01 * K[3])) * cm.par.cov_scale;
+          const double c10 = (0.0 + (a10 * K[0] + a11 * K[1])) * cm.par.cov_scale;
+          const double c11 = (cm.par.regularization + (a10 * K[2] + a11 * K[3])) * cm.par.cov_scale;
+          const double det = c00 * c11 - c10 * c01, invdet = 1.0 / det;
+          const double i00 = c11 * invdet, i10 = -c10 * invdet, i11 = c00 * invdet;
+          const double l00 = sqrt(i00), l10 = i10 / l00;
+          dn.p[3 * cap + c] = l00; dn.p[4 * cap + c] = l10; dn.p[5 * cap + c] = sqrt(i11 - l10 * l10);
+        } else if (cm.par.cost == CFEAR_P2L) {
+          dn.p[3 * cap + c] = K[0] * nt.x + K[1] * nt.y;                          // Ttar.linear() * tar_normal
+          dn.p[4 * cap + c] = K[2] * nt.x + K[3] * nt.y;
+        }
+        c++;
+      }
+      cur = nxt;
+    }
+  }
+  __syncthreads();
+  return total;
+}
+
+
+// One round of ceres::Solve's trust-region loop on wavefront 0 (same statements as lm_solve): judges the candidate that
+// was just evaluated (cnd, when have_cnd), then produces the next candidate or the stop flag.  st = the LDS state block.
+__device__ __forceinline__ void r3_lds_order() {          // lane 0's LDS stores above, the wavefront's loads below (one wavefront: the
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");   // LDS executes its operations in order; this orders the compiler)
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
+}
+__device__ __forceinline__ void r3_lm_round(double* st, const double cnd[10], const bool have_cnd, const int max_iter) {
+  const double function_tolerance = 1e-6, gradient_tolerance = 1e-10, parameter_tolerance = 1e-8;
+  const double min_relative_decrease = 1e-3, min_lm_diagonal = 1e-6, max_lm_diagonal = 1e32;
+  const double max_radius = 1e16, min_radius = 1e-32;
+  int* si = (int*)(st + S_INTS);
+  const bool l0 = (threadIdx.x & 63) == 0;
+  // The scalars of the loop stay in registers for the round; the vectors (x, the candidate, gradient and Gauss-Newton matrix at
+  // x, scaling, LM diagonal) are read from the block where a statement needs them and written back where one changes them.
+  double x_cost = st[S_XCOST], x_norm = st[S_XNORM], gradient_max_norm = st[S_GMAX], radius = st[S_RADIUS];
+  double decrease_factor = st[S_DEC], min_iter_cost = st[S_MINCOST], model_cost_change = st[S_MODEL];
+  double it_cost = st[S_ITCOST], it_rel = st[S_ITREL], last_rel = st[S_LASTREL];
+  int iteration = si[SI_ITER], num_consecutive_invalid_steps = si[SI_INVALID], n_pushed = si[SI_PUSHED];
+  bool reuse_diagonal = si[SI_REUSE] != 0, it_success = si[SI_ITSUCC] != 0, usable = si[SI_USABLE] != 0;
+  int done = 0;
+  bool proceed = true;
+  if (have_cnd) {
+    const double cand_cost = cnd[0];
+    const double d0 = st[S_X] - st[S_CAND], d1 = st[S_X + 1] - st[S_CAND + 1], d2 = st[S_X + 2] - st[S_CAND + 2];
+    const double step_norm2 = d0 * d0 + d1 * d1 + d2 * d2;
+    const double cost_change = x_cost - cand_cost;
+    const double step_bound = parameter_tolerance * (x_norm + parameter_tolerance);
+    if (step_norm2 <= step_bound * step_bound) { done = 1; proceed = false; }      // ||step|| <= tolerance (||x|| + tolerance)
+    else if (fabs(cost_change) <= function_tolerance * x_cost) { done = 1; proceed = false; }
+    else {
+      it_rel = cost_change / model_cost_change;
+      if (it_rel > min_relative_decrease) {
+        const double c0 = st[S_CAND], c1 = st[S_CAND + 1], c2 = st[S_CAND + 2];
+        x_norm = sqrt_newton(c0 * c0 + c1 * c1 + c2 * c2);
+        if (l0) {
+          st[S_X] = c0; st[S_X + 1] = c1; st[S_X + 2] = c2;
+#pragma unroll
+          for (int k = 1; k < 10; k++) st[S_CUR + k - 1] = cnd[k];
+        }
+        x_cost = cand_cost;
+        gradient_max_norm = fmax(fabs(cnd[1]), fmax(fabs(cnd[2]), fabs(cnd[3])));
+        it_cost = x_cost; it_success = true;
+        const double q = 2.0 * it_rel - 1.0;
+        radius = radius * rcp_newton(fmax(1.0 / 3.0, 1.0 - q * q * q));
+        radius = fmin(max_radius, radius);
+        decrease_factor = 2.0; reuse_diagonal = false;
+      } else {
+        it_cost = cand_cost; it_success = false;
+        radius = radius / decrease_factor; decrease_factor *= 2.0; reuse_diagonal = true;
+      }
+    }
+    r3_lds_order();
+  }
+  while (proceed) {
+    // FinalizeIterationAndCheckIfMinimizerCanContinue
+    n_pushed++;
+    last_rel = it_rel;
+    min_iter_cost = fmin(min_iter_cost, it_cost);
+    if (iteration >= max_iter || (it_success && gradient_max_norm <= gradient_tolerance) || radius <= min_radius) {
+      done = 1;
+      break;
+    }
+    iteration++;
+    it_cost = 0.0; it_rel = 0.0; it_success = false;
+    const double scale[3] = {st[S_SCALE], st[S_SCALE + 1], st[S_SCALE + 2]};
+    double gs[3], Hs[9];
+    {
+      const double* cur = st + S_CUR - 1;                  // cur[1 .. 9] = g, H upper triangle
+      gs[0] = cur[1] * scale[0]; gs[1] = cur[2] * scale[1]; gs[2] = cur[3] * scale[2];
+      Hs[0] = cur[4] * scale[0] * scale[0]; Hs[1] = cur[5] * scale[0] * scale[1]; Hs[2] = cur[6] * scale[0] * scale[2];
+      Hs[3] = Hs[1]; Hs[4] = cur[7] * scale[1] * scale[1]; Hs[5] = cur[8] * scale[1] * scale[2];
+      Hs[6] = Hs[2]; Hs[7] = Hs[5]; Hs[8] = cur[9] * scale[2] * scale[2];
+    }
+    double diagonal[3];
+    if (!reuse_diagonal) {
+      diagonal[0] = fmin(fmax(Hs[0], min_lm_diagonal), max_lm_diagonal);
+      diagonal[1] = fmin(fmax(Hs[4], min_lm_diagonal), max_lm_diagonal);
+      diagonal[2] = fmin(fmax(Hs[8], min_lm_diagonal), max_lm_diagonal);
+      if (l0) { st[S_DIAG] = diagonal[0]; st[S_DIAG + 1] = diagonal[1]; st[S_DIAG + 2] = diagonal[2]; }
+    } else {
+      diagonal[0] = st[S_DIAG]; diagonal[1] = st[S_DIAG + 1]; diagonal[2] = st[S_DIAG + 2];
+    }
+    double A[9];
+#pragma unroll
+    for (int k = 0; k < 9; k++) A[k] = Hs[k];
+    const double inv_radius = rcp_newton(radius);
+#pragma unroll
+    for (int k = 0; k < 3; k++) A[k * 3 + k] += diagonal[k] * inv_radius;
+    double y[3], step[3] = {0, 0, 0};
+    const bool solved = chol3_solve(A, gs, y);
+    reuse_diagonal = true;
+    bool step_is_valid = false;
+    model_cost_change = 0.0;
+    if (solved) {
+      step[0] = -y[0]; step[1] = -y[1]; step[2] = -y[2];
+      const double sg = step[0] * gs[0] + step[1] * gs[1] + step[2] * gs[2];
+      const double hs0 = Hs[0] * step[0] + Hs[1] * step[1] + Hs[2] * step[2];
+      const double hs1 = Hs[3] * step[0] + Hs[4] * step[1] + Hs[5] * step[2];
+      const double hs2 = Hs[6] * step[0] + Hs[7] * step[1] + Hs[8] * step[2];
+      model_cost_change = -sg - (step[0] * hs0 + step[1] * hs1 + step[2] * hs2) / 2.0;
+      step_is_valid = model_cost_change > 0.0;
+    }
+    if (!step_is_valid) {
+      if (++num_consecutive_invalid_steps >= 5) { usable = false; done = 1; break; }
+      radius = radius / decrease_factor; decrease_factor *= 2.0; reuse_diagonal = true;
+      it_cost = x_cost; it_success = false; it_rel = 0.0;
+      r3_lds_order();                                      // (the diagonal stored above is read again by the next turn)
+      continue;
+    }
+    num_consecutive_invalid_steps = 0;
+    double sn, cs;
+    const double c2 = st[S_X + 2] + step[2] * scale[2];
+    sincos_pose<true>(c2, &sn, &cs);
+    if (l0) {
+      st[S_CAND] = st[S_X] + step[0] * scale[0]; st[S_CAND + 1] = st[S_X + 1] + step[1] * scale[1]; st[S_CAND + 2] = c2;
+      st[S_COS] = cs; st[S_SIN] = sn;
+    }
+    break;
+  }
+  if (l0) {
+    st[S_XCOST] = x_cost; st[S_XNORM] = x_norm; st[S_GMAX] = gradient_max_norm; st[S_RADIUS] = radius; st[S_DEC] = decrease_factor;
+    st[S_MINCOST] = min_iter_cost; st[S_MODEL] = model_cost_change; st[S_ITCOST] = it_cost; st[S_ITREL] = it_rel;
+    st[S_LASTREL] = last_rel;
+    if (done) st[S_FINAL] = fmin(st[S_INIT], min_iter_cost);          // solver.cc SetSummaryFinalCost
+    si[SI_ITER] = iteration; si[SI_REUSE] = reuse_diagonal; si[SI_INVALID] = num_consecutive_invalid_steps;
+    si[SI_PUSHED] = n_pushed; si[SI_USABLE] = usable; si[SI_DONE] = done; si[SI_ITSUCC] = it_success;
+  }
+}
+
+// ceres::Solve for register3_kernel: lm_solve with the state in LDS.  The start pose is st[S_OUTER .. +3); the result is left
+// in the state block (S_X, S_FINAL, S_LASTREL, SI_PUSHED, SI_USABLE).  Block-wide collective.
+template <int COST, int LOSS>
+__device__ void lm_solve3(const RegCommon& cm, const Dense& dn, const int max_iter, double* part, int& phase, double* st) {
+  const bool w0 = (threadIdx.x >> 6) == 0;
+  int* si = (int*)(st + S_INTS);
+  double cnd[10];
+  {
+    const double x[3] = {st[S_OUTER], st[S_OUTER + 1], st[S_OUTER + 2]};
+    double s0, c0;
+    sincos_pose<true>(x[2], &s0, &c0);
+    eval_all<4, COST, LOSS>(cm, dn, x, c0, s0, cnd, part, phase);
+    if (w0) {
+      if ((threadIdx.x & 63) == 0) {
+        st[S_X] = x[0]; st[S_X + 1] = x[1]; st[S_X + 2] = x[2]; st[S_XCOST] = cnd[0];
+#pragma unroll
+        for (int k = 1; k < 10; k++) st[S_CUR + k - 1] = cnd[k];
+        st[S_SCALE] = 1.0 / (1.0 + sqrt(cnd[4]));            // jacobi scaling from iteration 0
+        st[S_SCALE + 1] = 1.0 / (1.0 + sqrt(cnd[7]));
+        st[S_SCALE + 2] = 1.0 / (1.0 + sqrt(cnd[9]));
+        st[S_DIAG] = 0.0; st[S_DIAG + 1] = 0.0; st[S_DIAG + 2] = 0.0;
+        st[S_XNORM] = sqrt_newton(x[0] * x[0] + x[1] * x[1] + x[2] * x[2]);
+        st[S_GMAX] = fmax(fabs(cnd[1]), fmax(fabs(cnd[2]), fabs(cnd[3])));
+        st[S_RADIUS] = 1e4; st[S_DEC] = 2.0; st[S_MINCOST] = cnd[0]; st[S_MODEL] = 0.0; st[S_ITCOST] = cnd[0]; st[S_ITREL] = 0.0;
+        st[S_CAND] = x[0]; st[S_CAND + 1] = x[1]; st[S_CAND + 2] = x[2];
+        st[S_INIT] = cnd[0]; st[S_LASTREL] = 0.0; st[S_FINAL] = cnd[0];
+        si[SI_ITER] = 0; si[SI_REUSE] = 0; si[SI_INVALID] = 0; si[SI_PUSHED] = 0; si[SI_USABLE] = 1; si[SI_DONE] = 0; si[SI_ITSUCC] = 1;
+      }
+      r3_lds_order();                                       // lane 0's block is read by the whole wavefront below
+      r3_lm_round(st, cnd, false, max_iter);
+    }
+  }
+  for (;;) {
+    __syncthreads();
+    if (__builtin_amdgcn_readfirstlane(si[SI_DONE])) break;
+    const double cand[3] = {st[S_CAND], st[S_CAND + 1], st[S_CAND + 2]};
+    const double cs = st[S_COS], sn = st[S_SIN];
+    eval_all<4, COST, LOSS>(cm, dn, cand, cs, sn, cnd, part, phase);      // its barrier also orders the state block
+    if (w0) r3_lm_round(st, cnd, true, max_iter);
+  }
+}
+
+template <int COST, int LOSS>
+__global__ __launch_bounds__(kReg3Threads, 3) void register3_kernel(const RegJob* __restrict__ jobs, const RegCommon cm) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  double* part = (double*)smem;
+  int* ipart = (int*)(smem + kRegIpartOff);
+  const RegJob& job = *(const RegJob*)((const char*)jobs + (size_t)blockIdx.x * cm.job_stride);
+  cfear_reg_result* res = cm.results + blockIdx.x;
+  const int last = job.n_scans - 1;
+  const int n_src = *job.scans[last].n_cells;
+  int sum_tar = 0;
+  for (int i = 0; i < last; i++) sum_tar += *job.scans[i].n_cells;
+  const int n_pairs = last * n_src;
+  R3Lds fl;
+  bool ok = n_pairs <= cm.slots_cap && r3_carve(smem, cm.lds_total, last, sum_tar, n_src, n_pairs, cm.dense_fields, fl);
+  if (ok) ok = r3_stage_once(job, fl, ipart + 2 * kRegMaxNW - 1);
+  if (!ok) {                                             // register_kernel takes it (launched behind this kernel)
+    if (threadIdx.x == 0) { res->status = kRegDeferred; res->reserved = 0.0; }
+    return;
+  }
+  Dense dn;
+  int phase = 0, iphase = 0;
+  const int rpb = COST == CFEAR_P2L ? 1 : 2;
+  // n_scan_normal.cpp:82-185.  The loop's own state (current pose, previous pose and score) lives in the LDS block too:
+  // st[S_OUTER .. +3) = parameters.back(), +3 .. +6 = prev_par, +6 = prev_score.
+  double* st = (double*)(smem + kR3StateOff);
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int k = 0; k < 3; k++) { st[S_OUTER + k] = job.poses[last][k]; st[S_OUTER + 3 + k] = job.poses[last][k]; }
+    st[S_OUTER + 6] = DBL_MAX;
+    st[S_FINAL] = 0.0; st[S_LASTREL] = 0.0;
+  }
+  __syncthreads();
+  bool success = true;
+  int itr = 1, lm_iters = 0, num_residuals = 0, fail_status = CFEAR_OK;
+  for (itr = 1; itr <= cm.par.max_itr_association && success; itr++) {
+    r3_restage(fl, last, st + S_OUTER);
+    const int n_blocks = r3_associate(job, cm, itr, fl, dn, ipart, iphase);
+    if (n_blocks < 0) {                                           // (block-uniform)
+      if (threadIdx.x == 0) { res->status = kRegDeferred; res->reserved = 0.0; }
+      return;
+    }
+    num_residuals = n_blocks * rpb;
+    success = num_residuals > 1;                                  // :368-369
+    if (!success) { fail_status = CFEAR_ERR_TOO_FEW_RESIDUALS; break; }
+    lm_solve3<COST, LOSS>(cm, dn, cm.par.max_itr_solver, part, phase, st);
+    const int* si = (const int*)(st + S_INTS);
+    const int n_pushed = __builtin_amdgcn_readfirstlane(si[SI_PUSHED]);
+    lm_iters += n_pushed - 1;
+    success = __builtin_amdgcn_readfirstlane(si[SI_USABLE]) != 0;
+    if (!success) fail_status = CFEAR_ERR_SOLVER;
+    // n_scan_normal.cpp:117-149 (selects: see register_kernel); every thread derives the same decision, thread 0 stores it
+    const double current_score = st[S_FINAL], prev_score = st[S_OUTER + 6];
+    const double rel_improvement = (prev_score - current_score) / prev_score;
+    const bool past_min = itr > cm.par.min_itr;
+    const bool worse = past_min && (prev_score < current_score);
+    const bool small_outer = past_min && !worse && (rel_improvement < cm.par.score_tolerance);
+    const bool small_inner = past_min && !worse && !small_outer && (st[S_LASTREL] < cm.par.score_tolerance || n_pushed == 1);
+    const bool stop = worse || small_outer || small_inner;
+    double xo[3], pp[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      const double xk = success ? st[S_X + k] : st[S_OUTER + k];
+      pp[k] = st[S_OUTER + 3 + k];
+      xo[k] = worse ? pp[k] : xk;
+      pp[k] = stop ? pp[k] : xo[k];
+    }
+    __syncthreads();                                              // every thread has read the block
+    if (threadIdx.x == 0) {
+#pragma unroll
+      for (int k = 0; k < 3; k++) { st[S_OUTER + k] = xo[k]; st[S_OUTER + 3 + k] = pp[k]; }
+      st[S_OUTER + 6] = stop ? prev_score : current_score;
+    }
+    __syncthreads();
+    if (stop) break;
+  }
+  if (threadIdx.x == 0) {
+    res->pose[0] = st[S_OUTER]; res->pose[1] = st[S_OUTER + 1]; res->pose[2] = st[S_OUTER + 2];
+    const double final_cost = st[S_FINAL];
+    res->final_cost = final_cost;
+    res->num_residuals = num_residuals;
+    res->outer_iters = itr;
+    res->lm_iters = lm_iters;
+    res->last_relative_decrease = st[S_LASTREL];
+    res->reserved = 0.0;
+    if (success) { res->score = final_cost / (double)num_residuals; res->status = CFEAR_OK; }   // :162
+    else { res->score = 0.0; res->status = fail_status; }
+  }
+}
+
 // association only (GetCost / cfear_cost_prepare): slot arrays stay in the caller's scratch
 __global__ __launch_bounds__(kRegThreads) void assoc_kernel(const RegJob* __restrict__ jobs, const RegCommon cm, int itr,
                                                             int32_t* n_blocks_out) {
@@ -1475,7 +2033,7 @@ int cfear_register_launch(cfear_ctx* ctx, const void* d_jobs, int n_jobs, const 
   cm.cost_only = mode ? 1 : 0;
   cm.n_samples = mode ? mode->n_samples : 0;
   cm.samples_per_axis = mode ? mode->samples_per_axis : 0;
-  cm.pad = 0;
+  cm.only_deferred = 0;
   cm.xy_half = mode ? mode->xy_half : 0.0;
   cm.yaw_half = mode ? mode->yaw_half : 0.0;
   cm.prior = mode ? mode->prior : nullptr;
@@ -1521,8 +2079,40 @@ int cfear_register_launch(cfear_ctx* ctx, const void* d_jobs, int n_jobs, const 
     CFEAR_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     threads = kRegNWBig * 64;
   }
+  // Regular batches go through register3_kernel first (three workgroups per CU); register_kernel behind it takes what that
+  // launch deferred (CFEAR_NO_REG3=1: register_kernel alone, for A/B runs).
+  static const bool no_reg3 = getenv("CFEAR_NO_REG3") != nullptr;
+  const bool use3 = !mode && !compact && n_jobs > 64 && !no_reg3;
+  if (use3) {
+    KernelFn f3;
+    switch (par->cost) {
+      case CFEAR_P2P: f3 = huber ? register3_kernel<CFEAR_P2P, CFEAR_LOSS_HUBER> : register3_kernel<CFEAR_P2P, -1>; break;
+      case CFEAR_P2L: f3 = huber ? register3_kernel<CFEAR_P2L, CFEAR_LOSS_HUBER> : register3_kernel<CFEAR_P2L, -1>; break;
+      default: f3 = huber ? register3_kernel<CFEAR_P2D, CFEAR_LOSS_HUBER> : register3_kernel<CFEAR_P2D, -1>; break;
+    }
+    CFEAR_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)f3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kReg3Lds));
+    RegCommon c3 = cm;
+    c3.lds_total = (uint32_t)kReg3Lds;
+    c3.big_mode = 0;
+    {
+      ProfScope ps(ctx, "register");
+      hipLaunchKernelGGL(f3, dim3(n_jobs), dim3(kReg3Threads), kReg3Lds, ctx->stream, (const RegJob*)d_jobs, c3);
+    }
+    CFEAR_HIP_CHECK(ctx, hipGetLastError());
+    cm.only_deferred = 1;
+    static const bool r3_stats = getenv("CFEAR_REG3_STATS") != nullptr;   // debug: how many registrations this launch left to register_kernel
+    if (r3_stats) {
+      std::vector<cfear_reg_result> h((size_t)n_jobs);
+      if (hipMemcpyAsync(h.data(), d_results, h.size() * sizeof(cfear_reg_result), hipMemcpyDeviceToHost, ctx->stream) == hipSuccess &&
+          hipStreamSynchronize(ctx->stream) == hipSuccess) {
+        int nd = 0;
+        for (const cfear_reg_result& r : h) nd += r.status == kRegDeferred;
+        fprintf(stderr, "register3: %d of %d registrations deferred\n", nd, n_jobs);
+      }
+    }
+  }
   {
-    ProfScope ps(ctx, mode ? "get_cost" : "register");
+    ProfScope ps(ctx, mode ? "get_cost" : (use3 ? "register_rest" : "register"));
     hipLaunchKernelGGL(fn, dim3(n_jobs, mode ? std::max(mode->blocks_per_job, 1) : 1), dim3(threads), lds, ctx->stream,
                        (const RegJob*)d_jobs, cm);
   }

@@ -315,9 +315,92 @@ __device__ __forceinline__ int upper_bound_u32(const uint32_t* a, int lo, int hi
   return lo;
 }
 
+// The matcher's search structure of a scan (ScanView::grid_*): the float means bucketed into a uniform kScanGrid x kScanGrid
+// grid over the scan's own extent, built ONCE per scan -- the counterpart of ComputeSearchTreeFromCells (pointnormal.cpp:
+// 151-162), which builds the reference's kd-tree once per MapPointNormal.  A registration copies the tables into LDS
+// (register.hip: register3_kernel) instead of bucketing every keyframe again.  Counting sort with LDS atomics; the order of
+// the records inside a cell is arbitrary (the nearest-neighbour rule breaks ties by the cell index a record carries).
+// Block-wide collective; lds: kScanGridLds bytes of scratch.
+constexpr size_t kScanGridLds = (size_t)kScanGridCells * 4 + 128;
+__device__ void grid_cells_block(const ScanView& v, int n, uint8_t* lds) {
+  const int tid = threadIdx.x, nth = blockDim.x;
+  unsigned* cnt = (unsigned*)lds;                            // [cells] counts -> scatter cursors
+  unsigned* ext = cnt + kScanGridCells;                      // [4] ordered images of min x, max x, min y, max y | [16] wave totals
+  auto ordered = [](float f) { unsigned u = __float_as_uint(f); return (u >> 31) ? ~u : (u | 0x80000000u); };
+  auto unordered = [](unsigned u) { return __uint_as_float((u >> 31) ? (u & 0x7fffffffu) : ~u); };
+  if (n > 65535) {                                           // the cell table is 16-bit: such a scan keeps the x-sorted route
+    if (tid == 0) *v.grid_geo = make_float4(0.f, 0.f, 0.f, 0.f);
+    return;
+  }
+  for (int c = tid; c < kScanGridCells; c += nth) cnt[c] = 0;
+  if (tid < 4) ext[tid] = (tid & 1) ? 0u : 0xFFFFFFFFu;
+  __syncthreads();
+  {
+    unsigned xl = 0xFFFFFFFFu, xh = 0u, yl = 0xFFFFFFFFu, yh = 0u;
+    for (int i = tid; i < n; i += nth) {
+      const float2 m = v.mean_f[i];
+      const unsigned ux = ordered(m.x), uy = ordered(m.y);
+      xl = min(xl, ux); xh = max(xh, ux); yl = min(yl, uy); yh = max(yh, uy);
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+      xl = min(xl, (unsigned)__shfl_xor((int)xl, o)); xh = max(xh, (unsigned)__shfl_xor((int)xh, o));
+      yl = min(yl, (unsigned)__shfl_xor((int)yl, o)); yh = max(yh, (unsigned)__shfl_xor((int)yh, o));
+    }
+    if ((tid & 63) == 0) { atomicMin(&ext[0], xl); atomicMax(&ext[1], xh); atomicMin(&ext[2], yl); atomicMax(&ext[3], yh); }
+  }
+  __syncthreads();
+  float x0 = 0.f, y0 = 0.f, span = 0.f;
+  if (n > 0) {
+    x0 = unordered(ext[0]); y0 = unordered(ext[2]);
+    span = fmaxf(unordered(ext[1]) - x0, unordered(ext[3]) - y0);
+  }
+  // cell edge: the extent split into kScanGrid cells, never below the matcher's radius (finer cells would only add rows to a query)
+  const float inv = 1.0f / fmaxf(span / (float)kScanGrid * 1.0001f, kScanGridMinEdge);
+  auto cell_of = [&](float x, float y) {                     // the same expression locates a query's cells in register.hip
+    const int cx = min(kScanGrid - 1, max(0, (int)floorf((x - x0) * inv)));
+    const int cy = min(kScanGrid - 1, max(0, (int)floorf((y - y0) * inv)));
+    return cy * kScanGrid + cx;
+  };
+  for (int i = tid; i < n; i += nth) { const float2 m = v.mean_f[i]; atomicAdd(&cnt[cell_of(m.x, m.y)], 1u); }
+  __syncthreads();
+  {                                                          // exclusive scan over the cells
+    const int per = (kScanGridCells + nth - 1) / nth, c0 = tid * per, c1 = min(kScanGridCells, c0 + per);
+    int tot = 0;
+    for (int c = c0; c < c1; c++) tot += (int)cnt[c];
+    const int incl = wave_incl_scan_i32(tot);
+    if ((tid & 63) == 63) ext[4 + (tid >> 6)] = (unsigned)incl;
+    __syncthreads();
+    int run = incl - tot;
+    for (int wv = 0; wv < (tid >> 6); wv++) run += (int)ext[4 + wv];
+    for (int c = c0; c < c1; c++) {
+      const int k = (int)cnt[c];
+      v.grid_cstart[c] = (unsigned short)run;
+      cnt[c] = (unsigned)run;
+      run += k;
+    }
+    if (tid < kScanGridStartPad - kScanGridCells) v.grid_cstart[kScanGridCells + tid] = (unsigned short)n;
+  }
+  __syncthreads();
+  for (int i = tid; i < n; i += nth) {
+    const float2 m = v.mean_f[i];
+    const unsigned pos = atomicAdd(&cnt[cell_of(m.x, m.y)], 1u);
+    v.grid_txyi[pos] = make_float4(m.x, m.y, __int_as_float(i), 0.f);
+  }
+  if (tid == 0) *v.grid_geo = make_float4(x0, y0, inv, 1.f);
+}
+
+__device__ void sort_cells_x(const ScanView& v, int n, unsigned long long* keys, const size_t lds_bytes);
+// The two search orders of a scan: sorted by (x, index) (the windowed search of the slot path, closest_idx) and the grid.
+// keys: LDS scratch for at least max(next_pow2(n) 64-bit keys, kScanGridLds bytes).
+__device__ void sort_cells_block(const ScanView& v, int n, unsigned long long* keys, const size_t lds_bytes = 0) {
+  sort_cells_x(v, n, keys, lds_bytes);
+  __syncthreads();
+  grid_cells_block(v, n, (uint8_t*)keys);
+}
+
 // Sorts the n float means of a scan by (x, cell index) into v.sorted_{x,y,idx}; block-wide collective.
 // keys: LDS scratch for at least next_pow2(n) 64-bit keys.
-__device__ void sort_cells_block(const ScanView& v, int n, unsigned long long* keys, const size_t lds_bytes = 0) {
+__device__ void sort_cells_x(const ScanView& v, int n, unsigned long long* keys, const size_t lds_bytes) {
   const int tid = threadIdx.x, nth = blockDim.x;
   int npad = 64;
   while (npad < n) npad <<= 1;
@@ -1614,7 +1697,7 @@ int cfear_surface_launch(cfear_ctx* ctx, const void* d_jobs, int n_jobs, const c
   int keys_pow2 = 64;
   while (keys_pow2 < max_cell_cap && keys_pow2 < kMaxPoints) keys_pow2 <<= 1;   // the x-sort holds at most 16 384 cells (128 KiB)
   cm.finish_keys = keys_pow2;
-  const size_t finish_lds = std::max((size_t)keys_pow2 * 8, (size_t)std::min(keys_pow2, 2048) * 16 + 1024);   // bucketed rank sort: two key arrays
+  const size_t finish_lds = std::max(std::max((size_t)keys_pow2 * 8, (size_t)std::min(keys_pow2, 2048) * 16 + 1024), kScanGridLds);   // bucketed rank sort: two key arrays; then the matcher grid's counters
   cm.finish_lds = (uint32_t)finish_lds;
   if (finish_lds > 64 * 1024)
     CFEAR_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)surface_finish_kernel,
@@ -1785,7 +1868,7 @@ extern "C" int cfear_scan_from_cells(cfear_ctx* ctx, const cfear_cell* cells, in
       CFEAR_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)scan_sort_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                                (int)((size_t)kMaxPoints * 8)));
     if (npad > kMaxPoints) { cfear_scan_destroy(s); return cfear_set_error(ctx, CFEAR_ERR_CAPACITY, "more than %d cells", kMaxPoints); }
-    const size_t sort_lds = std::max((size_t)npad * 8, (size_t)std::min(npad, 2048) * 16 + 1024);
+    const size_t sort_lds = std::max(std::max((size_t)npad * 8, (size_t)std::min(npad, 2048) * 16 + 1024), kScanGridLds);
     hipLaunchKernelGGL(scan_sort_kernel, dim3(1), dim3(kSurfThreads), sort_lds, ctx->stream, s->view, (uint32_t)sort_lds);
     CFEAR_HIP_CHECK(ctx, hipGetLastError());
   }
