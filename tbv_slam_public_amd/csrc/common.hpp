@@ -212,6 +212,23 @@ struct CovFit {
 // ---------------------------------------------------------------------------------------------
 #if defined(__HIPCC__)
 
+// Loads and stores through pointers that are KNOWN to address global memory but whose static type is generic (pointers kept
+// in job records, LDS tables, ScanView): a generic pointer compiles to flat_load / flat_store, which count in lgkmcnt as
+// well as vmcnt, so every wait for an LDS read behind one also waits for the memory round trip -- a loop that mixes LDS
+// reads with such loads runs them one at a time.  T: a scalar or an ext_vector_type (HIP's double2 / float4 structs have
+// no address-space-qualified copy constructors).
+typedef uint32_t g_u32x4 __attribute__((ext_vector_type(4)));
+typedef double g_f64x2 __attribute__((ext_vector_type(2)));
+typedef double g_f64x4 __attribute__((ext_vector_type(4)));
+typedef float g_f32x4 __attribute__((ext_vector_type(4)));
+template <class T>
+__device__ __forceinline__ T gload(const void* p) { return *(const __attribute__((address_space(1))) T*)p; }
+template <class T>
+__device__ __forceinline__ void gstore(void* p, T v) { *(__attribute__((address_space(1))) T*)p = v; }
+__device__ __forceinline__ double2 gload_d2(const double2* p) { const g_f64x2 v = gload<g_f64x2>(p); return make_double2(v.x, v.y); }
+__device__ __forceinline__ double4 gload_d4(const double4* p) { const g_f64x4 v = gload<g_f64x4>(p); return make_double4(v.x, v.y, v.z, v.w); }
+__device__ __forceinline__ float4 gload_f4(const float4* p) { const g_f32x4 v = gload<g_f32x4>(p); return make_float4(v.x, v.y, v.z, v.w); }
+
 // DPP move: lanes without a valid source (or masked off) receive 0.
 template <int CTRL, int ROW_MASK = 0xf, int BANK_MASK = 0xf, bool BOUND = true>
 __device__ __forceinline__ int dpp_mov(int v) {

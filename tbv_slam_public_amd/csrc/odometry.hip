@@ -650,26 +650,29 @@ static int process_frame(cfear_odometry* od, const uint8_t* polar, const uint8_t
   // four classes by the quartiles of the estimate, streams in index order inside a class: a full sort walked the
   // stream records in random order and cost more host time than the kernel saved.
   std::vector<double>& est = od->cost_est;
-  double cut[3] = {0.0, 0.0, 0.0};
+  // ... plus a class of its own for the heaviest 3 %: the registrations whose correspondences overflow the LDS arrays of
+  // register3_kernel run ~1.5 x as long as the rest and must not be the last ones to start
+  double cut[4] = {0.0, 0.0, 0.0, 0.0};
   {
     std::vector<double>& tmp = od->cost_tmp;
     tmp.assign(est.begin(), est.end());
-    if (B >= 8)
-      for (int q = 0; q < 3; q++) {
-        const size_t k = (size_t)B * (3 - q) / 4;                                // descending cuts: 75 %, 50 %, 25 %
-        std::nth_element(tmp.begin(), tmp.begin() + k, tmp.end());
-        cut[q] = tmp[k];
+    if (B >= 8) {
+      const size_t ks[4] = {(size_t)B * 97 / 100, (size_t)B * 3 / 4, (size_t)B / 2, (size_t)B / 4};   // descending cuts
+      for (int q = 0; q < 4; q++) {
+        std::nth_element(tmp.begin(), tmp.begin() + ks[q], tmp.end());
+        cut[q] = tmp[ks[q]];
       }
+    }
   }
   for (int b = 0; b < B; b++) {
     Stream& st = od->streams[b];
     st.Tguess = par.use_guess ? aff_mul(st.T_prev, st.Tmot) : st.T_prev;      // :164-168
     st.job = -1;
   }
-  for (int cls = 0; cls < 4; cls++)
+  for (int cls = 0; cls < 5; cls++)
   for (int b = 0; b < B; b++) {
     const double e = est[b];
-    const int c = e >= cut[0] ? 0 : e >= cut[1] ? 1 : e >= cut[2] ? 2 : 3;
+    const int c = e >= cut[0] ? 0 : e >= cut[1] ? 1 : e >= cut[2] ? 2 : e >= cut[3] ? 3 : 4;
     if (c != cls) continue;
     Stream& st = od->streams[b];
     if (st.keyframes.empty()) continue;                                       // :171-177 first frame: no registration

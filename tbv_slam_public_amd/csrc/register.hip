@@ -1371,8 +1371,17 @@ struct R3Lds {
   float4* txyi;            // [sum_tar] (x, y, index bits, -) grouped by (keyframe, cell)            } arrays alias both
   double* dense;           // = cstart
   int dense_cap;
+  int region;              // bytes of the aliased region: the keyframes' tables are staged in groups that fit it
 };
 constexpr int kR3Ptrs = 7;
+
+// The dense correspondence arrays of register3_kernel: entries [0, cap) in LDS (SoA, stride cap), the rest -- a registration
+// with more correspondences than the LDS holds -- in the job's global scratch (SoA, stride gcap).  Two typed pointers, two code
+// paths per access: no generic (flat) addressing.
+struct Dense3 {
+  double* p; int* sidx; const double2* smean; int cap; int n;
+  double* gp; int* gsidx; size_t gcap;
+};
 
 __device__ __forceinline__ bool r3_carve(uint8_t* smem, size_t lds_total, int last, int sum_tar, int n_src, int n_pairs, int fields,
                                          R3Lds& f) {
@@ -1385,11 +1394,12 @@ __device__ __forceinline__ bool r3_carve(uint8_t* smem, size_t lds_total, int la
   f.smean = (double2*)(smem + off); off += (size_t)n_src * 16;
   f.match = (unsigned short*)(smem + off); off += (((size_t)n_pairs + 7) & ~(size_t)7) * 2;
   off = (off + 15) & ~(size_t)15;
-  const size_t assoc = (size_t)last * kScanGridStartPad * 2 + (size_t)sum_tar * 16;
-  if (sum_tar > 65535 || off + assoc > lds_total) return false;
+  // room for one keyframe's tables at the very least (a keyframe that exceeds it: r3_associate reports it)
+  if (sum_tar > 65535 || off + (size_t)kScanGridStartPad * 2 + 4096 > lds_total) return false;
   f.cstart = (unsigned short*)(smem + off);
-  f.txyi = (float4*)(smem + off + (size_t)last * kScanGridStartPad * 2);
+  f.txyi = nullptr;                                        // set per group by r3_restage
   f.dense = (double*)(smem + off);
+  f.region = (int)(lds_total - off);
   f.dense_cap = (int)((lds_total - off) / ((size_t)fields * 8 + 4)) & ~1;
   return true;
 }
@@ -1400,10 +1410,10 @@ __device__ bool r3_stage_once(const RegJob& job, const R3Lds& f, int* flag /* LD
   if (tid == 0) {
     int acc = 0, pacc = 0, ok = 1;
     for (int i = 0; i < last; i++) {
-      const int n = *job.scans[i].n_cells;
+      const int n = gload<int>(job.scans[i].n_cells);
       f.koff[i] = acc; f.poff[i] = pacc;
       acc += n; pacc += kScanGridStartPad / 8 + n;
-      const float4 g = *job.scans[i].grid_geo;
+      const float4 g = gload_f4(job.scans[i].grid_geo);
       f.ggeo[i] = g;
       ok &= (g.w == 1.f);
     }
@@ -1420,72 +1430,93 @@ __device__ bool r3_stage_once(const RegJob& job, const R3Lds& f, int* flag /* LD
     tp[0] = tv.mean; tp[1] = tv.normal; tp[2] = tv.nsamples; tp[3] = tv.scale; tp[4] = tv.cov; tp[5] = tv.grid_cstart; tp[6] = tv.grid_txyi;
   }
   const ScanView& src = job.scans[last];
-  const int n_src = *src.n_cells;
-  for (int s = tid; s < n_src; s += kReg3Threads) f.smean[s] = src.mean[s];
+  const int n_src = gload<int>(src.n_cells);
+  for (int s = tid; s < n_src; s += kReg3Threads) f.smean[s] = gload_d2(src.mean + s);
   __syncthreads();
   return *flag != 0;
 }
 
-// every outer iteration: the keyframes' grid tables from global memory (L2) into the aliased LDS region, and the
-// source-to-keyframe transforms at the current pose (n_scan_normal.cpp:222)
-__device__ __forceinline__ void r3_restage(const R3Lds& f, int last, const double* xsrc) {
+// The grid tables of keyframes [i0, i1) from global memory (L2) into the aliased LDS region: their cell-start tables first
+// (made absolute: + the keyframe's first record inside the group), then their records.
+__device__ __forceinline__ void r3_restage(const R3Lds& f, int i0, int i1) {
   const int tid = threadIdx.x;
-  const int P = f.poff[last];
+  const int p_lo = f.poff[i0], P = f.poff[i1] - p_lo, k_lo = f.koff[i0];
   constexpr int kPieces = 8;                              // pieces a thread keeps in flight (8 x 256 x 16 B = 32 KB per round)
   constexpr int kCs = kScanGridStartPad / 8;              // pieces of one cell-start table
+  const int rec0 = (i1 - i0) * kCs;                       // first record piece
   for (int p0 = 0; p0 < P; p0 += kPieces * kReg3Threads) {
     uint4 v[kPieces];
     int dst[kPieces];                                     // LDS destination (in 16-byte units from cstart), -1 = none
+    unsigned add[kPieces];                                // cell-start pieces: the keyframe's first record inside the group, twice (u16 pairs)
 #pragma unroll
-    for (int k = 0; k < kPieces; k++) {
+    for (int k = 0; k < kPieces; k++) {                   // every load is issued before the first result is touched
       const int p = p0 + tid + k * kReg3Threads;
-      dst[k] = -1;
+      dst[k] = -1; add[k] = 0u;
       if (p < P) {
-        int i = 0;
-        while (i + 1 < last && p >= f.poff[i + 1]) i++;
-        const int j = p - f.poff[i];
+        int i = i0;
+        while (i + 1 < i1 && p + p_lo >= f.poff[i + 1]) i++;
+        const int j = p + p_lo - f.poff[i];
         const void* const* tp = f.tptr + i * kR3Ptrs;
-        if (j < kCs) {
-          v[k] = ((const uint4*)tp[5])[j];
-          const unsigned add = (unsigned)f.koff[i] * 0x10001u;       // u16 pairs: no carry, the sums stay below 65536
-          v[k].x += add; v[k].y += add; v[k].z += add; v[k].w += add;
-          dst[k] = i * kCs + j;
-        } else {
-          v[k] = ((const uint4*)tp[6])[j - kCs];
-          dst[k] = last * kCs + f.koff[i] + (j - kCs);
-        }
+        const bool is_cs = j < kCs;
+        const uint4* src = is_cs ? (const uint4*)tp[5] + j : (const uint4*)tp[6] + (j - kCs);
+        const g_u32x4 t = gload<g_u32x4>(src);
+        v[k] = make_uint4(t.x, t.y, t.z, t.w);
+        add[k] = is_cs ? (unsigned)(f.koff[i] - k_lo) * 0x10001u : 0u;     // no carry: the sums stay below 65536
+        dst[k] = is_cs ? (i - i0) * kCs + j : rec0 + (f.koff[i] - k_lo) + (j - kCs);
       }
     }
 #pragma unroll
     for (int k = 0; k < kPieces; k++)
-      if (dst[k] >= 0) ((uint4*)f.cstart)[dst[k]] = v[k];
+      if (dst[k] >= 0) {
+        uint4 t = v[k];
+        t.x += add[k]; t.y += add[k]; t.z += add[k]; t.w += add[k];
+        ((uint4*)f.cstart)[dst[k]] = t;
+      }
   }
-  if (tid < last) {                                        // Tsrctotar_i = Ttar_i^-1 * Tsrc
+  __syncthreads();
+}
+
+// One association pass (n_scan_normal.cpp:213-318) at the pose xsrc; fills `dn` (which overwrites the staged tables); returns
+// the number of blocks, or -1 when a keyframe's tables do not fit the LDS region at all (register_kernel's job).
+// associate_fused's two passes with the grid edge fixed at kScanGrid; the keyframes are staged in as many groups as the
+// region needs (one, unless the scans are unusually large).
+__device__ int r3_associate(const RegJob& job, const RegCommon& cm, int itr, const R3Lds& f, const double* xsrc, double* gl_dense,
+                            Dense3& dn, int* ipart, int& iphase) {
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int last = job.n_scans - 1;
+  const int n_src = gload<int>(job.scans[last].n_cells);
+  const int n_pairs = last * n_src;
+  const double curr_radius = (itr == 1) ? 2 * cm.par.radius : cm.par.radius;    // :220
+  const double r2 = curr_radius * curr_radius;
+  const float rwin = (float)curr_radius + 1e-3f;
+  constexpr int G = kScanGrid;
+  REG_T0();
+  if (tid < last) {                                        // Tsrctotar_i = Ttar_i^-1 * Tsrc  (:222)
     const double* k = f.kf + tid * 12;
     const Aff2 Ttar{k[0], k[1], k[2], k[3], k[4], k[5]};
     const Aff2 Tst = aff_mul(aff_inv(Ttar), aff_from_xyt(xsrc));
     double* o = f.kf + tid * 12 + 6;
     o[0] = Tst.l0; o[1] = Tst.l1; o[2] = Tst.l2; o[3] = Tst.l3; o[4] = Tst.t0; o[5] = Tst.t1;
   }
-  __syncthreads();
-}
-
-// One association pass (n_scan_normal.cpp:213-318) over the staged tables; fills `dn` (which overwrites the tables);
-// returns the number of blocks.  associate_fused's two passes with the grid edge fixed at kScanGrid.
-__device__ int r3_associate(const RegJob& job, const RegCommon& cm, int itr, const R3Lds& f, Dense& dn, int* ipart, int& iphase) {
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const int last = job.n_scans - 1;
-  const int n_src = *job.scans[last].n_cells;
-  const int n_pairs = last * n_src;
-  const double curr_radius = (itr == 1) ? 2 * cm.par.radius : cm.par.radius;    // :220
-  const double r2 = curr_radius * curr_radius;
-  const float rwin = (float)curr_radius + 1e-3f;
-  constexpr int G = kScanGrid;
   int accepted = 0;
-  {
-    int i = 0, s = tid;
-    while (s >= n_src && i < last) { s -= n_src; i++; }
-    for (int p = tid; p < n_pairs; p += kReg3Threads) {
+  for (int i0 = 0; i0 < last;) {
+    int i1 = i0, bytes = 0;                                // the keyframes [i0, i1) whose tables fit the region together
+    while (i1 < last) {
+      const int b = kScanGridStartPad * 2 + (f.koff[i1 + 1] - f.koff[i1]) * 16;
+      if (bytes + b > f.region) break;
+      bytes += b; i1++;
+    }
+    if (i1 == i0) return -1;                               // (block-uniform)
+    if (i0 > 0) __syncthreads();                           // the previous group's readers are done
+    r3_restage(f, i0, i1);                                 // (its barrier also publishes the transforms above)
+    REG_TACC(0);
+    const float4* txyi = (const float4*)(f.cstart + (size_t)(i1 - i0) * kScanGridStartPad);
+    // this thread's pairs p = tid + 256 k (the SAME pairs in every group layout and in pass 2) that fall into the group
+    const int lo = i0 * n_src, hi = i1 * n_src;
+    int p = lo + ((tid - lo) & (kReg3Threads - 1));
+    int i = i0, s = p - lo;
+    while (s >= n_src && i < i1) { s -= n_src; i++; }
+    for (; p < hi; p += kReg3Threads) {
       const double* T = f.kf + i * 12 + 6;
       const double2 u = f.smean[s];
       const double px = T[0] * u.x + T[1] * u.y + T[4];
@@ -1502,11 +1533,11 @@ __device__ int r3_associate(const RegJob& job, const RegCommon& cm, int itr, con
         const unsigned long long key = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)__float_as_int(c.z);
         bestkey = key < bestkey ? key : bestkey;
       };
-      const unsigned short* cs = f.cstart + i * kScanGridStartPad;
+      const unsigned short* cs = f.cstart + (i - i0) * kScanGridStartPad;
       auto scan_run = [&](int qb, int qe) {
         for (int q = qb; q < qe; q += 4) {
           const int l = qe - 1;
-          const float4 ca = f.txyi[q], cb = f.txyi[min(q + 1, l)], cc = f.txyi[min(q + 2, l)], cd = f.txyi[min(q + 3, l)];
+          const float4 ca = txyi[q], cb = txyi[min(q + 1, l)], cc = txyi[min(q + 2, l)], cd = txyi[min(q + 3, l)];
           visit(ca); visit(cb); visit(cc); visit(cd);
         }
       };
@@ -1524,16 +1555,18 @@ __device__ int r3_associate(const RegJob& job, const RegCommon& cm, int itr, con
       const float bestd = __uint_as_float((unsigned)(bestkey >> 32));
       int m = -1;
       if (best >= 0 && (double)bestd < r2) {                                    // pointnormal.cpp:250
-        const double2 ns = job.scans[last].normal[s];
-        const double2 nt = ((const double2*)f.tptr[i * kR3Ptrs + 1])[best];
+        const double2 ns = gload_d2(job.scans[last].normal + s);
+        const double2 nt = gload_d2((const double2*)f.tptr[i * kR3Ptrs + 1] + best);
         const double nsx = T[0] * ns.x + T[1] * ns.y, nsy = T[2] * ns.x + T[3] * ns.y;
         if (fmax(nsx * nt.x + nsy * nt.y, 0.0) > cm.angle_outlier) m = best;    // :244-245
       }
       f.match[p] = (unsigned short)m;
       accepted += (m >= 0);
       s += kReg3Threads;
-      while (s >= n_src && i < last) { s -= n_src; i++; }
+      while (s >= n_src && i < i1) { s -= n_src; i++; }
     }
+    REG_TACC(1);
+    i0 = i1;
   }
   const int incl = wave_incl_scan_i32(accepted);
   int base = incl - accepted, total;
@@ -1548,10 +1581,11 @@ __device__ int r3_associate(const RegJob& job, const RegCommon& cm, int itr, con
     total = __builtin_amdgcn_readfirstlane(tt);
     iphase ^= 1;
   }
-  if (total > f.dense_cap) return -1;                      // more correspondences than the LDS arrays hold: register_kernel's job
-  dense_bind(dn, f.dense, f.dense_cap, cm.dense_fields, f.smean);   // LDS only: every access below is a ds_ instruction
+  dn.p = f.dense; dn.cap = f.dense_cap; dn.sidx = (int*)(f.dense + (size_t)cm.dense_fields * f.dense_cap); dn.smean = f.smean;
+  dn.gp = gl_dense; dn.gcap = (size_t)cm.slots_cap; dn.gsidx = (int*)(gl_dense + (size_t)cm.dense_fields * cm.slots_cap);
   dn.n = total;
-  const size_t cap = (size_t)dn.cap;
+  const size_t cap = (size_t)dn.cap, gcap = dn.gcap;
+  REG_TACC(2);
   {
     struct Gathered {
       int best, i, s, tns, sns;
@@ -1567,14 +1601,14 @@ __device__ int r3_associate(const RegJob& job, const RegCommon& cm, int itr, con
       g.i = i; g.s = s;
       if (g.best >= 0) {
         const void* const* tp = f.tptr + i * kR3Ptrs;
-        g.nt = ((const double2*)tp[1])[g.best];
-        g.tm = ((const double2*)tp[0])[g.best];
-        g.tns = ((const int32_t*)tp[2])[g.best];
-        g.tsc = ((const double*)tp[3])[g.best];
-        g.ns = srcv.normal[s];
-        g.sns = srcv.nsamples[s];
-        g.ssc = srcv.scale[s];
-        if (cm.par.cost == CFEAR_P2D) g.S = ((const double4*)tp[4])[g.best];
+        g.nt = gload_d2((const double2*)tp[1] + g.best);
+        g.tm = gload_d2((const double2*)tp[0] + g.best);
+        g.tns = gload<int>((const int32_t*)tp[2] + g.best);
+        g.tsc = gload<double>((const double*)tp[3] + g.best);
+        g.ns = gload_d2(srcv.normal + s);
+        g.sns = gload<int>(srcv.nsamples + s);
+        g.ssc = gload<double>(srcv.scale + s);
+        if (cm.par.cost == CFEAR_P2D) g.S = gload_d4((const double4*)tp[4] + g.best);
       }
       return g;
     };
@@ -1593,10 +1627,10 @@ __device__ int r3_associate(const RegJob& job, const RegCommon& cm, int itr, con
         const double direction_similarity = fmax(nsx * nt.x + nsy * nt.y, 0.0);   // :244
         const double w = get_weight(cm.par.weight_opt, (double)cur.sns, (double)cur.tns,
                                     direction_similarity, cur.ssc, cur.tsc);       // :247-253, :273
-        dn.sidx[c] = cur.s;
-        dn.p[c] = K[0] * tm.x + K[1] * tm.y + K[4];                               // Ttar * tar_mean
-        dn.p[cap + c] = K[2] * tm.x + K[3] * tm.y + K[5];
-        dn.p[2 * cap + c] = w;
+        double e[6];                                       // tmx, tmy, w, a0, a1, a2
+        e[0] = K[0] * tm.x + K[1] * tm.y + K[4];                                  // Ttar * tar_mean
+        e[1] = K[2] * tm.x + K[3] * tm.y + K[5];
+        e[2] = w; e[3] = 0.0; e[4] = 0.0; e[5] = 0.0;
         if (cm.par.cost == CFEAR_P2D) {                                           // :288-297
           const double4 S = cur.S;
           const double a00 = K[0] * S.x + K[1] * S.z, a01 = K[0] * S.y + K[1] * S.w;
@@ -1608,20 +1642,64 @@ __device__ int r3_associate(const RegJob& job, const RegCommon& cm, int itr, con
           const double det = c00 * c11 - c10 * c01, invdet = 1.0 / det;
           const double i00 = c11 * invdet, i10 = -c10 * invdet, i11 = c00 * invdet;
           const double l00 = sqrt(i00), l10 = i10 / l00;
-          dn.p[3 * cap + c] = l00; dn.p[4 * cap + c] = l10; dn.p[5 * cap + c] = sqrt(i11 - l10 * l10);
+          e[3] = l00; e[4] = l10; e[5] = sqrt(i11 - l10 * l10);
         } else if (cm.par.cost == CFEAR_P2L) {
-          dn.p[3 * cap + c] = K[0] * nt.x + K[1] * nt.y;                          // Ttar.linear() * tar_normal
-          dn.p[4 * cap + c] = K[2] * nt.x + K[3] * nt.y;
+          e[3] = K[0] * nt.x + K[1] * nt.y;                                       // Ttar.linear() * tar_normal
+          e[4] = K[2] * nt.x + K[3] * nt.y;
+        }
+        const int nf = cm.dense_fields;
+        if (c < (int)cap) {
+          dn.sidx[c] = cur.s;
+          for (int k = 0; k < nf; k++) dn.p[k * cap + c] = e[k];
+        } else {
+          const size_t g = (size_t)c - cap;
+          gstore<int>(dn.gsidx + g, cur.s);
+          for (int k = 0; k < nf; k++) gstore<double>(dn.gp + k * gcap + g, e[k]);
         }
         c++;
       }
       cur = nxt;
     }
   }
+  if (total > (int)cap) __threadfence_block();             // the tail went to global memory
   __syncthreads();
+  REG_TACC(3);
   return total;
 }
 
+// cost, gradient and Gauss-Newton matrix of all correspondences at x (eval_all over Dense3); wavefront 0 receives the sums
+template <int COST, int LOSS>
+__device__ void eval_all3(const RegCommon& cm, const Dense3& dn, const double x[3], double c, double s, double out[10], double* part,
+                          int& phase) {
+  double acc[10];
+#pragma unroll
+  for (int k = 0; k < 10; k++) acc[k] = 0.0;
+  const size_t cap = (size_t)dn.cap, gcap = dn.gcap;
+  REG_T0();
+  for (int i = threadIdx.x; i < dn.n; i += kReg3Threads) {
+    double tmx, tmy, w, a0 = 0.0, a1 = 0.0, a2 = 0.0;
+    int si;
+    if (i < (int)cap) {
+      si = dn.sidx[i];
+      tmx = dn.p[i]; tmy = dn.p[cap + i]; w = dn.p[2 * cap + i];
+      if (COST != CFEAR_P2P) { a0 = dn.p[3 * cap + i]; a1 = dn.p[4 * cap + i]; }
+      if (COST == CFEAR_P2D) a2 = dn.p[5 * cap + i];
+    } else {
+      const size_t g = (size_t)i - cap;
+      si = gload<int>(dn.gsidx + g);
+      tmx = gload<double>(dn.gp + g); tmy = gload<double>(dn.gp + gcap + g); w = gload<double>(dn.gp + 2 * gcap + g);
+      if (COST != CFEAR_P2P) { a0 = gload<double>(dn.gp + 3 * gcap + g); a1 = gload<double>(dn.gp + 4 * gcap + g); }
+      if (COST == CFEAR_P2D) a2 = gload<double>(dn.gp + 5 * gcap + g);
+    }
+    const double2 sm = dn.smean[si];
+    eval_slot<COST, LOSS, true>(cm.par, sm.x, sm.y, tmx, tmy, a0, a1, a2, w, x[0], x[1], c, s, acc);
+  }
+  REG_TACC(4);
+  block_reduce10<4, false>(acc, part, phase);
+  REG_TACC(5);
+#pragma unroll
+  for (int k = 0; k < 10; k++) out[k] = acc[k];
+}
 
 // One round of ceres::Solve's trust-region loop on wavefront 0 (same statements as lm_solve): judges the candidate that
 // was just evaluated (cnd, when have_cnd), then produces the next candidate or the stop flag.  st = the LDS state block.
@@ -1755,7 +1833,7 @@ __device__ __forceinline__ void r3_lm_round(double* st, const double cnd[10], co
 // ceres::Solve for register3_kernel: lm_solve with the state in LDS.  The start pose is st[S_OUTER .. +3); the result is left
 // in the state block (S_X, S_FINAL, S_LASTREL, SI_PUSHED, SI_USABLE).  Block-wide collective.
 template <int COST, int LOSS>
-__device__ void lm_solve3(const RegCommon& cm, const Dense& dn, const int max_iter, double* part, int& phase, double* st) {
+__device__ void lm_solve3(const RegCommon& cm, const Dense3& dn, const int max_iter, double* part, int& phase, double* st) {
   const bool w0 = (threadIdx.x >> 6) == 0;
   int* si = (int*)(st + S_INTS);
   double cnd[10];
@@ -1763,7 +1841,7 @@ __device__ void lm_solve3(const RegCommon& cm, const Dense& dn, const int max_it
     const double x[3] = {st[S_OUTER], st[S_OUTER + 1], st[S_OUTER + 2]};
     double s0, c0;
     sincos_pose<true>(x[2], &s0, &c0);
-    eval_all<4, COST, LOSS>(cm, dn, x, c0, s0, cnd, part, phase);
+    eval_all3<COST, LOSS>(cm, dn, x, c0, s0, cnd, part, phase);
     if (w0) {
       if ((threadIdx.x & 63) == 0) {
         st[S_X] = x[0]; st[S_X + 1] = x[1]; st[S_X + 2] = x[2]; st[S_XCOST] = cnd[0];
@@ -1785,12 +1863,16 @@ __device__ void lm_solve3(const RegCommon& cm, const Dense& dn, const int max_it
     }
   }
   for (;;) {
+    REG_T0();
     __syncthreads();
+    REG_TACC(21);
     if (__builtin_amdgcn_readfirstlane(si[SI_DONE])) break;
     const double cand[3] = {st[S_CAND], st[S_CAND + 1], st[S_CAND + 2]};
     const double cs = st[S_COS], sn = st[S_SIN];
-    eval_all<4, COST, LOSS>(cm, dn, cand, cs, sn, cnd, part, phase);      // its barrier also orders the state block
+    eval_all3<COST, LOSS>(cm, dn, cand, cs, sn, cnd, part, phase);        // its barrier also orders the state block
+    REG_TACC(22);
     if (w0) r3_lm_round(st, cnd, true, max_iter);
+    REG_TACC(16);
   }
 }
 
@@ -1802,9 +1884,9 @@ __global__ __launch_bounds__(kReg3Threads, 3) void register3_kernel(const RegJob
   const RegJob& job = *(const RegJob*)((const char*)jobs + (size_t)blockIdx.x * cm.job_stride);
   cfear_reg_result* res = cm.results + blockIdx.x;
   const int last = job.n_scans - 1;
-  const int n_src = *job.scans[last].n_cells;
+  const int n_src = gload<int>(job.scans[last].n_cells);
   int sum_tar = 0;
-  for (int i = 0; i < last; i++) sum_tar += *job.scans[i].n_cells;
+  for (int i = 0; i < last; i++) sum_tar += gload<int>(job.scans[i].n_cells);
   const int n_pairs = last * n_src;
   R3Lds fl;
   bool ok = n_pairs <= cm.slots_cap && r3_carve(smem, cm.lds_total, last, sum_tar, n_src, n_pairs, cm.dense_fields, fl);
@@ -1813,7 +1895,11 @@ __global__ __launch_bounds__(kReg3Threads, 3) void register3_kernel(const RegJob
     if (threadIdx.x == 0) { res->status = kRegDeferred; res->reserved = 0.0; }
     return;
   }
-  Dense dn;
+  double* gl_dense = (double*)(cm.scratch + (size_t)blockIdx.x * cm.scratch_stride + slots_bytes(cm.slots_cap));
+#ifdef CFEAR_REG_TIMING
+  const long long t_total0 = __builtin_readcyclecounter();
+#endif
+  Dense3 dn;
   int phase = 0, iphase = 0;
   const int rpb = COST == CFEAR_P2L ? 1 : 2;
   // n_scan_normal.cpp:82-185.  The loop's own state (current pose, previous pose and score) lives in the LDS block too:
@@ -1829,8 +1915,7 @@ __global__ __launch_bounds__(kReg3Threads, 3) void register3_kernel(const RegJob
   bool success = true;
   int itr = 1, lm_iters = 0, num_residuals = 0, fail_status = CFEAR_OK;
   for (itr = 1; itr <= cm.par.max_itr_association && success; itr++) {
-    r3_restage(fl, last, st + S_OUTER);
-    const int n_blocks = r3_associate(job, cm, itr, fl, dn, ipart, iphase);
+    const int n_blocks = r3_associate(job, cm, itr, fl, st + S_OUTER, gl_dense, dn, ipart, iphase);
     if (n_blocks < 0) {                                           // (block-uniform)
       if (threadIdx.x == 0) { res->status = kRegDeferred; res->reserved = 0.0; }
       return;
@@ -1880,6 +1965,14 @@ __global__ __launch_bounds__(kReg3Threads, 3) void register3_kernel(const RegJob
     res->reserved = 0.0;
     if (success) { res->score = final_cost / (double)num_residuals; res->status = CFEAR_OK; }   // :162
     else { res->score = 0.0; res->status = fail_status; }
+#ifdef CFEAR_REG_TIMING
+    if (blockIdx.x == 0) {
+      printf("reg3 cycles: total %lld | restage %lld nn+gate %lld scan %lld gather %lld | eval %lld reduce %lld round %lld barrier %lld | outer %d lm %d n %d\n",
+             (long long)(__builtin_readcyclecounter() - t_total0), g_reg_t[0], g_reg_t[1], g_reg_t[2], g_reg_t[3], g_reg_t[4], g_reg_t[5],
+             g_reg_t[16], g_reg_t[21], itr, lm_iters, num_residuals);
+      for (int k = 0; k < 32; k++) g_reg_t[k] = 0;
+    }
+#endif
   }
 }
 
@@ -2081,8 +2174,7 @@ int cfear_register_launch(cfear_ctx* ctx, const void* d_jobs, int n_jobs, const 
   }
   // Regular batches go through register3_kernel first (three workgroups per CU); register_kernel behind it takes what that
   // launch deferred (CFEAR_NO_REG3=1: register_kernel alone, for A/B runs).
-  static const bool no_reg3 = getenv("CFEAR_NO_REG3") != nullptr;
-  const bool use3 = !mode && !compact && n_jobs > 64 && !no_reg3;
+  const bool use3 = !mode && !compact && n_jobs > 64 && !getenv("CFEAR_NO_REG3");   // (read per launch: the tests toggle it)
   if (use3) {
     KernelFn f3;
     switch (par->cost) {
@@ -2090,13 +2182,18 @@ int cfear_register_launch(cfear_ctx* ctx, const void* d_jobs, int n_jobs, const 
       case CFEAR_P2L: f3 = huber ? register3_kernel<CFEAR_P2L, CFEAR_LOSS_HUBER> : register3_kernel<CFEAR_P2L, -1>; break;
       default: f3 = huber ? register3_kernel<CFEAR_P2D, CFEAR_LOSS_HUBER> : register3_kernel<CFEAR_P2D, -1>; break;
     }
+    // CFEAR_REG3_LDS_KB (tests): a smaller LDS so that ordinary scans exercise the keyframe groups and the global tail of the
+    // dense arrays, which only unusually large registrations reach at the real size
+    const char* e_kb = getenv("CFEAR_REG3_LDS_KB");
+    const long kb = e_kb ? atol(e_kb) : 0;
+    const size_t r3_lds = kb >= 8 && kb <= 52 ? (size_t)kb * 1024 : kReg3Lds;
     CFEAR_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)f3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kReg3Lds));
     RegCommon c3 = cm;
-    c3.lds_total = (uint32_t)kReg3Lds;
+    c3.lds_total = (uint32_t)r3_lds;
     c3.big_mode = 0;
     {
       ProfScope ps(ctx, "register");
-      hipLaunchKernelGGL(f3, dim3(n_jobs), dim3(kReg3Threads), kReg3Lds, ctx->stream, (const RegJob*)d_jobs, c3);
+      hipLaunchKernelGGL(f3, dim3(n_jobs), dim3(kReg3Threads), r3_lds, ctx->stream, (const RegJob*)d_jobs, c3);
     }
     CFEAR_HIP_CHECK(ctx, hipGetLastError());
     cm.only_deferred = 1;

@@ -475,6 +475,50 @@ def test_small_and_large_batches_agree():
             np.testing.assert_allclose(b["final_cost"], small[q]["final_cost"], rtol=1e-11)
 
 
+def test_three_per_cu_kernel_matches_the_two_per_cu_kernel(monkeypatch):
+    """Batches of more than 64 regular registrations run on register3_kernel (three workgroups per CU: prebuilt per-scan grids
+    copied into LDS, association tables aliased with the LM arrays, solver state in LDS).  Same statements as register_kernel:
+    every integer outcome identical, poses and costs to rounding -- at its real LDS size, and with 14 KB of LDS, where the
+    keyframes' tables are staged in several groups and the dense arrays spill their tail to global memory (paths that only
+    unusually large registrations reach otherwise).  The oracle is the judge of both (test_iteration_counts_...)."""
+    from oracle import pyoracle as O
+    from tbv_slam_public_amd import api
+    rng = np.random.default_rng(5)
+    for cost, loss, opt in (("P2P", "Huber", 4), ("P2L", "Cauchy", 0), ("P2D", "Huber", 0)):
+        reg = api.n_scan_normal_reg(cost, loss, 0.1)
+        reg.par.weight_opt = opt
+        reg.SetParameters(8, 100)
+        jobs, ojobs = [], []
+        for seed in (31, 32):
+            cells, gt = _cells(seed, [0, 1, 2, 3, 4], k=20)
+            scans = [api.MapPointNormal(cells=c) for c in cells]
+            for rep in range(36):
+                n = int(rng.integers(2, 6))
+                idx = sorted(rng.choice(5, size=n, replace=False).tolist())
+                T = np.array([gt[i] for i in idx], dtype=np.float64)
+                T[-1] += np.concatenate([rng.normal(0, 0.4, 2), rng.normal(0, 0.015, 1)])
+                jobs.append(([scans[i] for i in idx], T))
+                ojobs.append(([cells[i] for i in idx], T))
+        monkeypatch.setenv("CFEAR_NO_REG3", "1")
+        base = reg.RegisterBatch(jobs)
+        monkeypatch.delenv("CFEAR_NO_REG3")
+        runs = {"52 KB": reg.RegisterBatch(jobs)}
+        monkeypatch.setenv("CFEAR_REG3_LDS_KB", "14")
+        runs["14 KB"] = reg.RegisterBatch(jobs)
+        monkeypatch.delenv("CFEAR_REG3_LDS_KB")
+        for name, out in runs.items():
+            for a, b in zip(base, out):
+                key = lambda r: (int(r["status"]), int(r["outer_iters"]), int(r["lm_iters"]), int(r["num_residuals"]))
+                assert key(a) == key(b), (cost, name, key(a), key(b))
+                np.testing.assert_allclose(b["pose"], a["pose"], rtol=0, atol=1e-11, err_msg=name)
+                np.testing.assert_allclose(b["final_cost"], a["final_cost"], rtol=1e-10, err_msg=name)
+        for r, (c, T) in list(zip(runs["14 KB"], ojobs))[::6]:            # a sample against the oracle itself
+            ok_o, po, ro = O.register(c, T, _oracle_par(reg))
+            assert (r["status"] == 0) == ok_o
+            assert (r["outer_iters"], r["lm_iters"], r["num_residuals"]) == (ro.outer_iters, ro.lm_iters, ro.num_residuals)
+            assert np.abs(r["pose"][:2] - po[-1, :2]).max() <= POS_TOL and abs(r["pose"][2] - po[-1, 2]) <= ROT_TOL
+
+
 def _rccl():
     """librccl through ctypes: a ONE-rank communicator (ncclGetUniqueId + ncclCommInitRank), as a C++ host would own it."""
     import ctypes as C
