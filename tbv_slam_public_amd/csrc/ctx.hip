@@ -117,7 +117,7 @@ size_t cfear_scan_slab_bytes(int cap) {
   b += align_up(c * sizeof(double4), 256);
   b += align_up(c * sizeof(double), 256) * 2;      // scale, avg_intensity
   b += align_up(c * sizeof(int32_t), 256);
-  b += align_up(c * sizeof(float4), 256) + align_up(kScanGridStartPad * 2, 256);   // prebuilt matcher grid
+  b += align_up((size_t)kScanGridStartPad * 2 + c * sizeof(float4), 256);          // prebuilt matcher grid: cell starts, then the records
   return b;
 }
 
@@ -137,8 +137,8 @@ ScanView cfear_scan_view(void* slab, int cap) {
   v.scale = (double*)p; p += align_up(c * sizeof(double), 256);
   v.avg_intensity = (double*)p; p += align_up(c * sizeof(double), 256);
   v.nsamples = (int32_t*)p; p += align_up(c * sizeof(int32_t), 256);
-  v.grid_txyi = (float4*)p; p += align_up(c * sizeof(float4), 256);
-  v.grid_cstart = (unsigned short*)p;
+  v.grid_cstart = (unsigned short*)p;               // ONE block: a registration copies cell starts and records in one sweep
+  v.grid_txyi = (float4*)(p + (size_t)kScanGridStartPad * 2);
   v.grid_geo = (float4*)((char*)slab + 16);        // inside the 256-byte header, behind the counter
   v.cap = cap;
   v.pad = 0;

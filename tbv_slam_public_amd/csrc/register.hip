@@ -1362,8 +1362,7 @@ constexpr size_t kReg3Lds = 52 * 1024;          // x 3 = 156 KB of the CU's 160 
 struct R3Lds {
   double* kf;              // [last][12]: Ttar (l0..l3, t0, t1), Tsrctotar (l0..l3, t0, t1)
   int* koff;               // [last + 1] prefix of the keyframes' cell counts
-  int* poff;               // [last + 1] prefix of their 16-byte pieces (cell-start table + records)
-  const void** tptr;       // [last][7]: mean, normal, nsamples, scale, cov, grid_cstart, grid_txyi (global pointers)
+  const void** tptr;       // [last][6]: mean, normal, nsamples, scale, cov, grid block (cell starts + records): global pointers
   float4* ggeo;            // [last] grid geometry (x0, y0, cells per metre, -)
   double2* smean;          // [n_src]
   unsigned short* match;   // [n_pairs] matched target (index inside its keyframe), 0xFFFF = none
@@ -1373,7 +1372,7 @@ struct R3Lds {
   int dense_cap;
   int region;              // bytes of the aliased region: the keyframes' tables are staged in groups that fit it
 };
-constexpr int kR3Ptrs = 7;
+constexpr int kR3Ptrs = 6;
 
 // The dense correspondence arrays of register3_kernel: entries [0, cap) in LDS (SoA, stride cap), the rest -- a registration
 // with more correspondences than the LDS holds -- in the job's global scratch (SoA, stride gcap).  Two typed pointers, two code
@@ -1390,7 +1389,6 @@ __device__ __forceinline__ bool r3_carve(uint8_t* smem, size_t lds_total, int la
   f.tptr = (const void**)(smem + off); off += (size_t)last * kR3Ptrs * 8;
   f.ggeo = (float4*)(smem + off); off += (size_t)last * 16;
   f.koff = (int*)(smem + off); off += (((size_t)last + 1) * 4 + 15) & ~(size_t)15;
-  f.poff = (int*)(smem + off); off += (((size_t)last + 1) * 4 + 15) & ~(size_t)15;
   f.smean = (double2*)(smem + off); off += (size_t)n_src * 16;
   f.match = (unsigned short*)(smem + off); off += (((size_t)n_pairs + 7) & ~(size_t)7) * 2;
   off = (off + 15) & ~(size_t)15;
@@ -1408,16 +1406,16 @@ __device__ __forceinline__ bool r3_carve(uint8_t* smem, size_t lds_total, int la
 __device__ bool r3_stage_once(const RegJob& job, const R3Lds& f, int* flag /* LDS */) {
   const int tid = threadIdx.x, last = job.n_scans - 1;
   if (tid == 0) {
-    int acc = 0, pacc = 0, ok = 1;
+    int acc = 0, ok = 1;
     for (int i = 0; i < last; i++) {
       const int n = gload<int>(job.scans[i].n_cells);
-      f.koff[i] = acc; f.poff[i] = pacc;
-      acc += n; pacc += kScanGridStartPad / 8 + n;
+      f.koff[i] = acc;
+      acc += n;
       const float4 g = gload_f4(job.scans[i].grid_geo);
       f.ggeo[i] = g;
       ok &= (g.w == 1.f);
     }
-    f.koff[last] = acc; f.poff[last] = pacc;
+    f.koff[last] = acc;
     *flag = ok;
   }
   if (tid >= 64 && tid < 64 + last) {
@@ -1427,7 +1425,7 @@ __device__ bool r3_stage_once(const RegJob& job, const R3Lds& f, int* flag /* LD
     k[0] = T.l0; k[1] = T.l1; k[2] = T.l2; k[3] = T.l3; k[4] = T.t0; k[5] = T.t1;
     const ScanView& tv = job.scans[i];
     const void** tp = f.tptr + i * kR3Ptrs;
-    tp[0] = tv.mean; tp[1] = tv.normal; tp[2] = tv.nsamples; tp[3] = tv.scale; tp[4] = tv.cov; tp[5] = tv.grid_cstart; tp[6] = tv.grid_txyi;
+    tp[0] = tv.mean; tp[1] = tv.normal; tp[2] = tv.nsamples; tp[3] = tv.scale; tp[4] = tv.cov; tp[5] = tv.grid_cstart;
   }
   const ScanView& src = job.scans[last];
   const int n_src = gload<int>(src.n_cells);
@@ -1436,42 +1434,57 @@ __device__ bool r3_stage_once(const RegJob& job, const R3Lds& f, int* flag /* LD
   return *flag != 0;
 }
 
-// The grid tables of keyframes [i0, i1) from global memory (L2) into the aliased LDS region: their cell-start tables first
-// (made absolute: + the keyframe's first record inside the group), then their records.
+// The grid tables of keyframes [i0, i1) from global memory into the aliased LDS region: their cell-start tables first (made
+// absolute: + the keyframe's first record inside the group), then their records.  A scan keeps both in ONE block (cell starts,
+// then records: ScanView::grid_cstart), so a keyframe is a run of 16-byte pieces from one base address; four keyframes x two
+// pieces per thread are in flight before the first one is stored (one memory round trip for the usual registration).
 __device__ __forceinline__ void r3_restage(const R3Lds& f, int i0, int i1) {
   const int tid = threadIdx.x;
-  const int p_lo = f.poff[i0], P = f.poff[i1] - p_lo, k_lo = f.koff[i0];
-  constexpr int kPieces = 8;                              // pieces a thread keeps in flight (8 x 256 x 16 B = 32 KB per round)
+  const int k_lo = f.koff[i0];
   constexpr int kCs = kScanGridStartPad / 8;              // pieces of one cell-start table
+  constexpr int kKf = 4, kPer = 2;
   const int rec0 = (i1 - i0) * kCs;                       // first record piece
-  for (int p0 = 0; p0 < P; p0 += kPieces * kReg3Threads) {
-    uint4 v[kPieces];
-    int dst[kPieces];                                     // LDS destination (in 16-byte units from cstart), -1 = none
-    unsigned add[kPieces];                                // cell-start pieces: the keyframe's first record inside the group, twice (u16 pairs)
+  uint4* out = (uint4*)f.cstart;
+  for (int ib = i0; ib < i1; ib += kKf) {
+    g_u32x4 v[kKf][kPer];
+    int dst[kKf][kPer];
+    unsigned add[kKf];
 #pragma unroll
-    for (int k = 0; k < kPieces; k++) {                   // every load is issued before the first result is touched
-      const int p = p0 + tid + k * kReg3Threads;
-      dst[k] = -1; add[k] = 0u;
-      if (p < P) {
-        int i = i0;
-        while (i + 1 < i1 && p + p_lo >= f.poff[i + 1]) i++;
-        const int j = p + p_lo - f.poff[i];
-        const void* const* tp = f.tptr + i * kR3Ptrs;
-        const bool is_cs = j < kCs;
-        const uint4* src = is_cs ? (const uint4*)tp[5] + j : (const uint4*)tp[6] + (j - kCs);
-        const g_u32x4 t = gload<g_u32x4>(src);
-        v[k] = make_uint4(t.x, t.y, t.z, t.w);
-        add[k] = is_cs ? (unsigned)(f.koff[i] - k_lo) * 0x10001u : 0u;     // no carry: the sums stay below 65536
-        dst[k] = is_cs ? (i - i0) * kCs + j : rec0 + (f.koff[i] - k_lo) + (j - kCs);
+    for (int q = 0; q < kKf; q++) {
+      const int i = ib + q;
+#pragma unroll
+      for (int h = 0; h < kPer; h++) dst[q][h] = -1;
+      add[q] = 0u;
+      if (i < i1) {                                       // (block-uniform)
+        const char* blob = (const char*)f.tptr[i * kR3Ptrs + 5];
+        const int rel = f.koff[i] - k_lo, np = kCs + f.koff[i + 1] - f.koff[i];
+        add[q] = (unsigned)rel * 0x10001u;                // u16 pairs: no carry, the sums stay below 65536
+#pragma unroll
+        for (int h = 0; h < kPer; h++) {
+          const int j = tid + h * kReg3Threads;
+          if (j < np) {
+            v[q][h] = gload<g_u32x4>(blob + (size_t)j * 16);
+            dst[q][h] = j < kCs ? (i - i0) * kCs + j : rec0 + rel + (j - kCs);
+          }
+        }
       }
     }
 #pragma unroll
-    for (int k = 0; k < kPieces; k++)
-      if (dst[k] >= 0) {
-        uint4 t = v[k];
-        t.x += add[k]; t.y += add[k]; t.z += add[k]; t.w += add[k];
-        ((uint4*)f.cstart)[dst[k]] = t;
+    for (int q = 0; q < kKf; q++)
+#pragma unroll
+      for (int h = 0; h < kPer; h++)
+        if (dst[q][h] >= 0) {
+          const unsigned a = dst[q][h] < rec0 ? add[q] : 0u;
+          out[dst[q][h]] = make_uint4(v[q][h].x + a, v[q][h].y + a, v[q][h].z + a, v[q][h].w + a);
+        }
+    for (int i = ib; i < min(ib + kKf, i1); i++) {        // keyframes beyond 2 x 256 pieces (more than 383 cells): the rest
+      const char* blob = (const char*)f.tptr[i * kR3Ptrs + 5];
+      const int rel = f.koff[i] - k_lo, np = kCs + f.koff[i + 1] - f.koff[i];
+      for (int j = tid + kPer * kReg3Threads; j < np; j += kReg3Threads) {
+        const g_u32x4 t = gload<g_u32x4>(blob + (size_t)j * 16);
+        out[rec0 + rel + (j - kCs)] = make_uint4(t.x, t.y, t.z, t.w);      // (j >= 512 > kCs: records only)
       }
+    }
   }
   __syncthreads();
 }
