@@ -344,7 +344,35 @@ def loopclosure_run(D, n_cand, steps, warmup, graph=None):
         cdist.register_candidates_sharded(tiny_jobs, tfn)
     D.barrier()
     fixed_ms = D.max_over_ranks(time.perf_counter() - t2) / steps * 1e3
-    return {"fixed_cost_ms": fixed_ms, "kernel_ms": kernel_ms, "collective": "rccl all_gather" if D.dist else "none (no process group)",
+    # What a rank of an 8-GPU run does per step, measured HERE (no 8-GPU node needed to read a future SCALE record against it):
+    # the block of n / 8 candidates rank 0 would own, through the same code -- marshalling, upload, launch, the collective
+    # (one rank's worth; the 8-rank all_gather moves 8 x 36 KiB over xGMI, a few microseconds more), read-back.
+    proj = None
+    if D.world == 1 and n_cand >= 64:
+        per8 = (n_cand + 7) // 8
+        blk_jobs = jobs[:per8]
+        blk_prep = reg.PrepareBatch(blk_jobs)
+        bfn = lambda _local: reg.RegisterBatch(blk_prep)
+        bfn.into = lambda _local, ptr: reg.RegisterBatchInto(blk_prep, ptr)
+        bfn.ctx = ctx
+        for _ in range(3):
+            cdist.register_candidates_sharded(blk_jobs, bfn)
+        D.barrier()
+        ctx.profile_enable(True); ctx.profile_read(reset=True)
+        t3 = time.perf_counter()
+        for _ in range(steps):
+            cdist.register_candidates_sharded(blk_jobs, bfn)
+        D.barrier()
+        blk_ms = (time.perf_counter() - t3) / steps * 1e3
+        bprof = ctx.profile_read(reset=True); ctx.profile_enable(False)
+        blk_kernel_ms = sum(v[0] for v in bprof.values()) / max(steps, 1)
+        full_ms = elapsed / steps * 1e3
+        proj = {"ranks": 8, "candidates_per_rank": per8, "step_ms_per_rank_block": blk_ms, "kernel_ms_per_rank_block": blk_kernel_ms,
+                "step_ms_one_rank_all_candidates": full_ms, "projected_speedup_at_8": full_ms / blk_ms,
+                "projected_efficiency_at_8": full_ms / blk_ms / 8.0,
+                "note": "measured at N = 1: the step of one rank's block (n / 8 candidates) through the same path incl. a one-rank "
+                        "RCCL all_gather; an 8-rank step costs this plus the wider gather (8 x %d KiB over xGMI)" % (per8 * 72 // 1024)}
+    return {"fixed_cost_ms": fixed_ms, "kernel_ms": kernel_ms, "projected_strong_scaling": proj, "collective": "rccl all_gather" if D.dist else "none (no process group)",
             "distinct_scans": n_frames,"metric": "loop-closure candidate registrations/sec (cached features, P2L 4x10)",
             "value": n_cand * steps / elapsed, "unit": "registrations/s", "n_gpus": D.world, "steps": steps,
             "warmup": max(warmup, 1), "ms_per_step": elapsed / steps * 1e3, "ms_per_4096": elapsed / steps * 1e3 * 4096.0 / n_cand,
@@ -720,20 +748,30 @@ def main(argv=None):
                     "failed_registrations": bad, "kernel_breakdown": {k: v[0] / max(v[1], 1) for k, v in sp.items()},
                     "note": "%d worlds x a closed lap of %d sweeps (%d distinct frames), every stream walks its lap" % (Ss, Fs, Ss * Fs)}
         out["config2_mulran"] = side_config(api.odometry_preset("CFEAR-3", "mulran", submap_scan_size=5), 70000, 0.0595238, True, 1024, 32, 320)
-        c4 = side_config(
-            api.odometry_params(filter_type=1, cacfar_range_res=0.175, cacfar_z_min=20.0, cacfar_nb_guard_cells=10,
-                                cacfar_window_size=40, cacfar_false_alarm_rate=0.01, radar_ccw=1, kstrong_range_res=0.175),
-            80000, 0.175, False, 512, 32, 480)
-        # the CA-CFAR rows kernel reads only the bins its arithmetic can reach (400 m cap, radar_driver.cpp:54: bin 2286 + guard
+        # Kvarntorp / Volvo sweeps reach Process() through radarDriver::Callback's rotate(.., ROTATE_90_COUNTERCLOCKWISE)
+        # (radar_driver.cpp:74-90), i.e. they ARRIVE [range bins][azimuths]: that is the layout timed here (the decode fused into
+        # the filter: cacfar_cols); the same run on pre-rotated sweeps -- work skipped -- is kept beside it as `prerotated_value`
+        c4_par = api.odometry_params(filter_type=1, cacfar_range_res=0.175, cacfar_z_min=20.0, cacfar_nb_guard_cells=10,
+                                     cacfar_window_size=40, cacfar_false_alarm_rate=0.01, radar_ccw=1, kstrong_range_res=0.175,
+                                     rotate_ccw=1)
+        c4 = side_config(c4_par, 80000, 0.175, True, 512, 32, 480)
+        c4_pre = side_config(api.odometry_params(filter_type=1, cacfar_range_res=0.175, cacfar_z_min=20.0, cacfar_nb_guard_cells=10,
+                                                 cacfar_window_size=40, cacfar_false_alarm_rate=0.01, radar_ccw=1,
+                                                 kstrong_range_res=0.175), 80000, 0.175, False, 512, 32, 160)
+        c4["input_layout"] = "[range bins][azimuths] (radar_driver.cpp:74-90): decode fused into the CA-CFAR sweep"
+        c4["prerotated_value"] = c4_pre["value"]
+        c4["prerotated_kernel_breakdown"] = c4_pre["kernel_breakdown"]
+        # the CA-CFAR kernels read only the bins their arithmetic can reach (400 m cap, radar_driver.cpp:54: bin 2286 + guard
         # + window of 3360); both the R*C figure and the bytes really requested are given
-        cr_ms = c4["kernel_breakdown"].get("cacfar_rows", 0.0)
-        if cr_ms > 0:
-            need_cols = min(COLS, (int(np.ceil(400.0 / 0.175)) + 10 + 40 + 15) // 16 * 16)
-            c4["roofline_cacfar_rows"] = {"bound": "hbm", "avg_launch_ms": cr_ms, "scans_per_launch": 512,
-                                          "achieved": IMG * 512 / (cr_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                          "frac": IMG * 512 / (cr_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                          "bytes_requested_per_scan": ROWS * need_cols,
-                                          "frac_of_bytes_requested": ROWS * need_cols * 512 / (cr_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+        need_cols = min(COLS, (int(np.ceil(400.0 / 0.175)) + 10 + 40 + 15) // 16 * 16)
+        for kname, brk in (("cacfar_cols", c4["kernel_breakdown"]), ("cacfar_rows", c4_pre["kernel_breakdown"])):
+            cr_ms = brk.get(kname, 0.0)
+            if cr_ms > 0:
+                c4["roofline_" + kname] = {"bound": "hbm", "avg_launch_ms": cr_ms, "scans_per_launch": 512,
+                                           "achieved": IMG * 512 / (cr_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                           "frac": IMG * 512 / (cr_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                           "bytes_requested_per_scan": ROWS * need_cols,
+                                           "frac_of_bytes_requested": ROWS * need_cols * 512 / (cr_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
         c4["failed_registrations_note"] = ("status CFEAR_ERR_TOO_FEW_RESIDUALS (n_scan_normal.cpp:368-369) on the streams of the "
                                            "feature-poor synthetic worlds (e.g. seed 80002: 16-47 surface points per sweep); the CPU "
                                            "oracle fails on the same (world, frame) steps -- tools/cfar_failed.py, "
@@ -742,7 +780,7 @@ def main(argv=None):
         # ---- loop-closure candidates from cached features (configs[3]) ---------------------------------------
         lc = loopclosure_run(D, args.candidates, 20, 3)
         out["loopclosure"] = {k: lc[k] for k in ("value", "unit", "ms_per_step", "ms_per_4096", "ok_fraction", "mean_outer_iters",
-                                                 "fixed_cost_ms", "kernel_ms", "collective", "distinct_scans")}
+                                                 "fixed_cost_ms", "kernel_ms", "collective", "distinct_scans", "projected_strong_scaling")}
         out["loopclosure"]["candidates"] = args.candidates
 
     # ---- CPU baseline: the oracle (port), 1 thread, bounded sample of the same frames -----------------

@@ -154,7 +154,11 @@ struct cfear_cacfar_fused {
   uint32_t* row_keys = nullptr;
   int32_t* row_cnt = nullptr;
   int kcap = 0;
+  // desc describes [range bins][azimuths] SOURCE images (rows = bins, cols = azimuths): the decode is fused into the filter
+  // (cacfar_cols_kernel); only where cfear_cacfar_cols_supported() says so
+  bool bins_major = false;
 };
+bool cfear_cacfar_cols_supported(const uint8_t* d_src, const cfear_polar_desc* sd, const cfear_cacfar_params* par);
 int cfear_cacfar_device(cfear_ctx* ctx, const uint8_t* d_polar, const cfear_polar_desc* desc,
                         const cfear_cacfar_params* par, float* d_xyzi, int32_t* d_n_points,
                         int32_t cap_points, uint8_t* d_det_mask, const cfear_cacfar_fused* fused = nullptr);

@@ -1083,6 +1083,7 @@ struct CfarArgs {
   uint32_t* row_keys;
   int32_t* row_cnt;
   int kcap;
+  int list_cap;                   // entries of a wavefront's candidate list (cacfar_cols_kernel: shorter than a chunk)
   int thr_i, bin_lo, bin_hi;      // candidate pre-test in integers: intensity >= thr_i, bin_lo <= bin < bin_hi
   int need_cols;                  // bins a row's arithmetic can touch: min(cols, bin_hi - 1 + guard + window), in 16s
   int colsp;                      // need_cols in whole 1024-bin chunks: the row's length in LDS
@@ -1136,59 +1137,16 @@ __host__ __device__ inline size_t cfar_wave_lds(int colsp, int pad_lo, int pad_h
 // 1024, of which the third held 18 busy lanes and cost 18 % of the kernel.
 // DL = dwords per lane of the LAST chunk (DL <= D; DL < D only with exactly NCH chunks): 2336 reachable bins are a chunk
 // of 1536 (D = 6) and one of 1024 (DL = 4) -- ten dwords per lane and row instead of twelve.
-template <int D, int NCH, int DL, bool KEYS, bool PRE>
-__global__ __launch_bounds__(256) void cacfar_rows_kernel(const CfarArgs a) {
-  constexpr int CB = 256 * D;                                                // bins per chunk (all but a shorter last one)
-  auto DJ = [](int j) { return (DL != D && j == NCH - 1) ? DL : D; };        // dwords per lane of chunk j (folds after unrolling)
-  typedef uint32_t u32x2 __attribute__((ext_vector_type(2), aligned(4)));
-  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  uint32_t* lut = (uint32_t*)smem;
-  lut[threadIdx.x] = a.lut[threadIdx.x];
-  __syncthreads();
+// One row of CA-CFAR on one wavefront (steps A .. D of cacfar_rows_kernel's comment): the row's bytes are in `cur` (lane l
+// owns the dwords [j CB + l 4 D_j ..) of chunk j) and -- STAGED -- already in LDS at `raw` (the reachable a.need_cols bytes + 16 zeros).
+// grow = the row's index in the OUTPUT (image * rows + azimuth); key_base = grow * kcap.
+template <int D, int NCH, int DL, bool KEYS, bool PRE, bool STAGED, typename AfterSwar>
+__device__ __forceinline__ void cfar_row(const CfarArgs& a, const int lane, const uint32_t* lut, uint32_t* P4, uint8_t* raw, uint32_t* det32,
+                                         unsigned short* list, uint32_t (&cur)[NCH][D], const int nch, const long long grow,
+                                         const long long key_base, AfterSwar&& after_swar) {
+  constexpr int CB = 256 * D;
+  auto DJ = [](int j) { return (DL != D && j == NCH - 1) ? DL : D; };
   const int colsp = a.colsp;
-  uint8_t* wbase = smem + 1024 + (size_t)wave * cfar_wave_lds(colsp, a.pad_lo, a.pad_hi, KEYS, CB);   // (the list holds a full chunk)
-  uint32_t* P4 = (uint32_t*)wbase + a.pad_lo;                                // P4[i] = sum_{q < 4 i} I_q^2, i in [-pad_lo, colsp / 4 + pad_hi]
-  uint8_t* raw = wbase + (((size_t)(a.pad_lo + colsp / 4 + 1 + a.pad_hi) * 4 + 15) & ~(size_t)15);   // the row itself
-  uint32_t* det32 = (uint32_t*)(raw + colsp + 16);                           // detections, bit per bin (bitmap output)
-  unsigned short* list = (unsigned short*)(raw + colsp + 16 + (KEYS ? 0 : colsp / 8));
-  for (int i = lane; i < a.pad_lo; i += 64) P4[-1 - i] = 0u;
-  const int nch = DL != D ? NCH : colsp / CB;
-  const long long step = (long long)gridDim.x * kRowsPerBlock;
-  long long grow = (long long)blockIdx.x * kRowsPerBlock + wave;
-  // (image, row) of the current and of the next row walk along with grow: no 64-bit division per row
-  const int step_b = (int)(step / a.rows), step_r = (int)(step - (long long)step_b * a.rows);
-  int cb = (int)(grow / a.rows), cr = (int)(grow - (long long)cb * a.rows);
-  auto row_ptr = [&](int b, int r) -> const uint8_t* { return a.polar + (long long)b * a.batch_stride + (long long)r * a.stride; };
-  // rows that cannot be read in aligned 16-byte pieces (odd strides, cols not a multiple of 16) are copied into LDS byte by
-  // byte first, zero-padded, and take their pieces from there (no prefetch)
-  auto is_direct = [&](const uint8_t* p) -> bool { return (((uintptr_t)p) & 15) == 0 && (a.cols & 15) == 0; };
-  // a lane's LB bytes of a chunk: 16-byte pieces where LB is a multiple of 16 (D = 4, 8), 8-byte pieces otherwise (D = 6:
-  // 24 lane is only 8-byte aligned, and ds_write_b128 wants 16)
-  auto issue = [&](const uint8_t* p, uint32_t (&dst)[NCH][D]) {
-#pragma unroll
-    for (int j = 0; j < NCH; j++) {
-      const int dj = DJ(j);
-      const int pos = j * CB + lane * 4 * dj;
-      // (no zeroing here: the registers of the lanes beyond need_cols are zeroed ONCE before the row loop; the masked loads
-      //  never write them, and the copies below move zeros)
-      if (dj % 4 == 0) {
-#pragma unroll
-        for (int k = 0; k < D / 4; k++)
-          if (4 * k < dj && pos + 16 * k < a.need_cols) {
-            const u32x4 v = __builtin_nontemporal_load((const u32x4*)(p + pos + 16 * k));
-            dst[j][4 * k] = v.x; dst[j][4 * k + 1] = v.y; dst[j][4 * k + 2] = v.z; dst[j][4 * k + 3] = v.w;
-          }
-      } else {
-#pragma unroll
-        for (int k = 0; k < D / 2; k++)
-          if (2 * k < dj && pos + 8 * k < a.need_cols) {
-            const u32x2 v = __builtin_nontemporal_load((const u32x2*)(p + pos + 8 * k));
-            dst[j][2 * k] = v.x; dst[j][2 * k + 1] = v.y;
-          }
-      }
-    }
-  };
   auto lds_put = [&](void* at, const uint32_t (&v)[D], int dj) {               // the first dj dwords of v
     if (dj % 4 == 0) {
 #pragma unroll
@@ -1219,43 +1177,7 @@ __global__ __launch_bounds__(256) void cacfar_rows_kernel(const CfarArgs a) {
 #define CFAR_T0()
 #define CFAR_T(k)
 #endif
-  uint32_t cur[NCH][D], nxt[NCH][D];
-#pragma unroll
-  for (int j = 0; j < NCH; j++)
-#pragma unroll
-    for (int d = 0; d < D; d++) { cur[j][d] = 0u; nxt[j][d] = 0u; }
-  if (grow < a.total_rows) { const uint8_t* p0 = row_ptr(cb, cr); if (is_direct(p0)) issue(p0, cur); }
-  // the first row's pieces are waited for HERE, so that inside the loop `cur` only ever comes from register copies: the
-  // compiler cannot count conditional loads and would otherwise wait for vmcnt(0) -- the NEXT row's requests -- at the
-  // first use of `cur` in every iteration
-  __builtin_amdgcn_s_waitcnt(0);
-  const uint8_t* rowp = row_ptr(cb, cr);
-  long long key_base = grow * (long long)a.kcap;
-  const long long key_step = step * (long long)a.kcap;
-  for (; grow < a.total_rows; grow += step, key_base += key_step) {
-    CFAR_T0();
-    cb += step_b; cr += step_r;
-    if (cr >= a.rows) { cr -= a.rows; cb++; }
-    if (!is_direct(rowp)) {
-      for (int pos = lane * 16; pos < colsp; pos += 1024) {
-        uint32_t w[4] = {0u, 0u, 0u, 0u};
-        for (int q = pos; q < min(pos + 16, a.cols); q++) w[(q - pos) >> 2] |= (uint32_t)rowp[q] << (8 * (q & 3));
-        *(uint4*)(raw + pos) = make_uint4(w[0], w[1], w[2], w[3]);
-      }
-      wave_sync();
-#pragma unroll
-      for (int j = 0; j < NCH; j++) {
-        const int dj = DJ(j);
-        const int pos = j * CB + lane * 4 * dj;
-#pragma unroll
-        for (int d = 0; d < D; d++) cur[j][d] = (d < dj && pos < colsp) ? *(const uint32_t*)(raw + pos + 4 * d) : 0u;
-      }
-    }
-    const bool have_next = grow + step < a.total_rows;
-    const uint8_t* nextp = have_next ? row_ptr(cb, cr) : rowp;
-    const bool next_direct = have_next && is_direct(nextp);
-    if (next_direct) issue(nextp, nxt);
-    rowp = nextp;                                                           // (this row is in registers / LDS from here on)
+  CFAR_T0();
     // ---- A: bytes + prefix sums of squares -> LDS ---------------------------------------------------------------
     uint32_t run = 0;
 #pragma unroll
@@ -1263,7 +1185,7 @@ __global__ __launch_bounds__(256) void cacfar_rows_kernel(const CfarArgs a) {
       if (j >= nch) break;
       const int dj = DJ(j);
       const int pos = j * CB + lane * 4 * dj;
-      lds_put(raw + pos, cur[j], dj);
+      if (!STAGED) lds_put(raw + pos, cur[j], dj);                            // (a staged row already sits there)
       uint32_t pre[D];                                                      // sums of squares before each of the lane's quads
       uint32_t acc = 0;
 #pragma unroll
@@ -1380,52 +1302,54 @@ __global__ __launch_bounds__(256) void cacfar_rows_kernel(const CfarArgs a) {
       cm[j] = cmask;
     }
     CFAR_T(1);
-    // The row's bytes are dead from here on (the rounds work from LDS): the NEXT row's pieces move into `cur` now, so that
-    // the wait for them does not sit behind this row's key stores (vmcnt counts stores too: at the end of the row the copy
-    // waited for the stores of the last round every time).
-    if (next_direct) {
-#pragma unroll
-      for (int j = 0; j < NCH; j++)
-#pragma unroll
-        for (int d = 0; d < D; d++) cur[j][d] = nxt[j][d];
-    }
+    after_swar();                                                           // (the rows kernel moves the NEXT row's pieces into `cur` here)
 #pragma unroll
     for (int j = 0; j < NCH; j++) {
       if (j >= cj_hi) break;
       if (j < cj_lo) continue;
       const int pos = j * CB + lane * 4 * DJ(j);
-      // the chunk's candidates -> list, behind the carried remainder, in bin order (lane, bit)
-      {
-        uint32_t m = cm[j];
-        const int pc = __popc(m);
-        const int incl = wave_incl_scan_i32(pc);
-        int off = C + incl - pc;
-        while (m) {
-          list[off++] = (unsigned short)(pos + __ffs((int)m) - 1);
-          m &= m - 1u;
+      // the chunk's candidates -> list, behind the carried remainder, in bin order (lane, bit).  STAGED (cacfar_cols_kernel): the
+      // list is shorter than a chunk + the carry, so that eight wavefronts share a CU's LDS with two 16-row tiles; a chunk whose
+      // candidates would not fit goes in two halves of 32 lanes (<= 1024 bins + 63 carried <= kCfarColsList; the pre-filter
+      // leaves ~100 candidates per row, so this is the exception)
+      uint32_t m = cm[j];
+      const int pc = __popc(m);
+      const int incl = wave_incl_scan_i32(pc);
+      const int tot = __builtin_amdgcn_readlane(incl, 63);
+      const int low = STAGED ? __builtin_amdgcn_readlane(incl, 31) : 0;     // candidates of lanes 0 .. 31
+      const int halves = (STAGED && C + tot > a.list_cap) ? 2 : 1;
+      for (int hh = 0; hh < halves; hh++) {
+        {
+          const bool mine = halves == 1 || (lane >> 5) == hh;
+          int off = C + incl - pc - (hh == 1 ? low : 0);
+          if (mine)
+            while (m) {
+              list[off++] = (unsigned short)(pos + __ffs((int)m) - 1);
+              m &= m - 1u;
+            }
+          C += halves == 1 ? tot : (hh == 0 ? low : tot - low);
         }
-        C += __builtin_amdgcn_readlane(incl, 63);
-      }
-      wave_sync();
-      CFAR_T(2);
+        wave_sync();
+        CFAR_T(2);
 #ifdef CFEAR_CFAR_TIMING
-      ctot += C;
+        ctot += C;
 #endif
-      int k0 = 0;
-      for (; k0 + 64 <= C; k0 += 64) round(k0, 64);
-      if (k0 > 0) {                                                         // carry the remainder (< 64) to the front
-        const int rem = C - k0;
-        wave_sync();
-        const unsigned short tmp = lane < rem ? list[k0 + lane] : (unsigned short)0;
-        wave_sync();
-        if (lane < rem) list[lane] = tmp;
-        C = rem;
-        wave_sync();
-      }
+        int k0 = 0;
+        for (; k0 + 64 <= C; k0 += 64) round(k0, 64);
+        if (k0 > 0) {                                                       // carry the remainder (< 64) to the front
+          const int rem = C - k0;
+          wave_sync();
+          const unsigned short tmp = lane < rem ? list[k0 + lane] : (unsigned short)0;
+          wave_sync();
+          if (lane < rem) list[lane] = tmp;
+          C = rem;
+          wave_sync();
+        }
 #ifdef CFEAR_CFAR_TIMING
-      ctot -= C;
+        ctot -= C;
 #endif
-      CFAR_T(3);
+        CFAR_T(3);
+      }
     }
     if (C > 0) round(0, C);
     CFAR_T(3);
@@ -1454,9 +1378,220 @@ __global__ __launch_bounds__(256) void cacfar_rows_kernel(const CfarArgs a) {
     if (lane == 0 && (grow % 20011) == 0)
       printf("cfar row %lld: prefix %lld | thresholds+swar %lld | list %lld | rounds %lld (%d rounds, %d candidates) | write %lld\n", grow,
              tq[0], tq[1], tq[2], tq[3], nrounds, ctot, tq[4]);
-    for (int k = 0; k < 6; k++) tq[k] = 0;
-    ctot = 0; nrounds = 0;
 #endif
+}
+
+template <int D, int NCH, int DL, bool KEYS, bool PRE>
+__global__ __launch_bounds__(256) void cacfar_rows_kernel(const CfarArgs a) {
+  constexpr int CB = 256 * D;                                                // bins per chunk (all but a shorter last one)
+  auto DJ = [](int j) { return (DL != D && j == NCH - 1) ? DL : D; };        // dwords per lane of chunk j (folds after unrolling)
+  typedef uint32_t u32x2 __attribute__((ext_vector_type(2), aligned(4)));
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  uint32_t* lut = (uint32_t*)smem;
+  lut[threadIdx.x] = a.lut[threadIdx.x];
+  __syncthreads();
+  const int colsp = a.colsp;
+  uint8_t* wbase = smem + 1024 + (size_t)wave * cfar_wave_lds(colsp, a.pad_lo, a.pad_hi, KEYS, CB);   // (the list holds a full chunk)
+  uint32_t* P4 = (uint32_t*)wbase + a.pad_lo;                                // P4[i] = sum_{q < 4 i} I_q^2, i in [-pad_lo, colsp / 4 + pad_hi]
+  uint8_t* raw = wbase + (((size_t)(a.pad_lo + colsp / 4 + 1 + a.pad_hi) * 4 + 15) & ~(size_t)15);   // the row itself
+  uint32_t* det32 = (uint32_t*)(raw + colsp + 16);                           // detections, bit per bin (bitmap output)
+  unsigned short* list = (unsigned short*)(raw + colsp + 16 + (KEYS ? 0 : colsp / 8));
+  for (int i = lane; i < a.pad_lo; i += 64) P4[-1 - i] = 0u;
+  const int nch = DL != D ? NCH : colsp / CB;
+  const long long step = (long long)gridDim.x * kRowsPerBlock;
+  long long grow = (long long)blockIdx.x * kRowsPerBlock + wave;
+  // (image, row) of the current and of the next row walk along with grow: no 64-bit division per row
+  const int step_b = (int)(step / a.rows), step_r = (int)(step - (long long)step_b * a.rows);
+  int cb = (int)(grow / a.rows), cr = (int)(grow - (long long)cb * a.rows);
+  auto row_ptr = [&](int b, int r) -> const uint8_t* { return a.polar + (long long)b * a.batch_stride + (long long)r * a.stride; };
+  // rows that cannot be read in aligned 16-byte pieces (odd strides, cols not a multiple of 16) are copied into LDS byte by
+  // byte first, zero-padded, and take their pieces from there (no prefetch)
+  auto is_direct = [&](const uint8_t* p) -> bool { return (((uintptr_t)p) & 15) == 0 && (a.cols & 15) == 0; };
+  // a lane's LB bytes of a chunk: 16-byte pieces where LB is a multiple of 16 (D = 4, 8), 8-byte pieces otherwise (D = 6:
+  // 24 lane is only 8-byte aligned, and ds_write_b128 wants 16)
+  auto issue = [&](const uint8_t* p, uint32_t (&dst)[NCH][D]) {
+#pragma unroll
+    for (int j = 0; j < NCH; j++) {
+      const int dj = DJ(j);
+      const int pos = j * CB + lane * 4 * dj;
+      // (no zeroing here: the registers of the lanes beyond need_cols are zeroed ONCE before the row loop; the masked loads
+      //  never write them, and the copies below move zeros)
+      if (dj % 4 == 0) {
+#pragma unroll
+        for (int k = 0; k < D / 4; k++)
+          if (4 * k < dj && pos + 16 * k < a.need_cols) {
+            const u32x4 v = __builtin_nontemporal_load((const u32x4*)(p + pos + 16 * k));
+            dst[j][4 * k] = v.x; dst[j][4 * k + 1] = v.y; dst[j][4 * k + 2] = v.z; dst[j][4 * k + 3] = v.w;
+          }
+      } else {
+#pragma unroll
+        for (int k = 0; k < D / 2; k++)
+          if (2 * k < dj && pos + 8 * k < a.need_cols) {
+            const u32x2 v = __builtin_nontemporal_load((const u32x2*)(p + pos + 8 * k));
+            dst[j][2 * k] = v.x; dst[j][2 * k + 1] = v.y;
+          }
+      }
+    }
+  };
+  auto wave_sync = [&]() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
+  };
+  uint32_t cur[NCH][D], nxt[NCH][D];
+#pragma unroll
+  for (int j = 0; j < NCH; j++)
+#pragma unroll
+    for (int d = 0; d < D; d++) { cur[j][d] = 0u; nxt[j][d] = 0u; }
+  if (grow < a.total_rows) { const uint8_t* p0 = row_ptr(cb, cr); if (is_direct(p0)) issue(p0, cur); }
+  // the first row's pieces are waited for HERE, so that inside the loop `cur` only ever comes from register copies: the
+  // compiler cannot count conditional loads and would otherwise wait for vmcnt(0) -- the NEXT row's requests -- at the
+  // first use of `cur` in every iteration
+  __builtin_amdgcn_s_waitcnt(0);
+  const uint8_t* rowp = row_ptr(cb, cr);
+  long long key_base = grow * (long long)a.kcap;
+  const long long key_step = step * (long long)a.kcap;
+  for (; grow < a.total_rows; grow += step, key_base += key_step) {
+    cb += step_b; cr += step_r;
+    if (cr >= a.rows) { cr -= a.rows; cb++; }
+    if (!is_direct(rowp)) {
+      for (int pos = lane * 16; pos < colsp; pos += 1024) {
+        uint32_t w[4] = {0u, 0u, 0u, 0u};
+        for (int q = pos; q < min(pos + 16, a.cols); q++) w[(q - pos) >> 2] |= (uint32_t)rowp[q] << (8 * (q & 3));
+        *(uint4*)(raw + pos) = make_uint4(w[0], w[1], w[2], w[3]);
+      }
+      wave_sync();
+#pragma unroll
+      for (int j = 0; j < NCH; j++) {
+        const int dj = DJ(j);
+        const int pos = j * CB + lane * 4 * dj;
+#pragma unroll
+        for (int d = 0; d < D; d++) cur[j][d] = (d < dj && pos < colsp) ? *(const uint32_t*)(raw + pos + 4 * d) : 0u;
+      }
+    }
+    const bool have_next = grow + step < a.total_rows;
+    const uint8_t* nextp = have_next ? row_ptr(cb, cr) : rowp;
+    const bool next_direct = have_next && is_direct(nextp);
+    if (next_direct) issue(nextp, nxt);
+    rowp = nextp;                                                           // (this row is in registers / LDS from here on)
+    cfar_row<D, NCH, DL, KEYS, PRE, false>(a, lane, lut, P4, raw, det32, list, cur, nch, grow, key_base, [&]() {
+      // The row's bytes are dead from here on (the rounds work from LDS): the NEXT row's pieces move into `cur` now, so that
+      // the wait for them does not sit behind this row's key stores (vmcnt counts stores too: at the end of the row the copy
+      // waited for the stores of the last round every time).
+      if (next_direct) {
+#pragma unroll
+        for (int j = 0; j < NCH; j++)
+#pragma unroll
+          for (int d = 0; d < D; d++) cur[j][d] = nxt[j][d];
+      }
+    });
+  }
+}
+
+// CA-CFAR on [range bins][azimuths] sweeps (the layout the non-Oxford drivers deliver, radar_driver.cpp:74-90): the decode
+// (cv::rotate 90 deg counter-clockwise) fused into the filter -- ONE pass over the image instead of rotate (read + write)
+// + cacfar_rows (read).  A workgroup takes a tile of 16 azimuths: the 16-byte pieces of the bins the arithmetic can reach
+// (a.need_cols source rows) are transposed into LDS with v_perm_b32 on 4 x 4 byte blocks, the next tile's pieces are
+// requested, and each wavefront runs cfar_row on four of the tile's rows straight from LDS.  Output row r holds source
+// column a.rows - 1 - r.  a.rows / a.cols are the ROTATED image's (azimuths, bins); a.stride / a.batch_stride the SOURCE's.
+// Key output only (the batched odometry).  Tiles of one image run on one XCD (blockIdx % 8): the eight tiles that share a
+// 128-byte line of a source row meet in that XCD's L2.
+constexpr int kCfarTile = 16;
+constexpr int kCfarColsWaves = 8;             // 2 workgroups x 8 wavefronts per CU: two rows of a tile per wavefront, four wavefronts per
+                                              // SIMD like cacfar_rows_kernel (4 x 4 rows: 0.364 ms per 512 sweeps, 6 x 3|2: 0.338)
+constexpr int kCfarColsList = 1152;           // list entries per wavefront (cfar_row's STAGED append)
+__host__ __device__ inline int cfar_cols_list_cap(int chunk_bins) { return chunk_bins + kCfarListSlack < kCfarColsList ? chunk_bins + kCfarListSlack : kCfarColsList; }
+__host__ __device__ inline size_t cfar_cols_wave_lds(int colsp, int pad_lo, int pad_hi, int chunk_bins) {
+  // P4 + list: the row lives in the tile
+  return (((size_t)(pad_lo + colsp / 4 + 1 + pad_hi) * 4 + 15) & ~(size_t)15) + (((size_t)cfar_cols_list_cap(chunk_bins) * 2 + 15) & ~(size_t)15);
+}
+template <int D, int NCH, int DL, bool PRE>
+__global__ __launch_bounds__(64 * kCfarColsWaves, 4) void cacfar_cols_kernel(const CfarArgs a, const int tiles) {
+  constexpr int CB = 256 * D;
+  auto DJ = [](int j) { return (DL != D && j == NCH - 1) ? DL : D; };
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  uint32_t* lut = (uint32_t*)smem;
+  lut[threadIdx.x] = a.lut[threadIdx.x];
+  const int colsp = a.colsp, tstride = a.need_cols + 16;      // (the arithmetic never reads a row beyond need_cols: cfar_derive)
+  uint8_t* tbase = smem + 1024;                               // [kCfarTile][tstride]: row lr = source column c0 + 15 - lr
+  uint8_t* wbase = tbase + (((size_t)kCfarTile * tstride + 15) & ~(size_t)15) + (size_t)wave * cfar_cols_wave_lds(colsp, a.pad_lo, a.pad_hi, CB);
+  uint32_t* P4 = (uint32_t*)wbase + a.pad_lo;
+  unsigned short* list = (unsigned short*)(wbase + (((size_t)(a.pad_lo + colsp / 4 + 1 + a.pad_hi) * 4 + 15) & ~(size_t)15));
+  for (int i = lane; i < a.pad_lo; i += 64) P4[-1 - i] = 0u;
+  for (int i = threadIdx.x; i < kCfarTile * 4; i += 64 * kCfarColsWaves)     // the 16 bytes of padding behind every tile row
+    *(uint32_t*)(tbase + (size_t)(i >> 2) * tstride + a.need_cols + 4 * (i & 3)) = 0u;
+  const int nch = DL != D ? NCH : colsp / CB;
+  const int xcd = blockIdx.x % kXcds, slot = blockIdx.x / kXcds, slots = gridDim.x / kXcds;
+  const int nq = ((a.batch - xcd + kXcds - 1) / kXcds) * tiles;               // (image, tile) items of this workgroup's XCD
+  auto locate = [&](const int q, int& b, int& tile) { const int im = q / tiles; b = im * kXcds + xcd; tile = q - im * tiles; };
+  constexpr int GP = (NCH * CB / 4 + 64 * kCfarColsWaves - 1) / (64 * kCfarColsWaves);   // groups of 4 bins per thread (upper bound)
+  const int need_groups = a.need_cols >> 2;
+  uint32_t rw[GP][4][4];
+  auto issue = [&](const int q) {                             // the pieces of item q: bins 4 g .. 4 g + 3, 16 source columns
+    int b, tile;
+    locate(q, b, tile);
+    const uint8_t* src = a.polar + (long long)b * a.batch_stride + tile * kCfarTile;
+#pragma unroll
+    for (int p = 0; p < GP; p++) {
+      const int g = (int)threadIdx.x + p * 64 * kCfarColsWaves;
+      if (g < need_groups) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+          const u32x4 v = *(const u32x4*)(src + (size_t)(4 * g + i) * a.stride);
+          rw[p][i][0] = v.x; rw[p][i][1] = v.y; rw[p][i][2] = v.z; rw[p][i][3] = v.w;
+        }
+      }
+    }
+  };
+#pragma unroll
+  for (int p = 0; p < GP; p++)
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+      for (int d = 0; d < 4; d++) rw[p][i][d] = 0u;            // groups beyond need_cols stay zero
+  int q = slot;
+  if (q < nq) issue(q);
+  while (q < nq) {
+#pragma unroll
+    for (int p = 0; p < GP; p++) {
+      const int g = (int)threadIdx.x + p * 64 * kCfarColsWaves;
+      if (g < need_groups) {
+#pragma unroll
+        for (int d = 0; d < 4; d++) {                         // source columns c0 + 4 d .. + 3 of bins 4 g .. 4 g + 3
+          const uint32_t w0 = rw[p][0][d], w1 = rw[p][1][d], w2 = rw[p][2][d], w3 = rw[p][3][d];
+          const uint32_t t0 = __builtin_amdgcn_perm(w1, w0, 0x05010400u), t1 = __builtin_amdgcn_perm(w1, w0, 0x07030602u);
+          const uint32_t t2 = __builtin_amdgcn_perm(w3, w2, 0x05010400u), t3 = __builtin_amdgcn_perm(w3, w2, 0x07030602u);
+          uint32_t colw[4];                                   // colw[e] = column c0 + 4 d + e as {bin 4g, +1, +2, +3}
+          colw[0] = __builtin_amdgcn_perm(t2, t0, 0x05040100u); colw[1] = __builtin_amdgcn_perm(t2, t0, 0x07060302u);
+          colw[2] = __builtin_amdgcn_perm(t3, t1, 0x05040100u); colw[3] = __builtin_amdgcn_perm(t3, t1, 0x07060302u);
+#pragma unroll
+          for (int e = 0; e < 4; e++) *(uint32_t*)(tbase + (size_t)(kCfarTile - 1 - (4 * d + e)) * tstride + 4 * g) = colw[e];
+        }
+      }
+    }
+    __syncthreads();
+    int b, tile;
+    locate(q, b, tile);
+    const int qn = q + slots;
+    if (qn < nq) issue(qn);
+    const int r0 = a.rows - kCfarTile - tile * kCfarTile;     // output row of tile row 0
+    for (int lr = wave; lr < kCfarTile; lr += kCfarColsWaves) {
+      uint8_t* raw = tbase + (size_t)lr * tstride;
+      uint32_t cur[NCH][D];
+#pragma unroll
+      for (int j = 0; j < NCH; j++) {
+        const int dj = DJ(j);
+        const int pos = j * CB + lane * 4 * dj;
+#pragma unroll
+        for (int d = 0; d < D; d++) cur[j][d] = (d < dj && j < nch && pos + 4 * d < a.need_cols) ? *(const uint32_t*)(raw + pos + 4 * d) : 0u;
+      }
+      const long long grow = (long long)b * a.rows + (r0 + lr);
+      cfar_row<D, NCH, DL, true, PRE, true>(a, lane, lut, P4, raw, nullptr, list, cur, nch, grow, grow * (long long)a.kcap, []() {});
+    }
+    __syncthreads();                                          // every row of the tile has been consumed
+    q = qn;
   }
 }
 
@@ -2107,19 +2242,10 @@ extern "C" int cfear_filter_kstrongest_legacy(cfear_ctx* ctx, const uint8_t* pol
   return CFEAR_OK;
 }
 
-// Device-side CA-CFAR entry (also used by the odometry pipeline).  With `fused` the rows kernel leaves per-row key lists for
-// surface_prep_kernel (cfear_cacfar_fused, common.hpp) and no cloud is built here.
-int cfear_cacfar_device(cfear_ctx* ctx, const uint8_t* d_polar, const cfear_polar_desc* desc,
-                        const cfear_cacfar_params* par, float* d_xyzi, int32_t* d_n_points,
-                        int32_t cap_points, uint8_t* d_det_mask, const cfear_cacfar_fused* fused) {
-  const int rows = desc->rows, cols = desc->cols, batch = desc->batch;
-  const int words = (cols + 63) / 64;
-  const bool keys = fused && fused->row_keys;
-  CfarArgs a;
-  memset(&a, 0, sizeof(a));
-  a.polar = d_polar; a.rows = rows; a.cols = cols; a.stride = desc->stride; a.batch = batch;
-  a.batch_stride = batch > 1 ? desc->batch_stride : (int64_t)rows * desc->stride;
-  a.total_rows = (long long)batch * rows;
+// The kernel arguments that follow from the filter's parameters alone (rows = azimuths, cols = bins of the ROTATED image);
+// D / DL / nch = the chunk geometry (cacfar_rows_kernel's template arguments).
+static void cfar_derive(CfarArgs& a, const cfear_cacfar_params* par, int rows, int cols, int& D, int& DL, int& nch) {
+  a.rows = rows; a.cols = cols;
   a.window = par->window_size; a.guard = par->nb_guard_cells;
   const double false_alarm_rate_ = (double)par->false_alarm_rate;
   const double N = par->window_size * 2;                                     // cfar.cpp:32
@@ -2128,16 +2254,6 @@ int cfear_cacfar_device(cfear_ctx* ctx, const uint8_t* d_polar, const cfear_pola
   a.static_threshold = (double)par->z_min;
   a.min_distance = (double)par->min_distance;
   a.max_distance = par->max_distance;
-  a.words = words;
-  if (keys) {
-    a.row_keys = fused->row_keys; a.row_cnt = fused->row_cnt; a.kcap = fused->kcap;
-  } else {
-    size_t bits_bytes = (size_t)batch * rows * words * 8, cnt_bytes = (size_t)batch * rows * 4;
-    char* ws = (char*)cfear_workspace(ctx, 3, bits_bytes + cnt_bytes + 256);
-    if (!ws) return cfear_set_error(ctx, CFEAR_ERR_HIP, "workspace allocation failed");
-    a.det_bits = (unsigned long long*)ws;
-    a.det_count = (int32_t*)(ws + (bits_bytes + 255) / 256 * 256);
-  }
   {
     // the candidate pre-test in integers.  intensity > static_threshold for integer intensities: the smallest passing value;
     // range > min_distance && range < max_distance (cfar.cpp:43-45, range = range_res * bin in double): the bin interval,
@@ -2166,24 +2282,98 @@ int cfear_cacfar_device(cfear_ctx* ctx, const uint8_t* d_polar, const cfear_pola
     a.pad_hi = a.pre_on ? std::max(0, a.pb1) + 2 : 0;
     a.kappa_lb = (float)(a.scaling / (2.0 * (double)a.window) * (1.0 - 3e-5));
   }
-  {
-    // chunk geometry: D dwords per lane and chunk.  Per-chunk overhead ~ 60 wave instructions, per dword of a lane ~ 25:
-    // the D in {4, 6, 8} with the cheapest cover of the reachable bins (without the pre-filter only D = 4 is built)
-    const bool pre = a.pre_on != 0;
-    int D = 4, DL = 4, nch = std::max(1, (a.need_cols + 1023) / 1024);
-    if (pre) {
-      // measured on the Kvarntorp rows: ~10 us per chunk and ~9 us per dword of a lane (per 204 800 rows)
-      auto cost = [](int n, int d, int dl) { return (long long)n * 10 + (long long)((n - 1) * d + dl) * 9; };
-      long long best = cost(nch, 4, 4);
-      for (int d : {6, 8}) {
-        const int n = std::max(1, (a.need_cols + 256 * d - 1) / (256 * d));
-        if (cost(n, d, d) < best) { best = cost(n, d, d); D = d; DL = d; nch = n; }
-        if (n == 2)                                          // two chunks: the second may be shorter
-          for (int dl = 2; dl < d; dl += 2)
-            if (256 * d + 256 * dl >= a.need_cols && cost(2, d, dl) < best) { best = cost(2, d, dl); D = d; DL = dl; nch = 2; }
-      }
+  // chunk geometry: D dwords per lane and chunk.  Per-chunk overhead ~ 60 wave instructions, per dword of a lane ~ 25:
+  // the D in {4, 6, 8} with the cheapest cover of the reachable bins (without the pre-filter only D = 4 is built)
+  D = 4; DL = 4; nch = std::max(1, (a.need_cols + 1023) / 1024);
+  if (a.pre_on) {
+    // measured on the Kvarntorp rows: ~10 us per chunk and ~9 us per dword of a lane (per 204 800 rows)
+    auto cost = [](int n, int d, int dl) { return (long long)n * 10 + (long long)((n - 1) * d + dl) * 9; };
+    long long best = cost(nch, 4, 4);
+    for (int d : {6, 8}) {
+      const int n = std::max(1, (a.need_cols + 256 * d - 1) / (256 * d));
+      if (cost(n, d, d) < best) { best = cost(n, d, d); D = d; DL = d; nch = n; }
+      if (n == 2)                                          // two chunks: the second may be shorter
+        for (int dl = 2; dl < d; dl += 2)
+          if (256 * d + 256 * dl >= a.need_cols && cost(2, d, dl) < best) { best = cost(2, d, dl); D = d; DL = dl; nch = 2; }
     }
-    a.colsp = (nch - 1) * 256 * D + 256 * DL;
+  }
+  a.colsp = (nch - 1) * 256 * D + 256 * DL;
+}
+
+static size_t cfar_cols_lds(const CfarArgs& a, int D) {
+  return 1024 + (size_t)kCfarTile * ((size_t)a.need_cols + 16) + (size_t)kCfarColsWaves * cfar_cols_wave_lds(a.colsp, a.pad_lo, a.pad_hi, 256 * D);
+}
+
+// [range bins][azimuths] sources through cacfar_cols_kernel: sd = the SOURCE images (rows = bins, cols = azimuths).
+bool cfear_cacfar_cols_supported(const uint8_t* d_src, const cfear_polar_desc* sd, const cfear_cacfar_params* par) {
+  if (sd->cols % kCfarTile != 0 || sd->rows % 16 != 0 || sd->stride % 16 != 0 || (uintptr_t)d_src % 16 != 0 ||
+      (sd->batch > 1 && sd->batch_stride % 16 != 0) || (int64_t)sd->rows * sd->stride >= ((int64_t)1 << 31))
+    return false;
+  CfarArgs a;
+  memset(&a, 0, sizeof(a));
+  int D, DL, nch;
+  cfar_derive(a, par, sd->cols, sd->rows, D, DL, nch);
+  return a.colsp <= 4096 && cfar_cols_lds(a, D) <= 160 * 1024 - 256;
+}
+
+// Device-side CA-CFAR entry (also used by the odometry pipeline).  With `fused` the rows kernel leaves per-row key lists for
+// surface_prep_kernel (cfear_cacfar_fused, common.hpp) and no cloud is built here; fused->bins_major: desc describes the
+// [range bins][azimuths] SOURCE images and the decode is fused into the filter (cacfar_cols_kernel).
+int cfear_cacfar_device(cfear_ctx* ctx, const uint8_t* d_polar, const cfear_polar_desc* desc,
+                        const cfear_cacfar_params* par, float* d_xyzi, int32_t* d_n_points,
+                        int32_t cap_points, uint8_t* d_det_mask, const cfear_cacfar_fused* fused) {
+  const bool keys = fused && fused->row_keys;
+  const bool cols_route = keys && fused->bins_major;
+  if (cols_route && !cfear_cacfar_cols_supported(d_polar, desc, par))
+    return cfear_set_error(ctx, CFEAR_ERR_INVALID_ARGUMENT, "fused CA-CFAR decode: unsupported image geometry");
+  const int rows = cols_route ? desc->cols : desc->rows, cols = cols_route ? desc->rows : desc->cols, batch = desc->batch;
+  const int words = (cols + 63) / 64;
+  CfarArgs a;
+  memset(&a, 0, sizeof(a));
+  a.polar = d_polar; a.stride = desc->stride; a.batch = batch;
+  a.batch_stride = batch > 1 ? desc->batch_stride : (int64_t)desc->rows * desc->stride;
+  a.total_rows = (long long)batch * rows;
+  a.words = words;
+  int D, DL, nch;
+  cfar_derive(a, par, rows, cols, D, DL, nch);
+  if (keys) {
+    a.row_keys = fused->row_keys; a.row_cnt = fused->row_cnt; a.kcap = fused->kcap;
+  } else {
+    size_t bits_bytes = (size_t)batch * rows * words * 8, cnt_bytes = (size_t)batch * rows * 4;
+    char* ws = (char*)cfear_workspace(ctx, 3, bits_bytes + cnt_bytes + 256);
+    if (!ws) return cfear_set_error(ctx, CFEAR_ERR_HIP, "workspace allocation failed");
+    a.det_bits = (unsigned long long*)ws;
+    a.det_count = (int32_t*)(ws + (bits_bytes + 255) / 256 * 256);
+  }
+  a.list_cap = cols_route ? cfar_cols_list_cap(256 * D) : 256 * D + kCfarListSlack;
+  if (cols_route) {
+    using ColsFn = void (*)(const CfarArgs, int);
+    const bool pre = a.pre_on != 0;
+    ColsFn fn = nullptr;
+    if (D == 4) {
+      fn = pre ? cacfar_cols_kernel<4, 4, 4, true> : cacfar_cols_kernel<4, 4, 4, false>;
+    } else if (D == 6) {
+      static const ColsFn f6s[2] = {cacfar_cols_kernel<6, 2, 2, true>, cacfar_cols_kernel<6, 2, 4, true>};
+      fn = DL != D ? f6s[DL / 2 - 1] : (ColsFn)cacfar_cols_kernel<6, 2, 6, true>;   // (colsp <= 4096: at most two chunks of 1536)
+    } else {
+      static const ColsFn f8s[3] = {cacfar_cols_kernel<8, 2, 2, true>, cacfar_cols_kernel<8, 2, 4, true>, cacfar_cols_kernel<8, 2, 6, true>};
+      fn = DL != D ? f8s[DL / 2 - 1] : (ColsFn)cacfar_cols_kernel<8, 2, 8, true>;
+    }
+    const size_t lds = cfar_cols_lds(a, D);
+    CFEAR_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    int n_cu = 256;
+    (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, ctx->device);
+    const int tiles = rows / kCfarTile;
+    const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(4, (size_t)(160 * 1024) / lds));
+    const long long per_xcd = (long long)tiles * ((batch + kXcds - 1) / kXcds);
+    const int slots = (int)std::max<long long>(1, std::min<long long>(per_xcd, std::max(1, n_cu * per_cu / kXcds)));
+    ProfScope ps(ctx, "cacfar_cols");
+    hipLaunchKernelGGL(fn, dim3((unsigned)(slots * kXcds)), dim3(64 * kCfarColsWaves), lds, ctx->stream, a, tiles);
+    CFEAR_HIP_CHECK(ctx, hipGetLastError());
+    return CFEAR_OK;
+  }
+  {
+    const bool pre = a.pre_on != 0;
     using KernelFn = void (*)(const CfarArgs);
     KernelFn fn = nullptr;
     if (D == 4) {

@@ -401,6 +401,15 @@ static int run_filter(cfear_odometry* od, const uint8_t* polar, int buf, const i
     od->decode_measured[buf] = true;                         // read once this buffer's frame has been synchronised
     return CFEAR_OK;
   }
+  // CA-CFAR on [range bins][azimuths] sweeps: the decode fused into the filter (cacfar_cols_kernel), one pass over the image
+  // instead of three (CFEAR_NO_FUSED_DECODE keeps rotate + cacfar_rows, for A/B runs and the tests that compare the two)
+  if (par.rotate_ccw && od->fused_cfar && !getenv("CFEAR_NO_FUSED_DECODE") && B >= 16 &&
+      cfear_cacfar_cols_supported(d_polar, &dd, &par.cacfar)) {
+    cfear_cacfar_params cp = par.cacfar;
+    cfear_cacfar_fused fz;
+    fz.row_keys = od->d_rowpts2[buf]; fz.row_cnt = od->d_rowcnt2[buf]; fz.kcap = od->row_k; fz.bins_major = true;
+    return cfear_cacfar_device(ctx, d_polar, &dd, &cp, nullptr, nullptr, od->cap_points, nullptr, &fz);
+  }
   if (par.rotate_ccw) {
     const size_t rot_bytes = (size_t)od->desc.rows * od->desc.stride;
     if (!od->d_rot && !dalloc(&od->d_rot, rot_bytes * B)) return cfear_set_error(ctx, CFEAR_ERR_HIP, "rotation buffer allocation failed");

@@ -1898,11 +1898,12 @@ __global__ __launch_bounds__(kReg3Threads, 3) void register3_kernel(const RegJob
   cfear_reg_result* res = cm.results + blockIdx.x;
   const int last = job.n_scans - 1;
   const int n_src = gload<int>(job.scans[last].n_cells);
-  int sum_tar = 0;
-  for (int i = 0; i < last; i++) sum_tar += gload<int>(job.scans[i].n_cells);
+  int sum_tar = 0, max_tar = 0;
+  for (int i = 0; i < last; i++) { const int n = gload<int>(job.scans[i].n_cells); sum_tar += n; max_tar = max(max_tar, n); }
   const int n_pairs = last * n_src;
   R3Lds fl;
   bool ok = n_pairs <= cm.slots_cap && r3_carve(smem, cm.lds_total, last, sum_tar, n_src, n_pairs, cm.dense_fields, fl);
+  ok = ok && kScanGridStartPad * 2 + max_tar * 16 <= fl.region;   // every keyframe's tables fit the region on their own
   if (ok) ok = r3_stage_once(job, fl, ipart + 2 * kRegMaxNW - 1);
   if (!ok) {                                             // register_kernel takes it (launched behind this kernel)
     if (threadIdx.x == 0) { res->status = kRegDeferred; res->reserved = 0.0; }
@@ -2187,7 +2188,12 @@ int cfear_register_launch(cfear_ctx* ctx, const void* d_jobs, int n_jobs, const 
   }
   // Regular batches go through register3_kernel first (three workgroups per CU); register_kernel behind it takes what that
   // launch deferred (CFEAR_NO_REG3=1: register_kernel alone, for A/B runs).
-  const bool use3 = !mode && !compact && n_jobs > 64 && !getenv("CFEAR_NO_REG3");   // (read per launch: the tests toggle it)
+  // ... for batches that fill the chip at two workgroups per CU: a smaller batch is a matter of latency, and register_kernel
+  // (tables staged once, not per outer iteration) finishes a registration sooner (512 CA-CFAR streams: 0.34 against 0.38 ms).
+  // CFEAR_REG3=1 forces it from 65 registrations on (tests), CFEAR_NO_REG3=1 switches it off (A/B runs); read per launch.
+  int n_cu3 = 256;
+  (void)hipDeviceGetAttribute(&n_cu3, hipDeviceAttributeMultiprocessorCount, ctx->device);
+  const bool use3 = !mode && !compact && n_jobs > 64 && !getenv("CFEAR_NO_REG3") && (n_jobs > 2 * n_cu3 || getenv("CFEAR_REG3"));
   if (use3) {
     KernelFn f3;
     switch (par->cost) {

@@ -178,6 +178,78 @@ def test_cacfar_pipeline_row_beyond_key_capacity_is_reported():
     od.close()
 
 
+@pytest.mark.parametrize("case", [dict(), dict(cacfar_max_distance=150.0), dict(cacfar_max_distance=700.0, cacfar_window_size=24, cacfar_nb_guard_cells=4),
+                                  dict(cacfar_max_distance=260.0, cacfar_false_alarm_rate=0.02, cacfar_z_min=30.0)])
+def test_cacfar_rotated_input_takes_the_fused_decode(case):
+    """CA-CFAR on [range bins][azimuths] sweeps (Kvarntorp / Volvo / MulRan drivers: radar_driver.cpp:74-90 rotates them
+    before Process()): from 16 streams on the decode is fused into the filter -- cacfar_cols_kernel transposes 16-azimuth tiles
+    into LDS and runs the row algorithm there, no rotated copy -- and the frames must equal (a) the same sweeps fed
+    pre-rotated, field by field, and (b) the oracle's CA-CFAR of np.rot90(sweep) followed by its fuser.  The cases move the
+    range window so that the reachable bins need every chunk geometry (D = 4 / 6 / 8 dwords per lane, shorter last chunk)."""
+    import torch
+    from oracle import pyoracle as O
+    from tbv_slam_public_amd import api, synth
+    n_frames, B = 3, 24
+    seqs = [synth.scene_v1(sd, n_frames, range_res=0.175, ccw=True)[0] for sd in (11, 12, 14)]
+    kw = dict(filter_type=1, cacfar_range_res=0.175, cacfar_z_min=20.0, cacfar_nb_guard_cells=10, cacfar_window_size=40,
+              cacfar_false_alarm_rate=0.01, radar_ccw=1, kstrong_range_res=0.175)
+    kw.update(case)
+    ref = api.OdometryKeyframeFuser(B, 400, 3360, api.odometry_params(**kw))
+    rot = api.OdometryKeyframeFuser(B, 3360, 400, api.odometry_params(rotate_ccw=1, **kw))
+    reg = O.reg_params(cost="P2P", loss="Huber", loss_limit=0.1, weight_opt=4, regularization=0.0)
+    fz = [O.Fuser(reg, res=3.0, submap_scan_size=4, weight_intensity=True, radar_ccw=True) for _ in seqs]
+    seen = set()
+    for f in range(n_frames):
+        batch = torch.from_numpy(np.stack([seqs[i % 3][f] for i in range(B)])).cuda()
+        sent = torch.rot90(batch, -1, dims=(1, 2)).contiguous()
+        a = ref.process(batch)
+        rot.ctx.profile_enable(True); rot.ctx.profile_read(reset=True)     # (the two fusers share the default context)
+        b = rot.process(sent)
+        seen |= set(rot.ctx.profile_read(reset=True))
+        rot.ctx.profile_enable(False)
+        for name in a.dtype.names:
+            np.testing.assert_array_equal(a[name], b[name], err_msg=name)
+        for q, s in enumerate(seqs):
+            img = np.rot90(sent[q].cpu().numpy(), 1)                       # what cv::rotate hands to Process()
+            cloud, _ = O.cacfar(img, kw["cacfar_window_size"], kw["cacfar_nb_guard_cells"], kw["cacfar_false_alarm_rate"], 0.175,
+                                kw["cacfar_z_min"], 2.5, kw.get("cacfar_max_distance", 400.0))
+            pose, oi = fz[q].process(cloud)
+            assert b["n_points"][q] == cloud.shape[0] and b["n_cells"][q] == oi[0], (f, q)
+            d = np.abs(b["pose"][q] - pose)
+            assert d[:2].max() <= POS_TOL and d[2] <= ROT_TOL, (f, q, d)
+    assert "cacfar_cols" in seen and "rotate_ccw" not in seen and "cacfar_rows" not in seen, sorted(seen)
+    assert b["n_points"].min() > 300
+    ref.close(); rot.close()
+
+
+def test_cacfar_fused_decode_rows_with_more_candidates_than_the_list_holds():
+    """cacfar_cols_kernel keeps a candidate list of 1152 entries per wavefront (a chunk of the row has up to 2048 bins): rows
+    whose candidates do not fit go through the list in two halves.  Uniform noise with a low static threshold makes every
+    bin a candidate; detections, cells and registration verdicts must equal the pre-rotated route's and the oracle's count."""
+    import torch
+    from oracle import pyoracle as O
+    from tbv_slam_public_amd import api
+    rng = np.random.default_rng(9)
+    B = 16
+    kw = dict(filter_type=1, cacfar_range_res=0.175, cacfar_z_min=5.0, cacfar_nb_guard_cells=2, cacfar_window_size=8,
+              cacfar_false_alarm_rate=0.2, radar_ccw=1, kstrong_range_res=0.175)
+    ref = api.OdometryKeyframeFuser(B, 400, 3360, api.odometry_params(**kw))
+    rot = api.OdometryKeyframeFuser(B, 3360, 400, api.odometry_params(rotate_ccw=1, **kw))
+    for f in range(2):
+        imgs = rng.integers(0, 256, (3, 400, 3360), dtype=np.uint8)
+        imgs[1, :, ::2] //= 8                                               # every other bin weak: long lists, many detections
+        batch = torch.from_numpy(np.stack([imgs[i % 3] for i in range(B)])).cuda()
+        a = ref.process(batch)
+        b = rot.process(torch.rot90(batch, -1, dims=(1, 2)).contiguous())
+        for name in a.dtype.names:
+            np.testing.assert_array_equal(a[name], b[name], err_msg=name)
+        for q in range(3):
+            cloud, _ = O.cacfar(imgs[q], 8, 2, 0.2, 0.175, 5.0, 2.5)
+            assert b["n_points"][q] == cloud.shape[0] or b["reg_status"][q] != 0, (f, q, b["n_points"][q], cloud.shape[0])
+    assert b["n_points"].max() > 16384
+    ref.close(); rot.close()
+
+
 @pytest.mark.parametrize("device_input,two_kernel", [(False, False), (True, False), (True, True)])
 def test_rotated_input_layout_equals_prerotated(device_input, two_kernel, monkeypatch):
     """par.rotate_ccw: images arrive as [range bins][azimuths] (non-Oxford drivers, radar_driver.cpp:74-90); the

@@ -502,6 +502,7 @@ def test_three_per_cu_kernel_matches_the_two_per_cu_kernel(monkeypatch):
         monkeypatch.setenv("CFEAR_NO_REG3", "1")
         base = reg.RegisterBatch(jobs)
         monkeypatch.delenv("CFEAR_NO_REG3")
+        monkeypatch.setenv("CFEAR_REG3", "1")                              # (the library takes it from 513 registrations on by itself)
         runs = {"52 KB": reg.RegisterBatch(jobs)}
         monkeypatch.setenv("CFEAR_REG3_LDS_KB", "14")
         runs["14 KB"] = reg.RegisterBatch(jobs)

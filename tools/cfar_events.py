@@ -1,9 +1,12 @@
 """hipEvent timing of the CA-CFAR pipeline in profile mode 1 (every kernel) and mode 2 (row kernel only), with prefetch like
-bench.py; compare with rocprofv3 --kernel-trace of the same command."""
+bench.py; compare with rocprofv3 --kernel-trace of the same command.  --bins-major: the sweeps arrive [range bins][azimuths]
+(decode fused into the filter: cacfar_cols_kernel)."""
 import sys, time, numpy as np, torch
 sys.path.insert(0, '/root/repo')
 from tbv_slam_public_amd import api, synth
-B, F = (int(sys.argv[1]) if len(sys.argv) > 1 else 512), 8
+BM = '--bins-major' in sys.argv
+args = [a for a in sys.argv[1:] if not a.startswith('--')]
+B, F = (int(args[0]) if args else 512), 8
 dev = "cuda"
 rings = torch.empty((min(B, 64), F, 400, 3360), dtype=torch.uint8, device=dev)
 for b in range(rings.shape[0]):
@@ -11,9 +14,11 @@ for b in range(rings.shape[0]):
     rings[b] = synth.render_frames_torch(sc, list(range(F)), dev)
 seq = torch.arange(B, device=dev) % rings.shape[0]
 batches = [rings[:, t].index_select(0, seq).contiguous() for t in range(F)]
+if BM:
+    batches = [torch.rot90(x, -1, dims=(1, 2)).contiguous() for x in batches]
 par = api.odometry_params(filter_type=1, cacfar_range_res=0.175, cacfar_z_min=20.0, cacfar_nb_guard_cells=10,
-                          cacfar_window_size=40, cacfar_false_alarm_rate=0.01, radar_ccw=1, kstrong_range_res=0.175)
-od = api.OdometryKeyframeFuser(B, 400, 3360, par)
+                          cacfar_window_size=40, cacfar_false_alarm_rate=0.01, radar_ccw=1, kstrong_range_res=0.175, rotate_ccw=int(BM))
+od = api.OdometryKeyframeFuser(B, 3360 if BM else 400, 400 if BM else 3360, par)
 ctx = od.ctx
 torch.cuda.synchronize()
 pp = lambda t: (t % (2 * F - 2)) if (t % (2 * F - 2)) < F else 2 * F - 2 - (t % (2 * F - 2))
