@@ -225,6 +225,7 @@ typedef uint32_t g_u32x4 __attribute__((ext_vector_type(4)));
 typedef double g_f64x2 __attribute__((ext_vector_type(2)));
 typedef double g_f64x4 __attribute__((ext_vector_type(4)));
 typedef float g_f32x4 __attribute__((ext_vector_type(4)));
+typedef float g_f32x2 __attribute__((ext_vector_type(2)));
 template <class T>
 __device__ __forceinline__ T gload(const void* p) { return *(const __attribute__((address_space(1))) T*)p; }
 template <class T>

@@ -1153,7 +1153,7 @@ __global__ __launch_bounds__(kFastThreads, 4) void surface_sort_kernel(const Sur
 #pragma unroll
     for (int u = 0; u < 8; u++) {
       const int i = tid + (j0 + u) * NT;
-      if (i < n) pp[u] = pts[i];
+      if (i < n) pp[u] = gload_f4(pts + i);                              // (global_load, not flat_load: gload's comment in common.hpp)
     }
 #pragma unroll
     for (int u = 0; u < 8; u++) {
@@ -1220,7 +1220,7 @@ __global__ __launch_bounds__(kFastThreads, 4) void surface_sort_kernel(const Sur
 #pragma unroll
       for (int u = 0; u < 8; u++) {
         const int i = tid + (j0 + u) * NT;
-        if (i < n) pq[u] = *(const float2*)&pts[i];
+        if (i < n) { const g_f32x2 t = gload<g_f32x2>(pts + i); pq[u] = make_float2(t.x, t.y); }
       }
 #pragma unroll
       for (int u = 0; u < 8; u++) {
@@ -1320,7 +1320,7 @@ __global__ __launch_bounds__(kFastThreads, 4) void surface_sort_kernel(const Sur
       float4 pp[8];
 #pragma unroll
       for (int u = 0; u < 8; u++)
-        if (tid + (j0 + u) * NT < n) pp[u] = pts[mycell[j0 + u]];
+        if (tid + (j0 + u) * NT < n) pp[u] = gload_f4(pts + mycell[j0 + u]);
 #pragma unroll
       for (int u = 0; u < 8; u++) {
         const int pos = tid + (j0 + u) * NT;
@@ -1336,7 +1336,7 @@ __global__ __launch_bounds__(kFastThreads, 4) void surface_sort_kernel(const Sur
     }
   } else {
     for (int pos = tid; pos < n; pos += NT) {
-      const float4 p = pts[order[pos]];
+      const float4 p = gload_f4(pts + order[pos]);
       scr.spt[pos] = make_float4(p.x, p.y, fmaxf(__fsub_rn(p.w, 60.0f), 0.0f), 0.f);
     }
     __threadfence_block();
@@ -1388,7 +1388,7 @@ __global__ __launch_bounds__(kFastThreads, 4) void surface_sort_kernel(const Sur
     unsigned short* vlist = (unsigned short*)(smem + ord2_off + (((size_t)cap_pts * PB + 15) & ~(size_t)15));
     if (!single)
       for (int i = tid; i < P1 - P0; i += NT) {
-        const float4 q = scr.spt[P0 + i];
+        const float4 q = gload_f4(scr.spt + P0 + i);
         lxy[i] = make_float2(q.x, q.y);
         if (WB) lw[i] = (uint8_t)q.z; else lwf[i] = q.z;
       }
@@ -1397,7 +1397,7 @@ __global__ __launch_bounds__(kFastThreads, 4) void surface_sort_kernel(const Sur
     STAMP(11);
     // neighbour runs of voxel v (relative to the staging area) and its own run
     auto runs_of = [&](int v, int* r0, int* r1, int& s, int& e) {
-      const uint32_t key = scr.vkey[v];
+      const uint32_t key = gload<uint32_t>(scr.vkey + v);
       s = (v ? (int)vs16[v - 1] : 0) - P0; e = (int)vs16[v] - P0;
       const int iy = (int)(key / (uint32_t)dbx), ix = (int)(key - (uint32_t)iy * (uint32_t)dbx);
       const int x0 = max(ix - 1, 0), x1 = min(ix + 1, dbx - 1);
@@ -1482,7 +1482,7 @@ __global__ __launch_bounds__(kFastThreads, 4) void surface_sort_kernel(const Sur
           const float cnt = (float)(e - s);
           c = make_float2(__fdiv_rn(ax, cnt), __fdiv_rn(ay, cnt));
         } else {
-          c = make_float2(cmo->cx, cmo->cy);
+          c = make_float2(gload<float>(&cmo->cx), gload<float>(&cmo->cy));
         }
         const double cx = (double)c.x, cy = (double)c.y;
         Moments mo{0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
