@@ -87,6 +87,7 @@ struct TmpCell {                              // one candidate cell per voxel (b
 // moments of the neighbourhood; surface_finish_kernel turns them into the cell.
 struct CellMom { double s0, s1x, s1y, sxx, sxy, syy; float cx, cy; int32_t cnt, pad; };
 static_assert(sizeof(CellMom) <= sizeof(TmpCell), "CellMom lives in the TmpCell slot");
+static_assert(sizeof(CellMom) == 64 && offsetof(CellMom, cx) == 48, "surface_finish_kernel reads a CellMom as four 16-byte pieces");
 
 // Per-scan global scratch (one region per job, shared by the fast pipeline and the single-kernel fallback):
 //   [0, 256)            SurfHdr
@@ -338,7 +339,7 @@ __device__ void grid_cells_block(const ScanView& v, int n, uint8_t* lds) {
   {
     unsigned xl = 0xFFFFFFFFu, xh = 0u, yl = 0xFFFFFFFFu, yh = 0u;
     for (int i = tid; i < n; i += nth) {
-      const float2 m = v.mean_f[i];
+      const g_f32x2 m = gload<g_f32x2>(v.mean_f + i);
       const unsigned ux = ordered(m.x), uy = ordered(m.y);
       xl = min(xl, ux); xh = max(xh, ux); yl = min(yl, uy); yh = max(yh, uy);
     }
@@ -361,7 +362,7 @@ __device__ void grid_cells_block(const ScanView& v, int n, uint8_t* lds) {
     const int cy = min(kScanGrid - 1, max(0, (int)floorf((y - y0) * inv)));
     return cy * kScanGrid + cx;
   };
-  for (int i = tid; i < n; i += nth) { const float2 m = v.mean_f[i]; atomicAdd(&cnt[cell_of(m.x, m.y)], 1u); }
+  for (int i = tid; i < n; i += nth) { const g_f32x2 m = gload<g_f32x2>(v.mean_f + i); atomicAdd(&cnt[cell_of(m.x, m.y)], 1u); }
   __syncthreads();
   {                                                          // exclusive scan over the cells
     const int per = (kScanGridCells + nth - 1) / nth, c0 = tid * per, c1 = min(kScanGridCells, c0 + per);
@@ -374,19 +375,19 @@ __device__ void grid_cells_block(const ScanView& v, int n, uint8_t* lds) {
     for (int wv = 0; wv < (tid >> 6); wv++) run += (int)ext[4 + wv];
     for (int c = c0; c < c1; c++) {
       const int k = (int)cnt[c];
-      v.grid_cstart[c] = (unsigned short)run;
+      gstore<unsigned short>(v.grid_cstart + c, (unsigned short)run);
       cnt[c] = (unsigned)run;
       run += k;
     }
-    if (tid < kScanGridStartPad - kScanGridCells) v.grid_cstart[kScanGridCells + tid] = (unsigned short)n;
+    if (tid < kScanGridStartPad - kScanGridCells) gstore<unsigned short>(v.grid_cstart + kScanGridCells + tid, (unsigned short)n);
   }
   __syncthreads();
   for (int i = tid; i < n; i += nth) {
-    const float2 m = v.mean_f[i];
+    const g_f32x2 m = gload<g_f32x2>(v.mean_f + i);
     const unsigned pos = atomicAdd(&cnt[cell_of(m.x, m.y)], 1u);
-    v.grid_txyi[pos] = make_float4(m.x, m.y, __int_as_float(i), 0.f);
+    gstore<g_f32x4>(v.grid_txyi + pos, g_f32x4{m.x, m.y, __int_as_float(i), 0.f});
   }
-  if (tid == 0) *v.grid_geo = make_float4(x0, y0, inv, 1.f);
+  if (tid == 0) gstore<g_f32x4>(v.grid_geo, g_f32x4{x0, y0, inv, 1.f});
 }
 
 __device__ void sort_cells_x(const ScanView& v, int n, unsigned long long* keys, const size_t lds_bytes);
@@ -407,7 +408,7 @@ __device__ void sort_cells_x(const ScanView& v, int n, unsigned long long* keys,
   for (int i = tid; i < npad; i += nth) {
     unsigned long long key = ~0ull;
     if (i < n) {
-      unsigned u = __float_as_uint(v.mean_f[i].x);
+      unsigned u = __float_as_uint(gload<float>(&v.mean_f[i].x));
       u ^= (u >> 31) ? 0xFFFFFFFFu : 0x80000000u;           // order-preserving float -> uint
       key = ((unsigned long long)u << 32) | (unsigned)i;
     }
@@ -462,7 +463,7 @@ __device__ void sort_cells_x(const ScanView& v, int n, unsigned long long* keys,
       for (; q + 1 < be; q += 2) { const unsigned long long k0 = keys2[q], k1 = keys2[q + 1]; rank += (k0 < key) + (k1 < key); }
       if (q < be) rank += keys2[q] < key;
       const int i = (int)(unsigned)(key & 0xFFFFFFFFu);
-      const float2 m = v.mean_f[i];
+      const g_f32x2 m = gload<g_f32x2>(v.mean_f + i);
       v.sorted_x[rank] = m.x;
       v.sorted_y[rank] = m.y;
       v.sorted_idx[rank] = i;
@@ -489,7 +490,7 @@ __device__ void sort_cells_x(const ScanView& v, int n, unsigned long long* keys,
       if (lp >= 2) rank += __shfl_xor(rank, 1);
       if (lp >= 4) rank += __shfl_xor(rank, 2);
       if (i < n && part == 0) {
-        const float2 m = v.mean_f[i];
+        const g_f32x2 m = gload<g_f32x2>(v.mean_f + i);
         v.sorted_x[rank] = m.x;
         v.sorted_y[rank] = m.y;
         v.sorted_idx[rank] = i;
@@ -511,10 +512,10 @@ __device__ void sort_cells_x(const ScanView& v, int n, unsigned long long* keys,
   }
   for (int i = tid; i < n; i += nth) {
     const int idx = (int)(keys[i] & 0xFFFFFFFFu);
-    const float2 m = v.mean_f[idx];
-    v.sorted_x[i] = m.x;
-    v.sorted_y[i] = m.y;
-    v.sorted_idx[i] = idx;
+    const g_f32x2 m = gload<g_f32x2>(v.mean_f + idx);
+    gstore<float>(v.sorted_x + i, m.x);
+    gstore<float>(v.sorted_y + i, m.y);
+    gstore<int32_t>(v.sorted_idx + i, idx);
   }
 }
 
@@ -998,7 +999,7 @@ __global__ __launch_bounds__(kFastThreads) void surface_prep_kernel(const SurfJo
     int run = 0, over = 0;
     for (int r0 = 0; r0 < job.rows; r0 += NT) {
       const int r = r0 + tid;
-      const int v = r < job.rows ? job.row_cnt[2 * r] : 0;
+      const int v = r < job.rows ? gload<int32_t>(job.row_cnt + 2 * r) : 0;
       over |= v > job.k;                                   // a CA-CFAR row beyond its key capacity (keys were dropped)
       const int incl = wave_incl_scan_i32(v);
       if (lane == 63) red_i[wave] = incl;
@@ -1048,9 +1049,9 @@ __global__ __launch_bounds__(kFastThreads) void surface_prep_kernel(const SurfJo
       if (i < n) {
         if (ROWS) {
           row[u] = rid[i];
-          key[u] = job.row_pts[(size_t)row[u] * job.k + (i - rowoff[row[u]])];
+          key[u] = gload<uint32_t>(job.row_pts + (size_t)row[u] * job.k + (i - rowoff[row[u]]));   // (global_load, not flat_load)
         } else {
-          p[u] = pts[i];
+          p[u] = gload_f4(pts + i);
         }
       }
     }
@@ -1067,10 +1068,10 @@ __global__ __launch_bounds__(kFastThreads) void surface_prep_kernel(const SurfJo
             const double d = rel_time_stamp_known_row((double)p[u].x, (double)p[u].y, th, t.x, t.y, cm.ccw != 0);
             p[u] = compensate_point_small(p[u], d, job.mot);
           }
-          pts[i] = p[u];
+          gstore<g_f32x4>(pts + i, g_f32x4{p[u].x, p[u].y, p[u].z, p[u].w});
         } else if (job.compensate) {
           p[u] = compensate_point_small(p[u], get_rel_time_stamp((double)p[u].x, (double)p[u].y, cm.ccw != 0), job.mot);
-          pts[i] = p[u];
+          gstore<g_f32x4>(pts + i, g_f32x4{p[u].x, p[u].y, p[u].z, p[u].w});
         }
         mnx = fminf(mnx, p[u].x); mxx = fmaxf(mxx, p[u].x);
         mny = fminf(mny, p[u].y); mxy = fmaxf(mxy, p[u].y);
@@ -1553,7 +1554,14 @@ __global__ __launch_bounds__(kFinishThreads) void surface_finish_kernel(const Su
     TmpCell t;
     int f = 0;
     if (v < V) {
-      const CellMom cmo = *(const CellMom*)&scr.tmp[v];
+      CellMom cmo;                                                     // (64 bytes as four global 16-byte loads: gload's comment in common.hpp)
+      {
+        const char* src = (const char*)&scr.tmp[v];
+        const g_f64x2 a = gload<g_f64x2>(src), b = gload<g_f64x2>(src + 16), c = gload<g_f64x2>(src + 32);
+        const g_u32x4 d = gload<g_u32x4>(src + 48);
+        cmo.s0 = a.x; cmo.s1x = a.y; cmo.s1y = b.x; cmo.sxx = b.y; cmo.sxy = c.x; cmo.syy = c.y;
+        cmo.cx = __uint_as_float(d.x); cmo.cy = __uint_as_float(d.y); cmo.cnt = (int32_t)d.z; cmo.pad = 0;
+      }
       if (cmo.cnt >= 6) {
         const Moments mo{cmo.cnt, cmo.s0, cmo.s1x, cmo.s1y, cmo.sxx, cmo.sxy, cmo.syy};
         f = finish_cell(mo, (double)cmo.cx, (double)cmo.cy, cm.origin[0], cm.origin[1], t);
@@ -1565,14 +1573,14 @@ __global__ __launch_bounds__(kFinishThreads) void surface_finish_kernel(const Su
     int off = run + inc - f;
     for (int wv = 0; wv < kFinishThreads / 64; wv++) { if (wv < wave) off += red_i2[rnd][wv]; run += red_i2[rnd][wv]; }
     if (f && off < job.out.cap) {
-      job.out.mean_f[off] = make_float2((float)t.mean[0], (float)t.mean[1]);  // pointnormal.cpp:154-157
-      job.out.mean[off] = make_double2(t.mean[0], t.mean[1]);
-      job.out.normal[off] = make_double2(t.normal[0], t.normal[1]);
-      job.out.cov[off] = make_double4(t.cov[0], t.cov[1], t.cov[2], t.cov[3]);
-      job.out.scale[off] = t.scale;
-      job.out.avg_intensity[off] = t.avg_intensity;
-      job.out.lambda[off] = make_double2(t.lmin, t.lmax);
-      job.out.nsamples[off] = t.nsamples;
+      gstore<g_f32x2>(job.out.mean_f + off, g_f32x2{(float)t.mean[0], (float)t.mean[1]});  // pointnormal.cpp:154-157
+      gstore<g_f64x2>(job.out.mean + off, g_f64x2{t.mean[0], t.mean[1]});
+      gstore<g_f64x2>(job.out.normal + off, g_f64x2{t.normal[0], t.normal[1]});
+      gstore<g_f64x4>(job.out.cov + off, g_f64x4{t.cov[0], t.cov[1], t.cov[2], t.cov[3]});
+      gstore<double>(job.out.scale + off, t.scale);
+      gstore<double>(job.out.avg_intensity + off, t.avg_intensity);
+      gstore<g_f64x2>(job.out.lambda + off, g_f64x2{t.lmin, t.lmax});
+      gstore<int32_t>(job.out.nsamples + off, t.nsamples);
     }
   }
   __threadfence_block();
