@@ -93,6 +93,23 @@ __device__ __forceinline__ int upper_bound_u32(const uint32_t* a, int lo, int hi
 }
 
 struct Moments { int n; double sx, sy, sxx, sxy, syy; };
+// all-reduce over aligned groups of G lanes (G = 4: quad, G = 16: DPP row); every lane ends with the same sum
+template <int G> __device__ __forceinline__ int group_sum_i32(int v) {
+  if (G >= 4) {
+    v += __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xf, 0xf, false);           // quad_perm [1,0,3,2]
+    v += __builtin_amdgcn_update_dpp(v, v, 0x4E, 0xf, 0xf, false);           // quad_perm [2,3,0,1]
+  }
+  if (G == 16) {
+    v += __builtin_amdgcn_update_dpp(v, v, 0x141, 0xf, 0xf, false);          // row_half_mirror
+    v += __builtin_amdgcn_update_dpp(v, v, 0x140, 0xf, 0xf, false);          // row_mirror
+  }
+  return v;
+}
+template <int G> __device__ __forceinline__ double group_sum_f64(double v) {
+  if (G >= 4) { v += dpp_f64<0xB1>(v); v += dpp_f64<0x4E>(v); }
+  if (G == 16) { v += dpp_f64<0x141>(v); v += dpp_f64<0x140>(v); }
+  return v;
+}
 typedef float v4f __attribute__((ext_vector_type(4)));
 #define CFEAR_LDS __attribute__((address_space(3)))
 
@@ -146,7 +163,7 @@ __global__ __launch_bounds__(kCoralThreads) void coral_kernel(const CoralJob* __
   const Aff2d Tref = aff_xyt(job.ref_pose);
   const Aff2d Tsrc = aff_compose(aff_xyt(job.src_pose), aff_xyt(job.offset));            // src->GetAffine() * Toffset (:101)
   auto point = [&](int i) -> float2 {                          // merged index: source points first (:132, :155)
-    return i < n_src ? tf_point(job.src[i], Tsrc) : tf_point(job.ref[i - n_src], Tref);
+    return i < n_src ? tf_point(gload_f4(job.src + i), Tsrc) : tf_point(gload_f4(job.ref + (i - n_src)), Tref);   // (global_load: gload's comment in common.hpp)
   };
   // ---- 1. bounding box of the merged cloud ------------------------------------------------------
   float mnx = FLT_MAX, mny = FLT_MAX, mxx = -FLT_MAX, mxy = -FLT_MAX;
@@ -240,7 +257,7 @@ __global__ __launch_bounds__(kCoralThreads) void coral_kernel(const CoralJob* __
         if (e == 0 || vx != pv) { cell_key[ord] = vx; cell_start[ord] = e; ord++; }
         pv = vx;
         const float2 p = point(idx);
-        const float inten = idx < n_src ? job.src[idx].w : job.ref[idx - n_src].w;
+        const float inten = idx < n_src ? gload<float>(&job.src[idx].w) : gload<float>(&job.ref[idx - n_src].w);
         spt[e] = make_float4(p.x, p.y, inten, __int_as_float(idx));
       }
     }
@@ -251,6 +268,187 @@ __global__ __launch_bounds__(kCoralThreads) void coral_kernel(const CoralJob* __
     rowbeg[y] = lower_bound_u32(cell_key, 0, V, (uint32_t)((long long)y * dbx));
   __threadfence_block();
   __syncthreads();
+  // ---- 3b. O(1) cell look-ups: ONE BIT per grid cell + the occupied cells before every 32-cell word (the map
+  //      surface_sort_kernel uses): the points before cell c = cell_start[wpref[c / 32] + popcount(occ[c / 32] below c)] --
+  //      two LDS reads and one dependent read instead of two binary searches over the row's cells (ten dependent reads) per
+  //      grid row and point.  Kept behind the sorted points when it fits the LDS (grids up to ~3 x 10^5 cells for the usual
+  //      peak clouds); otherwise the binary searches below. ---------------------------------------------------------
+  const long long ncells_ll = (long long)dbx * dby;
+  const size_t occ_off = spt_in_lds ? ((spt_off + (size_t)n * 16 + 15) & ~(size_t)15) : spt_off;
+  const long long nw32_ll = (ncells_ll >> 5) + 1;
+  const bool bitmap = occ_off + (size_t)nw32_ll * 6 + 16 <= kCoralRowbegOff;
+  uint32_t* occ = (uint32_t*)(smem + occ_off);
+  const int nw32 = bitmap ? (int)nw32_ll : 0;
+  unsigned short* wpref = (unsigned short*)(occ + nw32);
+  if (bitmap) {
+    for (int w = tid; w < nw32; w += kCoralThreads) occ[w] = 0u;
+    __syncthreads();
+    for (int o = tid; o < V; o += kCoralThreads) { const uint32_t c = cell_key[o]; atomicOr(&occ[c >> 5], 1u << (c & 31)); }
+    __syncthreads();
+    const int perw = (nw32 + kCoralThreads - 1) / kCoralThreads;
+    const int w0 = min(nw32, tid * perw), w1 = min(nw32, w0 + perw);
+    int to = 0;
+    for (int w = w0; w < w1; w++) to += __popc(occ[w]);
+    const int inclw = wave_incl_scan_i32(to);
+    if (lane == 63) red_c[wave] = inclw;
+    __syncthreads();
+    int runw = inclw - to;
+    for (int wv = 0; wv < wave; wv++) runw += red_c[wv];
+    for (int w = w0; w < w1; w++) { wpref[w] = (unsigned short)runw; runw += __popc(occ[w]); }
+    __syncthreads();
+  }
+  auto pbefore = [&](int c) -> int {                            // points in cells < c, 0 <= c <= ncells
+    const int w = c >> 5;
+    return cell_start[(int)wpref[w] + __popc(occ[w] & ((1u << (c & 31)) - 1u))];
+  };
+  // the three candidate runs of a query in cell (ix, iy): rows iy - 1 .. iy + 1, columns ix - 1 .. ix + 1 (empty outside the grid)
+  auto runs_of = [&](int ix, int iy, int* r0, int* r1) {
+    const int x0 = max(ix - 1, 0), x1 = min(ix + 1, dbx - 1);
+#pragma unroll
+    for (int d = 0; d < 3; d++) {
+      const int yy = iy - 1 + d;
+      const bool in = yy >= 0 && yy < dby;
+      const int cy = in ? yy : 0;
+      const int a = pbefore(cy * dbx + x0), b = pbefore(cy * dbx + x1 + 1);
+      r0[d] = in ? a : 0; r1[d] = in ? b : 0;
+    }
+  };
+  CORAL_T(3);
+  int* n_work = red_i;                                          // LDS counter (red_i is free after the sort)
+  if (tid == 0) *n_work = 0;
+  __syncthreads();
+  // Pass A (cheap, every point): does the point have ANY neighbour of the other cloud within the radius (overlap_req_ = 1,
+  // :138, :160)?  Float distance tests only, first hit ends the search.  Points without one are final (100, 100,
+  // invalid); the others go to a work list.  Pass B (expensive, work list only): fp64 moments and entropies.
+  auto find_overlap_bm = [&](auto* SP) {
+    for (int e0 = 0; e0 < n; e0 += kCoralThreads) {
+      const int e = e0 + tid;
+      bool hit = false;
+      if (e < n) {
+        const v4f q = SP[e];
+        const int idx = __float_as_int(q.w);
+        const bool q_is_src = idx < n_src;
+        int ix, iy, r0[3], r1[3];
+        cell_xy(make_float2(q.x, q.y), ix, iy);
+        runs_of(ix, iy, r0, r1);
+        auto test = [&](const v4f c) {
+          const float dxf = __fsub_rn(q.x, c.x), dyf = __fsub_rn(q.y, c.y);
+          const float d2 = __fadd_rn(__fmul_rn(dxf, dxf), __fmul_rn(dyf, dyf));
+          return (d2 < cm.r2) && ((__float_as_int(c.w) < n_src) != q_is_src);
+        };
+        // the point's own row first: the nearest returns of the other cloud usually share it
+#pragma unroll
+        for (int dd = 0; dd < 3; dd++) {
+          const int d = dd == 0 ? 1 : (dd == 1 ? 0 : 2);
+          int p = r0[d];
+          const int p1 = r1[d];
+          for (; p + 3 < p1 && !hit; p += 4) {                  // four independent loads per exit test
+            const v4f c0 = SP[p], c1 = SP[p + 1], c2 = SP[p + 2], c3 = SP[p + 3];
+            hit = ((int)test(c0) | (int)test(c1) | (int)test(c2) | (int)test(c3)) != 0;
+          }
+          for (; p < p1 && !hit; p++) hit = test(SP[p]);
+        }
+        if (!hit) { gstore<double>(jres + idx, 100.0); gstore<double>(sres + idx, 100.0); gstore<double>(wres + idx, 0.0); gstore<int32_t>(vres + idx, 0); }
+      }
+      const unsigned long long m = __ballot(hit);                // wave-aggregated append
+      int base = 0;
+      if (lane == 0 && m) base = atomicAdd(n_work, __popcll(m));
+      base = __shfl(base, 0);
+      if (hit) gstore<int32_t>(work + base + __popcll(m & ((1ull << lane) - 1ull)), e);
+    }
+  };
+  // Pass B: one lane per point of the work list.  (Lane groups for the heavy neighbourhoods -- sixteen lanes per point with
+  // more than 48 candidates, four above 12, DPP all-reduces of the partial moments -- were measured in round 4: the jobs
+  // that take 2.5 x the sweep time of the rest are not held up by a few heavy lanes, they simply visit more candidates; the
+  // classification pass cost more than the balance gained: 55 k cycles against 50 k per job.)
+  auto sweep_bm = [&](auto* SP, const int W) {
+    const int* work2 = work;
+    const int n16 = 0, n4 = 0;
+    auto tier = [&](auto g_tag, const int lbeg, const int lend) {
+      constexpr int G = decltype(g_tag)::value;
+      const int sub = tid & (G - 1);
+      for (int k0 = lbeg; k0 < lend; k0 += kCoralThreads / G) {
+        const int k = k0 + tid / G;
+        const bool act = k < lend;                               // (whole groups stay in the loop for the DPP sums)
+        const int e = act ? gload<int32_t>(work2 + k) : 0;
+        const v4f q = SP[e];
+        const int idx = __float_as_int(q.w);
+        const bool q_is_src = idx < n_src;
+        int ix, iy, r0[3], r1[3];
+        cell_xy(make_float2(q.x, q.y), ix, iy);
+        runs_of(ix, iy, r0, r1);
+        Moments ms{0, 0, 0, 0, 0, 0}, mr{0, 0, 0, 0, 0, 0};
+        const double qx = (double)q.x, qy = (double)q.y;
+        auto visit = [&](const v4f c) {
+          const float dxf = __fsub_rn(q.x, c.x), dyf = __fsub_rn(q.y, c.y);
+          const float d2 = __fadd_rn(__fmul_rn(dxf, dxf), __fmul_rn(dyf, dyf));  // FLANN L2_Simple
+          if (d2 < cm.r2) {                                                       // RadiusResultSet: strict <
+            const double dx = (double)c.x - qx, dy = (double)c.y - qy;
+            if (__float_as_int(c.w) < n_src) {
+              ms.n++; ms.sx += dx; ms.sy += dy; ms.sxx += dx * dx; ms.sxy += dx * dy; ms.syy += dy * dy;
+            } else {
+              mr.n++; mr.sx += dx; mr.sy += dy; mr.sxx += dx * dx; mr.sxy += dx * dy; mr.syy += dy * dy;
+            }
+          }
+        };
+        if (act) {
+#pragma unroll
+          for (int d = 0; d < 3; d++) {
+            int p = r0[d] + sub;
+            for (; p + G < r1[d]; p += 2 * G) {                  // two loads in flight
+              const v4f c0 = SP[p], c1 = SP[p + G];
+              visit(c0);
+              visit(c1);
+            }
+            if (p < r1[d]) visit(SP[p]);
+          }
+        }
+        if (G > 1) {
+          ms.n = group_sum_i32<G>(ms.n); mr.n = group_sum_i32<G>(mr.n);
+          ms.sx = group_sum_f64<G>(ms.sx); ms.sy = group_sum_f64<G>(ms.sy); ms.sxx = group_sum_f64<G>(ms.sxx);
+          ms.sxy = group_sum_f64<G>(ms.sxy); ms.syy = group_sum_f64<G>(ms.syy);
+          mr.sx = group_sum_f64<G>(mr.sx); mr.sy = group_sum_f64<G>(mr.sy); mr.sxx = group_sum_f64<G>(mr.sxx);
+          mr.sxy = group_sum_f64<G>(mr.sxy); mr.syy = group_sum_f64<G>(mr.syy);
+        }
+        if (act && sub == 0) {
+          double jr = 100.0, sr = 100.0, w = 0.0;
+          int valid = 0;
+          const Moments& own = q_is_src ? ms : mr;
+          const Moments& other = q_is_src ? mr : ms;
+          if (other.n >= 1) {                                                         // overlap_req_ = 1 (:138, :160)
+            const Moments mj{ms.n + mr.n, ms.sx + mr.sx, ms.sy + mr.sy, ms.sxx + mr.sxx, ms.sxy + mr.sxy, ms.syy + mr.syy};
+            double s00, s01, s11, j00, j01, j11;
+            if (cov_from_moments(own, s00, s01, s11) && cov_from_moments(mj, j00, j01, j11)) {
+              const double det_j = j00 * j11 - j01 * j01;                             // ComputeEntropy (:80-98)
+              const double det_s = s00 * s11 - s01 * s01;
+              if (!(isnan(det_s) || isnan(det_j))) {
+                const double sep_entropy = 1.0 / 2.0 * log(2.0 * M_PI * exp(1.0) * det_s + 0.00000001);
+                const double joint_entropy = 1.0 / 2.0 * log(2.0 * M_PI * exp(1.0) * det_j + 0.00000001);
+                if (!(isnan(sep_entropy) || isnan(joint_entropy))) {
+                  w = cm.weight_res_intensity ? (double)q.z : 1.0;                    // :180
+                  jr = w * joint_entropy; sr = w * sep_entropy; valid = 1;
+                }
+              }
+            }
+          }
+          gstore<double>(jres + idx, jr); gstore<double>(sres + idx, sr); gstore<double>(wres + idx, valid ? w : 0.0); gstore<int32_t>(vres + idx, valid);
+        }
+      }
+    };
+    (void)n16;
+    tier(std::integral_constant<int, 1>{}, n4, W);
+  };
+  if (bitmap) {
+    if (spt_in_lds) find_overlap_bm((CFEAR_LDS const v4f*)spt);
+    else find_overlap_bm((const v4f*)spt);
+    __threadfence_block();
+    __syncthreads();
+    const int Wb = *n_work;
+    CORAL_T(4);
+    __syncthreads();                                            // (red_c / red_i are reused by the sweep's counters)
+    if (spt_in_lds) sweep_bm((CFEAR_LDS const v4f*)spt, Wb);
+    else sweep_bm((const v4f*)spt, Wb);
+  } else {
   // ---- 4. moments of the source / reference neighbours of every point -> entropies -----------------------------
   // Instantiated per address space of the sorted points (ds_read_b128 when they sit in LDS); candidates are fetched
   // two at a time so the second load is in flight while the first is tested.
@@ -258,10 +456,6 @@ __global__ __launch_bounds__(kCoralThreads) void coral_kernel(const CoralJob* __
   // (overlap_req_ = 1, :138, :160)?  Float distance tests only, first hit ends the search.  Points without one are
   // final (100, 100, invalid); the others go to a work list.  Pass B (expensive, work list only): fp64 moments and
   // entropies -- typically a quarter to a half of the points, spread evenly over the workgroup.
-  CORAL_T(3);
-  int* n_work = red_i;                                          // LDS counter (red_i is free after the sort)
-  if (tid == 0) *n_work = 0;
-  __syncthreads();
   auto find_overlap = [&](auto* SP) {
     for (int e0 = 0; e0 < n; e0 += kCoralThreads) {
       const int e = e0 + tid;
@@ -366,6 +560,7 @@ __global__ __launch_bounds__(kCoralThreads) void coral_kernel(const CoralJob* __
   };
   if (spt_in_lds) sweep((CFEAR_LDS const v4f*)spt);
   else sweep((const v4f*)spt);
+  }
   __threadfence_block();
   __syncthreads();
   CORAL_T(5);
@@ -375,7 +570,7 @@ __global__ __launch_bounds__(kCoralThreads) void coral_kernel(const CoralJob* __
     double sj = 0.0, ss = 0.0, sw = 0.0;
     int cnt = 0;
     for (int i = tid * chunk; i < min(n, (tid + 1) * chunk); i++)
-      if (vres[i]) { sw += wres[i]; sj += jres[i]; ss += sres[i]; cnt++; }
+      if (gload<int32_t>(vres + i)) { sw += gload<double>(wres + i); sj += gload<double>(jres + i); ss += gload<double>(sres + i); cnt++; }
     sj = wave_sum_lane63_f64(sj); ss = wave_sum_lane63_f64(ss); sw = wave_sum_lane63_f64(sw);
     cnt = wave_sum_i32(cnt);
     if (lane == 63) { red_d[wave * 3] = sj; red_d[wave * 3 + 1] = ss; red_d[wave * 3 + 2] = sw; red_c[wave] = cnt; }
@@ -395,7 +590,7 @@ __global__ __launch_bounds__(kCoralThreads) void coral_kernel(const CoralJob* __
 #ifdef CFEAR_CORAL_TIMING
   CORAL_T(6);
   if (tid == 0 && (blockIdx.x % 997) == 0)
-    printf("coral job %d n %d W %d: bbox %lld | sort %lld | table %lld | overlap %lld | sweep %lld | reduce %lld | total %lld\n", blockIdx.x, n, W,
+    printf("coral job %d n %d W %d: bbox %lld | sort %lld | table %lld | overlap %lld | sweep %lld | reduce %lld | total %lld\n", blockIdx.x, n, *n_work,
            tq[1] - tq[0], tq[2] - tq[1], tq[3] - tq[2], tq[4] - tq[3], tq[5] - tq[4], tq[6] - tq[5], tq[6] - tq[0]);
 #endif
   if (cm.per_point) {
