@@ -73,6 +73,8 @@ struct RegCommon {
   int32_t big_mode;                           // 0: single launch | 1: first launch, registrations that only fit lds_big are deferred | 2: the deferred ones
   uint32_t lds_big;                           // dynamic LDS of the second launch (one workgroup per CU)
   int32_t only_deferred;                      // launched behind register3_kernel: only the registrations it marked kRegDeferred
+  int32_t r3_take_all;                        // register3_kernel (tests, CFEAR_REG3_LDS_KB): keep every registration that can run at all
+  int32_t pad2;
   double xy_half, yaw_half;
   const cfear_reg_result* prior;              // cost-only: source pose and itr_ come from these records (device)
 };
@@ -1356,7 +1358,8 @@ enum { SI_ITER = 0, SI_REUSE = 1, SI_INVALID = 2, SI_PUSHED = 3, SI_USABLE = 4, 
 constexpr size_t kR3StateOff = kRegFixedLds;                // behind register_kernel's fixed block
 constexpr size_t kR3FixedLds = kRegFixedLds + S_COUNT * 8;
 
-constexpr int kReg3Threads = 256;
+constexpr int kReg3NW = 4;                      // wavefronts of the regular form (three workgroups per CU)
+constexpr int kReg3NWLarge = 16;                // ... of the large form: one workgroup per CU with all of its LDS (register_large)
 constexpr size_t kReg3Lds = 52 * 1024;          // x 3 = 156 KB of the CU's 160 KB
 
 struct R3Lds {
@@ -1403,6 +1406,7 @@ __device__ __forceinline__ bool r3_carve(uint8_t* smem, size_t lds_total, int la
 }
 
 // once per registration: keyframe transforms and attribute pointers, piece prefix, source means
+template <int NT>
 __device__ bool r3_stage_once(const RegJob& job, const R3Lds& f, int* flag /* LDS */) {
   const int tid = threadIdx.x, last = job.n_scans - 1;
   if (tid == 0) {
@@ -1429,7 +1433,7 @@ __device__ bool r3_stage_once(const RegJob& job, const R3Lds& f, int* flag /* LD
   }
   const ScanView& src = job.scans[last];
   const int n_src = gload<int>(src.n_cells);
-  for (int s = tid; s < n_src; s += kReg3Threads) f.smean[s] = gload_d2(src.mean + s);
+  for (int s = tid; s < n_src; s += NT) f.smean[s] = gload_d2(src.mean + s);
   __syncthreads();
   return *flag != 0;
 }
@@ -1438,6 +1442,7 @@ __device__ bool r3_stage_once(const RegJob& job, const R3Lds& f, int* flag /* LD
 // absolute: + the keyframe's first record inside the group), then their records.  A scan keeps both in ONE block (cell starts,
 // then records: ScanView::grid_cstart), so a keyframe is a run of 16-byte pieces from one base address; four keyframes x two
 // pieces per thread are in flight before the first one is stored (one memory round trip for the usual registration).
+template <int NT>
 __device__ __forceinline__ void r3_restage(const R3Lds& f, int i0, int i1) {
   const int tid = threadIdx.x;
   const int k_lo = f.koff[i0];
@@ -1461,7 +1466,7 @@ __device__ __forceinline__ void r3_restage(const R3Lds& f, int i0, int i1) {
         add[q] = (unsigned)rel * 0x10001u;                // u16 pairs: no carry, the sums stay below 65536
 #pragma unroll
         for (int h = 0; h < kPer; h++) {
-          const int j = tid + h * kReg3Threads;
+          const int j = tid + h * NT;
           if (j < np) {
             v[q][h] = gload<g_u32x4>(blob + (size_t)j * 16);
             dst[q][h] = j < kCs ? (i - i0) * kCs + j : rec0 + rel + (j - kCs);
@@ -1480,7 +1485,7 @@ __device__ __forceinline__ void r3_restage(const R3Lds& f, int i0, int i1) {
     for (int i = ib; i < min(ib + kKf, i1); i++) {        // keyframes beyond 2 x 256 pieces (more than 383 cells): the rest
       const char* blob = (const char*)f.tptr[i * kR3Ptrs + 5];
       const int rel = f.koff[i] - k_lo, np = kCs + f.koff[i + 1] - f.koff[i];
-      for (int j = tid + kPer * kReg3Threads; j < np; j += kReg3Threads) {
+      for (int j = tid + kPer * NT; j < np; j += NT) {
         const g_u32x4 t = gload<g_u32x4>(blob + (size_t)j * 16);
         out[rec0 + rel + (j - kCs)] = make_uint4(t.x, t.y, t.z, t.w);      // (j >= 512 > kCs: records only)
       }
@@ -1493,6 +1498,7 @@ __device__ __forceinline__ void r3_restage(const R3Lds& f, int i0, int i1) {
 // the number of blocks, or -1 when a keyframe's tables do not fit the LDS region at all (register_kernel's job).
 // associate_fused's two passes with the grid edge fixed at kScanGrid; the keyframes are staged in as many groups as the
 // region needs (one, unless the scans are unusually large).
+template <int NT>
 __device__ int r3_associate(const RegJob& job, const RegCommon& cm, int itr, const R3Lds& f, const double* xsrc, double* gl_dense,
                             Dense3& dn, int* ipart, int& iphase) {
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -1521,15 +1527,15 @@ __device__ int r3_associate(const RegJob& job, const RegCommon& cm, int itr, con
     }
     if (i1 == i0) return -1;                               // (block-uniform)
     if (i0 > 0) __syncthreads();                           // the previous group's readers are done
-    r3_restage(f, i0, i1);                                 // (its barrier also publishes the transforms above)
+    r3_restage<NT>(f, i0, i1);                                 // (its barrier also publishes the transforms above)
     REG_TACC(0);
     const float4* txyi = (const float4*)(f.cstart + (size_t)(i1 - i0) * kScanGridStartPad);
     // this thread's pairs p = tid + 256 k (the SAME pairs in every group layout and in pass 2) that fall into the group
     const int lo = i0 * n_src, hi = i1 * n_src;
-    int p = lo + ((tid - lo) & (kReg3Threads - 1));
+    int p = lo + ((tid - lo) & (NT - 1));
     int i = i0, s = p - lo;
     while (s >= n_src && i < i1) { s -= n_src; i++; }
-    for (; p < hi; p += kReg3Threads) {
+    for (; p < hi; p += NT) {
       const double* T = f.kf + i * 12 + 6;
       const double2 u = f.smean[s];
       const double px = T[0] * u.x + T[1] * u.y + T[4];
@@ -1575,7 +1581,7 @@ __device__ int r3_associate(const RegJob& job, const RegCommon& cm, int itr, con
       }
       f.match[p] = (unsigned short)m;
       accepted += (m >= 0);
-      s += kReg3Threads;
+      s += NT;
       while (s >= n_src && i < i1) { s -= n_src; i++; }
     }
     REG_TACC(1);
@@ -1590,7 +1596,7 @@ __device__ int r3_associate(const RegJob& job, const RegCommon& cm, int itr, con
     for (int wv = 0; wv < wave; wv++) base += buf[wv];
     int tt = buf[0];
 #pragma unroll
-    for (int wv = 1; wv < 4; wv++) tt += buf[wv];
+    for (int wv = 1; wv < NT / 64; wv++) tt += buf[wv];
     total = __builtin_amdgcn_readfirstlane(tt);
     iphase ^= 1;
   }
@@ -1628,10 +1634,10 @@ __device__ int r3_associate(const RegJob& job, const RegCommon& cm, int itr, con
     int c = base, i = 0, s = tid;
     while (s >= n_src && i < last) { s -= n_src; i++; }
     Gathered cur = gather(tid, i, s);
-    for (int p = tid; p < n_pairs; p += kReg3Threads) {
-      s += kReg3Threads;
+    for (int p = tid; p < n_pairs; p += NT) {
+      s += NT;
       while (s >= n_src && i < last) { s -= n_src; i++; }
-      const Gathered nxt = gather(p + kReg3Threads, i, s);
+      const Gathered nxt = gather(p + NT, i, s);
       if (cur.best >= 0) {
         const double* K = f.kf + cur.i * 12;              // Ttar
         const double* T = K + 6;                          // Tsrctotar
@@ -1681,7 +1687,7 @@ __device__ int r3_associate(const RegJob& job, const RegCommon& cm, int itr, con
 }
 
 // cost, gradient and Gauss-Newton matrix of all correspondences at x (eval_all over Dense3); wavefront 0 receives the sums
-template <int COST, int LOSS>
+template <int NT, int COST, int LOSS>
 __device__ void eval_all3(const RegCommon& cm, const Dense3& dn, const double x[3], double c, double s, double out[10], double* part,
                           int& phase) {
   double acc[10];
@@ -1689,7 +1695,7 @@ __device__ void eval_all3(const RegCommon& cm, const Dense3& dn, const double x[
   for (int k = 0; k < 10; k++) acc[k] = 0.0;
   const size_t cap = (size_t)dn.cap, gcap = dn.gcap;
   REG_T0();
-  for (int i = threadIdx.x; i < dn.n; i += kReg3Threads) {
+  for (int i = threadIdx.x; i < dn.n; i += NT) {
     double tmx, tmy, w, a0 = 0.0, a1 = 0.0, a2 = 0.0;
     int si;
     if (i < (int)cap) {
@@ -1708,7 +1714,7 @@ __device__ void eval_all3(const RegCommon& cm, const Dense3& dn, const double x[
     eval_slot<COST, LOSS, true>(cm.par, sm.x, sm.y, tmx, tmy, a0, a1, a2, w, x[0], x[1], c, s, acc);
   }
   REG_TACC(4);
-  block_reduce10<4, false>(acc, part, phase);
+  block_reduce10<NT / 64, false>(acc, part, phase);
   REG_TACC(5);
 #pragma unroll
   for (int k = 0; k < 10; k++) out[k] = acc[k];
@@ -1845,7 +1851,7 @@ __device__ __forceinline__ void r3_lm_round(double* st, const double cnd[10], co
 
 // ceres::Solve for register3_kernel: lm_solve with the state in LDS.  The start pose is st[S_OUTER .. +3); the result is left
 // in the state block (S_X, S_FINAL, S_LASTREL, SI_PUSHED, SI_USABLE).  Block-wide collective.
-template <int COST, int LOSS>
+template <int NT, int COST, int LOSS>
 __device__ void lm_solve3(const RegCommon& cm, const Dense3& dn, const int max_iter, double* part, int& phase, double* st) {
   const bool w0 = (threadIdx.x >> 6) == 0;
   int* si = (int*)(st + S_INTS);
@@ -1854,7 +1860,7 @@ __device__ void lm_solve3(const RegCommon& cm, const Dense3& dn, const int max_i
     const double x[3] = {st[S_OUTER], st[S_OUTER + 1], st[S_OUTER + 2]};
     double s0, c0;
     sincos_pose<true>(x[2], &s0, &c0);
-    eval_all3<COST, LOSS>(cm, dn, x, c0, s0, cnd, part, phase);
+    eval_all3<NT, COST, LOSS>(cm, dn, x, c0, s0, cnd, part, phase);
     if (w0) {
       if ((threadIdx.x & 63) == 0) {
         st[S_X] = x[0]; st[S_X + 1] = x[1]; st[S_X + 2] = x[2]; st[S_XCOST] = cnd[0];
@@ -1882,20 +1888,22 @@ __device__ void lm_solve3(const RegCommon& cm, const Dense3& dn, const int max_i
     if (__builtin_amdgcn_readfirstlane(si[SI_DONE])) break;
     const double cand[3] = {st[S_CAND], st[S_CAND + 1], st[S_CAND + 2]};
     const double cs = st[S_COS], sn = st[S_SIN];
-    eval_all3<COST, LOSS>(cm, dn, cand, cs, sn, cnd, part, phase);        // its barrier also orders the state block
+    eval_all3<NT, COST, LOSS>(cm, dn, cand, cs, sn, cnd, part, phase);        // its barrier also orders the state block
     REG_TACC(22);
     if (w0) r3_lm_round(st, cnd, true, max_iter);
     REG_TACC(16);
   }
 }
 
-template <int COST, int LOSS>
-__global__ __launch_bounds__(kReg3Threads, 3) void register3_kernel(const RegJob* __restrict__ jobs, const RegCommon cm) {
+template <int NW, int COST, int LOSS>
+__global__ __launch_bounds__(NW * 64, NW == kReg3NW ? 3 : 4) void register3_kernel(const RegJob* __restrict__ jobs, const RegCommon cm) {
+  constexpr int NT = NW * 64;
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   double* part = (double*)smem;
   int* ipart = (int*)(smem + kRegIpartOff);
   const RegJob& job = *(const RegJob*)((const char*)jobs + (size_t)blockIdx.x * cm.job_stride);
   cfear_reg_result* res = cm.results + blockIdx.x;
+  if (cm.only_deferred && res->status != kRegDeferred) return;      // the large form: only what the launches before left
   const int last = job.n_scans - 1;
   const int n_src = gload<int>(job.scans[last].n_cells);
   int sum_tar = 0, max_tar = 0;
@@ -1904,7 +1912,13 @@ __global__ __launch_bounds__(kReg3Threads, 3) void register3_kernel(const RegJob
   R3Lds fl;
   bool ok = n_pairs <= cm.slots_cap && r3_carve(smem, cm.lds_total, last, sum_tar, n_src, n_pairs, cm.dense_fields, fl);
   ok = ok && kScanGridStartPad * 2 + max_tar * 16 <= fl.region;   // every keyframe's tables fit the region on their own
-  if (ok) ok = r3_stage_once(job, fl, ipart + 2 * kRegMaxNW - 1);
+  // ... and the registration is one this kernel is GOOD at: the keyframes' tables in at most two groups and room for 40 % of
+  // the pairs in the LDS arrays (scans of up to ~600 cells).  Beyond that (dense scenes: 1 400 cells per scan) it would
+  // restage keyframe by keyframe and evaluate mostly from global memory -- register_kernel's 80 KB / 160 KB forms are faster
+  // (1024 dense streams: 0.75 ms in this kernel before every registration was redone by register_large anyway).
+  if (ok && !cm.r3_take_all)
+    ok = last * kScanGridStartPad * 2 + sum_tar * 16 <= 2 * fl.region && 5 * fl.dense_cap >= 2 * n_pairs;
+  if (ok) ok = r3_stage_once<NT>(job, fl, ipart + 2 * kRegMaxNW - 1);
   if (!ok) {                                             // register_kernel takes it (launched behind this kernel)
     if (threadIdx.x == 0) { res->status = kRegDeferred; res->reserved = 0.0; }
     return;
@@ -1929,7 +1943,7 @@ __global__ __launch_bounds__(kReg3Threads, 3) void register3_kernel(const RegJob
   bool success = true;
   int itr = 1, lm_iters = 0, num_residuals = 0, fail_status = CFEAR_OK;
   for (itr = 1; itr <= cm.par.max_itr_association && success; itr++) {
-    const int n_blocks = r3_associate(job, cm, itr, fl, st + S_OUTER, gl_dense, dn, ipart, iphase);
+    const int n_blocks = r3_associate<NT>(job, cm, itr, fl, st + S_OUTER, gl_dense, dn, ipart, iphase);
     if (n_blocks < 0) {                                           // (block-uniform)
       if (threadIdx.x == 0) { res->status = kRegDeferred; res->reserved = 0.0; }
       return;
@@ -1937,7 +1951,7 @@ __global__ __launch_bounds__(kReg3Threads, 3) void register3_kernel(const RegJob
     num_residuals = n_blocks * rpb;
     success = num_residuals > 1;                                  // :368-369
     if (!success) { fail_status = CFEAR_ERR_TOO_FEW_RESIDUALS; break; }
-    lm_solve3<COST, LOSS>(cm, dn, cm.par.max_itr_solver, part, phase, st);
+    lm_solve3<NT, COST, LOSS>(cm, dn, cm.par.max_itr_solver, part, phase, st);
     const int* si = (const int*)(st + S_INTS);
     const int n_pushed = __builtin_amdgcn_readfirstlane(si[SI_PUSHED]);
     lm_iters += n_pushed - 1;
@@ -1976,7 +1990,7 @@ __global__ __launch_bounds__(kReg3Threads, 3) void register3_kernel(const RegJob
     res->outer_iters = itr;
     res->lm_iters = lm_iters;
     res->last_relative_decrease = st[S_LASTREL];
-    res->reserved = 0.0;
+    res->reserved = NW == kReg3NWLarge ? 1.0 : 0.0;               // a large registration: tells the caller to keep the large launches on
     if (success) { res->score = final_cost / (double)num_residuals; res->status = CFEAR_OK; }   // :162
     else { res->score = 0.0; res->status = fail_status; }
 #ifdef CFEAR_REG_TIMING
@@ -2140,7 +2154,7 @@ int cfear_register_launch(cfear_ctx* ctx, const void* d_jobs, int n_jobs, const 
   cm.cost_only = mode ? 1 : 0;
   cm.n_samples = mode ? mode->n_samples : 0;
   cm.samples_per_axis = mode ? mode->samples_per_axis : 0;
-  cm.only_deferred = 0;
+  cm.only_deferred = 0; cm.r3_take_all = 0; cm.pad2 = 0;
   cm.xy_half = mode ? mode->xy_half : 0.0;
   cm.yaw_half = mode ? mode->yaw_half : 0.0;
   cm.prior = mode ? mode->prior : nullptr;
@@ -2197,9 +2211,9 @@ int cfear_register_launch(cfear_ctx* ctx, const void* d_jobs, int n_jobs, const 
   if (use3) {
     KernelFn f3;
     switch (par->cost) {
-      case CFEAR_P2P: f3 = huber ? register3_kernel<CFEAR_P2P, CFEAR_LOSS_HUBER> : register3_kernel<CFEAR_P2P, -1>; break;
-      case CFEAR_P2L: f3 = huber ? register3_kernel<CFEAR_P2L, CFEAR_LOSS_HUBER> : register3_kernel<CFEAR_P2L, -1>; break;
-      default: f3 = huber ? register3_kernel<CFEAR_P2D, CFEAR_LOSS_HUBER> : register3_kernel<CFEAR_P2D, -1>; break;
+      case CFEAR_P2P: f3 = huber ? register3_kernel<kReg3NW, CFEAR_P2P, CFEAR_LOSS_HUBER> : register3_kernel<kReg3NW, CFEAR_P2P, -1>; break;
+      case CFEAR_P2L: f3 = huber ? register3_kernel<kReg3NW, CFEAR_P2L, CFEAR_LOSS_HUBER> : register3_kernel<kReg3NW, CFEAR_P2L, -1>; break;
+      default: f3 = huber ? register3_kernel<kReg3NW, CFEAR_P2D, CFEAR_LOSS_HUBER> : register3_kernel<kReg3NW, CFEAR_P2D, -1>; break;
     }
     // CFEAR_REG3_LDS_KB (tests): a smaller LDS so that ordinary scans exercise the keyframe groups and the global tail of the
     // dense arrays, which only unusually large registrations reach at the real size
@@ -2210,9 +2224,10 @@ int cfear_register_launch(cfear_ctx* ctx, const void* d_jobs, int n_jobs, const 
     RegCommon c3 = cm;
     c3.lds_total = (uint32_t)r3_lds;
     c3.big_mode = 0;
+    c3.r3_take_all = e_kb ? 1 : 0;
     {
       ProfScope ps(ctx, "register");
-      hipLaunchKernelGGL(f3, dim3(n_jobs), dim3(kReg3Threads), r3_lds, ctx->stream, (const RegJob*)d_jobs, c3);
+      hipLaunchKernelGGL(f3, dim3(n_jobs), dim3(kReg3NW * 64), r3_lds, ctx->stream, (const RegJob*)d_jobs, c3);
     }
     CFEAR_HIP_CHECK(ctx, hipGetLastError());
     cm.only_deferred = 1;
@@ -2234,8 +2249,29 @@ int cfear_register_launch(cfear_ctx* ctx, const void* d_jobs, int n_jobs, const 
   }
   CFEAR_HIP_CHECK(ctx, hipGetLastError());
   if (two) {
-    // Registrations the first launch deferred: 8 wavefronts and the whole LDS of a CU each.  Everything else returns at
-    // once (a batch without large scans pays a few microseconds; the caller switches this launch off when none show up).
+    // Registrations the launches above deferred (dense scenes: ~1 400 cells per scan), one workgroup per CU with all of its
+    // LDS.  First register3_kernel's large form: sixteen wavefronts (its phases need at most 128 VGPRs, so four fit a SIMD
+    // where register_kernel's 236 allow two), the keyframes' prebuilt tables staged group by group, dense arrays for ~5 000
+    // correspondences in LDS.  CFEAR_NO_REG3 leaves it out.
+    if (!getenv("CFEAR_NO_REG3")) {
+      KernelFn fl3;
+      switch (par->cost) {
+        case CFEAR_P2P: fl3 = huber ? register3_kernel<kReg3NWLarge, CFEAR_P2P, CFEAR_LOSS_HUBER> : register3_kernel<kReg3NWLarge, CFEAR_P2P, -1>; break;
+        case CFEAR_P2L: fl3 = huber ? register3_kernel<kReg3NWLarge, CFEAR_P2L, CFEAR_LOSS_HUBER> : register3_kernel<kReg3NWLarge, CFEAR_P2L, -1>; break;
+        default: fl3 = huber ? register3_kernel<kReg3NWLarge, CFEAR_P2D, CFEAR_LOSS_HUBER> : register3_kernel<kReg3NWLarge, CFEAR_P2D, -1>; break;
+      }
+      CFEAR_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)fl3, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      RegCommon c3 = cm;
+      c3.lds_total = cm.lds_big;
+      c3.big_mode = 0;
+      c3.only_deferred = 1;
+      c3.r3_take_all = 1;                                 // (whatever it still cannot run stays deferred for the launch below)
+      ProfScope ps(ctx, "register_large");
+      hipLaunchKernelGGL(fl3, dim3(n_jobs), dim3(kReg3NWLarge * 64), (size_t)cm.lds_big, ctx->stream, (const RegJob*)d_jobs, c3);
+      CFEAR_HIP_CHECK(ctx, hipGetLastError());
+    }
+    // ... then register_kernel with 8 wavefronts and the CU's LDS for what is left (scans without grid tables).  Everything
+    // else returns at once (the caller switches these launches off when no large scans show up).
     KernelFn fb;
     switch (par->cost) {
       case CFEAR_P2P: fb = huber ? register_kernel<kRegNWBig, CFEAR_P2P, CFEAR_LOSS_HUBER> : register_kernel<kRegNWBig, CFEAR_P2P, -1>; break;
@@ -2245,7 +2281,7 @@ int cfear_register_launch(cfear_ctx* ctx, const void* d_jobs, int n_jobs, const 
     CFEAR_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)fb, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     cm.big_mode = 2;
     cm.lds_total = cm.lds_big;
-    ProfScope ps(ctx, "register_large");
+    ProfScope ps(ctx, getenv("CFEAR_NO_REG3") ? "register_large" : "register_large_rest");
     hipLaunchKernelGGL(fb, dim3(n_jobs, 1), dim3(kRegNWBig * 64), (size_t)cm.lds_big, ctx->stream, (const RegJob*)d_jobs, cm);
     CFEAR_HIP_CHECK(ctx, hipGetLastError());
   }
