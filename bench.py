@@ -313,10 +313,19 @@ def loopclosure_run(D, n_cand, steps, warmup, graph=None):
     reg = api.n_scan_normal_reg("P2L", ctx=ctx)
     reg.SetParameters(4, 10)
     lo, hi, _per = cdist.shard_range(n_cand, D.world, D.rank)
-    prepared = reg.PrepareBatch(jobs[lo:hi])
-    fn = lambda _local: reg.RegisterBatch(prepared)
-    fn.into = lambda _local, ptr: reg.RegisterBatchInto(prepared, ptr)     # records stay on the GPU until the gather
+    # the scans' device views live in a table (what a loop-closure thread keeps for the graph's nodes); a candidate is two
+    # indices and two poses -- 56 bytes cross PCIe per candidate and step, the job records are written on the device
+    table = api.ScanTable(scans, ctx=ctx)
+    sid = {id(s): i for i, s in enumerate(scans)}
+
+    def to_cands(js):
+        return api.ScanTable.candidates([sid[id(j[0][0])] for j in js], [sid[id(j[0][1])] for j in js], [j[1][1] for j in js],
+                                        [j[1][0] for j in js])
+    cands = to_cands(jobs[lo:hi])
+    fn = lambda _local: reg.RegisterCandidates(table, cands)
+    fn.into = lambda _local, ptr: reg.RegisterCandidates(table, cands, device_ptr=ptr)   # records stay on the GPU until the gather
     fn.ctx = ctx
+    fn.same_stream = True                                       # the context runs on torch's current stream: no sync before the collective
     for _ in range(max(warmup, 1)):
         out = cdist.register_candidates_sharded(jobs, fn)
     D.barrier()
@@ -332,10 +341,11 @@ def loopclosure_run(D, n_cand, steps, warmup, graph=None):
     # collective, read-back) -- at 8 ranks a 4096-candidate step is 512 candidates = one wave of workgroups per rank, so a
     # strong-scaling curve is read as  step(N) ~ fixed_cost_ms + kernel_ms(1) / N
     tiny_jobs = [jobs[cdist.shard_range(n_cand, D.world, r)[0]] for r in range(D.world)]
-    tiny_prep = reg.PrepareBatch(tiny_jobs[D.rank:D.rank + 1])
-    tfn = lambda _local: reg.RegisterBatch(tiny_prep)
-    tfn.into = lambda _local, ptr: reg.RegisterBatchInto(tiny_prep, ptr)
+    tiny_c = to_cands(tiny_jobs[D.rank:D.rank + 1])
+    tfn = lambda _local: reg.RegisterCandidates(table, tiny_c)
+    tfn.into = lambda _local, ptr: reg.RegisterCandidates(table, tiny_c, device_ptr=ptr)
     tfn.ctx = ctx
+    tfn.same_stream = True
     for _ in range(3):
         cdist.register_candidates_sharded(tiny_jobs, tfn)
     D.barrier()
@@ -344,6 +354,14 @@ def loopclosure_run(D, n_cand, steps, warmup, graph=None):
         cdist.register_candidates_sharded(tiny_jobs, tfn)
     D.barrier()
     fixed_ms = D.max_over_ranks(time.perf_counter() - t2) / steps * 1e3
+    # ... of which the lone registration's own latency (a registration is a chain of dependent phases: ~0.1 ms whatever the
+    # batch) is not overhead: the same steps again with the kernels bracketed by events
+    ctx.profile_enable(True); ctx.profile_read(reset=True)
+    for _ in range(steps):
+        cdist.register_candidates_sharded(tiny_jobs, tfn)
+    D.barrier()
+    tprof = ctx.profile_read(reset=True); ctx.profile_enable(False)
+    tiny_kernel_ms = D.max_over_ranks(sum(v[0] for v in tprof.values()) / max(steps, 1))
     # What a rank of an 8-GPU run does per step, measured HERE (no 8-GPU node needed to read a future SCALE record against it):
     # the block of n / 8 candidates rank 0 would own, through the same code -- marshalling, upload, launch, the collective
     # (one rank's worth; the 8-rank all_gather moves 8 x 36 KiB over xGMI, a few microseconds more), read-back.
@@ -351,10 +369,11 @@ def loopclosure_run(D, n_cand, steps, warmup, graph=None):
     if D.world == 1 and n_cand >= 64:
         per8 = (n_cand + 7) // 8
         blk_jobs = jobs[:per8]
-        blk_prep = reg.PrepareBatch(blk_jobs)
-        bfn = lambda _local: reg.RegisterBatch(blk_prep)
-        bfn.into = lambda _local, ptr: reg.RegisterBatchInto(blk_prep, ptr)
+        blk_c = to_cands(blk_jobs)
+        bfn = lambda _local: reg.RegisterCandidates(table, blk_c)
+        bfn.into = lambda _local, ptr: reg.RegisterCandidates(table, blk_c, device_ptr=ptr)
         bfn.ctx = ctx
+        bfn.same_stream = True
         for _ in range(3):
             cdist.register_candidates_sharded(blk_jobs, bfn)
         D.barrier()
@@ -372,7 +391,8 @@ def loopclosure_run(D, n_cand, steps, warmup, graph=None):
                 "projected_efficiency_at_8": full_ms / blk_ms / 8.0,
                 "note": "measured at N = 1: the step of one rank's block (n / 8 candidates) through the same path incl. a one-rank "
                         "RCCL all_gather; an 8-rank step costs this plus the wider gather (8 x %d KiB over xGMI)" % (per8 * 72 // 1024)}
-    return {"fixed_cost_ms": fixed_ms, "kernel_ms": kernel_ms, "projected_strong_scaling": proj, "collective": "rccl all_gather" if D.dist else "none (no process group)",
+    return {"fixed_cost_ms": fixed_ms, "fixed_cost_kernel_ms": tiny_kernel_ms, "fixed_overhead_ms": max(fixed_ms - tiny_kernel_ms, 0.0),
+            "kernel_ms": kernel_ms, "projected_strong_scaling": proj, "collective": "rccl all_gather" if D.dist else "none (no process group)",
             "distinct_scans": n_frames,"metric": "loop-closure candidate registrations/sec (cached features, P2L 4x10)",
             "value": n_cand * steps / elapsed, "unit": "registrations/s", "n_gpus": D.world, "steps": steps,
             "warmup": max(warmup, 1), "ms_per_step": elapsed / steps * 1e3, "ms_per_4096": elapsed / steps * 1e3 * 4096.0 / n_cand,
@@ -780,7 +800,8 @@ def main(argv=None):
         # ---- loop-closure candidates from cached features (configs[3]) ---------------------------------------
         lc = loopclosure_run(D, args.candidates, 20, 3)
         out["loopclosure"] = {k: lc[k] for k in ("value", "unit", "ms_per_step", "ms_per_4096", "ok_fraction", "mean_outer_iters",
-                                                 "fixed_cost_ms", "kernel_ms", "collective", "distinct_scans", "projected_strong_scaling")}
+                                                 "fixed_cost_ms", "fixed_cost_kernel_ms", "fixed_overhead_ms", "kernel_ms", "collective",
+                                                 "distinct_scans", "projected_strong_scaling")}
         out["loopclosure"]["candidates"] = args.candidates
 
     # ---- CPU baseline: the oracle (port), 1 thread, bounded sample of the same frames -----------------

@@ -298,6 +298,24 @@ typedef struct cfear_reg_job {
 int cfear_register_batch(cfear_ctx* ctx, const cfear_reg_job* jobs, int32_t n_jobs,
                          const cfear_reg_params* par, cfear_reg_result* results);
 
+/* The same for a loop-closure thread that registers candidate PAIRS among scans it keeps (every graph node's
+ * cloud_normal_, types.h:119-122; loopclosure.cpp:658-721 walks the candidates of a query one by one): the scans' device
+ * views are uploaded ONCE as a table, and a batch is then 56 bytes per candidate -- two table indices and the two poses of
+ * loopclosure::Register's problem {to = fixed target, from = free source} (loopclosure.cpp:35-97) -- instead of a job
+ * record with both scans' views (608 bytes) marshalled on the host per candidate and call; the records the matcher reads
+ * are written by a small kernel on the device.  Results as for cfear_register_batch (host, or device: not synchronised).
+ * The table keeps no reference on the scans: they must outlive it.                                                  */
+typedef struct cfear_scan_table cfear_scan_table;
+typedef struct cfear_candidate {
+  int32_t target, source;               /* indices into the table */
+  double target_xyt[3], source_xyt[3];  /* Affine3dToVectorXYeZ of the two poses; the source pose is the initial guess */
+} cfear_candidate;                      /* 56 bytes */
+int cfear_scan_table_create(cfear_ctx* ctx, const cfear_scan* const* scans, int32_t n_scans, cfear_scan_table** out);
+int cfear_scan_table_size(const cfear_scan_table* table);
+int cfear_scan_table_destroy(cfear_scan_table* table);
+int cfear_register_candidates(cfear_ctx* ctx, const cfear_scan_table* table, const cfear_candidate* candidates,
+                              int32_t n_candidates, const cfear_reg_params* par, cfear_reg_result* results);
+
 /* Replaces n_scan_normal_reg::GetCost (n_scan_normal.cpp:186-211): one association pass at the
  * given poses + robust cost.  residuals (optional, host, cap entries) receives the robustified
  * residual vector; n_residuals its length; score = cost / max(n_residuals, 1).                */

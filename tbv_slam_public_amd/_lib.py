@@ -93,6 +93,10 @@ class RegJob(C.Structure):
                 ("poses_xyt", C.POINTER(C.c_double))]
 
 
+CANDIDATE_DTYPE = np.dtype([("target", "<i4"), ("source", "<i4"), ("target_xyt", "<f8", (3,)), ("source_xyt", "<f8", (3,))])
+assert CANDIDATE_DTYPE.itemsize == 56
+
+
 class CovSamplingParams(C.Structure):
     _fields_ = [("xy_range", C.c_double), ("yaw_range", C.c_double), ("samples_per_axis", C.c_int32),
                 ("pad", C.c_int32), ("covariance_scaler", C.c_double)]
@@ -211,6 +215,7 @@ EXPORTS = [
     "cfear_pose3d_from_xyt", "cfear_pose3d_to_xyt", "cfear_odometry_get_constraint",
     "cfear_shard_range", "cfear_gather_records", "cfear_register_batch_sharded", "cfear_verify_loop_candidates_sharded",
     "cfear_rccl_allgather", "cfear_rccl_allgather_device", "cfear_pgo_params_default", "cfear_pgo_solve",
+    "cfear_scan_table_create", "cfear_scan_table_size", "cfear_scan_table_destroy", "cfear_register_candidates",
 ]
 
 
@@ -278,6 +283,10 @@ def lib():
     L.cfear_ctx_profile_enable.argtypes = [vp, C.c_int]
     L.cfear_ctx_profile_read.argtypes = [vp, C.POINTER(C.c_char_p), C.POINTER(C.c_double),
                                          C.POINTER(C.c_int64), C.c_int, C.c_int]
+    L.cfear_scan_table_create.argtypes = [vp, C.POINTER(vp), C.c_int32, C.POINTER(vp)]
+    L.cfear_scan_table_size.argtypes = [vp]
+    L.cfear_scan_table_destroy.argtypes = [vp]
+    L.cfear_register_candidates.argtypes = [vp, vp, vp, C.c_int32, vp, vp]
     L.cfear_filter_kstrongest.argtypes = [vp, vp, C.POINTER(PolarDesc), C.POINTER(KStrongParams),
                                           C.POINTER(KStrongOut)]
     L.cfear_filter_cacfar.argtypes = [vp, vp, C.POINTER(PolarDesc), C.POINTER(CacfarParams), vp, vp,

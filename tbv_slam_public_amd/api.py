@@ -372,6 +372,43 @@ class MapPointNormal:
 # ------------------------------------------------------------------------------------------------
 # n_scan_normal_reg
 # ------------------------------------------------------------------------------------------------
+class ScanTable:
+    """The device views of a set of scans, uploaded once (cfear_scan_table_create): what a loop-closure thread keeps for the
+    graph nodes' cloud_normal_ (types.h:119-122) so that a candidate is two indices and two poses."""
+
+    def __init__(self, scans, ctx=None):
+        self.ctx = ctx or scans[0].ctx
+        self._scans = list(scans)                                  # the table holds no reference: keep the scans alive
+        hs = (C.c_void_p * len(scans))(*[s._h for s in scans])
+        self._h = C.c_void_p()
+        self.ctx.check(self.ctx._lib.cfear_scan_table_create(self.ctx.h, hs, len(scans), C.byref(self._h)))
+
+    def __len__(self):
+        return int(self.ctx._lib.cfear_scan_table_size(self._h))
+
+    @staticmethod
+    def candidates(targets, sources, source_xyt, target_xyt=None):
+        """CANDIDATE_DTYPE array from index arrays and [n][3] poses (target pose: the origin unless given)."""
+        n = len(targets)
+        c = np.zeros(n, L.CANDIDATE_DTYPE)
+        c["target"], c["source"] = targets, sources
+        c["source_xyt"] = np.asarray(source_xyt, dtype=np.float64).reshape(n, 3)
+        if target_xyt is not None:
+            c["target_xyt"] = np.asarray(target_xyt, dtype=np.float64).reshape(n, 3)
+        return c
+
+    def close(self):
+        if self._h:
+            self.ctx._lib.cfear_scan_table_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class n_scan_normal_reg:
     """n_scan_normal_reg(cost, loss=Huber, loss_limit=0.1, opt=Uniform) (n_scan_normal.h:35)."""
 
@@ -441,6 +478,20 @@ class n_scan_normal_reg:
         if n:
             self.ctx.check(self.ctx._lib.cfear_register_batch(self.ctx.h, arr, n, C.byref(self.par), C.c_void_p(int(device_ptr))))
         return n
+
+    def RegisterCandidates(self, table, cands, device_ptr=None):
+        """Candidate pairs among the scans of a ScanTable (cfear_register_candidates): cands = a CANDIDATE_DTYPE array
+        (ScanTable.candidates builds one) -- 56 bytes per candidate cross PCIe instead of a marshalled job record.  Returns a
+        RESULT_DTYPE array, or, with device_ptr (a device buffer of n * 72 bytes), leaves the records there without
+        synchronising and returns n."""
+        cands = np.ascontiguousarray(cands, dtype=L.CANDIDATE_DTYPE)
+        n = cands.shape[0]
+        out = None if device_ptr is not None else np.zeros(n, L.RESULT_DTYPE)
+        if n:
+            dst = C.c_void_p(int(device_ptr)) if device_ptr is not None else C.c_void_p(out.ctypes.data)
+            self.ctx.check(self.ctx._lib.cfear_register_candidates(self.ctx.h, table._h, C.c_void_p(cands.ctypes.data), n,
+                                                                   C.byref(self.par), dst))
+        return n if device_ptr is not None else out
 
     def GetCost(self, scans, Tsrc):
         """GetCost (n_scan_normal.cpp:186-211) -> (success, score(cost), residuals)."""

@@ -36,6 +36,8 @@ struct cfear_ctx {
   // pinned host staging for small read-backs
   void* pinned = nullptr;
   size_t pinned_bytes = 0;
+  hipEvent_t pinned_ev = nullptr;   // recorded behind the last asynchronous copy OUT of `pinned` (cfear_pinned_mark)
+  bool pinned_busy = false;
   // free list of scan slabs (capacity -> device pointers) so streaming does not hipMalloc
   struct Slab { void* p; int cap; };
   std::vector<Slab> free_slabs;
@@ -58,7 +60,11 @@ int cfear_set_error(cfear_ctx* ctx, int status, const char* fmt, ...);
 bool cfear_is_device_ptr(const void* p);
 // grow-only workspace `slot` of at least `bytes`; returns nullptr on allocation failure
 void* cfear_workspace(cfear_ctx* ctx, int slot, size_t bytes);
+// Pinned staging of at least `bytes`.  A caller that leaves an asynchronous copy from it in flight (results kept on the
+// device: no synchronisation before it returns) calls cfear_pinned_mark() behind the copy; cfear_pinned() then waits for
+// that copy before it hands the buffer out again.
 void* cfear_pinned(cfear_ctx* ctx, size_t bytes);
+void cfear_pinned_mark(cfear_ctx* ctx);
 
 // profiling: wrap a kernel launch
 int cfear_prof_row(cfear_ctx* ctx, const char* name);

@@ -43,7 +43,19 @@ void* cfear_workspace(cfear_ctx* ctx, int slot, size_t bytes) {
   return w.p;
 }
 
+void cfear_pinned_mark(cfear_ctx* ctx) {
+  if (!ctx->pinned_ev && hipEventCreateWithFlags(&ctx->pinned_ev, hipEventDisableTiming) != hipSuccess) {
+    (void)hipGetLastError();
+    ctx->pinned_ev = nullptr;
+    (void)hipStreamSynchronize(ctx->stream);               // no event: the copy is simply waited for here
+    return;
+  }
+  ctx->pinned_busy = hipEventRecord(ctx->pinned_ev, ctx->stream) == hipSuccess;
+  if (!ctx->pinned_busy) (void)hipStreamSynchronize(ctx->stream);
+}
+
 void* cfear_pinned(cfear_ctx* ctx, size_t bytes) {
+  if (ctx->pinned_busy) { (void)hipEventSynchronize(ctx->pinned_ev); ctx->pinned_busy = false; }
   if (ctx->pinned_bytes >= bytes && ctx->pinned) return ctx->pinned;
   if (ctx->pinned) { (void)hipStreamSynchronize(ctx->stream); (void)hipHostFree(ctx->pinned); ctx->pinned = nullptr; }
   size_t want = bytes + 4096;
@@ -255,6 +267,7 @@ int cfear_ctx_destroy(cfear_ctx* ctx) {
   for (auto& w : ctx->ws) if (w.p) (void)hipFree(w.p);
   for (auto& s : ctx->free_slabs) (void)hipFree(s.p);
   if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+  if (ctx->pinned_ev) (void)hipEventDestroy(ctx->pinned_ev);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
   return CFEAR_OK;

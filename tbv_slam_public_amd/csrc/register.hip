@@ -20,6 +20,7 @@
 // trust-region bookkeeping redundantly in registers (wave-uniform control flow, no broadcast).
 #include <cfloat>
 #include <cmath>
+#include <memory>
 
 #include "common.hpp"
 #include "fastmath.hpp"
@@ -2353,6 +2354,7 @@ int cfear_register_batch_device(cfear_ctx* ctx, const cfear_reg_job* jobs, int32
   cfear_reg_result* d_res = d_out ? d_out : (cfear_reg_result*)(ws + (jb + 255) / 256 * 256);
   if (d_used) *d_used = d_res;
   CFEAR_HIP_CHECK(ctx, hipMemcpyAsync(d_jobs, hjobs, jb, hipMemcpyHostToDevice, ctx->stream));
+  if (d_out) cfear_pinned_mark(ctx);                        // results stay on the device: nothing below waits for this copy
   // a registration whose keyframes do not fit the 80 KB association: second launch with a CU's whole LDS per workgroup
   const bool big = sz.fused_core > kRegLdsBudget;
   rc = cfear_register_launch(ctx, d_jobs, n_jobs, par, sz.slots_cap, sz.lds_targets, scr, d_res, nullptr, stride, compact, big);
@@ -2370,6 +2372,113 @@ extern "C" int cfear_register_batch(cfear_ctx* ctx, const cfear_reg_job* jobs, i
   const int rc = cfear_register_batch_device(ctx, jobs, n_jobs, par, nullptr, &d_res);
   if (rc != CFEAR_OK || n_jobs == 0) return rc;
   CFEAR_HIP_CHECK(ctx, hipMemcpyAsync(results, d_res, (size_t)n_jobs * sizeof(cfear_reg_result), hipMemcpyDeviceToHost, ctx->stream));
+  CFEAR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  return CFEAR_OK;
+}
+
+// ---- candidate pairs among a table of scans (loop closure) ---------------------------------------------------------
+struct cfear_scan_table {
+  cfear_ctx* ctx = nullptr;
+  ScanView* d_views = nullptr;          // [n] device
+  std::vector<int32_t> n_cells;         // host copy of the cell counts (launch geometry)
+};
+
+namespace {
+// candidate -> the job record register_kernel / register3_kernel read: scans {target, source}, poses {target, source guess}
+__global__ __launch_bounds__(256) void expand_candidates_kernel(const ScanView* __restrict__ views, const cfear_candidate* __restrict__ cands,
+                                                                int n, char* __restrict__ jobs, size_t stride) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const cfear_candidate c = cands[i];
+  RegJob* j = (RegJob*)(jobs + (size_t)i * stride);
+  j->n_scans = 2; j->itr = 0;
+#pragma unroll
+  for (int k = 0; k < 3; k++) { j->poses[0][k] = c.target_xyt[k]; j->poses[1][k] = c.source_xyt[k]; }
+  j->scans[0] = views[c.target];
+  j->scans[1] = views[c.source];
+}
+}  // namespace
+
+extern "C" int cfear_scan_table_create(cfear_ctx* ctx, const cfear_scan* const* scans, int32_t n_scans, cfear_scan_table** out) {
+  if (!ctx) return CFEAR_ERR_INVALID_ARGUMENT;
+  if (!scans || !out || n_scans < 1) return cfear_set_error(ctx, CFEAR_ERR_INVALID_ARGUMENT, "null argument / empty table");
+  *out = nullptr;
+  CFEAR_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  std::vector<ScanView> views((size_t)n_scans);
+  std::unique_ptr<cfear_scan_table> t(new cfear_scan_table());
+  t->ctx = ctx;
+  t->n_cells.resize((size_t)n_scans);
+  for (int i = 0; i < n_scans; i++) {
+    if (!scans[i]) return cfear_set_error(ctx, CFEAR_ERR_INVALID_ARGUMENT, "null scan handle");
+    if (scans[i]->ctx != ctx) return cfear_set_error(ctx, CFEAR_ERR_INVALID_ARGUMENT, "scan belongs to another context");
+    const int nc = cfear_scan_size(scans[i]);
+    if (nc < 0) return nc;
+    views[(size_t)i] = scans[i]->view;
+    t->n_cells[(size_t)i] = nc;
+  }
+  CFEAR_HIP_CHECK(ctx, hipMalloc((void**)&t->d_views, views.size() * sizeof(ScanView)));
+  if (hipMemcpyAsync(t->d_views, views.data(), views.size() * sizeof(ScanView), hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
+      hipStreamSynchronize(ctx->stream) != hipSuccess) {
+    (void)hipFree(t->d_views);
+    return cfear_set_error(ctx, CFEAR_ERR_HIP, "scan table upload failed");
+  }
+  *out = t.release();
+  return CFEAR_OK;
+}
+
+extern "C" int cfear_scan_table_size(const cfear_scan_table* t) { return t ? (int)t->n_cells.size() : CFEAR_ERR_INVALID_ARGUMENT; }
+
+extern "C" int cfear_scan_table_destroy(cfear_scan_table* t) {
+  if (!t) return CFEAR_OK;
+  (void)hipSetDevice(t->ctx->device);
+  (void)hipStreamSynchronize(t->ctx->stream);
+  if (t->d_views) (void)hipFree(t->d_views);
+  delete t;
+  return CFEAR_OK;
+}
+
+extern "C" int cfear_register_candidates(cfear_ctx* ctx, const cfear_scan_table* table, const cfear_candidate* cands, int32_t n,
+                                         const cfear_reg_params* par, cfear_reg_result* results) {
+  if (!ctx) return CFEAR_ERR_INVALID_ARGUMENT;
+  if (!table || !results || n < 0 || (n > 0 && !cands)) return cfear_set_error(ctx, CFEAR_ERR_INVALID_ARGUMENT, "null argument");
+  if (table->ctx != ctx) return cfear_set_error(ctx, CFEAR_ERR_INVALID_ARGUMENT, "table belongs to another context");
+  int rc = check_params(ctx, par);
+  if (rc != CFEAR_OK || n == 0) return rc;
+  CFEAR_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  const int nt = (int)table->n_cells.size();
+  const size_t stride = reg_job_stride(2);
+  const size_t cb = (size_t)n * sizeof(cfear_candidate), jb = (size_t)n * stride, rb = (size_t)n * sizeof(cfear_reg_result);
+  cfear_candidate* hc = (cfear_candidate*)cfear_pinned(ctx, cb);
+  if (!hc) return cfear_set_error(ctx, CFEAR_ERR_HIP, "pinned staging allocation failed");
+  JobSizes sz;
+  sz.cost = par->cost;
+  for (int i = 0; i < n; i++) {                             // the launch geometry: the same figures gather_job derives per job
+    const cfear_candidate& c = cands[i];
+    if (c.target < 0 || c.target >= nt || c.source < 0 || c.source >= nt)
+      return cfear_set_error(ctx, CFEAR_ERR_INVALID_ARGUMENT, "candidate %d refers to scan %d / %d of a table of %d", i, c.target, c.source, nt);
+    const int n_tar = table->n_cells[(size_t)c.target], n_src = table->n_cells[(size_t)c.source];
+    sz.lds_targets = std::max(sz.lds_targets, n_tar);
+    sz.slots_cap = std::max(sz.slots_cap, std::max(n_src, 1));
+    sz.fused_need = std::max(sz.fused_need, cfear_reg_fused_lds_need(2, n_tar, n_src, sz.cost));
+    sz.fused_core = std::max(sz.fused_core, reg_fused_lds_core(2, n_tar, n_src, sz.cost));
+    hc[i] = c;
+  }
+  const bool compact = sz.fused_need <= kRegLdsBudgetCompact && n >= 512;
+  const size_t c_off = (jb + 255) / 256 * 256, r_off = c_off + (cb + 255) / 256 * 256;
+  char* ws = (char*)cfear_workspace(ctx, 6, r_off + rb + 512);
+  char* scr = (char*)cfear_workspace(ctx, 7, reg_scratch_bytes(sz.slots_cap) * (size_t)n);
+  if (!ws || !scr) return cfear_set_error(ctx, CFEAR_ERR_HIP, "workspace allocation failed");
+  const bool dev_out = cfear_is_device_ptr(results);
+  cfear_reg_result* d_res = dev_out ? results : (cfear_reg_result*)(ws + r_off);
+  CFEAR_HIP_CHECK(ctx, hipMemcpyAsync(ws + c_off, hc, cb, hipMemcpyHostToDevice, ctx->stream));
+  if (dev_out) cfear_pinned_mark(ctx);                      // (no synchronisation below: the staging buffer stays in use)
+  hipLaunchKernelGGL(expand_candidates_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, (const ScanView*)table->d_views,
+                     (const cfear_candidate*)(ws + c_off), n, ws, stride);
+  CFEAR_HIP_CHECK(ctx, hipGetLastError());
+  rc = cfear_register_launch(ctx, ws, n, par, sz.slots_cap, sz.lds_targets, scr, d_res, nullptr, stride, compact, sz.fused_core > kRegLdsBudget);
+  if (rc != CFEAR_OK) { (void)hipStreamSynchronize(ctx->stream); return rc; }
+  if (dev_out) return CFEAR_OK;
+  CFEAR_HIP_CHECK(ctx, hipMemcpyAsync(results, d_res, rb, hipMemcpyDeviceToHost, ctx->stream));
   CFEAR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   return CFEAR_OK;
 }

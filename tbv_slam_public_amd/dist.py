@@ -117,7 +117,9 @@ def register_candidates_sharded(jobs, register_fn, group=None):
             torch.cuda.current_stream().synchronize()    # (the library writes on its own stream)
         got = register_fn.into(jobs[lo:hi], send.data_ptr())
         assert got == hi - lo
-        register_fn.ctx.synchronize()                    # the library runs on its own stream: torch must see the records
+        if not getattr(register_fn, "same_stream", False):
+            register_fn.ctx.synchronize()                # the library runs on its own stream: torch must see the records
+        # (same_stream: the context was created on torch's current stream -- the collective is simply ordered behind the kernel)
         dist.all_gather_into_tensor(b["recv_d"], send, group=group)
         b["recv_h"].copy_(b["recv_d"], non_blocking=True)
         torch.cuda.current_stream().synchronize()

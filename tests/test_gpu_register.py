@@ -520,6 +520,43 @@ def test_three_per_cu_kernel_matches_the_two_per_cu_kernel(monkeypatch):
             assert np.abs(r["pose"][:2] - po[-1, :2]).max() <= POS_TOL and abs(r["pose"][2] - po[-1, 2]) <= ROT_TOL
 
 
+def test_candidates_from_a_scan_table_equal_the_job_batch():
+    """cfear_register_candidates: the scans' views live in a device table, a candidate is two indices and two poses (56
+    bytes), the job records are written on the device.  Same kernels behind it: every record of a 600-candidate batch (the
+    compact geometry) and of a 40-candidate batch (the 8-wavefront kernel) equals cfear_register_batch's, byte for byte;
+    results left on the device read back the same; bad indices are an argument error."""
+    import torch
+    from tbv_slam_public_amd import _lib as L
+    from tbv_slam_public_amd import api
+    cells, gt = _cells(6, [0, 1, 2, 3, 4])
+    scans = [api.MapPointNormal(cells=c) for c in cells]
+    table = api.ScanTable(scans)
+    assert len(table) == 5
+    reg = api.n_scan_normal_reg("P2L")
+    reg.SetParameters(4, 10)
+    rng = np.random.default_rng(2)
+    for n in (600, 40):
+        tgt, src = rng.integers(0, 5, n), rng.integers(0, 5, n)
+        src = np.where(src == tgt, (src + 1) % 5, src)
+        tp = rng.normal(0, 0.3, (n, 3)) * [1, 1, 0.02]
+        guess = np.stack([gt[b] - gt[a] for a, b in zip(tgt, src)]) + tp + rng.normal(0, 0.3, (n, 3)) * [1, 1, 0.05]
+        jobs = [([scans[a], scans[b]], np.array([tp[i], guess[i]])) for i, (a, b) in enumerate(zip(tgt, src))]
+        ref = reg.RegisterBatch(jobs)
+        cands = api.ScanTable.candidates(tgt, src, guess, tp)
+        got = reg.RegisterCandidates(table, cands)
+        assert got.tobytes() == ref.tobytes()
+        buf = torch.zeros(n * L.RESULT_DTYPE.itemsize, dtype=torch.uint8, device="cuda")
+        assert reg.RegisterCandidates(table, cands, device_ptr=buf.data_ptr()) == n
+        reg.ctx.synchronize()
+        assert buf.cpu().numpy().tobytes() == ref.tobytes()
+        assert (ref["status"] == 0).mean() > 0.8
+    bad = api.ScanTable.candidates([0], [7], [[0, 0, 0]])
+    with pytest.raises(L.CfearError) as e:
+        reg.RegisterCandidates(table, bad)
+    assert e.value.status == L.ERR_INVALID_ARGUMENT
+    table.close()
+
+
 def _rccl():
     """librccl through ctypes: a ONE-rank communicator (ncclGetUniqueId + ncclCommInitRank), as a C++ host would own it."""
     import ctypes as C

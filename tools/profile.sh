@@ -1,11 +1,11 @@
 #!/bin/bash
 # rocprofv3 passes behind the numbers in bench.py / DESIGN.md.  Run on the GPU box from the repo root:
-#   bash tools/profile.sh r03
+#   bash tools/profile.sh r04
 # Raw output goes to /tmp (a kernel trace of torch's input generation is hundreds of MB); the judged summaries land under
 # gpurun_out/profiles_<tag>/ (copy them into profiles/<tag>/).  Counters are collected in their own passes (no trace
 # domains mixed in).
 set -u
-TAG=${1:-r03}
+TAG=${1:-r04}
 ROOT=$(pwd)
 OUT=/tmp/prof_$TAG
 SUM=$ROOT/gpurun_out/profiles_$TAG
@@ -18,7 +18,7 @@ import csv, glob, sys
 src = glob.glob(sys.argv[1] + "/**/*kernel_stats.csv", recursive=True)
 rows = list(csv.reader(open(src[0]))) if src else []
 ours = ("kstrongest_rows_kernel", "kstrong_cloud_kernel", "kstrong_image", "kstrong_extract", "kstrong_select", "kstrongest_cols", "cacfar_", "surface_", "register_kernel", "assoc_kernel", "eval_kernel",
-        "coral_kernel", "sc_descriptor", "sc_distance", "rotate_ccw", "compensate", "legacy_", "scan_sort", "cells_to_slab",
+        "register3_kernel", "coral_kernel", "sc_descriptor", "sc_distance", "rotate_ccw", "compensate", "legacy_", "scan_sort", "cells_to_slab",
         "slab_to_cells", "closest_idx")
 keep = [rows[0]] + [r for r in rows[1:] if any(k in r[0] for k in ours)] if rows else []
 csv.writer(open(sys.argv[2], "w")).writerows(keep)
@@ -60,6 +60,11 @@ export CFEAR_PMC_IMAGES=512
 keep_ours "$OUT/cacfar" "$SUM/cacfar_kernel_stats.csv"; rm -rf "$OUT/cacfar"
 ( cd /tmp && timeout 900 rocprofv3 --output-format csv --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU -d "$OUT/pmc_cacfar" -o p -- python "$ROOT/tools/cfar_events.py" 512 > /dev/null 2> "$OUT/pmc_cacfar.err" )
 ( cd /tmp && timeout 900 rocprofv3 --output-format csv --pmc FETCH_SIZE -d "$OUT/pmc_cacfar_fetch" -o p -- python "$ROOT/tools/cfar_events.py" 512 > /dev/null 2> "$OUT/pmc_cacfar_fetch.err" )
+# ... and on [range bins][azimuths] sweeps (the layout the Kvarntorp / Volvo / MulRan drivers deliver): cacfar_cols_kernel
+( cd /tmp && rocprofv3 --output-format csv --kernel-trace --stats -d "$OUT/cacfar_bm" -o c -- python "$ROOT/tools/cfar_events.py" 512 --bins-major > "$SUM/cacfar_bins_major_stdout.txt" 2> "$OUT/cacfar_bm.err" )
+keep_ours "$OUT/cacfar_bm" "$SUM/cacfar_bins_major_kernel_stats.csv"; rm -rf "$OUT/cacfar_bm"
+( cd /tmp && timeout 900 rocprofv3 --output-format csv --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU -d "$OUT/pmc_cacfar_cols" -o p -- python "$ROOT/tools/cfar_events.py" 512 --bins-major > /dev/null 2> "$OUT/pmc_cacfar_cols.err" )
+( cd /tmp && timeout 900 rocprofv3 --output-format csv --pmc FETCH_SIZE -d "$OUT/pmc_cacfar_cols_fetch" -o p -- python "$ROOT/tools/cfar_events.py" 512 --bins-major > /dev/null 2> "$OUT/pmc_cacfar_cols_fetch.err" )
 ( cd /tmp && rocprofv3 --output-format csv --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU -d "$OUT/pmc_sq" -o p -- python "$ROOT/tools/bench_filter.py" --iters 5 > /dev/null 2> "$OUT/pmc_sq.err" )
 ( cd /tmp && rocprofv3 --output-format csv --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU -d "$OUT/pmc_sq_dense" -o p -- python "$ROOT/tools/bench_filter.py" --iters 5 --data dense > /dev/null 2> "$OUT/pmc_sq_dense.err" )
 # whole pipeline under the SQ counters, SMALL run (counter collection serialises every dispatch)

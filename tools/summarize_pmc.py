@@ -57,6 +57,9 @@ if fetch and write:
     cf = _avg("pmc_cacfar_fetch", "cacfar_rows_kernel", "FETCH_SIZE")
     if cf:
         out["cacfar_rows_fetch_bytes_per_scan"] = cf * 1024.0 * 2.0 / 512
+    cc = _avg("pmc_cacfar_cols_fetch", "cacfar_cols_kernel", "FETCH_SIZE")
+    if cc:
+        out["cacfar_cols_fetch_bytes_per_scan"] = cc * 1024.0 * 2.0 / 512      # tools/cfar_events.py 512 --bins-major
     df = _avg("pmc_decode_fetch", "kstrong_image_kernel", "FETCH_SIZE")
     if df:
         out["kstrong_image_fetch_bytes_per_scan"] = df * 1024.0 * 2.0 / 512     # tools/decode_bench.py 512: [bins][azimuths] sweeps
