@@ -743,7 +743,10 @@ static int process_frame(cfear_odometry* od, const uint8_t* polar, const uint8_t
     // LDS of its CUs, so nothing co-resides: 2.51 ms per frame batch instead of 2.19.  Gated to start with the matcher,
     // to fill the ~0.2 ms in which the last uneven registrations leave CUs idle, its small workgroups took the LDS the
     // next 80 KB registration needed on every CU that drained: matcher 0.98 -> 1.47 ms, sweep 0.52 -> 1.32 ms, 2.68 ms
-    // per frame batch.)
+    // per frame batch.  Round 4, with register3_kernel's 52 KB / 127-VGPR workgroups -- three per CU, so that a finished one
+    // leaves room for the sweep beside the other two -- and the sweep enqueued behind the surface kernels on a stream of
+    // its own: matcher 1.35 -> 2.40 ms, sweep 1.12 -> 1.89 ms, 4.2 ms per 4096-stream frame batch instead of 3.5.  The
+    // sweep's short-lived workgroups keep taking the LDS a registration needs; the two do not share a CU gracefully.)
     // The next frame's filter needs no state of this frame: enqueue it now so the GPU sweeps the next
     // polar batch while the host applies the keyframe policy below.
     // A failed prefetch does not throw this frame away: its kernels already ran and its policy is applied below;
