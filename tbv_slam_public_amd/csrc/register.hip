@@ -1511,13 +1511,21 @@ __device__ int r3_associate(const RegJob& job, const RegCommon& cm, int itr, con
   const float rwin = (float)curr_radius + 1e-3f;
   constexpr int G = kScanGrid;
   REG_T0();
-  if (tid < last) {                                        // Tsrctotar_i = Ttar_i^-1 * Tsrc  (:222)
-    const double* k = f.kf + tid * 12;
-    const Aff2 Ttar{k[0], k[1], k[2], k[3], k[4], k[5]};
-    const Aff2 Tst = aff_mul(aff_inv(Ttar), aff_from_xyt(xsrc));
-    double* o = f.kf + tid * 12 + 6;
-    o[0] = Tst.l0; o[1] = Tst.l1; o[2] = Tst.l2; o[3] = Tst.l3; o[4] = Tst.t0; o[5] = Tst.t1;
-  }
+  // Tsrctotar_i = Ttar_i^-1 * Tsrc  (:222), on the last wavefront, ahead of the first group's table loads.  The
+  // rotation of the source pose by the polynomial sincos the LM loop uses for its evaluation points (an ulp or two from libm,
+  // the level at which device and host libm differ anyway; the chain is a tenth of libm's).
+  auto source_to_keyframes = [&]() {
+    const int k0 = tid - (NT - 64);
+    if (k0 >= 0 && k0 < last) {
+      const double* k = f.kf + k0 * 12;
+      const Aff2 Ttar{k[0], k[1], k[2], k[3], k[4], k[5]};
+      double sn, cs;
+      sincos_pose<true>(xsrc[2], &sn, &cs);
+      const Aff2 Tst = aff_mul(aff_inv(Ttar), Aff2{cs, -sn, sn, cs, xsrc[0], xsrc[1]});
+      double* o = f.kf + k0 * 12 + 6;
+      o[0] = Tst.l0; o[1] = Tst.l1; o[2] = Tst.l2; o[3] = Tst.l3; o[4] = Tst.t0; o[5] = Tst.t1;
+    }
+  };
   int accepted = 0;
   for (int i0 = 0; i0 < last;) {
     int i1 = i0, bytes = 0;                                // the keyframes [i0, i1) whose tables fit the region together
@@ -1528,7 +1536,8 @@ __device__ int r3_associate(const RegJob& job, const RegCommon& cm, int itr, con
     }
     if (i1 == i0) return -1;                               // (block-uniform)
     if (i0 > 0) __syncthreads();                           // the previous group's readers are done
-    r3_restage<NT>(f, i0, i1);                                 // (its barrier also publishes the transforms above)
+    if (i0 == 0) source_to_keyframes();                    // (in the shadow of the table loads it kept 25 more VGPRs live and bought nothing)
+    r3_restage<NT>(f, i0, i1);                             // (its barrier also publishes the transforms)
     REG_TACC(0);
     const float4* txyi = (const float4*)(f.cstart + (size_t)(i1 - i0) * kScanGridStartPad);
     // this thread's pairs p = tid + 256 k (the SAME pairs in every group layout and in pass 2) that fall into the group
@@ -1899,6 +1908,10 @@ __device__ void lm_solve3(const RegCommon& cm, const Dense3& dn, const int max_i
 template <int NW, int COST, int LOSS>
 __global__ __launch_bounds__(NW * 64, NW == kReg3NW ? 3 : 4) void register3_kernel(const RegJob* __restrict__ jobs, const RegCommon cm) {
   constexpr int NT = NW * 64;
+#ifdef CFEAR_REG_TIMING
+  const long long t_total0 = __builtin_readcyclecounter();
+#endif
+  REG_T0();
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   double* part = (double*)smem;
   int* ipart = (int*)(smem + kRegIpartOff);
@@ -1919,15 +1932,14 @@ __global__ __launch_bounds__(NW * 64, NW == kReg3NW ? 3 : 4) void register3_kern
   // (1024 dense streams: 0.75 ms in this kernel before every registration was redone by register_large anyway).
   if (ok && !cm.r3_take_all)
     ok = last * kScanGridStartPad * 2 + sum_tar * 16 <= 2 * fl.region && 5 * fl.dense_cap >= 2 * n_pairs;
+  REG_TACC(8);
   if (ok) ok = r3_stage_once<NT>(job, fl, ipart + 2 * kRegMaxNW - 1);
+  REG_TACC(9);
   if (!ok) {                                             // register_kernel takes it (launched behind this kernel)
     if (threadIdx.x == 0) { res->status = kRegDeferred; res->reserved = 0.0; }
     return;
   }
   double* gl_dense = (double*)(cm.scratch + (size_t)blockIdx.x * cm.scratch_stride + slots_bytes(cm.slots_cap));
-#ifdef CFEAR_REG_TIMING
-  const long long t_total0 = __builtin_readcyclecounter();
-#endif
   Dense3 dn;
   int phase = 0, iphase = 0;
   const int rpb = COST == CFEAR_P2L ? 1 : 2;
@@ -1996,8 +2008,8 @@ __global__ __launch_bounds__(NW * 64, NW == kReg3NW ? 3 : 4) void register3_kern
     else { res->score = 0.0; res->status = fail_status; }
 #ifdef CFEAR_REG_TIMING
     if (blockIdx.x == 0) {
-      printf("reg3 cycles: total %lld | restage %lld nn+gate %lld scan %lld gather %lld | eval %lld reduce %lld round %lld barrier %lld | outer %d lm %d n %d\n",
-             (long long)(__builtin_readcyclecounter() - t_total0), g_reg_t[0], g_reg_t[1], g_reg_t[2], g_reg_t[3], g_reg_t[4], g_reg_t[5],
+      printf("reg3 cycles: total %lld | sizes+carve %lld stage_once %lld | restage %lld nn+gate %lld scan %lld gather %lld | eval %lld reduce %lld round %lld barrier %lld | outer %d lm %d n %d\n",
+             (long long)(__builtin_readcyclecounter() - t_total0), g_reg_t[8], g_reg_t[9], g_reg_t[0], g_reg_t[1], g_reg_t[2], g_reg_t[3], g_reg_t[4], g_reg_t[5],
              g_reg_t[16], g_reg_t[21], itr, lm_iters, num_residuals);
       for (int k = 0; k < 32; k++) g_reg_t[k] = 0;
     }
