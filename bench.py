@@ -611,7 +611,7 @@ def main(argv=None):
     breakdown = {k: {"ms_per_frame_batch": v[0] / max(n_all, 1), "launches": int(v[1])} for k, v in prof_all.items()}
     # HBM traffic of that kernel from the committed PMC passes (rocprofv3 cannot run inside this process):
     # per-scan FETCH_SIZE x2 + WRITE_SIZE measured by tools/profile.sh, scaled to this launch's batch
-    for tag in ("r03", "r02", "r01"):
+    for tag in ("r04", "r03", "r02", "r01"):
         tj = os.path.join(ROOT, "profiles", tag, "pmc_traffic.json")
         if os.path.exists(tj):
             t = json.load(open(tj))
@@ -663,9 +663,13 @@ def main(argv=None):
     # 1 GPU only, after the timed region: extra passes and the CPU baseline
     # =====================================================================================================
     od.close()
+    skip = set(filter(None, os.environ.get("BENCH_SKIP", "").split(",")))   # debugging: leave extras out (dense,single,host,mulran)
+    def note(msg):                                              # progress on stderr (stdout carries the JSON line only)
+        sys.stderr.write("bench.py: %s\n" % msg)
+        sys.stderr.flush()
     if not args.no_extras and not (args.bins_major or args.keep_nodes or args.cov_sampling):
         # ---- dense rows: every azimuth holds >= k bins >= z_min (N_f ~ 16 000, the reference's upper bound) ----
-        if not args.dense:
+        if not args.dense and "dense" not in skip:
             Sd, Bd, nfr = 32, 1024, 24
             drings = make_rings(Sd, F, 50000, dev, dense=True)
             dss = StreamSet(Bd, Sd, F)
@@ -690,42 +694,44 @@ def main(argv=None):
             odd.close()
             del drings
         # ---- one sequence alone: the literal configs[1] case (latency-bound) ---------------------------------
-        od1 = new_fuser(1)
-        ss1 = StreamSet(1, 1, F)
-        run_odometry(od1, rings, ss1, 8)
-        D.barrier()
-        n1 = 400
-        ts = time.perf_counter()
-        st1 = run_odometry(od1, rings, ss1, n1, 8)
-        D.barrier()
-        ts = time.perf_counter() - ts
-        out["single_stream"] = {"value": n1 / ts, "unit": "registrations/s", "ms_per_frame": ts / n1 * 1e3, "frames": n1,
-                                "failed_registrations": st1["bad"],
-                                "note": "one sequence, frame t needs pose t-1: the rate is 1 / latency"}
-        od1.close()
+        if "single" not in skip:
+            od1 = new_fuser(1)
+            ss1 = StreamSet(1, 1, F)
+            run_odometry(od1, rings, ss1, 8)
+            D.barrier()
+            n1 = 400
+            ts = time.perf_counter()
+            st1 = run_odometry(od1, rings, ss1, n1, 8)
+            D.barrier()
+            ts = time.perf_counter() - ts
+            out["single_stream"] = {"value": n1 / ts, "unit": "registrations/s", "ms_per_frame": ts / n1 * 1e3, "frames": n1,
+                                    "failed_registrations": st1["bad"],
+                                    "note": "one sequence, frame t needs pose t-1: the rate is 1 / latency"}
+            od1.close()
         # ---- host-resident input: pinned images, the H2D copy inside the timed region --------------------------
-        Bh, Gh, nh = 512, 4, 12
-        hod = new_fuser(Bh)
-        hss = StreamSet(Bh, S, F)
-        host = torch.empty((Gh, Bh, ROWS, COLS), dtype=torch.uint8).pin_memory()
-        for g in range(Gh):
-            idx = torch.from_numpy(hss.seq * F + (hss.start + g) % F).to(dev)
-            host[g].copy_(rings.view(S * F, ROWS, COLS).index_select(0, idx))
-        torch.cuda.synchronize()
-        for g in range(Gh):
-            hod.process(host[g], host[(g + 1) % Gh])
-        D.barrier()
-        th = time.perf_counter()
-        for t in range(nh):
-            hod.process(host[t % Gh], host[(t + 1) % Gh])
-        D.barrier()
-        th = time.perf_counter() - th
-        out["host_input"] = {"value": Bh * nh / th, "unit": "registrations/s", "ms_per_frame_batch": th / nh * 1e3, "streams": Bh,
-                             "GBs_over_pcie": Bh * nh * IMG / th / 1e9,
-                             "note": "images in pinned host memory, one H2D copy per frame batch inside the timed region "
-                                     "(PCIe-bound; never `value`); a ring of %d frame batches cycles" % Gh}
-        hod.close()
-        del host
+        if "host" not in skip:
+            Bh, Gh, nh = 512, 4, 12
+            hod = new_fuser(Bh)
+            hss = StreamSet(Bh, S, F)
+            host = torch.empty((Gh, Bh, ROWS, COLS), dtype=torch.uint8).pin_memory()
+            for g in range(Gh):
+                idx = torch.from_numpy(hss.seq * F + (hss.start + g) % F).to(dev)
+                host[g].copy_(rings.view(S * F, ROWS, COLS).index_select(0, idx))
+            torch.cuda.synchronize()
+            for g in range(Gh):
+                hod.process(host[g], host[(g + 1) % Gh])
+            D.barrier()
+            th = time.perf_counter()
+            for t in range(nh):
+                hod.process(host[t % Gh], host[(t + 1) % Gh])
+            D.barrier()
+            th = time.perf_counter() - th
+            out["host_input"] = {"value": Bh * nh / th, "unit": "registrations/s", "ms_per_frame_batch": th / nh * 1e3, "streams": Bh,
+                                 "GBs_over_pcie": Bh * nh * IMG / th / 1e9,
+                                 "note": "images in pinned host memory, one H2D copy per frame batch inside the timed region "
+                                         "(PCIe-bound; never `value`); a ring of %d frame batches cycles" % Gh}
+            hod.close()
+            del host
         # ---- the other sensor setups of BASELINE.json, each on its own synthetic worlds ----------------------------
         # configs[2]: MulRan (sweeps arrive [range bins][azimuths], 0.0595 m bins, counter-clockwise, 5-keyframe window);
         # configs[4]: CA-CFAR on the Kvarntorp setup (0.175 m bins: 588 m range, ~15 000 detections per sweep)
@@ -767,14 +773,18 @@ def main(argv=None):
                     "mean_points_per_scan": pts / nfr, "mean_cells_per_scan": cells / nfr,
                     "failed_registrations": bad, "kernel_breakdown": {k: v[0] / max(v[1], 1) for k, v in sp.items()},
                     "note": "%d worlds x a closed lap of %d sweeps (%d distinct frames), every stream walks its lap" % (Ss, Fs, Ss * Fs)}
-        out["config2_mulran"] = side_config(api.odometry_preset("CFEAR-3", "mulran", submap_scan_size=5), 70000, 0.0595238, True, 1024, 32, 320)
+        note("extra: config2_mulran")
+        if "mulran" not in skip:
+            out["config2_mulran"] = side_config(api.odometry_preset("CFEAR-3", "mulran", submap_scan_size=5), 70000, 0.0595238, True, 1024, 32, 320)
         # Kvarntorp / Volvo sweeps reach Process() through radarDriver::Callback's rotate(.., ROTATE_90_COUNTERCLOCKWISE)
         # (radar_driver.cpp:74-90), i.e. they ARRIVE [range bins][azimuths]: that is the layout timed here (the decode fused into
         # the filter: cacfar_cols); the same run on pre-rotated sweeps -- work skipped -- is kept beside it as `prerotated_value`
         c4_par = api.odometry_params(filter_type=1, cacfar_range_res=0.175, cacfar_z_min=20.0, cacfar_nb_guard_cells=10,
                                      cacfar_window_size=40, cacfar_false_alarm_rate=0.01, radar_ccw=1, kstrong_range_res=0.175,
                                      rotate_ccw=1)
+        note("extra: config4_cacfar_kvarntorp ([bins][azimuths] input)")
         c4 = side_config(c4_par, 80000, 0.175, True, 512, 32, 480)
+        note("extra: config4_cacfar_kvarntorp (pre-rotated input)")
         c4_pre = side_config(api.odometry_params(filter_type=1, cacfar_range_res=0.175, cacfar_z_min=20.0, cacfar_nb_guard_cells=10,
                                                  cacfar_window_size=40, cacfar_false_alarm_rate=0.01, radar_ccw=1,
                                                  kstrong_range_res=0.175), 80000, 0.175, False, 512, 32, 160)
@@ -798,6 +808,7 @@ def main(argv=None):
                                            "tests/test_gpu_odometry.py::test_cacfar_pipeline_kvarntorp_preset")
         out["config4_cacfar_kvarntorp"] = c4
         # ---- loop-closure candidates from cached features (configs[3]) ---------------------------------------
+        note("extra: loopclosure")
         lc = loopclosure_run(D, args.candidates, 20, 3)
         out["loopclosure"] = {k: lc[k] for k in ("value", "unit", "ms_per_step", "ms_per_4096", "ok_fraction", "mean_outer_iters",
                                                  "fixed_cost_ms", "fixed_cost_kernel_ms", "fixed_overhead_ms", "kernel_ms", "collective",

@@ -373,6 +373,26 @@ class MapPointNormal {
 typedef boost::shared_ptr<MapPointNormal> MapNormalPtr;                                       // pointnormal.h:108
 #endif
 
+// The device views of a set of scans, uploaded once (cfear_scan_table): what the loop-closure thread keeps for the graph's
+// nodes so that a candidate is two indices and two poses.  Holds no reference on the scans.
+class ScanTable {
+ public:
+  ScanTable(Context& ctx, const std::vector<const MapPointNormal*>& scans) : ctx_(ctx), h_(nullptr) {
+    std::vector<const cfear_scan*> h(scans.size());
+    for (size_t i = 0; i < scans.size(); i++) h[i] = scans[i]->device();
+    ctx_.check(cfear_scan_table_create(ctx_.get(), h.data(), (int32_t)h.size(), &h_));
+  }
+  ~ScanTable() { if (h_) cfear_scan_table_destroy(h_); }
+  ScanTable(const ScanTable&) = delete;
+  ScanTable& operator=(const ScanTable&) = delete;
+  int size() const { return cfear_scan_table_size(h_); }
+  const cfear_scan_table* get() const { return h_; }
+
+ private:
+  Context& ctx_;
+  cfear_scan_table* h_;
+};
+
 class n_scan_normal_reg {
  public:
   explicit n_scan_normal_reg(Context& ctx, int cost = CFEAR_P2L, int loss = CFEAR_LOSS_HUBER, double loss_limit = 0.1,
@@ -448,6 +468,12 @@ class n_scan_normal_reg {
     return GetCost(h, poses, score, residuals);
   }
 #endif
+  // loopclosure::Register for a whole list of candidate pairs among the scans of a table (loopclosure.cpp:35-97 per candidate):
+  // one launch; results[i].status says what Register's bool would have.
+  void RegisterCandidates(const ScanTable& table, const std::vector<cfear_candidate>& candidates, std::vector<cfear_reg_result>& results) {
+    results.resize(candidates.size());
+    ctx_.check(cfear_register_candidates(ctx_.get(), table.get(), candidates.data(), (int32_t)candidates.size(), &par_, results.data()));
+  }
   double getScore() const { return score_; }
   bool GetCovarianceScaler(double& cov_scale) const {                                         // n_scan_normal.cpp:433-439
     if (summary_.num_residuals - 3 == 0) return false;

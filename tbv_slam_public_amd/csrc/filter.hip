@@ -1204,59 +1204,94 @@ __device__ __forceinline__ void cfar_row(const CfarArgs& a, const int lane, cons
     CFAR_T(0);
     // ---- B + C -------------------------------------------------------------------------------------------------
     int C = 0, ndet = 0;
-    auto round = [&](int k0, int cnt) {
-      const bool act = lane < cnt;
-      int bin = 0; uint32_t v = 0;
-      if (act) { bin = list[k0 + lane]; v = raw[bin]; }
-      const int t1 = bin - a.guard, t0 = t1 - a.window, f0 = bin + a.guard, f1 = f0 + a.window;   // cfar.cpp:48-53
-      const int lt0 = max(t0, 0), lf1 = min(f1, a.cols);                     // the windows as the row's ends cut them
-      const int nt = t1 - lt0, nf = lf1 - f0;
-      // getMean over an empty window is 0 / 0 = NaN: no detection (a window "ending" before bin 0 compares a size_t index
-      // with a negative end in the reference -- undefined there, no detection here)
-      const bool valid = act && nt > 0 && nf > 0;
-      const uint32_t st = P(max(t1, 0)) - P(lt0), sf = P(lf1) - P(min(f0, colsp));
-      const bool full = nt == a.window && nf == a.window;
-      bool det = false, slow = false;
+    // W candidates per lane and round (W = 1, 2): candidate k0 + 64 w + lane, w < W.  The decision of one candidate is a chain
+    // of dependent LDS reads (list -> byte and four prefixes -> table); with two per lane the two chains interleave, and a
+    // row's ~100 survivors take ONE round of 128 instead of a full and a partial round of 64 (the rounds were 38 % of a
+    // row's cycles).  Detections still leave in list (= bin) order: the first 64 candidates' keys, then the second 64's.
+    auto rounds = [&](auto w_tag, int k0, int cnt) {
+      constexpr int W = decltype(w_tag)::value;
+      bool act[W], valid[W], full[W], det[W], slow[W], edge[W];
+      int bin[W], nt[W], nf[W];
+      uint32_t v[W], st[W], sf[W];
+#pragma unroll
+      for (int w = 0; w < W; w++) {
+        act[w] = 64 * w + lane < cnt;
+        bin[w] = 0; v[w] = 0;
+        if (act[w]) bin[w] = list[k0 + 64 * w + lane];
+      }
+#pragma unroll
+      for (int w = 0; w < W; w++) if (act[w]) v[w] = raw[bin[w]];
+#pragma unroll
+      for (int w = 0; w < W; w++) {
+        const int t1 = bin[w] - a.guard, t0 = t1 - a.window, f0 = bin[w] + a.guard, f1 = f0 + a.window;   // cfar.cpp:48-53
+        const int lt0 = max(t0, 0), lf1 = min(f1, a.cols);                   // the windows as the row's ends cut them
+        nt[w] = t1 - lt0; nf[w] = lf1 - f0;
+        // getMean over an empty window is 0 / 0 = NaN: no detection (a window "ending" before bin 0 compares a size_t index
+        // with a negative end in the reference -- undefined there, no detection here)
+        valid[w] = act[w] && nt[w] > 0 && nf[w] > 0;
+        st[w] = P(max(t1, 0)) - P(lt0); sf[w] = P(lf1) - P(min(f0, colsp));
+        full[w] = nt[w] == a.window && nf[w] == a.window;
+        det[w] = false; slow[w] = false; edge[w] = false;
+      }
       if (PRE) {
-        // both windows full (every bin but the row's ends): the integer decision of step C
-        const uint32_t X = 2u * (st + sf) + 1u, L = lut[v];
-        det = valid && full && X < L;
-        slow = valid && full && X == L;
-        const bool edge = valid && !full;
-        if (__ballot(edge)) {
-          // a cut window: I^2 > scaling (S_t / n_t + S_f / n_f) / 2  <=>  I^2 2 n_t n_f > scaling (S_t n_f + S_f n_t) up to
-          // six roundings of 2^-53; the integers on both sides are exact in fp64, so unless the two sides agree to 1e-12
-          // the comparison is decided without the reference's divisions
-          const double lhs = (double)(v * v) * (double)(2 * nt * nf);
-          const double rhs = a.scaling * ((double)st * (double)nf + (double)sf * (double)nt);
-          const double d = lhs - rhs;
-          const bool sure = fabs(d) > fabs(rhs) * 1e-12;
-          if (edge) { det = sure && d > 0.0; slow = !sure; }
+        bool any_edge = false;
+#pragma unroll
+        for (int w = 0; w < W; w++) {
+          // both windows full (every bin but the row's ends): the integer decision of step C
+          const uint32_t X = 2u * (st[w] + sf[w]) + 1u, L = lut[v[w]];
+          det[w] = valid[w] && full[w] && X < L;
+          slow[w] = valid[w] && full[w] && X == L;
+          edge[w] = valid[w] && !full[w];
+          any_edge = any_edge || edge[w];
+        }
+        if (__ballot(any_edge)) {
+#pragma unroll
+          for (int w = 0; w < W; w++) {
+            // a cut window: I^2 > scaling (S_t / n_t + S_f / n_f) / 2  <=>  I^2 2 n_t n_f > scaling (S_t n_f + S_f n_t) up to
+            // six roundings of 2^-53; the integers on both sides are exact in fp64, so unless the two sides agree to 1e-12
+            // the comparison is decided without the reference's divisions
+            const double lhs = (double)(v[w] * v[w]) * (double)(2 * nt[w] * nf[w]);
+            const double rhs = a.scaling * ((double)st[w] * (double)nf[w] + (double)sf[w] * (double)nt[w]);
+            const double d = lhs - rhs;
+            const bool sure = fabs(d) > fabs(rhs) * 1e-12;
+            if (edge[w]) { det[w] = sure && d > 0.0; slow[w] = !sure; }
+          }
         }
       } else {
-        slow = valid;
+#pragma unroll
+        for (int w = 0; w < W; w++) slow[w] = valid[w];
       }
-      if (__ballot(slow)) {
-        if (slow) {                                                         // cfar.cpp:55-60, literally
-          const double trailing_mean = (double)st / (double)nt;
-          const double forwarding_mean = (double)sf / (double)nf;
-          const double mean = (trailing_mean + forwarding_mean) / 2.0;        // :56
-          const double threshold = a.scaling * mean;                          // :58
-          det = (double)(v * v) > threshold;                                  // :59-60
+      bool any_slow = false;
+#pragma unroll
+      for (int w = 0; w < W; w++) any_slow = any_slow || slow[w];
+      if (__ballot(any_slow)) {
+#pragma unroll
+        for (int w = 0; w < W; w++)
+          if (slow[w]) {                                                      // cfar.cpp:55-60, literally
+            const double trailing_mean = (double)st[w] / (double)nt[w];
+            const double forwarding_mean = (double)sf[w] / (double)nf[w];
+            const double mean = (trailing_mean + forwarding_mean) / 2.0;      // :56
+            const double threshold = a.scaling * mean;                        // :58
+            det[w] = (double)(v[w] * v[w]) > threshold;                       // :59-60
+          }
+      }
+#pragma unroll
+      for (int w = 0; w < W; w++) {
+        if (KEYS) {
+          const unsigned long long dm = __ballot(det[w]);
+          const int at = ndet + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(dm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)dm, 0u));
+          if (det[w] && at < a.kcap) a.row_keys[key_base + at] = (v[w] << 24) | (uint32_t)bin[w];
+          ndet += __popcll(dm);
+        } else {
+          if (det[w]) atomicOr(&det32[bin[w] >> 5], 1u << (bin[w] & 31));
         }
-      }
-      if (KEYS) {
-        const unsigned long long dm = __ballot(det);
-        const int at = ndet + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(dm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)dm, 0u));
-        if (det && at < a.kcap) a.row_keys[key_base + at] = (v << 24) | (uint32_t)bin;
-        ndet += __popcll(dm);
-      } else {
-        if (det) atomicOr(&det32[bin >> 5], 1u << (bin & 31));
       }
 #ifdef CFEAR_CFAR_TIMING
       nrounds++;
 #endif
     };
+    auto round = [&](int k0, int cnt) { rounds(std::integral_constant<int, 1>{}, k0, cnt); };
+    auto round2 = [&](int k0, int cnt) { rounds(std::integral_constant<int, 2>{}, k0, cnt); };
     // candidate test "byte >= t" for four bytes at once: with tl = t & 127 and y = ((x & 0x7f..) | 0x80..) - tl * 0x0101..,
     // bit 7 of a byte of y says (x & 127) >= tl; the verdict is y & x for t >= 128 and y | x below.
     const int cj_lo = a.bin_lo / CB, cj_hi = (a.bin_hi + CB - 1) / CB;      // chunks that hold bins of the range window
@@ -1310,7 +1345,7 @@ __device__ __forceinline__ void cfar_row(const CfarArgs& a, const int lane, cons
       const int pos = j * CB + lane * 4 * DJ(j);
       // the chunk's candidates -> list, behind the carried remainder, in bin order (lane, bit).  STAGED (cacfar_cols_kernel): the
       // list is shorter than a chunk + the carry, so that eight wavefronts share a CU's LDS with two 16-row tiles; a chunk whose
-      // candidates would not fit goes in two halves of 32 lanes (<= 1024 bins + 63 carried <= kCfarColsList; the pre-filter
+      // candidates would not fit goes in two halves of 32 lanes (<= 1024 bins + 127 carried <= kCfarColsList; the pre-filter
       // leaves ~100 candidates per row, so this is the exception)
       uint32_t m = cm[j];
       const int pc = __popc(m);
@@ -1335,13 +1370,15 @@ __device__ __forceinline__ void cfar_row(const CfarArgs& a, const int lane, cons
         ctot += C;
 #endif
         int k0 = 0;
-        for (; k0 + 64 <= C; k0 += 64) round(k0, 64);
-        if (k0 > 0) {                                                       // carry the remainder (< 64) to the front
+        for (; k0 + 128 <= C; k0 += 128) round2(k0, 128);
+        if (k0 > 0) {                                                       // carry the remainder (< 128) to the front
           const int rem = C - k0;
           wave_sync();
-          const unsigned short tmp = lane < rem ? list[k0 + lane] : (unsigned short)0;
+          const unsigned short tmp0 = lane < rem ? list[k0 + lane] : (unsigned short)0;
+          const unsigned short tmp1 = lane + 64 < rem ? list[k0 + 64 + lane] : (unsigned short)0;
           wave_sync();
-          if (lane < rem) list[lane] = tmp;
+          if (lane < rem) list[lane] = tmp0;
+          if (lane + 64 < rem) list[64 + lane] = tmp1;
           C = rem;
           wave_sync();
         }
@@ -1351,7 +1388,8 @@ __device__ __forceinline__ void cfar_row(const CfarArgs& a, const int lane, cons
         CFAR_T(3);
       }
     }
-    if (C > 0) round(0, C);
+    if (C > 64) round2(0, C);
+    else if (C > 0) round(0, C);
     CFAR_T(3);
     // ---- D ------------------------------------------------------------------------------------------------------
     if (KEYS) {
@@ -1513,7 +1551,7 @@ __global__ __launch_bounds__(64 * kCfarColsWaves, 4) void cacfar_cols_kernel(con
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   uint32_t* lut = (uint32_t*)smem;
-  lut[threadIdx.x] = a.lut[threadIdx.x];
+  if (threadIdx.x < 256) lut[threadIdx.x] = a.lut[threadIdx.x];   // (256 entries: the workgroup has more threads than that)
   const int colsp = a.colsp, tstride = a.need_cols + 16;      // (the arithmetic never reads a row beyond need_cols: cfar_derive)
   uint8_t* tbase = smem + 1024;                               // [kCfarTile][tstride]: row lr = source column c0 + 15 - lr
   uint8_t* wbase = tbase + (((size_t)kCfarTile * tstride + 15) & ~(size_t)15) + (size_t)wave * cfar_cols_wave_lds(colsp, a.pad_lo, a.pad_hi, CB);

@@ -1382,7 +1382,7 @@ constexpr int kR3Ptrs = 6;
 // with more correspondences than the LDS holds -- in the job's global scratch (SoA, stride gcap).  Two typed pointers, two code
 // paths per access: no generic (flat) addressing.
 struct Dense3 {
-  double* p; int* sidx; const double2* smean; int cap; int n;
+  double* p; unsigned short* sidx; const double2* smean; int cap; int n;     // (source cells < 65 536: 26 bytes per P2P pair)
   double* gp; int* gsidx; size_t gcap;
 };
 
@@ -1402,7 +1402,7 @@ __device__ __forceinline__ bool r3_carve(uint8_t* smem, size_t lds_total, int la
   f.txyi = nullptr;                                        // set per group by r3_restage
   f.dense = (double*)(smem + off);
   f.region = (int)(lds_total - off);
-  f.dense_cap = (int)((lds_total - off) / ((size_t)fields * 8 + 4)) & ~1;
+  f.dense_cap = (int)((lds_total - off) / ((size_t)fields * 8 + 2)) & ~3;
   return true;
 }
 
@@ -1610,7 +1610,7 @@ __device__ int r3_associate(const RegJob& job, const RegCommon& cm, int itr, con
     total = __builtin_amdgcn_readfirstlane(tt);
     iphase ^= 1;
   }
-  dn.p = f.dense; dn.cap = f.dense_cap; dn.sidx = (int*)(f.dense + (size_t)cm.dense_fields * f.dense_cap); dn.smean = f.smean;
+  dn.p = f.dense; dn.cap = f.dense_cap; dn.sidx = (unsigned short*)(f.dense + (size_t)cm.dense_fields * f.dense_cap); dn.smean = f.smean;
   dn.gp = gl_dense; dn.gcap = (size_t)cm.slots_cap; dn.gsidx = (int*)(gl_dense + (size_t)cm.dense_fields * cm.slots_cap);
   dn.n = total;
   const size_t cap = (size_t)dn.cap, gcap = dn.gcap;
@@ -1678,7 +1678,7 @@ __device__ int r3_associate(const RegJob& job, const RegCommon& cm, int itr, con
         }
         const int nf = cm.dense_fields;
         if (c < (int)cap) {
-          dn.sidx[c] = cur.s;
+          dn.sidx[c] = (unsigned short)cur.s;
           for (int k = 0; k < nf; k++) dn.p[k * cap + c] = e[k];
         } else {
           const size_t g = (size_t)c - cap;
@@ -1709,7 +1709,7 @@ __device__ void eval_all3(const RegCommon& cm, const Dense3& dn, const double x[
     double tmx, tmy, w, a0 = 0.0, a1 = 0.0, a2 = 0.0;
     int si;
     if (i < (int)cap) {
-      si = dn.sidx[i];
+      si = (int)dn.sidx[i];
       tmx = dn.p[i]; tmy = dn.p[cap + i]; w = dn.p[2 * cap + i];
       if (COST != CFEAR_P2P) { a0 = dn.p[3 * cap + i]; a1 = dn.p[4 * cap + i]; }
       if (COST == CFEAR_P2D) a2 = dn.p[5 * cap + i];
@@ -1924,7 +1924,7 @@ __global__ __launch_bounds__(NW * 64, NW == kReg3NW ? 3 : 4) void register3_kern
   for (int i = 0; i < last; i++) { const int n = gload<int>(job.scans[i].n_cells); sum_tar += n; max_tar = max(max_tar, n); }
   const int n_pairs = last * n_src;
   R3Lds fl;
-  bool ok = n_pairs <= cm.slots_cap && r3_carve(smem, cm.lds_total, last, sum_tar, n_src, n_pairs, cm.dense_fields, fl);
+  bool ok = n_pairs <= cm.slots_cap && n_src < 65536 && r3_carve(smem, cm.lds_total, last, sum_tar, n_src, n_pairs, cm.dense_fields, fl);
   ok = ok && kScanGridStartPad * 2 + max_tar * 16 <= fl.region;   // every keyframe's tables fit the region on their own
   // ... and the registration is one this kernel is GOOD at: the keyframes' tables in at most two groups and room for 40 % of
   // the pairs in the LDS arrays (scans of up to ~600 cells).  Beyond that (dense scenes: 1 400 cells per scan) it would

@@ -68,6 +68,14 @@ int main(int argc, char** argv) {
       cfear_reg_result rr{};
       ctx.check(cfear_register_batch_sharded(ctx.get(), &job, 1, &par, 0, 1, nullptr, nullptr, &rr));
       if (rr.pose[0] != T[1].x || rr.pose[1] != T[1].y || rr.pose[2] != T[1].theta) throw CfearError(-1, "sharded entry disagrees");
+      // ... and as a candidate pair among the scans of a device-resident table (cfear_register_candidates)
+      ScanTable table(ctx, {&m0, &m1});
+      n_scan_normal_reg creg(ctx, CFEAR_P2L);
+      creg.SetParameters(4, 10);
+      std::vector<cfear_reg_result> cres;
+      creg.RegisterCandidates(table, {cfear_candidate{0, 1, {0, 0, 0}, {2.0, 0.0, 0.0}}}, cres);
+      if (table.size() != 2 || cres[0].pose[0] != T[1].x || cres[0].pose[1] != T[1].y || cres[0].pose[2] != T[1].theta)
+        throw CfearError(-1, "candidate table disagrees");
     }
     double cov[36];
     cfear_cov_sampling_params sp;

@@ -2,7 +2,7 @@
 (rotate_ccw_rows_kernel, then kstrongest_rows_kernel) on N distinct MulRan-shaped images resident in HBM.
     python tools/decode_bench.py [N] [--two-pass | --tile | --lists | --image] [--iters K] [--zmin Z] [--dense]
 Prints the average time of one pass (hipEvents on the context's stream).  Under rocprofv3 (--kernel-trace --stats, or
---pmc FETCH_SIZE) it is the workload behind profiles/r03/decode_*.
+--pmc FETCH_SIZE) it is the workload behind profiles/r0N/decode_*.
 """
 import os
 import sys
