@@ -674,11 +674,11 @@ def main(argv=None):
             drings = make_rings(Sd, F, 50000, dev, dense=True)
             dss = StreamSet(Bd, Sd, F)
             odd = new_fuser(Bd)
-            run_odometry(odd, drings, dss, 4)
+            run_odometry(odd, drings, dss, 16)                   # (until every stream's keyframe window is full: the steady state)
             D.barrier()
             ctx.profile_enable(True); ctx.profile_read(reset=True)
             td = time.perf_counter()
-            dst = run_odometry(odd, drings, dss, nfr, 4)
+            dst = run_odometry(odd, drings, dss, nfr, 16)
             D.barrier()
             td = time.perf_counter() - td
             dprof = ctx.profile_read(reset=True); ctx.profile_enable(False)
