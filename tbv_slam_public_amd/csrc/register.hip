@@ -1933,7 +1933,7 @@ __global__ __launch_bounds__(NW * 64, NW == kReg3NW ? 3 : 4) void register3_kern
   if (ok && !cm.r3_take_all)
     ok = last * kScanGridStartPad * 2 + sum_tar * 16 <= 2 * fl.region && 5 * fl.dense_cap >= 2 * n_pairs;
   REG_TACC(8);
-  if (ok) ok = r3_stage_once<NT>(job, fl, ipart + 2 * kRegMaxNW - 1);
+  if (ok) ok = r3_stage_once<NT>(job, fl, (int*)(smem + kR3StateOff + S_INTS * 8) + 7);   // (the state block's spare int)
   REG_TACC(9);
   if (!ok) {                                             // register_kernel takes it (launched behind this kernel)
     if (threadIdx.x == 0) { res->status = kRegDeferred; res->reserved = 0.0; }

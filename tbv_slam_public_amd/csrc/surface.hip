@@ -1305,7 +1305,7 @@ __global__ __launch_bounds__(kFastThreads, 4) void surface_sort_kernel(const Sur
   //      global scratch (L2) and stage them slab by slab. ------------------------------------------------------------
   const size_t avail_all = kFastLds - 512 - ord2_off;
   const int cap_all = (n + 3) & ~3;
-  const bool single = V <= 4 * NT && (size_t)cap_all * (wbyte ? 9 : 12) + (size_t)V * 2 + 16 <= avail_all;
+  const bool single = V <= 4 * NT && (size_t)cap_all * (wbyte ? 9 : 12) + (size_t)V * 6 + 48 <= avail_all;   // points + per voxel: list entry (2) + grid position (4)
   if (single) {
 #pragma unroll
     for (int j = 0; j < kPer; j++) {
@@ -1372,7 +1372,7 @@ __global__ __launch_bounds__(kFastThreads, 4) void surface_sort_kernel(const Sur
     // a slab fits when its points (PB bytes each, padded) and its voxel list (2 bytes each) fit the staging area
     auto fits = [&](int yb) {
       const int np = pbefore(min(yb + 1, dby) * dbx) - P0, nv = ord(yb * dbx) - vbeg;
-      return nv <= kSlabVoxels && (size_t)((np + 3) & ~3) * PB + (size_t)nv * 2 + 16 <= avail;
+      return nv <= kSlabVoxels && (size_t)((np + 3) & ~3) * PB + (size_t)nv * 6 + 48 <= avail;
     };
     int lo = ya + 1, hi = dby;                                        // largest yb in [ya + 1, dby] that fits
     if (!fits(lo)) { hand_over(n, 1); return false; }                 // three grid rows exceed the staging area
@@ -1387,6 +1387,15 @@ __global__ __launch_bounds__(kFastThreads, 4) void surface_sort_kernel(const Sur
     uint8_t* lw = (uint8_t*)(smem + ord2_off + (size_t)cap_pts * 8);
     float* lwf = (float*)lw;
     unsigned short* vlist = (unsigned short*)(smem + ord2_off + (((size_t)cap_pts * PB + 15) & ~(size_t)15));
+    // grid position of the slab's voxels, (iy << 18 | ix), next to the list: runs_of() reads it for every voxel in the
+    // classification and again in its tier -- from global scratch that was an exposed L2 round trip (and an integer
+    // division) at the head of every round of every tier
+    uint32_t* vxy = (uint32_t*)((uint8_t*)vlist + ((((size_t)(vend - vbeg)) * 2 + 15) & ~(size_t)15));
+    for (int i = tid; i < vend - vbeg; i += NT) {
+      const uint32_t key = gload<uint32_t>(scr.vkey + vbeg + i);
+      const uint32_t iy = key / (uint32_t)dbx;
+      vxy[i] = (iy << 18) | (key - iy * (uint32_t)dbx);               // dbx * dby <= 2^18 cells, dby <= 4096 rows
+    }
     if (!single)
       for (int i = tid; i < P1 - P0; i += NT) {
         const float4 q = gload_f4(scr.spt + P0 + i);
@@ -1398,9 +1407,9 @@ __global__ __launch_bounds__(kFastThreads, 4) void surface_sort_kernel(const Sur
     STAMP(11);
     // neighbour runs of voxel v (relative to the staging area) and its own run
     auto runs_of = [&](int v, int* r0, int* r1, int& s, int& e) {
-      const uint32_t key = gload<uint32_t>(scr.vkey + v);
+      const uint32_t kxy = vxy[v - vbeg];
       s = (v ? (int)vs16[v - 1] : 0) - P0; e = (int)vs16[v] - P0;
-      const int iy = (int)(key / (uint32_t)dbx), ix = (int)(key - (uint32_t)iy * (uint32_t)dbx);
+      const int iy = (int)(kxy >> 18), ix = (int)(kxy & 0x3ffffu);
       const int x0 = max(ix - 1, 0), x1 = min(ix + 1, dbx - 1);
 #pragma unroll
       for (int d = 0; d < 3; d++) {
