@@ -1146,32 +1146,39 @@ __global__ __launch_bounds__(kFastThreads, 4) void surface_sort_kernel(const Sur
   __syncthreads();                                                   // rowoff is dead
   for (int w = tid; w < nw32; w += NT) occ[w] = 0u;
   __syncthreads();
+  STAMP(9);
+  const int jn = (n + NT - 1) / NT;                                   // rounds of NT points (<= kPer)
+  auto idx_of = [&](int j) { return tid + j * NT; };
   unsigned short mycell[kPer];                                        // the cells of this thread's points (registers); later their voxels
   bool w_small = true;                                                // every weight max(I - 60, 0) an integer in [0, 255]?
 #pragma unroll
   for (int j0 = 0; j0 < kPer; j0 += 8) {                              // eight loads in flight per thread
-    float4 pp[8];
+    if (j0 < jn) {
+      float4 pp[8];
 #pragma unroll
-    for (int u = 0; u < 8; u++) {
-      const int i = tid + (j0 + u) * NT;
-      if (i < n) pp[u] = gload_f4(pts + i);                              // (global_load, not flat_load: gload's comment in common.hpp)
-    }
+      for (int u = 0; u < 8; u++) {
+        const int i = idx_of(j0 + u);
+        if (i < n) pp[u] = gload_f4(pts + i);           // (global_load, not flat_load: gload's comment in common.hpp)
+      }
 #pragma unroll
-    for (int u = 0; u < 8; u++) {
-      const int j = j0 + u, i = tid + j * NT;
-      mycell[j] = 0;
-      if (i < n) {
-        const float4 p = pp[u];
-        const int ijk0 = (int)(floorf(p.x * cm.inv_leaf) - (float)min_bx);
-        const int ijk1 = (int)(floorf(p.y * cm.inv_leaf) - (float)min_by);
-        const int c = ijk0 + ijk1 * dbx;
-        mycell[j] = (unsigned short)c;                                  // complete for grids up to 65 536 cells
-        atomicOr(&occ[c >> 5], 1u << (c & 31));
-        const float wgt = fmaxf(__fsub_rn(p.w, 60.0f), 0.0f);
-        w_small = w_small && wgt <= 255.0f && wgt == truncf(wgt);
+      for (int u = 0; u < 8; u++) {
+        const int j = j0 + u, i = idx_of(j);
+        mycell[j] = 0;
+        if (i < n) {
+          const float4 p = pp[u];
+          const int ijk0 = (int)(floorf(p.x * cm.inv_leaf) - (float)min_bx);
+          const int ijk1 = (int)(floorf(p.y * cm.inv_leaf) - (float)min_by);
+          const int c = ijk0 + ijk1 * dbx;
+          mycell[j] = (unsigned short)c;                                // complete for grids up to 65 536 cells
+          atomicOr(&occ[c >> 5], 1u << (c & 31));
+          const float wgt = fmaxf(__fsub_rn(p.w, 60.0f), 0.0f);
+          w_small = w_small && wgt <= 255.0f && wgt == truncf(wgt);
+        }
       }
     }
+    if (j0 == 0) STAMP(16);
   }
+  STAMP(17);
   const bool wbyte = __syncthreads_and(w_small ? 1 : 0) != 0;
   STAMP(3);
   // ---- (d) occupied cells before every word (exclusive scan of the popcounts); the voxel keys in cell order --------
@@ -1186,28 +1193,45 @@ __global__ __launch_bounds__(kFastThreads, 4) void surface_sort_kernel(const Sur
   for (int wv = 0; wv < NW; wv++) { if (wv < wave) excl += red_i[wv]; V += red_i[wv]; }
   // LDS budget: occupancy | voxel cursors u16[V + 2] | order u16[n] (later: staged points)
   const size_t vs_off = ord_bytes, vs_bytes = (((size_t)V + 2) * 2 + 15) & ~(size_t)15;
-  const size_t ord2_off = vs_off + vs_bytes, need = ord2_off + (((size_t)n * 2 + 15) & ~(size_t)15);
-  if (need > kFastLds - 512) { hand_over(n, 1); return; }
+  const size_t ord2_off = vs_off + vs_bytes;
+  if (ord2_off + (((size_t)n * 2 + 15) & ~(size_t)15) > kFastLds - 512) { hand_over(n, 1); return; }
   unsigned short* vs16 = (unsigned short*)(smem + vs_off);
   uint32_t* vs32 = (uint32_t*)(smem + vs_off);
   unsigned short* order = (unsigned short*)(smem + ord2_off);
+  // Staging area (from ord2_off on, reusing the order array's LDS): points (x, y) 8 bytes + weight 1 or 4 bytes, then per
+  // voxel of the slab a list entry (2 bytes) and its grid position (iy << 18 | ix, 4 bytes).  A scan whose points and
+  // voxels fit at once (the usual 5 000-point scan) is ONE slab, known here -- its grid positions are written right
+  // where the keys are produced instead of being read back from global scratch at the head of the cells phase.
+  const size_t avail_all = kFastLds - 512 - ord2_off;
+  const int cap_all = (n + 3) & ~3;
+  const bool single = V <= 4 * NT && (size_t)cap_all * (wbyte ? 9 : 12) + (size_t)V * 6 + 48 <= avail_all;
+  auto vlist_off = [&](int cap_pts, int pb) { return ord2_off + (((size_t)cap_pts * pb + 15) & ~(size_t)15); };
+  auto vxy_off = [&](int cap_pts, int pb, int nv) { return vlist_off(cap_pts, pb) + (((size_t)nv * 2 + 15) & ~(size_t)15); };
   {
+    uint32_t* vxy1 = (uint32_t*)(smem + vxy_off(cap_all, wbyte ? 9 : 12, V));        // (behind the order array: 9 n > 2 n)
     int run_o = excl;
     for (int w = w0; w < w1; w++) {
       wpref[w] = (unsigned short)run_o;
       uint32_t bits = occ[w];
-      while (bits) { const int t = __ffs(bits) - 1; bits &= bits - 1; scr.vkey[run_o++] = (uint32_t)(32 * w + t); }
+      while (bits) {
+        const int t = __ffs(bits) - 1; bits &= bits - 1;
+        const uint32_t key = (uint32_t)(32 * w + t);
+        if (single) { const uint32_t iy = key / (uint32_t)dbx; vxy1[run_o] = (iy << 18) | (key - iy * (uint32_t)dbx); }
+        scr.vkey[run_o++] = key;
+      }
     }
   }
   for (int k = tid; k < (V + 3) / 2; k += NT) vs32[k] = 0u;           // per-voxel point counters
   __syncthreads();
+  STAMP(10);
   auto ord = [&](int c) { const int w = c >> 5; return (int)wpref[w] + __popc(occ[w] & ((1u << (c & 31)) - 1u)); };
-  // points per voxel; mycell[] holds the VOXEL (ordinal) of each point from here on.  Grids beyond 65 536 cells (long-range
-  // sensors) read the points a second time (L2): their cell needs 18 bits, and 32 more registers spilled the kernel.
+  // points per voxel; mycell[] holds the VOXEL (ordinal) of each point from here on.  Grids beyond 65 536
+  // cells (long-range sensors) read the points a second time (L2): their cell needs 18 bits, and 32 more registers
+  // spilled the kernel.
   if (ncells <= 65536) {
 #pragma unroll
     for (int j = 0; j < kPer; j++) {
-      const int i = tid + j * NT;
+      const int i = idx_of(j);
       if (i < n) {
         const int v = ord((int)mycell[j]);
         mycell[j] = (unsigned short)v;
@@ -1217,21 +1241,23 @@ __global__ __launch_bounds__(kFastThreads, 4) void surface_sort_kernel(const Sur
   } else {
 #pragma unroll
     for (int j0 = 0; j0 < kPer; j0 += 8) {
-      float2 pq[8];
+      if (j0 < jn) {
+        float2 pq[8];
 #pragma unroll
-      for (int u = 0; u < 8; u++) {
-        const int i = tid + (j0 + u) * NT;
-        if (i < n) { const g_f32x2 t = gload<g_f32x2>(pts + i); pq[u] = make_float2(t.x, t.y); }
-      }
+        for (int u = 0; u < 8; u++) {
+          const int i = idx_of(j0 + u);
+          if (i < n) { const g_f32x2 t = gload<g_f32x2>(pts + i); pq[u] = make_float2(t.x, t.y); }
+        }
 #pragma unroll
-      for (int u = 0; u < 8; u++) {
-        const int j = j0 + u, i = tid + j * NT;
-        if (i < n) {
-          const int ijk0 = (int)(floorf(pq[u].x * cm.inv_leaf) - (float)min_bx);
-          const int ijk1 = (int)(floorf(pq[u].y * cm.inv_leaf) - (float)min_by);
-          const int v = ord(ijk0 + ijk1 * dbx);
-          mycell[j] = (unsigned short)v;
-          atomicAdd(&vs32[v >> 1], (v & 1) ? 0x10000u : 1u);
+        for (int u = 0; u < 8; u++) {
+          const int j = j0 + u, i = idx_of(j);
+          if (i < n) {
+            const int ijk0 = (int)(floorf(pq[u].x * cm.inv_leaf) - (float)min_bx);
+            const int ijk1 = (int)(floorf(pq[u].y * cm.inv_leaf) - (float)min_by);
+            const int v = ord(ijk0 + ijk1 * dbx);
+            mycell[j] = (unsigned short)v;
+            atomicAdd(&vs32[v >> 1], (v & 1) ? 0x10000u : 1u);
+          }
         }
       }
     }
@@ -1251,10 +1277,10 @@ __global__ __launch_bounds__(kFastThreads, 4) void surface_sort_kernel(const Sur
   }
   __syncthreads();
   STAMP(4);
-  // ---- (e) scatter: the atomic cursor of a voxel ends at the start of the next one --------------------------------
+  // ---- (e) scatter: the atomic cursor of a voxel ends at the start of the next one ------------------------------
 #pragma unroll
   for (int j = 0; j < kPer; j++) {
-    const int i = tid + j * NT;
+    const int i = idx_of(j);
     if (i < n) {
       const int v = (int)mycell[j];
       const uint32_t old = atomicAdd(&vs32[v >> 1], (v & 1) ? 0x10000u : 1u);
@@ -1267,7 +1293,7 @@ __global__ __launch_bounds__(kFastThreads, 4) void surface_sort_kernel(const Sur
   // ---- (f) input order inside every voxel: rank of a point among its voxel's points (runs are a few points long) ---
 #pragma unroll
   for (int j = 0; j < kPer; j++) {
-    const int i = tid + j * NT;
+    const int i = idx_of(j);
     if (i < n) {
       const int v = (int)mycell[j];
       const int s0 = v ? (int)vs16[v - 1] : 0, e0 = (int)vs16[v];
@@ -1291,56 +1317,41 @@ __global__ __launch_bounds__(kFastThreads, 4) void surface_sort_kernel(const Sur
       mycell[j] = (unsigned short)(s0 + rank);
     }
   }
-  __syncthreads();
-#pragma unroll
-  for (int j = 0; j < kPer; j++) {
-    const int i = tid + j * NT;
-    if (i < n) order[mycell[j]] = (unsigned short)i;
-  }
-  __syncthreads();
+  __syncthreads();                                                     // the order array is dead: its LDS becomes the staging area
   STAMP(6);
-  // ---- (g) sorted points.  A scan whose points and voxel list fit the staging area at once (the usual 5 000-point
-  //      scan) gathers them from the cloud straight into LDS: every thread first takes its entries of the order array
-  //      into registers, because the staging area reuses that array's LDS.  Larger scans park the sorted points in
-  //      global scratch (L2) and stage them slab by slab. ------------------------------------------------------------
-  const size_t avail_all = kFastLds - 512 - ord2_off;
-  const int cap_all = (n + 3) & ~3;
-  const bool single = V <= 4 * NT && (size_t)cap_all * (wbyte ? 9 : 12) + (size_t)V * 6 + 48 <= avail_all;   // points + per voxel: list entry (2) + grid position (4)
-  if (single) {
-#pragma unroll
-    for (int j = 0; j < kPer; j++) {
-      const int pos = tid + j * NT;
-      if (pos < n) mycell[j] = order[pos];
-    }
-    __syncthreads();                                                   // the order array is dead
+  // ---- (g) sorted points.  mycell[j] is now the POSITION of the thread's j-th point in the sorted array, so every thread
+  //      re-reads its own points (coalesced, L2) and puts them in place: a one-slab scan straight into the LDS staging
+  //      area, larger scans into global scratch (L2) from where the slabs are staged.  The staged copies carry the
+  //      point's WEIGHT max(I - 60, 0) (pointnormal.cpp:15), not its intensity: float(I) - 60 is exact for I >= 60, so
+  //      the fp64 weight of the reference is just its widening. --------------------------------------------------------
+  {
     float2* sxy = (float2*)(smem + ord2_off);
     uint8_t* sw = (uint8_t*)(smem + ord2_off + (size_t)cap_all * 8);
     float* swf = (float*)sw;
 #pragma unroll
-    for (int j0 = 0; j0 < kPer; j0 += 8) {                            // eight gathers in flight per thread
-      float4 pp[8];
+    for (int j0 = 0; j0 < kPer; j0 += 8) {                            // eight loads in flight per thread
+      if (j0 < jn) {
+        float4 pp[8];
 #pragma unroll
-      for (int u = 0; u < 8; u++)
-        if (tid + (j0 + u) * NT < n) pp[u] = gload_f4(pts + mycell[j0 + u]);
+        for (int u = 0; u < 8; u++)
+          if (idx_of(j0 + u) < n) pp[u] = gload_f4(pts + idx_of(j0 + u));
 #pragma unroll
-      for (int u = 0; u < 8; u++) {
-        const int pos = tid + (j0 + u) * NT;
-        if (pos < n) {
-          const float4 p = pp[u];
-          // the staged copies carry the point's WEIGHT max(I - 60, 0) (pointnormal.cpp:15), not its intensity: float(I) - 60
-          // is exact for I >= 60, so the fp64 weight of the reference is just its widening
-          const float wgt = fmaxf(__fsub_rn(p.w, 60.0f), 0.0f);
-          sxy[pos] = make_float2(p.x, p.y);
-          if (wbyte) sw[pos] = (uint8_t)wgt; else swf[pos] = wgt;
+        for (int u = 0; u < 8; u++) {
+          if (idx_of(j0 + u) < n) {
+            const float4 p = pp[u];
+            const int pos = (int)mycell[j0 + u];
+            const float wgt = fmaxf(__fsub_rn(p.w, 60.0f), 0.0f);
+            if (single) {
+              sxy[pos] = make_float2(p.x, p.y);
+              if (wbyte) sw[pos] = (uint8_t)wgt; else swf[pos] = wgt;
+            } else {
+              scr.spt[pos] = make_float4(p.x, p.y, wgt, 0.f);
+            }
+          }
         }
       }
     }
-  } else {
-    for (int pos = tid; pos < n; pos += NT) {
-      const float4 p = gload_f4(pts + order[pos]);
-      scr.spt[pos] = make_float4(p.x, p.y, fmaxf(__fsub_rn(p.w, 60.0f), 0.0f), 0.f);
-    }
-    __threadfence_block();
+    if (!single) __threadfence_block();
   }
   __syncthreads();
   STAMP(7);
@@ -1367,35 +1378,42 @@ __global__ __launch_bounds__(kFastThreads, 4) void surface_sort_kernel(const Sur
   const size_t avail = kFastLds - 512 - ord2_off;
   const bool wi = cm.weight_intensity != 0;
   for (int ya = 0; ya < dby;) {                                       // block-uniform
-    const int P0 = pbefore(max(ya - 1, 0) * dbx);
-    const int vbeg = ord(ya * dbx);
+    const int P0 = single ? 0 : pbefore(max(ya - 1, 0) * dbx);
+    const int vbeg = single ? 0 : ord(ya * dbx);
     // a slab fits when its points (PB bytes each, padded) and its voxel list (2 bytes each) fit the staging area
     auto fits = [&](int yb) {
       const int np = pbefore(min(yb + 1, dby) * dbx) - P0, nv = ord(yb * dbx) - vbeg;
       return nv <= kSlabVoxels && (size_t)((np + 3) & ~3) * PB + (size_t)nv * 6 + 48 <= avail;
     };
-    int lo = ya + 1, hi = dby;                                        // largest yb in [ya + 1, dby] that fits
-    if (!fits(lo)) { hand_over(n, 1); return false; }                 // three grid rows exceed the staging area
+    int lo = single ? dby : ya + 1, hi = dby;                         // largest yb in [ya + 1, dby] that fits (one-slab scan: known)
+    if (!single && !fits(lo)) { hand_over(n, 1); return false; }      // three grid rows exceed the staging area
     while (lo < hi) {
       const int mid = (lo + hi + 1) >> 1;
       if (fits(mid)) lo = mid; else hi = mid - 1;
     }
     const int yb = lo;
-    const int P1 = pbefore(min(yb + 1, dby) * dbx);
-    const int vend = ord(yb * dbx);
+    const int P1 = single ? n : pbefore(min(yb + 1, dby) * dbx);
+    const int vend = single ? V : ord(yb * dbx);
     const int cap_pts = (P1 - P0 + 3) & ~3;
     uint8_t* lw = (uint8_t*)(smem + ord2_off + (size_t)cap_pts * 8);
     float* lwf = (float*)lw;
-    unsigned short* vlist = (unsigned short*)(smem + ord2_off + (((size_t)cap_pts * PB + 15) & ~(size_t)15));
+    unsigned short* vlist = (unsigned short*)(smem + vlist_off(cap_pts, PB));
     // grid position of the slab's voxels, (iy << 18 | ix), next to the list: runs_of() reads it for every voxel in the
     // classification and again in its tier -- from global scratch that was an exposed L2 round trip (and an integer
-    // division) at the head of every round of every tier
-    uint32_t* vxy = (uint32_t*)((uint8_t*)vlist + ((((size_t)(vend - vbeg)) * 2 + 15) & ~(size_t)15));
-    for (int i = tid; i < vend - vbeg; i += NT) {
-      const uint32_t key = gload<uint32_t>(scr.vkey + vbeg + i);
-      const uint32_t iy = key / (uint32_t)dbx;
-      vxy[i] = (iy << 18) | (key - iy * (uint32_t)dbx);               // dbx * dby <= 2^18 cells, dby <= 4096 rows
-    }
+    // division) at the head of every round of every tier.  (A one-slab scan's were written in phase (d).)
+    const size_t vxy_o = vxy_off(cap_pts, PB, vend - vbeg);
+    uint32_t* vxy = (uint32_t*)(smem + vxy_o);
+    // float centroids of the split voxels, by list position, for as many as still fit behind the grid positions (the
+    // rest go through the voxel's scratch slot: a global round trip at the head of a tier's round)
+    const size_t cen_o = (vxy_o + (size_t)(vend - vbeg) * 4 + 7) & ~(size_t)7;
+    float2* cen = (float2*)(smem + cen_o);
+    const int cen_cap = cen_o < kFastLds - 512 ? (int)((kFastLds - 512 - cen_o) / 8) : 0;
+    if (!single)
+      for (int i = tid; i < vend - vbeg; i += NT) {
+        const uint32_t key = gload<uint32_t>(scr.vkey + vbeg + i);
+        const uint32_t iy = key / (uint32_t)dbx;
+        vxy[i] = (iy << 18) | (key - iy * (uint32_t)dbx);             // dbx * dby <= 2^18 cells, dby <= 4096 rows
+      }
     if (!single)
       for (int i = tid; i < P1 - P0; i += NT) {
         const float4 q = gload_f4(scr.spt + P0 + i);
@@ -1471,7 +1489,9 @@ __global__ __launch_bounds__(kFastThreads, 4) void surface_sort_kernel(const Sur
       for (; p < e; p++) { const float2 q = lxy[p]; ax = __fadd_rn(ax, q.x); ay = __fadd_rn(ay, q.y); }
       const float cnt = (float)(e - s);
       CellMom* cmo = (CellMom*)&scr.tmp[v];
-      cmo->cx = __fdiv_rn(ax, cnt); cmo->cy = __fdiv_rn(ay, cnt);
+      const float2 c = make_float2(__fdiv_rn(ax, cnt), __fdiv_rn(ay, cnt));
+      cmo->cx = c.x; cmo->cy = c.y;
+      if (idx < cen_cap) cen[idx] = c;
     }
     __threadfence_block();
     __syncthreads();
@@ -1492,7 +1512,7 @@ __global__ __launch_bounds__(kFastThreads, 4) void surface_sort_kernel(const Sur
           const float cnt = (float)(e - s);
           c = make_float2(__fdiv_rn(ax, cnt), __fdiv_rn(ay, cnt));
         } else {
-          c = make_float2(gload<float>(&cmo->cx), gload<float>(&cmo->cy));
+          c = idx < cen_cap ? cen[idx] : make_float2(gload<float>(&cmo->cx), gload<float>(&cmo->cy));
         }
         const double cx = (double)c.x, cy = (double)c.y;
         Moments mo{0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
@@ -1765,18 +1785,21 @@ int cfear_surface_launch(cfear_ctx* ctx, const void* d_jobs, int n_jobs, const c
         }
         fprintf(stderr, "surface routes of %d jobs: fast %d  fallback %d (prepared %d)  done %d  prepped %d\n", n_jobs, routes[0], routes[1], prepared, routes[2], routes[3]);
       }
-      double acc[9] = {0}, sub[2] = {0}, cel[6] = {0};
+      double acc[9] = {0}, sub[5] = {0}, cel[6] = {0};
       const int m = std::min(n_jobs, 256);
       for (int j = 0; j < m; j++) {
-        long long t[16];
-        (void)hipMemcpy(t, d_scratch + (size_t)j * cm.scratch_stride + 64, sizeof(t), hipMemcpyDeviceToHost);
+        long long t[24];
+        (void)hipMemcpy(t, d_scratch + (size_t)(j * (n_jobs / m)) * cm.scratch_stride + 64, sizeof(t), hipMemcpyDeviceToHost);   // spread over the launch
         for (int q = 1; q < 9; q++) acc[q] += (double)(t[q] - t[q - 1]);
-        sub[0] += (double)(t[9] - t[1]); sub[1] += (double)(t[10] - t[9]);
+        sub[0] += (double)(t[9] - t[2]); sub[1] += (double)(t[10] - t[3]);
+        sub[2] += (double)(t[16] - t[9]); sub[3] += (double)(t[17] - t[16]); sub[4] += (double)(t[3] - t[17]);
         cel[0] += (double)(t[11] - t[7]); cel[1] += (double)(t[12] - t[11]); cel[2] += (double)(t[13] - t[12]);
         cel[3] += (double)(t[14] - t[13]); cel[4] += (double)(t[15] - t[14]); cel[5] += (double)(t[8] - t[15]);
       }
       fprintf(stderr, "  cells split (last slab, tid 0): stage %.0f  classify+list %.0f  centroids %.0f  16-lane %.0f  4-lane %.0f  1-lane %.0f\n",
               cel[0] / m, cel[1] / m, cel[2] / m, cel[3] / m, cel[4] / m, cel[5] / m);
+      fprintf(stderr, "  of hist: clear the bitmap %.0f, first 8 points per thread %.0f, the rest %.0f, barrier %.0f; of scan: word scan + voxel keys %.0f\n",
+              sub[0] / m, sub[2] / m, sub[3] / m, sub[4] / m, sub[1] / m);
       fprintf(stderr, "surface_sort phases (cycles, mean of %d jobs): count %.0f  comp+bbox %.0f  hist %.0f  scan %.0f  scatter %.0f  order %.0f  spt %.0f  cells %.0f\n",
               m, acc[1] / m, acc[2] / m, acc[3] / m, acc[4] / m, acc[5] / m, acc[6] / m, acc[7] / m, acc[8] / m);
     }
