@@ -1104,6 +1104,8 @@ __global__ __launch_bounds__(kFastThreads) void surface_prep_kernel(const SurfJo
   }
 }
 
+constexpr int kTierInFlight = 2;                    // candidates per lane in flight in the lane-group tiers of the moments pass (4: no faster)
+
 __global__ __launch_bounds__(kFastThreads, 4) void surface_sort_kernel(const SurfJob* __restrict__ jobs, const SurfCommon cm) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   constexpr int NT = kFastThreads, NW = NT / 64;
@@ -1516,24 +1518,21 @@ __global__ __launch_bounds__(kFastThreads, 4) void surface_sort_kernel(const Sur
         }
         const double cx = (double)c.x, cy = (double)c.y;
         Moments mo{0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+        // The three neighbour runs are walked as ONE sequence (no idle lanes and no loop tail at the end of every run),
+        // several candidates per lane in flight.  One lane per voxel keeps the oracle's order of additions.
+        const int n0 = r1[0] - r0[0], n01 = n0 + (r1[1] - r0[1]), C = n01 + (r1[2] - r0[2]);
+        auto at = [&](int k) { return k < n0 ? r0[0] + k : (k < n01 ? r0[1] + (k - n0) : r0[2] + (k - n01)); };
+        auto wgt_at = [&](int p) { return wi ? (WB ? (float)lw[p] : lwf[p]) : 0.f; };
+        constexpr int U = G == 1 ? 4 : kTierInFlight;
+        for (int k = sub; k < C; k += U * G) {
+          int pp[U]; float2 qq[U]; float ww[U];
 #pragma unroll
-        for (int d = 0; d < 3; d++) {
-          int p = r0[d] + sub;
-          if (G == 1) {
-            for (; p + 3 < r1[d]; p += 4) {                             // four independent LDS reads in flight
-              const float2 qa = lxy[p], qb = lxy[p + 1], qc = lxy[p + 2], qd = lxy[p + 3];
-              float wa = 0.f, wb = 0.f, wc = 0.f, wd = 0.f;
-              if (wi) {
-                if (WB) { wa = (float)lw[p]; wb = (float)lw[p + 1]; wc = (float)lw[p + 2]; wd = (float)lw[p + 3]; }
-                else { wa = lwf[p]; wb = lwf[p + 1]; wc = lwf[p + 2]; wd = lwf[p + 3]; }
-              }
-              accum_point(mo, c, cx, cy, qa.x, qa.y, wa, cm.r2, wi);
-              accum_point(mo, c, cx, cy, qb.x, qb.y, wb, cm.r2, wi);
-              accum_point(mo, c, cx, cy, qc.x, qc.y, wc, cm.r2, wi);
-              accum_point(mo, c, cx, cy, qd.x, qd.y, wd, cm.r2, wi);
-            }
-          }
-          for (; p < r1[d]; p += G) { const float2 q = lxy[p]; accum_point(mo, c, cx, cy, q.x, q.y, wi ? (WB ? (float)lw[p] : lwf[p]) : 0.f, cm.r2, wi); }
+          for (int u = 0; u < U; u++) pp[u] = at(min(k + u * G, C - 1));
+#pragma unroll
+          for (int u = 0; u < U; u++) { qq[u] = lxy[pp[u]]; ww[u] = wgt_at(pp[u]); }
+#pragma unroll
+          for (int u = 0; u < U; u++)
+            if (u == 0 || k + u * G < C) accum_point(mo, c, cx, cy, qq[u].x, qq[u].y, ww[u], cm.r2, wi);
         }
         if (G > 1) {
           mo.cnt = group_sum_i32<G>(mo.cnt);
