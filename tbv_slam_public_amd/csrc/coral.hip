@@ -95,10 +95,8 @@ __device__ __forceinline__ int upper_bound_u32(const uint32_t* a, int lo, int hi
 struct Moments { int n; double sx, sy, sxx, sxy, syy; };
 // all-reduce over aligned groups of G lanes (G = 4: quad, G = 16: DPP row); every lane ends with the same sum
 template <int G> __device__ __forceinline__ int group_sum_i32(int v) {
-  if (G >= 4) {
-    v += __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xf, 0xf, false);           // quad_perm [1,0,3,2]
-    v += __builtin_amdgcn_update_dpp(v, v, 0x4E, 0xf, 0xf, false);           // quad_perm [2,3,0,1]
-  }
+  if (G >= 2) v += __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xf, 0xf, false);   // quad_perm [1,0,3,2]
+  if (G >= 4) v += __builtin_amdgcn_update_dpp(v, v, 0x4E, 0xf, 0xf, false);   // quad_perm [2,3,0,1]
   if (G == 16) {
     v += __builtin_amdgcn_update_dpp(v, v, 0x141, 0xf, 0xf, false);          // row_half_mirror
     v += __builtin_amdgcn_update_dpp(v, v, 0x140, 0xf, 0xf, false);          // row_mirror
@@ -106,7 +104,8 @@ template <int G> __device__ __forceinline__ int group_sum_i32(int v) {
   return v;
 }
 template <int G> __device__ __forceinline__ double group_sum_f64(double v) {
-  if (G >= 4) { v += dpp_f64<0xB1>(v); v += dpp_f64<0x4E>(v); }
+  if (G >= 2) v += dpp_f64<0xB1>(v);
+  if (G >= 4) v += dpp_f64<0x4E>(v);
   if (G == 16) { v += dpp_f64<0x141>(v); v += dpp_f64<0x140>(v); }
   return v;
 }
@@ -132,6 +131,8 @@ __device__ __forceinline__ void fail_job(const CoralCommon& cm, int status) {
     r.joint = r.sep = r.overlap = 0.0; r.valid = 0; r.count_valid = 0; r.status = status; r.pad = 0;
   }
 }
+
+constexpr int kCoralSweepLanes = 1;                           // lanes per point of the work list in pass B (2: equal, 4: slower)
 
 __global__ __launch_bounds__(kCoralThreads) void coral_kernel(const CoralJob* __restrict__ jobs, const CoralCommon cm) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -263,9 +264,6 @@ __global__ __launch_bounds__(kCoralThreads) void coral_kernel(const CoralJob* __
     }
   }
   if (tid == 0) cell_start[V] = n;
-  __syncthreads();
-  for (int y = tid; y <= dby; y += kCoralThreads)
-    rowbeg[y] = lower_bound_u32(cell_key, 0, V, (uint32_t)((long long)y * dbx));
   __threadfence_block();
   __syncthreads();
   // ---- 3b. O(1) cell look-ups: ONE BIT per grid cell + the occupied cells before every 32-cell word (the map
@@ -280,6 +278,11 @@ __global__ __launch_bounds__(kCoralThreads) void coral_kernel(const CoralJob* __
   uint32_t* occ = (uint32_t*)(smem + occ_off);
   const int nw32 = bitmap ? (int)nw32_ll : 0;
   unsigned short* wpref = (unsigned short*)(occ + nw32);
+  if (!bitmap) {                                        // first cell of every grid row, for the binary searches
+    for (int y = tid; y <= dby; y += kCoralThreads)
+      rowbeg[y] = lower_bound_u32(cell_key, 0, V, (uint32_t)((long long)y * dbx));
+    __syncthreads();
+  }
   if (bitmap) {
     for (int w = tid; w < nw32; w += kCoralThreads) occ[w] = 0u;
     __syncthreads();
@@ -336,17 +339,13 @@ __global__ __launch_bounds__(kCoralThreads) void coral_kernel(const CoralJob* __
           const float d2 = __fadd_rn(__fmul_rn(dxf, dxf), __fmul_rn(dyf, dyf));
           return (d2 < cm.r2) && ((__float_as_int(c.w) < n_src) != q_is_src);
         };
-        // the point's own row first: the nearest returns of the other cloud usually share it
-#pragma unroll
-        for (int dd = 0; dd < 3; dd++) {
-          const int d = dd == 0 ? 1 : (dd == 1 ? 0 : 2);
-          int p = r0[d];
-          const int p1 = r1[d];
-          for (; p + 3 < p1 && !hit; p += 4) {                  // four independent loads per exit test
-            const v4f c0 = SP[p], c1 = SP[p + 1], c2 = SP[p + 2], c3 = SP[p + 3];
-            hit = ((int)test(c0) | (int)test(c1) | (int)test(c2) | (int)test(c3)) != 0;
-          }
-          for (; p < p1 && !hit; p++) hit = test(SP[p]);
+        // the three runs as ONE sequence, the point's own row first (the nearest returns of the other cloud usually share
+        // it); four independent loads per exit test
+        const int n0 = r1[1] - r0[1], n01 = n0 + (r1[0] - r0[0]), C = n01 + (r1[2] - r0[2]);
+        auto at = [&](int j) { return j < n0 ? r0[1] + j : (j < n01 ? r0[0] + (j - n0) : r0[2] + (j - n01)); };
+        for (int j = 0; j < C && !hit; j += 4) {
+          const v4f c0 = SP[at(j)], c1 = SP[at(min(j + 1, C - 1))], c2 = SP[at(min(j + 2, C - 1))], c3 = SP[at(min(j + 3, C - 1))];
+          hit = ((int)test(c0) | (int)test(c1) | (int)test(c2) | (int)test(c3)) != 0;
         }
         if (!hit) { gstore<double>(jres + idx, 100.0); gstore<double>(sres + idx, 100.0); gstore<double>(wres + idx, 0.0); gstore<int32_t>(vres + idx, 0); }
       }
@@ -391,16 +390,14 @@ __global__ __launch_bounds__(kCoralThreads) void coral_kernel(const CoralJob* __
             }
           }
         };
-        if (act) {
-#pragma unroll
-          for (int d = 0; d < 3; d++) {
-            int p = r0[d] + sub;
-            for (; p + G < r1[d]; p += 2 * G) {                  // two loads in flight
-              const v4f c0 = SP[p], c1 = SP[p + G];
-              visit(c0);
-              visit(c1);
-            }
-            if (p < r1[d]) visit(SP[p]);
+        if (act) {                                               // the three runs as ONE sequence, two loads in flight
+          const int n0 = r1[0] - r0[0], n01 = n0 + (r1[1] - r0[1]), C = n01 + (r1[2] - r0[2]);
+          auto at = [&](int j) { return j < n0 ? r0[0] + j : (j < n01 ? r0[1] + (j - n0) : r0[2] + (j - n01)); };
+          for (int j = sub; j < C; j += 2 * G) {
+            const bool two = j + G < C;
+            const v4f c0 = SP[at(j)], c1 = SP[at(two ? j + G : j)];
+            visit(c0);
+            if (two) visit(c1);
           }
         }
         if (G > 1) {
@@ -436,7 +433,7 @@ __global__ __launch_bounds__(kCoralThreads) void coral_kernel(const CoralJob* __
       }
     };
     (void)n16;
-    tier(std::integral_constant<int, 1>{}, n4, W);
+    tier(std::integral_constant<int, kCoralSweepLanes>{}, n4, W);
   };
   if (bitmap) {
     if (spt_in_lds) find_overlap_bm((CFEAR_LDS const v4f*)spt);
