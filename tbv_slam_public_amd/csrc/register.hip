@@ -1181,10 +1181,15 @@ __global__ __launch_bounds__(NW * 64) void register_kernel(const RegJob* __restr
   FusedLds fl;
   const bool fused = fused_carve(smem, cm.lds_total, last, sum_tar, n_src, n_slots, cm.dense_fields, fl, NW == kRegNWBig);
   if (!fused && cm.big_mode == 1) {
-    // Too large for the association in 80 KB of LDS, but not for a workgroup that owns the CU's LDS: leave it to the second
-    // launch instead of the x-window path below (13 x slower per registration on 1 400-cell scans).
+    // Too large for the association in 80 KB of LDS, but not for a workgroup that owns the CU's LDS: leave it to the
+    // launches behind this one instead of the x-window path below (13 x slower per registration on 1 400-cell scans).
+    // Those are register3_kernel's large forms (keyframe tables staged group by group: the source means and ONE keyframe's
+    // grid must fit) and this kernel again with the CU's LDS (every target packed at once) -- whatever none of them can
+    // run, the last one takes through the x-window path.
     FusedLds probe;
-    if (fused_carve(smem, cm.lds_big, last, sum_tar, n_src, n_slots, cm.dense_fields, probe, true)) {   // the second launch packs its targets
+    const size_t r3_need = 4096 + (size_t)last * 176 + (size_t)n_src * 16 + (size_t)kScanGridStartPad * 2 + (size_t)max_tar * 16;
+    if ((r3_need <= cm.lds_big && n_src < 65536 && sum_tar <= 65535) ||
+        fused_carve(smem, cm.lds_big, last, sum_tar, n_src, n_slots, cm.dense_fields, probe, true)) {   // (that launch packs its targets)
       if (threadIdx.x == 0) { res->status = kRegDeferred; res->reserved = 1.0; }
       return;
     }
@@ -1360,7 +1365,8 @@ constexpr size_t kR3StateOff = kRegFixedLds;                // behind register_k
 constexpr size_t kR3FixedLds = kRegFixedLds + S_COUNT * 8;
 
 constexpr int kReg3NW = 4;                      // wavefronts of the regular form (three workgroups per CU)
-constexpr int kReg3NWLarge = 16;                // ... of the large form: one workgroup per CU with all of its LDS (register_large)
+constexpr int kReg3NWLarge = 16;                // ... of the large form: one workgroup per CU with all of its LDS (register_large16)
+constexpr int kReg3NWHalf = 8;                  // ... of the half-CU form: two workgroups per CU, 80 KB each (register_large)
 constexpr size_t kReg3Lds = 52 * 1024;          // x 3 = 156 KB of the CU's 160 KB
 
 struct R3Lds {
@@ -1370,6 +1376,7 @@ struct R3Lds {
   float4* ggeo;            // [last] grid geometry (x0, y0, cells per metre, -)
   double2* smean;          // [n_src]
   unsigned short* match;   // [n_pairs] matched target (index inside its keyframe), 0xFFFF = none
+  unsigned short* gmatch;  // ... in the job's global scratch instead, when the LDS copy would leave no room for a keyframe's tables (else null)
   unsigned short* cstart;  // [last][kScanGridStartPad] absolute first record of every grid cell   } association phase; the dense
   float4* txyi;            // [sum_tar] (x, y, index bits, -) grouped by (keyframe, cell)            } arrays alias both
   double* dense;           // = cstart
@@ -1386,15 +1393,21 @@ struct Dense3 {
   double* gp; int* gsidx; size_t gcap;
 };
 
-__device__ __forceinline__ bool r3_carve(uint8_t* smem, size_t lds_total, int last, int sum_tar, int n_src, int n_pairs, int fields,
-                                         R3Lds& f) {
+__device__ __forceinline__ bool r3_carve(uint8_t* smem, size_t lds_total, int last, int sum_tar, int max_tar, int n_src, int n_pairs,
+                                         int fields, unsigned short* gmatch_buf, R3Lds& f) {
   size_t off = kR3FixedLds;
   f.kf = (double*)(smem + off); off += (size_t)last * 12 * 8;
   f.tptr = (const void**)(smem + off); off += (size_t)last * kR3Ptrs * 8;
   f.ggeo = (float4*)(smem + off); off += (size_t)last * 16;
   f.koff = (int*)(smem + off); off += (((size_t)last + 1) * 4 + 15) & ~(size_t)15;
   f.smean = (double2*)(smem + off); off += (size_t)n_src * 16;
-  f.match = (unsigned short*)(smem + off); off += (((size_t)n_pairs + 7) & ~(size_t)7) * 2;
+  // the match table: in LDS, unless that leaves no room for the largest keyframe's tables (1 400-cell scans in half a CU's
+  // LDS) -- then in the job's global scratch (L2; written and read once per outer iteration by the same thread)
+  const size_t match_bytes = (((size_t)n_pairs + 7) & ~(size_t)7) * 2;
+  const size_t need_one = (size_t)kScanGridStartPad * 2 + (size_t)max_tar * 16;
+  f.match = (unsigned short*)(smem + off); f.gmatch = nullptr;
+  if (gmatch_buf && ((off + match_bytes + 15) & ~(size_t)15) + need_one > lds_total) { f.match = nullptr; f.gmatch = gmatch_buf; }
+  else off += match_bytes;
   off = (off + 15) & ~(size_t)15;
   // room for one keyframe's tables at the very least (a keyframe that exceeds it: r3_associate reports it)
   if (sum_tar > 65535 || off + (size_t)kScanGridStartPad * 2 + 4096 > lds_total) return false;
@@ -1510,6 +1523,7 @@ __device__ int r3_associate(const RegJob& job, const RegCommon& cm, int itr, con
   const double r2 = curr_radius * curr_radius;
   const float rwin = (float)curr_radius + 1e-3f;
   constexpr int G = kScanGrid;
+  constexpr bool GM = NT != kReg3NW * 64;                  // the global match table exists in the large forms only (r3_carve)
   REG_T0();
   // Tsrctotar_i = Ttar_i^-1 * Tsrc  (:222), on the last wavefront, ahead of the first group's table loads.  The
   // rotation of the source pose by the polynomial sincos the LM loop uses for its evaluation points (an ulp or two from libm,
@@ -1589,7 +1603,8 @@ __device__ int r3_associate(const RegJob& job, const RegCommon& cm, int itr, con
         const double nsx = T[0] * ns.x + T[1] * ns.y, nsy = T[2] * ns.x + T[3] * ns.y;
         if (fmax(nsx * nt.x + nsy * nt.y, 0.0) > cm.angle_outlier) m = best;    // :244-245
       }
-      f.match[p] = (unsigned short)m;
+      if (GM && f.gmatch) gstore<unsigned short>(f.gmatch + p, (unsigned short)m);   // (block-uniform)
+      else f.match[p] = (unsigned short)m;
       accepted += (m >= 0);
       s += NT;
       while (s >= n_src && i < i1) { s -= n_src; i++; }
@@ -1597,6 +1612,7 @@ __device__ int r3_associate(const RegJob& job, const RegCommon& cm, int itr, con
     REG_TACC(1);
     i0 = i1;
   }
+  if (GM && f.gmatch) __threadfence_block();              // a thread reads back its OWN entries below: stores before loads
   const int incl = wave_incl_scan_i32(accepted);
   int base = incl - accepted, total;
   {
@@ -1623,9 +1639,13 @@ __device__ int r3_associate(const RegJob& job, const RegCommon& cm, int itr, con
       double4 S;
     };
     const ScanView& srcv = job.scans[last];
-    auto gather = [&](int p, int i, int s) {
+    auto match_at = [&](int p) -> int {
+      if (p >= n_pairs) return 0xFFFF;
+      return (GM && f.gmatch) ? (int)gload<unsigned short>(f.gmatch + p) : (int)f.match[p];
+    };
+    auto gather = [&](int best, int i, int s) {
       Gathered g;
-      g.best = p < n_pairs ? (int)f.match[p] : 0xFFFF;
+      g.best = best;
       if (g.best == 0xFFFF) g.best = -1;
       g.i = i; g.s = s;
       if (g.best >= 0) {
@@ -1643,11 +1663,15 @@ __device__ int r3_associate(const RegJob& job, const RegCommon& cm, int itr, con
     };
     int c = base, i = 0, s = tid;
     while (s >= n_src && i < last) { s -= n_src; i++; }
-    Gathered cur = gather(tid, i, s);
+    int m_next = GM ? match_at(tid + NT) : 0;             // the match two rounds ahead is in flight (global table: an L2 round trip)
+    Gathered cur = gather(match_at(tid), i, s);
     for (int p = tid; p < n_pairs; p += NT) {
       s += NT;
       while (s >= n_src && i < last) { s -= n_src; i++; }
-      const Gathered nxt = gather(p + NT, i, s);
+      int m_use;
+      if (GM) { m_use = m_next; m_next = match_at(p + 2 * NT); }
+      else m_use = match_at(p + NT);
+      const Gathered nxt = gather(m_use, i, s);
       if (cur.best >= 0) {
         const double* K = f.kf + cur.i * 12;              // Ttar
         const double* T = K + 6;                          // Tsrctotar
@@ -1924,7 +1948,10 @@ __global__ __launch_bounds__(NW * 64, NW == kReg3NW ? 3 : 4) void register3_kern
   for (int i = 0; i < last; i++) { const int n = gload<int>(job.scans[i].n_cells); sum_tar += n; max_tar = max(max_tar, n); }
   const int n_pairs = last * n_src;
   R3Lds fl;
-  bool ok = n_pairs <= cm.slots_cap && n_src < 65536 && r3_carve(smem, cm.lds_total, last, sum_tar, n_src, n_pairs, cm.dense_fields, fl);
+  // (the head of the job's scratch -- register_kernel's slot arrays, 52 bytes per pair -- is free in this kernel)
+  bool ok = n_pairs <= cm.slots_cap && n_src < 65536 &&
+            r3_carve(smem, cm.lds_total, last, sum_tar, max_tar, n_src, n_pairs, cm.dense_fields,
+                     NW != kReg3NW ? (unsigned short*)(cm.scratch + (size_t)blockIdx.x * cm.scratch_stride) : nullptr, fl);
   ok = ok && kScanGridStartPad * 2 + max_tar * 16 <= fl.region;   // every keyframe's tables fit the region on their own
   // ... and the registration is one this kernel is GOOD at: the keyframes' tables in at most two groups and room for 40 % of
   // the pairs in the LDS arrays (scans of up to ~600 cells).  Beyond that (dense scenes: 1 400 cells per scan) it would
@@ -2003,7 +2030,7 @@ __global__ __launch_bounds__(NW * 64, NW == kReg3NW ? 3 : 4) void register3_kern
     res->outer_iters = itr;
     res->lm_iters = lm_iters;
     res->last_relative_decrease = st[S_LASTREL];
-    res->reserved = NW == kReg3NWLarge ? 1.0 : 0.0;               // a large registration: tells the caller to keep the large launches on
+    res->reserved = NW != kReg3NW ? 1.0 : 0.0;               // a large registration: tells the caller to keep the large launches on
     if (success) { res->score = final_cost / (double)num_residuals; res->status = CFEAR_OK; }   // :162
     else { res->score = 0.0; res->status = fail_status; }
 #ifdef CFEAR_REG_TIMING
@@ -2267,21 +2294,35 @@ int cfear_register_launch(cfear_ctx* ctx, const void* d_jobs, int n_jobs, const 
     // where register_kernel's 236 allow two), the keyframes' prebuilt tables staged group by group, dense arrays for ~5 000
     // correspondences in LDS.  CFEAR_NO_REG3 leaves it out.
     if (!getenv("CFEAR_NO_REG3")) {
-      KernelFn fl3;
-      switch (par->cost) {
-        case CFEAR_P2P: fl3 = huber ? register3_kernel<kReg3NWLarge, CFEAR_P2P, CFEAR_LOSS_HUBER> : register3_kernel<kReg3NWLarge, CFEAR_P2P, -1>; break;
-        case CFEAR_P2L: fl3 = huber ? register3_kernel<kReg3NWLarge, CFEAR_P2L, CFEAR_LOSS_HUBER> : register3_kernel<kReg3NWLarge, CFEAR_P2L, -1>; break;
-        default: fl3 = huber ? register3_kernel<kReg3NWLarge, CFEAR_P2D, CFEAR_LOSS_HUBER> : register3_kernel<kReg3NWLarge, CFEAR_P2D, -1>; break;
+      // Half a CU each first (two workgroups per CU overlap each other's serial phases: the trust-region chain on one
+      // wavefront, the barriers), then one per CU for what even a global match table does not fit into 80 KB.
+      for (int form = 0; form < 2; form++) {
+        KernelFn fl3;
+        if (form == 0) {
+          switch (par->cost) {
+            case CFEAR_P2P: fl3 = huber ? register3_kernel<kReg3NWHalf, CFEAR_P2P, CFEAR_LOSS_HUBER> : register3_kernel<kReg3NWHalf, CFEAR_P2P, -1>; break;
+            case CFEAR_P2L: fl3 = huber ? register3_kernel<kReg3NWHalf, CFEAR_P2L, CFEAR_LOSS_HUBER> : register3_kernel<kReg3NWHalf, CFEAR_P2L, -1>; break;
+            default: fl3 = huber ? register3_kernel<kReg3NWHalf, CFEAR_P2D, CFEAR_LOSS_HUBER> : register3_kernel<kReg3NWHalf, CFEAR_P2D, -1>; break;
+          }
+        } else {
+          switch (par->cost) {
+            case CFEAR_P2P: fl3 = huber ? register3_kernel<kReg3NWLarge, CFEAR_P2P, CFEAR_LOSS_HUBER> : register3_kernel<kReg3NWLarge, CFEAR_P2P, -1>; break;
+            case CFEAR_P2L: fl3 = huber ? register3_kernel<kReg3NWLarge, CFEAR_P2L, CFEAR_LOSS_HUBER> : register3_kernel<kReg3NWLarge, CFEAR_P2L, -1>; break;
+            default: fl3 = huber ? register3_kernel<kReg3NWLarge, CFEAR_P2D, CFEAR_LOSS_HUBER> : register3_kernel<kReg3NWLarge, CFEAR_P2D, -1>; break;
+          }
+        }
+        const int nw_l = form == 0 ? kReg3NWHalf : kReg3NWLarge;
+        const size_t lds_l = form == 0 ? (size_t)(80 * 1024 - 256) : (size_t)cm.lds_big;
+        CFEAR_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)fl3, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        RegCommon c3 = cm;
+        c3.lds_total = (uint32_t)lds_l;
+        c3.big_mode = 0;
+        c3.only_deferred = 1;
+        c3.r3_take_all = 1;                               // (whatever it still cannot run stays deferred for the launch behind it)
+        ProfScope ps(ctx, form == 0 ? "register_large" : "register_large16");
+        hipLaunchKernelGGL(fl3, dim3(n_jobs), dim3(nw_l * 64), lds_l, ctx->stream, (const RegJob*)d_jobs, c3);
+        CFEAR_HIP_CHECK(ctx, hipGetLastError());
       }
-      CFEAR_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)fl3, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-      RegCommon c3 = cm;
-      c3.lds_total = cm.lds_big;
-      c3.big_mode = 0;
-      c3.only_deferred = 1;
-      c3.r3_take_all = 1;                                 // (whatever it still cannot run stays deferred for the launch below)
-      ProfScope ps(ctx, "register_large");
-      hipLaunchKernelGGL(fl3, dim3(n_jobs), dim3(kReg3NWLarge * 64), (size_t)cm.lds_big, ctx->stream, (const RegJob*)d_jobs, c3);
-      CFEAR_HIP_CHECK(ctx, hipGetLastError());
     }
     // ... then register_kernel with 8 wavefronts and the CU's LDS for what is left (scans without grid tables).  Everything
     // else returns at once (the caller switches these launches off when no large scans show up).

@@ -109,36 +109,50 @@ def _dense_cells(seed, frames):
     return out, gt
 
 
-def test_second_launch_capacity_with_packed_targets():
-    """1 900 cells per scan (cells of two dense scenes side by side, 600 m apart): four keyframes exceed what the second
-    launch held with 16-byte target records (1 650 cells per scan) and fit with the packed 10-byte ones (~2 070); ~2 800
-    cells per scan exceed that too and take the x-window path.  Both must give the oracle's result."""
+def test_second_launch_capacity_with_packed_targets(monkeypatch):
+    """Registrations too large for the 80 KB association are deferred to the launches behind it.  1 900 cells per scan (cells
+    of two dense scenes side by side, 600 m apart): four keyframes fit register_kernel's second launch with packed 10-byte
+    target records (~2 070 cells per scan); ~2 800 cells per scan exceed that and used to take the x-window path at once.
+    Since round 4 register3_kernel's half-CU form takes all of them (keyframe tables staged group by group) -- with ~2 300
+    cells per scan its match table moves to global scratch -- and must be the launch that does the work; with
+    CFEAR_NO_REG3=1 the older routes (second launch / x-window path) run.  Every route must give the oracle's result."""
     from oracle import pyoracle as O
     from tbv_slam_public_amd import api, synth
     frames = [0, 1, 2, 3, 4]
-    worlds = [synth.scene_dense(seed, 5) for seed in (9, 10)]
+    worlds = [synth.scene_dense(seed, 5) for seed in (9, 10, 11)]
     gt = worlds[0][1]
     poses = np.array([_rel(gt[0], gt[f]) for f in frames])
     poses[-1] += [0.25, -0.15, 0.006]
     reg = api.n_scan_normal_reg("P2P", "Huber", 0.1, 4)
-    for radius, keep, lo, hi, second in ((2.5, 950, 1700, 2000, 1.0), (3.0, 100000, 2100, 8000, None)):
+    for radius, keep, lo, hi, use in ((2.5, 950, 1700, 2000, (0, 1)), (3.0, 100000, 2100, 8000, (0, 1)), (2.5, 1150, 2299, 2301, (1, 2))):
         cells = []
         for f in frames:
             parts = []
-            for w, (imgs, _, _) in enumerate(worlds):
+            for w, (imgs, _, _) in enumerate([worlds[u] for u in use]):
                 sr, si, sc = O.kstrongest(imgs[f], 40, 60)
                 c = O.surface_points(O.kstrongest_cloud(sr, si, sc, 0.0438, 2.5), radius, 1.0, (0, 0), True).copy()
                 c["mean"][:, 0] += 600.0 * w
                 parts.append(c[:keep])
             cells.append(np.concatenate(parts))
         assert lo < min(len(c) for c in cells) and max(len(c) for c in cells) < hi, [len(c) for c in cells]
-        out = reg.RegisterBatch([([api.MapPointNormal(cells=c) for c in cells], poses)])[0]
+        maps = [api.MapPointNormal(cells=c) for c in cells]
         ok_o, po, ro = O.register(cells, poses, _oracle_par(reg))
-        assert (out["status"] == 0) == ok_o
-        assert (out["outer_iters"], out["lm_iters"], out["num_residuals"]) == (ro.outer_iters, ro.lm_iters, ro.num_residuals)
-        assert np.abs(out["pose"][:2] - po[-1, :2]).max() <= POS_TOL and abs(out["pose"][2] - po[-1, 2]) <= ROT_TOL
-        if second is not None:
-            assert out["reserved"] == second
+        for no_reg3 in (False, True):
+            if no_reg3:
+                monkeypatch.setenv("CFEAR_NO_REG3", "1")                    # (read per launch)
+            else:
+                monkeypatch.delenv("CFEAR_NO_REG3", raising=False)
+            reg.ctx.profile_enable(True); reg.ctx.profile_read(reset=True)
+            out = reg.RegisterBatch([(maps, poses)])[0]
+            prof = reg.ctx.profile_read(reset=True); reg.ctx.profile_enable(False)
+            if not no_reg3:                                               # the half-CU form did the work
+                others = [v[0] for k, v in prof.items() if k != "register_large"]
+                assert prof["register_large"][0] > 5 * max(others), prof
+            assert (out["status"] == 0) == ok_o
+            assert (out["outer_iters"], out["lm_iters"], out["num_residuals"]) == (ro.outer_iters, ro.lm_iters, ro.num_residuals)
+            assert np.abs(out["pose"][:2] - po[-1, :2]).max() <= POS_TOL and abs(out["pose"][2] - po[-1, 2]) <= ROT_TOL
+            assert out["reserved"] == 1.0
+    monkeypatch.delenv("CFEAR_NO_REG3", raising=False)
 
 
 def test_large_scans_take_the_second_launch():
