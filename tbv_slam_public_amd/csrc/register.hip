@@ -1541,6 +1541,20 @@ __device__ int r3_associate(const RegJob& job, const RegCommon& cm, int itr, con
     }
   };
   int accepted = 0;
+  int pend_p = -1, pend_i = 0, pend_best = -1;             // the pair whose normal gate is still open (see the search loop)
+  double2 pend_ns = make_double2(0.0, 0.0), pend_nt = make_double2(0.0, 0.0);
+  auto gate_pending = [&]() {
+    if (pend_p < 0) return;
+    int m = -1;
+    if (pend_best >= 0) {
+      const double* T = f.kf + pend_i * 12 + 6;
+      const double nsx = T[0] * pend_ns.x + T[1] * pend_ns.y, nsy = T[2] * pend_ns.x + T[3] * pend_ns.y;
+      if (fmax(nsx * pend_nt.x + nsy * pend_nt.y, 0.0) > cm.angle_outlier) m = pend_best;    // :244-245
+    }
+    if (GM && f.gmatch) gstore<unsigned short>(f.gmatch + pend_p, (unsigned short)m);   // (block-uniform)
+    else f.match[pend_p] = (unsigned short)m;
+    accepted += (m >= 0);
+  };
   for (int i0 = 0; i0 < last;) {
     int i1 = i0, bytes = 0;                                // the keyframes [i0, i1) whose tables fit the region together
     while (i1 < last) {
@@ -1578,10 +1592,9 @@ __device__ int r3_associate(const RegJob& job, const RegCommon& cm, int itr, con
       };
       const unsigned short* cs = f.cstart + (i - i0) * kScanGridStartPad;
       auto scan_run = [&](int qb, int qe) {
-        for (int q = qb; q < qe; q += 4) {
-          const int l = qe - 1;
-          const float4 ca = txyi[q], cb = txyi[min(q + 1, l)], cc = txyi[min(q + 2, l)], cd = txyi[min(q + 3, l)];
-          visit(ca); visit(cb); visit(cc); visit(cd);
+        for (int q = qb; q < qe; q += 2) {
+          const float4 ca = txyi[q], cb = txyi[min(q + 1, qe - 1)];
+          visit(ca); visit(cb);
         }
       };
       {
@@ -1596,19 +1609,21 @@ __device__ int r3_associate(const RegJob& job, const RegCommon& cm, int itr, con
       }
       const int best = bestkey == ~0ull ? -1 : (int)(unsigned)(bestkey & 0xFFFFFFFFu);
       const float bestd = __uint_as_float((unsigned)(bestkey >> 32));
-      int m = -1;
-      if (best >= 0 && (double)bestd < r2) {                                    // pointnormal.cpp:250
-        const double2 ns = gload_d2(job.scans[last].normal + s);
-        const double2 nt = gload_d2((const double2*)f.tptr[i * kR3Ptrs + 1] + best);
-        const double nsx = T[0] * ns.x + T[1] * ns.y, nsy = T[2] * ns.x + T[3] * ns.y;
-        if (fmax(nsx * nt.x + nsy * nt.y, 0.0) > cm.angle_outlier) m = best;    // :244-245
+      // The normal gate of THIS pair is decided one pair later: its two normals come from global memory (L2), the target's
+      // address only known now, and waiting for them here exposed an L2 round trip per pair -- the next pair's search
+      // covers it instead.
+      gate_pending();
+      pend_p = p; pend_i = i;
+      pend_best = (best >= 0 && (double)bestd < r2) ? best : -1;                // pointnormal.cpp:250
+      if (pend_best >= 0) {
+        pend_ns = gload_d2(job.scans[last].normal + s);
+        pend_nt = gload_d2((const double2*)f.tptr[i * kR3Ptrs + 1] + best);
       }
-      if (GM && f.gmatch) gstore<unsigned short>(f.gmatch + p, (unsigned short)m);   // (block-uniform)
-      else f.match[p] = (unsigned short)m;
-      accepted += (m >= 0);
       s += NT;
       while (s >= n_src && i < i1) { s -= n_src; i++; }
     }
+    gate_pending();
+    pend_p = -1;
     REG_TACC(1);
     i0 = i1;
   }
