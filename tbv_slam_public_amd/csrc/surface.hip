@@ -602,6 +602,7 @@ __device__ void surface_big_tail(const SurfJob& job, const SurfCommon& cm, const
     CellMom* cmo = (CellMom*)&scr.tmp[v];               // surface_finish_kernel turns the moments into the cell
     cmo->s0 = mo.s0; cmo->s1x = mo.s1x; cmo->s1y = mo.s1y; cmo->sxx = mo.sxx; cmo->sxy = mo.sxy; cmo->syy = mo.syy;
     cmo->cx = c.x; cmo->cy = c.y; cmo->cnt = mo.cnt;
+    scr.coff[v] = mo.cnt;                               // (the neighbour counts on their own: surface_finish_kernel reads them first)
   }
   if (tid == 0) {
     scr.hdr->route = kRouteFast;                        // moments computed; cells + compaction + x-sort pending
@@ -1452,7 +1453,7 @@ __global__ __launch_bounds__(kFastThreads, 4) void surface_sort_kernel(const Sur
           kb[u] = min(12, 32 - __clz(C - 1));
           slot[u] = atomicAdd(&bucket[kb[u]], 1);
         } else {
-          ((CellMom*)&scr.tmp[v])->cnt = 0;                               // cannot reach 6 neighbours (pointnormal.cpp:291)
+          gstore<int32_t>(scr.coff + v, 0);                               // cannot reach 6 neighbours (pointnormal.cpp:291)
         }
       }
     }
@@ -1540,9 +1541,12 @@ __global__ __launch_bounds__(kFastThreads, 4) void surface_sort_kernel(const Sur
           mo.sxx = group_sum_f64<G>(mo.sxx); mo.sxy = group_sum_f64<G>(mo.sxy); mo.syy = group_sum_f64<G>(mo.syy);
         }
         if (sub == 0) {
-          cmo->s0 = mo.s0; cmo->s1x = mo.s1x; cmo->s1y = mo.s1y; cmo->sxx = mo.sxx; cmo->sxy = mo.sxy; cmo->syy = mo.syy;
-          if (G == 1) { cmo->cx = c.x; cmo->cy = c.y; }
-          cmo->cnt = mo.cnt;
+          if (mo.cnt >= 6) {                                            // (fewer: no cell, pointnormal.cpp:291 -- only the count is read)
+            cmo->s0 = mo.s0; cmo->s1x = mo.s1x; cmo->s1y = mo.s1y; cmo->sxx = mo.sxx; cmo->sxy = mo.sxy; cmo->syy = mo.syy;
+            if (G == 1) { cmo->cx = c.x; cmo->cy = c.y; }
+            cmo->cnt = mo.cnt;
+          }
+          gstore<int32_t>(scr.coff + v, mo.cnt);
         }
       }
     };
@@ -1577,23 +1581,23 @@ __global__ __launch_bounds__(kFinishThreads) void surface_finish_kernel(const Su
   const SurfJob job = jobs[job_id];
   const int V = scr.hdr->V;
   int run = 0;                                                         // valid cells so far: every thread keeps the total
+  // Three of four voxels hold fewer than six neighbours and cannot become cells (pointnormal.cpp:291).  Their 64 bytes of
+  // moments were most of what this kernel pulled through the memory system (it is bound by that traffic, not by the eigen
+  // decompositions): the neighbour counts sit in an array of their own (4 bytes per voxel), read one round ahead, and a
+  // voxel's moments (four 16-byte global loads: gload's comment in common.hpp) are only requested when its count says so.
+  int cnt_next = tid < V ? gload<int32_t>(scr.coff + tid) : 0;
   for (int v0 = 0, rnd = 0; v0 < V; v0 += kFinishThreads, rnd ^= 1) { // cells + compaction in voxel order (= PCL's output order)
     const int v = v0 + tid;
+    const int cnt = cnt_next;
+    cnt_next = v + kFinishThreads < V ? gload<int32_t>(scr.coff + v + kFinishThreads) : 0;
     TmpCell t;
     int f = 0;
-    if (v < V) {
-      CellMom cmo;                                                     // (64 bytes as four global 16-byte loads: gload's comment in common.hpp)
-      {
-        const char* src = (const char*)&scr.tmp[v];
-        const g_f64x2 a = gload<g_f64x2>(src), b = gload<g_f64x2>(src + 16), c = gload<g_f64x2>(src + 32);
-        const g_u32x4 d = gload<g_u32x4>(src + 48);
-        cmo.s0 = a.x; cmo.s1x = a.y; cmo.s1y = b.x; cmo.sxx = b.y; cmo.sxy = c.x; cmo.syy = c.y;
-        cmo.cx = __uint_as_float(d.x); cmo.cy = __uint_as_float(d.y); cmo.cnt = (int32_t)d.z; cmo.pad = 0;
-      }
-      if (cmo.cnt >= 6) {
-        const Moments mo{cmo.cnt, cmo.s0, cmo.s1x, cmo.s1y, cmo.sxx, cmo.sxy, cmo.syy};
-        f = finish_cell(mo, (double)cmo.cx, (double)cmo.cy, cm.origin[0], cm.origin[1], t);
-      }
+    if (v < V && cnt >= 6) {
+      const char* src = (const char*)&scr.tmp[v];
+      const g_f64x2 a = gload<g_f64x2>(src), b = gload<g_f64x2>(src + 16), c = gload<g_f64x2>(src + 32);
+      const g_f32x2 d = gload<g_f32x2>(src + 48);
+      const Moments mo{cnt, a.x, a.y, b.x, b.y, c.x, c.y};
+      f = finish_cell(mo, (double)d.x, (double)d.y, cm.origin[0], cm.origin[1], t);
     }
     const int inc = wave_incl_scan_i32(f);
     if (lane == 63) red_i2[rnd][wave] = inc;                           // double-buffered: ONE barrier per round
