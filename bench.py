@@ -263,6 +263,20 @@ def whole_path_of(mean_points, mean_cells, keyframes, registrations_per_s_per_gp
 # neighbouring workloads (functions so that the odometry run can report them in its own line)
 # ---------------------------------------------------------------------------------------------------------
 def loopclosure_run(D, n_cand, steps, warmup, graph=None):
+    """loopclosure_step under a torch stream of its own: torch reports handle 0 for its default stream, and a context given 0
+    makes a PRIVATE stream -- on a real (non-default) stream the context, the RCCL all_gather and the read-back share ONE HIP
+    stream, so the collective is ordered behind the matcher with no host synchronisation in between (dist.py checks the
+    handles itself: Context.shares_torch_stream)."""
+    import torch
+    side = torch.cuda.Stream(device=D.dev)
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        out = _loopclosure_run(D, n_cand, steps, warmup, graph)
+    torch.cuda.current_stream().wait_stream(side)
+    return out
+
+
+def _loopclosure_run(D, n_cand, steps, warmup, graph=None):
     """BASELINE configs[3]: loop-closure candidate registrations (P2L, Huber 0.1, Uniform, SetParameters(4,10) --
     loopclosure.cpp:56-57) between cached surface-point sets, block-sharded over the ranks, results all_gathered
     (RCCL) in candidate order."""
@@ -325,7 +339,7 @@ def loopclosure_run(D, n_cand, steps, warmup, graph=None):
     fn = lambda _local: reg.RegisterCandidates(table, cands)
     fn.into = lambda _local, ptr: reg.RegisterCandidates(table, cands, device_ptr=ptr)   # records stay on the GPU until the gather
     fn.ctx = ctx
-    fn.same_stream = True                                       # the context runs on torch's current stream: no sync before the collective
+    assert ctx.shares_torch_stream(), "the loop-closure context must enqueue on torch's current stream"
     for _ in range(max(warmup, 1)):
         out = cdist.register_candidates_sharded(jobs, fn)
     D.barrier()
@@ -345,7 +359,6 @@ def loopclosure_run(D, n_cand, steps, warmup, graph=None):
     tfn = lambda _local: reg.RegisterCandidates(table, tiny_c)
     tfn.into = lambda _local, ptr: reg.RegisterCandidates(table, tiny_c, device_ptr=ptr)
     tfn.ctx = ctx
-    tfn.same_stream = True
     for _ in range(3):
         cdist.register_candidates_sharded(tiny_jobs, tfn)
     D.barrier()
@@ -373,7 +386,6 @@ def loopclosure_run(D, n_cand, steps, warmup, graph=None):
         bfn = lambda _local: reg.RegisterCandidates(table, blk_c)
         bfn.into = lambda _local, ptr: reg.RegisterCandidates(table, blk_c, device_ptr=ptr)
         bfn.ctx = ctx
-        bfn.same_stream = True
         for _ in range(3):
             cdist.register_candidates_sharded(blk_jobs, bfn)
         D.barrier()
@@ -499,7 +511,7 @@ def main(argv=None):
     ap.add_argument("--bins-major", action="store_true",
                     help="feed the images as [range bins][azimuths] (non-Oxford drivers): the decode of radarDriver::Callback "
                          "(radar_driver.cpp:74-90) becomes part of every step -- fused into the filter stage (kstrong_image), or "
-                         "with CFEAR_NO_FUSED_DECODE=1 the rotation kernel + the row sweep; not the BASELINE layout")
+                         "with --ctx-option FUSED_DECODE=0 the rotation kernel + the row sweep; not the BASELINE layout")
     ap.add_argument("--keep-nodes", action="store_true",
                     help="also keep every frame's compensated peaks cloud (pose-graph nodes, cfear_odometry_get_*); "
                          "off in the BASELINE configuration")
@@ -507,12 +519,20 @@ def main(argv=None):
                     help="odometry: also estimate every frame's covariance by cost sampling (27 GetCost per "
                          "registration, odometrykeyframefuser.cpp:203-208; off in the reference's presets)")
     ap.add_argument("--no-profile", action="store_true", help="experiment: no per-kernel hipEvents inside the timed region")
+    ap.add_argument("--ctx-option", action="append", default=[], metavar="NAME=VALUE",
+                    help="A/B runs: a context option of include/cfear_hip.h (enum cfear_option without the CFEAR_OPT_ prefix, e.g. "
+                         "FUSED_DECODE=0, MATCHER_LDS_KB=52) applied to every context this run creates")
     ap.add_argument("--dry-run", action="store_true", help="launcher test without GPUs: ranks rendezvous over gloo and exit")
     args = ap.parse_args(argv)
     maybe_self_launch(args, argv)
     D = Dist(args)
     if args.dry_run:
         return dry_run(D, args)
+    if args.ctx_option:
+        from tbv_slam_public_amd import api as _api, _lib as _L
+        for kv in args.ctx_option:
+            name, val = kv.split("=", 1)
+            _api.Context.default_options[getattr(_L, "OPT_" + name.upper())] = int(val)
     if args.workload in ("loopclosure", "verify"):
         out = (loopclosure_run(D, args.candidates, args.steps, args.warmup, args.graph) if args.workload == "loopclosure"
                else verify_run(D, args.candidates, args.steps, args.warmup))

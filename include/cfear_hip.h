@@ -70,6 +70,25 @@ int cfear_ctx_create(int device, void* hip_stream, cfear_ctx** out);
 int cfear_ctx_destroy(cfear_ctx* ctx);
 int cfear_ctx_synchronize(cfear_ctx* ctx);
 const char* cfear_last_error(const cfear_ctx* ctx);
+/* The hipStream_t the context enqueues on (the caller's, or the private one cfear_ctx_create made): lets the host
+ * order other work -- a collective, a copy -- behind the library's kernels without a host synchronisation.        */
+int cfear_ctx_get_stream(const cfear_ctx* ctx, void** hip_stream);
+/* Context options.  None is needed in production: they are TEST / MEASUREMENT hooks that select between routes the
+ * library otherwise chooses by itself, so that the parity tests can drive every route with ordinary inputs and an A/B
+ * run can compare two routes inside one process.  The library never reads the environment.
+ *   CFEAR_OPT_FUSED_DECODE   1 (default): [range bins][azimuths] sweeps are decoded inside the filter kernels
+ *                            (radar_driver.cpp:74-90 fused into the sweep); 0: rotation kernel + row sweep.  Read when
+ *                            an odometry object is created and per filter call.
+ *   CFEAR_OPT_MATCHER_LDS_KB 0 (default): the matcher sizes its LDS by the batch; 8..160: every registration runs in
+ *                            that many KB, so that ordinary scans exercise the keyframe groups and the global tail of
+ *                            the correspondence arrays (which only unusually large registrations reach otherwise).
+ *   CFEAR_OPT_MATCHER_WAVES  0 (default): wavefronts per registration chosen by the batch; 2, 4, 8, 16 force a form.
+ *   CFEAR_OPT_HOST_TIMELINE  1: the batched odometry prints where the host spends a frame (every 256 calls).
+ * Returns CFEAR_ERR_INVALID_ARGUMENT for an unknown option or a value outside its range.                          */
+enum cfear_option { CFEAR_OPT_FUSED_DECODE = 0, CFEAR_OPT_MATCHER_LDS_KB = 1, CFEAR_OPT_MATCHER_WAVES = 2,
+                    CFEAR_OPT_HOST_TIMELINE = 3, CFEAR_OPT_COUNT = 4 };
+int cfear_ctx_set_option(cfear_ctx* ctx, int32_t option, int64_t value);
+int cfear_ctx_get_option(const cfear_ctx* ctx, int32_t option, int64_t* value);
 /* Per-kernel-family device time measured with hipEvents on the context's stream.
  * enable=1 brackets every launch with events (adds a sync per read-out, not per launch); enable=2 only the polar
  * filter's row kernels (kstrongest_rows / cacfar_rows: the one HBM-bound launch of the path), which costs a batched

@@ -72,6 +72,8 @@ class Context {                                            // one per host threa
   Context& operator=(const Context&) = delete;
   cfear_ctx* get() const { return ctx_; }
   void check(int st) const { if (st != CFEAR_OK) throw CfearError(st, cfear_last_error(ctx_)); }
+  void* Stream() const { void* s = nullptr; check(cfear_ctx_get_stream(ctx_, &s)); return s; }      // the hipStream_t it enqueues on
+  void SetOption(cfear_option o, int64_t v) { check(cfear_ctx_set_option(ctx_, o, v)); }           // test / measurement hooks
   // The context of the calling thread on device 0, for the reference-signature constructors that take none
   // (the reference's objects are not shared between threads either).
   static Context& Default() { static thread_local Context c(0); return c; }

@@ -216,7 +216,11 @@ EXPORTS = [
     "cfear_shard_range", "cfear_gather_records", "cfear_register_batch_sharded", "cfear_verify_loop_candidates_sharded",
     "cfear_rccl_allgather", "cfear_rccl_allgather_device", "cfear_pgo_params_default", "cfear_pgo_solve",
     "cfear_scan_table_create", "cfear_scan_table_size", "cfear_scan_table_destroy", "cfear_register_candidates",
+    "cfear_ctx_get_stream", "cfear_ctx_set_option", "cfear_ctx_get_option",
 ]
+
+# enum cfear_option (include/cfear_hip.h): test / measurement hooks of a context
+OPT_FUSED_DECODE, OPT_MATCHER_LDS_KB, OPT_MATCHER_WAVES, OPT_HOST_TIMELINE, OPT_COUNT = 0, 1, 2, 3, 4
 
 
 class PgoParams(C.Structure):
@@ -278,6 +282,9 @@ def lib():
     L.cfear_ctx_create.argtypes = [C.c_int, vp, C.POINTER(vp)]
     L.cfear_ctx_destroy.argtypes = [vp]
     L.cfear_ctx_synchronize.argtypes = [vp]
+    L.cfear_ctx_get_stream.argtypes = [vp, C.POINTER(C.c_void_p)]
+    L.cfear_ctx_set_option.argtypes = [vp, C.c_int32, C.c_int64]
+    L.cfear_ctx_get_option.argtypes = [vp, C.c_int32, C.POINTER(C.c_int64)]
     L.cfear_last_error.argtypes = [vp]
     L.cfear_last_error.restype = C.c_char_p
     L.cfear_ctx_profile_enable.argtypes = [vp, C.c_int]

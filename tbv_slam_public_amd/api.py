@@ -39,6 +39,8 @@ class Context:
     that produces this context's inputs must then be synchronised by the caller (default_context() passes hipStreamLegacy
     for torch's default stream instead, which orders the two)."""
 
+    default_options = {}      # {L.OPT_*: value} applied to every new context (measurement scripts: bench.py --ctx-option)
+
     def __init__(self, device=0, stream=None):
         self._lib = L.lib()
         h = C.c_void_p()
@@ -48,6 +50,8 @@ class Context:
                                " (libcfear_hip needs an MI355X; there is no CPU fallback)")
         self.h = h
         self.device = device
+        for opt, val in Context.default_options.items():
+            self.set_option(opt, val)
 
     def check(self, rc, allowed=()):
         if rc != L.OK and rc not in allowed:
@@ -56,6 +60,29 @@ class Context:
 
     def synchronize(self):
         self.check(self._lib.cfear_ctx_synchronize(self.h))
+
+    def stream_handle(self):
+        """The hipStream_t this context enqueues on, as an int (the caller's stream, or the private one)."""
+        s = C.c_void_p()
+        self.check(self._lib.cfear_ctx_get_stream(self.h, C.byref(s)))
+        return int(s.value or 0)
+
+    def shares_torch_stream(self):
+        """True when work enqueued on torch's CURRENT stream is ordered with this context's kernels without a host
+        synchronisation: the two are the same HIP stream (torch's default stream reports 0 -- a context given 0 made a
+        private stream, so 0 never counts as shared)."""
+        import torch
+        ts = int(torch.cuda.current_stream().cuda_stream)
+        return ts != 0 and ts == self.stream_handle()
+
+    def set_option(self, option, value):
+        """cfear_ctx_set_option: the test / measurement hooks of include/cfear_hip.h (L.OPT_*)."""
+        self.check(self._lib.cfear_ctx_set_option(self.h, int(option), int(value)))
+
+    def get_option(self, option):
+        v = C.c_int64()
+        self.check(self._lib.cfear_ctx_get_option(self.h, int(option), C.byref(v)))
+        return int(v.value)
 
     def profile_enable(self, on=True):
         """True / 1: every kernel family; 2: only the polar filter's row kernels; False / 0: off."""

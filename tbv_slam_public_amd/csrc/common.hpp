@@ -43,6 +43,8 @@ struct cfear_ctx {
   std::vector<Slab> free_slabs;
   int64_t live_scans = 0;
   int trig_rows = 0;       // rows the cos/sin tables in ws[2] were built for
+  int n_cu = 256;          // compute units of the device (cfear_ctx_create)
+  int64_t opt[CFEAR_OPT_COUNT] = {1, 0, 0, 0};   // cfear_ctx_set_option (test / measurement hooks; include/cfear_hip.h)
   bool surf_list_dirty = true;   // the surface pipeline's hand-over counter may be non-zero (see cfear_surface_launch)
 };
 

@@ -254,7 +254,35 @@ int cfear_ctx_create(int device, void* hip_stream, cfear_ctx** out) {
     }
     ctx->own_stream = true;
   }
+  (void)hipDeviceGetAttribute(&ctx->n_cu, hipDeviceAttributeMultiprocessorCount, device);
+  if (ctx->n_cu < 1) ctx->n_cu = 256;
   *out = ctx;
+  return CFEAR_OK;
+}
+
+int cfear_ctx_get_stream(const cfear_ctx* ctx, void** hip_stream) {
+  if (!ctx || !hip_stream) return CFEAR_ERR_INVALID_ARGUMENT;
+  *hip_stream = (void*)ctx->stream;
+  return CFEAR_OK;
+}
+
+int cfear_ctx_set_option(cfear_ctx* ctx, int32_t option, int64_t value) {
+  if (!ctx) return CFEAR_ERR_INVALID_ARGUMENT;
+  bool ok = false;
+  switch (option) {
+    case CFEAR_OPT_FUSED_DECODE: case CFEAR_OPT_HOST_TIMELINE: ok = value == 0 || value == 1; break;
+    case CFEAR_OPT_MATCHER_LDS_KB: ok = value == 0 || (value >= 8 && value <= 160); break;
+    case CFEAR_OPT_MATCHER_WAVES: ok = value == 0 || value == 2 || value == 4 || value == 8 || value == 16; break;
+    default: return cfear_set_error(ctx, CFEAR_ERR_INVALID_ARGUMENT, "unknown option %d", (int)option);
+  }
+  if (!ok) return cfear_set_error(ctx, CFEAR_ERR_INVALID_ARGUMENT, "option %d: value %lld out of range", (int)option, (long long)value);
+  ctx->opt[option] = value;
+  return CFEAR_OK;
+}
+
+int cfear_ctx_get_option(const cfear_ctx* ctx, int32_t option, int64_t* value) {
+  if (!ctx || !value || option < 0 || option >= CFEAR_OPT_COUNT) return CFEAR_ERR_INVALID_ARGUMENT;
+  *value = ctx->opt[option];
   return CFEAR_OK;
 }
 

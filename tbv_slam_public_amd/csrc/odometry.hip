@@ -265,9 +265,9 @@ extern "C" int cfear_odometry_create(cfear_ctx* ctx, int32_t n_streams, const cf
   od->fused = par->filter_type == CFEAR_FILTER_KSTRONG && !par->keep_nodes && k <= 64 && rows <= 4096 &&
               rows * k <= cfear_surface_max_points();
   od->row_k = k;
-  // [range bins][azimuths] sources: decode fused into the sweep (CFEAR_NO_FUSED_DECODE keeps the two-kernel route, for
+  // [range bins][azimuths] sources: decode fused into the sweep (CFEAR_OPT_FUSED_DECODE = 0 keeps the two-kernel route, for
   // A/B runs and the tests that compare the two)
-  od->fused_decode = od->fused && par->rotate_ccw && !getenv("CFEAR_NO_FUSED_DECODE");
+  od->fused_decode = od->fused && par->rotate_ccw && ctx->opt[CFEAR_OPT_FUSED_DECODE] != 0;
   if (od->fused_decode) {
     ok = ok && dalloc(&od->d_decode_stats, 2 * 64 * 4);
     ok = ok && halloc(&od->h_decode_stats, 2 * 64 * 4);
@@ -402,8 +402,8 @@ static int run_filter(cfear_odometry* od, const uint8_t* polar, int buf, const i
     return CFEAR_OK;
   }
   // CA-CFAR on [range bins][azimuths] sweeps: the decode fused into the filter (cacfar_cols_kernel), one pass over the image
-  // instead of three (CFEAR_NO_FUSED_DECODE keeps rotate + cacfar_rows, for A/B runs and the tests that compare the two)
-  if (par.rotate_ccw && od->fused_cfar && !getenv("CFEAR_NO_FUSED_DECODE") && B >= 16 &&
+  // instead of three (CFEAR_OPT_FUSED_DECODE = 0 keeps rotate + cacfar_rows, for A/B runs and the tests that compare the two)
+  if (par.rotate_ccw && od->fused_cfar && ctx->opt[CFEAR_OPT_FUSED_DECODE] != 0 && B >= 16 &&
       cfear_cacfar_cols_supported(d_polar, &dd, &par.cacfar)) {
     cfear_cacfar_params cp = par.cacfar;
     cfear_cacfar_fused fz;
@@ -524,8 +524,8 @@ static int load_clouds(cfear_odometry* od, const cfear_sc_cloud* clouds, float* 
 }
 
 namespace {
-struct HostTimeline {          // CFEAR_OD_TIMING=1: where the host spends a frame (printed every 256 calls)
-  bool on = getenv("CFEAR_OD_TIMING") != nullptr;
+struct HostTimeline {          // CFEAR_OPT_HOST_TIMELINE = 1: where the host spends a frame (printed every 256 calls)
+  bool on = false;
   double acc[8] = {0};
   int calls = 0;
   std::chrono::steady_clock::time_point last, exit_t;
@@ -556,8 +556,9 @@ HostTimeline g_tl;
 
 static int process_frame(cfear_odometry* od, const uint8_t* polar, const uint8_t* polar_next, const cfear_sc_cloud* clouds,
                          const cfear_sc_cloud* peaks, cfear_frame_info* info, const int64_t* offsets, const int64_t* offsets_next) {
-  g_tl.start();
   cfear_ctx* ctx = od->ctx;
+  g_tl.on = ctx->opt[CFEAR_OPT_HOST_TIMELINE] != 0;
+  g_tl.start();
   CFEAR_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   const int B = od->n_streams;
   const cfear_odometry_params& par = od->par;

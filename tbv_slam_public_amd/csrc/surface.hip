@@ -1774,7 +1774,7 @@ int cfear_surface_launch(cfear_ctx* ctx, const void* d_jobs, int n_jobs, const c
 #ifdef CFEAR_SURF_TIMING
   {                                            // debug build only: phase split of surface_sort_kernel, averaged over the jobs
     static int calls = 0;
-    if (++calls % 40 == 0 || getenv("CFEAR_SURF_ROUTES")) {
+    if (++calls % 40 == 0) {
       (void)hipStreamSynchronize(ctx->stream);
       {
         int32_t nfb = -1;

@@ -114,12 +114,15 @@ def register_candidates_sharded(jobs, register_fn, group=None):
         send = b["send_d"]
         if hi - lo < per:
             send[(hi - lo) * rec:].zero_()               # padding slots are never returned
-            torch.cuda.current_stream().synchronize()    # (the library writes on its own stream)
+            if not register_fn.ctx.shares_torch_stream():
+                torch.cuda.current_stream().synchronize()    # (the library writes on its own stream)
         got = register_fn.into(jobs[lo:hi], send.data_ptr())
         assert got == hi - lo
-        if not getattr(register_fn, "same_stream", False):
-            register_fn.ctx.synchronize()                # the library runs on its own stream: torch must see the records
-        # (same_stream: the context was created on torch's current stream -- the collective is simply ordered behind the kernel)
+        # The collective is enqueued on torch's current stream.  When the context enqueues on that very stream (a context
+        # created on a non-default torch stream; checked here, not taken from the caller) it is simply ordered behind the
+        # kernels; otherwise the library ran on another stream and torch must wait for the records.
+        if not register_fn.ctx.shares_torch_stream():
+            register_fn.ctx.synchronize()
         dist.all_gather_into_tensor(b["recv_d"], send, group=group)
         b["recv_h"].copy_(b["recv_d"], non_blocking=True)
         torch.cuda.current_stream().synchronize()

@@ -251,17 +251,15 @@ def test_cacfar_fused_decode_rows_with_more_candidates_than_the_list_holds():
 
 
 @pytest.mark.parametrize("device_input,two_kernel", [(False, False), (True, False), (True, True)])
-def test_rotated_input_layout_equals_prerotated(device_input, two_kernel, monkeypatch):
+def test_rotated_input_layout_equals_prerotated(device_input, two_kernel):
     """par.rotate_ccw: images arrive as [range bins][azimuths] (non-Oxford drivers, radar_driver.cpp:74-90); the
     pipeline decodes them on the GPU -- fused into the filter stage (candidate lists, no rotated copy), or, with
-    CFEAR_NO_FUSED_DECODE (and for image geometries the fused stage does not take), by the rotation kernel -- and must then
-    behave exactly like the same frames fed in the Oxford layout."""
+    the context option CFEAR_OPT_FUSED_DECODE = 0 (and for image geometries the fused stage does not take), by the rotation
+    kernel -- and must then behave exactly like the same frames fed in the Oxford layout."""
     import torch
     from tbv_slam_public_amd import api, synth
-    if two_kernel:
-        monkeypatch.setenv("CFEAR_NO_FUSED_DECODE", "1")          # read when the odometry object is created
-    else:
-        monkeypatch.delenv("CFEAR_NO_FUSED_DECODE", raising=False)
+    from tbv_slam_public_amd import _lib as L
+    api.default_context().set_option(L.OPT_FUSED_DECODE, 0 if two_kernel else 1)   # read when the odometry object is created
     n_frames = 5
     seqs = [synth.scene_v1(sd, n_frames, range_res=0.0595238, ccw=True)[0] for sd in (4, 6)]
     kw = dict(kstrong_range_res=0.0595238, radar_ccw=1, submap_scan_size=5)
@@ -274,6 +272,7 @@ def test_rotated_input_layout_equals_prerotated(device_input, two_kernel, monkey
         b = rot.process(torch.from_numpy(sent).cuda() if device_input else sent)
         for name in a.dtype.names:
             np.testing.assert_array_equal(a[name], b[name], err_msg=name)
+    api.default_context().set_option(L.OPT_FUSED_DECODE, 1)
     assert (a["reg_status"] == 0).all() and a["n_cells"].min() > 100
 
 
