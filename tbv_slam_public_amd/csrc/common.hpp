@@ -46,6 +46,7 @@ struct cfear_ctx {
   int n_cu = 256;          // compute units of the device (cfear_ctx_create)
   int64_t opt[CFEAR_OPT_COUNT] = {1, 0, 0, 0};   // cfear_ctx_set_option (test / measurement hooks; include/cfear_hip.h)
   bool surf_list_dirty = true;   // the surface pipeline's hand-over counter may be non-zero (see cfear_surface_launch)
+  std::vector<const void*> full_lds_fns;   // kernels already allowed the CU's whole LDS on this device (matcher.hip)
 };
 
 int cfear_set_error(cfear_ctx* ctx, int status, const char* fmt, ...);
@@ -90,9 +91,6 @@ struct ProfScope {
 // ---------------------------------------------------------------------------------------------
 struct ScanView {          // plain pointers into one slab; passed to kernels by value / in tables
   float2* mean_f;          // float copy of the means (pointnormal.cpp:151-162), NN search space
-  float* sorted_x;         // the same float means sorted by (x, index): x, y and original cell index.
-  float* sorted_y;         //   The matcher's exact 1-NN only visits the window |x - qx| <= radius of
-  int32_t* sorted_idx;     //   this order instead of a kd-tree (register.hip).
   double2* mean;           // u_
   double2* normal;         // snormal_
   double4* cov;            // cov_ row-major (c00,c01,c10,c11)
@@ -101,11 +99,13 @@ struct ScanView {          // plain pointers into one slab; passed to kernels by
   double2* lambda;         // (lambda_min, lambda_max)
   int32_t* nsamples;
   int32_t* n_cells;        // device counter (written by the surface kernel)
-  // The matcher's search structure, prebuilt once per scan (sort_cells_block): the float means bucketed into a uniform
+  // The matcher's search structure, prebuilt once per scan (grid_cells_block): the float means bucketed into a uniform
   // kScanGrid x kScanGrid grid over the scan's own extent -- what the reference keeps as a kd-tree per MapPointNormal
-  // (pointnormal.cpp:151-162).  A registration copies these tables into LDS instead of rebuilding them.
-  float4* grid_txyi;       // [n] (x, y, cell index as int bits, 0) grouped by grid cell
-  unsigned short* grid_cstart;   // [kScanGridStartPad] first record of every grid cell (row-major), entries past the last cell = n
+  // (pointnormal.cpp:151-162).  ONE block that a registration copies into LDS in 16-byte pieces:
+  //   [kScanGridStartPad] u16  first record of every grid cell (row-major), entries past the last cell = n
+  //   [np] float2              (x, y) of the records, grouped by grid cell            np = scan_grid_pad(n)
+  //   [np] u16                 the records' cell indices (10 bytes per record in all: four keyframes + the LM arrays fit 40 KB)
+  unsigned short* grid;
   float4* grid_geo;        // (x0, y0, cells per metre, 1 = tables valid | 0 = more cells than the 16-bit table can address)
   int32_t cap;
   int32_t pad;
@@ -113,6 +113,8 @@ struct ScanView {          // plain pointers into one slab; passed to kernels by
 constexpr int kScanGrid = 32;                                  // grid cells per axis
 constexpr int kScanGridCells = kScanGrid * kScanGrid;
 constexpr int kScanGridStartPad = kScanGridCells + 8;          // u16 entries per scan: a multiple of 16 bytes
+__host__ __device__ inline int scan_grid_pad(int n) { return (n + 7) & ~7; }        // records per scan, padded: both record arrays are runs of 16-byte pieces
+__host__ __device__ inline size_t scan_grid_bytes(int n) { return (size_t)kScanGridStartPad * 2 + (size_t)scan_grid_pad(n) * 10; }
 constexpr float kScanGridMinEdge = 2.0f;                       // cell edge floor [m]: the matcher's radius (registration.h:131)
 
 struct cfear_scan {
@@ -120,7 +122,9 @@ struct cfear_scan {
   void* slab;
   ScanView view;
   int32_t n_cells_host;    // -1 until read back
+  int32_t refs = 1;        // the caller's handle + one per scan table that names it (handles are used from one host thread)
 };
+void cfear_scan_retain(cfear_scan* scan);   // cfear_scan_destroy drops one reference; the slab is recycled with the last
 
 size_t cfear_scan_slab_bytes(int cap);
 ScanView cfear_scan_view(void* slab, int cap);
@@ -193,8 +197,8 @@ int cfear_register_batch_device(cfear_ctx* ctx, const cfear_reg_job* jobs, int32
 size_t cfear_reg_job_bytes();
 int cfear_reg_max_scans();
 void cfear_reg_fill_job(void* dst, const ScanView* views, int n_scans, const double* poses_xyt);
-size_t cfear_register_scratch_bytes(int slots_cap);
-// Cost-only launches of the registration kernel (GetCost / cost sampling): n_samples = 0 evaluates each job
+size_t cfear_register_scratch_bytes(int pairs_cap);
+// Cost-only launches of the matcher (GetCost / cost sampling): n_samples = 0 evaluates each job
 // at its own source pose, n_samples = samples_per_axis^3 at the sampling grid around it; results then holds
 // max(n_samples, 1) records per job.  blocks_per_job workgroups share a job's samples (scratch: n_jobs x
 // blocks_per_job x cfear_register_scratch_bytes).
@@ -203,11 +207,15 @@ struct RegCostMode {
   double xy_half = 0.0, yaw_half = 0.0;
   const cfear_reg_result* prior = nullptr;   // device, [n_jobs]: evaluate around prior[j].pose with itr = prior[j].outer_iters
 };
-int cfear_register_launch(cfear_ctx* ctx, const void* d_jobs, int n_jobs, const cfear_reg_params* par, int slots_cap,
-                          int lds_targets, char* d_scratch, cfear_reg_result* d_results, const RegCostMode* mode = nullptr,
+// What the caller knows about the batch's registrations (the kernel decides per registration from the device-side sizes):
+struct RegLaunchHint {
+  bool small_pairs = false;   // every job is a two-scan candidate that fits 20 KB of LDS: the 2-wavefront form, eight per CU
+  bool big_pass = false;      // registrations the regular form is not good at may be among them (dense scans): add the large forms
+};
+int cfear_register_launch(cfear_ctx* ctx, const void* d_jobs, int n_jobs, const cfear_reg_params* par, int pairs_cap,
+                          char* d_scratch, cfear_reg_result* d_results, const RegCostMode* mode = nullptr,
                           size_t job_stride = 0,    // 0: full records (cfear_reg_job_bytes)
-                          bool compact = false,     // 2-wavefront / 40 KB geometry: the caller guarantees that every job fits
-                          bool big_pass = false);   // second launch (one workgroup per CU, all of its LDS) for registrations too large for 80 KB
+                          RegLaunchHint hint = RegLaunchHint());
 size_t cfear_reg_job_stride(int max_scans);         // bytes of a record that holds up to max_scans scan views
 void cfear_reg_job_set_itr(void* job, int itr);
 // quadratic fit of the cost samples -> 6x6 covariance (covariance.hip, host)

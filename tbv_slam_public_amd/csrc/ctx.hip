@@ -124,12 +124,11 @@ size_t cfear_scan_slab_bytes(int cap) {
   size_t c = (size_t)cap;
   size_t b = 256;                                  // header: n_cells counter
   b += align_up(c * sizeof(float2), 256);
-  b += align_up(c * sizeof(float), 256) * 3;       // sorted_x, sorted_y, sorted_idx
   b += align_up(c * sizeof(double2), 256) * 3;     // mean, normal, lambda
   b += align_up(c * sizeof(double4), 256);
   b += align_up(c * sizeof(double), 256) * 2;      // scale, avg_intensity
   b += align_up(c * sizeof(int32_t), 256);
-  b += align_up((size_t)kScanGridStartPad * 2 + c * sizeof(float4), 256);          // prebuilt matcher grid: cell starts, then the records
+  b += align_up(scan_grid_bytes(cap), 256);        // prebuilt matcher grid: cell starts, then the records (ScanView::grid)
   return b;
 }
 
@@ -139,9 +138,6 @@ ScanView cfear_scan_view(void* slab, int cap) {
   ScanView v;
   v.n_cells = (int32_t*)p; p += 256;
   v.mean_f = (float2*)p; p += align_up(c * sizeof(float2), 256);
-  v.sorted_x = (float*)p; p += align_up(c * sizeof(float), 256);
-  v.sorted_y = (float*)p; p += align_up(c * sizeof(float), 256);
-  v.sorted_idx = (int32_t*)p; p += align_up(c * sizeof(int32_t), 256);
   v.mean = (double2*)p; p += align_up(c * sizeof(double2), 256);
   v.normal = (double2*)p; p += align_up(c * sizeof(double2), 256);
   v.lambda = (double2*)p; p += align_up(c * sizeof(double2), 256);
@@ -149,8 +145,7 @@ ScanView cfear_scan_view(void* slab, int cap) {
   v.scale = (double*)p; p += align_up(c * sizeof(double), 256);
   v.avg_intensity = (double*)p; p += align_up(c * sizeof(double), 256);
   v.nsamples = (int32_t*)p; p += align_up(c * sizeof(int32_t), 256);
-  v.grid_cstart = (unsigned short*)p;               // ONE block: a registration copies cell starts and records in one sweep
-  v.grid_txyi = (float4*)(p + (size_t)kScanGridStartPad * 2);
+  v.grid = (unsigned short*)p;                     // ONE block: a registration copies cell starts and records in one sweep
   v.grid_geo = (float4*)((char*)slab + 16);        // inside the 256-byte header, behind the counter
   v.cap = cap;
   v.pad = 0;
@@ -192,9 +187,6 @@ int cfear_scan_clone_view(cfear_ctx* ctx, const ScanView& src, int n, cfear_scan
   };
   hipError_t e = cp(d.n_cells, src.n_cells, 4);
   if (e == hipSuccess) e = cp(d.mean_f, src.mean_f, c * sizeof(float2));
-  if (e == hipSuccess) e = cp(d.sorted_x, src.sorted_x, c * 4);
-  if (e == hipSuccess) e = cp(d.sorted_y, src.sorted_y, c * 4);
-  if (e == hipSuccess) e = cp(d.sorted_idx, src.sorted_idx, c * 4);
   if (e == hipSuccess) e = cp(d.mean, src.mean, c * sizeof(double2));
   if (e == hipSuccess) e = cp(d.normal, src.normal, c * sizeof(double2));
   if (e == hipSuccess) e = cp(d.lambda, src.lambda, c * sizeof(double2));
@@ -202,14 +194,15 @@ int cfear_scan_clone_view(cfear_ctx* ctx, const ScanView& src, int n, cfear_scan
   if (e == hipSuccess) e = cp(d.scale, src.scale, c * 8);
   if (e == hipSuccess) e = cp(d.avg_intensity, src.avg_intensity, c * 8);
   if (e == hipSuccess) e = cp(d.nsamples, src.nsamples, c * 4);
-  if (e == hipSuccess) e = cp(d.grid_txyi, src.grid_txyi, c * sizeof(float4));
-  if (e == hipSuccess) e = cp(d.grid_cstart, src.grid_cstart, (size_t)kScanGridStartPad * 2);
+  if (e == hipSuccess) e = cp(d.grid, src.grid, scan_grid_bytes(n));
   if (e == hipSuccess) e = cp(d.grid_geo, src.grid_geo, sizeof(float4));
   if (e != hipSuccess) { cfear_scan_destroy(s); return cfear_set_error(ctx, CFEAR_ERR_HIP, "scan copy failed: %s", hipGetErrorString(e)); }
   s->n_cells_host = n;
   *out = s;
   return CFEAR_OK;
 }
+
+void cfear_scan_retain(cfear_scan* scan) { if (scan) scan->refs++; }
 
 // ---- C-ABI ---------------------------------------------------------------------------------------
 extern "C" {
@@ -438,6 +431,7 @@ int cfear_scan_size(const cfear_scan* scan) {
 
 int cfear_scan_destroy(cfear_scan* scan) {
   if (!scan) return CFEAR_OK;
+  if (--scan->refs > 0) return CFEAR_OK;                   // a scan table still names it (cfear_scan_retain)
   cfear_ctx* ctx = scan->ctx;
   // the slab may still be read by enqueued kernels of this stream; later users are on the same
   // stream, so recycling it is ordered.

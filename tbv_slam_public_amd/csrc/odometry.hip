@@ -703,8 +703,10 @@ static int process_frame(cfear_odometry* od, const uint8_t* polar, const uint8_t
   g_tl.mark(1);
   if (n_jobs > 0) {
     OD_CHECK(hipStreamWaitEvent(ctx->stream, od->ev_jobs, 0));
-    rc = cfear_register_launch(ctx, od->d_reg_jobs, n_jobs, &par.reg, par.submap_scan_size * od->cell_cap, od->cell_cap,
-                               od->d_reg_scratch, od->d_results, nullptr, rjb, false, od->big_regs > 0);
+    RegLaunchHint hint;
+    hint.big_pass = od->big_regs > 0;
+    rc = cfear_register_launch(ctx, od->d_reg_jobs, n_jobs, &par.reg, par.submap_scan_size * od->cell_cap,
+                               od->d_reg_scratch, od->d_results, nullptr, rjb, hint);
     if (rc != CFEAR_OK) return fail(rc);
     if (par.estimate_cov_by_sampling) {
       // approximateCovarianceBySampling (:203-208, 261-316): n^3 GetCost evaluations around the pose the
@@ -717,8 +719,8 @@ static int process_frame(cfear_odometry* od, const uint8_t* polar, const uint8_t
       mode.yaw_half = par.cov_sampling.yaw_range * 0.5;
       mode.blocks_per_job = 1;                                    // one workgroup per stream: its scratch is reused
       mode.prior = od->d_results;
-      rc = cfear_register_launch(ctx, od->d_reg_jobs, n_jobs, &par.reg, par.submap_scan_size * od->cell_cap, od->cell_cap,
-                                 od->d_reg_scratch, od->d_samples, &mode, rjb);
+      rc = cfear_register_launch(ctx, od->d_reg_jobs, n_jobs, &par.reg, par.submap_scan_size * od->cell_cap,
+                                 od->d_reg_scratch, od->d_samples, &mode, rjb, hint);
       if (rc != CFEAR_OK) return fail(rc);
       OD_CHECK(hipMemcpyAsync(od->h_samples, od->d_samples, (size_t)n_jobs * od->fit.m * sizeof(cfear_reg_result),
                                           hipMemcpyDeviceToHost, ctx->stream));

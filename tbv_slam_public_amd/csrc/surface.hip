@@ -316,11 +316,11 @@ __device__ __forceinline__ int upper_bound_u32(const uint32_t* a, int lo, int hi
   return lo;
 }
 
-// The matcher's search structure of a scan (ScanView::grid_*): the float means bucketed into a uniform kScanGrid x kScanGrid
+// The matcher's search structure of a scan (ScanView::grid): the float means bucketed into a uniform kScanGrid x kScanGrid
 // grid over the scan's own extent, built ONCE per scan -- the counterpart of ComputeSearchTreeFromCells (pointnormal.cpp:
-// 151-162), which builds the reference's kd-tree once per MapPointNormal.  A registration copies the tables into LDS
-// (register.hip: register3_kernel) instead of bucketing every keyframe again.  Counting sort with LDS atomics; the order of
-// the records inside a cell is arbitrary (the nearest-neighbour rule breaks ties by the cell index a record carries).
+// 151-162), which builds the reference's kd-tree once per MapPointNormal.  A registration copies the block into LDS
+// (matcher.hip) instead of bucketing every keyframe again.  Counting sort with LDS atomics; the order of the records inside
+// a cell is arbitrary (the nearest-neighbour rule breaks ties by the cell index a record carries).
 // Block-wide collective; lds: kScanGridLds bytes of scratch.
 constexpr size_t kScanGridLds = (size_t)kScanGridCells * 4 + 128;
 __device__ void grid_cells_block(const ScanView& v, int n, uint8_t* lds) {
@@ -329,10 +329,14 @@ __device__ void grid_cells_block(const ScanView& v, int n, uint8_t* lds) {
   unsigned* ext = cnt + kScanGridCells;                      // [4] ordered images of min x, max x, min y, max y | [16] wave totals
   auto ordered = [](float f) { unsigned u = __float_as_uint(f); return (u >> 31) ? ~u : (u | 0x80000000u); };
   auto unordered = [](unsigned u) { return __uint_as_float((u >> 31) ? (u & 0x7fffffffu) : ~u); };
-  if (n > 65535) {                                           // the cell table is 16-bit: such a scan keeps the x-sorted route
+  if (n > 65535) {                                           // the tables are 16-bit: the matcher reports such a scan (CFEAR_ERR_CAPACITY)
     if (tid == 0) *v.grid_geo = make_float4(0.f, 0.f, 0.f, 0.f);
     return;
   }
+  const int np = scan_grid_pad(n);
+  unsigned short* cstart = v.grid;
+  float2* rec_xy = (float2*)(v.grid + kScanGridStartPad);
+  unsigned short* rec_idx = (unsigned short*)(rec_xy + np);
   for (int c = tid; c < kScanGridCells; c += nth) cnt[c] = 0;
   if (tid < 4) ext[tid] = (tid & 1) ? 0u : 0xFFFFFFFFu;
   __syncthreads();
@@ -357,7 +361,7 @@ __device__ void grid_cells_block(const ScanView& v, int n, uint8_t* lds) {
   }
   // cell edge: the extent split into kScanGrid cells, never below the matcher's radius (finer cells would only add rows to a query)
   const float inv = 1.0f / fmaxf(span / (float)kScanGrid * 1.0001f, kScanGridMinEdge);
-  auto cell_of = [&](float x, float y) {                     // the same expression locates a query's cells in register.hip
+  auto cell_of = [&](float x, float y) {                     // the same expression locates a query's cells in matcher.hip
     const int cx = min(kScanGrid - 1, max(0, (int)floorf((x - x0) * inv)));
     const int cy = min(kScanGrid - 1, max(0, (int)floorf((y - y0) * inv)));
     return cy * kScanGrid + cx;
@@ -375,153 +379,29 @@ __device__ void grid_cells_block(const ScanView& v, int n, uint8_t* lds) {
     for (int wv = 0; wv < (tid >> 6); wv++) run += (int)ext[4 + wv];
     for (int c = c0; c < c1; c++) {
       const int k = (int)cnt[c];
-      gstore<unsigned short>(v.grid_cstart + c, (unsigned short)run);
+      gstore<unsigned short>(cstart + c, (unsigned short)run);
       cnt[c] = (unsigned)run;
       run += k;
     }
-    if (tid < kScanGridStartPad - kScanGridCells) gstore<unsigned short>(v.grid_cstart + kScanGridCells + tid, (unsigned short)n);
+    if (tid < kScanGridStartPad - kScanGridCells) gstore<unsigned short>(cstart + kScanGridCells + tid, (unsigned short)n);
   }
   __syncthreads();
   for (int i = tid; i < n; i += nth) {
     const g_f32x2 m = gload<g_f32x2>(v.mean_f + i);
     const unsigned pos = atomicAdd(&cnt[cell_of(m.x, m.y)], 1u);
-    gstore<g_f32x4>(v.grid_txyi + pos, g_f32x4{m.x, m.y, __int_as_float(i), 0.f});
+    gstore<g_f32x2>(rec_xy + pos, m);
+    gstore<unsigned short>(rec_idx + pos, (unsigned short)i);
+  }
+  if (tid < np - n) {                                        // the padding records are copied with the rest: defined values
+    gstore<g_f32x2>(rec_xy + n + tid, g_f32x2{0.f, 0.f});
+    gstore<unsigned short>(rec_idx + n + tid, (unsigned short)0);
   }
   if (tid == 0) gstore<g_f32x4>(v.grid_geo, g_f32x4{x0, y0, inv, 1.f});
 }
 
-__device__ void sort_cells_x(const ScanView& v, int n, unsigned long long* keys, const size_t lds_bytes);
-// The two search orders of a scan: sorted by (x, index) (the windowed search of the slot path, closest_idx) and the grid.
-// keys: LDS scratch for at least max(next_pow2(n) 64-bit keys, kScanGridLds bytes).
-__device__ void sort_cells_block(const ScanView& v, int n, unsigned long long* keys, const size_t lds_bytes = 0) {
-  sort_cells_x(v, n, keys, lds_bytes);
-  __syncthreads();
-  grid_cells_block(v, n, (uint8_t*)keys);
-}
-
-// Sorts the n float means of a scan by (x, cell index) into v.sorted_{x,y,idx}; block-wide collective.
-// keys: LDS scratch for at least next_pow2(n) 64-bit keys.
-__device__ void sort_cells_x(const ScanView& v, int n, unsigned long long* keys, const size_t lds_bytes) {
-  const int tid = threadIdx.x, nth = blockDim.x;
-  int npad = 64;
-  while (npad < n) npad <<= 1;
-  for (int i = tid; i < npad; i += nth) {
-    unsigned long long key = ~0ull;
-    if (i < n) {
-      unsigned u = __float_as_uint(gload<float>(&v.mean_f[i].x));
-      u ^= (u >> 31) ? 0xFFFFFFFFu : 0x80000000u;           // order-preserving float -> uint
-      key = ((unsigned long long)u << 32) | (unsigned)i;
-    }
-    keys[i] = key;
-  }
-  __syncthreads();
-  if (n > 128 && n <= 2048 && lds_bytes >= (size_t)npad * 16 + 1024) {
-    // Bucketed rank sort.  A plain rank sort compares every key with every other (335 cells: 112 k comparisons, half of
-    // surface_finish_kernel's instructions); here the keys are first grouped into 64 buckets by x (a monotone function
-    // of x, so a key's rank = keys in lower buckets + smaller keys of its own bucket -- still the exact (x, index) order)
-    // with an LDS counting sort, and every key only meets the ~n / 64 keys of its bucket.
-    constexpr int B = 64;
-    unsigned long long* keys2 = keys + npad;
-    int* cnt = (int*)(keys2 + npad);                       // [B] counts -> cursors | [B + 1] starts | 32 floats
-    int* start = cnt + B;
-    float* red = (float*)(start + B + 1);
-    auto x_of = [](unsigned long long key) {
-      const unsigned u = (unsigned)(key >> 32);
-      return __uint_as_float((u >> 31) ? (u ^ 0x80000000u) : ~u);
-    };
-    float mn = FLT_MAX, mx = -FLT_MAX;
-    for (int i = tid; i < n; i += nth) { const float x = x_of(keys[i]); mn = fminf(mn, x); mx = fmaxf(mx, x); }
-    for (int o = 32; o > 0; o >>= 1) { mn = fminf(mn, __shfl_xor(mn, o)); mx = fmaxf(mx, __shfl_xor(mx, o)); }
-    if ((tid & 63) == 0) { red[tid >> 6] = mn; red[16 + (tid >> 6)] = mx; }
-    if (tid < B) cnt[tid] = 0;
-    __syncthreads();
-    mn = red[0]; mx = red[16];
-    for (int w = 1; w < (nth >> 6); w++) { mn = fminf(mn, red[w]); mx = fmaxf(mx, red[16 + w]); }
-    const float scale = mx > mn ? (float)B / (mx - mn) : 0.f;
-    auto bucket_of = [&](float x) { return min(B - 1, (int)((x - mn) * scale)); };
-    for (int i = tid; i < n; i += nth) atomicAdd(&cnt[bucket_of(x_of(keys[i]))], 1);
-    __syncthreads();
-    if (tid < 64) {                                        // B == 64: one wavefront scans the buckets
-      const int c = cnt[tid];
-      const int incl = wave_incl_scan_i32(c);
-      start[tid] = incl - c;
-      if (tid == 63) start[B] = incl;
-    }
-    __syncthreads();
-    if (tid < B) cnt[tid] = start[tid];
-    __syncthreads();
-    for (int i = tid; i < n; i += nth) {
-      const unsigned long long key = keys[i];
-      keys2[atomicAdd(&cnt[bucket_of(x_of(key))], 1)] = key;
-    }
-    __syncthreads();
-    for (int j = tid; j < n; j += nth) {
-      const unsigned long long key = keys2[j];
-      const int b = bucket_of(x_of(key));
-      const int bs = start[b], be = start[b + 1];
-      int rank = bs, q = bs;
-      for (; q + 1 < be; q += 2) { const unsigned long long k0 = keys2[q], k1 = keys2[q + 1]; rank += (k0 < key) + (k1 < key); }
-      if (q < be) rank += keys2[q] < key;
-      const int i = (int)(unsigned)(key & 0xFFFFFFFFu);
-      const g_f32x2 m = gload<g_f32x2>(v.mean_f + i);
-      v.sorted_x[rank] = m.x;
-      v.sorted_y[rank] = m.y;
-      v.sorted_idx[rank] = i;
-    }
-    return;
-  }
-  if (n <= 2048) {
-    // rank sort: keys are unique, so rank = #smaller keys; every lane reads the same LDS address per
-    // step (broadcast), no barriers -- far cheaper than ~50 bitonic passes for a few hundred cells.
-    // A few hundred keys leave most of the workgroup idle, so 2 or 4 adjacent lanes share a key and
-    // interleave the comparison range.
-    const int lp = (4 * n <= nth) ? 4 : (2 * n <= nth) ? 2 : 1;
-    const int nl = (n + 7) & ~7;                          // keys past n are ~0 (never smaller); npad >= 64 covers the round-up
-    for (int i0 = 0; i0 < n; i0 += nth / lp) {
-      const int i = i0 + tid / lp, part = tid % lp;
-      const unsigned long long key = i < n ? keys[i] : 0ull;
-      int rank = 0;
-      for (int j = 8 * part; j < nl; j += 8 * lp) {       // four 16-byte broadcast reads in flight per step
-        const ulonglong2 k0 = *(const ulonglong2*)(keys + j), k1 = *(const ulonglong2*)(keys + j + 2);
-        const ulonglong2 k2 = *(const ulonglong2*)(keys + j + 4), k3 = *(const ulonglong2*)(keys + j + 6);
-        rank += (k0.x < key) + (k0.y < key) + (k1.x < key) + (k1.y < key);
-        rank += (k2.x < key) + (k2.y < key) + (k3.x < key) + (k3.y < key);
-      }
-      if (lp >= 2) rank += __shfl_xor(rank, 1);
-      if (lp >= 4) rank += __shfl_xor(rank, 2);
-      if (i < n && part == 0) {
-        const g_f32x2 m = gload<g_f32x2>(v.mean_f + i);
-        v.sorted_x[rank] = m.x;
-        v.sorted_y[rank] = m.y;
-        v.sorted_idx[rank] = i;
-      }
-    }
-    return;
-  }
-  for (int k = 2; k <= npad; k <<= 1) {
-    for (int j = k >> 1; j > 0; j >>= 1) {
-      for (int t = tid; t < (npad >> 1); t += nth) {
-        const int lo = ((t & ~(j - 1)) << 1) | (t & (j - 1));
-        const int hi = lo | j;
-        const bool asc = (lo & k) == 0;
-        const unsigned long long a = keys[lo], b = keys[hi];
-        if ((a > b) == asc) { keys[lo] = b; keys[hi] = a; }
-      }
-      __syncthreads();
-    }
-  }
-  for (int i = tid; i < n; i += nth) {
-    const int idx = (int)(keys[i] & 0xFFFFFFFFu);
-    const g_f32x2 m = gload<g_f32x2>(v.mean_f + idx);
-    gstore<float>(v.sorted_x + i, m.x);
-    gstore<float>(v.sorted_y + i, m.y);
-    gstore<int32_t>(v.sorted_idx + i, idx);
-  }
-}
-
-__global__ __launch_bounds__(kSurfThreads) void scan_sort_kernel(ScanView v, uint32_t lds_bytes) {
-  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-  sort_cells_block(v, *v.n_cells, (unsigned long long*)smem, lds_bytes);
+__global__ __launch_bounds__(kSurfThreads) void scan_grid_kernel(ScanView v) {
+  __shared__ __attribute__((aligned(16))) uint8_t smem[kScanGridLds];
+  grid_cells_block(v, *v.n_cells, smem);
 }
 
 // Clouds with more than kMaxPoints points (CA-CFAR sweeps: cfar.cpp:35-71 puts no bound on the detections per row):
@@ -921,10 +801,10 @@ __device__ void surface_points_job(const SurfJob* __restrict__ jobs, const SurfC
     if (tid == 0) { int tot = 0; for (int wv = 0; wv < 16; wv++) tot += red_i[wv]; sh_misc[0] += tot; }
     __syncthreads();
   }
-  // ---- 6. x-sorted copy of the float means for the matcher's windowed exact 1-NN -----------------
+  // ---- 6. the matcher's grid over the float means (its exact 1-NN search structure) -----------------
   __threadfence_block();
   __syncthreads();
-  sort_cells_block(job.out, min(sh_misc[0], job.out.cap), (unsigned long long*)smem, kLdsRowbegOff);
+  grid_cells_block(job.out, min(sh_misc[0], job.out.cap), smem);
   if (tid == 0) {
     const int total = sh_misc[0];
     *job.out.n_cells = total <= job.out.cap ? total : job.out.cap;
@@ -1619,7 +1499,7 @@ __global__ __launch_bounds__(kFinishThreads) void surface_finish_kernel(const Su
   __syncthreads();
   const int total = run;
   const int cap = min(job.out.cap, cm.finish_keys);
-  sort_cells_block(job.out, min(total, cap), (unsigned long long*)smem, cm.finish_lds);
+  grid_cells_block(job.out, min(total, cap), smem);
   if (tid == 0) {
     *job.out.n_cells = total <= cap ? total : cap;
     cm.status[job_id] = total <= cap ? CFEAR_OK : CFEAR_ERR_CAPACITY;
@@ -1734,14 +1614,9 @@ int cfear_surface_launch(cfear_ctx* ctx, const void* d_jobs, int n_jobs, const c
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)cfear_surface_lds_bytes()));
   CFEAR_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)surface_sort_kernel,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFastLds));
-  int keys_pow2 = 64;
-  while (keys_pow2 < max_cell_cap && keys_pow2 < kMaxPoints) keys_pow2 <<= 1;   // the x-sort holds at most 16 384 cells (128 KiB)
-  cm.finish_keys = keys_pow2;
-  const size_t finish_lds = std::max(std::max((size_t)keys_pow2 * 8, (size_t)std::min(keys_pow2, 2048) * 16 + 1024), kScanGridLds);   // bucketed rank sort: two key arrays; then the matcher grid's counters
+  cm.finish_keys = std::min(max_cell_cap, kMaxPoints);     // cells a scan may hold (the matcher's 16-bit tables address 65 535)
+  const size_t finish_lds = kScanGridLds;                    // the matcher grid's counters
   cm.finish_lds = (uint32_t)finish_lds;
-  if (finish_lds > 64 * 1024)
-    CFEAR_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)surface_finish_kernel,
-                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)finish_lds));
   {
     // rows mode: rowoff i32[rows + 1] | row of every point u16[n] | (cos, sin) f64[rows]
     size_t prep_lds = 0;
@@ -1904,17 +1779,9 @@ extern "C" int cfear_scan_from_cells(cfear_ctx* ctx, const cfear_cell* cells, in
     CFEAR_HIP_CHECK(ctx, hipMemcpyAsync(d, cells, (size_t)n_cells * sizeof(cfear_cell), hipMemcpyHostToDevice, ctx->stream));
   hipLaunchKernelGGL(cells_to_slab_kernel, dim3((n_cells + 255) / 256 + 1), dim3(256), 0, ctx->stream, d, n_cells, s->view);
   CFEAR_HIP_CHECK(ctx, hipGetLastError());
-  {
-    int npad = 64;
-    while (npad < n_cells) npad <<= 1;
-    if ((size_t)npad * 8 > 64 * 1024)
-      CFEAR_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)scan_sort_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                               (int)((size_t)kMaxPoints * 8)));
-    if (npad > kMaxPoints) { cfear_scan_destroy(s); return cfear_set_error(ctx, CFEAR_ERR_CAPACITY, "more than %d cells", kMaxPoints); }
-    const size_t sort_lds = std::max(std::max((size_t)npad * 8, (size_t)std::min(npad, 2048) * 16 + 1024), kScanGridLds);
-    hipLaunchKernelGGL(scan_sort_kernel, dim3(1), dim3(kSurfThreads), sort_lds, ctx->stream, s->view, (uint32_t)sort_lds);
-    CFEAR_HIP_CHECK(ctx, hipGetLastError());
-  }
+  if (n_cells > kMaxPoints) { cfear_scan_destroy(s); return cfear_set_error(ctx, CFEAR_ERR_CAPACITY, "more than %d cells", kMaxPoints); }
+  hipLaunchKernelGGL(scan_grid_kernel, dim3(1), dim3(kSurfThreads), 0, ctx->stream, s->view);
+  CFEAR_HIP_CHECK(ctx, hipGetLastError());
   CFEAR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));     // caller's host array may go away
   s->n_cells_host = n_cells;
   *out = s;

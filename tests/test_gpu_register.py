@@ -109,50 +109,51 @@ def _dense_cells(seed, frames):
     return out, gt
 
 
-def test_second_launch_capacity_with_packed_targets(monkeypatch):
-    """Registrations too large for the 80 KB association are deferred to the launches behind it.  1 900 cells per scan (cells
-    of two dense scenes side by side, 600 m apart): four keyframes fit register_kernel's second launch with packed 10-byte
-    target records (~2 070 cells per scan); ~2 800 cells per scan exceed that and used to take the x-window path at once.
-    Since round 4 register3_kernel's half-CU form takes all of them (keyframe tables staged group by group) -- with ~2 300
-    cells per scan its match table moves to global scratch -- and must be the launch that does the work; with
-    CFEAR_NO_REG3=1 the older routes (second launch / x-window path) run.  Every route must give the oracle's result."""
+def test_large_registrations_on_every_form():
+    """Registrations the regular form (4 wavefronts, 40 KB) is not good at are deferred to the forms behind it: half a CU (8
+    wavefronts, 80 KB: keyframe tables staged group by group; with ~2 300 cells per scan the match table moves to global
+    scratch) and a whole CU (16 wavefronts).  1 900 / 2 300 / ~2 800 cells per scan (cells of two dense scenes side by side,
+    600 m apart).  Alone, such a job runs on the small-batch form at once (8 wavefronts, the CU's LDS); with the regular form
+    forced (context options) the large forms must be the launches that do the work.  Every route gives the oracle's result."""
     from oracle import pyoracle as O
     from tbv_slam_public_amd import api, synth
+    from tbv_slam_public_amd import _lib as L
     frames = [0, 1, 2, 3, 4]
     worlds = [synth.scene_dense(seed, 5) for seed in (9, 10, 11)]
     gt = worlds[0][1]
     poses = np.array([_rel(gt[0], gt[f]) for f in frames])
     poses[-1] += [0.25, -0.15, 0.006]
     reg = api.n_scan_normal_reg("P2P", "Huber", 0.1, 4)
-    for radius, keep, lo, hi, use in ((2.5, 950, 1700, 2000, (0, 1)), (3.0, 100000, 2100, 8000, (0, 1)), (2.5, 1150, 2299, 2301, (1, 2))):
-        cells = []
-        for f in frames:
-            parts = []
-            for w, (imgs, _, _) in enumerate([worlds[u] for u in use]):
-                sr, si, sc = O.kstrongest(imgs[f], 40, 60)
-                c = O.surface_points(O.kstrongest_cloud(sr, si, sc, 0.0438, 2.5), radius, 1.0, (0, 0), True).copy()
-                c["mean"][:, 0] += 600.0 * w
-                parts.append(c[:keep])
-            cells.append(np.concatenate(parts))
-        assert lo < min(len(c) for c in cells) and max(len(c) for c in cells) < hi, [len(c) for c in cells]
-        maps = [api.MapPointNormal(cells=c) for c in cells]
-        ok_o, po, ro = O.register(cells, poses, _oracle_par(reg))
-        for no_reg3 in (False, True):
-            if no_reg3:
-                monkeypatch.setenv("CFEAR_NO_REG3", "1")                    # (read per launch)
-            else:
-                monkeypatch.delenv("CFEAR_NO_REG3", raising=False)
-            reg.ctx.profile_enable(True); reg.ctx.profile_read(reset=True)
-            out = reg.RegisterBatch([(maps, poses)])[0]
-            prof = reg.ctx.profile_read(reset=True); reg.ctx.profile_enable(False)
-            if not no_reg3:                                               # the half-CU form did the work
-                others = [v[0] for k, v in prof.items() if k != "register_large"]
-                assert prof["register_large"][0] > 5 * max(others), prof
-            assert (out["status"] == 0) == ok_o
-            assert (out["outer_iters"], out["lm_iters"], out["num_residuals"]) == (ro.outer_iters, ro.lm_iters, ro.num_residuals)
-            assert np.abs(out["pose"][:2] - po[-1, :2]).max() <= POS_TOL and abs(out["pose"][2] - po[-1, 2]) <= ROT_TOL
-            assert out["reserved"] == 1.0
-    monkeypatch.delenv("CFEAR_NO_REG3", raising=False)
+    try:
+        for radius, keep, lo, hi, use in ((2.5, 950, 1700, 2000, (0, 1)), (3.0, 100000, 2100, 8000, (0, 1)), (2.5, 1150, 2299, 2301, (1, 2))):
+            cells = []
+            for f in frames:
+                parts = []
+                for w, (imgs, _, _) in enumerate([worlds[u] for u in use]):
+                    sr, si, sc = O.kstrongest(imgs[f], 40, 60)
+                    c = O.surface_points(O.kstrongest_cloud(sr, si, sc, 0.0438, 2.5), radius, 1.0, (0, 0), True).copy()
+                    c["mean"][:, 0] += 600.0 * w
+                    parts.append(c[:keep])
+                cells.append(np.concatenate(parts))
+            assert lo < min(len(c) for c in cells) and max(len(c) for c in cells) < hi, [len(c) for c in cells]
+            maps = [api.MapPointNormal(cells=c) for c in cells]
+            ok_o, po, ro = O.register(cells, poses, _oracle_par(reg))
+            for waves, kb in ((0, 0), (4, 40)):
+                reg.ctx.set_option(L.OPT_MATCHER_WAVES, waves); reg.ctx.set_option(L.OPT_MATCHER_LDS_KB, kb)
+                reg.ctx.profile_enable(True); reg.ctx.profile_read(reset=True)
+                out = reg.RegisterBatch([(maps, poses)])[0]
+                prof = reg.ctx.profile_read(reset=True); reg.ctx.profile_enable(False)
+                if waves:                                                     # the large forms did the work
+                    large = prof["register_large"][0] + prof["register_large16"][0]
+                    assert large > 5 * prof["register"][0], prof
+                else:
+                    assert not any(v[1] for k, v in prof.items() if k.startswith("register_large")), prof
+                assert (out["status"] == 0) == ok_o
+                assert (out["outer_iters"], out["lm_iters"], out["num_residuals"]) == (ro.outer_iters, ro.lm_iters, ro.num_residuals)
+                assert np.abs(out["pose"][:2] - po[-1, :2]).max() <= POS_TOL and abs(out["pose"][2] - po[-1, 2]) <= ROT_TOL
+                assert out["reserved"] == 1.0
+    finally:
+        reg.ctx.set_option(L.OPT_MATCHER_WAVES, 0); reg.ctx.set_option(L.OPT_MATCHER_LDS_KB, 0)
 
 
 def test_large_scans_take_the_second_launch():
@@ -337,10 +338,8 @@ def test_sharded_candidates_single_rank_through_the_library():
         assert np.abs(r["pose"][:2] - po[-1, :2]).max() <= POS_TOL and abs(r["pose"][2] - po[-1, 2]) <= ROT_TOL
 
 
-def test_sixteen_scans_slot_path_and_small_grid():
-    """n_scans = 16 (the C-ABI maximum): 15 keyframes x ~350 cells do not fit the workgroup's LDS, so the
-    registration runs on the global slot arrays (the non-fused path); with 8 keyframes it fits and uses a
-    22 x 22 grid per keyframe.  Both must reproduce the oracle."""
+def test_sixteen_scans():
+    """n_scans = 16 (the C-ABI maximum): 15 keyframes x ~350 cells, and 8 keyframes.  Both must reproduce the oracle."""
     from tbv_slam_public_amd import api
     frames = [0, 1, 2, 3, 4, 5]
     cells, gt = _cells(6, frames)
@@ -489,14 +488,16 @@ def test_small_and_large_batches_agree():
             np.testing.assert_allclose(b["final_cost"], small[q]["final_cost"], rtol=1e-11)
 
 
-def test_three_per_cu_kernel_matches_the_two_per_cu_kernel(monkeypatch):
-    """Batches of more than 64 regular registrations run on register3_kernel (three workgroups per CU: prebuilt per-scan grids
-    copied into LDS, association tables aliased with the LM arrays, solver state in LDS).  Same statements as register_kernel:
-    every integer outcome identical, poses and costs to rounding -- at its real LDS size, and with 14 KB of LDS, where the
-    keyframes' tables are staged in several groups and the dense arrays spill their tail to global memory (paths that only
-    unusually large registrations reach otherwise).  The oracle is the judge of both (test_iteration_counts_...)."""
+def test_every_form_of_the_matcher_agrees():
+    """One kernel, several forms (wavefronts per registration x LDS per workgroup, chosen by the batch): 144 registrations run
+    as the library chooses (8 wavefronts, tables and correspondence arrays side by side), then forced through the regular
+    form (4 wavefronts, 40 KB: tables aliased with the LM arrays, restaged per outer iteration), through 14 KB (keyframe tables
+    staged in several groups, the dense arrays' tail in global memory -- paths that only unusually large registrations reach
+    otherwise), the half-CU and whole-CU forms and the 2-wavefront form.  Same statements everywhere: every integer outcome
+    identical, poses and costs to rounding (the forms add the fp64 sums in different orders).  The oracle judges a sample."""
     from oracle import pyoracle as O
     from tbv_slam_public_amd import api
+    from tbv_slam_public_amd import _lib as L
     rng = np.random.default_rng(5)
     for cost, loss, opt in (("P2P", "Huber", 4), ("P2L", "Cauchy", 0), ("P2D", "Huber", 0)):
         reg = api.n_scan_normal_reg(cost, loss, 0.1)
@@ -513,21 +514,21 @@ def test_three_per_cu_kernel_matches_the_two_per_cu_kernel(monkeypatch):
                 T[-1] += np.concatenate([rng.normal(0, 0.4, 2), rng.normal(0, 0.015, 1)])
                 jobs.append(([scans[i] for i in idx], T))
                 ojobs.append(([cells[i] for i in idx], T))
-        monkeypatch.setenv("CFEAR_NO_REG3", "1")
         base = reg.RegisterBatch(jobs)
-        monkeypatch.delenv("CFEAR_NO_REG3")
-        monkeypatch.setenv("CFEAR_REG3", "1")                              # (the library takes it from 513 registrations on by itself)
-        runs = {"52 KB": reg.RegisterBatch(jobs)}
-        monkeypatch.setenv("CFEAR_REG3_LDS_KB", "14")
-        runs["14 KB"] = reg.RegisterBatch(jobs)
-        monkeypatch.delenv("CFEAR_REG3_LDS_KB")
+        runs = {}
+        try:
+            for waves, kb in ((4, 40), (4, 14), (8, 80), (16, 160), (2, 20)):
+                reg.ctx.set_option(L.OPT_MATCHER_WAVES, waves); reg.ctx.set_option(L.OPT_MATCHER_LDS_KB, kb)
+                runs["%d x %d KB" % (waves, kb)] = reg.RegisterBatch(jobs)
+        finally:
+            reg.ctx.set_option(L.OPT_MATCHER_WAVES, 0); reg.ctx.set_option(L.OPT_MATCHER_LDS_KB, 0)
         for name, out in runs.items():
             for a, b in zip(base, out):
                 key = lambda r: (int(r["status"]), int(r["outer_iters"]), int(r["lm_iters"]), int(r["num_residuals"]))
                 assert key(a) == key(b), (cost, name, key(a), key(b))
                 np.testing.assert_allclose(b["pose"], a["pose"], rtol=0, atol=1e-11, err_msg=name)
                 np.testing.assert_allclose(b["final_cost"], a["final_cost"], rtol=1e-10, err_msg=name)
-        for r, (c, T) in list(zip(runs["14 KB"], ojobs))[::6]:            # a sample against the oracle itself
+        for r, (c, T) in list(zip(runs["4 x 14 KB"], ojobs))[::6]:        # a sample against the oracle itself
             ok_o, po, ro = O.register(c, T, _oracle_par(reg))
             assert (r["status"] == 0) == ok_o
             assert (r["outer_iters"], r["lm_iters"], r["num_residuals"]) == (ro.outer_iters, ro.lm_iters, ro.num_residuals)
