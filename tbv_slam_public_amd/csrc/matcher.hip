@@ -467,23 +467,38 @@ __device__ __forceinline__ void sincos_pose(const double a, double* s, double* c
   else sincos(a, s, c);
 }
 
-// once per registration: keyframe transforms and attribute pointers, padded record prefix, source means
+// The sizes of a registration, read by EVERY wavefront for itself (lane i: scan i; at most 16 scans): two dependent memory
+// round trips in all instead of two per scan in turn, and the results are wave-uniform without an exchange.
+struct MtSizes {
+  int n_src, sum_pad, max_pad;   // source cells; the keyframes' padded record counts: total, largest
+  int koff_lane;                 // lane i < last: exclusive prefix of the padded counts (keyframe i's first record)
+  float4 geo_lane;               // lane i < last: keyframe i's grid geometry
+  bool grids_ok;                 // every keyframe carries valid grid tables
+};
+__device__ __forceinline__ MtSizes mt_sizes(const RegJob& job, const int last) {
+  const int lane = threadIdx.x & 63;
+  int n = 0;
+  float4 g = make_float4(0.f, 0.f, 0.f, 1.f);
+  if (lane <= last) n = gload<int>(job.scans[lane].n_cells);
+  if (lane < last) g = gload_f4(job.scans[lane].grid_geo);
+  const int np = lane < last ? scan_grid_pad(n) : 0;
+  const int incl = wave_incl_scan_i32(np);
+  MtSizes z;
+  z.koff_lane = incl - np;
+  z.geo_lane = g;
+  z.sum_pad = __builtin_amdgcn_readlane(incl, 63);
+  z.max_pad = __builtin_amdgcn_readlane(wave_incl_scan_max_i32(np), 63);
+  z.n_src = __builtin_amdgcn_readlane(n, last);
+  z.grids_ok = __ballot(lane < last && g.w != 1.f) == 0ull;
+  return z;
+}
+
+// once per registration: keyframe transforms and attribute pointers, padded record prefix, grid geometry, source means
 template <int NT>
-__device__ bool mt_stage_once(const RegJob& job, const MtLds& f, int* flag /* LDS */) {
+__device__ void mt_stage_once(const RegJob& job, const MtLds& f, const MtSizes& z) {
   const int tid = threadIdx.x, last = job.n_scans - 1;
-  if (tid == 0) {
-    int acc = 0, ok = 1;
-    for (int i = 0; i < last; i++) {
-      const int n = gload<int>(job.scans[i].n_cells);
-      f.koff[i] = acc;
-      acc += scan_grid_pad(n);
-      const float4 g = gload_f4(job.scans[i].grid_geo);
-      f.ggeo[i] = g;
-      ok &= (g.w == 1.f);
-    }
-    f.koff[last] = acc;
-    *flag = ok;
-  }
+  if (tid < last) { f.koff[tid] = z.koff_lane; f.ggeo[tid] = z.geo_lane; }
+  if (tid == last) f.koff[last] = z.sum_pad;
   if (tid >= 64 && tid < 64 + last) {
     const int i = tid - 64;
     const Aff2 T = aff_from_xyt(job.poses[i]);
@@ -494,10 +509,8 @@ __device__ bool mt_stage_once(const RegJob& job, const MtLds& f, int* flag /* LD
     tp[0] = tv.mean; tp[1] = tv.normal; tp[2] = tv.nsamples; tp[3] = tv.scale; tp[4] = tv.cov; tp[5] = tv.grid;
   }
   const ScanView& src = job.scans[last];
-  const int n_src = gload<int>(src.n_cells);
-  for (int s = tid; s < n_src; s += NT) f.smean[s] = gload_d2(src.mean + s);
+  for (int s = tid; s < z.n_src; s += NT) f.smean[s] = gload_d2(src.mean + s);
   __syncthreads();
-  return *flag != 0;
 }
 
 // The grid blocks of keyframes [i0, i1) from global memory into the region: their cell-start tables first (made absolute:
@@ -867,7 +880,7 @@ __device__ __forceinline__ void lm_round(double* st, const double cnd[10], const
     if (step_norm2 <= step_bound * step_bound) { done = 1; proceed = false; }      // ||step|| <= tolerance (||x|| + tolerance)
     else if (fabs(cost_change) <= function_tolerance * x_cost) { done = 1; proceed = false; }
     else {
-      it_rel = cost_change / model_cost_change;
+      it_rel = cost_change / model_cost_change;               // (rcp_newton instead of the IEEE quotient: +-0 on the kernel)
       if (it_rel > min_relative_decrease) {
         const double c0 = st[S_CAND], c1 = st[S_CAND + 1], c2 = st[S_CAND + 2];
         x_norm = sqrt_newton(c0 * c0 + c1 * c1 + c2 * c2);
@@ -1012,7 +1025,9 @@ __device__ void lm_solve(const MatchCommon& cm, const Dense& dn, const int max_i
     const double cs = st[S_COS], sn = st[S_SIN];
     eval_all<NT, COST, LOSS>(cm, dn, cand, cs, sn, cnd, part);        // its barrier also orders the state block
     REG_TACC(22);
-    if (w0) lm_round(st, cnd, true, max_iter);
+    // The round is the serial piece of an LM iteration (three wavefronts wait at the barrier for it): its wavefront takes issue
+    // priority over the other registrations' wavefronts on its SIMD for these ~400 instructions (register 1.154 -> 1.145 ms).
+    if (w0) { __builtin_amdgcn_s_setprio(3); lm_round(st, cnd, true, max_iter); __builtin_amdgcn_s_setprio(0); }
     REG_TACC(16);
   }
 }
@@ -1042,19 +1057,19 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && LOSS < 0) ? 3 : 4) void matche
   cfear_reg_result* res = cm.results + (size_t)blockIdx.x * m_out;
   if (cm.only_deferred && res->status != kRegDeferred) return;      // a later form: only what the launches before left
   const int last = job.n_scans - 1;
-  const int n_src = gload<int>(job.scans[last].n_cells);
-  int sum_pad = 0, max_pad = 0;
-  for (int i = 0; i < last; i++) { const int n = scan_grid_pad(gload<int>(job.scans[i].n_cells)); sum_pad += n; max_pad = max(max_pad, n); }
+  const MtSizes sz = mt_sizes(job, last);
+  const int n_src = sz.n_src, sum_pad = sz.sum_pad, max_pad = sz.max_pad;
   const int n_pairs = last * n_src;
   const size_t scr_idx = (size_t)blockIdx.x * gridDim.y + blockIdx.y;
   char* scr = cm.scratch + scr_idx * cm.scratch_stride;
   const MtFit fit = mt_fit(cm.lds_total, last, sum_pad, max_pad, n_src, cm.dense_fields, NW >= 8);
   MtLds fl;
-  bool ok = fit.can && n_pairs <= cm.pairs_cap && (cm.take_all || fit.good);
+  // (grids_ok false: a scan without grid tables -- more than 65 535 cells)
+  const bool ok = fit.can && sz.grids_ok && n_pairs <= cm.pairs_cap && (cm.take_all || fit.good);
   REG_TACC(8);
   if (ok) {
     mt_carve(smem, fit, last, (unsigned short*)scr, fl);
-    ok = mt_stage_once<NT>(job, fl, (int*)(st + S_INTS) + SI_FLAG);   // (false: a scan without grid tables -- more than 65 535 cells)
+    mt_stage_once<NT>(job, fl, sz);
   }
   REG_TACC(9);
   if (!ok) {
@@ -1187,19 +1202,16 @@ __global__ __launch_bounds__(256) void assoc_kernel(const RegJob* __restrict__ j
   constexpr int NT = 256;
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   int* ipart = (int*)(smem + kIpartOff);
-  double* st = (double*)(smem + kStateOff);
   const RegJob& job = jobs[0];
   const int last = job.n_scans - 1;
-  const int n_src = gload<int>(job.scans[last].n_cells);
-  int sum_pad = 0, max_pad = 0;
-  for (int i = 0; i < last; i++) { const int n = scan_grid_pad(gload<int>(job.scans[i].n_cells)); sum_pad += n; max_pad = max(max_pad, n); }
-  const MtFit fit = mt_fit(cm.lds_total, last, sum_pad, max_pad, n_src, 0, false);
+  const MtSizes sz = mt_sizes(job, last);
+  const MtFit fit = mt_fit(cm.lds_total, last, sz.sum_pad, sz.max_pad, sz.n_src, 0, false);
   MtLds fl;
-  bool ok = fit.can && last * n_src <= cm.pairs_cap;
+  const bool ok = fit.can && sz.grids_ok && last * sz.n_src <= cm.pairs_cap;
   if (ok) {
     mt_carve(smem, fit, last, nullptr, fl);
     fl.resident = false;                                   // (no dense arrays here: the region is the tables', group by group)
-    ok = mt_stage_once<NT>(job, fl, (int*)(st + S_INTS) + SI_FLAG);
+    mt_stage_once<NT>(job, fl, sz);
   }
   if (!ok) {
     if (threadIdx.x == 0) n_blocks_out[0] = -1;
@@ -1326,17 +1338,19 @@ constexpr size_t kLdsCu = 160 * 1024;                        // LDS of a gfx950 
 constexpr size_t kLdsPairs = 20 * 1024;                      // the 2-wavefront form for two-scan candidates: eight per CU
 size_t regular_lds(bool huber) { return huber ? kLdsCu / 4 : (kLdsCu / 3) & ~(size_t)255; }   // four (three: matcher_kernel) per CU
 
-// The first launch's form for a batch of n_wgs workgroups.  A batch that fills the chip several times over runs the regular
-// form (4 wavefronts, four registrations per CU; two-scan candidates: 2 wavefronts, eight per CU) -- throughput; a batch
-// below two workgroups per CU is a matter of latency: 8 wavefronts per registration and as much LDS as the CU can give each
-// (tables and correspondence arrays side by side: staged once, not per outer iteration).
+// The first launch's form for a batch of n_wgs workgroups (measured: tools/form_sweep.py).  A batch that fills
+// the chip several times over runs the regular form -- 4 wavefronts, four registrations per CU (two-scan candidates from eight
+// per CU on: 2 wavefronts, 20 KB) -- for throughput; below that every registration gets as much LDS as the CU can give its
+// share of the batch (tables and correspondence arrays side by side: staged once, not per outer iteration), and a batch of at
+// most one workgroup per CU is a matter of latency: 8 wavefronts per registration (two-scan candidates stay at 4: ~320 pairs
+// do not feed 512 lanes).
 struct Form { int nw; size_t lds; };
-Form first_form(const cfear_ctx* ctx, int n_wgs, bool huber, bool small_pairs) {
+Form first_form(const cfear_ctx* ctx, int n_wgs, bool huber, bool small_pairs, bool big_pass) {
   const int per_cu = std::max(1, (n_wgs + ctx->n_cu - 1) / ctx->n_cu);
   Form f;
-  if (per_cu <= 2) { f.nw = 8; f.lds = kLdsCu / per_cu - 256; }
-  else if (small_pairs) { f.nw = 2; f.lds = std::max(kLdsPairs, (kLdsCu / std::min(per_cu, 8)) & ~(size_t)255); }
-  else { f.nw = 4; f.lds = std::max(regular_lds(huber), (kLdsCu / std::min(per_cu, huber ? 4 : 3)) & ~(size_t)255); }
+  if (small_pairs && per_cu >= 8) { f.nw = 2; f.lds = kLdsPairs; }
+  else if (per_cu == 1 && !small_pairs) { f.nw = 8; f.lds = big_pass ? kLdsCu - 256 : kLdsCu / 2 - 256; }   // (large scans around: the CU's whole LDS at once)
+  else { f.nw = 4; f.lds = per_cu <= 2 ? kLdsCu / 2 - 256 : std::max(regular_lds(huber), (kLdsCu / std::min(per_cu, huber ? 4 : 3)) & ~(size_t)255); }
   if (ctx->opt[CFEAR_OPT_MATCHER_WAVES]) f.nw = (int)ctx->opt[CFEAR_OPT_MATCHER_WAVES];        // test / measurement hooks
   if (ctx->opt[CFEAR_OPT_MATCHER_LDS_KB]) f.lds = (size_t)ctx->opt[CFEAR_OPT_MATCHER_LDS_KB] * 1024 - (ctx->opt[CFEAR_OPT_MATCHER_LDS_KB] == 160 ? 256 : 0);
   return f;
@@ -1373,7 +1387,7 @@ int cfear_register_launch(cfear_ctx* ctx, const void* d_jobs, int n_jobs, const 
   const bool huber = par->loss == CFEAR_LOSS_HUBER;             // compile-time specialisations: cost metric x {Huber, any other loss}
   cm.lds_regular = (uint32_t)regular_lds(huber);
   const int by = mode ? std::max(mode->blocks_per_job, 1) : 1;
-  Form f0 = first_form(ctx, n_jobs * by, huber, hint.small_pairs);
+  Form f0 = first_form(ctx, n_jobs * by, huber, hint.small_pairs, hint.big_pass);
   if (mode) {                                                // cost-only launches come with 4 or 8 wavefronts
     if (hint.big_pass && f0.nw < 8) { f0.nw = 8; f0.lds = kLdsCu / 2 - 256; }   // cost sampling while dense scans show up
     if (f0.nw == 2) { f0.nw = 4; f0.lds = std::max(f0.lds, regular_lds(huber)); }
@@ -1384,16 +1398,18 @@ int cfear_register_launch(cfear_ctx* ctx, const void* d_jobs, int n_jobs, const 
   // wavefronts) for what even a global match table does not fit into 80 KB.  A launch behind another one only runs what that
   // one marked deferred; everything else returns at once (6-10 us: the caller switches them off when no large scans show up).
   const bool more = !mode && hint.big_pass && !(f0.nw >= 8 && f0.lds >= kLdsCu - 256);
-  const Form forms[3] = {f0, Form{8, kLdsCu / 2 - 256}, Form{16, kLdsCu - 256}};
-  static const char* const names[3] = {"register", "register_large", "register_large16"};
-  for (int k = 0; k < (more ? 3 : 1); k++) {
+  Form forms[3] = {f0, Form{8, kLdsCu / 2 - 256}, Form{16, kLdsCu - 256}};
+  const char* names[3] = {"register", "register_large", "register_large16"};
+  int n_forms = more ? 3 : 1;
+  if (more && f0.nw >= 8 && f0.lds >= forms[1].lds) { forms[1] = forms[2]; names[1] = names[2]; n_forms = 2; }   // (the first form IS the half-CU form)
+  for (int k = 0; k < n_forms; k++) {
     const Form& f = forms[k];
     const MatcherFn fn = matcher_fn(f.nw, par->cost, huber, mode != nullptr);
     if (f.lds > 64 * 1024) { const int rc = allow_full_lds(ctx, (const void*)fn); if (rc != CFEAR_OK) return rc; }
     MatchCommon c = cm;
     c.lds_total = (uint32_t)f.lds;
     c.only_deferred = k > 0;
-    c.final_launch = k == (more ? 2 : 0);
+    c.final_launch = k == n_forms - 1;
     c.take_all = k > 0 || !more;
     ProfScope ps(ctx, mode ? "get_cost" : names[k]);
     hipLaunchKernelGGL(fn, dim3(n_jobs, by), dim3((mode ? (f.nw <= 4 ? 4 : 8) : f.nw) * 64), f.lds, ctx->stream, (const RegJob*)d_jobs, c);

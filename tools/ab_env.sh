@@ -1,7 +1,7 @@
 #!/bin/bash
 # A/B of one build under two environments in ONE gpurun call (boxes differ by ~5 %): `VAR=1` (base) vs unset (new), alternating.
 #   VAR=CFEAR_NO_REG3 bash tools/ab_env.sh        BENCH_ARGS="--streams 2048" adds bench arguments
-VAR=${VAR:-CFEAR_NO_REG3}
+VAR=${VAR:-CFEAR_UNUSED}
 run() {
   python bench.py --no-cpu-baseline --no-extras ${BENCH_ARGS:-} 2>&1 | tail -1 | python -c "
 import json,sys
