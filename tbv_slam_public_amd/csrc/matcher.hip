@@ -189,8 +189,7 @@ __device__ __forceinline__ void loss_eval(int loss, double a, double w, double s
 enum {
   S_X = 0, S_XCOST = 3, S_CUR = 4 /* g[3], H[6] */, S_SCALE = 13, S_DIAG = 16, S_XNORM = 19, S_GMAX = 20, S_RADIUS = 21,
   S_DEC = 22, S_MINCOST = 23, S_MODEL = 24, S_CAND = 25, S_COS = 28, S_SIN = 29, S_ITCOST = 30, S_ITREL = 31, S_INIT = 32,
-  S_LASTREL = 33, S_FINAL = 34, S_INTS = 35 /* 8 ints */, S_OUTER = 39 /* x[3] prev_par[3] prev_score */, S_INVMODEL = 46, S_INVRADIUS = 47,
-  S_COUNT = 48
+  S_LASTREL = 33, S_FINAL = 34, S_INTS = 35 /* 8 ints */, S_OUTER = 39 /* x[3] prev_par[3] prev_score */, S_COUNT = 48
 };
 enum { SI_ITER = 0, SI_REUSE = 1, SI_INVALID = 2, SI_PUSHED = 3, SI_USABLE = 4, SI_DONE = 5, SI_ITSUCC = 6, SI_FLAG = 7 };
 constexpr int kMaxNW = 16;
@@ -439,9 +438,6 @@ __device__ __forceinline__ Slots slots_of(char* scratch, int cap) {
 // fp64 instructions is the longest serial piece of an LM iteration), no square roots.
 // Ceres factorises the same matrix with a sparse Cholesky; the solutions agree to rounding.
 __device__ __forceinline__ bool chol3_solve(const double A[9], const double b[3], double y[3]) {
-#ifdef MT_CONTRACT
-#pragma clang fp contract(fast)
-#endif
   const double d0 = A[0];
   if (!(d0 > 0.0)) return false;
   const double i0 = rcp_newton(d0);
@@ -460,21 +456,6 @@ __device__ __forceinline__ bool chol3_solve(const double A[9], const double b[3]
   y[2] = z2 * i2;
   y[1] = z1 * i1 - l21 * y[2];
   y[0] = z0 * i0 - l10 * y[1] - l20 * y[2];
-  return isfinite(y[0]) && isfinite(y[1]) && isfinite(y[2]);
-}
-
-// The same system by cofactors: ONE reciprocal (of the determinant) behind ~8 dependent operations instead of three dependent
-// reciprocals -- the six cofactors are independent of each other.  SPD test by the leading minors (Sylvester).
-__device__ __forceinline__ bool sym3_solve(const double A[9], const double b[3], double y[3]) {
-  const double a00 = A[0], a01 = A[1], a02 = A[2], a11 = A[4], a12 = A[5], a22 = A[8];
-  const double c00 = a11 * a22 - a12 * a12, c01 = a02 * a12 - a01 * a22, c02 = a01 * a12 - a02 * a11;
-  const double c11 = a00 * a22 - a02 * a02, c12 = a01 * a02 - a00 * a12, c22 = a00 * a11 - a01 * a01;
-  const double det = a00 * c00 + a01 * c01 + a02 * c02;
-  if (!(a00 > 0.0) || !(c22 > 0.0) || !(det > 0.0)) return false;
-  const double id = rcp_newton(det);
-  y[0] = (c00 * b[0] + c01 * b[1] + c02 * b[2]) * id;
-  y[1] = (c01 * b[0] + c11 * b[1] + c12 * b[2]) * id;
-  y[2] = (c02 * b[0] + c12 * b[1] + c22 * b[2]) * id;
   return isfinite(y[0]) && isfinite(y[1]) && isfinite(y[2]);
 }
 
@@ -876,9 +857,6 @@ __device__ __forceinline__ void mt_lds_order() {          // lane 0's LDS stores
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
 }
 __device__ __forceinline__ void lm_round(double* st, const double cnd[10], const bool have_cnd, const int max_iter) {
-#ifdef MT_CONTRACT
-#pragma clang fp contract(fast)
-#endif
   const double function_tolerance = 1e-6, gradient_tolerance = 1e-10, parameter_tolerance = 1e-8;
   const double min_relative_decrease = 1e-3, min_lm_diagonal = 1e-6, max_lm_diagonal = 1e32;
   const double max_radius = 1e16, min_radius = 1e-32;
@@ -889,9 +867,6 @@ __device__ __forceinline__ void lm_round(double* st, const double cnd[10], const
   double x_cost = st[S_XCOST], x_norm = st[S_XNORM], gradient_max_norm = st[S_GMAX], radius = st[S_RADIUS];
   double decrease_factor = st[S_DEC], min_iter_cost = st[S_MINCOST], model_cost_change = st[S_MODEL];
   double it_cost = st[S_ITCOST], it_rel = st[S_ITREL], last_rel = st[S_LASTREL];
-#ifdef MT_ROUND2
-  double inv_model = st[S_INVMODEL], inv_radius = st[S_INVRADIUS];
-#endif
   int iteration = si[SI_ITER], num_consecutive_invalid_steps = si[SI_INVALID], n_pushed = si[SI_PUSHED];
   bool reuse_diagonal = si[SI_REUSE] != 0, it_success = si[SI_ITSUCC] != 0, usable = si[SI_USABLE] != 0;
   int done = 0;
@@ -905,11 +880,7 @@ __device__ __forceinline__ void lm_round(double* st, const double cnd[10], const
     if (step_norm2 <= step_bound * step_bound) { done = 1; proceed = false; }      // ||step|| <= tolerance (||x|| + tolerance)
     else if (fabs(cost_change) <= function_tolerance * x_cost) { done = 1; proceed = false; }
     else {
-#ifdef MT_ROUND2
-      it_rel = cost_change * inv_model;
-#else
       it_rel = cost_change / model_cost_change;               // (rcp_newton instead of the IEEE quotient: +-0 on the kernel)
-#endif
       if (it_rel > min_relative_decrease) {
         const double c0 = st[S_CAND], c1 = st[S_CAND + 1], c2 = st[S_CAND + 2];
         x_norm = sqrt_newton(c0 * c0 + c1 * c1 + c2 * c2);
@@ -922,21 +893,11 @@ __device__ __forceinline__ void lm_round(double* st, const double cnd[10], const
         gradient_max_norm = fmax(fabs(cnd[1]), fmax(fabs(cnd[2]), fabs(cnd[3])));
         it_cost = x_cost; it_success = true;
         const double q = 2.0 * it_rel - 1.0;
-#ifdef MT_ROUND2
-        const double m = fmax(1.0 / 3.0, 1.0 - q * q * q);
-        radius = radius * rcp_newton(m);
-        inv_radius = radius < max_radius ? inv_radius * m : 1.0 / max_radius;   // (1 / radius without a second reciprocal on the chain)
-        radius = fmin(max_radius, radius);
-#else
         radius = radius * rcp_newton(fmax(1.0 / 3.0, 1.0 - q * q * q));
         radius = fmin(max_radius, radius);
-#endif
         decrease_factor = 2.0; reuse_diagonal = false;
       } else {
         it_cost = cand_cost; it_success = false;
-#ifdef MT_ROUND2
-        inv_radius *= decrease_factor;
-#endif
         radius = radius / decrease_factor; decrease_factor *= 2.0; reuse_diagonal = true;
       }
     }
@@ -974,17 +935,11 @@ __device__ __forceinline__ void lm_round(double* st, const double cnd[10], const
     double A[9];
 #pragma unroll
     for (int k = 0; k < 9; k++) A[k] = Hs[k];
-#ifndef MT_ROUND2
     const double inv_radius = rcp_newton(radius);
-#endif
 #pragma unroll
     for (int k = 0; k < 3; k++) A[k * 3 + k] += diagonal[k] * inv_radius;
     double y[3], step[3] = {0, 0, 0};
-#ifdef MT_ROUND2
-    const bool solved = sym3_solve(A, gs, y);
-#else
     const bool solved = chol3_solve(A, gs, y);
-#endif
     reuse_diagonal = true;
     bool step_is_valid = false;
     model_cost_change = 0.0;
@@ -996,15 +951,9 @@ __device__ __forceinline__ void lm_round(double* st, const double cnd[10], const
       const double hs2 = Hs[6] * step[0] + Hs[7] * step[1] + Hs[8] * step[2];
       model_cost_change = -sg - (step[0] * hs0 + step[1] * hs1 + step[2] * hs2) / 2.0;
       step_is_valid = model_cost_change > 0.0;
-#ifdef MT_ROUND2
-      inv_model = rcp_newton(model_cost_change);            // (for the next round's relative decrease: off its chain, beside the sincos below)
-#endif
     }
     if (!step_is_valid) {
       if (++num_consecutive_invalid_steps >= 5) { usable = false; done = 1; break; }
-#ifdef MT_ROUND2
-      inv_radius *= decrease_factor;
-#endif
       radius = radius / decrease_factor; decrease_factor *= 2.0; reuse_diagonal = true;
       it_cost = x_cost; it_success = false; it_rel = 0.0;
       mt_lds_order();                                      // (the diagonal stored above is read again by the next turn)
@@ -1024,9 +973,6 @@ __device__ __forceinline__ void lm_round(double* st, const double cnd[10], const
     st[S_XCOST] = x_cost; st[S_XNORM] = x_norm; st[S_GMAX] = gradient_max_norm; st[S_RADIUS] = radius; st[S_DEC] = decrease_factor;
     st[S_MINCOST] = min_iter_cost; st[S_MODEL] = model_cost_change; st[S_ITCOST] = it_cost; st[S_ITREL] = it_rel;
     st[S_LASTREL] = last_rel;
-#ifdef MT_ROUND2
-    st[S_INVMODEL] = inv_model; st[S_INVRADIUS] = inv_radius;
-#endif
     if (done) st[S_FINAL] = fmin(st[S_INIT], min_iter_cost);          // solver.cc SetSummaryFinalCost
     si[SI_ITER] = iteration; si[SI_REUSE] = reuse_diagonal; si[SI_INVALID] = num_consecutive_invalid_steps;
     si[SI_PUSHED] = n_pushed; si[SI_USABLE] = usable; si[SI_DONE] = done; si[SI_ITSUCC] = it_success;
@@ -1062,7 +1008,6 @@ __device__ void lm_solve(const MatchCommon& cm, const Dense& dn, const int max_i
         st[S_XNORM] = sqrt_newton(x[0] * x[0] + x[1] * x[1] + x[2] * x[2]);
         st[S_GMAX] = fmax(fabs(cnd[1]), fmax(fabs(cnd[2]), fabs(cnd[3])));
         st[S_RADIUS] = 1e4; st[S_DEC] = 2.0; st[S_MINCOST] = cnd[0]; st[S_MODEL] = 0.0; st[S_ITCOST] = cnd[0]; st[S_ITREL] = 0.0;
-        st[S_INVMODEL] = 0.0; st[S_INVRADIUS] = 1e-4;
         st[S_CAND] = x[0]; st[S_CAND + 1] = x[1]; st[S_CAND + 2] = x[2];
         st[S_INIT] = cnd[0]; st[S_LASTREL] = 0.0; st[S_FINAL] = cnd[0];
         si[SI_ITER] = 0; si[SI_REUSE] = 0; si[SI_INVALID] = 0; si[SI_PUSHED] = 0; si[SI_USABLE] = 1; si[SI_DONE] = 0; si[SI_ITSUCC] = 1;

@@ -34,7 +34,7 @@ int main() {
   for (int k = 0; k < 3; k++) init[S_CUR + k] = g[k];
   for (int k = 0; k < 6; k++) init[S_CUR + 3 + k] = H[k];
   init[S_SCALE] = 1.0 / (1.0 + 14.5); init[S_SCALE + 1] = 1.0 / (1.0 + 13.8); init[S_SCALE + 2] = 1.0 / (1.0 + 775.0);
-  init[S_XNORM] = 2.502; init[S_GMAX] = 40.0; init[S_RADIUS] = 1e4; init[S_DEC] = 2.0; init[S_MINCOST] = 31.0; init[S_MODEL] = 0.5; init[S_INVMODEL] = 2.0; init[S_INVRADIUS] = 1e-4;
+  init[S_XNORM] = 2.502; init[S_GMAX] = 40.0; init[S_RADIUS] = 1e4; init[S_DEC] = 2.0; init[S_MINCOST] = 31.0; init[S_MODEL] = 0.5;
   init[S_CAND] = 2.51; init[S_CAND + 1] = -0.11; init[S_CAND + 2] = 0.0131; init[S_ITCOST] = 31.0; init[S_INIT] = 33.0;
   int* si = (int*)(init + S_INTS);
   si[SI_ITER] = 2; si[SI_USABLE] = 1; si[SI_ITSUCC] = 1; si[SI_PUSHED] = 2;
