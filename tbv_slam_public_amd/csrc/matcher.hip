@@ -193,7 +193,7 @@ enum {
 };
 enum { SI_ITER = 0, SI_REUSE = 1, SI_INVALID = 2, SI_PUSHED = 3, SI_USABLE = 4, SI_DONE = 5, SI_ITSUCC = 6, SI_FLAG = 7 };
 constexpr int kMaxNW = 16;
-constexpr size_t kPartOff = 0;                               // [16][10] doubles: the block reduction's partials (one buffer: two
+constexpr size_t kPartOff = 0;                               // [10][16] doubles: the block reduction's partials (one buffer: two
 constexpr size_t kIpartOff = kMaxNW * 10 * 8;                //   barriers separate consecutive uses); [2][16] ints
 constexpr size_t kStateOff = kIpartOff + 2 * kMaxNW * 4;
 constexpr size_t kFixedLds = kStateOff + S_COUNT * 8;        // 1792 bytes
@@ -269,73 +269,59 @@ __device__ __forceinline__ void mt_carve(uint8_t* smem, const MtFit& m, int last
 }
 
 // 10 accumulators: cost, g[3], H upper triangle (00,01,02,11,12,22).  Wavefront 0 receives the totals (wave-uniform:
-// readlane), the others' v[] is unspecified.  One LDS buffer: the callers separate two reductions by two barriers.
+// readlane), the others' v[] is unspecified.  One LDS buffer of 10 x 4 NW doubles: the callers separate two reductions by
+// two barriers.
+// Value-splitting butterfly inside each 16-lane DPP row: a step that pairs lanes l and P(l) lets one class of lanes keep value
+// p and the other value q of a pair, so every step halves the number of live values (10 -> 5 -> 3, then two plain steps): 56
+// instructions instead of 180 (and instead of the 300 of ten full 64-lane reductions, which the forms other than 4 wavefronts
+// used until round 5: a third of an LM iteration of the 8-wavefront form).  bank_mask performs the class select (banks = lane
+// quads): row_mirror splits on lane bit 3 (banks 0,1 | 2,3), row_half_mirror on bit 2 (banks 0,2 | 1,3).
+constexpr size_t kPartBigBytes = 10 * 4 * kMaxNW * 8;        // the partials of the 8- / 16-wavefront forms: at the END of their LDS
 template <int NW>
-__device__ __forceinline__ void block_reduce10(double v[10], double* buf /*[16][10]*/) {
+__device__ __forceinline__ void block_reduce10(double v[10], double* buf /*[10][4 NW]*/) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  if (NW == 4) {
-    // Value-splitting butterfly inside each 16-lane DPP row: a step that pairs lanes l and P(l) lets
-    // one class of lanes keep value p and the other value q of a pair, so every step halves the
-    // number of live values (10 -> 5 -> 3, then two plain steps): 56 instructions instead of 180.
-    // bank_mask performs the class select (banks = lane quads): row_mirror splits on lane bit 3
-    // (banks 0,1 | 2,3), row_half_mirror on bit 2 (banks 0,2 | 1,3).
-    double v1[5];
+  constexpr int S = 4 * NW;                                  // partials per value: one per (wavefront, row)
+  double v1[5];
 #pragma unroll
-    for (int j = 0; j < 5; j++)
-      v1[j] = dpp_sel_f64<0x140, 0x3>(v[j + 5], v[j]) + dpp_sel_f64<0x140, 0xC>(v[j], v[j + 5]);
-    double w0 = dpp_sel_f64<0x141, 0x5>(v1[1], v1[0]) + dpp_sel_f64<0x141, 0xA>(v1[0], v1[1]);
-    double w1 = dpp_sel_f64<0x141, 0x5>(v1[3], v1[2]) + dpp_sel_f64<0x141, 0xA>(v1[2], v1[3]);
-    double w2 = v1[4] + dpp_f64<0x141>(v1[4]);
-    w0 += dpp_f64<0x4E>(w0); w1 += dpp_f64<0x4E>(w1); w2 += dpp_f64<0x4E>(w2);
-    w0 += dpp_f64<0xB1>(w0); w1 += dpp_f64<0xB1>(w1); w2 += dpp_f64<0xB1>(w2);
-    // the quad with lane bits (b3, b2) now holds the row sums of k = b2 + 5 b3 (w0), 2 + b2 + 5 b3 (w1)
-    // and 4 + 5 b3 (w2); partial (k, wave, row) goes to buf[k * 16 + wave * 4 + row]
-    const int row = lane >> 4, b3 = (lane >> 3) & 1, b2 = (lane >> 2) & 1;
-    const int slot = wave * 4 + row;
-    if ((lane & 3) == 0) {
-      buf[(b2 + 5 * b3) * 16 + slot] = w0;
-      buf[(2 + b2 + 5 * b3) * 16 + slot] = w1;
-      if (b2 == 0) buf[(4 + 5 * b3) * 16 + slot] = w2;
-    }
-    __syncthreads();
-    if (wave == 0) {
-      // 16 partials per k = one DPP row per k: three registers cover the 160 partials; the totals are
-      // read back with readlane, so they are wave-uniform (scalar branches downstream)
-      double r[3];
-#pragma unroll
-      for (int q = 0; q < 3; q++) {
-        const int j = q * 64 + lane;
-        r[q] = row16_sum_f64(j < 160 ? buf[j] : 0.0);
-      }
-#pragma unroll
-      for (int k = 0; k < 10; k++) v[k] = readlane_f64(r[k / 4], (k % 4) * 16);
-    }
-    return;
-  }
-  // generic NW: k-major buf[k * NW + wave]
-#pragma unroll
-  for (int k = 0; k < 10; k++) {
-    const double t = wave_sum_lane63_f64(v[k]);
-    if (lane == 63) buf[k * NW + wave] = t;
+  for (int j = 0; j < 5; j++)
+    v1[j] = dpp_sel_f64<0x140, 0x3>(v[j + 5], v[j]) + dpp_sel_f64<0x140, 0xC>(v[j], v[j + 5]);
+  double w0 = dpp_sel_f64<0x141, 0x5>(v1[1], v1[0]) + dpp_sel_f64<0x141, 0xA>(v1[0], v1[1]);
+  double w1 = dpp_sel_f64<0x141, 0x5>(v1[3], v1[2]) + dpp_sel_f64<0x141, 0xA>(v1[2], v1[3]);
+  double w2 = v1[4] + dpp_f64<0x141>(v1[4]);
+  w0 += dpp_f64<0x4E>(w0); w1 += dpp_f64<0x4E>(w1); w2 += dpp_f64<0x4E>(w2);
+  w0 += dpp_f64<0xB1>(w0); w1 += dpp_f64<0xB1>(w1); w2 += dpp_f64<0xB1>(w2);
+  // the quad with lane bits (b3, b2) now holds the row sums of k = b2 + 5 b3 (w0), 2 + b2 + 5 b3 (w1)
+  // and 4 + 5 b3 (w2); partial (k, wave, row) goes to buf[k * S + wave * 4 + row]
+  const int row = lane >> 4, b3 = (lane >> 3) & 1, b2 = (lane >> 2) & 1;
+  const int slot = wave * 4 + row;
+  if ((lane & 3) == 0) {
+    buf[(b2 + 5 * b3) * S + slot] = w0;
+    buf[(2 + b2 + 5 * b3) * S + slot] = w1;
+    if (b2 == 0) buf[(4 + 5 * b3) * S + slot] = w2;
   }
   __syncthreads();
   if (wave == 0) {
-    // lane-parallel cross-wave sum: partial j = k * NW + wave sits in lane j % 64 of register j / 64;
-    // aligned groups of NW lanes are summed by a DPP butterfly (fixed order)
-    constexpr int NR = (10 * NW + 63) / 64;
+    // partial j = k * S + slot sits in lane j % 64 of register j / 64; aligned groups of min(S, 16) lanes are summed by a DPP
+    // butterfly (fixed order), the rows of one value by wave-uniform adds; the totals are read back with readlane, so they
+    // are wave-uniform (scalar branches downstream)
+    constexpr int NR = (10 * S + 63) / 64;
     double r[NR];
 #pragma unroll
     for (int q = 0; q < NR; q++) {
       const int j = q * 64 + lane;
-      double t = j < 10 * NW ? buf[j] : 0.0;
-      if (NW >= 2) t += dpp_f64<0xB1>(t);      // quad_perm [1,0,3,2]
-      if (NW >= 4) t += dpp_f64<0x4E>(t);      // quad_perm [2,3,0,1]
-      if (NW >= 8) t += dpp_f64<0x141>(t);     // row_half_mirror
-      if (NW >= 16) t += dpp_f64<0x140>(t);    // row_mirror
+      double t = j < 10 * S ? buf[j] : 0.0;
+      t += dpp_f64<0xB1>(t);                   // quad_perm [1,0,3,2]
+      t += dpp_f64<0x4E>(t);                   // quad_perm [2,3,0,1]
+      t += dpp_f64<0x141>(t);                  // row_half_mirror (S >= 8)
+      if (S >= 16) t += dpp_f64<0x140>(t);     // row_mirror
       r[q] = t;
     }
 #pragma unroll
-    for (int k = 0; k < 10; k++) v[k] = readlane_f64(r[(k * NW) / 64], (k * NW) % 64);
+    for (int k = 0; k < 10; k++) {
+      if (S <= 16) v[k] = readlane_f64(r[(k * S) / 64], (k * S) % 64);
+      else if (S == 32) v[k] = readlane_f64(r[k / 2], (k % 2) * 32) + readlane_f64(r[k / 2], (k % 2) * 32 + 16);
+      else v[k] = ((readlane_f64(r[k], 0) + readlane_f64(r[k], 16)) + readlane_f64(r[k], 32)) + readlane_f64(r[k], 48);
+    }
   }
 }
 
@@ -1049,7 +1035,9 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && LOSS < 0) ? 3 : 4) void matche
 #endif
   REG_T0();
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-  double* part = (double*)(smem + kPartOff);
+  // (the large forms keep their reduction partials -- 10 x 4 NW doubles -- behind the carved LDS)
+  const uint32_t lds_eff = cm.lds_total - (NW >= 8 ? (uint32_t)kPartBigBytes : 0u);
+  double* part = NW >= 8 ? (double*)(smem + lds_eff) : (double*)(smem + kPartOff);
   int* ipart = (int*)(smem + kIpartOff);
   double* st = (double*)(smem + kStateOff);
   const RegJob& job = *(const RegJob*)((const char*)jobs + (size_t)blockIdx.x * cm.job_stride);
@@ -1062,7 +1050,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 4 && LOSS < 0) ? 3 : 4) void matche
   const int n_pairs = last * n_src;
   const size_t scr_idx = (size_t)blockIdx.x * gridDim.y + blockIdx.y;
   char* scr = cm.scratch + scr_idx * cm.scratch_stride;
-  const MtFit fit = mt_fit(cm.lds_total, last, sum_pad, max_pad, n_src, cm.dense_fields, NW >= 8);
+  const MtFit fit = mt_fit(lds_eff, last, sum_pad, max_pad, n_src, cm.dense_fields, NW >= 8);
   MtLds fl;
   // (grids_ok false: a scan without grid tables -- more than 65 535 cells)
   const bool ok = fit.can && sz.grids_ok && n_pairs <= cm.pairs_cap && (cm.take_all || fit.good);
@@ -1342,14 +1330,14 @@ size_t regular_lds(bool huber) { return huber ? kLdsCu / 4 : (kLdsCu / 3) & ~(si
 // the chip several times over runs the regular form -- 4 wavefronts, four registrations per CU (two-scan candidates from eight
 // per CU on: 2 wavefronts, 20 KB) -- for throughput; below that every registration gets as much LDS as the CU can give its
 // share of the batch (tables and correspondence arrays side by side: staged once, not per outer iteration), and a batch of at
-// most one workgroup per CU is a matter of latency: 8 wavefronts per registration (two-scan candidates stay at 4: ~320 pairs
+// most two workgroups per CU is a matter of latency: 8 wavefronts per registration (two-scan candidates stay at 4: ~320 pairs
 // do not feed 512 lanes).
 struct Form { int nw; size_t lds; };
 Form first_form(const cfear_ctx* ctx, int n_wgs, bool huber, bool small_pairs, bool big_pass) {
   const int per_cu = std::max(1, (n_wgs + ctx->n_cu - 1) / ctx->n_cu);
   Form f;
   if (small_pairs && per_cu >= 8) { f.nw = 2; f.lds = kLdsPairs; }
-  else if (per_cu == 1 && !small_pairs) { f.nw = 8; f.lds = big_pass ? kLdsCu - 256 : kLdsCu / 2 - 256; }   // (large scans around: the CU's whole LDS at once)
+  else if (per_cu <= 2 && !small_pairs) { f.nw = 8; f.lds = (big_pass && per_cu == 1) ? kLdsCu - 256 : kLdsCu / 2 - 256; }   // (large scans around: the CU's whole LDS at once)
   else { f.nw = 4; f.lds = per_cu <= 2 ? kLdsCu / 2 - 256 : std::max(regular_lds(huber), (kLdsCu / std::min(per_cu, huber ? 4 : 3)) & ~(size_t)255); }
   if (ctx->opt[CFEAR_OPT_MATCHER_WAVES]) f.nw = (int)ctx->opt[CFEAR_OPT_MATCHER_WAVES];        // test / measurement hooks
   if (ctx->opt[CFEAR_OPT_MATCHER_LDS_KB]) f.lds = (size_t)ctx->opt[CFEAR_OPT_MATCHER_LDS_KB] * 1024 - (ctx->opt[CFEAR_OPT_MATCHER_LDS_KB] == 160 ? 256 : 0);
