@@ -5,7 +5,7 @@
 // loopclosure::approximateCovarianceBySampling (tbv_slam/src/tbv_slam/loopclosure.cpp:146-205):
 // quadratic least-squares fit of the n^3 cost samples, convexity test, 2 H^-1 scaled by the
 // registration score.  The samples themselves -- n^3 GetCost evaluations per registration, the
-// expensive part -- come from the cost-only mode of register_kernel (register.hip), one launch for
+// expensive part -- come from the cost-only mode of matcher_kernel (matcher.hip), one launch for
 // all registrations of a batch.  The fit is a 27 x 10 problem per registration: host work, as in the
 // reference.
 #include <algorithm>

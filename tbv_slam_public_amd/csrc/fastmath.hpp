@@ -7,7 +7,7 @@ namespace {
 // A 64-bit literal pinned to a scalar register pair AT ITS USE.  gfx950's VOP3 encodings take no 64-bit literals, so the
 // compiler materialises every fp64 constant in registers and hoists it out of the enclosing loops -- the polynomial
 // coefficients below, inlined at a few sites of a long-running kernel, then hold ~30 VGPRs for the kernel's whole life
-// (register3_kernel: the difference between two and three wavefronts per SIMD).  The empty volatile asm keeps the two
+// (the matcher: the difference between two and three wavefronts per SIMD in round 4).  The empty volatile asm keeps the two
 // s_mov_b32 where they are written; the scalar unit is idle there anyway, and v_fma_f64 takes the pair as an operand.
 template <bool PIN>
 __device__ __forceinline__ double kc(double c) {

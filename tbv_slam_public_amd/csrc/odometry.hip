@@ -661,7 +661,7 @@ static int process_frame(cfear_odometry* od, const uint8_t* polar, const uint8_t
   // stream records in random order and cost more host time than the kernel saved.
   std::vector<double>& est = od->cost_est;
   // ... plus a class of its own for the heaviest 3 %: the registrations whose correspondences overflow the LDS arrays of
-  // register3_kernel run ~1.5 x as long as the rest and must not be the last ones to start
+  // the matcher run ~1.5 x as long as the rest and must not be the last ones to start
   double cut[4] = {0.0, 0.0, 0.0, 0.0};
   {
     std::vector<double>& tmp = od->cost_tmp;
@@ -746,7 +746,7 @@ static int process_frame(cfear_odometry* od, const uint8_t* polar, const uint8_t
     // LDS of its CUs, so nothing co-resides: 2.51 ms per frame batch instead of 2.19.  Gated to start with the matcher,
     // to fill the ~0.2 ms in which the last uneven registrations leave CUs idle, its small workgroups took the LDS the
     // next 80 KB registration needed on every CU that drained: matcher 0.98 -> 1.47 ms, sweep 0.52 -> 1.32 ms, 2.68 ms
-    // per frame batch.  Round 4, with register3_kernel's 52 KB / 127-VGPR workgroups -- three per CU, so that a finished one
+    // per frame batch.  Round 4, with 52 KB / 127-VGPR matcher workgroups -- three per CU, so that a finished one
     // leaves room for the sweep beside the other two -- and the sweep enqueued behind the surface kernels on a stream of
     // its own: matcher 1.35 -> 2.40 ms, sweep 1.12 -> 1.89 ms, 4.2 ms per 4096-stream frame batch instead of 3.5.  The
     // sweep's short-lived workgroups keep taking the LDS a registration needs; the two do not share a CU gracefully.)

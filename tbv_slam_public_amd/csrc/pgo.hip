@@ -12,7 +12,7 @@
 // closure.  Its kernels are block-tridiagonal recurrences -- 2 n dependent 6 x 6 steps per solve, a serial chain that a
 // CPU core finishes in well under a millisecond and a GPU wavefront in tens -- and the whole optimisation is ~10^8
 // flops, a thousandth of one registration batch.  The reference keeps it on the host as well ("sparse PGO, runs
-// once").  The trust-region bookkeeping is the one restated for the matcher (register.hip lm_solve).
+// once").  The trust-region bookkeeping is the one restated for the matcher (matcher.hip lm_round).
 //
 // Linear algebra: Ceres factorises J^T J + D^2 with CHOLMOD.  Here the same system is solved by conjugate gradients
 // preconditioned with the exact block-tridiagonal Cholesky factor of its odometry chain part; the loop constraints enter

@@ -3,11 +3,11 @@
 //
 // Restates, for a BATCH of candidates, what the loop-closure thread does per candidate in
 // ScanContextClosure::SearchAndAddConstraint (tbv_slam/src/tbv_slam/loopclosure.cpp:658-725):
-//   RegisterLoopCandidate (:320-364) -> loopclosure::Register (:35-97)          [register_kernel]
+//   RegisterLoopCandidate (:320-364) -> loopclosure::Register (:35-97)          [matcher_kernel]
 //   VerifyLoopCandidate (:365-384) -> VerifyByAlignment (:759-774) ->
 //     ScanLearningInterface::PredAlignment (alignmentinterface.cpp:349-367):
 //       getCorAlQualityMeasure (:437-456)                                         [coral_kernel]
-//       getCFEARQualityMeasure (:459-478) -> CFEARQuality (AlignmentQuality.cpp:330-354)  [register_kernel, cost only]
+//       getCFEARQualityMeasure (:459-478) -> CFEARQuality (AlignmentQuality.cpp:330-354)  [matcher_kernel, cost only]
 //       combined logistic model -> quality["alignment_quality"]
 //   VerificationModel (:220-238) over {odom-bounds, sc-sim, alignment_quality}
 //   ApplyConstratins (:261-274): accept by probability, all candidates or the best of each query.

@@ -1,5 +1,5 @@
 #!/bin/bash
-# the fused decode in the pipeline: A/B of the bins-major bench on sparse and dense scenes (CFEAR_NO_FUSED_DECODE=1 = rotation
+# the fused decode in the pipeline: A/B of the bins-major bench on sparse and dense scenes (context option FUSED_DECODE = 0 = rotation
 # kernel + row sweep always; default = fused decode on radar-like sweeps, the two-kernel route once the decode reports dense ones)
 for DENSE in "" "--dense --streams 1024 --sequences 64"; do
 for v in 1 0; do

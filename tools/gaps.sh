@@ -16,9 +16,9 @@ if mc:
     for r in csv.DictReader(open(mc[0])):
         copies.append((int(r['Start_Timestamp']), int(r['End_Timestamp']), 'COPY ' + r.get('Direction', '')))
 allv = sorted(ev + copies)
-ours = ('kstrongest_rows', 'surface_prep', 'surface_sort', 'surface_points', 'surface_finish', 'register_kernel')
+ours = ('kstrongest_rows', 'surface_prep', 'surface_sort', 'surface_points', 'surface_finish', 'matcher_kernel')
 # last quarter of the run = steady state
-k0 = [i for i, e in enumerate(allv) if 'register_kernel' in e[2]]
+k0 = [i for i, e in enumerate(allv) if 'matcher_kernel' in e[2]]
 start = k0[len(k0) // 2]
 gap = collections.defaultdict(list); dur = collections.defaultdict(list)
 prev_end = None
@@ -32,7 +32,7 @@ tot_gap = 0
 for k in gap:
     g = sum(gap[k]) / len(gap[k]); tot_gap += sum(gap[k])
     print("%-28s n=%5d  avg gap before %8.1f us   avg duration %8.1f us" % (k, len(gap[k]), g / 1e3, sum(dur[k]) / len(dur[k]) / 1e3))
-nreg = len(gap.get('register_kernel', [1]))
+nreg = len(gap.get('matcher_kernel', [1]))
 print("idle per frame batch: %.1f us" % (tot_gap / nreg / 1e3))
 PY
 rm -rf $OUT

@@ -1,11 +1,11 @@
 #!/bin/bash
 # rocprofv3 passes behind the numbers in bench.py / DESIGN.md.  Run on the GPU box from the repo root:
-#   bash tools/profile.sh r04
+#   bash tools/profile.sh r05
 # Raw output goes to /tmp (a kernel trace of torch's input generation is hundreds of MB); the judged summaries land under
 # gpurun_out/profiles_<tag>/ (copy them into profiles/<tag>/).  Counters are collected in their own passes (no trace
 # domains mixed in).
 set -u
-TAG=${1:-r04}
+TAG=${1:-r05}
 ROOT=$(pwd)
 OUT=/tmp/prof_$TAG
 SUM=$ROOT/gpurun_out/profiles_$TAG
@@ -17,8 +17,8 @@ keep_ours() {   # kernel_stats.csv of a run -> only this library's kernels (torc
 import csv, glob, sys
 src = glob.glob(sys.argv[1] + "/**/*kernel_stats.csv", recursive=True)
 rows = list(csv.reader(open(src[0]))) if src else []
-ours = ("kstrongest_rows_kernel", "kstrong_cloud_kernel", "kstrong_image", "kstrong_extract", "kstrong_select", "kstrongest_cols", "cacfar_", "surface_", "register_kernel", "assoc_kernel", "eval_kernel",
-        "register3_kernel", "coral_kernel", "sc_descriptor", "sc_distance", "rotate_ccw", "compensate", "legacy_", "scan_sort", "cells_to_slab",
+ours = ("kstrongest_rows_kernel", "kstrong_cloud_kernel", "kstrong_image", "kstrong_extract", "kstrong_select", "kstrongest_cols", "cacfar_", "surface_", "matcher_kernel", "assoc_kernel", "eval_kernel",
+        "expand_candidates", "coral_kernel", "sc_descriptor", "sc_distance", "rotate_ccw", "compensate", "legacy_", "scan_grid", "cells_to_slab",
         "slab_to_cells", "closest_idx")
 keep = [rows[0]] + [r for r in rows[1:] if any(k in r[0] for k in ours)] if rows else []
 csv.writer(open(sys.argv[2], "w")).writerows(keep)
@@ -51,7 +51,7 @@ for DATA in scene dense uniform; do
 done
 # HBM traffic of the sweep AS IT RUNS IN THE HEADLINE PIPELINE (fused: 4-byte keys per kept bin, no cloud): the default bench
 # command's configuration at a small batch (counter collection serialises every dispatch), kernel-filtered afterwards
-PIPE_ARGS="--no-cpu-baseline --no-extras --steps 1 --warmup 1 --frames-per-step 4 --streams 512 --sequences 32"   # (512 streams: register_kernel; the pmc_pipe pass below runs 1024 so that register3_kernel is the matcher)
+PIPE_ARGS="--no-cpu-baseline --no-extras --steps 1 --warmup 1 --frames-per-step 4 --streams 512 --sequences 32"   # (512 streams: the matcher's 8-wavefront form; the pmc_pipe pass below runs 4096 streams: the regular form, four per CU)
 ( cd /tmp && timeout 900 rocprofv3 --output-format csv --pmc FETCH_SIZE -d "$OUT/pmc_fetch" -o p -- python "$ROOT/bench.py" $PIPE_ARGS > /dev/null 2> "$OUT/pmc_fetch.err" )
 ( cd /tmp && timeout 900 rocprofv3 --output-format csv --pmc WRITE_SIZE -d "$OUT/pmc_write" -o p -- python "$ROOT/bench.py" $PIPE_ARGS > /dev/null 2> "$OUT/pmc_write.err" )
 export CFEAR_PMC_IMAGES=512
@@ -68,7 +68,7 @@ keep_ours "$OUT/cacfar_bm" "$SUM/cacfar_bins_major_kernel_stats.csv"; rm -rf "$O
 ( cd /tmp && rocprofv3 --output-format csv --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU -d "$OUT/pmc_sq" -o p -- python "$ROOT/tools/bench_filter.py" --iters 5 > /dev/null 2> "$OUT/pmc_sq.err" )
 ( cd /tmp && rocprofv3 --output-format csv --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU -d "$OUT/pmc_sq_dense" -o p -- python "$ROOT/tools/bench_filter.py" --iters 5 --data dense > /dev/null 2> "$OUT/pmc_sq_dense.err" )
 # whole pipeline under the SQ counters, SMALL run (counter collection serialises every dispatch)
-( cd /tmp && timeout 600 rocprofv3 --output-format csv --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU -d "$OUT/pmc_pipe" -o p -- python "$ROOT/bench.py" --no-cpu-baseline --no-extras --steps 1 --warmup 1 --frames-per-step 2 --streams 1024 --sequences 32 > /dev/null 2> "$OUT/pmc_pipe.err" )
+( cd /tmp && timeout 600 rocprofv3 --output-format csv --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU -d "$OUT/pmc_pipe" -o p -- python "$ROOT/bench.py" --no-cpu-baseline --no-extras --steps 1 --warmup 1 --frames-per-step 2 --streams 4096 --sequences 64 > /dev/null 2> "$OUT/pmc_pipe.err" )
 python "$ROOT/tools/summarize_pmc.py" "$OUT" "$SUM/pmc_traffic.json" > "$SUM/pmc_summary.txt" 2>&1
 rm -rf "$OUT"
 ls -la "$SUM"

@@ -1,5 +1,5 @@
 """One sequence alone (the literal configs[1] case): wall time per frame and hipEvent time per kernel -- where the latency
-of a frame goes (CFEAR_OD_TIMING=1 adds the host timeline).  Round 3: 0.255 ms per frame of which the kernels take 0.244
+of a frame goes (context option HOST_TIMELINE = 1 adds the host timeline).  Round 3: 0.255 ms per frame of which the kernels take 0.244
 (register 0.139, surface_sort 0.061, surface_finish 0.016, surface_prep 0.014, surface_points 0.007, sweep 0.008): the frame
 is a chain of single-workgroup latencies, not launch overhead."""
 import sys, time, numpy as np, torch

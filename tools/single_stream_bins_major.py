@@ -1,5 +1,5 @@
 """One MulRan-layout sequence alone ([range bins][azimuths] sweeps): wall time per frame and hipEvent time per kernel with the
-fused decode and (CFEAR_NO_FUSED_DECODE=1) with the rotation kernel + row sweep."""
+fused decode and (context option FUSED_DECODE = 0) with the rotation kernel + row sweep."""
 import sys, time, torch
 sys.path.insert(0, '/root/repo')
 from tbv_slam_public_amd import api, synth

@@ -15,8 +15,8 @@ for d in sorted(glob.glob(os.path.join(root, "pmc_*"))):
     for f in files:
         for row in csv.DictReader(open(f)):
             k = row.get("Kernel_Name", "?")
-            for name in ("kstrongest_rows_kernel", "kstrong_image_kernel", "kstrongest_cols_kernel", "kstrong_cloud_kernel", "cacfar_rows_kernel", "cacfar_cols_kernel", "cacfar_cloud_kernel", "register3_kernel", "coral_kernel",
-                         "surface_points_kernel", "surface_prep_kernel", "surface_sort_kernel", "surface_finish_kernel", "legacy_prepare_kernel", "legacy_cloud_kernel", "register_kernel", "assoc_kernel", "eval_kernel", "compensate_kernel"):
+            for name in ("kstrongest_rows_kernel", "kstrong_image_kernel", "kstrongest_cols_kernel", "kstrong_cloud_kernel", "cacfar_rows_kernel", "cacfar_cols_kernel", "cacfar_cloud_kernel", "coral_kernel",
+                         "surface_points_kernel", "surface_prep_kernel", "surface_sort_kernel", "surface_finish_kernel", "legacy_prepare_kernel", "legacy_cloud_kernel", "matcher_kernel", "assoc_kernel", "eval_kernel", "compensate_kernel"):
                 if name in k:
                     k = name
                     break
