@@ -765,12 +765,12 @@ def main(argv=None):
         # ---- the other sensor setups of BASELINE.json, each on its own synthetic worlds ----------------------------
         # configs[2]: MulRan (sweeps arrive [range bins][azimuths], 0.0595 m bins, counter-clockwise, 5-keyframe window);
         # configs[4]: CA-CFAR on the Kvarntorp setup (0.175 m bins: 588 m range, ~15 000 detections per sweep)
-        def side_config(params, seed0, range_res, bins_major, Bs, Ss, nfr):
+        def side_config(params, seed0, range_res, bins_major, Bs, Ss, nfr, scene_kw=None):
             from tbv_slam_public_amd import synth
             Fs = F                                               # the whole closed lap: frame Fs continues into frame 0
             sr = torch.empty((Ss, Fs, ROWS, COLS), dtype=torch.uint8, device=dev)
             for q in range(Ss):
-                scn = synth.Scene(seed0 + q, circle_frames=F, range_res=range_res, ccw=True)
+                scn = synth.Scene(seed0 + q, circle_frames=F, range_res=range_res, ccw=True, **(scene_kw or {}))
                 sr[q] = synth.render_frames_torch(scn, list(range(Fs)), dev)
             sod = api.OdometryKeyframeFuser(Bs, COLS if bins_major else ROWS, ROWS if bins_major else COLS, params, ctx=ctx)
             seq = torch.arange(Bs, device=dev) % Ss
@@ -812,12 +812,24 @@ def main(argv=None):
         c4_par = api.odometry_params(filter_type=1, cacfar_range_res=0.175, cacfar_z_min=20.0, cacfar_nb_guard_cells=10,
                                      cacfar_window_size=40, cacfar_false_alarm_rate=0.01, radar_ccw=1, kstrong_range_res=0.175,
                                      rotate_ccw=1)
+        # The worlds of this configuration: the 0.175 m bins reach 588 m, so synth.Scene spreads its default 60 walls over a 1.2 km
+        # square and a quarter of the worlds yield fewer surface points than any real scan (SURVEY 8d's realism gate: 184-484 per
+        # scan, the 5-95 % band of combined.txt; seed 80002: 12-47).  200 walls + 666 scatterers give 263-404 per world on average
+        # (tools/cfar_realism.py) and no failed registration; the sparse worlds stay as a labelled extra (`feature_poor`).
+        c4_world = dict(n_walls=200, n_scatter=666)
         note("extra: config4_cacfar_kvarntorp ([bins][azimuths] input)")
-        c4 = side_config(c4_par, 80000, 0.175, True, 512, 32, 480)
+        c4 = side_config(c4_par, 80000, 0.175, True, 512, 32, 480, c4_world)
         note("extra: config4_cacfar_kvarntorp (pre-rotated input)")
         c4_pre = side_config(api.odometry_params(filter_type=1, cacfar_range_res=0.175, cacfar_z_min=20.0, cacfar_nb_guard_cells=10,
                                                  cacfar_window_size=40, cacfar_false_alarm_rate=0.01, radar_ccw=1,
-                                                 kstrong_range_res=0.175), 80000, 0.175, False, 512, 32, 160)
+                                                 kstrong_range_res=0.175), 80000, 0.175, False, 512, 32, 160, c4_world)
+        note("extra: config4_cacfar_kvarntorp (feature-poor worlds)")
+        c4_poor = side_config(c4_par, 80000, 0.175, True, 512, 32, 96)
+        c4["feature_poor"] = {k: c4_poor[k] for k in ("value", "mean_cells_per_scan", "mean_points_per_scan", "failed_registrations", "frames")}
+        c4["feature_poor"]["note"] = ("the default 60-wall worlds at this range (round 4's config4 data): below the realism gate; their "
+                                      "failed registrations are CFEAR_ERR_TOO_FEW_RESIDUALS (n_scan_normal.cpp:368-369) on worlds with 12-47 "
+                                      "surface points per sweep, the CPU oracle fails on the same (world, frame) steps -- "
+                                      "tests/test_gpu_odometry.py::test_cacfar_pipeline_kvarntorp_preset")
         c4["input_layout"] = "[range bins][azimuths] (radar_driver.cpp:74-90): decode fused into the CA-CFAR sweep"
         c4["prerotated_value"] = c4_pre["value"]
         c4["prerotated_kernel_breakdown"] = c4_pre["kernel_breakdown"]
@@ -832,10 +844,6 @@ def main(argv=None):
                                            "frac": IMG * 512 / (cr_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                            "bytes_requested_per_scan": ROWS * need_cols,
                                            "frac_of_bytes_requested": ROWS * need_cols * 512 / (cr_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
-        c4["failed_registrations_note"] = ("status CFEAR_ERR_TOO_FEW_RESIDUALS (n_scan_normal.cpp:368-369) on the streams of the "
-                                           "feature-poor synthetic worlds (e.g. seed 80002: 16-47 surface points per sweep); the CPU "
-                                           "oracle fails on the same (world, frame) steps -- tools/cfar_failed.py, "
-                                           "tests/test_gpu_odometry.py::test_cacfar_pipeline_kvarntorp_preset")
         out["config4_cacfar_kvarntorp"] = c4
         # ---- loop-closure candidates from cached features (configs[3]) ---------------------------------------
         note("extra: loopclosure")

@@ -286,8 +286,9 @@ typedef struct cfear_reg_result {
   int32_t lm_iters;                     /* total LM iterations */
   int32_t status;                       /* CFEAR_OK / CFEAR_ERR_TOO_FEW_RESIDUALS / CFEAR_ERR_SOLVER */
   double last_relative_decrease;        /* summary_.iterations.back().relative_decrease */
-  double reserved;                      /* diagnostic: 1.0 when the registration was too large for the 80 KB association
-                                         * geometry (second launch / global-scratch path); 0.0 otherwise */
+  double reserved;                      /* diagnostic: 1.0 when the registration is one the matcher's regular form (4 wavefronts,
+                                         * 40 KB of LDS) is not good at -- dense scans; a caller that streams batches keeps
+                                         * the large forms switched on while it sees these; 0.0 otherwise */
 } cfear_reg_result;                     /* 72 bytes */
 
 /* Replaces n_scan_normal_reg::Register (n_scan_normal.cpp:82-185).  poses_xyt [n_scans][3]
@@ -302,12 +303,11 @@ int cfear_register(cfear_ctx* ctx, const cfear_scan* const* scans, int32_t n_sca
  * returns after the read-back) or DEVICE memory (the records stay on the GPU; the launch is
  * enqueued on the context's stream and not synchronised -- what a collective over the records
  * wants, cfear_register_batch_sharded).
- * Batches of up to 64 jobs run with 8 wavefronts per registration (latency), larger ones with 4
- * (throughput); the two geometries add the fp64 sums in different orders, so the SAME job may
- * differ by a few ulp of cost / pose between a small and a large batch -- e.g. between world 1 and
- * a sharded run whose per-rank block falls below 65.  Iteration counts and the accept / reject
- * decisions are the same in every test of this repository (tests/test_gpu_register.py), the poses
- * agree to 1e-12.                                                                              */
+ * The matcher runs in the form the batch calls for (wavefronts per registration x LDS per workgroup: 8 wavefronts up to two
+ * workgroups per CU, 4 beyond, 2 for large batches of two-scan candidates); the forms add the fp64 sums in different
+ * orders, so the SAME job may differ by a few ulp of cost / pose between a small and a large batch -- e.g. between world 1
+ * and a sharded run.  Iteration counts and the accept / reject decisions are the same in every test of this repository
+ * (tests/test_gpu_register.py::test_every_form_of_the_matcher_agrees), the poses agree to 1e-11.                       */
 typedef struct cfear_reg_job {
   const cfear_scan* const* scans;       /* n_scans handles */
   int32_t n_scans;
