@@ -46,7 +46,7 @@ struct cfear_ctx {
   int n_cu = 256;          // compute units of the device (cfear_ctx_create)
   int64_t opt[CFEAR_OPT_COUNT] = {1, 0, 0, 0};   // cfear_ctx_set_option (test / measurement hooks; include/cfear_hip.h)
   bool surf_list_dirty = true;   // the surface pipeline's hand-over counter may be non-zero (see cfear_surface_launch)
-  std::vector<const void*> full_lds_fns;   // kernels already allowed the CU's whole LDS on this device (matcher.hip)
+  std::vector<std::pair<const void*, int>> lds_allowed;   // kernels and the dynamic LDS they were already allowed on this device (cfear_allow_lds)
 };
 
 int cfear_set_error(cfear_ctx* ctx, int status, const char* fmt, ...);
@@ -68,6 +68,9 @@ void* cfear_workspace(cfear_ctx* ctx, int slot, size_t bytes);
 // that copy before it hands the buffer out again.
 void* cfear_pinned(cfear_ctx* ctx, size_t bytes);
 void cfear_pinned_mark(cfear_ctx* ctx);
+// hipFuncAttributeMaxDynamicSharedMemorySize, once per (context, kernel, size): the attribute is per device and contexts are
+// per device, so a launch path asks every time and pays a linear look-up over a dozen entries instead of a runtime call
+int cfear_allow_lds(cfear_ctx* ctx, const void* kernel, size_t bytes);
 
 // profiling: wrap a kernel launch
 int cfear_prof_row(cfear_ctx* ctx, const char* name);

@@ -681,7 +681,7 @@ extern "C" int cfear_coral_quality_batch(cfear_ctx* ctx, const cfear_coral_job* 
   double* d_pp = per_point ? (double*)((char*)d_res + (rb + 255) / 256 * 256) : nullptr;
   cm.scratch = scr;
   CFEAR_HIP_CHECK(ctx, hipMemcpyAsync(d_jobs, hj.data(), jb_bytes, hipMemcpyHostToDevice, ctx->stream));
-  CFEAR_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)coral_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  { const int rc_lds = cfear_allow_lds(ctx, (const void*)coral_kernel, 160 * 1024); if (rc_lds != CFEAR_OK) return rc_lds; }
   {
     ProfScope ps(ctx, "coral_quality");
     for (int j0 = 0; j0 < n_jobs; j0 += chunk) {

@@ -69,6 +69,20 @@ void* cfear_pinned(cfear_ctx* ctx, size_t bytes) {
   return ctx->pinned;
 }
 
+int cfear_allow_lds(cfear_ctx* ctx, const void* kernel, size_t bytes) {
+  if (bytes <= 64 * 1024) return CFEAR_OK;                     // the default limit: nothing to ask for
+  for (auto& e : ctx->lds_allowed)
+    if (e.first == kernel) {
+      if ((size_t)e.second >= bytes) return CFEAR_OK;
+      CFEAR_HIP_CHECK(ctx, hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+      e.second = (int)bytes;
+      return CFEAR_OK;
+    }
+  CFEAR_HIP_CHECK(ctx, hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+  ctx->lds_allowed.emplace_back(kernel, (int)bytes);
+  return CFEAR_OK;
+}
+
 // ---- profiling --------------------------------------------------------------------------------
 int cfear_prof_row(cfear_ctx* ctx, const char* name) {
   for (size_t i = 0; i < ctx->prof.size(); i++)

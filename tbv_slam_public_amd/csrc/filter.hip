@@ -2019,8 +2019,7 @@ int cfear_kstrong_cols_device(cfear_ctx* ctx, const uint8_t* d_src, const cfear_
   const size_t o_flag = n_rows * 4, o_wn = o_flag + n_tiles * 4, o_work = o_wn + 256, o_cand = (o_work + n_tiles * 4 + 255) / 256 * 256;
   uint32_t* work = nullptr;
   int32_t* work_n = nullptr;
-  int n_cu = 256;
-  (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, ctx->device);
+  const int n_cu = ctx->n_cu;
   if (fused->cand_stats) CFEAR_HIP_CHECK(ctx, hipMemsetAsync(fused->cand_stats, 0, 64 * 4, ctx->stream));
   if (!all_tiles) {
     char* ws = (char*)cfear_workspace(ctx, 12, o_cand + n_rows * kCandCap * 4);
@@ -2042,7 +2041,7 @@ int cfear_kstrong_cols_device(cfear_ctx* ctx, const uint8_t* d_src, const cfear_
     if (per_image) {
       CFEAR_HIP_CHECK(ctx, hipMemsetAsync(ws + o_flag, 0, o_work - o_flag, ctx->stream));
       const size_t lds = img_fixed + (size_t)a.rows * lds_cap * 4;
-      CFEAR_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)kstrong_image_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      { const int rc_lds = cfear_allow_lds(ctx, (const void*)kstrong_image_kernel, 160 * 1024); if (rc_lds != CFEAR_OK) return rc_lds; }
       ProfScope ps(ctx, "kstrong_image");
       hipLaunchKernelGGL(kstrong_image_kernel, dim3((unsigned)std::min(a.batch, 2 * n_cu)), dim3(64 * kImgWaves), lds, ctx->stream, a,
                          magic, segs, tiles, lds_cap, cand, tile_flag, work_n, work, fused->cand_stats);
@@ -2076,7 +2075,7 @@ int cfear_kstrong_cols_device(cfear_ctx* ctx, const uint8_t* d_src, const cfear_
   const dim3 grid((unsigned)(slots * kXcds));
   ProfScope ps(ctx, "kstrongest_cols");
   auto launch = [&](auto fn) {
-    (void)hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)cfear_allow_lds(ctx, (const void*)fn, 160 * 1024);
     hipLaunchKernelGGL(fn, grid, dim3(64 * kColsWaves), lds, ctx->stream, a, tiles, (const uint32_t*)work, (const int32_t*)work_n);
   };
   if (nchunk <= 1) { if (mask) launch(kstrongest_cols_kernel<1, true>); else launch(kstrongest_cols_kernel<1, false>); }
@@ -2398,11 +2397,10 @@ int cfear_cacfar_device(cfear_ctx* ctx, const uint8_t* d_polar, const cfear_pola
       fn = DL != D ? f8s[DL / 2 - 1] : (ColsFn)cacfar_cols_kernel<8, 2, 8, true>;
     }
     const size_t lds = cfar_cols_lds(a, D);
-    CFEAR_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    int n_cu = 256;
-    (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, ctx->device);
+    { const int rc_lds = cfear_allow_lds(ctx, (const void*)fn, lds); if (rc_lds != CFEAR_OK) return rc_lds; }
+    const int n_cu = ctx->n_cu;
     const int tiles = rows / kCfarTile;
-    const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(4, (size_t)(160 * 1024) / lds));
+    const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(4, 160 * 1024 / lds));
     const long long per_xcd = (long long)tiles * ((batch + kXcds - 1) / kXcds);
     const int slots = (int)std::max<long long>(1, std::min<long long>(per_xcd, std::max(1, n_cu * per_cu / kXcds)));
     ProfScope ps(ctx, "cacfar_cols");
@@ -2436,11 +2434,10 @@ int cfear_cacfar_device(cfear_ctx* ctx, const uint8_t* d_polar, const cfear_pola
     }
     const size_t rows_lds = 1024 + (size_t)kRowsPerBlock * cfar_wave_lds(a.colsp, a.pad_lo, a.pad_hi, keys, 256 * D);
     if (rows_lds > 64 * 1024)
-      CFEAR_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)rows_lds));
+      { const int rc_lds = cfear_allow_lds(ctx, (const void*)fn, rows_lds); if (rc_lds != CFEAR_OK) return rc_lds; }
     // persistent wavefronts: as many workgroups as the chip holds at this LDS footprint (160 KiB per CU)
-    int n_cu = 256;
-    (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, ctx->device);
-    const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(8, (size_t)(160 * 1024) / rows_lds));
+    const int n_cu = ctx->n_cu;
+    const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(8, 160 * 1024 / rows_lds));
     const long long want = (a.total_rows + kRowsPerBlock - 1) / kRowsPerBlock;
     const unsigned grid = (unsigned)std::max<long long>(1, std::min<long long>(want, (long long)n_cu * per_cu));
     ProfScope ps(ctx, "cacfar_rows");
@@ -2687,7 +2684,7 @@ int cfear_rotate_ccw_device(cfear_ctx* ctx, const uint8_t* d_src, const cfear_po
   if (sd->cols <= kRotMaxCols) {
     const int ppr = (sd->cols + 15) >> 4;
     const size_t lds = (size_t)kRotRows * ((ppr * 4) | 1) * 4;
-    CFEAR_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)rotate_ccw_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    { const int rc_lds = cfear_allow_lds(ctx, (const void*)rotate_ccw_rows_kernel, 160 * 1024); if (rc_lds != CFEAR_OK) return rc_lds; }
     for (int b0 = 0; b0 < sd->batch; b0 += 65535) {
       a.batch0 = b0;
       const dim3 grid((sd->rows + kRotRows - 1) / kRotRows, std::min(65535, sd->batch - b0));

@@ -1344,13 +1344,6 @@ Form first_form(const cfear_ctx* ctx, int n_wgs, bool huber, bool small_pairs, b
   return f;
 }
 
-// hipFuncAttributeMaxDynamicSharedMemorySize once per (context, kernel): the attribute is per device, contexts are per device
-int allow_full_lds(cfear_ctx* ctx, const void* fn) {
-  for (const void* p : ctx->full_lds_fns) if (p == fn) return CFEAR_OK;
-  CFEAR_HIP_CHECK(ctx, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsCu));
-  ctx->full_lds_fns.push_back(fn);
-  return CFEAR_OK;
-}
 }  // namespace
 
 // Enqueues the matcher over d_jobs [n_jobs] (device records, job_stride bytes apart), results to d_results [n_jobs] (device;
@@ -1393,7 +1386,7 @@ int cfear_register_launch(cfear_ctx* ctx, const void* d_jobs, int n_jobs, const 
   for (int k = 0; k < n_forms; k++) {
     const Form& f = forms[k];
     const MatcherFn fn = matcher_fn(f.nw, par->cost, huber, mode != nullptr);
-    if (f.lds > 64 * 1024) { const int rc = allow_full_lds(ctx, (const void*)fn); if (rc != CFEAR_OK) return rc; }
+    { const int rc = cfear_allow_lds(ctx, (const void*)fn, kLdsCu); if (rc != CFEAR_OK) return rc; }
     MatchCommon c = cm;
     c.lds_total = (uint32_t)f.lds;
     c.only_deferred = k > 0;
@@ -1799,7 +1792,7 @@ extern "C" int cfear_cost_prepare(cfear_ctx* ctx, const cfear_scan* const* scans
   cm.dense_fields = reg_dense_fields(par->cost);
   cm.lds_total = (uint32_t)(kLdsCu - 256);
   int32_t* d_nb = (int32_t*)((char*)c->d_job + sizeof(RegJob));
-  if (allow_full_lds(ctx, (const void*)assoc_kernel) != CFEAR_OK) return fail(CFEAR_ERR_HIP, "hipFuncSetAttribute failed");
+  if (cfear_allow_lds(ctx, (const void*)assoc_kernel, kLdsCu) != CFEAR_OK) return fail(CFEAR_ERR_HIP, "hipFuncSetAttribute failed");
   hipLaunchKernelGGL(assoc_kernel, dim3(1), dim3(256), (size_t)cm.lds_total, ctx->stream, (const RegJob*)c->d_job, cm, (int)itr, d_nb);
   if (hipGetLastError() != hipSuccess) return fail(CFEAR_ERR_HIP, "assoc_kernel launch failed");
   c->h_w.assign(std::max(c->n_slots, 1), -1.0);

@@ -331,7 +331,7 @@ extern "C" int cfear_sc_distance_batch(cfear_ctx* ctx, const double* desc_q, int
   a.chunk = (int)std::max<size_t>(1, std::min<size_t>({room, (size_t)m_max, (size_t)256, (size_t)S}));
   a.sim_off = (uint32_t)base;
   const size_t lds = base + (size_t)a.chunk * S * 8;
-  CFEAR_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)sc_distance_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  { const int rc_lds = cfear_allow_lds(ctx, (const void*)sc_distance_kernel, 160 * 1024); if (rc_lds != CFEAR_OK) return rc_lds; }
   {
     ProfScope ps(ctx, "sc_distance");
     hipLaunchKernelGGL(sc_distance_kernel, dim3(n_pairs), dim3(kScDistThreads), lds, ctx->stream, a);

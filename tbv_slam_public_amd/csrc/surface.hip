@@ -1610,10 +1610,8 @@ int cfear_surface_launch(cfear_ctx* ctx, const void* d_jobs, int n_jobs, const c
     CFEAR_HIP_CHECK(ctx, hipMemsetAsync(cm.fallback, 0, 4, ctx->stream));
   ctx->surf_list_dirty = true;
   // per launch: the attribute is per device, and contexts on other threads / devices share this code
-  CFEAR_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)surface_points_kernel,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)cfear_surface_lds_bytes()));
-  CFEAR_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)surface_sort_kernel,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFastLds));
+  { const int rc_lds = cfear_allow_lds(ctx, (const void*)surface_points_kernel, cfear_surface_lds_bytes()); if (rc_lds != CFEAR_OK) return rc_lds; }
+  { const int rc_lds = cfear_allow_lds(ctx, (const void*)surface_sort_kernel, kFastLds); if (rc_lds != CFEAR_OK) return rc_lds; }
   cm.finish_keys = std::min(max_cell_cap, kMaxPoints);     // cells a scan may hold (the matcher's 16-bit tables address 65 535)
   const size_t finish_lds = kScanGridLds;                    // the matcher grid's counters
   cm.finish_lds = (uint32_t)finish_lds;
@@ -1625,7 +1623,7 @@ int cfear_surface_launch(cfear_ctx* ctx, const void* d_jobs, int n_jobs, const c
       prep_lds = (((size_t)(polar->rows + 1) * 4 + 15) & ~(size_t)15) + ((np * 2 + 15) & ~(size_t)15) + (size_t)polar->rows * 16;
       if (prep_lds > 150 * 1024) return cfear_set_error(ctx, CFEAR_ERR_CAPACITY, "%d azimuths exceed the row tables", polar->rows);
       if (prep_lds > 64 * 1024)
-        CFEAR_HIP_CHECK(ctx, hipFuncSetAttribute((const void*)surface_prep_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)prep_lds));
+        { const int rc_lds = cfear_allow_lds(ctx, (const void*)surface_prep_kernel<true>, prep_lds); if (rc_lds != CFEAR_OK) return rc_lds; }
     }
     ProfScope ps(ctx, "surface_prep");
     if (polar) hipLaunchKernelGGL(surface_prep_kernel<true>, dim3(n_jobs), dim3(kFastThreads), prep_lds, ctx->stream, (const SurfJob*)d_jobs, cm);
