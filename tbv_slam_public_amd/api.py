@@ -405,7 +405,7 @@ class ScanTable:
 
     def __init__(self, scans, ctx=None):
         self.ctx = ctx or scans[0].ctx
-        self._scans = list(scans)                                  # the table holds no reference: keep the scans alive
+        self._scans = list(scans)                                  # (the table holds its own reference on every scan too)
         hs = (C.c_void_p * len(scans))(*[s._h for s in scans])
         self._h = C.c_void_p()
         self.ctx.check(self.ctx._lib.cfear_scan_table_create(self.ctx.h, hs, len(scans), C.byref(self._h)))

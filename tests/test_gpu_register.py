@@ -572,6 +572,35 @@ def test_candidates_from_a_scan_table_equal_the_job_batch():
     table.close()
 
 
+def test_a_scan_table_keeps_its_scans_alive():
+    """cfear_scan_table_create takes a reference on every scan: destroying the caller's handles -- and creating new scans, which
+    would recycle the freed slabs -- leaves the table's candidates registering against the SAME cells (round 4's table pointed
+    into recycled memory)."""
+    from tbv_slam_public_amd import api
+    cells, gt = _cells(6, [0, 1, 2, 3])
+    scans = [api.MapPointNormal(cells=c) for c in cells]
+    table = api.ScanTable(scans)
+    table._scans = []                                            # (the Python wrapper's own keep-alive list out of the way)
+    reg = api.n_scan_normal_reg("P2L")
+    reg.SetParameters(4, 10)
+    rng = np.random.default_rng(4)
+    n = 48
+    tgt, src = rng.integers(0, 4, n), rng.integers(0, 4, n)
+    src = np.where(src == tgt, (src + 1) % 4, src)
+    guess = np.stack([gt[b] - gt[a] for a, b in zip(tgt, src)]) + rng.normal(0, 0.2, (n, 3)) * [1, 1, 0.03]
+    cands = api.ScanTable.candidates(tgt, src, guess)
+    before = reg.RegisterCandidates(table, cands)
+    for sc in scans:
+        sc.close()
+    del scans
+    other, _ = _cells(9, [0, 1, 2, 3])
+    fresh = [api.MapPointNormal(cells=c) for c in other]         # same capacities: these would have taken the freed slabs
+    after = reg.RegisterCandidates(table, cands)
+    assert after.tobytes() == before.tobytes() and (before["status"] == 0).mean() > 0.8
+    table.close()
+    del fresh
+
+
 def _rccl():
     """librccl through ctypes: a ONE-rank communicator (ncclGetUniqueId + ncclCommInitRank), as a C++ host would own it."""
     import ctypes as C

@@ -130,3 +130,29 @@ def test_verification_with_empty_peak_clouds(data):
     assert (r["coral"][1:] == 0).all() and (r["cfear"][1:, 0] > 0).all()
     q, _ = api.coral_quality_batch([(pk, (0, 0, 0), empty, (0, 0, 0), (0, 0, 0))])
     assert q["status"][0] != 0 and q["valid"][0] == 0
+
+
+def test_context_options_and_stream_handle(data):
+    """cfear_ctx_set_option / _get_option / _get_stream: the test hooks that replaced the CFEAR_* environment switches.  Unknown
+    options and values outside their range are argument errors and leave the option unchanged; a context created on a torch
+    stream reports that stream's handle, and dist.py's ordering test (Context.shares_torch_stream) is true exactly there."""
+    import torch
+    from tbv_slam_public_amd import api
+    from tbv_slam_public_amd import _lib as L
+    ctx = api.Context(0)
+    assert ctx.get_option(L.OPT_FUSED_DECODE) == 1 and ctx.get_option(L.OPT_MATCHER_LDS_KB) == 0
+    ctx.set_option(L.OPT_MATCHER_LDS_KB, 52)
+    assert ctx.get_option(L.OPT_MATCHER_LDS_KB) == 52
+    for opt, val in ((L.OPT_MATCHER_LDS_KB, 4), (L.OPT_MATCHER_LDS_KB, 161), (L.OPT_MATCHER_WAVES, 3), (L.OPT_FUSED_DECODE, 2), (L.OPT_COUNT, 0), (-1, 0)):
+        with pytest.raises(L.CfearError) as e:
+            ctx.set_option(opt, val)
+        assert e.value.status == L.ERR_INVALID_ARGUMENT
+    assert ctx.get_option(L.OPT_MATCHER_LDS_KB) == 52 and ctx.get_option(L.OPT_MATCHER_WAVES) == 0
+    assert ctx.stream_handle() != 0 and not ctx.shares_torch_stream()      # a private stream: nothing of torch's is ordered with it
+    ctx.close()
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        shared = api.Context(0, stream=side.cuda_stream)
+        assert shared.stream_handle() == side.cuda_stream and shared.shares_torch_stream()
+    assert not shared.shares_torch_stream()                                # torch's current stream is the default one again
+    shared.close()
