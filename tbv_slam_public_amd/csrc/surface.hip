@@ -98,6 +98,8 @@ static_assert(sizeof(CellMom) == 64 && offsetof(CellMom, cx) == 48, "surface_fin
 //   + 132 N   u32[N + 4]   fast: voxel starts (V + 1 entries)
 constexpr int kFastMaxCells = 1 << 18;        // grid cells of the fast pipeline (one occupancy bit + 1/16 u16 per cell in LDS; the LDS check decides)
 constexpr int kFastThreads = 512;
+constexpr int kFastMaxPoints = 32768;         // points per scan the fast pipeline takes: up to kMaxPoints in the regular instantiation of
+                                              // surface_sort_kernel (32 points per thread in registers), beyond in its second one (64)
 constexpr size_t kFastLds = 78 * 1024;        // two workgroups per CU (160 KiB); three (52 KiB, 80 VGPRs) measured no faster: the kernel is issue-bound
 constexpr int kRouteFast = 0, kRouteFallback = 1, kRouteDone = 2, kRoutePrepped = 3;
 constexpr int kScanCreateMaxPoints = 1 << 20;  // cfear_scan_create: clouds beyond kMaxPoints take the global-memory path
@@ -898,7 +900,7 @@ __global__ __launch_bounds__(kFastThreads) void surface_prep_kernel(const SurfJo
   }
   if (n <= 0) { done(CFEAR_ERR_EMPTY_CLOUD); return; }
   if (n > cm.scratch_cap) { done(CFEAR_ERR_CAPACITY); return; }
-  if (n > kMaxPoints) { hand_over(n, 0); return; }         // big cloud: global-memory path of the single-kernel workgroup
+  if (n > kFastMaxPoints) { hand_over(n, 0); return; }     // big cloud: global-memory path of the single-kernel workgroup
   float4* pts = job.xyzi;
   // ---- (b) polar -> Cartesian (rows mode), motion compensation, bounding box ------------------------------------
   // rows mode: the azimuth row of every point as a u16 table behind rowoff (one thread per row fills its <= k slots;
@@ -987,15 +989,23 @@ __global__ __launch_bounds__(kFastThreads) void surface_prep_kernel(const SurfJo
 
 constexpr int kTierInFlight = 2;                    // candidates per lane in flight in the lane-group tiers of the moments pass (4: no faster)
 
+// KPER = points per thread the kernel can hold in registers: 32 (scans of up to kMaxPoints = 16 384 points: every k-strongest
+// cloud) and 64 (CA-CFAR sweeps beyond that -- cfar.cpp:35-71 puts no bound on the detections; at Pfa 0.01 the false alarms of a
+// 400 x 2286-bin sweep alone are ~10 k points -- launched behind the regular one, which leaves such scans untouched.  Its 64
+// positions per thread spill at 128 VGPRs (316 bytes of scratch per lane), and two spilling workgroups per CU still beat one
+// with 136 VGPRs: 0.52 against 0.60 ms per 512 sweeps).  Without it those scans took the single-kernel path -- milliseconds
+// each: 1.5 ms per frame batch of 512 Kvarntorp-preset sweeps of which a quarter exceed 16 384 points.
+template <int KPER>
 __global__ __launch_bounds__(kFastThreads, 4) void surface_sort_kernel(const SurfJob* __restrict__ jobs, const SurfCommon cm) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   constexpr int NT = kFastThreads, NW = NT / 64;
-  constexpr int kPer = kMaxPoints / NT;                               // <= 32 points per thread
+  constexpr int kPer = KPER;                                          // <= KPER points per thread
   int* red_i = (int*)(smem + kFastLds - 512 + 4 * NW * 4);             // [2][NW]
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int job_id = blockIdx.x;
   const SurfScratch scr = scratch_of(cm.scratch + (size_t)job_id * cm.scratch_stride, cm.scratch_cap);
-  if (scr.hdr->route != kRoutePrepped) return;                         // failed, empty or handed to the single-kernel path
+  if (scr.hdr->route != kRoutePrepped) return;                         // failed, empty, handed to the single-kernel path -- or done (second launch)
+  if (KPER * NT < kFastMaxPoints && scr.hdr->n > KPER * NT) return;    // the second instantiation's scan
   const SurfJob job = jobs[job_id];
   auto hand_over = [&](int n, int prepared) {                          // to the single-kernel path
     if (tid == 0) {
@@ -1611,7 +1621,9 @@ int cfear_surface_launch(cfear_ctx* ctx, const void* d_jobs, int n_jobs, const c
   ctx->surf_list_dirty = true;
   // per launch: the attribute is per device, and contexts on other threads / devices share this code
   { const int rc_lds = cfear_allow_lds(ctx, (const void*)surface_points_kernel, cfear_surface_lds_bytes()); if (rc_lds != CFEAR_OK) return rc_lds; }
-  { const int rc_lds = cfear_allow_lds(ctx, (const void*)surface_sort_kernel, kFastLds); if (rc_lds != CFEAR_OK) return rc_lds; }
+  { const int rc_lds = cfear_allow_lds(ctx, (const void*)surface_sort_kernel<32>, kFastLds); if (rc_lds != CFEAR_OK) return rc_lds; }
+  const bool big_scans = cap_points > kMaxPoints;            // scans beyond 16 384 points may come (CA-CFAR): the second instantiation behind the first
+  if (big_scans) { const int rc_lds = cfear_allow_lds(ctx, (const void*)surface_sort_kernel<64>, kFastLds); if (rc_lds != CFEAR_OK) return rc_lds; }
   cm.finish_keys = std::min(max_cell_cap, kMaxPoints);     // cells a scan may hold (the matcher's 16-bit tables address 65 535)
   const size_t finish_lds = kScanGridLds;                    // the matcher grid's counters
   cm.finish_lds = (uint32_t)finish_lds;
@@ -1619,7 +1631,7 @@ int cfear_surface_launch(cfear_ctx* ctx, const void* d_jobs, int n_jobs, const c
     // rows mode: rowoff i32[rows + 1] | row of every point u16[n] | (cos, sin) f64[rows]
     size_t prep_lds = 0;
     if (polar) {
-      const size_t np = (size_t)std::min<long long>((long long)polar->rows * polar->k, kMaxPoints);
+      const size_t np = (size_t)std::min<long long>((long long)polar->rows * polar->k, kFastMaxPoints);
       prep_lds = (((size_t)(polar->rows + 1) * 4 + 15) & ~(size_t)15) + ((np * 2 + 15) & ~(size_t)15) + (size_t)polar->rows * 16;
       if (prep_lds > 150 * 1024) return cfear_set_error(ctx, CFEAR_ERR_CAPACITY, "%d azimuths exceed the row tables", polar->rows);
       if (prep_lds > 64 * 1024)
@@ -1631,7 +1643,8 @@ int cfear_surface_launch(cfear_ctx* ctx, const void* d_jobs, int n_jobs, const c
   }
   {
     ProfScope ps(ctx, "surface_sort");
-    hipLaunchKernelGGL(surface_sort_kernel, dim3(n_jobs), dim3(kFastThreads), kFastLds, ctx->stream, (const SurfJob*)d_jobs, cm);
+    hipLaunchKernelGGL(surface_sort_kernel<32>, dim3(n_jobs), dim3(kFastThreads), kFastLds, ctx->stream, (const SurfJob*)d_jobs, cm);
+    if (big_scans) hipLaunchKernelGGL(surface_sort_kernel<64>, dim3(n_jobs), dim3(kFastThreads), kFastLds, ctx->stream, (const SurfJob*)d_jobs, cm);
   }
   {
     ProfScope ps(ctx, "surface_points");       // the single-kernel path drains the hand-over list (usually empty)
