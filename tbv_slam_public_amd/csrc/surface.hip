@@ -992,9 +992,10 @@ constexpr int kTierInFlight = 2;                    // candidates per lane in fl
 // KPER = points per thread the kernel can hold in registers: 32 (scans of up to kMaxPoints = 16 384 points: every k-strongest
 // cloud) and 64 (CA-CFAR sweeps beyond that -- cfar.cpp:35-71 puts no bound on the detections; at Pfa 0.01 the false alarms of a
 // 400 x 2286-bin sweep alone are ~10 k points -- launched behind the regular one, which leaves such scans untouched.  Its 64
-// positions per thread spill at 128 VGPRs (316 bytes of scratch per lane), and two spilling workgroups per CU still beat one
-// with 136 VGPRs: 0.52 against 0.60 ms per 512 sweeps).  Without it those scans took the single-kernel path -- milliseconds
-// each: 1.5 ms per frame batch of 512 Kvarntorp-preset sweeps of which a quarter exceed 16 384 points.
+// positions per thread are packed two per register (as 64 separate u16 they spilled 316 bytes per lane at the 128 VGPRs two
+// workgroups per CU allow; one workgroup per CU with 136 VGPRs was slower still: 0.60 / 0.52 / 0.49 ms per 512 sweeps).
+// Without it those scans took the single-kernel path -- milliseconds each: 1.5 ms per frame batch of 512 Kvarntorp-preset
+// sweeps of which a quarter exceed 16 384 points.
 template <int KPER>
 __global__ __launch_bounds__(kFastThreads, 4) void surface_sort_kernel(const SurfJob* __restrict__ jobs, const SurfCommon cm) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -1042,7 +1043,16 @@ __global__ __launch_bounds__(kFastThreads, 4) void surface_sort_kernel(const Sur
   STAMP(9);
   const int jn = (n + NT - 1) / NT;                                   // rounds of NT points (<= kPer)
   auto idx_of = [&](int j) { return tid + j * NT; };
-  unsigned short mycell[kPer];                                        // the cells of this thread's points (registers); later their voxels
+  // the cells of this thread's points (registers); later their voxels, then their positions.  The 64-point instantiation packs
+  // two per register (64 separate registers spill at the 128 VGPRs two workgroups per CU allow); all indices are compile-time.
+  struct Cells {
+    typename std::conditional<KPER == 32, unsigned short, uint32_t>::type w[KPER == 32 ? KPER : KPER / 2];
+    __device__ __forceinline__ int get(int j) const { return KPER == 32 ? (int)w[j] : (int)((w[j >> 1] >> ((j & 1) * 16)) & 0xffffu); }
+    __device__ __forceinline__ void set(int j, int v) {
+      if (KPER == 32) w[j] = (unsigned short)v;
+      else w[j >> 1] = (j & 1) ? ((w[j >> 1] & 0x0000ffffu) | ((uint32_t)v << 16)) : ((w[j >> 1] & 0xffff0000u) | ((uint32_t)v & 0xffffu));
+    }
+  } mycell;
   bool w_small = true;                                                // every weight max(I - 60, 0) an integer in [0, 255]?
 #pragma unroll
   for (int j0 = 0; j0 < kPer; j0 += 8) {                              // eight loads in flight per thread
@@ -1056,13 +1066,13 @@ __global__ __launch_bounds__(kFastThreads, 4) void surface_sort_kernel(const Sur
 #pragma unroll
       for (int u = 0; u < 8; u++) {
         const int j = j0 + u, i = idx_of(j);
-        mycell[j] = 0;
+        mycell.set(j, 0);
         if (i < n) {
           const float4 p = pp[u];
           const int ijk0 = (int)(floorf(p.x * cm.inv_leaf) - (float)min_bx);
           const int ijk1 = (int)(floorf(p.y * cm.inv_leaf) - (float)min_by);
           const int c = ijk0 + ijk1 * dbx;
-          mycell[j] = (unsigned short)c;                                // complete for grids up to 65 536 cells
+          mycell.set(j, c & 0xffff);                                    // complete for grids up to 65 536 cells
           atomicOr(&occ[c >> 5], 1u << (c & 31));
           const float wgt = fmaxf(__fsub_rn(p.w, 60.0f), 0.0f);
           w_small = w_small && wgt <= 255.0f && wgt == truncf(wgt);
@@ -1126,8 +1136,8 @@ __global__ __launch_bounds__(kFastThreads, 4) void surface_sort_kernel(const Sur
     for (int j = 0; j < kPer; j++) {
       const int i = idx_of(j);
       if (i < n) {
-        const int v = ord((int)mycell[j]);
-        mycell[j] = (unsigned short)v;
+        const int v = ord(mycell.get(j));
+        mycell.set(j, v);
         atomicAdd(&vs32[v >> 1], (v & 1) ? 0x10000u : 1u);
       }
     }
@@ -1148,7 +1158,7 @@ __global__ __launch_bounds__(kFastThreads, 4) void surface_sort_kernel(const Sur
             const int ijk0 = (int)(floorf(pq[u].x * cm.inv_leaf) - (float)min_bx);
             const int ijk1 = (int)(floorf(pq[u].y * cm.inv_leaf) - (float)min_by);
             const int v = ord(ijk0 + ijk1 * dbx);
-            mycell[j] = (unsigned short)v;
+            mycell.set(j, v);
             atomicAdd(&vs32[v >> 1], (v & 1) ? 0x10000u : 1u);
           }
         }
@@ -1175,7 +1185,7 @@ __global__ __launch_bounds__(kFastThreads, 4) void surface_sort_kernel(const Sur
   for (int j = 0; j < kPer; j++) {
     const int i = idx_of(j);
     if (i < n) {
-      const int v = (int)mycell[j];
+      const int v = mycell.get(j);
       const uint32_t old = atomicAdd(&vs32[v >> 1], (v & 1) ? 0x10000u : 1u);
       const int pos = (v & 1) ? (int)(old >> 16) : (int)(old & 0xffffu);
       order[pos] = (unsigned short)i;
@@ -1188,7 +1198,7 @@ __global__ __launch_bounds__(kFastThreads, 4) void surface_sort_kernel(const Sur
   for (int j = 0; j < kPer; j++) {
     const int i = idx_of(j);
     if (i < n) {
-      const int v = (int)mycell[j];
+      const int v = mycell.get(j);
       const int s0 = v ? (int)vs16[v - 1] : 0, e0 = (int)vs16[v];
       // The loop is a chain of dependent LDS round trips, not arithmetic: sixteen indices per trip (two aligned 16-byte
       // reads in flight) from the 16-byte boundary below the run on; positions outside the run are masked out, so there
@@ -1207,7 +1217,7 @@ __global__ __launch_bounds__(kFastThreads, 4) void surface_sort_kernel(const Sur
         const uint4 oa = *(const uint4*)(order + q), ob = *(const uint4*)(order + q + 8);
         rank += below(oa, q) + below(ob, q + 8);
       }
-      mycell[j] = (unsigned short)(s0 + rank);
+      mycell.set(j, s0 + rank);
     }
   }
   __syncthreads();                                                     // the order array is dead: its LDS becomes the staging area
@@ -1232,7 +1242,7 @@ __global__ __launch_bounds__(kFastThreads, 4) void surface_sort_kernel(const Sur
         for (int u = 0; u < 8; u++) {
           if (idx_of(j0 + u) < n) {
             const float4 p = pp[u];
-            const int pos = (int)mycell[j0 + u];
+            const int pos = mycell.get(j0 + u);
             const float wgt = fmaxf(__fsub_rn(p.w, 60.0f), 0.0f);
             if (single) {
               sxy[pos] = make_float2(p.x, p.y);
