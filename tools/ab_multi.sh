@@ -1,6 +1,7 @@
 #!/bin/bash
 # A/B/C... of several builds in ONE gpurun call (boxes differ by ~5 %): every tbv_slam_public_amd/variants/*.so against the
 # current libcfear_hip.so ("cur"), alternating, REPS rounds.  Prints value, ms per frame batch and the kernel breakdown.
+#   BENCH_ARGS="--dense --steps 3 --frames-per-step 8" / "--bins-major ..." select the scene population (default: the headline).
 #   build a variant:  make -C tbv_slam_public_amd/csrc EXTRA=-DMT_SOMETHING && cp tbv_slam_public_amd/libcfear_hip.so tbv_slam_public_amd/variants/something.so
 L=tbv_slam_public_amd
 cp $L/libcfear_hip.so /tmp/cur.so
