@@ -1027,8 +1027,9 @@ __device__ __forceinline__ void write_capacity(cfear_reg_result* r, const double
 // Wavefronts per SIMD the forms are compiled for: four (<= 128 VGPRs) -- except the regular form with a loss other than Huber
 // (~155 VGPRs: three; the host gives those launches 52 KB per workgroup instead of 40).
 // CO: the cost-only launches (GetCost / cost sampling) are instantiations of their own -- the same loop without the solve.
-template <int NW, int COST, int LOSS, bool CO>
-__global__ __launch_bounds__(NW * 64, (NW == 4 && LOSS < 0) ? 3 : 4) void matcher_kernel(const RegJob* __restrict__ jobs, const MatchCommon cm) {
+// WIDE (8 wavefronts, a batch of at most one workgroup per CU -- the single sequence): the whole register file, no spills.
+template <int NW, int COST, int LOSS, bool CO, bool WIDE = false>
+__global__ __launch_bounds__(NW * 64, WIDE ? 2 : ((NW == 4 && LOSS < 0) ? 3 : 4)) void matcher_kernel(const RegJob* __restrict__ jobs, const MatchCommon cm) {
   constexpr int NT = NW * 64;
 #ifdef CFEAR_REG_TIMING
   const long long t_total0 = __builtin_readcyclecounter();
@@ -1291,9 +1292,17 @@ MatcherFn matcher_fn_nw(int cost, bool huber) {
     default: return huber ? matcher_kernel<NW, CFEAR_P2D, CFEAR_LOSS_HUBER, CO> : matcher_kernel<NW, CFEAR_P2D, -1, CO>;
   }
 }
-// full registrations: 2 / 4 / 8 / 16 wavefronts; cost-only launches: 4 / 8
-MatcherFn matcher_fn(int nw, int cost, bool huber, bool cost_only) {
+MatcherFn matcher_fn_wide(int cost, bool huber) {
+  switch (cost) {
+    case CFEAR_P2P: return huber ? matcher_kernel<8, CFEAR_P2P, CFEAR_LOSS_HUBER, false, true> : matcher_kernel<8, CFEAR_P2P, -1, false, true>;
+    case CFEAR_P2L: return huber ? matcher_kernel<8, CFEAR_P2L, CFEAR_LOSS_HUBER, false, true> : matcher_kernel<8, CFEAR_P2L, -1, false, true>;
+    default: return huber ? matcher_kernel<8, CFEAR_P2D, CFEAR_LOSS_HUBER, false, true> : matcher_kernel<8, CFEAR_P2D, -1, false, true>;
+  }
+}
+// full registrations: 2 / 4 / 8 / 16 wavefronts (8 also `wide`); cost-only launches: 4 / 8
+MatcherFn matcher_fn(int nw, int cost, bool huber, bool cost_only, bool wide = false) {
   if (cost_only) return nw <= 4 ? matcher_fn_nw<4, true>(cost, huber) : matcher_fn_nw<8, true>(cost, huber);
+  if (nw == 8 && wide) return matcher_fn_wide(cost, huber);
   switch (nw) {
     case 2: return matcher_fn_nw<2, false>(cost, huber);
     case 4: return matcher_fn_nw<4, false>(cost, huber);
@@ -1385,7 +1394,7 @@ int cfear_register_launch(cfear_ctx* ctx, const void* d_jobs, int n_jobs, const 
   if (more && f0.nw >= 8 && f0.lds >= forms[1].lds) { forms[1] = forms[2]; names[1] = names[2]; n_forms = 2; }   // (the first form IS the half-CU form)
   for (int k = 0; k < n_forms; k++) {
     const Form& f = forms[k];
-    const MatcherFn fn = matcher_fn(f.nw, par->cost, huber, mode != nullptr);
+    const MatcherFn fn = matcher_fn(f.nw, par->cost, huber, mode != nullptr, n_jobs * by <= ctx->n_cu);
     { const int rc = cfear_allow_lds(ctx, (const void*)fn, kLdsCu); if (rc != CFEAR_OK) return rc; }
     MatchCommon c = cm;
     c.lds_total = (uint32_t)f.lds;
