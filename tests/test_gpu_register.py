@@ -520,6 +520,15 @@ def test_every_form_of_the_matcher_agrees():
             for waves, kb in ((4, 40), (4, 14), (8, 80), (16, 160), (2, 20)):
                 reg.ctx.set_option(L.OPT_MATCHER_WAVES, waves); reg.ctx.set_option(L.OPT_MATCHER_LDS_KB, kb)
                 runs["%d x %d KB" % (waves, kb)] = reg.RegisterBatch(jobs)
+            # the 8-wavefront form has two builds: a batch of at most one workgroup per CU (the runs above) takes the one
+            # compiled for the whole register file; 288 workgroups take the 128-VGPR build.  Same statements, same order
+            # of additions: the records are identical.
+            reg.ctx.set_option(L.OPT_MATCHER_WAVES, 8); reg.ctx.set_option(L.OPT_MATCHER_LDS_KB, 80)
+            many = reg.RegisterBatch(jobs * 4)
+            for a, b in zip(runs["8 x 80 KB"], many[:len(jobs)]):
+                for f in ("status", "outer_iters", "lm_iters", "num_residuals", "final_cost", "score"):
+                    assert a[f] == b[f], (cost, f, a[f], b[f])
+                assert np.array_equal(a["pose"], b["pose"]), (cost, a["pose"], b["pose"])
         finally:
             reg.ctx.set_option(L.OPT_MATCHER_WAVES, 0); reg.ctx.set_option(L.OPT_MATCHER_LDS_KB, 0)
         for name, out in runs.items():
