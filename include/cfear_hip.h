@@ -281,7 +281,9 @@ typedef struct cfear_reg_result {
   double pose[3];                       /* (x, y, theta) of the source after registration */
   double score;                         /* score_ = final_cost / num_residuals (getScore) */
   double final_cost;                    /* summary_.final_cost */
-  int32_t num_residuals;                /* summary_.num_residuals (elements) */
+  int32_t num_residuals;                /* summary_.num_residuals (elements): of the last problem that was solved -- a
+                                         * registration that ends with too few residuals in a later pass keeps the pass
+                                         * before's, as summary_ does; 0 when none was solved */
   int32_t outer_iters;                  /* itr_ on exit (timing key "itrs") */
   int32_t lm_iters;                     /* total LM iterations */
   int32_t status;                       /* CFEAR_OK / CFEAR_ERR_TOO_FEW_RESIDUALS / CFEAR_ERR_SOLVER */

@@ -1091,7 +1091,7 @@ __global__ __launch_bounds__(NW * 64, WIDE ? 2 : ((NW == 4 && LOSS < 0) ? 3 : 4)
   }
   __syncthreads();
   bool success = true;
-  int itr = 1, lm_iters = 0, num_residuals = 0, fail_status = CFEAR_OK;
+  int itr = 1, lm_iters = 0, num_residuals = 0, solved_residuals = 0, fail_status = CFEAR_OK;
   for (itr = 1;; itr++) {
     int a_itr = itr;
     const int sidx = (int)blockIdx.y + (itr - 1) * (int)gridDim.y;
@@ -1115,7 +1115,7 @@ __global__ __launch_bounds__(NW * 64, WIDE ? 2 : ((NW == 4 && LOSS < 0) ? 3 : 4)
     num_residuals = n_blocks * rpb;
     success = num_residuals > 1;                                  // :368-369
     if (!success && !CO) { fail_status = CFEAR_ERR_TOO_FEW_RESIDUALS; break; }
-    if (success) lm_solve<NT, COST, LOSS>(cm, dn, cm.par.max_itr_solver, part, st, CO);
+    if (success) { solved_residuals = num_residuals; lm_solve<NT, COST, LOSS>(cm, dn, cm.par.max_itr_solver, part, st, CO); }
     if (CO) {
       if (threadIdx.x == 0) {
         cfear_reg_result* r = res + sidx;
@@ -1166,13 +1166,15 @@ __global__ __launch_bounds__(NW * 64, WIDE ? 2 : ((NW == 4 && LOSS < 0) ? 3 : 4)
     res->pose[0] = st[S_OUTER]; res->pose[1] = st[S_OUTER + 1]; res->pose[2] = st[S_OUTER + 2];
     const double final_cost = st[S_FINAL];
     res->final_cost = final_cost;
-    res->num_residuals = num_residuals;
+    // summary_.num_residuals: of the last problem that was SOLVED -- an association pass that ends the loop with too few
+    // residuals (n_scan_normal.cpp:112-113) leaves the summary of the solve before it (0: there was none)
+    res->num_residuals = solved_residuals;
     res->outer_iters = itr;
     res->lm_iters = lm_iters;
     res->last_relative_decrease = st[S_LASTREL];
     // a registration the regular form is not good at (dense scans): tells the caller to keep the large forms on
     res->reserved = mt_fit(cm.lds_regular, last, sum_pad, max_pad, n_src, cm.dense_fields, false).good ? 0.0 : 1.0;
-    if (success) { res->score = final_cost / (double)num_residuals; res->status = CFEAR_OK; }   // :162
+    if (success) { res->score = final_cost / (double)solved_residuals; res->status = CFEAR_OK; }   // :162
     else { res->score = 0.0; res->status = fail_status; }
 #ifdef CFEAR_REG_TIMING
     if (blockIdx.x == 0) {

@@ -1,0 +1,161 @@
+"""GPU: a randomized sweep of the whole path against the CPU oracle on seeds no other test uses.
+
+Every other GPU test pins a handful of seeds per feature; this one draws scenes, filter parameters, cost / loss / weight
+combinations, window sizes and start poses at random and pushes them through filter -> surface points -> registration, the
+registrations as ONE batch per parameter set so that the batch-size dependent forms of the matcher all see them (and once
+more through the regular 4-wavefront form, which only batches of thousands reach by themselves).  The oracle judges every
+record.  CFEAR_SOAK=<n> sets the number of scenes (default 6: ~20 s; profiles/r05/soak.txt holds a run with 200)."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+POS_TOL, ROT_TOL = 1e-4, 1e-5
+N_SCENES = int(os.environ.get("CFEAR_SOAK", "6"))
+
+
+def _rel(a, b):
+    c, s = np.cos(a[2]), np.sin(a[2])
+    d = b[:2] - a[:2]
+    return np.array([c * d[0] + s * d[1], -s * d[0] + c * d[1], b[2] - a[2]])
+
+
+def _cmp_cells(got, exp):
+    assert got.shape[0] == exp.shape[0]
+    np.testing.assert_array_equal(got["nsamples"], exp["nsamples"])
+    np.testing.assert_allclose(got["mean"], exp["mean"], rtol=0, atol=1e-9)
+    np.testing.assert_allclose(got["cov"], exp["cov"], rtol=1e-9, atol=1e-10)
+    np.testing.assert_allclose(got["scale"], exp["scale"], rtol=1e-8)
+
+
+def test_random_scenes_through_the_whole_path():
+    from oracle import pyoracle as O
+    from tbv_slam_public_amd import api, synth
+    from tbv_slam_public_amd import _lib as L
+    rng = np.random.default_rng(20260929)
+    combos = [("P2L", "Huber", 0), ("P2P", "Huber", 4), ("P2D", "Huber", 0), ("P2L", "Cauchy", 4), ("P2P", "None", 1),
+              ("P2L", "Tukey", 2), ("P2P", "SoftLOne", 3), ("P2L", "Combined", 0)]
+    jobs_by_combo = {c: [] for c in combos}
+    n_filter = n_cells = 0
+    for q in range(N_SCENES):
+        seed = 500000 + q
+        kind = int(rng.integers(0, 3))
+        nf = 5
+        if kind == 0:
+            imgs, gt, _ = synth.scene_v1(seed, nf)
+        elif kind == 1:
+            imgs, gt, _ = synth.scene_dense(seed, nf)
+        else:
+            sc = synth.Scene(seed, circle_frames=64)
+            imgs = synth.render_frames_torch(sc, list(range(nf)), "cpu").numpy()
+            gt = np.stack([sc.pose_at(f, nf) for f in range(nf)])
+        k = int(rng.choice([8, 12, 20, 40]))
+        z_min = int(rng.choice([55, 60, 70, 90]))
+        radius = float(rng.choice([2.5, 3.0, 3.5]))
+        wi = bool(rng.integers(0, 2))
+        # filter: the GPU's lists and clouds are the oracle's, bit for bit
+        r = api.filter_kstrongest(np.ascontiguousarray(imgs[:nf]), k, z_min, 0.0438, 2.5, want_peaks=False)
+        cells_o, maps = [], []
+        for f in range(nf):
+            sr, si, scn = O.kstrongest(imgs[f], k, z_min)
+            cloud = O.kstrongest_cloud(sr, si, scn, 0.0438, 2.5)
+            np.testing.assert_array_equal(r["sel_count"][f], scn)
+            np.testing.assert_array_equal(r["sel_range"][f], sr)
+            assert r["n_points"][f] == cloud.shape[0]
+            np.testing.assert_array_equal(r["xyzi"][f, :cloud.shape[0]], cloud)
+            n_filter += 1
+            exp = O.surface_points(cloud, radius, 1.0, (0, 0), wi)
+            m = api.MapPointNormal(cloud, radius, (0.0, 0.0), wi)
+            _cmp_cells(m.GetCells(), exp)
+            n_cells += exp.shape[0]
+            # the registration below runs both sides on the ORACLE's cells: a 1e-9 difference in a mean must not decide a tie
+            cells_o.append(exp)
+            maps.append(api.MapPointNormal(cells=exp))
+        if min(len(c) for c in cells_o) < 12:
+            continue
+        for rep in range(6):
+            combo = combos[int(rng.integers(0, len(combos)))]
+            n = int(rng.integers(2, nf + 1))
+            idx = sorted(rng.choice(nf, size=n, replace=False).tolist())
+            T = np.array([_rel(gt[idx[0]], gt[i]) for i in idx], dtype=np.float64)
+            T[-1] += np.concatenate([rng.normal(0, 0.5, 2), rng.normal(0, 0.02, 1)])
+            jobs_by_combo[combo].append(([maps[i] for i in idx], [cells_o[i] for i in idx], T))
+    n_reg = 0
+    for (cost, loss, opt), jobs in jobs_by_combo.items():
+        if not jobs:
+            continue
+        reg = api.n_scan_normal_reg(cost, loss, 0.1, opt)
+        opar = O.reg_params(cost=reg.par.cost, loss=reg.par.loss, loss_limit=reg.par.loss_limit, weight_opt=reg.par.weight_opt,
+                            max_outer=reg.par.max_itr_association, max_inner=reg.par.max_itr_solver, min_outer=reg.par.min_itr,
+                            radius=reg.par.radius, cov_scale=reg.par.cov_scale, regularization=reg.par.regularization,
+                            first_itr=reg.par.itr)
+        expect = [O.register(c, T, opar) for _, c, T in jobs]
+        # GetCost at the start poses (n_scan_normal.cpp:186-211), one launch
+        costs = reg.GetCostBatch([(m, T) for m, _, T in jobs])
+        for rec, (_, c, T) in zip(costs, jobs):
+            ok_c, cost_o, res_o, score_o = O.get_cost(c, T, opar)
+            assert (rec["status"] == 0) == ok_c and rec["num_residuals"] == len(res_o), (cost, loss, opt, [len(x) for x in c])
+            np.testing.assert_allclose(rec["final_cost"], cost_o, rtol=1e-9, atol=1e-12)
+        try:
+            for waves, kb in ((0, 0), (4, 40)):
+                reg.ctx.set_option(L.OPT_MATCHER_WAVES, waves); reg.ctx.set_option(L.OPT_MATCHER_LDS_KB, kb)
+                out = reg.RegisterBatch([(m, T) for m, _, T in jobs])
+                for rec, (ok_o, po, ro), (_, c, T) in zip(out, expect, jobs):
+                    tag = (cost, loss, opt, waves, [len(x) for x in c], T[-1].tolist())
+                    assert (rec["status"] == 0) == ok_o, tag
+                    assert (rec["outer_iters"], rec["lm_iters"], rec["num_residuals"]) == (ro.outer_iters, ro.lm_iters, ro.num_residuals), tag
+                    if ok_o:
+                        assert np.abs(rec["pose"][:2] - po[-1, :2]).max() <= POS_TOL and abs(rec["pose"][2] - po[-1, 2]) <= ROT_TOL, tag
+                        np.testing.assert_allclose(rec["final_cost"], ro.final_cost, rtol=1e-9, atol=1e-12)
+                    n_reg += 1
+        finally:
+            reg.ctx.set_option(L.OPT_MATCHER_WAVES, 0); reg.ctx.set_option(L.OPT_MATCHER_LDS_KB, 0)
+    print("soak: %d scenes, %d sweeps filtered, %d cells, %d registrations compared" % (N_SCENES, n_filter, n_cells, n_reg))
+    assert n_reg >= 2 * N_SCENES
+
+
+def test_random_pipeline_configurations_keep_per_frame_parity():
+    """The batched odometry (polar sweeps in, poses out) on random presets: cost, loss, weights, window size, voxel size, k and
+    the input route drawn at random, four fresh streams each, every frame of every stream against the oracle's fuser."""
+    from test_gpu_odometry import _run
+    rng = np.random.default_rng(7)
+    n_cfg = max(2, N_SCENES // 3)
+    for q in range(n_cfg):
+        par = dict(reg_cost=int(rng.choice([0, 1])), reg_loss=int(rng.choice([1, 2])), reg_weight_opt=int(rng.choice([0, 4])),
+                   submap_scan_size=int(rng.choice([1, 3, 4, 5])), res=float(rng.choice([3.0, 3.5])),
+                   kstrong_k_strongest=int(rng.choice([12, 40])), weight_intensity=int(rng.integers(0, 2)))
+        seeds = [600000 + 4 * q + j for j in range(4)]
+        od = _run(seeds, 7, bool(rng.integers(0, 2)), par=par)
+        od.close()
+
+
+def test_random_coral_batches():
+    """CorAl alignment quality (AlignmentQuality.cpp:8-230) of random scan pairs under random offsets, radii and weighting, as
+    batches: {joint, sep, overlap}, the validity flag and the valid-point count against the oracle."""
+    from oracle import pyoracle as O
+    from tbv_slam_public_amd import api, synth
+    rng = np.random.default_rng(11)
+    total = 0
+    for q in range(max(2, N_SCENES // 3)):
+        imgs, gt, _ = synth.scene_v1(700000 + q, 3)
+        k = int(rng.choice([12, 40]))
+        clouds = []
+        for f in range(3):
+            sr, si, scn = O.kstrongest(imgs[f], k, 60)
+            clouds.append(O.kstrongest_cloud(sr, si, scn, 0.0438, 2.5, mask=O.peaks(imgs[f], k, sr, scn)))
+        radius = float(rng.choice([0.6, 1.0, 1.5]))
+        weight = bool(rng.integers(0, 2))
+        jobs = []
+        for a, b in [(0, 1), (0, 2), (1, 2)]:
+            for _ in range(3):
+                scale = rng.choice([0.05, 0.5, 2.0])
+                jobs.append((clouds[a], gt[a], clouds[b], gt[b], rng.normal(0, [scale, scale, 0.03 * scale])))
+        out, _ = api.coral_quality_batch(jobs, radius, weight)
+        for (rc, rp, sc, sp, off), r in zip(jobs, out):
+            ok, eq, pp = O.coral_quality(rc, sc, rp, sp, off, radius, weight)
+            np.testing.assert_allclose([r["joint"], r["sep"], r["overlap"]], eq, rtol=1e-8, atol=1e-12)
+            assert bool(r["valid"]) == ok and r["count_valid"] == int((pp[:, 2] > 0).sum())
+            total += 1
+    print("soak: %d CorAl jobs compared" % total)
