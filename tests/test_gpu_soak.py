@@ -4,7 +4,9 @@ Every other GPU test pins a handful of seeds per feature; this one draws scenes,
 combinations, window sizes and start poses at random and pushes them through filter -> surface points -> registration, the
 registrations as ONE batch per parameter set so that the batch-size dependent forms of the matcher all see them (and once
 more through the regular 4-wavefront form, which only batches of thousands reach by themselves).  The oracle judges every
-record.  CFEAR_SOAK=<n> sets the number of scenes (default 6: ~20 s; profiles/r05/soak.txt holds a run with 200)."""
+record.  Further down: the batched odometry on random presets, CorAl, covariance by cost sampling, Scan Context and the CA-CFAR
+pipeline, the same way.  CFEAR_SOAK=<n> sets the number of scenes (default 6: a few seconds; profiles/r05/soak.txt holds a run
+with 480: 5 736 registrations, 160 pipeline configurations x 4 streams x 7 frames, 1 440 CorAl jobs, ...)."""
 import os
 
 import numpy as np
@@ -159,3 +161,106 @@ def test_random_coral_batches():
             assert bool(r["valid"]) == ok and r["count_valid"] == int((pp[:, 2] > 0).sum())
             total += 1
     print("soak: %d CorAl jobs compared" % total)
+
+
+def test_random_covariances_by_cost_sampling():
+    """approximateCovarianceBySampling (odometrykeyframefuser.cpp:261-380) behind random registrations: the sample grid exact,
+    the sample costs to 1e-10, the fitted covariance and its success flag as the oracle's."""
+    from oracle import pyoracle as O
+    from tbv_slam_public_amd import api, synth
+    from test_gpu_register import _oracle_par
+    rng = np.random.default_rng(13)
+    done = 0
+    for q in range(max(2, N_SCENES // 3)):
+        imgs, gt, _ = synth.scene_v1(800000 + q, 4)
+        cells = []
+        for f in range(4):
+            sr, si, scn = O.kstrongest(imgs[f], 12, 60)
+            cells.append(O.surface_points(O.kstrongest_cloud(sr, si, scn, 0.0438, 2.5), 3.0, 1.0, (0, 0), True))
+        cost, loss, opt = [("P2P", "Huber", 4), ("P2L", "Huber", 0), ("P2D", "Huber", 0), ("P2L", "Cauchy", 4)][int(rng.integers(0, 4))]
+        n_scans = int(rng.integers(2, 5))
+        idx = sorted(rng.choice(4, size=n_scans, replace=False).tolist())
+        poses = np.array([_rel(gt[idx[0]], gt[i]) for i in idx])
+        poses[-1] += rng.normal(0, [0.3, 0.3, 0.01])
+        reg = api.n_scan_normal_reg(cost, loss, 0.1, opt)
+        scans = [api.MapPointNormal(cells=cells[i]) for i in idx]
+        ok, pg, _ = reg.Register(scans, poses)
+        if not ok:
+            continue
+        res = reg.summary_
+        n = int(rng.choice([2, 3, 4]))
+        sp = reg.sampling_params(samples_per_axis=n)
+        got_ok, cov, smp = reg.approximateCovarianceBySampling(scans, pg, sampling=sp, want_samples=True)
+        exp_ok, exp_cov, exp_smp = O.cov_by_sampling([cells[i] for i in idx], pg, _oracle_par(reg), res.final_cost, res.num_residuals,
+                                                     sp.xy_range, sp.yaw_range, n, sp.covariance_scaler)
+        np.testing.assert_array_equal(smp[:, :3], exp_smp[:, :3])
+        np.testing.assert_allclose(smp[:, 3], exp_smp[:, 3], rtol=1e-10)
+        assert got_ok == exp_ok
+        if exp_ok:
+            sel = np.ix_([0, 1, 5], [0, 1, 5])
+            np.testing.assert_allclose(cov[sel], exp_cov[sel], rtol=1e-4, atol=1e-14)
+        done += 1
+    print("soak: %d sampled covariances compared" % done)
+    assert done >= 1
+
+
+def test_random_scan_context_descriptors_and_distances():
+    """Radar Scan Context (RadarScancontext.cpp) on random peak clouds: descriptors (a few edge bins may differ, see
+    test_gpu_scancontext.py), and the column-shift distance of random pairs, bit for bit."""
+    from oracle import pyoracle as O
+    from tbv_slam_public_amd import api, synth
+    rng = np.random.default_rng(17)
+    n_pairs = 0
+    for q in range(max(2, N_SCENES // 3)):
+        imgs, _, _ = synth.scene_v1(900000 + q, 4)
+        k = int(rng.choice([12, 40]))
+        clouds = []
+        for f in range(4):
+            sr, si, scn = O.kstrongest(imgs[f], k, 60)
+            clouds.append(O.kstrongest_cloud(sr, si, scn, 0.0438, 2.5, mask=O.peaks(imgs[f], k, sr, scn)))
+        fn, div = [("sum", 1000.0), ("max", 1.0), ("sum", 1.0)][int(rng.integers(0, 3))]
+        par = api.sc_params(desc_function=fn, desc_divider=div)
+        desc = api.sc_descriptors(clouds, par)[0][:, 0]
+        for i, c in enumerate(clouds):
+            assert (desc[i] != O.sc_descriptor(c, 40, 120, 80.0, fn, div, 0.0, 0.0)).sum() <= 4
+        cand = np.concatenate([desc, np.stack([np.roll(desc[j], -int(rng.integers(1, 120)), axis=1) for j in range(2)])])
+        pairs = [(int(rng.integers(0, 4)), int(rng.integers(0, cand.shape[0]))) for _ in range(12)]
+        dist, shift = api.sc_distance_batch(desc, cand, pairs)
+        for (a, b), d, s in zip(pairs, dist, shift):
+            ed, es = O.sc_distance(desc[a], cand[b])
+            assert s == es and d == ed, (q, a, b, d, ed, s, es)
+            n_pairs += 1
+    print("soak: %d Scan Context distances compared" % n_pairs)
+
+
+def test_random_cacfar_pipelines():
+    """The CA-CFAR odometry (cfar.cpp:35-83 in front of the same fuser) with random window / guard / false-alarm settings on
+    random 0.175 m worlds, [range bins][azimuths] input (the fused decode) against the pre-rotated route, and the pre-rotated
+    route's point counts, cells and poses against the oracle."""
+    from oracle import pyoracle as O
+    from tbv_slam_public_amd import api, synth
+    rng = np.random.default_rng(19)
+    for q in range(max(1, N_SCENES // 6)):
+        imgs = synth.scene_v1(950000 + q, 4, range_res=0.175, ccw=True, n_walls=int(rng.choice([40, 120])), noise_scale=float(rng.choice([4.0, 7.0])))[0]
+        win, guard = int(rng.choice([24, 40])), int(rng.choice([4, 10]))
+        pfa, zmin = float(rng.choice([0.01, 0.003])), float(rng.choice([20.0, 35.0]))
+        kw = dict(filter_type=1, cacfar_range_res=0.175, cacfar_z_min=zmin, cacfar_nb_guard_cells=guard, cacfar_window_size=win,
+                  cacfar_false_alarm_rate=pfa, radar_ccw=1, kstrong_range_res=0.175)
+        reps = 16                                                    # (the fused decode starts at 16 streams)
+        plain = api.OdometryKeyframeFuser(reps, 400, 3360, api.odometry_params(**kw))
+        rot = api.OdometryKeyframeFuser(reps, 3360, 400, api.odometry_params(rotate_ccw=1, **kw))
+        par = plain.par if hasattr(plain, "par") else api.odometry_params(**kw)
+        fz = O.Fuser(O.reg_params(cost=par.reg.cost, loss=par.reg.loss, loss_limit=0.1, weight_opt=par.reg.weight_opt, regularization=0.0),
+                     res=par.res, submap_scan_size=par.submap_scan_size, weight_intensity=bool(par.weight_intensity), radar_ccw=True)
+        for f in range(4):
+            batch = np.ascontiguousarray(np.broadcast_to(imgs[f], (reps, 400, 3360)))
+            a = plain.process(batch)
+            c = rot.process(np.ascontiguousarray(np.rot90(batch, -1, axes=(1, 2))))
+            for name in a.dtype.names:
+                np.testing.assert_array_equal(a[name], c[name], err_msg="rotated " + name)
+            cloud, _ = O.cacfar(imgs[f], win, guard, pfa, 0.175, zmin, 2.5)
+            pose, info = fz.process(cloud)
+            assert (a["n_points"] == cloud.shape[0]).all() and (a["n_cells"] == info[0]).all(), (q, f)
+            d = np.abs(a["pose"] - pose)
+            assert d[:, :2].max() <= POS_TOL and d[:, 2].max() <= ROT_TOL, (q, f, d.max(axis=0))
+        plain.close(); rot.close()
