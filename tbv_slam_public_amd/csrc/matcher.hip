@@ -810,23 +810,39 @@ __device__ void eval_all(const MatchCommon& cm, const Dense& dn, const double x[
   for (int k = 0; k < 10; k++) acc[k] = 0.0;
   const size_t cap = (size_t)dn.cap, gcap = dn.gcap;
   REG_T0();
-  for (int i = threadIdx.x; i < dn.n; i += NT) {
-    double tmx, tmy, w, a0 = 0.0, a1 = 0.0, a2 = 0.0;
-    int si;
-    if (i < (int)cap) {
-      si = (int)dn.sidx[i];
-      tmx = dn.p[i]; tmy = dn.p[cap + i]; w = dn.p[2 * cap + i];
-      if (COST != CFEAR_P2P) { a0 = dn.p[3 * cap + i]; a1 = dn.p[4 * cap + i]; }
-      if (COST == CFEAR_P2D) a2 = dn.p[5 * cap + i];
-    } else {
-      const size_t g = (size_t)i - cap;
-      si = gload<int>(dn.gsidx + g);
-      tmx = gload<double>(dn.gp + g); tmy = gload<double>(dn.gp + gcap + g); w = gload<double>(dn.gp + 2 * gcap + g);
-      if (COST != CFEAR_P2P) { a0 = gload<double>(dn.gp + 3 * gcap + g); a1 = gload<double>(dn.gp + 4 * gcap + g); }
-      if (COST == CFEAR_P2D) a2 = gload<double>(dn.gp + 5 * gcap + g);
-    }
+  // entries [0, cap) from LDS, the rest from the job's global scratch: a thread meets its LDS entries first (i grows), so two
+  // loops add in the same order as one -- and the LDS loop, the hot one, carries no address-space branch.  The tail's loads
+  // are independent of the arithmetic: kTailU entries per thread are requested before the first one is used.
+  const int n_lds = min(dn.n, (int)cap);
+  for (int i = threadIdx.x; i < n_lds; i += NT) {
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0;
+    const int si = (int)dn.sidx[i];
+    const double tmx = dn.p[i], tmy = dn.p[cap + i], w = dn.p[2 * cap + i];
+    if (COST != CFEAR_P2P) { a0 = dn.p[3 * cap + i]; a1 = dn.p[4 * cap + i]; }
+    if (COST == CFEAR_P2D) a2 = dn.p[5 * cap + i];
     const double2 sm = dn.smean[si];
     eval_slot<COST, LOSS, true>(cm.par, sm.x, sm.y, tmx, tmy, a0, a1, a2, w, x[0], x[1], c, s, acc);
+  }
+  constexpr int kTailU = COST == CFEAR_P2P ? 4 : 2;
+  const int n_tail = dn.n - n_lds;
+  for (int g0 = threadIdx.x; g0 < n_tail; g0 += kTailU * NT) {
+    int si[kTailU];
+    double tmx[kTailU], tmy[kTailU], w[kTailU], a0[kTailU], a1[kTailU], a2[kTailU];
+#pragma unroll
+    for (int u = 0; u < kTailU; u++) {
+      const size_t g = (size_t)min(g0 + u * NT, n_tail - 1);
+      si[u] = gload<int>(dn.gsidx + g);
+      tmx[u] = gload<double>(dn.gp + g); tmy[u] = gload<double>(dn.gp + gcap + g); w[u] = gload<double>(dn.gp + 2 * gcap + g);
+      a0[u] = a1[u] = a2[u] = 0.0;
+      if (COST != CFEAR_P2P) { a0[u] = gload<double>(dn.gp + 3 * gcap + g); a1[u] = gload<double>(dn.gp + 4 * gcap + g); }
+      if (COST == CFEAR_P2D) a2[u] = gload<double>(dn.gp + 5 * gcap + g);
+    }
+#pragma unroll
+    for (int u = 0; u < kTailU; u++)
+      if (g0 + u * NT < n_tail) {
+        const double2 sm = dn.smean[si[u]];
+        eval_slot<COST, LOSS, true>(cm.par, sm.x, sm.y, tmx[u], tmy[u], a0[u], a1[u], a2[u], w[u], x[0], x[1], c, s, acc);
+      }
   }
   REG_TACC(4);
   block_reduce10<NT / 64>(acc, part);
