@@ -562,7 +562,9 @@ __device__ __forceinline__ void mt_restage(const MtLds& f, int i0, int i1) {
 // the region is aliased, overwrite the staged tables) and returns the number of blocks.  SLOTS = true (the cost object):
 // writes every pair's terms to the slot arrays `sl` instead (no compaction) and returns this thread's accepted pairs.
 // `staged`: the tables of every keyframe are already in the region (resident layout, an earlier pass of this registration).
-template <int NT, bool SLOTS>
+// COST: the cost function when the caller is compiled for one (the gather then carries no per-pair switches, no covariance
+// register and an unrolled store of its fields), -1: read from cm.par (the cost object).
+template <int NT, bool SLOTS, int COST = -1>
 __device__ int mt_associate(const RegJob& job, const MatchCommon& cm, int itr, const MtLds& f, const double* xsrc, double* gl_dense,
                             Dense& dn, int* ipart, int& iphase, bool& staged, const Slots* sl = nullptr) {
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -574,6 +576,7 @@ __device__ int mt_associate(const RegJob& job, const MatchCommon& cm, int itr, c
   const float rwin = (float)curr_radius + 1e-3f;
   constexpr int G = kScanGrid;
   constexpr bool GM = NT >= 512;                           // the global match table exists in the large forms only (mt_fit)
+  auto cost_is = [&](const int v) { return COST >= 0 ? COST == v : cm.par.cost == v; };
   REG_T0();
   // Tsrctotar_i = Ttar_i^-1 * Tsrc  (:222), on the last wavefront, ahead of the first group's table loads.  The
   // rotation of the source pose by the polynomial sincos the LM loop uses for its evaluation points (an ulp or two from libm,
@@ -730,7 +733,7 @@ __device__ int mt_associate(const RegJob& job, const MatchCommon& cm, int itr, c
         g.ns = gload_d2(srcv.normal + s);
         g.sns = gload<int>(srcv.nsamples + s);
         g.ssc = gload<double>(srcv.scale + s);
-        if (cm.par.cost == CFEAR_P2D) g.S = gload_d4((const double4*)tp[4] + g.best);
+        if (cost_is(CFEAR_P2D)) g.S = gload_d4((const double4*)tp[4] + g.best);
       }
       return g;
     };
@@ -757,7 +760,7 @@ __device__ int mt_associate(const RegJob& job, const MatchCommon& cm, int itr, c
         e[0] = K[0] * tm.x + K[1] * tm.y + K[4];                                  // Ttar * tar_mean
         e[1] = K[2] * tm.x + K[3] * tm.y + K[5];
         e[2] = w; e[3] = 0.0; e[4] = 0.0; e[5] = 0.0;
-        if (cm.par.cost == CFEAR_P2D) {                                           // :288-297
+        if (cost_is(CFEAR_P2D)) {                                                 // :288-297
           const double4 S = cur.S;
           const double a00 = K[0] * S.x + K[1] * S.z, a01 = K[0] * S.y + K[1] * S.w;
           const double a10 = K[2] * S.x + K[3] * S.z, a11 = K[2] * S.y + K[3] * S.w;
@@ -769,7 +772,7 @@ __device__ int mt_associate(const RegJob& job, const MatchCommon& cm, int itr, c
           const double i00 = c11 * invdet, i10 = -c10 * invdet, i11 = c00 * invdet;
           const double l00 = sqrt(i00), l10 = i10 / l00;
           e[3] = l00; e[4] = l10; e[5] = sqrt(i11 - l10 * l10);
-        } else if (cm.par.cost == CFEAR_P2L) {
+        } else if (cost_is(CFEAR_P2L)) {
           e[3] = K[0] * nt.x + K[1] * nt.y;                                       // Ttar.linear() * tar_normal
           e[4] = K[2] * nt.x + K[3] * nt.y;
         }
@@ -778,14 +781,16 @@ __device__ int mt_associate(const RegJob& job, const MatchCommon& cm, int itr, c
           sl->tmx[pp] = e[0]; sl->tmy[pp] = e[1]; sl->w[pp] = e[2]; sl->a0[pp] = e[3]; sl->a1[pp] = e[4]; sl->a2[pp] = e[5];
           sl->tidx[pp] = cur.best;
         } else {
-          const int nf = cm.dense_fields;
+          const int nf = COST == CFEAR_P2P ? 3 : (COST == CFEAR_P2L ? 5 : (COST == CFEAR_P2D ? 6 : cm.dense_fields));
           if (c < (int)cap) {
             dn.sidx[c] = (unsigned short)cur.s;
-            for (int k = 0; k < nf; k++) dn.p[k * cap + c] = e[k];
+#pragma unroll
+            for (int k = 0; k < 6; k++) if (k < nf) dn.p[k * cap + c] = e[k];
           } else {
             const size_t g = (size_t)c - cap;
             gstore<int>(dn.gsidx + g, cur.s);
-            for (int k = 0; k < nf; k++) gstore<double>(dn.gp + k * gcap + g, e[k]);
+#pragma unroll
+            for (int k = 0; k < 6; k++) if (k < nf) gstore<double>(dn.gp + k * gcap + g, e[k]);
           }
         }
         c++;
@@ -1127,7 +1132,7 @@ __global__ __launch_bounds__(NW * 64, WIDE ? 2 : ((NW == 4 && LOSS < 0) ? 3 : 4)
       }
       __syncthreads();
     } else if (itr > cm.par.max_itr_association || !success) break;
-    const int n_blocks = mt_associate<NT, false>(job, cm, a_itr, fl, st + S_OUTER, gl_dense, dn, ipart, iphase, staged);
+    const int n_blocks = mt_associate<NT, false, COST>(job, cm, a_itr, fl, st + S_OUTER, gl_dense, dn, ipart, iphase, staged);
     num_residuals = n_blocks * rpb;
     success = num_residuals > 1;                                  // :368-369
     if (!success && !CO) { fail_status = CFEAR_ERR_TOO_FEW_RESIDUALS; break; }
