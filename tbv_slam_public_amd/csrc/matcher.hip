@@ -577,6 +577,15 @@ __device__ int mt_associate(const RegJob& job, const MatchCommon& cm, int itr, c
   constexpr int G = kScanGrid;
   constexpr bool GM = NT >= 512;                           // the global match table exists in the large forms only (mt_fit)
   auto cost_is = [&](const int v) { return COST >= 0 ? COST == v : cm.par.cost == v; };
+  // pair p = keyframe i, source cell s: p / n_src by a multiplication (floor(2^32 / n_src) or one less: the quotient is exact
+  // or one short for p < 2^20, one correction) -- the running (i, s) pair it replaces cost a divergent loop per pair
+  const unsigned magic = n_src ? 0xFFFFFFFFu / (unsigned)n_src : 0u;
+  auto split = [&](const int p, int& i, int& s) {
+    unsigned q = __umulhi((unsigned)p, magic);
+    int r = p - (int)q * n_src;
+    if (r >= n_src) { q++; r -= n_src; }
+    i = (int)q; s = r;
+  };
   REG_T0();
   // Tsrctotar_i = Ttar_i^-1 * Tsrc  (:222), on the last wavefront, ahead of the first group's table loads.  The
   // rotation of the source pose by the polynomial sincos the LM loop uses for its evaluation points (an ulp or two from libm,
@@ -628,9 +637,9 @@ __device__ int mt_associate(const RegJob& job, const MatchCommon& cm, int itr, c
     // this thread's pairs p = tid + NT k (the SAME pairs in every group layout and in pass 2) that fall into the group
     const int lo = i0 * n_src, hi = i1 * n_src;
     int p = lo + ((tid - lo) & (NT - 1));
-    int i = i0, s = p - lo;
-    while (s >= n_src && i < i1) { s -= n_src; i++; }
     for (; p < hi; p += NT) {
+      int i, s;
+      split(p, i, s);
       const double* T = f.kf + i * 12 + 6;
       const double2 u = f.smean[s];
       const double px = T[0] * u.x + T[1] * u.y + T[4];
@@ -678,8 +687,6 @@ __device__ int mt_associate(const RegJob& job, const MatchCommon& cm, int itr, c
         pend_ns = gload_d2(job.scans[last].normal + s);
         pend_nt = gload_d2((const double2*)f.tptr[i * kPtrs + 1] + best);
       }
-      s += NT;
-      while (s >= n_src && i < i1) { s -= n_src; i++; }
     }
     gate_pending();
     pend_p = -1;
@@ -737,13 +744,12 @@ __device__ int mt_associate(const RegJob& job, const MatchCommon& cm, int itr, c
       }
       return g;
     };
-    int c = base, i = 0, s = tid;
-    while (s >= n_src && i < last) { s -= n_src; i++; }
+    int c = base, i, s;
+    split(tid, i, s);
     int m_next = GM ? match_at(tid + NT) : 0;             // the match two rounds ahead is in flight (global table: an L2 round trip)
     Gathered cur = gather(match_at(tid), i, s);
     for (int p = tid; p < n_pairs; p += NT) {
-      s += NT;
-      while (s >= n_src && i < last) { s -= n_src; i++; }
+      split(p + NT, i, s);                                // (beyond the last pair: no match, nothing is read through it)
       int m_use;
       if (GM) { m_use = m_next; m_next = match_at(p + 2 * NT); }
       else m_use = match_at(p + NT);
