@@ -77,4 +77,12 @@ __device__ __forceinline__ double sqrt_newton(const double a) {
   return fma(fma(-s, s, a), h, s);
 }
 
+// 1 / sqrt(a) for a normal, finite a > 0: the device library's own refinement of v_rsq_f64 (one coupled step,
+// y0 + y0 e (1/2 + 3/8 e), e = 1 - a y0^2 -- the same bits) without its class test for zero / infinity / NaN.
+__device__ __forceinline__ double rsqrt_newton(const double a) {
+  const double y0 = __builtin_amdgcn_rsq(a);
+  const double e = fma(y0 * -a, y0, 1.0);
+  return fma(y0 * e, fma(e, 0.375, 0.5), y0);
+}
+
 }  // namespace

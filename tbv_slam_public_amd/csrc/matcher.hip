@@ -142,7 +142,7 @@ __device__ __forceinline__ void loss_eval(int loss, double a, double w, double s
       if (s > b) {
         // one reciprocal square root instead of sqrt + divide (r = s * rsqrt(s), a / r = a * rsqrt(s));
         // agrees with ceres::HuberLoss to rounding
-        const double q = rsqrt(s);
+        const double q = rsqrt_newton(s);                  // (s > b > 0, finite)
         rho0 = 2.0 * a * (s * q) - b; rho1 = fmax(dmin, a * q);
       } else { rho0 = s; rho1 = 1.0; }
       break;
@@ -365,8 +365,9 @@ __device__ __forceinline__ void eval_slot(const cfear_reg_params& par, double sm
     acc[1] -= g0; acc[2] -= g1;
     acc[3] = fma(j02, g0, acc[3]); acc[3] = fma(j12, g1, acc[3]);
     const double h02 = rho1 * j02, h12 = rho1 * j12;
+    // (H11 = H00 = the sum of rho': acc[7] is filled from acc[4] by the caller, p2p_mirror())
     acc[4] += rho1; acc[6] = fma(-rho1, j02, acc[6]); acc[9] = fma(h02, j02, acc[9]);
-    acc[7] += rho1; acc[8] = fma(-rho1, j12, acc[8]); acc[9] = fma(h12, j12, acc[9]);
+    acc[8] = fma(-rho1, j12, acc[8]); acc[9] = fma(h12, j12, acc[9]);
   } else if (WITH_JAC) {
     // Corrector with alpha = 0 scales residual and Jacobian rows by sqrt(rho'); the normal equations
     // only need the products, (sqrt(rho') J)^T (sqrt(rho') r) = rho' J^T r, so no square root here.
@@ -855,6 +856,7 @@ __device__ void eval_all(const MatchCommon& cm, const Dense& dn, const double x[
         eval_slot<COST, LOSS, true>(cm.par, sm.x, sm.y, tmx[u], tmy[u], a0[u], a1[u], a2[u], w[u], x[0], x[1], c, s, acc);
       }
   }
+  if (COST == CFEAR_P2P) acc[7] = acc[4];                  // H11 = H00 (eval_slot)
   REG_TACC(4);
   block_reduce10<NT / 64>(acc, part);
   REG_TACC(5);
@@ -1299,6 +1301,7 @@ __global__ __launch_bounds__(256) void eval_kernel(const RegJob* __restrict__ jo
     if (o.raw_j) for (int k = 0; k < 6; k++) o.raw_j[slot * 6 + k] = j[k];
     if (o.rob_r) { o.rob_r[slot * 2] = r0 * sr; o.rob_r[slot * 2 + 1] = r1 * sr; }
   }
+  if (cm.par.cost == CFEAR_P2P) acc[7] = acc[4];           // H11 = H00 (eval_slot)
   block_reduce10<4>(acc, part);
   if (threadIdx.x == 0 && o.neq) for (int k = 0; k < 10; k++) o.neq[k] = acc[k];
 }
