@@ -325,6 +325,53 @@ __device__ __forceinline__ void block_reduce10(double v[10], double* buf /*[10][
   }
 }
 
+// The same for the P2P blocks, whose Gauss-Newton matrix has H01 = 0 and H11 = H00 exactly (eval_slot): eight sums -- v[5] and
+// v[7] are not read; wavefront 0 receives all ten (v[5] = 0, v[7] = v[4]).  8 -> 4 -> 2 live values, then two plain steps.
+template <int NW>
+__device__ __forceinline__ void block_reduce8_p2p(double v[10], double* buf /*[8][4 NW]*/) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  constexpr int S = 4 * NW;
+  const double a[8] = {v[0], v[1], v[2], v[3], v[4], v[6], v[8], v[9]};
+  double v1[4];
+#pragma unroll
+  for (int j = 0; j < 4; j++)
+    v1[j] = dpp_sel_f64<0x140, 0x3>(a[j + 4], a[j]) + dpp_sel_f64<0x140, 0xC>(a[j], a[j + 4]);
+  double w0 = dpp_sel_f64<0x141, 0x5>(v1[1], v1[0]) + dpp_sel_f64<0x141, 0xA>(v1[0], v1[1]);
+  double w1 = dpp_sel_f64<0x141, 0x5>(v1[3], v1[2]) + dpp_sel_f64<0x141, 0xA>(v1[2], v1[3]);
+  w0 += dpp_f64<0x4E>(w0); w1 += dpp_f64<0x4E>(w1);
+  w0 += dpp_f64<0xB1>(w0); w1 += dpp_f64<0xB1>(w1);
+  // the quad with lane bits (b3, b2) holds the row sums of packed value b2 + 4 b3 (w0) and 2 + b2 + 4 b3 (w1)
+  const int row = lane >> 4, b3 = (lane >> 3) & 1, b2 = (lane >> 2) & 1;
+  const int slot = wave * 4 + row;
+  if ((lane & 3) == 0) {
+    buf[(b2 + 4 * b3) * S + slot] = w0;
+    buf[(2 + b2 + 4 * b3) * S + slot] = w1;
+  }
+  __syncthreads();
+  if (wave == 0) {
+    constexpr int NR = (8 * S + 63) / 64;
+    double r[NR];
+#pragma unroll
+    for (int q = 0; q < NR; q++) {
+      const int j = q * 64 + lane;
+      double t = j < 8 * S ? buf[j] : 0.0;
+      t += dpp_f64<0xB1>(t);
+      t += dpp_f64<0x4E>(t);
+      t += dpp_f64<0x141>(t);
+      if (S >= 16) t += dpp_f64<0x140>(t);
+      r[q] = t;
+    }
+    double o[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      if (S <= 16) o[k] = readlane_f64(r[(k * S) / 64], (k * S) % 64);
+      else if (S == 32) o[k] = readlane_f64(r[k / 2], (k % 2) * 32) + readlane_f64(r[k / 2], (k % 2) * 32 + 16);
+      else o[k] = ((readlane_f64(r[k], 0) + readlane_f64(r[k], 16)) + readlane_f64(r[k], 32)) + readlane_f64(r[k], 48);
+    }
+    v[0] = o[0]; v[1] = o[1]; v[2] = o[2]; v[3] = o[3]; v[4] = o[4]; v[5] = 0.0; v[6] = o[5]; v[7] = o[4]; v[8] = o[6]; v[9] = o[7];
+  }
+}
+
 // Residual block of one correspondence at pose x (c = cos th, s = sin th): adds to acc[10].
 // COST / LOSS are compile-time (LOSS = -1: runtime switch) so the hot P2P/P2L + Huber kernels carry no
 // per-correspondence branching and constant Jacobian entries fold away.  The accumulations use fma():
@@ -856,9 +903,9 @@ __device__ void eval_all(const MatchCommon& cm, const Dense& dn, const double x[
         eval_slot<COST, LOSS, true>(cm.par, sm.x, sm.y, tmx[u], tmy[u], a0[u], a1[u], a2[u], w[u], x[0], x[1], c, s, acc);
       }
   }
-  if (COST == CFEAR_P2P) acc[7] = acc[4];                  // H11 = H00 (eval_slot)
   REG_TACC(4);
-  block_reduce10<NT / 64>(acc, part);
+  if (COST == CFEAR_P2P) block_reduce8_p2p<NT / 64>(acc, part);
+  else block_reduce10<NT / 64>(acc, part);
   REG_TACC(5);
 #pragma unroll
   for (int k = 0; k < 10; k++) out[k] = acc[k];
