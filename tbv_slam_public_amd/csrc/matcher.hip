@@ -556,7 +556,7 @@ __device__ __forceinline__ void mt_restage(const MtLds& f, int i0, int i1) {
   const int tid = threadIdx.x;
   const int k_lo = f.koff[i0], NP = f.koff[i1] - k_lo;
   constexpr int kCs = kScanGridStartPad / 8;               // pieces of one cell-start table
-  constexpr int kKf = NT >= 256 ? 4 : 1, kPer = NT >= 256 ? 2 : 512 / NT;   // (kPer * NT >= 512 > kCs: the loop behind it only meets records)
+  constexpr int kKf = NT >= 256 ? 4 : 1, kPer = 2;   // (kPer * NT >= 256 > kCs: the loop behind it only meets records)
   const int xy0 = (i1 - i0) * kCs, ix0 = xy0 + NP / 2;      // first (x, y) piece, first index piece
   uint4* out = (uint4*)f.tables;
   auto dst_of = [&](int i, int j, int rel, int np) {
