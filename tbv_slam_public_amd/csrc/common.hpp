@@ -211,6 +211,17 @@ struct RegCostMode {
   const cfear_reg_result* prior = nullptr;   // device, [n_jobs]: evaluate around prior[j].pose with itr = prior[j].outer_iters
 };
 // What the caller knows about the batch's registrations (the kernel decides per registration from the device-side sizes):
+// cfear_coral_quality_batch in two halves (coral.hip): launch, then read back -- host work of the caller in between
+struct CoralPending {
+  std::vector<char> host_jobs;        // the uploaded job records (pageable: must outlive the copy)
+  void* d_res = nullptr;
+  void* d_pp = nullptr;
+  int n_jobs = 0, cap = 0;
+};
+int cfear_coral_enqueue(cfear_ctx* ctx, const cfear_coral_job* jobs, int32_t n_jobs, const cfear_coral_params* par, bool want_per_point,
+                        CoralPending& pend);
+int cfear_coral_collect(cfear_ctx* ctx, const cfear_coral_job* jobs, const CoralPending& pend, cfear_coral_result* results, double* per_point);
+
 struct RegLaunchHint {
   bool small_pairs = false;   // every job is a two-scan candidate that fits 20 KB of LDS: the 2-wavefront form, eight per CU
   bool big_pass = false;      // registrations the regular form is not good at may be among them (dense scans): add the large forms

@@ -605,12 +605,17 @@ extern "C" void cfear_coral_params_default(cfear_coral_params* p) {
   p->pad = 0;
 }
 
-extern "C" int cfear_coral_quality_batch(cfear_ctx* ctx, const cfear_coral_job* jobs, int32_t n_jobs,
-                                         const cfear_coral_params* par, cfear_coral_result* results, double* per_point) {
+// The batch in two halves, so that a caller with host work of its own (verify.hip) can do it while the kernel runs:
+// cfear_coral_enqueue stages the clouds, uploads the jobs and launches; cfear_coral_collect reads the results back and
+// synchronises.  `pend` carries what must outlive the launch.
+int cfear_coral_enqueue(cfear_ctx* ctx, const cfear_coral_job* jobs, int32_t n_jobs, const cfear_coral_params* par, bool want_per_point,
+                        CoralPending& pend) {
+  pend.n_jobs = 0;
   if (!ctx) return CFEAR_ERR_INVALID_ARGUMENT;
-  if (!jobs || !par || !results || n_jobs < 0) return cfear_set_error(ctx, CFEAR_ERR_INVALID_ARGUMENT, "null argument");
+  if (!jobs || !par || n_jobs < 0) return cfear_set_error(ctx, CFEAR_ERR_INVALID_ARGUMENT, "null argument");
   if (!(par->radius > 0.0)) return cfear_set_error(ctx, CFEAR_ERR_INVALID_ARGUMENT, "radius must be > 0");
   if (n_jobs == 0) return CFEAR_OK;
+  const bool per_point = want_per_point;
   CFEAR_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   // stage host clouds once each (perturbation sets and candidate lists share clouds)
   std::map<const float*, size_t> staged;                 // host pointer -> offset (floats) in the staging buffer
@@ -651,7 +656,8 @@ extern "C" int cfear_coral_quality_batch(cfear_ctx* ctx, const cfear_coral_job* 
       if (len[kv.first] > 0)
         CFEAR_HIP_CHECK(ctx, hipMemcpyAsync(d_stage + kv.second, kv.first, (size_t)len[kv.first] * 16, hipMemcpyHostToDevice, ctx->stream));
   }
-  std::vector<CoralJob> hj(n_jobs);
+  pend.host_jobs.resize((size_t)n_jobs * sizeof(CoralJob));
+  CoralJob* hj = (CoralJob*)pend.host_jobs.data();
   for (int j = 0; j < n_jobs; j++) {
     const cfear_coral_job& jb = jobs[j];
     CoralJob& o = hj[j];
@@ -680,7 +686,7 @@ extern "C" int cfear_coral_quality_batch(cfear_ctx* ctx, const cfear_coral_job* 
   cfear_coral_result* d_res = (cfear_coral_result*)(ws + (jb_bytes + 255) / 256 * 256);
   double* d_pp = per_point ? (double*)((char*)d_res + (rb + 255) / 256 * 256) : nullptr;
   cm.scratch = scr;
-  CFEAR_HIP_CHECK(ctx, hipMemcpyAsync(d_jobs, hj.data(), jb_bytes, hipMemcpyHostToDevice, ctx->stream));
+  CFEAR_HIP_CHECK(ctx, hipMemcpyAsync(d_jobs, hj, jb_bytes, hipMemcpyHostToDevice, ctx->stream));
   { const int rc_lds = cfear_allow_lds(ctx, (const void*)coral_kernel, 160 * 1024); if (rc_lds != CFEAR_OK) return rc_lds; }
   {
     ProfScope ps(ctx, "coral_quality");
@@ -692,6 +698,17 @@ extern "C" int cfear_coral_quality_batch(cfear_ctx* ctx, const cfear_coral_job* 
     }
   }
   CFEAR_HIP_CHECK(ctx, hipGetLastError());
+  pend.n_jobs = n_jobs; pend.cap = cap; pend.d_res = d_res; pend.d_pp = d_pp;
+  return CFEAR_OK;
+}
+
+int cfear_coral_collect(cfear_ctx* ctx, const cfear_coral_job* jobs, const CoralPending& pend, cfear_coral_result* results, double* per_point) {
+  const int n_jobs = pend.n_jobs, cap = pend.cap;
+  if (n_jobs == 0) return CFEAR_OK;
+  const size_t rb = (size_t)n_jobs * sizeof(cfear_coral_result);
+  const size_t pp_bytes = per_point ? (size_t)n_jobs * cap * 3 * sizeof(double) : 0;
+  const cfear_coral_result* d_res = (const cfear_coral_result*)pend.d_res;
+  const double* d_pp = (const double*)pend.d_pp;
   CFEAR_HIP_CHECK(ctx, hipMemcpyAsync(results, d_res, rb, hipMemcpyDeviceToHost, ctx->stream));
   std::vector<double> hpp;
   if (per_point) {
@@ -711,6 +728,16 @@ extern "C" int cfear_coral_quality_batch(cfear_ctx* ctx, const cfear_coral_job* 
     if (results[j].status != CFEAR_OK && results[j].status != CFEAR_ERR_EMPTY_CLOUD)
       return cfear_set_error(ctx, results[j].status, "job %d: %s", j, cfear_status_string(results[j].status));
   return CFEAR_OK;
+}
+
+extern "C" int cfear_coral_quality_batch(cfear_ctx* ctx, const cfear_coral_job* jobs, int32_t n_jobs,
+                                         const cfear_coral_params* par, cfear_coral_result* results, double* per_point) {
+  if (!ctx) return CFEAR_ERR_INVALID_ARGUMENT;
+  if (!results) return cfear_set_error(ctx, CFEAR_ERR_INVALID_ARGUMENT, "null argument");
+  CoralPending pend;
+  const int rc = cfear_coral_enqueue(ctx, jobs, n_jobs, par, per_point != nullptr, pend);
+  if (rc != CFEAR_OK) return rc;
+  return cfear_coral_collect(ctx, jobs, pend, results, per_point);
 }
 
 extern "C" int cfear_coral_quality(cfear_ctx* ctx, const cfear_coral_job* job, const cfear_coral_params* par,

@@ -14,6 +14,7 @@
 // Three device launches for the whole batch; the classifiers are a dozen multiply-adds per candidate on the host,
 // as in the reference.  Training the classifiers (sklearn through pybind11 in the reference,
 // alignmentinterface.cpp:192-222) is not part of the library: coefficients come in through cfear_verify_params.
+#include <chrono>
 #include <algorithm>
 #include <cmath>
 #include <numeric>
@@ -92,6 +93,13 @@ extern "C" int cfear_verify_loop_candidates(cfear_ctx* ctx, const cfear_verify_j
     if (!jobs[j].from_scan || !jobs[j].to_scan)
       return cfear_set_error(ctx, CFEAR_ERR_INVALID_ARGUMENT, "candidate %d: null scan handle", j);
   const size_t n = (size_t)n_jobs;
+#ifdef CFEAR_VERIFY_TIMING
+  auto t_last = std::chrono::steady_clock::now();
+  double t_acc[8] = {0};
+  auto mark = [&](int k) { const auto t = std::chrono::steady_clock::now(); t_acc[k] += std::chrono::duration<double, std::micro>(t - t_last).count(); t_last = t; };
+#else
+  auto mark = [](int) {};
+#endif
 
   // ---- RegisterLoopCandidate: scans {to, from}, poses {Tto = Tfrom * t_be, Tfrom}; P2L, Huber 0.1, uniform
   // weights, SetParameters(4, 10) (loopclosure.cpp:56-57) ------------------------------------------------------
@@ -111,8 +119,10 @@ extern "C" int cfear_verify_loop_candidates(cfear_ctx* ctx, const cfear_verify_j
     rj[j].scans = &handles[2 * j]; rj[j].n_scans = 2; rj[j].pad = 0; rj[j].poses_xyt = &poses[6 * j];
   }
   std::vector<cfear_reg_result> reg(n);
+  mark(0);
   int rc = cfear_register_batch(ctx, rj.data(), n_jobs, &rp, reg.data());
   if (rc != CFEAR_OK) return rc;
+  mark(1);
 
   // covariance: Register's constant, or the sampled one (:62-71)
   std::vector<double> cov(36 * n, 0.0);
@@ -130,35 +140,21 @@ extern "C" int cfear_verify_loop_candidates(cfear_ctx* ctx, const cfear_verify_j
     for (size_t j = 0; j < n; j++) { cov[36 * j] = 0.01; cov[36 * j + 7] = 0.01; cov[36 * j + 35] = 1e-4; }   // n_scan_normal.cpp:171
   }
 
+  // Talign first: the CorAl jobs need nothing else of this block, and their kernel (the longest of a verification step) then
+  // runs while the host rotates the covariances and marshals the cost jobs below
+  std::vector<double> inv_yaw(n, 0.0);
   for (size_t j = 0; j < n; j++) {
     cfear_verify_result& r = results[j];
     r.reg = reg[j];
     r.reg_ok = reg[j].status == CFEAR_OK ? 1 : 0;
     r.cov_sampled = r.reg_ok ? sampled[j] : 0;
-    double* C = r.cov;
     if (r.reg_ok) {                                         // loopclosure.cpp:90-94
       double inv[3];
       xyt_inverse(reg[j].pose, inv);                        // Trevised^-1
       xyt_compose(inv, &poses[6 * j], r.t_be);              // Talign = Trevised^-1 * Tto
-      for (int k = 0; k < 36; k++) C[k] = cov[36 * j + k];
-      // reg_cov.block<3,3>(0,0) = R^-1 * block * R^-T: only the x-y part of the block is touched by a yaw rotation
-      const double c = std::cos(inv[2]), s = std::sin(inv[2]);
-      const double R[9] = {c, -s, 0, s, c, 0, 0, 0, 1};
-      double B[9], T[9];
-      for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) B[a * 3 + b] = C[a * 6 + b];
-      for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) {
-        double t = 0.0;
-        for (int k = 0; k < 3; k++) t += R[a * 3 + k] * B[k * 3 + b];
-        T[a * 3 + b] = t;
-      }
-      for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) {
-        double t = 0.0;
-        for (int k = 0; k < 3; k++) t += T[a * 3 + k] * R[b * 3 + k];
-        C[a * 6 + b] = t;
-      }
-    } else {                                                // Tdiff and Cov keep their initial Identity (:351-353)
+      inv_yaw[j] = inv[2];
+    } else {                                                // Tdiff keeps its initial Identity (:351-353)
       r.t_be[0] = r.t_be[1] = r.t_be[2] = 0.0;
-      for (int k = 0; k < 36; k++) C[k] = (k % 7 == 0) ? 1.0 : 0.0;
     }
   }
 
@@ -173,8 +169,36 @@ extern "C" int cfear_verify_loop_candidates(cfear_ctx* ctx, const cfear_verify_j
     for (int k = 0; k < 3; k++) { c.ref_pose[k] = jobs[j].from_pose[k]; c.src_pose[k] = to_pose[3 * j + k]; c.offset[k] = 0.0; }
   }
   std::vector<cfear_coral_result> coral(n);
-  rc = cfear_coral_quality_batch(ctx, cjobs.data(), n_jobs, &par->coral, coral.data(), nullptr);
+  mark(2);
+  CoralPending pend;
+  rc = cfear_coral_enqueue(ctx, cjobs.data(), n_jobs, &par->coral, false, pend);
   if (rc != CFEAR_OK) return rc;
+  mark(3);
+
+  for (size_t j = 0; j < n; j++) {                          // (the CorAl kernel is running)
+    cfear_verify_result& r = results[j];
+    double* C = r.cov;
+    if (r.reg_ok) {
+      for (int k = 0; k < 36; k++) C[k] = cov[36 * j + k];
+      // reg_cov.block<3,3>(0,0) = R^-1 * block * R^-T: only the x-y part of the block is touched by a yaw rotation
+      const double c = std::cos(inv_yaw[j]), s = std::sin(inv_yaw[j]);
+      const double R[9] = {c, -s, 0, s, c, 0, 0, 0, 1};
+      double B[9], T[9];
+      for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) B[a * 3 + b] = C[a * 6 + b];
+      for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) {
+        double t = 0.0;
+        for (int k = 0; k < 3; k++) t += R[a * 3 + k] * B[k * 3 + b];
+        T[a * 3 + b] = t;
+      }
+      for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) {
+        double t = 0.0;
+        for (int k = 0; k < 3; k++) t += T[a * 3 + k] * R[b * 3 + k];
+        C[a * 6 + b] = t;
+      }
+    } else {                                                // Cov keeps its initial Identity (:351-353)
+      for (int k = 0; k < 36; k++) C[k] = (k % 7 == 0) ? 1.0 : 0.0;
+    }
+  }
 
   cfear_reg_params qp;                                              // n_scan_normal_reg(P2L, Huber, 0.3), fresh: itr_ = 0
   cfear_reg_params_default(&qp);
@@ -191,8 +215,12 @@ extern "C" int cfear_verify_loop_candidates(cfear_ctx* ctx, const cfear_verify_j
     qj[j].scans = &qh[2 * j]; qj[j].n_scans = 2; qj[j].pad = 0; qj[j].poses_xyt = &qposes[6 * j];
   }
   std::vector<cfear_reg_result> q(n);
-  rc = cfear_get_cost_batch(ctx, qj.data(), n_jobs, &qp, q.data());
+  mark(4);
+  rc = cfear_get_cost_batch(ctx, qj.data(), n_jobs, &qp, q.data());   // (same stream: returns after the CorAl kernel too)
+  const int rc_coral = cfear_coral_collect(ctx, cjobs.data(), pend, coral.data(), nullptr);
   if (rc != CFEAR_OK) return rc;
+  if (rc_coral != CFEAR_OK) return rc_coral;
+  mark(5);
 
   for (size_t j = 0; j < n; j++) {
     cfear_verify_result& r = results[j];
@@ -239,5 +267,10 @@ extern "C" int cfear_verify_loop_candidates(cfear_ctx* ctx, const cfear_verify_j
     }
     i = e;
   }
+  mark(6);
+#ifdef CFEAR_VERIFY_TIMING
+  fprintf(stderr, "verify us: marshal reg %.0f | register_batch %.0f | Talign + coral jobs %.0f | coral enqueue %.0f | cov + cost jobs %.0f | get_cost_batch + coral results %.0f | classify + sort %.0f\n",
+          t_acc[0], t_acc[1], t_acc[2], t_acc[3], t_acc[4], t_acc[5], t_acc[6]);
+#endif
   return CFEAR_OK;
 }
