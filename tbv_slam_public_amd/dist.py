@@ -159,12 +159,12 @@ def verify_candidates_sharded(cands, verify_fn, model_threshold=0.8, all_candida
     VERIFY_RESULT_DTYPE array`; fn_selects: verify_fn applies the selection itself with the same threshold / policy
     (api.verify_loop_candidates does), so a single process need not redo it."""
     import torch.distributed as dist
-    groups = [int(c.get("group", 0)) for c in cands]
+    groups_of = lambda: [int(c.get("group", 0)) for c in cands]   # (only the paths that select here walk the list)
     if not (dist.is_available() and dist.is_initialized()):
         out = verify_fn(cands)                                # one rank sees every candidate of every query: a verify_fn
         if fn_selects:                                        # that already ran ApplyConstratins (the library does) is final
             return out
-        return apply_constraints(out, groups, model_threshold, all_candidates)
+        return apply_constraints(out, groups_of(), model_threshold, all_candidates)
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     lo, hi, _per = shard_range(len(cands), world, rank)
     local = verify_fn(cands[lo:hi])
@@ -172,4 +172,4 @@ def verify_candidates_sharded(cands, verify_fn, model_threshold=0.8, all_candida
     out = _gather_records(local, len(cands), group)
     if world == 1 and fn_selects:                             # one rank saw every candidate of every query and has selected
         return out
-    return apply_constraints(out, groups, model_threshold, all_candidates)
+    return apply_constraints(out, groups_of(), model_threshold, all_candidates)
