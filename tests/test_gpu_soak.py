@@ -6,7 +6,7 @@ registrations as ONE batch per parameter set so that the batch-size dependent fo
 more through the regular 4-wavefront form, which only batches of thousands reach by themselves).  The oracle judges every
 record.  Further down: the batched odometry on random presets, CorAl, covariance by cost sampling, Scan Context and the CA-CFAR
 pipeline, the same way.  CFEAR_SOAK=<n> sets the number of scenes (default 6: a few seconds; profiles/r05/soak.txt holds a run
-with 480: 5 736 registrations, 160 pipeline configurations x 4 streams x 7 frames, 1 440 CorAl jobs, ...)."""
+with 2000: 23 892 registrations, 666 pipeline configurations x 4 streams x 7 frames, 5 994 CorAl jobs, ...)."""
 import os
 
 import numpy as np
