@@ -39,6 +39,7 @@ namespace {
 
 #ifdef CFEAR_REG_TIMING   // debug build only: cycle split of workgroup 0, printed at kernel end
 __device__ long long g_reg_t[32];
+__device__ unsigned long long g_reg_sum[4];   // every workgroup of a launch: sum of cycles, count, longest (printed by the NEXT launch's workgroup 0)
 #define REG_T0() long long _t0 = __builtin_readcyclecounter()
 #define REG_TACC(k) do { const long long _t1 = __builtin_readcyclecounter(); \
     if (threadIdx.x == 0 && blockIdx.x == 0) g_reg_t[k] += _t1 - _t0; _t0 = _t1; } while (0)
@@ -1109,6 +1110,10 @@ __global__ __launch_bounds__(NW * 64, WIDE ? 2 : ((NW == 4 && LOSS < 0) ? 3 : 4)
   constexpr int NT = NW * 64;
 #ifdef CFEAR_REG_TIMING
   const long long t_total0 = __builtin_readcyclecounter();
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0 && g_reg_sum[1]) {   // the previous launch's workgroups
+    printf("matcher launch: %llu workgroups, mean %llu cycles, longest %llu\n", g_reg_sum[1], g_reg_sum[0] / g_reg_sum[1], g_reg_sum[2]);
+    g_reg_sum[0] = g_reg_sum[1] = g_reg_sum[2] = 0;
+  }
 #endif
   REG_T0();
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -1253,6 +1258,10 @@ __global__ __launch_bounds__(NW * 64, WIDE ? 2 : ((NW == 4 && LOSS < 0) ? 3 : 4)
     if (success) { res->score = final_cost / (double)solved_residuals; res->status = CFEAR_OK; }   // :162
     else { res->score = 0.0; res->status = fail_status; }
 #ifdef CFEAR_REG_TIMING
+    {
+      const unsigned long long cyc = (unsigned long long)(__builtin_readcyclecounter() - t_total0);
+      atomicAdd(&g_reg_sum[0], cyc); atomicAdd(&g_reg_sum[1], 1ull); atomicMax(&g_reg_sum[2], cyc);
+    }
     if (blockIdx.x == 0) {
       printf("matcher cycles: total %lld | sizes+carve %lld stage_once %lld | restage %lld nn+gate %lld scan %lld gather %lld | eval %lld reduce %lld round %lld barrier %lld | outer %d lm %d n %d\n",
              (long long)(__builtin_readcyclecounter() - t_total0), g_reg_t[8], g_reg_t[9], g_reg_t[0], g_reg_t[1], g_reg_t[2], g_reg_t[3], g_reg_t[4], g_reg_t[5],
