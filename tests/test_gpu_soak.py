@@ -5,7 +5,7 @@ combinations, window sizes and start poses at random and pushes them through fil
 registrations as ONE batch per parameter set so that the batch-size dependent forms of the matcher all see them (and once
 more through the regular 4-wavefront form, which only batches of thousands reach by themselves).  The oracle judges every
 record.  Further down: the batched odometry on random presets, CorAl, covariance by cost sampling, Scan Context and the CA-CFAR
-pipeline, the same way.  CFEAR_SOAK=<n> sets the number of scenes (default 6: a few seconds; profiles/r05/soak.txt holds a run
+pipeline, the same way.  CFEAR_SOAK=<n> sets the number of scenes, CFEAR_SOAK_SEED=<k> draws another sweep (default 6: a few seconds; profiles/r05/soak.txt holds a run
 with 2000: 23 892 registrations, 666 pipeline configurations x 4 streams x 7 frames, 5 994 CorAl jobs, ...)."""
 import os
 
@@ -16,6 +16,7 @@ pytestmark = pytest.mark.gpu
 
 POS_TOL, ROT_TOL = 1e-4, 1e-5
 N_SCENES = int(os.environ.get("CFEAR_SOAK", "6"))
+SEED = int(os.environ.get("CFEAR_SOAK_SEED", "0"))            # another sweep: other scenes, other draws
 
 
 def _rel(a, b):
@@ -36,13 +37,13 @@ def test_random_scenes_through_the_whole_path():
     from oracle import pyoracle as O
     from tbv_slam_public_amd import api, synth
     from tbv_slam_public_amd import _lib as L
-    rng = np.random.default_rng(20260929)
+    rng = np.random.default_rng(20260929 + SEED)
     combos = [("P2L", "Huber", 0), ("P2P", "Huber", 4), ("P2D", "Huber", 0), ("P2L", "Cauchy", 4), ("P2P", "None", 1),
               ("P2L", "Tukey", 2), ("P2P", "SoftLOne", 3), ("P2L", "Combined", 0)]
     jobs_by_combo = {c: [] for c in combos}
     n_filter = n_cells = 0
     for q in range(N_SCENES):
-        seed = 500000 + q
+        seed = 500000 + 10000 * SEED + q
         kind = int(rng.integers(0, 3))
         nf = 5
         if kind == 0:
@@ -98,8 +99,12 @@ def test_random_scenes_through_the_whole_path():
         costs = reg.GetCostBatch([(m, T) for m, _, T in jobs])
         for rec, (_, c, T) in zip(costs, jobs):
             ok_c, cost_o, res_o, score_o = O.get_cost(c, T, opar)
-            assert (rec["status"] == 0) == ok_c and rec["num_residuals"] == len(res_o), (cost, loss, opt, [len(x) for x in c])
-            np.testing.assert_allclose(rec["final_cost"], cost_o, rtol=1e-9, atol=1e-12)
+            assert (rec["status"] == 0) == ok_c, (cost, loss, opt, [len(x) for x in c])
+            if ok_c:
+                assert rec["num_residuals"] == len(res_o)
+                np.testing.assert_allclose(rec["final_cost"], cost_o, rtol=1e-9, atol=1e-12)
+            else:                                             # too few residuals (:200-203): the reference leaves its outputs untouched
+                assert rec["num_residuals"] <= 1
         try:
             for waves, kb in ((0, 0), (4, 40)):
                 reg.ctx.set_option(L.OPT_MATCHER_WAVES, waves); reg.ctx.set_option(L.OPT_MATCHER_LDS_KB, kb)
@@ -122,13 +127,13 @@ def test_random_pipeline_configurations_keep_per_frame_parity():
     """The batched odometry (polar sweeps in, poses out) on random presets: cost, loss, weights, window size, voxel size, k and
     the input route drawn at random, four fresh streams each, every frame of every stream against the oracle's fuser."""
     from test_gpu_odometry import _run
-    rng = np.random.default_rng(7)
+    rng = np.random.default_rng(7 + SEED)
     n_cfg = max(2, N_SCENES // 3)
     for q in range(n_cfg):
         par = dict(reg_cost=int(rng.choice([0, 1])), reg_loss=int(rng.choice([1, 2])), reg_weight_opt=int(rng.choice([0, 4])),
                    submap_scan_size=int(rng.choice([1, 3, 4, 5])), res=float(rng.choice([3.0, 3.5])),
                    kstrong_k_strongest=int(rng.choice([12, 40])), weight_intensity=int(rng.integers(0, 2)))
-        seeds = [600000 + 4 * q + j for j in range(4)]
+        seeds = [600000 + 10000 * SEED + 4 * q + j for j in range(4)]
         od = _run(seeds, 7, bool(rng.integers(0, 2)), par=par)
         od.close()
 
@@ -138,10 +143,10 @@ def test_random_coral_batches():
     batches: {joint, sep, overlap}, the validity flag and the valid-point count against the oracle."""
     from oracle import pyoracle as O
     from tbv_slam_public_amd import api, synth
-    rng = np.random.default_rng(11)
+    rng = np.random.default_rng(11 + SEED)
     total = 0
     for q in range(max(2, N_SCENES // 3)):
-        imgs, gt, _ = synth.scene_v1(700000 + q, 3)
+        imgs, gt, _ = synth.scene_v1(700000 + 10000 * SEED + q, 3)
         k = int(rng.choice([12, 40]))
         clouds = []
         for f in range(3):
@@ -169,10 +174,10 @@ def test_random_covariances_by_cost_sampling():
     from oracle import pyoracle as O
     from tbv_slam_public_amd import api, synth
     from test_gpu_register import _oracle_par
-    rng = np.random.default_rng(13)
+    rng = np.random.default_rng(13 + SEED)
     done = 0
     for q in range(max(2, N_SCENES // 3)):
-        imgs, gt, _ = synth.scene_v1(800000 + q, 4)
+        imgs, gt, _ = synth.scene_v1(800000 + 10000 * SEED + q, 4)
         cells = []
         for f in range(4):
             sr, si, scn = O.kstrongest(imgs[f], 12, 60)
@@ -209,10 +214,10 @@ def test_random_scan_context_descriptors_and_distances():
     test_gpu_scancontext.py), and the column-shift distance of random pairs, bit for bit."""
     from oracle import pyoracle as O
     from tbv_slam_public_amd import api, synth
-    rng = np.random.default_rng(17)
+    rng = np.random.default_rng(17 + SEED)
     n_pairs = 0
     for q in range(max(2, N_SCENES // 3)):
-        imgs, _, _ = synth.scene_v1(900000 + q, 4)
+        imgs, _, _ = synth.scene_v1(900000 + 10000 * SEED + q, 4)
         k = int(rng.choice([12, 40]))
         clouds = []
         for f in range(4):
@@ -239,9 +244,9 @@ def test_random_cacfar_pipelines():
     route's point counts, cells and poses against the oracle."""
     from oracle import pyoracle as O
     from tbv_slam_public_amd import api, synth
-    rng = np.random.default_rng(19)
+    rng = np.random.default_rng(19 + SEED)
     for q in range(max(1, N_SCENES // 6)):
-        imgs = synth.scene_v1(950000 + q, 4, range_res=0.175, ccw=True, n_walls=int(rng.choice([40, 120])), noise_scale=float(rng.choice([4.0, 7.0])))[0]
+        imgs = synth.scene_v1(950000 + 10000 * SEED + q, 4, range_res=0.175, ccw=True, n_walls=int(rng.choice([40, 120])), noise_scale=float(rng.choice([4.0, 7.0])))[0]
         win, guard = int(rng.choice([24, 40])), int(rng.choice([4, 10]))
         pfa, zmin = float(rng.choice([0.01, 0.003])), float(rng.choice([20.0, 35.0]))
         kw = dict(filter_type=1, cacfar_range_res=0.175, cacfar_z_min=zmin, cacfar_nb_guard_cells=guard, cacfar_window_size=win,
