@@ -413,7 +413,7 @@ __device__ __forceinline__ void eval_slot(const cfear_reg_params& par, double sm
     acc[1] -= g0; acc[2] -= g1;
     acc[3] = fma(j02, g0, acc[3]); acc[3] = fma(j12, g1, acc[3]);
     const double h02 = rho1 * j02, h12 = rho1 * j12;
-    // (H11 = H00 = the sum of rho': acc[7] is filled from acc[4] by the caller, p2p_mirror())
+    // (H11 = H00 = the sum of rho': acc[7] is not accumulated -- block_reduce8_p2p and the cost object's evaluation set it from acc[4])
     acc[4] += rho1; acc[6] = fma(-rho1, j02, acc[6]); acc[9] = fma(h02, j02, acc[9]);
     acc[8] = fma(-rho1, j12, acc[8]); acc[9] = fma(h12, j12, acc[9]);
   } else if (WITH_JAC) {
