@@ -816,7 +816,7 @@ def main(argv=None):
         # square and a quarter of the worlds yield fewer surface points than any real scan (SURVEY 8d's realism gate: 184-484 per
         # scan, the 5-95 % band of combined.txt; seed 80002: 12-47).  150 walls + 500 scatterers give ~290 per scan on average
         # (tools/cfar_realism.py) and no failed registration; the sparse worlds stay as a labelled extra (`feature_poor`).
-        # A quarter of these sweeps exceed 16 384 detections: they run through surface_sort_kernel's second instantiation.
+        # A quarter of these sweeps exceed 16 384 detections: they run through the 64-points-per-thread instantiation of surface_sort_mixed_kernel.
         c4_world = dict(n_walls=150, n_scatter=500)
         note("extra: config4_cacfar_kvarntorp ([bins][azimuths] input)")
         c4 = side_config(c4_par, 80000, 0.175, True, 512, 32, 480, c4_world)

@@ -991,13 +991,13 @@ constexpr int kTierInFlight = 2;                    // candidates per lane in fl
 
 // KPER = points per thread the kernel can hold in registers: 32 (scans of up to kMaxPoints = 16 384 points: every k-strongest
 // cloud) and 64 (CA-CFAR sweeps beyond that -- cfar.cpp:35-71 puts no bound on the detections; at Pfa 0.01 the false alarms of a
-// 400 x 2286-bin sweep alone are ~10 k points -- launched behind the regular one, which leaves such scans untouched.  Its 64
+// 400 x 2286-bin sweep alone are ~10 k points -- surface_sort_mixed_kernel below picks the instantiation per scan).  Its 64
 // positions per thread are packed two per register (as 64 separate u16 they spilled 316 bytes per lane at the 128 VGPRs two
 // workgroups per CU allow; one workgroup per CU with 136 VGPRs was slower still: 0.60 / 0.52 / 0.49 ms per 512 sweeps).
 // Without it those scans took the single-kernel path -- milliseconds each: 1.5 ms per frame batch of 512 Kvarntorp-preset
 // sweeps of which a quarter exceed 16 384 points.
 template <int KPER>
-__global__ __launch_bounds__(kFastThreads, 4) void surface_sort_kernel(const SurfJob* __restrict__ jobs, const SurfCommon cm) {
+__device__ __forceinline__ void surface_sort_job(const SurfJob* __restrict__ jobs, const SurfCommon& cm) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   constexpr int NT = kFastThreads, NW = NT / 64;
   constexpr int kPer = KPER;                                          // <= KPER points per thread
@@ -1006,7 +1006,7 @@ __global__ __launch_bounds__(kFastThreads, 4) void surface_sort_kernel(const Sur
   const int job_id = blockIdx.x;
   const SurfScratch scr = scratch_of(cm.scratch + (size_t)job_id * cm.scratch_stride, cm.scratch_cap);
   if (scr.hdr->route != kRoutePrepped) return;                         // failed, empty, handed to the single-kernel path -- or done (second launch)
-  if (KPER * NT < kFastMaxPoints && scr.hdr->n > KPER * NT) return;    // the second instantiation's scan
+  if (KPER * NT < kFastMaxPoints && scr.hdr->n > KPER * NT) return;    // (a larger scan than this instantiation holds: the mixed kernel's)
   const SurfJob job = jobs[job_id];
   auto hand_over = [&](int n, int prepared) {                          // to the single-kernel path
     if (tid == 0) {
@@ -1468,6 +1468,19 @@ __global__ __launch_bounds__(kFastThreads, 4) void surface_sort_kernel(const Sur
   }
 }
 
+// The regular launch: every scan fits 32 points per thread (k-strongest clouds).
+__global__ __launch_bounds__(kFastThreads, 4) void surface_sort_kernel(const SurfJob* __restrict__ jobs, const SurfCommon cm) {
+  surface_sort_job<32>(jobs, cm);
+}
+// Batches that may hold scans beyond 16 384 points (CA-CFAR): ONE launch in which a workgroup takes the instantiation its scan
+// needs.  (Two launches, the second leaving the first's scans untouched, were two workgroup latencies behind each other for a
+// batch of one workgroup per slot: 0.246 + 0.257 ms per 512 Kvarntorp-preset sweeps.)
+__global__ __launch_bounds__(kFastThreads, 4) void surface_sort_mixed_kernel(const SurfJob* __restrict__ jobs, const SurfCommon cm) {
+  const SurfScratch scr = scratch_of(cm.scratch + (size_t)blockIdx.x * cm.scratch_stride, cm.scratch_cap);
+  if (scr.hdr->n > 32 * kFastThreads) surface_sort_job<64>(jobs, cm);  // (block-uniform)
+  else surface_sort_job<32>(jobs, cm);
+}
+
 constexpr int kFinishThreads = 256;
 
 __global__ __launch_bounds__(kFinishThreads) void surface_finish_kernel(const SurfJob* __restrict__ jobs, const SurfCommon cm) {
@@ -1631,9 +1644,9 @@ int cfear_surface_launch(cfear_ctx* ctx, const void* d_jobs, int n_jobs, const c
   ctx->surf_list_dirty = true;
   // per launch: the attribute is per device, and contexts on other threads / devices share this code
   { const int rc_lds = cfear_allow_lds(ctx, (const void*)surface_points_kernel, cfear_surface_lds_bytes()); if (rc_lds != CFEAR_OK) return rc_lds; }
-  { const int rc_lds = cfear_allow_lds(ctx, (const void*)surface_sort_kernel<32>, kFastLds); if (rc_lds != CFEAR_OK) return rc_lds; }
-  const bool big_scans = cap_points > kMaxPoints;            // scans beyond 16 384 points may come (CA-CFAR): the second instantiation behind the first
-  if (big_scans) { const int rc_lds = cfear_allow_lds(ctx, (const void*)surface_sort_kernel<64>, kFastLds); if (rc_lds != CFEAR_OK) return rc_lds; }
+  { const int rc_lds = cfear_allow_lds(ctx, (const void*)surface_sort_kernel, kFastLds); if (rc_lds != CFEAR_OK) return rc_lds; }
+  const bool big_scans = cap_points > kMaxPoints;            // scans beyond 16 384 points may come (CA-CFAR): the kernel with both instantiations
+  if (big_scans) { const int rc_lds = cfear_allow_lds(ctx, (const void*)surface_sort_mixed_kernel, kFastLds); if (rc_lds != CFEAR_OK) return rc_lds; }
   cm.finish_keys = std::min(max_cell_cap, kMaxPoints);     // cells a scan may hold (the matcher's 16-bit tables address 65 535)
   const size_t finish_lds = kScanGridLds;                    // the matcher grid's counters
   cm.finish_lds = (uint32_t)finish_lds;
@@ -1653,8 +1666,8 @@ int cfear_surface_launch(cfear_ctx* ctx, const void* d_jobs, int n_jobs, const c
   }
   {
     ProfScope ps(ctx, "surface_sort");
-    hipLaunchKernelGGL(surface_sort_kernel<32>, dim3(n_jobs), dim3(kFastThreads), kFastLds, ctx->stream, (const SurfJob*)d_jobs, cm);
-    if (big_scans) hipLaunchKernelGGL(surface_sort_kernel<64>, dim3(n_jobs), dim3(kFastThreads), kFastLds, ctx->stream, (const SurfJob*)d_jobs, cm);
+    if (big_scans) hipLaunchKernelGGL(surface_sort_mixed_kernel, dim3(n_jobs), dim3(kFastThreads), kFastLds, ctx->stream, (const SurfJob*)d_jobs, cm);
+    else hipLaunchKernelGGL(surface_sort_kernel, dim3(n_jobs), dim3(kFastThreads), kFastLds, ctx->stream, (const SurfJob*)d_jobs, cm);
   }
   {
     ProfScope ps(ctx, "surface_points");       // the single-kernel path drains the hand-over list (usually empty)

@@ -226,7 +226,7 @@ def test_cacfar_sweeps_beyond_16384_points_stay_on_the_fast_pipeline():
     """CA-CFAR puts no bound on a sweep's detections (cfar.cpp:35-71): with the Kvarntorp preset the false alarms of a 400 x
     2286-bin sweep alone are ~10 k points, and worlds with realistic surface-point counts push a quarter of the sweeps beyond
     the 16 384 points surface_sort_kernel's regular instantiation holds.  Those scans run through its second instantiation (64
-    points per thread) instead of the single-kernel path; points, cells and poses must equal the oracle's, frame by frame,
+    points per thread; one launch serves both: surface_sort_mixed_kernel) instead of the single-kernel path; points, cells and poses must equal the oracle's, frame by frame,
     and the single-kernel path must have nothing to do."""
     from oracle import pyoracle as O
     from tbv_slam_public_amd import api, synth
