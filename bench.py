@@ -262,220 +262,337 @@ def whole_path_of(mean_points, mean_cells, keyframes, registrations_per_s_per_gp
 # ---------------------------------------------------------------------------------------------------------
 # neighbouring workloads (functions so that the odometry run can report them in its own line)
 # ---------------------------------------------------------------------------------------------------------
-def loopclosure_run(D, n_cand, steps, warmup, graph=None):
-    """loopclosure_step under a torch stream of its own: torch reports handle 0 for its default stream, and a context given 0
-    makes a PRIVATE stream -- on a real (non-default) stream the context, the RCCL all_gather and the read-back share ONE HIP
-    stream, so the collective is ordered behind the matcher with no host synchronisation in between (dist.py checks the
-    handles itself: Context.shares_torch_stream)."""
+class LoopClosureWorld:
+    """What a loop-closure thread holds (BASELINE configs[3]): the graph nodes' cached surface points as a scan table on this
+    rank's GPU, and candidate batches drawn among them -- pairs 2..6 frames (5-15 m) apart, guess error N(0, 1 m), N(0, 3 deg);
+    P2L, Huber 0.1, Uniform, SetParameters(4, 10) (loopclosure.cpp:56-57).  Every rank featurises the scans itself (duplicates
+    across ranks tolerated, no feature exchange: SURVEY 8e) and draws the SAME candidate list (seeded)."""
+
+    def __init__(self, D, graph=None):
+        import torch
+        from tbv_slam_public_amd import api, synth
+        self.D = D
+        self.ctx = ctx = api.Context(D.local_rank, stream=torch.cuda.current_stream().cuda_stream)
+        if graph:
+            # a precomputed simple_graph.sgh (tools/make_graph.py, or the reference's SaveGraph): the cached surface points
+            # of every node feed the matcher directly, as loopclosure::Register does (types.h:119-122)
+            nodes = [nd for nd in api.LoadSimpleGraph(graph) if nd["cells"] is not None and len(nd["cells"]) > 0]
+            assert len(nodes) >= 8, "the graph needs at least 8 nodes with surface points"
+            self.gt = np.stack([nd["T_xyt"] for nd in nodes])
+            self.scans = [api.MapPointNormal(cells=nd["cells"], ctx=ctx) for nd in nodes]
+            self.lap = len(nodes)
+            self.data = "simple_graph %s (%d nodes)" % (os.path.basename(graph), len(nodes))
+        else:
+            # 1024 DISTINCT scans: 16 synthetic worlds x a closed lap of 64 sweeps each (rendered and filtered on the GPU);
+            # a 10 k-frame Oxford sequence holds ~3 000 keyframes, so a candidate batch must not revisit 40 scans
+            n_worlds, lap = 16, 64
+            gt_list, self.scans = [], []
+            for wd in range(n_worlds):
+                sc = synth.Scene(3000 + wd, circle_frames=lap)
+                imgs = synth.render_frames_torch(sc, list(range(lap)), D.dev)
+                torch.cuda.synchronize()
+                r = api.filter_kstrongest(imgs, 40, 60, 0.0438, 2.5, ctx=ctx)
+                ctx.synchronize()
+                xyzi, npts = r["xyzi"].cpu().numpy(), r["n_points"].cpu().numpy()
+                for f in range(lap):
+                    gt_list.append(sc.pose_at(f, lap))
+                    self.scans.append(api.MapPointNormal(xyzi[f, :int(npts[f])], 3.0, (0, 0), True, ctx=ctx))
+                del imgs, r
+            self.gt = np.stack(gt_list)
+            self.lap = lap
+            self.data = "synthetic (scene_v1)"
+        self.n_frames = len(self.scans)
+        self.table = api.ScanTable(self.scans, ctx=ctx)
+        self.reg = api.n_scan_normal_reg("P2L", ctx=ctx)
+        self.reg.SetParameters(4, 10)
+        self.comm = None
+        if D.dist is not None:                                       # the host's own communicator (as a C++ node would hold one)
+            def exchange(raw):
+                t = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(D.dev)
+                D.dist.broadcast(t, 0)
+                return bytes(t.cpu().numpy())
+            try:
+                self.comm = api.RcclComm(ctx, D.world, D.rank, exchange)
+            except Exception as e:
+                if D.world > 1:
+                    raise
+                print("bench.py: no 1-rank ncclComm_t (%s): the step runs without the collective" % e, file=sys.stderr)
+
+    def candidates(self, n, seed=11):
+        from tbv_slam_public_amd import api
+        rng = np.random.Generator(np.random.PCG64(seed))
+        base = rng.integers(0, self.n_frames // self.lap, n) * self.lap
+        i = base + rng.integers(0, self.lap - 7, n)
+        j = i + rng.integers(2, 7, n)
+        a, b = self.gt[i], self.gt[j]
+        c, s_ = np.cos(a[:, 2]), np.sin(a[:, 2])
+        d = b[:, :2] - a[:, :2]
+        rel = np.stack([c * d[:, 0] + s_ * d[:, 1], -s_ * d[:, 0] + c * d[:, 1], b[:, 2] - a[:, 2]], axis=1)
+        guess = rel + np.concatenate([rng.normal(0, 1.0, (n, 2)), rng.normal(0, np.deg2rad(3.0), (n, 1))], axis=1)
+        return api.ScanTable.candidates(i, j, guess)
+
+    def close(self):
+        if self.comm is not None:
+            self.comm.close()
+
+
+def pipe_measure(D, W, cands_all, steps, warmup, graph=True, depth=2):
+    """One sharded candidate batch through the C-ABI pipe (cfear_candidate_pipe: upload -> expand -> matcher on the context's
+    stream, ncclAllGather of the 72-byte records + read-back on the exchange stream), every rank handing in the full list:
+    the step's latency (submit, collect, repeat), the same steps pipelined (step k + 1 submitted before step k is collected),
+    the matcher's own time (hipEvents, a pass of its own: per-kernel events do not go into a captured graph) and the exchange
+    stream's time per step."""
+    from tbv_slam_public_amd import api, _lib as L
+    n = int(cands_all.shape[0])
+    ctx = W.ctx
+    pipe = api.CandidatePipe(W.reg, W.table, n, W.comm, D.rank, D.world, depth=depth, graph=graph, timing=True)
+    out = np.empty(n, L.RESULT_DTYPE)
+    for _ in range(max(warmup, 1) + 2 * depth):                        # (the first step of a slot also captures its graph)
+        pipe.collect(pipe.submit(cands_all), out)
+    D.barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        pipe.collect(pipe.submit(cands_all), out)
+    D.barrier()
+    lat_ms = D.max_over_ranks(time.perf_counter() - t0) / steps * 1e3
+    st = pipe.stats()
+    D.barrier()
+    t0 = time.perf_counter()
+    tk = pipe.submit(cands_all)
+    for _ in range(steps - 1):
+        tk2 = pipe.submit(cands_all)
+        pipe.collect(tk, out)
+        tk = tk2
+    pipe.collect(tk, out)
+    D.barrier()
+    pl_ms = D.max_over_ranks(time.perf_counter() - t0) / steps * 1e3
+    st2 = pipe.stats()
+    ctx.profile_enable(True); ctx.profile_read(reset=True)
+    for _ in range(steps):
+        pipe.collect(pipe.submit(cands_all), out)
+    D.barrier()
+    prof = ctx.profile_read(reset=True); ctx.profile_enable(False)
+    kernel_ms = D.max_over_ranks(sum(v[0] for v in prof.values()) / max(steps, 1))
+    gather_ms = D.max_over_ranks((st2["exchange_ms"] - st["exchange_ms"]) / max(st2["steps"] - st["steps"], 1))
+    pipe.close()
+    return {"candidates": n, "candidates_per_rank": (n + D.world - 1) // D.world, "step_ms": lat_ms, "kernel_ms": kernel_ms,
+            "gather_ms": gather_ms, "value": n / (lat_ms * 1e-3), "pipelined_step_ms": pl_ms, "pipelined_value": n / (pl_ms * 1e-3),
+            "pipelined_over_kernel": pl_ms / kernel_ms if kernel_ms > 0 else None, "graph_slots": st["graph_slots"], "depth": depth,
+            "ok_fraction": float((out["status"] == 0).mean()), "mean_outer_iters": float(out["outer_iters"].mean())}
+
+
+def _on_side_stream(D, fn):
+    """fn() under a torch stream of its own: torch reports handle 0 for its default stream, and a context given 0 makes a PRIVATE
+    stream -- on a real (non-default) stream the context, torch's collectives and the read-back share ONE HIP stream
+    (dist.py checks the handles itself: Context.shares_torch_stream)."""
     import torch
     side = torch.cuda.Stream(device=D.dev)
     side.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(side):
-        out = _loopclosure_run(D, n_cand, steps, warmup, graph)
+        out = fn()
     torch.cuda.current_stream().wait_stream(side)
     return out
 
 
-def _loopclosure_run(D, n_cand, steps, warmup, graph=None):
-    """BASELINE configs[3]: loop-closure candidate registrations (P2L, Huber 0.1, Uniform, SetParameters(4,10) --
-    loopclosure.cpp:56-57) between cached surface-point sets, block-sharded over the ranks, results all_gathered
-    (RCCL) in candidate order."""
-    import torch
-    from tbv_slam_public_amd import api, synth
+def loopclosure_run(D, n_cand, steps, warmup, graph=None, world_obj=None):
+    return _on_side_stream(D, lambda: _loopclosure_run(D, n_cand, steps, warmup, graph, world_obj))
+
+
+def _loopclosure_run(D, n_cand, steps, warmup, graph=None, world_obj=None):
+    """BASELINE configs[3]: loop-closure candidate registrations between cached surface-point sets, block-sharded over the
+    ranks, results all_gathered (RCCL) in candidate order.  The step goes through the C-ABI pipe (what a C++ host calls);
+    the Python mirror of the same step (dist.py over torch.distributed) is timed beside it."""
+    from tbv_slam_public_amd import api
     from tbv_slam_public_amd import dist as cdist
-    ctx = api.Context(D.local_rank, stream=torch.cuda.current_stream().cuda_stream)
-    if graph:
-        # a precomputed simple_graph.sgh (tools/make_graph.py, or the reference's SaveGraph): the cached surface points
-        # of every node feed the matcher directly, as loopclosure::Register does (types.h:119-122)
-        nodes = [nd for nd in api.LoadSimpleGraph(graph) if nd["cells"] is not None and len(nd["cells"]) > 0]
-        n_frames = len(nodes)
-        assert n_frames >= 8, "the graph needs at least 8 nodes with surface points"
-        gt = np.stack([nd["T_xyt"] for nd in nodes])
-        scans = [api.MapPointNormal(cells=nd["cells"], ctx=ctx) for nd in nodes]
-    else:
-        # 1024 DISTINCT scans: 16 synthetic worlds x a closed lap of 64 sweeps each (rendered and filtered on the GPU);
-        # a 10 k-frame Oxford sequence holds ~3 000 keyframes, so a candidate batch must not revisit 40 scans
-        n_worlds, lap = 16, 64
-        n_frames = n_worlds * lap
-        gt_list, scans = [], []
-        for wd in range(n_worlds):                     # every rank featurises the scans it may reference
-            sc = synth.Scene(3000 + wd, circle_frames=lap)
-            imgs = synth.render_frames_torch(sc, list(range(lap)), D.dev)
-            torch.cuda.synchronize()                   # the library's stream is not torch's
-            r = api.filter_kstrongest(imgs, 40, 60, 0.0438, 2.5, ctx=ctx)
-            ctx.synchronize()
-            xyzi, npts = r["xyzi"].cpu().numpy(), r["n_points"].cpu().numpy()
-            for f in range(lap):
-                gt_list.append(sc.pose_at(f, lap))
-                scans.append(api.MapPointNormal(xyzi[f, :int(npts[f])], 3.0, (0, 0), True, ctx=ctx))
-            del imgs, r
-        gt = np.stack(gt_list)
-    rng = np.random.Generator(np.random.PCG64(11))
-
-    def rel(a, b):
-        c, s = np.cos(a[2]), np.sin(a[2])
-        d = b[:2] - a[:2]
-        return np.array([c * d[0] + s * d[1], -s * d[0] + c * d[1], b[2] - a[2]])
-    jobs = []
-    lap_len = n_frames if graph else 64
-    for _ in range(n_cand):                        # pairs 2..6 frames (5-15 m) apart, guess error N(0, 1 m), N(0, 3 deg)
-        base = int(rng.integers(0, n_frames // lap_len)) * lap_len
-        i = base + int(rng.integers(0, lap_len - 7))
-        j = i + int(rng.integers(2, 7))
-        guess = rel(gt[i], gt[j]) + np.concatenate([rng.normal(0, 1.0, 2), rng.normal(0, np.deg2rad(3.0), 1)])
-        jobs.append(([scans[i], scans[j]], np.array([[0.0, 0.0, 0.0], guess])))
-    reg = api.n_scan_normal_reg("P2L", ctx=ctx)
-    reg.SetParameters(4, 10)
+    W = world_obj or LoopClosureWorld(D, graph)
+    cands = W.candidates(n_cand)
+    full = pipe_measure(D, W, cands, steps, warmup)
+    # what a step costs whatever the batch: ONE candidate per rank through the same code (upload, launches, the collective,
+    # read-back) -- a strong-scaling curve is read as  step(N) ~ fixed_cost_ms + kernel_ms(1) / N; the lone registration's own
+    # latency (a chain of dependent phases, ~0.07 ms whatever the batch) is not overhead
+    tiny = pipe_measure(D, W, cands[:D.world], steps, warmup)
+    # What a rank of an 8-GPU run does per step, measured HERE (no 8-GPU node needed to read a future SCALE record against it):
+    # the block of n / 8 candidates rank 0 would own, through the same code (the 8-rank all_gather moves 8 x 36 KiB over xGMI
+    # instead of 36 KiB inside one GPU, a few microseconds more)
+    proj = None
+    if D.world == 1 and n_cand >= 64:
+        per8 = (n_cand + 7) // 8
+        blk = pipe_measure(D, W, cands[:per8], steps, warmup)
+        proj = {"ranks": 8, "candidates_per_rank": per8, "step_ms_per_rank_block": blk["step_ms"],
+                "kernel_ms_per_rank_block": blk["kernel_ms"], "gather_ms_per_rank_block": blk["gather_ms"],
+                "pipelined_step_ms_per_rank_block": blk["pipelined_step_ms"],
+                "pipelined_over_kernel": blk["pipelined_over_kernel"],
+                "step_ms_one_rank_all_candidates": full["step_ms"], "projected_speedup_at_8": full["step_ms"] / blk["step_ms"],
+                "projected_efficiency_at_8": full["step_ms"] / blk["step_ms"] / 8.0,
+                "projected_pipelined_efficiency_at_8": full["pipelined_step_ms"] / blk["pipelined_step_ms"] / 8.0,
+                "note": "measured at N = 1: the step of one rank's block (n / 8 candidates) through the same path incl. a one-rank "
+                        "ncclAllGather; an 8-rank step costs this plus the wider gather (8 x %d KiB over xGMI)" % (per8 * 72 // 1024)}
+    # the Python mirror (tests, this bench's verify workload): dist.register_candidates_sharded over torch.distributed
     lo, hi, _per = cdist.shard_range(n_cand, D.world, D.rank)
-    # the scans' device views live in a table (what a loop-closure thread keeps for the graph's nodes); a candidate is two
-    # indices and two poses -- 56 bytes cross PCIe per candidate and step, the job records are written on the device
-    table = api.ScanTable(scans, ctx=ctx)
-    sid = {id(s): i for i, s in enumerate(scans)}
-
-    def to_cands(js):
-        return api.ScanTable.candidates([sid[id(j[0][0])] for j in js], [sid[id(j[0][1])] for j in js], [j[1][1] for j in js],
-                                        [j[1][0] for j in js])
-    cands = to_cands(jobs[lo:hi])
-    fn = lambda _local: reg.RegisterCandidates(table, cands)
-    fn.into = lambda _local, ptr: reg.RegisterCandidates(table, cands, device_ptr=ptr)   # records stay on the GPU until the gather
-    fn.ctx = ctx
-    assert ctx.shares_torch_stream(), "the loop-closure context must enqueue on torch's current stream"
-    for _ in range(max(warmup, 1)):
+    mine = cands[lo:hi]
+    fn = lambda _local: W.reg.RegisterCandidates(W.table, mine)
+    fn.into = lambda _local, ptr: W.reg.RegisterCandidates(W.table, mine, device_ptr=ptr)   # records stay on the GPU until the gather
+    fn.ctx = W.ctx
+    jobs = [None] * n_cand                                             # (the mirror takes the list for its length only)
+    for _ in range(3):
         out = cdist.register_candidates_sharded(jobs, fn)
     D.barrier()
-    ctx.profile_enable(True); ctx.profile_read(reset=True)
     t1 = time.perf_counter()
     for _ in range(steps):
         out = cdist.register_candidates_sharded(jobs, fn)
     D.barrier()
-    elapsed = D.max_over_ranks(time.perf_counter() - t1)
-    prof = ctx.profile_read(reset=True); ctx.profile_enable(False)
-    kernel_ms = D.max_over_ranks(sum(v[0] for v in prof.values()) / max(steps, 1))
-    # what a step costs whatever the batch: ONE candidate per rank through the same code (job upload, launch, the
-    # collective, read-back) -- at 8 ranks a 4096-candidate step is 512 candidates = one wave of workgroups per rank, so a
-    # strong-scaling curve is read as  step(N) ~ fixed_cost_ms + kernel_ms(1) / N
-    tiny_jobs = [jobs[cdist.shard_range(n_cand, D.world, r)[0]] for r in range(D.world)]
-    tiny_c = to_cands(tiny_jobs[D.rank:D.rank + 1])
-    tfn = lambda _local: reg.RegisterCandidates(table, tiny_c)
-    tfn.into = lambda _local, ptr: reg.RegisterCandidates(table, tiny_c, device_ptr=ptr)
-    tfn.ctx = ctx
-    for _ in range(3):
-        cdist.register_candidates_sharded(tiny_jobs, tfn)
-    D.barrier()
-    t2 = time.perf_counter()
-    for _ in range(steps):
-        cdist.register_candidates_sharded(tiny_jobs, tfn)
-    D.barrier()
-    fixed_ms = D.max_over_ranks(time.perf_counter() - t2) / steps * 1e3
-    # ... of which the lone registration's own latency (a registration is a chain of dependent phases: ~0.1 ms whatever the
-    # batch) is not overhead: the same steps again with the kernels bracketed by events
-    ctx.profile_enable(True); ctx.profile_read(reset=True)
-    for _ in range(steps):
-        cdist.register_candidates_sharded(tiny_jobs, tfn)
-    D.barrier()
-    tprof = ctx.profile_read(reset=True); ctx.profile_enable(False)
-    tiny_kernel_ms = D.max_over_ranks(sum(v[0] for v in tprof.values()) / max(steps, 1))
-    # What a rank of an 8-GPU run does per step, measured HERE (no 8-GPU node needed to read a future SCALE record against it):
-    # the block of n / 8 candidates rank 0 would own, through the same code -- marshalling, upload, launch, the collective
-    # (one rank's worth; the 8-rank all_gather moves 8 x 36 KiB over xGMI, a few microseconds more), read-back.
-    proj = None
-    if D.world == 1 and n_cand >= 64:
-        per8 = (n_cand + 7) // 8
-        blk_jobs = jobs[:per8]
-        blk_c = to_cands(blk_jobs)
-        bfn = lambda _local: reg.RegisterCandidates(table, blk_c)
-        bfn.into = lambda _local, ptr: reg.RegisterCandidates(table, blk_c, device_ptr=ptr)
-        bfn.ctx = ctx
-        for _ in range(3):
-            cdist.register_candidates_sharded(blk_jobs, bfn)
-        D.barrier()
-        ctx.profile_enable(True); ctx.profile_read(reset=True)
-        t3 = time.perf_counter()
-        for _ in range(steps):
-            cdist.register_candidates_sharded(blk_jobs, bfn)
-        D.barrier()
-        blk_ms = (time.perf_counter() - t3) / steps * 1e3
-        bprof = ctx.profile_read(reset=True); ctx.profile_enable(False)
-        blk_kernel_ms = sum(v[0] for v in bprof.values()) / max(steps, 1)
-        full_ms = elapsed / steps * 1e3
-        proj = {"ranks": 8, "candidates_per_rank": per8, "step_ms_per_rank_block": blk_ms, "kernel_ms_per_rank_block": blk_kernel_ms,
-                "step_ms_one_rank_all_candidates": full_ms, "projected_speedup_at_8": full_ms / blk_ms,
-                "projected_efficiency_at_8": full_ms / blk_ms / 8.0,
-                "note": "measured at N = 1: the step of one rank's block (n / 8 candidates) through the same path incl. a one-rank "
-                        "RCCL all_gather; an 8-rank step costs this plus the wider gather (8 x %d KiB over xGMI)" % (per8 * 72 // 1024)}
-    return {"fixed_cost_ms": fixed_ms, "fixed_cost_kernel_ms": tiny_kernel_ms, "fixed_overhead_ms": max(fixed_ms - tiny_kernel_ms, 0.0),
-            "kernel_ms": kernel_ms, "projected_strong_scaling": proj, "collective": "rccl all_gather" if D.dist else "none (no process group)",
-            "distinct_scans": n_frames,"metric": "loop-closure candidate registrations/sec (cached features, P2L 4x10)",
-            "value": n_cand * steps / elapsed, "unit": "registrations/s", "n_gpus": D.world, "steps": steps,
-            "warmup": max(warmup, 1), "ms_per_step": elapsed / steps * 1e3, "ms_per_4096": elapsed / steps * 1e3 * 4096.0 / n_cand,
+    py_ms = D.max_over_ranks(time.perf_counter() - t1) / steps * 1e3
+    if world_obj is None:
+        W.close()
+    return {"fixed_cost_ms": tiny["step_ms"], "fixed_cost_kernel_ms": tiny["kernel_ms"],
+            "fixed_overhead_ms": max(tiny["step_ms"] - tiny["kernel_ms"], 0.0),
+            "kernel_ms": full["kernel_ms"], "gather_ms": full["gather_ms"], "pipelined_ms_per_step": full["pipelined_step_ms"],
+            "pipelined_value": full["pipelined_value"], "graph_slots": full["graph_slots"],
+            "projected_strong_scaling": proj,
+            "collective": "ncclAllGather on the pipe's exchange stream (cfear_candidate_pipe)" if W.comm is not None else "none (no communicator)",
+            "python_mirror_ms_per_step": py_ms, "python_mirror_shares_torch_stream": bool(W.ctx.shares_torch_stream()),
+            "distinct_scans": W.n_frames, "metric": "loop-closure candidate registrations/sec (cached features, P2L 4x10)",
+            "value": full["value"], "unit": "registrations/s", "n_gpus": D.world, "steps": steps,
+            "warmup": max(warmup, 1), "ms_per_step": full["step_ms"], "ms_per_4096": full["step_ms"] * 4096.0 / n_cand,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32 search / f64 solve",
-            "data": ("simple_graph %s (%d nodes)" % (os.path.basename(graph), n_frames)) if graph else "synthetic (scene_v1)",
+            "data": W.data,
             "config": {"workload": "configs[3]: %d loop-closure candidates sharded over %d rank(s), all_gather of "
                                    "72-byte result records" % (n_cand, D.world), "candidates": n_cand},
-            "ok_fraction": float((out["status"] == 0).mean()), "mean_outer_iters": float(out["outer_iters"].mean()),
+            "ok_fraction": full["ok_fraction"], "mean_outer_iters": full["mean_outer_iters"],
+            "python_mirror_ok_fraction": float((out["status"] == 0).mean()),
             "reference_cpu_ms_per_candidate": "8.3-9.7 (evaluation/data/oxford_all_tbv_model_8/job_*/time_statistics.txt)"}
+
+
+class VerifyWorld:
+    """40 nodes of one synthetic lap with surface points and peak clouds on the GPU; candidates 3 per query node."""
+
+    def __init__(self, D):
+        import torch
+        from tbv_slam_public_amd import api, synth
+        self.ctx = ctx = api.Context(D.local_rank, stream=torch.cuda.current_stream().cuda_stream)
+        self.n_frames = n_frames = 40
+        sc = synth.Scene(3)
+        self.gt = np.stack([sc.pose_at(f, n_frames) for f in range(n_frames)])
+        self.scans, self.peaks = [], []
+        for f in range(n_frames):
+            r = api.filter_kstrongest(sc.render(f, n_frames), 40, 60, 0.0438, 2.5, want_peaks=True, ctx=ctx)
+            self.scans.append(api.MapPointNormal(r["xyzi"][0, :int(r["n_points"][0])], 3.0, (0, 0), True, ctx=ctx))
+            self.peaks.append(torch.from_numpy(np.ascontiguousarray(r["xyzi_peaks"][0, :int(r["n_peaks"][0])])).cuda())   # device-resident
+        self.par = api.verify_params(ctx)
+
+    def candidates(self, n, lo=0, hi=None):
+        """candidates lo .. hi-1 of the seeded list of n (every rank draws the same list and keeps its block)"""
+        rng = np.random.Generator(np.random.PCG64(11))
+        hi = n if hi is None else hi
+        i = rng.integers(0, self.n_frames - 7, n)
+        j = i + rng.integers(2, 7, n)
+        noise = np.concatenate([rng.normal(0, 1.0, (n, 2)), rng.normal(0, np.deg2rad(3.0), (n, 1))], axis=1)
+        sim, ob = rng.uniform(0.05, 0.5, n), rng.uniform(0, 0.3, n)
+        cands = []
+        for q in range(lo, hi):
+            a, b = self.gt[j[q]], self.gt[i[q]]
+            c, s_ = np.cos(a[2]), np.sin(a[2])
+            d = b[:2] - a[:2]
+            guess = np.array([c * d[0] + s_ * d[1], -s_ * d[0] + c * d[1], b[2] - a[2]]) + noise[q]
+            cands.append(dict(from_scan=self.scans[j[q]], to_scan=self.scans[i[q]], from_peaks=self.peaks[j[q]], to_peaks=self.peaks[i[q]],
+                              from_pose=self.gt[j[q]], t_be_guess=guess, sc_sim=float(sim[q]), odom_bounds=float(ob[q]), group=q // 3))
+        return cands
+
+
+def verify_measure(D, V, n_cand, steps, warmup):
+    """n_cand candidates verified end to end per step, block-sharded over the ranks, one all_gather of 480-byte records
+    (dist.verify_candidates_sharded over torch.distributed), ApplyConstratins over the gathered list."""
+    from tbv_slam_public_amd import api
+    from tbv_slam_public_amd import dist as cdist
+    lo, hi, _per = cdist.shard_range(n_cand, D.world, D.rank)
+    prepared = api.prepare_verify_batch(V.candidates(n_cand, lo, hi))
+    groups = [{"group": q // 3} for q in range(n_cand)]                # (the gather step reads the list's length and groups)
+    par = V.par
+    fn = lambda _local: api.verify_loop_candidates(prepared, par, V.ctx)
+    for _ in range(max(warmup, 1)):
+        out = cdist.verify_candidates_sharded(groups, fn, par.model_threshold, bool(par.all_candidates), fn_selects=True)
+    D.barrier()
+    t1 = time.perf_counter()
+    for _ in range(steps):
+        out = cdist.verify_candidates_sharded(groups, fn, par.model_threshold, bool(par.all_candidates), fn_selects=True)
+    D.barrier()
+    ms = D.max_over_ranks(time.perf_counter() - t1) / steps * 1e3
+    return {"candidates": n_cand, "candidates_per_rank": (n_cand + D.world - 1) // D.world, "step_ms": ms, "value": n_cand / (ms * 1e-3),
+            "reg_ok_fraction": float(out["reg_ok"].mean()), "accepted_fraction": float(out["accepted"].mean())}
 
 
 def verify_run(D, n_cand, steps, warmup):
     """Full loop-candidate verification per step (RegisterLoopCandidate + VerifyLoopCandidate + ApplyConstratins,
     tbv_slam/src/tbv_slam/loopclosure.cpp:320-384, 261-274): registration, CorAl and CFEAR alignment quality, both
     classifiers; 3 candidates per query node; block-sharded over the ranks, one all_gather of 480-byte records."""
-    import torch
-    from tbv_slam_public_amd import api, synth
-    from tbv_slam_public_amd import dist as cdist
-    ctx = api.Context(D.local_rank, stream=torch.cuda.current_stream().cuda_stream)
-    n_frames = 40
-    sc = synth.Scene(3)
-    gt = np.stack([sc.pose_at(f, n_frames) for f in range(n_frames)])
-    scans, peaks = [], []
-    for f in range(n_frames):
-        r = api.filter_kstrongest(sc.render(f, n_frames), 40, 60, 0.0438, 2.5, want_peaks=True, ctx=ctx)
-        scans.append(api.MapPointNormal(r["xyzi"][0, :int(r["n_points"][0])], 3.0, (0, 0), True, ctx=ctx))
-        peaks.append(torch.from_numpy(np.ascontiguousarray(r["xyzi_peaks"][0, :int(r["n_peaks"][0])])).cuda())   # device-resident
-    rng = np.random.Generator(np.random.PCG64(11))
+    def go():
+        m = verify_measure(D, VerifyWorld(D), n_cand, steps, warmup)
+        return {"metric": "loop-closure candidate verifications/sec (register P2L 4x10 + CorAl + CFEAR quality + classifiers)",
+                "value": m["value"], "unit": "candidates/s", "n_gpus": D.world, "steps": steps,
+                "warmup": max(warmup, 1), "ms_per_step": m["step_ms"], "higher_is_better": True,
+                "scaling": "strong", "vs_baseline": None, "dtype": "f32 search / f64 solve + entropy", "data": "synthetic (scene_v1)",
+                "config": {"workload": "%d loop-closure candidates (3 per query) verified end to end, sharded over %d rank(s), "
+                                       "all_gather of 480-byte records" % (n_cand, D.world), "candidates": n_cand},
+                "reg_ok_fraction": m["reg_ok_fraction"], "accepted_fraction": m["accepted_fraction"],
+                "reference_cpu_ms_per_candidate": "8.3-9.7 Register + 20-22 VerifyByAlignment "
+                                                  "(evaluation/data/oxford_all_tbv_model_8/job_*/time_statistics.txt)"}
+    return _on_side_stream(D, go)
 
-    def rel(a, b):
-        c, s = np.cos(a[2]), np.sin(a[2])
-        d = b[:2] - a[:2]
-        return np.array([c * d[0] + s * d[1], -s * d[0] + c * d[1], b[2] - a[2]])
-    cands = []
-    for q in range(n_cand):
-        i = int(rng.integers(0, n_frames - 7))
-        j = i + int(rng.integers(2, 7))
-        guess = rel(gt[j], gt[i]) + np.concatenate([rng.normal(0, 1.0, 2), rng.normal(0, np.deg2rad(3.0), 1)])
-        cands.append(dict(from_scan=scans[j], to_scan=scans[i], from_peaks=peaks[j], to_peaks=peaks[i], from_pose=gt[j],
-                          t_be_guess=guess, sc_sim=float(rng.uniform(0.05, 0.5)), odom_bounds=float(rng.uniform(0, 0.3)),
-                          group=q // 3))
-    par = api.verify_params(ctx)
-    lo, hi, _per = cdist.shard_range(n_cand, D.world, D.rank)
-    prepared = api.prepare_verify_batch(cands[lo:hi])
-    fn = lambda _local: api.verify_loop_candidates(prepared, par, ctx)
-    for _ in range(max(warmup, 1)):
-        out = cdist.verify_candidates_sharded(cands, fn, par.model_threshold, bool(par.all_candidates), fn_selects=True)
-    D.barrier()
-    t1 = time.perf_counter()
-    for _ in range(steps):
-        out = cdist.verify_candidates_sharded(cands, fn, par.model_threshold, bool(par.all_candidates), fn_selects=True)
-    D.barrier()
-    elapsed = D.max_over_ranks(time.perf_counter() - t1)
-    return {"metric": "loop-closure candidate verifications/sec (register P2L 4x10 + CorAl + CFEAR quality + classifiers)",
-            "value": n_cand * steps / elapsed, "unit": "candidates/s", "n_gpus": D.world, "steps": steps,
-            "warmup": max(warmup, 1), "ms_per_step": elapsed / steps * 1e3, "higher_is_better": True,
-            "scaling": "strong", "vs_baseline": None, "dtype": "f32 search / f64 solve + entropy", "data": "synthetic (scene_v1)",
-            "config": {"workload": "%d loop-closure candidates (3 per query) verified end to end, sharded over %d rank(s), "
-                                   "all_gather of 480-byte records" % (n_cand, D.world), "candidates": n_cand},
-            "reg_ok_fraction": float(out["reg_ok"].mean()), "accepted_fraction": float(out["accepted"].mean()),
-            "reference_cpu_ms_per_candidate": "8.3-9.7 Register + 20-22 VerifyByAlignment "
-                                              "(evaluation/data/oxford_all_tbv_model_8/job_*/time_statistics.txt)"}
+
+def sharded_section(D, n_cand, steps, warmup, world_obj=None):
+    """The workloads north_star SHARDS (loopclosure.cpp:658-721: independent candidates), run by every rank of `bench.py
+    --gpus N` behind the odometry replicas, whatever N: strong = configs[3] as written, n_cand candidates block-partitioned
+    over the N ranks, one all_gather of 72-byte (verification: 480-byte) records; weak = n_cand candidates PER rank (what a
+    chip needs to be full: 512 pairs take 0.13 ms, 4096 take 0.32).  `ranks` is read off the gathered data."""
+    def go():
+        W = world_obj or LoopClosureWorld(D)
+        strong = pipe_measure(D, W, W.candidates(n_cand), steps, warmup)
+        weak = strong if D.world == 1 else pipe_measure(D, W, W.candidates(n_cand * D.world), steps, warmup)
+        V = VerifyWorld(D)
+        vs = verify_measure(D, V, n_cand, max(steps // 2, 2), 2)
+        vw = vs if D.world == 1 else verify_measure(D, V, n_cand * D.world, max(steps // 2, 2), 2)
+        ranks = len(D.gather(D.rank))
+        if world_obj is None:
+            W.close()
+        return {"loopclosure_sharded": {"ranks": ranks, "strong": strong, "weak": weak,
+                                        "path": "cfear_candidate_pipe (C-ABI): ncclAllGather of 72-byte records on the pipe's exchange "
+                                                "stream" if W.comm is not None else "cfear_candidate_pipe, no communicator",
+                                        "unit": "registrations/s (value = candidates of ALL ranks / step; pipelined_value: two steps in flight)"},
+                "verify_sharded": {"ranks": ranks, "strong": vs, "weak": vw,
+                                   "path": "dist.verify_candidates_sharded: torch.distributed all_gather of 480-byte records, "
+                                           "ApplyConstratins after the gather", "unit": "candidates/s"}}
+    return _on_side_stream(D, go)
 
 
 # ---------------------------------------------------------------------------------------------------------
 def dry_run(D, args):
-    """Launcher dry run (no GPU): the ranks rendezvous over gloo, rank 0 prints the line's launch-related keys."""
+    """Launcher dry run (no GPU): the ranks rendezvous over gloo, rank 0 prints the line's launch-related keys.  The sharded
+    step runs too -- partition, padded blocks, ONE all_gather, unpadding (dist.py over gloo) -- with a stand-in for the
+    per-rank compute (the product has no CPU path): record i carries its own candidate index and the rank that produced it."""
+    from tbv_slam_public_amd import _lib as L
+    from tbv_slam_public_amd import dist as cdist
     ranks = D.gather(D.rank)
+
+    def stand_in(n_total):
+        lo, hi, _per = cdist.shard_range(n_total, D.world, D.rank)
+
+        def fn(local):
+            out = np.zeros(len(local), L.RESULT_DTYPE)
+            out["pose"][:, 0] = np.arange(lo, hi)
+            out["pose"][:, 1] = D.rank
+            return out
+        t0 = time.perf_counter()
+        out = cdist.register_candidates_sharded([None] * n_total, fn) if D.dist else fn([None] * n_total)
+        ms = (time.perf_counter() - t0) * 1e3
+        assert (out["pose"][:, 0] == np.arange(n_total)).all(), "gathered records are not in candidate order"
+        return {"candidates": n_total, "candidates_per_rank": (n_total + D.world - 1) // D.world, "step_ms": ms,
+                "value": n_total / (ms * 1e-3), "ranks_seen": int(np.unique(out["pose"][:, 1]).shape[0])}
+    strong, weak = stand_in(args.candidates), stand_in(args.candidates * D.world)
     if D.rank == 0:
         print(json.dumps({"metric": "launcher dry run", "n_gpus": D.world, "rccl_ranks": len(ranks), "ranks": ranks,
-                          "per_rank_value": D.gather(0.0), "backend": "gloo", "steps": args.steps, "warmup": args.warmup}))
+                          "per_rank_value": D.gather(0.0), "backend": "gloo", "steps": args.steps, "warmup": args.warmup,
+                          "loopclosure_sharded": {"ranks": strong["ranks_seen"], "strong": strong, "weak": weak,
+                                                  "path": "dist.register_candidates_sharded over gloo, stand-in compute (dry run)"}}))
     else:
         D.gather(0.0)
     D.close()
@@ -506,6 +623,9 @@ def main(argv=None):
                          "a batch of candidate registrations from cached features, sharded over the ranks "
                          "with one RCCL all_gather of the result records per step")
     ap.add_argument("--candidates", type=int, default=4096)
+    ap.add_argument("--no-sharded", action="store_true",
+                    help="odometry: skip the sharded loop-closure / verification section behind the replicas (a kernel trace of the "
+                         "command then holds the odometry launches only)")
     ap.add_argument("--graph", default=None, help="loopclosure: take the nodes' cached surface points from this simple_graph.sgh "
                                                   "(tools/make_graph.py writes one) instead of featurising synthetic sweeps")
     ap.add_argument("--bins-major", action="store_true",
@@ -536,6 +656,8 @@ def main(argv=None):
     if args.workload in ("loopclosure", "verify"):
         out = (loopclosure_run(D, args.candidates, args.steps, args.warmup, args.graph) if args.workload == "loopclosure"
                else verify_run(D, args.candidates, args.steps, args.warmup))
+        if args.workload == "loopclosure" and not args.graph:
+            out.update(sharded_section(D, args.candidates, args.steps, args.warmup))
         vals = D.gather(out["value"])
         if D.rank == 0:
             out["rccl_ranks"] = len(vals)
@@ -544,6 +666,11 @@ def main(argv=None):
     import torch
     from tbv_slam_public_amd import api
     dev = D.dev
+
+    def note(msg):                                              # progress on stderr (stdout carries the JSON line only)
+        if D.rank == 0:
+            sys.stderr.write("bench.py: %s\n" % msg)
+            sys.stderr.flush()
     B, K, W, FPS = args.streams, args.steps, max(args.warmup, 1), max(args.frames_per_step, 1)
     S, F = min(args.sequences, B), args.ring
     # ---- synthetic input, resident in HBM ------------------------------------------------------------
@@ -620,6 +747,14 @@ def main(argv=None):
     elapsed = D.max_over_ranks(elapsed_local)
     per_rank = D.gather(B * FPS * K / elapsed_local)
     bad_total = sum(D.gather(tot["bad"]))
+    # ---- the workloads that SHARD, on every rank, whatever N (the odometry above is replicas only) -------------------
+    sharded, lc_world = {}, None
+    if not (args.no_sharded or args.no_extras) and D.dist is not None:
+        note("sharded: loop closure + verification over %d rank(s)" % D.world)
+        lc_world = _on_side_stream(D, lambda: LoopClosureWorld(D))
+        sharded = sharded_section(D, args.candidates, 20, 3, lc_world)
+        if D.world > 1:
+            lc_world.close()
     if D.rank != 0:
         return D.close()
 
@@ -676,6 +811,7 @@ def main(argv=None):
         "failed_registrations": int(bad_total),
         "input_generation_s": t_gen,
     }
+    out.update(sharded)
     if D.world > 1:
         return emit(D, out)
 
@@ -684,9 +820,6 @@ def main(argv=None):
     # =====================================================================================================
     od.close()
     skip = set(filter(None, os.environ.get("BENCH_SKIP", "").split(",")))   # debugging: leave extras out (dense,single,host,mulran)
-    def note(msg):                                              # progress on stderr (stdout carries the JSON line only)
-        sys.stderr.write("bench.py: %s\n" % msg)
-        sys.stderr.flush()
     if not args.no_extras and not (args.bins_major or args.keep_nodes or args.cov_sampling):
         # ---- dense rows: every azimuth holds >= k bins >= z_min (N_f ~ 16 000, the reference's upper bound) ----
         if not args.dense and "dense" not in skip:
@@ -848,11 +981,14 @@ def main(argv=None):
         out["config4_cacfar_kvarntorp"] = c4
         # ---- loop-closure candidates from cached features (configs[3]) ---------------------------------------
         note("extra: loopclosure")
-        lc = loopclosure_run(D, args.candidates, 20, 3)
+        lc = loopclosure_run(D, args.candidates, 20, 3, world_obj=lc_world)
         out["loopclosure"] = {k: lc[k] for k in ("value", "unit", "ms_per_step", "ms_per_4096", "ok_fraction", "mean_outer_iters",
-                                                 "fixed_cost_ms", "fixed_cost_kernel_ms", "fixed_overhead_ms", "kernel_ms", "collective",
-                                                 "distinct_scans", "projected_strong_scaling")}
+                                                 "fixed_cost_ms", "fixed_cost_kernel_ms", "fixed_overhead_ms", "kernel_ms", "gather_ms",
+                                                 "pipelined_ms_per_step", "pipelined_value", "graph_slots", "collective",
+                                                 "python_mirror_ms_per_step", "distinct_scans", "projected_strong_scaling")}
         out["loopclosure"]["candidates"] = args.candidates
+    if lc_world is not None:
+        lc_world.close()
 
     # ---- CPU baseline: the oracle (port), 1 thread, bounded sample of the same frames -----------------
     if not args.no_cpu_baseline and not (args.bins_major or args.keep_nodes):

@@ -579,6 +579,12 @@ typedef struct cfear_rccl_comm { cfear_ctx* ctx; void* nccl_comm; int32_t world,
 int cfear_rccl_allgather(void* user /* cfear_rccl_comm* */, const void* send, void* recv_all, size_t bytes_per_rank);
 /* the same collective on DEVICE buffers: enqueued on the communicator's context stream, not synchronised */
 int cfear_rccl_allgather_device(void* user /* cfear_rccl_comm* */, const void* d_send, void* d_recv_all, size_t bytes_per_rank);
+/* A communicator of the library's own making for hosts that have none (librccl.so resolved at run time): rank 0 asks for
+ * the 128-byte id and hands it to its peers by whatever means it has (MPI, a socket, torch.distributed); every rank then
+ * calls cfear_rccl_comm_init with it.  The communicator's collectives run on streams of `ctx`.                          */
+int cfear_rccl_unique_id(char id128[128]);
+int cfear_rccl_comm_init(cfear_ctx* ctx, const char id128[128], int32_t world, int32_t rank, cfear_rccl_comm* out);
+int cfear_rccl_comm_destroy(cfear_rccl_comm* comm);
 int cfear_shard_range(int32_t n, int32_t world, int32_t rank, int32_t* lo, int32_t* hi, int32_t* per_rank);
 /* the gather step alone: local = this rank's hi - lo records; all = n_total records in candidate order */
 int cfear_gather_records(const void* local, int32_t n_total, int32_t record_bytes, int32_t world, int32_t rank,
@@ -586,6 +592,28 @@ int cfear_gather_records(const void* local, int32_t n_total, int32_t record_byte
 int cfear_register_batch_sharded(cfear_ctx* ctx, const cfear_reg_job* jobs, int32_t n_jobs, const cfear_reg_params* par,
                                  int32_t rank, int32_t world, cfear_allgather_fn gather, void* user,
                                  cfear_reg_result* results);
+/* Pipelined steps of a sharded candidate batch (loopclosure.cpp:658-721 hands candidates over as the odometry produces
+ * nodes): a rank's block of an 8-way sharded batch is ~0.13 ms of kernel, so what sits around the kernel decides the
+ * rate.  A pipe keeps up to `depth` steps in flight: submit() stages this rank's block of the FULL candidate list,
+ * enqueues upload -> expand -> matcher on the context's stream and all_gather -> device-to-host copy on the pipe's
+ * exchange stream, and returns without waiting; collect() waits on ONE event and returns all n records in candidate
+ * order (status rules as cfear_register_batch_sharded: every rank enters the collective, every rank returns the first
+ * failed rank's status).  comm = NULL (world 1 only): no collective.  flags & CFEAR_PIPE_GRAPH: the compute chain of a slot
+ * is captured into a hipGraph on its first step and replayed while the block size, the parameters and the context's
+ * workspaces stay the same.  Steps are collected in any order, but a slot (ticket % depth) is free again only after its
+ * collect.  The table must outlive the pipe.                                                                          */
+typedef struct cfear_candidate_pipe cfear_candidate_pipe;
+enum { CFEAR_PIPE_GRAPH = 1, CFEAR_PIPE_TIMING = 2 /* hipEvents around the exchange of every step (measurement) */ };
+int cfear_candidate_pipe_create(cfear_ctx* ctx, const cfear_scan_table* table, int32_t max_candidates, int32_t rank,
+                                int32_t world, const cfear_rccl_comm* comm, int32_t depth, int32_t flags,
+                                cfear_candidate_pipe** out);
+int cfear_candidate_pipe_submit(cfear_candidate_pipe* pipe, const cfear_candidate* candidates, int32_t n_total,
+                                const cfear_reg_params* par, int64_t* ticket);
+int cfear_candidate_pipe_collect(cfear_candidate_pipe* pipe, int64_t ticket, cfear_reg_result* results);
+int cfear_candidate_pipe_destroy(cfear_candidate_pipe* pipe);
+/* measurement: the exchange stream's time (all_gather + read-back, CFEAR_PIPE_TIMING) summed over the collected steps, their
+ * number, and how many slots currently replay a captured graph */
+int cfear_candidate_pipe_stats(const cfear_candidate_pipe* pipe, double* exchange_ms_sum, int64_t* steps_collected, int32_t* graph_slots);
 /* verification: ApplyConstratins (loopclosure.cpp:261-274) is redone over the gathered list, because the candidates
  * of one query may sit on two ranks                                                                             */
 int cfear_verify_loop_candidates_sharded(cfear_ctx* ctx, const cfear_verify_job* jobs, int32_t n_jobs,

@@ -217,7 +217,16 @@ EXPORTS = [
     "cfear_rccl_allgather", "cfear_rccl_allgather_device", "cfear_pgo_params_default", "cfear_pgo_solve",
     "cfear_scan_table_create", "cfear_scan_table_size", "cfear_scan_table_destroy", "cfear_register_candidates",
     "cfear_ctx_get_stream", "cfear_ctx_set_option", "cfear_ctx_get_option",
+    "cfear_rccl_unique_id", "cfear_rccl_comm_init", "cfear_rccl_comm_destroy",
+    "cfear_candidate_pipe_create", "cfear_candidate_pipe_submit", "cfear_candidate_pipe_collect", "cfear_candidate_pipe_destroy", "cfear_candidate_pipe_stats",
 ]
+
+PIPE_GRAPH, PIPE_TIMING = 1, 2      # enum { CFEAR_PIPE_GRAPH, CFEAR_PIPE_TIMING }
+
+
+class RcclComm(C.Structure):        # cfear_rccl_comm
+    _fields_ = [("ctx", C.c_void_p), ("nccl_comm", C.c_void_p), ("world", C.c_int32), ("pad", C.c_int32)]
+
 
 # enum cfear_option (include/cfear_hip.h): test / measurement hooks of a context
 OPT_FUSED_DECODE, OPT_MATCHER_LDS_KB, OPT_MATCHER_WAVES, OPT_HOST_TIMELINE, OPT_COUNT = 0, 1, 2, 3, 4
@@ -387,5 +396,14 @@ def lib():
     L.cfear_acc_vel_sanity_check.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_double)]
     L.cfear_odometry_get_covariance.argtypes = [vp, vp, vp]
     L.cfear_odometry_destroy.argtypes = [vp]
+    L.cfear_rccl_unique_id.argtypes = [vp]
+    L.cfear_rccl_comm_init.argtypes = [vp, vp, C.c_int32, C.c_int32, C.POINTER(RcclComm)]
+    L.cfear_rccl_comm_destroy.argtypes = [C.POINTER(RcclComm)]
+    L.cfear_candidate_pipe_create.argtypes = [vp, vp, C.c_int32, C.c_int32, C.c_int32, C.POINTER(RcclComm), C.c_int32, C.c_int32,
+                                              C.POINTER(vp)]
+    L.cfear_candidate_pipe_submit.argtypes = [vp, vp, C.c_int32, C.POINTER(RegParams), C.POINTER(C.c_int64)]
+    L.cfear_candidate_pipe_collect.argtypes = [vp, C.c_int64, vp]
+    L.cfear_candidate_pipe_destroy.argtypes = [vp]
+    L.cfear_candidate_pipe_stats.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_int32)]
     _LIB = L
     return L

@@ -436,6 +436,81 @@ class ScanTable:
             pass
 
 
+class RcclComm:
+    """cfear_rccl_comm made by the library itself (cfear_rccl_unique_id / cfear_rccl_comm_init): `exchange(b)` hands rank 0's
+    128-byte id to every rank -- any broadcast will do (bench.py uses torch.distributed); world 1 needs none."""
+
+    def __init__(self, ctx, world=1, rank=0, exchange=None):
+        self.ctx = ctx
+        lib = ctx._lib
+        uid = C.create_string_buffer(128)
+        if rank == 0:
+            rc = lib.cfear_rccl_unique_id(uid)
+            if rc != L.OK:
+                raise L.CfearError(rc, "librccl.so / ncclGetUniqueId not available")
+        if world > 1:
+            raw = exchange(bytes(uid.raw))
+            assert len(raw) == 128
+            uid = C.create_string_buffer(raw, 128)
+        self.c = L.RcclComm()
+        ctx.check(lib.cfear_rccl_comm_init(ctx.h, uid, int(world), int(rank), C.byref(self.c)))
+        self.world, self.rank = int(world), int(rank)
+
+    def close(self):
+        if getattr(self, "c", None) is not None and self.c.nccl_comm:
+            self.ctx._lib.cfear_rccl_comm_destroy(C.byref(self.c))
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class CandidatePipe:
+    """cfear_candidate_pipe: up to `depth` sharded candidate steps in flight (submit never waits, collect waits on one event);
+    every rank hands in the FULL candidate list and gets all n records back in candidate order."""
+
+    def __init__(self, reg, table, max_candidates, comm=None, rank=0, world=1, depth=2, graph=False, timing=False):
+        self.reg, self.table, self.ctx, self.comm = reg, table, reg.ctx, comm
+        self._h = C.c_void_p()
+        self.ctx.check(self.ctx._lib.cfear_candidate_pipe_create(self.ctx.h, table._h, int(max_candidates), int(rank), int(world),
+                                                                 C.byref(comm.c) if comm is not None else None, int(depth),
+                                                                 (L.PIPE_GRAPH if graph else 0) | (L.PIPE_TIMING if timing else 0),
+                                                                 C.byref(self._h)))
+        self.depth = int(depth)
+
+    def stats(self):
+        """{exchange_ms: all_gather + read-back summed over the collected steps (timing=True), steps, graph_slots}"""
+        ms, n, g = C.c_double(), C.c_int64(), C.c_int32()
+        self.ctx.check(self.ctx._lib.cfear_candidate_pipe_stats(self._h, C.byref(ms), C.byref(n), C.byref(g)))
+        return {"exchange_ms": float(ms.value), "steps": int(n.value), "graph_slots": int(g.value)}
+
+    def submit(self, cands):
+        cands = np.ascontiguousarray(cands, dtype=L.CANDIDATE_DTYPE)
+        t = C.c_int64()
+        self.ctx.check(self.ctx._lib.cfear_candidate_pipe_submit(self._h, C.c_void_p(cands.ctypes.data), cands.shape[0],
+                                                                 C.byref(self.reg.par), C.byref(t)))
+        return (int(t.value), cands.shape[0])
+
+    def collect(self, ticket, out=None):
+        t, n = ticket
+        out = np.empty(n, L.RESULT_DTYPE) if out is None else out
+        self.ctx.check(self.ctx._lib.cfear_candidate_pipe_collect(self._h, t, C.c_void_p(out.ctypes.data)))
+        return out
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.ctx._lib.cfear_candidate_pipe_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class n_scan_normal_reg:
     """n_scan_normal_reg(cost, loss=Huber, loss_limit=0.1, opt=Uniform) (n_scan_normal.h:35)."""
 

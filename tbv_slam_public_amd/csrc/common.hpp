@@ -32,7 +32,7 @@ struct cfear_ctx {
   std::vector<hipEvent_t> event_pool;
   // grow-only device workspaces (indexed by purpose so stages of one pipeline do not alias)
   struct Ws { void* p = nullptr; size_t bytes = 0; };
-  Ws ws[13];
+  Ws ws[16];
   // pinned host staging for small read-backs
   void* pinned = nullptr;
   size_t pinned_bytes = 0;

@@ -1600,8 +1600,10 @@ struct cfear_scan_table {
 namespace {
 // candidate -> the job record matcher_kernel reads: scans {target, source}, poses {target, source guess}
 __global__ __launch_bounds__(256) void expand_candidates_kernel(const ScanView* __restrict__ views, const cfear_candidate* __restrict__ cands,
-                                                                int n, char* __restrict__ jobs, size_t stride) {
+                                                                int n, char* __restrict__ jobs, size_t stride, int32_t* __restrict__ trailer,
+                                                                int trailer_status) {
   const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i == 0 && trailer) { trailer[0] = trailer_status; trailer[1] = n; }   // the sharded step's {rank status, records} (shard.hip)
   if (i >= n) return;
   const cfear_candidate c = cands[i];
   RegJob* j = (RegJob*)(jobs + (size_t)i * stride);
@@ -1654,19 +1656,17 @@ extern "C" int cfear_scan_table_destroy(cfear_scan_table* t) {
   return CFEAR_OK;
 }
 
-extern "C" int cfear_register_candidates(cfear_ctx* ctx, const cfear_scan_table* table, const cfear_candidate* cands, int32_t n,
-                                         const cfear_reg_params* par, cfear_reg_result* results) {
-  if (!ctx) return CFEAR_ERR_INVALID_ARGUMENT;
-  if (!table || !results || n < 0 || (n > 0 && !cands)) return cfear_set_error(ctx, CFEAR_ERR_INVALID_ARGUMENT, "null argument");
+// The enqueue half of a candidate batch: validates the candidates while it copies them into `h_stage` (pinned, n records, owned
+// by the caller until the upload has run), uploads them, expands them into job records and launches the matcher with its
+// records going to d_res (device).  Nothing is synchronised.  d_trailer (optional, device int32[2]) receives {trailer_status, n}
+// from the expand kernel -- the status trailer of a sharded step travels behind the block without an enqueue of its own.
+int cfear_candidates_enqueue(cfear_ctx* ctx, const cfear_scan_table* table, const cfear_candidate* cands, int32_t n,
+                             const cfear_reg_params* par, cfear_candidate* h_stage, cfear_reg_result* d_res, int32_t* d_trailer,
+                             int trailer_status) {
   if (table->ctx != ctx) return cfear_set_error(ctx, CFEAR_ERR_INVALID_ARGUMENT, "table belongs to another context");
-  int rc = check_params(ctx, par);
-  if (rc != CFEAR_OK || n == 0) return rc;
-  CFEAR_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   const int nt = (int)table->n_cells.size();
   const size_t stride = reg_job_stride(2);
-  const size_t cb = (size_t)n * sizeof(cfear_candidate), jb = (size_t)n * stride, rb = (size_t)n * sizeof(cfear_reg_result);
-  cfear_candidate* hc = (cfear_candidate*)cfear_pinned(ctx, cb);
-  if (!hc) return cfear_set_error(ctx, CFEAR_ERR_HIP, "pinned staging allocation failed");
+  const size_t cb = (size_t)n * sizeof(cfear_candidate), jb = (size_t)n * stride;
   JobSizes sz;
   sz.cost = par->cost; sz.huber = par->loss == CFEAR_LOSS_HUBER;
   int max_tar = 0, max_src = 0;
@@ -1676,29 +1676,48 @@ extern "C" int cfear_register_candidates(cfear_ctx* ctx, const cfear_scan_table*
       return cfear_set_error(ctx, CFEAR_ERR_INVALID_ARGUMENT, "candidate %d refers to scan %d / %d of a table of %d", i, c.target, c.source, nt);
     max_tar = std::max(max_tar, table->n_cells[(size_t)c.target]);
     max_src = std::max(max_src, table->n_cells[(size_t)c.source]);
-    hc[i] = c;
+    h_stage[i] = c;
   }
   // the launch geometry from the LARGEST target and source of the batch (a pair's needs grow with both: if that pair fits a
   // form, every candidate does) -- one evaluation per batch, not per candidate (4096 candidates: 0.1 ms of host time)
   sz.add(2, scan_grid_pad(max_tar), scan_grid_pad(max_tar), max_src);
-  const size_t c_off = (jb + 255) / 256 * 256, r_off = c_off + (cb + 255) / 256 * 256;
-  char* ws = (char*)cfear_workspace(ctx, 6, r_off + rb + 512);
+  const size_t c_off = (jb + 255) / 256 * 256;
+  char* ws = (char*)cfear_workspace(ctx, 6, c_off + cb + 512);
   char* scr = (char*)cfear_workspace(ctx, 7, reg_scratch_bytes(sz.pairs_cap) * (size_t)n);
   if (!ws || !scr) return cfear_set_error(ctx, CFEAR_ERR_HIP, "workspace allocation failed");
-  const bool dev_out = cfear_is_device_ptr(results);
-  cfear_reg_result* d_res = dev_out ? results : (cfear_reg_result*)(ws + r_off);
-  CFEAR_HIP_CHECK(ctx, hipMemcpyAsync(ws + c_off, hc, cb, hipMemcpyHostToDevice, ctx->stream));
-  if (dev_out) cfear_pinned_mark(ctx);                      // (no synchronisation below: the staging buffer stays in use)
+  CFEAR_HIP_CHECK(ctx, hipMemcpyAsync(ws + c_off, h_stage, cb, hipMemcpyHostToDevice, ctx->stream));
   hipLaunchKernelGGL(expand_candidates_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, (const ScanView*)table->d_views,
-                     (const cfear_candidate*)(ws + c_off), n, ws, stride);
+                     (const cfear_candidate*)(ws + c_off), n, ws, stride, d_trailer, trailer_status);
   CFEAR_HIP_CHECK(ctx, hipGetLastError());
-  rc = cfear_register_launch(ctx, ws, n, par, sz.pairs_cap, scr, d_res, nullptr, stride, sz.hint(n));
+  return cfear_register_launch(ctx, ws, n, par, sz.pairs_cap, scr, d_res, nullptr, stride, sz.hint(n));
+}
+
+extern "C" int cfear_register_candidates(cfear_ctx* ctx, const cfear_scan_table* table, const cfear_candidate* cands, int32_t n,
+                                         const cfear_reg_params* par, cfear_reg_result* results) {
+  if (!ctx) return CFEAR_ERR_INVALID_ARGUMENT;
+  if (!table || !results || n < 0 || (n > 0 && !cands)) return cfear_set_error(ctx, CFEAR_ERR_INVALID_ARGUMENT, "null argument");
+  int rc = check_params(ctx, par);
+  if (rc != CFEAR_OK || n == 0) return rc;
+  CFEAR_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  const size_t cb = (size_t)n * sizeof(cfear_candidate), rb = (size_t)n * sizeof(cfear_reg_result);
+  cfear_candidate* hc = (cfear_candidate*)cfear_pinned(ctx, cb);
+  if (!hc) return cfear_set_error(ctx, CFEAR_ERR_HIP, "pinned staging allocation failed");
+  const bool dev_out = cfear_is_device_ptr(results);
+  cfear_reg_result* d_res = results;
+  if (!dev_out) {
+    d_res = (cfear_reg_result*)cfear_workspace(ctx, 13, rb);
+    if (!d_res) return cfear_set_error(ctx, CFEAR_ERR_HIP, "workspace allocation failed");
+  }
+  rc = cfear_candidates_enqueue(ctx, table, cands, n, par, hc, d_res, nullptr, 0);
+  if (dev_out) cfear_pinned_mark(ctx);                      // (no synchronisation below: the staging buffer stays in use)
   if (rc != CFEAR_OK) { (void)hipStreamSynchronize(ctx->stream); return rc; }
   if (dev_out) return CFEAR_OK;
   CFEAR_HIP_CHECK(ctx, hipMemcpyAsync(results, d_res, rb, hipMemcpyDeviceToHost, ctx->stream));
   CFEAR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   return CFEAR_OK;
 }
+
+int cfear_check_reg_params(cfear_ctx* ctx, const cfear_reg_params* par) { return check_params(ctx, par); }
 
 extern "C" int cfear_register(cfear_ctx* ctx, const cfear_scan* const* scans, int32_t n_scans, double* poses_xyt,
                               const cfear_reg_params* par, cfear_reg_result* result) {

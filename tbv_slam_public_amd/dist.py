@@ -78,9 +78,8 @@ def _gather_records(local, n, group):
     dev = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
     rec = local.dtype.itemsize
     b = _buffers(per * rec, world, dev)
-    sh = b["send_h"].numpy()
+    sh = b["send_h"].numpy()                            # (zeroed when it was made; padding slots are never returned)
     sh[:(hi - lo) * rec] = local.view(np.uint8).reshape(-1)
-    sh[(hi - lo) * rec:] = 0                            # padding slots are never returned
     if dev.type == "cuda":
         b["send_d"].copy_(b["send_h"], non_blocking=True)
         dist.all_gather_into_tensor(b["recv_d"], b["send_d"], group=group)
@@ -111,11 +110,7 @@ def register_candidates_sharded(jobs, register_fn, group=None):
         rec = L.RESULT_DTYPE.itemsize
         dev = torch.device("cuda", torch.cuda.current_device())
         b = _buffers(per * rec, world, dev)
-        send = b["send_d"]
-        if hi - lo < per:
-            send[(hi - lo) * rec:].zero_()               # padding slots are never returned
-            if not register_fn.ctx.shares_torch_stream():
-                torch.cuda.current_stream().synchronize()    # (the library writes on its own stream)
+        send = b["send_d"]                               # (zeroed when it was made; padding slots are never returned)
         got = register_fn.into(jobs[lo:hi], send.data_ptr())
         assert got == hi - lo
         # The collective is enqueued on torch's current stream.  When the context enqueues on that very stream (a context

@@ -195,6 +195,12 @@ def test_bench_launcher_starts_the_ranks_itself():
     out = json.loads(line)
     assert out["n_gpus"] == 2 and out["rccl_ranks"] == 2 and out["ranks"] == [0.0, 1.0] and out["steps"] == 7
     assert len(out["per_rank_value"]) == 2
+    # the sharded workloads are part of the line at every N: strong = 4096 candidates over the ranks, weak = 4096 per rank;
+    # `ranks` is read off the gathered records (which rank produced each), not off the launcher's environment
+    sh = out["loopclosure_sharded"]
+    assert sh["ranks"] == 2
+    assert sh["strong"]["candidates"] == 4096 and sh["strong"]["candidates_per_rank"] == 2048
+    assert sh["weak"]["candidates"] == 8192 and sh["weak"]["candidates_per_rank"] == 4096
 
 
 def test_bench_refuses_more_gpus_than_visible():

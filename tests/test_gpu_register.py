@@ -709,3 +709,66 @@ def test_python_sharded_path_runs_the_collective_at_world_one():
     finally:
         dist.destroy_process_group()
     np.testing.assert_array_equal(out, ref)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("graph", [False, True])
+@pytest.mark.parametrize("with_comm", [False, True])
+def test_candidate_pipe_equals_register_candidates(graph, with_comm):
+    """cfear_candidate_pipe (the sharded loop-closure step kept in flight: upload -> expand -> matcher on the context's stream,
+    ncclAllGather + read-back on the exchange stream) returns byte for byte what cfear_register_candidates returns -- direct
+    launches and the captured hipGraph, with and without a one-rank ncclComm_t, steps collected in and out of order, batches
+    whose contents and sizes change between steps (a replayed graph must read the NEW candidates; another size re-captures)."""
+    from tbv_slam_public_amd import api, _lib as L
+    cells, gt = _cells(6, [0, 1, 2, 3, 4])
+    ctx = api.Context(0)                                            # a stream of its own (the legacy stream cannot be captured)
+    scans = [api.MapPointNormal(cells=c, ctx=ctx) for c in cells]
+    table = api.ScanTable(scans, ctx=ctx)
+    reg = api.n_scan_normal_reg("P2L", ctx=ctx)
+    reg.SetParameters(4, 10)
+    comm = None
+    if with_comm:
+        _rccl()                                                     # (skips without librccl)
+        comm = api.RcclComm(reg.ctx, 1, 0)
+    rng = np.random.default_rng(8)
+
+    def batch(n):
+        tgt, src = rng.integers(0, 5, n), rng.integers(0, 5, n)
+        src = np.where(src == tgt, (src + 1) % 5, src)
+        guess = np.stack([gt[b] - gt[a] for a, b in zip(tgt, src)]) + rng.normal(0, 0.3, (n, 3)) * [1, 1, 0.05]
+        return api.ScanTable.candidates(tgt, src, guess)
+    pipe = api.CandidatePipe(reg, table, 700, comm, 0, 1, depth=3, graph=graph, timing=True)
+    batches = [batch(n) for n in (600, 600, 600, 600, 40, 600, 1, 700)]
+    refs = [reg.RegisterCandidates(table, b) for b in batches]
+    # in order, one at a time
+    for b, r in zip(batches, refs):
+        assert pipe.collect(pipe.submit(b)).tobytes() == r.tobytes()
+    # three in flight, collected out of order
+    for k in range(0, 6, 3):
+        tk = [pipe.submit(b) for b in batches[k:k + 3]]
+        for q in (1, 0, 2):
+            assert pipe.collect(tk[q]).tobytes() == refs[k + q].tobytes()
+    st = pipe.stats()
+    assert st["steps"] == 14 and st["exchange_ms"] > 0.0
+    assert st["graph_slots"] == (3 if graph else 0)
+    # a fourth step without a collect is refused, the pipe stays usable
+    tk = [pipe.submit(batches[0]) for _ in range(3)]
+    with pytest.raises(L.CfearError) as e:
+        pipe.submit(batches[0])
+    assert e.value.status == L.ERR_INVALID_ARGUMENT
+    for t in tk:
+        assert pipe.collect(t).tobytes() == refs[0].tobytes()
+    # a candidate outside the table fails THAT step (the rank still enters the exchange); the next step is fine
+    bad = batches[4].copy()
+    bad["source"][3] = 99
+    t = pipe.submit(bad)
+    with pytest.raises(L.CfearError) as e:
+        pipe.collect(t)
+    assert e.value.status == L.ERR_INVALID_ARGUMENT
+    assert pipe.collect(pipe.submit(batches[4])).tobytes() == refs[4].tobytes()
+    # an empty batch
+    assert pipe.collect(pipe.submit(batches[0][:0])).shape[0] == 0
+    pipe.close()
+    if comm is not None:
+        comm.close()
+    table.close()
