@@ -184,7 +184,7 @@ def make_rings(n_seq, ring, seed0, dev, dense=False):
     rings = torch.empty((n_seq, ring, ROWS, COLS), dtype=torch.uint8, device=dev)
     kw = dict(synth.DENSE_KW) if dense else {}
     for s in range(n_seq):
-        sc = synth.Scene(seed0 + s, circle_frames=ring, **kw)
+        sc = synth.Scene(seed0 + s, circle_frames=ring, cols=COLS, **kw)
         rings[s] = synth.render_frames_torch(sc, list(range(ring)), dev)
     torch.cuda.synchronize()
     return rings
@@ -612,6 +612,9 @@ def main(argv=None):
                          "share of the uneven last registrations of a batch: +6 %% registrations/s at twice the batch latency)")
     ap.add_argument("--sequences", type=int, default=256, help="distinct synthetic worlds per GPU (streams = worlds x start frames)")
     ap.add_argument("--ring", type=int, default=64, help="frames of the closed circle every world is rendered along")
+    ap.add_argument("--cols", type=int, default=COLS,
+                    help="range bins per azimuth (BASELINE metric: 3360 = MulRan's native width; Oxford's native sweeps are 3768 wide, "
+                         "radar_filters.cpp:49-52 -- rows then start off the 16-byte grid); every R*C figure of the line follows it")
     ap.add_argument("--cpu-frames", type=int, default=0, help="frames of CPU baseline (0 = auto, ~10-30 s)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true",
@@ -644,6 +647,8 @@ def main(argv=None):
                          "FUSED_DECODE=0, MATCHER_LDS_KB=52) applied to every context this run creates")
     ap.add_argument("--dry-run", action="store_true", help="launcher test without GPUs: ranks rendezvous over gloo and exit")
     args = ap.parse_args(argv)
+    global COLS, IMG
+    COLS, IMG = int(args.cols), ROWS * int(args.cols)
     maybe_self_launch(args, argv)
     D = Dist(args)
     if args.dry_run:
@@ -778,7 +783,7 @@ def main(argv=None):
         roof["traffic"] = None
 
     out = {
-        "metric": "radar scan registrations/sec (400x3360 polar)",
+        "metric": "radar scan registrations/sec (400x%d polar)" % COLS,
         "value": value,
         "unit": "registrations/s",
         "n_gpus": D.world,
@@ -903,7 +908,7 @@ def main(argv=None):
             Fs = F                                               # the whole closed lap: frame Fs continues into frame 0
             sr = torch.empty((Ss, Fs, ROWS, COLS), dtype=torch.uint8, device=dev)
             for q in range(Ss):
-                scn = synth.Scene(seed0 + q, circle_frames=F, range_res=range_res, ccw=True, **(scene_kw or {}))
+                scn = synth.Scene(seed0 + q, circle_frames=F, range_res=range_res, ccw=True, cols=COLS, **(scene_kw or {}))
                 sr[q] = synth.render_frames_torch(scn, list(range(Fs)), dev)
             sod = api.OdometryKeyframeFuser(Bs, COLS if bins_major else ROWS, ROWS if bins_major else COLS, params, ctx=ctx)
             seq = torch.arange(Bs, device=dev) % Ss

@@ -28,7 +28,7 @@ def _run(seeds, n_frames, device_input, **kw):
     from tbv_slam_public_amd import api, synth
     seqs = [synth.scene_v1(sd, n_frames, **kw.get("scene", {}))[0] for sd in seeds]
     par = api.odometry_params(**kw.get("par", {}))
-    od = api.OdometryKeyframeFuser(len(seeds), 400, 3360, par)
+    od = api.OdometryKeyframeFuser(len(seeds), 400, seqs[0].shape[2], par)
     exp = [_oracle_sequence(seq, par.kstrong.k_strongest, par.kstrong.z_min, par.kstrong.range_res,
                             par.reg.cost, par.reg.loss, par.reg.weight_opt, par.res, par.submap_scan_size,
                             bool(par.weight_intensity), bool(par.radar_ccw)) for seq in seqs]
@@ -61,6 +61,14 @@ def test_cfear3_oxford_two_streams_host_input():
 
 def test_cfear3_oxford_device_input():
     _run([2], 8, True)
+
+
+@pytest.mark.parametrize("device_input", [False, True])
+def test_cfear3_oxford_native_width(device_input):
+    """Oxford sweeps are 400 x 3768 (radar_filters.cpp:49-52, radar_driver.cpp:48-73): a row length that is NOT a multiple of
+    16, so every second row starts 8 bytes off the 16-byte grid -- the fused key route of the sweep, surface_prep's row walk and
+    the prefetch of the next frame all see misaligned rows.  Two streams, ten frames, host and device input, per-frame parity."""
+    _run([0, 1], 10, device_input, scene=dict(cols=3768))
 
 
 def test_cfear1_p2l_single_keyframe():
