@@ -599,6 +599,7 @@ def dry_run(D, args):
 
 
 def main(argv=None):
+    global COLS, IMG
     argv = sys.argv[1:] if argv is None else argv
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -612,7 +613,7 @@ def main(argv=None):
                          "share of the uneven last registrations of a batch: +6 %% registrations/s at twice the batch latency)")
     ap.add_argument("--sequences", type=int, default=256, help="distinct synthetic worlds per GPU (streams = worlds x start frames)")
     ap.add_argument("--ring", type=int, default=64, help="frames of the closed circle every world is rendered along")
-    ap.add_argument("--cols", type=int, default=COLS,
+    ap.add_argument("--cols", type=int, default=3360,
                     help="range bins per azimuth (BASELINE metric: 3360 = MulRan's native width; Oxford's native sweeps are 3768 wide, "
                          "radar_filters.cpp:49-52 -- rows then start off the 16-byte grid); every R*C figure of the line follows it")
     ap.add_argument("--cpu-frames", type=int, default=0, help="frames of CPU baseline (0 = auto, ~10-30 s)")
@@ -647,7 +648,6 @@ def main(argv=None):
                          "FUSED_DECODE=0, MATCHER_LDS_KB=52) applied to every context this run creates")
     ap.add_argument("--dry-run", action="store_true", help="launcher test without GPUs: ranks rendezvous over gloo and exit")
     args = ap.parse_args(argv)
-    global COLS, IMG
     COLS, IMG = int(args.cols), ROWS * int(args.cols)
     maybe_self_launch(args, argv)
     D = Dist(args)
