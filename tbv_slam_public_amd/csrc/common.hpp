@@ -225,6 +225,7 @@ int cfear_coral_collect(cfear_ctx* ctx, const cfear_coral_job* jobs, const Coral
 struct RegLaunchHint {
   bool small_pairs = false;   // every job is a two-scan candidate that fits 20 KB of LDS: the 2-wavefront form, eight per CU
   bool big_pass = false;      // registrations the regular form is not good at may be among them (dense scans): add the large forms
+  bool whole_cu = false;      // cost-only launches: a job that does not fit half a CU's LDS is among them
 };
 int cfear_register_launch(cfear_ctx* ctx, const void* d_jobs, int n_jobs, const cfear_reg_params* par, int pairs_cap,
                           char* d_scratch, cfear_reg_result* d_results, const RegCostMode* mode = nullptr,

@@ -608,8 +608,21 @@ extern "C" void cfear_coral_params_default(cfear_coral_params* p) {
 // The batch in two halves, so that a caller with host work of its own (verify.hip) can do it while the kernel runs:
 // cfear_coral_enqueue stages the clouds, uploads the jobs and launches; cfear_coral_collect reads the results back and
 // synchronises.  `pend` carries what must outlive the launch.
+static int coral_enqueue_impl(cfear_ctx* ctx, const cfear_coral_job* jobs, int32_t n_jobs, const cfear_coral_params* par, bool want_per_point,
+                              CoralPending& pend);
+
+// The enqueue half may leave asynchronous copies FROM pageable host memory in flight (pend.host_jobs, the caller's peak
+// clouds): when it fails behind the first of them the stream is drained before the error returns, so that whoever destroys
+// `pend` or the clouds next does not pull them from under a copy (collect() is the only other place that waits).
 int cfear_coral_enqueue(cfear_ctx* ctx, const cfear_coral_job* jobs, int32_t n_jobs, const cfear_coral_params* par, bool want_per_point,
                         CoralPending& pend) {
+  const int rc = coral_enqueue_impl(ctx, jobs, n_jobs, par, want_per_point, pend);
+  if (rc != CFEAR_OK) (void)hipStreamSynchronize(ctx->stream);
+  return rc;
+}
+
+static int coral_enqueue_impl(cfear_ctx* ctx, const cfear_coral_job* jobs, int32_t n_jobs, const cfear_coral_params* par, bool want_per_point,
+                              CoralPending& pend) {
   pend.n_jobs = 0;
   if (!ctx) return CFEAR_ERR_INVALID_ARGUMENT;
   if (!jobs || !par || n_jobs < 0) return cfear_set_error(ctx, CFEAR_ERR_INVALID_ARGUMENT, "null argument");

@@ -1143,8 +1143,15 @@ __global__ __launch_bounds__(NW * 64, WIDE ? 2 : ((NW == 4 && LOSS < 0) ? 3 : 4)
   }
   REG_TACC(9);
   if (!ok) {
-    if (cm.final_launch) {                                  // nothing behind this launch: report it
-      for (int sidx = blockIdx.y * NT + (int)threadIdx.x; sidx < m_out; sidx += (int)gridDim.y * NT) write_capacity(res + sidx, job.poses[last]);
+    if (cm.final_launch) {                                  // nothing behind this launch: report it -- and whether the largest
+      // form (a whole CU's LDS, the match table in global scratch) would hold it: a caller that launched without the large
+      // forms (RegLaunchHint::big_pass off) launches again with them (odometry.hip)
+      const double larger = (mt_fit((uint32_t)(160 * 1024 - 256 - kPartBigBytes), last, sum_pad, max_pad, n_src, cm.dense_fields, true).can &&
+                             sz.grids_ok && n_pairs <= cm.pairs_cap && lds_eff < 160u * 1024u - 256u - (uint32_t)kPartBigBytes) ? 1.0 : 0.0;
+      for (int sidx = blockIdx.y * NT + (int)threadIdx.x; sidx < m_out; sidx += (int)gridDim.y * NT) {
+        write_capacity(res + sidx, job.poses[last]);
+        res[sidx].reserved = larger;
+      }
     } else if (threadIdx.x == 0) { res->status = kRegDeferred; res->reserved = 0.0; }
     return;
   }
@@ -1467,7 +1474,12 @@ int cfear_register_launch(cfear_ctx* ctx, const void* d_jobs, int n_jobs, const 
   const int by = mode ? std::max(mode->blocks_per_job, 1) : 1;
   Form f0 = first_form(ctx, n_jobs * by, huber, hint.small_pairs, hint.big_pass);
   if (mode) {                                                // cost-only launches come with 4 or 8 wavefronts
-    if (hint.big_pass && f0.nw < 8) { f0.nw = 8; f0.lds = kLdsCu / 2 - 256; }   // cost sampling while dense scans show up
+    // A job beyond half a CU's LDS among them (the host's marshalling saw its sizes): ONE launch of the 8-wavefront form with the CU's whole LDS, i.e. the capacity of
+    // the full registrations' last form (a deferred chain like theirs would race here: the workgroups that share a job's
+    // samples all read the job's first record to see whether it was deferred while the first of them already overwrites it) --
+    // GetCost / cost sampling / CFEAR quality of a pair that Register holds no longer come back as CFEAR_ERR_CAPACITY
+    if (hint.whole_cu) { f0.nw = 8; f0.lds = kLdsCu - 256; }
+    else if (hint.big_pass && f0.nw < 8) { f0.nw = 8; f0.lds = kLdsCu / 2 - 256; }   // cost sampling while dense scans show up
     if (f0.nw == 2) { f0.nw = 4; f0.lds = std::max(f0.lds, regular_lds(huber)); }
     f0.nw = f0.nw <= 4 ? 4 : 8;
   }
@@ -1502,14 +1514,15 @@ namespace {
 // what the host learns about a batch while it marshals it: the scratch size and which forms its registrations want
 struct JobSizes {
   int pairs_cap = 1, cost = CFEAR_P2L;
-  bool huber = true, small_pairs = true, any_large = false;
+  bool huber = true, small_pairs = true, any_large = false, any_huge = false;
   void add(int n_scans, int sum_pad, int max_pad, int n_src) {
     const int last = n_scans - 1, fields = reg_dense_fields(cost);
     pairs_cap = std::max(pairs_cap, last * std::max(n_src, 1));
+    any_huge = any_huge || !mt_fit((uint32_t)(kLdsCu / 2 - 256 - kPartBigBytes), last, sum_pad, max_pad, n_src, fields, true).can;
     small_pairs = small_pairs && n_scans == 2 && mt_fit(kLdsPairs, last, sum_pad, max_pad, n_src, fields, false).good;
     any_large = any_large || !mt_fit(regular_lds(huber), last, sum_pad, max_pad, n_src, fields, false).good;
   }
-  RegLaunchHint hint(int n_jobs) const { RegLaunchHint h; h.small_pairs = small_pairs && n_jobs > 0; h.big_pass = any_large; return h; }
+  RegLaunchHint hint(int n_jobs) const { RegLaunchHint h; h.small_pairs = small_pairs && n_jobs > 0; h.big_pass = any_large; h.whole_cu = any_huge; return h; }
 };
 
 int gather_job(cfear_ctx* ctx, const cfear_scan* const* scans, int n_scans, const double* poses, unsigned char* dst, JobSizes& sz) {
@@ -1656,8 +1669,8 @@ extern "C" int cfear_scan_table_destroy(cfear_scan_table* t) {
   return CFEAR_OK;
 }
 
-// The enqueue half of a candidate batch: validates the candidates while it copies them into `h_stage` (pinned, n records, owned
-// by the caller until the upload has run), uploads them, expands them into job records and launches the matcher with its
+// The enqueue half of a candidate batch: validates the candidates while it copies them into `h_stage` (PINNED host memory, n
+// records, owned by the caller until the expand kernel has run), expands them into job records and launches the matcher with its
 // records going to d_res (device).  Nothing is synchronised.  d_trailer (optional, device int32[2]) receives {trailer_status, n}
 // from the expand kernel -- the status trailer of a sharded step travels behind the block without an enqueue of its own.
 int cfear_candidates_enqueue(cfear_ctx* ctx, const cfear_scan_table* table, const cfear_candidate* cands, int32_t n,
@@ -1666,7 +1679,7 @@ int cfear_candidates_enqueue(cfear_ctx* ctx, const cfear_scan_table* table, cons
   if (table->ctx != ctx) return cfear_set_error(ctx, CFEAR_ERR_INVALID_ARGUMENT, "table belongs to another context");
   const int nt = (int)table->n_cells.size();
   const size_t stride = reg_job_stride(2);
-  const size_t cb = (size_t)n * sizeof(cfear_candidate), jb = (size_t)n * stride;
+  const size_t jb = (size_t)n * stride;
   JobSizes sz;
   sz.cost = par->cost; sz.huber = par->loss == CFEAR_LOSS_HUBER;
   int max_tar = 0, max_src = 0;
@@ -1681,13 +1694,13 @@ int cfear_candidates_enqueue(cfear_ctx* ctx, const cfear_scan_table* table, cons
   // the launch geometry from the LARGEST target and source of the batch (a pair's needs grow with both: if that pair fits a
   // form, every candidate does) -- one evaluation per batch, not per candidate (4096 candidates: 0.1 ms of host time)
   sz.add(2, scan_grid_pad(max_tar), scan_grid_pad(max_tar), max_src);
-  const size_t c_off = (jb + 255) / 256 * 256;
-  char* ws = (char*)cfear_workspace(ctx, 6, c_off + cb + 512);
+  char* ws = (char*)cfear_workspace(ctx, 6, jb + 512);
   char* scr = (char*)cfear_workspace(ctx, 7, reg_scratch_bytes(sz.pairs_cap) * (size_t)n);
   if (!ws || !scr) return cfear_set_error(ctx, CFEAR_ERR_HIP, "workspace allocation failed");
-  CFEAR_HIP_CHECK(ctx, hipMemcpyAsync(ws + c_off, h_stage, cb, hipMemcpyHostToDevice, ctx->stream));
+  // no upload: h_stage is pinned, i.e. mapped into the device's address space -- the expand kernel reads the 56-byte records
+  // over PCIe itself (one copy engine round trip less in a chain whose kernel takes 0.07 - 0.3 ms)
   hipLaunchKernelGGL(expand_candidates_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, (const ScanView*)table->d_views,
-                     (const cfear_candidate*)(ws + c_off), n, ws, stride, d_trailer, trailer_status);
+                     (const cfear_candidate*)h_stage, n, ws, stride, d_trailer, trailer_status);
   CFEAR_HIP_CHECK(ctx, hipGetLastError());
   return cfear_register_launch(ctx, ws, n, par, sz.pairs_cap, scr, d_res, nullptr, stride, sz.hint(n));
 }

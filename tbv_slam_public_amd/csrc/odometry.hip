@@ -709,13 +709,13 @@ static int process_frame(cfear_odometry* od, const uint8_t* polar, const uint8_t
     OD_CHECK(hipEventRecord(od->ev_jobs, od->copy_stream));
   }
   g_tl.mark(1);
-  if (n_jobs > 0) {
-    OD_CHECK(hipStreamWaitEvent(ctx->stream, od->ev_jobs, 0));
+  // the matcher over this frame's jobs (+ the cost samples around its results); big_pass adds the large forms
+  auto launch_register = [&](bool big_pass) -> int {
     RegLaunchHint hint;
-    hint.big_pass = od->big_regs > 0;
-    rc = cfear_register_launch(ctx, od->d_reg_jobs, n_jobs, &par.reg, par.submap_scan_size * od->cell_cap,
-                               od->d_reg_scratch, od->d_results, nullptr, rjb, hint);
-    if (rc != CFEAR_OK) return fail(rc);
+    hint.big_pass = big_pass;
+    int lrc = cfear_register_launch(ctx, od->d_reg_jobs, n_jobs, &par.reg, par.submap_scan_size * od->cell_cap,
+                                    od->d_reg_scratch, od->d_results, nullptr, rjb, hint);
+    if (lrc != CFEAR_OK) return lrc;
     if (par.estimate_cov_by_sampling) {
       // approximateCovarianceBySampling (:203-208, 261-316): n^3 GetCost evaluations around the pose the
       // registration just produced; pose and leftover itr_ are read from d_results on the device, so no host
@@ -727,12 +727,20 @@ static int process_frame(cfear_odometry* od, const uint8_t* polar, const uint8_t
       mode.yaw_half = par.cov_sampling.yaw_range * 0.5;
       mode.blocks_per_job = 1;                                    // one workgroup per stream: its scratch is reused
       mode.prior = od->d_results;
-      rc = cfear_register_launch(ctx, od->d_reg_jobs, n_jobs, &par.reg, par.submap_scan_size * od->cell_cap,
-                                 od->d_reg_scratch, od->d_samples, &mode, rjb, hint);
-      if (rc != CFEAR_OK) return fail(rc);
-      OD_CHECK(hipMemcpyAsync(od->h_samples, od->d_samples, (size_t)n_jobs * od->fit.m * sizeof(cfear_reg_result),
-                                          hipMemcpyDeviceToHost, ctx->stream));
+      lrc = cfear_register_launch(ctx, od->d_reg_jobs, n_jobs, &par.reg, par.submap_scan_size * od->cell_cap,
+                                  od->d_reg_scratch, od->d_samples, &mode, rjb, hint);
+      if (lrc != CFEAR_OK) return lrc;
+      if (hipMemcpyAsync(od->h_samples, od->d_samples, (size_t)n_jobs * od->fit.m * sizeof(cfear_reg_result),
+                         hipMemcpyDeviceToHost, ctx->stream) != hipSuccess)
+        return cfear_set_error(ctx, CFEAR_ERR_HIP, "sample read-back failed");
     }
+    return CFEAR_OK;
+  };
+  const bool launched_big = od->big_regs > 0;
+  if (n_jobs > 0) {
+    OD_CHECK(hipStreamWaitEvent(ctx->stream, od->ev_jobs, 0));
+    rc = launch_register(launched_big);
+    if (rc != CFEAR_OK) return fail(rc);
   }
   if (par.keep_nodes) {
     // Compensate(*cloud_peaks, TprevMot, ccw) (odometrykeyframefuser.cpp:149): off the critical path, behind the matcher
@@ -771,6 +779,20 @@ static int process_frame(cfear_odometry* od, const uint8_t* polar, const uint8_t
   g_tl.mark(2);
   OD_CHECK(hipEventSynchronize(od->ev_results));
   g_tl.mark(3);
+  if (n_jobs > 0 && !launched_big) {
+    // A registration too large for the first form of a launch WITHOUT the large forms comes back as CFEAR_ERR_CAPACITY with
+    // `reserved` set when a larger form holds it (matcher_kernel): the first dense frame of a run.  Run the frame's jobs again
+    // with the large forms on (the job records are still on the device; everything else of the frame is unaffected) and keep
+    // them on for the frames to come (big_regs below) -- without this the stream ran on its motion guess for ever.
+    bool retry = false;
+    for (int j = 0; j < n_jobs && !retry; j++) retry = od->h_results[j].status == CFEAR_ERR_CAPACITY && od->h_results[j].reserved != 0.0;
+    if (retry) {
+      rc = launch_register(true);
+      if (rc != CFEAR_OK) return fail(rc);
+      OD_CHECK(hipMemcpyAsync(od->h_results, od->d_results, (size_t)n_jobs * sizeof(cfear_reg_result), hipMemcpyDeviceToHost, ctx->stream));
+      OD_CHECK(hipStreamSynchronize(ctx->stream));
+    }
+  }
   if (od->decode_measured[od->cur_buf]) {                  // this frame's sweeps went through the fused decode: how dense were they?
     od->decode_measured[od->cur_buf] = false;
     uint64_t cands = 0;

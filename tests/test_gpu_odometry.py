@@ -302,12 +302,13 @@ def test_rotated_input_layout_equals_prerotated(device_input, two_kernel):
     import torch
     from tbv_slam_public_amd import api, synth
     from tbv_slam_public_amd import _lib as L
-    api.default_context().set_option(L.OPT_FUSED_DECODE, 0 if two_kernel else 1)   # read when the odometry object is created
+    ctx = api.Context(0, torch.cuda.current_stream(0).cuda_stream or 1)   # a context of this test's own: the option it changes
+    ctx.set_option(L.OPT_FUSED_DECODE, 0 if two_kernel else 1)            # (read when the odometry object is created) dies with it
     n_frames = 5
     seqs = [synth.scene_v1(sd, n_frames, range_res=0.0595238, ccw=True)[0] for sd in (4, 6)]
     kw = dict(kstrong_range_res=0.0595238, radar_ccw=1, submap_scan_size=5)
-    ref = api.OdometryKeyframeFuser(2, 400, 3360, api.odometry_params(**kw))
-    rot = api.OdometryKeyframeFuser(2, 3360, 400, api.odometry_params(rotate_ccw=1, **kw))
+    ref = api.OdometryKeyframeFuser(2, 400, 3360, api.odometry_params(**kw), ctx=ctx)
+    rot = api.OdometryKeyframeFuser(2, 3360, 400, api.odometry_params(rotate_ccw=1, **kw), ctx=ctx)
     for f in range(n_frames):
         batch = np.stack([seq[f] for seq in seqs])
         sent = np.ascontiguousarray(np.rot90(batch, -1, axes=(1, 2)))
@@ -315,8 +316,8 @@ def test_rotated_input_layout_equals_prerotated(device_input, two_kernel):
         b = rot.process(torch.from_numpy(sent).cuda() if device_input else sent)
         for name in a.dtype.names:
             np.testing.assert_array_equal(a[name], b[name], err_msg=name)
-    api.default_context().set_option(L.OPT_FUSED_DECODE, 1)
     assert (a["reg_status"] == 0).all() and a["n_cells"].min() > 100
+    ref.close(); rot.close()
 
 
 @pytest.mark.parametrize("reps", [32, 64])
@@ -692,3 +693,36 @@ def test_fuser_graph_goes_to_disk_and_back(tmp_path):
     ok2, T2, _ = reg.Register(loaded, guess.copy())
     assert ok1 and ok2
     np.testing.assert_array_equal(T1, T2)
+
+
+def test_dense_scans_from_the_first_frame_turn_the_large_forms_on():
+    """A batch that starts on dense scans (~1 600 cells per scan: beyond what the regular 4-wavefront / 40 KB form of the matcher
+    holds) with the large forms still off: the first registration comes back CFEAR_ERR_CAPACITY with `reserved` set, the frame's
+    jobs are launched again with the large forms and they stay on -- no frame runs on its motion guess (round 5 reported
+    capacity on every frame: nothing told the odometry to turn the forms on).  The regular form is forced through the context's
+    options so that two streams behave like a batch beyond two workgroups per CU."""
+    import torch
+    from tbv_slam_public_amd import api, synth
+    from tbv_slam_public_amd import _lib as L
+    ctx = api.Context(0, torch.cuda.current_stream(0).cuda_stream or 1)
+    ctx.set_option(L.OPT_MATCHER_WAVES, 4); ctx.set_option(L.OPT_MATCHER_LDS_KB, 40)
+    n_frames = 5
+    seqs = [synth.scene_dense(sd, n_frames)[0] for sd in (7, 8)]
+    par = api.odometry_params()
+    od = api.OdometryKeyframeFuser(2, 400, 3360, par, ctx=ctx)
+    exp = [_oracle_sequence(seq, par.kstrong.k_strongest, par.kstrong.z_min, par.kstrong.range_res, par.reg.cost, par.reg.loss,
+                            par.reg.weight_opt, par.res, par.submap_scan_size, bool(par.weight_intensity), bool(par.radar_ccw)) for seq in seqs]
+    ctx.profile_enable(True); ctx.profile_read(reset=True)
+    for f in range(n_frames):
+        info = od.process(np.stack([seq[f] for seq in seqs]))
+        for b in range(2):
+            pose_o, info_o, _ = exp[b][f]
+            assert info["n_cells"][b] == info_o[0] and info["n_cells"][b] > 1400
+            if f > 0:
+                assert info["reg_status"][b] == 0 and bool(info_o[2]), (f, b, info["reg_status"][b])
+                assert info["outer_iters"][b] == info_o[3]
+            d = np.abs(info["pose"][b] - pose_o)
+            assert d[:2].max() <= POS_TOL and d[2] <= ROT_TOL, (f, b, d)
+    prof = ctx.profile_read(reset=True); ctx.profile_enable(False)
+    assert "register_large" in prof or "register_large16" in prof, prof.keys()
+    od.close()
