@@ -255,3 +255,94 @@ def test_nearest_neighbour_ties():
     idx, d2 = tree.knn(np.zeros(2, np.float32), 1)
     assert d2[0] == 1.0 and int(idx[0]) in (0, 1, 2, 3, 8)
     print("tie at the origin among {0,1,2,3,8}: reference returns", int(idx[0]), "(lowest-index rule gives 0)")
+
+
+def test_tie_rule_on_oracle_cells():
+    """Which way does the one FLANN-lineage tree of this image go on the oracle's OWN cell sets?  (VERDICT r05 #5.)
+
+    The oracle (and the HIP matcher, bit for bit) returns the LOWEST cell index among equidistant targets; the reference asks
+    pcl::KdTreeFLANN<PointXY>::nearestKSearch(k = 1) (pointnormal.cpp:249), i.e. FLANN 1.9.1's KDTreeSingleIndex with
+    KDTreeSingleIndexParams(15) (pointnormal.cpp:151-162) -- absent here.  Its header-only descendant, the reference's vendored
+    nanoflann (same middleSplit, same leaf scan with a strict `<` against the worst distance), is compiled as oracle/_ref.
+    Over the scene pairs of tests/test_oracle_order_robustness.py (CFEAR-3: P2P, Huber 0.1, weight option 4):
+
+      * the keyframe's float means go into Tree2f with leaf size 15; the source's means, moved by the start pose AND by the
+        registered pose, are the queries -- the searches Register runs in its first and in its last association pass;
+      * a query whose two nearest targets are equidistant in float is a TIE; counted: how often the tree's 1-NN index differs
+        from the oracle's lowest-index answer (the distances always agree: asserted);
+      * every group of cells with bit-identical float means gets the tree's winner moved to the group's lowest index (a
+        permutation of the target's cells: nothing else of the problem changes) and the pair is registered again -- how far the
+        pose moves when the oracle is given the tree's tie rule.
+
+    Measured (this container, 200 pairs, 134 892 queries): 8 802 queries (6.5 %) have an exact tie for the nearest target, and the
+    tree answers 4 313 of them (49 % of the ties, 3.2 % of all queries, on 196 of 200 pairs) with another index than the lowest
+    -- it takes whichever duplicate its leaf holds first, a coin toss against the cell index.  Giving the oracle the tree's
+    winners moves the registered pose by: median 1.9e-16 m, 90 % of the pairs <= 1e-6 m, 96 % <= 1e-4 m, worst 3.3e-3 m / 1.3e-4
+    rad.  So against a FLANN-lineage tie rule ~4 % of CFEAR-3 registrations differ by more than the 1e-4 m budget -- the same
+    figure as flipping EVERY tie (test_oracle_order_robustness.py), because half the ties flip and the worst pairs are the same.
+    The disagreement is far above 1 % of pairs, which the round-5 review asked to be REPORTED rather than built: reproducing a
+    leaf order on the GPU needs the reference's tree (build order, split rule, leaf size), and only a reference-written golden
+    (tools/ref_golden, `tie_*` arrays) can say whether FLANN 1.9.1 orders its leaves like nanoflann.
+    """
+    from oracle import pyoracle as O
+    from tbv_slam_public_amd import synth
+    L = _ref()
+    par = O.reg_params(cost="P2P", loss="Huber", loss_limit=0.1, weight_opt=4)
+    n_pairs = int(os.environ.get("CFEAR_TIE_PAIRS", "200"))
+    queries = ties = differ = pairs_with_diff = 0
+    dpos, drot = [], []
+    for seed in range(1000, 1000 + n_pairs):
+        imgs, gt, _ = synth.scene_v1(seed, 2)
+        cells = []
+        for f in range(2):
+            sr, si, sc = O.kstrongest(imgs[f], 40, 60)
+            cells.append(O.surface_points(O.kstrongest_cloud(sr, si, sc, 0.0438, 2.5), 3.0, 1.0, (0, 0), True))
+        c, s = np.cos(gt[0][2]), np.sin(gt[0][2])
+        d = gt[1][:2] - gt[0][:2]
+        guess = np.array([c * d[0] + s * d[1], -s * d[0] + c * d[1], gt[1][2] - gt[0][2]]) + [0.3, -0.2, 0.01]
+        poses = np.array([[0.0, 0.0, 0.0], guess])
+        ok, p_can, r_can = O.register(cells, poses, par)
+        assert ok
+        tgt = cells[0]
+        mf = np.ascontiguousarray(tgt["mean"], np.float64).astype(np.float32)
+        tree = RefTree2f(L, mf, leaf=15)
+        pair_diff = 0
+        for pose in (guess, p_can[-1]):
+            cs, sn = np.cos(pose[2]), np.sin(pose[2])
+            q = cells[1]["mean"] @ np.array([[cs, -sn], [sn, cs]]).T + pose[:2]
+            mine = O.closest_idx(tgt, q, 1e9)                        # the oracle's 1-NN (no radius cut: the tie rule alone)
+            for i in range(q.shape[0]):
+                qf = q[i].astype(np.float32)
+                idx, d2 = tree.knn(qf, 2)
+                dd = _l2_simple(qf, mf)
+                assert d2[0] == dd[mine[i]]                          # same nearest DISTANCE, always
+                queries += 1
+                if d2.shape[0] > 1 and d2[1] == d2[0]:
+                    ties += 1
+                    one, _ = tree.knn(qf, 1)
+                    if int(one[0]) != int(mine[i]):
+                        differ += 1
+                        pair_diff += 1
+        pairs_with_diff += pair_diff > 0
+        # the tree's winner of every duplicate group -> the group's lowest index
+        order = np.arange(len(tgt))
+        _, inv, cnt = np.unique(mf, axis=0, return_inverse=True, return_counts=True)
+        for g in np.nonzero(cnt > 1)[0]:
+            members = np.nonzero(inv == g)[0]                        # ascending cell indices
+            win, _ = tree.knn(mf[members[0]], 1)
+            w = int(win[0])
+            assert w in members
+            if w != members[0]:
+                order[members[0]], order[w] = order[w], order[members[0]]
+        ok2, p_tree, r_tree = O.register([tgt[order].copy(), cells[1]], poses, par)
+        assert ok2
+        dpos.append(np.abs(p_can[-1, :2] - p_tree[-1, :2]).max())
+        drot.append(abs(p_can[-1, 2] - p_tree[-1, 2]))
+    dpos, drot = np.array(dpos), np.array(drot)
+    print("tie rule: %d pairs, %d queries, %d ties (%.2f %%), tree != lowest index on %d (%.1f %% of ties, %.2f %% of queries, %d pairs)"
+          % (n_pairs, queries, ties, 100.0 * ties / queries, differ, 100.0 * differ / max(ties, 1), 100.0 * differ / queries, pairs_with_diff))
+    print("pose moved by the tree's tie rule: median %.1e m, <=1e-6: %.0f %%, <=1e-4: %.0f %%, worst %.1e m / %.1e rad"
+          % (np.median(dpos), 100 * (dpos <= 1e-6).mean(), 100 * (dpos <= 1e-4).mean(), dpos.max(), drot.max()))
+    assert ties > 0 and differ <= ties
+    assert dpos.max() <= 2e-2 and drot.max() <= 1e-3                 # inside the all-ties-flipped bound (3.3e-3 m measured there)
+    assert np.median(dpos) <= 1e-9

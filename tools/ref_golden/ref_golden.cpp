@@ -2,7 +2,7 @@
 // image: tbv_slam/docker/Dockerfile) on the inputs tools/ref_golden/export_inputs.py wrote, and leaves the outputs as raw
 // arrays + manifest.txt for pack_outputs.py.  Not buildable in this repository's image (no ROS / PCL / Eigen / Ceres /
 // OpenCV / Boost); never run there.  Calls: radar_filters.h:84-113, cfar.h:27-42, utils.h:49, pointnormal.h:110-243,
-// n_scan_normal.h:27-85, types.h:93-194.   usage: rosrun ref_golden ref_golden IN_DIR OUT_DIR   (roscore must be up)
+// n_scan_normal.h:27-85, odometrykeyframefuser.h:197-249, types.h:93-194.   usage: rosrun ref_golden ref_golden IN_DIR OUT_DIR   (roscore must be up)
 #include <cv_bridge/cv_bridge.h>
 #include <ros/ros.h>
 
@@ -12,6 +12,7 @@
 
 #include "cfear_radarodometry/cfar.h"
 #include "cfear_radarodometry/n_scan_normal.h"
+#include "cfear_radarodometry/odometrykeyframefuser.h"
 #include "cfear_radarodometry/pointnormal.h"
 #include "cfear_radarodometry/radar_filters.h"
 #include "cfear_radarodometry/types.h"
@@ -130,6 +131,60 @@ int main(int argc, char** argv) {
     reg.getScore(score, nres);
     w.put(std::string("r_") + cs.name + "_pose", "float64", par, {3});
     w.put(std::string("r_") + cs.name + "_meta", "float64", std::vector<double>{(double)ok, (double)nres, score, (double)okc, cost, (double)residuals.size()}, {6});
+  }
+  // ---- the 1-NN tie rule (pointnormal.cpp:238-254 -> pcl::KdTreeFLANN::nearestKSearch(1), FLANN 1.9.1 KDTreeSingleIndex(15)) ----
+  // (a) every cell of scan 0 asks for its own mean: cells with bit-identical float means (~17 groups per scan) are exact ties,
+  //     the answer is the tree's winner of the group; (b) the queries export_inputs.py wrote (scan 1's means moved by the start
+  //     pose: the searches of Register's first association pass), radius 2 r = 6 m.
+  //     Compared by tests/test_golden.py::test_reference_tie_rule against the oracle's "lowest index".
+  {
+    std::vector<int32_t> self_idx;
+    for (const cell& c : scans[0]->GetCells()) {
+      const std::vector<int> r = scans[0]->GetClosestIdx(Eigen::Vector2d(c.u_(0), c.u_(1)), 6.0);
+      self_idx.push_back(r.empty() ? -1 : r[0]);
+    }
+    w.put("r_tie_self_idx", "int32", self_idx, {(long)self_idx.size()});
+    const Arr& tq = in.at("tie_q");
+    const double* q = (const double*)tq.bytes.data();
+    std::vector<int32_t> q_idx;
+    for (long i = 0; i < tq.dims[0]; i++) {
+      const std::vector<int> r = scans[0]->GetClosestIdx(Eigen::Vector2d(q[2 * i], q[2 * i + 1]), 6.0);
+      q_idx.push_back(r.empty() ? -1 : r[0]);
+    }
+    w.put("r_tie_query_idx", "int32", q_idx, {(long)q_idx.size()});
+  }
+  // ---- a 50-frame OdometryKeyframeFuser pose trace (odometrykeyframefuser.cpp:143-259), CFEAR-3 preset, from raw sweeps ----
+  // (launch/oxford/eval/params/baseline/oxford_cfear-3: P2P, Huber 0.1, weight option 4, 4 keyframes, res 3, k 40, z_min 60,
+  //  intensity weights, compensation on).  One run pins the filter -> compensate -> surface points -> Register (LM path, tie rule)
+  //  -> keyframe policy chain end to end.  Compared by tests/test_golden.py::test_reference_odometry_trace.
+  {
+    const Arr& seq = in.at("seq_img");
+    const int nf = (int)seq.dims[0], rows = (int)seq.dims[1], cols = (int)seq.dims[2];
+    OdometryKeyframeFuser::Parameters op;
+    op.cost_type = "P2P"; op.weight_opt = weightoption::Combined_weights; op.submap_scan_size = 4; op.weight_intensity_ = true;
+    op.res = 3.0; op.loss_type_ = "Huber"; op.loss_limit_ = 0.1; op.visualize = false; op.publish_tf_ = false; op.store_graph = false;
+    op.compensate = true; op.radar_ccw = false; op.use_guess = true; op.use_keyframe = true;
+    MapPointNormal::downsample_factor = 1;
+    OdometryKeyframeFuser fuser(op, true);
+    std::vector<double> trace;
+    std::vector<int32_t> npts;
+    for (int f = 0; f < nf; f++) {
+      cv_bridge::CvImagePtr cv(new cv_bridge::CvImage());
+      cv->encoding = "mono8";
+      cv->image = cv::Mat(rows, cols, CV_8UC1, (void*)(seq.bytes.data() + (size_t)f * rows * cols)).clone();
+      StructuredKStrongest filt(cv, 60, 40, 2.5, 0.0438);
+      Cloud::Ptr c(new Cloud()), cp(new Cloud());
+      filt.getPeaksFilteredPointCloud(c, false);
+      filt.getPeaksFilteredPointCloud(cp, true);
+      npts.push_back((int32_t)c->size());
+      Eigen::Affine3d Tcurr = Eigen::Affine3d::Identity();
+      fuser.pointcloudCallback(c, cp, Tcurr, ros::Time(1547120000 + 0.25 * f));
+      std::vector<double> par;
+      Affine3dToVectorXYeZ(Tcurr, par);
+      trace.insert(trace.end(), par.begin(), par.end());
+    }
+    w.put("r_odom_trace", "float64", trace, {nf, 3});
+    w.put("r_odom_npts", "int32", npts, {nf});
   }
   // ---- one simple_graph.sgh written by the reference's own Boost archive (types.cpp:103-130) ----
   {
