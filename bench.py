@@ -771,7 +771,8 @@ def main(argv=None):
     breakdown = {k: {"ms_per_frame_batch": v[0] / max(n_all, 1), "launches": int(v[1])} for k, v in prof_all.items()}
     # HBM traffic of that kernel from the committed PMC passes (rocprofv3 cannot run inside this process):
     # per-scan FETCH_SIZE x2 + WRITE_SIZE measured by tools/profile.sh, scaled to this launch's batch
-    for tag in ("r05", "r04", "r03", "r02", "r01"):
+    roof["traffic_measured_in_run"] = False       # rocprofv3 cannot attach to this process: the PMC passes are separate runs
+    for tag in ("r06", "r05", "r04", "r03", "r02", "r01"):
         tj = os.path.join(ROOT, "profiles", tag, "pmc_traffic.json")
         if os.path.exists(tj):
             t = json.load(open(tj))
