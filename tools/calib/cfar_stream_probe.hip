@@ -100,16 +100,28 @@ __global__ __launch_bounds__(THREADS, 1) void stream_kernel(const Args a, const 
     for (int u = 0; u < U; u++) cur[u] = nxt[u];
 #pragma unroll
     for (int u = 0; u < U; u++) nxt[u] = load_row(c_begin + it + U + u + G + W - 1);
+    // every ring read of the block first (32 independent LDS reads in flight), then the block's writes: the rows read by the
+    // steps of a block (<= c0 + U + G - 2) are older than the rows it writes (>= c0 + G + W - 1), and a slot is read before the
+    // row that replaces it is written
+    uint32_t r_outT[U], r_inT[U], r_outF[U], r_cen[U];
+    {
+      int s = s_new;
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        int s_inT = s - (2 * G + W); if (s_inT < 0) s_inT += SPAN;
+        int s_outF = s - W; if (s_outF < 0) s_outF += SPAN;
+        int s_cen = s - (G + W - 1); if (s_cen < 0) s_cen += SPAN;
+        r_outT[u] = myring[s * LANES]; r_inT[u] = myring[s_inT * LANES]; r_outF[u] = myring[s_outF * LANES]; r_cen[u] = myring[s_cen * LANES];
+        s = s + 1 == SPAN ? 0 : s + 1;
+      }
+      s = s_new;
+#pragma unroll
+      for (int u = 0; u < U; u++) { myring[s * LANES] = cur[u]; s = s + 1 == SPAN ? 0 : s + 1; }
+    }
 #pragma unroll
     for (int u = 0; u < U; u++) {
       const int c = c_begin + it + u;
-      // slots relative to s_new: row c+49 -> s_new; c-51 -> s_new (before the write); c-11 -> s_new - 60; c+9 -> s_new - 40; c -> s_new - 49
-      int s_inT = s_new - (2 * G + W); if (s_inT < 0) s_inT += SPAN;
-      int s_outF = s_new - W; if (s_outF < 0) s_outF += SPAN;
-      int s_cen = s_new - (G + W - 1); if (s_cen < 0) s_cen += SPAN;
-      const uint32_t outT = myring[s_new * LANES];
-      const uint32_t inT = myring[s_inT * LANES], outF = myring[s_outF * LANES], cen = myring[s_cen * LANES];
-      myring[s_new * LANES] = cur[u];
+      const uint32_t outT = r_outT[u], inT = r_inT[u], outF = r_outF[u], cen = r_cen[u];
       const uint32_t inF = cur[u];
       const bool decide = c >= x0 && c < x1;
 #pragma unroll
