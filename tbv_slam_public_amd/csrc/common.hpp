@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <cstddef>
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
@@ -222,6 +223,34 @@ int cfear_coral_enqueue(cfear_ctx* ctx, const cfear_coral_job* jobs, int32_t n_j
                         CoralPending& pend);
 int cfear_coral_collect(cfear_ctx* ctx, const cfear_coral_job* jobs, const CoralPending& pend, cfear_coral_result* results, double* per_point);
 
+// One registration of the matcher (matcher.hip).  The scan views come LAST so that a batch whose jobs use at most m scans can be
+// stored with the shorter stride reg_job_stride(m): a two-scan loop-closure candidate is 0.5 KB instead of 1.9 KB to build and
+// upload.  Kernels only ever touch scans[0 .. n_scans).
+constexpr int kRegMaxScans = 16;
+struct RegJob {
+  int32_t n_scans;
+  int32_t itr;                                // cost-only launches: this job's leftover itr_ (0: use par.itr)
+  double poses[kRegMaxScans][3];
+  ScanView scans[kRegMaxScans];
+};
+inline size_t reg_job_stride(int max_scans) {
+  return (offsetof(RegJob, scans) + (size_t)max_scans * sizeof(ScanView) + 15) & ~(size_t)15;
+}
+// One CorAl job of coral_kernel (coral.hip): two peak clouds on the DEVICE and their poses
+struct CoralJob {
+  const float4* ref;
+  const float4* src;
+  const int32_t* n_ref_ptr;           // device-side counts (pipelines), or nullptr -> the host values
+  const int32_t* n_src_ptr;
+  int32_t n_ref, n_src;
+  double ref_pose[3], src_pose[3], offset[3];
+};
+// coral_kernel over job records that already sit on the device (verify.hip builds them there): results to d_results [n_jobs]
+// (device), nothing is synchronised.  cap = the largest n_ref + n_src among the jobs (the per-job scratch's size).
+int cfear_coral_launch_device(cfear_ctx* ctx, const CoralJob* d_jobs, int n_jobs, int cap, const cfear_coral_params* par,
+                              cfear_coral_result* d_results);
+int cfear_coral_max_points();
+
 struct RegLaunchHint {
   bool small_pairs = false;   // every job is a two-scan candidate that fits 20 KB of LDS: the 2-wavefront form, eight per CU
   bool big_pass = false;      // registrations the regular form is not good at may be among them (dense scans): add the large forms
@@ -231,6 +260,8 @@ int cfear_register_launch(cfear_ctx* ctx, const void* d_jobs, int n_jobs, const 
                           char* d_scratch, cfear_reg_result* d_results, const RegCostMode* mode = nullptr,
                           size_t job_stride = 0,    // 0: full records (cfear_reg_job_bytes)
                           RegLaunchHint hint = RegLaunchHint());
+// launch geometry of a batch of two-scan jobs from its largest target / source (what cfear_register_candidates derives)
+void cfear_reg_pair_geometry(const cfear_reg_params* par, int max_tar_cells, int max_src_cells, int* pairs_cap, RegLaunchHint* hint);
 size_t cfear_reg_job_stride(int max_scans);         // bytes of a record that holds up to max_scans scan views
 void cfear_reg_job_set_itr(void* job, int itr);
 // quadratic fit of the cost samples -> 6x6 covariance (covariance.hip, host)

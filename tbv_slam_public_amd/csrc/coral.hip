@@ -38,14 +38,7 @@ constexpr size_t kCoralRowbegOff = (size_t)kCoralMaxPoints * 8 + 16;
 constexpr size_t kCoralSmallOff = (kCoralRowbegOff + (size_t)(kCoralMaxGridRows + 1) * 4 + 15) / 16 * 16;
 constexpr size_t kCoralLdsTotal = kCoralSmallOff + 1024;
 
-struct CoralJob {
-  const float4* ref;
-  const float4* src;
-  const int32_t* n_ref_ptr;           // device-side counts (pipelines), or nullptr -> the host values
-  const int32_t* n_src_ptr;
-  int32_t n_ref, n_src;
-  double ref_pose[3], src_pose[3], offset[3];
-};
+// (struct CoralJob: common.hpp -- verify.hip's kernels write job records too)
 
 struct CoralCommon {
   double radius;
@@ -597,6 +590,36 @@ __global__ __launch_bounds__(kCoralThreads) void coral_kernel(const CoralJob* __
 }
 
 }  // namespace
+
+int cfear_coral_max_points() { return kCoralMaxPoints; }
+
+int cfear_coral_launch_device(cfear_ctx* ctx, const CoralJob* d_jobs, int n_jobs, int cap, const cfear_coral_params* par,
+                              cfear_coral_result* d_results) {
+  if (!(par->radius > 0.0)) return cfear_set_error(ctx, CFEAR_ERR_INVALID_ARGUMENT, "radius must be > 0");
+  if (n_jobs <= 0) return CFEAR_OK;
+  if (cap > kCoralMaxPoints) return cfear_set_error(ctx, CFEAR_ERR_CAPACITY, "a job's %d points exceed %d", cap, kCoralMaxPoints);
+  CoralCommon cm;
+  cm.radius = par->radius;
+  cm.r2 = (float)(par->radius * par->radius);            // radiusSearch passes float(radius * radius) to FLANN
+  cm.inv_cell = (float)(1.0 / (par->radius * 1.0001));
+  cm.weight_res_intensity = par->weight_res_intensity;
+  cm.cap = std::max(cap, 1);
+  cm.scratch_stride = coral_scratch_bytes(cm.cap);
+  cm.per_point = nullptr;
+  const int chunk = (int)std::max<size_t>(1, std::min<size_t>((size_t)n_jobs, ((size_t)1 << 30) / cm.scratch_stride));
+  char* scr = (char*)cfear_workspace(ctx, 10, cm.scratch_stride * (size_t)chunk);
+  if (!scr) return cfear_set_error(ctx, CFEAR_ERR_HIP, "workspace allocation failed");
+  cm.scratch = scr;
+  { const int rc_lds = cfear_allow_lds(ctx, (const void*)coral_kernel, 160 * 1024); if (rc_lds != CFEAR_OK) return rc_lds; }
+  ProfScope ps(ctx, "coral_quality");
+  for (int j0 = 0; j0 < n_jobs; j0 += chunk) {
+    const int nj = std::min(chunk, n_jobs - j0);
+    cm.results = d_results + j0;
+    hipLaunchKernelGGL(coral_kernel, dim3(nj), dim3(kCoralThreads), kCoralLdsTotal, ctx->stream, d_jobs + j0, cm);
+  }
+  CFEAR_HIP_CHECK(ctx, hipGetLastError());
+  return CFEAR_OK;
+}
 
 extern "C" void cfear_coral_params_default(cfear_coral_params* p) {
   if (!p) return;

@@ -48,21 +48,9 @@ __device__ unsigned long long g_reg_sum[4];   // every workgroup of a launch: su
 #define REG_TACC(k)
 #endif
 
-constexpr int kMaxScans = 16;
+constexpr int kMaxScans = kRegMaxScans;
 constexpr int kRegDeferred = 1000;            // internal status between the launches of a batch with large registrations
-
-// One registration.  The scan views come LAST so that a batch whose jobs use at most m scans can be stored with the
-// shorter stride reg_job_stride(m): a two-scan loop-closure candidate is 0.5 KB instead of 1.9 KB to build and upload.
-// Kernels only ever touch scans[0 .. n_scans).
-struct RegJob {
-  int32_t n_scans;
-  int32_t itr;                                // cost-only launches: this job's leftover itr_ (0: use par.itr)
-  double poses[kMaxScans][3];
-  ScanView scans[kMaxScans];
-};
-inline size_t reg_job_stride(int max_scans) {
-  return (offsetof(RegJob, scans) + (size_t)max_scans * sizeof(ScanView) + 15) & ~(size_t)15;
-}
+// (struct RegJob and reg_job_stride: common.hpp -- verify.hip's kernels write job records too)
 
 struct MatchCommon {
   cfear_reg_params par;
@@ -1731,6 +1719,14 @@ extern "C" int cfear_register_candidates(cfear_ctx* ctx, const cfear_scan_table*
 }
 
 int cfear_check_reg_params(cfear_ctx* ctx, const cfear_reg_params* par) { return check_params(ctx, par); }
+
+void cfear_reg_pair_geometry(const cfear_reg_params* par, int max_tar_cells, int max_src_cells, int* pairs_cap, RegLaunchHint* hint) {
+  JobSizes sz;
+  sz.cost = par->cost; sz.huber = par->loss == CFEAR_LOSS_HUBER;
+  sz.add(2, scan_grid_pad(max_tar_cells), scan_grid_pad(max_tar_cells), max_src_cells);
+  *pairs_cap = sz.pairs_cap;
+  *hint = sz.hint(1);
+}
 
 extern "C" int cfear_register(cfear_ctx* ctx, const cfear_scan* const* scans, int32_t n_scans, double* poses_xyt,
                               const cfear_reg_params* par, cfear_reg_result* result) {

@@ -17,6 +17,7 @@
 #include <chrono>
 #include <algorithm>
 #include <cmath>
+#include <map>
 #include <numeric>
 #include <vector>
 
@@ -84,14 +85,294 @@ extern "C" int cfear_verify_by_odometry(const double* rel_xyt, int32_t n, double
   return CFEAR_OK;
 }
 
-extern "C" int cfear_verify_loop_candidates(cfear_ctx* ctx, const cfear_verify_job* jobs, int32_t n_jobs,
-                                            const cfear_verify_params* par, cfear_verify_result* results) {
-  if (!ctx) return CFEAR_ERR_INVALID_ARGUMENT;
-  if (!jobs || !par || !results || n_jobs < 0) return cfear_set_error(ctx, CFEAR_ERR_INVALID_ARGUMENT, "null argument");
-  if (n_jobs == 0) return CFEAR_OK;
-  for (int j = 0; j < n_jobs; j++)
-    if (!jobs[j].from_scan || !jobs[j].to_scan)
-      return cfear_set_error(ctx, CFEAR_ERR_INVALID_ARGUMENT, "candidate %d: null scan handle", j);
+// ---- the device chain (the usual configuration: Register's constant covariance) ---------------------------------------
+// Round 5's step was half host time: between the registration and the two quality measures the host read the poses back,
+// composed Talign / Tto per candidate, marshalled 4096 CorAl jobs and 4096 cost jobs and uploaded them, and at the end ran
+// the classifiers -- 0.5 ms of a 2.1 ms step with the GPU idle.  Now ONE 296-byte record per candidate goes up and the
+// whole chain is enqueued at once:  expand -> matcher (Register) -> prepare (Talign, Tto, the cost and CorAl job records,
+// the rotated covariance) -> matcher (cost only: CFEARQuality) -> coral_kernel -> finish (feature vector, both logistic
+// models) -> ONE read-back of the 480-byte results.  The host keeps what needs a sort: ApplyConstratins.
+namespace {
+
+struct VerifyDev {                      // what a candidate needs on the device
+  ScanView to, from;
+  const float4* from_peaks;
+  const float4* to_peaks;
+  int32_t n_from, n_to;
+  double from_pose[3], t_be_guess[3];
+  double sc_sim, odom_bounds;
+};
+
+struct VerifyChain {
+  const VerifyDev* cand;
+  char* reg_jobs;                       // RegJob records, `stride` bytes apart: scans {to, from}, poses {Tto, Tfrom}
+  char* cost_jobs;                      // scans {from, to}, poses {Tfrom, Tto'}: feature_vek = {ref, src} (AlignmentQuality.cpp:330-354)
+  size_t stride;
+  CoralJob* coral_jobs;
+  const cfear_reg_result* reg;
+  const cfear_reg_result* q;
+  const cfear_coral_result* coral;
+  cfear_verify_result* out;
+  int32_t* first_bad;                   // smallest candidate index whose CorAl job failed (INT_MAX: none)
+  int n;
+  cfear_verify_params par;
+};
+
+__device__ __forceinline__ void d_xyt_compose(const double a[3], const double b[3], double o[3]) {
+  double s, c;
+  sincos(a[2], &s, &c);
+  const double x = c * b[0] - s * b[1] + a[0], y = s * b[0] + c * b[1] + a[1];
+  o[0] = x; o[1] = y; o[2] = a[2] + b[2];
+}
+__device__ __forceinline__ void d_xyt_inverse(const double a[3], double o[3]) {
+  double s, c;
+  sincos(a[2], &s, &c);
+  const double x = -(c * a[0] + s * a[1]), y = s * a[0] - c * a[1];
+  o[0] = x; o[1] = y; o[2] = -a[2];
+}
+
+// RegisterLoopCandidate's problem (loopclosure.cpp:35-60): scans {to, from}, poses {Tto = Tfrom * t_be, Tfrom}
+__global__ __launch_bounds__(256) void verify_expand_kernel(const VerifyChain c) {
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j == 0) *c.first_bad = 0x7fffffff;
+  if (j >= c.n) return;
+  const VerifyDev& v = c.cand[j];
+  RegJob* r = (RegJob*)(c.reg_jobs + (size_t)j * c.stride);
+  r->n_scans = 2; r->itr = 0;
+  double tto[3];
+  d_xyt_compose(v.from_pose, v.t_be_guess, tto);
+#pragma unroll
+  for (int k = 0; k < 3; k++) { r->poses[0][k] = tto[k]; r->poses[1][k] = v.from_pose[k]; }
+  r->scans[0] = v.to; r->scans[1] = v.from;
+}
+
+// Talign = Trevised^-1 * Tto (loopclosure.cpp:90-94), the covariance in that frame (:62-71 constant; :93), and the job records
+// of the two quality measures at Tfrom, Tto' = Tfrom * t_be (:367-372; current = from, prev = to)
+__global__ __launch_bounds__(256) void verify_prepare_kernel(const VerifyChain c) {
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= c.n) return;
+  const VerifyDev& v = c.cand[j];
+  const cfear_reg_result reg = c.reg[j];
+  const RegJob* rj = (const RegJob*)(c.reg_jobs + (size_t)j * c.stride);
+  cfear_verify_result& r = c.out[j];
+  r.reg = reg;
+  r.reg_ok = reg.status == CFEAR_OK ? 1 : 0;
+  r.cov_sampled = 0;
+  double* C = r.cov;
+  if (r.reg_ok) {
+    double inv[3];
+    d_xyt_inverse(reg.pose, inv);                          // Trevised^-1
+    d_xyt_compose(inv, rj->poses[0], r.t_be);              // Talign = Trevised^-1 * Tto
+    for (int k = 0; k < 36; k++) C[k] = 0.0;
+    C[0] = 0.01; C[7] = 0.01; C[35] = 1e-4;                 // n_scan_normal.cpp:171-175
+    // reg_cov.block<3,3>(0,0) = R^-1 * block * R^-T: only the x-y part of the block is touched by a yaw rotation
+    double sn, cs;
+    sincos(inv[2], &sn, &cs);
+    const double R[9] = {cs, -sn, 0, sn, cs, 0, 0, 0, 1};
+    double B[9], T[9];
+    for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) B[a * 3 + b] = C[a * 6 + b];
+    for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) {
+      double t = 0.0;
+      for (int k = 0; k < 3; k++) t += R[a * 3 + k] * B[k * 3 + b];
+      T[a * 3 + b] = t;
+    }
+    for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) {
+      double t = 0.0;
+      for (int k = 0; k < 3; k++) t += T[a * 3 + k] * R[b * 3 + k];
+      C[a * 6 + b] = t;
+    }
+  } else {                                                 // Tdiff and Cov keep their initial Identity (:351-353)
+    r.t_be[0] = r.t_be[1] = r.t_be[2] = 0.0;
+    for (int k = 0; k < 36; k++) C[k] = (k % 7 == 0) ? 1.0 : 0.0;
+  }
+  double to_pose[3];
+  d_xyt_compose(v.from_pose, r.t_be, to_pose);
+  RegJob* qj = (RegJob*)(c.cost_jobs + (size_t)j * c.stride);
+  qj->n_scans = 2; qj->itr = 0;
+#pragma unroll
+  for (int k = 0; k < 3; k++) { qj->poses[0][k] = v.from_pose[k]; qj->poses[1][k] = to_pose[k]; }
+  qj->scans[0] = v.from; qj->scans[1] = v.to;
+  CoralJob& cj = c.coral_jobs[j];                          // CreateQualityType(scan_curr, scan_prev): ref = current
+  cj.ref = v.from_peaks; cj.src = v.to_peaks; cj.n_ref_ptr = nullptr; cj.n_src_ptr = nullptr;
+  cj.n_ref = v.n_from; cj.n_src = v.n_to;
+#pragma unroll
+  for (int k = 0; k < 3; k++) { cj.ref_pose[k] = v.from_pose[k]; cj.src_pose[k] = to_pose[k]; cj.offset[k] = 0.0; }
+}
+
+// PredAlignment's feature vector and the two logistic models (alignmentinterface.cpp:349-367, 271-279; loopclosure.cpp:220-238)
+__global__ __launch_bounds__(256) void verify_finish_kernel(const VerifyChain c) {
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= c.n) return;
+  const VerifyDev& v = c.cand[j];
+  cfear_verify_result& r = c.out[j];
+  const cfear_coral_result co = c.coral[j];
+  const cfear_reg_result q = c.q[j];
+  if (co.status != CFEAR_OK && co.status != CFEAR_ERR_EMPTY_CLOUD) atomicMin(c.first_bad, j);
+  r.coral[0] = co.joint; r.coral[1] = co.sep; r.coral[2] = co.overlap;
+  if (q.status == CFEAR_OK) {                               // AlignmentQuality.cpp:344-348
+    r.cfear[0] = q.final_cost;
+    r.cfear[1] = (double)q.num_residuals;
+    r.cfear[2] = (*v.to.n_cells + *v.from.n_cells) / 2.0;
+  } else {
+    r.cfear[0] = r.cfear[1] = r.cfear[2] = 0.0;             // :349-351
+  }
+  double z = c.par.align_intercept;                         // predict_linear (alignmentinterface.cpp:271-279)
+  for (int k = 0; k < 3; k++) z += c.par.align_coef[k] * r.coral[k];
+  for (int k = 0; k < 3; k++) z += c.par.align_coef[3 + k] * r.cfear[k];
+  r.alignment_quality = z;
+  r.odom_bounds = v.odom_bounds;
+  r.sc_sim = v.sc_sim;
+  if (c.par.verification_disabled) {
+    r.probability = 0.0;                                    // loopclosure.cpp:377
+  } else {
+    const double zl = c.par.loop_coef[0] * r.odom_bounds + c.par.loop_coef[1] * r.sc_sim + c.par.loop_coef[2] * r.alignment_quality +
+                      c.par.loop_intercept;
+    r.probability = 1.0 / (1.0 + exp(-zl));
+  }
+  r.accepted = 0;
+  r.rank = 0;
+}
+
+// ApplyConstratins per query (jobs sharing `group`): sort by probability, larger first (loopclosure.cpp:261-274)
+void apply_constraints(const cfear_verify_job* jobs, size_t n, const cfear_verify_params* par, cfear_verify_result* results) {
+  std::vector<int> order(n);
+  std::iota(order.begin(), order.end(), 0);
+  std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
+    if (jobs[a].group != jobs[b].group) return jobs[a].group < jobs[b].group;
+    return results[a].probability > results[b].probability;
+  });
+  for (size_t i = 0; i < n;) {
+    size_t e = i;
+    while (e < n && jobs[order[e]].group == jobs[order[i]].group) e++;
+    for (size_t k = i; k < e; k++) {
+      cfear_verify_result& r = results[order[k]];
+      r.rank = (int32_t)(k - i);
+      const bool considered = par->all_candidates || k == i;
+      r.accepted = considered && r.probability > par->model_threshold ? 1 : 0;
+    }
+    i = e;
+  }
+}
+
+int verify_device_chain(cfear_ctx* ctx, const cfear_verify_job* jobs, int32_t n_jobs, const cfear_verify_params* par,
+                        cfear_verify_result* results) {
+  const size_t n = (size_t)n_jobs;
+  CFEAR_HIP_CHECK(ctx, hipSetDevice(ctx->device));
+  // ---- host: one record per candidate; peak clouds that live on the host are staged once each -----------------------
+  std::map<const float*, const float4*> where;           // cloud -> its device address (one hipPointerGetAttributes per distinct cloud)
+  std::vector<std::pair<const float*, int>> to_stage;
+  size_t stage_floats = 0;
+  int max_cells = 0, cap = 1;
+  for (size_t j = 0; j < n; j++) {
+    const cfear_verify_job& jb = jobs[j];
+    if (jb.from_scan->ctx != ctx || jb.to_scan->ctx != ctx) return cfear_set_error(ctx, CFEAR_ERR_INVALID_ARGUMENT, "candidate %zu: scan belongs to another context", j);
+    if (jb.n_from < 0 || jb.n_to < 0 || (jb.n_from > 0 && !jb.from_peaks) || (jb.n_to > 0 && !jb.to_peaks))
+      return cfear_set_error(ctx, CFEAR_ERR_INVALID_ARGUMENT, "job %zu: null cloud", j);
+    if ((long long)jb.n_from + jb.n_to > cfear_coral_max_points())
+      return cfear_set_error(ctx, CFEAR_ERR_CAPACITY, "job %zu: %d + %d points exceed %d", j, jb.n_from, jb.n_to, cfear_coral_max_points());
+    cap = std::max(cap, jb.n_from + jb.n_to);
+    const float* ptrs[2] = {jb.from_peaks, jb.to_peaks};
+    const int ns[2] = {jb.n_from, jb.n_to};
+    for (int c = 0; c < 2; c++) {
+      if (ns[c] == 0 || !ptrs[c]) continue;
+      auto it = where.find(ptrs[c]);
+      if (it == where.end()) {
+        if (cfear_is_device_ptr(ptrs[c])) where[ptrs[c]] = (const float4*)ptrs[c];
+        else { where[ptrs[c]] = (const float4*)(uintptr_t)(stage_floats * 4); to_stage.emplace_back(ptrs[c], ns[c]); stage_floats += ((size_t)ns[c] * 4 + 3) & ~(size_t)3; }
+      } else if (!to_stage.empty()) {
+        for (auto& ts : to_stage) if (ts.first == ptrs[c]) { if (ns[c] > ts.second) return cfear_set_error(ctx, CFEAR_ERR_INVALID_ARGUMENT, "job %zu: a host cloud is used with two lengths", j); break; }
+      }
+    }
+    const int ct = cfear_scan_size(jb.to_scan), cf = cfear_scan_size(jb.from_scan);
+    if (ct < 0) return ct;
+    if (cf < 0) return cf;
+    max_cells = std::max(max_cells, std::max(ct, cf));
+  }
+  float* d_stage = nullptr;
+  if (stage_floats) {
+    d_stage = (float*)cfear_workspace(ctx, 8, stage_floats * 4);
+    if (!d_stage) return cfear_set_error(ctx, CFEAR_ERR_HIP, "workspace allocation failed");
+    for (auto& ts : to_stage) {
+      const size_t off = (size_t)(uintptr_t)where[ts.first] / 4;
+      CFEAR_HIP_CHECK(ctx, hipMemcpyAsync(d_stage + off, ts.first, (size_t)ts.second * 16, hipMemcpyHostToDevice, ctx->stream));
+      where[ts.first] = (const float4*)(d_stage + off);
+    }
+  }
+  VerifyDev* hc = (VerifyDev*)cfear_pinned(ctx, n * sizeof(VerifyDev));
+  if (!hc) return cfear_set_error(ctx, CFEAR_ERR_HIP, "pinned staging allocation failed");
+  for (size_t j = 0; j < n; j++) {
+    const cfear_verify_job& jb = jobs[j];
+    VerifyDev& v = hc[j];
+    v.to = jb.to_scan->view; v.from = jb.from_scan->view;
+    v.from_peaks = jb.n_from > 0 ? where[jb.from_peaks] : nullptr;
+    v.to_peaks = jb.n_to > 0 ? where[jb.to_peaks] : nullptr;
+    v.n_from = jb.n_from; v.n_to = jb.n_to;
+    for (int k = 0; k < 3; k++) { v.from_pose[k] = jb.from_pose[k]; v.t_be_guess[k] = jb.t_be_guess[k]; }
+    v.sc_sim = jb.sc_sim; v.odom_bounds = jb.odom_bounds;
+  }
+  // ---- device buffers: one workspace, carved ---------------------------------------------------------------------------
+  const size_t stride = reg_job_stride(2);
+  auto up = [](size_t b) { return (b + 255) / 256 * 256; };
+  const size_t o_cand = 0, o_reg_jobs = o_cand + up(n * sizeof(VerifyDev)), o_cost_jobs = o_reg_jobs + up(n * stride),
+               o_coral_jobs = o_cost_jobs + up(n * stride), o_reg = o_coral_jobs + up(n * sizeof(CoralJob)),
+               o_q = o_reg + up(n * sizeof(cfear_reg_result)), o_coral = o_q + up(n * sizeof(cfear_reg_result)),
+               o_out = o_coral + up(n * sizeof(cfear_coral_result)), o_flag = o_out + up(n * sizeof(cfear_verify_result)), total = o_flag + 256;
+  char* ws = (char*)cfear_workspace(ctx, 14, total);
+  // RegisterLoopCandidate: P2L, Huber 0.1, uniform weights, SetParameters(4, 10) (loopclosure.cpp:56-57); CFEARQuality:
+  // n_scan_normal_reg(P2L, Huber, 0.3), fresh -- itr_ = 0 (AlignmentQuality.cpp:330-354)
+  cfear_reg_params rp, qp;
+  cfear_reg_params_default(&rp);
+  rp.cost = CFEAR_P2L; rp.max_itr_association = 4; rp.max_itr_solver = 10;
+  cfear_reg_params_default(&qp);
+  qp.cost = CFEAR_P2L; qp.loss_limit = 0.3; qp.itr = 0;
+  int pairs_cap = 1, pairs_cap_q = 1;
+  RegLaunchHint hint, hint_q;
+  cfear_reg_pair_geometry(&rp, max_cells, max_cells, &pairs_cap, &hint);
+  cfear_reg_pair_geometry(&qp, max_cells, max_cells, &pairs_cap_q, &hint_q);
+  hint_q.small_pairs = false;
+  char* scr = (char*)cfear_workspace(ctx, 7, cfear_register_scratch_bytes(std::max(pairs_cap, pairs_cap_q)) * n);
+  if (!ws || !scr) return cfear_set_error(ctx, CFEAR_ERR_HIP, "workspace allocation failed");
+  VerifyChain c;
+  c.cand = (const VerifyDev*)(ws + o_cand); c.reg_jobs = ws + o_reg_jobs; c.cost_jobs = ws + o_cost_jobs; c.stride = stride;
+  c.coral_jobs = (CoralJob*)(ws + o_coral_jobs); c.reg = (const cfear_reg_result*)(ws + o_reg); c.q = (const cfear_reg_result*)(ws + o_q);
+  c.coral = (const cfear_coral_result*)(ws + o_coral); c.out = (cfear_verify_result*)(ws + o_out); c.first_bad = (int32_t*)(ws + o_flag);
+  c.n = n_jobs; c.par = *par;
+  const dim3 grid((unsigned)((n + 255) / 256)), block(256);
+  // ---- the chain ---------------------------------------------------------------------------------------------------------
+  CFEAR_HIP_CHECK(ctx, hipMemcpyAsync(ws + o_cand, hc, n * sizeof(VerifyDev), hipMemcpyHostToDevice, ctx->stream));
+  cfear_pinned_mark(ctx);
+  int rc = CFEAR_OK;
+  { ProfScope ps(ctx, "verify_glue"); hipLaunchKernelGGL(verify_expand_kernel, grid, block, 0, ctx->stream, c); }
+  rc = cfear_register_launch(ctx, c.reg_jobs, n_jobs, &rp, pairs_cap, scr, (cfear_reg_result*)(ws + o_reg), nullptr, stride, hint);
+  if (rc == CFEAR_OK) {
+    { ProfScope ps(ctx, "verify_glue"); hipLaunchKernelGGL(verify_prepare_kernel, grid, block, 0, ctx->stream, c); }
+    RegCostMode mode;                                        // GetCost at the jobs' own poses
+    mode.blocks_per_job = std::max(1, std::min(1, (1024 + n_jobs - 1) / n_jobs));
+    rc = cfear_register_launch(ctx, c.cost_jobs, n_jobs, &qp, pairs_cap_q, scr, (cfear_reg_result*)(ws + o_q), &mode, stride, hint_q);
+  }
+  if (rc == CFEAR_OK) rc = cfear_coral_launch_device(ctx, c.coral_jobs, n_jobs, cap, &par->coral, (cfear_coral_result*)(ws + o_coral));
+  if (rc != CFEAR_OK) { (void)hipStreamSynchronize(ctx->stream); return rc; }
+  { ProfScope ps(ctx, "verify_glue"); hipLaunchKernelGGL(verify_finish_kernel, grid, block, 0, ctx->stream, c); }
+  CFEAR_HIP_CHECK(ctx, hipGetLastError());
+  int32_t first_bad = 0x7fffffff;
+  CFEAR_HIP_CHECK(ctx, hipMemcpyAsync(results, ws + o_out, n * sizeof(cfear_verify_result), hipMemcpyDeviceToHost, ctx->stream));
+  CFEAR_HIP_CHECK(ctx, hipMemcpyAsync(&first_bad, ws + o_flag, 4, hipMemcpyDeviceToHost, ctx->stream));
+  CFEAR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  if (first_bad != 0x7fffffff) {
+    cfear_coral_result bad;
+    CFEAR_HIP_CHECK(ctx, hipMemcpy(&bad, ws + o_coral + (size_t)first_bad * sizeof(cfear_coral_result), sizeof(bad), hipMemcpyDeviceToHost));
+    return cfear_set_error(ctx, bad.status, "job %d: %s", first_bad, cfear_status_string(bad.status));
+  }
+  apply_constraints(jobs, n, par, results);
+  return CFEAR_OK;
+}
+
+}  // namespace
+
+// The chain with the host between its kernels: kept for par.use_covariance_sampling (the sampled covariance is fitted on the
+// host from 27 cost samples per candidate, loopclosure.cpp:62-71, 99-208).
+static int verify_host_chain(cfear_ctx* ctx, const cfear_verify_job* jobs, int32_t n_jobs,
+                             const cfear_verify_params* par, cfear_verify_result* results) {
   const size_t n = (size_t)n_jobs;
 #ifdef CFEAR_VERIFY_TIMING
   auto t_last = std::chrono::steady_clock::now();
@@ -249,28 +530,22 @@ extern "C" int cfear_verify_loop_candidates(cfear_ctx* ctx, const cfear_verify_j
     r.rank = 0;
   }
 
-  // ---- ApplyConstratins per query (jobs sharing `group`): sort by probability, larger first ------------------
-  std::vector<int> order(n);
-  std::iota(order.begin(), order.end(), 0);
-  std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
-    if (jobs[a].group != jobs[b].group) return jobs[a].group < jobs[b].group;
-    return results[a].probability > results[b].probability;
-  });
-  for (size_t i = 0; i < n;) {
-    size_t e = i;
-    while (e < n && jobs[order[e]].group == jobs[order[i]].group) e++;
-    for (size_t k = i; k < e; k++) {
-      cfear_verify_result& r = results[order[k]];
-      r.rank = (int32_t)(k - i);
-      const bool considered = par->all_candidates || k == i;
-      r.accepted = considered && r.probability > par->model_threshold ? 1 : 0;
-    }
-    i = e;
-  }
+  apply_constraints(jobs, n, par, results);
   mark(6);
 #ifdef CFEAR_VERIFY_TIMING
   fprintf(stderr, "verify us: marshal reg %.0f | register_batch %.0f | Talign + coral jobs %.0f | coral enqueue %.0f | cov + cost jobs %.0f | get_cost_batch + coral results %.0f | classify + sort %.0f\n",
           t_acc[0], t_acc[1], t_acc[2], t_acc[3], t_acc[4], t_acc[5], t_acc[6]);
 #endif
   return CFEAR_OK;
+}
+
+extern "C" int cfear_verify_loop_candidates(cfear_ctx* ctx, const cfear_verify_job* jobs, int32_t n_jobs,
+                                            const cfear_verify_params* par, cfear_verify_result* results) {
+  if (!ctx) return CFEAR_ERR_INVALID_ARGUMENT;
+  if (!jobs || !par || !results || n_jobs < 0) return cfear_set_error(ctx, CFEAR_ERR_INVALID_ARGUMENT, "null argument");
+  if (n_jobs == 0) return CFEAR_OK;
+  for (int j = 0; j < n_jobs; j++)
+    if (!jobs[j].from_scan || !jobs[j].to_scan)
+      return cfear_set_error(ctx, CFEAR_ERR_INVALID_ARGUMENT, "candidate %d: null scan handle", j);
+  return par->use_covariance_sampling ? verify_host_chain(ctx, jobs, n_jobs, par, results) : verify_device_chain(ctx, jobs, n_jobs, par, results);
 }

@@ -41,12 +41,18 @@ def _candidates(nodes):
             cand(2, 0, (0.0, 0.0, 0.0), 0.40, 0.9, 5)]          # good alignment, but odometry / appearance disagree
 
 
-def _run_both(nodes, cands, sampling=False, **pk):
+def _run_both(nodes, cands, sampling=False, peaks_on="host", **pk):
     from oracle import pyoracle as O
     from tbv_slam_public_amd import api
     par = api.verify_params(use_covariance_sampling=int(sampling), **pk)
-    jobs = [dict(from_scan=nodes[c["f"]]["scan"], to_scan=nodes[c["t"]]["scan"], from_peaks=nodes[c["f"]]["peaks"],
-                 to_peaks=nodes[c["t"]]["peaks"], from_pose=nodes[c["f"]]["T"], t_be_guess=c["t_be_guess"],
+    if peaks_on == "host":
+        pk_of = lambda i: nodes[i]["peaks"]
+    else:                                     # "device": every cloud resident on the GPU; "mixed": the even nodes' only
+        import torch
+        dev = {i: torch.from_numpy(np.ascontiguousarray(nd["peaks"])).cuda() for i, nd in enumerate(nodes)}
+        pk_of = lambda i: dev[i] if (peaks_on == "device" or i % 2 == 0) else nodes[i]["peaks"]
+    jobs = [dict(from_scan=nodes[c["f"]]["scan"], to_scan=nodes[c["t"]]["scan"], from_peaks=pk_of(c["f"]),
+                 to_peaks=pk_of(c["t"]), from_pose=nodes[c["f"]]["T"], t_be_guess=c["t_be_guess"],
                  sc_sim=c["sc_sim"], odom_bounds=c["odom_bounds"], group=c["group"]) for c in cands]
     got = api.verify_loop_candidates(jobs, par)
     exp = [O.verify_loop_candidate(nodes[c["f"]]["cells"], nodes[c["f"]]["peaks"], nodes[c["f"]]["T"], nodes[c["t"]]["cells"],
@@ -70,9 +76,12 @@ def _compare(got, exp, cands, thr=0.8, all_candidates=True):
     np.testing.assert_array_equal(got["accepted"].astype(bool), acc)
 
 
-def test_verify_candidates_match_oracle(nodes):
+@pytest.mark.parametrize("peaks_on", ["host", "device", "mixed"])
+def test_verify_candidates_match_oracle(nodes, peaks_on):
+    """The device chain (expand -> Register -> prepare -> CFEAR quality -> CorAl -> finish, one read-back) with the peak clouds
+    in host memory (staged once per distinct cloud), resident on the GPU, and both in one batch."""
     cands = _candidates(nodes)
-    got, exp = _run_both(nodes, cands)
+    got, exp = _run_both(nodes, cands, peaks_on=peaks_on)
     _compare(got, exp, cands)
     # what the scenario is meant to exercise
     np.testing.assert_array_equal(got["reg_ok"], [1, 1, 1, 1, 0, 1])
