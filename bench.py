@@ -509,6 +509,9 @@ def verify_measure(D, V, n_cand, steps, warmup):
     groups = [{"group": q // 3} for q in range(n_cand)]                # (the gather step reads the list's length and groups)
     par = V.par
     fn = lambda _local: api.verify_loop_candidates(prepared, par, V.ctx)
+    fn.into = lambda _local, ptr: api.verify_loop_candidates(prepared, par, V.ctx, device_ptr=ptr)   # records stay on the GPU until the gather
+    gids = np.arange(n_cand, dtype=np.int32) // 3
+    fn.select = lambda out, _groups: api.verify_apply_constraints(out, gids, par)
     for _ in range(max(warmup, 1)):
         out = cdist.verify_candidates_sharded(groups, fn, par.model_threshold, bool(par.all_candidates), fn_selects=True)
     D.barrier()

@@ -554,8 +554,14 @@ typedef struct cfear_verify_result {
   cfear_reg_result reg;                 /* the registration's own record                                                     */
 } cfear_verify_result;                  /* 480 bytes */
 
+/* results: host memory -- every field filled, ApplyConstratins applied over the batch; or DEVICE memory (a sharded caller
+ * gathers the records there, cfear_rccl_allgather_device): the records are left on the device with accepted = rank = 0, the
+ * call still waits for the chain and reports its errors, and the selection is the caller's, over the gathered list
+ * (cfear_verify_apply_constraints; not available with use_covariance_sampling).                                       */
 int cfear_verify_loop_candidates(cfear_ctx* ctx, const cfear_verify_job* jobs, int32_t n_jobs,
                                  const cfear_verify_params* par, cfear_verify_result* results);
+/* ApplyConstratins (loopclosure.cpp:261-274) over host records: groups [n] = the candidates' query ids.  No context. */
+int cfear_verify_apply_constraints(const int32_t* groups, int32_t n, const cfear_verify_params* par, cfear_verify_result* results);
 /* loopclosure::VerifyByOdometry (loopclosure.cpp:776-808).  rel_xyt [n][3]: the odometry constraints'
  * RelativeMotion(i, i+1), i = to .. from-1.  similarity = 1 - exp(-(max(|T_odom| - 5, 0) / travelled)^2 / 2 sigma^2);
  * 1 when verify_via_odometry is 0.  No context: pure host arithmetic.                                               */

@@ -203,7 +203,7 @@ EXPORTS = [
     "cfear_coral_quality_batch", "cfear_sc_params_default", "cfear_sc_descriptors", "cfear_sc_distance_batch",
     "cfear_polar_rotate_ccw", "cfear_scan_closest_idx",
     "cfear_sc_manager_params_default", "cfear_sc_manager_create", "cfear_sc_manager_add", "cfear_sc_manager_detect",
-    "cfear_sc_manager_size", "cfear_sc_manager_destroy", "cfear_verify_params_default", "cfear_verify_loop_candidates", "cfear_verify_by_odometry",
+    "cfear_sc_manager_size", "cfear_sc_manager_destroy", "cfear_verify_params_default", "cfear_verify_loop_candidates", "cfear_verify_by_odometry", "cfear_verify_apply_constraints",
     "cfear_cost_prepare", "cfear_cost_num_blocks", "cfear_cost_num_residuals", "cfear_cost_get_blocks",
     "cfear_cost_evaluate", "cfear_cost_normal_eq", "cfear_cost_destroy",
     "cfear_odometry_params_default", "cfear_odometry_params_preset", "cfear_odometry_create", "cfear_odometry_process",
@@ -348,6 +348,7 @@ def lib():
     L.cfear_verify_params_default.argtypes = [C.POINTER(VerifyParams)]
     L.cfear_verify_params_default.restype = None
     L.cfear_verify_loop_candidates.argtypes = [vp, C.POINTER(VerifyJob), C.c_int32, C.POINTER(VerifyParams), vp]
+    L.cfear_verify_apply_constraints.argtypes = [vp, C.c_int32, C.POINTER(VerifyParams), vp]
     L.cfear_verify_by_odometry.argtypes = [vp, C.c_int32, C.c_double, C.c_int32, C.POINTER(C.c_double)]
     L.cfear_get_cost.argtypes = [vp, C.POINTER(vp), C.c_int32, C.POINTER(C.c_double), C.POINTER(RegParams),
                                  C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int32,

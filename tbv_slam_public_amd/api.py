@@ -839,18 +839,30 @@ def VerifyByOdometry(rel_xyt, odom_sigma_error=0.03, verify_via_odometry=True, c
     return out.value
 
 
-def verify_loop_candidates(cands, par=None, ctx=None):
+def verify_loop_candidates(cands, par=None, ctx=None, device_ptr=None):
     """RegisterLoopCandidate + VerifyLoopCandidate + ApplyConstratins (loopclosure.cpp:320-384, 261-274) for a batch.
     cands: list of dicts with keys from_scan, to_scan (MapPointNormal), from_peaks, to_peaks (float32 [n, 4], NumPy
     or torch CUDA), from_pose (x, y, theta), t_be_guess, sc_sim, odom_bounds, group -- or a prepare_verify_batch
-    result.  -> VERIFY_RESULT_DTYPE array."""
+    result.  -> VERIFY_RESULT_DTYPE array; with device_ptr (a device buffer of n * 480 bytes) the records stay there
+    WITHOUT the selection (accepted = rank = 0: verify_apply_constraints over the gathered list) and n is returned."""
     ctx = ctx or default_context()
     par = par or verify_params(ctx)
     arr, n, _keep = cands if isinstance(cands, tuple) else prepare_verify_batch(cands)
-    out = np.zeros(n, L.VERIFY_RESULT_DTYPE)
+    out = None if device_ptr is not None else np.zeros(n, L.VERIFY_RESULT_DTYPE)
     if n:
-        ctx.check(ctx._lib.cfear_verify_loop_candidates(ctx.h, arr, n, C.byref(par), out.ctypes.data))
-    return out
+        dst = C.c_void_p(int(device_ptr)) if device_ptr is not None else C.c_void_p(out.ctypes.data)
+        ctx.check(ctx._lib.cfear_verify_loop_candidates(ctx.h, arr, n, C.byref(par), dst))
+    return n if device_ptr is not None else out
+
+
+def verify_apply_constraints(results, groups, par):
+    """cfear_verify_apply_constraints: ApplyConstratins (loopclosure.cpp:261-274) over gathered records, in place."""
+    g = np.ascontiguousarray(groups, dtype=np.int32)
+    assert results.flags["C_CONTIGUOUS"] and results.dtype == L.VERIFY_RESULT_DTYPE and g.shape[0] == results.shape[0]
+    rc = L.lib().cfear_verify_apply_constraints(C.c_void_p(g.ctypes.data), int(g.shape[0]), C.byref(par), C.c_void_p(results.ctypes.data))
+    if rc != L.OK:
+        raise L.CfearError(rc, "cfear_verify_apply_constraints")
+    return results
 
 
 def prepare_verify_batch(cands):

@@ -233,19 +233,28 @@ __global__ __launch_bounds__(256) void verify_finish_kernel(const VerifyChain c)
   r.rank = 0;
 }
 
-// ApplyConstratins per query (jobs sharing `group`): sort by probability, larger first (loopclosure.cpp:261-274)
-void apply_constraints(const cfear_verify_job* jobs, size_t n, const cfear_verify_params* par, cfear_verify_result* results) {
-  std::vector<int> order(n);
-  std::iota(order.begin(), order.end(), 0);
-  std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
-    if (jobs[a].group != jobs[b].group) return jobs[a].group < jobs[b].group;
-    return results[a].probability > results[b].probability;
-  });
+// ApplyConstratins per query (candidates sharing `group`): sort by probability, larger first; accept above the threshold, every
+// candidate or only the best (loopclosure.cpp:261-274).  The keys are pulled out of the 480-byte records first (the sort then
+// walks 16-byte entries); candidate lists arrive grouped by query, so the usual case is one pass over short runs.
+void apply_constraints_groups(const int32_t* groups, size_t group_stride_bytes, size_t n, const cfear_verify_params* par,
+                              cfear_verify_result* results) {
+  struct Key { int32_t group, index; double prob; };
+  std::vector<Key> keys(n);
+  bool grouped = true;
+  for (size_t i = 0; i < n; i++) {
+    keys[i].group = *(const int32_t*)((const char*)groups + i * group_stride_bytes);
+    keys[i].index = (int32_t)i;
+    keys[i].prob = results[i].probability;
+    grouped = grouped && (i == 0 || keys[i].group >= keys[i - 1].group);
+  }
+  auto by_prob = [](const Key& a, const Key& b) { return a.prob > b.prob; };
+  if (!grouped) std::stable_sort(keys.begin(), keys.end(), [](const Key& a, const Key& b) { return a.group < b.group; });
   for (size_t i = 0; i < n;) {
     size_t e = i;
-    while (e < n && jobs[order[e]].group == jobs[order[i]].group) e++;
+    while (e < n && keys[e].group == keys[i].group) e++;
+    std::stable_sort(keys.begin() + (ptrdiff_t)i, keys.begin() + (ptrdiff_t)e, by_prob);
     for (size_t k = i; k < e; k++) {
-      cfear_verify_result& r = results[order[k]];
+      cfear_verify_result& r = results[keys[k].index];
       r.rank = (int32_t)(k - i);
       const bool considered = par->all_candidates || k == i;
       r.accepted = considered && r.probability > par->model_threshold ? 1 : 0;
@@ -253,10 +262,20 @@ void apply_constraints(const cfear_verify_job* jobs, size_t n, const cfear_verif
     i = e;
   }
 }
+void apply_constraints(const cfear_verify_job* jobs, size_t n, const cfear_verify_params* par, cfear_verify_result* results) {
+  if (n) apply_constraints_groups(&jobs[0].group, sizeof(cfear_verify_job), n, par, results);
+}
 
 int verify_device_chain(cfear_ctx* ctx, const cfear_verify_job* jobs, int32_t n_jobs, const cfear_verify_params* par,
                         cfear_verify_result* results) {
   const size_t n = (size_t)n_jobs;
+#ifdef CFEAR_VERIFY_TIMING
+  auto t_last = std::chrono::steady_clock::now();
+  double t_acc[8] = {0};
+  auto mark = [&](int k) { const auto t = std::chrono::steady_clock::now(); t_acc[k] += std::chrono::duration<double, std::micro>(t - t_last).count(); t_last = t; };
+#else
+  auto mark = [](int) {};
+#endif
   CFEAR_HIP_CHECK(ctx, hipSetDevice(ctx->device));
   // ---- host: one record per candidate; peak clouds that live on the host are staged once each -----------------------
   std::map<const float*, const float4*> where;           // cloud -> its device address (one hipPointerGetAttributes per distinct cloud)
@@ -298,6 +317,7 @@ int verify_device_chain(cfear_ctx* ctx, const cfear_verify_job* jobs, int32_t n_
       where[ts.first] = (const float4*)(d_stage + off);
     }
   }
+  mark(0);
   VerifyDev* hc = (VerifyDev*)cfear_pinned(ctx, n * sizeof(VerifyDev));
   if (!hc) return cfear_set_error(ctx, CFEAR_ERR_HIP, "pinned staging allocation failed");
   for (size_t j = 0; j < n; j++) {
@@ -310,6 +330,7 @@ int verify_device_chain(cfear_ctx* ctx, const cfear_verify_job* jobs, int32_t n_
     for (int k = 0; k < 3; k++) { v.from_pose[k] = jb.from_pose[k]; v.t_be_guess[k] = jb.t_be_guess[k]; }
     v.sc_sim = jb.sc_sim; v.odom_bounds = jb.odom_bounds;
   }
+  mark(1);
   // ---- device buffers: one workspace, carved ---------------------------------------------------------------------------
   const size_t stride = reg_job_stride(2);
   auto up = [](size_t b) { return (b + 255) / 256 * 256; };
@@ -335,7 +356,10 @@ int verify_device_chain(cfear_ctx* ctx, const cfear_verify_job* jobs, int32_t n_
   VerifyChain c;
   c.cand = (const VerifyDev*)(ws + o_cand); c.reg_jobs = ws + o_reg_jobs; c.cost_jobs = ws + o_cost_jobs; c.stride = stride;
   c.coral_jobs = (CoralJob*)(ws + o_coral_jobs); c.reg = (const cfear_reg_result*)(ws + o_reg); c.q = (const cfear_reg_result*)(ws + o_q);
-  c.coral = (const cfear_coral_result*)(ws + o_coral); c.out = (cfear_verify_result*)(ws + o_out); c.first_bad = (int32_t*)(ws + o_flag);
+  // results on the DEVICE (a sharded caller gathers them there): the finish kernel writes them in place, nothing but the error
+  // flag comes back, and ApplyConstratins is the caller's (cfear_verify_apply_constraints over the gathered list)
+  const bool dev_out = cfear_is_device_ptr(results);
+  c.coral = (const cfear_coral_result*)(ws + o_coral); c.out = dev_out ? results : (cfear_verify_result*)(ws + o_out); c.first_bad = (int32_t*)(ws + o_flag);
   c.n = n_jobs; c.par = *par;
   const dim3 grid((unsigned)((n + 255) / 256)), block(256);
   // ---- the chain ---------------------------------------------------------------------------------------------------------
@@ -354,8 +378,9 @@ int verify_device_chain(cfear_ctx* ctx, const cfear_verify_job* jobs, int32_t n_
   if (rc != CFEAR_OK) { (void)hipStreamSynchronize(ctx->stream); return rc; }
   { ProfScope ps(ctx, "verify_glue"); hipLaunchKernelGGL(verify_finish_kernel, grid, block, 0, ctx->stream, c); }
   CFEAR_HIP_CHECK(ctx, hipGetLastError());
+  mark(2);
   int32_t first_bad = 0x7fffffff;
-  CFEAR_HIP_CHECK(ctx, hipMemcpyAsync(results, ws + o_out, n * sizeof(cfear_verify_result), hipMemcpyDeviceToHost, ctx->stream));
+  if (!dev_out) CFEAR_HIP_CHECK(ctx, hipMemcpyAsync(results, ws + o_out, n * sizeof(cfear_verify_result), hipMemcpyDeviceToHost, ctx->stream));
   CFEAR_HIP_CHECK(ctx, hipMemcpyAsync(&first_bad, ws + o_flag, 4, hipMemcpyDeviceToHost, ctx->stream));
   CFEAR_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
   if (first_bad != 0x7fffffff) {
@@ -363,7 +388,13 @@ int verify_device_chain(cfear_ctx* ctx, const cfear_verify_job* jobs, int32_t n_
     CFEAR_HIP_CHECK(ctx, hipMemcpy(&bad, ws + o_coral + (size_t)first_bad * sizeof(cfear_coral_result), sizeof(bad), hipMemcpyDeviceToHost));
     return cfear_set_error(ctx, bad.status, "job %d: %s", first_bad, cfear_status_string(bad.status));
   }
-  apply_constraints(jobs, n, par, results);
+  mark(3);
+  if (!dev_out) apply_constraints(jobs, n, par, results);
+  mark(4);
+#ifdef CFEAR_VERIFY_TIMING
+  fprintf(stderr, "verify us: scan clouds + sizes %.0f | fill records %.0f | enqueue the chain %.0f | kernels + read-back %.0f | ApplyConstratins %.0f\n",
+          t_acc[0], t_acc[1], t_acc[2], t_acc[3], t_acc[4]);
+#endif
   return CFEAR_OK;
 }
 
@@ -547,5 +578,15 @@ extern "C" int cfear_verify_loop_candidates(cfear_ctx* ctx, const cfear_verify_j
   for (int j = 0; j < n_jobs; j++)
     if (!jobs[j].from_scan || !jobs[j].to_scan)
       return cfear_set_error(ctx, CFEAR_ERR_INVALID_ARGUMENT, "candidate %d: null scan handle", j);
-  return par->use_covariance_sampling ? verify_host_chain(ctx, jobs, n_jobs, par, results) : verify_device_chain(ctx, jobs, n_jobs, par, results);
+  if (par->use_covariance_sampling) {
+    if (cfear_is_device_ptr(results)) return cfear_set_error(ctx, CFEAR_ERR_INVALID_ARGUMENT, "results on the device are not available with use_covariance_sampling");
+    return verify_host_chain(ctx, jobs, n_jobs, par, results);
+  }
+  return verify_device_chain(ctx, jobs, n_jobs, par, results);
+}
+
+extern "C" int cfear_verify_apply_constraints(const int32_t* groups, int32_t n, const cfear_verify_params* par, cfear_verify_result* results) {
+  if (!par || n < 0 || (n > 0 && (!groups || !results))) return CFEAR_ERR_INVALID_ARGUMENT;
+  if (n > 0) apply_constraints_groups(groups, sizeof(int32_t), (size_t)n, par, results);
+  return CFEAR_OK;
 }

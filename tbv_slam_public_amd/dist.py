@@ -161,10 +161,29 @@ def verify_candidates_sharded(cands, verify_fn, model_threshold=0.8, all_candida
             return out
         return apply_constraints(out, groups_of(), model_threshold, all_candidates)
     world, rank = dist.get_world_size(group), dist.get_rank(group)
-    lo, hi, _per = shard_range(len(cands), world, rank)
+    n = len(cands)
+    lo, hi, per = shard_range(n, world, rank)
+    if dist.get_backend(group) == "nccl" and hasattr(verify_fn, "into"):
+        # the records never visit the host before the gather: the chain's last kernel writes them into the send tensor,
+        # all_gather_into_tensor moves them over xGMI, ONE device-to-host copy returns all n -- and the selection runs once, over
+        # the whole list (verify_fn.select: the library's ApplyConstratins on host records)
+        import torch
+        rec = L.VERIFY_RESULT_DTYPE.itemsize
+        dev = torch.device("cuda", torch.cuda.current_device())
+        b = _buffers(per * rec, world, dev)
+        got = verify_fn.into(cands[lo:hi], b["send_d"].data_ptr())     # (waits for the chain: its error flag comes back)
+        assert got == hi - lo
+        dist.all_gather_into_tensor(b["recv_d"], b["send_d"], group=group)
+        b["recv_h"].copy_(b["recv_d"], non_blocking=True)
+        torch.cuda.current_stream().synchronize()
+        allr = b["recv_h"].numpy().view(L.VERIFY_RESULT_DTYPE).reshape(world, per)
+        out = allr[0, :n].copy() if world == 1 else _unpad(allr, n, world)
+        if hasattr(verify_fn, "select"):
+            return verify_fn.select(out, groups_of())
+        return apply_constraints(out, groups_of(), model_threshold, all_candidates)
     local = verify_fn(cands[lo:hi])
     assert local.dtype == L.VERIFY_RESULT_DTYPE
-    out = _gather_records(local, len(cands), group)
+    out = _gather_records(local, n, group)
     if world == 1 and fn_selects:                             # one rank saw every candidate of every query and has selected
         return out
     return apply_constraints(out, groups_of(), model_threshold, all_candidates)
