@@ -511,7 +511,7 @@ def verify_measure(D, V, n_cand, steps, warmup):
     fn = lambda _local: api.verify_loop_candidates(prepared, par, V.ctx)
     fn.into = lambda _local, ptr: api.verify_loop_candidates(prepared, par, V.ctx, device_ptr=ptr)   # records stay on the GPU until the gather
     gids = np.arange(n_cand, dtype=np.int32) // 3
-    fn.select = lambda out, _groups: api.verify_apply_constraints(out, gids, par)
+    fn.select = lambda out: api.verify_apply_constraints(out, gids, par)
     for _ in range(max(warmup, 1)):
         out = cdist.verify_candidates_sharded(groups, fn, par.model_threshold, bool(par.all_candidates), fn_selects=True)
     D.barrier()

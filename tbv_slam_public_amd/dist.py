@@ -166,7 +166,7 @@ def verify_candidates_sharded(cands, verify_fn, model_threshold=0.8, all_candida
     if dist.get_backend(group) == "nccl" and hasattr(verify_fn, "into"):
         # the records never visit the host before the gather: the chain's last kernel writes them into the send tensor,
         # all_gather_into_tensor moves them over xGMI, ONE device-to-host copy returns all n -- and the selection runs once, over
-        # the whole list (verify_fn.select: the library's ApplyConstratins on host records)
+        # the whole list (verify_fn.select(records): the library's ApplyConstratins on host records)
         import torch
         rec = L.VERIFY_RESULT_DTYPE.itemsize
         dev = torch.device("cuda", torch.cuda.current_device())
@@ -178,8 +178,8 @@ def verify_candidates_sharded(cands, verify_fn, model_threshold=0.8, all_candida
         torch.cuda.current_stream().synchronize()
         allr = b["recv_h"].numpy().view(L.VERIFY_RESULT_DTYPE).reshape(world, per)
         out = allr[0, :n].copy() if world == 1 else _unpad(allr, n, world)
-        if hasattr(verify_fn, "select"):
-            return verify_fn.select(out, groups_of())
+        if hasattr(verify_fn, "select"):                      # (a caller that keeps the query ids as an array: no walk over the list)
+            return verify_fn.select(out)
         return apply_constraints(out, groups_of(), model_threshold, all_candidates)
     local = verify_fn(cands[lo:hi])
     assert local.dtype == L.VERIFY_RESULT_DTYPE
