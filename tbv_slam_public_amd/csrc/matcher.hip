@@ -38,6 +38,11 @@
 namespace {
 
 #ifdef CFEAR_REG_TIMING   // debug build only: cycle split of workgroup 0, printed at kernel end
+// Two levels of marks.  The KERNEL's own timer runs without a gap from its first instruction to the result record: buckets 8,
+// 9 (sizes + carve, staging), 10 (every association pass, whole), 11 (every solve, whole), 12 (the outer loop's break tests), 13
+// (the tail) add up to the kernel's total by construction.  Inside mt_associate / eval_all / lm_solve, timers of their own split
+// those two big buckets (0-3; 4, 5, 16, 21, 22); what a function's inner buckets do not cover shows as the difference to its
+// whole -- round 5 printed the inner buckets only and 45 % of the cycles had no name.
 __device__ long long g_reg_t[32];
 __device__ unsigned long long g_reg_sum[4];   // every workgroup of a launch: sum of cycles, count, longest (printed by the NEXT launch's workgroup 0)
 #define REG_T0() long long _t0 = __builtin_readcyclecounter()
@@ -1097,11 +1102,13 @@ template <int NW, int COST, int LOSS, bool CO, bool WIDE = false>
 __global__ __launch_bounds__(NW * 64, WIDE ? 2 : ((NW == 4 && LOSS < 0) ? 3 : 4)) void matcher_kernel(const RegJob* __restrict__ jobs, const MatchCommon cm) {
   constexpr int NT = NW * 64;
 #ifdef CFEAR_REG_TIMING
-  const long long t_total0 = __builtin_readcyclecounter();
   if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0 && g_reg_sum[1]) {   // the previous launch's workgroups
     printf("matcher launch: %llu workgroups, mean %llu cycles, longest %llu\n", g_reg_sum[1], g_reg_sum[0] / g_reg_sum[1], g_reg_sum[2]);
     g_reg_sum[0] = g_reg_sum[1] = g_reg_sum[2] = 0;
   }
+  // (taken BEHIND that printf: a device printf is a host call of ~0.1 ms -- round 5's "total" started before it, which is where
+  //  most of its 45 % of cycles without a name went)
+  const long long t_total0 = __builtin_readcyclecounter();
 #endif
   REG_T0();
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -1187,11 +1194,14 @@ __global__ __launch_bounds__(NW * 64, WIDE ? 2 : ((NW == 4 && LOSS < 0) ? 3 : 4)
       }
       __syncthreads();
     } else if (itr > cm.par.max_itr_association || !success) break;
+    REG_TACC(12);                                                 // (the outer loop between a solve and the next association)
     const int n_blocks = mt_associate<NT, false, COST>(job, cm, a_itr, fl, st + S_OUTER, gl_dense, dn, ipart, iphase, staged);
+    REG_TACC(10);
     num_residuals = n_blocks * rpb;
     success = num_residuals > 1;                                  // :368-369
     if (!success && !CO) { fail_status = CFEAR_ERR_TOO_FEW_RESIDUALS; break; }
     if (success) { solved_residuals = num_residuals; lm_solve<NT, COST, LOSS>(cm, dn, cm.par.max_itr_solver, part, st, CO); }
+    REG_TACC(11);
     if (CO) {
       if (threadIdx.x == 0) {
         cfear_reg_result* r = res + sidx;
@@ -1258,9 +1268,12 @@ __global__ __launch_bounds__(NW * 64, WIDE ? 2 : ((NW == 4 && LOSS < 0) ? 3 : 4)
       atomicAdd(&g_reg_sum[0], cyc); atomicAdd(&g_reg_sum[1], 1ull); atomicMax(&g_reg_sum[2], cyc);
     }
     if (blockIdx.x == 0) {
-      printf("matcher cycles: total %lld | sizes+carve %lld stage_once %lld | restage %lld nn+gate %lld scan %lld gather %lld | eval %lld reduce %lld round %lld barrier %lld | outer %d lm %d n %d\n",
-             (long long)(__builtin_readcyclecounter() - t_total0), g_reg_t[8], g_reg_t[9], g_reg_t[0], g_reg_t[1], g_reg_t[2], g_reg_t[3], g_reg_t[4], g_reg_t[5],
-             g_reg_t[16], g_reg_t[21], itr, lm_iters, num_residuals);
+      REG_TACC(13);
+      const long long top = g_reg_t[8] + g_reg_t[9] + g_reg_t[10] + g_reg_t[11] + g_reg_t[12] + g_reg_t[13];
+      printf("matcher cycles: total %lld = top-level buckets %lld | sizes+carve %lld stage_once %lld association %lld solve %lld outer-loop tests %lld tail %lld\n",
+             (long long)(__builtin_readcyclecounter() - t_total0), top, g_reg_t[8], g_reg_t[9], g_reg_t[10], g_reg_t[11], g_reg_t[12], g_reg_t[13]);
+      printf("matcher cycles (inside): association: restage %lld nn+gate %lld scan %lld gather %lld | solve: eval %lld reduce %lld round %lld barrier %lld (an LM iteration's evaluation as a whole, eval + reduce + call: %lld) | outer %d lm %d n %d\n",
+             g_reg_t[0], g_reg_t[1], g_reg_t[2], g_reg_t[3], g_reg_t[4], g_reg_t[5], g_reg_t[16], g_reg_t[21], g_reg_t[22], itr, lm_iters, num_residuals);
       for (int k = 0; k < 32; k++) g_reg_t[k] = 0;
     }
 #endif
