@@ -600,13 +600,14 @@ int cfear_register_batch_sharded(cfear_ctx* ctx, const cfear_reg_job* jobs, int3
                                  cfear_reg_result* results);
 /* Pipelined steps of a sharded candidate batch (loopclosure.cpp:658-721 hands candidates over as the odometry produces
  * nodes): a rank's block of an 8-way sharded batch is ~0.13 ms of kernel, so what sits around the kernel decides the
- * rate.  A pipe keeps up to `depth` steps in flight: submit() stages this rank's block of the FULL candidate list,
- * enqueues upload -> expand -> matcher on the context's stream and all_gather -> device-to-host copy on the pipe's
- * exchange stream, and returns without waiting; collect() waits on ONE event and returns all n records in candidate
+ * rate.  A pipe keeps up to `depth` steps in flight: submit() stages this rank's block of the FULL candidate list (pinned:
+ * the device reads it in place), enqueues the expand kernel on the pipe's preparation stream (beside the previous step's
+ * matcher), the matcher on the context's stream and all_gather -> device-to-host copy on the pipe's exchange stream, and
+ * returns without waiting; collect() waits on ONE event and returns all n records in candidate
  * order (status rules as cfear_register_batch_sharded: every rank enters the collective, every rank returns the first
- * failed rank's status).  comm = NULL (world 1 only): no collective.  flags & CFEAR_PIPE_GRAPH: the compute chain of a slot
- * is captured into a hipGraph on its first step and replayed while the block size, the parameters and the context's
- * workspaces stay the same.  Steps are collected in any order, but a slot (ticket % depth) is free again only after its
+ * failed rank's status).  comm = NULL (world 1 only): no collective.  flags & CFEAR_PIPE_GRAPH: a slot's matcher launches
+ * are captured into a hipGraph on its first step and replayed while the block's size and geometry, the parameters and the
+ * context's scratch stay the same.  Steps are collected in any order, but a slot (ticket % depth) is free again only after its
  * collect.  The table must outlive the pipe.                                                                          */
 typedef struct cfear_candidate_pipe cfear_candidate_pipe;
 enum { CFEAR_PIPE_GRAPH = 1, CFEAR_PIPE_TIMING = 2 /* hipEvents around the exchange of every step (measurement) */ };

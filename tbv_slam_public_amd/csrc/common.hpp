@@ -260,6 +260,18 @@ int cfear_register_launch(cfear_ctx* ctx, const void* d_jobs, int n_jobs, const 
                           char* d_scratch, cfear_reg_result* d_results, const RegCostMode* mode = nullptr,
                           size_t job_stride = 0,    // 0: full records (cfear_reg_job_bytes)
                           RegLaunchHint hint = RegLaunchHint());
+// candidate batches in two halves (matcher.hip; cfear_candidate_pipe in shard.hip runs them on different streams)
+struct CandGeometry { int pairs_cap = 1; RegLaunchHint hint; };
+struct cfear_scan_table;
+int cfear_candidates_expand(cfear_ctx* ctx, hipStream_t stream, const cfear_scan_table* table, const cfear_candidate* cands, int32_t n,
+                            const cfear_reg_params* par, cfear_candidate* h_stage, char* d_jobs, int32_t* d_trailer, int trailer_status,
+                            CandGeometry* geom);
+int cfear_candidates_match(cfear_ctx* ctx, const char* d_jobs, int32_t n, const cfear_reg_params* par, const CandGeometry* geom,
+                           cfear_reg_result* d_res);
+int cfear_candidates_enqueue(cfear_ctx* ctx, const cfear_scan_table* table, const cfear_candidate* cands, int32_t n,
+                             const cfear_reg_params* par, cfear_candidate* h_stage, cfear_reg_result* d_res, int32_t* d_trailer,
+                             int trailer_status);
+int cfear_check_reg_params(cfear_ctx* ctx, const cfear_reg_params* par);
 // launch geometry of a batch of two-scan jobs from its largest target / source (what cfear_register_candidates derives)
 void cfear_reg_pair_geometry(const cfear_reg_params* par, int max_tar_cells, int max_src_cells, int* pairs_cap, RegLaunchHint* hint);
 size_t cfear_reg_job_stride(int max_scans);         // bytes of a record that holds up to max_scans scan views

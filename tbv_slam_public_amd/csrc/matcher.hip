@@ -1670,17 +1670,17 @@ extern "C" int cfear_scan_table_destroy(cfear_scan_table* t) {
   return CFEAR_OK;
 }
 
-// The enqueue half of a candidate batch: validates the candidates while it copies them into `h_stage` (PINNED host memory, n
-// records, owned by the caller until the expand kernel has run), expands them into job records and launches the matcher with its
-// records going to d_res (device).  Nothing is synchronised.  d_trailer (optional, device int32[2]) receives {trailer_status, n}
-// from the expand kernel -- the status trailer of a sharded step travels behind the block without an enqueue of its own.
-int cfear_candidates_enqueue(cfear_ctx* ctx, const cfear_scan_table* table, const cfear_candidate* cands, int32_t n,
-                             const cfear_reg_params* par, cfear_candidate* h_stage, cfear_reg_result* d_res, int32_t* d_trailer,
-                             int trailer_status) {
+// A candidate batch in two halves (cfear_candidate_pipe runs them on different streams; cfear_candidates_enqueue is both in a row).
+// expand: validates the candidates while it copies them into `h_stage` (PINNED host memory, n records, owned by the caller until
+// the kernel has run) and turns them into job records at d_jobs (n * reg_job_stride(2) bytes) on `stream` -- no upload: pinned
+// memory is mapped into the device's address space, the kernel reads the 56-byte records over PCIe itself.  d_trailer
+// (optional, device int32[2]) receives {trailer_status, n}: the status trailer of a sharded step travels behind the block
+// without an enqueue of its own.  geom receives what the matcher's launch needs to know about the batch.
+int cfear_candidates_expand(cfear_ctx* ctx, hipStream_t stream, const cfear_scan_table* table, const cfear_candidate* cands, int32_t n,
+                            const cfear_reg_params* par, cfear_candidate* h_stage, char* d_jobs, int32_t* d_trailer, int trailer_status,
+                            CandGeometry* geom) {
   if (table->ctx != ctx) return cfear_set_error(ctx, CFEAR_ERR_INVALID_ARGUMENT, "table belongs to another context");
   const int nt = (int)table->n_cells.size();
-  const size_t stride = reg_job_stride(2);
-  const size_t jb = (size_t)n * stride;
   JobSizes sz;
   sz.cost = par->cost; sz.huber = par->loss == CFEAR_LOSS_HUBER;
   int max_tar = 0, max_src = 0;
@@ -1695,15 +1695,30 @@ int cfear_candidates_enqueue(cfear_ctx* ctx, const cfear_scan_table* table, cons
   // the launch geometry from the LARGEST target and source of the batch (a pair's needs grow with both: if that pair fits a
   // form, every candidate does) -- one evaluation per batch, not per candidate (4096 candidates: 0.1 ms of host time)
   sz.add(2, scan_grid_pad(max_tar), scan_grid_pad(max_tar), max_src);
-  char* ws = (char*)cfear_workspace(ctx, 6, jb + 512);
-  char* scr = (char*)cfear_workspace(ctx, 7, reg_scratch_bytes(sz.pairs_cap) * (size_t)n);
-  if (!ws || !scr) return cfear_set_error(ctx, CFEAR_ERR_HIP, "workspace allocation failed");
-  // no upload: h_stage is pinned, i.e. mapped into the device's address space -- the expand kernel reads the 56-byte records
-  // over PCIe itself (one copy engine round trip less in a chain whose kernel takes 0.07 - 0.3 ms)
-  hipLaunchKernelGGL(expand_candidates_kernel, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, (const ScanView*)table->d_views,
-                     (const cfear_candidate*)h_stage, n, ws, stride, d_trailer, trailer_status);
+  geom->pairs_cap = sz.pairs_cap; geom->hint = sz.hint(n);
+  hipLaunchKernelGGL(expand_candidates_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, (const ScanView*)table->d_views,
+                     (const cfear_candidate*)h_stage, n, d_jobs, reg_job_stride(2), d_trailer, trailer_status);
   CFEAR_HIP_CHECK(ctx, hipGetLastError());
-  return cfear_register_launch(ctx, ws, n, par, sz.pairs_cap, scr, d_res, nullptr, stride, sz.hint(n));
+  return CFEAR_OK;
+}
+
+// match: the matcher over the job records expand left at d_jobs, on the context's stream; records to d_res (device)
+int cfear_candidates_match(cfear_ctx* ctx, const char* d_jobs, int32_t n, const cfear_reg_params* par, const CandGeometry* geom,
+                           cfear_reg_result* d_res) {
+  char* scr = (char*)cfear_workspace(ctx, 7, reg_scratch_bytes(geom->pairs_cap) * (size_t)n);
+  if (!scr) return cfear_set_error(ctx, CFEAR_ERR_HIP, "workspace allocation failed");
+  return cfear_register_launch(ctx, d_jobs, n, par, geom->pairs_cap, scr, d_res, nullptr, reg_job_stride(2), geom->hint);
+}
+
+int cfear_candidates_enqueue(cfear_ctx* ctx, const cfear_scan_table* table, const cfear_candidate* cands, int32_t n,
+                             const cfear_reg_params* par, cfear_candidate* h_stage, cfear_reg_result* d_res, int32_t* d_trailer,
+                             int trailer_status) {
+  char* ws = (char*)cfear_workspace(ctx, 6, (size_t)n * reg_job_stride(2) + 512);
+  if (!ws) return cfear_set_error(ctx, CFEAR_ERR_HIP, "workspace allocation failed");
+  CandGeometry geom;
+  const int rc = cfear_candidates_expand(ctx, ctx->stream, table, cands, n, par, h_stage, ws, d_trailer, trailer_status, &geom);
+  if (rc != CFEAR_OK) return rc;
+  return cfear_candidates_match(ctx, ws, n, par, &geom, d_res);
 }
 
 extern "C" int cfear_register_candidates(cfear_ctx* ctx, const cfear_scan_table* table, const cfear_candidate* cands, int32_t n,

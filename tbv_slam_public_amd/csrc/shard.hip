@@ -262,15 +262,16 @@ extern "C" int cfear_verify_loop_candidates_sharded(cfear_ctx* ctx, const cfear_
 // GPU for the matcher only; a rank's block of an 8-way sharded batch (512 candidates) is a quarter of a chip's worth of
 // workgroups and ~0.13 ms of kernel, so whatever sits around the kernel decides the rate.  The pipe keeps `depth` steps in
 // flight: the matcher of step k + 1 runs on the context's stream while the collective and the device-to-host copy of step k
-// run on the pipe's exchange stream; submit never waits, collect waits on ONE event.  Optionally the compute chain of a slot is
-// captured once into a hipGraph and replayed (the nodes' addresses are the slot's own buffers; the candidates change IN the
-// pinned staging the upload node reads).
+// run on the pipe's exchange stream, and the expand kernel of step k + 1 on a preparation stream beside them; submit never waits,
+// collect waits on ONE event.  Optionally a slot's matcher launches are captured once into a hipGraph and replayed while the
+// block's size, geometry and parameters stay the same.
 struct cfear_candidate_pipe {
   cfear_ctx* ctx = nullptr;
   const cfear_scan_table* table = nullptr;
   cfear_rccl_comm comm{};                 // nccl_comm == nullptr: no collective (world 1)
   int rank = 0, world = 1, depth = 2, max_total = 0, per_cap = 0;
   hipStream_t xstream = nullptr;          // exchange stream: all_gather + read-back
+  hipStream_t pstream = nullptr;          // preparation stream: step k + 1's expand kernel runs beside step k's matcher
   int use_graph = 0, timing = 0;
   int64_t next_ticket = 0;
   double exchange_ms = 0.0;               // CFEAR_PIPE_TIMING: sum over collected steps of (all_gather + read-back) on the exchange stream
@@ -278,41 +279,43 @@ struct cfear_candidate_pipe {
   struct Slot {
     cfear_candidate* h_cands = nullptr;   // pinned [per_cap]
     char* h_recv = nullptr;               // pinned [world][per_cap * 72 + 8]
+    char* d_jobs = nullptr;               // device [per_cap] job records (reg_job_stride(2) bytes each)
     char* d_send = nullptr;               // device [per_cap * 72 + 8]
     char* d_recv = nullptr;               // device [world][...]
-    hipEvent_t computed = nullptr, xbegin = nullptr, done = nullptr;
+    hipEvent_t prepared = nullptr, computed = nullptr, xbegin = nullptr, done = nullptr;
     int64_t ticket = -1;                  // the step in this slot (-1: free)
     int n_total = 0, status = CFEAR_OK;
     hipGraphExec_t exec = nullptr;        // the captured compute chain ...
     int g_n = -1, g_per = -1;             // ... of a block of g_n candidates (g_per slots per rank) with parameters g_par,
     cfear_reg_params g_par{};             //     whose nodes hold the context's workspaces as they were at capture
-    const void* g_ws6 = nullptr; const void* g_ws7 = nullptr;
+    const void* g_ws7 = nullptr;
+    int g_pairs_cap = 0, g_hint = 0;
   };
   std::vector<Slot> slots;
   size_t block_bytes() const { return (size_t)per_cap * sizeof(cfear_reg_result) + sizeof(ShardTrailer); }
 };
 
-int cfear_candidates_enqueue(cfear_ctx* ctx, const cfear_scan_table* table, const cfear_candidate* cands, int32_t n,
-                             const cfear_reg_params* par, cfear_candidate* h_stage, cfear_reg_result* d_res, int32_t* d_trailer,
-                             int trailer_status);
-int cfear_check_reg_params(cfear_ctx* ctx, const cfear_reg_params* par);
 
 extern "C" int cfear_candidate_pipe_destroy(cfear_candidate_pipe* p) {
   if (!p) return CFEAR_OK;
   (void)hipSetDevice(p->ctx->device);
   (void)hipStreamSynchronize(p->ctx->stream);
   if (p->xstream) (void)hipStreamSynchronize(p->xstream);
+  if (p->pstream) (void)hipStreamSynchronize(p->pstream);
   for (auto& s : p->slots) {
     if (s.exec) (void)hipGraphExecDestroy(s.exec);
     if (s.h_cands) (void)hipHostFree(s.h_cands);
     if (s.h_recv) (void)hipHostFree(s.h_recv);
     if (s.d_send) (void)hipFree(s.d_send);
+    if (s.d_jobs) (void)hipFree(s.d_jobs);
+    if (s.prepared) (void)hipEventDestroy(s.prepared);
     if (s.d_recv) (void)hipFree(s.d_recv);
     if (s.computed) (void)hipEventDestroy(s.computed);
     if (s.xbegin) (void)hipEventDestroy(s.xbegin);
     if (s.done) (void)hipEventDestroy(s.done);
   }
   if (p->xstream) (void)hipStreamDestroy(p->xstream);
+  if (p->pstream) (void)hipStreamDestroy(p->pstream);
   delete p;
   return CFEAR_OK;
 }
@@ -336,10 +339,13 @@ extern "C" int cfear_candidate_pipe_create(cfear_ctx* ctx, const cfear_scan_tabl
   p->slots.resize((size_t)depth);
   const size_t bb = (p->block_bytes() + 255) / 256 * 256;
   bool ok = hipStreamCreateWithFlags(&p->xstream, hipStreamNonBlocking) == hipSuccess;
+  ok = ok && hipStreamCreateWithFlags(&p->pstream, hipStreamNonBlocking) == hipSuccess;
   for (auto& s : p->slots) {
     ok = ok && hipHostMalloc((void**)&s.h_cands, (size_t)p->per_cap * sizeof(cfear_candidate), hipHostMallocDefault) == hipSuccess;
     ok = ok && hipHostMalloc((void**)&s.h_recv, bb * (size_t)world, hipHostMallocDefault) == hipSuccess;
     ok = ok && hipMalloc((void**)&s.d_send, bb) == hipSuccess;
+    ok = ok && hipMalloc((void**)&s.d_jobs, (size_t)p->per_cap * reg_job_stride(2) + 256) == hipSuccess;
+    ok = ok && hipEventCreateWithFlags(&s.prepared, hipEventDisableTiming) == hipSuccess;
     ok = ok && hipMalloc((void**)&s.d_recv, bb * (size_t)world) == hipSuccess;
     ok = ok && hipMemsetAsync(s.d_send, 0, bb, ctx->stream) == hipSuccess;        // padding slots: zero once, never written
     ok = ok && hipEventCreateWithFlags(&s.computed, hipEventDisableTiming) == hipSuccess;
@@ -375,31 +381,31 @@ extern "C" int cfear_candidate_pipe_submit(cfear_candidate_pipe* p, const cfear_
   // From here on nothing returns before the collective: peers are on their way into it (see gather_records_status).
   int local_rc = CFEAR_OK;
   if (n > 0) {
+    // expand on the preparation stream: it needs nothing of the steps in flight (its job buffer is the slot's own), so step
+    // k + 1's expand runs beside step k's matcher and the context's stream carries matcher after matcher
+    CandGeometry geom;
+    local_rc = cfear_candidates_expand(ctx, p->pstream, p->table, cands + lo, n, par, s.h_cands, s.d_jobs, d_trailer, CFEAR_OK, &geom);
+    if (local_rc == CFEAR_OK && (hipEventRecord(s.prepared, p->pstream) != hipSuccess || hipStreamWaitEvent(ctx->stream, s.prepared, 0) != hipSuccess))
+      local_rc = cfear_set_error(ctx, CFEAR_ERR_HIP, "candidate pipe: event between the preparation and the compute stream failed");
+    const int hint_bits = (geom.hint.small_pairs ? 1 : 0) | (geom.hint.big_pass ? 2 : 0) | (geom.hint.whole_cu ? 4 : 0);
     const bool graph = p->use_graph && ctx->profile == 0;         // (per-kernel events do not go into a capture)
-    const bool replay = graph && s.exec && s.g_n == n && s.g_per == per && memcmp(&s.g_par, par, sizeof(*par)) == 0 &&
-                        s.g_ws6 == ctx->ws[6].p && s.g_ws7 == ctx->ws[7].p;
-    if (replay) {
-      // the captured chain reads the candidates from the slot's staging: validate + copy, then ONE launch
-      const int nt = cfear_scan_table_size(p->table);
-      for (int i = 0; i < n && local_rc == CFEAR_OK; i++) {
-        const cfear_candidate& c = cands[lo + i];
-        if (c.target < 0 || c.target >= nt || c.source < 0 || c.source >= nt)
-          local_rc = cfear_set_error(ctx, CFEAR_ERR_INVALID_ARGUMENT, "candidate %d refers to scan %d / %d of a table of %d", lo + i, c.target, c.source, nt);
-        s.h_cands[i] = c;
-      }
-      if (local_rc == CFEAR_OK && hipGraphLaunch(s.exec, ctx->stream) != hipSuccess) local_rc = cfear_set_error(ctx, CFEAR_ERR_HIP, "hipGraphLaunch failed");
+    const bool replay = graph && s.exec && s.g_n == n && memcmp(&s.g_par, par, sizeof(*par)) == 0 && s.g_ws7 == ctx->ws[7].p &&
+                        s.g_pairs_cap == geom.pairs_cap && s.g_hint == hint_bits;
+    if (local_rc != CFEAR_OK) {
+    } else if (replay) {
+      if (hipGraphLaunch(s.exec, ctx->stream) != hipSuccess) local_rc = cfear_set_error(ctx, CFEAR_ERR_HIP, "hipGraphLaunch failed");
     } else if (graph && s.g_n != -2) {
-      // first step of this shape in this slot: run it once directly (workspaces and LDS attributes settle outside a capture),
-      // then capture the same chain for the steps to come
-      local_rc = cfear_candidates_enqueue(ctx, p->table, cands + lo, n, par, s.h_cands, (cfear_reg_result*)s.d_send, d_trailer, CFEAR_OK);
+      // first step of this shape in this slot: run the matcher once directly (workspaces and LDS attributes settle outside a
+      // capture), then capture the same launches for the steps to come
+      local_rc = cfear_candidates_match(ctx, s.d_jobs, n, par, &geom, (cfear_reg_result*)s.d_send);
       if (local_rc == CFEAR_OK && hipStreamSynchronize(ctx->stream) == hipSuccess) {
         if (s.exec) { (void)hipGraphExecDestroy(s.exec); s.exec = nullptr; }
         hipGraph_t g = nullptr;
         bool cap = hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal) == hipSuccess;
-        int crc = cap ? cfear_candidates_enqueue(ctx, p->table, cands + lo, n, par, s.h_cands, (cfear_reg_result*)s.d_send, d_trailer, CFEAR_OK) : CFEAR_ERR_HIP;
+        int crc = cap ? cfear_candidates_match(ctx, s.d_jobs, n, par, &geom, (cfear_reg_result*)s.d_send) : CFEAR_ERR_HIP;
         if (cap && hipStreamEndCapture(ctx->stream, &g) != hipSuccess) crc = CFEAR_ERR_HIP;
         if (crc == CFEAR_OK && g && hipGraphInstantiate(&s.exec, g, nullptr, nullptr, 0) == hipSuccess) {
-          s.g_n = n; s.g_per = per; s.g_par = *par; s.g_ws6 = ctx->ws[6].p; s.g_ws7 = ctx->ws[7].p;
+          s.g_n = n; s.g_per = per; s.g_par = *par; s.g_ws7 = ctx->ws[7].p; s.g_pairs_cap = geom.pairs_cap; s.g_hint = hint_bits;
         } else {
           (void)hipGetLastError();
           s.exec = nullptr; s.g_n = -2;                           // capture is not available here: direct launches from now on
@@ -408,7 +414,7 @@ extern "C" int cfear_candidate_pipe_submit(cfear_candidate_pipe* p, const cfear_
         // (the direct run above already produced this step's records)
       }
     } else {
-      local_rc = cfear_candidates_enqueue(ctx, p->table, cands + lo, n, par, s.h_cands, (cfear_reg_result*)s.d_send, d_trailer, CFEAR_OK);
+      local_rc = cfear_candidates_match(ctx, s.d_jobs, n, par, &geom, (cfear_reg_result*)s.d_send);
     }
   }
   if (n == 0 || local_rc != CFEAR_OK) {                           // an empty or failed block: zeros + the status
