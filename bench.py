@@ -336,27 +336,26 @@ class LoopClosureWorld:
             self.comm.close()
 
 
-def pipe_measure(D, W, cands_all, steps, warmup, graph=True, depth=2):
-    """One sharded candidate batch through the C-ABI pipe (cfear_candidate_pipe: upload -> expand -> matcher on the context's
-    stream, ncclAllGather of the 72-byte records + read-back on the exchange stream), every rank handing in the full list:
-    the step's latency (submit, collect, repeat), the same steps pipelined (step k + 1 submitted before step k is collected),
-    the matcher's own time (hipEvents, a pass of its own: per-kernel events do not go into a captured graph) and the exchange
-    stream's time per step."""
+def pipe_measure(D, W, cands_all, steps, warmup, graph=False, depth=2):
+    """One sharded candidate batch through the C-ABI pipe (cfear_candidate_pipe: expand on the preparation stream, matcher on the
+    context's stream, ncclAllGather of the 72-byte records + read-back on the exchange stream), every rank handing in the full
+    list: the step's latency (submit, collect, repeat), the same steps pipelined (step k + 1 submitted before step k is
+    collected), the matcher's own time (hipEvents, a pass of its own) and -- from a second pipe with events around the exchange,
+    which cost a few microseconds per step -- the exchange stream's time per step.  graph: replay the matcher launches from a
+    captured hipGraph (measured slower than direct launches on ROCm 7.0: 0.145 against 0.138 ms per pipelined 512-block)."""
     from tbv_slam_public_amd import api, _lib as L
     n = int(cands_all.shape[0])
     ctx = W.ctx
-    pipe = api.CandidatePipe(W.reg, W.table, n, W.comm, D.rank, D.world, depth=depth, graph=graph, timing=True)
+    pipe = api.CandidatePipe(W.reg, W.table, n, W.comm, D.rank, D.world, depth=depth, graph=graph, timing=False)
     out = np.empty(n, L.RESULT_DTYPE)
-    for _ in range(max(warmup, 1) + 2 * depth):                        # (the first step of a slot also captures its graph)
+    for _ in range(max(warmup, 1) + 2 * depth + 10):                   # (a communicator's first collectives set its channels up)
         pipe.collect(pipe.submit(cands_all), out)
     D.barrier()
-    st0 = pipe.stats()
     t0 = time.perf_counter()
     for _ in range(steps):
         pipe.collect(pipe.submit(cands_all), out)
     D.barrier()
     lat_ms = D.max_over_ranks(time.perf_counter() - t0) / steps * 1e3
-    st = pipe.stats()
     D.barrier()
     t0 = time.perf_counter()
     tk = pipe.submit(cands_all)
@@ -367,22 +366,27 @@ def pipe_measure(D, W, cands_all, steps, warmup, graph=True, depth=2):
     pipe.collect(tk, out)
     D.barrier()
     pl_ms = D.max_over_ranks(time.perf_counter() - t0) / steps * 1e3
-    st2 = pipe.stats()
+    graph_slots = pipe.stats()["graph_slots"]
     ctx.profile_enable(True); ctx.profile_read(reset=True)
     for _ in range(steps):
         pipe.collect(pipe.submit(cands_all), out)
     D.barrier()
     prof = ctx.profile_read(reset=True); ctx.profile_enable(False)
     kernel_ms = D.max_over_ranks(sum(v[0] for v in prof.values()) / max(steps, 1))
-    # the exchange stream's time per step with nothing beside it (the latency steps); while step k + 1's matcher runs the same
-    # exchange waits for compute units and takes longer -- without holding anything up
-    gather_ms = D.max_over_ranks((st["exchange_ms"] - st0["exchange_ms"]) / max(st["steps"] - st0["steps"], 1))
-    gather_pl_ms = D.max_over_ranks((st2["exchange_ms"] - st["exchange_ms"]) / max(st2["steps"] - st["steps"], 1))
     pipe.close()
+    tpipe = api.CandidatePipe(W.reg, W.table, n, W.comm, D.rank, D.world, depth=depth, graph=False, timing=True)
+    for _ in range(4):
+        tpipe.collect(tpipe.submit(cands_all), out)
+    st0 = tpipe.stats()
+    for _ in range(steps):
+        tpipe.collect(tpipe.submit(cands_all), out)
+    st = tpipe.stats()
+    gather_ms = D.max_over_ranks((st["exchange_ms"] - st0["exchange_ms"]) / max(st["steps"] - st0["steps"], 1))
+    tpipe.close()
     return {"candidates": n, "candidates_per_rank": (n + D.world - 1) // D.world, "step_ms": lat_ms, "kernel_ms": kernel_ms,
-            "gather_ms": gather_ms, "gather_ms_while_pipelined": gather_pl_ms, "value": n / (lat_ms * 1e-3), "pipelined_step_ms": pl_ms, "pipelined_value": n / (pl_ms * 1e-3),
-            "pipelined_over_kernel": pl_ms / kernel_ms if kernel_ms > 0 else None, "graph_slots": st["graph_slots"], "depth": depth,
-            "ok_fraction": float((out["status"] == 0).mean()), "mean_outer_iters": float(out["outer_iters"].mean())}
+            "gather_ms": gather_ms, "value": n / (lat_ms * 1e-3), "pipelined_step_ms": pl_ms,
+            "pipelined_value": n / (pl_ms * 1e-3), "pipelined_over_kernel": pl_ms / kernel_ms if kernel_ms > 0 else None, "graph_slots": graph_slots,
+            "depth": depth, "ok_fraction": float((out["status"] == 0).mean()), "mean_outer_iters": float(out["outer_iters"].mean())}
 
 
 def _on_side_stream(D, fn):
