@@ -272,7 +272,10 @@ class LoopClosureWorld:
         import torch
         from tbv_slam_public_amd import api, synth
         self.D = D
-        self.ctx = ctx = api.Context(D.local_rank, stream=torch.cuda.current_stream().cuda_stream)
+        # a stream of the library's own (the pipe's compute stream; its exchange and preparation streams are the pipe's): the
+        # loop-closure thread shares no stream with torch -- the Python mirror of the step (dist.py) then waits for the
+        # kernels before its collective, which it checks for itself (Context.shares_torch_stream)
+        self.ctx = ctx = api.Context(D.local_rank)
         if graph:
             # a precomputed simple_graph.sgh (tools/make_graph.py, or the reference's SaveGraph): the cached surface points
             # of every node feed the matcher directly, as loopclosure::Register does (types.h:119-122)
@@ -290,7 +293,7 @@ class LoopClosureWorld:
             for wd in range(n_worlds):
                 sc = synth.Scene(3000 + wd, circle_frames=lap)
                 imgs = synth.render_frames_torch(sc, list(range(lap)), D.dev)
-                torch.cuda.synchronize()
+                torch.cuda.synchronize()                   # (the library's stream is not torch's)
                 r = api.filter_kstrongest(imgs, 40, 60, 0.0438, 2.5, ctx=ctx)
                 ctx.synchronize()
                 xyzi, npts = r["xyzi"].cpu().numpy(), r["n_points"].cpu().numpy()
@@ -336,7 +339,7 @@ class LoopClosureWorld:
             self.comm.close()
 
 
-def pipe_measure(D, W, cands_all, steps, warmup, graph=False, depth=2):
+def pipe_measure(D, W, cands_all, steps, warmup, graph=False, depth=3):
     """One sharded candidate batch through the C-ABI pipe (cfear_candidate_pipe: expand on the preparation stream, matcher on the
     context's stream, ncclAllGather of the 72-byte records + read-back on the exchange stream), every rank handing in the full
     list: the step's latency (submit, collect, repeat), the same steps pipelined (step k + 1 submitted before step k is
@@ -356,14 +359,17 @@ def pipe_measure(D, W, cands_all, steps, warmup, graph=False, depth=2):
         pipe.collect(pipe.submit(cands_all), out)
     D.barrier()
     lat_ms = D.max_over_ranks(time.perf_counter() - t0) / steps * 1e3
+    def pipelined(k):
+        tks = [pipe.submit(cands_all) for _ in range(depth - 1)]
+        for _ in range(k - (depth - 1)):
+            tks.append(pipe.submit(cands_all))
+            pipe.collect(tks.pop(0), out)
+        while tks:
+            pipe.collect(tks.pop(0), out)
+    pipelined(12)              # (the first overlapped steps of a process pay for the runtime's lazily made hardware queues: ~10 ms once)
     D.barrier()
     t0 = time.perf_counter()
-    tk = pipe.submit(cands_all)
-    for _ in range(steps - 1):
-        tk2 = pipe.submit(cands_all)
-        pipe.collect(tk, out)
-        tk = tk2
-    pipe.collect(tk, out)
+    pipelined(steps)
     D.barrier()
     pl_ms = D.max_over_ranks(time.perf_counter() - t0) / steps * 1e3
     graph_slots = pipe.stats()["graph_slots"]
