@@ -476,6 +476,7 @@ class n_scan_normal_reg {
     results.resize(candidates.size());
     ctx_.check(cfear_register_candidates(ctx_.get(), table.get(), candidates.data(), (int32_t)candidates.size(), &par_, results.data()));
   }
+  const cfear_reg_params& params() const { return par_; }
   double getScore() const { return score_; }
   bool GetCovarianceScaler(double& cov_scale) const {                                         // n_scan_normal.cpp:433-439
     if (summary_.num_residuals - 3 == 0) return false;
@@ -505,6 +506,41 @@ class n_scan_normal_reg {
 
 // radarDriver + OdometryKeyframeFuser for n independent sequences, one frame per call (cfear_odometry_*): the whole
 // path polar image -> pose on the GPU; with par.keep_nodes the RadarScan of every frame can be collected.
+// Sharded candidate steps kept in flight (cfear_candidate_pipe): what the loop-closure thread of a rank
+// calls per candidate batch when the node's GPUs share the work (loopclosure.cpp:658-721: independent candidates).  comm: the
+// host's ncclComm_t in a cfear_rccl_comm (or one made by cfear_rccl_comm_init), nullptr for a single rank without a collective.
+class CandidatePipe {
+ public:
+  CandidatePipe(Context& ctx, const ScanTable& table, int max_candidates, int rank = 0, int world = 1, const cfear_rccl_comm* comm = nullptr,
+                int depth = 2, int flags = 0) : ctx_(ctx), h_(nullptr) {
+    ctx_.check(cfear_candidate_pipe_create(ctx_.get(), table.get(), max_candidates, rank, world, comm, depth, flags, &h_));
+  }
+  ~CandidatePipe() { if (h_) cfear_candidate_pipe_destroy(h_); }
+  CandidatePipe(const CandidatePipe&) = delete;
+  CandidatePipe& operator=(const CandidatePipe&) = delete;
+  // every rank hands in the FULL list; returns without waiting
+  int64_t submit(const std::vector<cfear_candidate>& all_candidates, const n_scan_normal_reg& reg) {
+    int64_t ticket = -1;
+    sizes_[ticket_slot(next_)] = all_candidates.size();
+    ctx_.check(cfear_candidate_pipe_submit(h_, all_candidates.data(), (int32_t)all_candidates.size(), &reg.params(), &ticket));
+    next_ = ticket + 1;
+    return ticket;
+  }
+  // all records of that batch, every rank's block, candidate order
+  void collect(int64_t ticket, std::vector<cfear_reg_result>& results) {
+    results.resize(sizes_[ticket_slot(ticket)]);
+    cfear_reg_result dummy;
+    ctx_.check(cfear_candidate_pipe_collect(h_, ticket, results.empty() ? &dummy : results.data()));
+  }
+
+ private:
+  static size_t ticket_slot(int64_t t) { return (size_t)(t % 16); }          // (depth <= 16)
+  Context& ctx_;
+  cfear_candidate_pipe* h_;
+  int64_t next_ = 0;
+  size_t sizes_[16] = {};
+};
+
 class OdometryKeyframeFuser {
  public:
   OdometryKeyframeFuser(Context& ctx, int n_streams, int rows, int cols, const cfear_odometry_params* par = nullptr)

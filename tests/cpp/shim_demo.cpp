@@ -9,6 +9,7 @@
 // With a fifth argument "bins-major" the file holds [2][cols][rows] images as a non-Oxford driver publishes them.
 #include <cmath>
 #include <cstdio>
+#include <cstring>
 #include <cstdlib>
 #include <memory>
 #include <string>
@@ -76,6 +77,17 @@ int main(int argc, char** argv) {
       creg.RegisterCandidates(table, {cfear_candidate{0, 1, {0, 0, 0}, {2.0, 0.0, 0.0}}}, cres);
       if (table.size() != 2 || cres[0].pose[0] != T[1].x || cres[0].pose[1] != T[1].y || cres[0].pose[2] != T[1].theta)
         throw CfearError(-1, "candidate table disagrees");
+      // ... and through the pipe that keeps sharded steps in flight (cfear_candidate_pipe; one rank, no communicator here): two
+      // steps submitted before the first is collected, byte-identical records
+      CandidatePipe pipe(ctx, table, 4);
+      const std::vector<cfear_candidate> batch = {cfear_candidate{0, 1, {0, 0, 0}, {2.0, 0.0, 0.0}}, cfear_candidate{0, 1, {0, 0, 0}, {2.1, -0.1, 0.01}}};
+      const int64_t t0 = pipe.submit(batch, creg), t1 = pipe.submit(batch, creg);
+      std::vector<cfear_reg_result> p0, p1, direct;
+      pipe.collect(t0, p0);
+      pipe.collect(t1, p1);
+      creg.RegisterCandidates(table, batch, direct);
+      if (p0.size() != 2 || memcmp(p0.data(), direct.data(), 2 * sizeof(cfear_reg_result)) != 0 || memcmp(p1.data(), direct.data(), 2 * sizeof(cfear_reg_result)) != 0)
+        throw CfearError(-1, "candidate pipe disagrees");
     }
     double cov[36];
     cfear_cov_sampling_params sp;
