@@ -383,9 +383,12 @@ extern "C" int cfear_candidate_pipe_submit(cfear_candidate_pipe* p, const cfear_
   if (n > 0) {
     // expand on the preparation stream: it needs nothing of the steps in flight (its job buffer is the slot's own), so step
     // k + 1's expand runs beside step k's matcher and the context's stream carries matcher after matcher
+    // (with nothing in flight there is no matcher to run beside: the expand goes straight onto the compute stream, one event hop less)
+    bool idle = true;
+    for (auto& o : p->slots) idle = idle && o.ticket < 0;
     CandGeometry geom;
-    local_rc = cfear_candidates_expand(ctx, p->pstream, p->table, cands + lo, n, par, s.h_cands, s.d_jobs, d_trailer, CFEAR_OK, &geom);
-    if (local_rc == CFEAR_OK && (hipEventRecord(s.prepared, p->pstream) != hipSuccess || hipStreamWaitEvent(ctx->stream, s.prepared, 0) != hipSuccess))
+    local_rc = cfear_candidates_expand(ctx, idle ? ctx->stream : p->pstream, p->table, cands + lo, n, par, s.h_cands, s.d_jobs, d_trailer, CFEAR_OK, &geom);
+    if (!idle && local_rc == CFEAR_OK && (hipEventRecord(s.prepared, p->pstream) != hipSuccess || hipStreamWaitEvent(ctx->stream, s.prepared, 0) != hipSuccess))
       local_rc = cfear_set_error(ctx, CFEAR_ERR_HIP, "candidate pipe: event between the preparation and the compute stream failed");
     const int hint_bits = (geom.hint.small_pairs ? 1 : 0) | (geom.hint.big_pass ? 2 : 0) | (geom.hint.whole_cu ? 4 : 0);
     const bool graph = p->use_graph && ctx->profile == 0;         // (per-kernel events do not go into a capture)
