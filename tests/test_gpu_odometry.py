@@ -113,6 +113,8 @@ def test_cacfar_pipeline_fused_keys_special_rows():
     (a) more than 16 384 detections per sweep (false-alarm rate 0.05: ~41 000): the scan leaves the fast pipeline and the single-kernel
         path converts the row keys itself;
     (b) images whose rows cannot be read in 16-byte pieces (3350 columns): the byte-copy path of the rows kernel;
+    (d) rows that start on 4-byte boundaries and end inside a 16-byte piece (3352 columns, like Oxford's native 3768): read in
+        pieces with the ragged tail cleared in registers -- but for the image's last row, which takes the byte copy;
     (c) a range window that cuts the row at both ends (min / max distance) with a window that the first bins cut.
     Point counts, cell counts and poses equal the oracle's, frame by frame."""
     from oracle import pyoracle as O
@@ -122,6 +124,7 @@ def test_cacfar_pipeline_fused_keys_special_rows():
     reg = O.reg_params(cost="P2P", loss="Huber", loss_limit=0.1, weight_opt=4, regularization=0.0)
     cases = [dict(cols=3360, pfa=0.05, z=20.0, win=40, guard=10, mind=2.5, min_pts=16385),
              dict(cols=3350, pfa=0.01, z=20.0, win=40, guard=10, mind=2.5, min_pts=500),
+             dict(cols=3352, pfa=0.01, z=20.0, win=40, guard=10, mind=2.5, min_pts=500),   # (d) below
              dict(cols=3360, pfa=0.02, z=30.0, win=24, guard=4, mind=1.0, min_pts=500)]
     for c in cases:
         seq = np.ascontiguousarray(base[:, :, :c["cols"]])
