@@ -2,7 +2,7 @@
 # quick PMC look at the per-frame kernels (small batch); raw rocprofv3 output is deleted, only the summary is kept
 set -u
 ROOT=$(pwd); OUT=$ROOT/gpurun_out/pc; rm -rf $OUT; mkdir -p $OUT; export TMPDIR=/tmp
-ARGS="--no-cpu-baseline --no-extras --steps 1 --warmup 1 --frames-per-step 2 --streams ${STREAMS:-512} --sequences 32"
+ARGS="--no-cpu-baseline --no-extras --steps 1 --warmup 1 --frames-per-step 2 --streams ${STREAMS:-512} --sequences ${SEQS:-64}"   # (streams / sequences <= the ring's 64 frames, or bench.py refuses)
 cd /tmp
 rocprofv3 --output-format csv --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU -d $OUT/pmc_sq -o p -- python $ROOT/bench.py $ARGS > /dev/null 2> $OUT/pmc.err
 rocprofv3 --output-format csv --pmc SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_VMEM SQ_INSTS_SMEM SQ_ACTIVE_INST_LDS -d $OUT/pmc_mem -o p -- python $ROOT/bench.py $ARGS > /dev/null 2> $OUT/pmc2.err
