@@ -783,10 +783,14 @@ def main(argv=None):
     sharded, lc_world = {}, None
     if not (args.no_sharded or args.no_extras) and D.dist is not None:
         note("sharded: loop closure + verification over %d rank(s)" % D.world)
-        lc_world = _on_side_stream(D, lambda: LoopClosureWorld(D))
-        sharded = sharded_section(D, args.candidates, 20, 3, lc_world)
-        if D.world > 1:
-            lc_world.close()
+        try:
+            lc_world = _on_side_stream(D, lambda: LoopClosureWorld(D))
+            sharded = sharded_section(D, args.candidates, 20, 3, lc_world)
+            if D.world > 1:
+                lc_world.close()
+        except Exception as e:       # (a failure every rank shares -- no librccl, no communicator -- must not cost the headline line)
+            sys.stderr.write("bench.py: rank %d: sharded section failed: %r\n" % (D.rank, e))
+            sharded, lc_world = {"loopclosure_sharded": {"error": repr(e)}, "verify_sharded": {"error": repr(e)}}, None
     if D.rank != 0:
         return D.close()
 
